@@ -1,0 +1,87 @@
+"""Pins the oracle restatement of devo/projective_ops.py and devo/ba.py against outputs of the REAL
+reference Python modules (fixtures written by tools/gen_golden.py in the build container)."""
+import os
+import numpy as np
+import torch
+from oracle import pops
+from oracle.lie import SE3
+from oracle import se3 as K
+
+DT = torch.float64
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: (torch.from_numpy(z[k]) if z[k].ndim else z[k].item()) for k in z.files}
+
+
+def test_transform_golden(golden_dir):
+    g = _load(golden_dir, "transform_f64.npz")
+    a = (SE3(g["poses"]), g["patches"], g["intrinsics"], g["ii"], g["jj"], g["kk"])
+    c, v, (Ji, Jj, Jz) = pops.transform(*a, jacobian=True)
+    for got, key in ((c, "coords"), (v, "valid"), (Ji, "Ji"), (Jj, "Jj"), (Jz, "Jz")):
+        assert torch.allclose(got.double(), g[key].double(), rtol=1e-10, atol=1e-10), key
+    assert torch.allclose(pops.transform(*a, depth=True), g["coords_depth"], rtol=1e-10, atol=1e-10)
+    assert torch.allclose(pops.transform(*a, tonly=True), g["coords_tonly"], rtol=1e-10, atol=1e-10)
+    assert torch.allclose(pops.flow_mag(*a, beta=0.5), g["flow_mag"], rtol=1e-10, atol=1e-10)
+    M = int(g["M"])
+    pc = pops.point_cloud(SE3(g["poses"]), g["patches"], g["intrinsics"], torch.arange(g["patches"].shape[1]) // M)
+    assert torch.allclose(pc, g["point_cloud"], rtol=1e-10, atol=1e-10)
+
+
+def test_ba_golden(golden_dir):
+    g = _load(golden_dir, "ba_train_f64.npz")
+    bounds = g["bounds"].tolist()
+    for ep in (10.0, 100.0):
+        for so in (False, True):
+            G, P = SE3(g["poses"].clone()), g["patches"].clone()
+            for it in range(2):
+                G, P = pops.BA(G, P, g["intrinsics"], g["target"], g["weight"], 1e-4, g["ii"], g["jj"], g["kk"],
+                               bounds, ep=ep, fixedp=1, structure_only=so)
+                tag = f"ep{int(ep)}_so{int(so)}_it{it + 1}"
+                assert torch.allclose(G.data, g["poses_" + tag], rtol=1e-9, atol=1e-9), tag
+                assert torch.allclose(P, g["patches_" + tag], rtol=1e-9, atol=1e-9), tag
+    G, P = pops.BA(SE3(g["poses"].clone()), g["patches"].clone(), g["intrinsics"], g["target"], g["weight"],
+                   g["lmbda_tensor"], g["ii"], g["jj"], g["kk"], bounds, ep=10.0, fixedp=1)
+    assert torch.allclose(G.data, g["poses_lmtensor"], rtol=1e-9, atol=1e-9)
+    assert torch.allclose(P, g["patches_lmtensor"], rtol=1e-9, atol=1e-9)
+
+
+def test_ba_gradients_golden(golden_dir):
+    g = _load(golden_dir, "ba_train_f64.npz")
+    tgt = g["target"].clone().requires_grad_(True)
+    wgt = g["weight"].clone().requires_grad_(True)
+    G, P = pops.BA(SE3(g["poses"].clone()), g["patches"].clone(), g["intrinsics"], tgt, wgt, 1e-4,
+                   g["ii"], g["jj"], g["kk"], g["bounds"].tolist(), ep=10.0, fixedp=1)
+    cf = pops.transform(G, P, g["intrinsics"], g["ii"], g["jj"], g["kk"])
+    loss = (cf * g["loss_weights"]).sum() + (G.log() ** 2).sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - g["loss"]) < 1e-8 * max(1.0, abs(g["loss"]))
+    assert torch.allclose(tgt.grad, g["grad_target"], rtol=1e-7, atol=1e-9)
+    assert torch.allclose(wgt.grad, g["grad_weight"], rtol=1e-7, atol=1e-9)
+
+
+def test_cholesky_golden(golden_dir):
+    g = _load(golden_dir, "cholesky_f64.npz")
+    H = g["H"].clone().requires_grad_(True)
+    b = g["b"].clone().requires_grad_(True)
+    x = pops.CholeskySolver.apply(H, b)
+    x.backward(g["gx"])
+    assert torch.allclose(x, g["x"], rtol=1e-12, atol=1e-12)
+    assert torch.allclose(H.grad, g["dH"], rtol=1e-12, atol=1e-12)
+    assert torch.allclose(b.grad, g["db"], rtol=1e-12, atol=1e-12)
+    # failure branch (ba.py:16-20): zeros, no gradient
+    bad = -torch.eye(4, dtype=DT)[None]
+    assert torch.equal(pops.CholeskySolver.apply(bad, torch.ones(1, 4, 1, dtype=DT)), torch.zeros(1, 4, 1, dtype=DT))
+
+
+def test_groups_golden(golden_dir):
+    g = _load(golden_dir, "groups_f64.npz")
+    X = SE3(g["poses"])
+    assert torch.allclose((SE3(g["poses"][:, :, None]) * g["pts"]), g["act"], atol=1e-12)
+    assert torch.allclose(X.retr(g["a"]).data, g["retr"], atol=1e-12)
+    assert torch.allclose(X.matrix(), g["matrix"], atol=1e-12)
+    assert torch.allclose(X.inv().data, g["inv"], atol=1e-12)
+    assert torch.allclose(X.log(), g["log"], atol=1e-12)
+    assert torch.allclose((X * X.inv()[:, [0]]).data, g["mul"], atol=1e-12)
+    assert torch.allclose(K.as_matrix(g["poses"][0]), g["matrix"][0], atol=1e-12)

@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Benchmark of the DEVO update-op hot path on MI355X (BASELINE.json metric:
+"update-op iterations/sec (altcorr+fastba) at 96 patches, N=15 keyframes").
+
+One STEP = one update-op iteration on a fixed patch graph (devo/devo.py:308-338 minus the Update MLP):
+    reproject (projective_ops.transform)  ->  altcorr lookup at 2 pyramid levels (r=3)
+    ->  target = centre + delta  ->  fastba bundle adjustment, 2 Gauss-Newton iterations.
+All inputs are synthetic, resident in HBM before the timed region; the step is captured in a
+HIP graph and replayed.  Multi-GPU: one process per GPU, independent sequences (seed 1234 + rank), no data-path
+collective (replicas; "scaling": "weak"); the aggregate is steps*ranks / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2] [--dtype f32|f16]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--layout", default="cl", choices=["cl", "nchw"], help="storage of the feature pyramid")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=50, help="launch pairs timed for the roofline figure")
+    return ap.parse_args()
+
+
+def build_inputs(cfg, seed, device, dtype, layout):
+    from devo_amd import synth, altcorr
+    n, M, H, W, C = cfg["n"], cfg["M"], cfg["H"], cfg["W"], cfg["C"]
+    poses = synth.make_poses(n, seed)
+    patches, centres = synth.make_patches(n, M, H, W, seed=seed)
+    intr = synth.make_intrinsics(n, H, W)
+    ii, jj, kk = synth.full_graph(n, M)
+    fmap, gmap = synth.make_features(n, M, C, H, W, centres, seed=seed)
+    delta, weight = synth.make_update_outputs(len(ii), seed)
+    d = dict(poses0=poses.to(device), patches0=patches.to(device), intr=intr.to(device),
+             ii=ii.to(device), jj=jj.to(device), kk=kk.to(device), delta=delta.to(device), weight=weight.to(device),
+             lmbda=torch.as_tensor([1e-4], device=device))
+    f0 = fmap.to(device)
+    f1 = synth.pyramid_l1(f0)
+    f0, f1, g = f0.to(dtype), f1.to(dtype), gmap.to(device).to(dtype)
+    if layout == "cl":
+        f0, f1 = altcorr.channels_last(f0), altcorr.channels_last(f1)
+    d.update(pyramid=[f0, f1], gmap=g.contiguous())
+    d["poses"] = d["poses0"].clone()
+    d["patches"] = d["patches0"].clone()
+    cpu = dict(poses=poses, patches=patches, intr=intr, ii=ii, jj=jj, kk=kk, delta=delta, weight=weight,
+               fmap=fmap, gmap=gmap)
+    return d, cpu
+
+
+def alg_bytes(cfg, E, esize):
+    """Touch-once traffic of the two-level lookup: fmap2 + gmap + coords + ii,jj + output."""
+    n, M, H, W, C, R = cfg["n"], cfg["M"], cfg["H"], cfg["W"], cfg["C"], cfg["R"]
+    Dm = 2 * R + 1
+    tot = 0
+    for (h, w) in ((H, W), (H // 4, W // 4)):
+        tot += esize * n * C * h * w + esize * n * M * C * 9 + 4 * E * 2 * 9 + 16 * E + esize * E * Dm * Dm * 9
+    return tot
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from devo_amd import synth, altcorr, distributed as D
+    from devo_amd.backends import cuda_ba, cuda_corr
+
+    cfg = synth.workload(args.workload)
+    dtype = torch.float32 if args.dtype == "f32" else torch.float16
+    d, cpu = build_inputs(cfg, 1234 + rank, device, dtype, args.layout)
+    n, M, R = cfg["n"], cfg["M"], cfg["R"]
+    E = d["ii"].numel()
+    Np = d["patches"].shape[1]
+    ws = cuda_ba.workspace(E, Np, n - 1, device)
+    Dm = 2 * R + 1
+    corr_out = torch.empty(1, E, Dm * Dm * 9 * 2, dtype=dtype, device=device)
+
+    def lookup(coords):
+        for lvl, (fm, s) in enumerate(zip(d["pyramid"], (1, 4))):
+            cuda_corr.forward_into(corr_out, d["gmap"], fm, coords / s, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl)
+
+    def step():
+        d["poses"].copy_(d["poses0"])
+        d["patches"].copy_(d["patches0"])
+        coords = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
+        lookup(coords)
+        target = coords[:, :, :, 1, 1] + d["delta"]                        # devo.py:330
+        cuda_ba.forward(d["poses"], d["patches"], d["intr"], target, d["weight"], d["lmbda"],
+                        d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
+
+    # ---- warm up eagerly once (library load, kernel code upload), then capture
+    step()
+    torch.cuda.synchronize()
+    if args.no_graph:
+        run = step
+    else:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        run = graph.replay
+    for _ in range(args.warmup):
+        run()
+
+    D.barrier_sync(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    D.barrier_sync(device)
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed
+
+    # ---- roofline figure for the dominant kernel (altcorr lookup), HIP events on the launch stream
+    coords = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
+    for _ in range(5):
+        lookup(coords)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # pre-divide so only the lookup kernels sit between the events
+    cs = [coords / 1, coords / 4]
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(args.kernel_reps):
+        for lvl, (fm, c_) in enumerate(zip(d["pyramid"], cs)):
+            cuda_corr.forward_into(corr_out, d["gmap"], fm, c_, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl)
+    ev1.record()
+    torch.cuda.synchronize()
+    launches = 2 * args.kernel_reps
+    t_launch = ev0.elapsed_time(ev1) * 1e-3 / launches                      # s per launch (avg over both levels)
+    b_alg = alg_bytes(cfg, E, 4 if dtype == torch.float32 else 2) / 2.0     # bytes per launch (avg over both levels)
+    achieved = b_alg / t_launch / 1e9
+
+    # BA alone (2 Gauss-Newton iterations), for the ">= 10x the CPU ba.py solve" target
+    tgt = coords[:, :, :, 1, 1] + d["delta"]
+    ev0.record()
+    for _ in range(20):
+        d["poses"].copy_(d["poses0"]); d["patches"].copy_(d["patches0"])
+        cuda_ba.forward(d["poses"], d["patches"], d["intr"], tgt, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
+    ev1.record()
+    torch.cuda.synchronize()
+    t_ba_gpu = ev0.elapsed_time(ev1) * 1e-3 / 20
+
+    out = {
+        "metric": "update-op iterations/sec (altcorr+fastba) at 96 patches, N=15 keyframes",
+        "value": round(value, 2), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.workload}: M={M} patches/frame, n={n} keyframes, E={E} edges, r={R}, "
+                               f"2 pyramid levels {cfg['H']}x{cfg['W']} + /4, C={cfg['C']}, 2 GN iterations, "
+                               f"pyramid layout {args.layout}, {'HIP graph' if not args.no_graph else 'eager'}",
+                   "parallelism": f"replicas x{world}"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "corr_fwd_cl_kernel" if args.layout == "cl" else "corr_fwd_generic_kernel",
+                     "alg_bytes_per_launch": int(b_alg), "us_per_launch": round(t_launch * 1e6, 2)},
+        "ba": {"gpu_ms": round(t_ba_gpu * 1e3, 4)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, cpu, E)
+        out["ba"]["cpu_ms"] = out["cpu_baseline"]["ba_ms"]
+        out["ba"]["speedup"] = round(out["cpu_baseline"]["ba_ms"] / (t_ba_gpu * 1e3), 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, cpu, E):
+    """The reference's CPU-capable path, restated (oracle/pops.py == devo/ba.py + projective_ops.py; the
+    reference has no CPU corr, so oracle/altcorr.py's gather formulation stands in), timed on the host cores.
+    Bounded sample: 2 full-size BA steps x 3 repetitions + the lookup on 256 edges per level."""
+    from oracle import pops, altcorr as oc
+    from oracle.lie import SE3
+    from devo_amd import synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    n, R = cfg["n"], cfg["R"]
+    poses, patches, intr = cpu["poses"], cpu["patches"], cpu["intr"]
+    ii, jj, kk = cpu["ii"], cpu["jj"], cpu["kk"]
+    bounds = [-64, -64, cfg["W"] + 64, cfg["H"] + 64]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        coords = pops.transform(SE3(poses), patches, intr, ii, jj, kk)
+        t_tr = time.perf_counter() - t0
+        target = coords[..., 1, 1, :] + cpu["delta"]
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            G, P = SE3(poses.clone()), patches.clone()
+            for _ in range(2):
+                G, P = pops.BA(G, P, intr, target, cpu["weight"], 1e-4, ii, jj, kk, bounds, ep=10.0, fixedp=1)
+        t_ba = (time.perf_counter() - t0) / reps
+        ns = 256
+        sel = torch.randperm(E, generator=torch.Generator().manual_seed(0))[:ns]
+        c2 = coords.permute(0, 1, 4, 2, 3).contiguous()[:, sel]
+        f1l = synth.pyramid_l1(cpu["fmap"])
+        t0 = time.perf_counter()
+        oc.corr_forward(cpu["gmap"], cpu["fmap"], c2, kk[sel], jj[sel], R, acc=torch.float32)
+        oc.corr_forward(cpu["gmap"], f1l, c2 / 4, kk[sel], jj[sel], R, acc=torch.float32)
+        t_corr = (time.perf_counter() - t0) * (E / ns)
+    step_s = t_tr + t_corr + t_ba
+    return {"value": round(1.0 / step_s, 4), "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"torch-CPU fp32: transform (full, {E} edges) + 2x ba.py-style BA (full, x{reps} reps) + "
+                      f"2-level lookup on {ns} of {E} edges, scaled",
+            "ba_ms": round(t_ba * 1e3, 2), "corr_ms_scaled": round(t_corr * 1e3, 1), "transform_ms": round(t_tr * 1e3, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""ctypes binding of libdevo_hip.so (include/devo_hip.h).
+
+There is NO fallback: if the library is missing or a tensor is not on a GPU the call raises.  PyTorch is
+used only for device memory and streams (tensor.data_ptr(), torch.cuda.current_stream()).
+"""
+import ctypes
+import os
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdevo_hip.so")
+
+DEVO_F32, DEVO_F16, DEVO_F64 = 0, 1, 2
+_DT = {torch.float32: DEVO_F32, torch.float16: DEVO_F16, torch.float64: DEVO_F64}
+
+_c_i64p = ctypes.POINTER(ctypes.c_int64)
+_vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/devo_hip.h exactly
+_SIGNATURES = {
+    "devo_abi_version": [],
+    "devo_last_error": [],
+    "devo_corr_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i64, _i64, _i64, _i, _i, _vp],
+    "devo_corr_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i64, _i, _i, _vp],
+    "devo_patchify_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _c_i64p, _i, _i, _vp],
+    "devo_patchify_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "devo_ba_workspace_bytes": [_i, _i, _i],
+    "devo_ba_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
+    "devo_neighbors_workspace_bytes": [_i],
+    "devo_ba_neighbors": [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp],
+    "devo_ba_reproject": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "devo_transform": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+}
+for _n in ("exp", "log", "inv"):
+    _SIGNATURES[f"devo_se3_{_n}"] = [_vp, _vp, _i64, _i, _vp]
+    _SIGNATURES[f"devo_se3_{_n}_backward"] = [_vp, _vp, _vp, _i64, _i, _vp]
+for _n in ("mul", "adj", "adjT", "act", "act4"):
+    _SIGNATURES[f"devo_se3_{_n}"] = [_vp, _vp, _vp, _i64, _i, _vp]
+    _SIGNATURES[f"devo_se3_{_n}_backward"] = [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]
+_SIGNATURES["devo_se3_as_matrix"] = [_vp, _vp, _i64, _i, _vp]
+_SIGNATURES["devo_se3_jinv"] = [_vp, _vp, _vp, _i64, _i, _vp]
+_RESTYPE = {"devo_last_error": ctypes.c_char_p, "devo_ba_workspace_bytes": _sz, "devo_neighbors_workspace_bytes": _sz}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m devo_amd.build` (hipcc --offload-arch=gfx950). "
+                "devo_amd has no CPU fallback.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, ctypes.c_int)
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().devo_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def dtype_code(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"devo_amd: unsupported dtype {t.dtype}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("devo_amd: tensors must live on the GPU (the HIP path has no CPU fallback)")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def i64arr(vals):
+    return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])

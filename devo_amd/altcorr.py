@@ -1,0 +1,67 @@
+"""Host-side mirror of devo/altcorr/correlation.py (CorrLayer :5-31, PatchLayer :34-49, patchify :51-68,
+corr :71-72) over the HIP kernels, plus the fused two-level lookup used by DEVO.corr / CorrBlock."""
+import torch
+from .backends import cuda_corr
+
+
+class CorrLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fmap1, fmap2, coords, ii, jj, radius, dropout):
+        ctx.save_for_backward(fmap1, fmap2, coords, ii, jj)
+        ctx.radius, ctx.dropout = radius, dropout
+        corr, = cuda_corr.forward(fmap1, fmap2, coords, ii, jj, radius)
+        return corr
+
+    @staticmethod
+    def backward(ctx, grad):
+        fmap1, fmap2, coords, ii, jj = ctx.saved_tensors
+        if ctx.dropout < 1:
+            # correlation.py:20-25: only a random subset of edges propagates gradient; the draw stays here
+            keep = torch.rand(len(ii), device=ii.device) < ctx.dropout
+            coords, grad, ii, jj = coords[:, keep], grad[:, keep], ii[keep], jj[keep]
+        d1, d2 = cuda_corr.backward(fmap1, fmap2, coords, ii, jj, grad, ctx.radius)
+        return d1, d2, None, None, None, None, None
+
+
+class PatchLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, coords, radius):
+        ctx.radius = radius
+        ctx.save_for_backward(net, coords)
+        patches, = cuda_corr.patchify_forward(net, coords, radius)
+        return patches
+
+    @staticmethod
+    def backward(ctx, grad):
+        net, coords = ctx.saved_tensors
+        g, = cuda_corr.patchify_backward(net, coords, grad, ctx.radius)
+        return g, None, None
+
+
+def patchify(net, coords, radius, mode="bilinear"):
+    """(2r+1)^2 patches of `net` around `coords`, bilinear in the sub-pixel offset (correlation.py:51-68)."""
+    patches = PatchLayer.apply(net, coords, radius)
+    if mode != "bilinear":
+        return patches
+    frac = (coords - coords.floor()).to(net.device)
+    dx, dy = frac[:, :, None, None, None].unbind(dim=-1)
+    d = 2 * radius + 1
+    return ((1 - dy) * (1 - dx) * patches[..., :d, :d] + (1 - dy) * dx * patches[..., :d, 1:]
+            + dy * (1 - dx) * patches[..., 1:, :d] + dy * dx * patches[..., 1:, 1:])
+
+
+def corr(fmap1, fmap2, coords, ii, jj, radius=1, dropout=1):
+    return CorrLayer.apply(fmap1, fmap2, coords, ii, jj, radius, dropout)
+
+
+def corr_pyramid(fmap1, pyramid, coords, ii, jj, radius=3, scales=(1, 4)):
+    """Inference-only fused form of
+        torch.stack([corr(fmap1, pyramid[l], coords / scales[l], ii, jj, radius) for l], -1).view(1, E, -1)
+    (devo/devo.py:215-217): one kernel per level writing straight into the stacked layout."""
+    return cuda_corr.forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales)
+
+
+def channels_last(fmap):
+    """Re-lay a [B,n,C,H,W] feature pyramid level as channels-last storage (strides (.., 1, W*C, C)) while
+    keeping its logical shape: this is the layout the LDS-staged lookup kernel wants."""
+    return fmap.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)

@@ -1,0 +1,101 @@
+"""HIP-backed module with the interface of the reference's `cuda_ba` extension (devo/fastba/ba.cpp:152-157):
+forward (in-place bundle adjustment), neighbors, reproject — plus `transform`, the fused form of
+devo/projective_ops.py:53-105 that DEVO.update really calls.  No CPU fallback."""
+import torch
+from .. import _lib as L
+
+
+def _idx(*ts):
+    return [t.long().contiguous() for t in ts]
+
+
+def workspace(E, Np, N, device):
+    nbytes = L.lib().devo_ba_workspace_bytes(int(E), int(Np), int(N))
+    if nbytes == 0:
+        raise RuntimeError(f"cuda_ba: unsupported problem size (E={E}, Np={Np}, N={N}; at most 32 optimised poses)")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations, ws=None, status=None):
+    """ba.cpp:153.  Mutates `poses` ([1,Nbuf,7]) and `patches` ([1,Np,3,P,P]) in place and returns []
+    (devo/fastba/ba.py:7-8 passes poses.data; devo/devo.py:337 relies on the mutation)."""
+    L.require_gpu(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk)
+    for name, t in (("poses", poses), ("patches", patches)):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError(f"cuda_ba.forward: {name} must be a contiguous float32 tensor (it is updated in place)")
+    P = patches.shape[-1]
+    Nbuf = poses.numel() // 7
+    Np = patches.numel() // (3 * P * P)
+    ii, jj, kk = _idx(ii, jj, kk)
+    E = ii.numel()
+    intrinsics = intrinsics.float().contiguous()
+    target = target.float().contiguous()
+    weight = weight.float().contiguous()
+    lmbda = lmbda.float().reshape(-1).contiguous()
+    if ws is None:
+        ws = workspace(E, Np, int(t1) - int(t0), poses.device)
+    rc = L.lib().devo_ba_forward(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(target), L.ptr(weight),
+                                 L.ptr(lmbda), L.ptr(ii), L.ptr(jj), L.ptr(kk), E, Nbuf, Np, P, int(t0), int(t1),
+                                 int(iterations), L.ptr(ws), ws.numel(), L.ptr(status), L.stream())
+    L.check(rc, "cuda_ba.forward")
+    return []
+
+
+def neighbors(ii, jj):
+    """ba.cpp:154 -> [ix, jx] (int64, on the GPU); no device<->host round trip (the reference does five)."""
+    L.require_gpu(ii, jj)
+    ii, jj = _idx(ii, jj)
+    E = ii.numel()
+    ix = torch.empty(E, dtype=torch.int64, device=ii.device)
+    jx = torch.empty(E, dtype=torch.int64, device=ii.device)
+    ws = torch.empty(L.lib().devo_neighbors_workspace_bytes(E), dtype=torch.uint8, device=ii.device)
+    rc = L.lib().devo_ba_neighbors(L.ptr(ii), L.ptr(jj), L.ptr(ix), L.ptr(jx), E, L.ptr(ws), ws.numel(), L.stream())
+    L.check(rc, "cuda_ba.neighbors")
+    return [ix, jx]
+
+
+def reproject(poses, patches, intrinsics, ii, jj, kk):
+    """ba.cpp:155 -> coords [1, E, 2, P, P] (no depth clamp, ba_cuda.cu:368-418)."""
+    L.require_gpu(poses, patches, intrinsics, ii, jj, kk)
+    P = patches.shape[-1]
+    ii, jj, kk = _idx(ii, jj, kk)
+    E = ii.numel()
+    poses = poses.float().contiguous()
+    patches = patches.float().contiguous()
+    intrinsics = intrinsics.float().contiguous()
+    coords = torch.empty(1, E, 2, P, P, dtype=torch.float32, device=poses.device)
+    rc = L.lib().devo_ba_reproject(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(ii), L.ptr(jj), L.ptr(kk),
+                                   L.ptr(coords), E, P, L.stream())
+    L.check(rc, "cuda_ba.reproject")
+    return coords
+
+
+def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, jacobian=False, tonly=False,
+              layout="pp2"):
+    """Fused projective transform with the semantics of devo/projective_ops.py:53-105 (batch 1, no autograd).
+    layout "pp2": coords [1,E,P,P,2|3] as the reference returns; "2pp": [1,E,2,P,P] (devo/devo.py:223)."""
+    L.require_gpu(poses, patches, intrinsics, ii, jj, kk)
+    P = patches.shape[-1]
+    ii, jj, kk = _idx(ii, jj, kk)
+    E = ii.numel()
+    dev = poses.device
+    poses = poses.float().contiguous()
+    patches = patches.float().contiguous()
+    intrinsics = intrinsics.float().contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    c_pp2 = torch.empty(1, E, P, P, 3 if depth else 2, **f32) if layout == "pp2" else None
+    c_2pp = torch.empty(1, E, 2, P, P, **f32) if layout == "2pp" else None
+    v = torch.empty(1, E, **f32) if (valid or jacobian) else None
+    Ji = torch.empty(1, E, 2, 6, **f32) if jacobian else None
+    Jj = torch.empty(1, E, 2, 6, **f32) if jacobian else None
+    Jz = torch.empty(1, E, 2, 1, **f32) if jacobian else None
+    flags = (1 if depth else 0) | (2 if tonly else 0)
+    rc = L.lib().devo_transform(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(ii), L.ptr(jj), L.ptr(kk),
+                                L.ptr(c_pp2), L.ptr(c_2pp), L.ptr(v), L.ptr(Ji), L.ptr(Jj), L.ptr(Jz), E, P, flags, L.stream())
+    L.check(rc, "cuda_ba.transform")
+    c = c_pp2 if layout == "pp2" else c_2pp
+    if jacobian:
+        return c, v, (Ji, Jj, Jz)
+    if valid:
+        return c, v
+    return c

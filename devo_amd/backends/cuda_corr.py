@@ -1,0 +1,107 @@
+"""HIP-backed module with the interface of the reference's `cuda_corr` extension
+(devo/altcorr/correlation.cpp:57-63): forward, backward, patchify_forward, patchify_backward.
+Every function allocates its outputs with torch and enqueues ONE fused kernel of libdevo_hip.so on the
+current stream.  No CPU fallback."""
+import torch
+from .. import _lib as L
+
+
+def _prep(fmap1, fmap2, coords, ii, jj):
+    L.require_gpu(fmap1, fmap2, coords, ii, jj)
+    if fmap1.dtype != fmap2.dtype:
+        raise RuntimeError("cuda_corr: fmap1 and fmap2 must have the same dtype")
+    if fmap1.dim() != 5 or fmap2.dim() != 5 or coords.dim() != 5:
+        raise RuntimeError("cuda_corr: expected fmap1 [B,Np,C,P,P], fmap2 [B,n,C,H,W], coords [B,E,2,P,P]")
+    fmap1 = fmap1.contiguous()
+    coords = coords.float().contiguous()
+    ii = ii.long().contiguous()
+    jj = jj.long().contiguous()
+    return fmap1, fmap2, coords, ii, jj
+
+
+def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, offset):
+    """corr forward writing element l of edge (b,e) at out[(b*E+e)*estride + l*lstride + offset]."""
+    fmap1, fmap2, coords, ii, jj = _prep(fmap1, fmap2, coords, ii, jj)
+    B, E = coords.shape[:2]
+    P = coords.shape[3]
+    _, Np, C = fmap1.shape[:3]
+    n2, H2, W2 = fmap2.shape[1], fmap2.shape[3], fmap2.shape[4]
+    rc = L.lib().devo_corr_forward(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(ii), L.ptr(jj), L.ptr(out),
+                                   B, E, Np, n2, C, P, H2, W2, L.i64arr(fmap2.stride()), estride, lstride, offset,
+                                   int(radius), L.dtype_code(fmap1), L.stream())
+    L.check(rc, "cuda_corr.forward")
+
+
+def forward(fmap1, fmap2, coords, ii, jj, radius):
+    """correlation.cpp:58.  Returns [corr] with logical shape [B, E, 2r+1 (x offset), 2r+1 (y offset), P, P]
+    (the reference returns the same logical tensor as a permuted view; here it is contiguous)."""
+    B, E = coords.shape[:2]
+    P = coords.shape[3]
+    Dm = 2 * int(radius) + 1
+    out = torch.empty(B, E, Dm, Dm, P, P, dtype=fmap1.dtype, device=fmap1.device)
+    forward_into(out, fmap1, fmap2, coords, ii, jj, radius, Dm * Dm * P * P, 1, 0)
+    return [out]
+
+
+def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales):
+    """Fused equivalent of devo/devo.py:215-217 / enet.py:212-216:
+    torch.stack([corr(fmap1, pyr[l], coords / scales[l], ...) for l], -1).view(B, E, -1) without the
+    per-level tensors or the stack copy: each level's kernel writes its interleaved slice directly."""
+    B, E = coords.shape[:2]
+    P = coords.shape[3]
+    Dm = 2 * int(radius) + 1
+    nl = len(pyramid)
+    per = Dm * Dm * P * P
+    out = torch.empty(B, E, per * nl, dtype=fmap1.dtype, device=fmap1.device)
+    for lvl, (fm, s) in enumerate(zip(pyramid, scales)):
+        forward_into(out, fmap1, fm, coords / s, ii, jj, radius, per * nl, nl, lvl)
+    return out
+
+
+def backward(fmap1, fmap2, coords, ii, jj, grad, radius):
+    """correlation.cpp:59 -> [fmap1_grad, fmap2_grad] (fp32 only, like the reference's float grad accessor)."""
+    fmap1, fmap2, coords, ii, jj = _prep(fmap1, fmap2, coords, ii, jj)
+    L.require_gpu(grad)
+    if fmap1.dtype != torch.float32:
+        raise RuntimeError("cuda_corr.backward: fp32 only")
+    B, E = coords.shape[:2]
+    P = coords.shape[3]
+    _, Np, C = fmap1.shape[:3]
+    n2, H2, W2 = fmap2.shape[1], fmap2.shape[3], fmap2.shape[4]
+    grad = grad.float().contiguous()
+    d1 = torch.empty_like(fmap1)
+    d2 = torch.empty_strided(fmap2.shape, fmap2.stride(), dtype=fmap2.dtype, device=fmap2.device)
+    span = 1 + sum((s - 1) * st for s, st in zip(fmap2.shape, fmap2.stride()))
+    rc = L.lib().devo_corr_backward(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(ii), L.ptr(jj), L.ptr(grad),
+                                    L.ptr(d1), L.ptr(d2), B, E, Np, n2, C, P, H2, W2, L.i64arr(fmap2.stride()), span,
+                                    int(radius), L.dtype_code(fmap1), L.stream())
+    L.check(rc, "cuda_corr.backward")
+    return [d1, d2]
+
+
+def patchify_forward(net, coords, radius):
+    """correlation.cpp:61: net [B,C,H,W], coords [B,M,2] -> [patches [B,M,C,D,D]]"""
+    L.require_gpu(net, coords)
+    B, M = coords.shape[:2]
+    C, H, W = net.shape[1:]
+    D = 2 * int(radius) + 2
+    coords = coords.float().contiguous()
+    out = torch.empty(B, M, C, D, D, dtype=net.dtype, device=net.device)
+    rc = L.lib().devo_patchify_forward(L.ptr(net), L.ptr(coords), L.ptr(out), B, M, C, H, W, L.i64arr(net.stride()),
+                                       int(radius), L.dtype_code(net), L.stream())
+    L.check(rc, "cuda_corr.patchify_forward")
+    return [out]
+
+
+def patchify_backward(net, coords, gradient, radius):
+    """correlation.cpp:62 -> [net_gradient [B,C,H,W]]"""
+    L.require_gpu(net, coords, gradient)
+    B, M = coords.shape[:2]
+    C, H, W = net.shape[1:]
+    coords = coords.float().contiguous()
+    gradient = gradient.to(net.dtype).contiguous()
+    out = torch.empty(B, C, H, W, dtype=net.dtype, device=net.device)
+    rc = L.lib().devo_patchify_backward(L.ptr(coords), L.ptr(gradient), L.ptr(out), B, M, C, H, W, int(radius),
+                                        L.dtype_code(net), L.stream())
+    L.check(rc, "cuda_corr.patchify_backward")
+    return [out]

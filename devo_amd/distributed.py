@@ -1,0 +1,54 @@
+"""Multi-GPU harness helpers.  The update/BA hot path shards at SEQUENCE granularity: every
+rank owns an independent sequence (its own pyramid, graph, poses, patches), so inference/benchmark runs are
+replicas with NO data-path collective; the only communication is the timing barrier and a max-reduce of the
+elapsed time.  (Training adds DDP's gradient all-reduce over RCCL — the reference's only collective,
+train.py:107.)  Works with any torch.distributed backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" on CPU."""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def barrier_sync(device=None):
+    """barrier + device synchronize on both sides of a timed region (bench contract)."""
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    if world() > 1:
+        dist.barrier()
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value, device=None):
+    """MAX over ranks of a python float (the slowest rank defines the step time)."""
+    if world() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def shard_sequences(num_sequences, rank_=None, world_=None):
+    """Indices of the independent sequences this rank owns (contiguous block partition, remainder to the
+    first ranks) — mirrors DistributedSampler's role in train.py:91-93 without shuffling."""
+    r = rank() if rank_ is None else rank_
+    w = world() if world_ is None else world_
+    base, rem = divmod(num_sequences, w)
+    lo = r * base + min(r, rem)
+    return list(range(lo, lo + base + (1 if r < rem else 0)))
+
+
+def aggregate_throughput(units_per_rank, elapsed_s, device=None):
+    """Whole-job throughput: total units over the max-over-ranks time."""
+    total = units_per_rank
+    if world() > 1:
+        t = torch.tensor([float(units_per_rank)], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total = float(t.item())
+    return total / max_over_ranks(elapsed_s, device)

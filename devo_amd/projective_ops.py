@@ -1,0 +1,80 @@
+"""Host-side mirror of devo/projective_ops.py (iproj :19-29, proj :32-50, transform :53-105,
+point_cloud :107-109, flow_mag :111-121).
+
+Two execution paths with identical results:
+  * no gradient needed (inference, DEVO.update -> devo.py:222): ONE fused HIP kernel (cuda_ba.transform);
+  * autograd needed (training, enet.py:341,363-369): the same maths as a torch composition over the HIP
+    SE3 ops of devo_amd.lietorch, so gradients flow exactly as in the reference.
+"""
+import torch
+from .lietorch import SE3
+from .backends import cuda_ba
+
+MIN_DEPTH = 0.2
+
+
+def _K(intrinsics):
+    return [intrinsics[..., k, None, None] for k in range(4)]
+
+
+def iproj(patches, intrinsics):
+    fx, fy, cx, cy = _K(intrinsics)
+    px, py, pd = patches[:, :, 0], patches[:, :, 1], patches[:, :, 2]
+    return torch.stack([(px - cx) / fx, (py - cy) / fy, torch.ones_like(pd), pd], dim=-1)
+
+
+def proj(Xh, intrinsics, depth=False):
+    fx, fy, cx, cy = _K(intrinsics)
+    rz = 1.0 / Xh[..., 2].clamp(min=0.1)
+    u = fx * (rz * Xh[..., 0]) + cx
+    v = fy * (rz * Xh[..., 1]) + cy
+    return torch.stack([u, v, rz] if depth else [u, v], dim=-1)
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t.requires_grad for t in ts)
+
+
+def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, jacobian=False, tonly=False):
+    """coords [1,E,P,P,2(+1)] (+ validity [1,E], + (Ji [1,E,2,6], Jj [1,E,2,6], Jz [1,E,2,1]))."""
+    if (not _needs_grad(poses.data, patches, intrinsics) and poses.data.dtype == torch.float32
+            and poses.data.shape[0] == 1):
+        return cuda_ba.transform(poses.data, patches, intrinsics, ii, jj, kk, depth=depth, valid=valid,
+                                 jacobian=jacobian, tonly=tonly, layout="pp2")
+
+    Gij = poses[:, jj] * poses[:, ii].inv()
+    if tonly:
+        Gij.data[..., 3:] = torch.as_tensor([0, 0, 0, 1], dtype=Gij.data.dtype, device=Gij.data.device)
+    X1 = Gij[:, :, None, None] * iproj(patches[:, kk], intrinsics[:, ii])
+    c = X1.shape[2] // 2
+    x1 = proj(X1, intrinsics[:, jj], depth)
+    if jacobian:
+        X, Y, Z, H = X1[..., c, c, :].unbind(dim=-1)
+        fx, fy = intrinsics[:, jj, 0], intrinsics[:, jj, 1]
+        o = torch.zeros_like(Z)
+        big = Z.abs() > 0.2
+        d = torch.where(big, 1.0 / torch.where(big, Z, torch.ones_like(Z)), o)
+        Jj = torch.stack([
+            torch.stack([fx * d * H, o, -fx * X * d * d * H, -fx * X * d * d * Y,
+                         fx * d * Z + fx * X * d * d * X, -fx * d * Y], -1),
+            torch.stack([o, fy * d * H, -fy * Y * d * d * H, -fy * d * Z - fy * Y * d * d * Y,
+                         fy * Y * d * d * X, fy * d * X], -1)], dim=-2)
+        Ji = -Gij[:, :, None].adjT(Jj)
+        t = Gij.data[..., :3]
+        Jz = torch.stack([fx * d * t[..., 0] - fx * X * d * d * t[..., 2],
+                          fy * d * t[..., 1] - fy * Y * d * d * t[..., 2]], -1)[..., None]
+        return x1, (Z > 0.2).float(), (Ji, Jj, Jz)
+    if valid:
+        return x1, (X1[..., c, c, 2] > 0.2).float()
+    return x1
+
+
+def point_cloud(poses, patches, intrinsics, ix):
+    return poses[:, ix, None, None].inv() * iproj(patches, intrinsics[:, ix])
+
+
+def flow_mag(poses, patches, intrinsics, ii, jj, kk, beta=0.3):
+    c0 = transform(poses, patches, intrinsics, ii, ii, kk)
+    full = (transform(poses, patches, intrinsics, ii, jj, kk) - c0).norm(dim=-1)
+    trans = (transform(poses, patches, intrinsics, ii, jj, kk, tonly=True) - c0).norm(dim=-1)
+    return beta * full + (1 - beta) * trans

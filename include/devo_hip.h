@@ -1,0 +1,146 @@
+/* libdevo_hip.so — C ABI of the MI355X-native (gfx950) DEVO update + bundle-adjustment hot path.
+ *
+ * Every entry point replaces one function of the reference's three pybind11 extension modules
+ * (cuda_corr, cuda_ba, lietorch_backends); the reference binding it stands in for is cited as
+ * file:line relative to the tum-vision/DEVO tree.  Conventions:
+ *   - all pointers are DEVICE pointers (HBM) unless marked host; nothing is allocated or freed
+ *     inside a call; scratch space is passed in as `ws` (size from the matching *_workspace_bytes);
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t; NULL = the legacy default stream
+ *     the reference launches on) and never synchronises with the host;
+ *   - return value: DEVO_OK (0) or a DEVO_ERR_* code; devo_last_error() gives the message
+ *     (the Python layer raises RuntimeError, as the reference's TORCH_CHECK / C++ exceptions do);
+ *   - index arrays are int64 (torch.long), as in the reference;
+ *   - `dtype`: DEVO_F32 / DEVO_F16 / DEVO_F64 select the element type of the floating tensors
+ *     named "T*" below (void* in the signature).
+ */
+#ifndef DEVO_HIP_H
+#define DEVO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* devo_stream_t; /* hipStream_t */
+
+enum { DEVO_OK = 0, DEVO_ERR_ARG = 1, DEVO_ERR_LAUNCH = 2, DEVO_ERR_UNSUPPORTED = 3, DEVO_ERR_WORKSPACE = 4 };
+enum { DEVO_F32 = 0, DEVO_F16 = 1, DEVO_F64 = 2 };
+
+int devo_abi_version(void);
+const char* devo_last_error(void); /* thread-local message of the last failing call */
+
+/* ------------------------------------------------------------------------------------------------
+ * altcorr  (reference module cuda_corr: devo/altcorr/correlation.cpp:57-63)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* cuda_corr.forward  (correlation.cpp:58 -> correlation_kernel.cu:193-233, kernel :82-136).
+ *   fmap1  T [B, Np, C, P, P] contiguous                (patch features, "gmap")
+ *   fmap2  T [B, n2, C, H2, W2] with ELEMENT strides f2s[5] = (b, n, c, h, w); channels-last
+ *            storage (c stride 1) selects the LDS-staged fast kernel, anything else the generic one
+ *   coords f32 [B, E, 2, P, P] contiguous (x then y)
+ *   ii, jj i64 [E]  (patch index into fmap1 dim 1, frame index into fmap2 dim 1)
+ *   out    T: logical tensor [B, E, D-1 (x offset), D-1 (y offset), P, P], D = 2*radius+2 — i.e. the
+ *            reference's permuted result — element (b,e,l) with l the row-major logical index is
+ *            written at out[(b*E + e) * out_estride + l * out_lstride + out_offset].
+ *            (out_estride = (D-1)^2*P*P, out_lstride = 1, out_offset = 0 gives a contiguous tensor;
+ *             out_lstride = 2 and out_offset = level writes straight into the stacked
+ *             [B, E, (D-1)^2*P*P, 2] buffer that devo/devo.py:217 / enet.py:216 build with torch.stack.) */
+int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
+                      const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
+                      const int64_t* f2s /* host, 5 */, int64_t out_estride, int64_t out_lstride,
+                      int64_t out_offset, int radius, int dtype, devo_stream_t stream);
+
+/* cuda_corr.backward  (correlation.cpp:59 -> correlation_kernel.cu:236-286, kernel :139-190).
+ *   grad f32: the gradient of the logical [B,E,D-1,D-1,P,P] output, contiguous.
+ *   fmap1_grad [B,Np,C,P,P] contiguous, fmap2_grad with the strides of fmap2: both are ZEROED and then
+ *   accumulated here.  DEVO_F32 only (the reference's grad accessor is float, :146,280). */
+int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
+                       const int64_t* jj, const float* grad, void* fmap1_grad, void* fmap2_grad, int B, int E,
+                       int Np, int n2, int C, int P, int H2, int W2, const int64_t* f2s /* host, 5 */,
+                       int64_t f2_numel_span /* elements spanned by fmap2 storage */, int radius, int dtype,
+                       devo_stream_t stream);
+
+/* cuda_corr.patchify_forward  (correlation.cpp:61 -> correlation_kernel.cu:288-307, kernel :16-47).
+ *   net T [B, C, H, W] with element strides ns[4]; coords f32 [B, M, 2]; out T [B, M, C, D, D] contiguous
+ *   (zero where the tap is out of bounds). */
+int devo_patchify_forward(const void* net, const float* coords, void* out, int B, int M, int C, int H, int W,
+                          const int64_t* ns /* host, 4 */, int radius, int dtype, devo_stream_t stream);
+
+/* cuda_corr.patchify_backward  (correlation.cpp:62 -> correlation_kernel.cu:310-333, kernel :49-80).
+ *   grad T [B, M, C, D, D] contiguous -> net_grad T [B, C, H, W] contiguous (zeroed here). F32/F64. */
+int devo_patchify_backward(const float* coords, const void* grad, void* net_grad, int B, int M, int C, int H,
+                           int W, int radius, int dtype, devo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fastba  (reference module cuda_ba: devo/fastba/ba.cpp:152-157)
+ * ---------------------------------------------------------------------------------------------- */
+
+size_t devo_ba_workspace_bytes(int E, int Np /* patch slots = patches.shape[1] */, int N /* t1 - t0 */);
+
+/* cuda_ba.forward  (ba.cpp:153 -> ba_cuda.cu:422-540).  IN-PLACE on poses and patches, returns nothing.
+ *   poses f32 [Nbuf,7]; patches f32 [Np,3,P,P]; intrinsics f32 [>=1,4] (row 0 only, ba_cuda.cu:233-237);
+ *   target, weight f32 [E,2]; lmbda f32 [1]; ii,jj,kk i64 [E]; frames < t0 are fixed; t1-t0 == 0 is the
+ *   structure-only branch.  A Cholesky breakdown (the reference's cuSOLVER exception, swallowed by
+ *   devo/devo.py:336-340) leaves poses/patches of that iteration untouched and sets *status_flag (i32,
+ *   device, may be NULL) to the failing iteration + 1. */
+int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target,
+                    const float* weight, const float* lmbda, const int64_t* ii, const int64_t* jj,
+                    const int64_t* kk, int E, int Nbuf, int Np, int P, int t0, int t1, int iterations, void* ws,
+                    size_t ws_bytes, int* status_flag, devo_stream_t stream);
+
+size_t devo_neighbors_workspace_bytes(int E);
+
+/* cuda_ba.neighbors  (ba.cpp:154 -> ba.cpp:104-149): for every edge the previous / next edge of the same
+ * ii[e] ordered by jj (stable), -1 at the ends.  ix, jx i64 [E] on the device; bit-exact. */
+int devo_ba_neighbors(const int64_t* ii, const int64_t* jj, int64_t* ix, int64_t* jx, int E, void* ws,
+                      size_t ws_bytes, devo_stream_t stream);
+
+/* cuda_ba.reproject  (ba.cpp:155 -> ba_cuda.cu:543-575, kernel :368-418): coords f32 [E,2,P,P], no Z clamp. */
+int devo_ba_reproject(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                      const int64_t* jj, const int64_t* kk, float* coords, int E, int P, devo_stream_t stream);
+
+/* Fused restatement of devo/projective_ops.py:53-105 `transform` (the reprojection DEVO.update really
+ * calls, devo/devo.py:222): per-frame intrinsics [n,4], Z clamped at 0.1 in the projection.
+ *   coords  f32 [E, P, P, 2 (+1 if depth)]  when coords_pp2 != NULL   (reference layout, :70)
+ *   coords_2pp f32 [E, 2, P, P] when != NULL (the permute(0,1,4,2,3).contiguous() of devo.py:223)
+ *   valid   f32 [E] or NULL (Z > 0.2 at the centre pixel, :100/:103)
+ *   Ji, Jj  f32 [E,2,6], Jz f32 [E,2] or NULL  (:73-98; Ji already negated as in :96)
+ *   flags   bit0 = depth, bit1 = tonly */
+int devo_transform(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                   const int64_t* jj, const int64_t* kk, float* coords_pp2, float* coords_2pp, float* valid,
+                   float* Ji, float* Jj, float* Jz, int E, int P, int flags, devo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * lietorch SE3 subset  (reference module lietorch_backends: devo/lietorch/src/lietorch.cpp:286-316,
+ * group_id 3 only; kernels lietorch_gpu.cu:20-294).  X: T [n,7], tangent: T [n,6], gradients of group
+ * elements are written to the first 6 of 7 slots (slot 7 = 0).  dtype F32 or F64.
+ * ---------------------------------------------------------------------------------------------- */
+int devo_se3_exp(const void* a, void* X, int64_t n, int dtype, devo_stream_t s);                    /* :287 expm */
+int devo_se3_exp_backward(const void* grad, const void* a, void* da, int64_t n, int dtype, devo_stream_t s);
+int devo_se3_log(const void* X, void* a, int64_t n, int dtype, devo_stream_t s);                    /* :290 logm */
+int devo_se3_log_backward(const void* grad, const void* X, void* dX, int64_t n, int dtype, devo_stream_t s);
+int devo_se3_inv(const void* X, void* Y, int64_t n, int dtype, devo_stream_t s);                    /* :293 inv */
+int devo_se3_inv_backward(const void* grad, const void* X, void* dX, int64_t n, int dtype, devo_stream_t s);
+int devo_se3_mul(const void* X, const void* Y, void* Z, int64_t n, int dtype, devo_stream_t s);     /* :296 mul */
+int devo_se3_mul_backward(const void* grad, const void* X, const void* Y, void* dX, void* dY, int64_t n,
+                          int dtype, devo_stream_t s);
+int devo_se3_adj(const void* X, const void* a, void* b, int64_t n, int dtype, devo_stream_t s);     /* :299 adj */
+int devo_se3_adj_backward(const void* grad, const void* X, const void* a, void* dX, void* da, int64_t n,
+                          int dtype, devo_stream_t s);
+int devo_se3_adjT(const void* X, const void* a, void* b, int64_t n, int dtype, devo_stream_t s);    /* :302 adjT */
+int devo_se3_adjT_backward(const void* grad, const void* X, const void* a, void* dX, void* da, int64_t n,
+                           int dtype, devo_stream_t s);
+int devo_se3_act(const void* X, const void* p, void* q, int64_t n, int dtype, devo_stream_t s);     /* :305 act */
+int devo_se3_act_backward(const void* grad, const void* X, const void* p, void* dX, void* dp, int64_t n,
+                          int dtype, devo_stream_t s);
+int devo_se3_act4(const void* X, const void* p, void* q, int64_t n, int dtype, devo_stream_t s);    /* :308 act4 */
+int devo_se3_act4_backward(const void* grad, const void* X, const void* p, void* dX, void* dp, int64_t n,
+                           int dtype, devo_stream_t s);
+int devo_se3_as_matrix(const void* X, void* T44, int64_t n, int dtype, devo_stream_t s);            /* :313 as_matrix */
+int devo_se3_jinv(const void* X, const void* a, void* b, int64_t n, int dtype, devo_stream_t s);    /* :314 Jinv */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEVO_HIP_H */

@@ -1,0 +1,144 @@
+"""GPU parity of altcorr (cuda_corr.*) against the CPU oracle: the correlation lookup (channels-last fast
+path, generic-stride path, fp32/fp16/fp64, r=3 and r=5, out-of-bounds / negative / integer / widely spread
+coordinates), its backward, the fused pyramid output, and patchify forward/backward.
+Tolerance: 1e-4 relative to the output scale for fp32 (north_star); 2e-3 for fp16 storage."""
+import pytest
+import torch
+from oracle import altcorr as A
+from util import assert_rel, channels_last5
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _case(n=4, Np=20, C=128, H=30, W=40, E=200, R=3, seed=0, spread=1.0, jitter=True):
+    g = torch.Generator().manual_seed(seed)
+    f1 = torch.randn(1, Np, C, 3, 3, generator=g) / 4
+    f2 = torch.randn(1, n, C, H, W, generator=g) / 4
+    base = torch.stack([torch.rand(E, generator=g) * (W + 12) - 6, torch.rand(E, generator=g) * (H + 12) - 6], 1)
+    oy, ox = torch.meshgrid(torch.arange(3.) - 1, torch.arange(3.) - 1, indexing="ij")
+    off = torch.stack([ox, oy], 0)                                    # [2,3,3]: x offsets vary along j0
+    scale = spread * (0.6 + 0.9 * torch.rand(E, 1, 1, 1, generator=g))
+    coords = base[:, :, None, None] + scale * off[None]
+    if jitter:
+        coords = coords + 0.2 * torch.randn(coords.shape, generator=g)
+    coords[0] = coords[0].round()                                     # an exactly-integer edge (dx = dy = 0)
+    coords[1] = -50.0 + off                                           # a fully out-of-bounds edge
+    ii = torch.randint(0, Np, (E,), generator=g)
+    jj = torch.randint(0, n, (E,), generator=g)
+    return f1, f2, coords[None].contiguous(), ii, jj, R
+
+
+def _run(f1, f2, coords, ii, jj, R, layout="cl", dtype=torch.float32):
+    from devo_amd.backends import cuda_corr
+    f1d = f1.to(DEV, dtype)
+    f2d = f2.to(DEV, dtype)
+    if layout == "cl":
+        f2d = channels_last5(f2d)
+    out, = cuda_corr.forward(f1d, f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
+    return out
+
+
+@pytest.mark.parametrize("layout", ["cl", "nchw"])
+@pytest.mark.parametrize("R", [3, 5])
+def test_forward_fp32(layout, R):
+    c = _case(R=R, seed=R)
+    ref = A.corr_forward(*c)
+    got = _run(*c, layout=layout)
+    assert got.shape == ref.shape and got.is_contiguous()
+    assert_rel(got, ref, 1e-4, f"corr fwd {layout} R={R}")
+    assert torch.count_nonzero(got[0, 1]) == 0                         # out-of-bounds taps are exactly 0
+
+
+def test_forward_wide_spread_uses_fallback_path():
+    """patch pixels far apart (bounding box > 512 positions): the per-tap path of the fast kernel."""
+    c = _case(seed=7, spread=9.0, E=64)
+    assert_rel(_run(*c, layout="cl"), A.corr_forward(*c), 1e-4, "wide spread")
+    c = _case(seed=8, spread=3.5, E=64)                                 # several 128-position chunks
+    assert_rel(_run(*c, layout="cl"), A.corr_forward(*c), 1e-4, "multi-chunk")
+
+
+def test_forward_fp16_and_fp64():
+    c = _case(seed=11)
+    ref = A.corr_forward(c[0].half().float(), c[1].half().float(), *c[2:])
+    assert_rel(_run(*c, layout="cl", dtype=torch.float16), ref, 2e-3, "fp16 cl")
+    assert_rel(_run(*c, layout="nchw", dtype=torch.float16), ref, 2e-3, "fp16 nchw")
+    assert_rel(_run(*c, layout="nchw", dtype=torch.float64), A.corr_forward(*c), 1e-6, "fp64")
+
+
+def test_small_channel_count_goes_generic():
+    c = _case(C=24, seed=13)
+    assert_rel(_run(*c, layout="cl"), A.corr_forward(*c), 1e-4, "C=24")
+
+
+def test_fused_pyramid_equals_stack():
+    """devo.py:215-217: torch.stack([corr1, corr2], -1).view(1, E, -1)"""
+    from devo_amd import altcorr
+    f1, f2, coords, ii, jj, R = _case(H=32, W=48, seed=17)
+    f2b = torch.nn.functional.avg_pool2d(f2[0], 4, 4)[None]
+    pyr = [channels_last5(f2.to(DEV)), channels_last5(f2b.to(DEV))]
+    args = (coords.to(DEV), ii.to(DEV), jj.to(DEV))
+    fused = altcorr.corr_pyramid(f1.to(DEV), pyr, *args, radius=R, scales=(1, 4))
+    c1 = altcorr.corr(f1.to(DEV), pyr[0], args[0] / 1, args[1], args[2], R)
+    c2 = altcorr.corr(f1.to(DEV), pyr[1], args[0] / 4, args[1], args[2], R)
+    assert torch.equal(fused, torch.stack([c1, c2], -1).view(1, len(ii), -1))
+    ref = torch.stack([A.corr_forward(f1, f2, coords, ii, jj, R), A.corr_forward(f1, f2b, coords / 4, ii, jj, R)], -1)
+    assert_rel(fused, ref.view(1, len(ii), -1), 1e-4, "pyramid")
+
+
+@pytest.mark.parametrize("layout", ["cl", "nchw"])
+def test_backward_fp32(layout):
+    from devo_amd.backends import cuda_corr
+    f1, f2, coords, ii, jj, R = _case(n=3, Np=12, C=64, H=20, W=24, E=60, seed=19)
+    g = torch.randn(1, 60, 7, 7, 3, 3, generator=torch.Generator().manual_seed(1))
+    r1, r2 = A.corr_backward(f1, f2, coords, ii, jj, g, R)
+    f2d = f2.to(DEV)
+    if layout == "cl":
+        f2d = channels_last5(f2d)
+    d1, d2 = cuda_corr.backward(f1.to(DEV), f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), g.to(DEV), R)
+    assert d2.stride() == f2d.stride()
+    assert_rel(d1, r1, 1e-4, "d_fmap1")
+    assert_rel(d2, r2, 1e-4, "d_fmap2")
+
+
+def test_autograd_layer_and_dropout():
+    from devo_amd import altcorr
+    f1, f2, coords, ii, jj, R = _case(n=3, Np=12, C=32, H=20, W=24, E=40, seed=23)
+    a = f1.to(DEV).requires_grad_(True)
+    b = channels_last5(f2.to(DEV)).requires_grad_(True)
+    out = altcorr.corr(a, b, coords.to(DEV), ii.to(DEV), jj.to(DEV), R, 1)
+    g = torch.randn(out.shape, generator=torch.Generator().manual_seed(2))
+    out.backward(g.to(DEV))
+    r1, r2 = A.corr_backward(f1, f2, coords, ii, jj, g, R)
+    assert_rel(a.grad, r1, 1e-4, "autograd d1")
+    assert_rel(b.grad, r2, 1e-4, "autograd d2")
+    # dropout < 1 keeps a random subset of edges (correlation.py:20-25): gradient magnitude shrinks, stays finite
+    a.grad = None
+    torch.manual_seed(0)
+    altcorr.corr(a, b, coords.to(DEV), ii.to(DEV), jj.to(DEV), R, 0.2).backward(g.to(DEV))
+    assert torch.isfinite(a.grad).all() and a.grad.abs().sum() < r1.abs().sum()
+
+
+def test_patchify():
+    from devo_amd.backends import cuda_corr
+    from devo_amd import altcorr
+    g = torch.Generator().manual_seed(29)
+    net = torch.randn(3, 16, 20, 24, generator=g)
+    coords = torch.stack([torch.rand(3, 10, generator=g) * 30 - 3, torch.rand(3, 10, generator=g) * 26 - 3], -1)
+    coords[:, :3] = coords[:, :3].floor()
+    for R in (0, 1, 3):
+        ref = A.patchify_forward(net, coords, R)
+        got, = cuda_corr.patchify_forward(net.to(DEV), coords.to(DEV), R)
+        assert torch.equal(got.cpu(), ref)                               # pure gather: bit-exact
+        got_cl, = cuda_corr.patchify_forward(net.to(DEV).contiguous(memory_format=torch.channels_last), coords.to(DEV), R)
+        assert torch.equal(got_cl.cpu(), ref)
+        gr = torch.randn(ref.shape, generator=g)
+        back, = cuda_corr.patchify_backward(net.to(DEV), coords.to(DEV), gr.to(DEV), R)
+        assert_rel(back, A.patchify_backward(net, coords, gr, R), 1e-5, "patchify bwd")
+    x = net.to(DEV).requires_grad_(True)
+    ci = coords.floor().to(DEV)
+    y = altcorr.patchify(x, ci, 1)
+    assert torch.equal(y.detach().cpu(), A.patchify(net, coords.floor(), 1))
+    y.sum().backward()
+    assert torch.isfinite(x.grad).all()
+    assert torch.equal(cuda_corr.patchify_forward(net.to(DEV).half(), coords.to(DEV), 1)[0].cpu(), A.patchify_forward(net.half(), coords, 1))

@@ -1,0 +1,154 @@
+"""GPU parity of fastba (cuda_ba.*) against the CPU oracle (oracle/fastba.py, oracle/pops.py):
+bundle adjustment (in place, 1-2 iterations, fixed-pose window, structure-only, shuffled / duplicated edges,
+patches whose edges have different source frames), unique(kk) compaction, neighbors (bit-exact), reproject,
+and the fused transform (vs the oracle restatement of projective_ops.transform and vs the reference goldens).
+Tolerance: integer outputs bit-exact; fp32 poses / inverse depths within 1e-4 (north_star) of the fp64 oracle."""
+import os
+import numpy as np
+import pytest
+import torch
+from oracle import fastba as F
+from oracle import pops
+from oracle.lie import SE3 as OSE3
+from devo_amd import synth
+from util import assert_rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def scene(n=8, M=12, H=60, W=80, seed=3, sigma=1.0, keep=0.85, shuffle=True):
+    poses = synth.make_poses(n, seed)
+    patches, _ = synth.make_patches(n, M, H, W, seed=seed)
+    intr = synth.make_intrinsics(n, H, W)
+    ii, jj, kk = synth.full_graph(n, M)
+    g = torch.Generator().manual_seed(seed)
+    if shuffle:
+        perm = torch.randperm(len(ii), generator=g)[: int(keep * len(ii))]
+        ii, jj, kk = ii[perm], jj[perm], kk[perm]
+    delta, weight = synth.make_update_outputs(len(ii), seed, sigma=sigma)
+    c0 = pops.transform(OSE3(poses.double()), patches.double(), intr.double(), ii, jj, kk)
+    target = (c0[..., 1, 1, :] + delta.double()).float()
+    return poses, patches, intr, target, weight, ii, jj, kk
+
+
+def run_ba(poses, patches, intr, target, weight, ii, jj, kk, t0, t1, iters):
+    from devo_amd import fastba
+    from devo_amd.lietorch import SE3
+    P = poses.clone().to(DEV)
+    Q = patches.clone().to(DEV)
+    lm = torch.as_tensor([1e-4], device=DEV)
+    out = fastba.BA(SE3(P), Q, intr.to(DEV), target.to(DEV), weight.to(DEV), lm, ii.to(DEV), jj.to(DEV), kk.to(DEV), t0, t1, iters)
+    assert out == []
+    return P.cpu(), Q.cpu()
+
+
+def check(got, ref64, tol=1e-4):
+    p, q = got
+    assert torch.isfinite(p).all() and torch.isfinite(q).all()
+    assert_rel(p[..., :3], ref64[0][..., :3], tol, "translation")
+    assert_rel(p[..., 3:], ref64[0][..., 3:], tol, "quaternion")
+    assert_rel(q[:, :, 2], ref64[1][:, :, 2], tol, "inverse depth")
+    assert torch.equal(q[:, :, :2], ref64[1][:, :, :2].float())
+
+
+@pytest.mark.parametrize("iters", [1, 2])
+@pytest.mark.parametrize("t0", [1, 3])
+def test_ba_matches_oracle(iters, t0):
+    s = scene()
+    n = s[0].shape[1]
+    ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], t0, n, iters, dtype=torch.float64)
+    check(run_ba(*s, t0, n, iters), ref)
+
+
+def test_ba_structure_only_and_unobserved_patches():
+    s = scene(keep=0.5)
+    n = s[0].shape[1]
+    ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], n, n, 2, dtype=torch.float64)
+    got = run_ba(*s, n, n, 2)
+    assert torch.equal(got[0], s[0])
+    check(got, ref)
+
+
+def test_ba_cfg_sizes_and_duplicates():
+    """closer to cfg2: n=15 (14 optimised poses), M=20; plus duplicated edges and an unsorted list"""
+    s = list(scene(n=15, M=20, H=120, W=160, seed=5, keep=1.0))
+    dup = torch.arange(0, len(s[5]), 7)
+    for k in (3, 4):
+        s[k] = torch.cat([s[k], s[k][:, dup]], 1)
+    for k in (5, 6, 7):
+        s[k] = torch.cat([s[k], s[k][dup]])
+    ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], 1, 15, 2, dtype=torch.float64)
+    check(run_ba(*s, 1, 15, 2), ref)
+
+
+def test_ba_patch_with_mixed_source_frames():
+    """ii is taken per edge (ba_cuda.cu:241), not per patch: edges of one patch may name different source frames."""
+    s = list(scene(seed=9))
+    g = torch.Generator().manual_seed(1)
+    s[5] = torch.where(torch.rand(len(s[5]), generator=g) < 0.3, torch.randint(0, 8, (len(s[5]),), generator=g), s[5])
+    ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], 1, 8, 1, dtype=torch.float64)
+    check(run_ba(*s, 1, 8, 1), ref, tol=2e-4)
+
+
+def test_ba_requires_contiguous_inplace_buffers():
+    from devo_amd.backends import cuda_ba
+    s = scene()
+    bad = s[0].to(DEV).repeat(1, 1, 2)[..., ::2]
+    with pytest.raises(RuntimeError):
+        cuda_ba.forward(bad, s[1].to(DEV), s[2].to(DEV), s[3].to(DEV), s[4].to(DEV), torch.tensor([1e-4], device=DEV),
+                        s[5].to(DEV), s[6].to(DEV), s[7].to(DEV), 1, 8, 2)
+
+
+def test_neighbors_bit_exact():
+    from devo_amd import fastba
+    g = torch.Generator().manual_seed(0)
+    for E, nk, nj in ((1, 1, 1), (7, 3, 4), (5000, 300, 12), (20000, 40, 5)):
+        ii = torch.randint(0, nk, (E,), generator=g) * 3 + 100
+        jj = torch.randint(0, nj, (E,), generator=g)
+        rix, rjx = F.neighbors(ii, jj)
+        ix, jx = fastba.neighbors(ii.to(DEV), jj.to(DEV))
+        assert ix.dtype == torch.int64 and ix.is_cuda
+        assert torch.equal(ix.cpu(), rix) and torch.equal(jx.cpu(), rjx)
+
+
+def test_reproject_and_transform():
+    from devo_amd.backends import cuda_ba
+    poses, patches, intr, target, weight, ii, jj, kk = scene()
+    d = lambda t: t.to(DEV)
+    r = cuda_ba.reproject(d(poses), d(patches), d(intr), d(ii), d(jj), d(kk))
+    assert_rel(r, F.reproject(poses, patches, intr, ii, jj, kk, dtype=torch.float64), 1e-5, "reproject")
+    # push some patches behind / close to the camera to hit the Z clamps and validity gates
+    patches2 = patches.clone()
+    patches2[0, ::5, 2] = 40.0
+    poses2 = poses.clone()
+    poses2[0, 2, 2] -= 3.0
+    O = OSE3(poses2.double())
+    a64 = (patches2.double(), intr.double(), ii, jj, kk)
+    c, v, (Ji, Jj, Jz) = pops.transform(O, *a64, jacobian=True)
+    gc, gv, (gJi, gJj, gJz) = cuda_ba.transform(d(poses2), d(patches2), d(intr), d(ii), d(jj), d(kk), jacobian=True)
+    assert_rel(gc, c, 1e-5, "coords")
+    assert torch.equal(gv.cpu().double(), v)
+    for got, ref, name in ((gJi, Ji, "Ji"), (gJj, Jj, "Jj"), (gJz, Jz, "Jz")):
+        assert_rel(got, ref, 1e-4, name)
+    assert_rel(cuda_ba.transform(d(poses2), d(patches2), d(intr), d(ii), d(jj), d(kk), depth=True), pops.transform(O, *a64, depth=True), 1e-5, "depth")
+    assert_rel(cuda_ba.transform(d(poses2), d(patches2), d(intr), d(ii), d(jj), d(kk), tonly=True), pops.transform(O, *a64, tonly=True), 1e-5, "tonly")
+    c2 = cuda_ba.transform(d(poses2), d(patches2), d(intr), d(ii), d(jj), d(kk), layout="2pp")
+    assert torch.equal(c2, gc.permute(0, 1, 4, 2, 3).contiguous())       # devo.py:223
+
+
+def test_transform_golden(golden_dir):
+    """fused kernel vs outputs of the REAL reference projective_ops.transform (tests/golden)."""
+    from devo_amd import projective_ops as P
+    from devo_amd.lietorch import SE3
+    z = np.load(os.path.join(golden_dir, "transform_f64.npz"))
+    g = {k: torch.from_numpy(z[k]) for k in z.files if z[k].ndim}
+    d = lambda k: g[k].float().to(DEV) if g[k].is_floating_point() else g[k].to(DEV)
+    args = (SE3(d("poses")), d("patches"), d("intrinsics"), d("ii"), d("jj"), d("kk"))
+    with torch.no_grad():
+        c, v, (Ji, Jj, Jz) = P.transform(*args, jacobian=True)
+        fm = P.flow_mag(*args, beta=0.5)
+    assert_rel(c, g["coords"], 1e-5, "coords")
+    assert torch.equal(v.cpu(), g["valid"].float())
+    assert_rel(Ji, g["Ji"], 1e-4, "Ji"); assert_rel(Jj, g["Jj"], 1e-4, "Jj"); assert_rel(Jz, g["Jz"], 1e-4, "Jz")
+    assert_rel(fm, g["flow_mag"], 1e-4, "flow_mag")

@@ -19,16 +19,35 @@ def _prep(fmap1, fmap2, coords, ii, jj):
     return fmap1, fmap2, coords, ii, jj
 
 
-def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, offset):
+PLAN_MIN_EDGES = 2048      # below this the lookup is launch-bound and a locality plan cannot pay for itself
+
+
+def plan(coords, jj, n_frames, height, coord_scale=1.0):
+    """Locality plan (devo_corr_order): edge slots sorted by (target frame, 16-row band).  One plan serves every
+    level of a pyramid; `coords / coord_scale` must be the coordinates of the level with `height` rows."""
+    L.require_gpu(coords, jj)
+    coords = coords.float().contiguous()
+    jj = jj.long().contiguous()
+    B, E = coords.shape[:2]
+    order = torch.empty(B * E, dtype=torch.int32, device=coords.device)
+    rc = L.lib().devo_corr_order(L.ptr(coords), L.ptr(jj), L.ptr(order), B, E, int(n_frames), coords.shape[3], int(height),
+                                 float(coord_scale), L.stream())
+    L.check(rc, "cuda_corr.plan")
+    return order
+
+
+def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, offset, order=None):
     """corr forward writing element l of edge (b,e) at out[(b*E+e)*estride + l*lstride + offset]."""
     fmap1, fmap2, coords, ii, jj = _prep(fmap1, fmap2, coords, ii, jj)
+    if order is None and coords.shape[0] * coords.shape[1] >= PLAN_MIN_EDGES:
+        order = plan(coords, jj, fmap2.shape[1], fmap2.shape[3])
     B, E = coords.shape[:2]
     P = coords.shape[3]
     _, Np, C = fmap1.shape[:3]
     n2, H2, W2 = fmap2.shape[1], fmap2.shape[3], fmap2.shape[4]
     rc = L.lib().devo_corr_forward(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(ii), L.ptr(jj), L.ptr(out),
                                    B, E, Np, n2, C, P, H2, W2, L.i64arr(fmap2.stride()), estride, lstride, offset,
-                                   int(radius), L.dtype_code(fmap1), L.stream())
+                                   int(radius), L.dtype_code(fmap1), L.ptr(order), L.stream())
     L.check(rc, "cuda_corr.forward")
 
 
@@ -53,8 +72,11 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales):
     nl = len(pyramid)
     per = Dm * Dm * P * P
     out = torch.empty(B, E, per * nl, dtype=fmap1.dtype, device=fmap1.device)
+    order = None
+    if B * E >= PLAN_MIN_EDGES:
+        order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0])
     for lvl, (fm, s) in enumerate(zip(pyramid, scales)):
-        forward_into(out, fmap1, fm, coords / s, ii, jj, radius, per * nl, nl, lvl)
+        forward_into(out, fmap1, fm, coords / s, ii, jj, radius, per * nl, nl, lvl, order=order)
     return out
 
 

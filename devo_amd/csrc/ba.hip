@@ -678,21 +678,27 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
   const size_t n6 = 6 * (size_t)N;
   const size_t acc_lds = sizeof(float) * (n6 * (n6 + 1) + n6 + ACC_WAVES * n6 + 4);
   const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 4);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_ba_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+  if (acc_lds > 64 * 1024 || solve_lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)k_ba_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("devo_ba_forward: cannot reserve %zu / %zu bytes of LDS", acc_lds, solve_lds);
+      return DEVO_ERR_LAUNCH;
+    }
   }
   for (int it = 0; it < iterations; it++) {
     hipLaunchKernelGGL(k_ba_accumulate, dim3(L.n_part), dim3(ACC_THREADS), acc_lds, st, poses, patches, intrinsics, target,
                        weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej);
+    if ((rc = check_launch("devo_ba_forward(accumulate)"))) return rc;
     if (N > 0) {
       hipLaunchKernelGGL(k_ba_reduce, dim3(blocks_for((long long)(n6 * n6 + n6), 256, 256)), dim3(256), 0, st, partials, L.n_part, N, S, y);
+      if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag);
+      if ((rc = check_launch("devo_ba_forward(solve)"))) return rc;
     }
-    hipLaunchKernelGGL(k_ba_retract, dim3(blocks_for(L.max_seg, 256, 1024)), dim3(256), 0, st, poses, patches, dX, patch_rec,
+    hipLaunchKernelGGL(k_ba_retract, dim3(blocks_for(L.max_seg > N ? L.max_seg : N, 256, 1024)), dim3(256), 0, st, poses, patches, dX, patch_rec,
                        edge_ej, jj, perm_b, counts, kx, ii, meta, P, t0, N);
+    if ((rc = check_launch("devo_ba_forward(retract)"))) return rc;
   }
   return check_launch("devo_ba_forward");
 }

@@ -10,15 +10,15 @@
 // + output permutation are fused into the epilogue (no raw D x D tensor, no temporaries, no stack copy).
 #include "common.h"
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 namespace devo {
 
 constexpr int PP = 9;          // patch pixels (P = 3)
 constexpr int MAXD = 12;       // 2*R+2 for R <= 5
-constexpr int KC = 32;         // channels staged per LDS chunk
-constexpr int ROWPAD = KC + 4; // LDS row stride in floats: conflict-free ds_read_b128 (36*l mod 64 distinct per 16 lanes)
+constexpr int KC = 16;         // channels staged per LDS chunk
+constexpr int ROWPAD = KC + 4; // LDS row stride in floats: conflict-free ds_read_b128 (20*l mod 64 distinct per 16 lanes)
 constexpr int NT = 128;        // threads per workgroup (2 waves): one chunk of 128 box positions
-constexpr int MAXPOS = 512;    // largest bounding box handled by the staged path
 
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
@@ -69,128 +69,247 @@ __device__ __forceinline__ void corr_epilogue(const float* sraw, const float* sd
 
 // -------------------------------------------------------------------------------------------------
 // Fast path: fmap2 channels-last (channel stride 1), C % KC == 0.
-// grid = B*E workgroups of NT threads.
+// ONE WAVE PER EDGE, no workgroup barriers.  A wave owns a private LDS tile holding, per KC-channel chunk,
+// the bounding box of the edge: NP*64 positions x KC channels (each lane owns NP positions, rows lane+64q).
+// The patch features f1[k][0..8] are wave-uniform: they are fetched with scalar loads one 4-channel step
+// ahead of their use and enter the FMAs as SGPR operands (no LDS bandwidth, no VALU slots).
 // -------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(NT) void corr_fwd_cl_kernel(
+constexpr int WPB = 2;                      // waves (edges) per workgroup
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // a wave's LDS instructions execute in order; this only pins the compiler's ordering
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T, int NP>
+__global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     const T* __restrict__ fmap1, const T* __restrict__ fmap2, const float* __restrict__ coords,
-    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int E, int Np, int n2,
+    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int H2, int W2, int64_t s_b, int64_t s_n, int64_t s_h, int64_t s_w, int64_t out_estride,
-    int64_t out_lstride, int64_t out_offset, int R) {
-  __shared__ __attribute__((aligned(16))) float s_f2[NT * ROWPAD];
-  __shared__ float s_raw[PP * MAXD * MAXD];
-  __shared__ float s_dx[PP], s_dy[PP];
-  __shared__ int s_ox[PP], s_oy[PP];
-
+    int64_t out_lstride, int64_t out_offset, int R, const int* __restrict__ order) {
+  constexpr int F2_FLOATS = NP * 64 * ROWPAD;          // box tile
+  constexpr int WAVE_FLOATS = F2_FLOATS;
+  static_assert(F2_FLOATS >= PP * MAXD * MAXD, "raw windows must fit in the box tile");
+  __shared__ __attribute__((aligned(16))) float s_tile[WPB * WAVE_FLOATS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware schedule: workgroup g runs on XCD g % 8 (observed dispatch order); give every XCD one contiguous
+  // slice of the (frame, row-band)-sorted edge list so that its private L2 sees each feature row ~once.
+  // (bijective for any grid size: XCD x owns ceil((nwg - x) / 8) workgroups.)
+  const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+  const int vwg = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
+  const int slot = vwg * WPB + wave;
+  if (slot >= BE) return;                                   // wave-uniform; no barriers in this kernel
+  const int be = order ? order[slot] : slot;
+  float* tile = s_tile + wave * WAVE_FLOATS;
   const int D = 2 * R + 2;
-  const int be = blockIdx.x;
-  const int b = be / E, e = be % E;
-  const int tid = threadIdx.x;
+  const int b = be / E, e = be - b * E;
 
-  if (tid < PP) {
-    float x = coords[((int64_t)be * 2 + 0) * PP + tid];
-    float y = coords[((int64_t)be * 2 + 1) * PP + tid];
-    float fx = floorf(x), fy = floorf(y);
-    s_ox[tid] = floor_to_int(x) - R;
-    s_oy[tid] = floor_to_int(y) - R;
-    s_dx[tid] = x - fx;
-    s_dy[tid] = y - fy;
+  // ---- geometry: lane p (< 9) owns patch pixel p
+  float px = 0.0f, py = 0.0f;
+  if (lane < PP) {
+    px = coords[((int64_t)be * 2 + 0) * PP + lane];
+    py = coords[((int64_t)be * 2 + 1) * PP + lane];
   }
-  for (int i = tid; i < PP * D * D; i += NT) s_raw[i] = 0.0f;
-  __syncthreads();
-
-  int xmin = s_ox[0], xmax = s_ox[0], ymin = s_oy[0], ymax = s_oy[0];
+  const int my_ox = floor_to_int(px) - R, my_oy = floor_to_int(py) - R;
+  const float my_dx = px - floorf(px), my_dy = py - floorf(py);
+  int ox[PP], oy[PP];
+#pragma unroll
+  for (int p = 0; p < PP; p++) { ox[p] = __builtin_amdgcn_readlane(my_ox, p); oy[p] = __builtin_amdgcn_readlane(my_oy, p); }
+  int xmin = ox[0], xmax = ox[0], ymin = oy[0], ymax = oy[0];
 #pragma unroll
   for (int p = 1; p < PP; p++) {
-    xmin = min(xmin, s_ox[p]); xmax = max(xmax, s_ox[p]);
-    ymin = min(ymin, s_oy[p]); ymax = max(ymax, s_oy[p]);
+    xmin = min(xmin, ox[p]); xmax = max(xmax, ox[p]);
+    ymin = min(ymin, oy[p]); ymax = max(ymax, oy[p]);
   }
   const int bw = xmax - xmin + D, bh = ymax - ymin + D;
   const long long npos_ll = (long long)bw * bh;
 
   const int64_t pi = ii[e];
   const int64_t fj = jj[e];
-  const T* __restrict__ f1 = fmap1 + ((int64_t)b * Np + pi) * C * PP;           // [C][9], wave-uniform
+  const T* __restrict__ f1 = fmap1 + ((int64_t)b * Np + pi) * C * PP;           // [C][9]
   const T* __restrict__ f2 = fmap2 + (int64_t)b * s_b + fj * s_n;
   T* outp = out + (int64_t)be * out_estride + out_offset;
 
-  if (npos_ll <= MAXPOS) {
+  if (npos_ll <= NP * 64) {
     const int npos = (int)npos_ll;
-    for (int base = 0; base < npos; base += NT) {
-      const int mypos = base + tid;
-      const int py = mypos / bw, px = mypos - py * bw;
-      float acc[PP];
+    float acc[NP][PP];
 #pragma unroll
-      for (int p = 0; p < PP; p++) acc[p] = 0.0f;
+    for (int q = 0; q < NP; q++)
+#pragma unroll
+      for (int p = 0; p < PP; p++) acc[q][p] = 0.0f;
 
-      for (int kc = 0; kc < C; kc += KC) {
-        // ---- stage [NT positions][KC channels] of frame fj into LDS (16 B per lane, 8 lanes per position)
-        constexpr int VEC = 16 / sizeof(T);            // elements per 16-byte load
-        constexpr int PARTS = KC / VEC;                // 16-byte loads per position
+    constexpr int VEC = 16 / sizeof(T);            // elements per 16-byte load
+    constexpr int PARTS = KC / VEC;                // 16-byte loads per position
+    constexpr int ITERS = NP * PARTS;              // NP*64 positions * PARTS loads / 64 lanes
+    // per-lane source offsets of the ITERS loads of one chunk (position = q / PARTS, part = q % PARTS)
+    int64_t soff[ITERS];
+    bool sok[ITERS];
 #pragma unroll
-        for (int it = 0; it < PARTS; it++) {
-          int q = tid + it * NT;
-          int pos = q / PARTS, part = q - pos * PARTS;
-          int gp = base + pos;
-          int gy = ymin + gp / bw, gx = xmin + (gp % bw);
-          bool ok = (gp < npos) && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
-          float v[VEC];
-          if (ok) {
-            const T* src = f2 + (int64_t)gy * s_h + (int64_t)gx * s_w + kc + part * VEC;
-            uint4 raw = *reinterpret_cast<const uint4*>(src);
-            const T* rv = reinterpret_cast<const T*>(&raw);
+    for (int it = 0; it < ITERS; it++) {
+      const int q = lane + it * 64;
+      const int pos = q / PARTS, part = q - pos * PARTS;
+      const int gy = ymin + pos / bw, gx = xmin + (pos % bw);
+      sok[it] = (pos < npos) && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
+      soff[it] = (int64_t)gy * s_h + (int64_t)gx * s_w + part * VEC;
+    }
+    // f1 operands: wave-uniform scalar loads, software-pipelined one 4-channel step ahead
+    float wn[4 * PP];
 #pragma unroll
-            for (int u = 0; u < VEC; u++) v[u] = to_f32<T>(rv[u]);
-          } else {
+    for (int u = 0; u < 4 * PP; u++) wn[u] = to_f32<T>(f1[u]);
+    // box chunk: global -> registers one whole chunk ahead of its use (the loads fly under the FMAs)
+    uint4 raw[ITERS];
 #pragma unroll
-            for (int u = 0; u < VEC; u++) v[u] = 0.0f;
-          }
-          float* dst = s_f2 + pos * ROWPAD + part * VEC;
+    for (int it = 0; it < ITERS; it++) {
+      raw[it] = make_uint4(0, 0, 0, 0);
+      if (sok[it]) raw[it] = *reinterpret_cast<const uint4*>(f2 + soff[it]);
+    }
+    for (int kc = 0; kc < C; kc += KC) {
+      wave_lds_fence();                            // previous chunk's reads are done before the tile is overwritten
+      // ---- registers -> LDS (as fp32)
 #pragma unroll
-          for (int u = 0; u < VEC; u += 4) *reinterpret_cast<float4*>(dst + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
+      for (int it = 0; it < ITERS; it++) {
+        const int q = lane + it * 64;
+        const int pos = q / PARTS, part = q - pos * PARTS;
+        const T* rv = reinterpret_cast<const T*>(&raw[it]);
+        float* dst = tile + pos * ROWPAD + part * VEC;
+#pragma unroll
+        for (int u = 0; u < VEC; u += 4)
+          *reinterpret_cast<float4*>(dst + u) =
+              make_float4(to_f32<T>(rv[u]), to_f32<T>(rv[u + 1]), to_f32<T>(rv[u + 2]), to_f32<T>(rv[u + 3]));
+      }
+      wave_lds_fence();
+      if (kc + KC < C) {
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+          if (sok[it]) raw[it] = *reinterpret_cast<const uint4*>(f2 + soff[it] + kc + KC);
         }
-        __syncthreads();
-        // ---- 9 accumulators per position; f1 operands are wave-uniform
-        const float* row = s_f2 + tid * ROWPAD;
+      }
+      // ---- NP x 9 accumulators per lane, 4 channels per step
+      float4 vn[NP];
 #pragma unroll
-        for (int k = 0; k < KC; k += 4) {
-          float4 v = *reinterpret_cast<const float4*>(row + k);
-          const T* w = f1 + (int64_t)(kc + k) * PP;
+      for (int q = 0; q < NP; q++) vn[q] = *reinterpret_cast<const float4*>(tile + (lane + 64 * q) * ROWPAD);
+#pragma unroll
+      for (int k = 0; k < KC; k += 4) {
+        float w[4 * PP];
+        float4 v[NP];
+#pragma unroll
+        for (int u = 0; u < 4 * PP; u++) w[u] = wn[u];
+#pragma unroll
+        for (int q = 0; q < NP; q++) v[q] = vn[q];
+        // prefetch the next step's operands (next chunk's first step wraps to the start of the tile only for
+        // the f1 side; the box side is re-read after the next staging)
+        {
+          const int kn = kc + k + 4;
+          const T* wsrc = f1 + (int64_t)(kn < C ? kn : 0) * PP;
+#pragma unroll
+          for (int u = 0; u < 4 * PP; u++) wn[u] = to_f32<T>(wsrc[u]);
+          if (k + 4 < KC) {
+#pragma unroll
+            for (int q = 0; q < NP; q++) vn[q] = *reinterpret_cast<const float4*>(tile + (lane + 64 * q) * ROWPAD + k + 4);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
 #pragma unroll
           for (int p = 0; p < PP; p++) {
-            acc[p] = fmaf(to_f32<T>(w[p]), v.x, acc[p]);
-            acc[p] = fmaf(to_f32<T>(w[PP + p]), v.y, acc[p]);
-            acc[p] = fmaf(to_f32<T>(w[2 * PP + p]), v.z, acc[p]);
-            acc[p] = fmaf(to_f32<T>(w[3 * PP + p]), v.w, acc[p]);
+            acc[q][p] = fmaf(w[p], v[q].x, acc[q][p]);
+            acc[q][p] = fmaf(w[PP + p], v[q].y, acc[q][p]);
+            acc[q][p] = fmaf(w[2 * PP + p], v[q].z, acc[q][p]);
+            acc[q][p] = fmaf(w[3 * PP + p], v[q].w, acc[q][p]);
           }
         }
-        __syncthreads();
       }
-      // ---- scatter this position's 9 sums into the per-pixel raw windows
+    }
+    // ---- the tile is free now: scatter every position's 9 sums into the per-pixel raw windows [p][a][c]
+    wave_lds_fence();
+    for (int i = lane; i < PP * D * D; i += 64) tile[i] = 0.0f;
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+      const int mypos = q * 64 + lane;
       if (mypos < npos) {
-        const int gy = ymin + py, gx = xmin + px;
+        const int gy = ymin + mypos / bw, gx = xmin + (mypos % bw);
 #pragma unroll
         for (int p = 0; p < PP; p++) {
-          int a = gy - s_oy[p], c = gx - s_ox[p];
-          if (a >= 0 && a < D && c >= 0 && c < D) s_raw[p * D * D + a * D + c] = acc[p];
+          const int a = gy - oy[p], c = gx - ox[p];
+          if (a >= 0 && a < D && c >= 0 && c < D) tile[p * D * D + a * D + c] = acc[q][p];
         }
       }
     }
   } else {
     // ---- patch pixels spread far apart: evaluate the 9 windows one tap at a time (rare)
-    for (int o = tid; o < PP * D * D; o += NT) {
-      int p = o / (D * D), a = (o / D) % D, c = o % D;
-      int gy = s_oy[p] + a, gx = s_ox[p] + c;
+    for (int o = lane; o < PP * D * D; o += 64) {
+      const int p = o / (D * D), a = (o / D) % D, c = o % D;
+      int oxp = ox[0], oyp = oy[0];
+#pragma unroll
+      for (int q = 1; q < PP; q++) { if (p == q) { oxp = ox[q]; oyp = oy[q]; } }
+      const int gy = oyp + a, gx = oxp + c;
       float s = 0.0f;
       if (gy >= 0 && gy < H2 && gx >= 0 && gx < W2) {
         const T* src = f2 + (int64_t)gy * s_h + (int64_t)gx * s_w;
         for (int k = 0; k < C; k++) s = fmaf(to_f32<T>(f1[k * PP + p]), to_f32<T>(src[k]), s);
       }
-      s_raw[o] = s;
+      tile[o] = s;
+    }
+  }
+  wave_lds_fence();
+  // ---- fused bilinear blend + axis swap + output permutation (correlation_kernel.cu:221-232)
+  const int Dm = D - 1;
+  const int total = Dm * Dm * PP;
+  for (int l0 = 0; l0 < total; l0 += 64) {          // wave-uniform trip count: the shuffles below need all lanes
+    const int l = l0 + lane;
+    const int p = l % PP;              // i0*3 + j0
+    const int a = (l / PP) % Dm;       // y offset  (logical dim 3)
+    const int c = l / (PP * Dm);       // x offset  (logical dim 2: permute(0,1,3,2,4,5))
+    const float dxp = __shfl(my_dx, p), dyp = __shfl(my_dy, p);
+    if (l < total) {
+      const float* r = tile + p * D * D + a * D + c;
+      outp[(int64_t)l * out_lstride] = from_f32<T>(blend4(dxp, dyp, r[0], r[1], r[D], r[D + 1]));
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Locality plan: order[] = edge slots sorted by (batch, target frame, 16-row band of the patch centre).
+// One workgroup, LDS counting sort (bins = frames x bands).  The order only affects which edges run
+// together (L2 reuse of the feature rows); results are independent of it.
+// -------------------------------------------------------------------------------------------------
+constexpr int ORDER_THREADS = 1024;
+constexpr int ORDER_MAXBINS = 4096;
+__global__ __launch_bounds__(ORDER_THREADS) void corr_order_kernel(const float* __restrict__ coords,
+                                                                   const int64_t* __restrict__ jj, int BE, int E, int n2,
+                                                                   int H2, float inv_scale, int nb, int* __restrict__ order) {
+  __shared__ int s_cnt[ORDER_MAXBINS];
+  const int nbins = ((BE + E - 1) / E) * n2 * nb;
+  for (int i = threadIdx.x; i < nbins; i += ORDER_THREADS) s_cnt[i] = 0;
+  __syncthreads();
+  auto bin_of = [&](int be) -> int {
+    const int b = be / E, e = be - b * E;
+    const float y = coords[((int64_t)be * 2 + 1) * PP + 4] * inv_scale;      // centre pixel [1][1]
+    int band = (int)(fminf(fmaxf(y, 0.0f), (float)(H2 - 1))) / 16;
+    band = min(max(band, 0), nb - 1);
+    int f = (int)jj[e];
+    f = min(max(f, 0), n2 - 1);
+    return (b * n2 + f) * nb + band;
+  };
+  for (int be = threadIdx.x; be < BE; be += ORDER_THREADS) atomicAdd(&s_cnt[bin_of(be)], 1);
+  __syncthreads();
+  if (threadIdx.x < 64) {                                   // exclusive scan of the bins by one wave
+    int carry = 0;
+    for (int base = 0; base < nbins; base += 64) {
+      const int i = base + threadIdx.x;
+      const int v = (i < nbins) ? s_cnt[i] : 0;
+      int x = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(x, off); if ((int)threadIdx.x >= off) x += t; }
+      if (i < nbins) s_cnt[i] = carry + x - v;
+      carry += __shfl(x, 63);
     }
   }
   __syncthreads();
-  corr_epilogue<T>(s_raw, s_dx, s_dy, outp, D, out_lstride);
+  for (int be = threadIdx.x; be < BE; be += ORDER_THREADS) order[atomicAdd(&s_cnt[bin_of(be)], 1)] = be;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -363,15 +482,23 @@ using namespace devo;
 template <typename T>
 static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                            const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int H2, int W2,
-                           const int64_t* f2s, int64_t oes, int64_t ols, int64_t ooff, int R, hipStream_t st) {
+                           const int64_t* f2s, int64_t oes, int64_t ols, int64_t ooff, int R, const int* order,
+                           hipStream_t st) {
   const bool cl = (f2s[2] == 1) && (C % KC == 0) && (f2s[3] % (16 / sizeof(T)) == 0) && (f2s[4] % (16 / sizeof(T)) == 0) &&
                   (f2s[0] % (16 / sizeof(T)) == 0) && (f2s[1] % (16 / sizeof(T)) == 0) &&
-                  ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) && sizeof(T) <= 4;
-  dim3 grid((unsigned)((long long)B * E)), block(NT);
+                  ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) && ((reinterpret_cast<uintptr_t>(fmap1) & 15) == 0) && sizeof(T) <= 4;
+  const long long BE = (long long)B * E;
   if (cl) {
-    hipLaunchKernelGGL(corr_fwd_cl_kernel<T>, grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
-                       (T*)out, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R);
+    dim3 grid((unsigned)((BE + WPB - 1) / WPB)), block(WPB * 64);
+    static const bool force4 = getenv("DEVO_CORR_NP4") != nullptr;      // debug switch
+    if (R <= 3 && !force4)
+      hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 2>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
+                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order);
+    else
+      hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 4>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
+                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order);
   } else {
+    dim3 grid((unsigned)BE), block(NT);
     hipLaunchKernelGGL(corr_fwd_generic_kernel<T>, grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii,
                        jj, (T*)out, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], oes, ols, ooff, R);
   }
@@ -383,7 +510,7 @@ extern "C" {
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
                       const int64_t* f2s, int64_t out_estride, int64_t out_lstride, int64_t out_offset, int radius,
-                      int dtype, devo_stream_t stream) {
+                      int dtype, const int* order, devo_stream_t stream) {
   DEVO_REQUIRE(P == 3, "devo_corr_forward: patch size P must be 3 (got %d)", P);
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_forward: radius %d unsupported (max 5)", radius);
   DEVO_REQUIRE(B >= 0 && E >= 0 && C > 0 && H2 > 0 && W2 > 0, "devo_corr_forward: bad sizes");
@@ -391,12 +518,26 @@ int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords,
   if ((long long)B * E == 0) return DEVO_OK;
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case DEVO_F32: return launch_corr_fwd<float>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, out_estride, out_lstride, out_offset, radius, st);
-    case DEVO_F16: return launch_corr_fwd<__half>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, out_estride, out_lstride, out_offset, radius, st);
-    case DEVO_F64: return launch_corr_fwd<double>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, out_estride, out_lstride, out_offset, radius, st);
+    case DEVO_F32: return launch_corr_fwd<float>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, out_estride, out_lstride, out_offset, radius, order, st);
+    case DEVO_F16: return launch_corr_fwd<__half>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, out_estride, out_lstride, out_offset, radius, order, st);
+    case DEVO_F64: return launch_corr_fwd<double>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, out_estride, out_lstride, out_offset, radius, order, st);
   }
   set_error("devo_corr_forward: unknown dtype %d", dtype);
   return DEVO_ERR_UNSUPPORTED;
+}
+
+int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, int E, int n2, int P, int H2,
+                    float coord_scale, devo_stream_t stream) {
+  DEVO_REQUIRE(P == 3, "devo_corr_order: patch size P must be 3 (got %d)", P);
+  DEVO_REQUIRE(B >= 0 && E >= 0 && n2 > 0 && H2 > 0 && coord_scale > 0.0f, "devo_corr_order: bad sizes");
+  const long long BE = (long long)B * E;
+  if (BE == 0) return DEVO_OK;
+  int nb = (H2 + 15) / 16;
+  while ((long long)B * n2 * nb > ORDER_MAXBINS && nb > 1) nb = (nb + 1) / 2;      // coarser bands if there are many frames
+  DEVO_REQUIRE((long long)B * n2 * nb <= ORDER_MAXBINS && BE < (1LL << 31), "devo_corr_order: too many frames (%d x %d)", B, n2);
+  hipLaunchKernelGGL(corr_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, (hipStream_t)stream, coords, jj, (int)BE, E, n2, H2,
+                     1.0f / coord_scale, nb, order);
+  return check_launch("devo_corr_order");
 }
 
 int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,

@@ -45,11 +45,21 @@ const char* devo_last_error(void); /* thread-local message of the last failing c
  *            written at out[(b*E + e) * out_estride + l * out_lstride + out_offset].
  *            (out_estride = (D-1)^2*P*P, out_lstride = 1, out_offset = 0 gives a contiguous tensor;
  *             out_lstride = 2 and out_offset = level writes straight into the stacked
- *             [B, E, (D-1)^2*P*P, 2] buffer that devo/devo.py:217 / enet.py:216 build with torch.stack.) */
+ *             [B, E, (D-1)^2*P*P, 2] buffer that devo/devo.py:217 / enet.py:216 build with torch.stack.)
+ *   order  optional locality plan from devo_corr_order (NULL = process edges in list order). */
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
                       const int64_t* f2s /* host, 5 */, int64_t out_estride, int64_t out_lstride,
-                      int64_t out_offset, int radius, int dtype, devo_stream_t stream);
+                      int64_t out_offset, int radius, int dtype, const int* order /* i32 [B*E] or NULL */,
+                      devo_stream_t stream);
+
+/* Locality plan for devo_corr_forward (no reference counterpart: the reference walks edges in list order).
+ * order i32 [B*E]: the edge slots sorted by (batch, target frame jj, 16-row band of the patch centre), so that
+ * the lookup kernel's XCD-aware schedule streams every feature row through an L2 about once.  `coord_scale`
+ * is the factor the caller divides coords by for the pyramid level whose height is H2 (1 for level 0); one
+ * plan serves all levels of a pyramid.  The plan only changes WHICH edges run together, never any result. */
+int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, int E, int n2, int P, int H2,
+                    float coord_scale, devo_stream_t stream);
 
 /* cuda_corr.backward  (correlation.cpp:59 -> correlation_kernel.cu:236-286, kernel :139-190).
  *   grad f32: the gradient of the logical [B,E,D-1,D-1,P,P] output, contiguous.

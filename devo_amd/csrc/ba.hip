@@ -17,13 +17,14 @@
 //   ba_retract    : pose retraction Exp(dX) * G and per-patch depth update  dz = Q (u - e^T dX).
 #include "common.h"
 #include "se3_dev.h"
+#include <stdlib.h>
 
 namespace devo {
 
 constexpr int BA_MAXN = 32;          // optimised poses per call (6N <= 192 rows keeps S in LDS)
 constexpr int ACC_WAVES = 8;         // waves per ba_accumulate workgroup
 constexpr int ACC_THREADS = ACC_WAVES * 64;
-constexpr int ACC_MAX_WG = 64;       // partial systems written per iteration
+constexpr int ACC_MAX_WG = 256;      // partial systems written per iteration
 
 struct BaMeta { int n_seg; int fail; int pad[2]; };
 
@@ -38,18 +39,21 @@ __device__ __forceinline__ unsigned wave_or(unsigned v) {
   for (int off = 32; off >= 1; off >>= 1) v |= (unsigned)__shfl_xor((int)v, off);
   return v;
 }
+__device__ __forceinline__ float readlane_f(float v, int lane) {       // lane must be wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 __device__ __forceinline__ void lds_add(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ int ftab_lookup(int my_le, int f) { return __shfl(my_le, f); }   // lane f holds table entry f
 // LDS traffic of ONE wave is processed in order; this only stops the compiler from moving accesses across.
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
 
-// In-place exclusive scan of data[0..n) by ONE workgroup of 1024 threads; data[n] = total; *total_out too.
-__global__ __launch_bounds__(1024) void k_excl_scan(int* data, int n, int* total_out) {
-  __shared__ int s_part[1024];
+// In-place exclusive scan of data[0..n) by ONE workgroup of 1024 threads; data[n] = total (returned to all).
+__device__ __forceinline__ int block_excl_scan_1024(int* data, int n, int* s_part) {
   const int t = threadIdx.x;
   const int chunk = (n + 1023) / 1024;
   const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
@@ -65,7 +69,15 @@ __global__ __launch_bounds__(1024) void k_excl_scan(int* data, int n, int* total
   }
   int run = s_part[t] - s;                      // exclusive prefix of this thread's chunk
   for (int i = lo; i < hi; i++) { int v = data[i]; data[i] = run; run += v; }
-  if (t == 1023) { data[n] = s_part[1023]; if (total_out) *total_out = s_part[1023]; }
+  const int total = s_part[1023];
+  if (t == 1023) data[n] = total;
+  __syncthreads();
+  return total;
+}
+__global__ __launch_bounds__(1024) void k_excl_scan(int* data, int n, int* total_out) {
+  __shared__ int s_part[1024];
+  const int total = block_excl_scan_1024(data, n, s_part);
+  if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
 __global__ void k_flag_ids(const int64_t* __restrict__ kk, int E, int Np, int* flags) {
@@ -106,6 +118,58 @@ __global__ void k_sort_segments(const int* __restrict__ seg_start, const int* __
       out[a + r] = x;
     }
   }
+}
+
+// Whole graph preparation in ONE launch (one workgroup of 1024 threads) for E <= 2^17:
+//   range of kk -> presence flags over [kmin, kmax] -> rank (sorted unique patch ids, ba_cuda.cu:435-437)
+//   -> per-patch edge counts -> segment starts -> scatter.   (k_sort_segments then fixes the in-segment order.)
+// Everything a lane needs a RETURNED atomic for lives in LDS when it fits (<= 16384 ids in range, <= 8192 unique
+// patches — DEVO's sliding window is ~2k patches); otherwise the same arrays in the workspace are used.
+constexpr int PREP_FLAGS_LDS = 16384;
+constexpr int PREP_SEGS_LDS = 8192;
+__global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
+                                                     int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a) {
+  extern __shared__ int s_mem[];
+  int* s_part = s_mem;                       // 1024
+  int* s_flags = s_part + 1024;              // PREP_FLAGS_LDS + 1
+  int* s_counts = s_flags + PREP_FLAGS_LDS + 1;   // PREP_SEGS_LDS + 1
+  int* s_cursor = s_counts + PREP_SEGS_LDS + 1;   // PREP_SEGS_LDS
+  __shared__ int s_min, s_max;
+  const int t = threadIdx.x;
+  if (t == 0) { s_min = 0x7fffffff; s_max = -1; }
+  __syncthreads();
+  int lo = 0x7fffffff, hi = -1;
+  for (int e = t; e < E; e += 1024) { const int64_t k = kk[e]; if (k >= 0 && k < Np) { lo = min(lo, (int)k); hi = max(hi, (int)k); } }
+  for (int off = 32; off >= 1; off >>= 1) { lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); }
+  if ((t & 63) == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+  __syncthreads();
+  const int kmin = s_min, kmax = s_max;
+  const int Rg = (kmax >= kmin) ? kmax - kmin + 1 : 0;
+  int* rank = (Rg <= PREP_FLAGS_LDS) ? s_flags : g_rank;
+  for (int i = t; i <= Rg; i += 1024) rank[i] = 0;
+  __syncthreads();
+  for (int e = t; e < E; e += 1024) { const int64_t k = kk[e]; if (k >= 0 && k < Np) rank[(int)k - kmin] = 1; }
+  __syncthreads();
+  const int n_seg = block_excl_scan_1024(rank, Rg, s_part);
+  if (t == 0) { meta->n_seg = n_seg; meta->fail = 0; }
+  int* counts = (n_seg <= PREP_SEGS_LDS) ? s_counts : g_counts;
+  int* cursor = (n_seg <= PREP_SEGS_LDS) ? s_cursor : g_cursor;
+  for (int i = t; i <= n_seg; i += 1024) counts[i] = 0;
+  for (int i = t; i < n_seg; i += 1024) cursor[i] = 0;
+  __syncthreads();
+  for (int e = t; e < E; e += 1024) {
+    const int64_t k = kk[e];
+    const int r = (k >= 0 && k < Np) ? rank[(int)k - kmin] : 0;
+    ku[e] = r;
+    atomicAdd(&counts[r], 1);
+  }
+  for (int p = t; p < Rg; p += 1024)
+    if (rank[p + 1] != rank[p]) kx[rank[p]] = kmin + p;
+  __syncthreads();
+  block_excl_scan_1024(counts, n_seg, s_part);
+  for (int e = t; e < E; e += 1024) { const int sgm = ku[e]; perm_a[counts[sgm] + atomicAdd(&cursor[sgm], 1)] = e; }
+  // publish the segment starts: entries beyond n_seg = E so that any reader sees empty tails
+  for (int i = t; i <= max_seg; i += 1024) g_counts[i] = (i <= n_seg) ? counts[i] : E;
 }
 
 // ------------------------------------------------------------------------------------------------- per-edge maths
@@ -149,13 +213,175 @@ __device__ __forceinline__ void edge_terms(const float* __restrict__ poses, cons
 }
 
 // ------------------------------------------------------------------------------------------------- accumulate
+struct AccCtx {
+  const float* poses; const float* patches; const float* target; const float* weight;
+  const int64_t* ii; const int64_t* jj; const int64_t* kk; const int* perm;
+  float* patch_rec; float* edge_e;
+  float fx, fy, cx, cy, lm;
+  int P, t0, N, n6, LD, dbg;
+};
+
+// General per-patch accumulation (any number of edges, duplicated (patch, frame) pairs, edges of one patch with
+// different source frames): lane-private blocks and the Schur rank-1 update go into the workgroup's LDS system
+// with LDS atomics.  Correct for every input but slow (ds_add_f32 costs ~10 cycles per lane), so the kernels
+// below only use it for the rare irregular patches.
+__device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, int a0, int m, float* S_lds, float* y_lds,
+                                                       float* col, int lane) {
+  const float* __restrict__ poses = K.poses; const float* __restrict__ patches = K.patches;
+  const float* __restrict__ target = K.target; const float* __restrict__ weight = K.weight;
+  const int64_t* __restrict__ ii = K.ii; const int64_t* __restrict__ jj = K.jj; const int64_t* __restrict__ kk = K.kk;
+  const int* __restrict__ perm = K.perm;
+  float* patch_rec = K.patch_rec; float* edge_e = K.edge_e;
+  const float fx = K.fx, fy = K.fy, cx = K.cx, cy = K.cy, lm = K.lm;
+  const int P = K.P, t0 = K.t0, N = K.N, n6 = K.n6, LD = K.LD, dbg = K.dbg;
+  for (int i = lane; i < n6; i += 64) col[i] = 0.0f;
+  wave_lds_sync();
+  float Csum = 0.0f, usum = 0.0f;
+  unsigned fmask = 0;           // frames (relative to t0) this patch touches
+
+  for (int base = 0; base < m; base += 64) {
+    const bool act = base + lane < m;
+    const int e = act ? perm[a0 + base + lane] : 0;
+    EdgeTerms T;
+    int ix = -1, jx = -1;
+    if (act) {
+      const int fi = (int)ii[e], fj = (int)jj[e];
+      edge_terms(poses, patches, P, fx, fy, cx, cy, target, weight, fi, fj, (int)kk[e], e, T);
+      ix = fi - t0; jx = fj - t0;
+      if (ix >= N) ix = -1;
+      if (jx >= N) jx = -1;
+    } else {
+      T.w[0] = T.w[1] = 0.0f; T.r[0] = T.r[1] = 0.0f; T.Jz[0] = T.Jz[1] = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 6; c++) { T.Ji[0][c] = T.Ji[1][c] = T.Jj[0][c] = T.Jj[1][c] = 0.0f; }
+    }
+    // ---- patch-level scalars C, u (ba_cuda.cu:321-322)
+    const float wz0 = T.w[0] * T.Jz[0], wz1 = T.w[1] * T.Jz[1];
+    const float wr0 = T.w[0] * T.r[0], wr1 = T.w[1] * T.r[1];
+    Csum += wz0 * T.Jz[0] + wz1 * T.Jz[1];
+    usum += wz0 * T.r[0] + wz1 * T.r[1];
+    float ej[6], ei[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      ej[c] = (jx >= 0) ? (wz0 * T.Jj[0][c] + wz1 * T.Jj[1][c]) : 0.0f;       // E_j += w Jz Jj   (:311)
+      ei[c] = (ix >= 0) ? -(wz0 * T.Ji[0][c] + wz1 * T.Ji[1][c]) : 0.0f;      // E_i -= w Jz Ji   (:309)
+    }
+    if (act) {
+      float* rec = edge_e + ((int64_t)(a0 + base + lane)) * 12;
+#pragma unroll
+      for (int c = 0; c < 6; c++) { rec[c] = ej[c]; rec[6 + c] = ei[c]; }
+    }
+    if (N > 0 && !(dbg & 1)) {
+      if (jx >= 0) fmask |= 1u << jx;
+      if (ix >= 0) fmask |= 1u << ix;
+      // ---- frame-j blocks are lane-private (one edge per target frame): straight into LDS
+      if (jx >= 0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          lds_add(&col[6 * jx + c], ej[c]);
+          lds_add(&y_lds[6 * jx + c], wr0 * T.Jj[0][c] + wr1 * T.Jj[1][c]);                               // v_j += w r Jj (:316)
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int c = 0; c <= a; c++)
+            lds_add(&S_lds[(6 * jx + a) * LD + 6 * jx + c],
+                    T.w[0] * T.Jj[0][a] * T.Jj[0][c] + T.w[1] * T.Jj[1][a] * T.Jj[1][c]);                 // B_jj (:299)
+        if (ix >= 0) {
+          // B_ij = -w Ji Jj^T and B_ji = its transpose (:300-303): keep the one in the lower triangle
+          // (both when i == j: they land on the same diagonal block).
+#pragma unroll
+          for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+              const float vij = -(T.w[0] * T.Ji[0][a] * T.Jj[0][c] + T.w[1] * T.Ji[1][a] * T.Jj[1][c]);  // block (i,j)[a][c]
+              if (ix > jx) lds_add(&S_lds[(6 * ix + a) * LD + 6 * jx + c], vij);
+              else if (ix < jx) lds_add(&S_lds[(6 * jx + c) * LD + 6 * ix + a], vij);
+              else { lds_add(&S_lds[(6 * ix + a) * LD + 6 * ix + c], vij); lds_add(&S_lds[(6 * ix + c) * LD + 6 * ix + a], vij); }
+            }
+        }
+      }
+      // ---- frame-i blocks: in DEVO graphs all edges of a patch share the source frame -> reduce the
+      //      6x6 / 6x1 blocks across the wavefront with shuffles and add once; otherwise lane-private.
+      const unsigned long long bi = (dbg & 2) ? 0ULL : __ballot(ix >= 0);
+      if (bi) {
+        const int ix0 = __shfl(ix, __ffsll((long long)bi) - 1);
+        const bool uniform = (__ballot(ix >= 0 && ix != ix0) == 0ULL);
+        if (uniform) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            const float vc = wave_sum(ei[c]);
+            const float vv = wave_sum((ix >= 0) ? -(wr0 * T.Ji[0][c] + wr1 * T.Ji[1][c]) : 0.0f);        // v_i -= w r Ji (:314)
+            if (lane == 0) { lds_add(&col[6 * ix0 + c], vc); lds_add(&y_lds[6 * ix0 + c], vv); }
+          }
+#pragma unroll
+          for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = 0; c <= a; c++) {
+              float v = (ix >= 0) ? (T.w[0] * T.Ji[0][a] * T.Ji[0][c] + T.w[1] * T.Ji[1][a] * T.Ji[1][c]) : 0.0f;   // B_ii (:297)
+              v = wave_sum(v);
+              if (lane == 0) lds_add(&S_lds[(6 * ix0 + a) * LD + 6 * ix0 + c], v);
+            }
+        } else if (ix >= 0) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            lds_add(&col[6 * ix + c], ei[c]);
+            lds_add(&y_lds[6 * ix + c], -(wr0 * T.Ji[0][c] + wr1 * T.Ji[1][c]));
+          }
+#pragma unroll
+          for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = 0; c <= a; c++)
+              lds_add(&S_lds[(6 * ix + a) * LD + 6 * ix + c],
+                      T.w[0] * T.Ji[0][a] * T.Ji[0][c] + T.w[1] * T.Ji[1][a] * T.Ji[1][c]);
+        }
+      }
+    }
+  }
+  // ---- finish the patch: C, u, Q
+  Csum = wave_sum(Csum);
+  usum = wave_sum(usum);
+  const float Q = 1.0f / (Csum + lm);                                   // ba_cuda.cu:492
+  fmask = wave_or(fmask);
+  if (lane == 0) { patch_rec[(int64_t)s * 2] = Q; patch_rec[(int64_t)s * 2 + 1] = usum; }
+  if (N > 0 && !(dbg & 4)) {
+    wave_lds_sync();                                                    // the patch's E column is complete in LDS
+    // ---- Schur complement, patch by patch:  S -= Q e e^T (lower triangle),  y -= Q u e   (:511-512)
+    // The column is pulled into registers once (lane l holds rows l, l+64, l+128); column entries are then
+    // broadcast with v_readlane, so the loop issues LDS atomics only — no LDS read sits between them.
+    float cr[3];
+#pragma unroll
+    for (int g = 0; g < 3; g++) cr[g] = (lane + 64 * g < n6) ? col[lane + 64 * g] : 0.0f;
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      if (64 * g >= n6) break;                                          // uniform
+      const int r = lane + 64 * g;
+      const float qer = -Q * cr[g];
+      const bool live = (r < n6) && (cr[g] != 0.0f);
+      if (live) lds_add(&y_lds[r], qer * usum);
+      for (unsigned mm = fmask; mm; mm &= mm - 1) {                     // uniform trip count
+        const int fb = __ffs((int)mm) - 1;
+        if (6 * fb > 64 * g + 63) break;                                // uniform: no row of this group reaches it
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          const int cc = 6 * fb + c;
+          const float ec = readlane_f(cc < 64 ? cr[0] : (cc < 128 ? cr[1] : cr[2]), cc & 63);
+          if (live && cc <= r) lds_add(&S_lds[r * LD + cc], qer * ec);
+        }
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+// Generic accumulate kernel (any N <= 32): every patch through the atomic path.
 // LDS (dynamic): S_lds [n6 * LD] (lower triangle used), y_lds [n6], per-wave column buffers [ACC_WAVES][n6].
 __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
     const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
     const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
     const int* __restrict__ perm, const int* __restrict__ seg_start, const BaMeta* __restrict__ meta, int P, int t0,
-    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e) {
+    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n6 = 6 * N, LD = n6 + 1;
   float* S_lds = smem;
@@ -163,146 +389,14 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
   float* col_all = y_lds + n6;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* col = col_all + wave * n6;
-
   for (int i = tid; i < n6 * LD + n6; i += ACC_THREADS) smem[i] = 0.0f;
   __syncthreads();
-
-  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
-  const float lm = lmbda[0];
+  AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, edge_e, intr[0], intr[1], intr[2], intr[3], lmbda[0],
+           P, t0, N, n6, LD, dbg};
   const int n_seg = meta->n_seg;
-
   for (int s = blockIdx.x * ACC_WAVES + wave; s < n_seg; s += gridDim.x * ACC_WAVES) {
     const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
-    for (int i = lane; i < n6; i += 64) col[i] = 0.0f;
-    wave_lds_sync();
-    float Csum = 0.0f, usum = 0.0f;
-    unsigned fmask = 0;           // frames (relative to t0) this patch touches
-
-    for (int base = 0; base < m; base += 64) {
-      const bool act = base + lane < m;
-      const int e = act ? perm[a0 + base + lane] : 0;
-      EdgeTerms T;
-      int ix = -1, jx = -1;
-      if (act) {
-        const int fi = (int)ii[e], fj = (int)jj[e];
-        edge_terms(poses, patches, P, fx, fy, cx, cy, target, weight, fi, fj, (int)kk[e], e, T);
-        ix = fi - t0; jx = fj - t0;
-        if (ix >= N) ix = -1;
-        if (jx >= N) jx = -1;
-      } else {
-        T.w[0] = T.w[1] = 0.0f; T.r[0] = T.r[1] = 0.0f; T.Jz[0] = T.Jz[1] = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 6; c++) { T.Ji[0][c] = T.Ji[1][c] = T.Jj[0][c] = T.Jj[1][c] = 0.0f; }
-      }
-      // ---- patch-level scalars C, u (ba_cuda.cu:321-322)
-      const float wz0 = T.w[0] * T.Jz[0], wz1 = T.w[1] * T.Jz[1];
-      const float wr0 = T.w[0] * T.r[0], wr1 = T.w[1] * T.r[1];
-      Csum += wz0 * T.Jz[0] + wz1 * T.Jz[1];
-      usum += wz0 * T.r[0] + wz1 * T.r[1];
-      float ej[6], ei[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        ej[c] = (jx >= 0) ? (wz0 * T.Jj[0][c] + wz1 * T.Jj[1][c]) : 0.0f;       // E_j += w Jz Jj   (:311)
-        ei[c] = (ix >= 0) ? -(wz0 * T.Ji[0][c] + wz1 * T.Ji[1][c]) : 0.0f;      // E_i -= w Jz Ji   (:309)
-      }
-      if (act) {
-        float* rec = edge_e + ((int64_t)(a0 + base + lane)) * 12;
-#pragma unroll
-        for (int c = 0; c < 6; c++) { rec[c] = ej[c]; rec[6 + c] = ei[c]; }
-      }
-      if (N > 0) {
-        if (jx >= 0) fmask |= 1u << jx;
-        if (ix >= 0) fmask |= 1u << ix;
-        // ---- frame-j blocks are lane-private (one edge per target frame): straight into LDS
-        if (jx >= 0) {
-#pragma unroll
-          for (int c = 0; c < 6; c++) {
-            lds_add(&col[6 * jx + c], ej[c]);
-            lds_add(&y_lds[6 * jx + c], wr0 * T.Jj[0][c] + wr1 * T.Jj[1][c]);                               // v_j += w r Jj (:316)
-          }
-#pragma unroll
-          for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int c = 0; c <= a; c++)
-              lds_add(&S_lds[(6 * jx + a) * LD + 6 * jx + c],
-                      T.w[0] * T.Jj[0][a] * T.Jj[0][c] + T.w[1] * T.Jj[1][a] * T.Jj[1][c]);                 // B_jj (:299)
-          if (ix >= 0) {
-            // B_ij = -w Ji Jj^T and B_ji = its transpose (:300-303): keep the one in the lower triangle
-            // (both when i == j: they land on the same diagonal block).
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-              for (int c = 0; c < 6; c++) {
-                const float vij = -(T.w[0] * T.Ji[0][a] * T.Jj[0][c] + T.w[1] * T.Ji[1][a] * T.Jj[1][c]);  // block (i,j)[a][c]
-                if (ix > jx) lds_add(&S_lds[(6 * ix + a) * LD + 6 * jx + c], vij);
-                else if (ix < jx) lds_add(&S_lds[(6 * jx + c) * LD + 6 * ix + a], vij);
-                else { lds_add(&S_lds[(6 * ix + a) * LD + 6 * ix + c], vij); lds_add(&S_lds[(6 * ix + c) * LD + 6 * ix + a], vij); }
-              }
-          }
-        }
-        // ---- frame-i blocks: in DEVO graphs all edges of a patch share the source frame -> reduce the
-        //      6x6 / 6x1 blocks across the wavefront with shuffles and add once; otherwise lane-private.
-        const unsigned long long bi = __ballot(ix >= 0);
-        if (bi) {
-          const int ix0 = __shfl(ix, __ffsll((long long)bi) - 1);
-          const bool uniform = (__ballot(ix >= 0 && ix != ix0) == 0ULL);
-          if (uniform) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-              const float vc = wave_sum(ei[c]);
-              const float vv = wave_sum((ix >= 0) ? -(wr0 * T.Ji[0][c] + wr1 * T.Ji[1][c]) : 0.0f);        // v_i -= w r Ji (:314)
-              if (lane == 0) { lds_add(&col[6 * ix0 + c], vc); lds_add(&y_lds[6 * ix0 + c], vv); }
-            }
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-              for (int c = 0; c <= a; c++) {
-                float v = (ix >= 0) ? (T.w[0] * T.Ji[0][a] * T.Ji[0][c] + T.w[1] * T.Ji[1][a] * T.Ji[1][c]) : 0.0f;   // B_ii (:297)
-                v = wave_sum(v);
-                if (lane == 0) lds_add(&S_lds[(6 * ix0 + a) * LD + 6 * ix0 + c], v);
-              }
-          } else if (ix >= 0) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-              lds_add(&col[6 * ix + c], ei[c]);
-              lds_add(&y_lds[6 * ix + c], -(wr0 * T.Ji[0][c] + wr1 * T.Ji[1][c]));
-            }
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-              for (int c = 0; c <= a; c++)
-                lds_add(&S_lds[(6 * ix + a) * LD + 6 * ix + c],
-                        T.w[0] * T.Ji[0][a] * T.Ji[0][c] + T.w[1] * T.Ji[1][a] * T.Ji[1][c]);
-          }
-        }
-      }
-    }
-    // ---- finish the patch: C, u, Q
-    Csum = wave_sum(Csum);
-    usum = wave_sum(usum);
-    const float Q = 1.0f / (Csum + lm);                                   // ba_cuda.cu:492
-    fmask = wave_or(fmask);
-    if (lane == 0) { patch_rec[(int64_t)s * 2] = Q; patch_rec[(int64_t)s * 2 + 1] = usum; }
-    if (N > 0) {
-      wave_lds_sync();                                                    // the patch's E column is complete in LDS
-      // ---- Schur complement, patch by patch:  S -= Q e e^T (lower triangle),  y -= Q u e   (:511-512)
-      for (int r = lane; r < n6; r += 64) {
-        const float er = col[r];
-        if (er == 0.0f) continue;
-        const float qer = Q * er;
-        lds_add(&y_lds[r], -qer * usum);
-        for (unsigned mm = fmask; mm; mm &= mm - 1) {
-          const int fb = __ffs((int)mm) - 1;
-          if (6 * fb > r) break;
-#pragma unroll
-          for (int c = 0; c < 6; c++) {
-            const int cc = 6 * fb + c;
-            if (cc <= r) lds_add(&S_lds[r * LD + cc], -qer * col[cc]);
-          }
-        }
-      }
-      wave_lds_sync();
-    }
+    accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane);
   }
   __syncthreads();
   if (N > 0) {
@@ -311,36 +405,267 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
   }
 }
 
+// Register-resident accumulate kernel for N <= NMAX optimised poses (the DEVO sizes: 7..14).
+// Each wave keeps its OWN copy of the lower block-triangle of S in registers: lane (a,b) = (lane/6, lane%6) < 36
+// holds entry [a][b] of every 6x6 block, Sreg[block].  A regular patch (<= 64 edges, one source frame, distinct
+// target frames) is folded in with wave-uniform control flow and plain LDS reads of a per-wave scratch that the
+// patch's edge lanes filled: no atomics, fixed summation order.  Irregular patches take the atomic path into the
+// workgroup's LDS system.  At the end the register copies are added into LDS one wave at a time.
+constexpr int REG_WAVES = 4;      // 256 threads: one wave per SIMD, so the register copy of S never spills
+constexpr int REG_THREADS = REG_WAVES * 64;
+constexpr int SCR_ROWS = 28;     // per-edge scratch rows: Jj_x[6] Jj_y[6] Ji_x[6] Ji_y[6] w_x w_y (w r)_x (w r)_y
+
+template <int NMAX>
+__global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
+    const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
+    const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ lmbda,
+    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
+    const int* __restrict__ perm, const int* __restrict__ seg_start, const BaMeta* __restrict__ meta, int P, int t0,
+    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n6 = 6 * N, LD = n6 + 1;
+  float* S_lds = smem;
+  float* y_lds = S_lds + n6 * LD;
+  float* col_all = y_lds + n6;
+  float* scr_all = col_all + REG_WAVES * n6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* col = col_all + wave * n6;
+  float* scr = scr_all + wave * (SCR_ROWS * 64);
+  for (int i = tid; i < n6 * LD + n6; i += REG_THREADS) smem[i] = 0.0f;
+  __syncthreads();
+  AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, edge_e, intr[0], intr[1], intr[2], intr[3], lmbda[0],
+           P, t0, N, n6, LD, dbg};
+
+  const int pa = (lane < 36) ? lane / 6 : 0, pb = (lane < 36) ? lane % 6 : 0;    // this lane's position inside a 6x6 block
+  float Sreg[NMAX * (NMAX + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < NMAX * (NMAX + 1) / 2; i++) Sreg[i] = 0.0f;
+  float yreg[2] = {0.0f, 0.0f};                                 // rows lane, lane + 64  (n6 <= 96)
+
+  const int n_seg = meta->n_seg;
+  for (int s = blockIdx.x * REG_WAVES + wave; s < n_seg; s += gridDim.x * REG_WAVES) {
+    const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
+    if (m > 64) { accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane); continue; }
+    const bool act = lane < m;
+    const int e = act ? perm[a0 + lane] : 0;
+    EdgeTerms T;
+    int ix = -1, jx = -1;
+    if (act) {
+      const int fi = (int)ii[e], fj = (int)jj[e];
+      edge_terms(poses, patches, P, K.fx, K.fy, K.cx, K.cy, target, weight, fi, fj, (int)kk[e], e, T);
+      ix = fi - t0; jx = fj - t0;
+      if (ix >= N) ix = -1;
+      if (jx >= N) jx = -1;
+    } else {
+      T.w[0] = T.w[1] = 0.0f; T.r[0] = T.r[1] = 0.0f; T.Jz[0] = T.Jz[1] = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 6; c++) { T.Ji[0][c] = T.Ji[1][c] = T.Jj[0][c] = T.Jj[1][c] = 0.0f; }
+    }
+    // ---- regular?  one source frame, distinct target frames (frame -> lane table built through the column buffer)
+    const unsigned long long bi = __ballot(ix >= 0);
+    const int src = bi ? __shfl(ix, __ffsll((long long)bi) - 1) : -1;
+    const bool mixed = __ballot(ix >= 0 && ix != src) != 0ULL;
+    int* ftab = reinterpret_cast<int*>(col);                    // borrowed before the column is built
+    if (lane < N) ftab[lane] = -1;
+    wave_lds_sync();
+    if (jx >= 0) ftab[jx] = lane;
+    wave_lds_sync();
+    const bool dup = (jx >= 0) && (ftab[jx] != lane);
+    const int my_le = (lane < N) ? ftab[lane] : -1;              // lane f holds the edge lane that targets frame f
+    wave_lds_sync();
+    if (mixed || __ballot(dup) != 0ULL) { accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane); continue; }
+
+    // ---- per-edge quantities into the wave's scratch; the patch's E column into `col`
+    for (int i = lane; i < n6; i += 64) col[i] = 0.0f;
+    const float wz0 = T.w[0] * T.Jz[0], wz1 = T.w[1] * T.Jz[1];
+    const float wr0 = T.w[0] * T.r[0], wr1 = T.w[1] * T.r[1];
+    float Csum = wz0 * T.Jz[0] + wz1 * T.Jz[1];
+    float usum = wz0 * T.r[0] + wz1 * T.r[1];
+    float ej[6], ei[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      ej[c] = (jx >= 0) ? (wz0 * T.Jj[0][c] + wz1 * T.Jj[1][c]) : 0.0f;       // E_j += w Jz Jj   (ba_cuda.cu:311)
+      ei[c] = (ix >= 0) ? -(wz0 * T.Ji[0][c] + wz1 * T.Ji[1][c]) : 0.0f;      // E_i -= w Jz Ji   (:309)
+      scr[c * 64 + lane] = T.Jj[0][c];
+      scr[(6 + c) * 64 + lane] = T.Jj[1][c];
+      scr[(12 + c) * 64 + lane] = (ix >= 0) ? T.Ji[0][c] : 0.0f;
+      scr[(18 + c) * 64 + lane] = (ix >= 0) ? T.Ji[1][c] : 0.0f;
+    }
+    scr[24 * 64 + lane] = T.w[0]; scr[25 * 64 + lane] = T.w[1];
+    scr[26 * 64 + lane] = wr0;    scr[27 * 64 + lane] = wr1;
+    if (act) {
+      float* rec = edge_e + ((int64_t)(a0 + lane)) * 12;
+#pragma unroll
+      for (int c = 0; c < 6; c++) { rec[c] = ej[c]; rec[6 + c] = ei[c]; }
+    }
+    wave_lds_sync();
+    if (jx >= 0) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) col[6 * jx + c] = ej[c];      // distinct target frames: plain stores
+    }
+    Csum = wave_sum(Csum);
+    usum = wave_sum(usum);
+#pragma unroll
+    for (int c = 0; c < 6; c++) ei[c] = wave_sum(ei[c]);
+    wave_lds_sync();
+    if (src >= 0 && lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) col[6 * src + c] += ei[c];
+    }
+    const float Q = 1.0f / (Csum + K.lm);                       // ba_cuda.cu:492
+    if (lane == 0) { patch_rec[(int64_t)s * 2] = Q; patch_rec[(int64_t)s * 2 + 1] = usum; }
+    unsigned fmask = wave_or((jx >= 0 ? 1u << jx : 0u) | (ix >= 0 ? 1u << ix : 0u));
+    wave_lds_sync();
+    if (N == 0) continue;
+
+    // ---- fold the patch into the register-resident block triangle (wave-uniform control flow)
+    int blk = 0;
+#pragma unroll
+    for (int fr = 0; fr < NMAX; fr++) {
+#pragma unroll
+      for (int fc = 0; fc <= fr; fc++, blk++) {
+        if (fr < N && ((fmask >> fr) & 1u) && ((fmask >> fc) & 1u)) {
+          float v = -Q * col[6 * fr + pa] * col[6 * fc + pb];   // Schur: S -= Q e e^T  (:511)
+          const int le_r = __builtin_amdgcn_readlane(my_le, fr);
+          const int le_c = __builtin_amdgcn_readlane(my_le, fc);
+          if (fr == fc) {
+            if (le_r >= 0)                                        // B_jj += w Jj Jj^T  (:299)
+              v += scr[24 * 64 + le_r] * scr[pa * 64 + le_r] * scr[pb * 64 + le_r] +
+                   scr[25 * 64 + le_r] * scr[(6 + pa) * 64 + le_r] * scr[(6 + pb) * 64 + le_r];
+            if (fr == src) {
+              for (int q = 0; q < m; q++)                         // B_ii += sum over the patch's edges of w Ji Ji^T  (:297)
+                v += scr[24 * 64 + q] * scr[(12 + pa) * 64 + q] * scr[(12 + pb) * 64 + q] +
+                     scr[25 * 64 + q] * scr[(18 + pa) * 64 + q] * scr[(18 + pb) * 64 + q];
+              if (le_r >= 0)                                      // self edge: B_ij + B_ji land on the diagonal block
+                v -= scr[24 * 64 + le_r] * (scr[(12 + pa) * 64 + le_r] * scr[pb * 64 + le_r] + scr[pa * 64 + le_r] * scr[(12 + pb) * 64 + le_r]) +
+                     scr[25 * 64 + le_r] * (scr[(18 + pa) * 64 + le_r] * scr[(6 + pb) * 64 + le_r] + scr[(6 + pa) * 64 + le_r] * scr[(18 + pb) * 64 + le_r]);
+            }
+          } else {
+            if (fc == src && le_r >= 0)                           // block (j,i) = -w Jj Ji^T  (:303)
+              v -= scr[24 * 64 + le_r] * scr[pa * 64 + le_r] * scr[(12 + pb) * 64 + le_r] +
+                   scr[25 * 64 + le_r] * scr[(6 + pa) * 64 + le_r] * scr[(18 + pb) * 64 + le_r];
+            if (fr == src && le_c >= 0)                           // block (i,j) = -w Ji Jj^T  (:302)
+              v -= scr[24 * 64 + le_c] * scr[(12 + pa) * 64 + le_c] * scr[pb * 64 + le_c] +
+                   scr[25 * 64 + le_c] * scr[(18 + pa) * 64 + le_c] * scr[(6 + pb) * 64 + le_c];
+          }
+          Sreg[blk] += v;
+        }
+      }
+    }
+    // ---- right-hand side rows lane, lane+64:  y = v - Q u e   (v_i -= w r Ji, v_j += w r Jj; :314-316, :512)
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const int r = lane + 64 * g;
+      const int f = min(r / 6, N - 1), a = r - 6 * (r / 6);
+      const int le = ftab_lookup(my_le, f);                       // shuffle while every lane is still active
+      if (r < n6) {
+        float v = -Q * usum * col[r];
+        if (le >= 0) v += scr[26 * 64 + le] * scr[a * 64 + le] + scr[27 * 64 + le] * scr[(6 + a) * 64 + le];
+        if (f == src)
+          for (int q = 0; q < m; q++) v -= scr[26 * 64 + q] * scr[(12 + a) * 64 + q] + scr[27 * 64 + q] * scr[(18 + a) * 64 + q];
+        yreg[g] += v;
+      }
+    }
+    wave_lds_sync();
+  }
+
+  // ---- add the 8 register copies into the LDS system, one wave at a time (fixed order)
+  __syncthreads();
+  for (int w = 0; w < REG_WAVES; w++) {
+    if (wave == w && N > 0) {
+      if (lane < 36) {
+        int blk = 0;
+#pragma unroll
+        for (int fr = 0; fr < NMAX; fr++) {
+#pragma unroll
+          for (int fc = 0; fc <= fr; fc++, blk++) {
+            if (fr < N && (fr != fc || pb <= pa)) S_lds[(6 * fr + pa) * LD + 6 * fc + pb] += Sreg[blk];
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 2; g++) if (lane + 64 * g < n6) y_lds[lane + 64 * g] += yreg[g];
+    }
+    __syncthreads();
+  }
+  if (N > 0) {
+    float* out = partials + (int64_t)blockIdx.x * (n6 * LD + n6);
+    for (int i = tid; i < n6 * LD + n6; i += REG_THREADS) out[i] = smem[i];
+  }
+}
+
 // S = sum of partial lower triangles, mirrored; S_dd <- S_dd*(1+1e-4)+1 (ba_cuda.cu:517-518); y = sum.
-__global__ void k_ba_reduce(const float* __restrict__ partials, int n_part, int N, float* __restrict__ S, float* __restrict__ y) {
+// 256-thread workgroups: wave g sums partials [g*n_part/4, (g+1)*n_part/4) for 64 consecutive outputs (coalesced,
+// 8 loads in flight), the four wave results are combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void k_ba_reduce(const float* __restrict__ partials, int n_part, int N, float* __restrict__ S,
+                                                   float* __restrict__ y) {
+  __shared__ float s_sum[4][64];
   const int n6 = 6 * N, LD = n6 + 1, stride = n6 * LD + n6;
   const int total = n6 * n6 + n6;
-  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += blockDim.x * gridDim.x) {
-    if (o < n6 * n6) {
-      int r = o / n6, c = o % n6;
-      int rr = max(r, c), cc = min(r, c);
-      float s = 0.0f;
-      for (int p = 0; p < n_part; p++) s += partials[(int64_t)p * stride + rr * LD + cc];
-      if (r == c) s = s + (1e-4f * s + 1.0f);
-      S[o] = s;
-    } else {
-      int r = o - n6 * n6;
-      float s = 0.0f;
-      for (int p = 0; p < n_part; p++) s += partials[(int64_t)p * stride + n6 * LD + r];
-      y[r] = s;
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + lane;
+  int r = 0, c = 1, src = 0;
+  if (o < total) {
+    if (o < n6 * n6) { r = o / n6; c = o % n6; src = max(r, c) * LD + min(r, c); }
+    else src = n6 * LD + (o - n6 * n6);
+  }
+  const int per = (n_part + 3) / 4;
+  const int p0 = g * per, p1 = min(n_part, p0 + per);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (o < total) {
+    const float* base = partials + src;
+    int p = p0;
+    for (; p + 8 <= p1; p += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc[u] += base[(int64_t)(p + u) * stride];
     }
+    for (; p < p1; p++) acc[(p - p0) & 7] += base[(int64_t)p * stride];
+  }
+  s_sum[g][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (g == 0 && o < total) {
+    float sum = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
+    if (o < n6 * n6) { if (r == c) sum = sum + (1e-4f * sum + 1.0f); S[o] = sum; }
+    else y[o - n6 * n6] = sum;
   }
 }
 
 // ------------------------------------------------------------------------------------------------- solve
 // One workgroup.  A (n6+1) x LD lower-triangular working matrix lives in LDS; row n6 holds y^T, so after the
-// factorisation row n6 is z = L^{-1} y.  Blocked by the 6x6 pose blocks.
-constexpr int SOLVE_THREADS = 256;
+// factorisation row n6 is z = L^{-1} y.  Blocked by the 6x6 pose blocks.  There is no serial section: every
+// thread that owns a panel row factors the 6x6 diagonal block itself, in registers, from the same LDS values
+// (broadcast reads) — cheaper than one lane doing it followed by a barrier.
+constexpr int SOLVE_THREADS = 1024;
+
+__device__ __forceinline__ bool chol6(float L[6][6], float inv[6]) {   // in-register lower Cholesky of a 6x6 block
+  bool ok = true;                                                      // inv[c] = 1 / L[c][c]
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    float d = L[c][c];
+#pragma unroll
+    for (int k = 0; k < c; k++) d -= L[c][k] * L[c][k];
+    if (!(d > 0.0f)) ok = false;
+    const float ld = sqrtf(d);
+    inv[c] = 1.0f / ld;
+    L[c][c] = ld;
+#pragma unroll
+    for (int a = c + 1; a < 6; a++) {
+      float v = L[a][c];
+#pragma unroll
+      for (int k = 0; k < c; k++) v -= L[a][k] * L[c][k];
+      L[a][c] = v * inv[c];
+    }
+  }
+  return ok;
+}
+
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restrict__ S, const float* __restrict__ y, int N,
                                                             float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag) {
   extern __shared__ __attribute__((aligned(16))) float A[];
   __shared__ int s_fail;
   const int n6 = 6 * N, LD = n6 + 1, rows = n6 + 1;
+  float* Ld = A + rows * LD;                    // [N][36] factored diagonal blocks
+  float* xs = Ld + N * 36;                      // [n6] solution
   const int tid = threadIdx.x;
   if (tid == 0) s_fail = 0;
   for (int i = tid; i < n6 * n6; i += SOLVE_THREADS) { int r = i / n6, c = i % n6; A[r * LD + c] = S[i]; }
@@ -350,60 +675,48 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
 
   for (int jb = 0; jb < N; jb++) {
     const int j0 = 6 * jb;
-    // (a) factor the 6x6 diagonal block (one lane; 6 dependent pivots)
-    if (tid == 0) {
+    const int r = j0 + 6 + tid;                  // this thread's panel row (if any)
+    if (r < rows || tid == 0) {
       float L[6][6];
 #pragma unroll
       for (int a = 0; a < 6; a++)
 #pragma unroll
         for (int c = 0; c <= a; c++) L[a][c] = A[(j0 + a) * LD + j0 + c];
-      bool ok = true;
+      float inv[6];
+      const bool ok = chol6(L, inv);
+      if (tid == 0) {
+        if (!ok) s_fail = 1;
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
-        float d = L[c][c];
+        for (int a = 0; a < 6; a++)
 #pragma unroll
-        for (int k = 0; k < c; k++) d -= L[c][k] * L[c][k];
-        if (!(d > 0.0f)) ok = false;
-        float ld = sqrtf(d), inv = 1.0f / ld;
-        L[c][c] = ld;
+          for (int c = 0; c <= a; c++) Ld[jb * 36 + a * 6 + c] = (a == c) ? inv[a] : L[a][c];      // diagonal stored as reciprocal
+      }
+      if (r < rows) {                            // panel:  x L_bb^T = A[r][block]
+        float x[6];
 #pragma unroll
-        for (int a = c + 1; a < 6; a++) {
-          float v = L[a][c];
+        for (int c = 0; c < 6; c++) {
+          float v = A[r * LD + j0 + c];
 #pragma unroll
-          for (int k = 0; k < c; k++) v -= L[a][k] * L[c][k];
-          L[a][c] = v * inv;
+          for (int k = 0; k < c; k++) v -= x[k] * L[c][k];
+          x[c] = v * inv[c];
         }
+#pragma unroll
+        for (int c = 0; c < 6; c++) A[r * LD + j0 + c] = x[c];
       }
-      if (!ok) s_fail = 1;
-#pragma unroll
-      for (int a = 0; a < 6; a++)
-#pragma unroll
-        for (int c = 0; c <= a; c++) A[(j0 + a) * LD + j0 + c] = L[a][c];
     }
     __syncthreads();
-    // (b) panel: every row below solves  x L_bb^T = A[row][block]
-    for (int r = j0 + 6 + tid; r < rows; r += SOLVE_THREADS) {
-      float x[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        float v = A[r * LD + j0 + c];
-#pragma unroll
-        for (int k = 0; k < c; k++) v -= x[k] * A[(j0 + c) * LD + j0 + k];
-        x[c] = v / A[(j0 + c) * LD + j0 + c];
-      }
-#pragma unroll
-      for (int c = 0; c < 6; c++) A[r * LD + j0 + c] = x[c];
-    }
-    __syncthreads();
-    // (c) trailing update of the lower triangle (and of the rhs row)
+    // trailing update of the lower triangle (and of the rhs row)
     const int rem = rows - (j0 + 6);
-    for (int idx = tid; idx < rem * rem; idx += SOLVE_THREADS) {
-      int r = j0 + 6 + idx / rem, c = j0 + 6 + idx % rem;
-      if (c > r || c >= n6) continue;
+    for (int idx = tid; idx < rem * (rem + 1) / 2; idx += SOLVE_THREADS) {      // lower triangle only
+      int tr = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+      while (tr * (tr + 1) / 2 > idx) tr--;
+      while ((tr + 1) * (tr + 2) / 2 <= idx) tr++;
+      const int rr = j0 + 6 + tr, cc = j0 + 6 + (idx - tr * (tr + 1) / 2);
+      if (cc >= n6) continue;
       float v = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 6; k++) v += A[r * LD + j0 + k] * A[c * LD + j0 + k];
-      A[r * LD + c] -= v;
+      for (int k = 0; k < 6; k++) v += A[rr * LD + j0 + k] * A[cc * LD + j0 + k];
+      A[rr * LD + cc] -= v;
     }
     __syncthreads();
   }
@@ -411,29 +724,32 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     if (tid == 0) { meta->fail = iter + 1; if (status_flag) *status_flag = iter + 1; }
     return;
   }
-  // back substitution  L^T x = z  (z = row n6), bottom-up by blocks; x overwrites z
+  // back substitution  L^T x = z  (z = row n6), bottom-up by blocks; every thread solves the 6x6 triangle itself
   float* z = A + n6 * LD;
   for (int jb = N - 1; jb >= 0; jb--) {
     const int j0 = 6 * jb;
+    float xb[6];
+#pragma unroll
+    for (int c = 5; c >= 0; c--) {
+      float v = z[j0 + c];
+#pragma unroll
+      for (int k = c + 1; k < 6; k++) v -= Ld[jb * 36 + k * 6 + c] * xb[k];
+      xb[c] = v * Ld[jb * 36 + c * 6 + c];
+    }
     if (tid == 0) {
 #pragma unroll
-      for (int c = 5; c >= 0; c--) {
-        float v = z[j0 + c];
-#pragma unroll
-        for (int k = c + 1; k < 6; k++) v -= A[(j0 + k) * LD + j0 + c] * z[j0 + k];
-        z[j0 + c] = v / A[(j0 + c) * LD + j0 + c];
-      }
+      for (int c = 0; c < 6; c++) xs[j0 + c] = xb[c];
     }
-    __syncthreads();
+    __syncthreads();                             // all reads of z[j0..j0+5] done before rows above are updated
     for (int r = tid; r < j0; r += SOLVE_THREADS) {
       float v = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 6; k++) v += A[(j0 + k) * LD + r] * z[j0 + k];
+      for (int k = 0; k < 6; k++) v += A[(j0 + k) * LD + r] * xb[k];
       z[r] -= v;
     }
     __syncthreads();
   }
-  for (int i = tid; i < n6; i += SOLVE_THREADS) dX[i] = z[i];
+  for (int i = tid; i < n6; i += SOLVE_THREADS) dX[i] = xs[i];
 }
 
 // ------------------------------------------------------------------------------------------------- retract
@@ -445,32 +761,34 @@ __global__ void k_ba_retract(float* __restrict__ poses, float* __restrict__ patc
                              int t0, int N) {
   if (meta->fail) return;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = blockDim.x * gridDim.x;
+  const int lane = threadIdx.x & 63, wave = gid >> 6, nwaves = gsz >> 6;
   const int n_seg = meta->n_seg;
-  for (int s = gid; s < n_seg; s += gsz) {
-    const float* rec = patch_rec + (int64_t)s * 2;
+  for (int s = wave; s < n_seg; s += nwaves) {                      // one wave per patch, lanes over its edges
     const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
-    float acc = rec[1];                                            // u
+    float part = 0.0f;
     if (N > 0) {
-      for (int q = 0; q < m; q++) {
+      for (int q = lane; q < m; q += 64) {
         const int e = perm[a0 + q];
         const int ix = (int)ii[e] - t0, jx = (int)jj[e] - t0;
         const float* er = edge_e + (int64_t)(a0 + q) * 12;
         if (jx >= 0 && jx < N) {
 #pragma unroll
-          for (int c = 0; c < 6; c++) acc -= er[c] * dX[6 * jx + c];
+          for (int c = 0; c < 6; c++) part += er[c] * dX[6 * jx + c];
         }
         if (ix >= 0 && ix < N) {
 #pragma unroll
-          for (int c = 0; c < 6; c++) acc -= er[6 + c] * dX[6 * ix + c];
+          for (int c = 0; c < 6; c++) part += er[6 + c] * dX[6 * ix + c];
         }
       }
+      part = wave_sum(part);
     }
-    const float dz = rec[0] * acc;                                 // Q (u - E^T dX)   (ba_cuda.cu:523)
+    const float dz = patch_rec[(int64_t)s * 2] * (patch_rec[(int64_t)s * 2 + 1] - part);   // Q (u - E^T dX)  (ba_cuda.cu:523)
     float* pd = patches + ((int64_t)kx[s] * 3 + 2) * P * P;
     float d = pd[0] + dz;                                          // reads pixel [0][0] (:198)
     d = (d > 20.0f) ? 1.0f : d;
     d = fmaxf(d, 1e-4f);
-    for (int i = 0; i < P * P; i++) pd[i] = d;
+    __builtin_amdgcn_wave_barrier();                               // every lane has read pd[0] before it is rewritten
+    for (int i = lane; i < P * P; i += 64) pd[i] = d;
   }
   for (int t = gid; t < N; t += gsz) {
     float* p = poses + (int64_t)(t0 + t) * 7;
@@ -599,7 +917,7 @@ static BaLayout ba_layout(int E, int Np, int N) {
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   L.max_seg = E < Np ? E : Np;
   if (L.max_seg < 1) L.max_seg = 1;
-  int want = (L.max_seg + ACC_WAVES - 1) / ACC_WAVES;
+  int want = (L.max_seg + REG_WAVES - 1) / REG_WAVES;
   L.n_part = want < ACC_MAX_WG ? (want < 1 ? 1 : want) : ACC_MAX_WG;
   const size_t n6 = 6 * (size_t)N;
   L.meta = take(sizeof(BaMeta));
@@ -662,41 +980,57 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
   float* edge_ej = (float*)(w + L.edge_ej);
 
   // ---- graph preparation: kx = unique(kk) sorted, ku = inverse (ba_cuda.cu:435-437), edges grouped by patch
-  // (meta, rank, counts, cursor are contiguous at the head of the workspace)
-  if (hipMemsetAsync(w + L.meta, 0, L.ku - L.meta, st) != hipSuccess) { set_error("devo_ba_forward: memset failed"); return DEVO_ERR_LAUNCH; }
   if (status_flag && hipMemsetAsync(status_flag, 0, sizeof(int), st) != hipSuccess) { set_error("devo_ba_forward: memset failed"); return DEVO_ERR_LAUNCH; }
-  const int eb = blocks_for(E, 256, 1024);
-  hipLaunchKernelGGL(k_flag_ids, dim3(eb), dim3(256), 0, st, kk, E, Np, rank);
-  hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, rank, Np, &meta->n_seg);
-  hipLaunchKernelGGL(k_rank_edges, dim3(blocks_for(E > Np ? E : Np, 256, 1024)), dim3(256), 0, st, kk, E, Np, rank, ku, kx, counts);
-  hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, counts, L.max_seg, (int*)nullptr);
-  hipLaunchKernelGGL(k_scatter_edges, dim3(eb), dim3(256), 0, st, ku, E, counts, cursor, perm_a);
-  hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, &meta->n_seg, perm_a, perm_b);
-  int rc = check_launch("devo_ba_forward(prepare)");
-  if (rc) return rc;
+  int rc;
+  const size_t prep_lds = sizeof(int) * (1024 + PREP_FLAGS_LDS + 1 + 2 * PREP_SEGS_LDS + 1 + 8);
+  static bool prep_attr = false;
+  if (!prep_attr) { (void)hipFuncSetAttribute((const void*)k_ba_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds); (void)hipGetLastError(); prep_attr = true; }
+  if (E <= (1 << 17)) {
+    hipLaunchKernelGGL(k_ba_prepare, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a);
+    hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, &meta->n_seg, perm_a, perm_b);
+  } else {
+    // (meta, rank, counts, cursor are contiguous at the head of the workspace)
+    if (hipMemsetAsync(w + L.meta, 0, L.ku - L.meta, st) != hipSuccess) { set_error("devo_ba_forward: memset failed"); return DEVO_ERR_LAUNCH; }
+    const int eb = blocks_for(E, 256, 1024);
+    hipLaunchKernelGGL(k_flag_ids, dim3(eb), dim3(256), 0, st, kk, E, Np, rank);
+    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, rank, Np, &meta->n_seg);
+    hipLaunchKernelGGL(k_rank_edges, dim3(blocks_for(E > Np ? E : Np, 256, 1024)), dim3(256), 0, st, kk, E, Np, rank, ku, kx, counts);
+    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, counts, L.max_seg, (int*)nullptr);
+    hipLaunchKernelGGL(k_scatter_edges, dim3(eb), dim3(256), 0, st, ku, E, counts, cursor, perm_a);
+    hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, &meta->n_seg, perm_a, perm_b);
+  }
+  if ((rc = check_launch("devo_ba_forward(prepare)"))) return rc;
 
   const size_t n6 = 6 * (size_t)N;
   const size_t acc_lds = sizeof(float) * (n6 * (n6 + 1) + n6 + ACC_WAVES * n6 + 4);
-  const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 4);
-  if (acc_lds > 64 * 1024 || solve_lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)k_ba_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds) != hipSuccess ||
+  const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 36 * (size_t)N + n6 + 4);
+  const int dbg = getenv("DEVO_BA_ABLATE") ? atoi(getenv("DEVO_BA_ABLATE")) : 0;
+  const bool use_reg = (N <= 16) && !(dbg & 8);
+  const size_t acc_lds_used = use_reg ? sizeof(float) * (n6 * (n6 + 1) + n6 + REG_WAVES * n6 + 4 + REG_WAVES * SCR_ROWS * 64) : acc_lds;
+  typedef void (*acc_fn_t)(const float*, const float*, const float*, const float*, const float*, const float*, const int64_t*,
+                           const int64_t*, const int64_t*, const int*, const int*, const BaMeta*, int, int, int, float*, float*,
+                           float*, int);
+  acc_fn_t acc_fn = k_ba_accumulate;
+  if (use_reg) acc_fn = (N <= 8) ? k_ba_accumulate_reg<8> : (N <= 11) ? k_ba_accumulate_reg<11> : (N <= 14) ? k_ba_accumulate_reg<14> : k_ba_accumulate_reg<16>;
+  if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds_used) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
       (void)hipGetLastError();
-      set_error("devo_ba_forward: cannot reserve %zu / %zu bytes of LDS", acc_lds, solve_lds);
+      set_error("devo_ba_forward: cannot reserve %zu / %zu bytes of LDS", acc_lds_used, solve_lds);
       return DEVO_ERR_LAUNCH;
     }
   }
   for (int it = 0; it < iterations; it++) {
-    hipLaunchKernelGGL(k_ba_accumulate, dim3(L.n_part), dim3(ACC_THREADS), acc_lds, st, poses, patches, intrinsics, target,
-                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej);
+    hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? REG_THREADS : ACC_THREADS), acc_lds_used, st, poses, patches, intrinsics, target,
+                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, dbg);
     if ((rc = check_launch("devo_ba_forward(accumulate)"))) return rc;
     if (N > 0) {
-      hipLaunchKernelGGL(k_ba_reduce, dim3(blocks_for((long long)(n6 * n6 + n6), 256, 256)), dim3(256), 0, st, partials, L.n_part, N, S, y);
+      hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((n6 * n6 + n6 + 63) / 64)), dim3(256), 0, st, partials, L.n_part, N, S, y);
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag);
       if ((rc = check_launch("devo_ba_forward(solve)"))) return rc;
     }
-    hipLaunchKernelGGL(k_ba_retract, dim3(blocks_for(L.max_seg > N ? L.max_seg : N, 256, 1024)), dim3(256), 0, st, poses, patches, dX, patch_rec,
+    hipLaunchKernelGGL(k_ba_retract, dim3(blocks_for((long long)L.max_seg * 64 > N ? (long long)L.max_seg * 64 : N, 256, 2048)), dim3(256), 0, st, poses, patches, dX, patch_rec,
                        edge_ej, jj, perm_b, counts, kx, ii, meta, P, t0, N);
     if ((rc = check_launch("devo_ba_forward(retract)"))) return rc;
   }

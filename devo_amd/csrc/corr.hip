@@ -11,6 +11,7 @@
 #include "common.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
+#include <vector>
 
 namespace devo {
 
@@ -69,12 +70,20 @@ __device__ __forceinline__ void corr_epilogue(const float* sraw, const float* sd
 
 // -------------------------------------------------------------------------------------------------
 // Fast path: fmap2 channels-last (channel stride 1), C % KC == 0.
-// ONE WAVE PER EDGE, no workgroup barriers.  A wave owns a private LDS tile holding, per KC-channel chunk,
-// the bounding box of the edge: NP*64 positions x KC channels (each lane owns NP positions, rows lane+64q).
-// The patch features f1[k][0..8] are wave-uniform: they are fetched with scalar loads one 4-channel step
-// ahead of their use and enter the FMAs as SGPR operands (no LDS bandwidth, no VALU slots).
+// ONE WAVE PER EDGE, no workgroup barriers, TAP-centric: lane t owns window tap (a, c) = (t / D, t % D) of every
+// one of the 9 patch pixels (D = 2r+2 = 8 -> exactly one wave of taps; r = 5 -> 144 taps, NG = 3 per lane) and
+// keeps 9 accumulators.  Per KC-channel chunk the wave stages
+//   * the union bounding box of the 9 windows (<= TILEPOS positions x KC channels, coalesced 16-byte loads issued
+//     one chunk ahead) and
+//   * the patch features of the chunk, transposed to [pixel][KC],
+// into its private LDS tile.  For pixel p a lane reads ITS tap's position of the box (ds_read_b128 = 4 channels)
+// and issues 4 FMAs whose patch operand f1[k][p] is broadcast INSIDE the instruction from lane p of the same
+// 16-lane row (DPP row_newbcast:p): no scalar-memory latency in the loop, no broadcast LDS reads, no wasted
+// multiply-adds (exactly the 9 * D^2 * C products the lookup needs).
+// Boxes that do not fit the tile (patch pixels spread apart) stage the 9 windows one after the other.
 // -------------------------------------------------------------------------------------------------
-constexpr int WPB = 2;                      // waves (edges) per workgroup
+constexpr int WPB = 1;                      // waves (edges) per workgroup
+constexpr int F1ROW = KC + 4;               // row stride of the transposed patch chunk
 
 __device__ __forceinline__ void wave_lds_fence() {
   // a wave's LDS instructions execute in order; this only pins the compiler's ordering
@@ -82,15 +91,39 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <typename T, int NP>
+// 12 FMAs: three pixels (P0, P0+1, P0+2) x four channels.  acc_i += f1[k+u][P0+i] * v_i[u]; w[u] holds
+// f1[k+u][lane & 15], read through DPP from lane P0+i of the row.  The three accumulators are interleaved so that
+// consecutive instructions are independent.
+#define DEVO_FMA_LINE(ACC, W, V, P) "v_fmac_f32_dpp " ACC ", " W ", " V " row_newbcast:" #P " row_mask:0xf bank_mask:0xf\n"
+#define DEVO_FMA_TRIPLE(P0, P1, P2)                                                                    \
+  asm("s_nop 1\n" /* VALU-written VGPR -> DPP read needs 2 wait states; hipcc does not pad inside asm */ \
+      DEVO_FMA_LINE("%0", "%3", "%7", P0) DEVO_FMA_LINE("%1", "%3", "%11", P1) DEVO_FMA_LINE("%2", "%3", "%15", P2) \
+      DEVO_FMA_LINE("%0", "%4", "%8", P0) DEVO_FMA_LINE("%1", "%4", "%12", P1) DEVO_FMA_LINE("%2", "%4", "%16", P2) \
+      DEVO_FMA_LINE("%0", "%5", "%9", P0) DEVO_FMA_LINE("%1", "%5", "%13", P1) DEVO_FMA_LINE("%2", "%5", "%17", P2) \
+      DEVO_FMA_LINE("%0", "%6", "%10", P0) DEVO_FMA_LINE("%1", "%6", "%14", P1) DEVO_FMA_LINE("%2", "%6", "%18", P2) \
+      : "+v"(a0), "+v"(a1), "+v"(a2)                                                                    \
+      : "v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w), "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y),    \
+        "v"(v1.z), "v"(v1.w), "v"(v2.x), "v"(v2.y), "v"(v2.z), "v"(v2.w))
+
+__device__ __forceinline__ void fma_px012(float& a0, float& a1, float& a2, float4 w, float4 v0, float4 v1, float4 v2) { DEVO_FMA_TRIPLE(0, 1, 2); }
+__device__ __forceinline__ void fma_px345(float& a0, float& a1, float& a2, float4 w, float4 v0, float4 v1, float4 v2) { DEVO_FMA_TRIPLE(3, 4, 5); }
+__device__ __forceinline__ void fma_px678(float& a0, float& a1, float& a2, float4 w, float4 v0, float4 v1, float4 v2) { DEVO_FMA_TRIPLE(6, 7, 8); }
+
+template <typename T, int NG, int RMAX>
 __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     const T* __restrict__ fmap1, const T* __restrict__ fmap2, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int H2, int W2, int64_t s_b, int64_t s_n, int64_t s_h, int64_t s_w, int64_t out_estride,
-    int64_t out_lstride, int64_t out_offset, int R, const int* __restrict__ order) {
-  constexpr int F2_FLOATS = NP * 64 * ROWPAD;          // box tile
-  constexpr int WAVE_FLOATS = F2_FLOATS;
-  static_assert(F2_FLOATS >= PP * MAXD * MAXD, "raw windows must fit in the box tile");
+    int64_t out_lstride, int64_t out_offset, int R, const int* __restrict__ order, unsigned long long* __restrict__ trace) {
+  constexpr int TILEPOS = (NG == 1) ? 128 : 256;       // box positions staged per chunk (loads per lane = TILEPOS * PARTS / 64)
+  constexpr int TILE_SLOTS = (NG == 1) ? 704 : 1408;   // 16-byte slots of the box tile
+  constexpr int F2_FLOATS = TILE_SLOTS * 4;            // box tile
+  constexpr int F1_FLOATS = PP * F1ROW;                // transposed patch chunk
+  constexpr int DMAX = 2 * RMAX + 2;
+  constexpr int RW_FLOATS = (PP * (DMAX * DMAX + 1) + 3) / 4 * 4;   // the 9 raw windows [p][a][c], row stride D*D+1
+  constexpr int WAVE_FLOATS = F2_FLOATS + F1_FLOATS + RW_FLOATS;
+  static_assert(NG * 64 >= DMAX * DMAX && TILEPOS >= NG * 64, "tap groups must cover the window");
+  static_assert(ROWPAD == 20, "slot arithmetic below assumes 5 slots (20 floats) per position");
   __shared__ __attribute__((aligned(16))) float s_tile[WPB * WAVE_FLOATS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -101,9 +134,12 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
   const int vwg = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
   const int slot = vwg * WPB + wave;
   if (slot >= BE) return;                                   // wave-uniform; no barriers in this kernel
+  const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ULL;
   const int be = order ? order[slot] : slot;
   float* tile = s_tile + wave * WAVE_FLOATS;
-  const int D = 2 * R + 2;
+  float* f1t = tile + F2_FLOATS;
+  float* rawwin = f1t + F1_FLOATS;
+  const int D = 2 * R + 2, ntap = D * D;
   const int b = be / E, e = be - b * E;
 
   // ---- geometry: lane p (< 9) owns patch pixel p
@@ -123,8 +159,13 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     xmin = min(xmin, ox[p]); xmax = max(xmax, ox[p]);
     ymin = min(ymin, oy[p]); ymax = max(ymax, oy[p]);
   }
-  const int bw = xmax - xmin + D, bh = ymax - ymin + D;
-  const long long npos_ll = (long long)bw * bh;
+  const long long npos_ll = (long long)(xmax - xmin + D) * (ymax - ymin + D);
+  // Box row pitch in 16-byte slots: the smallest value >= 5*bw that is = 8 (mod 16).  With 5 slots per position
+  // this makes the tap-centric ds_read_b128 pattern (lane groups {0-3,12-15,20-27}, ... = 4 window rows x 4 taps)
+  // bank-conflict free for every box width.
+  auto pitch_of = [](int w) -> int { const int s = 5 * w; return s + ((8 - s) & 15); };
+  auto fits = [&](int w, int h) -> bool { return (long long)w * h <= TILEPOS && (long long)h * pitch_of(w) <= TILE_SLOTS; };
+  const bool whole = (npos_ll <= TILEPOS) && fits(xmax - xmin + D, ymax - ymin + D);   // the union box fits the tile (the usual case)
 
   const int64_t pi = ii[e];
   const int64_t fj = jj[e];
@@ -132,126 +173,166 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
   const T* __restrict__ f2 = fmap2 + (int64_t)b * s_b + fj * s_n;
   T* outp = out + (int64_t)be * out_estride + out_offset;
 
-  if (npos_ll <= NP * 64) {
-    const int npos = (int)npos_ll;
-    float acc[NP][PP];
+  constexpr int VEC = 16 / sizeof(T);            // elements per 16-byte load
+  constexpr int PARTS = KC / VEC;                // 16-byte loads per position
+  constexpr int ITERS = TILEPOS * PARTS / 64;    // 16-byte loads per lane to fill the tile
+  constexpr int F1N = (KC * PP + 63) / 64;       // patch-chunk elements per lane (144 -> 3)
+  // patch chunk: element el = lane + 64 j of the [KC][9] block goes to f1t[el % 9][el / 9]
+  int f1dst[F1N];
 #pragma unroll
-    for (int q = 0; q < NP; q++)
-#pragma unroll
-      for (int p = 0; p < PP; p++) acc[q][p] = 0.0f;
+  for (int j = 0; j < F1N; j++) { const int el = lane + 64 * j; f1dst[j] = (el < KC * PP) ? (el % PP) * F1ROW + el / PP : -1; }
+  const float* wrow = f1t + min(lane & 15, PP - 1) * F1ROW;        // this lane's patch pixel (lanes 9..15 of a row unused)
 
-    constexpr int VEC = 16 / sizeof(T);            // elements per 16-byte load
-    constexpr int PARTS = KC / VEC;                // 16-byte loads per position
-    constexpr int ITERS = NP * PARTS;              // NP*64 positions * PARTS loads / 64 lanes
-    // per-lane source offsets of the ITERS loads of one chunk (position = q / PARTS, part = q % PARTS)
+  // this lane's taps
+  int ta[NG], tc[NG];
+#pragma unroll
+  for (int g = 0; g < NG; g++) { const int t = min(lane + 64 * g, ntap - 1); ta[g] = t / D; tc[g] = t - ta[g] * D; }
+
+  float acc[NG][PP];
+#pragma unroll
+  for (int g = 0; g < NG; g++)
+#pragma unroll
+    for (int p = 0; p < PP; p++) acc[g][p] = 0.0f;
+
+  // One "stage" = one box staged chunk by chunk.  Modes: the union box of all 9 pixels (1 stage, the usual case);
+  // if that does not fit the tile, the three pixel rows {0,1,2} {3,4,5} {6,7,8} one after the other (3 stages);
+  // if even a row's box is too large, the 9 windows one by one (9 stages).
+  int txmin[3], txmax[3], tymin[3], tymax[3];
+  bool rows_fit = true;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    txmin[t] = min(ox[3 * t], min(ox[3 * t + 1], ox[3 * t + 2])); txmax[t] = max(ox[3 * t], max(ox[3 * t + 1], ox[3 * t + 2]));
+    tymin[t] = min(oy[3 * t], min(oy[3 * t + 1], oy[3 * t + 2])); tymax[t] = max(oy[3 * t], max(oy[3 * t + 1], oy[3 * t + 2]));
+    rows_fit = rows_fit && ((long long)(txmax[t] - txmin[t] + D) * (tymax[t] - tymin[t] + D) <= TILEPOS) &&
+               fits(txmax[t] - txmin[t] + D, tymax[t] - tymin[t] + D);
+  }
+  const int mode = whole ? 0 : (rows_fit ? 1 : 2);
+  const int nstage = (mode == 0) ? 1 : (mode == 1 ? 3 : PP);
+  for (int sp = 0; sp < nstage; sp++) {
+    int bx0, by0, bw, npos;
+    if (mode == 0) { bx0 = xmin; by0 = ymin; bw = xmax - xmin + D; npos = (int)npos_ll; }
+    else if (mode == 1) {
+      bx0 = sp == 0 ? txmin[0] : (sp == 1 ? txmin[1] : txmin[2]);
+      by0 = sp == 0 ? tymin[0] : (sp == 1 ? tymin[1] : tymin[2]);
+      const int bx1 = sp == 0 ? txmax[0] : (sp == 1 ? txmax[1] : txmax[2]);
+      const int by1 = sp == 0 ? tymax[0] : (sp == 1 ? tymax[1] : tymax[2]);
+      bw = bx1 - bx0 + D; npos = bw * (by1 - by0 + D);
+    } else { bx0 = __builtin_amdgcn_readlane(my_ox, sp); by0 = __builtin_amdgcn_readlane(my_oy, sp); bw = D; npos = ntap; }
+    const int PT = pitch_of(bw);
+    // LDS offset (in floats) of this lane's tap for every pixel (only the pixels of this stage are used)
+    int rowoff[NG][PP];
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+      for (int p = 0; p < PP; p++)
+        rowoff[g][p] = (mode != 2) ? ((oy[p] - by0 + ta[g]) * PT + 5 * (ox[p] - bx0 + tc[g])) * 4 : (ta[g] * PT + 5 * tc[g]) * 4;
+
     int64_t soff[ITERS];
+    int sdst[ITERS];                                // LDS destination (floats) of each staged 16-byte piece; -1 = none
     bool sok[ITERS];
+    {
+      // position of load `it` = (lane + 64*it) / PARTS: one division, then steps of 64/PARTS positions with carry
+      constexpr int STEP = 64 / PARTS;
+      const int part = lane % PARTS;
+      int pos = lane / PARTS;
+      int pyy = pos / bw, pxx = pos - pyy * bw;
 #pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-      const int q = lane + it * 64;
-      const int pos = q / PARTS, part = q - pos * PARTS;
-      const int gy = ymin + pos / bw, gx = xmin + (pos % bw);
-      sok[it] = (pos < npos) && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
-      soff[it] = (int64_t)gy * s_h + (int64_t)gx * s_w + part * VEC;
+      for (int it = 0; it < ITERS; it++) {
+        const int gy = by0 + pyy, gx = bx0 + pxx;
+        sdst[it] = (pos < npos) ? (pyy * PT + 5 * pxx) * 4 + part * VEC : -1;
+        sok[it] = (pos < npos) && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
+        soff[it] = (int64_t)gy * s_h + (int64_t)gx * s_w + part * VEC;
+        pos += STEP; pxx += STEP;
+        while (pxx >= bw) { pxx -= bw; pyy++; }
+      }
     }
-    // f1 operands: wave-uniform scalar loads, software-pipelined one 4-channel step ahead
-    float wn[4 * PP];
-#pragma unroll
-    for (int u = 0; u < 4 * PP; u++) wn[u] = to_f32<T>(f1[u]);
-    // box chunk: global -> registers one whole chunk ahead of its use (the loads fly under the FMAs)
+    // ---- global -> registers one whole chunk ahead of its use (the loads fly under the FMAs)
     uint4 raw[ITERS];
+    T raw1[F1N];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
       raw[it] = make_uint4(0, 0, 0, 0);
       if (sok[it]) raw[it] = *reinterpret_cast<const uint4*>(f2 + soff[it]);
     }
+#pragma unroll
+    for (int j = 0; j < F1N; j++) raw1[j] = (f1dst[j] >= 0) ? f1[lane + 64 * j] : from_f32<T>(0.0f);
+
     for (int kc = 0; kc < C; kc += KC) {
       wave_lds_fence();                            // previous chunk's reads are done before the tile is overwritten
       // ---- registers -> LDS (as fp32)
 #pragma unroll
       for (int it = 0; it < ITERS; it++) {
-        const int q = lane + it * 64;
-        const int pos = q / PARTS, part = q - pos * PARTS;
-        const T* rv = reinterpret_cast<const T*>(&raw[it]);
-        float* dst = tile + pos * ROWPAD + part * VEC;
+        if (sdst[it] >= 0) {
+          const T* rv = reinterpret_cast<const T*>(&raw[it]);
+          float* dst = tile + sdst[it];
 #pragma unroll
-        for (int u = 0; u < VEC; u += 4)
-          *reinterpret_cast<float4*>(dst + u) =
-              make_float4(to_f32<T>(rv[u]), to_f32<T>(rv[u + 1]), to_f32<T>(rv[u + 2]), to_f32<T>(rv[u + 3]));
+          for (int u = 0; u < VEC; u += 4)
+            *reinterpret_cast<float4*>(dst + u) =
+                make_float4(to_f32<T>(rv[u]), to_f32<T>(rv[u + 1]), to_f32<T>(rv[u + 2]), to_f32<T>(rv[u + 3]));
+        }
       }
+#pragma unroll
+      for (int j = 0; j < F1N; j++) if (f1dst[j] >= 0) f1t[f1dst[j]] = to_f32<T>(raw1[j]);
       wave_lds_fence();
       if (kc + KC < C) {
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
           if (sok[it]) raw[it] = *reinterpret_cast<const uint4*>(f2 + soff[it] + kc + KC);
         }
+#pragma unroll
+        for (int j = 0; j < F1N; j++) if (f1dst[j] >= 0) raw1[j] = f1[(int64_t)(kc + KC) * PP + lane + 64 * j];
       }
-      // ---- NP x 9 accumulators per lane, 4 channels per step
-      float4 vn[NP];
+      // ---- 9 accumulators per tap, 4 channels per step
+      if (mode != 2) {
+        const bool t0 = (mode == 0) || sp == 0, t1 = (mode == 0) || sp == 1, t2 = (mode == 0) || sp == 2;   // uniform
+#pragma unroll 4
+        for (int k = 0; k < KC; k += 4) {
+          const float4 w = *reinterpret_cast<const float4*>(wrow + k);
 #pragma unroll
-      for (int q = 0; q < NP; q++) vn[q] = *reinterpret_cast<const float4*>(tile + (lane + 64 * q) * ROWPAD);
-#pragma unroll
-      for (int k = 0; k < KC; k += 4) {
-        float w[4 * PP];
-        float4 v[NP];
-#pragma unroll
-        for (int u = 0; u < 4 * PP; u++) w[u] = wn[u];
-#pragma unroll
-        for (int q = 0; q < NP; q++) v[q] = vn[q];
-        // prefetch the next step's operands (next chunk's first step wraps to the start of the tile only for
-        // the f1 side; the box side is re-read after the next staging)
-        {
-          const int kn = kc + k + 4;
-          const T* wsrc = f1 + (int64_t)(kn < C ? kn : 0) * PP;
-#pragma unroll
-          for (int u = 0; u < 4 * PP; u++) wn[u] = to_f32<T>(wsrc[u]);
-          if (k + 4 < KC) {
-#pragma unroll
-            for (int q = 0; q < NP; q++) vn[q] = *reinterpret_cast<const float4*>(tile + (lane + 64 * q) * ROWPAD + k + 4);
+          for (int g = 0; g < NG; g++) {
+            if (t0) {
+              const float4 v0 = *reinterpret_cast<const float4*>(tile + rowoff[g][0] + k);
+              const float4 v1 = *reinterpret_cast<const float4*>(tile + rowoff[g][1] + k);
+              const float4 v2 = *reinterpret_cast<const float4*>(tile + rowoff[g][2] + k);
+              fma_px012(acc[g][0], acc[g][1], acc[g][2], w, v0, v1, v2);
+            }
+            if (t1) {
+              const float4 v3 = *reinterpret_cast<const float4*>(tile + rowoff[g][3] + k);
+              const float4 v4 = *reinterpret_cast<const float4*>(tile + rowoff[g][4] + k);
+              const float4 v5 = *reinterpret_cast<const float4*>(tile + rowoff[g][5] + k);
+              fma_px345(acc[g][3], acc[g][4], acc[g][5], w, v3, v4, v5);
+            }
+            if (t2) {
+              const float4 v6 = *reinterpret_cast<const float4*>(tile + rowoff[g][6] + k);
+              const float4 v7 = *reinterpret_cast<const float4*>(tile + rowoff[g][7] + k);
+              const float4 v8 = *reinterpret_cast<const float4*>(tile + rowoff[g][8] + k);
+              fma_px678(acc[g][6], acc[g][7], acc[g][8], w, v6, v7, v8);
+            }
           }
         }
+      } else {
+        // one pixel per stage: its patch operand is fetched from lane sp of the row with a shuffle (rare path)
 #pragma unroll
-        for (int q = 0; q < NP; q++) {
+        for (int k = 0; k < KC; k += 4) {
+          const float4 w = *reinterpret_cast<const float4*>(wrow + k);
+          const float wx = __shfl(w.x, sp), wy = __shfl(w.y, sp), wz = __shfl(w.z, sp), ww = __shfl(w.w, sp);
 #pragma unroll
-          for (int p = 0; p < PP; p++) {
-            acc[q][p] = fmaf(w[p], v[q].x, acc[q][p]);
-            acc[q][p] = fmaf(w[PP + p], v[q].y, acc[q][p]);
-            acc[q][p] = fmaf(w[2 * PP + p], v[q].z, acc[q][p]);
-            acc[q][p] = fmaf(w[3 * PP + p], v[q].w, acc[q][p]);
+          for (int g = 0; g < NG; g++) {
+            const float4 v = *reinterpret_cast<const float4*>(tile + rowoff[g][0] + k);
+            const float s = fmaf(ww, v.w, fmaf(wz, v.z, fmaf(wy, v.y, wx * v.x)));
+#pragma unroll
+            for (int p = 0; p < PP; p++) acc[g][p] += (p == sp) ? s : 0.0f;
           }
         }
       }
     }
-    // ---- the tile is free now: scatter every position's 9 sums into the per-pixel raw windows [p][a][c]
-    wave_lds_fence();
-    for (int i = lane; i < PP * D * D; i += 64) tile[i] = 0.0f;
-    wave_lds_fence();
+  }
+  // ---- raw windows [p][a][c] (row stride D*D+1: conflict-free epilogue reads)
 #pragma unroll
-    for (int q = 0; q < NP; q++) {
-      const int mypos = q * 64 + lane;
-      if (mypos < npos) {
-        const int gy = ymin + mypos / bw, gx = xmin + (mypos % bw);
+  for (int g = 0; g < NG; g++) {
+    if (lane + 64 * g < ntap) {
 #pragma unroll
-        for (int p = 0; p < PP; p++) {
-          const int a = gy - oy[p], c = gx - ox[p];
-          if (a >= 0 && a < D && c >= 0 && c < D) tile[p * D * D + a * D + c] = acc[q][p];
-        }
-      }
-    }
-  } else {
-    // ---- patch pixels spread far apart: evaluate the 9 windows one tap at a time (rare)
-    for (int o = lane; o < PP * D * D; o += 64) {
-      const int p = o / (D * D), a = (o / D) % D, c = o % D;
-      int oxp = ox[0], oyp = oy[0];
-#pragma unroll
-      for (int q = 1; q < PP; q++) { if (p == q) { oxp = ox[q]; oyp = oy[q]; } }
-      const int gy = oyp + a, gx = oxp + c;
-      float s = 0.0f;
-      if (gy >= 0 && gy < H2 && gx >= 0 && gx < W2) {
-        const T* src = f2 + (int64_t)gy * s_h + (int64_t)gx * s_w;
-        for (int k = 0; k < C; k++) s = fmaf(to_f32<T>(f1[k * PP + p]), to_f32<T>(src[k]), s);
-      }
-      tile[o] = s;
+      for (int p = 0; p < PP; p++) rawwin[p * (D * D + 1) + ta[g] * D + tc[g]] = acc[g][p];
     }
   }
   wave_lds_fence();
@@ -265,9 +346,13 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     const int c = l / (PP * Dm);       // x offset  (logical dim 2: permute(0,1,3,2,4,5))
     const float dxp = __shfl(my_dx, p), dyp = __shfl(my_dy, p);
     if (l < total) {
-      const float* r = tile + p * D * D + a * D + c;
+      const float* r = rawwin + p * (D * D + 1) + a * D + c;
       outp[(int64_t)l * out_lstride] = from_f32<T>(blend4(dxp, dyp, r[0], r[1], r[D], r[D + 1]));
     }
+  }
+  if (trace && lane == 0) {                          // debug: per-wave (start, end, box size, hw id)
+    unsigned long long* t = trace + (size_t)slot * 4;
+    t[0] = t_start; t[1] = __builtin_readcyclecounter(); t[2] = (unsigned long long)npos_ll; t[3] = blockIdx.x;
   }
 }
 
@@ -486,17 +571,38 @@ static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* co
                            hipStream_t st) {
   const bool cl = (f2s[2] == 1) && (C % KC == 0) && (f2s[3] % (16 / sizeof(T)) == 0) && (f2s[4] % (16 / sizeof(T)) == 0) &&
                   (f2s[0] % (16 / sizeof(T)) == 0) && (f2s[1] % (16 / sizeof(T)) == 0) &&
-                  ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) && ((reinterpret_cast<uintptr_t>(fmap1) & 15) == 0) && sizeof(T) <= 4;
+                  ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) && sizeof(T) <= 4;
   const long long BE = (long long)B * E;
   if (cl) {
     dim3 grid((unsigned)((BE + WPB - 1) / WPB)), block(WPB * 64);
-    static const bool force4 = getenv("DEVO_CORR_NP4") != nullptr;      // debug switch
-    if (R <= 3 && !force4)
-      hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 2>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
-                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order);
+    static const bool force4 = getenv("DEVO_CORR_NP4") != nullptr;      // debug switch: run the r > 3 instantiation
+    unsigned long long* trace = nullptr;                                // debug switch: per-wave cycle stamps to stderr
+    const bool do_trace = getenv("DEVO_CORR_TRACE") != nullptr;
+    if (do_trace) { (void)hipMalloc(&trace, (size_t)BE * 32); (void)hipMemset(trace, 0, (size_t)BE * 32); }
+    if (R <= 3 && !force4)   // (the <4,5> instantiation has room for every supported radius)
+      hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 1, 3>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
+                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace);
     else
-      hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 4>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
-                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order);
+      hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 3, 5>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
+                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace);
+    if (do_trace) {
+      (void)hipDeviceSynchronize();
+      std::vector<unsigned long long> h((size_t)BE * 4);
+      (void)hipMemcpy(h.data(), trace, (size_t)BE * 32, hipMemcpyDeviceToHost);
+      unsigned long long t0 = ~0ULL, t1 = 0; double sum = 0, mx = 0, sum_small = 0; long n_small = 0, n_big = 0; double sum_big = 0;
+      for (long long i = 0; i < BE; i++) {
+        const unsigned long long* t = &h[i * 4];
+        if (!t[1]) continue;
+        if (t[0] < t0) t0 = t[0];
+        if (t[1] > t1) t1 = t[1];
+        const double d = (double)(t[1] - t[0]);
+        sum += d; if (d > mx) mx = d;
+        if (t[2] <= 128) { sum_small += d; n_small++; } else { sum_big += d; n_big++; }
+      }
+      fprintf(stderr, "[corr trace] span %.0f ticks; wave mean %.0f max %.0f; box<=128: n %ld mean %.0f; box>128: n %ld mean %.0f; sum/span = %.1f waves in flight\n",
+              (double)(t1 - t0), sum / BE, mx, n_small, n_small ? sum_small / n_small : 0.0, n_big, n_big ? sum_big / n_big : 0.0, sum / (double)(t1 - t0));
+      (void)hipFree(trace);
+    }
   } else {
     dim3 grid((unsigned)BE), block(NT);
     hipLaunchKernelGGL(corr_fwd_generic_kernel<T>, grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii,

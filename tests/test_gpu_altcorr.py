@@ -142,3 +142,41 @@ def test_patchify():
     y.sum().backward()
     assert torch.isfinite(x.grad).all()
     assert torch.equal(cuda_corr.patchify_forward(net.to(DEV).half(), coords.to(DEV), 1)[0].cpu(), A.patchify_forward(net.half(), coords, 1))
+
+
+def test_batch_of_two_and_plan_independence():
+    """B = 2 (the reference kernels index coords[n][m]...), and: the locality plan only reorders work."""
+    from devo_amd.backends import cuda_corr
+    g = torch.Generator().manual_seed(31)
+    B, E, Np, n, C, H, W, R = 2, 300, 10, 3, 32, 24, 32, 3
+    f1 = torch.randn(B, Np, C, 3, 3, generator=g)
+    f2 = torch.randn(B, n, C, H, W, generator=g)
+    coords = torch.rand(B, E, 2, 3, 3, generator=g) * torch.tensor([W + 6.0, H + 6.0]).view(1, 1, 2, 1, 1) - 3.0
+    ii = torch.randint(0, Np, (E,), generator=g)
+    jj = torch.randint(0, n, (E,), generator=g)
+    ref = A.corr_forward(f1, f2, coords, ii, jj, R)
+    f2d = channels_last5(f2.to(DEV))
+    args = (f1.to(DEV), f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV))
+    out_auto, = cuda_corr.forward(*args, R)                       # B*E < PLAN_MIN_EDGES: list order
+    assert_rel(out_auto, ref, 1e-4, "B=2")
+    plan = cuda_corr.plan(args[2], args[4], n, H)
+    assert sorted(plan.cpu().tolist()) == list(range(B * E))      # a permutation of the edge slots
+    out_plan = torch.empty_like(out_auto)
+    cuda_corr.forward_into(out_plan, *args, R, 7 * 7 * 9, 1, 0, order=plan)
+    assert torch.equal(out_plan, out_auto)                        # bit-identical with and without the plan
+
+
+def test_rejects_bad_arguments():
+    from devo_amd.backends import cuda_corr
+    f1 = torch.zeros(1, 2, 16, 3, 3, device=DEV)
+    f2 = torch.zeros(1, 2, 16, 8, 8, device=DEV)
+    c = torch.zeros(1, 4, 2, 3, 3, device=DEV)
+    i = torch.zeros(4, dtype=torch.long, device=DEV)
+    with pytest.raises(RuntimeError):
+        cuda_corr.forward(f1, f2, c, i, i, 6)                     # radius > 5
+    with pytest.raises(RuntimeError):
+        cuda_corr.forward(f1, f2.half(), c, i, i, 3)              # dtype mismatch
+    with pytest.raises(RuntimeError):
+        cuda_corr.forward(f1, f2, torch.zeros(1, 4, 2, 2, 2, device=DEV), i, i, 3)   # patch size != 3
+    out, = cuda_corr.forward(f1, f2, c[:, :0], i[:0], i[:0], 3)   # empty edge list
+    assert out.shape == (1, 0, 7, 7, 3, 3)

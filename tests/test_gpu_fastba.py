@@ -152,3 +152,31 @@ def test_transform_golden(golden_dir):
     assert torch.equal(v.cpu(), g["valid"].float())
     assert_rel(Ji, g["Ji"], 1e-4, "Ji"); assert_rel(Jj, g["Jj"], 1e-4, "Jj"); assert_rel(Jz, g["Jz"], 1e-4, "Jz")
     assert_rel(fm, g["flow_mag"], 1e-4, "flow_mag")
+
+
+def test_ba_empty_and_limits():
+    from devo_amd.backends import cuda_ba
+    s = scene()
+    d = lambda t: t.to(DEV)
+    P, Q = d(s[0]).clone(), d(s[1]).clone()
+    e = torch.zeros(0, dtype=torch.long, device=DEV)
+    assert cuda_ba.forward(P, Q, d(s[2]), d(s[3])[:, :0], d(s[4])[:, :0], torch.tensor([1e-4], device=DEV), e, e, e, 1, 8, 2) == []
+    assert torch.equal(P.cpu(), s[0]) and torch.equal(Q.cpu(), s[1])          # no edges: nothing moves
+    with pytest.raises(RuntimeError):                                           # more than 32 optimised poses
+        big = torch.zeros(1, 40, 7, device=DEV); big[..., 6] = 1
+        cuda_ba.forward(big, Q, d(s[2]), d(s[3]), d(s[4]), torch.tensor([1e-4], device=DEV), d(s[5]), d(s[6]), d(s[7]), 1, 40, 1)
+
+
+def test_ba_failure_flag_on_breakdown():
+    """NaN weights make the Cholesky pivot test fail: like the reference's exception (devo.py:336-340) the call
+    leaves poses / patches untouched, and reports it through the device status flag."""
+    from devo_amd.backends import cuda_ba
+    s = scene()
+    d = lambda t: t.to(DEV)
+    P, Q = d(s[0]).clone(), d(s[1]).clone()
+    w = d(s[4]).clone()
+    w[0, 0, 0] = float("nan")
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    cuda_ba.forward(P, Q, d(s[2]), d(s[3]), w, torch.tensor([1e-4], device=DEV), d(s[5]), d(s[6]), d(s[7]), 1, 8, 2, status=status)
+    assert int(status.item()) == 1
+    assert torch.equal(P.cpu(), s[0]) and torch.equal(Q.cpu(), s[1])

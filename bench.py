@@ -173,6 +173,16 @@ def main():
     torch.cuda.synchronize()
     t_ba_gpu = ev0.elapsed_time(ev1) * 1e-3 / 20
 
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(f"{args.workload}/{args.dtype}/{args.layout}")
+        if rec:
+            traffic = int((2.0 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024)
+            traffic_src = f"profiles/pmc_traffic.json ({rec['round']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x read correction)"
+    except (OSError, ValueError, KeyError):
+        pass
+
     out = {
         "metric": "update-op iterations/sec (altcorr+fastba) at 96 patches, N=15 keyframes",
         "value": round(value, 2), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,7 +193,7 @@ def main():
                                f"pyramid layout {args.layout}, {'HIP graph' if not args.no_graph else 'eager'}",
                    "parallelism": f"replicas x{world}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "corr_fwd_cl_kernel" if args.layout == "cl" else "corr_fwd_generic_kernel",
                      "alg_bytes_per_launch": int(b_alg), "us_per_launch": round(t_launch * 1e6, 2)},
         "ba": {"gpu_ms": round(t_ba_gpu * 1e3, 4)},

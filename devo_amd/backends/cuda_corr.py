@@ -22,16 +22,16 @@ def _prep(fmap1, fmap2, coords, ii, jj):
 PLAN_MIN_EDGES = 2048      # below this the lookup is launch-bound and a locality plan cannot pay for itself
 
 
-def plan(coords, jj, n_frames, height, coord_scale=1.0):
+def plan(coords, jj, n_frames, height, coord_scale=1.0, radius=3):
     """Locality plan (devo_corr_order): edge slots sorted by (target frame, 16-row band).  One plan serves every
     level of a pyramid; `coords / coord_scale` must be the coordinates of the level with `height` rows."""
     L.require_gpu(coords, jj)
     coords = coords.float().contiguous()
     jj = jj.long().contiguous()
     B, E = coords.shape[:2]
-    order = torch.empty(B * E, dtype=torch.int32, device=coords.device)
+    order = torch.empty(B * E + 1, dtype=torch.int32, device=coords.device)      # [B*E] = number of heavy edges
     rc = L.lib().devo_corr_order(L.ptr(coords), L.ptr(jj), L.ptr(order), B, E, int(n_frames), coords.shape[3], int(height),
-                                 float(coord_scale), L.stream())
+                                 float(coord_scale), int(radius), L.stream())
     L.check(rc, "cuda_corr.plan")
     return order
 
@@ -40,7 +40,7 @@ def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, of
     """corr forward writing element l of edge (b,e) at out[(b*E+e)*estride + l*lstride + offset]."""
     fmap1, fmap2, coords, ii, jj = _prep(fmap1, fmap2, coords, ii, jj)
     if order is None and coords.shape[0] * coords.shape[1] >= PLAN_MIN_EDGES:
-        order = plan(coords, jj, fmap2.shape[1], fmap2.shape[3])
+        order = plan(coords, jj, fmap2.shape[1], fmap2.shape[3], 1.0, radius)
     B, E = coords.shape[:2]
     P = coords.shape[3]
     _, Np, C = fmap1.shape[:3]
@@ -74,7 +74,7 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales):
     out = torch.empty(B, E, per * nl, dtype=fmap1.dtype, device=fmap1.device)
     order = None
     if B * E >= PLAN_MIN_EDGES:
-        order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0])
+        order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius)
     for lvl, (fm, s) in enumerate(zip(pyramid, scales)):
         forward_into(out, fmap1, fm, coords / s, ii, jj, radius, per * nl, nl, lvl, order=order)
     return out

@@ -17,7 +17,7 @@ namespace devo {
 
 constexpr int PP = 9;          // patch pixels (P = 3)
 constexpr int MAXD = 12;       // 2*R+2 for R <= 5
-constexpr int KC = 16;         // channels staged per LDS chunk
+constexpr int KC = 8;          // channels staged per LDS chunk
 constexpr int ROWPAD = KC + 4; // LDS row stride in floats: conflict-free ds_read_b128 (20*l mod 64 distinct per 16 lanes)
 constexpr int NT = 128;        // threads per workgroup (2 waves): one chunk of 128 box positions
 
@@ -82,7 +82,7 @@ __device__ __forceinline__ void corr_epilogue(const float* sraw, const float* sd
 // multiply-adds (exactly the 9 * D^2 * C products the lookup needs).
 // Boxes that do not fit the tile (patch pixels spread apart) stage the 9 windows one after the other.
 // -------------------------------------------------------------------------------------------------
-constexpr int WPB = 1;                      // waves (edges) per workgroup
+constexpr int WPB = 1;                      // waves (edges) per workgroup (the heavy-first schedule assumes 1)
 constexpr int F1ROW = KC + 4;               // row stride of the transposed patch chunk
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -116,29 +116,42 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     int C, int H2, int W2, int64_t s_b, int64_t s_n, int64_t s_h, int64_t s_w, int64_t out_estride,
     int64_t out_lstride, int64_t out_offset, int R, const int* __restrict__ order, unsigned long long* __restrict__ trace) {
   constexpr int TILEPOS = (NG == 1) ? 128 : 256;       // box positions staged per chunk (loads per lane = TILEPOS * PARTS / 64)
-  constexpr int TILE_SLOTS = (NG == 1) ? 704 : 1408;   // 16-byte slots of the box tile
+  constexpr int TILE_SLOTS = ((NG == 1) ? 704 : 1408) * (ROWPAD / 4) / 5;   // 16-byte slots of the box tile (704 at 5 slots per position)
   constexpr int F2_FLOATS = TILE_SLOTS * 4;            // box tile
   constexpr int F1_FLOATS = PP * F1ROW;                // transposed patch chunk
   constexpr int DMAX = 2 * RMAX + 2;
   constexpr int RW_FLOATS = (PP * (DMAX * DMAX + 1) + 3) / 4 * 4;   // the 9 raw windows [p][a][c], row stride D*D+1
-  constexpr int WAVE_FLOATS = F2_FLOATS + F1_FLOATS + RW_FLOATS;
+  constexpr int WAVE_FLOATS = F2_FLOATS + F1_FLOATS;   // the raw windows reuse the box tile once all chunks are done
+  static_assert(RW_FLOATS <= F2_FLOATS, "raw windows must fit in the box tile");
   static_assert(NG * 64 >= DMAX * DMAX && TILEPOS >= NG * 64, "tap groups must cover the window");
-  static_assert(ROWPAD == 20, "slot arithmetic below assumes 5 slots (20 floats) per position");
+  constexpr int SPP = ROWPAD / 4;                       // 16-byte slots per staged position (odd: 5 for KC = 16, 3 for KC = 8)
+  static_assert(ROWPAD % 4 == 0 && (SPP & 1) == 1, "the conflict-free pitch needs an odd number of slots per position");
   __shared__ __attribute__((aligned(16))) float s_tile[WPB * WAVE_FLOATS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // XCD-aware schedule: workgroup g runs on XCD g % 8 (observed dispatch order); give every XCD one contiguous
-  // slice of the (frame, row-band)-sorted edge list so that its private L2 sees each feature row ~once.
-  // (bijective for any grid size: XCD x owns ceil((nwg - x) / 8) workgroups.)
-  const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
-  const int vwg = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
-  const int slot = vwg * WPB + wave;
+  // Schedule (with a plan): the first `nh` workgroups take the plan's HEAVY edges (multi-pass boxes) so that the
+  // longest work items start first on every XCD; the others take the (frame, row-band)-sorted edges XCD-aware:
+  // workgroup g runs on XCD g % 8 (observed dispatch order) and every XCD owns one contiguous slice of the sorted list,
+  // so that its private L2 sees each feature row about once.  (Bijective for any grid size.)
+  const int g = blockIdx.x * WPB + wave;                     // WPB == 1: one wave per workgroup
+  const int nh = order ? min(max(order[BE], 0), BE) : 0;
+  int slot;
+  if (g < nh) {
+    slot = g;
+  } else {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7;
+    auto heavy_on = [&](int x) -> int { return nh > x ? (nh - x + 7) >> 3 : 0; };          // heavy workgroups on XCD x
+    auto total_on = [&](int x) -> int { return nwg > x ? (nwg - x + 7) >> 3 : 0; };        // all workgroups on XCD x
+    int start = nh;
+    for (int x = 0; x < xcd; x++) start += total_on(x) - heavy_on(x);
+    slot = start + (blockIdx.x >> 3) - heavy_on(xcd);
+  }
   if (slot >= BE) return;                                   // wave-uniform; no barriers in this kernel
   const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ULL;
   const int be = order ? order[slot] : slot;
   float* tile = s_tile + wave * WAVE_FLOATS;
   float* f1t = tile + F2_FLOATS;
-  float* rawwin = f1t + F1_FLOATS;
+  float* rawwin = tile;
   const int D = 2 * R + 2, ntap = D * D;
   const int b = be / E, e = be - b * E;
 
@@ -160,10 +173,10 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     ymin = min(ymin, oy[p]); ymax = max(ymax, oy[p]);
   }
   const long long npos_ll = (long long)(xmax - xmin + D) * (ymax - ymin + D);
-  // Box row pitch in 16-byte slots: the smallest value >= 5*bw that is = 8 (mod 16).  With 5 slots per position
+  // Box row pitch in 16-byte slots: the smallest value >= SPP*bw that is = 8 (mod 16).  With an odd SPP slots per position
   // this makes the tap-centric ds_read_b128 pattern (lane groups {0-3,12-15,20-27}, ... = 4 window rows x 4 taps)
   // bank-conflict free for every box width.
-  auto pitch_of = [](int w) -> int { const int s = 5 * w; return s + ((8 - s) & 15); };
+  auto pitch_of = [](int w) -> int { const int s = SPP * w; return s + ((8 - s) & 15); };
   auto fits = [&](int w, int h) -> bool { return (long long)w * h <= TILEPOS && (long long)h * pitch_of(w) <= TILE_SLOTS; };
   const bool whole = (npos_ll <= TILEPOS) && fits(xmax - xmin + D, ymax - ymin + D);   // the union box fits the tile (the usual case)
 
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     for (int g = 0; g < NG; g++)
 #pragma unroll
       for (int p = 0; p < PP; p++)
-        rowoff[g][p] = (mode != 2) ? ((oy[p] - by0 + ta[g]) * PT + 5 * (ox[p] - bx0 + tc[g])) * 4 : (ta[g] * PT + 5 * tc[g]) * 4;
+        rowoff[g][p] = (mode != 2) ? ((oy[p] - by0 + ta[g]) * PT + SPP * (ox[p] - bx0 + tc[g])) * 4 : (ta[g] * PT + SPP * tc[g]) * 4;
 
     int64_t soff[ITERS];
     int sdst[ITERS];                                // LDS destination (floats) of each staged 16-byte piece; -1 = none
@@ -239,25 +252,33 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 #pragma unroll
       for (int it = 0; it < ITERS; it++) {
         const int gy = by0 + pyy, gx = bx0 + pxx;
-        sdst[it] = (pos < npos) ? (pyy * PT + 5 * pxx) * 4 + part * VEC : -1;
+        sdst[it] = (pos < npos) ? (pyy * PT + SPP * pxx) * 4 + part * VEC : -1;
         sok[it] = (pos < npos) && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
         soff[it] = (int64_t)gy * s_h + (int64_t)gx * s_w + part * VEC;
         pos += STEP; pxx += STEP;
         while (pxx >= bw) { pxx -= bw; pyy++; }
       }
     }
-    // ---- global -> registers one whole chunk ahead of its use (the loads fly under the FMAs)
+    // ---- global -> registers one whole chunk ahead of its use (the loads fly under the FMAs).  (Two chunks ahead
+    //      costs 28 more VGPRs = one wave per SIMD less, and measured slower.)
     uint4 raw[ITERS];
     T raw1[F1N];
+    auto fetch = [&](int kch) {
 #pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-      raw[it] = make_uint4(0, 0, 0, 0);
-      if (sok[it]) raw[it] = *reinterpret_cast<const uint4*>(f2 + soff[it]);
-    }
+      for (int it = 0; it < ITERS; it++) {
+        if (sok[it]) raw[it] = *reinterpret_cast<const uint4*>(f2 + soff[it] + kch);
+      }
 #pragma unroll
-    for (int j = 0; j < F1N; j++) raw1[j] = (f1dst[j] >= 0) ? f1[lane + 64 * j] : from_f32<T>(0.0f);
+      for (int j = 0; j < F1N; j++) if (f1dst[j] >= 0) raw1[j] = f1[(int64_t)kch * PP + lane + 64 * j];
+    };
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) raw[it] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < F1N; j++) raw1[j] = from_f32<T>(0.0f);
+    fetch(0);
 
     for (int kc = 0; kc < C; kc += KC) {
+    {
       wave_lds_fence();                            // previous chunk's reads are done before the tile is overwritten
       // ---- registers -> LDS (as fp32)
 #pragma unroll
@@ -274,14 +295,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 #pragma unroll
       for (int j = 0; j < F1N; j++) if (f1dst[j] >= 0) f1t[f1dst[j]] = to_f32<T>(raw1[j]);
       wave_lds_fence();
-      if (kc + KC < C) {
-#pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-          if (sok[it]) raw[it] = *reinterpret_cast<const uint4*>(f2 + soff[it] + kc + KC);
-        }
-#pragma unroll
-        for (int j = 0; j < F1N; j++) if (f1dst[j] >= 0) raw1[j] = f1[(int64_t)(kc + KC) * PP + lane + 64 * j];
-      }
+      if (kc + KC < C) fetch(kc + KC);
       // ---- 9 accumulators per tap, 4 channels per step
       if (mode != 2) {
         const bool t0 = (mode == 0) || sp == 0, t1 = (mode == 0) || sp == 1, t2 = (mode == 0) || sp == 2;   // uniform
@@ -326,8 +340,10 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
         }
       }
     }
+    }
   }
-  // ---- raw windows [p][a][c] (row stride D*D+1: conflict-free epilogue reads)
+  // ---- raw windows [p][a][c] (row stride D*D+1: conflict-free epilogue reads); they overwrite the dead box tile
+  wave_lds_fence();
 #pragma unroll
   for (int g = 0; g < NG; g++) {
     if (lane + 64 * g < ntap) {
@@ -365,24 +381,42 @@ constexpr int ORDER_THREADS = 1024;
 constexpr int ORDER_MAXBINS = 4096;
 __global__ __launch_bounds__(ORDER_THREADS) void corr_order_kernel(const float* __restrict__ coords,
                                                                    const int64_t* __restrict__ jj, int BE, int E, int n2,
-                                                                   int H2, float inv_scale, int nb, int* __restrict__ order) {
+                                                                   int H2, float inv_scale, int nb, int D, int heavy_pos,
+                                                                   int* __restrict__ order) {
   __shared__ int s_cnt[ORDER_MAXBINS];
+  __shared__ int s_heavy[2];                                // [0] = count (pass 1), [1] = cursor (pass 2)
   const int nbins = ((BE + E - 1) / E) * n2 * nb;
   for (int i = threadIdx.x; i < nbins; i += ORDER_THREADS) s_cnt[i] = 0;
+  if (threadIdx.x < 2) s_heavy[threadIdx.x] = 0;
   __syncthreads();
+  // bin of an edge, or -1 for a HEAVY edge (the box of its 9 windows exceeds `heavy_pos` positions: it will be staged
+  // in several passes and run 2-4x longer) — heavy edges go to the front of the plan so that they start first.
   auto bin_of = [&](int be) -> int {
     const int b = be / E, e = be - b * E;
-    const float y = coords[((int64_t)be * 2 + 1) * PP + 4] * inv_scale;      // centre pixel [1][1]
+    const float* c = coords + (int64_t)be * 2 * PP;
+    float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
+#pragma unroll
+    for (int p = 0; p < PP; p += 2) {                        // corners + centre of the 3x3 patch (pixels 0,2,4,6,8)
+      const float x = floorf(c[p] * inv_scale), y = floorf(c[PP + p] * inv_scale);
+      xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y);
+    }
+    const float area = (xhi - xlo + (float)D) * (yhi - ylo + (float)D);
+    if (!(area <= (float)heavy_pos)) return -1;
+    const float y = c[PP + 4] * inv_scale;                   // centre pixel [1][1]
     int band = (int)(fminf(fmaxf(y, 0.0f), (float)(H2 - 1))) / 16;
     band = min(max(band, 0), nb - 1);
     int f = (int)jj[e];
     f = min(max(f, 0), n2 - 1);
     return (b * n2 + f) * nb + band;
   };
-  for (int be = threadIdx.x; be < BE; be += ORDER_THREADS) atomicAdd(&s_cnt[bin_of(be)], 1);
+  for (int be = threadIdx.x; be < BE; be += ORDER_THREADS) {
+    const int bin = bin_of(be);
+    atomicAdd(bin >= 0 ? &s_cnt[bin] : &s_heavy[0], 1);
+  }
   __syncthreads();
-  if (threadIdx.x < 64) {                                   // exclusive scan of the bins by one wave
-    int carry = 0;
+  const int n_heavy = s_heavy[0];
+  if (threadIdx.x < 64) {                                   // exclusive scan of the bins by one wave, starting after the heavy list
+    int carry = n_heavy;
     for (int base = 0; base < nbins; base += 64) {
       const int i = base + threadIdx.x;
       const int v = (i < nbins) ? s_cnt[i] : 0;
@@ -394,7 +428,11 @@ __global__ __launch_bounds__(ORDER_THREADS) void corr_order_kernel(const float* 
     }
   }
   __syncthreads();
-  for (int be = threadIdx.x; be < BE; be += ORDER_THREADS) order[atomicAdd(&s_cnt[bin_of(be)], 1)] = be;
+  for (int be = threadIdx.x; be < BE; be += ORDER_THREADS) {
+    const int bin = bin_of(be);
+    order[atomicAdd(bin >= 0 ? &s_cnt[bin] : &s_heavy[1], 1)] = be;
+  }
+  if (threadIdx.x == 0) order[BE] = n_heavy;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -633,7 +671,7 @@ int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords,
 }
 
 int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, int E, int n2, int P, int H2,
-                    float coord_scale, devo_stream_t stream) {
+                    float coord_scale, int radius, devo_stream_t stream) {
   DEVO_REQUIRE(P == 3, "devo_corr_order: patch size P must be 3 (got %d)", P);
   DEVO_REQUIRE(B >= 0 && E >= 0 && n2 > 0 && H2 > 0 && coord_scale > 0.0f, "devo_corr_order: bad sizes");
   const long long BE = (long long)B * E;
@@ -641,8 +679,9 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   int nb = (H2 + 15) / 16;
   while ((long long)B * n2 * nb > ORDER_MAXBINS && nb > 1) nb = (nb + 1) / 2;      // coarser bands if there are many frames
   DEVO_REQUIRE((long long)B * n2 * nb <= ORDER_MAXBINS && BE < (1LL << 31), "devo_corr_order: too many frames (%d x %d)", B, n2);
+  DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_order: radius %d unsupported (max 5)", radius);
   hipLaunchKernelGGL(corr_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, (hipStream_t)stream, coords, jj, (int)BE, E, n2, H2,
-                     1.0f / coord_scale, nb, order);
+                     1.0f / coord_scale, nb, 2 * radius + 2, radius <= 3 ? 128 : 256, order);
   return check_launch("devo_corr_order");
 }
 

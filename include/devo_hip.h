@@ -50,16 +50,18 @@ const char* devo_last_error(void); /* thread-local message of the last failing c
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
                       const int64_t* f2s /* host, 5 */, int64_t out_estride, int64_t out_lstride,
-                      int64_t out_offset, int radius, int dtype, const int* order /* i32 [B*E] or NULL */,
+                      int64_t out_offset, int radius, int dtype, const int* order /* i32 [B*E + 1] or NULL */,
                       devo_stream_t stream);
 
 /* Locality plan for devo_corr_forward (no reference counterpart: the reference walks edges in list order).
- * order i32 [B*E]: the edge slots sorted by (batch, target frame jj, 16-row band of the patch centre), so that
- * the lookup kernel's XCD-aware schedule streams every feature row through an L2 about once.  `coord_scale`
+ * order i32 [B*E + 1]: first the HEAVY edge slots (union box of the 9 windows larger than the kernel's LDS tile:
+ * they run 2-4x longer and should start first), then the others sorted by (batch, target frame jj, 16-row band of
+ * the patch centre), so that the lookup kernel's XCD-aware schedule streams every feature row through an L2 about
+ * once; order[B*E] = number of heavy edges.  `coord_scale`
  * is the factor the caller divides coords by for the pyramid level whose height is H2 (1 for level 0); one
  * plan serves all levels of a pyramid.  The plan only changes WHICH edges run together, never any result. */
 int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, int E, int n2, int P, int H2,
-                    float coord_scale, devo_stream_t stream);
+                    float coord_scale, int radius, devo_stream_t stream);
 
 /* cuda_corr.backward  (correlation.cpp:59 -> correlation_kernel.cu:236-286, kernel :139-190).
  *   grad f32: the gradient of the logical [B,E,D-1,D-1,P,P] output, contiguous.

@@ -29,7 +29,7 @@ def plan(coords, jj, n_frames, height, coord_scale=1.0, radius=3):
     coords = coords.float().contiguous()
     jj = jj.long().contiguous()
     B, E = coords.shape[:2]
-    order = torch.empty(B * E + 1, dtype=torch.int32, device=coords.device)      # [B*E] = number of heavy edges
+    order = torch.empty(2 * B * E + 1, dtype=torch.int32, device=coords.device)  # [:B*E] slots, [B*E] = #heavy, rest scratch
     rc = L.lib().devo_corr_order(L.ptr(coords), L.ptr(jj), L.ptr(order), B, E, int(n_frames), coords.shape[3], int(height),
                                  float(coord_scale), int(radius), L.stream())
     L.check(rc, "cuda_corr.plan")

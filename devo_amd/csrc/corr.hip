@@ -373,45 +373,58 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 }
 
 // -------------------------------------------------------------------------------------------------
-// Locality plan: order[] = edge slots sorted by (batch, target frame, 16-row band of the patch centre).
-// One workgroup, LDS counting sort (bins = frames x bands).  The order only affects which edges run
+// Locality plan: order[] = heavy edge slots, then the rest sorted by (batch, target frame, 16-row band of the
+// patch centre).  Binning on all CUs, then one workgroup's LDS counting sort (bins = frames x bands).  The order only affects which edges run
 // together (L2 reuse of the feature rows); results are independent of it.
 // -------------------------------------------------------------------------------------------------
 constexpr int ORDER_THREADS = 1024;
 constexpr int ORDER_MAXBINS = 4096;
-__global__ __launch_bounds__(ORDER_THREADS) void corr_order_kernel(const float* __restrict__ coords,
-                                                                   const int64_t* __restrict__ jj, int BE, int E, int n2,
-                                                                   int H2, float inv_scale, int nb, int D, int heavy_pos,
-                                                                   int* __restrict__ order) {
-  __shared__ int s_cnt[ORDER_MAXBINS];
-  __shared__ int s_heavy[2];                                // [0] = count (pass 1), [1] = cursor (pass 2)
-  const int nbins = ((BE + E - 1) / E) * n2 * nb;
-  for (int i = threadIdx.x; i < nbins; i += ORDER_THREADS) s_cnt[i] = 0;
-  if (threadIdx.x < 2) s_heavy[threadIdx.x] = 0;
-  __syncthreads();
-  // bin of an edge, or -1 for a HEAVY edge (the box of its 9 windows exceeds `heavy_pos` positions: it will be staged
-  // in several passes and run 2-4x longer) — heavy edges go to the front of the plan so that they start first.
-  auto bin_of = [&](int be) -> int {
-    const int b = be / E, e = be - b * E;
-    const float* c = coords + (int64_t)be * 2 * PP;
-    float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
+constexpr int BIN_THREADS = 256;
+
+// Step 1 (all CUs): bin of every edge slot -> bins[be]; -1 marks a HEAVY edge (the box of its 9 windows exceeds
+// `heavy_pos` positions: it is staged in several passes and runs 2-4x longer) — heavy edges go to the front of the plan.
+__global__ __launch_bounds__(BIN_THREADS) void corr_bin_kernel(const float* __restrict__ coords,
+                                                               const int64_t* __restrict__ jj, int BE, int E, int n2, int H2,
+                                                               float inv_scale, int nb, int D, int heavy_pos,
+                                                               int* __restrict__ bins) {
+  const int be = blockIdx.x * BIN_THREADS + threadIdx.x;
+  if (be >= BE) return;
+  const int b = be / E, e = be - b * E;
+  const float* c = coords + (int64_t)be * 2 * PP;
+  float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
 #pragma unroll
-    for (int p = 0; p < PP; p += 2) {                        // corners + centre of the 3x3 patch (pixels 0,2,4,6,8)
-      const float x = floorf(c[p] * inv_scale), y = floorf(c[PP + p] * inv_scale);
-      xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y);
-    }
-    const float area = (xhi - xlo + (float)D) * (yhi - ylo + (float)D);
-    if (!(area <= (float)heavy_pos)) return -1;
+  for (int p = 0; p < PP; p += 2) {                          // corners + centre of the 3x3 patch (pixels 0,2,4,6,8)
+    const float x = floorf(c[p] * inv_scale), y = floorf(c[PP + p] * inv_scale);
+    xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y);
+  }
+  const float area = (xhi - xlo + (float)D) * (yhi - ylo + (float)D);
+  int bin = -1;
+  if (area <= (float)heavy_pos) {                            // (NaN coordinates compare false -> heavy list; harmless)
     const float y = c[PP + 4] * inv_scale;                   // centre pixel [1][1]
     int band = (int)(fminf(fmaxf(y, 0.0f), (float)(H2 - 1))) / 16;
     band = min(max(band, 0), nb - 1);
     int f = (int)jj[e];
     f = min(max(f, 0), n2 - 1);
-    return (b * n2 + f) * nb + band;
-  };
-  for (int be = threadIdx.x; be < BE; be += ORDER_THREADS) {
-    const int bin = bin_of(be);
-    atomicAdd(bin >= 0 ? &s_cnt[bin] : &s_heavy[0], 1);
+    bin = (b * n2 + f) * nb + band;
+  }
+  bins[be] = bin;
+}
+
+// Step 2 (one workgroup): LDS counting sort of the bins; the heavy list first.
+__global__ __launch_bounds__(ORDER_THREADS) void corr_order_kernel(const int* __restrict__ bins, int BE, int nbins,
+                                                                   int* __restrict__ order) {
+  __shared__ int s_cnt[ORDER_MAXBINS];
+  __shared__ int s_heavy[2];                                // [0] = count (pass 1), [1] = cursor (pass 2)
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < nbins; i += ORDER_THREADS) s_cnt[i] = 0;
+  if (threadIdx.x < 2) s_heavy[threadIdx.x] = 0;
+  __syncthreads();
+  for (int be0 = 0; be0 < BE; be0 += ORDER_THREADS) {       // block-uniform trip count (ballots below)
+    const int be = be0 + threadIdx.x;
+    const int bin = be < BE ? bins[be] : 0x7fffffff;
+    const unsigned long long hv = __ballot(bin < 0);
+    if (bin >= 0 && bin < nbins) atomicAdd(&s_cnt[bin], 1);
+    if (hv != 0ull && lane == 0) atomicAdd(&s_heavy[0], __popcll(hv));
   }
   __syncthreads();
   const int n_heavy = s_heavy[0];
@@ -428,9 +441,15 @@ __global__ __launch_bounds__(ORDER_THREADS) void corr_order_kernel(const float* 
     }
   }
   __syncthreads();
-  for (int be = threadIdx.x; be < BE; be += ORDER_THREADS) {
-    const int bin = bin_of(be);
-    order[atomicAdd(bin >= 0 ? &s_cnt[bin] : &s_heavy[1], 1)] = be;
+  for (int be0 = 0; be0 < BE; be0 += ORDER_THREADS) {
+    const int be = be0 + threadIdx.x;
+    const int bin = be < BE ? bins[be] : 0x7fffffff;
+    const unsigned long long hv = __ballot(bin < 0);
+    int hbase = 0;
+    if (hv != 0ull && lane == 0) hbase = atomicAdd(&s_heavy[1], __popcll(hv));
+    hbase = __shfl(hbase, 0);
+    if (bin < 0) order[hbase + __popcll(hv & ((1ull << lane) - 1ull))] = be;
+    else if (bin < nbins) order[atomicAdd(&s_cnt[bin], 1)] = be;
   }
   if (threadIdx.x == 0) order[BE] = n_heavy;
 }
@@ -678,10 +697,14 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   if (BE == 0) return DEVO_OK;
   int nb = (H2 + 15) / 16;
   while ((long long)B * n2 * nb > ORDER_MAXBINS && nb > 1) nb = (nb + 1) / 2;      // coarser bands if there are many frames
-  DEVO_REQUIRE((long long)B * n2 * nb <= ORDER_MAXBINS && BE < (1LL << 31), "devo_corr_order: too many frames (%d x %d)", B, n2);
+  DEVO_REQUIRE((long long)B * n2 * nb <= ORDER_MAXBINS && BE < (1LL << 30), "devo_corr_order: too many frames (%d x %d)", B, n2);
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_order: radius %d unsupported (max 5)", radius);
-  hipLaunchKernelGGL(corr_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, (hipStream_t)stream, coords, jj, (int)BE, E, n2, H2,
-                     1.0f / coord_scale, nb, 2 * radius + 2, radius <= 3 ? 128 : 256, order);
+  int* bins = order + BE + 1;                                 // scratch half of the plan buffer
+  hipLaunchKernelGGL(corr_bin_kernel, dim3((unsigned)((BE + BIN_THREADS - 1) / BIN_THREADS)), dim3(BIN_THREADS), 0,
+                     (hipStream_t)stream, coords, jj, (int)BE, E, n2, H2, 1.0f / coord_scale, nb, 2 * radius + 2,
+                     radius <= 3 ? 128 : 256, bins);
+  hipLaunchKernelGGL(corr_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, (hipStream_t)stream, bins, (int)BE,
+                     B * n2 * nb, order);
   return check_launch("devo_corr_order");
 }
 

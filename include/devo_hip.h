@@ -50,11 +50,12 @@ const char* devo_last_error(void); /* thread-local message of the last failing c
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
                       const int64_t* f2s /* host, 5 */, int64_t out_estride, int64_t out_lstride,
-                      int64_t out_offset, int radius, int dtype, const int* order /* i32 [B*E + 1] or NULL */,
+                      int64_t out_offset, int radius, int dtype, const int* order /* plan buffer, i32 [>= B*E + 1], or NULL */,
                       devo_stream_t stream);
 
 /* Locality plan for devo_corr_forward (no reference counterpart: the reference walks edges in list order).
- * order i32 [B*E + 1]: first the HEAVY edge slots (union box of the 9 windows larger than the kernel's LDS tile:
+ * order i32 [2*B*E + 1] (the plan buffer; devo_corr_forward reads the first B*E + 1 entries, the rest is scratch
+ * of this call): first the HEAVY edge slots (union box of the 9 windows larger than the kernel's LDS tile:
  * they run 2-4x longer and should start first), then the others sorted by (batch, target frame jj, 16-row band of
  * the patch centre), so that the lookup kernel's XCD-aware schedule streams every feature row through an L2 about
  * once; order[B*E] = number of heavy edges.  `coord_scale`

@@ -6,11 +6,11 @@ import torch
 from .. import _lib as L
 
 
-def _prep(fmap1, fmap2, coords, ii, jj):
+def _prep(fmap1, fmap2, coords, ii, jj, allow_blocked=False):
     L.require_gpu(fmap1, fmap2, coords, ii, jj)
     if fmap1.dtype != fmap2.dtype:
         raise RuntimeError("cuda_corr: fmap1 and fmap2 must have the same dtype")
-    if fmap1.dim() != 5 or fmap2.dim() != 5 or coords.dim() != 5:
+    if fmap1.dim() != 5 or fmap2.dim() not in ((5, 6) if allow_blocked else (5,)) or coords.dim() != 5:
         raise RuntimeError("cuda_corr: expected fmap1 [B,Np,C,P,P], fmap2 [B,n,C,H,W], coords [B,E,2,P,P]")
     fmap1 = fmap1.contiguous()
     coords = coords.float().contiguous()
@@ -38,15 +38,21 @@ def plan(coords, jj, n_frames, height, coord_scale=1.0, radius=3):
 
 def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, offset, order=None):
     """corr forward writing element l of edge (b,e) at out[(b*E+e)*estride + l*lstride + offset]."""
-    fmap1, fmap2, coords, ii, jj = _prep(fmap1, fmap2, coords, ii, jj)
+    fmap1, fmap2, coords, ii, jj = _prep(fmap1, fmap2, coords, ii, jj, allow_blocked=True)
     if order is None and coords.shape[0] * coords.shape[1] >= PLAN_MIN_EDGES:
         order = plan(coords, jj, fmap2.shape[1], fmap2.shape[3], 1.0, radius)
     B, E = coords.shape[:2]
     P = coords.shape[3]
     _, Np, C = fmap1.shape[:3]
     n2, H2, W2 = fmap2.shape[1], fmap2.shape[3], fmap2.shape[4]
+    cblock, strides = 0, fmap2.stride()
+    if fmap2.dim() == 6:                      # channel-blocked storage [B, n, C/cb, H, W, cb] (altcorr.channel_blocked)
+        cblock = fmap2.shape[5]
+        if fmap2.stride(5) != 1 or fmap2.shape[2] * cblock != C:
+            raise RuntimeError("cuda_corr.forward: malformed channel-blocked fmap2")
+        strides = strides[:5]
     rc = L.lib().devo_corr_forward(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(ii), L.ptr(jj), L.ptr(out),
-                                   B, E, Np, n2, C, P, H2, W2, L.i64arr(fmap2.stride()), estride, lstride, offset,
+                                   B, E, Np, n2, C, P, H2, W2, L.i64arr(strides), cblock, estride, lstride, offset,
                                    int(radius), L.dtype_code(fmap1), L.ptr(order), L.stream())
     L.check(rc, "cuda_corr.forward")
 

@@ -12,6 +12,7 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 #include <vector>
+#include <type_traits>
 
 namespace devo {
 
@@ -108,24 +109,55 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ void fma_px012(float& a0, float& a1, float& a2, float4 w, float4 v0, float4 v1, float4 v2) { DEVO_FMA_TRIPLE(0, 1, 2); }
 __device__ __forceinline__ void fma_px345(float& a0, float& a1, float& a2, float4 w, float4 v0, float4 v1, float4 v2) { DEVO_FMA_TRIPLE(3, 4, 5); }
 __device__ __forceinline__ void fma_px678(float& a0, float& a1, float& a2, float4 w, float4 v0, float4 v1, float4 v2) { DEVO_FMA_TRIPLE(6, 7, 8); }
+// 4 FMAs of one pixel (split boxes: the pixels of a stage are selected with wave-uniform branches)
+#define DEVO_FMA_ONE(P)                                                                                       \
+  asm("s_nop 1\n" DEVO_FMA_LINE("%0", "%1", "%5", P) DEVO_FMA_LINE("%0", "%2", "%6", P)                          \
+          DEVO_FMA_LINE("%0", "%3", "%7", P) DEVO_FMA_LINE("%0", "%4", "%8", P)                                  \
+      : "+v"(a)                                                                                               \
+      : "v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w))
+template <int P> __device__ __forceinline__ void fma_one(float& a, float4 w, float4 v);
+template <> __device__ __forceinline__ void fma_one<0>(float& a, float4 w, float4 v) { DEVO_FMA_ONE(0); }
+template <> __device__ __forceinline__ void fma_one<1>(float& a, float4 w, float4 v) { DEVO_FMA_ONE(1); }
+template <> __device__ __forceinline__ void fma_one<2>(float& a, float4 w, float4 v) { DEVO_FMA_ONE(2); }
+template <> __device__ __forceinline__ void fma_one<3>(float& a, float4 w, float4 v) { DEVO_FMA_ONE(3); }
+template <> __device__ __forceinline__ void fma_one<4>(float& a, float4 w, float4 v) { DEVO_FMA_ONE(4); }
+template <> __device__ __forceinline__ void fma_one<5>(float& a, float4 w, float4 v) { DEVO_FMA_ONE(5); }
+template <> __device__ __forceinline__ void fma_one<6>(float& a, float4 w, float4 v) { DEVO_FMA_ONE(6); }
+template <> __device__ __forceinline__ void fma_one<7>(float& a, float4 w, float4 v) { DEVO_FMA_ONE(7); }
+template <> __device__ __forceinline__ void fma_one<8>(float& a, float4 w, float4 v) { DEVO_FMA_ONE(8); }
+
+
+// Tile capacity of the staged kernel (NG = 1: r <= 3, NG = 3: r <= 5) — shared with the locality plan, whose HEAVY
+// class must be exactly the set of edges whose union box does not fit.
+constexpr int SPP = ROWPAD / 4;                 // 16-byte slots per staged position (odd: 3 for KC = 8)
+static_assert(ROWPAD % 4 == 0 && (SPP & 1) == 1, "the conflict-free pitch needs an odd number of slots per position");
+__host__ __device__ constexpr int tile_positions(int ng) { return ng == 1 ? 160 : 256; }
+__host__ __device__ constexpr int tile_slots(int ng) { return ng == 1 ? 528 : 960; }
+// Box row pitch in 16-byte slots: the smallest value >= SPP*w that is = 8 (mod 16).  With an odd SPP this makes the
+// tap-centric ds_read_b128 pattern (lane groups {0-3,12-15,20-27}, ... = 4 window rows x 4 taps) bank-conflict free
+// for every box width.
+__host__ __device__ __forceinline__ int tile_pitch(int w) { const int s = SPP * w; return s + ((8 - s) & 15); }
+__host__ __device__ __forceinline__ bool tile_fits(int w, int h, int ng) {
+  return (long long)w * h <= tile_positions(ng) && (long long)h * tile_pitch(w) <= tile_slots(ng);
+}
 
 template <typename T, int NG, int RMAX>
 __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     const T* __restrict__ fmap1, const T* __restrict__ fmap2, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int H2, int W2, int64_t s_b, int64_t s_n, int64_t s_h, int64_t s_w, int64_t out_estride,
-    int64_t out_lstride, int64_t out_offset, int R, const int* __restrict__ order, unsigned long long* __restrict__ trace) {
-  constexpr int TILEPOS = (NG == 1) ? 128 : 256;       // box positions staged per chunk (loads per lane = TILEPOS * PARTS / 64)
-  constexpr int TILE_SLOTS = ((NG == 1) ? 704 : 1408) * (ROWPAD / 4) / 5;   // 16-byte slots of the box tile (704 at 5 slots per position)
+    int64_t out_lstride, int64_t out_offset, int R, const int* __restrict__ order, unsigned long long* __restrict__ trace,
+    int64_t chunk_stride /* elements between consecutive KC-channel chunks of a pixel (KC, or the block stride) */) {
+  constexpr int TILEPOS = tile_positions(NG);          // box positions staged per chunk
+  constexpr int TILE_SLOTS = tile_slots(NG);           // 16-byte slots of the box tile
   constexpr int F2_FLOATS = TILE_SLOTS * 4;            // box tile
   constexpr int F1_FLOATS = PP * F1ROW;                // transposed patch chunk
   constexpr int DMAX = 2 * RMAX + 2;
   constexpr int RW_FLOATS = (PP * (DMAX * DMAX + 1) + 3) / 4 * 4;   // the 9 raw windows [p][a][c], row stride D*D+1
-  constexpr int WAVE_FLOATS = F2_FLOATS + F1_FLOATS;   // the raw windows reuse the box tile once all chunks are done
+  constexpr int ZERO_OFF = F2_FLOATS + F1_FLOATS;      // KC zeros: what the taps of pixels outside the current stage read
+  constexpr int WAVE_FLOATS = F2_FLOATS + F1_FLOATS + KC;   // the raw windows reuse the box tile once all chunks are done
   static_assert(RW_FLOATS <= F2_FLOATS, "raw windows must fit in the box tile");
   static_assert(NG * 64 >= DMAX * DMAX && TILEPOS >= NG * 64, "tap groups must cover the window");
-  constexpr int SPP = ROWPAD / 4;                       // 16-byte slots per staged position (odd: 5 for KC = 16, 3 for KC = 8)
-  static_assert(ROWPAD % 4 == 0 && (SPP & 1) == 1, "the conflict-free pitch needs an odd number of slots per position");
   __shared__ __attribute__((aligned(16))) float s_tile[WPB * WAVE_FLOATS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -152,6 +184,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
   float* tile = s_tile + wave * WAVE_FLOATS;
   float* f1t = tile + F2_FLOATS;
   float* rawwin = tile;
+  if (lane < KC) tile[ZERO_OFF + lane] = 0.0f;
   const int D = 2 * R + 2, ntap = D * D;
   const int b = be / E, e = be - b * E;
 
@@ -161,6 +194,8 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     px = coords[((int64_t)be * 2 + 0) * PP + lane];
     py = coords[((int64_t)be * 2 + 1) * PP + lane];
   }
+  unsigned long long t_geo = 0, t_first = 0, t_loop = 0;
+  if (trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_geo = __builtin_readcyclecounter(); }
   const int my_ox = floor_to_int(px) - R, my_oy = floor_to_int(py) - R;
   const float my_dx = px - floorf(px), my_dy = py - floorf(py);
   int ox[PP], oy[PP];
@@ -173,11 +208,8 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     ymin = min(ymin, oy[p]); ymax = max(ymax, oy[p]);
   }
   const long long npos_ll = (long long)(xmax - xmin + D) * (ymax - ymin + D);
-  // Box row pitch in 16-byte slots: the smallest value >= SPP*bw that is = 8 (mod 16).  With an odd SPP slots per position
-  // this makes the tap-centric ds_read_b128 pattern (lane groups {0-3,12-15,20-27}, ... = 4 window rows x 4 taps)
-  // bank-conflict free for every box width.
-  auto pitch_of = [](int w) -> int { const int s = SPP * w; return s + ((8 - s) & 15); };
-  auto fits = [&](int w, int h) -> bool { return (long long)w * h <= TILEPOS && (long long)h * pitch_of(w) <= TILE_SLOTS; };
+  auto pitch_of = [](int w) -> int { return tile_pitch(w); };
+  auto fits = [&](int w, int h) -> bool { return tile_fits(w, h, NG); };
   const bool whole = (npos_ll <= TILEPOS) && fits(xmax - xmin + D, ymax - ymin + D);   // the union box fits the tile (the usual case)
 
   const int64_t pi = ii[e];
@@ -188,7 +220,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 
   constexpr int VEC = 16 / sizeof(T);            // elements per 16-byte load
   constexpr int PARTS = KC / VEC;                // 16-byte loads per position
-  constexpr int ITERS = TILEPOS * PARTS / 64;    // 16-byte loads per lane to fill the tile
+  constexpr int ITERS = (TILEPOS * PARTS + 63) / 64;   // 16-byte loads per lane to fill the tile
   constexpr int F1N = (KC * PP + 63) / 64;       // patch-chunk elements per lane (144 -> 3)
   // patch chunk: element el = lane + 64 j of the [KC][9] block goes to f1t[el % 9][el / 9]
   int f1dst[F1N];
@@ -238,49 +270,55 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     for (int g = 0; g < NG; g++)
 #pragma unroll
       for (int p = 0; p < PP; p++)
-        rowoff[g][p] = (mode != 2) ? ((oy[p] - by0 + ta[g]) * PT + SPP * (ox[p] - bx0 + tc[g])) * 4 : (ta[g] * PT + SPP * tc[g]) * 4;
+      {
+          const bool in_stage = (mode == 0) || (mode == 1 ? (p / 3 == sp) : (p == sp));     // wave-uniform
+          rowoff[g][p] = in_stage ? ((oy[p] - by0 + ta[g]) * PT + SPP * (ox[p] - bx0 + tc[g])) * 4 : ZERO_OFF;
+        }
 
-    int64_t soff[ITERS];
-    int sdst[ITERS];                                // LDS destination (floats) of each staged 16-byte piece; -1 = none
+    unsigned sbyte[ITERS];                          // byte offset of each staged 16-byte piece inside the target frame
+    int sdst[ITERS];                                // its LDS destination (floats); -1 = none
     bool sok[ITERS];
     {
-      // position of load `it` = (lane + 64*it) / PARTS: one division, then steps of 64/PARTS positions with carry
+      // load `it` of this lane covers position (lane + 64*it) / PARTS of the box, 16-byte piece (lane % PARTS)
       constexpr int STEP = 64 / PARTS;
       const int part = lane % PARTS;
-      int pos = lane / PARTS;
-      int pyy = pos / bw, pxx = pos - pyy * bw;
+      const float inv_bw = 1.0f / (float)bw;
+      const int sh32 = (int)s_h, sw32 = (int)s_w;   // the launcher guarantees that a frame spans < 2^31 bytes
 #pragma unroll
       for (int it = 0; it < ITERS; it++) {
+        const int pos = lane / PARTS + it * STEP;
+        const int pyy = (int)(((float)pos + 0.5f) * inv_bw);     // exact: pos < 256 <= 2^8, error margin 0.5 / bw
+        const int pxx = pos - pyy * bw;
         const int gy = by0 + pyy, gx = bx0 + pxx;
         sdst[it] = (pos < npos) ? (pyy * PT + SPP * pxx) * 4 + part * VEC : -1;
         sok[it] = (pos < npos) && gy >= 0 && gy < H2 && gx >= 0 && gx < W2;
-        soff[it] = (int64_t)gy * s_h + (int64_t)gx * s_w + part * VEC;
-        pos += STEP; pxx += STEP;
-        while (pxx >= bw) { pxx -= bw; pyy++; }
+        sbyte[it] = (unsigned)(gy * sh32 + gx * sw32 + part * VEC) * (unsigned)sizeof(T);
       }
     }
     // ---- global -> registers one whole chunk ahead of its use (the loads fly under the FMAs).  (Two chunks ahead
     //      costs 28 more VGPRs = one wave per SIMD less, and measured slower.)
     uint4 raw[ITERS];
     T raw1[F1N];
-    auto fetch = [&](int kch) {
+    auto fetch = [&](int64_t kch, int kc1) {
+      const char* fb = reinterpret_cast<const char*>(f2 + kch);            // wave-uniform base + 32-bit lane offset
 #pragma unroll
       for (int it = 0; it < ITERS; it++) {
-        if (sok[it]) raw[it] = *reinterpret_cast<const uint4*>(f2 + soff[it] + kch);
+        if (sok[it]) raw[it] = *reinterpret_cast<const uint4*>(fb + sbyte[it]);
       }
 #pragma unroll
-      for (int j = 0; j < F1N; j++) if (f1dst[j] >= 0) raw1[j] = f1[(int64_t)kch * PP + lane + 64 * j];
+      for (int j = 0; j < F1N; j++) if (f1dst[j] >= 0) raw1[j] = f1[(int64_t)kc1 * PP + lane + 64 * j];
     };
 #pragma unroll
     for (int it = 0; it < ITERS; it++) raw[it] = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < F1N; j++) raw1[j] = from_f32<T>(0.0f);
-    fetch(0);
+    int64_t koff = 0;
+    fetch(koff, 0);
+    if (trace && sp == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_first = __builtin_readcyclecounter(); }
 
-    for (int kc = 0; kc < C; kc += KC) {
-    {
+    // registers -> LDS (as fp32), then the next chunk's loads are issued so that they fly under the FMAs
+    auto stage = [&](int kc) {
       wave_lds_fence();                            // previous chunk's reads are done before the tile is overwritten
-      // ---- registers -> LDS (as fp32)
 #pragma unroll
       for (int it = 0; it < ITERS; it++) {
         if (sdst[it] >= 0) {
@@ -295,55 +333,40 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 #pragma unroll
       for (int j = 0; j < F1N; j++) if (f1dst[j] >= 0) f1t[f1dst[j]] = to_f32<T>(raw1[j]);
       wave_lds_fence();
-      if (kc + KC < C) fetch(kc + KC);
-      // ---- 9 accumulators per tap, 4 channels per step
-      if (mode != 2) {
-        const bool t0 = (mode == 0) || sp == 0, t1 = (mode == 0) || sp == 1, t2 = (mode == 0) || sp == 2;   // uniform
-#pragma unroll 4
-        for (int k = 0; k < KC; k += 4) {
-          const float4 w = *reinterpret_cast<const float4*>(wrow + k);
+      if (kc + KC < C) { koff += chunk_stride; fetch(koff, kc + KC); }
+    };
+    // ---- 9 accumulators per tap, 4 channels per step.  Branch-free: the pixels that are not part of this stage (split
+    //      boxes only) read the zero slot, so their FMAs add 0.  The tap reads of the next pixel row are in flight under
+    //      the FMAs of the current one.
+    for (int kc = 0; kc < C; kc += KC) {
+      stage(kc);
 #pragma unroll
-          for (int g = 0; g < NG; g++) {
-            if (t0) {
-              const float4 v0 = *reinterpret_cast<const float4*>(tile + rowoff[g][0] + k);
-              const float4 v1 = *reinterpret_cast<const float4*>(tile + rowoff[g][1] + k);
-              const float4 v2 = *reinterpret_cast<const float4*>(tile + rowoff[g][2] + k);
-              fma_px012(acc[g][0], acc[g][1], acc[g][2], w, v0, v1, v2);
-            }
-            if (t1) {
-              const float4 v3 = *reinterpret_cast<const float4*>(tile + rowoff[g][3] + k);
-              const float4 v4 = *reinterpret_cast<const float4*>(tile + rowoff[g][4] + k);
-              const float4 v5 = *reinterpret_cast<const float4*>(tile + rowoff[g][5] + k);
-              fma_px345(acc[g][3], acc[g][4], acc[g][5], w, v3, v4, v5);
-            }
-            if (t2) {
-              const float4 v6 = *reinterpret_cast<const float4*>(tile + rowoff[g][6] + k);
-              const float4 v7 = *reinterpret_cast<const float4*>(tile + rowoff[g][7] + k);
-              const float4 v8 = *reinterpret_cast<const float4*>(tile + rowoff[g][8] + k);
-              fma_px678(acc[g][6], acc[g][7], acc[g][8], w, v6, v7, v8);
-            }
-          }
-        }
-      } else {
-        // one pixel per stage: its patch operand is fetched from lane sp of the row with a shuffle (rare path)
+      for (int k = 0; k < KC; k += 4) {
+        const float4 w = *reinterpret_cast<const float4*>(wrow + k);
 #pragma unroll
-        for (int k = 0; k < KC; k += 4) {
-          const float4 w = *reinterpret_cast<const float4*>(wrow + k);
-          const float wx = __shfl(w.x, sp), wy = __shfl(w.y, sp), wz = __shfl(w.z, sp), ww = __shfl(w.w, sp);
-#pragma unroll
-          for (int g = 0; g < NG; g++) {
-            const float4 v = *reinterpret_cast<const float4*>(tile + rowoff[g][0] + k);
-            const float s = fmaf(ww, v.w, fmaf(wz, v.z, fmaf(wy, v.y, wx * v.x)));
-#pragma unroll
-            for (int p = 0; p < PP; p++) acc[g][p] += (p == sp) ? s : 0.0f;
-          }
+        for (int g = 0; g < NG; g++) {
+          const float4 v0 = *reinterpret_cast<const float4*>(tile + rowoff[g][0] + k);
+          const float4 v1 = *reinterpret_cast<const float4*>(tile + rowoff[g][1] + k);
+          const float4 v2 = *reinterpret_cast<const float4*>(tile + rowoff[g][2] + k);
+          const float4 v3 = *reinterpret_cast<const float4*>(tile + rowoff[g][3] + k);
+          const float4 v4 = *reinterpret_cast<const float4*>(tile + rowoff[g][4] + k);
+          const float4 v5 = *reinterpret_cast<const float4*>(tile + rowoff[g][5] + k);
+          fma_px012(acc[g][0], acc[g][1], acc[g][2], w, v0, v1, v2);
+          __builtin_amdgcn_sched_barrier(0);     // at most two rows of tap reads (24 VGPRs) in flight
+          const float4 v6 = *reinterpret_cast<const float4*>(tile + rowoff[g][6] + k);
+          const float4 v7 = *reinterpret_cast<const float4*>(tile + rowoff[g][7] + k);
+          const float4 v8 = *reinterpret_cast<const float4*>(tile + rowoff[g][8] + k);
+          fma_px345(acc[g][3], acc[g][4], acc[g][5], w, v3, v4, v5);
+          __builtin_amdgcn_sched_barrier(0);
+          fma_px678(acc[g][6], acc[g][7], acc[g][8], w, v6, v7, v8);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-    }
     }
   }
   // ---- raw windows [p][a][c] (row stride D*D+1: conflict-free epilogue reads); they overwrite the dead box tile
   wave_lds_fence();
+  if (trace) t_loop = __builtin_readcyclecounter();
 #pragma unroll
   for (int g = 0; g < NG; g++) {
     if (lane + 64 * g < ntap) {
@@ -355,22 +378,34 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
   // ---- fused bilinear blend + axis swap + output permutation (correlation_kernel.cu:221-232)
   const int Dm = D - 1;
   const int total = Dm * Dm * PP;
-  for (int l0 = 0; l0 < total; l0 += 64) {          // wave-uniform trip count: the shuffles below need all lanes
-    const int l = l0 + lane;
-    const int p = l % PP;              // i0*3 + j0
-    const int a = (l / PP) % Dm;       // y offset  (logical dim 3)
-    const int c = l / (PP * Dm);       // x offset  (logical dim 2: permute(0,1,3,2,4,5))
-    const float dxp = __shfl(my_dx, p), dyp = __shfl(my_dy, p);
-    if (l < total) {
-      const float* r = rawwin + p * (D * D + 1) + a * D + c;
-      outp[(int64_t)l * out_lstride] = from_f32<T>(blend4(dxp, dyp, r[0], r[1], r[D], r[D + 1]));
+  {
+    // output element l = (cx * Dm + a) * 9 + p: cx = x offset (logical dim 2: permute(0,1,3,2,4,5)), a = y offset, p = i0*3+j0.
+    // l advances by 64 = 7 * 9 + 1 per pass: the indices are carried instead of re-divided.
+    int q = lane / PP, p = lane - q * PP;
+    int cx = q / Dm, a = q - cx * Dm;
+    T* op = outp + (int64_t)lane * out_lstride;
+    const int64_t ostep = 64 * out_lstride;
+    for (int l0 = 0; l0 < total; l0 += 64) {        // wave-uniform trip count: the shuffles below need all lanes
+      const float dxp = __shfl(my_dx, p), dyp = __shfl(my_dy, p);
+      if (l0 + lane < total) {
+        const float* r = rawwin + p * (D * D + 1) + a * D + cx;
+        *op = from_f32<T>(blend4(dxp, dyp, r[0], r[1], r[D], r[D + 1]));
+      }
+      op += ostep;
+      p += 1; a += 7;
+      if (p >= PP) { p -= PP; a += 1; }
+      while (a >= Dm) { a -= Dm; cx += 1; }
     }
   }
   if (trace && lane == 0) {                          // debug: per-wave (start, end, box size, hw id)
-    unsigned long long* t = trace + (size_t)slot * 4;
+    unsigned long long* t = trace + (size_t)slot * 8;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     t[0] = t_start; t[1] = __builtin_readcyclecounter(); t[2] = (unsigned long long)npos_ll; t[3] = blockIdx.x;
+    t[4] = t_geo; t[5] = t_first; t[6] = t_loop;
   }
 }
+
+#include "corr_dma.h"
 
 // -------------------------------------------------------------------------------------------------
 // Locality plan: order[] = heavy edge slots, then the rest sorted by (batch, target frame, 16-row band of the
@@ -382,24 +417,24 @@ constexpr int ORDER_MAXBINS = 4096;
 constexpr int BIN_THREADS = 256;
 
 // Step 1 (all CUs): bin of every edge slot -> bins[be]; -1 marks a HEAVY edge (the box of its 9 windows exceeds
-// `heavy_pos` positions: it is staged in several passes and runs 2-4x longer) — heavy edges go to the front of the plan.
+// tile of the staged kernel: it is staged in several passes and runs 2-4x longer) — heavy edges go to the front of the plan.
 __global__ __launch_bounds__(BIN_THREADS) void corr_bin_kernel(const float* __restrict__ coords,
                                                                const int64_t* __restrict__ jj, int BE, int E, int n2, int H2,
-                                                               float inv_scale, int nb, int D, int heavy_pos,
+                                                               float inv_scale, int nb, int D, int ng,
                                                                int* __restrict__ bins) {
   const int be = blockIdx.x * BIN_THREADS + threadIdx.x;
   if (be >= BE) return;
   const int b = be / E, e = be - b * E;
   const float* c = coords + (int64_t)be * 2 * PP;
-  float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
+  // union box of the 9 windows, computed exactly like the lookup kernel does (floor_to_int of the scaled coordinate)
+  int xlo = 0x7fffffff, xhi = -0x7fffffff, ylo = 0x7fffffff, yhi = -0x7fffffff;
 #pragma unroll
-  for (int p = 0; p < PP; p += 2) {                          // corners + centre of the 3x3 patch (pixels 0,2,4,6,8)
-    const float x = floorf(c[p] * inv_scale), y = floorf(c[PP + p] * inv_scale);
-    xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y);
+  for (int p = 0; p < PP; p++) {
+    const int x = floor_to_int(c[p] * inv_scale), y = floor_to_int(c[PP + p] * inv_scale);
+    xlo = min(xlo, x); xhi = max(xhi, x); ylo = min(ylo, y); yhi = max(yhi, y);
   }
-  const float area = (xhi - xlo + (float)D) * (yhi - ylo + (float)D);
   int bin = -1;
-  if (area <= (float)heavy_pos) {                            // (NaN coordinates compare false -> heavy list; harmless)
+  if (tile_fits(xhi - xlo + D, yhi - ylo + D, ng)) {
     const float y = c[PP + 4] * inv_scale;                   // centre pixel [1][1]
     int band = (int)(fminf(fmaxf(y, 0.0f), (float)(H2 - 1))) / 16;
     band = min(max(band, 0), nb - 1);
@@ -624,32 +659,51 @@ using namespace devo;
 template <typename T>
 static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                            const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int H2, int W2,
-                           const int64_t* f2s, int64_t oes, int64_t ols, int64_t ooff, int R, const int* order,
+                           const int64_t* f2s, int cblock, int64_t oes, int64_t ols, int64_t ooff, int R, const int* order,
                            hipStream_t st) {
-  const bool cl = (f2s[2] == 1) && (C % KC == 0) && (f2s[3] % (16 / sizeof(T)) == 0) && (f2s[4] % (16 / sizeof(T)) == 0) &&
+  // channel-blocked storage [.., C/cb, H, W, cb]: f2s[2] is the stride between channel blocks, the cb channels of a
+  // pixel are contiguous.  Only the staged kernels read it (cb must equal their channel chunk).
+  const bool blocked = cblock > 1;
+  if (blocked && (cblock != KC || sizeof(T) != 4 || C % KC != 0)) {
+    set_error("devo_corr_forward: channel-blocked fmap2 needs cblock == %d and fp32 (got %d)", KC, cblock);
+    return DEVO_ERR_UNSUPPORTED;
+  }
+  const int64_t chunk_stride = blocked ? f2s[2] : KC;
+  const bool cl = (blocked || f2s[2] == 1) && (C % KC == 0) && (f2s[3] % (16 / sizeof(T)) == 0) && (f2s[4] % (16 / sizeof(T)) == 0) &&
                   (f2s[0] % (16 / sizeof(T)) == 0) && (f2s[1] % (16 / sizeof(T)) == 0) &&
-                  ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) && sizeof(T) <= 4;
+                  ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) && sizeof(T) <= 4 &&
+                  f2s[3] >= 0 && f2s[4] >= 0 &&                                     // 32-bit in-frame offsets (bytes)
+                  ((long long)(H2 - 1) * f2s[3] + (long long)(W2 - 1) * f2s[4] + KC) * (long long)sizeof(T) < (1LL << 31);
   const long long BE = (long long)B * E;
   if (cl) {
     dim3 grid((unsigned)((BE + WPB - 1) / WPB)), block(WPB * 64);
     static const bool force4 = getenv("DEVO_CORR_NP4") != nullptr;      // debug switch: run the r > 3 instantiation
     unsigned long long* trace = nullptr;                                // debug switch: per-wave cycle stamps to stderr
     const bool do_trace = getenv("DEVO_CORR_TRACE") != nullptr;
-    if (do_trace) { (void)hipMalloc(&trace, (size_t)BE * 32); (void)hipMemset(trace, 0, (size_t)BE * 32); }
-    if (R <= 3 && !force4)   // (the <4,5> instantiation has room for every supported radius)
+    if (do_trace) { (void)hipMalloc(&trace, (size_t)BE * 64); (void)hipMemset(trace, 0, (size_t)BE * 64); }
+    static const bool no_dma = getenv("DEVO_CORR_DMA") == nullptr;      // experimental LDS-direct kernel: opt-in
+    const size_t dma_lds = sizeof(float) * (2 * DMA_BUF_FLOATS + (size_t)PP * (C + 4));
+    if (std::is_same<T, float>::value && R <= 3 && !force4 && !no_dma && !blocked && C % 4 == 0 && (size_t)C * 4 <= DMA_ZERO_BYTES &&
+        dma_lds <= 48 * 1024)
+      hipLaunchKernelGGL(corr_fwd_dma_kernel, dim3((unsigned)BE), dim3(64), dma_lds, st, (const float*)fmap1, (const float*)fmap2,
+                         coords, ii, jj, (float*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff,
+                         R, order, trace);
+    else if (R <= 3 && !force4)   // (the <4,5> instantiation has room for every supported radius)
       hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 1, 3>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
-                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace);
+                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace, chunk_stride);
     else
       hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 3, 5>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
-                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace);
+                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace, chunk_stride);
     if (do_trace) {
       (void)hipDeviceSynchronize();
-      std::vector<unsigned long long> h((size_t)BE * 4);
-      (void)hipMemcpy(h.data(), trace, (size_t)BE * 32, hipMemcpyDeviceToHost);
+      std::vector<unsigned long long> h((size_t)BE * 8);
+      (void)hipMemcpy(h.data(), trace, (size_t)BE * 64, hipMemcpyDeviceToHost);
+      double ph[4] = {0, 0, 0, 0};
       unsigned long long t0 = ~0ULL, t1 = 0; double sum = 0, mx = 0, sum_small = 0; long n_small = 0, n_big = 0; double sum_big = 0;
       for (long long i = 0; i < BE; i++) {
-        const unsigned long long* t = &h[i * 4];
+        const unsigned long long* t = &h[i * 8];
         if (!t[1]) continue;
+        ph[0] += (double)(t[4] - t[0]); ph[1] += (double)(t[5] - t[4]); ph[2] += (double)(t[6] - t[5]); ph[3] += (double)(t[1] - t[6]);
         if (t[0] < t0) t0 = t[0];
         if (t[1] > t1) t1 = t[1];
         const double d = (double)(t[1] - t[0]);
@@ -658,9 +712,11 @@ static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* co
       }
       fprintf(stderr, "[corr trace] span %.0f ticks; wave mean %.0f max %.0f; box<=128: n %ld mean %.0f; box>128: n %ld mean %.0f; sum/span = %.1f waves in flight\n",
               (double)(t1 - t0), sum / BE, mx, n_small, n_small ? sum_small / n_small : 0.0, n_big, n_big ? sum_big / n_big : 0.0, sum / (double)(t1 - t0));
+      fprintf(stderr, "[corr trace] phase means: geometry %.0f, first chunk %.0f, channel loop %.0f, epilogue %.0f\n", ph[0] / BE, ph[1] / BE, ph[2] / BE, ph[3] / BE);
       (void)hipFree(trace);
     }
   } else {
+    if (blocked) { set_error("devo_corr_forward: channel-blocked fmap2 must be 16-byte aligned with aligned strides"); return DEVO_ERR_UNSUPPORTED; }
     dim3 grid((unsigned)BE), block(NT);
     hipLaunchKernelGGL(corr_fwd_generic_kernel<T>, grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii,
                        jj, (T*)out, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], oes, ols, ooff, R);
@@ -672,8 +728,8 @@ extern "C" {
 
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
-                      const int64_t* f2s, int64_t out_estride, int64_t out_lstride, int64_t out_offset, int radius,
-                      int dtype, const int* order, devo_stream_t stream) {
+                      const int64_t* f2s, int cblock, int64_t out_estride, int64_t out_lstride, int64_t out_offset,
+                      int radius, int dtype, const int* order, devo_stream_t stream) {
   DEVO_REQUIRE(P == 3, "devo_corr_forward: patch size P must be 3 (got %d)", P);
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_forward: radius %d unsupported (max 5)", radius);
   DEVO_REQUIRE(B >= 0 && E >= 0 && C > 0 && H2 > 0 && W2 > 0, "devo_corr_forward: bad sizes");
@@ -681,9 +737,9 @@ int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords,
   if ((long long)B * E == 0) return DEVO_OK;
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case DEVO_F32: return launch_corr_fwd<float>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, out_estride, out_lstride, out_offset, radius, order, st);
-    case DEVO_F16: return launch_corr_fwd<__half>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, out_estride, out_lstride, out_offset, radius, order, st);
-    case DEVO_F64: return launch_corr_fwd<double>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, out_estride, out_lstride, out_offset, radius, order, st);
+    case DEVO_F32: return launch_corr_fwd<float>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, st);
+    case DEVO_F16: return launch_corr_fwd<__half>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, st);
+    case DEVO_F64: return launch_corr_fwd<double>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, st);
   }
   set_error("devo_corr_forward: unknown dtype %d", dtype);
   return DEVO_ERR_UNSUPPORTED;
@@ -702,7 +758,7 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   int* bins = order + BE + 1;                                 // scratch half of the plan buffer
   hipLaunchKernelGGL(corr_bin_kernel, dim3((unsigned)((BE + BIN_THREADS - 1) / BIN_THREADS)), dim3(BIN_THREADS), 0,
                      (hipStream_t)stream, coords, jj, (int)BE, E, n2, H2, 1.0f / coord_scale, nb, 2 * radius + 2,
-                     radius <= 3 ? 128 : 256, bins);
+                     radius <= 3 ? 1 : 3, bins);
   hipLaunchKernelGGL(corr_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, (hipStream_t)stream, bins, (int)BE,
                      B * n2 * nb, order);
   return check_launch("devo_corr_order");

@@ -49,7 +49,7 @@ const char* devo_last_error(void); /* thread-local message of the last failing c
  *   order  optional locality plan from devo_corr_order (NULL = process edges in list order). */
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
-                      const int64_t* f2s /* host, 5 */, int64_t out_estride, int64_t out_lstride,
+                      const int64_t* f2s /* host, 5 */, int cblock, int64_t out_estride, int64_t out_lstride,
                       int64_t out_offset, int radius, int dtype, const int* order /* plan buffer, i32 [>= B*E + 1], or NULL */,
                       devo_stream_t stream);
 

@@ -374,6 +374,16 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
   }
 }
 
+// Partial systems are stored compactly: lower block triangle, block (fr, fc <= fr) at (fr (fr+1)/2 + fc) * 36 as a
+// full 6x6 [a][b] (of a diagonal block only a >= b is meaningful), then y [n6].
+__device__ __forceinline__ int tri_blocks(int N) { return N * (N + 1) / 2; }
+__device__ __forceinline__ void block_of(int blk, int& fr, int& fc) {   // inverse of blk = fr (fr+1)/2 + fc
+  fr = (int)((sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
+  while (fr * (fr + 1) / 2 > blk) fr--;
+  while ((fr + 1) * (fr + 2) / 2 <= blk) fr++;
+  fc = blk - fr * (fr + 1) / 2;
+}
+
 // Generic accumulate kernel (any N <= 32): every patch through the atomic path.
 // LDS (dynamic): S_lds [n6 * LD] (lower triangle used), y_lds [n6], per-wave column buffers [ACC_WAVES][n6].
 __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
@@ -400,8 +410,15 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
   }
   __syncthreads();
   if (N > 0) {
-    float* out = partials + (int64_t)blockIdx.x * (n6 * LD + n6);
-    for (int i = tid; i < n6 * LD + n6; i += ACC_THREADS) out[i] = smem[i];
+    const int nt = tri_blocks(N) * 36;
+    float* out = partials + (int64_t)blockIdx.x * (nt + n6);
+    for (int i = tid; i < nt; i += ACC_THREADS) {
+      int fr, fc;
+      block_of(i / 36, fr, fc);
+      const int ab = i % 36;
+      out[i] = S_lds[(6 * fr + ab / 6) * LD + 6 * fc + ab % 6];
+    }
+    for (int i = tid; i < n6; i += ACC_THREADS) out[nt + i] = y_lds[i];
   }
 }
 
@@ -471,12 +488,18 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     if (jx >= 0) ftab[jx] = lane;
     wave_lds_sync();
     const bool dup = (jx >= 0) && (ftab[jx] != lane);
-    const int my_le = (lane < N) ? ftab[lane] : -1;              // lane f holds the edge lane that targets frame f
     wave_lds_sync();
-    if (mixed || __ballot(dup) != 0ULL) { accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane); continue; }
+    // slot of every edge in the wave's scratch: its target frame if that is optimised (distinct per edge), else a slot
+    // behind the N frame slots (fixed target frames only matter for the source-frame sums)
+    const unsigned long long fixm = __ballot(act && jx < 0);
+    const int nslot = N + __popcll(fixm);
+    if (mixed || __ballot(dup) != 0ULL || nslot > 64) { accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane); continue; }
+    const int slot = (jx >= 0) ? jx : N + __popcll(fixm & ((1ULL << lane) - 1ULL));
 
-    // ---- per-edge quantities into the wave's scratch; the patch's E column into `col`
+    // ---- per-edge quantities into the wave's scratch [row][slot]; the patch's E column into `col`
     for (int i = lane; i < n6; i += 64) col[i] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < SCR_ROWS; r++) scr[r * 64 + lane] = 0.0f;          // frames without an edge read zeros
     const float wz0 = T.w[0] * T.Jz[0], wz1 = T.w[1] * T.Jz[1];
     const float wr0 = T.w[0] * T.r[0], wr1 = T.w[1] * T.r[1];
     float Csum = wz0 * T.Jz[0] + wz1 * T.Jz[1];
@@ -486,22 +509,25 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     for (int c = 0; c < 6; c++) {
       ej[c] = (jx >= 0) ? (wz0 * T.Jj[0][c] + wz1 * T.Jj[1][c]) : 0.0f;       // E_j += w Jz Jj   (ba_cuda.cu:311)
       ei[c] = (ix >= 0) ? -(wz0 * T.Ji[0][c] + wz1 * T.Ji[1][c]) : 0.0f;      // E_i -= w Jz Ji   (:309)
-      scr[c * 64 + lane] = T.Jj[0][c];
-      scr[(6 + c) * 64 + lane] = T.Jj[1][c];
-      scr[(12 + c) * 64 + lane] = (ix >= 0) ? T.Ji[0][c] : 0.0f;
-      scr[(18 + c) * 64 + lane] = (ix >= 0) ? T.Ji[1][c] : 0.0f;
     }
-    scr[24 * 64 + lane] = T.w[0]; scr[25 * 64 + lane] = T.w[1];
-    scr[26 * 64 + lane] = wr0;    scr[27 * 64 + lane] = wr1;
+    wave_lds_sync();
     if (act) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        scr[c * 64 + slot] = T.Jj[0][c];
+        scr[(6 + c) * 64 + slot] = T.Jj[1][c];
+        scr[(12 + c) * 64 + slot] = (ix >= 0) ? T.Ji[0][c] : 0.0f;
+        scr[(18 + c) * 64 + slot] = (ix >= 0) ? T.Ji[1][c] : 0.0f;
+      }
+      scr[24 * 64 + slot] = T.w[0]; scr[25 * 64 + slot] = T.w[1];
+      scr[26 * 64 + slot] = wr0;    scr[27 * 64 + slot] = wr1;
       float* rec = edge_e + ((int64_t)(a0 + lane)) * 12;
 #pragma unroll
       for (int c = 0; c < 6; c++) { rec[c] = ej[c]; rec[6 + c] = ei[c]; }
-    }
-    wave_lds_sync();
-    if (jx >= 0) {
+      if (jx >= 0) {
 #pragma unroll
-      for (int c = 0; c < 6; c++) col[6 * jx + c] = ej[c];      // distinct target frames: plain stores
+        for (int c = 0; c < 6; c++) col[6 * jx + c] = ej[c];    // distinct target frames: plain stores
+      }
     }
     Csum = wave_sum(Csum);
     usum = wave_sum(usum);
@@ -514,41 +540,76 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     }
     const float Q = 1.0f / (Csum + K.lm);                       // ba_cuda.cu:492
     if (lane == 0) { patch_rec[(int64_t)s * 2] = Q; patch_rec[(int64_t)s * 2 + 1] = usum; }
-    unsigned fmask = wave_or((jx >= 0 ? 1u << jx : 0u) | (ix >= 0 ? 1u << ix : 0u));
     wave_lds_sync();
     if (N == 0) continue;
 
-    // ---- fold the patch into the register-resident block triangle (wave-uniform control flow)
-    int blk = 0;
+    // ---- fold the patch into the register-resident block triangle.  Everything a lane needs is pulled into registers
+    //      with wide LDS reads first (frame slots 0..NSL-1: element [pa] / [pb] of every Jacobian row), then the 6x6 block
+    //      entries are pure register arithmetic with no branches; slots without an edge hold zeros, block rows >= N are
+    //      computed but never flushed.
+    {
+      constexpr int NSL = ((NMAX + 3) / 4) * 4;
+      auto ld4 = [&](int row, int g4, float (&o)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(scr + row * 64 + 4 * g4);
+        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+      };
+      {
+        // pass 1: Schur rank-1 term and the target-frame diagonal blocks
+        float cr[NSL], cc[NSL], Dg[NSL];
 #pragma unroll
-    for (int fr = 0; fr < NMAX; fr++) {
+        for (int g4 = 0; g4 < NSL / 4; g4++) {
+          float jxa[4], jxb[4], jya[4], jyb[4], w0[4], w1[4];
+          ld4(pa, g4, jxa); ld4(pb, g4, jxb); ld4(6 + pa, g4, jya); ld4(6 + pb, g4, jyb); ld4(24, g4, w0); ld4(25, g4, w1);
 #pragma unroll
-      for (int fc = 0; fc <= fr; fc++, blk++) {
-        if (fr < N && ((fmask >> fr) & 1u) && ((fmask >> fc) & 1u)) {
-          float v = -Q * col[6 * fr + pa] * col[6 * fc + pb];   // Schur: S -= Q e e^T  (:511)
-          const int le_r = __builtin_amdgcn_readlane(my_le, fr);
-          const int le_c = __builtin_amdgcn_readlane(my_le, fc);
-          if (fr == fc) {
-            if (le_r >= 0)                                        // B_jj += w Jj Jj^T  (:299)
-              v += scr[24 * 64 + le_r] * scr[pa * 64 + le_r] * scr[pb * 64 + le_r] +
-                   scr[25 * 64 + le_r] * scr[(6 + pa) * 64 + le_r] * scr[(6 + pb) * 64 + le_r];
-            if (fr == src) {
-              for (int q = 0; q < m; q++)                         // B_ii += sum over the patch's edges of w Ji Ji^T  (:297)
-                v += scr[24 * 64 + q] * scr[(12 + pa) * 64 + q] * scr[(12 + pb) * 64 + q] +
-                     scr[25 * 64 + q] * scr[(18 + pa) * 64 + q] * scr[(18 + pb) * 64 + q];
-              if (le_r >= 0)                                      // self edge: B_ij + B_ji land on the diagonal block
-                v -= scr[24 * 64 + le_r] * (scr[(12 + pa) * 64 + le_r] * scr[pb * 64 + le_r] + scr[pa * 64 + le_r] * scr[(12 + pb) * 64 + le_r]) +
-                     scr[25 * 64 + le_r] * (scr[(18 + pa) * 64 + le_r] * scr[(6 + pb) * 64 + le_r] + scr[(6 + pa) * 64 + le_r] * scr[(18 + pb) * 64 + le_r]);
-            }
-          } else {
-            if (fc == src && le_r >= 0)                           // block (j,i) = -w Jj Ji^T  (:303)
-              v -= scr[24 * 64 + le_r] * scr[pa * 64 + le_r] * scr[(12 + pb) * 64 + le_r] +
-                   scr[25 * 64 + le_r] * scr[(6 + pa) * 64 + le_r] * scr[(18 + pb) * 64 + le_r];
-            if (fr == src && le_c >= 0)                           // block (i,j) = -w Ji Jj^T  (:302)
-              v -= scr[24 * 64 + le_c] * scr[(12 + pa) * 64 + le_c] * scr[pb * 64 + le_c] +
-                   scr[25 * 64 + le_c] * scr[(18 + pa) * 64 + le_c] * scr[(6 + pb) * 64 + le_c];
+          for (int u = 0; u < 4; u++) {
+            const int f = 4 * g4 + u;
+            Dg[f] = w0[u] * jxa[u] * jxb[u] + w1[u] * jya[u] * jyb[u];            // B_jj += w Jj Jj^T      (:299)
+            cr[f] = col[6 * f + pa];
+            cc[f] = col[6 * f + pb];
           }
-          Sreg[blk] += v;
+        }
+        int blk = 0;
+#pragma unroll
+        for (int fr = 0; fr < NMAX; fr++) {
+#pragma unroll
+          for (int fc = 0; fc <= fr; fc++, blk++) {
+            float v = -Q * cr[fr] * cc[fc];                      // Schur: S -= Q e e^T  (:511)
+            if (fr == fc) v += Dg[fr];
+            Sreg[blk] += v;
+          }
+        }
+      }
+      if (src >= 0) {
+        // pass 2 (source frame optimised): row and column `src` get the (i,j) / (j,i) blocks, the diagonal gets B_ii;
+        // a self edge (target == source) puts B_ij + B_ji on the diagonal as well
+        float Rr[NSL], Cq[NSL];
+        float bii = 0.0f;
+#pragma unroll
+        for (int g4 = 0; g4 < NSL / 4; g4++) {
+          float jxa[4], jxb[4], jya[4], jyb[4], ixa[4], ixb[4], iya[4], iyb[4], w0[4], w1[4];
+          ld4(pa, g4, jxa); ld4(pb, g4, jxb); ld4(6 + pa, g4, jya); ld4(6 + pb, g4, jyb);
+          ld4(12 + pa, g4, ixa); ld4(12 + pb, g4, ixb); ld4(18 + pa, g4, iya); ld4(18 + pb, g4, iyb);
+          ld4(24, g4, w0); ld4(25, g4, w1);
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int f = 4 * g4 + u;
+            Rr[f] = w0[u] * jxa[u] * ixb[u] + w1[u] * jya[u] * iyb[u];            // block (j,i): w Jj Ji^T  (:303)
+            Cq[f] = w0[u] * ixa[u] * jxb[u] + w1[u] * iya[u] * jyb[u];            // block (i,j): w Ji Jj^T  (:302)
+            bii += w0[u] * ixa[u] * ixb[u] + w1[u] * iya[u] * iyb[u];             // B_ii += w Ji Ji^T      (:297)
+          }
+        }
+        for (int q = NSL; q < nslot; q++)                        // more fixed-target edges than spare slots (rare)
+          bii += scr[24 * 64 + q] * scr[(12 + pa) * 64 + q] * scr[(12 + pb) * 64 + q] +
+                 scr[25 * 64 + q] * scr[(18 + pa) * 64 + q] * scr[(18 + pb) * 64 + q];
+#pragma unroll
+        for (int sf = 0; sf < NMAX; sf++) {
+          if (src == sf) {                                       // wave-uniform
+#pragma unroll
+            for (int fc = 0; fc < sf; fc++) Sreg[sf * (sf + 1) / 2 + fc] -= Cq[fc];
+#pragma unroll
+            for (int fr = sf + 1; fr < NMAX; fr++) Sreg[fr * (fr + 1) / 2 + sf] -= Rr[fr];
+            Sreg[sf * (sf + 1) / 2 + sf] += bii - (Rr[sf] + Cq[sf]);
+          }
         }
       }
     }
@@ -556,58 +617,73 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
 #pragma unroll
     for (int g = 0; g < 2; g++) {
       const int r = lane + 64 * g;
-      const int f = min(r / 6, N - 1), a = r - 6 * (r / 6);
-      const int le = ftab_lookup(my_le, f);                       // shuffle while every lane is still active
       if (r < n6) {
+        const int f = r / 6, a = r - 6 * f;
         float v = -Q * usum * col[r];
-        if (le >= 0) v += scr[26 * 64 + le] * scr[a * 64 + le] + scr[27 * 64 + le] * scr[(6 + a) * 64 + le];
+        v += scr[26 * 64 + f] * scr[a * 64 + f] + scr[27 * 64 + f] * scr[(6 + a) * 64 + f];
         if (f == src)
-          for (int q = 0; q < m; q++) v -= scr[26 * 64 + q] * scr[(12 + a) * 64 + q] + scr[27 * 64 + q] * scr[(18 + a) * 64 + q];
+          for (int q = 0; q < nslot; q++) v -= scr[26 * 64 + q] * scr[(12 + a) * 64 + q] + scr[27 * 64 + q] * scr[(18 + a) * 64 + q];
         yreg[g] += v;
       }
     }
     wave_lds_sync();
   }
 
-  // ---- add the 8 register copies into the LDS system, one wave at a time (fixed order)
-  __syncthreads();
-  for (int w = 0; w < REG_WAVES; w++) {
-    if (wave == w && N > 0) {
-      if (lane < 36) {
-        int blk = 0;
+  // ---- every wave parks its register copy in its own LDS slab (all waves at once), then the workgroup adds the slabs
+  //      and the atomic-path system in a fixed order and writes the compact partial
+  float* tri_all = scr_all + REG_WAVES * (SCR_ROWS * 64);     // [REG_WAVES][nt + n6]
+  const int nt = tri_blocks(N) * 36;
+  if (N > 0) {
+    float* tri = tri_all + wave * (nt + n6);
+    if (lane < 36) {
+      int blk = 0;
 #pragma unroll
-        for (int fr = 0; fr < NMAX; fr++) {
+      for (int fr = 0; fr < NMAX; fr++) {
 #pragma unroll
-          for (int fc = 0; fc <= fr; fc++, blk++) {
-            if (fr < N && (fr != fc || pb <= pa)) S_lds[(6 * fr + pa) * LD + 6 * fc + pb] += Sreg[blk];
-          }
+        for (int fc = 0; fc <= fr; fc++, blk++) {
+          if (fr < N) tri[blk * 36 + lane] = Sreg[blk];
         }
       }
-#pragma unroll
-      for (int g = 0; g < 2; g++) if (lane + 64 * g < n6) y_lds[lane + 64 * g] += yreg[g];
     }
-    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; g++) if (lane + 64 * g < n6) tri[nt + lane + 64 * g] = yreg[g];
   }
+  __syncthreads();
   if (N > 0) {
-    float* out = partials + (int64_t)blockIdx.x * (n6 * LD + n6);
-    for (int i = tid; i < n6 * LD + n6; i += REG_THREADS) out[i] = smem[i];
+    float* out = partials + (int64_t)blockIdx.x * (nt + n6);
+    for (int i = tid; i < nt + n6; i += REG_THREADS) {
+      float v;
+      if (i < nt) {
+        int fr, fc;
+        block_of(i / 36, fr, fc);
+        const int ab = i % 36;
+        v = S_lds[(6 * fr + ab / 6) * LD + 6 * fc + ab % 6];
+      } else v = y_lds[i - nt];
+#pragma unroll
+      for (int w = 0; w < REG_WAVES; w++) v += tri_all[w * (nt + n6) + i];
+      out[i] = v;
+    }
   }
 }
 
-// S = sum of partial lower triangles, mirrored; S_dd <- S_dd*(1+1e-4)+1 (ba_cuda.cu:517-518); y = sum.
-// 256-thread workgroups: wave g sums partials [g*n_part/4, (g+1)*n_part/4) for 64 consecutive outputs (coalesced,
-// 8 loads in flight), the four wave results are combined through LDS in a fixed order.
+// S = sum of the compact partials, mirrored; S_dd <- S_dd*(1+1e-4)+1 (ba_cuda.cu:517-518); y = sum.
+// 256-thread workgroups: wave g sums partials [g*n_part/4, (g+1)*n_part/4) for 64 consecutive outputs (8 loads in
+// flight), the four wave results are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void k_ba_reduce(const float* __restrict__ partials, int n_part, int N, float* __restrict__ S,
                                                    float* __restrict__ y) {
   __shared__ float s_sum[4][64];
-  const int n6 = 6 * N, LD = n6 + 1, stride = n6 * LD + n6;
+  const int n6 = 6 * N, nt = tri_blocks(N) * 36, stride = nt + n6;
   const int total = n6 * n6 + n6;
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int o = blockIdx.x * 64 + lane;
   int r = 0, c = 1, src = 0;
   if (o < total) {
-    if (o < n6 * n6) { r = o / n6; c = o % n6; src = max(r, c) * LD + min(r, c); }
-    else src = n6 * LD + (o - n6 * n6);
+    if (o < n6 * n6) {
+      r = o / n6; c = o % n6;
+      int fr = r / 6, a = r % 6, fc = c / 6, b = c % 6;
+      if (fr < fc || (fr == fc && a < b)) { int t = fr; fr = fc; fc = t; t = a; a = b; b = t; }   // mirror
+      src = (fr * (fr + 1) / 2 + fc) * 36 + a * 6 + b;
+    } else src = nt + (o - n6 * n6);
   }
   const int per = (n_part + 3) / 4;
   const int p0 = g * per, p1 = min(n_part, p0 + per);
@@ -1006,7 +1082,8 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
   const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 36 * (size_t)N + n6 + 4);
   const int dbg = getenv("DEVO_BA_ABLATE") ? atoi(getenv("DEVO_BA_ABLATE")) : 0;
   const bool use_reg = (N <= 16) && !(dbg & 8);
-  const size_t acc_lds_used = use_reg ? sizeof(float) * (n6 * (n6 + 1) + n6 + REG_WAVES * n6 + 4 + REG_WAVES * SCR_ROWS * 64) : acc_lds;
+  const size_t acc_lds_used = use_reg ? sizeof(float) * (n6 * (n6 + 1) + n6 + REG_WAVES * n6 + 4 + REG_WAVES * SCR_ROWS * 64 +
+                                                        REG_WAVES * ((size_t)N * (N + 1) / 2 * 36 + n6)) : acc_lds;
   typedef void (*acc_fn_t)(const float*, const float*, const float*, const float*, const float*, const float*, const int64_t*,
                            const int64_t*, const int64_t*, const int*, const int*, const BaMeta*, int, int, int, float*, float*,
                            float*, int);

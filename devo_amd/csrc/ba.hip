@@ -53,23 +53,30 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // In-place exclusive scan of data[0..n) by ONE workgroup of 1024 threads; data[n] = total (returned to all).
+// Thread chunks -> wave scan with shuffles -> the 16 wave totals scanned by wave 0: two barriers.  s_part: >= 48 ints.
 __device__ __forceinline__ int block_excl_scan_1024(int* data, int n, int* s_part) {
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int chunk = (n + 1023) / 1024;
   const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
   int s = 0;
   for (int i = lo; i < hi; i++) s += data[i];
-  s_part[t] = s;
+  int x = s;                                    // inclusive scan of the chunk sums inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(x, off); if (lane >= off) x += v; }
+  if (lane == 63) s_part[wave] = x;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    int v = (t >= off) ? s_part[t - off] : 0;
-    __syncthreads();
-    s_part[t] += v;
-    __syncthreads();
+  if (wave == 0) {
+    const int w = (lane < 16) ? s_part[lane] : 0;
+    int y = w;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) { const int v = __shfl_up(y, off); if (lane >= off) y += v; }
+    if (lane < 16) s_part[16 + lane] = y - w;   // exclusive prefix of every wave
+    if (lane == 15) s_part[32] = y;             // grand total
   }
-  int run = s_part[t] - s;                      // exclusive prefix of this thread's chunk
+  __syncthreads();
+  int run = s_part[16 + wave] + x - s;          // exclusive prefix of this thread's chunk
   for (int i = lo; i < hi; i++) { int v = data[i]; data[i] = run; run += v; }
-  const int total = s_part[1023];
+  const int total = s_part[32];
   if (t == 1023) data[n] = total;
   __syncthreads();
   return total;
@@ -127,6 +134,8 @@ __global__ void k_sort_segments(const int* __restrict__ seg_start, const int* __
 // patches — DEVO's sliding window is ~2k patches); otherwise the same arrays in the workspace are used.
 constexpr int PREP_FLAGS_LDS = 16384;
 constexpr int PREP_SEGS_LDS = 8192;
+constexpr int PREP_CACHE = 32;               // edges per thread kept in registers (E <= 32768: one round trip to memory)
+template <int CACHE>      // CACHE = 0: kk is re-read by every pass; else ceil(E / 1024) <= CACHE edges per thread in registers
 __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
                                                      int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a) {
   extern __shared__ int s_mem[];
@@ -137,9 +146,31 @@ __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__
   __shared__ int s_min, s_max;
   const int t = threadIdx.x;
   if (t == 0) { s_min = 0x7fffffff; s_max = -1; }
+  // patch id of edge t + 1024 i (or -1: out of range / no edge).  CACHED: all loads in flight at once, every later
+  // pass runs from registers; otherwise kk is re-read by every pass.
+  constexpr bool CACHED = CACHE > 0;
+  int kreg[CACHED ? CACHE : 1];
+  auto patch_of = [&](int i) -> int {
+    if (CACHED) return kreg[i];
+    const int e = t + 1024 * i;
+    if (e >= E) return -1;
+    const int64_t k = kk[e];
+    return (k >= 0 && k < Np) ? (int)k : -1;
+  };
+  const int iters = CACHED ? CACHE : (E + 1023) / 1024;
+  if (CACHED) {
+#pragma unroll
+    for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
+      const int e = t + 1024 * i;
+      int64_t k = -1;
+      if (e < E) k = kk[e];
+      kreg[i] = (k >= 0 && k < Np) ? (int)k : -1;
+    }
+  }
   __syncthreads();
   int lo = 0x7fffffff, hi = -1;
-  for (int e = t; e < E; e += 1024) { const int64_t k = kk[e]; if (k >= 0 && k < Np) { lo = min(lo, (int)k); hi = max(hi, (int)k); } }
+#pragma unroll
+  for (int i = 0; i < iters; i++) { const int k = patch_of(i); if (k >= 0) { lo = min(lo, k); hi = max(hi, k); } }
   for (int off = 32; off >= 1; off >>= 1) { lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); }
   if ((t & 63) == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
   __syncthreads();
@@ -148,7 +179,8 @@ __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__
   int* rank = (Rg <= PREP_FLAGS_LDS) ? s_flags : g_rank;
   for (int i = t; i <= Rg; i += 1024) rank[i] = 0;
   __syncthreads();
-  for (int e = t; e < E; e += 1024) { const int64_t k = kk[e]; if (k >= 0 && k < Np) rank[(int)k - kmin] = 1; }
+#pragma unroll
+  for (int i = 0; i < iters; i++) { const int k = patch_of(i); if (k >= 0) rank[k - kmin] = 1; }
   __syncthreads();
   const int n_seg = block_excl_scan_1024(rank, Rg, s_part);
   if (t == 0) { meta->n_seg = n_seg; meta->fail = 0; }
@@ -157,17 +189,45 @@ __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__
   for (int i = t; i <= n_seg; i += 1024) counts[i] = 0;
   for (int i = t; i < n_seg; i += 1024) cursor[i] = 0;
   __syncthreads();
-  for (int e = t; e < E; e += 1024) {
-    const int64_t k = kk[e];
-    const int r = (k >= 0 && k < Np) ? rank[(int)k - kmin] : 0;
-    ku[e] = r;
-    atomicAdd(&counts[r], 1);
+  // Runs of consecutive lanes with the same segment (the edges of a patch are usually adjacent in the edge list) share
+  // ONE LDS atomic issued by the first lane of the run — same-address LDS atomics serialise, and this workgroup is the
+  // only one running.  (All lanes execute the ballots / shuffles; only the stores are guarded.)
+  const int lane = t & 63;
+  auto run_of = [&](int key, int& head_lane, int& next_head) {
+    const int prev = __shfl_up(key, 1);
+    const bool head = (lane == 0) || (prev != key);
+    const unsigned long long H = __ballot(head);
+    const unsigned long long upto = (2ULL << lane) - 1ULL;            // bits 0..lane (all ones for lane 63)
+    head_lane = 63 - __clzll((long long)(H & upto));
+    const unsigned long long above = H & ~upto;
+    next_head = above ? __ffsll((long long)above) - 1 : 64;
+  };
+  // segment of every edge (edges with a bad patch id go to segment 0, like before)
+#pragma unroll
+  for (int i = 0; i < iters; i++) {
+    const int e = t + 1024 * i;
+    int r = -1;
+    if (e < E) { const int k = patch_of(i); r = (k >= 0) ? rank[k - kmin] : 0; ku[e] = r; }
+    if (CACHED) kreg[i] = r;
+    int hl, nh;
+    run_of(r, hl, nh);
+    if (r >= 0 && hl == lane) atomicAdd(&counts[r], nh - lane);
   }
   for (int p = t; p < Rg; p += 1024)
     if (rank[p + 1] != rank[p]) kx[rank[p]] = kmin + p;
   __syncthreads();
   block_excl_scan_1024(counts, n_seg, s_part);
-  for (int e = t; e < E; e += 1024) { const int sgm = ku[e]; perm_a[counts[sgm] + atomicAdd(&cursor[sgm], 1)] = e; }
+#pragma unroll
+  for (int i = 0; i < iters; i++) {
+    const int e = t + 1024 * i;
+    const int sgm = CACHED ? kreg[i] : (e < E ? ku[e] : -1);
+    int hl, nh;
+    run_of(sgm, hl, nh);
+    int base = 0;
+    if (sgm >= 0 && hl == lane) base = atomicAdd(&cursor[sgm], nh - lane);
+    base = __shfl(base, hl);
+    if (sgm >= 0) perm_a[counts[sgm] + base + (lane - hl)] = e;
+  }
   // publish the segment starts: entries beyond n_seg = E so that any reader sees empty tails
   for (int i = t; i <= max_seg; i += 1024) g_counts[i] = (i <= n_seg) ? counts[i] : E;
 }
@@ -721,9 +781,8 @@ __device__ __forceinline__ bool chol6(float L[6][6], float inv[6]) {   // in-reg
 #pragma unroll
     for (int k = 0; k < c; k++) d -= L[c][k] * L[c][k];
     if (!(d > 0.0f)) ok = false;
-    const float ld = sqrtf(d);
-    inv[c] = 1.0f / ld;
-    L[c][c] = ld;
+    inv[c] = __frsqrt_rn(d);                     // one v_rsq_f32 on the serial path instead of sqrt + divide
+    L[c][c] = d * inv[c];
 #pragma unroll
     for (int a = c + 1; a < 6; a++) {
       float v = L[a][c];
@@ -735,23 +794,44 @@ __device__ __forceinline__ bool chol6(float L[6][6], float inv[6]) {   // in-reg
   return ok;
 }
 
+constexpr int SOLVE_TRAIL = 4;      // trailing-update entries per thread with precomputed coordinates (covers N <= 14)
+
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restrict__ S, const float* __restrict__ y, int N,
                                                             float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag) {
   extern __shared__ __attribute__((aligned(16))) float A[];
   __shared__ int s_fail;
   const int n6 = 6 * N, LD = n6 + 1, rows = n6 + 1;
   float* Ld = A + rows * LD;                    // [N][36] factored diagonal blocks
-  float* xs = Ld + N * 36;                      // [n6] solution
   const int tid = threadIdx.x;
   if (tid == 0) s_fail = 0;
+#ifdef DEVO_SOLVE_TRACE
+  long long c0 = clock64(), cl = 0, cp = 0, ct = 0, cb = 0, cx;
+#endif
   for (int i = tid; i < n6 * n6; i += SOLVE_THREADS) { int r = i / n6, c = i % n6; A[r * LD + c] = S[i]; }
   for (int i = tid; i < n6; i += SOLVE_THREADS) A[n6 * LD + i] = y[i];
+  // (row, column) of trailing-update entry idx = tid + 1024 k in a lower triangle, relative to the trailing corner:
+  // the same for every block step
+  int tr[SOLVE_TRAIL], tc[SOLVE_TRAIL];
+#pragma unroll
+  for (int k = 0; k < SOLVE_TRAIL; k++) {
+    const int idx = tid + SOLVE_THREADS * k;
+    int r = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    while (r * (r + 1) / 2 > idx) r--;
+    while ((r + 1) * (r + 2) / 2 <= idx) r++;
+    tr[k] = r; tc[k] = idx - r * (r + 1) / 2;
+  }
   __syncthreads();
   if (meta->fail) return;                        // an earlier iteration broke down: the reference call has thrown by now
+#ifdef DEVO_SOLVE_TRACE
+  cl = clock64() - c0;
+#endif
 
   for (int jb = 0; jb < N; jb++) {
     const int j0 = 6 * jb;
     const int r = j0 + 6 + tid;                  // this thread's panel row (if any)
+#ifdef DEVO_SOLVE_TRACE
+    cx = clock64();
+#endif
     if (r < rows || tid == 0) {
       float L[6][6];
 #pragma unroll
@@ -781,26 +861,44 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
       }
     }
     __syncthreads();
+#ifdef DEVO_SOLVE_TRACE
+    cp += clock64() - cx; cx = clock64();
+#endif
     // trailing update of the lower triangle (and of the rhs row)
     const int rem = rows - (j0 + 6);
-    for (int idx = tid; idx < rem * (rem + 1) / 2; idx += SOLVE_THREADS) {      // lower triangle only
-      int tr = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-      while (tr * (tr + 1) / 2 > idx) tr--;
-      while ((tr + 1) * (tr + 2) / 2 <= idx) tr++;
-      const int rr = j0 + 6 + tr, cc = j0 + 6 + (idx - tr * (tr + 1) / 2);
-      if (cc >= n6) continue;
+    const int cnt = rem * (rem + 1) / 2;
+    auto update = [&](int trr, int tcc) {
+      const int rr = j0 + 6 + trr, cc = j0 + 6 + tcc;
+      if (cc >= n6) return;                      // the rhs row has no diagonal entry
       float v = 0.0f;
 #pragma unroll
       for (int k = 0; k < 6; k++) v += A[rr * LD + j0 + k] * A[cc * LD + j0 + k];
       A[rr * LD + cc] -= v;
+    };
+#pragma unroll
+    for (int k = 0; k < SOLVE_TRAIL; k++)
+      if (tid + SOLVE_THREADS * k < cnt) update(tr[k], tc[k]);
+    for (int idx = tid + SOLVE_THREADS * SOLVE_TRAIL; idx < cnt; idx += SOLVE_THREADS) {     // N > 14 only
+      int r2 = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+      while (r2 * (r2 + 1) / 2 > idx) r2--;
+      while ((r2 + 1) * (r2 + 2) / 2 <= idx) r2++;
+      update(r2, idx - r2 * (r2 + 1) / 2);
     }
     __syncthreads();
+#ifdef DEVO_SOLVE_TRACE
+    ct += clock64() - cx;
+#endif
   }
   if (s_fail) {
     if (tid == 0) { meta->fail = iter + 1; if (status_flag) *status_flag = iter + 1; }
     return;
   }
-  // back substitution  L^T x = z  (z = row n6), bottom-up by blocks; every thread solves the 6x6 triangle itself
+  // back substitution  L^T x = z  (z = row n6), bottom-up by blocks, by ONE wave: no workgroup barriers (the other
+  // waves are done).  Every lane solves the 6x6 triangle itself (uniform LDS reads), then updates its rows of z.
+  if (tid >= 64) return;
+#ifdef DEVO_SOLVE_TRACE
+  cx = clock64();
+#endif
   float* z = A + n6 * LD;
   for (int jb = N - 1; jb >= 0; jb--) {
     const int j0 = 6 * jb;
@@ -812,20 +910,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
       for (int k = c + 1; k < 6; k++) v -= Ld[jb * 36 + k * 6 + c] * xb[k];
       xb[c] = v * Ld[jb * 36 + c * 6 + c];
     }
-    if (tid == 0) {
-#pragma unroll
-      for (int c = 0; c < 6; c++) xs[j0 + c] = xb[c];
-    }
-    __syncthreads();                             // all reads of z[j0..j0+5] done before rows above are updated
-    for (int r = tid; r < j0; r += SOLVE_THREADS) {
+    if (tid < 6) dX[j0 + tid] = (tid == 0) ? xb[0] : (tid == 1) ? xb[1] : (tid == 2) ? xb[2] : (tid == 3) ? xb[3] : (tid == 4) ? xb[4] : xb[5];
+    wave_lds_sync();                             // all reads of z[j0..j0+5] done before rows above are updated
+    for (int r = tid; r < j0; r += 64) {
       float v = 0.0f;
 #pragma unroll
       for (int k = 0; k < 6; k++) v += A[(j0 + k) * LD + r] * xb[k];
       z[r] -= v;
     }
-    __syncthreads();
+    wave_lds_sync();
   }
-  for (int i = tid; i < n6; i += SOLVE_THREADS) dX[i] = xs[i];
+#ifdef DEVO_SOLVE_TRACE
+  cb = clock64() - cx;
+  if (tid == 0 && iter == 0) printf("solve: load %lld panel %lld trail %lld backsub %lld\n", cl, cp, ct, cb);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------- retract
@@ -1060,9 +1158,20 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
   int rc;
   const size_t prep_lds = sizeof(int) * (1024 + PREP_FLAGS_LDS + 1 + 2 * PREP_SEGS_LDS + 1 + 8);
   static bool prep_attr = false;
-  if (!prep_attr) { (void)hipFuncSetAttribute((const void*)k_ba_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds); (void)hipGetLastError(); prep_attr = true; }
+  if (!prep_attr) {
+      (void)hipFuncSetAttribute((const void*)k_ba_prepare<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+      (void)hipFuncSetAttribute((const void*)k_ba_prepare<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+      (void)hipFuncSetAttribute((const void*)k_ba_prepare<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+      (void)hipFuncSetAttribute((const void*)k_ba_prepare<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+      (void)hipFuncSetAttribute((const void*)k_ba_prepare<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+      (void)hipGetLastError(); prep_attr = true;
+    }
   if (E <= (1 << 17)) {
-    hipLaunchKernelGGL(k_ba_prepare, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a);
+    typedef void (*prep_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*);
+    const int ept = (E + 1023) / 1024;                         // edges per thread
+    prep_fn_t prep = ept <= 8 ? k_ba_prepare<8> : ept <= 16 ? k_ba_prepare<16> : ept <= 24 ? k_ba_prepare<24> :
+                     ept <= 32 ? k_ba_prepare<32> : k_ba_prepare<0>;
+    hipLaunchKernelGGL(prep, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a);
     hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, &meta->n_seg, perm_a, perm_b);
   } else {
     // (meta, rank, counts, cursor are contiguous at the head of the workspace)

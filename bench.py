@@ -32,7 +32,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"])
-    ap.add_argument("--layout", default="cl", choices=["cl", "nchw"], help="storage of the feature pyramid")
+    ap.add_argument("--layout", default="blk8", choices=["blk8", "cl", "nchw"],
+                    help="storage of the feature pyramid: channel-blocked [n,C/8,H,W,8] / channels-last / the reference's NCHW")
+    ap.add_argument("--overlap-prepare", action="store_true",
+                    help="run the BA index preparation (cuda_ba.prepare) on a side stream under the lookup instead of inside "
+                         "cuda_ba.forward (measured slower on MI355X: the fork/join costs more than the 26 us it hides)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=50, help="launch pairs timed for the roofline figure")
@@ -56,6 +60,8 @@ def build_inputs(cfg, seed, device, dtype, layout):
     f0, f1, g = f0.to(dtype), f1.to(dtype), gmap.to(device).to(dtype)
     if layout == "cl":
         f0, f1 = altcorr.channels_last(f0), altcorr.channels_last(f1)
+    elif layout == "blk8":
+        f0, f1 = altcorr.channel_blocked(f0, 8), altcorr.channel_blocked(f1, 8)
     d.update(pyramid=[f0, f1], gmap=g.contiguous())
     d["poses"] = d["poses0"].clone()
     d["patches"] = d["patches0"].clone()
@@ -106,14 +112,25 @@ def main():
         for lvl, (fm, s) in enumerate(zip(d["pyramid"], (1, 4))):
             cuda_corr.forward_into(corr_out, d["gmap"], fm, coords / s, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order)
 
+    prep_stream = torch.cuda.Stream() if args.overlap_prepare else None
+
     def step():
+        cur = torch.cuda.current_stream()
+        if prep_stream is not None:
+            # the index half of the BA (unique patches, edges grouped by patch) depends on kk only: it runs on a second
+            # stream under the reprojection + lookup (a fork/join inside the captured graph)
+            prep_stream.wait_stream(cur)
+            with torch.cuda.stream(prep_stream):
+                cuda_ba.prepare(d["kk"], Np, n - 1, ws)
         d["poses"].copy_(d["poses0"])
         d["patches"].copy_(d["patches0"])
         coords = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
         lookup(coords)
         target = coords[:, :, :, 1, 1] + d["delta"]                        # devo.py:330
+        if prep_stream is not None:
+            cur.wait_stream(prep_stream)
         cuda_ba.forward(d["poses"], d["patches"], d["intr"], target, d["weight"], d["lmbda"],
-                        d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
+                        d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws, prepared=prep_stream is not None)
 
     # ---- warm up eagerly once (library load, kernel code upload), then capture
     step()
@@ -190,11 +207,12 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.workload}: M={M} patches/frame, n={n} keyframes, E={E} edges, r={R}, "
                                f"2 pyramid levels {cfg['H']}x{cfg['W']} + /4, C={cfg['C']}, 2 GN iterations, "
-                               f"pyramid layout {args.layout}, {'HIP graph' if not args.no_graph else 'eager'}",
+                               f"pyramid layout {args.layout}, {'HIP graph' if not args.no_graph else 'eager'}"
+                               f"{', BA index preparation on a second stream' if args.overlap_prepare else ''}",
                    "parallelism": f"replicas x{world}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "corr_fwd_cl_kernel" if args.layout == "cl" else "corr_fwd_generic_kernel",
+                     "kernel": "corr_fwd_generic_kernel" if args.layout == "nchw" else "corr_fwd_cl_kernel",
                      "alg_bytes_per_launch": int(b_alg), "us_per_launch": round(t_launch * 1e6, 2)},
         "ba": {"gpu_ms": round(t_ba_gpu * 1e3, 4)},
     }

@@ -16,9 +16,22 @@ def workspace(E, Np, N, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
-def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations, ws=None, status=None):
+def prepare(kk, n_patch_slots, n_opt, ws):
+    """Index half of cuda_ba.forward (ba_cuda.cu:435-437: unique patches, edges grouped by patch), which depends on
+    `kk` only: call it early — e.g. on a side stream while the correlation lookup runs — and pass `prepared=True` to
+    forward().  `n_patch_slots` = patches.shape[1], `n_opt` = t1 - t0; `ws` from workspace()."""
+    L.require_gpu(kk, ws)
+    kk = kk.long().contiguous()
+    rc = L.lib().devo_ba_prepare(L.ptr(kk), kk.numel(), int(n_patch_slots), int(n_opt), L.ptr(ws), ws.numel(), L.stream())
+    L.check(rc, "cuda_ba.prepare")
+    return ws
+
+
+def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations, ws=None, status=None,
+            prepared=False):
     """ba.cpp:153.  Mutates `poses` ([1,Nbuf,7]) and `patches` ([1,Np,3,P,P]) in place and returns []
-    (devo/fastba/ba.py:7-8 passes poses.data; devo/devo.py:337 relies on the mutation)."""
+    (devo/fastba/ba.py:7-8 passes poses.data; devo/devo.py:337 relies on the mutation).
+    prepared=True: `ws` already holds the result of prepare() for this kk / t1 - t0."""
     L.require_gpu(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk)
     for name, t in (("poses", poses), ("patches", patches)):
         if t.dtype != torch.float32 or not t.is_contiguous():
@@ -34,9 +47,12 @@ def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t
     lmbda = lmbda.float().reshape(-1).contiguous()
     if ws is None:
         ws = workspace(E, Np, int(t1) - int(t0), poses.device)
-    rc = L.lib().devo_ba_forward(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(target), L.ptr(weight),
-                                 L.ptr(lmbda), L.ptr(ii), L.ptr(jj), L.ptr(kk), E, Nbuf, Np, P, int(t0), int(t1),
-                                 int(iterations), L.ptr(ws), ws.numel(), L.ptr(status), L.stream())
+    if prepared and ws is None:
+        raise RuntimeError("cuda_ba.forward: prepared=True needs the workspace that prepare() filled")
+    fn = L.lib().devo_ba_forward_prepared if prepared else L.lib().devo_ba_forward
+    rc = fn(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(target), L.ptr(weight),
+            L.ptr(lmbda), L.ptr(ii), L.ptr(jj), L.ptr(kk), E, Nbuf, Np, P, int(t0), int(t1),
+            int(iterations), L.ptr(ws), ws.numel(), L.ptr(status), L.stream())
     L.check(rc, "cuda_ba.forward")
     return []
 

@@ -450,8 +450,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
     const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
     const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
-    const int* __restrict__ perm, const int* __restrict__ seg_start, const BaMeta* __restrict__ meta, int P, int t0,
-    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int dbg) {
+    const int* __restrict__ perm, const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int P, int t0,
+    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int dbg, int iter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n6 = 6 * N, LD = n6 + 1;
   float* S_lds = smem;
@@ -464,6 +464,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
   AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, edge_e, intr[0], intr[1], intr[2], intr[3], lmbda[0],
            P, t0, N, n6, LD, dbg};
   const int n_seg = meta->n_seg;
+  if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = 0;     // a prepared graph may be solved many times
   for (int s = blockIdx.x * ACC_WAVES + wave; s < n_seg; s += gridDim.x * ACC_WAVES) {
     const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
     accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane);
@@ -497,8 +498,8 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
     const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
-    const int* __restrict__ perm, const int* __restrict__ seg_start, const BaMeta* __restrict__ meta, int P, int t0,
-    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int dbg) {
+    const int* __restrict__ perm, const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int P, int t0,
+    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int dbg, int iter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n6 = 6 * N, LD = n6 + 1;
   float* S_lds = smem;
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
   float yreg[2] = {0.0f, 0.0f};                                 // rows lane, lane + 64  (n6 <= 96)
 
   const int n_seg = meta->n_seg;
+  if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = 0;     // a prepared graph may be solved many times
   for (int s = blockIdx.x * REG_WAVES + wave; s < n_seg; s += gridDim.x * REG_WAVES) {
     const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
     if (m > 64) { accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane); continue; }
@@ -1125,18 +1127,10 @@ size_t devo_ba_workspace_bytes(int E, int Np, int N) {
   return ba_layout(E, Np, N).total;
 }
 
-int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
-                    const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Nbuf, int Np,
-                    int P, int t0, int t1, int iterations, void* ws, size_t ws_bytes, int* status_flag,
-                    devo_stream_t stream) {
-  const int N = t1 - t0;
-  DEVO_REQUIRE(E >= 0 && Np > 0 && Nbuf > 0 && P > 0, "devo_ba_forward: bad sizes");
-  DEVO_REQUIRE(N >= 0 && t0 >= 0 && t1 <= Nbuf, "devo_ba_forward: bad pose window [%d,%d) for %d poses", t0, t1, Nbuf);
-  if (N > BA_MAXN) { set_error("devo_ba_forward: %d optimised poses > %d supported", N, BA_MAXN); return DEVO_ERR_UNSUPPORTED; }
-  if (E == 0 || iterations <= 0) return DEVO_OK;
+// ---- graph preparation: kx = unique(kk) sorted, ku = inverse (ba_cuda.cu:435-437), edges grouped by patch
+static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, size_t ws_bytes, hipStream_t st) {
   const BaLayout L = ba_layout(E, Np, N);
-  if (ws == nullptr || ws_bytes < L.total) { set_error("devo_ba_forward: workspace %zu < %zu bytes", ws_bytes, L.total); return DEVO_ERR_WORKSPACE; }
-  hipStream_t st = (hipStream_t)stream;
+  if (ws == nullptr || ws_bytes < L.total) { set_error("devo_ba_prepare: workspace %zu < %zu bytes", ws_bytes, L.total); return DEVO_ERR_WORKSPACE; }
   char* w = (char*)ws;
   BaMeta* meta = (BaMeta*)(w + L.meta);
   int* rank = (int*)(w + L.rank);
@@ -1146,26 +1140,16 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
   int* perm_a = (int*)(w + L.perm_a);
   int* perm_b = (int*)(w + L.perm_b);
   int* kx = (int*)(w + L.kx);
-  float* partials = (float*)(w + L.partials);
-  float* S = (float*)(w + L.S);
-  float* y = (float*)(w + L.y);
-  float* dX = (float*)(w + L.dX);
-  float* patch_rec = (float*)(w + L.patch_rec);
-  float* edge_ej = (float*)(w + L.edge_ej);
-
-  // ---- graph preparation: kx = unique(kk) sorted, ku = inverse (ba_cuda.cu:435-437), edges grouped by patch
-  if (status_flag && hipMemsetAsync(status_flag, 0, sizeof(int), st) != hipSuccess) { set_error("devo_ba_forward: memset failed"); return DEVO_ERR_LAUNCH; }
-  int rc;
   const size_t prep_lds = sizeof(int) * (1024 + PREP_FLAGS_LDS + 1 + 2 * PREP_SEGS_LDS + 1 + 8);
   static bool prep_attr = false;
   if (!prep_attr) {
-      (void)hipFuncSetAttribute((const void*)k_ba_prepare<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
-      (void)hipFuncSetAttribute((const void*)k_ba_prepare<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
-      (void)hipFuncSetAttribute((const void*)k_ba_prepare<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
-      (void)hipFuncSetAttribute((const void*)k_ba_prepare<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
-      (void)hipFuncSetAttribute((const void*)k_ba_prepare<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
-      (void)hipGetLastError(); prep_attr = true;
-    }
+    (void)hipFuncSetAttribute((const void*)k_ba_prepare<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+    (void)hipFuncSetAttribute((const void*)k_ba_prepare<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+    (void)hipFuncSetAttribute((const void*)k_ba_prepare<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+    (void)hipFuncSetAttribute((const void*)k_ba_prepare<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+    (void)hipFuncSetAttribute((const void*)k_ba_prepare<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+    (void)hipGetLastError(); prep_attr = true;
+  }
   if (E <= (1 << 17)) {
     typedef void (*prep_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*);
     const int ept = (E + 1023) / 1024;                         // edges per thread
@@ -1175,7 +1159,7 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
     hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, &meta->n_seg, perm_a, perm_b);
   } else {
     // (meta, rank, counts, cursor are contiguous at the head of the workspace)
-    if (hipMemsetAsync(w + L.meta, 0, L.ku - L.meta, st) != hipSuccess) { set_error("devo_ba_forward: memset failed"); return DEVO_ERR_LAUNCH; }
+    if (hipMemsetAsync(w + L.meta, 0, L.ku - L.meta, st) != hipSuccess) { set_error("devo_ba_prepare: memset failed"); return DEVO_ERR_LAUNCH; }
     const int eb = blocks_for(E, 256, 1024);
     hipLaunchKernelGGL(k_flag_ids, dim3(eb), dim3(256), 0, st, kk, E, Np, rank);
     hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, rank, Np, &meta->n_seg);
@@ -1184,7 +1168,59 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
     hipLaunchKernelGGL(k_scatter_edges, dim3(eb), dim3(256), 0, st, ku, E, counts, cursor, perm_a);
     hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, &meta->n_seg, perm_a, perm_b);
   }
-  if ((rc = check_launch("devo_ba_forward(prepare)"))) return rc;
+  return check_launch("devo_ba_prepare");
+}
+
+static int ba_check_args(const char* who, int E, int Nbuf, int Np, int P, int t0, int t1) {
+  const int N = t1 - t0;
+  if (!(E >= 0 && Np > 0 && Nbuf > 0 && P > 0)) { set_error("%s: bad sizes", who); return DEVO_ERR_ARG; }
+  if (!(N >= 0 && t0 >= 0 && t1 <= Nbuf)) { set_error("%s: bad pose window [%d,%d) for %d poses", who, t0, t1, Nbuf); return DEVO_ERR_ARG; }
+  if (N > BA_MAXN) { set_error("%s: %d optimised poses > %d supported", who, N, BA_MAXN); return DEVO_ERR_UNSUPPORTED; }
+  return DEVO_OK;
+}
+
+int devo_ba_prepare(const int64_t* kk, int E, int Np, int N, void* ws, size_t ws_bytes, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && Np > 0 && N >= 0, "devo_ba_prepare: bad sizes");
+  if (N > BA_MAXN) { set_error("devo_ba_prepare: %d optimised poses > %d supported", N, BA_MAXN); return DEVO_ERR_UNSUPPORTED; }
+  if (E == 0) return DEVO_OK;
+  return ba_prepare_impl(kk, E, Np, N, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
+                    const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Nbuf, int Np,
+                    int P, int t0, int t1, int iterations, void* ws, size_t ws_bytes, int* status_flag,
+                    devo_stream_t stream) {
+  int rc;
+  if ((rc = ba_check_args("devo_ba_forward", E, Nbuf, Np, P, t0, t1))) return rc;
+  if (E == 0 || iterations <= 0) return DEVO_OK;
+  if ((rc = ba_prepare_impl(kk, E, Np, t1 - t0, ws, ws_bytes, (hipStream_t)stream))) return rc;
+  return devo_ba_forward_prepared(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, E, Nbuf, Np, P, t0, t1,
+                                  iterations, ws, ws_bytes, status_flag, stream);
+}
+
+int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
+                             const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Nbuf,
+                             int Np, int P, int t0, int t1, int iterations, void* ws, size_t ws_bytes, int* status_flag,
+                             devo_stream_t stream) {
+  int rc;
+  if ((rc = ba_check_args("devo_ba_forward", E, Nbuf, Np, P, t0, t1))) return rc;
+  const int N = t1 - t0;
+  if (E == 0 || iterations <= 0) return DEVO_OK;
+  const BaLayout L = ba_layout(E, Np, N);
+  if (ws == nullptr || ws_bytes < L.total) { set_error("devo_ba_forward: workspace %zu < %zu bytes", ws_bytes, L.total); return DEVO_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  char* w = (char*)ws;
+  BaMeta* meta = (BaMeta*)(w + L.meta);
+  int* counts = (int*)(w + L.counts);
+  int* perm_b = (int*)(w + L.perm_b);
+  int* kx = (int*)(w + L.kx);
+  float* partials = (float*)(w + L.partials);
+  float* S = (float*)(w + L.S);
+  float* y = (float*)(w + L.y);
+  float* dX = (float*)(w + L.dX);
+  float* patch_rec = (float*)(w + L.patch_rec);
+  float* edge_ej = (float*)(w + L.edge_ej);
+  if (status_flag && hipMemsetAsync(status_flag, 0, sizeof(int), st) != hipSuccess) { set_error("devo_ba_forward: memset failed"); return DEVO_ERR_LAUNCH; }
 
   const size_t n6 = 6 * (size_t)N;
   const size_t acc_lds = sizeof(float) * (n6 * (n6 + 1) + n6 + ACC_WAVES * n6 + 4);
@@ -1194,8 +1230,8 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
   const size_t acc_lds_used = use_reg ? sizeof(float) * (n6 * (n6 + 1) + n6 + REG_WAVES * n6 + 4 + REG_WAVES * SCR_ROWS * 64 +
                                                         REG_WAVES * ((size_t)N * (N + 1) / 2 * 36 + n6)) : acc_lds;
   typedef void (*acc_fn_t)(const float*, const float*, const float*, const float*, const float*, const float*, const int64_t*,
-                           const int64_t*, const int64_t*, const int*, const int*, const BaMeta*, int, int, int, float*, float*,
-                           float*, int);
+                           const int64_t*, const int64_t*, const int*, const int*, BaMeta*, int, int, int, float*, float*,
+                           float*, int, int);
   acc_fn_t acc_fn = k_ba_accumulate;
   if (use_reg) acc_fn = (N <= 8) ? k_ba_accumulate_reg<8> : (N <= 11) ? k_ba_accumulate_reg<11> : (N <= 14) ? k_ba_accumulate_reg<14> : k_ba_accumulate_reg<16>;
   if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
@@ -1208,7 +1244,7 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
   }
   for (int it = 0; it < iterations; it++) {
     hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? REG_THREADS : ACC_THREADS), acc_lds_used, st, poses, patches, intrinsics, target,
-                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, dbg);
+                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, dbg, it);
     if ((rc = check_launch("devo_ba_forward(accumulate)"))) return rc;
     if (N > 0) {
       hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((n6 * n6 + n6 + 63) / 64)), dim3(256), 0, st, partials, L.n_part, N, S, y);

@@ -102,6 +102,18 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
                     const int64_t* kk, int E, int Nbuf, int Np, int P, int t0, int t1, int iterations, void* ws,
                     size_t ws_bytes, int* status_flag, devo_stream_t stream);
 
+/* The same call split in two, for callers that know the graph before target/weight are ready (in DEVO: before the
+ * correlation lookup and the update network, devo/devo.py:213-240): devo_ba_prepare does the index work of
+ * ba_cuda.cu:435-437 (unique patches, edges grouped by patch; depends on kk only) — e.g. on a second stream —
+ * and devo_ba_forward_prepared runs the Gauss-Newton iterations on the prepared workspace.  A prepared workspace
+ * stays valid (any number of forward calls) until kk, E, Np or t1 - t0 change. */
+int devo_ba_prepare(const int64_t* kk, int E, int Np, int N /* t1 - t0 */, void* ws, size_t ws_bytes,
+                    devo_stream_t stream);
+int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsics, const float* target,
+                             const float* weight, const float* lmbda, const int64_t* ii, const int64_t* jj,
+                             const int64_t* kk, int E, int Nbuf, int Np, int P, int t0, int t1, int iterations,
+                             void* ws, size_t ws_bytes, int* status_flag, devo_stream_t stream);
+
 size_t devo_neighbors_workspace_bytes(int E);
 
 /* cuda_ba.neighbors  (ba.cpp:154 -> ba.cpp:104-149): for every edge the previous / next edge of the same

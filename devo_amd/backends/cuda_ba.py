@@ -45,10 +45,10 @@ def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t
     target = target.float().contiguous()
     weight = weight.float().contiguous()
     lmbda = lmbda.float().reshape(-1).contiguous()
-    if ws is None:
-        ws = workspace(E, Np, int(t1) - int(t0), poses.device)
     if prepared and ws is None:
         raise RuntimeError("cuda_ba.forward: prepared=True needs the workspace that prepare() filled")
+    if ws is None:
+        ws = workspace(E, Np, int(t1) - int(t0), poses.device)
     fn = L.lib().devo_ba_forward_prepared if prepared else L.lib().devo_ba_forward
     rc = fn(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(target), L.ptr(weight),
             L.ptr(lmbda), L.ptr(ii), L.ptr(jj), L.ptr(kk), E, Nbuf, Np, P, int(t0), int(t1),

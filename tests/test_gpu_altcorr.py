@@ -35,11 +35,14 @@ def _run(f1, f2, coords, ii, jj, R, layout="cl", dtype=torch.float32):
     f2d = f2.to(DEV, dtype)
     if layout == "cl":
         f2d = channels_last5(f2d)
+    elif layout == "blk8":
+        from devo_amd import altcorr
+        f2d = altcorr.channel_blocked(f2d, 8)
     out, = cuda_corr.forward(f1d, f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
     return out
 
 
-@pytest.mark.parametrize("layout", ["cl", "nchw"])
+@pytest.mark.parametrize("layout", ["cl", "nchw", "blk8"])
 @pytest.mark.parametrize("R", [3, 5])
 def test_forward_fp32(layout, R):
     c = _case(R=R, seed=R)
@@ -56,6 +59,21 @@ def test_forward_wide_spread_uses_fallback_path():
     assert_rel(_run(*c, layout="cl"), A.corr_forward(*c), 1e-4, "wide spread")
     c = _case(seed=8, spread=3.5, E=64)                                 # several 128-position chunks
     assert_rel(_run(*c, layout="cl"), A.corr_forward(*c), 1e-4, "multi-chunk")
+
+
+def test_channel_blocked_layout_is_bit_identical_and_checked():
+    """[B,n,C/8,H,W,8] storage feeds the same kernel through other addresses: results are bit-identical to
+    channels-last (split boxes and the opt-in LDS-direct kernel's layouts included); bad block sizes are rejected."""
+    from devo_amd import altcorr
+    from devo_amd.backends import cuda_corr
+    for seed, spread in ((11, 1.0), (12, 3.5), (13, 9.0)):
+        c = _case(seed=seed, spread=spread, E=96)
+        assert torch.equal(_run(*c, layout="blk8"), _run(*c, layout="cl"))
+    f1, f2, coords, ii, jj, R = _case(E=8)
+    with pytest.raises(RuntimeError):
+        cuda_corr.forward(f1.to(DEV), altcorr.channel_blocked(f2.to(DEV), 4), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
+    with pytest.raises(RuntimeError):
+        cuda_corr.forward(f1.to(DEV).half(), altcorr.channel_blocked(f2.to(DEV).half(), 8), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
 
 
 def test_forward_fp16_and_fp64():

@@ -180,3 +180,34 @@ def test_ba_failure_flag_on_breakdown():
     cuda_ba.forward(P, Q, d(s[2]), d(s[3]), w, torch.tensor([1e-4], device=DEV), d(s[5]), d(s[6]), d(s[7]), 1, 8, 2, status=status)
     assert int(status.item()) == 1
     assert torch.equal(P.cpu(), s[0]) and torch.equal(Q.cpu(), s[1])
+
+
+def test_prepare_then_forward_prepared_equals_forward():
+    """cuda_ba.prepare + forward(prepared=True) is the same computation as forward(); a prepared workspace can be
+    solved again (also after a run that broke down: the sticky failure flag is reset by the next call)."""
+    from devo_amd.backends import cuda_ba
+    poses, patches, intr, target, weight, ii, jj, kk = scene(seed=21)
+    n = poses.shape[1]
+    dev = lambda t: t.to(DEV)
+    lm = torch.as_tensor([1e-4], device=DEV)
+    args = (dev(intr), dev(target), dev(weight), lm, dev(ii), dev(jj), dev(kk), 1, n, 2)
+    P0, Q0 = dev(poses.clone()), dev(patches.clone())
+    cuda_ba.forward(P0, Q0, *args)
+    E, Np = ii.numel(), patches.shape[1]
+    ws = cuda_ba.workspace(E, Np, n - 1, torch.device(DEV))
+    cuda_ba.prepare(dev(kk), Np, n - 1, ws)
+    for _ in range(2):                                             # the same prepared workspace twice
+        P1, Q1 = dev(poses.clone()), dev(patches.clone())
+        cuda_ba.forward(P1, Q1, *args, ws=ws, prepared=True)
+        assert torch.equal(P0, P1) and torch.equal(Q0, Q1)
+    # break it (NaN target -> Cholesky breakdown), then solve again on the same workspace
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    bad = list(args); bad[1] = torch.full_like(args[1], float("nan"))
+    P2, Q2 = dev(poses.clone()), dev(patches.clone())
+    cuda_ba.forward(P2, Q2, *bad, ws=ws, prepared=True, status=status)
+    assert int(status) > 0
+    P3, Q3 = dev(poses.clone()), dev(patches.clone())
+    cuda_ba.forward(P3, Q3, *args, ws=ws, prepared=True, status=status)
+    assert int(status) == 0 and torch.equal(P0, P3) and torch.equal(Q0, Q3)
+    with pytest.raises(RuntimeError):
+        cuda_ba.forward(P3, Q3, *args, prepared=True)              # needs the prepared workspace

@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="cfg2")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--dtype", default="f32")
-ap.add_argument("--layout", default="cl")
+ap.add_argument("--layout", default="blk8")
 ap.add_argument("--no-plan", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)

@@ -36,11 +36,13 @@ def plan(coords, jj, n_frames, height, coord_scale=1.0, radius=3):
     return order
 
 
-def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, offset, order=None):
-    """corr forward writing element l of edge (b,e) at out[(b*E+e)*estride + l*lstride + offset]."""
+def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, offset, order=None, coord_div=1.0):
+    """corr forward writing element l of edge (b,e) at out[(b*E+e)*estride + l*lstride + offset].
+    coord_div: the kernel looks up at coords / coord_div (same IEEE division as `coords / s` on the tensor, without
+    materialising it)."""
     fmap1, fmap2, coords, ii, jj = _prep(fmap1, fmap2, coords, ii, jj, allow_blocked=True)
     if order is None and coords.shape[0] * coords.shape[1] >= PLAN_MIN_EDGES:
-        order = plan(coords, jj, fmap2.shape[1], fmap2.shape[3], 1.0, radius)
+        order = plan(coords, jj, fmap2.shape[1], fmap2.shape[3], float(coord_div), radius)
     B, E = coords.shape[:2]
     P = coords.shape[3]
     _, Np, C = fmap1.shape[:3]
@@ -53,7 +55,7 @@ def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, of
         strides = strides[:5]
     rc = L.lib().devo_corr_forward(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(ii), L.ptr(jj), L.ptr(out),
                                    B, E, Np, n2, C, P, H2, W2, L.i64arr(strides), cblock, estride, lstride, offset,
-                                   int(radius), L.dtype_code(fmap1), L.ptr(order), L.stream())
+                                   int(radius), L.dtype_code(fmap1), L.ptr(order), float(coord_div), L.stream())
     L.check(rc, "cuda_corr.forward")
 
 
@@ -82,7 +84,7 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales):
     if B * E >= PLAN_MIN_EDGES:
         order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius)
     for lvl, (fm, s) in enumerate(zip(pyramid, scales)):
-        forward_into(out, fmap1, fm, coords / s, ii, jj, radius, per * nl, nl, lvl, order=order)
+        forward_into(out, fmap1, fm, coords, ii, jj, radius, per * nl, nl, lvl, order=order, coord_div=s)
     return out
 
 

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int H2, int W2, int64_t s_b, int64_t s_n, int64_t s_h, int64_t s_w, int64_t out_estride,
     int64_t out_lstride, int64_t out_offset, int R, const int* __restrict__ order, unsigned long long* __restrict__ trace,
-    int64_t chunk_stride /* elements between consecutive KC-channel chunks of a pixel (KC, or the block stride) */) {
+    int64_t chunk_stride /* elements between consecutive KC-channel chunks of a pixel (KC, or the block stride) */,
+    float coord_div /* coordinates are divided by this (pyramid level scale) */) {
   constexpr int TILEPOS = tile_positions(NG);          // box positions staged per chunk
   constexpr int TILE_SLOTS = tile_slots(NG);           // 16-byte slots of the box tile
   constexpr int F2_FLOATS = TILE_SLOTS * 4;            // box tile
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
   // ---- geometry: lane p (< 9) owns patch pixel p
   float px = 0.0f, py = 0.0f;
   if (lane < PP) {
-    px = coords[((int64_t)be * 2 + 0) * PP + lane];
-    py = coords[((int64_t)be * 2 + 1) * PP + lane];
+    px = coords[((int64_t)be * 2 + 0) * PP + lane] / coord_div;
+    py = coords[((int64_t)be * 2 + 1) * PP + lane] / coord_div;
   }
   unsigned long long t_geo = 0, t_first = 0, t_loop = 0;
   if (trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_geo = __builtin_readcyclecounter(); }
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(NT) void corr_fwd_generic_kernel(
     const T* __restrict__ fmap1, const T* __restrict__ fmap2, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int E, int Np, int n2,
     int C, int H2, int W2, int64_t s_b, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int64_t out_estride,
-    int64_t out_lstride, int64_t out_offset, int R) {
+    int64_t out_lstride, int64_t out_offset, int R, float coord_div) {
   __shared__ float s_raw[PP * MAXD * MAXD];
   __shared__ float s_dx[PP], s_dy[PP];
   __shared__ int s_ox[PP], s_oy[PP];
@@ -507,8 +508,8 @@ __global__ __launch_bounds__(NT) void corr_fwd_generic_kernel(
   const int b = be / E, e = be % E;
   const int tid = threadIdx.x;
   if (tid < PP) {
-    float x = coords[((int64_t)be * 2 + 0) * PP + tid];
-    float y = coords[((int64_t)be * 2 + 1) * PP + tid];
+    float x = coords[((int64_t)be * 2 + 0) * PP + tid] / coord_div;
+    float y = coords[((int64_t)be * 2 + 1) * PP + tid] / coord_div;
     s_ox[tid] = floor_to_int(x) - R;
     s_oy[tid] = floor_to_int(y) - R;
     s_dx[tid] = x - floorf(x);
@@ -660,7 +661,7 @@ template <typename T>
 static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                            const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int H2, int W2,
                            const int64_t* f2s, int cblock, int64_t oes, int64_t ols, int64_t ooff, int R, const int* order,
-                           hipStream_t st) {
+                           float coord_div, hipStream_t st) {
   // channel-blocked storage [.., C/cb, H, W, cb]: f2s[2] is the stride between channel blocks, the cb channels of a
   // pixel are contiguous.  Only the staged kernels read it (cb must equal their channel chunk).
   const bool blocked = cblock > 1;
@@ -687,13 +688,13 @@ static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* co
         dma_lds <= 48 * 1024)
       hipLaunchKernelGGL(corr_fwd_dma_kernel, dim3((unsigned)BE), dim3(64), dma_lds, st, (const float*)fmap1, (const float*)fmap2,
                          coords, ii, jj, (float*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff,
-                         R, order, trace);
+                         R, order, trace, coord_div);
     else if (R <= 3 && !force4)   // (the <4,5> instantiation has room for every supported radius)
       hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 1, 3>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
-                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace, chunk_stride);
+                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace, chunk_stride, coord_div);
     else
       hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 3, 5>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
-                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace, chunk_stride);
+                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace, chunk_stride, coord_div);
     if (do_trace) {
       (void)hipDeviceSynchronize();
       std::vector<unsigned long long> h((size_t)BE * 8);
@@ -719,7 +720,7 @@ static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* co
     if (blocked) { set_error("devo_corr_forward: channel-blocked fmap2 must be 16-byte aligned with aligned strides"); return DEVO_ERR_UNSUPPORTED; }
     dim3 grid((unsigned)BE), block(NT);
     hipLaunchKernelGGL(corr_fwd_generic_kernel<T>, grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii,
-                       jj, (T*)out, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], oes, ols, ooff, R);
+                       jj, (T*)out, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], oes, ols, ooff, R, coord_div);
   }
   return check_launch("devo_corr_forward");
 }
@@ -729,17 +730,18 @@ extern "C" {
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
                       const int64_t* f2s, int cblock, int64_t out_estride, int64_t out_lstride, int64_t out_offset,
-                      int radius, int dtype, const int* order, devo_stream_t stream) {
+                      int radius, int dtype, const int* order, float coord_div, devo_stream_t stream) {
   DEVO_REQUIRE(P == 3, "devo_corr_forward: patch size P must be 3 (got %d)", P);
+  DEVO_REQUIRE(coord_div > 0.0f, "devo_corr_forward: coord_div must be positive");
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_forward: radius %d unsupported (max 5)", radius);
   DEVO_REQUIRE(B >= 0 && E >= 0 && C > 0 && H2 > 0 && W2 > 0, "devo_corr_forward: bad sizes");
   DEVO_REQUIRE(f2s != nullptr, "devo_corr_forward: fmap2 strides missing");
   if ((long long)B * E == 0) return DEVO_OK;
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case DEVO_F32: return launch_corr_fwd<float>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, st);
-    case DEVO_F16: return launch_corr_fwd<__half>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, st);
-    case DEVO_F64: return launch_corr_fwd<double>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, st);
+    case DEVO_F32: return launch_corr_fwd<float>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, st);
+    case DEVO_F16: return launch_corr_fwd<__half>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, st);
+    case DEVO_F64: return launch_corr_fwd<double>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, st);
   }
   set_error("devo_corr_forward: unknown dtype %d", dtype);
   return DEVO_ERR_UNSUPPORTED;

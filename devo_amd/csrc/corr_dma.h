@@ -58,7 +58,8 @@ __global__ __launch_bounds__(64) void corr_fwd_dma_kernel(
     const float* __restrict__ fmap1, const float* __restrict__ fmap2, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, float* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int H2, int W2, int64_t s_b, int64_t s_n, int64_t s_h, int64_t s_w, int64_t out_estride,
-    int64_t out_lstride, int64_t out_offset, int R, const int* __restrict__ order, unsigned long long* __restrict__ trace) {
+    int64_t out_lstride, int64_t out_offset, int R, const int* __restrict__ order, unsigned long long* __restrict__ trace,
+    float coord_div) {
   extern __shared__ __attribute__((aligned(16))) float dma_smem[];
   float* const buf0 = dma_smem;
   float* const buf1 = dma_smem + DMA_BUF_FLOATS;
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(64) void corr_fwd_dma_kernel(
   // ---- geometry: lane p (< 9) owns patch pixel p
   float px = 0.0f, py = 0.0f;
   if (lane < PP) {
-    px = coords[((int64_t)be * 2 + 0) * PP + lane];
-    py = coords[((int64_t)be * 2 + 1) * PP + lane];
+    px = coords[((int64_t)be * 2 + 0) * PP + lane] / coord_div;
+    py = coords[((int64_t)be * 2 + 1) * PP + lane] / coord_div;
   }
   const int64_t pi = ii[e];
   const int64_t fj = jj[e];

@@ -211,3 +211,32 @@ def test_prepare_then_forward_prepared_equals_forward():
     assert int(status) == 0 and torch.equal(P0, P3) and torch.equal(Q0, Q3)
     with pytest.raises(RuntimeError):
         cuda_ba.forward(P3, Q3, *args, prepared=True)              # needs the prepared workspace
+
+
+def test_update_schedule_18_iterations():
+    """the whole update schedule of enet.py:300-339 — 18 update iterations on a growing graph (8 frames
+    for the first 8 iterations, then one more frame per iteration up to 15), each = reproject -> target = centre +
+    replayed delta -> 2 Gauss-Newton iterations — must stay within 1e-4 of the fp64 oracle run on the same replay."""
+    from devo_amd.backends import cuda_ba
+    n, M, H, W = 15, 16, 120, 160
+    poses = synth.make_poses(n, 31)
+    patches, _ = synth.make_patches(n, M, H, W, seed=31)
+    intr = synth.make_intrinsics(n, H, W)
+    dev = lambda t: t.to(DEV)
+    P, Q = dev(poses.clone()), dev(patches.clone())
+    P64, Q64 = poses.double(), patches.double()
+    lm = torch.tensor([1e-4])
+    ws = None
+    for it in range(18):
+        nk = 8 if it < 8 else min(15, 8 + it - 7)
+        ii, jj, kk = synth.full_graph(nk, M)
+        delta, weight = synth.make_update_outputs(len(ii), 100 + it, sigma=0.3)
+        # GPU path
+        c = cuda_ba.transform(P, Q, dev(intr), dev(ii), dev(jj), dev(kk), layout="2pp")
+        target = c[:, :, :, 1, 1] + dev(delta)
+        cuda_ba.forward(P, Q, dev(intr), target, dev(weight), dev(lm), dev(ii), dev(jj), dev(kk), 1, nk, 2)
+        # fp64 oracle on the same replay
+        c64 = pops.transform(OSE3(P64), Q64, intr.double(), ii, jj, kk)
+        t64 = c64[..., 1, 1, :] + delta.double()
+        P64, Q64 = F.ba(P64, Q64, intr.double(), t64, weight.double(), lm, ii, jj, kk, 1, nk, 2, dtype=torch.float64)
+    check((P.cpu(), Q.cpu()), (P64, Q64), tol=1e-4)

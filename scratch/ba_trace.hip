@@ -797,6 +797,8 @@ __device__ __forceinline__ bool chol6(float L[6][6], float inv[6]) {   // in-reg
   return ok;
 }
 
+constexpr int SOLVE_TRAIL = 4;      // trailing-update entries per thread with precomputed coordinates (covers N <= 14)
+
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restrict__ S, const float* __restrict__ y, int N,
                                                             float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag) {
   extern __shared__ __attribute__((aligned(16))) float A[];
@@ -804,32 +806,29 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   const int n6 = 6 * N, LD = n6 + 1, rows = n6 + 1;
   float* Ld = A + rows * LD;                    // [N][36] factored diagonal blocks (diagonal stored as reciprocal)
   float* Li = Ld + N * 36;                      // [N][36] their inverses (for the back-substitution)
-  float* xs = Li + N * 36;                      // [n6] solution
   const int tid = threadIdx.x;
   if (tid == 0) s_fail = 0;
-  {
-    // k_ba_reduce wrote this very image (rows x LD, the right-hand side is row n6); eight loads in flight per thread
-    const int total = rows * LD - 1;
-    for (int i0 = tid; i0 < total; i0 += SOLVE_THREADS * 8) {
-      float v[8];
+  long long c0 = clock64(), cl = 0, cp = 0, cpb = 0, ct = 0, ctb = 0, ci = 0, cb = 0, cx;
+  for (int i = tid; i < rows * LD - 1; i += SOLVE_THREADS) A[i] = S[i];      // k_ba_reduce wrote this very image
+  // (row, column) of trailing-update entry idx = tid + 1024 k in a lower triangle, relative to the trailing corner:
+  // the same for every block step
+  int tr[SOLVE_TRAIL], tc[SOLVE_TRAIL];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int i = i0 + SOLVE_THREADS * u; v[u] = (i < total) ? S[i] : 0.0f; }
-#pragma unroll
-      for (int u = 0; u < 8; u++) { const int i = i0 + SOLVE_THREADS * u; if (i < total) A[i] = v[u]; }
-    }
+  for (int k = 0; k < SOLVE_TRAIL; k++) {
+    const int idx = tid + SOLVE_THREADS * k;
+    int r = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    while (r * (r + 1) / 2 > idx) r--;
+    while ((r + 1) * (r + 2) / 2 <= idx) r++;
+    tr[k] = r; tc[k] = idx - r * (r + 1) / 2;
   }
-  // This thread's 2x2 tile (ty >= tx) of the trailing lower triangle, relative to the trailing corner — the same for
-  // every block step; 2x2 register tiles halve the LDS reads of the update (12 + 12 operands for 4 entries).
-  int ty = (int)((sqrtf(8.0f * (float)tid + 1.0f) - 1.0f) * 0.5f);
-  while (ty * (ty + 1) / 2 > tid) ty--;
-  while ((ty + 1) * (ty + 2) / 2 <= tid) ty++;
-  const int tx = tid - ty * (ty + 1) / 2;
   __syncthreads();
   if (meta->fail) return;                        // an earlier iteration broke down: the reference call has thrown by now
+  cl = clock64() - c0;
 
   for (int jb = 0; jb < N; jb++) {
     const int j0 = 6 * jb;
     const int r = j0 + 6 + tid;                  // this thread's panel row (if any)
+    cx = clock64();
     if (r < rows || tid == 0) {
       float L[6][6];
 #pragma unroll
@@ -858,43 +857,52 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
         for (int c = 0; c < 6; c++) A[r * LD + j0 + c] = x[c];
       }
     }
+    cp += clock64() - cx; cx = clock64();
     __syncthreads();
-    // trailing update of the lower triangle (and of the rhs row) in 2x2 tiles; inputs = the panel columns, outputs =
-    // the columns to their right (disjoint), so everything is fetched before anything is written back
+    cpb += clock64() - cx; cx = clock64();
+    // trailing update of the lower triangle (and of the rhs row): all operands of a thread's entries are fetched
+    // before anything is written back (inputs = the panel columns, outputs = columns to their right: disjoint)
     const int rem = rows - (j0 + 6);
-    const int nt = (rem + 1) / 2;                // tiles per side
-    for (int t = tid; t < nt * (nt + 1) / 2; t += SOLVE_THREADS) {
-      int yy = ty, xx = tx;
-      if (t != tid) {                            // N > 14 only: more tiles than threads
-        yy = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while (yy * (yy + 1) / 2 > t) yy--;
-        while ((yy + 1) * (yy + 2) / 2 <= t) yy++;
-        xx = t - yy * (yy + 1) / 2;
-      }
-      const int r0 = j0 + 6 + 2 * yy, c0 = j0 + 6 + 2 * xx;
-      const bool r1ok = r0 + 1 < rows, c1ok = c0 + 1 < n6;          // second row / column inside the matrix
-      const int r1 = r1ok ? r0 + 1 : r0, c1 = c1ok ? c0 + 1 : c0;
-      if (c0 >= n6) continue;                    // the rhs row has no diagonal entry
-      float pa0[6], pa1[6], pb0[6], pb1[6];
+    const int cnt = rem * (rem + 1) / 2;
+    {
+      float pa[SOLVE_TRAIL][6], pb[SOLVE_TRAIL][6], old[SOLVE_TRAIL];
+      bool on[SOLVE_TRAIL];
 #pragma unroll
-      for (int q = 0; q < 6; q++) {
-        pa0[q] = A[r0 * LD + j0 + q]; pa1[q] = A[r1 * LD + j0 + q];
-        pb0[q] = A[c0 * LD + j0 + q]; pb1[q] = A[c1 * LD + j0 + q];
-      }
-      float o00 = A[r0 * LD + c0], o01 = A[r0 * LD + c1], o10 = A[r1 * LD + c0], o11 = A[r1 * LD + c1];
-      float v00 = 0.0f, v01 = 0.0f, v10 = 0.0f, v11 = 0.0f;
+      for (int k = 0; k < SOLVE_TRAIL; k++) {
+        const int rr = j0 + 6 + tr[k], cc = j0 + 6 + tc[k];
+        on[k] = (tid + SOLVE_THREADS * k < cnt) && (cc < n6);      // the rhs row has no diagonal entry
+        if (on[k]) {
 #pragma unroll
-      for (int q = 0; q < 6; q++) {
-        v00 += pa0[q] * pb0[q]; v01 += pa0[q] * pb1[q];
-        v10 += pa1[q] * pb0[q]; v11 += pa1[q] * pb1[q];
+          for (int q = 0; q < 6; q++) { pa[k][q] = A[rr * LD + j0 + q]; pb[k][q] = A[cc * LD + j0 + q]; }
+          old[k] = A[rr * LD + cc];
+        }
       }
-      A[r0 * LD + c0] = o00 - v00;                                   // c0 <= r0 always (xx <= yy)
-      if (c1ok && c1 <= r0) A[r0 * LD + c1] = o01 - v01;             // above the diagonal on diagonal tiles: skip
-      if (r1ok) A[r1 * LD + c0] = o10 - v10;
-      if (r1ok && c1ok) A[r1 * LD + c1] = o11 - v11;
+#pragma unroll
+      for (int k = 0; k < SOLVE_TRAIL; k++) {
+        if (on[k]) {
+          float v = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 6; q++) v += pa[k][q] * pb[k][q];
+          A[(j0 + 6 + tr[k]) * LD + j0 + 6 + tc[k]] = old[k] - v;
+        }
+      }
     }
+    for (int idx = tid + SOLVE_THREADS * SOLVE_TRAIL; idx < cnt; idx += SOLVE_THREADS) {     // N > 14 only
+      int r2 = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+      while (r2 * (r2 + 1) / 2 > idx) r2--;
+      while ((r2 + 1) * (r2 + 2) / 2 <= idx) r2++;
+      const int rr = j0 + 6 + r2, cc = j0 + 6 + (idx - r2 * (r2 + 1) / 2);
+      if (cc >= n6) continue;
+      float v = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 6; q++) v += A[rr * LD + j0 + q] * A[cc * LD + j0 + q];
+      A[rr * LD + cc] -= v;
+    }
+    ct += clock64() - cx; cx = clock64();
     __syncthreads();
+    ctb += clock64() - cx;
   }
+  cx = clock64();
   if (s_fail) {
     if (tid == 0) { meta->fail = iter + 1; if (status_flag) *status_flag = iter + 1; }
     return;
@@ -924,9 +932,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   }
   __syncthreads();
   // back substitution  L^T x = z  (z = row n6), bottom-up by blocks, by ONE wave: no workgroup barriers (the other
-  // waves are done).  x_b = L_bb^-T z_b from the inverse block, then the lanes update their rows of z.  The solution is
-  // collected in LDS (a global store inside the loop would put a vmcnt wait into every step's fence).
+  // waves are done).  x_b = L_bb^-T z_b from the inverse block, then the lanes update their rows of z.
   if (tid >= 64) return;
+  ci = clock64() - cx; cx = clock64();
   float* z = A + n6 * LD;
   for (int jb = N - 1; jb >= 0; jb--) {
     const int j0 = 6 * jb;
@@ -940,7 +948,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
       for (int k = c; k < 6; k++) v += Li[jb * 36 + k * 6 + c] * zb[k];       // (L^-T)[c][k] = (L^-1)[k][c]
       xb[c] = v;
     }
-    if (tid < 6) xs[j0 + tid] = (tid == 0) ? xb[0] : (tid == 1) ? xb[1] : (tid == 2) ? xb[2] : (tid == 3) ? xb[3] : (tid == 4) ? xb[4] : xb[5];
+    if (tid < 6) dX[j0 + tid] = (tid == 0) ? xb[0] : (tid == 1) ? xb[1] : (tid == 2) ? xb[2] : (tid == 3) ? xb[3] : (tid == 4) ? xb[4] : xb[5];
     wave_lds_sync();                             // all reads of z[j0..j0+5] done before rows above are updated
     for (int r = tid; r < j0; r += 64) {
       float v = 0.0f;
@@ -950,7 +958,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     }
     wave_lds_sync();
   }
-  for (int i = tid; i < n6; i += 64) dX[i] = xs[i];
+  cb = clock64() - cx;
+  if (tid == 0 && iter == 0) printf("solve: load %lld panel %lld +bar %lld trail %lld +bar %lld inv %lld backsub %lld\n", cl, cp, cpb, ct, ctb, ci, cb);
 }
 
 // ------------------------------------------------------------------------------------------------- retract

@@ -31,6 +31,13 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half(v); }
 template <> __device__ __forceinline__ double from_f32<double>(float v) { return (double)v; }
 
+// output stores bypass the caches' allocation (written once, read by a later kernel)
+__device__ __forceinline__ void store_streamed(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void store_streamed(double* p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void store_streamed(__half* p, __half v) {
+  __builtin_nontemporal_store(__half_as_ushort(v), reinterpret_cast<unsigned short*>(p));
+}
+
 __device__ __forceinline__ int floor_to_int(float v) {
   // static_cast<int>(floor(v)) (correlation_kernel.cu:118-119), made safe for non-finite / huge inputs
   float f = floorf(v);
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
       const float dxp = __shfl(my_dx, p), dyp = __shfl(my_dy, p);
       if (l0 + lane < total) {
         const float* r = rawwin + p * (D * D + 1) + a * D + cx;
-        *op = from_f32<T>(blend4(dxp, dyp, r[0], r[1], r[D], r[D + 1]));
+        store_streamed(op, from_f32<T>(blend4(dxp, dyp, r[0], r[1], r[D], r[D + 1])));      // keep the L2 for feature rows
       }
       op += ostep;
       p += 1; a += 7;

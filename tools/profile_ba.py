@@ -20,7 +20,7 @@ ws = cuda_ba.workspace(E, d["patches"].shape[1], n - 1, dev)
 coords = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
 tgt = coords[:, :, :, 1, 1] + d["delta"]
 def run():
-    d["poses"].copy_(d["poses0"]); d["patches"].copy_(d["patches0"])
+    d["state"].copy_(d["state0"])
     cuda_ba.forward(d["poses"], d["patches"], d["intr"], tgt, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
 run(); torch.cuda.synchronize()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

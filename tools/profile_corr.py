@@ -25,12 +25,11 @@ E = d["ii"].numel()
 Dm = 2 * R + 1
 out = torch.empty(1, E, Dm * Dm * 18, dtype=dt, device=dev)
 coords = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
-cs = [coords / 1, coords / 4]
 order = None if a.no_plan else cuda_corr.plan(coords, d["jj"], n, cfg["H"])
 if a.no_plan:
     cuda_corr.PLAN_MIN_EDGES = 1 << 60
 for _ in range(a.reps):
-    for lvl, (fm, c_) in enumerate(zip(d["pyramid"], cs)):
-        cuda_corr.forward_into(out, d["gmap"], fm, c_, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order)
+    for lvl, (fm, s_) in enumerate(zip(d["pyramid"], (1.0, 4.0))):
+        cuda_corr.forward_into(out, d["gmap"], fm, coords, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order, coord_div=s_)
 torch.cuda.synchronize()
 print("done", E)

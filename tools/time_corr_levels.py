@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""time L0 and L1 lookups separately for a list of library variants (DEVO_LIBS=comma list)"""
+"""Time the level-0 and level-1 lookups separately (median of 30 single launches, HIP events).
+    LAYOUT=cl|blk8   DEVO_LIBS=a.so,b.so (A/B different builds of libdevo_hip.so in ONE gpurun call: box-to-box
+    variation is ~1 %, larger than most kernel tweaks)."""
 import os, sys, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -15,27 +17,26 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     n, R = cfg["n"], cfg["R"]; E = d["ii"].numel(); Dm = 2 * R + 1
     out = torch.empty(1, E, Dm * Dm * 18, device=dev)
     coords = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
-    cs = [coords / 1, coords / 4]
     order = cuda_corr.plan(coords, d["jj"], n, cfg["H"])
     from devo_amd import altcorr
     lay = os.environ.get("LAYOUT", "cl")
     ref = []
     for lvl in (0, 1):
-        o = torch.zeros_like(out); cuda_corr.forward_into(o, d["gmap"], d["pyramid"][lvl], cs[lvl], d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order); ref.append(o)
+        o = torch.zeros_like(out); cuda_corr.forward_into(o, d["gmap"], d["pyramid"][lvl], coords, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order, coord_div=(1.0, 4.0)[lvl]); ref.append(o)
     if lay.startswith("blk"):
         d["pyramid"] = [altcorr.channel_blocked(f, int(lay[3:])) for f in d["pyramid"]]
         for lvl in (0, 1):
-            o = torch.zeros_like(out); cuda_corr.forward_into(o, d["gmap"], d["pyramid"][lvl], cs[lvl], d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order)
+            o = torch.zeros_like(out); cuda_corr.forward_into(o, d["gmap"], d["pyramid"][lvl], coords, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order, coord_div=(1.0, 4.0)[lvl])
             print("blocked vs cl equal:", torch.equal(o, ref[lvl]), float((o - ref[lvl]).abs().max()))
     res = []
     for lvl in (0, 1):
-        fm, c_ = d["pyramid"][lvl], cs[lvl]
-        for _ in range(5): cuda_corr.forward_into(out, d["gmap"], fm, c_, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order)
+        fm, c_, dv = d["pyramid"][lvl], coords, (1.0, 4.0)[lvl]
+        for _ in range(5): cuda_corr.forward_into(out, d["gmap"], fm, c_, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order, coord_div=dv)
         torch.cuda.synchronize()
         ts = []
         for _ in range(30):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); cuda_corr.forward_into(out, d["gmap"], fm, c_, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order); b.record()
+            a.record(); cuda_corr.forward_into(out, d["gmap"], fm, c_, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order, coord_div=dv); b.record()
             torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
         ts.sort(); res.append(ts[len(ts) // 2])
     print(f"{os.path.basename(os.environ.get('DEVO_LIB','default')):24s} {lay} nodma={os.environ.get('DEVO_CORR_NODMA','0')} L0 {res[0]:7.1f} us   L1 {res[1]:7.1f} us", flush=True)

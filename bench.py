@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"])
     ap.add_argument("--layout", default="blk8", choices=["blk8", "cl", "nchw"],
                     help="storage of the feature pyramid: channel-blocked [n,C/8,H,W,8] / channels-last / the reference's NCHW")
+    ap.add_argument("--fuse-levels", action="store_true",
+                    help="both pyramid levels in ONE lookup launch (devo_corr_forward_pyramid2) instead of one launch per level "
+                         "(measured: same time, 240 us for both levels either way)")
     ap.add_argument("--overlap-prepare", action="store_true",
                     help="run the BA index preparation (cuda_ba.prepare) on a side stream under the lookup instead of inside "
                          "cuda_ba.forward (measured slower on MI355X: the fork/join costs more than the 26 us it hides)")
@@ -115,11 +118,16 @@ def main():
     Dm = 2 * R + 1
     corr_out = torch.empty(1, E, Dm * Dm * 9 * 2, dtype=dtype, device=device)
 
-    def lookup(coords):
-        order = cuda_corr.plan(coords, d["jj"], n, cfg["H"])                # locality plan, shared by both levels
-        for lvl, (fm, s) in enumerate(zip(d["pyramid"], (1, 4))):
-            cuda_corr.forward_into(corr_out, d["gmap"], fm, coords, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order,
-                                   coord_div=float(s))                       # the kernel looks up at coords / s
+    def lookup(coords, order=None):
+        if not args.fuse_levels:
+            if order is None:
+                order = cuda_corr.plan(coords, d["jj"], n, cfg["H"])            # locality plan, shared by both levels
+            for lvl, (fm, s) in enumerate(zip(d["pyramid"], (1, 4))):
+                cuda_corr.forward_into(corr_out, d["gmap"], fm, coords, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order,
+                                       coord_div=float(s))                   # the kernel looks up at coords / s
+        else:
+            # plan + ONE launch for both levels (workgroups of the two levels alternate on every CU)
+            cuda_corr.forward_pyramid(d["gmap"], d["pyramid"], coords, d["kk"], d["jj"], R, (1, 4), out=corr_out, order=order)
 
     prep_stream = torch.cuda.Stream() if args.overlap_prepare else None
 
@@ -178,14 +186,12 @@ def main():
     torch.cuda.synchronize()
     ev0.record()
     for _ in range(args.kernel_reps):
-        for lvl, (fm, s_) in enumerate(zip(d["pyramid"], (1.0, 4.0))):
-            cuda_corr.forward_into(corr_out, d["gmap"], fm, coords, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order,
-                                   coord_div=s_)
+        lookup(coords, order=order)
     ev1.record()
     torch.cuda.synchronize()
-    launches = 2 * args.kernel_reps
-    t_launch = ev0.elapsed_time(ev1) * 1e-3 / launches                      # s per launch (avg over both levels)
-    b_alg = alg_bytes(cfg, E, 4 if dtype == torch.float32 else 2) / 2.0     # bytes per launch (avg over both levels)
+    launches = (1 if args.fuse_levels else 2) * args.kernel_reps
+    t_launch = ev0.elapsed_time(ev1) * 1e-3 / launches                      # s per launch
+    b_alg = alg_bytes(cfg, E, 4 if dtype == torch.float32 else 2) / (1.0 if args.fuse_levels else 2.0)   # bytes per launch
     achieved = b_alg / t_launch / 1e9
 
     # BA alone (2 Gauss-Newton iterations), for the ">= 10x the CPU ba.py solve" target
@@ -203,7 +209,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             rec = json.load(f).get(f"{args.workload}/{args.dtype}/{args.layout}")
         if rec:
-            traffic = int((2.0 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024)
+            traffic = int((2.0 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024) * (2 if args.fuse_levels else 1)
             traffic_src = f"profiles/pmc_traffic.json ({rec['round']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x read correction)"
     except (OSError, ValueError, KeyError):
         pass
@@ -215,7 +221,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.workload}: M={M} patches/frame, n={n} keyframes, E={E} edges, r={R}, "
                                f"2 pyramid levels {cfg['H']}x{cfg['W']} + /4, C={cfg['C']}, 2 GN iterations, "
-                               f"pyramid layout {args.layout}, {'HIP graph' if not args.no_graph else 'eager'}"
+                               f"pyramid layout {args.layout}, {'both levels in one lookup launch' if args.fuse_levels else 'one lookup launch per level'}, "
+                               f"{'HIP graph' if not args.no_graph else 'eager'}"
                                f"{', BA index preparation on a second stream' if args.overlap_prepare else ''}",
                    "parallelism": f"replicas x{world}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -2,6 +2,7 @@
 (devo/altcorr/correlation.cpp:57-63): forward, backward, patchify_forward, patchify_backward.
 Every function allocates its outputs with torch and enqueues ONE fused kernel of libdevo_hip.so on the
 current stream.  No CPU fallback."""
+import ctypes
 import torch
 from .. import _lib as L
 
@@ -70,19 +71,47 @@ def forward(fmap1, fmap2, coords, ii, jj, radius):
     return [out]
 
 
-def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales):
+def _level_desc(fmap2, C):
+    """(H, W, strides[5], cblock) of one pyramid level as the C ABI wants them."""
+    cblock, strides = 0, fmap2.stride()
+    if fmap2.dim() == 6:
+        cblock = fmap2.shape[5]
+        if fmap2.stride(5) != 1 or fmap2.shape[2] * cblock != C:
+            raise RuntimeError("cuda_corr: malformed channel-blocked fmap2")
+        strides = strides[:5]
+    return fmap2.shape[3], fmap2.shape[4], [int(x) for x in strides], int(cblock)
+
+
+def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, order=None):
     """Fused equivalent of devo/devo.py:215-217 / enet.py:212-216:
-    torch.stack([corr(fmap1, pyr[l], coords / scales[l], ...) for l], -1).view(B, E, -1) without the
-    per-level tensors or the stack copy: each level's kernel writes its interleaved slice directly."""
+    torch.stack([corr(fmap1, pyr[l], coords / scales[l], ...) for l], -1).view(B, E, -1) without the per-level
+    tensors, the scaled coordinate tensors or the stack copy: each level's workgroups write their interleaved slice
+    directly.  Two levels in a layout the staged kernel reads go out as ONE launch (devo_corr_forward_pyramid2)."""
     B, E = coords.shape[:2]
     P = coords.shape[3]
     Dm = 2 * int(radius) + 1
     nl = len(pyramid)
     per = Dm * Dm * P * P
-    out = torch.empty(B, E, per * nl, dtype=fmap1.dtype, device=fmap1.device)
-    order = None
-    if B * E >= PLAN_MIN_EDGES:
+    if out is None:
+        out = torch.empty(B, E, per * nl, dtype=fmap1.dtype, device=fmap1.device)
+    if order is None and B * E >= PLAN_MIN_EDGES:
         order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius)
+    if nl == 2 and B * E > 0 and pyramid[0].dtype == pyramid[1].dtype and pyramid[0].dtype in (torch.float32, torch.float16):
+        f1, f2a, c_, ii_, jj_ = _prep(fmap1, pyramid[0], coords, ii, jj, allow_blocked=True)
+        _prep(fmap1, pyramid[1], coords, ii, jj, allow_blocked=True)
+        C, Np = f1.shape[2], f1.shape[1]
+        d0, d1 = _level_desc(pyramid[0], C), _level_desc(pyramid[1], C)
+        hw = (ctypes.c_int * 4)(d0[0], d0[1], d1[0], d1[1])
+        cb = (ctypes.c_int * 2)(d0[3], d1[3])
+        cd = (ctypes.c_float * 2)(float(scales[0]), float(scales[1]))
+        rc = L.lib().devo_corr_forward_pyramid2(L.ptr(f1), L.ptr(pyramid[0]), L.ptr(pyramid[1]), L.ptr(c_), L.ptr(ii_), L.ptr(jj_),
+                                                L.ptr(out), B, E, Np, pyramid[0].shape[1], C, P, hw, L.i64arr(d0[2] + d1[2]), cb,
+                                                per * nl, nl, L.i64arr([0, 1]), int(radius), L.dtype_code(f1), L.ptr(order), cd,
+                                                L.stream())
+        if rc == 0:
+            return out
+        if rc != 3:                                             # DEVO_ERR_UNSUPPORTED: fall through to one launch per level
+            L.check(rc, "cuda_corr.forward_pyramid")
     for lvl, (fm, s) in enumerate(zip(pyramid, scales)):
         forward_into(out, fmap1, fm, coords, ii, jj, radius, per * nl, nl, lvl, order=order, coord_div=s)
     return out

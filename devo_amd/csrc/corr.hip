@@ -148,14 +148,33 @@ __host__ __device__ __forceinline__ bool tile_fits(int w, int h, int ng) {
   return (long long)w * h <= tile_positions(ng) && (long long)h * tile_pitch(w) <= tile_slots(ng);
 }
 
+// One pyramid level as the staged kernel sees it.
+struct CorrLevel {
+  const void* fmap2;
+  int H2, W2;
+  int64_t s_b, s_n, s_h, s_w;     // element strides of batch, frame, row, column
+  int64_t chunk_stride;           // elements between consecutive KC-channel chunks of a pixel (KC, or the block stride)
+  int64_t out_offset;             // element offset of this level inside an edge's output record
+  float coord_div;                // coordinates are divided by this (pyramid level scale)
+};
+
+// nlev == 1: workgroup g -> edge slot g of level 0.  nlev == 2 (fused pyramid lookup): the two levels alternate in
+// groups of 8 workgroups (one per XCD), so that every CU runs fine-level waves (which wait on HBM/L2) next to
+// coarse-level waves (LDS/VALU-bound) and each level keeps its XCD-aware edge order.
 template <typename T, int NG, int RMAX>
 __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
-    const T* __restrict__ fmap1, const T* __restrict__ fmap2, const float* __restrict__ coords,
+    const T* __restrict__ fmap1, CorrLevel lv0, CorrLevel lv1, int nlev, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
-    int C, int H2, int W2, int64_t s_b, int64_t s_n, int64_t s_h, int64_t s_w, int64_t out_estride,
-    int64_t out_lstride, int64_t out_offset, int R, const int* __restrict__ order, unsigned long long* __restrict__ trace,
-    int64_t chunk_stride /* elements between consecutive KC-channel chunks of a pixel (KC, or the block stride) */,
-    float coord_div /* coordinates are divided by this (pyramid level scale) */) {
+    int C, int64_t out_estride, int64_t out_lstride, int R, const int* __restrict__ order,
+    unsigned long long* __restrict__ trace) {
+  const int lvl = (nlev == 2) ? ((blockIdx.x >> 3) & 1) : 0;                      // wave-uniform
+  const int gid = (nlev == 2) ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : blockIdx.x;
+  const int nitems = (nlev == 2) ? (gridDim.x >> 1) : gridDim.x;                    // workgroups of this level
+  const CorrLevel& LV = lvl ? lv1 : lv0;
+  const T* __restrict__ fmap2 = static_cast<const T*>(LV.fmap2);
+  const int H2 = LV.H2, W2 = LV.W2;
+  const int64_t s_b = LV.s_b, s_n = LV.s_n, s_h = LV.s_h, s_w = LV.s_w, chunk_stride = LV.chunk_stride, out_offset = LV.out_offset;
+  const float coord_div = LV.coord_div;
   constexpr int TILEPOS = tile_positions(NG);          // box positions staged per chunk
   constexpr int TILE_SLOTS = tile_slots(NG);           // 16-byte slots of the box tile
   constexpr int F2_FLOATS = TILE_SLOTS * 4;            // box tile
@@ -173,18 +192,18 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
   // longest work items start first on every XCD; the others take the (frame, row-band)-sorted edges XCD-aware:
   // workgroup g runs on XCD g % 8 (observed dispatch order) and every XCD owns one contiguous slice of the sorted list,
   // so that its private L2 sees each feature row about once.  (Bijective for any grid size.)
-  const int g = blockIdx.x * WPB + wave;                     // WPB == 1: one wave per workgroup
+  const int g = gid * WPB + wave;                            // WPB == 1: one wave per workgroup
   const int nh = order ? min(max(order[BE], 0), BE) : 0;
   int slot;
   if (g < nh) {
     slot = g;
   } else {
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7;
+    const int nwg = nitems, xcd = gid & 7;
     auto heavy_on = [&](int x) -> int { return nh > x ? (nh - x + 7) >> 3 : 0; };          // heavy workgroups on XCD x
     auto total_on = [&](int x) -> int { return nwg > x ? (nwg - x + 7) >> 3 : 0; };        // all workgroups on XCD x
     int start = nh;
     for (int x = 0; x < xcd; x++) start += total_on(x) - heavy_on(x);
-    slot = start + (blockIdx.x >> 3) - heavy_on(xcd);
+    slot = start + (gid >> 3) - heavy_on(xcd);
   }
   if (slot >= BE) return;                                   // wave-uniform; no barriers in this kernel
   const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ULL;
@@ -406,7 +425,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     }
   }
   if (trace && lane == 0) {                          // debug: per-wave (start, end, box size, hw id)
-    unsigned long long* t = trace + (size_t)slot * 8;
+    unsigned long long* t = trace + ((size_t)lvl * BE + slot) * 8;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     t[0] = t_start; t[1] = __builtin_readcyclecounter(); t[2] = (unsigned long long)npos_ll; t[3] = blockIdx.x;
     t[4] = t_geo; t[5] = t_first; t[6] = t_loop;
@@ -664,71 +683,101 @@ __global__ void patchify_bwd_kernel(const float* __restrict__ coords, const T* _
 
 using namespace devo;
 
+// Is this level readable by the staged kernel (corr_fwd_cl_kernel)?  Fills the level block if so.
+template <typename T>
+static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t* f2s, int cblock, int64_t out_offset,
+                         float coord_div, CorrLevel* lv, int* err) {
+  // channel-blocked storage [.., C/cb, H, W, cb]: f2s[2] is the stride between channel blocks, the cb channels of a
+  // pixel are contiguous.  Only the staged kernel reads it (cb must equal its channel chunk).
+  const bool blocked = cblock > 1;
+  *err = DEVO_OK;
+  if (blocked && (cblock != KC || sizeof(T) != 4 || C % KC != 0)) {
+    set_error("devo_corr_forward: channel-blocked fmap2 needs cblock == %d and fp32 (got %d)", KC, cblock);
+    *err = DEVO_ERR_UNSUPPORTED;
+    return false;
+  }
+  const int64_t v = 16 / sizeof(T);
+  const bool ok = (blocked || f2s[2] == 1) && (C % KC == 0) && (f2s[3] % v == 0) && (f2s[4] % v == 0) && (f2s[0] % v == 0) &&
+                  (f2s[1] % v == 0) && ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) && sizeof(T) <= 4 &&
+                  f2s[3] >= 0 && f2s[4] >= 0 &&                                     // 32-bit in-frame offsets (bytes)
+                  ((long long)(H2 - 1) * f2s[3] + (long long)(W2 - 1) * f2s[4] + KC) * (long long)sizeof(T) < (1LL << 31);
+  if (!ok) {
+    if (blocked) { set_error("devo_corr_forward: channel-blocked fmap2 must be 16-byte aligned with aligned strides"); *err = DEVO_ERR_UNSUPPORTED; }
+    return false;
+  }
+  lv->fmap2 = fmap2; lv->H2 = H2; lv->W2 = W2;
+  lv->s_b = f2s[0]; lv->s_n = f2s[1]; lv->s_h = f2s[3]; lv->s_w = f2s[4];
+  lv->chunk_stride = blocked ? f2s[2] : KC;
+  lv->out_offset = out_offset; lv->coord_div = coord_div;
+  return true;
+}
+
+// nlev = 1 or 2 levels in ONE launch of the staged kernel
+template <typename T>
+static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLevel& lv1, int nlev, const float* coords,
+                         const int64_t* ii, const int64_t* jj, void* out, long long BE, int E, int Np, int n2, int C,
+                         int64_t oes, int64_t ols, int R, const int* order, hipStream_t st) {
+  const unsigned per_level = (nlev == 2) ? (unsigned)((BE + 7) / 8 * 8) : (unsigned)BE;      // whole groups of 8 alternate
+  dim3 grid(per_level * nlev), block(WPB * 64);
+  static const bool force4 = getenv("DEVO_CORR_NP4") != nullptr;      // debug switch: run the r > 3 instantiation
+  unsigned long long* trace = nullptr;                                // debug switch: per-wave cycle stamps to stderr
+  const bool do_trace = getenv("DEVO_CORR_TRACE") != nullptr;
+  const size_t nrec = (size_t)BE * nlev;
+  if (do_trace) { (void)hipMalloc(&trace, nrec * 64); (void)hipMemset(trace, 0, nrec * 64); }
+  if (R <= 3 && !force4)   // (the <3,5> instantiation has room for every supported radius)
+    hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 1, 3>), grid, block, 0, st, (const T*)fmap1, lv0, lv1, nlev, coords, ii, jj,
+                       (T*)out, (int)BE, E, Np, n2, C, oes, ols, R, order, trace);
+  else
+    hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 3, 5>), grid, block, 0, st, (const T*)fmap1, lv0, lv1, nlev, coords, ii, jj,
+                       (T*)out, (int)BE, E, Np, n2, C, oes, ols, R, order, trace);
+  if (do_trace) {
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(nrec * 8);
+    (void)hipMemcpy(h.data(), trace, nrec * 64, hipMemcpyDeviceToHost);
+    for (int l = 0; l < nlev; l++) {
+      double ph[4] = {0, 0, 0, 0}, sum = 0, mx = 0;
+      long cnt = 0;
+      for (long long i = 0; i < BE; i++) {
+        const unsigned long long* t = &h[((size_t)l * BE + i) * 8];
+        if (!t[1]) continue;
+        ph[0] += (double)(t[4] - t[0]); ph[1] += (double)(t[5] - t[4]); ph[2] += (double)(t[6] - t[5]); ph[3] += (double)(t[1] - t[6]);
+        const double d = (double)(t[1] - t[0]);
+        sum += d; if (d > mx) mx = d;
+        cnt++;
+      }
+      if (!cnt) cnt = 1;
+      fprintf(stderr, "[corr trace] level slot %d: wave mean %.0f max %.0f cycles; phase means: geometry %.0f, first chunk %.0f, channel loop %.0f, epilogue %.0f\n",
+              l, sum / cnt, mx, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt);
+    }
+    (void)hipFree(trace);
+  }
+  return check_launch("devo_corr_forward");
+}
+
 template <typename T>
 static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                            const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int H2, int W2,
                            const int64_t* f2s, int cblock, int64_t oes, int64_t ols, int64_t ooff, int R, const int* order,
                            float coord_div, hipStream_t st) {
-  // channel-blocked storage [.., C/cb, H, W, cb]: f2s[2] is the stride between channel blocks, the cb channels of a
-  // pixel are contiguous.  Only the staged kernels read it (cb must equal their channel chunk).
-  const bool blocked = cblock > 1;
-  if (blocked && (cblock != KC || sizeof(T) != 4 || C % KC != 0)) {
-    set_error("devo_corr_forward: channel-blocked fmap2 needs cblock == %d and fp32 (got %d)", KC, cblock);
-    return DEVO_ERR_UNSUPPORTED;
-  }
-  const int64_t chunk_stride = blocked ? f2s[2] : KC;
-  const bool cl = (blocked || f2s[2] == 1) && (C % KC == 0) && (f2s[3] % (16 / sizeof(T)) == 0) && (f2s[4] % (16 / sizeof(T)) == 0) &&
-                  (f2s[0] % (16 / sizeof(T)) == 0) && (f2s[1] % (16 / sizeof(T)) == 0) &&
-                  ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) && sizeof(T) <= 4 &&
-                  f2s[3] >= 0 && f2s[4] >= 0 &&                                     // 32-bit in-frame offsets (bytes)
-                  ((long long)(H2 - 1) * f2s[3] + (long long)(W2 - 1) * f2s[4] + KC) * (long long)sizeof(T) < (1LL << 31);
   const long long BE = (long long)B * E;
-  if (cl) {
-    dim3 grid((unsigned)((BE + WPB - 1) / WPB)), block(WPB * 64);
-    static const bool force4 = getenv("DEVO_CORR_NP4") != nullptr;      // debug switch: run the r > 3 instantiation
-    unsigned long long* trace = nullptr;                                // debug switch: per-wave cycle stamps to stderr
-    const bool do_trace = getenv("DEVO_CORR_TRACE") != nullptr;
-    if (do_trace) { (void)hipMalloc(&trace, (size_t)BE * 64); (void)hipMemset(trace, 0, (size_t)BE * 64); }
-    static const bool no_dma = getenv("DEVO_CORR_DMA") == nullptr;      // experimental LDS-direct kernel: opt-in
+  CorrLevel lv;
+  int err;
+  if (staged_level<T>(fmap2, C, H2, W2, f2s, cblock, ooff, coord_div, &lv, &err)) {
+    static const bool use_dma = getenv("DEVO_CORR_DMA") != nullptr;     // experimental LDS-direct kernel: opt-in
     const size_t dma_lds = sizeof(float) * (2 * DMA_BUF_FLOATS + (size_t)PP * (C + 4));
-    if (std::is_same<T, float>::value && R <= 3 && !force4 && !no_dma && !blocked && C % 4 == 0 && (size_t)C * 4 <= DMA_ZERO_BYTES &&
-        dma_lds <= 48 * 1024)
+    if (std::is_same<T, float>::value && R <= 3 && use_dma && cblock <= 1 && C % 4 == 0 && (size_t)C * 4 <= DMA_ZERO_BYTES &&
+        dma_lds <= 48 * 1024) {
       hipLaunchKernelGGL(corr_fwd_dma_kernel, dim3((unsigned)BE), dim3(64), dma_lds, st, (const float*)fmap1, (const float*)fmap2,
                          coords, ii, jj, (float*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff,
-                         R, order, trace, coord_div);
-    else if (R <= 3 && !force4)   // (the <4,5> instantiation has room for every supported radius)
-      hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 1, 3>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
-                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace, chunk_stride, coord_div);
-    else
-      hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 3, 5>), grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii, jj,
-                         (T*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff, R, order, trace, chunk_stride, coord_div);
-    if (do_trace) {
-      (void)hipDeviceSynchronize();
-      std::vector<unsigned long long> h((size_t)BE * 8);
-      (void)hipMemcpy(h.data(), trace, (size_t)BE * 64, hipMemcpyDeviceToHost);
-      double ph[4] = {0, 0, 0, 0};
-      unsigned long long t0 = ~0ULL, t1 = 0; double sum = 0, mx = 0, sum_small = 0; long n_small = 0, n_big = 0; double sum_big = 0;
-      for (long long i = 0; i < BE; i++) {
-        const unsigned long long* t = &h[i * 8];
-        if (!t[1]) continue;
-        ph[0] += (double)(t[4] - t[0]); ph[1] += (double)(t[5] - t[4]); ph[2] += (double)(t[6] - t[5]); ph[3] += (double)(t[1] - t[6]);
-        if (t[0] < t0) t0 = t[0];
-        if (t[1] > t1) t1 = t[1];
-        const double d = (double)(t[1] - t[0]);
-        sum += d; if (d > mx) mx = d;
-        if (t[2] <= 128) { sum_small += d; n_small++; } else { sum_big += d; n_big++; }
-      }
-      fprintf(stderr, "[corr trace] span %.0f ticks; wave mean %.0f max %.0f; box<=128: n %ld mean %.0f; box>128: n %ld mean %.0f; sum/span = %.1f waves in flight\n",
-              (double)(t1 - t0), sum / BE, mx, n_small, n_small ? sum_small / n_small : 0.0, n_big, n_big ? sum_big / n_big : 0.0, sum / (double)(t1 - t0));
-      fprintf(stderr, "[corr trace] phase means: geometry %.0f, first chunk %.0f, channel loop %.0f, epilogue %.0f\n", ph[0] / BE, ph[1] / BE, ph[2] / BE, ph[3] / BE);
-      (void)hipFree(trace);
+                         R, order, (unsigned long long*)nullptr, coord_div);
+      return check_launch("devo_corr_forward");
     }
-  } else {
-    if (blocked) { set_error("devo_corr_forward: channel-blocked fmap2 must be 16-byte aligned with aligned strides"); return DEVO_ERR_UNSUPPORTED; }
-    dim3 grid((unsigned)BE), block(NT);
-    hipLaunchKernelGGL(corr_fwd_generic_kernel<T>, grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii,
-                       jj, (T*)out, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], oes, ols, ooff, R, coord_div);
+    return launch_staged<T>(fmap1, lv, lv, 1, coords, ii, jj, out, BE, E, Np, n2, C, oes, ols, R, order, st);
   }
+  if (err) return err;
+  dim3 grid((unsigned)BE), block(NT);
+  hipLaunchKernelGGL(corr_fwd_generic_kernel<T>, grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii,
+                     jj, (T*)out, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], oes, ols, ooff, R, coord_div);
   return check_launch("devo_corr_forward");
 }
 
@@ -751,6 +800,37 @@ int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords,
     case DEVO_F64: return launch_corr_fwd<double>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, st);
   }
   set_error("devo_corr_forward: unknown dtype %d", dtype);
+  return DEVO_ERR_UNSUPPORTED;
+}
+
+int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const void* fmap2_l1, const float* coords,
+                               const int64_t* ii, const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P,
+                               const int* hw /* host: H0, W0, H1, W1 */, const int64_t* f2s /* host: 5 + 5 */,
+                               const int* cblock /* host, 2 */, int64_t out_estride, int64_t out_lstride,
+                               const int64_t* out_offset /* host, 2 */, int radius, int dtype, const int* order,
+                               const float* coord_div /* host, 2 */, devo_stream_t stream) {
+  DEVO_REQUIRE(P == 3, "devo_corr_forward_pyramid2: patch size P must be 3 (got %d)", P);
+  DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_forward_pyramid2: radius %d unsupported (max 5)", radius);
+  DEVO_REQUIRE(hw && f2s && cblock && out_offset && coord_div, "devo_corr_forward_pyramid2: missing level description");
+  DEVO_REQUIRE(B >= 0 && E >= 0 && C > 0 && hw[0] > 0 && hw[1] > 0 && hw[2] > 0 && hw[3] > 0, "devo_corr_forward_pyramid2: bad sizes");
+  DEVO_REQUIRE(coord_div[0] > 0.0f && coord_div[1] > 0.0f, "devo_corr_forward_pyramid2: coord_div must be positive");
+  const long long BE = (long long)B * E;
+  if (BE == 0) return DEVO_OK;
+  CorrLevel l0, l1;
+  int e0 = DEVO_OK, e1 = DEVO_OK;
+  bool ok = false;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DEVO_F32) {
+    ok = staged_level<float>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0) &&
+         staged_level<float>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
+    if (ok) return launch_staged<float>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
+  } else if (dtype == DEVO_F16) {
+    ok = staged_level<__half>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0) &&
+         staged_level<__half>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
+    if (ok) return launch_staged<__half>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
+  }
+  // not both levels readable by the staged kernel: the caller issues one devo_corr_forward per level instead
+  set_error("devo_corr_forward_pyramid2: levels not eligible for the fused launch (layout / dtype)");
   return DEVO_ERR_UNSUPPORTED;
 }
 

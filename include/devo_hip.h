@@ -54,6 +54,18 @@ int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords,
                       float coord_div /* coords are divided by this in the kernel (pyramid level scale; 1 = as given) */,
                       devo_stream_t stream);
 
+/* Both levels of a 2-level pyramid lookup (devo/devo.py:215-217) in ONE launch: workgroups of the fine and the coarse
+ * level alternate on every CU (the fine level waits on memory, the coarse one is LDS/VALU-bound), each writing its
+ * slice of the edge's output record (out_offset[l], stride out_lstride).  Same results as two devo_corr_forward
+ * calls.  Only for levels the staged kernel reads (channels-last or channel-blocked storage, fp32/fp16); otherwise
+ * DEVO_ERR_UNSUPPORTED is returned and nothing is launched. */
+int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const void* fmap2_l1, const float* coords,
+                               const int64_t* ii, const int64_t* jj, void* out, int B, int E, int Np, int n2, int C,
+                               int P, const int* hw /* host: H0, W0, H1, W1 */, const int64_t* f2s /* host: 5 + 5 */,
+                               const int* cblock /* host, 2 */, int64_t out_estride, int64_t out_lstride,
+                               const int64_t* out_offset /* host, 2 */, int radius, int dtype, const int* order,
+                               const float* coord_div /* host, 2 */, devo_stream_t stream);
+
 /* Locality plan for devo_corr_forward (no reference counterpart: the reference walks edges in list order).
  * order i32 [2*B*E + 1] (the plan buffer; devo_corr_forward reads the first B*E + 1 entries, the rest is scratch
  * of this call): first the HEAVY edge slots (union box of the 9 windows larger than the kernel's LDS tile:

@@ -199,3 +199,22 @@ def test_rejects_bad_arguments():
         cuda_corr.forward(f1, f2, torch.zeros(1, 4, 2, 2, 2, device=DEV), i, i, 3)   # patch size != 3
     out, = cuda_corr.forward(f1, f2, c[:, :0], i[:0], i[:0], 3)   # empty edge list
     assert out.shape == (1, 0, 7, 7, 3, 3)
+
+
+def test_fused_pyramid_single_launch_matches_per_level_launches():
+    """devo_corr_forward_pyramid2 (both levels in one launch) == one devo_corr_forward per level, bit for bit, for
+    channels-last and channel-blocked pyramids, with and without a plan; NCHW falls back to per-level launches."""
+    from devo_amd import altcorr
+    from devo_amd.backends import cuda_corr
+    f1, f2, coords, ii, jj, R = _case(H=32, W=48, E=300, seed=23, spread=1.6)
+    f2b = torch.nn.functional.avg_pool2d(f2[0], 4, 4)[None]
+    args = (coords.to(DEV), ii.to(DEV), jj.to(DEV))
+    for lay in (channels_last5, lambda t: altcorr.channel_blocked(t, 8), lambda t: t):
+        pyr = [lay(f2.to(DEV)), lay(f2b.to(DEV))]
+        per = torch.empty(1, len(ii), 2 * 49 * 9, device=DEV)
+        for lvl, s in enumerate((1, 4)):
+            cuda_corr.forward_into(per, f1.to(DEV), pyr[lvl], args[0], args[1], args[2], R, 2 * 49 * 9, 2, lvl, coord_div=float(s))
+        fused = cuda_corr.forward_pyramid(f1.to(DEV), pyr, *args, R, (1, 4))
+        assert torch.equal(fused, per)
+        order = cuda_corr.plan(args[0], args[2], f2.shape[1], f2.shape[3])
+        assert torch.equal(cuda_corr.forward_pyramid(f1.to(DEV), pyr, *args, R, (1, 4), order=order), per)

@@ -306,14 +306,17 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
     int sdst[ITERS];                                // its LDS destination (floats); -1 = none
     bool sok[ITERS];
     {
-      // load `it` of this lane covers position (lane + 64*it) / PARTS of the box, 16-byte piece (lane % PARTS)
+      // Each 8-lane group (the unit a ds_write_b128 is serviced in) takes ONE 16-byte piece index of 8 consecutive
+      // positions: their LDS slots are 3 apart (odd) = 8 different bank quads, so the staging store is conflict-free
+      // (piece-major lanes would put pieces 0/1 of positions x and x+8/3 on the same banks: 2-way in every group).
       constexpr int STEP = 64 / PARTS;
-      const int part = lane % PARTS;
+      const int part = (lane >> 3) % PARTS;
+      const int pos_l = ((lane >> 3) / PARTS) * 8 + (lane & 7);
       const float inv_bw = 1.0f / (float)bw;
       const int sh32 = (int)s_h, sw32 = (int)s_w;   // the launcher guarantees that a frame spans < 2^31 bytes
 #pragma unroll
       for (int it = 0; it < ITERS; it++) {
-        const int pos = lane / PARTS + it * STEP;
+        const int pos = pos_l + it * STEP;
         const int pyy = (int)(((float)pos + 0.5f) * inv_bw);     // exact: pos < 256 <= 2^8, error margin 0.5 / bw
         const int pxx = pos - pyy * bw;
         const int gy = by0 + pyy, gx = bx0 + pxx;

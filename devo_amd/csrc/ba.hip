@@ -134,7 +134,6 @@ __global__ void k_sort_segments(const int* __restrict__ seg_start, const int* __
 // patches — DEVO's sliding window is ~2k patches); otherwise the same arrays in the workspace are used.
 constexpr int PREP_FLAGS_LDS = 16384;
 constexpr int PREP_SEGS_LDS = 8192;
-constexpr int PREP_CACHE = 32;               // edges per thread kept in registers (E <= 32768: one round trip to memory)
 template <int CACHE>      // CACHE = 0: kk is re-read by every pass; else ceil(E / 1024) <= CACHE edges per thread in registers
 __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
                                                      int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a) {
@@ -278,7 +277,7 @@ struct AccCtx {
   const int64_t* ii; const int64_t* jj; const int64_t* kk; const int* perm;
   float* patch_rec; float* edge_e;
   float fx, fy, cx, cy, lm;
-  int P, t0, N, n6, LD, dbg;
+  int P, t0, N, n6, LD;
 };
 
 // General per-patch accumulation (any number of edges, duplicated (patch, frame) pairs, edges of one patch with
@@ -293,7 +292,7 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
   const int* __restrict__ perm = K.perm;
   float* patch_rec = K.patch_rec; float* edge_e = K.edge_e;
   const float fx = K.fx, fy = K.fy, cx = K.cx, cy = K.cy, lm = K.lm;
-  const int P = K.P, t0 = K.t0, N = K.N, n6 = K.n6, LD = K.LD, dbg = K.dbg;
+  const int P = K.P, t0 = K.t0, N = K.N, n6 = K.n6, LD = K.LD;
   for (int i = lane; i < n6; i += 64) col[i] = 0.0f;
   wave_lds_sync();
   float Csum = 0.0f, usum = 0.0f;
@@ -331,7 +330,7 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
 #pragma unroll
       for (int c = 0; c < 6; c++) { rec[c] = ej[c]; rec[6 + c] = ei[c]; }
     }
-    if (N > 0 && !(dbg & 1)) {
+    if (N > 0) {
       if (jx >= 0) fmask |= 1u << jx;
       if (ix >= 0) fmask |= 1u << ix;
       // ---- frame-j blocks are lane-private (one edge per target frame): straight into LDS
@@ -363,7 +362,7 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
       }
       // ---- frame-i blocks: in DEVO graphs all edges of a patch share the source frame -> reduce the
       //      6x6 / 6x1 blocks across the wavefront with shuffles and add once; otherwise lane-private.
-      const unsigned long long bi = (dbg & 2) ? 0ULL : __ballot(ix >= 0);
+      const unsigned long long bi = __ballot(ix >= 0);
       if (bi) {
         const int ix0 = __shfl(ix, __ffsll((long long)bi) - 1);
         const bool uniform = (__ballot(ix >= 0 && ix != ix0) == 0ULL);
@@ -404,7 +403,7 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
   const float Q = 1.0f / (Csum + lm);                                   // ba_cuda.cu:492
   fmask = wave_or(fmask);
   if (lane == 0) { patch_rec[(int64_t)s * 2] = Q; patch_rec[(int64_t)s * 2 + 1] = usum; }
-  if (N > 0 && !(dbg & 4)) {
+  if (N > 0) {
     wave_lds_sync();                                                    // the patch's E column is complete in LDS
     // ---- Schur complement, patch by patch:  S -= Q e e^T (lower triangle),  y -= Q u e   (:511-512)
     // The column is pulled into registers once (lane l holds rows l, l+64, l+128); column entries are then
@@ -451,7 +450,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
     const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
     const int* __restrict__ perm, const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int P, int t0,
-    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int dbg, int iter) {
+    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int iter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n6 = 6 * N, LD = n6 + 1;
   float* S_lds = smem;
@@ -462,7 +461,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
   for (int i = tid; i < n6 * LD + n6; i += ACC_THREADS) smem[i] = 0.0f;
   __syncthreads();
   AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, edge_e, intr[0], intr[1], intr[2], intr[3], lmbda[0],
-           P, t0, N, n6, LD, dbg};
+           P, t0, N, n6, LD};
   const int n_seg = meta->n_seg;
   if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = 0;     // a prepared graph may be solved many times
   for (int s = blockIdx.x * ACC_WAVES + wave; s < n_seg; s += gridDim.x * ACC_WAVES) {
@@ -499,7 +498,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
     const int* __restrict__ perm, const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int P, int t0,
-    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int dbg, int iter) {
+    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int iter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n6 = 6 * N, LD = n6 + 1;
   float* S_lds = smem;
@@ -512,7 +511,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
   for (int i = tid; i < n6 * LD + n6; i += REG_THREADS) smem[i] = 0.0f;
   __syncthreads();
   AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, edge_e, intr[0], intr[1], intr[2], intr[3], lmbda[0],
-           P, t0, N, n6, LD, dbg};
+           P, t0, N, n6, LD};
 
   const int pa = (lane < 36) ? lane / 6 : 0, pb = (lane < 36) ? lane % 6 : 0;    // this lane's position inside a 6x6 block
   float Sreg[NMAX * (NMAX + 1) / 2];
@@ -1250,13 +1249,13 @@ int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsi
   const size_t n6 = 6 * (size_t)N;
   const size_t acc_lds = sizeof(float) * (n6 * (n6 + 1) + n6 + ACC_WAVES * n6 + 4);
   const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 72 * (size_t)N + n6 + 4);
-  const int dbg = getenv("DEVO_BA_ABLATE") ? atoi(getenv("DEVO_BA_ABLATE")) : 0;
-  const bool use_reg = (N <= 16) && !(dbg & 8);
+  static const bool force_generic = getenv("DEVO_BA_GENERIC") != nullptr;   // test switch: the general accumulate kernel for every N
+  const bool use_reg = (N <= 16) && !force_generic;
   const size_t acc_lds_used = use_reg ? sizeof(float) * (n6 * (n6 + 1) + n6 + REG_WAVES * n6 + 4 + REG_WAVES * SCR_ROWS * 64 +
                                                         REG_WAVES * ((size_t)N * (N + 1) / 2 * 36 + n6)) : acc_lds;
   typedef void (*acc_fn_t)(const float*, const float*, const float*, const float*, const float*, const float*, const int64_t*,
                            const int64_t*, const int64_t*, const int*, const int*, BaMeta*, int, int, int, float*, float*,
-                           float*, int, int);
+                           float*, int);
   acc_fn_t acc_fn = k_ba_accumulate;
   if (use_reg) acc_fn = (N <= 8) ? k_ba_accumulate_reg<8> : (N <= 11) ? k_ba_accumulate_reg<11> : (N <= 14) ? k_ba_accumulate_reg<14> : k_ba_accumulate_reg<16>;
   if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
@@ -1269,7 +1268,7 @@ int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsi
   }
   for (int it = 0; it < iterations; it++) {
     hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? REG_THREADS : ACC_THREADS), acc_lds_used, st, poses, patches, intrinsics, target,
-                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, dbg, it);
+                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, it);
     if ((rc = check_launch("devo_ba_forward(accumulate)"))) return rc;
     if (N > 0) {
       hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((n6 * n6 + n6 + 63) / 64)), dim3(256), 0, st, partials, L.n_part, N, S, y);

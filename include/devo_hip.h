@@ -51,7 +51,8 @@ int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
                       const int64_t* f2s /* host, 5 */, int cblock, int64_t out_estride, int64_t out_lstride,
                       int64_t out_offset, int radius, int dtype, const int* order /* plan buffer, i32 [>= B*E + 1], or NULL */,
-                      float coord_div /* coords are divided by this in the kernel (pyramid level scale; 1 = as given) */,
+                      float coord_div /* coords are divided by this in the kernel (correctly rounded IEEE division; pyramid level
+                                         scale, 1 = as given; DEVO's scales 1 and 4 are exact either way) */,
                       devo_stream_t stream);
 
 /* Both levels of a 2-level pyramid lookup (devo/devo.py:215-217) in ONE launch: workgroups of the fine and the coarse

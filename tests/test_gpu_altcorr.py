@@ -218,3 +218,55 @@ def test_fused_pyramid_single_launch_matches_per_level_launches():
         assert torch.equal(fused, per)
         order = cuda_corr.plan(args[0], args[2], f2.shape[1], f2.shape[3])
         assert torch.equal(cuda_corr.forward_pyramid(f1.to(DEV), pyr, *args, R, (1, 4), order=order), per)
+
+
+@pytest.mark.parametrize("R", [0, 1, 2, 4])
+def test_forward_other_radii(R):
+    """every radius the reference accepts below r = 5 (correlation.py callers use 3; patchify uses 0/1)"""
+    c = _case(R=R, seed=40 + R, E=120)
+    ref = A.corr_forward(*c)
+    for layout in ("cl", "blk8", "nchw"):
+        assert_rel(_run(*c, layout=layout), ref, 1e-4, f"corr fwd {layout} R={R}")
+
+
+def test_coord_div_equals_divided_coordinates_everywhere():
+    """forward_into(coords, coord_div=s) == forward_into(coords / s) bit for bit in the staged AND the generic kernel.
+    The kernel performs a correctly rounded IEEE division: for DEVO's power-of-two scales that is the same number
+    however the caller divides; for other scales it equals a true division (tensor divisor) — torch's CUDA/HIP
+    `tensor / python_scalar` multiplies by the reciprocal instead and can differ in the last bit."""
+    from devo_amd.backends import cuda_corr
+    f1, f2, coords, ii, jj, R = _case(E=150, seed=51)
+    args = (f1.to(DEV), ii.to(DEV), jj.to(DEV))
+    c = coords.to(DEV)
+    for lay in (channels_last5, lambda t: t):
+        fm = lay(f2.to(DEV))
+        for s in (4.0, 3.0):
+            a = torch.empty(1, len(ii), 49 * 9, device=DEV); b = torch.empty_like(a)
+            cuda_corr.forward_into(a, args[0], fm, c, args[1], args[2], R, 49 * 9, 1, 0, coord_div=s)
+            cuda_corr.forward_into(b, args[0], fm, c / torch.full((), s, device=DEV), args[1], args[2], R, 49 * 9, 1, 0)
+            assert torch.equal(a, b)
+            if s == 4.0:
+                cuda_corr.forward_into(b, args[0], fm, c / s, args[1], args[2], R, 49 * 9, 1, 0)
+                assert torch.equal(a, b)
+
+
+def test_fused_pyramid_odd_edge_count_and_batch_of_two():
+    """E not a multiple of 8 (the fused launch pads every level to whole groups of 8 workgroups) and B = 2"""
+    from devo_amd.backends import cuda_corr
+    B, n, Np, C, H, W, E, R = 2, 3, 10, 128, 32, 48, 2053, 3
+    g = torch.Generator().manual_seed(61)
+    f1 = (torch.randn(B, Np, C, 3, 3, generator=g) / 4).to(DEV)
+    f2 = torch.randn(B, n, C, H, W, generator=g) / 4
+    f2b = torch.stack([torch.nn.functional.avg_pool2d(f2[b], 4, 4) for b in range(B)])
+    coords = (torch.rand(B, E, 2, 3, 3, generator=g) * torch.tensor([W, H]).view(1, 1, 2, 1, 1)).to(DEV)
+    ii = torch.randint(0, Np, (E,), generator=g).to(DEV)
+    jj = torch.randint(0, n, (E,), generator=g).to(DEV)
+    pyr = [channels_last5(f2.to(DEV)), channels_last5(f2b.to(DEV))]
+    fused = cuda_corr.forward_pyramid(f1, pyr, coords, ii, jj, R, (1, 4))          # B*E >= PLAN_MIN_EDGES: planned
+    per = torch.empty_like(fused)
+    for lvl, s in enumerate((1, 4)):
+        cuda_corr.forward_into(per, f1, pyr[lvl], coords, ii, jj, R, 2 * 49 * 9, 2, lvl, coord_div=float(s))
+    assert torch.equal(fused, per)
+    ref = torch.stack([A.corr_forward(f1.cpu(), f2, coords.cpu(), ii.cpu(), jj.cpu(), R),
+                       A.corr_forward(f1.cpu(), f2b, coords.cpu() / 4, ii.cpu(), jj.cpu(), R)], -1)
+    assert_rel(fused, ref.view(B, E, -1), 1e-4, "fused pyramid B=2")

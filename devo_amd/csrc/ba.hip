@@ -508,7 +508,14 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* col = col_all + wave * n6;
   float* scr = scr_all + wave * (SCR_ROWS * 64);
-  for (int i = tid; i < n6 * LD + n6; i += REG_THREADS) smem[i] = 0.0f;
+  __shared__ int s_used_atomic;                                 // did any wave of this workgroup take the atomic path?
+  {
+    const int nz = n6 * LD + n6, nz4 = nz >> 2;                 // smem is 16-byte aligned
+    float4* z4 = reinterpret_cast<float4*>(smem);
+    for (int i = tid; i < nz4; i += REG_THREADS) z4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = (nz4 << 2) + tid; i < nz; i += REG_THREADS) smem[i] = 0.0f;
+    if (tid == 0) s_used_atomic = 0;
+  }
   __syncthreads();
   AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, edge_e, intr[0], intr[1], intr[2], intr[3], lmbda[0],
            P, t0, N, n6, LD};
@@ -523,7 +530,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
   if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = 0;     // a prepared graph may be solved many times
   for (int s = blockIdx.x * REG_WAVES + wave; s < n_seg; s += gridDim.x * REG_WAVES) {
     const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
-    if (m > 64) { accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane); continue; }
+    if (m > 64) { if (lane == 0) s_used_atomic = 1; accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane); continue; }
     const bool act = lane < m;
     const int e = act ? perm[a0 + lane] : 0;
     EdgeTerms T;
@@ -554,7 +561,11 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     // behind the N frame slots (fixed target frames only matter for the source-frame sums)
     const unsigned long long fixm = __ballot(act && jx < 0);
     const int nslot = N + __popcll(fixm);
-    if (mixed || __ballot(dup) != 0ULL || nslot > 64) { accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane); continue; }
+    if (mixed || __ballot(dup) != 0ULL || nslot > 64) {
+      if (lane == 0) s_used_atomic = 1;
+      accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane);
+      continue;
+    }
     const int slot = (jx >= 0) ? jx : N + __popcll(fixm & ((1ULL << lane) - 1ULL));
 
     // ---- per-edge quantities into the wave's scratch [row][slot]; the patch's E column into `col`
@@ -712,14 +723,17 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
   __syncthreads();
   if (N > 0) {
     float* out = partials + (int64_t)blockIdx.x * (nt + n6);
+    const bool with_atomic = s_used_atomic != 0;               // workgroup-uniform; usually false: no index arithmetic then
     for (int i = tid; i < nt + n6; i += REG_THREADS) {
-      float v;
-      if (i < nt) {
-        int fr, fc;
-        block_of(i / 36, fr, fc);
-        const int ab = i % 36;
-        v = S_lds[(6 * fr + ab / 6) * LD + 6 * fc + ab % 6];
-      } else v = y_lds[i - nt];
+      float v = 0.0f;
+      if (with_atomic) {
+        if (i < nt) {
+          int fr, fc;
+          block_of(i / 36, fr, fc);
+          const int ab = i % 36;
+          v = S_lds[(6 * fr + ab / 6) * LD + 6 * fc + ab % 6];
+        } else v = y_lds[i - nt];
+      }
 #pragma unroll
       for (int w = 0; w < REG_WAVES; w++) v += tri_all[w * (nt + n6) + i];
       out[i] = v;

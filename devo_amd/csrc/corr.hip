@@ -475,18 +475,36 @@ __global__ __launch_bounds__(BIN_THREADS) void corr_bin_kernel(const float* __re
   bins[be] = bin;
 }
 
-// Step 2 (one workgroup): LDS counting sort of the bins; the heavy list first.
+// Step 2 (one workgroup): LDS counting sort of the bins; the heavy list first.  CACHE > 0: the ceil(BE / 1024) <= CACHE
+// bins of a thread are loaded at once into registers (one round trip to memory instead of one per loop iteration and
+// pass); CACHE == 0: any BE, bins re-read by both passes.
+template <int CACHE>
 __global__ __launch_bounds__(ORDER_THREADS) void corr_order_kernel(const int* __restrict__ bins, int BE, int nbins,
                                                                    int* __restrict__ order) {
   __shared__ int s_cnt[ORDER_MAXBINS];
   __shared__ int s_heavy[2];                                // [0] = count (pass 1), [1] = cursor (pass 2)
+  constexpr bool CACHED = CACHE > 0;
   const int lane = threadIdx.x & 63;
+  int breg[CACHED ? CACHE : 1];
+  if (CACHED) {
+#pragma unroll
+    for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
+      const int be = threadIdx.x + ORDER_THREADS * i;
+      breg[i] = be < BE ? bins[be] : 0x7fffffff;
+    }
+  }
+  auto bin_at = [&](int i) -> int {
+    if (CACHED) return breg[i];
+    const int be = threadIdx.x + ORDER_THREADS * i;
+    return be < BE ? bins[be] : 0x7fffffff;
+  };
+  const int iters = CACHED ? CACHE : (BE + ORDER_THREADS - 1) / ORDER_THREADS;   // block-uniform (ballots below)
   for (int i = threadIdx.x; i < nbins; i += ORDER_THREADS) s_cnt[i] = 0;
   if (threadIdx.x < 2) s_heavy[threadIdx.x] = 0;
   __syncthreads();
-  for (int be0 = 0; be0 < BE; be0 += ORDER_THREADS) {       // block-uniform trip count (ballots below)
-    const int be = be0 + threadIdx.x;
-    const int bin = be < BE ? bins[be] : 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < iters; i++) {
+    const int bin = bin_at(i);
     const unsigned long long hv = __ballot(bin < 0);
     if (bin >= 0 && bin < nbins) atomicAdd(&s_cnt[bin], 1);
     if (hv != 0ull && lane == 0) atomicAdd(&s_heavy[0], __popcll(hv));
@@ -506,9 +524,10 @@ __global__ __launch_bounds__(ORDER_THREADS) void corr_order_kernel(const int* __
     }
   }
   __syncthreads();
-  for (int be0 = 0; be0 < BE; be0 += ORDER_THREADS) {
-    const int be = be0 + threadIdx.x;
-    const int bin = be < BE ? bins[be] : 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < iters; i++) {
+    const int be = threadIdx.x + ORDER_THREADS * i;
+    const int bin = bin_at(i);
     const unsigned long long hv = __ballot(bin < 0);
     int hbase = 0;
     if (hv != 0ull && lane == 0) hbase = atomicAdd(&s_heavy[1], __popcll(hv));
@@ -851,8 +870,11 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   hipLaunchKernelGGL(corr_bin_kernel, dim3((unsigned)((BE + BIN_THREADS - 1) / BIN_THREADS)), dim3(BIN_THREADS), 0,
                      (hipStream_t)stream, coords, jj, (int)BE, E, n2, H2, 1.0f / coord_scale, nb, 2 * radius + 2,
                      radius <= 3 ? 1 : 3, bins);
-  hipLaunchKernelGGL(corr_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, (hipStream_t)stream, bins, (int)BE,
-                     B * n2 * nb, order);
+  typedef void (*order_fn_t)(const int*, int, int, int*);
+  const long long per_thread = (BE + ORDER_THREADS - 1) / ORDER_THREADS;
+  order_fn_t order_fn = per_thread <= 8 ? corr_order_kernel<8> : per_thread <= 16 ? corr_order_kernel<16> :
+                        per_thread <= 24 ? corr_order_kernel<24> : per_thread <= 32 ? corr_order_kernel<32> : corr_order_kernel<0>;
+  hipLaunchKernelGGL(order_fn, dim3(1), dim3(ORDER_THREADS), 0, (hipStream_t)stream, bins, (int)BE, B * n2 * nb, order);
   return check_launch("devo_corr_order");
 }
 

@@ -64,8 +64,8 @@ def corr_pyramid(fmap1, pyramid, coords, ii, jj, radius=3, scales=(1, 4)):
 def channel_blocked(fmap, cb=8):
     """Re-lay a [B,n,C,H,W] pyramid level as channel-blocked storage [B, n, C/cb, H, W, cb]: the cb channels of a
     pixel are contiguous and horizontally adjacent pixels follow each other, so that one row of a lookup box is one
-    contiguous run of memory (full cache lines) for every channel chunk.  Inference lookup only (cuda_corr.forward /
-    corr_pyramid accept the 6-D tensor in place of fmap2)."""
+    contiguous run of memory (full cache lines) for every channel chunk.  Inference lookup only, fp32 or fp16
+    (cuda_corr.forward / corr_pyramid accept the 6-D tensor in place of fmap2)."""
     B, n, C, H, W = fmap.shape
     if C % cb:
         raise RuntimeError(f"channel_blocked: C={C} is not a multiple of {cb}")

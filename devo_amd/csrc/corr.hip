@@ -713,8 +713,8 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
   // pixel are contiguous.  Only the staged kernel reads it (cb must equal its channel chunk).
   const bool blocked = cblock > 1;
   *err = DEVO_OK;
-  if (blocked && (cblock != KC || sizeof(T) != 4 || C % KC != 0)) {
-    set_error("devo_corr_forward: channel-blocked fmap2 needs cblock == %d and fp32 (got %d)", KC, cblock);
+  if (blocked && (cblock != KC || sizeof(T) > 4 || C % KC != 0)) {
+    set_error("devo_corr_forward: channel-blocked fmap2 needs cblock == %d and fp32 / fp16 (got %d)", KC, cblock);
     *err = DEVO_ERR_UNSUPPORTED;
     return false;
   }

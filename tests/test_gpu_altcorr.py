@@ -73,7 +73,9 @@ def test_channel_blocked_layout_is_bit_identical_and_checked():
     with pytest.raises(RuntimeError):
         cuda_corr.forward(f1.to(DEV), altcorr.channel_blocked(f2.to(DEV), 4), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
     with pytest.raises(RuntimeError):
-        cuda_corr.forward(f1.to(DEV).half(), altcorr.channel_blocked(f2.to(DEV).half(), 8), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
+        cuda_corr.forward(f1.to(DEV).double(), altcorr.channel_blocked(f2.to(DEV).double(), 8), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
+    c = _case(seed=14, E=96)                                          # fp16 storage, blocked == channels-last
+    assert torch.equal(_run(*c, layout="blk8", dtype=torch.float16), _run(*c, layout="cl", dtype=torch.float16))
 
 
 def test_forward_fp16_and_fp64():

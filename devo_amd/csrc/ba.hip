@@ -201,16 +201,46 @@ __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__
     const unsigned long long above = H & ~upto;
     next_head = above ? __ffsll((long long)above) - 1 : 64;
   };
-  // segment of every edge (edges with a bad patch id go to segment 0, like before)
+  // segment of every edge (edges with a bad patch id go to segment 0, like before).  CACHED: the run head's atomic
+  // RETURNS the run's offset inside its segment, so every edge knows its place before the segment starts exist and the
+  // scatter pass needs no second round of atomics.
+  int posin[CACHED ? CACHE : 1];
+  if (CACHED) {
+    // three batched sweeps (LDS reads / shuffles / atomics are each issued back to back for all of a thread's edges —
+    // interleaved per edge, every returned LDS atomic would serialise the whole dependent chain behind it)
+    // (one packed register per edge besides its segment: 1024 threads leave 128 VGPRs per thread)
 #pragma unroll
-  for (int i = 0; i < iters; i++) {
-    const int e = t + 1024 * i;
-    int r = -1;
-    if (e < E) { const int k = patch_of(i); r = (k >= 0) ? rank[k - kmin] : 0; ku[e] = r; }
-    if (CACHED) kreg[i] = r;
-    int hl, nh;
-    run_of(r, hl, nh);
-    if (r >= 0 && hl == lane) atomicAdd(&counts[r], nh - lane);
+    for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
+      const int k = kreg[i];
+      kreg[i] = (t + 1024 * i < E) ? ((k >= 0) ? rank[k - kmin] : 0) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
+      int hl, nh;
+      run_of(kreg[i], hl, nh);
+      posin[i] = hl | (nh << 8);                               // head lane of my run | lane after its end
+    }
+#pragma unroll
+    for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
+      const int hl = posin[i] & 255, nh = posin[i] >> 8;
+      int base = 0;
+      if (kreg[i] >= 0 && hl == lane) base = atomicAdd(&counts[kreg[i]], nh - lane);   // E < 2^25: fits next to hl
+      posin[i] = (base << 6) | hl;
+    }
+#pragma unroll
+    for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
+      const int hl = posin[i] & 63;
+      posin[i] = __shfl(posin[i] >> 6, hl) + (lane - hl);
+    }
+  } else {
+    for (int i = 0; i < iters; i++) {
+      const int e = t + 1024 * i;
+      int r = -1;
+      if (e < E) { const int k = patch_of(i); r = (k >= 0) ? rank[k - kmin] : 0; ku[e] = r; }   // ku: re-read by the scatter pass
+      int hl, nh;
+      run_of(r, hl, nh);
+      if (r >= 0 && hl == lane) atomicAdd(&counts[r], nh - lane);
+    }
   }
   for (int p = t; p < Rg; p += 1024)
     if (rank[p + 1] != rank[p]) kx[rank[p]] = kmin + p;
@@ -219,13 +249,18 @@ __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__
 #pragma unroll
   for (int i = 0; i < iters; i++) {
     const int e = t + 1024 * i;
-    const int sgm = CACHED ? kreg[i] : (e < E ? ku[e] : -1);
-    int hl, nh;
-    run_of(sgm, hl, nh);
-    int base = 0;
-    if (sgm >= 0 && hl == lane) base = atomicAdd(&cursor[sgm], nh - lane);
-    base = __shfl(base, hl);
-    if (sgm >= 0) perm_a[counts[sgm] + base + (lane - hl)] = e;
+    if (CACHED) {
+      const int sgm = kreg[i];
+      if (sgm >= 0) perm_a[counts[sgm] + posin[i]] = e;
+    } else {
+      const int sgm = e < E ? ku[e] : -1;
+      int hl, nh;
+      run_of(sgm, hl, nh);
+      int base = 0;
+      if (sgm >= 0 && hl == lane) base = atomicAdd(&cursor[sgm], nh - lane);
+      base = __shfl(base, hl);
+      if (sgm >= 0) perm_a[counts[sgm] + base + (lane - hl)] = e;
+    }
   }
   // publish the segment starts: entries beyond n_seg = E so that any reader sees empty tails
   for (int i = t; i <= max_seg; i += 1024) g_counts[i] = (i <= n_seg) ? counts[i] : E;

@@ -26,7 +26,8 @@ constexpr int ACC_WAVES = 8;         // waves per ba_accumulate workgroup
 constexpr int ACC_THREADS = ACC_WAVES * 64;
 constexpr int ACC_MAX_WG = 256;      // partial systems written per iteration
 
-struct BaMeta { int n_seg; int fail; int pad[2]; };
+struct BaMeta { int n_seg; int fail; int sig; int pad; };   // sig: what the workspace was prepared for (ba_sig)
+__host__ __device__ __forceinline__ int ba_sig(int E, int N) { return (int)(0x5ec0de00u ^ ((unsigned)E * 2654435761u) ^ ((unsigned)N << 24)); }
 
 // ------------------------------------------------------------------------------------------------- utilities
 __device__ __forceinline__ float wave_sum(float v) {
@@ -113,7 +114,9 @@ __global__ void k_scatter_edges(const int* __restrict__ ku, int E, const int* __
   }
 }
 // Restore a deterministic (ascending edge id) order inside every segment: rank sort, one wave per segment.
-__global__ void k_sort_segments(const int* __restrict__ seg_start, const int* __restrict__ n_seg_p, const int* __restrict__ in, int* out) {
+__global__ void k_sort_segments(const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int sig, const int* __restrict__ in, int* out) {
+  const int* n_seg_p = &meta->n_seg;
+  if (blockIdx.x == 0 && threadIdx.x == 0) meta->sig = sig;      // the workspace now holds a prepared graph
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (blockDim.x * gridDim.x) >> 6;
   const int n_seg = *n_seg_p;
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
     const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
     const int* __restrict__ perm, const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int P, int t0,
-    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int iter) {
+    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int iter, int sig, int max_seg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n6 = 6 * N, LD = n6 + 1;
   float* S_lds = smem;
@@ -497,8 +500,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
   __syncthreads();
   AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, edge_e, intr[0], intr[1], intr[2], intr[3], lmbda[0],
            P, t0, N, n6, LD};
-  const int n_seg = meta->n_seg;
-  if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = 0;     // a prepared graph may be solved many times
+  // a workspace that was not prepared for this (E, N) is not touched: the call fails (status -1) instead of walking
+  // garbage tables; a prepared graph may be solved many times (the sticky failure flag is reset here)
+  const bool prepared = meta->sig == sig;
+  const int n_seg = prepared ? min(meta->n_seg, max_seg) : 0;
+  if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = prepared ? 0 : -1;
   for (int s = blockIdx.x * ACC_WAVES + wave; s < n_seg; s += gridDim.x * ACC_WAVES) {
     const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
     accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane);
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
     const int* __restrict__ perm, const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int P, int t0,
-    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int iter) {
+    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int iter, int sig, int max_seg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n6 = 6 * N, LD = n6 + 1;
   float* S_lds = smem;
@@ -561,8 +567,11 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
   for (int i = 0; i < NMAX * (NMAX + 1) / 2; i++) Sreg[i] = 0.0f;
   float yreg[2] = {0.0f, 0.0f};                                 // rows lane, lane + 64  (n6 <= 96)
 
-  const int n_seg = meta->n_seg;
-  if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = 0;     // a prepared graph may be solved many times
+  // a workspace that was not prepared for this (E, N) is not touched: the call fails (status -1) instead of walking
+  // garbage tables; a prepared graph may be solved many times (the sticky failure flag is reset here)
+  const bool prepared = meta->sig == sig;
+  const int n_seg = prepared ? min(meta->n_seg, max_seg) : 0;
+  if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = prepared ? 0 : -1;
   for (int s = blockIdx.x * REG_WAVES + wave; s < n_seg; s += gridDim.x * REG_WAVES) {
     const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
     if (m > 64) { if (lane == 0) s_used_atomic = 1; accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane); continue; }
@@ -873,7 +882,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   while ((ty + 1) * (ty + 2) / 2 <= tid) ty++;
   const int tx = tid - ty * (ty + 1) / 2;
   __syncthreads();
-  if (meta->fail) return;                        // an earlier iteration broke down: the reference call has thrown by now
+  if (meta->fail) {                              // an earlier iteration broke down: the reference call has thrown by now
+    if (tid == 0 && meta->fail < 0 && status_flag) *status_flag = -1;          // (or the workspace was never prepared)
+    return;
+  }
 
   for (int jb = 0; jb < N; jb++) {
     const int j0 = 6 * jb;
@@ -1229,7 +1241,7 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     prep_fn_t prep = ept <= 8 ? k_ba_prepare<8> : ept <= 16 ? k_ba_prepare<16> : ept <= 24 ? k_ba_prepare<24> :
                      ept <= 32 ? k_ba_prepare<32> : k_ba_prepare<0>;
     hipLaunchKernelGGL(prep, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a);
-    hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, &meta->n_seg, perm_a, perm_b);
+    hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, meta, ba_sig(E, N), perm_a, perm_b);
   } else {
     // (meta, rank, counts, cursor are contiguous at the head of the workspace)
     if (hipMemsetAsync(w + L.meta, 0, L.ku - L.meta, st) != hipSuccess) { set_error("devo_ba_prepare: memset failed"); return DEVO_ERR_LAUNCH; }
@@ -1239,7 +1251,7 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     hipLaunchKernelGGL(k_rank_edges, dim3(blocks_for(E > Np ? E : Np, 256, 1024)), dim3(256), 0, st, kk, E, Np, rank, ku, kx, counts);
     hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, counts, L.max_seg, (int*)nullptr);
     hipLaunchKernelGGL(k_scatter_edges, dim3(eb), dim3(256), 0, st, ku, E, counts, cursor, perm_a);
-    hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, &meta->n_seg, perm_a, perm_b);
+    hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, meta, ba_sig(E, N), perm_a, perm_b);
   }
   return check_launch("devo_ba_prepare");
 }
@@ -1304,7 +1316,7 @@ int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsi
                                                         REG_WAVES * ((size_t)N * (N + 1) / 2 * 36 + n6)) : acc_lds;
   typedef void (*acc_fn_t)(const float*, const float*, const float*, const float*, const float*, const float*, const int64_t*,
                            const int64_t*, const int64_t*, const int*, const int*, BaMeta*, int, int, int, float*, float*,
-                           float*, int);
+                           float*, int, int, int);
   acc_fn_t acc_fn = k_ba_accumulate;
   if (use_reg) acc_fn = (N <= 8) ? k_ba_accumulate_reg<8> : (N <= 11) ? k_ba_accumulate_reg<11> : (N <= 14) ? k_ba_accumulate_reg<14> : k_ba_accumulate_reg<16>;
   if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
@@ -1317,7 +1329,7 @@ int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsi
   }
   for (int it = 0; it < iterations; it++) {
     hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? REG_THREADS : ACC_THREADS), acc_lds_used, st, poses, patches, intrinsics, target,
-                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, it);
+                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, it, ba_sig(E, N), L.max_seg);
     if ((rc = check_launch("devo_ba_forward(accumulate)"))) return rc;
     if (N > 0) {
       hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((n6 * n6 + n6 + 63) / 64)), dim3(256), 0, st, partials, L.n_part, N, S, y);

@@ -120,7 +120,8 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
  * correlation lookup and the update network, devo/devo.py:213-240): devo_ba_prepare does the index work of
  * ba_cuda.cu:435-437 (unique patches, edges grouped by patch; depends on kk only) — e.g. on a second stream —
  * and devo_ba_forward_prepared runs the Gauss-Newton iterations on the prepared workspace.  A prepared workspace
- * stays valid (any number of forward calls) until kk, E, Np or t1 - t0 change. */
+ * stays valid (any number of forward calls) until kk, E, Np or t1 - t0 change.  devo_ba_forward_prepared on a
+ * workspace that was not prepared for this (E, t1 - t0) touches nothing and sets *status_flag to -1. */
 int devo_ba_prepare(const int64_t* kk, int E, int Np, int N /* t1 - t0 */, void* ws, size_t ws_bytes,
                     devo_stream_t stream);
 int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsics, const float* target,

@@ -211,6 +211,14 @@ def test_prepare_then_forward_prepared_equals_forward():
     assert int(status) == 0 and torch.equal(P0, P3) and torch.equal(Q0, Q3)
     with pytest.raises(RuntimeError):
         cuda_ba.forward(P3, Q3, *args, prepared=True)              # needs the prepared workspace
+    # a workspace that was never prepared (or prepared for another graph size) is refused on the device: nothing is
+    # touched and the status flag says -1 — no walk through garbage tables
+    for junk in (torch.zeros_like(ws), torch.randint(0, 255, ws.shape, dtype=torch.uint8, device=DEV)):
+        P4, Q4 = dev(poses.clone()), dev(patches.clone())
+        status.zero_()
+        cuda_ba.forward(P4, Q4, *args, ws=junk, prepared=True, status=status)
+        torch.cuda.synchronize()
+        assert int(status) == -1 and torch.equal(P4, dev(poses)) and torch.equal(Q4, dev(patches))
 
 
 def test_update_schedule_18_iterations():

@@ -27,6 +27,22 @@ def prepare(kk, n_patch_slots, n_opt, ws):
     return ws
 
 
+def prepared_tables(ws, E, n_patch_slots, n_opt):
+    """(n_seg, kx, seg_start, perm) of a prepared workspace — the sorted unique patch ids of kk and its edges grouped by
+    patch (the index work of ba_cuda.cu:435-437); for tests."""
+    dev = ws.device
+    m = min(int(E), int(n_patch_slots))
+    n_seg = torch.zeros(1, dtype=torch.int32, device=dev)
+    kx = torch.zeros(m, dtype=torch.int32, device=dev)
+    seg = torch.zeros(m + 1, dtype=torch.int32, device=dev)
+    perm = torch.zeros(int(E), dtype=torch.int32, device=dev)
+    rc = L.lib().devo_ba_prepared_tables(L.ptr(ws), ws.numel(), int(E), int(n_patch_slots), int(n_opt), L.ptr(n_seg), L.ptr(kx),
+                                         L.ptr(seg), L.ptr(perm), L.stream())
+    L.check(rc, "cuda_ba.prepared_tables")
+    n = int(n_seg)
+    return n, kx[:n], seg[:n + 1], perm
+
+
 def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, iterations, ws=None, status=None,
             prepared=False):
     """ba.cpp:153.  Mutates `poses` ([1,Nbuf,7]) and `patches` ([1,Np,3,P,P]) in place and returns []

@@ -16,6 +16,7 @@
 //                   an extra row, blocked back-substitution.
 //   ba_retract    : pose retraction Exp(dX) * G and per-patch depth update  dz = Q (u - e^T dX).
 #include "common.h"
+#include <cstddef>
 #include "se3_dev.h"
 #include <stdlib.h>
 
@@ -1269,6 +1270,22 @@ int devo_ba_prepare(const int64_t* kk, int E, int Np, int N, void* ws, size_t ws
   if (N > BA_MAXN) { set_error("devo_ba_prepare: %d optimised poses > %d supported", N, BA_MAXN); return DEVO_ERR_UNSUPPORTED; }
   if (E == 0) return DEVO_OK;
   return ba_prepare_impl(kk, E, Np, N, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int devo_ba_prepared_tables(const void* ws, size_t ws_bytes, int E, int Np, int N, int* n_seg, int* kx, int* seg_start,
+                            int* perm, devo_stream_t stream) {
+  DEVO_REQUIRE(E > 0 && Np > 0 && N >= 0 && N <= BA_MAXN, "devo_ba_prepared_tables: bad sizes");
+  const BaLayout L = ba_layout(E, Np, N);
+  if (ws == nullptr || ws_bytes < L.total) { set_error("devo_ba_prepared_tables: workspace %zu < %zu bytes", ws_bytes, L.total); return DEVO_ERR_WORKSPACE; }
+  const char* w = (const char*)ws;
+  hipStream_t st = (hipStream_t)stream;
+  bool ok = true;
+  if (n_seg) ok = ok && hipMemcpyAsync(n_seg, w + L.meta + offsetof(BaMeta, n_seg), sizeof(int), hipMemcpyDeviceToDevice, st) == hipSuccess;
+  if (kx) ok = ok && hipMemcpyAsync(kx, w + L.kx, sizeof(int) * (size_t)L.max_seg, hipMemcpyDeviceToDevice, st) == hipSuccess;
+  if (seg_start) ok = ok && hipMemcpyAsync(seg_start, w + L.counts, sizeof(int) * ((size_t)L.max_seg + 1), hipMemcpyDeviceToDevice, st) == hipSuccess;
+  if (perm) ok = ok && hipMemcpyAsync(perm, w + L.perm_b, sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, st) == hipSuccess;
+  if (!ok) { (void)hipGetLastError(); set_error("devo_ba_prepared_tables: copy failed"); return DEVO_ERR_LAUNCH; }
+  return DEVO_OK;
 }
 
 int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,

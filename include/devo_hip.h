@@ -124,6 +124,12 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
  * workspace that was not prepared for this (E, t1 - t0) touches nothing and sets *status_flag to -1. */
 int devo_ba_prepare(const int64_t* kk, int E, int Np, int N /* t1 - t0 */, void* ws, size_t ws_bytes,
                     devo_stream_t stream);
+/* Inspection of a prepared workspace (tests / debugging): copies (device to device, any pointer may be NULL)
+ * *n_seg = number of distinct patches with edges, kx i32 [min(E,Np)] = their ids ascending (the first output of
+ * torch::_unique(kk), ba_cuda.cu:435-437), seg_start i32 [min(E,Np)+1] and perm i32 [E]: the edges of patch kx[s]
+ * are perm[seg_start[s] .. seg_start[s+1]) in ascending edge order (the inverse map of _unique, grouped). */
+int devo_ba_prepared_tables(const void* ws, size_t ws_bytes, int E, int Np, int N, int* n_seg, int* kx,
+                            int* seg_start, int* perm, devo_stream_t stream);
 int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsics, const float* target,
                              const float* weight, const float* lmbda, const int64_t* ii, const int64_t* jj,
                              const int64_t* kk, int E, int Nbuf, int Np, int P, int t0, int t1, int iterations,

@@ -248,3 +248,28 @@ def test_update_schedule_18_iterations():
         t64 = c64[..., 1, 1, :] + delta.double()
         P64, Q64 = F.ba(P64, Q64, intr.double(), t64, weight.double(), lm, ii, jj, kk, 1, nk, 2, dtype=torch.float64)
     check((P.cpu(), Q.cpu()), (P64, Q64), tol=1e-4)
+
+
+@pytest.mark.parametrize("E,Np,ordered", [(5000, 300, False), (21600, 1440, True), (40000, 700, False), (200000, 5000, False)])
+def test_prepare_tables_bit_exact(E, Np, ordered):
+    """The index half of the BA against torch.unique(kk, sorted, return_inverse) (ba_cuda.cu:435-437), bit-exact:
+    sorted unique patch ids and, per patch, exactly its edges in ascending order — for the register-cached
+    single-workgroup kernel (E <= 32768), the re-reading one and the multi-kernel path (E > 2^17)."""
+    from devo_amd.backends import cuda_ba
+    g = torch.Generator().manual_seed(E)
+    if ordered:
+        kk = torch.arange(Np).repeat_interleave(E // Np)
+    else:
+        kk = torch.randint(0, Np, (E,), generator=g)
+        kk[kk % 7 == 3] = 5                                     # gaps in the id range and one very long segment
+    ws = cuda_ba.workspace(E, Np, 7, torch.device(DEV))
+    cuda_ba.prepare(kk.to(DEV), Np, 7, ws)
+    n_seg, kx, seg, perm = cuda_ba.prepared_tables(ws, E, Np, 7)
+    kx_ref, inv = torch.unique(kk, sorted=True, return_inverse=True)
+    assert n_seg == len(kx_ref) and torch.equal(kx.cpu().long(), kx_ref)
+    seg, perm = seg.cpu().long(), perm.cpu().long()
+    assert seg[0] == 0 and seg[-1] == E and torch.equal(seg[1:] - seg[:-1], torch.bincount(inv, minlength=n_seg))
+    assert torch.equal(inv[perm], torch.repeat_interleave(torch.arange(n_seg), seg[1:] - seg[:-1]))   # grouped by patch
+    same = inv[perm][1:] == inv[perm][:-1]
+    assert bool((perm[1:][same] > perm[:-1][same]).all())       # ascending edge ids inside every patch
+    assert torch.equal(torch.sort(perm).values, torch.arange(E))

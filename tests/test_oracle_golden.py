@@ -85,3 +85,17 @@ def test_groups_golden(golden_dir):
     assert torch.allclose(X.log(), g["log"], atol=1e-12)
     assert torch.allclose((X * X.inv()[:, [0]]).data, g["mul"], atol=1e-12)
     assert torch.allclose(K.as_matrix(g["poses"][0]), g["matrix"][0], atol=1e-12)
+
+
+def test_update_operator_matches_reference(golden_dir):
+    """oracle/update.py == the reference's devo.enet.Update (tools/gen_golden_update.py ran the real module, fp64)"""
+    import numpy as np
+    from oracle import update as U
+    z = np.load(os.path.join(golden_dir, "update_f64.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    for tag in ("irregular", "full"):
+        t = lambda k: torch.from_numpy(z[f"{tag}/{k}"])
+        net, delta, weight = U.update(sd, t("net").double(), t("inp").double(), t("corr").double(), t("ii"), t("jj"), t("kk"))
+        for got, ref in ((net, t("net_out")), (delta, t("delta")), (weight, t("weight"))):
+            assert got.shape == ref.shape
+            assert float((got - ref).abs().max()) <= 1e-10 * max(1.0, float(ref.abs().max()))

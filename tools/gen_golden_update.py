@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/update_f64.npz by running the REAL reference `devo.enet.Update` (enet.py:32-99, with
+blocks.py's GatedResidual / SoftAgg) from /root/reference on CPU, fp64, at a reduced width (dim = 32) so that the
+fixture stays small.  Runs only in the build container.  Nothing from the reference is copied: the file holds data
+(seeded weights as produced by the module's own initialisers, inputs, expected outputs).
+
+Shims installed before `import devo.enet` (modules the reference imports at module scope and that are absent here):
+  cuda_corr, cuda_ba          stubs; cuda_ba.neighbors = oracle/fastba.py:neighbors (bit-exact restatement of ba.cpp:104-149)
+  torch_scatter               scatter_sum / scatter_softmax restated with index_add / scatter_reduce
+  lietorch_backends           the oracle's SE3 backend (not used by Update)
+  torchvision.ops, matplotlib.pyplot, utils.voxel_utils, utils.viz_utils   empty stubs (import-time only)
+"""
+import os
+import sys
+import types
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import lie as olie, fastba as ofb          # noqa: E402
+from devo_amd import synth                             # noqa: E402
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_shims():
+    _mod("cuda_corr", forward=None, backward=None, patchify_forward=None, patchify_backward=None)
+    _mod("cuda_ba", forward=None, reproject=None, neighbors=lambda ii, jj: list(ofb.neighbors(ii, jj)))
+
+    def scatter_sum(src, index, dim=-1, out=None, dim_size=None):
+        shape = list(src.shape)
+        shape[dim] = int(dim_size) if dim_size is not None else int(index.max()) + 1
+        return torch.zeros(shape, dtype=src.dtype).index_add(dim, index, src)
+
+    def scatter_softmax(src, index, dim=-1):
+        d = dim % src.dim()
+        shape = list(src.shape)
+        shape[d] = int(index.max()) + 1
+        idx = index.view([-1 if k == d else 1 for k in range(src.dim())]).expand_as(src)
+        mx = torch.full(shape, float("-inf"), dtype=src.dtype).scatter_reduce(d, idx, src, "amax", include_self=True)
+        e = (src - mx.gather(d, idx)).exp()
+        return e / torch.zeros(shape, dtype=src.dtype).scatter_add(d, idx, e).gather(d, idx)
+    _mod("torch_scatter", scatter_sum=scatter_sum, scatter_softmax=scatter_softmax)
+    sys.modules["lietorch_backends"] = olie.backend
+    tv = _mod("torchvision"); tv.ops = _mod("torchvision.ops", batched_nms=None)
+    mp = _mod("matplotlib"); mp.pyplot = _mod("matplotlib.pyplot")
+    _mod("utils")
+    _mod("utils.voxel_utils", std=None, rescale=None, voxel_augment=None)
+    _mod("utils.viz_utils", visualize_voxel=None, visualize_N_voxels=None, visualize_scorer_map=None)
+    sys.path.insert(0, REF)
+
+
+def main():
+    install_shims()
+    from devo.enet import Update
+    torch.manual_seed(1234)
+    dim, p = 32, 3
+    up = Update(p, dim=dim).double().eval()
+    out = {}
+    for k, v in up.state_dict().items():
+        out["sd/" + k] = v.numpy()
+    g = torch.Generator().manual_seed(7)
+    for tag, (n, M, keep) in {"irregular": (6, 5, 0.7), "full": (5, 4, 1.0)}.items():
+        ii, jj, kk = synth.full_graph(n, M)
+        if keep < 1.0:
+            sel = torch.randperm(len(ii), generator=g)[: int(keep * len(ii))]
+            ii, jj, kk = ii[sel], jj[sel], kk[sel]
+        E = len(ii)
+        # inputs are fp32-representable (stored as fp32: half the fixture), the module runs in fp64
+        net = torch.randn(1, E, dim, generator=g).double()
+        inp = torch.randn(1, E, dim, generator=g).double()
+        corr = torch.randn(1, E, 2 * 49 * p * p, generator=g).double()
+        with torch.no_grad():
+            net2, (delta, weight, _) = up(net, inp, corr, None, ii, jj, kk)
+        for k, v in dict(ii=ii, jj=jj, kk=kk, net=net.float(), inp=inp.float(), corr=corr.float(), net_out=net2, delta=delta,
+                         weight=weight).items():
+            out[f"{tag}/{k}"] = v.numpy()
+    path = os.path.join(ROOT, "tests", "golden", "update_f64.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path) // 1024, "KB")
+
+
+if __name__ == "__main__":
+    main()

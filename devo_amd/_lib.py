@@ -37,6 +37,15 @@ _SIGNATURES = {
     "devo_ba_reproject": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "devo_transform": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
 }
+_f = ctypes.c_float
+_SIGNATURES.update({
+    "devo_upd_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp],
+    "devo_upd_masked_gather": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "devo_upd_softagg": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "devo_upd_expand_add": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "devo_upd_gated_residual": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
+    "devo_upd_heads": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+})
 for _n in ("exp", "log", "inv"):
     _SIGNATURES[f"devo_se3_{_n}"] = [_vp, _vp, _i64, _i, _vp]
     _SIGNATURES[f"devo_se3_{_n}_backward"] = [_vp, _vp, _vp, _i64, _i, _vp]

@@ -1,0 +1,249 @@
+// Update operator (devo/enet.py:32-99, devo/blocks.py:15-48): the element-wise / reduction
+// pieces between the GEMMs, for gfx950.  The dense layers themselves are plain library GEMMs (hipBLASLt through
+// torch.nn.functional.linear); what is written here are the ops the reference spreads over ~40 small ATen /
+// torch_scatter launches:
+//   * row LayerNorm (eps 1e-3) with up to two fused residual inputs and an optional fused ReLU        (enet.py:47,53-55,65,83)
+//   * masked neighbour gather  net[:, ix] * (ix >= 0)                                                (enet.py:86-91)
+//   * SoftAgg: per-group softmax over the edges + weighted sum, one pass over HBM per operand        (blocks.py:42-43)
+//   * expand-and-add of the aggregated rows back onto the edges  net += h(y)[:, group]               (blocks.py:46, enet.py:93-94)
+//   * gated residual  x + sigmoid(g) * r                                                             (blocks.py:28-29)
+//   * the two 2-wide heads: ReLU -> Linear(dim, 2) (-> Sigmoid)                                      (enet.py:68-78,96-98)
+// All kernels: fp32 or fp16 storage (DEVO runs the update under autocast), fp32 arithmetic, one wave per row where a
+// row reduction is needed (dim = 384 -> 6 elements per lane), no atomics, fixed summation order.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+namespace devo {
+
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<__half>(const __half* p) { return __half2float(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<__half>(__half* p, float v) { *p = __float2half(v); }
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+constexpr int UPD_MAXPER = 16;      // elements of a row per lane: dim <= 1024
+
+// out[r] = LN(x[r] + a[r] + b[r]) * gamma + beta  (a, b optional), optionally ReLU'd; optional copy of the pre-norm sum.
+// One wave per row; two-pass mean / variance in registers (the row is read once).
+template <typename T>
+__global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ b,
+                                                   const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                   T* __restrict__ out, int64_t rows, int dim, float eps, int relu) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int per = (dim + 63) / 64;
+  float v[UPD_MAXPER];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < UPD_MAXPER; k++) {
+    const int c = lane + 64 * k;
+    v[k] = 0.0f;
+    if (k < per && c < dim) {
+      float t = ld(x + row * dim + c);
+      if (a) t += ld(a + row * dim + c);
+      if (b) t += ld(b + row * dim + c);
+      v[k] = t;
+      s += t;
+    }
+  }
+  const float mean = wsum(s) / (float)dim;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < UPD_MAXPER; k++) {
+    const int c = lane + 64 * k;
+    if (k < per && c < dim) { const float d = v[k] - mean; q += d * d; }
+  }
+  const float rstd = rsqrtf(wsum(q) / (float)dim + eps);           // biased variance, like torch.nn.LayerNorm
+#pragma unroll
+  for (int k = 0; k < UPD_MAXPER; k++) {
+    const int c = lane + 64 * k;
+    if (k < per && c < dim) {
+      float o = (v[k] - mean) * rstd * ld(gamma + c) + ld(beta + c);
+      if (relu) o = fmaxf(o, 0.0f);
+      st(out + row * dim + c, o);
+    }
+  }
+}
+
+// out[e] = idx[e] >= 0 ? src[idx[e]] : 0
+template <typename T>
+__global__ void k_masked_gather(const T* __restrict__ src, const int64_t* __restrict__ idx, T* __restrict__ out, int64_t E, int dim) {
+  const int64_t n = E * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / dim;
+    const int c = (int)(i - e * dim);
+    const int64_t j = idx[e];
+    st(out + i, j >= 0 ? ld(src + j * dim + c) : 0.0f);
+  }
+}
+
+// SoftAgg reduction: for group s (edges perm[seg[s] .. seg[s+1])) and channel c
+//   y[s][c] = sum_e f[e][c] * exp(g[e][c] - max_e g[e][c]) / sum_e exp(g[e][c] - max)
+// one thread per channel, workgroups stride over the groups (n_seg lives on the device); group_of[e] = s is
+// written for the expand step.
+template <typename T>
+__global__ __launch_bounds__(256) void k_softagg(const T* __restrict__ f, const T* __restrict__ g, const int* __restrict__ perm,
+                                                 const int* __restrict__ seg, const int* __restrict__ n_seg_p, T* __restrict__ y,
+                                                 int* __restrict__ group_of, int dim) {
+  const int n_seg = *n_seg_p;
+  const int nslab = (dim + 255) / 256;
+  for (int w = blockIdx.x; w < n_seg * nslab; w += gridDim.x) {
+    const int s = w / nslab, c = (w - s * nslab) * 256 + threadIdx.x;
+    const int a0 = seg[s], a1 = seg[s + 1];
+    if (c < dim) {
+      float m = -3.0e38f;
+      for (int a = a0; a < a1; a++) m = fmaxf(m, ld(g + (int64_t)perm[a] * dim + c));
+      float den = 0.0f, num = 0.0f;
+      for (int a = a0; a < a1; a++) {
+        const int64_t e = perm[a];
+        const float w_ = __expf(ld(g + e * dim + c) - m);
+        den += w_;
+        num += ld(f + e * dim + c) * w_;
+      }
+      st(y + (int64_t)s * dim + c, num / den);
+    }
+    if (group_of && (w - s * nslab) == 0)
+      for (int a = a0 + threadIdx.x; a < a1; a += 256) group_of[perm[a]] = s;
+  }
+}
+
+// net[e] += hy[group_of[e]]
+template <typename T>
+__global__ void k_expand_add(T* __restrict__ net, const T* __restrict__ hy, const int* __restrict__ group_of, int64_t E, int dim) {
+  const int64_t n = E * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / dim;
+    const int c = (int)(i - e * dim);
+    st(net + i, ld(net + i) + ld(hy + (int64_t)group_of[e] * dim + c));
+  }
+}
+
+// out = x + sigmoid(gate) * res
+template <typename T>
+__global__ void k_gated_residual(const T* __restrict__ x, const T* __restrict__ gate, const T* __restrict__ res, T* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gt = 1.0f / (1.0f + __expf(-ld(gate + i)));
+    st(out + i, ld(x + i) + gt * ld(res + i));
+  }
+}
+
+// delta[e] = Wd relu(net[e]) + bd ; weight[e] = sigmoid(Ww relu(net[e]) + bw)   (Wd, Ww: [2, dim]); one wave per edge
+template <typename T>
+__global__ __launch_bounds__(256) void k_heads(const T* __restrict__ net, const T* __restrict__ Wd, const T* __restrict__ bd,
+                                               const T* __restrict__ Ww, const T* __restrict__ bw, T* __restrict__ delta,
+                                               T* __restrict__ weight, int64_t E, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= E) return;
+  float d0 = 0.0f, d1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
+  for (int c = lane; c < dim; c += 64) {
+    const float v = fmaxf(ld(net + e * dim + c), 0.0f);
+    d0 += v * ld(Wd + c); d1 += v * ld(Wd + dim + c);
+    w0 += v * ld(Ww + c); w1 += v * ld(Ww + dim + c);
+  }
+  d0 = wsum(d0); d1 = wsum(d1); w0 = wsum(w0); w1 = wsum(w1);
+  if (lane == 0) {
+    st(delta + e * 2, d0 + ld(bd)); st(delta + e * 2 + 1, d1 + ld(bd + 1));
+    st(weight + e * 2, 1.0f / (1.0f + __expf(-(w0 + ld(bw)))));
+    st(weight + e * 2 + 1, 1.0f / (1.0f + __expf(-(w1 + ld(bw + 1)))));
+  }
+}
+
+static unsigned grid_for(long long n, int per_block, int cap) {
+  long long b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+}  // namespace devo
+
+using namespace devo;
+
+#define UPD_DISPATCH(DT, CALL_F32, CALL_F16)                                                  \
+  do {                                                                                        \
+    if ((DT) == DEVO_F32) { CALL_F32; }                                                       \
+    else if ((DT) == DEVO_F16) { CALL_F16; }                                                  \
+    else { set_error("update ops: fp32 / fp16 only (dtype %d)", (int)(DT)); return DEVO_ERR_UNSUPPORTED; } \
+  } while (0)
+
+extern "C" {
+
+int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const void* gamma, const void* beta, void* out,
+                       int64_t rows, int dim, float eps, int relu, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(rows >= 0 && dim > 0 && dim <= 64 * UPD_MAXPER, "devo_upd_layernorm: dim %d unsupported (1..%d)", dim, 64 * UPD_MAXPER);
+  if (rows == 0) return DEVO_OK;
+  hipStream_t st_ = (hipStream_t)stream;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  UPD_DISPATCH(dtype,
+    hipLaunchKernelGGL(k_layernorm<float>, grid, block, 0, st_, (const float*)x, (const float*)add1, (const float*)add2, (const float*)gamma, (const float*)beta, (float*)out, rows, dim, eps, relu),
+    hipLaunchKernelGGL(k_layernorm<__half>, grid, block, 0, st_, (const __half*)x, (const __half*)add1, (const __half*)add2, (const __half*)gamma, (const __half*)beta, (__half*)out, rows, dim, eps, relu));
+  return check_launch("devo_upd_layernorm");
+}
+
+int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64_t E, int dim, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && dim > 0, "devo_upd_masked_gather: bad sizes");
+  if (E == 0) return DEVO_OK;
+  hipStream_t st_ = (hipStream_t)stream;
+  const dim3 grid(grid_for(E * dim, 256, 8192)), block(256);
+  UPD_DISPATCH(dtype,
+    hipLaunchKernelGGL(k_masked_gather<float>, grid, block, 0, st_, (const float*)src, idx, (float*)out, E, dim),
+    hipLaunchKernelGGL(k_masked_gather<__half>, grid, block, 0, st_, (const __half*)src, idx, (__half*)out, E, dim));
+  return check_launch("devo_upd_masked_gather");
+}
+
+int devo_upd_softagg(const void* f, const void* g, const int* perm, const int* seg_start, const int* n_seg, void* y,
+                     int* group_of, int64_t E, int dim, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && dim > 0, "devo_upd_softagg: bad sizes");
+  if (E == 0) return DEVO_OK;
+  hipStream_t st_ = (hipStream_t)stream;
+  const dim3 grid(grid_for(E * ((dim + 255) / 256), 1, 2048)), block(256);
+  UPD_DISPATCH(dtype,
+    hipLaunchKernelGGL(k_softagg<float>, grid, block, 0, st_, (const float*)f, (const float*)g, perm, seg_start, n_seg, (float*)y, group_of, dim),
+    hipLaunchKernelGGL(k_softagg<__half>, grid, block, 0, st_, (const __half*)f, (const __half*)g, perm, seg_start, n_seg, (__half*)y, group_of, dim));
+  return check_launch("devo_upd_softagg");
+}
+
+int devo_upd_expand_add(void* net, const void* hy, const int* group_of, int64_t E, int dim, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && dim > 0, "devo_upd_expand_add: bad sizes");
+  if (E == 0) return DEVO_OK;
+  hipStream_t st_ = (hipStream_t)stream;
+  const dim3 grid(grid_for(E * dim, 256, 8192)), block(256);
+  UPD_DISPATCH(dtype,
+    hipLaunchKernelGGL(k_expand_add<float>, grid, block, 0, st_, (float*)net, (const float*)hy, group_of, E, dim),
+    hipLaunchKernelGGL(k_expand_add<__half>, grid, block, 0, st_, (__half*)net, (const __half*)hy, group_of, E, dim));
+  return check_launch("devo_upd_expand_add");
+}
+
+int devo_upd_gated_residual(const void* x, const void* gate, const void* res, void* out, int64_t n, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(n >= 0, "devo_upd_gated_residual: bad size");
+  if (n == 0) return DEVO_OK;
+  hipStream_t st_ = (hipStream_t)stream;
+  const dim3 grid(grid_for(n, 256, 8192)), block(256);
+  UPD_DISPATCH(dtype,
+    hipLaunchKernelGGL(k_gated_residual<float>, grid, block, 0, st_, (const float*)x, (const float*)gate, (const float*)res, (float*)out, n),
+    hipLaunchKernelGGL(k_gated_residual<__half>, grid, block, 0, st_, (const __half*)x, (const __half*)gate, (const __half*)res, (__half*)out, n));
+  return check_launch("devo_upd_gated_residual");
+}
+
+int devo_upd_heads(const void* net, const void* Wd, const void* bd, const void* Ww, const void* bw, void* delta, void* weight,
+                   int64_t E, int dim, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && dim > 0, "devo_upd_heads: bad sizes");
+  if (E == 0) return DEVO_OK;
+  hipStream_t st_ = (hipStream_t)stream;
+  const dim3 grid((unsigned)((E + 3) / 4)), block(256);
+  UPD_DISPATCH(dtype,
+    hipLaunchKernelGGL(k_heads<float>, grid, block, 0, st_, (const float*)net, (const float*)Wd, (const float*)bd, (const float*)Ww, (const float*)bw, (float*)delta, (float*)weight, E, dim),
+    hipLaunchKernelGGL(k_heads<__half>, grid, block, 0, st_, (const __half*)net, (const __half*)Wd, (const __half*)bd, (const __half*)Ww, (const __half*)bw, (__half*)delta, (__half*)weight, E, dim));
+  return check_launch("devo_upd_heads");
+}
+
+}  // extern "C"

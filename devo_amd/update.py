@@ -1,0 +1,175 @@
+"""DEVO's `Update` operator (devo/enet.py:32-99, devo/blocks.py:15-48) on the HIP path.
+
+Same module tree and parameter names as the reference (`corr.0.weight`, `agg_kk.f.bias`, `gru.1.gate.0.weight`, ...), so
+a reference checkpoint's `update.*` entries load with `load_state_dict`.  Inference (`torch.no_grad()`): the dense
+layers are library GEMMs (`torch.nn.functional.linear` -> hipBLASLt), everything between them runs in the fused
+kernels of devo_amd/csrc/update.hip — LayerNorm with the residual sums and the ReLU fused in, masked neighbour
+gather, SoftAgg's per-group softmax + weighted sum + expand, gated residual, the two 2-wide heads — with the group
+tables built by the bundle adjustment's own index kernels (`cuda_ba.prepare`) and `cuda_ba.neighbors`.
+With gradients enabled the same computation runs as a plain torch composition (no torch_scatter needed).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from .backends import cuda_ba
+
+DIM = 384
+
+
+class GradientClip(nn.Module):                       # blocks.py:50-58: identity in the forward pass
+    def forward(self, x):
+        return x
+
+
+class GatedResidual(nn.Module):                      # blocks.py:15-29
+    def __init__(self, dim):
+        super().__init__()
+        self.gate = nn.Sequential(nn.Linear(dim, dim), nn.Sigmoid())
+        self.res = nn.Sequential(nn.Linear(dim, dim), nn.ReLU(inplace=True), nn.Linear(dim, dim))
+
+    def forward(self, x):
+        return x + self.gate(x) * self.res(x)
+
+
+class SoftAgg(nn.Module):                            # blocks.py:31-48 (expand=True)
+    def __init__(self, dim=512):
+        super().__init__()
+        self.f = nn.Linear(dim, dim)
+        self.g = nn.Linear(dim, dim)
+        self.h = nn.Linear(dim, dim)
+
+    def forward(self, x, ix):                        # torch composition (autograd path)
+        _, jx = torch.unique(ix, return_inverse=True)
+        n = int(jx.max()) + 1
+        B, E, C = x.shape
+        idx = jx.view(1, E, 1).expand(B, E, C)
+        gx, fx = self.g(x), self.f(x)
+        mx = torch.full((B, n, C), float("-inf"), dtype=x.dtype, device=x.device).scatter_reduce(1, idx, gx, "amax", include_self=True)
+        ex = (gx - mx.gather(1, idx)).exp()
+        w = ex / torch.zeros(B, n, C, dtype=x.dtype, device=x.device).scatter_add(1, idx, ex).gather(1, idx)
+        y = torch.zeros(B, n, C, dtype=x.dtype, device=x.device).scatter_add(1, idx, fx * w)
+        return self.h(y)[:, jx]
+
+
+class _Groups:
+    """Edges grouped by an integer key, through the BA's index kernels: perm / seg_start / n_seg (+ group_of scratch)."""
+
+    def __init__(self, key):
+        E = key.numel()
+        bound = int(key.max()) + 1 if E else 1       # one host sync per distinct graph (cached by the caller)
+        ws = cuda_ba.workspace(E, bound, 0, key.device)
+        cuda_ba.prepare(key, bound, 0, ws)
+        self.n_seg, _, self.seg_start, self.perm = cuda_ba.prepared_tables(ws, E, bound, 0)
+        self.n_seg_dev = torch.tensor([self.n_seg], dtype=torch.int32, device=key.device)
+        self.seg_start = self.seg_start.contiguous()
+        self.group_of = torch.empty(E, dtype=torch.int32, device=key.device)
+
+
+def _ln(x, add1, add2, mod, relu=False):
+    out = torch.empty_like(x)
+    rc = L.lib().devo_upd_layernorm(L.ptr(x), L.ptr(add1), L.ptr(add2), L.ptr(mod.weight), L.ptr(mod.bias), L.ptr(out),
+                                    x.shape[0], x.shape[1], float(mod.eps), int(relu), L.dtype_code(x), L.stream())
+    L.check(rc, "update.layernorm")
+    return out
+
+
+class Update(nn.Module):
+    def __init__(self, p, dim=DIM):
+        super().__init__()
+        self.dim = dim
+        self.c1 = nn.Sequential(nn.Linear(dim, dim), nn.ReLU(inplace=True), nn.Linear(dim, dim))
+        self.c2 = nn.Sequential(nn.Linear(dim, dim), nn.ReLU(inplace=True), nn.Linear(dim, dim))
+        self.norm = nn.LayerNorm(dim, eps=1e-3)
+        self.agg_kk = SoftAgg(dim)
+        self.agg_ij = SoftAgg(dim)
+        self.gru = nn.Sequential(nn.LayerNorm(dim, eps=1e-3), GatedResidual(dim), nn.LayerNorm(dim, eps=1e-3), GatedResidual(dim))
+        self.corr = nn.Sequential(nn.Linear(2 * 49 * p * p, dim), nn.ReLU(inplace=True), nn.Linear(dim, dim),
+                                  nn.LayerNorm(dim, eps=1e-3), nn.ReLU(inplace=True), nn.Linear(dim, dim))
+        self.d = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(dim, 2), GradientClip())
+        self.w = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(dim, 2), GradientClip(), nn.Sigmoid())
+        self._graph_key, self._graph = None, None
+
+    # ------------------------------------------------------------------------------------------ torch / autograd path
+    def forward_torch(self, net, inp, corr, ii, jj, kk):
+        """enet.py:80-99 as a torch composition over GPU tensors (differentiable)."""
+        net = net + inp + self.corr(corr)
+        net = self.norm(net)
+        ix, jx = cuda_ba.neighbors(kk, jj)              # HIP kernel: GPU tensors only, like everything here
+        mask_ix = (ix >= 0).to(net.dtype).reshape(1, -1, 1)
+        mask_jx = (jx >= 0).to(net.dtype).reshape(1, -1, 1)
+        net = net + self.c1(mask_ix * net[:, ix])
+        net = net + self.c2(mask_jx * net[:, jx])
+        net = net + self.agg_kk(net, kk)
+        net = net + self.agg_ij(net, ii * 12345 + jj)
+        net = self.gru(net)
+        return net, (self.d(net), self.w(net), None)
+
+    # ------------------------------------------------------------------------------------------ HIP inference path
+    def _tables(self, ii, jj, kk):
+        key = (ii.data_ptr(), jj.data_ptr(), kk.data_ptr(), ii._version, jj._version, kk._version, ii.numel())
+        if key != self._graph_key:
+            ix, jx = cuda_ba.neighbors(kk, jj)
+            self._graph = (ix, jx, _Groups(kk.long().contiguous()), _Groups((ii.long() * 12345 + jj.long()).contiguous()))
+            self._graph_key = key
+        return self._graph
+
+    def _soft_agg(self, agg, net, G):
+        f, g = F.linear(net, agg.f.weight, agg.f.bias), F.linear(net, agg.g.weight, agg.g.bias)
+        y = torch.empty(G.n_seg, net.shape[1], dtype=net.dtype, device=net.device)
+        lib, dt, E, dim = L.lib(), L.dtype_code(net), net.shape[0], net.shape[1]
+        L.check(lib.devo_upd_softagg(L.ptr(f), L.ptr(g), L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev), L.ptr(y),
+                                     L.ptr(G.group_of), E, dim, dt, L.stream()), "update.softagg")
+        hy = F.linear(y, agg.h.weight, agg.h.bias)
+        L.check(lib.devo_upd_expand_add(L.ptr(net), L.ptr(hy), L.ptr(G.group_of), E, dim, dt, L.stream()), "update.expand_add")
+
+    def _gated(self, gr, x):
+        gate = F.linear(x, gr.gate[0].weight, gr.gate[0].bias)
+        res = F.linear(torch.relu_(F.linear(x, gr.res[0].weight, gr.res[0].bias)), gr.res[2].weight, gr.res[2].bias)
+        out = torch.empty_like(x)
+        L.check(L.lib().devo_upd_gated_residual(L.ptr(x), L.ptr(gate), L.ptr(res), L.ptr(out), x.numel(), L.dtype_code(x), L.stream()),
+                "update.gated_residual")
+        return out
+
+    def forward(self, net, inp, corr, flow, ii, jj, kk):
+        """update operator (enet.py:80): -> net, (delta, weight, None)"""
+        if torch.is_grad_enabled() and (net.requires_grad or inp.requires_grad or corr.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            return self.forward_torch(net, inp, corr, ii, jj, kk)
+        L.require_gpu(net, inp, corr, ii, jj, kk)
+        B, E, dim = net.shape
+        if B != 1:
+            raise RuntimeError("Update: batch size 1 (DEVO never batches the update operator)")
+        dt = self.norm.weight.dtype
+        x, inp2, c = net.reshape(E, dim).to(dt).contiguous(), inp.reshape(E, dim).to(dt).contiguous(), corr.reshape(E, -1).to(dt)
+        lib, code = L.lib(), L.dtype_code(x)
+        ix, jx, Gkk, Gij = self._tables(ii, jj, kk)
+
+        # corr MLP (enet.py:59-66) and net = norm(net + inp + corr)  (:82-83), the two adds fused into the LayerNorm
+        c = torch.relu_(F.linear(c, self.corr[0].weight, self.corr[0].bias))
+        c = F.linear(c, self.corr[2].weight, self.corr[2].bias)
+        c = _ln(c, None, None, self.corr[3], relu=True)
+        c = F.linear(c, self.corr[5].weight, self.corr[5].bias)
+        x = _ln(x, inp2, c, self.norm)
+
+        # neighbour mixing along the patch trajectory (:86-91)
+        for mlp, idx in ((self.c1, ix), (self.c2, jx)):
+            t = torch.empty_like(x)
+            L.check(lib.devo_upd_masked_gather(L.ptr(x), L.ptr(idx), L.ptr(t), E, dim, code, L.stream()), "update.masked_gather")
+            t = torch.relu_(F.linear(t, mlp[0].weight, mlp[0].bias))
+            x = torch.addmm(x, t, mlp[2].weight.t()).add_(mlp[2].bias)
+
+        # soft aggregation over the edges of a patch, then over the edges of a frame pair (:93-94)
+        self._soft_agg(self.agg_kk, x, Gkk)
+        self._soft_agg(self.agg_ij, x, Gij)
+
+        # "gru": LayerNorm -> GatedResidual, twice (:52-57)
+        x = self._gated(self.gru[1], _ln(x, None, None, self.gru[0]))
+        x = self._gated(self.gru[3], _ln(x, None, None, self.gru[2]))
+
+        delta = torch.empty(E, 2, dtype=dt, device=x.device)
+        weight = torch.empty(E, 2, dtype=dt, device=x.device)
+        L.check(lib.devo_upd_heads(L.ptr(x), L.ptr(self.d[1].weight), L.ptr(self.d[1].bias), L.ptr(self.w[1].weight),
+                                   L.ptr(self.w[1].bias), L.ptr(delta), L.ptr(weight), E, dim, code, L.stream()), "update.heads")
+        return x.view(1, E, dim), (delta.view(1, E, 2), weight.view(1, E, 2), None)

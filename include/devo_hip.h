@@ -186,6 +186,40 @@ int devo_se3_act4_backward(const void* grad, const void* X, const void* p, void*
 int devo_se3_as_matrix(const void* X, void* T44, int64_t n, int dtype, devo_stream_t s);            /* :313 as_matrix */
 int devo_se3_jinv(const void* X, const void* a, void* b, int64_t n, int dtype, devo_stream_t s);    /* :314 Jinv */
 
+/* ------------------------------------------------------------------------------------------------
+ * Update operator pieces (devo/enet.py:32-99, devo/blocks.py:15-48) — the reductions and
+ * element-wise steps between the GEMMs (the dense layers are plain library GEMMs issued by the host side).
+ * T = DEVO_F32 / DEVO_F16 storage, fp32 arithmetic; rows are contiguous [rows, dim].
+ * ---------------------------------------------------------------------------------------------- */
+
+/* out = LayerNorm(x + add1 + add2) * gamma + beta (nn.LayerNorm(dim, eps), enet.py:47,53-55,65; add1/add2 may be
+ * NULL: the residual sums of enet.py:82-83 fused in), optionally followed by ReLU (enet.py:65-66). dim <= 1024. */
+int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const void* gamma, const void* beta,
+                       void* out, int64_t rows, int dim, float eps, int relu, int dtype, devo_stream_t stream);
+
+/* out[e] = idx[e] >= 0 ? src[idx[e]] : 0   — `mask * net[:, ix]` of enet.py:87-91 (idx from devo_ba_neighbors). */
+int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64_t E, int dim, int dtype,
+                           devo_stream_t stream);
+
+/* SoftAgg reduction (blocks.py:42-43: torch_scatter.scatter_softmax + scatter_sum over dim 1): for every group s
+ * (edges perm[seg_start[s] .. seg_start[s+1]), tables from devo_ba_prepare / devo_ba_prepared_tables on the group key,
+ * *n_seg groups) y[s] = sum_e f[e] * softmax_over_group(g)[e], channel-wise.  group_of i32 [E] (optional) receives
+ * the group index of every edge for devo_upd_expand_add. */
+int devo_upd_softagg(const void* f, const void* g, const int* perm, const int* seg_start, const int* n_seg, void* y,
+                     int* group_of, int64_t E, int dim, int dtype, devo_stream_t stream);
+
+/* net[e] += hy[group_of[e]]   — `net + h(y)[:, jx]` of blocks.py:46 / enet.py:93-94, in place. */
+int devo_upd_expand_add(void* net, const void* hy, const int* group_of, int64_t E, int dim, int dtype,
+                        devo_stream_t stream);
+
+/* out = x + sigmoid(gate) * res   — GatedResidual (blocks.py:28-29) after its three Linear layers. */
+int devo_upd_gated_residual(const void* x, const void* gate, const void* res, void* out, int64_t n, int dtype,
+                            devo_stream_t stream);
+
+/* delta[e] = Wd relu(net[e]) + bd;  weight[e] = sigmoid(Ww relu(net[e]) + bw)   (Wd, Ww [2, dim]; enet.py:68-78). */
+int devo_upd_heads(const void* net, const void* Wd, const void* bd, const void* Ww, const void* bw, void* delta,
+                   void* weight, int64_t E, int dim, int dtype, devo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

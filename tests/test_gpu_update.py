@@ -1,0 +1,118 @@
+"""GPU parity of the Update operator (devo_amd/update.py + csrc/update.hip through the C ABI)
+against the CPU oracle (oracle/update.py, itself pinned to the reference's devo.enet.Update by tests/golden/update_f64.npz):
+the reference-generated golden at dim 32, the real width (dim 384) on a cfg-like graph with random weights, fp16
+storage, the torch/autograd path, and the individual fused ops.  Tolerance: 1e-4 of the output scale in fp32 (north_star),
+2e-2 for fp16 storage."""
+import os
+import numpy as np
+import pytest
+import torch
+from oracle import update as U
+from devo_amd import synth
+from util import assert_rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _module(sd, p=3, dim=None, dtype=torch.float32):
+    from devo_amd.update import Update
+    dim = dim or sd["norm.weight"].numel()
+    m = Update(p, dim=dim)
+    m.load_state_dict({k: v.float() for k, v in sd.items()})       # the reference's own keys
+    return m.to(DEV).to(dtype).eval()
+
+
+def test_update_matches_reference_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "update_f64.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    m = _module(sd)
+    for tag in ("irregular", "full"):
+        t = lambda k: torch.from_numpy(z[f"{tag}/{k}"])
+        with torch.no_grad():
+            net, (delta, weight, _) = m(t("net").to(DEV), t("inp").to(DEV), t("corr").to(DEV), None,
+                                        t("ii").to(DEV), t("jj").to(DEV), t("kk").to(DEV))
+        assert_rel(net, t("net_out"), 1e-4, f"{tag} net")
+        assert_rel(delta, t("delta"), 1e-4, f"{tag} delta")
+        assert_rel(weight, t("weight"), 1e-4, f"{tag} weight")
+
+
+def _random_case(n=8, M=12, dim=384, seed=5, keep=0.9):
+    from devo_amd.update import Update
+    torch.manual_seed(seed)
+    m = Update(3, dim=dim)
+    sd = {k: v.double() for k, v in m.state_dict().items()}
+    ii, jj, kk = synth.full_graph(n, M)
+    g = torch.Generator().manual_seed(seed)
+    sel = torch.randperm(len(ii), generator=g)[: int(keep * len(ii))]
+    ii, jj, kk = ii[sel], jj[sel], kk[sel]
+    E = len(ii)
+    net = torch.randn(1, E, dim, generator=g)
+    inp = torch.randn(1, E, dim, generator=g)
+    corr = torch.randn(1, E, 882, generator=g)
+    return m, sd, net, inp, corr, ii, jj, kk
+
+
+def test_update_full_width_fp32_fp16_and_torch_path():
+    m, sd, net, inp, corr, ii, jj, kk = _random_case()
+    ref = U.update(sd, net.double(), inp.double(), corr.double(), ii, jj, kk)
+    args = (net.to(DEV), inp.to(DEV), corr.to(DEV), None, ii.to(DEV), jj.to(DEV), kk.to(DEV))
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        n1, (d1, w1, _) = m(*args)
+        n1b, (d1b, w1b, _) = m(*args)                               # cached graph tables
+    for got, want, name in ((n1, ref[0], "net"), (d1, ref[1], "delta"), (w1, ref[2], "weight")):
+        assert_rel(got, want, 1e-4, f"fp32 {name}")
+    assert torch.equal(n1, n1b) and torch.equal(d1, d1b) and torch.equal(w1, w1b)
+    # differentiable torch composition on the GPU (no torch_scatter): same values, gradients flow
+    netg = args[0].clone().requires_grad_(True)
+    n2, (d2, w2, _) = m(netg, *args[1:])
+    assert_rel(n2.detach(), ref[0], 1e-4, "torch path net")
+    (d2.sum() + w2.sum()).backward()
+    assert torch.isfinite(netg.grad).all() and float(netg.grad.abs().max()) > 0
+    # fp16 storage (DEVO runs the update under autocast)
+    mh = m.half()
+    with torch.no_grad():
+        n3, (d3, w3, _) = mh(args[0].half(), args[1].half(), args[2].half(), None, *args[4:])
+    assert n3.dtype == torch.float16
+    assert_rel(n3.float(), ref[0], 2e-2, "fp16 net")
+    assert_rel(w3.float(), ref[2], 2e-2, "fp16 weight")
+
+
+def test_update_single_ops():
+    """layer norm (+ fused adds, ReLU), masked gather, soft aggregation, gated residual, heads — each against torch"""
+    import devo_amd._lib as L
+    from devo_amd.update import _Groups
+    g = torch.Generator().manual_seed(3)
+    E, dim = 777, 384
+    x, a, b = (torch.randn(E, dim, generator=g).to(DEV) for _ in range(3))
+    gam, bet = torch.randn(dim, generator=g).to(DEV), torch.randn(dim, generator=g).to(DEV)
+    out = torch.empty_like(x)
+    lib = L.lib()
+    L.check(lib.devo_upd_layernorm(L.ptr(x), L.ptr(a), L.ptr(b), L.ptr(gam), L.ptr(bet), L.ptr(out), E, dim, 1e-3, 1, 0, L.stream()), "ln")
+    ref = torch.relu(torch.nn.functional.layer_norm((x + a + b).double(), (dim,), gam.double(), bet.double(), 1e-3))
+    assert_rel(out, ref, 1e-5, "layernorm")
+    idx = torch.randint(-1, E, (E,), generator=g).to(DEV)
+    L.check(lib.devo_upd_masked_gather(L.ptr(x), L.ptr(idx), L.ptr(out), E, dim, 0, L.stream()), "gather")
+    assert torch.equal(out, x[idx] * (idx >= 0).float()[:, None])
+    key = torch.randint(0, 40, (E,), generator=g) * 977                # sparse key range
+    G = _Groups(key.to(DEV))
+    y = torch.empty(G.n_seg, dim, device=DEV)
+    L.check(lib.devo_upd_softagg(L.ptr(x), L.ptr(a), L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev), L.ptr(y), L.ptr(G.group_of),
+                                 E, dim, 0, L.stream()), "softagg")
+    _, inv = torch.unique(key, return_inverse=True)
+    yref = U.segment_softmax_sum(x.cpu().double()[None], a.cpu().double()[None], inv)[0]
+    assert G.n_seg == yref.shape[0] and torch.equal(G.group_of.cpu().long(), inv)
+    assert_rel(y, yref, 1e-5, "softagg")
+    net = b.clone()
+    L.check(lib.devo_upd_expand_add(L.ptr(net), L.ptr(y), L.ptr(G.group_of), E, dim, 0, L.stream()), "expand")
+    assert_rel(net, b.cpu().double() + yref[inv], 1e-5, "expand_add")
+    L.check(lib.devo_upd_gated_residual(L.ptr(x), L.ptr(a), L.ptr(b), L.ptr(out), x.numel(), 0, L.stream()), "gated")
+    assert_rel(out, x.double() + torch.sigmoid(a.double()) * b.double(), 1e-5, "gated residual")
+    Wd, Ww = torch.randn(2, dim, generator=g).to(DEV) / 20, torch.randn(2, dim, generator=g).to(DEV) / 20
+    bd, bw = torch.randn(2, generator=g).to(DEV), torch.randn(2, generator=g).to(DEV)
+    delta, weight = torch.empty(E, 2, device=DEV), torch.empty(E, 2, device=DEV)
+    L.check(lib.devo_upd_heads(L.ptr(x), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(delta), L.ptr(weight), E, dim, 0, L.stream()), "heads")
+    r = torch.relu(x.double())
+    assert_rel(delta, r @ Wd.double().t() + bd.double(), 1e-5, "delta head")
+    assert_rel(weight, torch.sigmoid(r @ Ww.double().t() + bw.double()), 1e-5, "weight head")

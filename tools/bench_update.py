@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Time the Update operator at the metric's configuration (cfg2: E = 21 600 edges, dim 384):
+HIP inference path (library GEMMs + fused kernels of csrc/update.hip) vs the plain torch composition of the same module
+on the same GPU, fp32 and fp16 storage.  Not part of the headline metric (SURVEY §8d excludes the Update MLP)."""
+import argparse, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from devo_amd import synth
+from devo_amd.update import Update
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="cfg2")
+ap.add_argument("--reps", type=int, default=20)
+a = ap.parse_args()
+cfg = synth.workload(a.workload)
+dev = torch.device("cuda", 0)
+ii, jj, kk = (t.to(dev) for t in synth.full_graph(cfg["n"], cfg["M"]))
+E = ii.numel()
+torch.manual_seed(0)
+for dtype in (torch.float32, torch.float16):
+    m = Update(3).to(dev).to(dtype).eval()
+    net, inp = torch.randn(1, E, 384, device=dev, dtype=dtype), torch.randn(1, E, 384, device=dev, dtype=dtype)
+    corr = torch.randn(1, E, 882, device=dev, dtype=dtype)
+    def hip():
+        with torch.no_grad():
+            return m(net, inp, corr, None, ii, jj, kk)
+    def ref():
+        with torch.no_grad():
+            return m.forward_torch(net, inp, corr, ii, jj, kk)
+    for name, fn in (("hip", hip), ("torch", ref)):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps): fn()
+        e1.record(); torch.cuda.synchronize()
+        print(f"update op  E={E} dim=384 {str(dtype)[6:]:8s} {name:6s} {e0.elapsed_time(e1) / a.reps:8.3f} ms", flush=True)

@@ -30,45 +30,72 @@ __device__ __forceinline__ float wsum(float v) {
 
 constexpr int UPD_MAXPER = 16;      // elements of a row per lane: dim <= 1024
 
-// out[r] = LN(x[r] + a[r] + b[r]) * gamma + beta  (a, b optional), optionally ReLU'd; optional copy of the pre-norm sum.
-// One wave per row; two-pass mean / variance in registers (the row is read once).
-template <typename T>
+template <typename T> struct Vec2;
+template <> struct Vec2<float> { typedef float2 type; };
+template <> struct Vec2<__half> { typedef __half2 type; };
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 ld2(const __half* p) { return __half22float2(*reinterpret_cast<const __half2*>(p)); }
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ void st2(__half* p, float2 v) { *reinterpret_cast<__half2*>(p) = __float22half2_rn(v); }
+
+// out[r] = LN(x[r] + a[r] + b[r]) * gamma + beta  (a, b optional), optionally ReLU'd.
+// One wave per row; two-pass mean / variance in registers (the row is read once).  PAIRS: the row is walked in
+// 128-element strips, every lane owning 2 adjacent elements of a strip (8- / 4-byte accesses); otherwise scalars.
+template <typename T, bool PAIRS>
 __global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ b,
                                                    const T* __restrict__ gamma, const T* __restrict__ beta,
                                                    T* __restrict__ out, int64_t rows, int dim, float eps, int relu) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const int per = (dim + 63) / 64;
+  constexpr int W = PAIRS ? 2 : 1;
+  const int per = (dim + 64 * W - 1) / (64 * W);
   float v[UPD_MAXPER];
   float s = 0.0f;
 #pragma unroll
-  for (int k = 0; k < UPD_MAXPER; k++) {
-    const int c = lane + 64 * k;
-    v[k] = 0.0f;
+  for (int k = 0; k < UPD_MAXPER / W; k++) {
+    const int c = (lane + 64 * k) * W;
     if (k < per && c < dim) {
-      float t = ld(x + row * dim + c);
-      if (a) t += ld(a + row * dim + c);
-      if (b) t += ld(b + row * dim + c);
-      v[k] = t;
-      s += t;
+      if (PAIRS) {
+        float2 t = ld2(x + row * dim + c);
+        if (a) { const float2 u = ld2(a + row * dim + c); t.x += u.x; t.y += u.y; }
+        if (b) { const float2 u = ld2(b + row * dim + c); t.x += u.x; t.y += u.y; }
+        v[2 * k] = t.x; v[2 * k + 1] = t.y;
+        s += t.x + t.y;
+      } else {
+        float t = ld(x + row * dim + c);
+        if (a) t += ld(a + row * dim + c);
+        if (b) t += ld(b + row * dim + c);
+        v[k] = t;
+        s += t;
+      }
     }
   }
   const float mean = wsum(s) / (float)dim;
   float q = 0.0f;
 #pragma unroll
-  for (int k = 0; k < UPD_MAXPER; k++) {
-    const int c = lane + 64 * k;
-    if (k < per && c < dim) { const float d = v[k] - mean; q += d * d; }
+  for (int k = 0; k < UPD_MAXPER / W; k++) {
+    const int c = (lane + 64 * k) * W;
+    if (k < per && c < dim) {
+#pragma unroll
+      for (int u = 0; u < W; u++) { const float d = v[W * k + u] - mean; q += d * d; }
+    }
   }
   const float rstd = rsqrtf(wsum(q) / (float)dim + eps);           // biased variance, like torch.nn.LayerNorm
 #pragma unroll
-  for (int k = 0; k < UPD_MAXPER; k++) {
-    const int c = lane + 64 * k;
+  for (int k = 0; k < UPD_MAXPER / W; k++) {
+    const int c = (lane + 64 * k) * W;
     if (k < per && c < dim) {
-      float o = (v[k] - mean) * rstd * ld(gamma + c) + ld(beta + c);
-      if (relu) o = fmaxf(o, 0.0f);
-      st(out + row * dim + c, o);
+      if (PAIRS) {
+        const float2 gm = ld2(gamma + c), bt = ld2(beta + c);
+        float2 o = make_float2((v[2 * k] - mean) * rstd * gm.x + bt.x, (v[2 * k + 1] - mean) * rstd * gm.y + bt.y);
+        if (relu) { o.x = fmaxf(o.x, 0.0f); o.y = fmaxf(o.y, 0.0f); }
+        st2(out + row * dim + c, o);
+      } else {
+        float o = (v[k] - mean) * rstd * ld(gamma + c) + ld(beta + c);
+        if (relu) o = fmaxf(o, 0.0f);
+        st(out + row * dim + c, o);
+      }
     }
   }
 }
@@ -87,28 +114,30 @@ __global__ void k_masked_gather(const T* __restrict__ src, const int64_t* __rest
 
 // SoftAgg reduction: for group s (edges perm[seg[s] .. seg[s+1])) and channel c
 //   y[s][c] = sum_e f[e][c] * exp(g[e][c] - max_e g[e][c]) / sum_e exp(g[e][c] - max)
-// one thread per channel, workgroups stride over the groups (n_seg lives on the device); group_of[e] = s is
-// written for the expand step.
+// ONE pass over the group's rows (online softmax: the running sums are rescaled when the maximum grows), one thread per
+// channel pair, workgroups stride over the groups (n_seg lives on the device).  f and g have row stride `ld_fg` (they
+// may be the two halves of one [E, 2 dim] GEMM output).  group_of[e] = s is written for the expand step.
 template <typename T>
-__global__ __launch_bounds__(256) void k_softagg(const T* __restrict__ f, const T* __restrict__ g, const int* __restrict__ perm,
-                                                 const int* __restrict__ seg, const int* __restrict__ n_seg_p, T* __restrict__ y,
+__global__ __launch_bounds__(256) void k_softagg(const T* __restrict__ f, const T* __restrict__ g, int64_t ld_fg,
+                                                 const int* __restrict__ perm, const int* __restrict__ seg,
+                                                 const int* __restrict__ n_seg_p, T* __restrict__ y,
                                                  int* __restrict__ group_of, int dim) {
   const int n_seg = *n_seg_p;
-  const int nslab = (dim + 255) / 256;
+  const int nslab = (dim + 511) / 512;
   for (int w = blockIdx.x; w < n_seg * nslab; w += gridDim.x) {
-    const int s = w / nslab, c = (w - s * nslab) * 256 + threadIdx.x;
+    const int s = w / nslab, c = ((w - s * nslab) * 256 + threadIdx.x) * 2;
     const int a0 = seg[s], a1 = seg[s + 1];
-    if (c < dim) {
-      float m = -3.0e38f;
-      for (int a = a0; a < a1; a++) m = fmaxf(m, ld(g + (int64_t)perm[a] * dim + c));
-      float den = 0.0f, num = 0.0f;
+    if (c < dim) {                                           // dim is even (checked by the launcher)
+      float m0 = -3.0e38f, m1 = -3.0e38f, den0 = 0.0f, den1 = 0.0f, num0 = 0.0f, num1 = 0.0f;
       for (int a = a0; a < a1; a++) {
         const int64_t e = perm[a];
-        const float w_ = __expf(ld(g + e * dim + c) - m);
-        den += w_;
-        num += ld(f + e * dim + c) * w_;
+        const float2 gv = ld2(g + e * ld_fg + c), fv = ld2(f + e * ld_fg + c);
+        const float n0 = fmaxf(m0, gv.x), n1 = fmaxf(m1, gv.y);
+        const float r0 = __expf(m0 - n0), r1 = __expf(m1 - n1), w0 = __expf(gv.x - n0), w1 = __expf(gv.y - n1);
+        den0 = den0 * r0 + w0; num0 = num0 * r0 + fv.x * w0; m0 = n0;
+        den1 = den1 * r1 + w1; num1 = num1 * r1 + fv.y * w1; m1 = n1;
       }
-      st(y + (int64_t)s * dim + c, num / den);
+      st2(y + (int64_t)s * dim + c, make_float2(num0 / den0, num1 / den1));
     }
     if (group_of && (w - s * nslab) == 0)
       for (int a = a0 + threadIdx.x; a < a1; a += 256) group_of[perm[a]] = s;
@@ -126,11 +155,15 @@ __global__ void k_expand_add(T* __restrict__ net, const T* __restrict__ hy, cons
   }
 }
 
-// out = x + sigmoid(gate) * res
+// out = x + sigmoid(gate) * res      (gate rows have stride ld_gate: it may be a column block of a wider GEMM output)
 template <typename T>
-__global__ void k_gated_residual(const T* __restrict__ x, const T* __restrict__ gate, const T* __restrict__ res, T* __restrict__ out, int64_t n) {
+__global__ void k_gated_residual(const T* __restrict__ x, const T* __restrict__ gate, int64_t ld_gate, const T* __restrict__ res,
+                                 T* __restrict__ out, int64_t rows, int dim) {
+  const int64_t n = rows * dim;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gt = 1.0f / (1.0f + __expf(-ld(gate + i)));
+    const int64_t r = i / dim;
+    const int c = (int)(i - r * dim);
+    const float gt = 1.0f / (1.0f + __expf(-ld(gate + r * ld_gate + c)));
     st(out + i, ld(x + i) + gt * ld(res + i));
   }
 }
@@ -183,9 +216,17 @@ int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const 
   if (rows == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  UPD_DISPATCH(dtype,
-    hipLaunchKernelGGL(k_layernorm<float>, grid, block, 0, st_, (const float*)x, (const float*)add1, (const float*)add2, (const float*)gamma, (const float*)beta, (float*)out, rows, dim, eps, relu),
-    hipLaunchKernelGGL(k_layernorm<__half>, grid, block, 0, st_, (const __half*)x, (const __half*)add1, (const __half*)add2, (const __half*)gamma, (const __half*)beta, (__half*)out, rows, dim, eps, relu));
+  auto al8 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+  const bool pairs = (dim % 2 == 0) && al8(x) && al8(add1) && al8(add2) && al8(gamma) && al8(beta) && al8(out);
+  if (pairs) {
+    UPD_DISPATCH(dtype,
+      hipLaunchKernelGGL((k_layernorm<float, true>), grid, block, 0, st_, (const float*)x, (const float*)add1, (const float*)add2, (const float*)gamma, (const float*)beta, (float*)out, rows, dim, eps, relu),
+      hipLaunchKernelGGL((k_layernorm<__half, true>), grid, block, 0, st_, (const __half*)x, (const __half*)add1, (const __half*)add2, (const __half*)gamma, (const __half*)beta, (__half*)out, rows, dim, eps, relu));
+  } else {
+    UPD_DISPATCH(dtype,
+      hipLaunchKernelGGL((k_layernorm<float, false>), grid, block, 0, st_, (const float*)x, (const float*)add1, (const float*)add2, (const float*)gamma, (const float*)beta, (float*)out, rows, dim, eps, relu),
+      hipLaunchKernelGGL((k_layernorm<__half, false>), grid, block, 0, st_, (const __half*)x, (const __half*)add1, (const __half*)add2, (const __half*)gamma, (const __half*)beta, (__half*)out, rows, dim, eps, relu));
+  }
   return check_launch("devo_upd_layernorm");
 }
 
@@ -200,15 +241,16 @@ int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64
   return check_launch("devo_upd_masked_gather");
 }
 
-int devo_upd_softagg(const void* f, const void* g, const int* perm, const int* seg_start, const int* n_seg, void* y,
-                     int* group_of, int64_t E, int dim, int dtype, devo_stream_t stream) {
-  DEVO_REQUIRE(E >= 0 && dim > 0, "devo_upd_softagg: bad sizes");
+int devo_upd_softagg(const void* f, const void* g, int64_t ld_fg, const int* perm, const int* seg_start, const int* n_seg,
+                     void* y, int* group_of, int64_t E, int dim, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && dim > 0 && dim % 2 == 0 && ld_fg >= dim && ld_fg % 2 == 0, "devo_upd_softagg: bad sizes (dim and the row stride must be even)");
+  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y)) & 7) == 0, "devo_upd_softagg: operands must be 8-byte aligned");
   if (E == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
-  const dim3 grid(grid_for(E * ((dim + 255) / 256), 1, 2048)), block(256);
+  const dim3 grid(grid_for(E * ((dim + 511) / 512), 1, 4096)), block(256);
   UPD_DISPATCH(dtype,
-    hipLaunchKernelGGL(k_softagg<float>, grid, block, 0, st_, (const float*)f, (const float*)g, perm, seg_start, n_seg, (float*)y, group_of, dim),
-    hipLaunchKernelGGL(k_softagg<__half>, grid, block, 0, st_, (const __half*)f, (const __half*)g, perm, seg_start, n_seg, (__half*)y, group_of, dim));
+    hipLaunchKernelGGL(k_softagg<float>, grid, block, 0, st_, (const float*)f, (const float*)g, ld_fg, perm, seg_start, n_seg, (float*)y, group_of, dim),
+    hipLaunchKernelGGL(k_softagg<__half>, grid, block, 0, st_, (const __half*)f, (const __half*)g, ld_fg, perm, seg_start, n_seg, (__half*)y, group_of, dim));
   return check_launch("devo_upd_softagg");
 }
 
@@ -223,14 +265,15 @@ int devo_upd_expand_add(void* net, const void* hy, const int* group_of, int64_t 
   return check_launch("devo_upd_expand_add");
 }
 
-int devo_upd_gated_residual(const void* x, const void* gate, const void* res, void* out, int64_t n, int dtype, devo_stream_t stream) {
-  DEVO_REQUIRE(n >= 0, "devo_upd_gated_residual: bad size");
-  if (n == 0) return DEVO_OK;
+int devo_upd_gated_residual(const void* x, const void* gate, int64_t ld_gate, const void* res, void* out, int64_t rows, int dim,
+                            int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(rows >= 0 && dim > 0 && ld_gate >= dim, "devo_upd_gated_residual: bad sizes");
+  if (rows == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
-  const dim3 grid(grid_for(n, 256, 8192)), block(256);
+  const dim3 grid(grid_for(rows * dim, 256, 8192)), block(256);
   UPD_DISPATCH(dtype,
-    hipLaunchKernelGGL(k_gated_residual<float>, grid, block, 0, st_, (const float*)x, (const float*)gate, (const float*)res, (float*)out, n),
-    hipLaunchKernelGGL(k_gated_residual<__half>, grid, block, 0, st_, (const __half*)x, (const __half*)gate, (const __half*)res, (__half*)out, n));
+    hipLaunchKernelGGL(k_gated_residual<float>, grid, block, 0, st_, (const float*)x, (const float*)gate, ld_gate, (const float*)res, (float*)out, rows, dim),
+    hipLaunchKernelGGL(k_gated_residual<__half>, grid, block, 0, st_, (const __half*)x, (const __half*)gate, ld_gate, (const __half*)res, (__half*)out, rows, dim));
   return check_launch("devo_upd_gated_residual");
 }
 

@@ -89,7 +89,7 @@ class Update(nn.Module):
                                   nn.LayerNorm(dim, eps=1e-3), nn.ReLU(inplace=True), nn.Linear(dim, dim))
         self.d = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(dim, 2), GradientClip())
         self.w = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(dim, 2), GradientClip(), nn.Sigmoid())
-        self._graph_key, self._graph = None, None
+        self._graph_key, self._graph, self._wcat = None, None, {}
 
     # ------------------------------------------------------------------------------------------ torch / autograd path
     def forward_torch(self, net, inp, corr, ii, jj, kk):
@@ -115,20 +115,38 @@ class Update(nn.Module):
             self._graph_key = key
         return self._graph
 
-    def _soft_agg(self, agg, net, G):
-        f, g = F.linear(net, agg.f.weight, agg.f.bias), F.linear(net, agg.g.weight, agg.g.bias)
-        y = torch.empty(G.n_seg, net.shape[1], dtype=net.dtype, device=net.device)
-        lib, dt, E, dim = L.lib(), L.dtype_code(net), net.shape[0], net.shape[1]
-        L.check(lib.devo_upd_softagg(L.ptr(f), L.ptr(g), L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev), L.ptr(y),
-                                     L.ptr(G.group_of), E, dim, dt, L.stream()), "update.softagg")
+    # The f and g layers of a SoftAgg share their input: ONE GEMM on concatenated weights (cached, rebuilt when a parameter
+    # changes).
+    def _cat(self, name, a, b):
+        key = (a.weight.data_ptr(), a.weight._version, b.weight.data_ptr(), b.weight._version, a.weight.dtype)
+        hit = self._wcat.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, torch.cat([a.weight, b.weight], 0).contiguous(), torch.cat([a.bias, b.bias], 0).contiguous())
+            self._wcat[name] = hit
+        return hit[1], hit[2]
+
+    @staticmethod
+    def _linear_relu(x, lin):
+        """relu(x W^T + b) with the bias and the ReLU in the GEMM epilogue (hipBLASLt)"""
+        return torch._addmm_activation(lin.bias, x, lin.weight.t(), use_gelu=False)
+
+    def _soft_agg(self, name, agg, net, G):
+        W, b = self._cat(name, agg.f, agg.g)
+        fg = F.linear(net, W, b)                                   # [E, 2 dim]: f | g
+        E, dim = net.shape
+        y = torch.empty(G.n_seg, dim, dtype=net.dtype, device=net.device)
+        lib, dt = L.lib(), L.dtype_code(net)
+        L.check(lib.devo_upd_softagg(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
+                                     L.ptr(y), L.ptr(G.group_of), E, dim, dt, L.stream()), "update.softagg")
         hy = F.linear(y, agg.h.weight, agg.h.bias)
         L.check(lib.devo_upd_expand_add(L.ptr(net), L.ptr(hy), L.ptr(G.group_of), E, dim, dt, L.stream()), "update.expand_add")
 
     def _gated(self, gr, x):
         gate = F.linear(x, gr.gate[0].weight, gr.gate[0].bias)
-        res = F.linear(torch.relu_(F.linear(x, gr.res[0].weight, gr.res[0].bias)), gr.res[2].weight, gr.res[2].bias)
+        res = F.linear(self._linear_relu(x, gr.res[0]), gr.res[2].weight, gr.res[2].bias)     # ReLU in the GEMM epilogue
         out = torch.empty_like(x)
-        L.check(L.lib().devo_upd_gated_residual(L.ptr(x), L.ptr(gate), L.ptr(res), L.ptr(out), x.numel(), L.dtype_code(x), L.stream()),
+        E, dim = x.shape
+        L.check(L.lib().devo_upd_gated_residual(L.ptr(x), L.ptr(gate), dim, L.ptr(res), L.ptr(out), E, dim, L.dtype_code(x), L.stream()),
                 "update.gated_residual")
         return out
 
@@ -147,7 +165,7 @@ class Update(nn.Module):
         ix, jx, Gkk, Gij = self._tables(ii, jj, kk)
 
         # corr MLP (enet.py:59-66) and net = norm(net + inp + corr)  (:82-83), the two adds fused into the LayerNorm
-        c = torch.relu_(F.linear(c, self.corr[0].weight, self.corr[0].bias))
+        c = self._linear_relu(c, self.corr[0])
         c = F.linear(c, self.corr[2].weight, self.corr[2].bias)
         c = _ln(c, None, None, self.corr[3], relu=True)
         c = F.linear(c, self.corr[5].weight, self.corr[5].bias)
@@ -157,12 +175,12 @@ class Update(nn.Module):
         for mlp, idx in ((self.c1, ix), (self.c2, jx)):
             t = torch.empty_like(x)
             L.check(lib.devo_upd_masked_gather(L.ptr(x), L.ptr(idx), L.ptr(t), E, dim, code, L.stream()), "update.masked_gather")
-            t = torch.relu_(F.linear(t, mlp[0].weight, mlp[0].bias))
-            x = torch.addmm(x, t, mlp[2].weight.t()).add_(mlp[2].bias)
+            t = self._linear_relu(t, mlp[0])
+            x.add_(F.linear(t, mlp[2].weight, mlp[2].bias))
 
         # soft aggregation over the edges of a patch, then over the edges of a frame pair (:93-94)
-        self._soft_agg(self.agg_kk, x, Gkk)
-        self._soft_agg(self.agg_ij, x, Gij)
+        self._soft_agg("agg_kk", self.agg_kk, x, Gkk)
+        self._soft_agg("agg_ij", self.agg_ij, x, Gij)
 
         # "gru": LayerNorm -> GatedResidual, twice (:52-57)
         x = self._gated(self.gru[1], _ln(x, None, None, self.gru[0]))

@@ -204,17 +204,19 @@ int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64
 /* SoftAgg reduction (blocks.py:42-43: torch_scatter.scatter_softmax + scatter_sum over dim 1): for every group s
  * (edges perm[seg_start[s] .. seg_start[s+1]), tables from devo_ba_prepare / devo_ba_prepared_tables on the group key,
  * *n_seg groups) y[s] = sum_e f[e] * softmax_over_group(g)[e], channel-wise.  group_of i32 [E] (optional) receives
- * the group index of every edge for devo_upd_expand_add. */
-int devo_upd_softagg(const void* f, const void* g, const int* perm, const int* seg_start, const int* n_seg, void* y,
-                     int* group_of, int64_t E, int dim, int dtype, devo_stream_t stream);
+ * the group index of every edge for devo_upd_expand_add.  f and g may be column blocks of one wider matrix (the two
+ * Linear layers share their input: one GEMM): rows of stride ld_fg.  dim even, operands 8-byte aligned. */
+int devo_upd_softagg(const void* f, const void* g, int64_t ld_fg /* row stride of f and g (>= dim) */, const int* perm,
+                     const int* seg_start, const int* n_seg, void* y, int* group_of, int64_t E, int dim, int dtype,
+                     devo_stream_t stream);
 
 /* net[e] += hy[group_of[e]]   — `net + h(y)[:, jx]` of blocks.py:46 / enet.py:93-94, in place. */
 int devo_upd_expand_add(void* net, const void* hy, const int* group_of, int64_t E, int dim, int dtype,
                         devo_stream_t stream);
 
 /* out = x + sigmoid(gate) * res   — GatedResidual (blocks.py:28-29) after its three Linear layers. */
-int devo_upd_gated_residual(const void* x, const void* gate, const void* res, void* out, int64_t n, int dtype,
-                            devo_stream_t stream);
+int devo_upd_gated_residual(const void* x, const void* gate, int64_t ld_gate /* row stride of gate */, const void* res,
+                            void* out, int64_t rows, int dim, int dtype, devo_stream_t stream);
 
 /* delta[e] = Wd relu(net[e]) + bd;  weight[e] = sigmoid(Ww relu(net[e]) + bw)   (Wd, Ww [2, dim]; enet.py:68-78). */
 int devo_upd_heads(const void* net, const void* Wd, const void* bd, const void* Ww, const void* bw, void* delta,

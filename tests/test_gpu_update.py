@@ -98,7 +98,7 @@ def test_update_single_ops():
     key = torch.randint(0, 40, (E,), generator=g) * 977                # sparse key range
     G = _Groups(key.to(DEV))
     y = torch.empty(G.n_seg, dim, device=DEV)
-    L.check(lib.devo_upd_softagg(L.ptr(x), L.ptr(a), L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev), L.ptr(y), L.ptr(G.group_of),
+    L.check(lib.devo_upd_softagg(L.ptr(x), L.ptr(a), dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev), L.ptr(y), L.ptr(G.group_of),
                                  E, dim, 0, L.stream()), "softagg")
     _, inv = torch.unique(key, return_inverse=True)
     yref = U.segment_softmax_sum(x.cpu().double()[None], a.cpu().double()[None], inv)[0]
@@ -107,7 +107,7 @@ def test_update_single_ops():
     net = b.clone()
     L.check(lib.devo_upd_expand_add(L.ptr(net), L.ptr(y), L.ptr(G.group_of), E, dim, 0, L.stream()), "expand")
     assert_rel(net, b.cpu().double() + yref[inv], 1e-5, "expand_add")
-    L.check(lib.devo_upd_gated_residual(L.ptr(x), L.ptr(a), L.ptr(b), L.ptr(out), x.numel(), 0, L.stream()), "gated")
+    L.check(lib.devo_upd_gated_residual(L.ptr(x), L.ptr(a), dim, L.ptr(b), L.ptr(out), E, dim, 0, L.stream()), "gated")
     assert_rel(out, x.double() + torch.sigmoid(a.double()) * b.double(), 1e-5, "gated residual")
     Wd, Ww = torch.randn(2, dim, generator=g).to(DEV) / 20, torch.randn(2, dim, generator=g).to(DEV) / 20
     bd, bw = torch.randn(2, generator=g).to(DEV), torch.randn(2, generator=g).to(DEV)

@@ -11,13 +11,15 @@ from devo_amd.update import Update
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="cfg2")
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--only", default="", help="hip | torch")
+ap.add_argument("--dtype", default="", help="f32 | f16")
 a = ap.parse_args()
 cfg = synth.workload(a.workload)
 dev = torch.device("cuda", 0)
 ii, jj, kk = (t.to(dev) for t in synth.full_graph(cfg["n"], cfg["M"]))
 E = ii.numel()
 torch.manual_seed(0)
-for dtype in (torch.float32, torch.float16):
+for dtype in [d for d in (torch.float32, torch.float16) if not a.dtype or a.dtype == {torch.float32: 'f32', torch.float16: 'f16'}[d]]:
     m = Update(3).to(dev).to(dtype).eval()
     net, inp = torch.randn(1, E, 384, device=dev, dtype=dtype), torch.randn(1, E, 384, device=dev, dtype=dtype)
     corr = torch.randn(1, E, 882, device=dev, dtype=dtype)
@@ -27,7 +29,7 @@ for dtype in (torch.float32, torch.float16):
     def ref():
         with torch.no_grad():
             return m.forward_torch(net, inp, corr, ii, jj, kk)
-    for name, fn in (("hip", hip), ("torch", ref)):
+    for name, fn in [(n_, f_) for n_, f_ in (("hip", hip), ("torch", ref)) if not a.only or a.only == n_]:
         for _ in range(3): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -18,9 +18,19 @@ from .backends import cuda_ba
 DIM = 384
 
 
-class GradientClip(nn.Module):                       # blocks.py:50-58: identity in the forward pass
-    def forward(self, x):
+class _GradClip(torch.autograd.Function):            # blocks.py:72-81: identity forward; backward NaN -> 0, clamp +-0.01
+    @staticmethod
+    def forward(ctx, x):
         return x
+
+    @staticmethod
+    def backward(ctx, grad):
+        return torch.nan_to_num(grad, nan=0.0, posinf=float("inf"), neginf=float("-inf")).clamp(min=-0.01, max=0.01)
+
+
+class GradientClip(nn.Module):                       # blocks.py:84-89
+    def forward(self, x):
+        return _GradClip.apply(x)
 
 
 class GatedResidual(nn.Module):                      # blocks.py:15-29

@@ -116,3 +116,13 @@ def test_update_single_ops():
     r = torch.relu(x.double())
     assert_rel(delta, r @ Wd.double().t() + bd.double(), 1e-5, "delta head")
     assert_rel(weight, torch.sigmoid(r @ Ww.double().t() + bw.double()), 1e-5, "weight head")
+
+
+def test_gradient_clip_backward_semantics():
+    """blocks.py:72-81: the delta / weight heads pass gradients through GradClip — NaN -> 0, clamped to +-0.01"""
+    from devo_amd.update import GradientClip
+    x = torch.tensor([1.0, 2.0, 3.0, 4.0], device=DEV, requires_grad=True)
+    y = GradientClip()(x)
+    assert torch.equal(y, x)
+    y.backward(torch.tensor([0.5, -0.5, float("nan"), 0.003], device=DEV))
+    assert torch.equal(x.grad.cpu(), torch.tensor([0.01, -0.01, 0.0, 0.003]))

@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=50, help="launch pairs timed for the roofline figure")
+    ap.add_argument("--with-update", action="store_true",
+                    help="additionally time a FULL DEVO update iteration: the step with the Update operator (devo_amd.update, "
+                         "random weights, fp16) between lookup and BA, feeding delta / weight to the BA (extra field; the headline "
+                         "metric excludes the Update MLP, SURVEY 8d)")
     return ap.parse_args()
 
 
@@ -231,6 +235,33 @@ def main():
                      "alg_bytes_per_launch": int(b_alg), "us_per_launch": round(t_launch * 1e6, 2)},
         "ba": {"gpu_ms": round(t_ba_gpu * 1e3, 4)},
     }
+
+    if args.with_update:
+        from devo_amd.update import Update
+        torch.manual_seed(1234 + rank)
+        upd = Update(3).to(device).half().eval()
+        net_h = torch.zeros(1, E, 384, device=device, dtype=torch.float16)
+        inp_h = torch.randn(1, E, 384, device=device, dtype=torch.float16) * 0.1
+
+        def full_iteration():
+            d["state"].copy_(d["state0"])
+            coords = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
+            lookup(coords)
+            with torch.no_grad():
+                _, (delta, weight, _) = upd(net_h, inp_h, corr_out.half(), None, d["ii"], d["jj"], d["kk"])
+            target = coords[:, :, :, 1, 1] + delta.float()
+            cuda_ba.forward(d["poses"], d["patches"], d["intr"], target, weight.float(), d["lmbda"],
+                            d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
+        for _ in range(3):
+            full_iteration()
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(30):
+            full_iteration()
+        ev1.record()
+        torch.cuda.synchronize()
+        out["full_update_iteration"] = {"ms": round(ev0.elapsed_time(ev1) / 30, 4),
+                                        "note": "reproject + 2-level lookup + Update operator (fp16, random weights) + 2 GN iterations, eager launches"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, cpu, E)

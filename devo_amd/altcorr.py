@@ -72,6 +72,31 @@ def channel_blocked(fmap, cb=8):
     return fmap.reshape(B, n, C // cb, cb, H, W).permute(0, 1, 2, 4, 5, 3).contiguous()
 
 
+def build_pyramid(fmap, out=None, slot=None):
+    """devo/devo.py:526-527 + utils.py:70-79 in one kernel: NCHW frames fmap [B, n, C, H, W] -> the two channel-blocked
+    pyramid levels the lookup kernel wants, ([B, n, C/8, H, W, 8], [B, n, C/8, H/4, W/4, 8]) (level 1 = 4x4 mean).
+    `out=(l0, l1), slot=k`: write the n frames of `fmap` into frames k.. of existing ring buffers instead."""
+    from . import _lib as L
+    L.require_gpu(fmap)
+    B, n, C, H, W = fmap.shape
+    fmap = fmap.contiguous()
+    if out is None:
+        l0 = torch.empty(B, n, C // 8, H, W, 8, dtype=fmap.dtype, device=fmap.device)
+        l1 = torch.empty(B, n, C // 8, H // 4, W // 4, 8, dtype=fmap.dtype, device=fmap.device)
+        views = [(fmap[b], l0[b], l1[b]) for b in range(B)]
+    else:
+        l0, l1 = out
+        k = int(slot or 0)
+        if l0.shape[2:] != (C // 8, H, W, 8) or l1.shape[2:] != (C // 8, H // 4, W // 4, 8) or not (l0.is_contiguous() and l1.is_contiguous()):
+            raise RuntimeError("build_pyramid: ring buffers must be contiguous channel-blocked tensors of matching size")
+        views = [(fmap[b], l0[b, k:k + n], l1[b, k:k + n]) for b in range(B)]
+    for src, d0, d1 in views:
+        rc = L.lib().devo_pyramid_build(L.ptr(src), L.ptr(d0), L.ptr(d1), n, C, H, W, C * H * W, d0.stride(0), d1.stride(0),
+                                        L.dtype_code(fmap), L.stream())
+        L.check(rc, "altcorr.build_pyramid")
+    return l0, l1
+
+
 def channels_last(fmap):
     """Re-lay a [B,n,C,H,W] feature pyramid level as channels-last storage (strides (.., 1, W*C, C)) while
     keeping its logical shape: this is the layout the LDS-staged lookup kernel wants."""

@@ -701,6 +701,56 @@ __global__ void patchify_bwd_kernel(const float* __restrict__ coords, const T* _
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Pyramid build for the lookup (devo/devo.py:526-527, devo/utils.py:70-79): from NCHW feature frames to the
+// channel-blocked storage the staged lookup kernel wants, both levels in one pass over the input:
+//   l0[f][c/8][y][x][c%8]        = fmap[f][c][y][x]                                   (avg_pool2d(.,1,1) = copy)
+//   l1[f][c/8][y/4][x/4][c%8]    = mean of the 4x4 window (F.avg_pool2d(fmap, 4, 4): floor(H/4) x floor(W/4))
+// One workgroup = 8 channels x 4 rows x 128 columns, transposed through LDS: reads are coalesced along x of one
+// channel row, writes are whole 32-byte pixel blocks of consecutive pixels.
+// -------------------------------------------------------------------------------------------------
+constexpr int PYR_WC = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void pyramid_blocked_kernel(const T* __restrict__ fmap, T* __restrict__ l0, T* __restrict__ l1,
+                                                              int C, int H, int W, int64_t f_stride, int64_t l0_fstride,
+                                                              int64_t l1_fstride) {
+  __shared__ float tile[8][4][PYR_WC + 1];
+  const int nrb = (H + 3) / 4, ncb = C / 8;
+  const int f = blockIdx.x / (ncb * nrb), rem = blockIdx.x - f * ncb * nrb;
+  const int cb = rem / nrb, rb = rem - cb * nrb;
+  const int x0 = blockIdx.y * PYR_WC, y0 = rb * 4;
+  const int wc = min(PYR_WC, W - x0);
+  const T* src = fmap + (int64_t)f * f_stride + (int64_t)cb * 8 * H * W;
+  for (int i = threadIdx.x; i < 8 * 4 * PYR_WC; i += 256) {
+    const int x = i % PYR_WC, r = (i / PYR_WC) % 4, ch = i / (4 * PYR_WC);
+    const int y = y0 + r;
+    tile[ch][r][x] = (x < wc && y < H) ? to_f32<T>(src[((int64_t)ch * H + y) * W + x0 + x]) : 0.0f;
+  }
+  __syncthreads();
+  T* d0 = l0 + (int64_t)f * l0_fstride + (int64_t)cb * H * W * 8;
+  for (int i = threadIdx.x; i < 4 * PYR_WC * 8; i += 256) {              // consecutive threads -> consecutive output elements
+    const int ch = i % 8, x = (i / 8) % PYR_WC, r = i / (8 * PYR_WC);
+    const int y = y0 + r;
+    if (x < wc && y < H) d0[((int64_t)y * W + x0 + x) * 8 + ch] = from_f32<T>(tile[ch][r][x]);
+  }
+  const int H4 = H / 4, W4 = W / 4;
+  if (l1 && rb < H4) {
+    T* d1 = l1 + (int64_t)f * l1_fstride + ((int64_t)cb * H4 + rb) * W4 * 8;
+    for (int i = threadIdx.x; i < (PYR_WC / 4) * 8; i += 256) {
+      const int ch = i % 8, xp = i / 8;
+      const int gx = x0 / 4 + xp;
+      if (gx < W4) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int u = 0; u < 4; u++) sum += tile[ch][r][4 * xp + u];
+        d1[(int64_t)gx * 8 + ch] = from_f32<T>(sum * 0.0625f);
+      }
+    }
+  }
+}
+
 }  // namespace devo
 
 using namespace devo;
@@ -854,6 +904,21 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
   // not both levels readable by the staged kernel: the caller issues one devo_corr_forward per level instead
   set_error("devo_corr_forward_pyramid2: levels not eligible for the fused launch (layout / dtype)");
   return DEVO_ERR_UNSUPPORTED;
+}
+
+int devo_pyramid_build(const void* fmap, void* l0, void* l1, int F, int C, int H, int W, int64_t fmap_fstride,
+                       int64_t l0_fstride, int64_t l1_fstride, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(F >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "devo_pyramid_build: bad sizes (C must be a multiple of 8)");
+  DEVO_REQUIRE(fmap && l0, "devo_pyramid_build: null tensor");
+  if (F == 0) return DEVO_OK;
+  const dim3 grid((unsigned)((long long)F * (C / 8) * ((H + 3) / 4)), (unsigned)((W + PYR_WC - 1) / PYR_WC)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DEVO_F32)
+    hipLaunchKernelGGL(pyramid_blocked_kernel<float>, grid, block, 0, st, (const float*)fmap, (float*)l0, (float*)l1, C, H, W, fmap_fstride, l0_fstride, l1_fstride);
+  else if (dtype == DEVO_F16)
+    hipLaunchKernelGGL(pyramid_blocked_kernel<__half>, grid, block, 0, st, (const __half*)fmap, (__half*)l0, (__half*)l1, C, H, W, fmap_fstride, l0_fstride, l1_fstride);
+  else { set_error("devo_pyramid_build: fp32 / fp16 only"); return DEVO_ERR_UNSUPPORTED; }
+  return check_launch("devo_pyramid_build");
 }
 
 int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, int E, int n2, int P, int H2,

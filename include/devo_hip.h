@@ -78,6 +78,14 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
 int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, int E, int n2, int P, int H2,
                     float coord_scale, int radius, devo_stream_t stream);
 
+/* Pyramid build for the lookup (devo/devo.py:526-527: fmap1_[slot] = avg_pool2d(fmap, 1, 1), fmap2_[slot] =
+ * avg_pool2d(fmap, 4, 4); devo/utils.py:70-79): F frames fmap T [F, C, H, W] (contiguous frames, frame stride
+ * fmap_fstride elements) -> channel-blocked level 0  l0 T [F, C/8, H, W, 8] and level 1  l1 T [F, C/8, H/4, W/4, 8]
+ * (4x4 mean; NULL = skip), frame strides l0_fstride / l1_fstride so that a frame can be written into a slot of a
+ * ring buffer.  One pass over the input.  DEVO_F32 / DEVO_F16 (fp32 accumulation). */
+int devo_pyramid_build(const void* fmap, void* l0, void* l1, int F, int C, int H, int W, int64_t fmap_fstride,
+                       int64_t l0_fstride, int64_t l1_fstride, int dtype, devo_stream_t stream);
+
 /* cuda_corr.backward  (correlation.cpp:59 -> correlation_kernel.cu:236-286, kernel :139-190).
  *   grad f32: the gradient of the logical [B,E,D-1,D-1,P,P] output, contiguous.
  *   fmap1_grad [B,Np,C,P,P] contiguous, fmap2_grad with the strides of fmap2: both are ZEROED and then

@@ -272,3 +272,23 @@ def test_fused_pyramid_odd_edge_count_and_batch_of_two():
     ref = torch.stack([A.corr_forward(f1.cpu(), f2, coords.cpu(), ii.cpu(), jj.cpu(), R),
                        A.corr_forward(f1.cpu(), f2b, coords.cpu() / 4, ii.cpu(), jj.cpu(), R)], -1)
     assert_rel(fused, ref.view(B, E, -1), 1e-4, "fused pyramid B=2")
+
+
+def test_build_pyramid_blocked():
+    """devo.py:526-527 / utils.py:70-79 in one kernel: blocked level 0 is a bit-exact re-layout, level 1 the 4x4 mean
+    (torch's avg_pool2d sums in another order: 1e-6), odd sizes floor like avg_pool2d, ring-buffer slots, fp16."""
+    from devo_amd import altcorr
+    g = torch.Generator().manual_seed(71)
+    for (n, C, H, W), dt in (((3, 128, 30, 44), torch.float32), ((2, 16, 17, 150), torch.float32), ((2, 64, 32, 48), torch.float16)):
+        f = (torch.randn(1, n, C, H, W, generator=g) / 4).to(DEV, dt)
+        l0, l1 = altcorr.build_pyramid(f)
+        assert torch.equal(l0, altcorr.channel_blocked(f, 8))
+        ref1 = torch.nn.functional.avg_pool2d(f[0].float(), 4, 4)[None]
+        assert l1.shape == (1, n, C // 8, H // 4, W // 4, 8)
+        got1 = l1.permute(0, 1, 2, 5, 3, 4).reshape(1, n, C, H // 4, W // 4).float()
+        assert_rel(got1, ref1, 1e-6 if dt == torch.float32 else 2e-3, "pooled level")
+    ring0 = torch.zeros(1, 5, 16, 30, 44, 8, device=DEV); ring1 = torch.zeros(1, 5, 16, 7, 11, 8, device=DEV)
+    f = torch.randn(1, 1, 128, 30, 44, generator=g).to(DEV)
+    altcorr.build_pyramid(f, out=(ring0, ring1), slot=3)
+    a0, a1 = altcorr.build_pyramid(f)
+    assert torch.equal(ring0[:, 3:4], a0) and torch.equal(ring1[:, 3:4], a1) and float(ring0[:, :3].abs().max()) == 0.0

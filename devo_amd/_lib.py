@@ -47,6 +47,11 @@ _SIGNATURES.update({
     "devo_upd_gated_residual": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp],
     "devo_upd_heads": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
 })
+_SIGNATURES.update({
+    "devo_voxelize": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp],
+    "devo_voxel_std_workspace_bytes": [_i],
+    "devo_voxel_std": [_vp, _i, _i64, _vp, _sz, _vp],
+})
 for _n in ("exp", "log", "inv"):
     _SIGNATURES[f"devo_se3_{_n}"] = [_vp, _vp, _i64, _i, _vp]
     _SIGNATURES[f"devo_se3_{_n}_backward"] = [_vp, _vp, _vp, _i64, _i, _vp]
@@ -55,7 +60,7 @@ for _n in ("mul", "adj", "adjT", "act", "act4"):
     _SIGNATURES[f"devo_se3_{_n}_backward"] = [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]
 _SIGNATURES["devo_se3_as_matrix"] = [_vp, _vp, _i64, _i, _vp]
 _SIGNATURES["devo_se3_jinv"] = [_vp, _vp, _vp, _i64, _i, _vp]
-_RESTYPE = {"devo_last_error": ctypes.c_char_p, "devo_ba_workspace_bytes": _sz, "devo_neighbors_workspace_bytes": _sz}
+_RESTYPE = {"devo_last_error": ctypes.c_char_p, "devo_voxel_std_workspace_bytes": _sz, "devo_ba_workspace_bytes": _sz, "devo_neighbors_workspace_bytes": _sz}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -230,6 +230,22 @@ int devo_upd_gated_residual(const void* x, const void* gate, int64_t ld_gate /* 
 int devo_upd_heads(const void* net, const void* Wd, const void* bd, const void* Ww, const void* bw, void* delta,
                    void* weight, int64_t E, int dim, int dtype, devo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Event voxelisation — the step in front of the encoders.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* to_voxel_grid (utils/event_utils.py:180-232): N events (x, y f32 pixel coordinates, t f64 ascending timestamps,
+ * p i8 polarity with 0 meaning -1) vote trilinearly into grid f32 [bins, H, W] (zeroed here; corners outside are
+ * dropped).  Weights in fp64 like the reference, accumulation with fp32 atomics (order differs: fp32 rounding). */
+int devo_voxelize(const float* xs, const float* ys, const double* ts, const signed char* ps, int64_t N, int H, int W,
+                  int bins, float* grid, devo_stream_t stream);
+
+/* std (utils/voxel_utils.py:6-28, devo/devo.py:438-452), in place: vox f32 [nseg, len] — nseg = b (sequence-wise) or
+ * b*n (frame-wise); every segment's NON-ZERO entries are standardised with the mean / stddev of those entries; nothing
+ * is changed if any segment has no non-zero entry.  ws: devo_voxel_std_workspace_bytes(nseg). */
+size_t devo_voxel_std_workspace_bytes(int nseg);
+int devo_voxel_std(float* vox, int nseg, int64_t len, void* ws, size_t ws_bytes, devo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

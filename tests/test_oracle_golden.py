@@ -99,3 +99,17 @@ def test_update_operator_matches_reference(golden_dir):
         for got, ref in ((net, t("net_out")), (delta, t("delta")), (weight, t("weight"))):
             assert got.shape == ref.shape
             assert float((got - ref).abs().max()) <= 1e-10 * max(1.0, float(ref.abs().max()))
+
+
+def test_event_voxel_grid_and_std_match_reference(golden_dir):
+    """oracle/events.py == the reference's to_voxel_grid (utils/event_utils.py:180-232) and std (utils/voxel_utils.py:6-28)"""
+    import numpy as np
+    from oracle import events as EV
+    z = np.load(os.path.join(golden_dir, "events_f32.npz"))
+    for tag, (H, W) in (("int", (48, 64)), ("frac", (40, 56))):
+        vox = EV.to_voxel_grid(z[f"{tag}/xs"], z[f"{tag}/ys"], z[f"{tag}/ts"], z[f"{tag}/ps"], H, W, 5)
+        ref = torch.from_numpy(z[f"{tag}/vox"])
+        assert torch.equal(vox, ref)                            # same operations in the same order: bit-identical
+        seq = torch.stack([ref, ref.flip(0) * 0.5])[None]
+        assert torch.equal(EV.std(seq.clone(), True), torch.from_numpy(z[f"{tag}/std_seq"]))
+        assert torch.equal(EV.std(seq.clone(), False), torch.from_numpy(z[f"{tag}/std_frame"]))

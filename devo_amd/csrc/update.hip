@@ -41,8 +41,13 @@ __device__ __forceinline__ void st2(__half* p, float2 v) { *reinterpret_cast<__h
 // out[r] = LN(x[r] + a[r] + b[r]) * gamma + beta  (a, b optional), optionally ReLU'd.
 // One wave per row; two-pass mean / variance in registers (the row is read once).  PAIRS: the row is walked in
 // 128-element strips, every lane owning 2 adjacent elements of a strip (8- / 4-byte accesses); otherwise scalars.
+// Extra input terms (any may be absent): hy[group_of[row]] (SoftAgg expand, blocks.py:46) and sigmoid(gate[row]) * res[row]
+// (GatedResidual, blocks.py:28-29) — so that  net + agg(net)  and  x + gate * res  never make a round trip to HBM
+// before the LayerNorm that follows them (enet.py:52-57).
 template <typename T, bool PAIRS>
 __global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ b,
+                                                   const T* __restrict__ hy, const int* __restrict__ group_of,
+                                                   const T* __restrict__ gate, int64_t ld_gate, const T* __restrict__ res,
                                                    const T* __restrict__ gamma, const T* __restrict__ beta,
                                                    T* __restrict__ out, int64_t rows, int dim, float eps, int relu) {
   const int lane = threadIdx.x & 63;
@@ -50,6 +55,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ x, cons
   if (row >= rows) return;
   constexpr int W = PAIRS ? 2 : 1;
   const int per = (dim + 64 * W - 1) / (64 * W);
+  const T* hrow = hy ? hy + (int64_t)group_of[row] * dim : nullptr;
   float v[UPD_MAXPER];
   float s = 0.0f;
 #pragma unroll
@@ -60,12 +66,19 @@ __global__ __launch_bounds__(256) void k_layernorm(const T* __restrict__ x, cons
         float2 t = ld2(x + row * dim + c);
         if (a) { const float2 u = ld2(a + row * dim + c); t.x += u.x; t.y += u.y; }
         if (b) { const float2 u = ld2(b + row * dim + c); t.x += u.x; t.y += u.y; }
+        if (hrow) { const float2 u = ld2(hrow + c); t.x += u.x; t.y += u.y; }
+        if (gate) {
+          const float2 gv = ld2(gate + row * ld_gate + c), rv = ld2(res + row * dim + c);
+          t.x += rv.x / (1.0f + __expf(-gv.x)); t.y += rv.y / (1.0f + __expf(-gv.y));
+        }
         v[2 * k] = t.x; v[2 * k + 1] = t.y;
         s += t.x + t.y;
       } else {
         float t = ld(x + row * dim + c);
         if (a) t += ld(a + row * dim + c);
         if (b) t += ld(b + row * dim + c);
+        if (hrow) t += ld(hrow + c);
+        if (gate) t += ld(res + row * dim + c) / (1.0f + __expf(-ld(gate + row * ld_gate + c)));
         v[k] = t;
         s += t;
       }
@@ -168,17 +181,25 @@ __global__ void k_gated_residual(const T* __restrict__ x, const T* __restrict__ 
   }
 }
 
+// net[e] = x[e] + sigmoid(gate[e]) * res[e] (gate == nullptr: net = x as given, nothing stored), then
 // delta[e] = Wd relu(net[e]) + bd ; weight[e] = sigmoid(Ww relu(net[e]) + bw)   (Wd, Ww: [2, dim]); one wave per edge
 template <typename T>
-__global__ __launch_bounds__(256) void k_heads(const T* __restrict__ net, const T* __restrict__ Wd, const T* __restrict__ bd,
-                                               const T* __restrict__ Ww, const T* __restrict__ bw, T* __restrict__ delta,
-                                               T* __restrict__ weight, int64_t E, int dim) {
+__global__ __launch_bounds__(256) void k_heads(const T* __restrict__ x, const T* __restrict__ gate, int64_t ld_gate,
+                                               const T* __restrict__ res, T* __restrict__ net_out, const T* __restrict__ Wd,
+                                               const T* __restrict__ bd, const T* __restrict__ Ww, const T* __restrict__ bw,
+                                               T* __restrict__ delta, T* __restrict__ weight, int64_t E, int dim) {
   const int lane = threadIdx.x & 63;
   const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= E) return;
   float d0 = 0.0f, d1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
   for (int c = lane; c < dim; c += 64) {
-    const float v = fmaxf(ld(net + e * dim + c), 0.0f);
+    float nv = ld(x + e * dim + c);
+    if (gate) {
+      nv += ld(res + e * dim + c) / (1.0f + __expf(-ld(gate + e * ld_gate + c)));
+      st(net_out + e * dim + c, nv);
+      nv = ld(net_out + e * dim + c);                       // the heads see the stored (rounded) value, like separate kernels
+    }
+    const float v = fmaxf(nv, 0.0f);
     d0 += v * ld(Wd + c); d1 += v * ld(Wd + dim + c);
     w0 += v * ld(Ww + c); w1 += v * ld(Ww + dim + c);
   }
@@ -210,23 +231,30 @@ using namespace devo;
 
 extern "C" {
 
-int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const void* gamma, const void* beta, void* out,
-                       int64_t rows, int dim, float eps, int relu, int dtype, devo_stream_t stream) {
+int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const void* hy, const int* group_of, const void* gate,
+                       int64_t ld_gate, const void* res, const void* gamma, const void* beta, void* out, int64_t rows, int dim,
+                       float eps, int relu, int dtype, devo_stream_t stream) {
   DEVO_REQUIRE(rows >= 0 && dim > 0 && dim <= 64 * UPD_MAXPER, "devo_upd_layernorm: dim %d unsupported (1..%d)", dim, 64 * UPD_MAXPER);
+  DEVO_REQUIRE((hy == nullptr) == (group_of == nullptr) && (gate == nullptr) == (res == nullptr) && (gate == nullptr || ld_gate >= dim),
+               "devo_upd_layernorm: hy needs group_of, gate needs res");
   if (rows == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   auto al8 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
-  const bool pairs = (dim % 2 == 0) && al8(x) && al8(add1) && al8(add2) && al8(gamma) && al8(beta) && al8(out);
+  const bool pairs = (dim % 2 == 0) && (ld_gate % 2 == 0) && al8(x) && al8(add1) && al8(add2) && al8(hy) && al8(gate) && al8(res) &&
+                     al8(gamma) && al8(beta) && al8(out);
+#define LN_ARGS(TT) (const TT*)x, (const TT*)add1, (const TT*)add2, (const TT*)hy, group_of, (const TT*)gate, ld_gate, (const TT*)res, \
+                    (const TT*)gamma, (const TT*)beta, (TT*)out, rows, dim, eps, relu
   if (pairs) {
     UPD_DISPATCH(dtype,
-      hipLaunchKernelGGL((k_layernorm<float, true>), grid, block, 0, st_, (const float*)x, (const float*)add1, (const float*)add2, (const float*)gamma, (const float*)beta, (float*)out, rows, dim, eps, relu),
-      hipLaunchKernelGGL((k_layernorm<__half, true>), grid, block, 0, st_, (const __half*)x, (const __half*)add1, (const __half*)add2, (const __half*)gamma, (const __half*)beta, (__half*)out, rows, dim, eps, relu));
+      hipLaunchKernelGGL((k_layernorm<float, true>), grid, block, 0, st_, LN_ARGS(float)),
+      hipLaunchKernelGGL((k_layernorm<__half, true>), grid, block, 0, st_, LN_ARGS(__half)));
   } else {
     UPD_DISPATCH(dtype,
-      hipLaunchKernelGGL((k_layernorm<float, false>), grid, block, 0, st_, (const float*)x, (const float*)add1, (const float*)add2, (const float*)gamma, (const float*)beta, (float*)out, rows, dim, eps, relu),
-      hipLaunchKernelGGL((k_layernorm<__half, false>), grid, block, 0, st_, (const __half*)x, (const __half*)add1, (const __half*)add2, (const __half*)gamma, (const __half*)beta, (__half*)out, rows, dim, eps, relu));
+      hipLaunchKernelGGL((k_layernorm<float, false>), grid, block, 0, st_, LN_ARGS(float)),
+      hipLaunchKernelGGL((k_layernorm<__half, false>), grid, block, 0, st_, LN_ARGS(__half)));
   }
+#undef LN_ARGS
   return check_launch("devo_upd_layernorm");
 }
 
@@ -277,15 +305,16 @@ int devo_upd_gated_residual(const void* x, const void* gate, int64_t ld_gate, co
   return check_launch("devo_upd_gated_residual");
 }
 
-int devo_upd_heads(const void* net, const void* Wd, const void* bd, const void* Ww, const void* bw, void* delta, void* weight,
-                   int64_t E, int dim, int dtype, devo_stream_t stream) {
+int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void* res, void* net_out, const void* Wd, const void* bd,
+                   const void* Ww, const void* bw, void* delta, void* weight, int64_t E, int dim, int dtype, devo_stream_t stream) {
   DEVO_REQUIRE(E >= 0 && dim > 0, "devo_upd_heads: bad sizes");
+  DEVO_REQUIRE(gate == nullptr || (res != nullptr && net_out != nullptr && ld_gate >= dim), "devo_upd_heads: gate needs res and net_out");
   if (E == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
   const dim3 grid((unsigned)((E + 3) / 4)), block(256);
   UPD_DISPATCH(dtype,
-    hipLaunchKernelGGL(k_heads<float>, grid, block, 0, st_, (const float*)net, (const float*)Wd, (const float*)bd, (const float*)Ww, (const float*)bw, (float*)delta, (float*)weight, E, dim),
-    hipLaunchKernelGGL(k_heads<__half>, grid, block, 0, st_, (const __half*)net, (const __half*)Wd, (const __half*)bd, (const __half*)Ww, (const __half*)bw, (__half*)delta, (__half*)weight, E, dim));
+    hipLaunchKernelGGL(k_heads<float>, grid, block, 0, st_, (const float*)x, (const float*)gate, ld_gate, (const float*)res, (float*)net_out, (const float*)Wd, (const float*)bd, (const float*)Ww, (const float*)bw, (float*)delta, (float*)weight, E, dim),
+    hipLaunchKernelGGL(k_heads<__half>, grid, block, 0, st_, (const __half*)x, (const __half*)gate, ld_gate, (const __half*)res, (__half*)net_out, (const __half*)Wd, (const __half*)bd, (const __half*)Ww, (const __half*)bw, (__half*)delta, (__half*)weight, E, dim));
   return check_launch("devo_upd_heads");
 }
 

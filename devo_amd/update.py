@@ -77,9 +77,14 @@ class _Groups:
         self.group_of = torch.empty(E, dtype=torch.int32, device=key.device)
 
 
-def _ln(x, add1, add2, mod, relu=False):
+def _ln(x, mod, add1=None, add2=None, expand=None, gated=None, relu=False):
+    """LayerNorm(x + add1 + add2 + hy[group_of] + sigmoid(gate) * res), optionally ReLU'd — one fused kernel.
+    expand = (hy, group_of); gated = (gate, res)."""
     out = torch.empty_like(x)
-    rc = L.lib().devo_upd_layernorm(L.ptr(x), L.ptr(add1), L.ptr(add2), L.ptr(mod.weight), L.ptr(mod.bias), L.ptr(out),
+    hy, grp = expand if expand is not None else (None, None)
+    gate, res = gated if gated is not None else (None, None)
+    rc = L.lib().devo_upd_layernorm(L.ptr(x), L.ptr(add1), L.ptr(add2), L.ptr(hy), L.ptr(grp), L.ptr(gate),
+                                    gate.stride(0) if gate is not None else 0, L.ptr(res), L.ptr(mod.weight), L.ptr(mod.bias), L.ptr(out),
                                     x.shape[0], x.shape[1], float(mod.eps), int(relu), L.dtype_code(x), L.stream())
     L.check(rc, "update.layernorm")
     return out
@@ -141,24 +146,21 @@ class Update(nn.Module):
         return torch._addmm_activation(lin.bias, x, lin.weight.t(), use_gelu=False)
 
     def _soft_agg(self, name, agg, net, G):
+        """-> (h(y), group_of): the aggregated rows and the edge -> group map; the caller adds h(y)[group_of] to net
+        (devo_upd_expand_add, or fused into the LayerNorm that follows)."""
         W, b = self._cat(name, agg.f, agg.g)
         fg = F.linear(net, W, b)                                   # [E, 2 dim]: f | g
         E, dim = net.shape
         y = torch.empty(G.n_seg, dim, dtype=net.dtype, device=net.device)
-        lib, dt = L.lib(), L.dtype_code(net)
-        L.check(lib.devo_upd_softagg(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
-                                     L.ptr(y), L.ptr(G.group_of), E, dim, dt, L.stream()), "update.softagg")
-        hy = F.linear(y, agg.h.weight, agg.h.bias)
-        L.check(lib.devo_upd_expand_add(L.ptr(net), L.ptr(hy), L.ptr(G.group_of), E, dim, dt, L.stream()), "update.expand_add")
+        L.check(L.lib().devo_upd_softagg(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
+                                         L.ptr(y), L.ptr(G.group_of), E, dim, L.dtype_code(net), L.stream()), "update.softagg")
+        return F.linear(y, agg.h.weight, agg.h.bias), G.group_of
 
-    def _gated(self, gr, x):
+    def _gate_res(self, gr, x):
+        """the three Linear layers of a GatedResidual -> (gate pre-activation, res); the caller fuses x + sigmoid(gate) * res"""
         gate = F.linear(x, gr.gate[0].weight, gr.gate[0].bias)
         res = F.linear(self._linear_relu(x, gr.res[0]), gr.res[2].weight, gr.res[2].bias)     # ReLU in the GEMM epilogue
-        out = torch.empty_like(x)
-        E, dim = x.shape
-        L.check(L.lib().devo_upd_gated_residual(L.ptr(x), L.ptr(gate), dim, L.ptr(res), L.ptr(out), E, dim, L.dtype_code(x), L.stream()),
-                "update.gated_residual")
-        return out
+        return gate, res
 
     def forward(self, net, inp, corr, flow, ii, jj, kk):
         """update operator (enet.py:80): -> net, (delta, weight, None)"""
@@ -177,9 +179,9 @@ class Update(nn.Module):
         # corr MLP (enet.py:59-66) and net = norm(net + inp + corr)  (:82-83), the two adds fused into the LayerNorm
         c = self._linear_relu(c, self.corr[0])
         c = F.linear(c, self.corr[2].weight, self.corr[2].bias)
-        c = _ln(c, None, None, self.corr[3], relu=True)
+        c = _ln(c, self.corr[3], relu=True)
         c = F.linear(c, self.corr[5].weight, self.corr[5].bias)
-        x = _ln(x, inp2, c, self.norm)
+        x = _ln(x, self.norm, add1=inp2, add2=c)
 
         # neighbour mixing along the patch trajectory (:86-91)
         for mlp, idx in ((self.c1, ix), (self.c2, jx)):
@@ -188,16 +190,20 @@ class Update(nn.Module):
             t = self._linear_relu(t, mlp[0])
             x.add_(F.linear(t, mlp[2].weight, mlp[2].bias))
 
-        # soft aggregation over the edges of a patch, then over the edges of a frame pair (:93-94)
-        self._soft_agg("agg_kk", self.agg_kk, x, Gkk)
-        self._soft_agg("agg_ij", self.agg_ij, x, Gij)
+        # soft aggregation over the edges of a patch, then over the edges of a frame pair (:93-94); the second expand is
+        # fused into the LayerNorm of the "gru" (:52-57), and each GatedResidual into the op that consumes it
+        hy, grp = self._soft_agg("agg_kk", self.agg_kk, x, Gkk)
+        L.check(lib.devo_upd_expand_add(L.ptr(x), L.ptr(hy), L.ptr(grp), E, dim, code, L.stream()), "update.expand_add")
+        hy, grp = self._soft_agg("agg_ij", self.agg_ij, x, Gij)
+        x = _ln(x, self.gru[0], expand=(hy, grp))                                  # LN(net + agg_ij(net))
+        x = _ln(x, self.gru[2], gated=self._gate_res(self.gru[1], x))             # LN(GatedResidual(.))
+        gate, res = self._gate_res(self.gru[3], x)
 
-        # "gru": LayerNorm -> GatedResidual, twice (:52-57)
-        x = self._gated(self.gru[1], _ln(x, None, None, self.gru[0]))
-        x = self._gated(self.gru[3], _ln(x, None, None, self.gru[2]))
-
+        net_out = torch.empty_like(x)
         delta = torch.empty(E, 2, dtype=dt, device=x.device)
         weight = torch.empty(E, 2, dtype=dt, device=x.device)
-        L.check(lib.devo_upd_heads(L.ptr(x), L.ptr(self.d[1].weight), L.ptr(self.d[1].bias), L.ptr(self.w[1].weight),
-                                   L.ptr(self.w[1].bias), L.ptr(delta), L.ptr(weight), E, dim, code, L.stream()), "update.heads")
+        L.check(lib.devo_upd_heads(L.ptr(x), L.ptr(gate), gate.stride(0), L.ptr(res), L.ptr(net_out), L.ptr(self.d[1].weight),
+                                   L.ptr(self.d[1].bias), L.ptr(self.w[1].weight), L.ptr(self.w[1].bias), L.ptr(delta), L.ptr(weight),
+                                   E, dim, code, L.stream()), "update.heads")
+        x = net_out
         return x.view(1, E, dim), (delta.view(1, E, 2), weight.view(1, E, 2), None)

@@ -200,9 +200,12 @@ int devo_se3_jinv(const void* X, const void* a, void* b, int64_t n, int dtype, d
  * T = DEVO_F32 / DEVO_F16 storage, fp32 arithmetic; rows are contiguous [rows, dim].
  * ---------------------------------------------------------------------------------------------- */
 
-/* out = LayerNorm(x + add1 + add2) * gamma + beta (nn.LayerNorm(dim, eps), enet.py:47,53-55,65; add1/add2 may be
- * NULL: the residual sums of enet.py:82-83 fused in), optionally followed by ReLU (enet.py:65-66). dim <= 1024. */
-int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const void* gamma, const void* beta,
+/* out = LayerNorm(x + add1 + add2 + hy[group_of[row]] + sigmoid(gate) * res) * gamma + beta — nn.LayerNorm(dim, eps)
+ * (enet.py:47,53-55,65) with the sums in front of it fused in: the residual sums of enet.py:82-83 (add1, add2), the
+ * SoftAgg expand of blocks.py:46 (hy + group_of) and the GatedResidual of blocks.py:28-29 (gate with row stride
+ * ld_gate, res); every term may be NULL.  Optionally followed by ReLU (enet.py:65-66).  dim <= 1024. */
+int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const void* hy, const int* group_of,
+                       const void* gate, int64_t ld_gate, const void* res, const void* gamma, const void* beta,
                        void* out, int64_t rows, int dim, float eps, int relu, int dtype, devo_stream_t stream);
 
 /* out[e] = idx[e] >= 0 ? src[idx[e]] : 0   — `mask * net[:, ix]` of enet.py:87-91 (idx from devo_ba_neighbors). */
@@ -226,9 +229,11 @@ int devo_upd_expand_add(void* net, const void* hy, const int* group_of, int64_t 
 int devo_upd_gated_residual(const void* x, const void* gate, int64_t ld_gate /* row stride of gate */, const void* res,
                             void* out, int64_t rows, int dim, int dtype, devo_stream_t stream);
 
-/* delta[e] = Wd relu(net[e]) + bd;  weight[e] = sigmoid(Ww relu(net[e]) + bw)   (Wd, Ww [2, dim]; enet.py:68-78). */
-int devo_upd_heads(const void* net, const void* Wd, const void* bd, const void* Ww, const void* bw, void* delta,
-                   void* weight, int64_t E, int dim, int dtype, devo_stream_t stream);
+/* net[e] = x[e] + sigmoid(gate[e]) * res[e] -> net_out (the last GatedResidual; gate == NULL: net = x, nothing stored),
+ * then delta[e] = Wd relu(net[e]) + bd;  weight[e] = sigmoid(Ww relu(net[e]) + bw)   (Wd, Ww [2, dim]; enet.py:68-78). */
+int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void* res, void* net_out, const void* Wd,
+                   const void* bd, const void* Ww, const void* bw, void* delta, void* weight, int64_t E, int dim,
+                   int dtype, devo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Event voxelisation — the step in front of the encoders.

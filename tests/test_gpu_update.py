@@ -89,9 +89,19 @@ def test_update_single_ops():
     gam, bet = torch.randn(dim, generator=g).to(DEV), torch.randn(dim, generator=g).to(DEV)
     out = torch.empty_like(x)
     lib = L.lib()
-    L.check(lib.devo_upd_layernorm(L.ptr(x), L.ptr(a), L.ptr(b), L.ptr(gam), L.ptr(bet), L.ptr(out), E, dim, 1e-3, 1, 0, L.stream()), "ln")
+    N0 = None
+    L.check(lib.devo_upd_layernorm(L.ptr(x), L.ptr(a), L.ptr(b), N0, N0, N0, 0, N0, L.ptr(gam), L.ptr(bet), L.ptr(out), E, dim, 1e-3, 1, 0,
+                                   L.stream()), "ln")
     ref = torch.relu(torch.nn.functional.layer_norm((x + a + b).double(), (dim,), gam.double(), bet.double(), 1e-3))
     assert_rel(out, ref, 1e-5, "layernorm")
+    # all fused input terms at once: + hy[group_of] + sigmoid(gate) * res, gate with a wider row stride
+    hy = torch.randn(50, dim, generator=g).to(DEV)
+    grp = torch.randint(0, 50, (E,), generator=g).to(torch.int32).to(DEV)
+    wide = torch.randn(E, 2 * dim, generator=g).to(DEV)
+    L.check(lib.devo_upd_layernorm(L.ptr(x), L.ptr(a), N0, L.ptr(hy), L.ptr(grp), L.ptr(wide), 2 * dim, L.ptr(b), L.ptr(gam), L.ptr(bet),
+                                   L.ptr(out), E, dim, 1e-3, 0, 0, L.stream()), "ln fused")
+    pre = x.double() + a.double() + hy.double()[grp.long()] + torch.sigmoid(wide[:, :dim].double()) * b.double()
+    assert_rel(out, torch.nn.functional.layer_norm(pre, (dim,), gam.double(), bet.double(), 1e-3), 1e-5, "fused layernorm")
     idx = torch.randint(-1, E, (E,), generator=g).to(DEV)
     L.check(lib.devo_upd_masked_gather(L.ptr(x), L.ptr(idx), L.ptr(out), E, dim, 0, L.stream()), "gather")
     assert torch.equal(out, x[idx] * (idx >= 0).float()[:, None])
@@ -112,10 +122,17 @@ def test_update_single_ops():
     Wd, Ww = torch.randn(2, dim, generator=g).to(DEV) / 20, torch.randn(2, dim, generator=g).to(DEV) / 20
     bd, bw = torch.randn(2, generator=g).to(DEV), torch.randn(2, generator=g).to(DEV)
     delta, weight = torch.empty(E, 2, device=DEV), torch.empty(E, 2, device=DEV)
-    L.check(lib.devo_upd_heads(L.ptr(x), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(delta), L.ptr(weight), E, dim, 0, L.stream()), "heads")
+    L.check(lib.devo_upd_heads(L.ptr(x), N0, 0, N0, N0, L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(delta), L.ptr(weight), E, dim, 0,
+                               L.stream()), "heads")
     r = torch.relu(x.double())
     assert_rel(delta, r @ Wd.double().t() + bd.double(), 1e-5, "delta head")
     assert_rel(weight, torch.sigmoid(r @ Ww.double().t() + bw.double()), 1e-5, "weight head")
+    net_out = torch.empty_like(x)
+    L.check(lib.devo_upd_heads(L.ptr(x), L.ptr(wide), 2 * dim, L.ptr(b), L.ptr(net_out), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw),
+                               L.ptr(delta), L.ptr(weight), E, dim, 0, L.stream()), "gated heads")
+    nref = x.double() + torch.sigmoid(wide[:, :dim].double()) * b.double()
+    assert_rel(net_out, nref, 1e-5, "gated residual inside the heads kernel")
+    assert_rel(delta, torch.relu(nref) @ Wd.double().t() + bd.double(), 1e-5, "delta head after the gated residual")
 
 
 def test_gradient_clip_backward_semantics():

@@ -292,3 +292,19 @@ def test_build_pyramid_blocked():
     altcorr.build_pyramid(f, out=(ring0, ring1), slot=3)
     a0, a1 = altcorr.build_pyramid(f)
     assert torch.equal(ring0[:, 3:4], a0) and torch.equal(ring1[:, 3:4], a1) and float(ring0[:, :3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_forward_random_configurations(seed):
+    """random small problems: channel counts incl. non-multiples of 8 (generic kernel), tiny images (windows larger than
+    the image), every radius, few / many edges, all layouts the configuration allows — always against the oracle"""
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    C = [8, 16, 24, 64, 128, 12][ri(0, 5)]
+    R = ri(0, 5)
+    H, W = ri(4, 40), ri(4, 48)
+    c = _case(n=ri(1, 4), Np=ri(1, 9), C=C, H=H, W=W, E=ri(3, 260), R=R, seed=2000 + seed, spread=[0.3, 1.0, 2.5][ri(0, 2)])
+    ref = A.corr_forward(*c)
+    layouts = ["cl", "nchw"] + (["blk8"] if C % 8 == 0 else [])
+    for layout in layouts:
+        assert_rel(_run(*c, layout=layout), ref, 1e-4, f"seed {seed} C={C} R={R} {H}x{W} {layout}")

@@ -273,3 +273,22 @@ def test_prepare_tables_bit_exact(E, Np, ordered):
     same = inv[perm][1:] == inv[perm][:-1]
     assert bool((perm[1:][same] > perm[:-1][same]).all())       # ascending edge ids inside every patch
     assert torch.equal(torch.sort(perm).values, torch.arange(E))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ba_random_graphs(seed):
+    """random graphs: frame counts 2..16, few patches, dropped / duplicated / shuffled edges, different fixed-pose
+    windows — the register kernels of every size class (<= 8, 11, 14, 16 poses) and the irregular-patch path"""
+    g = torch.Generator().manual_seed(500 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    n = [3, 6, 9, 12, 15, 17][seed]
+    s = list(scene(n=n, M=ri(2, 7), H=96, W=128, seed=40 + seed, keep=[1.0, 0.8, 0.6][ri(0, 2)], sigma=0.5))
+    if seed % 2:                                               # duplicate a few edges (irregular patches)
+        E = len(s[5])
+        dup = torch.randint(0, E, (max(2, E // 20),), generator=g)
+        s[3] = torch.cat([s[3], s[3][:, dup]], 1); s[4] = torch.cat([s[4], s[4][:, dup]], 1)
+        for k in (5, 6, 7):
+            s[k] = torch.cat([s[k], s[k][dup]])
+    t0 = ri(1, max(1, n - 2))
+    ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], t0, n, 2, dtype=torch.float64)
+    check(run_ba(*s, t0, n, 2), ref)

@@ -292,3 +292,10 @@ def test_ba_random_graphs(seed):
     t0 = ri(1, max(1, n - 2))
     ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], t0, n, 2, dtype=torch.float64)
     check(run_ba(*s, t0, n, 2), ref)
+
+
+def test_ba_more_than_16_optimised_poses_uses_the_general_kernel():
+    """N = t1 - t0 in 17..32: the LDS-atomic accumulate kernel (no register-resident S)"""
+    s = scene(n=22, M=4, H=96, W=128, seed=77, keep=0.9, sigma=0.5)
+    ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], 1, 22, 2, dtype=torch.float64)
+    check(run_ba(*s, 1, 22, 2), ref)

@@ -12,30 +12,33 @@ from . import projective_ops as pops
 
 
 class CholeskySolver(torch.autograd.Function):
-    """devo/ba.py:12-37: solve by Cholesky; zeros and no gradient when the factorisation fails."""
+    """devo/ba.py:12-37: solve by Cholesky; zeros and no gradient when the factorisation fails.  The failure flag stays
+    on the device (no host synchronisation): the result and the gradients are masked with it."""
     @staticmethod
     def forward(ctx, H, b):
         L, info = torch.linalg.cholesky_ex(H)
-        ctx.failed = bool(torch.any(info))
-        if ctx.failed:
-            return torch.zeros_like(b)
-        x = torch.cholesky_solve(b, L)
-        ctx.save_for_backward(L, x)
+        bad = (info != 0).view(-1, 1, 1)
+        x = torch.cholesky_solve(b, torch.where(bad, torch.eye(H.shape[-1], dtype=H.dtype, device=H.device), L))
+        x = torch.where(bad, torch.zeros_like(x), x)
+        ctx.save_for_backward(L, x, bad)
         return x
 
     @staticmethod
     def backward(ctx, g):
-        if ctx.failed:
-            return None, None
-        L, x = ctx.saved_tensors
-        dz = torch.cholesky_solve(g, L)
+        L, x, bad = ctx.saved_tensors
+        Ls = torch.where(bad, torch.eye(L.shape[-1], dtype=L.dtype, device=L.device), L)
+        dz = torch.where(bad, torch.zeros_like(g), torch.cholesky_solve(g, Ls))
         return -x @ dz.transpose(-1, -2), dz
 
 
 def BA(poses, patches, intrinsics, targets, weights, lmbda, ii, jj, kk, bounds, ep=100.0, PRINT=False,
-       fixedp=1, structure_only=False):
+       fixedp=1, structure_only=False, n_frames=None):
+    """One differentiable Gauss-Newton step (devo/ba.py:86-182).  `n_frames` (optional, = max(ii, jj) + 1) saves the
+    one host synchronisation this function otherwise needs to size the pose system."""
     dev, dt = patches.device, patches.dtype
-    n = max(int(ii.max()), int(jj.max())) + 1 - fixedp
+    if n_frames is None:
+        n_frames = int(torch.maximum(ii.max(), jj.max())) + 1
+    n = int(n_frames) - fixedp
     coords, ok, (Ji, Jj, Jz) = pops.transform(poses, patches, intrinsics, ii, jj, kk, jacobian=True)
     c = coords.shape[3] // 2
     ctr = coords[0, :, c, c, :]
@@ -49,32 +52,46 @@ def BA(poses, patches, intrinsics, targets, weights, lmbda, ii, jj, kk, bounds, 
     w = gate[:, None] * weights[0]
     Ji, Jj, Jz = Ji[0], Jj[0], Jz[0, :, :, 0]
 
-    kx, ku = torch.unique(kk, return_inverse=True, sorted=True)
-    m = kx.shape[0]
+    # Patches: the reference compacts to the patches that have edges (torch.unique, ba.py:104).  Working on ALL patch
+    # slots instead gives the same update (a slot without edges has C = u = 0 and a zero column of E, hence dZ = 0) and
+    # needs neither the data-dependent output size nor the host synchronisation of unique().  Only a per-patch damping
+    # vector, which is indexed by the compacted list, still goes through unique().
+    per_patch_lmbda = isinstance(lmbda, torch.Tensor) and lmbda.numel() > 1
+    if per_patch_lmbda:
+        kx, ku = torch.unique(kk, return_inverse=True, sorted=True)
+        m = kx.shape[0]
+        lmbda = lmbda.reshape(m)
+    else:
+        kx, ku, m = None, kk, patches.shape[1]
     a, b_ = ii - fixedp, jj - fixedp
     six = torch.arange(6, device=dev)
     n6 = 6 * max(n, 0)
-    S = torch.zeros(n6, n6, dtype=dt, device=dev)
-    Emat = torch.zeros(n6, m, dtype=dt, device=dev)
+    # flat accumulators: index_add (atomics) instead of index_put(accumulate=True), which sorts its indices on the GPU
+    S = torch.zeros(n6 * n6, dtype=dt, device=dev)
+    Emat = torch.zeros(n6 * m, dtype=dt, device=dev)
     v = torch.zeros(n6, dtype=dt, device=dev)
     if n > 0:
-        for (ra, Ja), (rb, Jb) in (((a, Ji), (a, Ji)), ((a, Ji), (b_, Jj)), ((b_, Jj), (a, Ji)), ((b_, Jj), (b_, Jj))):
-            sel = (ra >= 0) & (rb >= 0) & (ra < n) & (rb < n)
-            blk = torch.einsum('er,erp,erq->epq', w, Ja, Jb)[sel]
-            rows = ((6 * ra[sel])[:, None, None] + six[None, :, None]).expand_as(blk)
-            cols = ((6 * rb[sel])[:, None, None] + six[None, None, :]).expand_as(blk)
-            S = S.index_put((rows, cols), blk, accumulate=True)
-        for ra, Ja in ((a, Ji), (b_, Jj)):
-            sel = (ra >= 0) & (ra < n)
-            rows = (6 * ra[sel])[:, None] + six[None]
-            Emat = Emat.index_put((rows, ku[sel][:, None].expand_as(rows)),
-                                  torch.einsum('er,erp,er->ep', w, Ja, Jz)[sel], accumulate=True)
-            v = v.index_put((rows,), torch.einsum('er,erp,er->ep', w, Ja, r)[sel], accumulate=True)
+        # frames outside the optimised window [fixedp, fixedp + n) contribute nothing: their blocks are zeroed and their
+        # (clamped) indices point at block 0 — no boolean-mask indexing, no host synchronisation
+        ina, inb = ((a >= 0) & (a < n)), ((b_ >= 0) & (b_ < n))
+        ca, cb = a.clamp(0, n - 1), b_.clamp(0, n - 1)
+        fa, fb = ina.to(dt), inb.to(dt)
+        for (ra, ma, Ja), (rb, mb, Jb) in (((ca, fa, Ji), (ca, fa, Ji)), ((ca, fa, Ji), (cb, fb, Jj)),
+                                           ((cb, fb, Jj), (ca, fa, Ji)), ((cb, fb, Jj), (cb, fb, Jj))):
+            # sum_r w_r Ja[r,p] Jb[r,q] as broadcast products (an einsum here becomes 18 000 batched 6x2x6 GEMMs: 140 us)
+            wj = (w * (ma * mb)[:, None])[:, :, None] * Ja
+            blk = wj[:, 0, :, None] * Jb[:, 0, None, :] + wj[:, 1, :, None] * Jb[:, 1, None, :]
+            rows = (6 * ra)[:, None, None] + six[None, :, None]
+            cols = (6 * rb)[:, None, None] + six[None, None, :]
+            S = S.index_add(0, (rows * n6 + cols).reshape(-1), blk.reshape(-1))
+        for ra, ma, Ja in ((ca, fa, Ji), (cb, fb, Jj)):
+            rows = (6 * ra)[:, None] + six[None]
+            wm = w * ma[:, None]
+            Emat = Emat.index_add(0, (rows * m + ku[:, None]).reshape(-1), (((wm * Jz)[:, :, None] * Ja).sum(1)).reshape(-1))
+            v = v.index_add(0, rows.reshape(-1), (((wm * r)[:, :, None] * Ja).sum(1)).reshape(-1))
+    S, Emat = S.view(n6, n6), Emat.view(n6, m)
     C = torch.zeros(m, dtype=dt, device=dev).index_add(0, ku, (w * Jz * Jz).sum(-1))
     u = torch.zeros(m, dtype=dt, device=dev).index_add(0, ku, (w * Jz * r).sum(-1))
-
-    if isinstance(lmbda, torch.Tensor):
-        lmbda = lmbda.reshape(m)
     Q = 1.0 / (C + lmbda)
 
     if structure_only or n == 0:
@@ -88,10 +105,13 @@ def BA(poses, patches, intrinsics, targets, weights, lmbda, ii, jj, kk, bounds, 
         dZ = Q * (u - Emat.t() @ dX)
 
     P = patches.shape[-1]
-    disp = patches[:, :, 2] + torch.zeros_like(patches[:, :, 2]).index_add(1, kx, dZ.view(1, m, 1, 1).expand(1, m, P, P))
+    if kx is None:
+        disp = patches[:, :, 2] + dZ.view(1, m, 1, 1)
+    else:
+        disp = patches[:, :, 2] + torch.zeros_like(patches[:, :, 2]).index_add(1, kx, dZ.view(1, m, 1, 1).expand(1, m, P, P))
     patches = torch.stack([patches[:, :, 0], patches[:, :, 1], disp.clamp(min=1e-3, max=10.0)], dim=2)
     if dX is not None:
         upd = torch.zeros(1, poses.data.shape[1], 6, dtype=dt, device=dev)
-        upd = upd.index_add(1, fixedp + torch.arange(n, device=dev), dX.view(1, n, 6))
+        upd[:, fixedp:fixedp + n] = dX.view(1, n, 6)
         poses = poses.retr(upd)
     return poses, patches

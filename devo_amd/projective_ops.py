@@ -42,15 +42,20 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
         return cuda_ba.transform(poses.data, patches, intrinsics, ii, jj, kk, depth=depth, valid=valid,
                                  jacobian=jacobian, tonly=tonly, layout="pp2")
 
-    Gij = poses[:, jj] * poses[:, ii].inv()
+    # gathers along the edge axis with index_select: its backward is an atomic index_add, whereas the backward of
+    # advanced indexing (`x[:, idx]`) sorts the indices on the GPU (0.3 ms per gather at 18 000 edges)
+    SE3 = type(poses)
+    take = lambda t, idx: torch.index_select(t, 1, idx)
+    Gij = SE3(take(poses.data, jj)) * SE3(take(poses.data, ii)).inv()
     if tonly:
         Gij.data[..., 3:] = torch.as_tensor([0, 0, 0, 1], dtype=Gij.data.dtype, device=Gij.data.device)
-    X1 = Gij[:, :, None, None] * iproj(patches[:, kk], intrinsics[:, ii])
+    X1 = Gij[:, :, None, None] * iproj(take(patches, kk), take(intrinsics, ii))
     c = X1.shape[2] // 2
-    x1 = proj(X1, intrinsics[:, jj], depth)
+    intr_j = take(intrinsics, jj)
+    x1 = proj(X1, intr_j, depth)
     if jacobian:
         X, Y, Z, H = X1[..., c, c, :].unbind(dim=-1)
-        fx, fy = intrinsics[:, jj, 0], intrinsics[:, jj, 1]
+        fx, fy = intr_j[..., 0], intr_j[..., 1]
         o = torch.zeros_like(Z)
         big = Z.abs() > 0.2
         d = torch.where(big, 1.0 / torch.where(big, Z, torch.ones_like(Z)), o)

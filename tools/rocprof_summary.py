@@ -22,6 +22,27 @@ def kernel_stats(path):
         print(f"{n:7d} {t:12.1f} {t / n:10.2f} {100 * t / tot:6.2f}  {name[:110]}")
 
 
+def kernel_resources(path, only="devo::"):
+    """Launch geometry and occupancy limits of every kernel (north_star: LDS / wavefront occupancy for fastba):
+    waves per SIMD allowed by VGPRs (512-entry file, granule 8) and workgroups per CU allowed by LDS (160 KiB)."""
+    seen = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            name = r.get("Kernel_Name") or ""
+            if only not in name or name in seen:
+                continue
+            seen[name] = r
+    print(f"{'grid(WGs)':>10} {'WG':>5} {'VGPR':>5} {'AGPR':>5} {'SGPR':>5} {'LDS B':>7} {'scratch':>7} {'waves/SIMD(vgpr)':>17} {'WGs/CU(lds)':>12}  kernel")
+    for name, r in seen.items():
+        wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+        grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(wg, 1)
+        v, a, lds = int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"]), int(r["LDS_Block_Size"])
+        alloc = (v + a + 7) // 8 * 8
+        wps = min(8, 512 // max(alloc, 8))
+        wgs = 163840 // lds if lds else 32
+        print(f"{grid:10d} {wg:5d} {v:5d} {a:5d} {int(r['SGPR_Count']):5d} {lds:7d} {int(r['Scratch_Size']):7d} {wps:17d} {min(wgs, 32):12d}  {name[:90]}")
+
+
 def counter_stats(path, match):
     agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
     with open(path) as f:
@@ -42,7 +63,12 @@ if __name__ == "__main__":
     match = sys.argv[2] if len(sys.argv) > 2 else "corr_fwd"
     for p in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)):
         print("==", p)
+        if match == "--resources":
+            kernel_resources(p)
+            continue
         kernel_stats(p)
+    if match == "--resources":
+        sys.exit(0)
     for p in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         print("==", p)
         counter_stats(p, match)

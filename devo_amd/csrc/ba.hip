@@ -118,6 +118,7 @@ __global__ void k_scatter_edges(const int* __restrict__ ku, int E, const int* __
 __global__ void k_sort_segments(const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int sig, const int* __restrict__ in, int* out) {
   const int* n_seg_p = &meta->n_seg;
   if (blockIdx.x == 0 && threadIdx.x == 0) meta->sig = sig;      // the workspace now holds a prepared graph
+  if (meta->pad) return;                                         // the list was already grouped: perm is the identity
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (blockDim.x * gridDim.x) >> 6;
   const int n_seg = *n_seg_p;
@@ -140,7 +141,8 @@ constexpr int PREP_FLAGS_LDS = 16384;
 constexpr int PREP_SEGS_LDS = 8192;
 template <int CACHE>      // CACHE = 0: kk is re-read by every pass; else ceil(E / 1024) <= CACHE edges per thread in registers
 __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
-                                                     int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a) {
+                                                     int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
+                                                     int* perm_b) {
   extern __shared__ int s_mem[];
   int* s_part = s_mem;                       // 1024
   int* s_flags = s_part + 1024;              // PREP_FLAGS_LDS + 1
@@ -170,7 +172,34 @@ __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__
       kreg[i] = (k >= 0 && k < Np) ? (int)k : -1;
     }
   }
-  __syncthreads();
+  // Already grouped?  If the patch ids are ascending along the edge list (kk-major graphs: enet.py:300-301, any list
+  // built patch by patch) every segment is a run, the permutation is the identity and the whole counting sort below
+  // can be skipped.  headmask bit i = edge t + 1024 i starts a run.
+  __shared__ int s_last[16][CACHED ? CACHE : 1];
+  unsigned headmask = 0u;
+  int ascending = 0;
+  if (CACHED) {
+    const int lane_ = t & 63, wave_ = t >> 6;
+    if (lane_ == 63) {
+#pragma unroll
+      for (int i = 0; i < (CACHED ? CACHE : 1); i++) s_last[wave_][i] = kreg[i];
+    }
+    __syncthreads();
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
+      const int e = t + 1024 * i;
+      int prev = __shfl_up(kreg[i], 1);
+      if (lane_ == 0) prev = (wave_ > 0) ? s_last[wave_ - 1][i] : (i > 0 ? s_last[15][i > 0 ? i - 1 : 0] : -1);
+      if (e < E) {
+        ok = ok && kreg[i] >= 0 && (e == 0 || prev <= kreg[i]);
+        if (e == 0 || prev != kreg[i]) headmask |= 1u << i;
+      }
+    }
+    ascending = __syncthreads_and(ok ? 1 : 0);
+  } else {
+    __syncthreads();
+  }
   int lo = 0x7fffffff, hi = -1;
 #pragma unroll
   for (int i = 0; i < iters; i++) { const int k = patch_of(i); if (k >= 0) { lo = min(lo, k); hi = max(hi, k); } }
@@ -186,7 +215,20 @@ __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__
   for (int i = 0; i < iters; i++) { const int k = patch_of(i); if (k >= 0) rank[k - kmin] = 1; }
   __syncthreads();
   const int n_seg = block_excl_scan_1024(rank, Rg, s_part);
-  if (t == 0) { meta->n_seg = n_seg; meta->fail = 0; }
+  if (t == 0) { meta->n_seg = n_seg; meta->fail = 0; meta->pad = ascending; }     // pad = 1: k_sort_segments has nothing to do
+  if (CACHED && ascending) {
+    // segment starts = the run heads, permutation = identity (ascending edge ids inside every patch by construction)
+#pragma unroll
+    for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
+      const int e = t + 1024 * i;
+      if (e < E) {
+        perm_b[e] = e;
+        if ((headmask >> i) & 1u) { const int r = rank[kreg[i] - kmin]; g_counts[r] = e; kx[r] = kreg[i]; }
+      }
+    }
+    for (int i = n_seg + t; i <= max_seg; i += 1024) g_counts[i] = E;      // segment n_seg starts at E; empty tails
+    return;
+  }
   int* counts = (n_seg <= PREP_SEGS_LDS) ? s_counts : g_counts;
   int* cursor = (n_seg <= PREP_SEGS_LDS) ? s_cursor : g_cursor;
   for (int i = t; i <= n_seg; i += 1024) counts[i] = 0;
@@ -1237,11 +1279,11 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     (void)hipGetLastError(); prep_attr = true;
   }
   if (E <= (1 << 17)) {
-    typedef void (*prep_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*);
+    typedef void (*prep_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*);
     const int ept = (E + 1023) / 1024;                         // edges per thread
     prep_fn_t prep = ept <= 8 ? k_ba_prepare<8> : ept <= 16 ? k_ba_prepare<16> : ept <= 24 ? k_ba_prepare<24> :
                      ept <= 32 ? k_ba_prepare<32> : k_ba_prepare<0>;
-    hipLaunchKernelGGL(prep, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a);
+    hipLaunchKernelGGL(prep, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b);
     hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, meta, ba_sig(E, N), perm_a, perm_b);
   } else {
     // (meta, rank, counts, cursor are contiguous at the head of the workspace)

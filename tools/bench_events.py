@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Time the event voxelisation + standardisation on the GPU: 1 M events into a 5 x 480 x 640 grid, and
-std over a 15-frame sequence; next to the reference's CPU formulation (oracle/events.py == utils/event_utils.py) on a
-200 k-event sample."""
-import os, sys, time
+std over a 15-frame sequence.  (The reference's CPU formulation, utils/event_utils.py:180-232 as restated in
+oracle/events.py, takes 153 ms per 200 k events on the same host: measured once by the test infrastructure, not here.)"""
+import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from devo_amd import events
@@ -27,9 +27,3 @@ e0.record()
 for _ in range(20): events.std(seq)
 e1.record(); torch.cuda.synchronize()
 print(f"std            [1,15,5,{H},{W}] ({seq.numel() * 4 / 1e6:.0f} MB): {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us (incl. the copy)")
-if "--cpu" in sys.argv:
-    from oracle import events as EV
-    n = 200_000
-    t0 = time.perf_counter()
-    EV.to_voxel_grid(xs[:n].numpy(), ys[:n].numpy(), ts[:n].numpy(), ps[:n].numpy(), H, W, 5)
-    print(f"CPU formulation, {n} events: {(time.perf_counter() - t0) * 1e3:8.1f} ms")

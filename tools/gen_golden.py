@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/*.npz by running the REAL reference Python modules
+"""TEST INFRASTRUCTURE (fixture generator; build container only — it imports the reference and oracle/).
+
+Generate tests/golden/*.npz by running the REAL reference Python modules
 (devo/projective_ops.py, devo/ba.py, devo/lietorch/groups.py) from /root/reference on CPU.
 
 Runs only in the build container (the GPU box has no /root/reference).  Nothing from the

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/events_f32.npz by running the REAL reference functions utils/event_utils.py:to_voxel_grid and
+"""TEST INFRASTRUCTURE (fixture generator; build container only — it imports the reference).
+
+Generate tests/golden/events_f32.npz by running the REAL reference functions utils/event_utils.py:to_voxel_grid and
 utils/voxel_utils.py:std from /root/reference on CPU (seeded synthetic event streams).  Build container only; the file
 holds data (inputs + expected outputs).  Import-time stubs: h5py, numba (jit = identity), torchvision.transforms.functional."""
 import os

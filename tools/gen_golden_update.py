@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/update_f64.npz by running the REAL reference `devo.enet.Update` (enet.py:32-99, with
+"""TEST INFRASTRUCTURE (fixture generator; build container only — it imports the reference and oracle/).
+
+Generate tests/golden/update_f64.npz by running the REAL reference `devo.enet.Update` (enet.py:32-99, with
 blocks.py's GatedResidual / SoftAgg) from /root/reference on CPU, fp64, at a reduced width (dim = 32) so that the
 fixture stays small.  Runs only in the build container.  Nothing from the reference is copied: the file holds data
 (seeded weights as produced by the module's own initialisers, inputs, expected outputs).

@@ -144,8 +144,10 @@ def main():
             with torch.cuda.stream(prep_stream):
                 cuda_ba.prepare(d["kk"], Np, n - 1, ws)
         d["state"].copy_(d["state0"])                                      # fresh poses + patches (bench harness)
-        coords = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
-        lookup(coords)
+        # reprojection; the kernel also emits the lookup's plan bins while it holds the coordinates
+        coords, order = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp",
+                                          plan_for=(n, cfg["H"], R))
+        lookup(coords, order=cuda_corr.plan_finish(order, d["jj"], n, cfg["H"], R))
         target = coords[:, :, :, 1, 1] + d["delta"]                        # devo.py:330
         if prep_stream is not None:
             cur.wait_stream(prep_stream)

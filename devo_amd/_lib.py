@@ -36,7 +36,7 @@ _SIGNATURES = {
     "devo_neighbors_workspace_bytes": [_i],
     "devo_ba_neighbors": [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp],
     "devo_ba_reproject": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "devo_transform": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "devo_transform": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp],
 }
 _f = ctypes.c_float
 _SIGNATURES.update({

@@ -103,9 +103,12 @@ def reproject(poses, patches, intrinsics, ii, jj, kk):
 
 
 def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, jacobian=False, tonly=False,
-              layout="pp2"):
+              layout="pp2", plan_for=None):
     """Fused projective transform with the semantics of devo/projective_ops.py:53-105 (batch 1, no autograd).
-    layout "pp2": coords [1,E,P,P,2|3] as the reference returns; "2pp": [1,E,2,P,P] (devo/devo.py:223)."""
+    layout "pp2": coords [1,E,P,P,2|3] as the reference returns; "2pp": [1,E,2,P,P] (devo/devo.py:223).
+    plan_for=(n_frames, height, radius): also start the lookup's locality plan for these coordinates (the kernel emits
+    the plan bins while it holds them); the half-built plan buffer is returned LAST — finish it with
+    cuda_corr.plan_finish(buffer, jj, n_frames, height, radius)."""
     L.require_gpu(poses, patches, intrinsics, ii, jj, kk)
     P = patches.shape[-1]
     ii, jj, kk = _idx(ii, jj, kk)
@@ -122,12 +125,16 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     Jj = torch.empty(1, E, 2, 6, **f32) if jacobian else None
     Jz = torch.empty(1, E, 2, 1, **f32) if jacobian else None
     flags = (1 if depth else 0) | (2 if tonly else 0)
+    plan, pf = None, (0, 0, 0)
+    if plan_for is not None:
+        pf = tuple(int(x) for x in plan_for)
+        plan = torch.empty(2 * E + 1, dtype=torch.int32, device=dev)
     rc = L.lib().devo_transform(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(ii), L.ptr(jj), L.ptr(kk),
-                                L.ptr(c_pp2), L.ptr(c_2pp), L.ptr(v), L.ptr(Ji), L.ptr(Jj), L.ptr(Jz), E, P, flags, L.stream())
+                                L.ptr(c_pp2), L.ptr(c_2pp), L.ptr(v), L.ptr(Ji), L.ptr(Jj), L.ptr(Jz), E, P, flags,
+                                L.ptr(plan), pf[0], pf[1], pf[2], L.stream())
     L.check(rc, "cuda_ba.transform")
     c = c_pp2 if layout == "pp2" else c_2pp
-    if jacobian:
-        return c, v, (Ji, Jj, Jz)
-    if valid:
-        return c, v
-    return c
+    out = (c, v, (Ji, Jj, Jz)) if jacobian else ((c, v) if valid else c)
+    if plan_for is None:
+        return out
+    return (out + (plan,)) if isinstance(out, tuple) else (out, plan)

@@ -37,6 +37,16 @@ def plan(coords, jj, n_frames, height, coord_scale=1.0, radius=3):
     return order
 
 
+def plan_finish(order, jj, n_frames, height, radius=3, batch=1):
+    """Second half of plan() for a buffer whose bins cuda_ba.transform(..., plan_for=...) has already written."""
+    L.require_gpu(order, jj)
+    jj = jj.long().contiguous()
+    E = (order.numel() - 1) // (2 * batch)
+    rc = L.lib().devo_corr_order(None, L.ptr(jj), L.ptr(order), batch, E, int(n_frames), 3, int(height), 1.0, int(radius), L.stream())
+    L.check(rc, "cuda_corr.plan_finish")
+    return order
+
+
 def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, offset, order=None, coord_div=1.0):
     """corr forward writing element l of edge (b,e) at out[(b*E+e)*estride + l*lstride + offset].
     coord_div: the kernel looks up at coords / coord_div (same IEEE division as `coords / s` on the tensor, without

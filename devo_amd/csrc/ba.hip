@@ -18,6 +18,7 @@
 #include "common.h"
 #include <cstddef>
 #include "se3_dev.h"
+#include "corr_tile.h"
 #include <stdlib.h>
 
 namespace devo {
@@ -1131,7 +1132,8 @@ __global__ void k_reproject(const float* __restrict__ poses, const float* __rest
 __global__ void k_transform(const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
                             const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
                             float* __restrict__ c_pp2, float* __restrict__ c_2pp, float* __restrict__ valid,
-                            float* __restrict__ Ji, float* __restrict__ Jj, float* __restrict__ Jz, int E, int P, int flags) {
+                            float* __restrict__ Ji, float* __restrict__ Jj, float* __restrict__ Jz, int E, int P, int flags,
+                            int* __restrict__ plan_bins, int plan_n2, int plan_H2, int plan_nb, int plan_D, int plan_ng) {
   const bool depth = flags & 1, tonly = flags & 2;
   const int PPx = P * P, ctr = (P / 2) * P + P / 2, nc = depth ? 3 : 2;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
@@ -1143,6 +1145,8 @@ __global__ void k_transform(const float* __restrict__ poses, const float* __rest
     const float fxj = intr[fj * 4], fyj = intr[fj * 4 + 1], cxj = intr[fj * 4 + 2], cyj = intr[fj * 4 + 3];
     const float* pk = patches + kk[e] * 3 * PPx;
     float Xc = 0, Yc = 0, Zc = 1, Hc = 0;
+    int bx[9], by[9];                                            // integer pixels for the lookup's locality plan (P == 3)
+    float bcy = 0.0f;
     for (int i = 0; i < PPx; i++) {
       const float w = pk[2 * PPx + i];
       V3<float> X0{(pk[i] - cxi) / fxi, (pk[PPx + i] - cyi) / fyi, 1.0f};
@@ -1152,7 +1156,10 @@ __global__ void k_transform(const float* __restrict__ poses, const float* __rest
       const float u = fxj * (d * X1.x) + cxj, v = fyj * (d * X1.y) + cyj;
       if (c_pp2) { float* o = c_pp2 + ((int64_t)e * PPx + i) * nc; o[0] = u; o[1] = v; if (depth) o[2] = d; }
       if (c_2pp) { c_2pp[(int64_t)e * 2 * PPx + i] = u; c_2pp[(int64_t)e * 2 * PPx + PPx + i] = v; }
+      if (plan_bins && i < 9) { bx[i] = corr_floor_to_int(u); by[i] = corr_floor_to_int(v); if (i == 4) bcy = v; }
     }
+    // the lookup's plan bins, while the coordinates are still in registers (saves the plan's own pass over coords)
+    if (plan_bins) plan_bins[e] = corr_plan_bin(bx, by, bcy, 0, (int)fj, plan_n2, plan_H2, plan_nb, plan_D, plan_ng);
     if (valid) valid[e] = (Zc > 0.2f) ? 1.0f : 0.0f;
     if (Jj) {
       const float d = (fabsf(Zc) > 0.2f) ? 1.0f / Zc : 0.0f;
@@ -1441,11 +1448,18 @@ int devo_ba_reproject(const float* poses, const float* patches, const float* int
 
 int devo_transform(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii, const int64_t* jj,
                    const int64_t* kk, float* coords_pp2, float* coords_2pp, float* valid, float* Ji, float* Jj, float* Jz, int E,
-                   int P, int flags, devo_stream_t stream) {
+                   int P, int flags, int* plan, int plan_frames, int plan_height, int plan_radius, devo_stream_t stream) {
   if (E <= 0) return DEVO_OK;
   DEVO_REQUIRE(!(Ji || Jz) || Jj, "devo_transform: Jj must be requested together with Ji / Jz");
+  int nb = 0;
+  if (plan) {
+    DEVO_REQUIRE(P == 3 && plan_frames > 0 && plan_height > 0 && plan_radius >= 0 && plan_radius <= 5, "devo_transform: bad plan geometry");
+    nb = corr_plan_bands(1, plan_frames, plan_height);
+    DEVO_REQUIRE(nb > 0, "devo_transform: too many frames for a locality plan (%d)", plan_frames);
+  }
   hipLaunchKernelGGL(k_transform, dim3(blocks_for(E, 128, 4096)), dim3(128), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
-                     kk, coords_pp2, coords_2pp, valid, Ji, Jj, Jz, E, P, flags);
+                     kk, coords_pp2, coords_2pp, valid, Ji, Jj, Jz, E, P, flags, plan ? plan + E + 1 : nullptr, plan_frames, plan_height,
+                     nb, 2 * plan_radius + 2, plan_radius <= 3 ? 1 : 3);
   return check_launch("devo_transform");
 }
 

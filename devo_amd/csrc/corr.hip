@@ -9,6 +9,7 @@
 // patch pixel) whose f1 operands are wave-uniform scalar (SGPR) loads, and the bilinear blend + axis swap
 // + output permutation are fused into the epilogue (no raw D x D tensor, no temporaries, no stack copy).
 #include "common.h"
+#include "corr_tile.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 #include <vector>
@@ -18,8 +19,8 @@ namespace devo {
 
 constexpr int PP = 9;          // patch pixels (P = 3)
 constexpr int MAXD = 12;       // 2*R+2 for R <= 5
-constexpr int KC = 8;          // channels staged per LDS chunk
-constexpr int ROWPAD = KC + 4; // LDS row stride in floats: conflict-free ds_read_b128 (20*l mod 64 distinct per 16 lanes)
+constexpr int KC = CORR_KC;     // channels staged per LDS chunk
+constexpr int ROWPAD = CORR_ROWPAD; // LDS row stride of a staged position in floats
 constexpr int NT = 128;        // threads per workgroup (2 waves): one chunk of 128 box positions
 
 template <typename T> __device__ __forceinline__ float to_f32(T v);
@@ -38,12 +39,7 @@ __device__ __forceinline__ void store_streamed(__half* p, __half v) {
   __builtin_nontemporal_store(__half_as_ushort(v), reinterpret_cast<unsigned short*>(p));
 }
 
-__device__ __forceinline__ int floor_to_int(float v) {
-  // static_cast<int>(floor(v)) (correlation_kernel.cu:118-119), made safe for non-finite / huge inputs
-  float f = floorf(v);
-  f = fminf(fmaxf(f, -1.0e6f), 1.0e6f);
-  return (f == f) ? (int)f : -1000000;
-}
+__device__ __forceinline__ int floor_to_int(float v) { return corr_floor_to_int(v); }
 
 struct EdgeGeom {
   int ox[PP], oy[PP];     // window origin (tap 0,0) of each patch pixel in frame coordinates
@@ -133,20 +129,6 @@ template <> __device__ __forceinline__ void fma_one<6>(float& a, float4 w, float
 template <> __device__ __forceinline__ void fma_one<7>(float& a, float4 w, float4 v) { DEVO_FMA_ONE(7); }
 template <> __device__ __forceinline__ void fma_one<8>(float& a, float4 w, float4 v) { DEVO_FMA_ONE(8); }
 
-
-// Tile capacity of the staged kernel (NG = 1: r <= 3, NG = 3: r <= 5) — shared with the locality plan, whose HEAVY
-// class must be exactly the set of edges whose union box does not fit.
-constexpr int SPP = ROWPAD / 4;                 // 16-byte slots per staged position (odd: 3 for KC = 8)
-static_assert(ROWPAD % 4 == 0 && (SPP & 1) == 1, "the conflict-free pitch needs an odd number of slots per position");
-__host__ __device__ constexpr int tile_positions(int ng) { return ng == 1 ? 160 : 256; }
-__host__ __device__ constexpr int tile_slots(int ng) { return ng == 1 ? 528 : 960; }
-// Box row pitch in 16-byte slots: the smallest value >= SPP*w that is = 8 (mod 16).  With an odd SPP this makes the
-// tap-centric ds_read_b128 pattern (lane groups {0-3,12-15,20-27}, ... = 4 window rows x 4 taps) bank-conflict free
-// for every box width.
-__host__ __device__ __forceinline__ int tile_pitch(int w) { const int s = SPP * w; return s + ((8 - s) & 15); }
-__host__ __device__ __forceinline__ bool tile_fits(int w, int h, int ng) {
-  return (long long)w * h <= tile_positions(ng) && (long long)h * tile_pitch(w) <= tile_slots(ng);
-}
 
 // One pyramid level as the staged kernel sees it.
 struct CorrLevel {
@@ -443,35 +425,24 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 // together (L2 reuse of the feature rows); results are independent of it.
 // -------------------------------------------------------------------------------------------------
 constexpr int ORDER_THREADS = 1024;
-constexpr int ORDER_MAXBINS = 4096;
+constexpr int ORDER_MAXBINS = CORR_ORDER_MAXBINS;
 constexpr int BIN_THREADS = 256;
 
 // Step 1 (all CUs): bin of every edge slot -> bins[be]; -1 marks a HEAVY edge (the box of its 9 windows exceeds
 // tile of the staged kernel: it is staged in several passes and runs 2-4x longer) — heavy edges go to the front of the plan.
 __global__ __launch_bounds__(BIN_THREADS) void corr_bin_kernel(const float* __restrict__ coords,
                                                                const int64_t* __restrict__ jj, int BE, int E, int n2, int H2,
-                                                               float inv_scale, int nb, int D, int ng,
+                                                               float coord_div, int nb, int D, int ng,
                                                                int* __restrict__ bins) {
   const int be = blockIdx.x * BIN_THREADS + threadIdx.x;
   if (be >= BE) return;
   const int b = be / E, e = be - b * E;
   const float* c = coords + (int64_t)be * 2 * PP;
   // union box of the 9 windows, computed exactly like the lookup kernel does (floor_to_int of the scaled coordinate)
-  int xlo = 0x7fffffff, xhi = -0x7fffffff, ylo = 0x7fffffff, yhi = -0x7fffffff;
+  int xs[PP], ys[PP];
 #pragma unroll
-  for (int p = 0; p < PP; p++) {
-    const int x = floor_to_int(c[p] * inv_scale), y = floor_to_int(c[PP + p] * inv_scale);
-    xlo = min(xlo, x); xhi = max(xhi, x); ylo = min(ylo, y); yhi = max(yhi, y);
-  }
-  int bin = -1;
-  if (tile_fits(xhi - xlo + D, yhi - ylo + D, ng)) {
-    const float y = c[PP + 4] * inv_scale;                   // centre pixel [1][1]
-    int band = (int)(fminf(fmaxf(y, 0.0f), (float)(H2 - 1))) / 16;
-    band = min(max(band, 0), nb - 1);
-    int f = (int)jj[e];
-    f = min(max(f, 0), n2 - 1);
-    bin = (b * n2 + f) * nb + band;
-  }
+  for (int p = 0; p < PP; p++) { xs[p] = floor_to_int(c[p] / coord_div); ys[p] = floor_to_int(c[PP + p] / coord_div); }
+  const int bin = corr_plan_bin(xs, ys, c[PP + 4] / coord_div, b, (int)jj[e], n2, H2, nb, D, ng);
   bins[be] = bin;
 }
 
@@ -927,14 +898,14 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   DEVO_REQUIRE(B >= 0 && E >= 0 && n2 > 0 && H2 > 0 && coord_scale > 0.0f, "devo_corr_order: bad sizes");
   const long long BE = (long long)B * E;
   if (BE == 0) return DEVO_OK;
-  int nb = (H2 + 15) / 16;
-  while ((long long)B * n2 * nb > ORDER_MAXBINS && nb > 1) nb = (nb + 1) / 2;      // coarser bands if there are many frames
-  DEVO_REQUIRE((long long)B * n2 * nb <= ORDER_MAXBINS && BE < (1LL << 30), "devo_corr_order: too many frames (%d x %d)", B, n2);
+  const int nb = corr_plan_bands(B, n2, H2);
+  DEVO_REQUIRE(nb > 0 && BE < (1LL << 30), "devo_corr_order: too many frames (%d x %d)", B, n2);
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_order: radius %d unsupported (max 5)", radius);
   int* bins = order + BE + 1;                                 // scratch half of the plan buffer
-  hipLaunchKernelGGL(corr_bin_kernel, dim3((unsigned)((BE + BIN_THREADS - 1) / BIN_THREADS)), dim3(BIN_THREADS), 0,
-                     (hipStream_t)stream, coords, jj, (int)BE, E, n2, H2, 1.0f / coord_scale, nb, 2 * radius + 2,
-                     radius <= 3 ? 1 : 3, bins);
+  if (coords != nullptr)                                      // NULL: devo_transform has already written the bins
+    hipLaunchKernelGGL(corr_bin_kernel, dim3((unsigned)((BE + BIN_THREADS - 1) / BIN_THREADS)), dim3(BIN_THREADS), 0,
+                       (hipStream_t)stream, coords, jj, (int)BE, E, n2, H2, coord_scale, nb, 2 * radius + 2,
+                       radius <= 3 ? 1 : 3, bins);
   typedef void (*order_fn_t)(const int*, int, int, int*);
   const long long per_thread = (BE + ORDER_THREADS - 1) / ORDER_THREADS;
   order_fn_t order_fn = per_thread <= 8 ? corr_order_kernel<8> : per_thread <= 16 ? corr_order_kernel<16> :

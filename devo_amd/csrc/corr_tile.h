@@ -1,0 +1,55 @@
+// Tile geometry of the staged lookup kernel and the plan's bin of an edge — shared by corr.hip (lookup + plan kernels)
+// and ba.hip (the fused reprojection can emit the plan's bins while it still holds the coordinates).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace devo {
+
+constexpr int CORR_KC = 8;                       // channels staged per LDS chunk
+constexpr int CORR_ROWPAD = CORR_KC + 4;         // LDS row stride of a staged position in floats
+// Tile capacity of the staged kernel (NG = 1: r <= 3, NG = 3: r <= 5) — shared with the locality plan, whose HEAVY
+// class must be exactly the set of edges whose union box does not fit.
+constexpr int SPP = CORR_ROWPAD / 4;                 // 16-byte slots per staged position (odd: 3 for KC = 8)
+static_assert(CORR_ROWPAD % 4 == 0 && (SPP & 1) == 1, "the conflict-free pitch needs an odd number of slots per position");
+__host__ __device__ constexpr int tile_positions(int ng) { return ng == 1 ? 160 : 256; }
+__host__ __device__ constexpr int tile_slots(int ng) { return ng == 1 ? 528 : 960; }
+// Box row pitch in 16-byte slots: the smallest value >= SPP*w that is = 8 (mod 16).  With an odd SPP this makes the
+// tap-centric ds_read_b128 pattern (lane groups {0-3,12-15,20-27}, ... = 4 window rows x 4 taps) bank-conflict free
+// for every box width.
+__host__ __device__ __forceinline__ int tile_pitch(int w) { const int s = SPP * w; return s + ((8 - s) & 15); }
+__host__ __device__ __forceinline__ bool tile_fits(int w, int h, int ng) {
+  return (long long)w * h <= tile_positions(ng) && (long long)h * tile_pitch(w) <= tile_slots(ng);
+}
+
+
+// Plan bin of an edge from its 9 window origins: -1 = HEAVY (the union box does not fit the tile), else
+// (batch, target frame, 16-row band of the patch centre).  x[p], y[p]: integer pixel of patch pixel p at the plan's level.
+__device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float centre_y, int b, int frame, int n2, int H2, int nb,
+                                             int D, int ng) {
+  int xlo = x[0], xhi = x[0], ylo = y[0], yhi = y[0];
+#pragma unroll
+  for (int p = 1; p < 9; p++) { xlo = min(xlo, x[p]); xhi = max(xhi, x[p]); ylo = min(ylo, y[p]); yhi = max(yhi, y[p]); }
+  if (!tile_fits(xhi - xlo + D, yhi - ylo + D, ng)) return -1;
+  int band = (int)(fminf(fmaxf(centre_y, 0.0f), (float)(H2 - 1))) / 16;
+  band = min(max(band, 0), nb - 1);
+  const int f = min(max(frame, 0), n2 - 1);
+  return (b * n2 + f) * nb + band;
+}
+
+// number of row bands per frame in the plan's bins (coarser if there are many frames: the counting sort keeps one LDS
+// counter per bin); 0 = too many frames
+constexpr int CORR_ORDER_MAXBINS = 4096;
+inline int corr_plan_bands(long long B, int n2, int H2) {
+  int nb = (H2 + 15) / 16;
+  while (B * n2 * nb > CORR_ORDER_MAXBINS && nb > 1) nb = (nb + 1) / 2;
+  return (B * n2 * nb <= CORR_ORDER_MAXBINS) ? nb : 0;
+}
+
+__device__ __forceinline__ int corr_floor_to_int(float v) {
+  // static_cast<int>(floor(v)) (correlation_kernel.cu:118-119), made safe for non-finite / huge inputs
+  float f = floorf(v);
+  f = fminf(fmaxf(f, -1.0e6f), 1.0e6f);
+  return (f == f) ? (int)f : -1000000;
+}
+
+}  // namespace devo

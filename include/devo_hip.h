@@ -160,10 +160,15 @@ int devo_ba_reproject(const float* poses, const float* patches, const float* int
  *   coords_2pp f32 [E, 2, P, P] when != NULL (the permute(0,1,4,2,3).contiguous() of devo.py:223)
  *   valid   f32 [E] or NULL (Z > 0.2 at the centre pixel, :100/:103)
  *   Ji, Jj  f32 [E,2,6], Jz f32 [E,2] or NULL  (:73-98; Ji already negated as in :96)
- *   flags   bit0 = depth, bit1 = tonly */
+ *   flags   bit0 = depth, bit1 = tonly
+ *   plan    optional locality-plan buffer of the lookup (i32 [2*E + 1], see devo_corr_order): while the
+ *           coordinates are still in registers the kernel writes every edge's plan bin (for a pyramid whose
+ *           level 0 has plan_frames frames of plan_height rows, lookup radius plan_radius) into the buffer's
+ *           scratch half; devo_corr_order(coords = NULL, ...) then only sorts.  P == 3.  NULL = no plan. */
 int devo_transform(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
                    const int64_t* jj, const int64_t* kk, float* coords_pp2, float* coords_2pp, float* valid,
-                   float* Ji, float* Jj, float* Jz, int E, int P, int flags, devo_stream_t stream);
+                   float* Ji, float* Jj, float* Jz, int E, int P, int flags, int* plan, int plan_frames,
+                   int plan_height, int plan_radius, devo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * lietorch SE3 subset  (reference module lietorch_backends: devo/lietorch/src/lietorch.cpp:286-316,

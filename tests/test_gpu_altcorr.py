@@ -308,3 +308,24 @@ def test_forward_random_configurations(seed):
     layouts = ["cl", "nchw"] + (["blk8"] if C % 8 == 0 else [])
     for layout in layouts:
         assert_rel(_run(*c, layout=layout), ref, 1e-4, f"seed {seed} C={C} R={R} {H}x{W} {layout}")
+
+
+def test_plan_started_by_the_reprojection_kernel_equals_plan():
+    """cuda_ba.transform(..., plan_for=...) + cuda_corr.plan_finish == cuda_corr.plan on the same coordinates: the same
+    heavy set in front and the same multiset of edges in every (frame, band) bin (order inside a bin is free)"""
+    from devo_amd import synth
+    from devo_amd.backends import cuda_ba, cuda_corr
+    n, M, H, W = 6, 40, 60, 80
+    poses, (patches, _), intr = synth.make_poses(n, 9), synth.make_patches(n, M, H, W, seed=9), synth.make_intrinsics(n, H, W)
+    ii, jj, kk = (t.to(DEV) for t in synth.full_graph(n, M))
+    args = (poses.to(DEV), patches.to(DEV), intr.to(DEV), ii, jj, kk)
+    coords, buf = cuda_ba.transform(*args, layout="2pp", plan_for=(n, H, 3))
+    assert torch.equal(coords, cuda_ba.transform(*args, layout="2pp"))
+    a = cuda_corr.plan_finish(buf, jj, n, H, 3).cpu()
+    b = cuda_corr.plan(coords, jj, n, H).cpu()
+    E = ii.numel()
+    assert sorted(a[:E].tolist()) == list(range(E)) and int(a[E]) == int(b[E])
+    nh = int(a[E])
+    assert sorted(a[:nh].tolist()) == sorted(b[:nh].tolist())
+    key = lambda o: torch.stack([jj.cpu()[o[nh:E].long()], (coords.cpu()[0, o[nh:E].long(), 1, 1, 1].clamp(0, H - 1) / 16).floor().long()], 1)
+    assert torch.equal(key(a), key(b))                              # same (frame, band) sequence after the heavy list

@@ -210,11 +210,16 @@ def main():
     torch.cuda.synchronize()
     t_ba_gpu = ev0.elapsed_time(ev1) * 1e-3 / 20
 
+    # which lookup kernel the library picks for this configuration (devo_amd/csrc/corr.hip: launch_staged)
+    mfma = dtype == torch.float32 and cfg["C"] == 128 and os.environ.get("DEVO_CORR_MFMA", "1")[:1] != "0"
+    lookup_kernel = "corr_fwd_generic_kernel" if args.layout == "nchw" else ("corr_fwd_mfma_kernel" if mfma else "corr_fwd_cl_kernel")
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(f"{args.workload}/{args.dtype}/{args.layout}")
-        if rec:
+            recs = json.load(f)
+        key = f"{args.workload}/{args.dtype}/{args.layout}"
+        rec = (recs.get(key + "/staged") if lookup_kernel == "corr_fwd_cl_kernel" else None) or recs.get(key)
+        if rec and rec.get("kernel", "corr_fwd_cl_kernel") == lookup_kernel:
             traffic = int((2.0 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024) * (2 if args.fuse_levels else 1)
             traffic_src = f"profiles/pmc_traffic.json ({rec['round']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x read correction)"
     except (OSError, ValueError, KeyError):
@@ -233,7 +238,7 @@ def main():
                    "parallelism": f"replicas x{world}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "corr_fwd_generic_kernel" if args.layout == "nchw" else "corr_fwd_cl_kernel",
+                     "kernel": lookup_kernel,
                      "alg_bytes_per_launch": int(b_alg), "us_per_launch": round(t_launch * 1e6, 2)},
         "ba": {"gpu_ms": round(t_ba_gpu * 1e3, 4)},
     }

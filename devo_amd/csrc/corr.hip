@@ -136,6 +136,10 @@ struct CorrLevel {
   int H2, W2;
   int64_t s_b, s_n, s_h, s_w;     // element strides of batch, frame, row, column
   int64_t chunk_stride;           // elements between consecutive KC-channel chunks of a pixel (KC, or the block stride)
+  int cb_shift;                   // log2 of the channels stored contiguously per pixel (channel block); 30 for channels-last
+  int64_t block_stride;           // elements between consecutive channel blocks (unused for channels-last)
+  unsigned frame_bytes;           // extent of one frame (all blocks) in bytes: the buffer-load bound of the matrix-core kernel
+  bool staged_ok, mfma_ok;        // which of the two fast kernels can read this level
   int64_t out_offset;             // element offset of this level inside an edge's output record
   float coord_div;                // coordinates are divided by this (pyramid level scale)
 };
@@ -418,6 +422,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 }
 
 #include "corr_dma.h"
+#include "corr_mfma.h"
 
 // -------------------------------------------------------------------------------------------------
 // Locality plan: order[] = heavy edge slots, then the rest sorted by (batch, target frame, 16-row band of the
@@ -726,31 +731,44 @@ __global__ __launch_bounds__(256) void pyramid_blocked_kernel(const T* __restric
 
 using namespace devo;
 
-// Is this level readable by the staged kernel (corr_fwd_cl_kernel)?  Fills the level block if so.
+// Describes one level for the fast kernels; false = neither of them can read it (generic kernel, or an error for
+// channel-blocked storage, which only the fast kernels understand).
+static bool corr_mfma_enabled() {                // DEVO_CORR_MFMA=0: fp32 lookups take the staged (tap-centric) kernel instead
+  static const char* env = getenv("DEVO_CORR_MFMA");
+  static const bool on = !(env && env[0] == '0');
+  return on;
+}
+
 template <typename T>
 static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t* f2s, int cblock, int64_t out_offset,
                          float coord_div, CorrLevel* lv, int* err) {
   // channel-blocked storage [.., C/cb, H, W, cb]: f2s[2] is the stride between channel blocks, the cb channels of a
-  // pixel are contiguous.  Only the staged kernel reads it (cb must equal its channel chunk).
+  // pixel are contiguous.  The staged kernel wants cb == its channel chunk (8), the matrix-core kernel any multiple of 4.
   const bool blocked = cblock > 1;
   *err = DEVO_OK;
-  if (blocked && (cblock != KC || sizeof(T) > 4 || C % KC != 0)) {
-    set_error("devo_corr_forward: channel-blocked fmap2 needs cblock == %d and fp32 / fp16 (got %d)", KC, cblock);
-    *err = DEVO_ERR_UNSUPPORTED;
-    return false;
-  }
   const int64_t v = 16 / sizeof(T);
-  const bool ok = (blocked || f2s[2] == 1) && (C % KC == 0) && (f2s[3] % v == 0) && (f2s[4] % v == 0) && (f2s[0] % v == 0) &&
-                  (f2s[1] % v == 0) && ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) && sizeof(T) <= 4 &&
-                  f2s[3] >= 0 && f2s[4] >= 0 &&                                     // 32-bit in-frame offsets (bytes)
-                  ((long long)(H2 - 1) * f2s[3] + (long long)(W2 - 1) * f2s[4] + KC) * (long long)sizeof(T) < (1LL << 31);
-  if (!ok) {
-    if (blocked) { set_error("devo_corr_forward: channel-blocked fmap2 must be 16-byte aligned with aligned strides"); *err = DEVO_ERR_UNSUPPORTED; }
+  const int cb = blocked ? cblock : C;
+  const long long plane_bytes = ((long long)(H2 - 1) * f2s[3] + (long long)(W2 - 1) * f2s[4] + (blocked ? cb : C)) * (long long)sizeof(T);
+  const long long frame_bytes = blocked ? (long long)(C / (cb > 0 ? cb : 1) - 1) * f2s[2] * (long long)sizeof(T) + plane_bytes : plane_bytes;
+  const bool aligned = sizeof(T) <= 4 && (blocked || f2s[2] == 1) && (f2s[3] % v == 0) && (f2s[4] % v == 0) && (f2s[0] % v == 0) &&
+                       (f2s[1] % v == 0) && (!blocked || f2s[2] % v == 0) && ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) &&
+                       f2s[3] >= 0 && f2s[4] >= 0 && (!blocked || (f2s[2] >= 0 && C % cb == 0));
+  lv->staged_ok = aligned && (C % KC == 0) && (!blocked || cblock == KC) && plane_bytes < (1LL << 31);   // 32-bit in-plane offsets
+  lv->mfma_ok = aligned && std::is_same<T, float>::value && corr_mfma_enabled() && (C == 128) && (!blocked || (cb >= 4 && (cb & (cb - 1)) == 0)) &&
+                frame_bytes < (1LL << 31);                                                             // 32-bit in-frame offsets
+  if (!lv->staged_ok && !lv->mfma_ok) {
+    if (blocked) {
+      set_error("devo_corr_forward: channel-blocked fmap2 needs fp32 / fp16, 16-byte aligned strides and cblock == %d (got %d)", KC, cblock);
+      *err = DEVO_ERR_UNSUPPORTED;
+    }
     return false;
   }
   lv->fmap2 = fmap2; lv->H2 = H2; lv->W2 = W2;
   lv->s_b = f2s[0]; lv->s_n = f2s[1]; lv->s_h = f2s[3]; lv->s_w = f2s[4];
   lv->chunk_stride = blocked ? f2s[2] : KC;
+  lv->cb_shift = 30; if (blocked) { int sh = 0; while ((1 << sh) < cb) sh++; lv->cb_shift = sh; }
+  lv->block_stride = blocked ? f2s[2] : 0;
+  lv->frame_bytes = (unsigned)(frame_bytes < (1LL << 31) ? frame_bytes : 0);
   lv->out_offset = out_offset; lv->coord_div = coord_div;
   return true;
 }
@@ -767,7 +785,22 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
   const bool do_trace = getenv("DEVO_CORR_TRACE") != nullptr;
   const size_t nrec = (size_t)BE * nlev;
   if (do_trace) { (void)hipMalloc(&trace, nrec * 64); (void)hipMemset(trace, 0, nrec * 64); }
-  if (R <= 3 && !force4)   // (the <3,5> instantiation has room for every supported radius)
+  const bool mfma = lv0.mfma_ok && (nlev == 1 || lv1.mfma_ok);
+  if (std::is_same<T, float>::value && mfma) {                        // matrix-core kernel (corr_mfma.h)
+    const unsigned wgs = (unsigned)((BE + DEVO_MFMA_WPB - 1) / DEVO_MFMA_WPB);
+    const dim3 mgrid(((nlev == 2) ? (wgs + 7) / 8 * 8 : wgs) * nlev), mblock(64 * DEVO_MFMA_WPB);
+    if (R <= 3)
+      hipLaunchKernelGGL((corr_fwd_mfma_kernel<3, 8>), mgrid, mblock, 0, st, (const float*)fmap1, lv0, lv1, nlev, coords, ii, jj,
+                         (float*)out, (int)BE, E, Np, n2, C, oes, ols, R, order, trace);
+    else
+      hipLaunchKernelGGL((corr_fwd_mfma_kernel<5, 8>), mgrid, mblock, 0, st, (const float*)fmap1, lv0, lv1, nlev, coords, ii, jj,
+                         (float*)out, (int)BE, E, Np, n2, C, oes, ols, R, order, trace);
+  } else
+  if (!(lv0.staged_ok && (nlev == 1 || lv1.staged_ok))) {
+    set_error("devo_corr_forward: this channel-blocked layout is only readable by the matrix-core kernel (fp32, C == 128)");
+    if (trace) (void)hipFree(trace);
+    return DEVO_ERR_UNSUPPORTED;
+  } else if (R <= 3 && !force4)   // (the <3,5> instantiation has room for every supported radius)
     hipLaunchKernelGGL((corr_fwd_cl_kernel<T, 1, 3>), grid, block, 0, st, (const T*)fmap1, lv0, lv1, nlev, coords, ii, jj,
                        (T*)out, (int)BE, E, Np, n2, C, oes, ols, R, order, trace);
   else
@@ -808,7 +841,7 @@ static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* co
   if (staged_level<T>(fmap2, C, H2, W2, f2s, cblock, ooff, coord_div, &lv, &err)) {
     static const bool use_dma = getenv("DEVO_CORR_DMA") != nullptr;     // experimental LDS-direct kernel: opt-in
     const size_t dma_lds = sizeof(float) * (2 * DMA_BUF_FLOATS + (size_t)PP * (C + 4));
-    if (std::is_same<T, float>::value && R <= 3 && use_dma && cblock <= 1 && C % 4 == 0 && (size_t)C * 4 <= DMA_ZERO_BYTES &&
+    if (std::is_same<T, float>::value && R <= 3 && use_dma && lv.staged_ok && cblock <= 1 && C % 4 == 0 && (size_t)C * 4 <= DMA_ZERO_BYTES &&
         dma_lds <= 48 * 1024) {
       hipLaunchKernelGGL(corr_fwd_dma_kernel, dim3((unsigned)BE), dim3(64), dma_lds, st, (const float*)fmap1, (const float*)fmap2,
                          coords, ii, jj, (float*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff,

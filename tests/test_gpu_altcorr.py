@@ -2,6 +2,9 @@
 path, generic-stride path, fp32/fp16/fp64, r=3 and r=5, out-of-bounds / negative / integer / widely spread
 coordinates), its backward, the fused pyramid output, and patchify forward/backward.
 Tolerance: 1e-4 relative to the output scale for fp32 (north_star); 2e-3 for fp16 storage."""
+import os
+import subprocess
+import sys
 import pytest
 import torch
 from oracle import altcorr as A
@@ -70,8 +73,17 @@ def test_channel_blocked_layout_is_bit_identical_and_checked():
         c = _case(seed=seed, spread=spread, E=96)
         assert torch.equal(_run(*c, layout="blk8"), _run(*c, layout="cl"))
     f1, f2, coords, ii, jj, R = _case(E=8)
-    with pytest.raises(RuntimeError):
-        cuda_corr.forward(f1.to(DEV), altcorr.channel_blocked(f2.to(DEV), 4), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
+    h = lambda t: t.to(DEV).half()
+    with pytest.raises(RuntimeError):                                 # the staged kernel (fp16) reads 8-channel blocks only
+        cuda_corr.forward(h(f1), altcorr.channel_blocked(h(f2), 4), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
+    if os.environ.get("DEVO_CORR_MFMA", "1") != "0":                  # the matrix-core kernel (fp32, C = 128): any power of two >= 4
+        c = _case(seed=15, spread=3.5, E=96)
+        for cb in (4, 16, 32):
+            out, = cuda_corr.forward(c[0].to(DEV), altcorr.channel_blocked(c[1].to(DEV), cb), c[2].to(DEV), c[3].to(DEV), c[4].to(DEV), c[5])
+            assert torch.equal(out, _run(*c, layout="cl")), cb
+    else:
+        with pytest.raises(RuntimeError):
+            cuda_corr.forward(f1.to(DEV), altcorr.channel_blocked(f2.to(DEV), 4), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
     with pytest.raises(RuntimeError):
         cuda_corr.forward(f1.to(DEV).double(), altcorr.channel_blocked(f2.to(DEV).double(), 8), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
     c = _case(seed=14, E=96)                                          # fp16 storage, blocked == channels-last
@@ -329,3 +341,15 @@ def test_plan_started_by_the_reprojection_kernel_equals_plan():
     assert sorted(a[:nh].tolist()) == sorted(b[:nh].tolist())
     key = lambda o: torch.stack([jj.cpu()[o[nh:E].long()], (coords.cpu()[0, o[nh:E].long(), 1, 1, 1].clamp(0, H - 1) / 16).floor().long()], 1)
     assert torch.equal(key(a), key(b))                              # same (frame, band) sequence after the heavy list
+
+
+def test_staged_kernel_stays_covered():
+    """fp32 / C = 128 lookups take the matrix-core kernel by default; DEVO_CORR_MFMA=0 (read once per process) routes them
+    through the staged tap-centric kernel, which fp16 storage and other channel counts always use: same parity tests."""
+    if os.environ.get("DEVO_CORR_MFMA", "1") == "0":
+        pytest.skip("already running on the staged kernel")
+    env = dict(os.environ, DEVO_CORR_MFMA="0")
+    sel = "test_forward_fp32 or test_forward_wide_spread or test_channel_blocked or test_fused_pyramid or test_batch_of_two or test_forward_other_radii or test_coord_div"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", sel],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

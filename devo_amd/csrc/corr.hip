@@ -1,13 +1,13 @@
 // altcorr for gfx950: patch <-> frame local correlation lookup (forward + backward) and patchify.
 // Replaces devo/altcorr/correlation_kernel.cu (reference module cuda_corr, correlation.cpp:57-63).
 //
-// Design: the reference launches one thread per (edge, pixel, tap) and walks the
-// 128 channels with a stride of H*W elements, then blends/permutes with ~14 ATen kernels.  Here ONE
-// workgroup owns one edge and works POSITION-centric: the 9 patch pixels' (2R+2)^2 windows overlap almost
-// entirely, so the union bounding box (~10x10 px) is staged once through LDS with coalesced 16-byte loads
-// from a channels-last pyramid, every lane owns one position of the box and keeps 9 accumulators (one per
-// patch pixel) whose f1 operands are wave-uniform scalar (SGPR) loads, and the bilinear blend + axis swap
-// + output permutation are fused into the epilogue (no raw D x D tensor, no temporaries, no stack copy).
+// Design: the reference launches one thread per (edge, pixel, tap) and walks the 128 channels
+// with a stride of H*W elements, then blends/permutes with ~14 ATen kernels.  Here ONE WAVE owns one edge; the 9 patch
+// pixels' (2R+2)^2 windows overlap almost entirely, so only their union bounding box (~10x10 px) is fetched, with
+// 16-byte loads from a channel-blocked (or channels-last) pyramid, and the bilinear blend + axis swap + output
+// permutation are fused into the epilogue (no raw D x D tensor, no temporaries, no stack copy).  Two fast kernels:
+//   corr_fwd_mfma_kernel (corr_mfma.h, fp32 / C = 128): position-centric, lanes = box pixels, products on the matrix cores;
+//   corr_fwd_cl_kernel (below, fp32 / fp16, any C % 8 == 0): tap-centric, box staged through LDS, DPP-broadcast FMAs.
 #include "common.h"
 #include "corr_tile.h"
 #include <hip/hip_fp16.h>

@@ -72,14 +72,19 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_WPB) __attribute__((amdgpu_waves_per
   const int be = order ? order[slot] : slot;
   const int D = 2 * R + 2, ntap = D * D;
   const int b = be / E, e = be - b * E;
+  const int64_t pi = ii[e];                 // requested together with the coordinates (one round trip, not two)
+  const int64_t fj = jj[e];
 
   // ---- geometry: lane p (< 9) owns patch pixel p
   // (the 18 coordinates come through the scalar cache: a vector load would queue behind the other waves' feature fetches)
   float px = 0.0f, py = 0.0f;
   {
     const float* __restrict__ ce = coords + (int64_t)be * (2 * PP);
+    float cv[2 * PP];
 #pragma unroll
-    for (int p = 0; p < PP; p++) { const float cx_ = ce[p], cy_ = ce[PP + p]; if (lane == p) { px = cx_; py = cy_; } }
+    for (int p = 0; p < 2 * PP; p++) cv[p] = ce[p];             // 18 scalar loads in flight together (no branch around them)
+#pragma unroll
+    for (int p = 0; p < PP; p++) { px = (lane == p) ? cv[p] : px; py = (lane == p) ? cv[PP + p] : py; }
     px = px / LV.coord_div; py = py / LV.coord_div;
   }
   unsigned long long t_geo = 0, t_first = 0, t_loop = 0;
@@ -101,8 +106,6 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_WPB) __attribute__((amdgpu_waves_per
   const int nslots = box_mode ? (int)npos_ll : PP * ntap;
   const int npass = (nslots + 63) >> 6;
 
-  const int64_t pi = ii[e];
-  const int64_t fj = jj[e];
   const float* __restrict__ f1 = fmap1 + ((int64_t)b * Np + pi) * C * PP;           // [C][9]
   float* outp = out + (int64_t)be * out_estride + LV.out_offset;
   // Raw buffer descriptors (base, byte size): a lane whose offset is >= the size gets 0 WITHOUT a memory access — that is

@@ -192,10 +192,25 @@ def main():
     # only the lookup kernels sit between the events
     order = cuda_corr.plan(coords, d["jj"], n, cfg["H"])
     torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(args.kernel_reps):
-        lookup(coords, order=order)
-    ev1.record()
+
+    def lookups():
+        for _ in range(args.kernel_reps):
+            lookup(coords, order=order)
+    if args.no_graph:
+        ev0.record(); lookups(); ev1.record()
+    else:
+        # replayed from a HIP graph like the timed step: eager back-to-back launches add 5-10 us of launch gap per kernel,
+        # which rocprofv3's kernel durations (profiles/) do not contain
+        kgraph = torch.cuda.CUDAGraph()
+        kside = torch.cuda.Stream()
+        kside.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(kside):
+            with torch.cuda.graph(kgraph, stream=kside):
+                lookups()
+        torch.cuda.current_stream().wait_stream(kside)
+        kgraph.replay()
+        torch.cuda.synchronize()
+        ev0.record(); kgraph.replay(); ev1.record()
     torch.cuda.synchronize()
     launches = (1 if args.fuse_levels else 2) * args.kernel_reps
     t_launch = ev0.elapsed_time(ev1) * 1e-3 / launches                      # s per launch

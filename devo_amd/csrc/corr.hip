@@ -787,14 +787,15 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
   if (do_trace) { (void)hipMalloc(&trace, nrec * 64); (void)hipMemset(trace, 0, nrec * 64); }
   const bool mfma = lv0.mfma_ok && (nlev == 1 || lv1.mfma_ok);
   if (std::is_same<T, float>::value && mfma) {                        // matrix-core kernel (corr_mfma.h)
-    const unsigned wgs = (unsigned)((BE + DEVO_MFMA_WPB - 1) / DEVO_MFMA_WPB);
-    const dim3 mgrid(((nlev == 2) ? (wgs + 7) / 8 * 8 : wgs) * nlev), mblock(64 * DEVO_MFMA_WPB);
-    if (R <= 3)
-      hipLaunchKernelGGL((corr_fwd_mfma_kernel<3, 8>), mgrid, mblock, 0, st, (const float*)fmap1, lv0, lv1, nlev, coords, ii, jj,
-                         (float*)out, (int)BE, E, Np, n2, C, oes, ols, R, order, trace);
-    else
-      hipLaunchKernelGGL((corr_fwd_mfma_kernel<5, 8>), mgrid, mblock, 0, st, (const float*)fmap1, lv0, lv1, nlev, coords, ii, jj,
-                         (float*)out, (int)BE, E, Np, n2, C, oes, ols, R, order, trace);
+    static const char* split_env = getenv("DEVO_CORR_SPLIT_LEVELS");  // debug: fused lookups as two sets of workgroups
+    const bool both = nlev == 2 && !(split_env && split_env[0] == '1') && !do_trace;
+    typedef void (*mfma_fn_t)(const float*, CorrLevel, CorrLevel, int, const float*, const int64_t*, const int64_t*, float*, int, int,
+                              int, int, int, int64_t, int64_t, int, const int*, unsigned long long*);
+    const mfma_fn_t fn = both ? (R <= 3 ? corr_fwd_mfma_kernel<3, 8, 2> : corr_fwd_mfma_kernel<5, 8, 2>)
+                              : (R <= 3 ? corr_fwd_mfma_kernel<3, 8, 1> : corr_fwd_mfma_kernel<5, 8, 1>);
+    const dim3 mgrid(both ? (unsigned)BE : per_level * nlev), mblock(64);
+    hipLaunchKernelGGL(fn, mgrid, mblock, 0, st, (const float*)fmap1, lv0, lv1, nlev, coords, ii, jj, (float*)out, (int)BE, E, Np, n2,
+                       C, oes, ols, R, order, trace);
   } else
   if (!(lv0.staged_ok && (nlev == 1 || lv1.staged_ok))) {
     set_error("devo_corr_forward: this channel-blocked layout is only readable by the matrix-core kernel (fp32, C == 128)");

@@ -1,4 +1,4 @@
-// altcorr lookup on the matrix cores, fp32 (included by corr.hip inside namespace devo).
+// altcorr lookup on the matrix cores, fp32, C = 128 (included by corr.hip inside namespace devo).
 //
 // ONE WAVE PER EDGE, POSITION-centric: lane l owns one pixel of the union bounding box of the 9 patch pixels'
 // (2r+2)^2 windows (64 positions per pass; a 10x10 box takes two passes) and reads that pixel's channels STRAIGHT
@@ -6,20 +6,23 @@
 // v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 outer products per instruction, block b = positions 4b..4b+3
 // (the B operand is the lane's own feature value of one channel) against 4 patch pixels (the A operand).  The A
 // operand of all 16 blocks is taken from ONE block of the A register (cbsz:4 abid:u), so a single register loaded
-// as  lane (u, i) <- f1[k0 + u][4g + i]  feeds the 16 channels k0..k0+15 of pixel group g: the whole patch chunk
-// is 3 registers per 16 channels and never touches LDS either.  Per channel and pass: 3 MFMAs (pixel groups
+// as  lane (u, i) <- f1[k0 + u][4g + i]  feeds the 16 channels k0..k0+15 of pixel group g: the whole patch is
+// 24 registers, loaded once per edge, and never touches LDS either.  Per channel and pass: 3 MFMAs (pixel groups
 // {0-3} {4-7} {8}), 2 passes of the matrix pipe each, while the vector ALU stays free for the addressing and the
 // other waves' epilogues.
 // After a pass every lane scatters its 9 sums to the taps they are (position - window origin of pixel p, if inside
-// the window) of the raw windows [p][a][c] in LDS (2.3 KB per wave = the only LDS of the kernel); the fused
+// the window) of the raw windows [p][a][c] in LDS (2.3 KB per wave and level = the only LDS of the kernel); the fused
 // bilinear / permutation epilogue is the one of corr_fwd_cl_kernel.
 // Boxes of any size work (ceil(npos / 64) passes); when the patch pixels are spread so far apart that the box
 // holds more positions than the 9 windows together, the passes walk the windows one after the other instead.
+//
+// NL = 2 (the fused pyramid lookup): the wave does BOTH pyramid levels of its edge, one after the other — the plan
+// entry, the coordinates and the 24 patch registers are fetched once instead of twice (an edge's start-up, three
+// dependent memory round trips, costs about as much as one level's channel loop), the feature fetches run on from the
+// last pass of level 0 into the first pass of level 1, and the epilogue writes the two levels' interleaved outputs
+// (torch.stack([c0, c1], -1)) as whole lines.
 #pragma once
 
-#ifndef DEVO_MFMA_WPB
-#define DEVO_MFMA_WPB 1
-#endif
 #ifndef DEVO_MFMA_RING
 #define DEVO_MFMA_RING 4
 #endif
@@ -29,17 +32,16 @@
 typedef float mfma_acc4 __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 
-// Plan -> first edge slot of workgroup `gid` of `nitems`, each workgroup taking `per` consecutive slots (see
-// corr_fwd_cl_kernel: workgroups with heavy edges first, the rest XCD-aware)
-__device__ __forceinline__ int corr_plan_slot(const int* __restrict__ order, int BE, int gid, int nitems, int per) {
-  const int nh = order ? (min(max(order[BE], 0), BE) + per - 1) / per : 0;
-  if (gid < nh) return gid * per;
+// Plan -> edge slot of workgroup `gid` of `nitems` (see corr_fwd_cl_kernel: heavy edges first, the rest XCD-aware)
+__device__ __forceinline__ int corr_plan_slot(const int* __restrict__ order, int BE, int gid, int nitems) {
+  const int nh = order ? min(max(order[BE], 0), BE) : 0;
+  if (gid < nh) return gid;
   const int xcd = gid & 7;
   auto heavy_on = [&](int x) -> int { return nh > x ? (nh - x + 7) >> 3 : 0; };
   auto total_on = [&](int x) -> int { return nitems > x ? (nitems - x + 7) >> 3 : 0; };
   int start = nh;
   for (int x = 0; x < xcd; x++) start += total_on(x) - heavy_on(x);
-  return (start + (gid >> 3) - heavy_on(xcd)) * per;
+  return start + (gid >> 3) - heavy_on(xcd);
 }
 
 #define DEVO_MFMA_STEP(U, BV)                                                         \
@@ -47,26 +49,24 @@ __device__ __forceinline__ int corr_plan_slot(const int* __restrict__ order, int
   acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, (BV), acc1, 4, (U), 0);              \
   acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, (BV), acc2, 4, (U), 0)
 
-template <int RMAX, int NGR>       // NGR = C / 16 steps per pass (a multiple of 4)
-__global__ __launch_bounds__(64 * DEVO_MFMA_WPB) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WAVES, DEVO_MFMA_WAVES))) void corr_fwd_mfma_kernel(
+template <int RMAX, int NGR, int NL>       // NGR = C / 16 steps per pass (a multiple of the ring); NL = levels per wave
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WAVES, DEVO_MFMA_WAVES))) void corr_fwd_mfma_kernel(
     const float* __restrict__ fmap1, CorrLevel lv0, CorrLevel lv1, int nlev, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, float* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int64_t out_estride, int64_t out_lstride, int R, const int* __restrict__ order,
     unsigned long long* __restrict__ trace) {
-  const int lvl = (nlev == 2) ? ((blockIdx.x >> 3) & 1) : 0;                      // wave-uniform
-  const int gid = (nlev == 2) ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : blockIdx.x;
-  const int nitems = (nlev == 2) ? (gridDim.x >> 1) : gridDim.x;
-  const CorrLevel& LV = lvl ? lv1 : lv0;
-  const float* __restrict__ fmap2 = static_cast<const float*>(LV.fmap2);
-  const int H2 = LV.H2, W2 = LV.W2;
+  // NL == 1 with nlev == 2: the levels alternate in groups of 8 workgroups (see corr_fwd_cl_kernel); NL == 2: one
+  // workgroup per edge does both.  lev(l) = the level this wave works on as its l-th.
+  const int wlvl = (NL == 1 && nlev == 2) ? ((blockIdx.x >> 3) & 1) : 0;                      // wave-uniform
+  const int gid = (NL == 1 && nlev == 2) ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : blockIdx.x;
+  const int nitems = (NL == 1 && nlev == 2) ? (gridDim.x >> 1) : gridDim.x;
+  auto second = [&](int l) -> bool { return NL == 2 ? (l != 0) : (wlvl != 0); };   // does index l mean pyramid level 1?
+#define LVF(l, F) (second(l) ? lv1.F : lv0.F)
   constexpr int DMAX = 2 * RMAX + 2;
-  constexpr int WPB = DEVO_MFMA_WPB;          // waves = edges per workgroup: consecutive plan slots share a CU's L1
   constexpr int RW_FLOATS = (PP * (DMAX * DMAX + 1) + 3) / 4 * 4;
-  __shared__ __attribute__((aligned(16))) float s_rawwin[WPB * RW_FLOATS];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* rawwin = s_rawwin + wave * RW_FLOATS;
-  const int slot = corr_plan_slot(order, BE, gid, nitems, WPB) + wave;
+  __shared__ __attribute__((aligned(16))) float s_rawwin[NL * RW_FLOATS];
+  const int lane = threadIdx.x;
+  const int slot = corr_plan_slot(order, BE, gid, nitems);
   if (slot >= BE) return;                     // wave-uniform; no workgroup barriers in this kernel
   const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ULL;
   const int be = order ? order[slot] : slot;
@@ -77,56 +77,56 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_WPB) __attribute__((amdgpu_waves_per
 
   // ---- geometry: lane p (< 9) owns patch pixel p
   // (the 18 coordinates come through the scalar cache: a vector load would queue behind the other waves' feature fetches)
-  float px = 0.0f, py = 0.0f;
+  float cpx = 0.0f, cpy = 0.0f;             // undivided coordinates of this lane's patch pixel
   {
     const float* __restrict__ ce = coords + (int64_t)be * (2 * PP);
     float cv[2 * PP];
 #pragma unroll
     for (int p = 0; p < 2 * PP; p++) cv[p] = ce[p];             // 18 scalar loads in flight together (no branch around them)
 #pragma unroll
-    for (int p = 0; p < PP; p++) { px = (lane == p) ? cv[p] : px; py = (lane == p) ? cv[PP + p] : py; }
-    px = px / LV.coord_div; py = py / LV.coord_div;
+    for (int p = 0; p < PP; p++) { cpx = (lane == p) ? cv[p] : cpx; cpy = (lane == p) ? cv[PP + p] : cpy; }
   }
   unsigned long long t_geo = 0, t_first = 0, t_loop = 0;
   if (trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_geo = __builtin_readcyclecounter(); }
-  const int my_ox = floor_to_int(px) - R, my_oy = floor_to_int(py) - R;
-  const float my_dx = px - floorf(px), my_dy = py - floorf(py);
-  int ox[PP], oy[PP];
+  // window origin of the lane's pixel at level index l (recomputed where needed instead of kept: registers)
+  auto origin_x = [&](int l) -> int { return floor_to_int(cpx / LVF(l, coord_div)) - R; };
+  auto origin_y = [&](int l) -> int { return floor_to_int(cpy / LVF(l, coord_div)) - R; };
+  struct Geo { int xmin, ymin, bw, nslots, npass; bool box_mode; float inv_bw; };      // wave-uniform
+  auto make_geo = [&](int l) -> Geo {
+    const int mox = origin_x(l), moy = origin_y(l);
+    int xmin = __builtin_amdgcn_readlane(mox, 0), xmax = xmin, ymin = __builtin_amdgcn_readlane(moy, 0), ymax = ymin;
 #pragma unroll
-  for (int p = 0; p < PP; p++) { ox[p] = __builtin_amdgcn_readlane(my_ox, p); oy[p] = __builtin_amdgcn_readlane(my_oy, p); }
-  int xmin = ox[0], xmax = ox[0], ymin = oy[0], ymax = oy[0];
-#pragma unroll
-  for (int p = 1; p < PP; p++) {
-    xmin = min(xmin, ox[p]); xmax = max(xmax, ox[p]);
-    ymin = min(ymin, oy[p]); ymax = max(ymax, oy[p]);
-  }
-  const int bw = xmax - xmin + D;
-  const long long npos_ll = (long long)bw * (ymax - ymin + D);
-  const bool box_mode = npos_ll <= (long long)PP * ntap;        // else: the 9 windows one after the other
-  const int nslots = box_mode ? (int)npos_ll : PP * ntap;
-  const int npass = (nslots + 63) >> 6;
+    for (int p = 1; p < PP; p++) {
+      const int x = __builtin_amdgcn_readlane(mox, p), y = __builtin_amdgcn_readlane(moy, p);
+      xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
+    }
+    Geo g;
+    g.xmin = xmin; g.ymin = ymin; g.bw = xmax - xmin + D;
+    const long long npos_ll = (long long)g.bw * (ymax - ymin + D);
+    g.box_mode = npos_ll <= (long long)PP * ntap;        // else: the 9 windows one after the other
+    g.nslots = g.box_mode ? (int)npos_ll : PP * ntap;
+    g.npass = (g.nslots + 63) >> 6;
+    g.inv_bw = 1.0f / (float)g.bw;
+    return g;
+  };
+  const Geo g0 = make_geo(0);
+  const Geo g1 = (NL == 2) ? make_geo(1) : g0;
+  const int np0 = g0.npass, nseg = (NL == 2) ? np0 + g1.npass : np0;     // segments = passes of level 0, then of level 1
+  auto seg_level = [&](int s) -> int { return (NL == 2 && s >= np0) ? 1 : 0; };
 
-  const float* __restrict__ f1 = fmap1 + ((int64_t)b * Np + pi) * C * PP;           // [C][9]
-  float* outp = out + (int64_t)be * out_estride + LV.out_offset;
   // Raw buffer descriptors (base, byte size): a lane whose offset is >= the size gets 0 WITHOUT a memory access — that is
   // how lanes beyond the box, positions outside the image and the fetches that run ahead past the last step are switched off
   // without a branch (a fetch behind a branch makes the compiler wait for ALL outstanding loads at the join).
-  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(fmap2 + (int64_t)b * LV.s_b + fj * LV.s_n), 0, LV.frame_bytes, 0x00020000);
+  auto frame_rsrc = [&](int l) -> __amdgpu_buffer_rsrc_t {
+    const float* base = static_cast<const float*>(LVF(l, fmap2)) + (int64_t)b * LVF(l, s_b) + fj * LVF(l, s_n);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, LVF(l, frame_bytes), 0x00020000);
+  };
+  const float* __restrict__ f1 = fmap1 + ((int64_t)b * Np + pi) * C * PP;           // [C][9]
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f1), 0, (unsigned)(C * PP) * 4u, 0x00020000);
   constexpr unsigned OFF_NONE = 0x80000000u;               // > any frame (the launcher guarantees < 2^31 bytes)
 
-  // 16-byte piece q (4 channels) of the 16-channel step kg starts at channel c = 16 kg + 4 q: block c / cb, offset c % cb
-  // (cb is a power of two, 1 << cb_shift; channels-last = one block of all channels, cb_shift = 30)
-  const int cb_shift = LV.cb_shift;
-  const unsigned block_bytes = (unsigned)LV.block_stride * (unsigned)sizeof(float);
-  auto piece = [&](int c) -> unsigned {
-    const unsigned blk = (unsigned)c >> cb_shift;
-    return blk * block_bytes + ((unsigned)c - (blk << cb_shift)) * (unsigned)sizeof(float);
-  };
-
   // A operand: lane (u, i) = (lane >> 2, lane & 3) holds f1[k0 + u][4g + i] (pixel 8 repeated in the unused rows of group 2).
-  // The whole patch (NGR steps x 3 registers) stays in registers for all passes of the edge.
+  // The whole patch (NGR steps x 3 registers) stays in registers for all passes (and both levels) of the edge.
   const int au = lane >> 2, ai = lane & 3;
   const unsigned aoff0 = (unsigned)(au * PP + ai) * 4u, aoff1 = aoff0 + 16u, aoff2 = (unsigned)(au * PP + 8) * 4u;
   float pa[NGR][3];
@@ -138,50 +138,65 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_WPB) __attribute__((amdgpu_waves_per
     pa[g][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ka + aoff2, 0, 0));
   }
   __builtin_amdgcn_sched_barrier(0);        // patch loads first: the loop's s_waitcnt counts assume they are the oldest
-  const float inv_bw = 1.0f / (float)bw;
-  const int sh32 = (int)LV.s_h, sw32 = (int)LV.s_w;
 
-  // position of this lane in pass ps: frame pixel (gy, gx), whether it is one of the box's positions, whether it lies
-  // inside the image, and its byte offset inside the frame (OFF_NONE = fetch nothing)
+  // position of this lane in segment s: frame pixel (gy, gx), whether it is one of the box's positions, whether it lies
+  // inside the image, and its byte offset inside the frame (OFF_NONE = fetch nothing; every segment past the last one)
   struct Pos { int gy, gx; bool listed, inside; unsigned off; };
-  auto position = [&](int ps) -> Pos {
+  auto position = [&](int sg) -> Pos {
+    const int l = seg_level(sg);
+    const Geo& G = l ? g1 : g0;
+    const int ps = l ? sg - np0 : sg;
     Pos q;
     const int s = ps * 64 + lane;
-    const int sc = min(s, nslots - 1);
-    if (box_mode) {
-      const int pyy = (int)(((float)sc + 0.5f) * inv_bw);     // exact: sc < 2^16, error margin 0.5 / bw
-      q.gy = ymin + pyy; q.gx = xmin + (sc - pyy * bw);
+    const int sc = max(min(s, G.nslots - 1), 0);
+    if (G.box_mode) {
+      const int pyy = (int)(((float)sc + 0.5f) * G.inv_bw);     // exact: sc < 2^16, error margin 0.5 / bw
+      q.gy = G.ymin + pyy; q.gx = G.xmin + (sc - pyy * G.bw);
     } else {
       const int wp = sc / ntap, t = sc - wp * ntap;
       const int ta = t / D;
-      q.gy = __shfl(my_oy, wp) + ta; q.gx = __shfl(my_ox, wp) + (t - ta * D);
+      q.gy = __shfl(origin_y(l), wp) + ta; q.gx = __shfl(origin_x(l), wp) + (t - ta * D);
     }
-    q.listed = s < nslots;
-    q.inside = q.gy >= 0 && q.gy < H2 && q.gx >= 0 && q.gx < W2;
-    q.off = (q.listed && q.inside) ? (unsigned)(q.gy * sh32 + q.gx * sw32) * (unsigned)sizeof(float) : OFF_NONE;
+    q.listed = s < G.nslots && sg < nseg;
+    q.inside = q.gy >= 0 && q.gy < LVF(l, H2) && q.gx >= 0 && q.gx < LVF(l, W2);
+    q.off = (q.listed && q.inside) ? (unsigned)(q.gy * (int)LVF(l, s_h) + q.gx * (int)LVF(l, s_w)) * (unsigned)sizeof(float) : OFF_NONE;
     return q;
   };
 
-  // One step = 16 channels of one pass = 4 x 16 bytes of the lane's position.  Steps are fetched THREE ahead of their
-  // products into a ring of four register sets, running on across pass boundaries (the fetches of the pass after the
-  // last one are out of range = no memory access).  The step loop is fully unrolled: ring slots, patch registers and
+  // One step = 16 channels of one pass = 4 x 16 bytes of the lane's position.  Steps are fetched RING-1 ahead of their
+  // products into a ring of register sets, running on across pass and level boundaries (the fetches of the segment after
+  // the last one are out of range = no memory access).  The step loop is fully unrolled: ring slots, patch registers and
   // the MFMAs' abid are all static.
+  // 16-byte piece q (4 channels) of step g starts at channel c = 16 g + 4 q: block c / cb, offset c % cb
+  // (cb is a power of two, 1 << cb_shift; channels-last = one block of all channels, cb_shift = 30)
   auto as_f4 = [](v4u32 v) -> float4 { float4 f; __builtin_memcpy(&f, &v, sizeof(f)); return f; };
-  constexpr int RING = DEVO_MFMA_RING;       // register sets (steps in flight + the one being multiplied); divides NGR
+  constexpr int RING = DEVO_MFMA_RING;
   float4 rb[RING][4];
-  auto fetch = [&](int slot, int g, unsigned off) {
+  auto fetch = [&](int ring, int g, unsigned off, __amdgpu_buffer_rsrc_t rs, int cb_shift, unsigned block_bytes) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) rb[slot][q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs2, off + piece(16 * g + 4 * q), 0, 0));
+    for (int q = 0; q < 4; q++) {
+      const unsigned c = 16u * g + 4u * q, blk = c >> cb_shift;
+      rb[ring][q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, off + blk * block_bytes + (c - (blk << cb_shift)) * 4u, 0, 0));
+    }
   };
   mfma_acc4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
   Pos cur = position(0), nxt = position(1);
+  {
+    const __amdgpu_buffer_rsrc_t r0 = frame_rsrc(0);
+    const int sh0 = LVF(0, cb_shift); const unsigned bb0 = (unsigned)LVF(0, block_stride) * 4u;
 #pragma unroll
-  for (int g = 0; g < RING - 1; g++) { fetch(g, g % NGR, cur.off); __builtin_amdgcn_sched_barrier(0); }
+    for (int g = 0; g < RING - 1; g++) { fetch(g, g % NGR, cur.off, r0, sh0, bb0); __builtin_amdgcn_sched_barrier(0); }
+  }
   if (trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_first = __builtin_readcyclecounter(); }
-  for (int ps = 0; ps < npass; ps++) {
+  for (int sg = 0; sg < nseg; sg++) {
+    const int lc = seg_level(sg), ln = seg_level(min(sg + 1, nseg - 1));         // wave-uniform
+    const __amdgpu_buffer_rsrc_t rsc = frame_rsrc(lc), rsn = frame_rsrc(ln);
+    const int shc = LVF(lc, cb_shift), shn = LVF(ln, cb_shift);
+    const unsigned bbc = (unsigned)LVF(lc, block_stride) * 4u, bbn = (unsigned)LVF(ln, block_stride) * 4u;
 #pragma unroll
     for (int g = 0; g < NGR; g++) {
-      fetch((g + RING - 1) % RING, (g + RING - 1) % NGR, (g + RING - 1 < NGR) ? cur.off : nxt.off);
+      if (g + RING - 1 < NGR) fetch((g + RING - 1) % RING, g + RING - 1, cur.off, rsc, shc, bbc);       // (static condition)
+      else fetch((g + RING - 1) % RING, g + RING - 1 - NGR, nxt.off, rsn, shn, bbn);
       __builtin_amdgcn_sched_barrier(0);
       {
         const float a0 = pa[g][0], a1 = pa[g][1], a2 = pa[g][2];
@@ -195,46 +210,57 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_WPB) __attribute__((amdgpu_waves_per
     }
     // ---- end of a pass.  Scatter: position (gy, gx) is tap (gy - oy[p], gx - ox[p]) of pixel p if that lies inside
     //      its window.  Out-of-image positions contribute exactly 0 (correlation_kernel.cu:136: within_bounds).
-    if (cur.listed) {
-      const float v[PP] = {acc0[0], acc0[1], acc0[2], acc0[3], acc1[0], acc1[1], acc1[2], acc1[3], acc2[0]};
+    {
+      float* rawwin = s_rawwin + lc * RW_FLOATS;
+      // (window origins broadcast BEFORE the branch: inside it the lanes that hold them may be switched off)
+      const int mox = origin_x(lc), moy = origin_y(lc);
+      int ox[PP], oy[PP];
 #pragma unroll
-      for (int p = 0; p < PP; p++) {
-        const int ta = cur.gy - oy[p], tc = cur.gx - ox[p];
-        if ((unsigned)ta < (unsigned)D && (unsigned)tc < (unsigned)D)
-          rawwin[p * (ntap + 1) + ta * D + tc] = cur.inside ? v[p] : 0.0f;
+      for (int p = 0; p < PP; p++) { ox[p] = __builtin_amdgcn_readlane(mox, p); oy[p] = __builtin_amdgcn_readlane(moy, p); }
+      if (cur.listed) {
+        const float v[PP] = {acc0[0], acc0[1], acc0[2], acc0[3], acc1[0], acc1[1], acc1[2], acc1[3], acc2[0]};
+#pragma unroll
+        for (int p = 0; p < PP; p++) {
+          const int ta = cur.gy - oy[p], tc = cur.gx - ox[p];
+          if ((unsigned)ta < (unsigned)D && (unsigned)tc < (unsigned)D)
+            rawwin[p * (ntap + 1) + ta * D + tc] = cur.inside ? v[p] : 0.0f;
+        }
       }
     }
     acc0 = mfma_acc4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0; acc2 = acc0;
     cur = nxt;
-    nxt = position(ps + 2);
+    nxt = position(sg + 2);
   }
   wave_lds_fence();
   if (trace) t_loop = __builtin_readcyclecounter();
-  // ---- fused bilinear blend + axis swap + output permutation (correlation_kernel.cu:221-232), as in corr_fwd_cl_kernel
-  const int Dm = D - 1;
-  const int total = Dm * Dm * PP;
+  // ---- fused bilinear blend + axis swap + output permutation (correlation_kernel.cu:221-232), as in corr_fwd_cl_kernel.
+  //      Output element (l, t): level index l, t = (cx * Dm + a) * 9 + p (cx = x offset: permute(0,1,3,2,4,5), a = y offset,
+  //      p = i0*3+j0) goes to  out[be * estride + t * lstride + offset(l)];  NL == 2 walks n = t * 2 + l so that
+  //      consecutive lanes write consecutive addresses of the standard stacked layout (lstride 2, offsets 0 / 1).
   {
-    int q = lane / PP, p = lane - q * PP;
-    int cx = q / Dm, a = q - cx * Dm;
-    float* op = outp + (int64_t)lane * out_lstride;
-    const int64_t ostep = 64 * out_lstride;
-    for (int l0 = 0; l0 < total; l0 += 64) {        // wave-uniform trip count: the shuffles below need all lanes
-      const float dxp = __shfl(my_dx, p), dyp = __shfl(my_dy, p);
-      if (l0 + lane < total) {
-        const float* r = rawwin + p * (ntap + 1) + a * D + cx;
-        store_streamed(op, blend4(dxp, dyp, r[0], r[1], r[D], r[D + 1]));
+    const int Dm = D - 1;
+    const int per = Dm * Dm * PP, total = NL * per;
+    float* ob = out + (int64_t)be * out_estride;
+    for (int n0 = 0; n0 < total; n0 += 64) {           // wave-uniform trip count: the shuffles below need all lanes
+      const int n = min(n0 + lane, total - 1);
+      const int l = (NL == 2) ? (n & 1) : 0, t = (NL == 2) ? (n >> 1) : n;
+      const int q = t / PP, p = t - q * PP;
+      const int cx = q / Dm, a = q - cx * Dm;
+      const float div = LVF(l, coord_div);
+      const float fx = __shfl(cpx, p) / div, fy = __shfl(cpy, p) / div;       // same IEEE division as the geometry above
+      const float dxp = fx - floorf(fx), dyp = fy - floorf(fy);
+      if (n0 + lane < total) {
+        const float* r = s_rawwin + l * RW_FLOATS + p * (ntap + 1) + a * D + cx;
+        store_streamed(ob + (int64_t)t * out_lstride + LVF(l, out_offset), blend4(dxp, dyp, r[0], r[1], r[D], r[D + 1]));
       }
-      op += ostep;
-      p += 1; a += 7;
-      if (p >= PP) { p -= PP; a += 1; }
-      while (a >= Dm) { a -= Dm; cx += 1; }
     }
   }
   if (trace && lane == 0) {                          // debug: per-wave cycle stamps (see launch_staged)
-    unsigned long long* t = trace + ((size_t)lvl * BE + slot) * 8;
+    unsigned long long* t = trace + ((size_t)wlvl * BE + slot) * 8;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    t[0] = t_start; t[1] = __builtin_readcyclecounter(); t[2] = (unsigned long long)npos_ll; t[3] = blockIdx.x;
+    t[0] = t_start; t[1] = __builtin_readcyclecounter(); t[2] = (unsigned long long)g0.nslots; t[3] = blockIdx.x;
     t[4] = t_geo; t[5] = t_first; t[6] = t_loop;
   }
+#undef LVF
 }
 #undef DEVO_MFMA_STEP

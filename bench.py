@@ -236,8 +236,11 @@ def main():
             recs = json.load(f)
         key = f"{args.workload}/{args.dtype}/{args.layout}"
         rec = (recs.get(key + "/staged") if lookup_kernel == "corr_fwd_cl_kernel" else None) or recs.get(key)
+        per_launch = 2 if args.fuse_levels else 1                  # records are per level launch ...
+        if args.fuse_levels and lookup_kernel == "corr_fwd_mfma_kernel" and recs.get(key + "/fused"):
+            rec, per_launch = recs[key + "/fused"], 1              # ... except the two-level launch's own record
         if rec and rec.get("kernel", "corr_fwd_cl_kernel") == lookup_kernel:
-            traffic = int((2.0 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024) * (2 if args.fuse_levels else 1)
+            traffic = int((2.0 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024) * per_launch
             traffic_src = f"profiles/pmc_traffic.json ({rec['round']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x read correction)"
     except (OSError, ValueError, KeyError):
         pass

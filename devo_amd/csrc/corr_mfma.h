@@ -111,6 +111,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   };
   const Geo g0 = make_geo(0);
   const Geo g1 = (NL == 2) ? make_geo(1) : g0;
+  // window origins of the 9 pixels per level index -> LDS (the scatter reads them back as broadcasts: LDS instructions,
+  // not vector ALU — every vector instruction of this kernel competes with the MFMAs for the SIMD's issue slot);
+  // sub-pixel fractions -> one register pair: lane p holds level index 0's, lane 16 + p level index 1's
+  __shared__ int s_org[NL][PP][2];
+  float fdx, fdy;
+  {
+#pragma unroll
+    for (int l = 0; l < NL; l++) if (lane < PP) { s_org[l][lane][0] = origin_x(l); s_org[l][lane][1] = origin_y(l); }
+    const int src = lane & 15;                                   // lanes 16.. take the coordinates of lane - 16
+    const float sx = __shfl(cpx, src), sy = __shfl(cpy, src);
+    const float dv = LVF((NL == 2 && lane >= 16) ? 1 : 0, coord_div);
+    const float qx = sx / dv, qy = sy / dv;                        // same IEEE division as origin_x / origin_y
+    fdx = qx - floorf(qx); fdy = qy - floorf(qy);
+  }
   const int np0 = g0.npass, nseg = (NL == 2) ? np0 + g1.npass : np0;     // segments = passes of level 0, then of level 1
   auto seg_level = [&](int s) -> int { return (NL == 2 && s >= np0) ? 1 : 0; };
 
@@ -176,7 +190,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const unsigned c = 16u * g + 4u * q, blk = c >> cb_shift;
-      rb[ring][q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, off + blk * block_bytes + (c - (blk << cb_shift)) * 4u, 0, 0));
+      // lane offset in the vector operand (the range check looks at it alone), piece offset in the scalar one: no vector add
+      rb[ring][q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, off, blk * block_bytes + (c - (blk << cb_shift)) * 4u, 0));
     }
   };
   mfma_acc4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -212,16 +227,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
     //      its window.  Out-of-image positions contribute exactly 0 (correlation_kernel.cu:136: within_bounds).
     {
       float* rawwin = s_rawwin + lc * RW_FLOATS;
-      // (window origins broadcast BEFORE the branch: inside it the lanes that hold them may be switched off)
-      const int mox = origin_x(lc), moy = origin_y(lc);
-      int ox[PP], oy[PP];
-#pragma unroll
-      for (int p = 0; p < PP; p++) { ox[p] = __builtin_amdgcn_readlane(mox, p); oy[p] = __builtin_amdgcn_readlane(moy, p); }
+      const int (*org)[2] = s_org[lc];
       if (cur.listed) {
         const float v[PP] = {acc0[0], acc0[1], acc0[2], acc0[3], acc1[0], acc1[1], acc1[2], acc1[3], acc2[0]};
 #pragma unroll
         for (int p = 0; p < PP; p++) {
-          const int ta = cur.gy - oy[p], tc = cur.gx - ox[p];
+          const int ta = cur.gy - org[p][1], tc = cur.gx - org[p][0];
           if ((unsigned)ta < (unsigned)D && (unsigned)tc < (unsigned)D)
             rawwin[p * (ntap + 1) + ta * D + tc] = cur.inside ? v[p] : 0.0f;
         }
@@ -239,20 +250,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   //      consecutive lanes write consecutive addresses of the standard stacked layout (lstride 2, offsets 0 / 1).
   {
     const int Dm = D - 1;
-    const int per = Dm * Dm * PP, total = NL * per;
-    float* ob = out + (int64_t)be * out_estride;
+    const int total = NL * Dm * Dm * PP;
+    // lane's element n = n0 + lane: level index l = n % NL (constant per lane), t = n / NL advances by 64 / NL per round:
+    // the (p, a, cx) decomposition is carried instead of re-divided
+    constexpr int TSTEP = 64 / NL, PSTEP = TSTEP % PP, QSTEP = TSTEP / PP;
+    const int l = (NL == 2) ? (lane & 1) : 0;
+    int t = (NL == 2) ? (lane >> 1) : lane;
+    int q = t / PP, p = t - q * PP;
+    int cx = q / Dm, a = q - cx * Dm;
+    const float* rw = s_rawwin + l * RW_FLOATS;
+    float* op = out + (int64_t)be * out_estride + (int64_t)t * out_lstride + LVF(l, out_offset);
+    const int64_t ostep = (int64_t)TSTEP * out_lstride;
     for (int n0 = 0; n0 < total; n0 += 64) {           // wave-uniform trip count: the shuffles below need all lanes
-      const int n = min(n0 + lane, total - 1);
-      const int l = (NL == 2) ? (n & 1) : 0, t = (NL == 2) ? (n >> 1) : n;
-      const int q = t / PP, p = t - q * PP;
-      const int cx = q / Dm, a = q - cx * Dm;
-      const float div = LVF(l, coord_div);
-      const float fx = __shfl(cpx, p) / div, fy = __shfl(cpy, p) / div;       // same IEEE division as the geometry above
-      const float dxp = fx - floorf(fx), dyp = fy - floorf(fy);
+      const float dxp = __shfl(fdx, p + 16 * l), dyp = __shfl(fdy, p + 16 * l);
       if (n0 + lane < total) {
-        const float* r = s_rawwin + l * RW_FLOATS + p * (ntap + 1) + a * D + cx;
-        store_streamed(ob + (int64_t)t * out_lstride + LVF(l, out_offset), blend4(dxp, dyp, r[0], r[1], r[D], r[D + 1]));
+        const float* r = rw + p * (ntap + 1) + a * D + cx;
+        store_streamed(op, blend4(dxp, dyp, r[0], r[1], r[D], r[D + 1]));
       }
+      op += ostep;
+      p += PSTEP; a += QSTEP;
+      if (p >= PP) { p -= PP; a += 1; }
+      while (a >= Dm) { a -= Dm; cx += 1; }
     }
   }
   if (trace && lane == 0) {                          // debug: per-wave cycle stamps (see launch_staged)

@@ -15,6 +15,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--layout", default="blk8")
 ap.add_argument("--no-plan", action="store_true")
+ap.add_argument("--per-level", action="store_true", help="one launch per pyramid level instead of the fused two-level launch the bench uses")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = synth.workload(a.workload)
@@ -29,7 +30,10 @@ order = None if a.no_plan else cuda_corr.plan(coords, d["jj"], n, cfg["H"])
 if a.no_plan:
     cuda_corr.PLAN_MIN_EDGES = 1 << 60
 for _ in range(a.reps):
-    for lvl, (fm, s_) in enumerate(zip(d["pyramid"], (1.0, 4.0))):
-        cuda_corr.forward_into(out, d["gmap"], fm, coords, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order, coord_div=s_)
+    if a.per_level:
+        for lvl, (fm, s_) in enumerate(zip(d["pyramid"], (1.0, 4.0))):
+            cuda_corr.forward_into(out, d["gmap"], fm, coords, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order, coord_div=s_)
+    else:
+        cuda_corr.forward_pyramid(d["gmap"], d["pyramid"], coords, d["kk"], d["jj"], R, (1, 4), out=out, order=order)
 torch.cuda.synchronize()
 print("done", E)

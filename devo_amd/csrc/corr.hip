@@ -754,7 +754,7 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
                        (f2s[1] % v == 0) && (!blocked || f2s[2] % v == 0) && ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) &&
                        f2s[3] >= 0 && f2s[4] >= 0 && (!blocked || (f2s[2] >= 0 && C % cb == 0));
   lv->staged_ok = aligned && (C % KC == 0) && (!blocked || cblock == KC) && plane_bytes < (1LL << 31);   // 32-bit in-plane offsets
-  lv->mfma_ok = aligned && std::is_same<T, float>::value && corr_mfma_enabled() && (C == 128) && (!blocked || (cb >= 4 && (cb & (cb - 1)) == 0)) &&
+  lv->mfma_ok = aligned && std::is_same<T, float>::value && corr_mfma_enabled() && (C == 128) && (!blocked || cb == 4 || cb == 8 || cb == 16) &&
                 frame_bytes < (1LL << 31);                                                             // 32-bit in-frame offsets
   if (!lv->staged_ok && !lv->mfma_ok) {
     if (blocked) {

@@ -182,36 +182,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   // the last one are out of range = no memory access).  The step loop is fully unrolled: ring slots, patch registers and
   // the MFMAs' abid are all static.
   // 16-byte piece q (4 channels) of step g starts at channel c = 16 g + 4 q: block c / cb, offset c % cb
-  // (cb is a power of two, 1 << cb_shift; channels-last = one block of all channels, cb_shift = 30)
+  // (cb = 1 << cb_shift; channels-last = one block of all channels, cb_shift = 30)
   auto as_f4 = [](v4u32 v) -> float4 { float4 f; __builtin_memcpy(&f, &v, sizeof(f)); return f; };
   constexpr int RING = DEVO_MFMA_RING;
   float4 rb[RING][4];
-  auto fetch = [&](int ring, int g, unsigned off, __amdgpu_buffer_rsrc_t rs, int cb_shift, unsigned block_bytes) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const unsigned c = 16u * g + 4u * q, blk = c >> cb_shift;
-      // lane offset in the vector operand (the range check looks at it alone), piece offset in the scalar one: no vector add
-      rb[ring][q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, off, blk * block_bytes + (c - (blk << cb_shift)) * 4u, 0));
-    }
+  // Byte offset of piece q of step g = g * G16 + d[q]: linear in g for the layouts the launcher lets through (channel
+  // blocks of 4, 8 or 16 channels, or channels-last), so a step costs 4 scalar adds besides its 4 loads.
+  struct Pieces { unsigned g16, d1, d2, d3; };
+  auto pieces_of = [&](int l) -> Pieces {
+    const int sh = LVF(l, cb_shift);
+    const unsigned bb = (unsigned)LVF(l, block_stride) * 4u;
+    auto piece = [&](unsigned c) -> unsigned { const unsigned blk = c >> sh; return blk * bb + (c - (blk << sh)) * 4u; };
+    return Pieces{piece(16u), piece(4u), piece(8u), piece(12u)};
+  };
+  auto fetch = [&](int ring, int g, unsigned off, __amdgpu_buffer_rsrc_t rs, const Pieces& pc) {
+    // lane offset in the vector operand (the range check looks at it alone), piece offset in the scalar one: no vector add
+    const unsigned base = (unsigned)g * pc.g16;
+    rb[ring][0] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, off, base, 0));
+    rb[ring][1] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, off, base + pc.d1, 0));
+    rb[ring][2] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, off, base + pc.d2, 0));
+    rb[ring][3] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, off, base + pc.d3, 0));
   };
   mfma_acc4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
   Pos cur = position(0), nxt = position(1);
   {
     const __amdgpu_buffer_rsrc_t r0 = frame_rsrc(0);
-    const int sh0 = LVF(0, cb_shift); const unsigned bb0 = (unsigned)LVF(0, block_stride) * 4u;
+    const Pieces pc0 = pieces_of(0);
 #pragma unroll
-    for (int g = 0; g < RING - 1; g++) { fetch(g, g % NGR, cur.off, r0, sh0, bb0); __builtin_amdgcn_sched_barrier(0); }
+    for (int g = 0; g < RING - 1; g++) { fetch(g, g % NGR, cur.off, r0, pc0); __builtin_amdgcn_sched_barrier(0); }
   }
   if (trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_first = __builtin_readcyclecounter(); }
   for (int sg = 0; sg < nseg; sg++) {
     const int lc = seg_level(sg), ln = seg_level(min(sg + 1, nseg - 1));         // wave-uniform
     const __amdgpu_buffer_rsrc_t rsc = frame_rsrc(lc), rsn = frame_rsrc(ln);
-    const int shc = LVF(lc, cb_shift), shn = LVF(ln, cb_shift);
-    const unsigned bbc = (unsigned)LVF(lc, block_stride) * 4u, bbn = (unsigned)LVF(ln, block_stride) * 4u;
+    const Pieces pcc = pieces_of(lc), pcn = pieces_of(ln);
 #pragma unroll
     for (int g = 0; g < NGR; g++) {
-      if (g + RING - 1 < NGR) fetch((g + RING - 1) % RING, g + RING - 1, cur.off, rsc, shc, bbc);       // (static condition)
-      else fetch((g + RING - 1) % RING, g + RING - 1 - NGR, nxt.off, rsn, shn, bbn);
+      if (g + RING - 1 < NGR) fetch((g + RING - 1) % RING, g + RING - 1, cur.off, rsc, pcc);       // (static condition)
+      else fetch((g + RING - 1) % RING, g + RING - 1 - NGR, nxt.off, rsn, pcn);
       __builtin_amdgcn_sched_barrier(0);
       {
         const float a0 = pa[g][0], a1 = pa[g][1], a2 = pa[g][2];
@@ -270,6 +278,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
       op += ostep;
       p += PSTEP; a += QSTEP;
       if (p >= PP) { p -= PP; a += 1; }
+      if (a >= Dm) { a -= Dm; cx += 1; }             // (two plain selects cover every radius >= 3; the loop is for tiny windows)
+      if (a >= Dm) { a -= Dm; cx += 1; }
       while (a >= Dm) { a -= Dm; cx += 1; }
     }
   }

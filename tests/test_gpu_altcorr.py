@@ -76,9 +76,9 @@ def test_channel_blocked_layout_is_bit_identical_and_checked():
     h = lambda t: t.to(DEV).half()
     with pytest.raises(RuntimeError):                                 # the staged kernel (fp16) reads 8-channel blocks only
         cuda_corr.forward(h(f1), altcorr.channel_blocked(h(f2), 4), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
-    if os.environ.get("DEVO_CORR_MFMA", "1") != "0":                  # the matrix-core kernel (fp32, C = 128): any power of two >= 4
+    if os.environ.get("DEVO_CORR_MFMA", "1") != "0":                  # the matrix-core kernel (fp32, C = 128): blocks of 4, 8 or 16 channels
         c = _case(seed=15, spread=3.5, E=96)
-        for cb in (4, 16, 32):
+        for cb in (4, 16):
             out, = cuda_corr.forward(c[0].to(DEV), altcorr.channel_blocked(c[1].to(DEV), cb), c[2].to(DEV), c[3].to(DEV), c[4].to(DEV), c[5])
             assert torch.equal(out, _run(*c, layout="cl")), cb
     else:

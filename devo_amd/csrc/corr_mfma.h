@@ -63,7 +63,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   auto second = [&](int l) -> bool { return NL == 2 ? (l != 0) : (wlvl != 0); };   // does index l mean pyramid level 1?
 #define LVF(l, F) (second(l) ? lv1.F : lv0.F)
   constexpr int DMAX = 2 * RMAX + 2;
-  constexpr int RW_FLOATS = (PP * (DMAX * DMAX + 1) + 3) / 4 * 4;
+  // Per level index one LDS area that holds the 9 sums of every box position until the epilogue, in one of two layouts:
+  //   box layout  [p][BOXS]         position s of pixel p at p * BOXS + s: a pass stores its 9 sums with 9 immediate-offset
+  //                                 ds_writes (boxes of <= BOXS positions: the usual case)
+  //   raw windows [p][D*D + 1]      tap (a, c) of pixel p (large boxes, window-by-window passes): conditional scatter
+  // The epilogue reads both as  base(p) + a * rowstride + c  (rowstride = box width / D).
+  constexpr int BOXS = 128;
+  constexpr int RWIN_FLOATS = (PP * (DMAX * DMAX + 1) + 3) / 4 * 4;
+  constexpr int RW_FLOATS = RWIN_FLOATS > PP * BOXS ? RWIN_FLOATS : PP * BOXS;
   __shared__ __attribute__((aligned(16))) float s_rawwin[NL * RW_FLOATS];
   const int lane = threadIdx.x;
   const int slot = corr_plan_slot(order, BE, gid, nitems);
@@ -88,10 +95,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   }
   unsigned long long t_geo = 0, t_first = 0, t_loop = 0;
   if (trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_geo = __builtin_readcyclecounter(); }
-  // window origin of the lane's pixel at level index l (recomputed where needed instead of kept: registers)
-  auto origin_x = [&](int l) -> int { return floor_to_int(cpx / LVF(l, coord_div)) - R; };
-  auto origin_y = [&](int l) -> int { return floor_to_int(cpy / LVF(l, coord_div)) - R; };
-  struct Geo { int xmin, ymin, bw, nslots, npass; bool box_mode; float inv_bw; };      // wave-uniform
+  // scaled coordinates of the lane's pixel per level index.  coords / div is the reference's true division; for a power of
+  // two (1 and 4 in DEVO) x * (1 / div) is the same correctly rounded value, and it spares ~12 vector instructions per
+  // division (every vector instruction of this kernel competes with the MFMAs for the SIMD's issue slot).
+  float qx[NL], qy[NL];
+  {
+    auto pow2 = [](float d) -> bool { return (__float_as_uint(d) & 0x807fffffu) == 0u && d >= 1.0f; };
+    bool all_pow2 = true;
+#pragma unroll
+    for (int l = 0; l < NL; l++) all_pow2 = all_pow2 && pow2(LVF(l, coord_div));
+    if (all_pow2) {                                                   // wave-uniform
+#pragma unroll
+      for (int l = 0; l < NL; l++) { const float iv = 1.0f / LVF(l, coord_div); qx[l] = cpx * iv; qy[l] = cpy * iv; }
+    } else {
+#pragma unroll
+      for (int l = 0; l < NL; l++) { const float dv = LVF(l, coord_div); qx[l] = cpx / dv; qy[l] = cpy / dv; }
+    }
+  }
+  auto origin_x = [&](int l) -> int { return floor_to_int((NL == 2 && l) ? qx[NL - 1] : qx[0]) - R; };
+  auto origin_y = [&](int l) -> int { return floor_to_int((NL == 2 && l) ? qy[NL - 1] : qy[0]) - R; };
+  struct Geo { int xmin, ymin, bw, nslots, npass; bool box_mode, boxlay; float inv_bw; };      // wave-uniform
   auto make_geo = [&](int l) -> Geo {
     const int mox = origin_x(l), moy = origin_y(l);
     int xmin = __builtin_amdgcn_readlane(mox, 0), xmax = xmin, ymin = __builtin_amdgcn_readlane(moy, 0), ymax = ymin;
@@ -106,6 +129,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
     g.box_mode = npos_ll <= (long long)PP * ntap;        // else: the 9 windows one after the other
     g.nslots = g.box_mode ? (int)npos_ll : PP * ntap;
     g.npass = (g.nslots + 63) >> 6;
+    g.boxlay = g.box_mode && g.nslots <= BOXS;
     g.inv_bw = 1.0f / (float)g.bw;
     return g;
   };
@@ -119,11 +143,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   {
 #pragma unroll
     for (int l = 0; l < NL; l++) if (lane < PP) { s_org[l][lane][0] = origin_x(l); s_org[l][lane][1] = origin_y(l); }
-    const int src = lane & 15;                                   // lanes 16.. take the coordinates of lane - 16
-    const float sx = __shfl(cpx, src), sy = __shfl(cpy, src);
-    const float dv = LVF((NL == 2 && lane >= 16) ? 1 : 0, coord_div);
-    const float qx = sx / dv, qy = sy / dv;                        // same IEEE division as origin_x / origin_y
-    fdx = qx - floorf(qx); fdy = qy - floorf(qy);
+    const int src = lane & 15;                                   // lanes 16.. take the fractions of lane - 16 at level index 1
+    const bool hi = NL == 2 && lane >= 16;
+    const float ax = __shfl(qx[0], src), ay = __shfl(qy[0], src), bx = __shfl(qx[NL - 1], src), by = __shfl(qy[NL - 1], src);
+    const float qx_ = hi ? bx : ax, qy_ = hi ? by : ay;
+    fdx = qx_ - floorf(qx_); fdy = qy_ - floorf(qy_);
+  }
+  // where the epilogue finds tap (0, 0) of pixel p (lane p: level index 0, lane 16 + p: level index 1), and the row stride
+  int fbase;
+  {
+    const int p_ = min(lane & 15, PP - 1), l_ = (NL == 2 && lane >= 16) ? 1 : 0;
+    const Geo& G = l_ ? g1 : g0;
+    fbase = G.boxlay ? p_ * BOXS + (s_org[l_][p_][1] - G.ymin) * G.bw + (s_org[l_][p_][0] - G.xmin) : p_ * (ntap + 1);
   }
   const int np0 = g0.npass, nseg = (NL == 2) ? np0 + g1.npass : np0;     // segments = passes of level 0, then of level 1
   auto seg_level = [&](int s) -> int { return (NL == 2 && s >= np0) ? 1 : 0; };
@@ -169,7 +200,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
     } else {
       const int wp = sc / ntap, t = sc - wp * ntap;
       const int ta = t / D;
-      q.gy = __shfl(origin_y(l), wp) + ta; q.gx = __shfl(origin_x(l), wp) + (t - ta * D);
+      q.gy = s_org[l][wp][1] + ta; q.gx = s_org[l][wp][0] + (t - ta * D);          // (window origins live in LDS)
     }
     q.listed = s < G.nslots && sg < nseg;
     q.inside = q.gy >= 0 && q.gy < LVF(l, H2) && q.gx >= 0 && q.gx < LVF(l, W2);
@@ -236,13 +267,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
     {
       float* rawwin = s_rawwin + lc * RW_FLOATS;
       const int (*org)[2] = s_org[lc];
+      const bool boxlay = lc ? g1.boxlay : g0.boxlay;                       // wave-uniform
+      const int ps = lc ? sg - np0 : sg;
       if (cur.listed) {
         const float v[PP] = {acc0[0], acc0[1], acc0[2], acc0[3], acc1[0], acc1[1], acc1[2], acc1[3], acc2[0]};
+        if (boxlay) {
+          float* dst = rawwin + ps * 64 + lane;
 #pragma unroll
-        for (int p = 0; p < PP; p++) {
-          const int ta = cur.gy - org[p][1], tc = cur.gx - org[p][0];
-          if ((unsigned)ta < (unsigned)D && (unsigned)tc < (unsigned)D)
-            rawwin[p * (ntap + 1) + ta * D + tc] = cur.inside ? v[p] : 0.0f;
+          for (int p = 0; p < PP; p++) dst[p * BOXS] = cur.inside ? v[p] : 0.0f;
+        } else {
+#pragma unroll
+          for (int p = 0; p < PP; p++) {
+            const int ta = cur.gy - org[p][1], tc = cur.gx - org[p][0];
+            if ((unsigned)ta < (unsigned)D && (unsigned)tc < (unsigned)D)
+              rawwin[p * (ntap + 1) + ta * D + tc] = cur.inside ? v[p] : 0.0f;
+          }
         }
       }
     }
@@ -267,13 +306,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
     int q = t / PP, p = t - q * PP;
     int cx = q / Dm, a = q - cx * Dm;
     const float* rw = s_rawwin + l * RW_FLOATS;
+    const int rstride = (l ? g1.boxlay : g0.boxlay) ? (l ? g1.bw : g0.bw) : D;       // per lane (l is)
     float* op = out + (int64_t)be * out_estride + (int64_t)t * out_lstride + LVF(l, out_offset);
     const int64_t ostep = (int64_t)TSTEP * out_lstride;
     for (int n0 = 0; n0 < total; n0 += 64) {           // wave-uniform trip count: the shuffles below need all lanes
       const float dxp = __shfl(fdx, p + 16 * l), dyp = __shfl(fdy, p + 16 * l);
+      const int base = __shfl(fbase, p + 16 * l);
       if (n0 + lane < total) {
-        const float* r = rw + p * (ntap + 1) + a * D + cx;
-        store_streamed(op, blend4(dxp, dyp, r[0], r[1], r[D], r[D + 1]));
+        const float* r = rw + base + a * rstride + cx;
+        store_streamed(op, blend4(dxp, dyp, r[0], r[1], r[rstride], r[rstride + 1]));
       }
       op += ostep;
       p += PSTEP; a += QSTEP;

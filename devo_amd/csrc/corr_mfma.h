@@ -91,7 +91,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
 #pragma unroll
     for (int p = 0; p < 2 * PP; p++) cv[p] = ce[p];             // 18 scalar loads in flight together (no branch around them)
 #pragma unroll
-    for (int p = 0; p < PP; p++) { cpx = (lane == p) ? cv[p] : cpx; cpy = (lane == p) ? cv[PP + p] : cpy; }
+    for (int p = 0; p < PP; p++) {                              // scalar -> lane p (one instruction each, no compare + select)
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(cpx) : "s"(cv[p]), "n"(p));
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(cpy) : "s"(cv[PP + p]), "n"(p));
+    }
   }
   unsigned long long t_geo = 0, t_first = 0, t_loop = 0;
   if (trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_geo = __builtin_readcyclecounter(); }
@@ -177,10 +180,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   float pa[NGR][3];
 #pragma unroll
   for (int g = 0; g < NGR; g++) {
-    const unsigned ka = (unsigned)g * (16u * PP * 4u);
-    pa[g][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ka + aoff0, 0, 0));
-    pa[g][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ka + aoff1, 0, 0));
-    pa[g][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ka + aoff2, 0, 0));
+    const unsigned ka = (unsigned)g * (16u * PP * 4u);        // in the scalar offset operand: no vector adds
+    pa[g][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, aoff0, ka, 0));
+    pa[g][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, aoff1, ka, 0));
+    pa[g][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, aoff2, ka, 0));
   }
   __builtin_amdgcn_sched_barrier(0);        // patch loads first: the loop's s_waitcnt counts assume they are the oldest
 
@@ -291,34 +294,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   }
   wave_lds_fence();
   if (trace) t_loop = __builtin_readcyclecounter();
-  // ---- fused bilinear blend + axis swap + output permutation (correlation_kernel.cu:221-232), as in corr_fwd_cl_kernel.
-  //      Output element (l, t): level index l, t = (cx * Dm + a) * 9 + p (cx = x offset: permute(0,1,3,2,4,5), a = y offset,
-  //      p = i0*3+j0) goes to  out[be * estride + t * lstride + offset(l)];  NL == 2 walks n = t * 2 + l so that
-  //      consecutive lanes write consecutive addresses of the standard stacked layout (lstride 2, offsets 0 / 1).
+  // ---- fused bilinear blend + axis swap + output permutation (correlation_kernel.cu:221-232).
+  //      Output element (l, t): level index l, t = q * 9 + p with q = cx * Dm + a (cx = x offset: permute(0,1,3,2,4,5),
+  //      a = y offset), p = i0*3+j0, goes to  out[be * estride + t * lstride + offset(l)].  A lane keeps ITS (p, l) for the
+  //      whole epilogue — blend weights, result-area base and row stride are lane constants, no shuffles in the loop — and
+  //      walks q = grp, grp + GRPS, ...; the 9 * NL * GRPS active lanes of a round write consecutive addresses of the standard
+  //      stacked layout (lstride NL, offsets 0 / 1).
   {
-    const int Dm = D - 1;
-    const int total = NL * Dm * Dm * PP;
-    // lane's element n = n0 + lane: level index l = n % NL (constant per lane), t = n / NL advances by 64 / NL per round:
-    // the (p, a, cx) decomposition is carried instead of re-divided
-    constexpr int TSTEP = 64 / NL, PSTEP = TSTEP % PP, QSTEP = TSTEP / PP;
-    const int l = (NL == 2) ? (lane & 1) : 0;
-    int t = (NL == 2) ? (lane >> 1) : lane;
-    int q = t / PP, p = t - q * PP;
-    int cx = q / Dm, a = q - cx * Dm;
-    const float* rw = s_rawwin + l * RW_FLOATS;
+    const int Dm = D - 1, nq = Dm * Dm;
+    constexpr int NPL = PP * NL, GRPS = 64 / NPL;               // 18 (p, l) pairs x 3 q's, or 9 x 7
+    const int grp = lane / NPL, pl = lane - grp * NPL;
+    const int p = pl / NL, l = pl - p * NL;
+    const bool active = grp < GRPS;
+    const float dxp = __shfl(fdx, p + 16 * l), dyp = __shfl(fdy, p + 16 * l);
+    const int base = __shfl(fbase, p + 16 * l);
+    float w00, w01, w10, w11;
+    {
+#pragma clang fp contract(off)
+      w00 = (1.0f - dxp) * (1.0f - dyp); w01 = dxp * (1.0f - dyp); w10 = (1.0f - dxp) * dyp; w11 = dxp * dyp;   // blend4's factors
+    }
     const int rstride = (l ? g1.boxlay : g0.boxlay) ? (l ? g1.bw : g0.bw) : D;       // per lane (l is)
-    float* op = out + (int64_t)be * out_estride + (int64_t)t * out_lstride + LVF(l, out_offset);
-    const int64_t ostep = (int64_t)TSTEP * out_lstride;
-    for (int n0 = 0; n0 < total; n0 += 64) {           // wave-uniform trip count: the shuffles below need all lanes
-      const float dxp = __shfl(fdx, p + 16 * l), dyp = __shfl(fdy, p + 16 * l);
-      const int base = __shfl(fbase, p + 16 * l);
-      if (n0 + lane < total) {
-        const float* r = rw + base + a * rstride + cx;
-        store_streamed(op, blend4(dxp, dyp, r[0], r[1], r[rstride], r[rstride + 1]));
+    int q = grp;
+    int cx = q / Dm, a = q - cx * Dm;
+    const float* rw = s_rawwin + l * RW_FLOATS + base;
+    float* op = out + (int64_t)be * out_estride + (int64_t)(q * PP + p) * out_lstride + LVF(l, out_offset);
+    const int64_t ostep = (int64_t)(GRPS * PP) * out_lstride;
+    for (int q0 = 0; q0 < nq; q0 += GRPS) {
+      if (active && q < nq) {
+        const float* r = rw + a * rstride + cx;
+        float o;
+        {
+#pragma clang fp contract(off)
+          o = w00 * r[0]; o = o + w01 * r[1]; o = o + w10 * r[rstride]; o = o + w11 * r[rstride + 1];
+        }
+        store_streamed(op, o);
       }
       op += ostep;
-      p += PSTEP; a += QSTEP;
-      if (p >= PP) { p -= PP; a += 1; }
+      q += GRPS; a += GRPS;
       if (a >= Dm) { a -= Dm; cx += 1; }             // (two plain selects cover every radius >= 3; the loop is for tiny windows)
       if (a >= Dm) { a -= Dm; cx += 1; }
       while (a >= Dm) { a -= Dm; cx += 1; }

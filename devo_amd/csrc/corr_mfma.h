@@ -118,14 +118,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   auto origin_x = [&](int l) -> int { return floor_to_int((NL == 2 && l) ? qx[NL - 1] : qx[0]) - R; };
   auto origin_y = [&](int l) -> int { return floor_to_int((NL == 2 && l) ? qy[NL - 1] : qy[0]) - R; };
   struct Geo { int xmin, ymin, bw, nslots, npass; bool box_mode, boxlay; float inv_bw; };      // wave-uniform
+  // min / max over lanes 0..8 inside the first 16-lane row with 4 DPP row shifts each (hipcc turns min/max chains over
+  // readlane results into vector min3/max3 plus moves: 90 vector instructions per level instead of 24)
+  auto row_min = [&](int v) -> int {
+    v = (lane < PP) ? v : 0x7fffffff;
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));     // row_shr:1
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));     // row_shr:2
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xf, false));     // row_shr:4
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xf, false));     // row_shr:8
+    return __builtin_amdgcn_readlane(v, 15);
+  };
   auto make_geo = [&](int l) -> Geo {
     const int mox = origin_x(l), moy = origin_y(l);
-    int xmin = __builtin_amdgcn_readlane(mox, 0), xmax = xmin, ymin = __builtin_amdgcn_readlane(moy, 0), ymax = ymin;
-#pragma unroll
-    for (int p = 1; p < PP; p++) {
-      const int x = __builtin_amdgcn_readlane(mox, p), y = __builtin_amdgcn_readlane(moy, p);
-      xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
-    }
+    const int xmin = row_min(mox), xmax = -row_min(-mox), ymin = row_min(moy), ymax = -row_min(-moy);
     Geo g;
     g.xmin = xmin; g.ymin = ymin; g.bw = xmax - xmin + D;
     const long long npos_ll = (long long)g.bw * (ymax - ymin + D);
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
     g.nslots = g.box_mode ? (int)npos_ll : PP * ntap;
     g.npass = (g.nslots + 63) >> 6;
     g.boxlay = g.box_mode && g.nslots <= BOXS;
-    g.inv_bw = 1.0f / (float)g.bw;
+    g.inv_bw = __builtin_amdgcn_rcpf((float)g.bw);       // 1 ulp is plenty for the row / column split below
     return g;
   };
   const Geo g0 = make_geo(0);
@@ -315,7 +320,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
     }
     const int rstride = (l ? g1.boxlay : g0.boxlay) ? (l ? g1.bw : g0.bw) : D;       // per lane (l is)
     int q = grp;
-    int cx = q / Dm, a = q - cx * Dm;
+    int cx = 0, a = q;
+    while (a >= Dm) { a -= Dm; cx += 1; }           // (grp < 7: only windows smaller than 7 x 7 take a turn)
     const float* rw = s_rawwin + l * RW_FLOATS + base;
     float* op = out + (int64_t)be * out_estride + (int64_t)(q * PP + p) * out_lstride + LVF(l, out_offset);
     const int64_t ostep = (int64_t)(GRPS * PP) * out_lstride;

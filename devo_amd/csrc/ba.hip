@@ -875,7 +875,11 @@ __global__ __launch_bounds__(256) void k_ba_reduce(const float* __restrict__ par
 // factorisation row n6 is z = L^{-1} y.  Blocked by the 6x6 pose blocks.  There is no serial section: every
 // thread that owns a panel row factors the 6x6 diagonal block itself, in registers, from the same LDS values
 // (broadcast reads) — cheaper than one lane doing it followed by a barrier.
-constexpr int SOLVE_THREADS = 1024;
+#ifndef DEVO_SOLVE_THREADS
+#define DEVO_SOLVE_THREADS 1024
+#endif
+constexpr int SOLVE_THREADS = DEVO_SOLVE_THREADS;
+constexpr int SOLVE_PRE = 4;            // tiles per thread whose coordinates are kept in registers
 
 __device__ __forceinline__ bool chol6(float L[6][6], float inv[6]) {   // in-register lower Cholesky of a 6x6 block
   bool ok = true;                                                      // inv[c] = 1 / L[c][c]
@@ -921,10 +925,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   }
   // This thread's 2x2 tile (ty >= tx) of the trailing lower triangle, relative to the trailing corner — the same for
   // every block step; 2x2 register tiles halve the LDS reads of the update (12 + 12 operands for 4 entries).
-  int ty = (int)((sqrtf(8.0f * (float)tid + 1.0f) - 1.0f) * 0.5f);
-  while (ty * (ty + 1) / 2 > tid) ty--;
-  while ((ty + 1) * (ty + 2) / 2 <= tid) ty++;
-  const int tx = tid - ty * (ty + 1) / 2;
+  auto tile_of = [](int t, int& yy, int& xx) {
+    yy = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (yy * (yy + 1) / 2 > t) yy--;
+    while ((yy + 1) * (yy + 2) / 2 <= t) yy++;
+    xx = t - yy * (yy + 1) / 2;
+  };
+  int pty[SOLVE_PRE], ptx[SOLVE_PRE];
+#pragma unroll
+  for (int k = 0; k < SOLVE_PRE; k++) tile_of(tid + SOLVE_THREADS * k, pty[k], ptx[k]);
   __syncthreads();
   if (meta->fail) {                              // an earlier iteration broke down: the reference call has thrown by now
     if (tid == 0 && meta->fail < 0 && status_flag) *status_flag = -1;          // (or the workspace was never prepared)
@@ -967,14 +976,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     // the columns to their right (disjoint), so everything is fetched before anything is written back
     const int rem = rows - (j0 + 6);
     const int nt = (rem + 1) / 2;                // tiles per side
-    for (int t = tid; t < nt * (nt + 1) / 2; t += SOLVE_THREADS) {
-      int yy = ty, xx = tx;
-      if (t != tid) {                            // N > 14 only: more tiles than threads
-        yy = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while (yy * (yy + 1) / 2 > t) yy--;
-        while ((yy + 1) * (yy + 2) / 2 <= t) yy++;
-        xx = t - yy * (yy + 1) / 2;
-      }
+    const int ntiles = nt * (nt + 1) / 2;
+    for (int k = 0; tid + SOLVE_THREADS * k < ntiles; k++) {
+      const int t = tid + SOLVE_THREADS * k;
+      int yy, xx;
+      if (k < SOLVE_PRE) { yy = (k == 0) ? pty[0] : (k == 1) ? pty[1] : (k == 2) ? pty[2] : pty[3]; xx = (k == 0) ? ptx[0] : (k == 1) ? ptx[1] : (k == 2) ? ptx[2] : ptx[3]; }
+      else tile_of(t, yy, xx);                   // large N only: more tiles than registers kept for them
       const int r0 = j0 + 6 + 2 * yy, c0 = j0 + 6 + 2 * xx;
       const bool r1ok = r0 + 1 < rows, c1ok = c0 + 1 < n6;          // second row / column inside the matrix
       const int r1 = r1ok ? r0 + 1 : r0, c1 = c1ok ? c0 + 1 : c0;

@@ -902,6 +902,8 @@ __device__ __forceinline__ bool chol6(float L[6][6], float inv[6]) {   // in-reg
   return ok;
 }
 
+__device__ unsigned long long g_solve_stamps[8];     // debug (DEVO_BA_TRACE): cycle stamps of the last solve
+
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restrict__ S, const float* __restrict__ y, int N,
                                                             float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag) {
   extern __shared__ __attribute__((aligned(16))) float A[];
@@ -911,6 +913,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   float* Li = Ld + N * 36;                      // [N][36] their inverses (for the back-substitution)
   float* xs = Li + N * 36;                      // [n6] solution
   const int tid = threadIdx.x;
+  const unsigned long long st0 = __builtin_readcyclecounter();
   if (tid == 0) s_fail = 0;
   {
     // k_ba_reduce wrote this very image (rows x LD, the right-hand side is row n6); eight loads in flight per thread
@@ -940,6 +943,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     return;
   }
 
+  const unsigned long long st1 = __builtin_readcyclecounter();
   for (int jb = 0; jb < N; jb++) {
     const int j0 = 6 * jb;
     const int r = j0 + 6 + tid;                  // this thread's panel row (if any)
@@ -1006,6 +1010,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     }
     __syncthreads();
   }
+  const unsigned long long st2 = __builtin_readcyclecounter();
   if (s_fail) {
     if (tid == 0) { meta->fail = iter + 1; if (status_flag) *status_flag = iter + 1; }
     return;
@@ -1038,6 +1043,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   // waves are done).  x_b = L_bb^-T z_b from the inverse block, then the lanes update their rows of z.  The solution is
   // collected in LDS (a global store inside the loop would put a vmcnt wait into every step's fence).
   if (tid >= 64) return;
+  const unsigned long long st3 = __builtin_readcyclecounter();
   float* z = A + n6 * LD;
   for (int jb = N - 1; jb >= 0; jb--) {
     const int j0 = 6 * jb;
@@ -1062,6 +1068,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     wave_lds_sync();
   }
   for (int i = tid; i < n6; i += 64) dX[i] = xs[i];
+  if (tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st3; g_solve_stamps[4] = __builtin_readcyclecounter(); }
 }
 
 // ------------------------------------------------------------------------------------------------- retract
@@ -1408,6 +1415,13 @@ int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsi
       hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((n6 * n6 + n6 + 63) / 64)), dim3(256), 0, st, partials, L.n_part, N, S, y);
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag);
+      static const bool ba_trace = getenv("DEVO_BA_TRACE") != nullptr;
+      if (ba_trace) {
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_solve_stamps), sizeof(h));
+        fprintf(stderr, "[ba trace] solve: load %llu, factorisation %llu, block inverses %llu, back substitution %llu cycles\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3]);
+      }
       if ((rc = check_launch("devo_ba_forward(solve)"))) return rc;
     }
     hipLaunchKernelGGL(k_ba_retract, dim3(blocks_for((long long)L.max_seg * 64 > N ? (long long)L.max_seg * 64 : N, 256, 2048)), dim3(256), 0, st, poses, patches, dX, patch_rec,

@@ -29,7 +29,9 @@ __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float c
   int xlo = x[0], xhi = x[0], ylo = y[0], yhi = y[0];
 #pragma unroll
   for (int p = 1; p < 9; p++) { xlo = min(xlo, x[p]); xhi = max(xhi, x[p]); ylo = min(ylo, y[p]); yhi = max(yhi, y[p]); }
-  if (!tile_fits(xhi - xlo + D, yhi - ylo + D, ng)) return -1;
+  // HEAVY = more than two 64-position passes of the matrix-core kernel (which includes every box the staged kernel's tile
+  // cannot hold): the long items start first
+  if ((long long)(xhi - xlo + D) * (yhi - ylo + D) > 128 || !tile_fits(xhi - xlo + D, yhi - ylo + D, ng)) return -1;
   int band = (int)(fminf(fmaxf(centre_y, 0.0f), (float)(H2 - 1))) / 16;
   band = min(max(band, 0), nb - 1);
   const int f = min(max(frame, 0), n2 - 1);

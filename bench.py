@@ -216,6 +216,7 @@ def main():
     t_launch = ev0.elapsed_time(ev1) * 1e-3 / launches                      # s per launch
     b_alg = alg_bytes(cfg, E, 4 if dtype == torch.float32 else 2) / (1.0 if args.fuse_levels else 2.0)   # bytes per launch
     achieved = b_alg / t_launch / 1e9
+    f_alg = 2.0 * cfg["C"] * E * 9 * (2 * R + 2) ** 2 * (2.0 if args.fuse_levels else 1.0)    # flops per launch
 
     # BA alone (2 Gauss-Newton iterations), for the ">= 10x the CPU ba.py solve" target
     tgt = coords[:, :, :, 1, 1] + d["delta"]
@@ -259,6 +260,10 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": lookup_kernel,
+                     # the FMA ceiling beside the HBM figure.  F_alg = 2 * C * E * 9 * D^2 per level; fp32 peak
+                     # 157.3 TFLOP/s (vector FMA and fp32 MFMA alike); t_min = max(B_alg / HBM peak, F_alg / fp32 peak)
+                     "alg_gflop_per_launch": round(f_alg / 1e9, 3), "achieved_tflops": round(f_alg / t_launch / 1e12, 2),
+                     "t_min_us": round(max(b_alg / (HBM_PEAK_GBS * 1e9), f_alg / 157.3e12) * 1e6, 1),
                      "alg_bytes_per_launch": int(b_alg), "us_per_launch": round(t_launch * 1e6, 2)},
         "ba": {"gpu_ms": round(t_ba_gpu * 1e3, 4)},
     }

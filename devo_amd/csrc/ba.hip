@@ -879,7 +879,6 @@ __global__ __launch_bounds__(256) void k_ba_reduce(const float* __restrict__ par
 #define DEVO_SOLVE_THREADS 1024
 #endif
 constexpr int SOLVE_THREADS = DEVO_SOLVE_THREADS;
-constexpr int SOLVE_PRE = 4;            // tiles per thread whose coordinates are kept in registers
 
 __device__ __forceinline__ bool chol6(float L[6][6], float inv[6]) {   // in-register lower Cholesky of a 6x6 block
   bool ok = true;                                                      // inv[c] = 1 / L[c][c]
@@ -905,7 +904,7 @@ __device__ __forceinline__ bool chol6(float L[6][6], float inv[6]) {   // in-reg
 __device__ unsigned long long g_solve_stamps[8];     // debug (DEVO_BA_TRACE): cycle stamps of the last solve
 
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restrict__ S, const float* __restrict__ y, int N,
-                                                            float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag) {
+                                                            float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps) {
   extern __shared__ __attribute__((aligned(16))) float A[];
   __shared__ int s_fail;
   const int n6 = 6 * N, LD = n6 + 1, rows = n6 + 1;
@@ -913,7 +912,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   float* Li = Ld + N * 36;                      // [N][36] their inverses (for the back-substitution)
   float* xs = Li + N * 36;                      // [n6] solution
   const int tid = threadIdx.x;
-  const unsigned long long st0 = __builtin_readcyclecounter();
+  const unsigned long long st0 = stamps ? __builtin_readcyclecounter() : 0ull;      // (s_memtime stalls: debug only)
   if (tid == 0) s_fail = 0;
   {
     // k_ba_reduce wrote this very image (rows x LD, the right-hand side is row n6); eight loads in flight per thread
@@ -934,16 +933,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     while ((yy + 1) * (yy + 2) / 2 <= t) yy++;
     xx = t - yy * (yy + 1) / 2;
   };
-  int pty[SOLVE_PRE], ptx[SOLVE_PRE];
-#pragma unroll
-  for (int k = 0; k < SOLVE_PRE; k++) tile_of(tid + SOLVE_THREADS * k, pty[k], ptx[k]);
+  int ty, tx;                                  // this thread's first tile: the only one it has for N <= 14 at 1024 threads
+  tile_of(tid, ty, tx);
   __syncthreads();
   if (meta->fail) {                              // an earlier iteration broke down: the reference call has thrown by now
     if (tid == 0 && meta->fail < 0 && status_flag) *status_flag = -1;          // (or the workspace was never prepared)
     return;
   }
 
-  const unsigned long long st1 = __builtin_readcyclecounter();
+  const unsigned long long st1 = stamps ? __builtin_readcyclecounter() : 0ull;
   for (int jb = 0; jb < N; jb++) {
     const int j0 = 6 * jb;
     const int r = j0 + 6 + tid;                  // this thread's panel row (if any)
@@ -984,8 +982,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     for (int k = 0; tid + SOLVE_THREADS * k < ntiles; k++) {
       const int t = tid + SOLVE_THREADS * k;
       int yy, xx;
-      if (k < SOLVE_PRE) { yy = (k == 0) ? pty[0] : (k == 1) ? pty[1] : (k == 2) ? pty[2] : pty[3]; xx = (k == 0) ? ptx[0] : (k == 1) ? ptx[1] : (k == 2) ? ptx[2] : ptx[3]; }
-      else tile_of(t, yy, xx);                   // large N only: more tiles than registers kept for them
+      if (k == 0) { yy = ty; xx = tx; }
+      else tile_of(t, yy, xx);                   // large N only: more tiles than threads
       const int r0 = j0 + 6 + 2 * yy, c0 = j0 + 6 + 2 * xx;
       const bool r1ok = r0 + 1 < rows, c1ok = c0 + 1 < n6;          // second row / column inside the matrix
       const int r1 = r1ok ? r0 + 1 : r0, c1 = c1ok ? c0 + 1 : c0;
@@ -1010,7 +1008,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     }
     __syncthreads();
   }
-  const unsigned long long st2 = __builtin_readcyclecounter();
+  const unsigned long long st2 = stamps ? __builtin_readcyclecounter() : 0ull;
   if (s_fail) {
     if (tid == 0) { meta->fail = iter + 1; if (status_flag) *status_flag = iter + 1; }
     return;
@@ -1043,7 +1041,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   // waves are done).  x_b = L_bb^-T z_b from the inverse block, then the lanes update their rows of z.  The solution is
   // collected in LDS (a global store inside the loop would put a vmcnt wait into every step's fence).
   if (tid >= 64) return;
-  const unsigned long long st3 = __builtin_readcyclecounter();
+  const unsigned long long st3 = stamps ? __builtin_readcyclecounter() : 0ull;
   float* z = A + n6 * LD;
   for (int jb = N - 1; jb >= 0; jb--) {
     const int j0 = 6 * jb;
@@ -1068,7 +1066,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     wave_lds_sync();
   }
   for (int i = tid; i < n6; i += 64) dX[i] = xs[i];
-  if (tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st3; g_solve_stamps[4] = __builtin_readcyclecounter(); }
+  if (stamps && tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st3; g_solve_stamps[4] = __builtin_readcyclecounter(); }
 }
 
 // ------------------------------------------------------------------------------------------------- retract
@@ -1414,8 +1412,8 @@ int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsi
     if (N > 0) {
       hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((n6 * n6 + n6 + 63) / 64)), dim3(256), 0, st, partials, L.n_part, N, S, y);
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
-      hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag);
       static const bool ba_trace = getenv("DEVO_BA_TRACE") != nullptr;
+      hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace ? 1 : 0);
       if (ba_trace) {
         unsigned long long h[8];
         (void)hipStreamSynchronize(st);

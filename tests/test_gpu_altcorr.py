@@ -353,3 +353,25 @@ def test_staged_kernel_stays_covered():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", sel],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("R,spread,scales", [(1, 1.0, (1, 4)), (5, 1.0, (1, 4)), (3, 3.5, (1, 4)), (3, 9.0, (1, 4)),
+                                              (3, 1.0, (1.0, 3.0)), (2, 2.0, (2.0, 8.0))])
+def test_fused_pyramid_radii_spreads_and_scales(R, spread, scales):
+    """the wave that does both levels of an edge (fp32, C = 128): other radii (raw-window and box layouts of the result
+    area), boxes of 3+ passes and window-by-window passes (spread patches), and level scales that are not powers of two
+    (true division instead of the exact reciprocal) — bit-identical to one launch per level, within 1e-4 of the oracle"""
+    from devo_amd.backends import cuda_corr
+    f1, f2, coords, ii, jj, _ = _case(H=32, W=48, E=257, R=R, seed=100 + R, spread=spread)
+    f2b = torch.nn.functional.avg_pool2d(f2[0], 4, 4)[None]
+    pyr = [channels_last5(f2.to(DEV)), channels_last5(f2b.to(DEV))]
+    args = (coords.to(DEV), ii.to(DEV), jj.to(DEV))
+    Dm = 2 * R + 1
+    per = torch.empty(1, len(ii), 2 * Dm * Dm * 9, device=DEV)
+    for lvl, s in enumerate(scales):
+        cuda_corr.forward_into(per, f1.to(DEV), pyr[lvl], *args, R, 2 * Dm * Dm * 9, 2, lvl, coord_div=float(s))
+    fused = cuda_corr.forward_pyramid(f1.to(DEV), pyr, *args, R, scales)
+    assert torch.equal(fused, per)
+    div = lambda s: coords / torch.tensor(float(s))                   # true division (a python scalar would multiply)
+    ref = torch.stack([A.corr_forward(f1, f2, div(scales[0]), ii, jj, R), A.corr_forward(f1, f2b, div(scales[1]), ii, jj, R)], -1)
+    assert_rel(fused, ref.view(1, len(ii), -1), 1e-4, f"fused R={R} spread={spread} scales={scales}")

@@ -229,7 +229,7 @@ def main():
     t_ba_gpu = ev0.elapsed_time(ev1) * 1e-3 / 20
 
     # which lookup kernel the library picks for this configuration (devo_amd/csrc/corr.hip: launch_staged)
-    mfma = dtype == torch.float32 and cfg["C"] == 128 and os.environ.get("DEVO_CORR_MFMA", "1")[:1] != "0"
+    mfma = cfg["C"] == 128 and os.environ.get("DEVO_CORR_MFMA", "1")[:1] != "0"          # fp32 and fp16 storage
     lookup_kernel = "corr_fwd_generic_kernel" if args.layout == "nchw" else ("corr_fwd_mfma_kernel" if mfma else "corr_fwd_cl_kernel")
     traffic, traffic_src = None, None
     try:

@@ -754,7 +754,9 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
                        (f2s[1] % v == 0) && (!blocked || f2s[2] % v == 0) && ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) &&
                        f2s[3] >= 0 && f2s[4] >= 0 && (!blocked || (f2s[2] >= 0 && C % cb == 0));
   lv->staged_ok = aligned && (C % KC == 0) && (!blocked || cblock == KC) && plane_bytes < (1LL << 31);   // 32-bit in-plane offsets
-  lv->mfma_ok = aligned && std::is_same<T, float>::value && corr_mfma_enabled() && (C == 128) && (!blocked || cb == 4 || cb == 8 || cb == 16) &&
+  // the matrix-core kernel: C = 128, 16-byte pieces inside a channel block, piece offsets linear in the step
+  const bool cb_ok = !blocked || (sizeof(T) == 4 ? (cb == 4 || cb == 8 || cb == 16) : (cb == 8 || cb == 16 || cb == 32));
+  lv->mfma_ok = aligned && sizeof(T) <= 4 && corr_mfma_enabled() && (C == 128) && cb_ok &&
                 frame_bytes < (1LL << 31);                                                             // 32-bit in-frame offsets
   if (!lv->staged_ok && !lv->mfma_ok) {
     if (blocked) {
@@ -786,15 +788,17 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
   const size_t nrec = (size_t)BE * nlev;
   if (do_trace) { (void)hipMalloc(&trace, nrec * 64); (void)hipMemset(trace, 0, nrec * 64); }
   const bool mfma = lv0.mfma_ok && (nlev == 1 || lv1.mfma_ok);
-  if (std::is_same<T, float>::value && mfma) {                        // matrix-core kernel (corr_mfma.h)
+  if (mfma) {                                                         // matrix-core kernel (corr_mfma.h)
     static const char* split_env = getenv("DEVO_CORR_SPLIT_LEVELS");  // debug: fused lookups as two sets of workgroups
     const bool both = nlev == 2 && !(split_env && split_env[0] == '1') && !do_trace;
-    typedef void (*mfma_fn_t)(const float*, CorrLevel, CorrLevel, int, const float*, const int64_t*, const int64_t*, float*, int, int,
+    typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;   // (never fp64: mfma_ok is false)
+    typedef void (*mfma_fn_t)(const MT*, CorrLevel, CorrLevel, int, const float*, const int64_t*, const int64_t*, MT*, int, int,
                               int, int, int, int64_t, int64_t, int, const int*, unsigned long long*);
-    const mfma_fn_t fn = both ? (R <= 3 ? corr_fwd_mfma_kernel<3, 8, 2> : corr_fwd_mfma_kernel<5, 8, 2>)
-                              : (R <= 3 ? corr_fwd_mfma_kernel<3, 8, 1> : corr_fwd_mfma_kernel<5, 8, 1>);
+    constexpr int NGR = sizeof(MT) == 2 ? 4 : 8;                       // C = 128: steps of 32 / 16 channels
+    const mfma_fn_t fn = both ? (R <= 3 ? corr_fwd_mfma_kernel<MT, 3, NGR, 2> : corr_fwd_mfma_kernel<MT, 5, NGR, 2>)
+                              : (R <= 3 ? corr_fwd_mfma_kernel<MT, 3, NGR, 1> : corr_fwd_mfma_kernel<MT, 5, NGR, 1>);
     const dim3 mgrid(both ? (unsigned)BE : per_level * nlev), mblock(64);
-    hipLaunchKernelGGL(fn, mgrid, mblock, 0, st, (const float*)fmap1, lv0, lv1, nlev, coords, ii, jj, (float*)out, (int)BE, E, Np, n2,
+    hipLaunchKernelGGL(fn, mgrid, mblock, 0, st, (const MT*)fmap1, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2,
                        C, oes, ols, R, order, trace);
   } else
   if (!(lv0.staged_ok && (nlev == 1 || lv1.staged_ok))) {

@@ -1,4 +1,4 @@
-// altcorr lookup on the matrix cores, fp32, C = 128 (included by corr.hip inside namespace devo).
+// altcorr lookup on the matrix cores, fp32 or fp16 storage, C = 128 (included by corr.hip inside namespace devo).
 //
 // ONE WAVE PER EDGE, POSITION-centric: lane l owns one pixel of the union bounding box of the 9 patch pixels'
 // (2r+2)^2 windows (64 positions per pass; a 10x10 box takes two passes) and reads that pixel's channels STRAIGHT
@@ -31,6 +31,9 @@
 #endif
 typedef float mfma_acc4 __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+typedef _Float16 mfma_h4 __attribute__((ext_vector_type(4)));
+// fp16 storage: v_mfma_f32_4x4x4_16b_f16 takes 4 channels per instruction (exact fp16 products, fp32 accumulation): a step is
+// 32 channels = the same four 16-byte fetches per lane, 8 MFMAs per pixel group instead of 16, the patch is 12 registers.
 
 // Plan -> edge slot of workgroup `gid` of `nitems` (see corr_fwd_cl_kernel: heavy edges first, the rest XCD-aware)
 __device__ __forceinline__ int corr_plan_slot(const int* __restrict__ order, int BE, int gid, int nitems) {
@@ -44,15 +47,19 @@ __device__ __forceinline__ int corr_plan_slot(const int* __restrict__ order, int
   return start + (gid >> 3) - heavy_on(xcd);
 }
 
+#define DEVO_MFMA_STEP_H(U, BV)                                                       \
+  acc0 = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, (BV), acc0, 4, (U), 0);              \
+  acc1 = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, (BV), acc1, 4, (U), 0);              \
+  acc2 = __builtin_amdgcn_mfma_f32_4x4x4f16(a2, (BV), acc2, 4, (U), 0)
 #define DEVO_MFMA_STEP(U, BV)                                                         \
   acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, (BV), acc0, 4, (U), 0);              \
   acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, (BV), acc1, 4, (U), 0);              \
   acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, (BV), acc2, 4, (U), 0)
 
-template <int RMAX, int NGR, int NL>       // NGR = C / 16 steps per pass (a multiple of the ring); NL = levels per wave
+template <typename T, int RMAX, int NGR, int NL>   // NGR = C / (16 | 32) steps per pass (a multiple of the ring); NL = levels per wave
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WAVES, DEVO_MFMA_WAVES))) void corr_fwd_mfma_kernel(
-    const float* __restrict__ fmap1, CorrLevel lv0, CorrLevel lv1, int nlev, const float* __restrict__ coords,
-    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, float* __restrict__ out, int BE, int E, int Np, int n2,
+    const T* __restrict__ fmap1, CorrLevel lv0, CorrLevel lv1, int nlev, const float* __restrict__ coords,
+    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int64_t out_estride, int64_t out_lstride, int R, const int* __restrict__ order,
     unsigned long long* __restrict__ trace) {
   // NL == 1 with nlev == 2: the levels alternate in groups of 8 workgroups (see corr_fwd_cl_kernel); NL == 2: one
@@ -60,6 +67,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   const int wlvl = (NL == 1 && nlev == 2) ? ((blockIdx.x >> 3) & 1) : 0;                      // wave-uniform
   const int gid = (NL == 1 && nlev == 2) ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : blockIdx.x;
   const int nitems = (NL == 1 && nlev == 2) ? (gridDim.x >> 1) : gridDim.x;
+  constexpr bool HALF = sizeof(T) == 2;
+  constexpr int STEPCH = HALF ? 32 : 16;             // channels per step (four 16-byte pieces of a position)
+  constexpr unsigned ESZ = sizeof(T);
   auto second = [&](int l) -> bool { return NL == 2 ? (l != 0) : (wlvl != 0); };   // does index l mean pyramid level 1?
 #define LVF(l, F) (second(l) ? lv1.F : lv0.F)
   constexpr int DMAX = 2 * RMAX + 2;
@@ -171,24 +181,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   // how lanes beyond the box, positions outside the image and the fetches that run ahead past the last step are switched off
   // without a branch (a fetch behind a branch makes the compiler wait for ALL outstanding loads at the join).
   auto frame_rsrc = [&](int l) -> __amdgpu_buffer_rsrc_t {
-    const float* base = static_cast<const float*>(LVF(l, fmap2)) + (int64_t)b * LVF(l, s_b) + fj * LVF(l, s_n);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, LVF(l, frame_bytes), 0x00020000);
+    const T* base = static_cast<const T*>(LVF(l, fmap2)) + (int64_t)b * LVF(l, s_b) + fj * LVF(l, s_n);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, LVF(l, frame_bytes), 0x00020000);
   };
-  const float* __restrict__ f1 = fmap1 + ((int64_t)b * Np + pi) * C * PP;           // [C][9]
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f1), 0, (unsigned)(C * PP) * 4u, 0x00020000);
+  const T* __restrict__ f1 = fmap1 + ((int64_t)b * Np + pi) * C * PP;           // [C][9]
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f1), 0, (unsigned)(C * PP) * ESZ, 0x00020000);
   constexpr unsigned OFF_NONE = 0x80000000u;               // > any frame (the launcher guarantees < 2^31 bytes)
 
   // A operand: lane (u, i) = (lane >> 2, lane & 3) holds f1[k0 + u][4g + i] (pixel 8 repeated in the unused rows of group 2).
   // The whole patch (NGR steps x 3 registers) stays in registers for all passes (and both levels) of the edge.
   const int au = lane >> 2, ai = lane & 3;
   const unsigned aoff0 = (unsigned)(au * PP + ai) * 4u, aoff1 = aoff0 + 16u, aoff2 = (unsigned)(au * PP + 8) * 4u;
-  float pa[NGR][3];
+  float pa[HALF ? 1 : NGR][3];                 // fp32: lane (u, i) <- f1[16 g + u][4 grp + i]
+  mfma_h4 ph[HALF ? NGR / 2 : 1][3];            // fp16: lane (u, i) <- f1[64 h + 4 u .. + 3][4 grp + i] (four channels per MFMA)
+  if constexpr (!HALF) {
 #pragma unroll
-  for (int g = 0; g < NGR; g++) {
-    const unsigned ka = (unsigned)g * (16u * PP * 4u);        // in the scalar offset operand: no vector adds
-    pa[g][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, aoff0, ka, 0));
-    pa[g][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, aoff1, ka, 0));
-    pa[g][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, aoff2, ka, 0));
+    for (int g = 0; g < NGR; g++) {
+      const unsigned ka = (unsigned)g * (16u * PP * 4u);        // in the scalar offset operand: no vector adds
+      pa[g][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, aoff0, ka, 0));
+      pa[g][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, aoff1, ka, 0));
+      pa[g][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, aoff2, ka, 0));
+    }
+  } else {
+    const unsigned hpix[3] = {(unsigned)ai, (unsigned)(4 + ai), 8u};
+#pragma unroll
+    for (int h = 0; h < NGR / 2; h++)
+#pragma unroll
+      for (int grp = 0; grp < 3; grp++) {
+        unsigned short r4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          r4[r] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs1, (unsigned)((4 * au + r) * PP + hpix[grp]) * 2u, (unsigned)h * (64u * PP * 2u), 0);
+        __builtin_memcpy(&ph[h][grp], r4, sizeof(r4));
+      }
   }
   __builtin_amdgcn_sched_barrier(0);        // patch loads first: the loop's s_waitcnt counts assume they are the oldest
 
@@ -212,7 +237,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
     }
     q.listed = s < G.nslots && sg < nseg;
     q.inside = q.gy >= 0 && q.gy < LVF(l, H2) && q.gx >= 0 && q.gx < LVF(l, W2);
-    q.off = (q.listed && q.inside) ? (unsigned)(q.gy * (int)LVF(l, s_h) + q.gx * (int)LVF(l, s_w)) * (unsigned)sizeof(float) : OFF_NONE;
+    q.off = (q.listed && q.inside) ? (unsigned)(q.gy * (int)LVF(l, s_h) + q.gx * (int)LVF(l, s_w)) * ESZ : OFF_NONE;
     return q;
   };
 
@@ -227,12 +252,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   float4 rb[RING][4];
   // Byte offset of piece q of step g = g * G16 + d[q]: linear in g for the layouts the launcher lets through (channel
   // blocks of 4, 8 or 16 channels, or channels-last), so a step costs 4 scalar adds besides its 4 loads.
-  struct Pieces { unsigned g16, d1, d2, d3; };
+  struct Pieces { unsigned g16, d1, d2, d3; };       // byte offsets: one step further / pieces 1..3 of a step
   auto pieces_of = [&](int l) -> Pieces {
     const int sh = LVF(l, cb_shift);
-    const unsigned bb = (unsigned)LVF(l, block_stride) * 4u;
-    auto piece = [&](unsigned c) -> unsigned { const unsigned blk = c >> sh; return blk * bb + (c - (blk << sh)) * 4u; };
-    return Pieces{piece(16u), piece(4u), piece(8u), piece(12u)};
+    const unsigned bb = (unsigned)LVF(l, block_stride) * ESZ;
+    constexpr unsigned PCH = 16 / ESZ;                            // channels per 16-byte piece (4 | 8)
+    auto piece = [&](unsigned c) -> unsigned { const unsigned blk = c >> sh; return blk * bb + (c - (blk << sh)) * ESZ; };
+    return Pieces{piece(4 * PCH), piece(PCH), piece(2 * PCH), piece(3 * PCH)};
   };
   auto fetch = [&](int ring, int g, unsigned off, __amdgpu_buffer_rsrc_t rs, const Pieces& pc) {
     // lane offset in the vector operand (the range check looks at it alone), piece offset in the scalar one: no vector add
@@ -261,12 +287,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
       else fetch((g + RING - 1) % RING, g + RING - 1 - NGR, nxt.off, rsn, pcn);
       __builtin_amdgcn_sched_barrier(0);
       {
-        const float a0 = pa[g][0], a1 = pa[g][1], a2 = pa[g][2];
         const float4 b0 = rb[g % RING][0], b1 = rb[g % RING][1], b2 = rb[g % RING][2], b3 = rb[g % RING][3];
-        DEVO_MFMA_STEP(0, b0.x);  DEVO_MFMA_STEP(1, b0.y);  DEVO_MFMA_STEP(2, b0.z);  DEVO_MFMA_STEP(3, b0.w);
-        DEVO_MFMA_STEP(4, b1.x);  DEVO_MFMA_STEP(5, b1.y);  DEVO_MFMA_STEP(6, b1.z);  DEVO_MFMA_STEP(7, b1.w);
-        DEVO_MFMA_STEP(8, b2.x);  DEVO_MFMA_STEP(9, b2.y);  DEVO_MFMA_STEP(10, b2.z); DEVO_MFMA_STEP(11, b2.w);
-        DEVO_MFMA_STEP(12, b3.x); DEVO_MFMA_STEP(13, b3.y); DEVO_MFMA_STEP(14, b3.z); DEVO_MFMA_STEP(15, b3.w);
+        if constexpr (!HALF) {
+          const float a0 = pa[g][0], a1 = pa[g][1], a2 = pa[g][2];
+          DEVO_MFMA_STEP(0, b0.x);  DEVO_MFMA_STEP(1, b0.y);  DEVO_MFMA_STEP(2, b0.z);  DEVO_MFMA_STEP(3, b0.w);
+          DEVO_MFMA_STEP(4, b1.x);  DEVO_MFMA_STEP(5, b1.y);  DEVO_MFMA_STEP(6, b1.z);  DEVO_MFMA_STEP(7, b1.w);
+          DEVO_MFMA_STEP(8, b2.x);  DEVO_MFMA_STEP(9, b2.y);  DEVO_MFMA_STEP(10, b2.z); DEVO_MFMA_STEP(11, b2.w);
+          DEVO_MFMA_STEP(12, b3.x); DEVO_MFMA_STEP(13, b3.y); DEVO_MFMA_STEP(14, b3.z); DEVO_MFMA_STEP(15, b3.w);
+        } else {
+          // channels 32 g + 4 q .. + 3 = block (8 (g & 1) + q) of patch register pair g / 2; B = the q-th 8 bytes of the step
+          const mfma_h4 a0 = ph[g >> 1][0], a1 = ph[g >> 1][1], a2 = ph[g >> 1][2];
+          mfma_h4 bq[8];
+          __builtin_memcpy(&bq[0], &b0, 16); __builtin_memcpy(&bq[2], &b1, 16); __builtin_memcpy(&bq[4], &b2, 16); __builtin_memcpy(&bq[6], &b3, 16);
+          if ((g & 1) == 0) {                    // (abid must be a literal: the unrolled loop folds this branch)
+            DEVO_MFMA_STEP_H(0, bq[0]); DEVO_MFMA_STEP_H(1, bq[1]); DEVO_MFMA_STEP_H(2, bq[2]); DEVO_MFMA_STEP_H(3, bq[3]);
+            DEVO_MFMA_STEP_H(4, bq[4]); DEVO_MFMA_STEP_H(5, bq[5]); DEVO_MFMA_STEP_H(6, bq[6]); DEVO_MFMA_STEP_H(7, bq[7]);
+          } else {
+            DEVO_MFMA_STEP_H(8, bq[0]); DEVO_MFMA_STEP_H(9, bq[1]); DEVO_MFMA_STEP_H(10, bq[2]); DEVO_MFMA_STEP_H(11, bq[3]);
+            DEVO_MFMA_STEP_H(12, bq[4]); DEVO_MFMA_STEP_H(13, bq[5]); DEVO_MFMA_STEP_H(14, bq[6]); DEVO_MFMA_STEP_H(15, bq[7]);
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -323,7 +363,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
     int cx = 0, a = q;
     while (a >= Dm) { a -= Dm; cx += 1; }           // (grp < 7: only windows smaller than 7 x 7 take a turn)
     const float* rw = s_rawwin + l * RW_FLOATS + base;
-    float* op = out + (int64_t)be * out_estride + (int64_t)(q * PP + p) * out_lstride + LVF(l, out_offset);
+    T* op = out + (int64_t)be * out_estride + (int64_t)(q * PP + p) * out_lstride + LVF(l, out_offset);
     const int64_t ostep = (int64_t)(GRPS * PP) * out_lstride;
     for (int q0 = 0; q0 < nq; q0 += GRPS) {
       if (active && q < nq) {
@@ -333,7 +373,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
 #pragma clang fp contract(off)
           o = w00 * r[0]; o = o + w01 * r[1]; o = o + w10 * r[rstride]; o = o + w11 * r[rstride + 1];
         }
-        store_streamed(op, o);
+        store_streamed(op, from_f32<T>(o));
       }
       op += ostep;
       q += GRPS; a += GRPS;
@@ -351,3 +391,4 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
 #undef LVF
 }
 #undef DEVO_MFMA_STEP
+#undef DEVO_MFMA_STEP_H

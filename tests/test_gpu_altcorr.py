@@ -81,6 +81,9 @@ def test_channel_blocked_layout_is_bit_identical_and_checked():
         for cb in (4, 16):
             out, = cuda_corr.forward(c[0].to(DEV), altcorr.channel_blocked(c[1].to(DEV), cb), c[2].to(DEV), c[3].to(DEV), c[4].to(DEV), c[5])
             assert torch.equal(out, _run(*c, layout="cl")), cb
+        for cb in (16, 32):                                           # fp16 storage: blocks of 8, 16 or 32 channels
+            out, = cuda_corr.forward(h(c[0]), altcorr.channel_blocked(h(c[1]), cb), c[2].to(DEV), c[3].to(DEV), c[4].to(DEV), c[5])
+            assert torch.equal(out, _run(*c, layout="cl", dtype=torch.float16)), cb
     else:
         with pytest.raises(RuntimeError):
             cuda_corr.forward(f1.to(DEV), altcorr.channel_blocked(f2.to(DEV), 4), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
@@ -375,3 +378,25 @@ def test_fused_pyramid_radii_spreads_and_scales(R, spread, scales):
     div = lambda s: coords / torch.tensor(float(s))                   # true division (a python scalar would multiply)
     ref = torch.stack([A.corr_forward(f1, f2, div(scales[0]), ii, jj, R), A.corr_forward(f1, f2b, div(scales[1]), ii, jj, R)], -1)
     assert_rel(fused, ref.view(1, len(ii), -1), 1e-4, f"fused R={R} spread={spread} scales={scales}")
+
+
+def test_fused_pyramid_fp16_storage():
+    """fp16 features on the matrix cores (4 channels per MFMA, exact products, fp32 accumulation): the two-level wave equals
+    the per-level launches bit for bit and the fp32 oracle within the fp16-storage tolerance (2e-3)"""
+    from devo_amd import altcorr
+    from devo_amd.backends import cuda_corr
+    for R, spread, lay in ((3, 1.0, "cl"), (3, 3.5, "blk8"), (5, 1.0, "blk8"), (3, 9.0, "cl")):
+        f1, f2, coords, ii, jj, _ = _case(H=32, W=48, E=257, R=R, seed=200 + R, spread=spread)
+        f2b = torch.nn.functional.avg_pool2d(f2[0], 4, 4)[None]
+        conv = (lambda t: channels_last5(t)) if lay == "cl" else (lambda t: altcorr.channel_blocked(t, 8))
+        pyr = [conv(f2.to(DEV).half()), conv(f2b.to(DEV).half())]
+        args = (coords.to(DEV), ii.to(DEV), jj.to(DEV))
+        Dm = 2 * R + 1
+        per = torch.empty(1, len(ii), 2 * Dm * Dm * 9, device=DEV, dtype=torch.float16)
+        for lvl, s_ in enumerate((1, 4)):
+            cuda_corr.forward_into(per, f1.to(DEV).half(), pyr[lvl], *args, R, 2 * Dm * Dm * 9, 2, lvl, coord_div=float(s_))
+        fused = cuda_corr.forward_pyramid(f1.to(DEV).half(), pyr, *args, R, (1, 4))
+        assert torch.equal(fused, per)
+        ref = torch.stack([A.corr_forward(f1.half().float(), f2.half().float(), coords, ii, jj, R),
+                           A.corr_forward(f1.half().float(), f2b.half().float(), coords / 4, ii, jj, R)], -1)
+        assert_rel(fused.float(), ref.view(1, len(ii), -1), 2e-3, f"fused fp16 R={R} spread={spread} {lay}")

@@ -756,7 +756,8 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
   lv->staged_ok = aligned && (C % KC == 0) && (!blocked || cblock == KC) && plane_bytes < (1LL << 31);   // 32-bit in-plane offsets
   // the matrix-core kernel: C = 128, 16-byte pieces inside a channel block, piece offsets linear in the step
   const bool cb_ok = !blocked || (sizeof(T) == 4 ? (cb == 4 || cb == 8 || cb == 16) : (cb == 8 || cb == 16 || cb == 32));
-  lv->mfma_ok = aligned && sizeof(T) <= 4 && corr_mfma_enabled() && (C == 128) && cb_ok &&
+  const bool c_ok = sizeof(T) == 4 ? (C == 64 || C == 128) : (C == 128 || C == 256);            // 4 or 8 steps per pass
+  lv->mfma_ok = aligned && sizeof(T) <= 4 && corr_mfma_enabled() && c_ok && cb_ok &&
                 frame_bytes < (1LL << 31);                                                             // 32-bit in-frame offsets
   if (!lv->staged_ok && !lv->mfma_ok) {
     if (blocked) {
@@ -794,15 +795,20 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
     typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;   // (never fp64: mfma_ok is false)
     typedef void (*mfma_fn_t)(const MT*, CorrLevel, CorrLevel, int, const float*, const int64_t*, const int64_t*, MT*, int, int,
                               int, int, int, int64_t, int64_t, int, const int*, unsigned long long*);
-    constexpr int NGR = sizeof(MT) == 2 ? 4 : 8;                       // C = 128: steps of 32 / 16 channels
-    const mfma_fn_t fn = both ? (R <= 3 ? corr_fwd_mfma_kernel<MT, 3, NGR, 2> : corr_fwd_mfma_kernel<MT, 5, NGR, 2>)
-                              : (R <= 3 ? corr_fwd_mfma_kernel<MT, 3, NGR, 1> : corr_fwd_mfma_kernel<MT, 5, NGR, 1>);
+    // steps of 16 (fp32) / 32 (fp16) channels per pass, 4 or 8 of them (16 would not fit the patch into the registers):
+    // C = 64 / 128 (fp32), 128 / 256 (fp16)
+    constexpr int SC = sizeof(MT) == 2 ? 32 : 16;
+    const int ngr = C / SC;
+#define DEVO_MFMA_PICK(NGR) (both ? (R <= 3 ? corr_fwd_mfma_kernel<MT, 3, NGR, 2> : corr_fwd_mfma_kernel<MT, 5, NGR, 2>) \
+                                  : (R <= 3 ? corr_fwd_mfma_kernel<MT, 3, NGR, 1> : corr_fwd_mfma_kernel<MT, 5, NGR, 1>))
+    const mfma_fn_t fn = ngr == 4 ? DEVO_MFMA_PICK(4) : DEVO_MFMA_PICK(8);
+#undef DEVO_MFMA_PICK
     const dim3 mgrid(both ? (unsigned)BE : per_level * nlev), mblock(64);
     hipLaunchKernelGGL(fn, mgrid, mblock, 0, st, (const MT*)fmap1, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2,
                        C, oes, ols, R, order, trace);
   } else
   if (!(lv0.staged_ok && (nlev == 1 || lv1.staged_ok))) {
-    set_error("devo_corr_forward: this channel-blocked layout is only readable by the matrix-core kernel (fp32, C == 128)");
+    set_error("devo_corr_forward: this channel-blocked layout is only readable by the matrix-core kernel (fp32: C = 64 / 128, fp16: C = 128 / 256)");
     if (trace) (void)hipFree(trace);
     return DEVO_ERR_UNSUPPORTED;
   } else if (R <= 3 && !force4)   // (the <3,5> instantiation has room for every supported radius)

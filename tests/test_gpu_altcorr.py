@@ -400,3 +400,21 @@ def test_fused_pyramid_fp16_storage():
         ref = torch.stack([A.corr_forward(f1.half().float(), f2.half().float(), coords, ii, jj, R),
                            A.corr_forward(f1.half().float(), f2b.half().float(), coords / 4, ii, jj, R)], -1)
         assert_rel(fused.float(), ref.view(1, len(ii), -1), 2e-3, f"fused fp16 R={R} spread={spread} {lay}")
+
+
+@pytest.mark.parametrize("C,dtype", [(64, torch.float32), (256, torch.float16)])
+def test_matrix_core_kernel_other_channel_counts(C, dtype):
+    """4 steps per pass (fp32 C = 64) and 8 (fp16 C = 256) of the matrix-core kernel, per level and fused"""
+    from devo_amd import altcorr
+    from devo_amd.backends import cuda_corr
+    f1, f2, coords, ii, jj, R = _case(C=C, H=32, W=48, E=150, seed=300 + C, spread=1.5)
+    tol = 1e-4 if dtype == torch.float32 else 2e-3
+    q = (lambda t: t) if dtype == torch.float32 else (lambda t: t.half().float())
+    ref0 = A.corr_forward(q(f1), q(f2), coords, ii, jj, R)
+    for lay in ("cl", "blk8"):
+        assert_rel(_run(f1, f2, coords, ii, jj, R, layout=lay, dtype=dtype).float(), ref0, tol, f"C={C} {lay}")
+    f2b = torch.nn.functional.avg_pool2d(f2[0], 4, 4)[None]
+    pyr = [altcorr.channel_blocked(f2.to(DEV, dtype), 8), altcorr.channel_blocked(f2b.to(DEV, dtype), 8)]
+    fused = cuda_corr.forward_pyramid(f1.to(DEV, dtype), pyr, coords.to(DEV), ii.to(DEV), jj.to(DEV), R, (1, 4))
+    ref = torch.stack([ref0, A.corr_forward(q(f1), q(f2b), coords / 4, ii, jj, R)], -1)
+    assert_rel(fused.float(), ref.view(1, len(ii), -1), tol, f"fused C={C}")

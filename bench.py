@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--overlap-prepare", action="store_true",
                     help="run the BA index preparation (cuda_ba.prepare) on a side stream under the lookup instead of inside "
                          "cuda_ba.forward (measured slower on MI355X: the fork/join costs more than the 26 us it hides)")
+    ap.add_argument("--separate-index-kernels", action="store_true",
+                    help="the lookup plan's ordering kernel and the BA's index preparation as two launches (inside their own calls) "
+                         "instead of one launch with two workgroups (cuda_ba.prepare(..., plan=...))")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=50, help="launch pairs timed for the roofline figure")
@@ -149,12 +152,17 @@ def main():
         # reprojection; the kernel also emits the lookup's plan bins while it holds the coordinates
         coords, order = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp",
                                           plan_for=(n, cfg["H"], R))
-        lookup(coords, order=cuda_corr.plan_finish(order, d["jj"], n, cfg["H"], R))
+        if args.separate_index_kernels or prep_stream is not None:
+            order = cuda_corr.plan_finish(order, d["jj"], n, cfg["H"], R)
+        else:
+            # the plan's ordering step and the BA's index preparation (both single-workgroup, independent) in ONE launch
+            cuda_ba.prepare(d["kk"], Np, n - 1, ws, plan=(order, n, cfg["H"]))
+        lookup(coords, order=order)
         target = coords[:, :, :, 1, 1] + d["delta"]                        # devo.py:330
         if prep_stream is not None:
             cur.wait_stream(prep_stream)
         cuda_ba.forward(d["poses"], d["patches"], d["intr"], target, d["weight"], d["lmbda"],
-                        d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws, prepared=prep_stream is not None)
+                        d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws, prepared=(prep_stream is not None) or not args.separate_index_kernels)
 
     # ---- warm up eagerly once (library load, kernel code upload), then capture
     step()

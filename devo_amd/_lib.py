@@ -31,6 +31,7 @@ _SIGNATURES = {
     "devo_ba_workspace_bytes": [_i, _i, _i],
     "devo_ba_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
     "devo_ba_prepare": [_vp, _i, _i, _i, _vp, _sz, _vp],
+    "devo_ba_prepare_plan": [_vp, _i, _i, _i, _vp, _sz, _vp, _i, _i, _vp],
     "devo_ba_prepared_tables": [_vp, _sz, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "devo_ba_forward_prepared": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
     "devo_neighbors_workspace_bytes": [_i],

@@ -16,13 +16,23 @@ def workspace(E, Np, N, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
-def prepare(kk, n_patch_slots, n_opt, ws):
+def prepare(kk, n_patch_slots, n_opt, ws, plan=None):
     """Index half of cuda_ba.forward (ba_cuda.cu:435-437: unique patches, edges grouped by patch), which depends on
     `kk` only: call it early — e.g. on a side stream while the correlation lookup runs — and pass `prepared=True` to
-    forward().  `n_patch_slots` = patches.shape[1], `n_opt` = t1 - t0; `ws` from workspace()."""
+    forward().  `n_patch_slots` = patches.shape[1], `n_opt` = t1 - t0; `ws` from workspace().
+    plan=(buffer, n_frames, height): the half-built locality plan of transform(..., plan_for=...) is finished in the same
+    launch (two independent single-workgroup kernels side by side); the buffer is then what cuda_corr.plan_finish returns."""
     L.require_gpu(kk, ws)
     kk = kk.long().contiguous()
-    rc = L.lib().devo_ba_prepare(L.ptr(kk), kk.numel(), int(n_patch_slots), int(n_opt), L.ptr(ws), ws.numel(), L.stream())
+    if plan is None:
+        rc = L.lib().devo_ba_prepare(L.ptr(kk), kk.numel(), int(n_patch_slots), int(n_opt), L.ptr(ws), ws.numel(), L.stream())
+    else:
+        buf, n_frames, height = plan
+        L.require_gpu(buf)
+        if buf.dtype != torch.int32 or buf.numel() < 2 * kk.numel() + 1:
+            raise RuntimeError("cuda_ba.prepare: plan must be the int32 [2E+1] buffer of transform(..., plan_for=...)")
+        rc = L.lib().devo_ba_prepare_plan(L.ptr(kk), kk.numel(), int(n_patch_slots), int(n_opt), L.ptr(ws), ws.numel(),
+                                          L.ptr(buf), int(n_frames), int(height), L.stream())
     L.check(rc, "cuda_ba.prepare")
     return ws
 

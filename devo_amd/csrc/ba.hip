@@ -19,6 +19,7 @@
 #include <cstddef>
 #include "se3_dev.h"
 #include "corr_tile.h"
+#include "corr_plan.h"
 #include <stdlib.h>
 
 namespace devo {
@@ -141,9 +142,9 @@ __global__ void k_sort_segments(const int* __restrict__ seg_start, BaMeta* __res
 constexpr int PREP_FLAGS_LDS = 16384;
 constexpr int PREP_SEGS_LDS = 8192;
 template <int CACHE>      // CACHE = 0: kk is re-read by every pass; else ceil(E / 1024) <= CACHE edges per thread in registers
-__global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
-                                                     int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
-                                                     int* perm_b) {
+__device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
+                                                int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
+                                                int* perm_b) {
   extern __shared__ int s_mem[];
   int* s_part = s_mem;                       // 1024
   int* s_flags = s_part + 1024;              // PREP_FLAGS_LDS + 1
@@ -311,6 +312,28 @@ __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__
   }
   // publish the segment starts: entries beyond n_seg = E so that any reader sees empty tails
   for (int i = t; i <= max_seg; i += 1024) g_counts[i] = (i <= n_seg) ? counts[i] : E;
+}
+
+template <int CACHE>
+__global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
+                                                     int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
+                                                     int* perm_b) {
+  ba_prepare_body<CACHE>(kk, E, Np, max_seg, meta, g_rank, g_counts, g_cursor, ku, kx, perm_a, perm_b);
+}
+
+template <int CACHE>
+__global__ __launch_bounds__(ORDER_THREADS) void k_order_only(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order) {
+  corr_order_body<CACHE>(bins, BE, nbins, order);
+}
+
+// Workgroup 0: the BA's index preparation; workgroup 1: the ordering step of the lookup's locality plan (corr_plan.h).
+// Two single-workgroup, latency-bound kernels that do not depend on each other run side by side in one launch.
+template <int CACHE>
+__global__ __launch_bounds__(1024) void k_prepare_and_order(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
+                                                            int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
+                                                            int* perm_b, const int* __restrict__ bins, int nbins, int* __restrict__ order) {
+  if (blockIdx.x == 0) ba_prepare_body<CACHE>(kk, E, Np, max_seg, meta, g_rank, g_counts, g_cursor, ku, kx, perm_a, perm_b);
+  else corr_order_body<CACHE>(bins, E, nbins, order);
 }
 
 // ------------------------------------------------------------------------------------------------- per-edge maths
@@ -1275,7 +1298,10 @@ size_t devo_ba_workspace_bytes(int E, int Np, int N) {
 }
 
 // ---- graph preparation: kx = unique(kk) sorted, ku = inverse (ba_cuda.cu:435-437), edges grouped by patch
-static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, size_t ws_bytes, hipStream_t st) {
+// plan != NULL: also finish the lookup's locality plan (bins at plan + E + 1, see devo_transform) — in the same launch when
+// the single-workgroup path is taken, else with the plan's own kernel
+static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, size_t ws_bytes, hipStream_t st,
+                           int* plan = nullptr, int plan_nbins = 0) {
   const BaLayout L = ba_layout(E, Np, N);
   if (ws == nullptr || ws_bytes < L.total) { set_error("devo_ba_prepare: workspace %zu < %zu bytes", ws_bytes, L.total); return DEVO_ERR_WORKSPACE; }
   char* w = (char*)ws;
@@ -1302,7 +1328,24 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     const int ept = (E + 1023) / 1024;                         // edges per thread
     prep_fn_t prep = ept <= 8 ? k_ba_prepare<8> : ept <= 16 ? k_ba_prepare<16> : ept <= 24 ? k_ba_prepare<24> :
                      ept <= 32 ? k_ba_prepare<32> : k_ba_prepare<0>;
-    hipLaunchKernelGGL(prep, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b);
+    if (plan && ept <= 32) {
+      typedef void (*both_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, const int*, int, int*);
+      both_fn_t both = ept <= 8 ? k_prepare_and_order<8> : ept <= 16 ? k_prepare_and_order<16> : ept <= 24 ? k_prepare_and_order<24> :
+                       k_prepare_and_order<32>;
+      static bool both_attr = false;
+      if (!both_attr) {
+        (void)hipFuncSetAttribute((const void*)k_prepare_and_order<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+        (void)hipFuncSetAttribute((const void*)k_prepare_and_order<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+        (void)hipFuncSetAttribute((const void*)k_prepare_and_order<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+        (void)hipFuncSetAttribute((const void*)k_prepare_and_order<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+        (void)hipGetLastError(); both_attr = true;
+      }
+      hipLaunchKernelGGL(both, dim3(2), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b,
+                         plan + E + 1, plan_nbins, plan);
+      plan = nullptr;                                          // done
+    } else {
+      hipLaunchKernelGGL(prep, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b);
+    }
     hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, meta, ba_sig(E, N), perm_a, perm_b);
   } else {
     // (meta, rank, counts, cursor are contiguous at the head of the workspace)
@@ -1314,6 +1357,13 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, counts, L.max_seg, (int*)nullptr);
     hipLaunchKernelGGL(k_scatter_edges, dim3(eb), dim3(256), 0, st, ku, E, counts, cursor, perm_a);
     hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, meta, ba_sig(E, N), perm_a, perm_b);
+  }
+  if (plan) {                                                 // the plan's ordering step on its own
+    typedef void (*order_fn_t)(const int*, int, int, int*);
+    const long long per_thread = ((long long)E + ORDER_THREADS - 1) / ORDER_THREADS;
+    order_fn_t order_fn = per_thread <= 8 ? k_order_only<8> : per_thread <= 16 ? k_order_only<16> : per_thread <= 24 ? k_order_only<24> :
+                          per_thread <= 32 ? k_order_only<32> : k_order_only<0>;
+    hipLaunchKernelGGL(order_fn, dim3(1), dim3(ORDER_THREADS), 0, st, plan + E + 1, E, plan_nbins, plan);
   }
   return check_launch("devo_ba_prepare");
 }
@@ -1347,6 +1397,17 @@ int devo_ba_prepared_tables(const void* ws, size_t ws_bytes, int E, int Np, int 
   if (perm) ok = ok && hipMemcpyAsync(perm, w + L.perm_b, sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, st) == hipSuccess;
   if (!ok) { (void)hipGetLastError(); set_error("devo_ba_prepared_tables: copy failed"); return DEVO_ERR_LAUNCH; }
   return DEVO_OK;
+}
+
+int devo_ba_prepare_plan(const int64_t* kk, int E, int Np, int N, void* ws, size_t ws_bytes, int* plan, int plan_frames,
+                         int plan_height, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && Np > 0 && N >= 0, "devo_ba_prepare_plan: bad sizes");
+  if (N > BA_MAXN) { set_error("devo_ba_prepare_plan: %d optimised poses > %d supported", N, BA_MAXN); return DEVO_ERR_UNSUPPORTED; }
+  DEVO_REQUIRE(plan != nullptr && plan_frames > 0 && plan_height > 0, "devo_ba_prepare_plan: missing plan");
+  if (E == 0) return DEVO_OK;
+  const int nb = corr_plan_bands(1, plan_frames, plan_height);
+  DEVO_REQUIRE(nb > 0, "devo_ba_prepare_plan: too many frames for a locality plan (%d)", plan_frames);
+  return ba_prepare_impl(kk, E, Np, N, ws, ws_bytes, (hipStream_t)stream, plan, plan_frames * nb);
 }
 
 int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,

@@ -10,6 +10,7 @@
 //   corr_fwd_cl_kernel (below, fp32 / fp16, any C % 8 == 0): tap-centric, box staged through LDS, DPP-broadcast FMAs.
 #include "common.h"
 #include "corr_tile.h"
+#include "corr_plan.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 #include <vector>
@@ -429,8 +430,6 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 // patch centre).  Binning on all CUs, then one workgroup's LDS counting sort (bins = frames x bands).  The order only affects which edges run
 // together (L2 reuse of the feature rows); results are independent of it.
 // -------------------------------------------------------------------------------------------------
-constexpr int ORDER_THREADS = 1024;
-constexpr int ORDER_MAXBINS = CORR_ORDER_MAXBINS;
 constexpr int BIN_THREADS = 256;
 
 // Step 1 (all CUs): bin of every edge slot -> bins[be]; -1 marks a HEAVY edge (the box of its 9 windows exceeds
@@ -457,61 +456,7 @@ __global__ __launch_bounds__(BIN_THREADS) void corr_bin_kernel(const float* __re
 template <int CACHE>
 __global__ __launch_bounds__(ORDER_THREADS) void corr_order_kernel(const int* __restrict__ bins, int BE, int nbins,
                                                                    int* __restrict__ order) {
-  __shared__ int s_cnt[ORDER_MAXBINS];
-  __shared__ int s_heavy[2];                                // [0] = count (pass 1), [1] = cursor (pass 2)
-  constexpr bool CACHED = CACHE > 0;
-  const int lane = threadIdx.x & 63;
-  int breg[CACHED ? CACHE : 1];
-  if (CACHED) {
-#pragma unroll
-    for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
-      const int be = threadIdx.x + ORDER_THREADS * i;
-      breg[i] = be < BE ? bins[be] : 0x7fffffff;
-    }
-  }
-  auto bin_at = [&](int i) -> int {
-    if (CACHED) return breg[i];
-    const int be = threadIdx.x + ORDER_THREADS * i;
-    return be < BE ? bins[be] : 0x7fffffff;
-  };
-  const int iters = CACHED ? CACHE : (BE + ORDER_THREADS - 1) / ORDER_THREADS;   // block-uniform (ballots below)
-  for (int i = threadIdx.x; i < nbins; i += ORDER_THREADS) s_cnt[i] = 0;
-  if (threadIdx.x < 2) s_heavy[threadIdx.x] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < iters; i++) {
-    const int bin = bin_at(i);
-    const unsigned long long hv = __ballot(bin < 0);
-    if (bin >= 0 && bin < nbins) atomicAdd(&s_cnt[bin], 1);
-    if (hv != 0ull && lane == 0) atomicAdd(&s_heavy[0], __popcll(hv));
-  }
-  __syncthreads();
-  const int n_heavy = s_heavy[0];
-  if (threadIdx.x < 64) {                                   // exclusive scan of the bins by one wave, starting after the heavy list
-    int carry = n_heavy;
-    for (int base = 0; base < nbins; base += 64) {
-      const int i = base + threadIdx.x;
-      const int v = (i < nbins) ? s_cnt[i] : 0;
-      int x = v;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(x, off); if ((int)threadIdx.x >= off) x += t; }
-      if (i < nbins) s_cnt[i] = carry + x - v;
-      carry += __shfl(x, 63);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < iters; i++) {
-    const int be = threadIdx.x + ORDER_THREADS * i;
-    const int bin = bin_at(i);
-    const unsigned long long hv = __ballot(bin < 0);
-    int hbase = 0;
-    if (hv != 0ull && lane == 0) hbase = atomicAdd(&s_heavy[1], __popcll(hv));
-    hbase = __shfl(hbase, 0);
-    if (bin < 0) order[hbase + __popcll(hv & ((1ull << lane) - 1ull))] = be;
-    else if (bin < nbins) order[atomicAdd(&s_cnt[bin], 1)] = be;
-  }
-  if (threadIdx.x == 0) order[BE] = n_heavy;
+  corr_order_body<CACHE>(bins, BE, nbins, order);
 }
 
 // -------------------------------------------------------------------------------------------------

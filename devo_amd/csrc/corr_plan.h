@@ -1,0 +1,74 @@
+// The locality plan's ordering step as a device function: corr.hip wraps it into corr_order_kernel, ba.hip runs it as the
+// second workgroup of k_prepare_and_order (next to the BA's index preparation: both are single-workgroup, latency-bound
+// kernels that do not depend on each other).
+#pragma once
+#include "corr_tile.h"
+
+namespace devo {
+
+constexpr int ORDER_THREADS = 1024;
+constexpr int ORDER_MAXBINS = CORR_ORDER_MAXBINS;
+
+// One workgroup: LDS counting sort of the bins; the heavy list first.  CACHE > 0: the ceil(BE / 1024) <= CACHE bins of a
+// thread are loaded at once into registers (one round trip to memory instead of one per loop iteration and pass);
+// CACHE == 0: any BE, bins re-read by both passes.
+template <int CACHE>
+__device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order) {
+  __shared__ int s_cnt[ORDER_MAXBINS];
+  __shared__ int s_heavy[2];                                // [0] = count (pass 1), [1] = cursor (pass 2)
+  constexpr bool CACHED = CACHE > 0;
+  const int lane = threadIdx.x & 63;
+  int breg[CACHED ? CACHE : 1];
+  if (CACHED) {
+#pragma unroll
+    for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
+      const int be = threadIdx.x + ORDER_THREADS * i;
+      breg[i] = be < BE ? bins[be] : 0x7fffffff;
+    }
+  }
+  auto bin_at = [&](int i) -> int {
+    if (CACHED) return breg[i];
+    const int be = threadIdx.x + ORDER_THREADS * i;
+    return be < BE ? bins[be] : 0x7fffffff;
+  };
+  const int iters = CACHED ? CACHE : (BE + ORDER_THREADS - 1) / ORDER_THREADS;   // block-uniform (ballots below)
+  for (int i = threadIdx.x; i < nbins; i += ORDER_THREADS) s_cnt[i] = 0;
+  if (threadIdx.x < 2) s_heavy[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < iters; i++) {
+    const int bin = bin_at(i);
+    const unsigned long long hv = __ballot(bin < 0);
+    if (bin >= 0 && bin < nbins) atomicAdd(&s_cnt[bin], 1);
+    if (hv != 0ull && lane == 0) atomicAdd(&s_heavy[0], __popcll(hv));
+  }
+  __syncthreads();
+  const int n_heavy = s_heavy[0];
+  if (threadIdx.x < 64) {                                   // exclusive scan of the bins by one wave, starting after the heavy list
+    int carry = n_heavy;
+    for (int base = 0; base < nbins; base += 64) {
+      const int i = base + threadIdx.x;
+      const int v = (i < nbins) ? s_cnt[i] : 0;
+      int x = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(x, off); if ((int)threadIdx.x >= off) x += t; }
+      if (i < nbins) s_cnt[i] = carry + x - v;
+      carry += __shfl(x, 63);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < iters; i++) {
+    const int be = threadIdx.x + ORDER_THREADS * i;
+    const int bin = bin_at(i);
+    const unsigned long long hv = __ballot(bin < 0);
+    int hbase = 0;
+    if (hv != 0ull && lane == 0) hbase = atomicAdd(&s_heavy[1], __popcll(hv));
+    hbase = __shfl(hbase, 0);
+    if (bin < 0) order[hbase + __popcll(hv & ((1ull << lane) - 1ull))] = be;
+    else if (bin < nbins) order[atomicAdd(&s_cnt[bin], 1)] = be;
+  }
+  if (threadIdx.x == 0) order[BE] = n_heavy;
+}
+
+}  // namespace devo

@@ -132,6 +132,12 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
  * workspace that was not prepared for this (E, t1 - t0) touches nothing and sets *status_flag to -1. */
 int devo_ba_prepare(const int64_t* kk, int E, int Np, int N /* t1 - t0 */, void* ws, size_t ws_bytes,
                     devo_stream_t stream);
+/* devo_ba_prepare + the ordering step of the lookup's locality plan (devo_corr_order with coords = NULL) in ONE launch:
+ * both are single-workgroup, latency-bound kernels that do not depend on each other, so they run as two workgroups side
+ * by side.  plan: i32 [2E + 1] whose bins devo_transform(..., plan, plan_frames, plan_height, radius) has written
+ * (batch 1); afterwards it is the finished plan for devo_corr_forward*. */
+int devo_ba_prepare_plan(const int64_t* kk, int E, int Np, int N /* t1 - t0 */, void* ws, size_t ws_bytes, int* plan,
+                         int plan_frames, int plan_height, devo_stream_t stream);
 /* Inspection of a prepared workspace (tests / debugging): copies (device to device, any pointer may be NULL)
  * *n_seg = number of distinct patches with edges, kx i32 [min(E,Np)] = their ids ascending (the first output of
  * torch::_unique(kk), ba_cuda.cu:435-437), seg_start i32 [min(E,Np)+1] and perm i32 [E]: the edges of patch kx[s]

@@ -299,3 +299,35 @@ def test_ba_more_than_16_optimised_poses_uses_the_general_kernel():
     s = scene(n=22, M=4, H=96, W=128, seed=77, keep=0.9, sigma=0.5)
     ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], 1, 22, 2, dtype=torch.float64)
     check(run_ba(*s, 1, 22, 2), ref)
+
+
+def test_prepare_with_plan_equals_the_two_separate_calls():
+    """cuda_ba.prepare(..., plan=...) (BA index preparation + the lookup plan's ordering step as two workgroups of one launch)
+    leaves the same BA tables and a plan with the same heavy set and the same (frame, band) sequence as the separate calls"""
+    from devo_amd.backends import cuda_ba, cuda_corr
+    n, M, H, W = 6, 40, 60, 80
+    poses, (patches, _), intr = synth.make_poses(n, 9), synth.make_patches(n, M, H, W, seed=9), synth.make_intrinsics(n, H, W)
+    ii, jj, kk = (t.to(DEV) for t in synth.full_graph(n, M))
+    E, Np = ii.numel(), patches.shape[1]
+    args = (poses.to(DEV), patches.to(DEV), intr.to(DEV), ii, jj, kk)
+    coords, buf_a = cuda_ba.transform(*args, layout="2pp", plan_for=(n, H, 3))
+    _, buf_b = cuda_ba.transform(*args, layout="2pp", plan_for=(n, H, 3))
+    ws_a, ws_b = cuda_ba.workspace(E, Np, n - 1, DEV), cuda_ba.workspace(E, Np, n - 1, DEV)
+    cuda_ba.prepare(kk, Np, n - 1, ws_a, plan=(buf_a, n, H))
+    cuda_ba.prepare(kk, Np, n - 1, ws_b)
+    plan_b = cuda_corr.plan_finish(buf_b, jj, n, H, 3)
+    ta, tb = cuda_ba.prepared_tables(ws_a, E, Np, n - 1), cuda_ba.prepared_tables(ws_b, E, Np, n - 1)
+    assert ta[0] == tb[0] and all(torch.equal(x, y) for x, y in zip(ta[1:], tb[1:]))
+    a, b = buf_a.cpu(), plan_b.cpu()
+    nh = int(a[E])
+    assert nh == int(b[E]) and sorted(a[:E].tolist()) == list(range(E)) and sorted(a[:nh].tolist()) == sorted(b[:nh].tolist())
+    key = lambda o: torch.stack([jj.cpu()[o[nh:E].long()], (coords.cpu()[0, o[nh:E].long(), 1, 1, 1].clamp(0, H - 1) / 16).floor().long()], 1)
+    assert torch.equal(key(a), key(b))
+    # and the BA runs on the tables of the combined launch
+    tgt = coords[:, :, :, 1, 1] + 0.1
+    w = torch.ones(1, E, 2, device=DEV)
+    pa, qa, pb, qb = args[0].clone(), args[1].clone(), args[0].clone(), args[1].clone()
+    lm = torch.tensor([1e-4], device=DEV)
+    cuda_ba.forward(pa, qa, args[2], tgt, w, lm, ii, jj, kk, 1, n, 2, ws=ws_a, prepared=True)
+    cuda_ba.forward(pb, qb, args[2], tgt, w, lm, ii, jj, kk, 1, n, 2)
+    assert torch.equal(pa, pb) and torch.equal(qa, qb)

@@ -144,7 +144,7 @@ constexpr int PREP_SEGS_LDS = 8192;
 template <int CACHE>      // CACHE = 0: kk is re-read by every pass; else ceil(E / 1024) <= CACHE edges per thread in registers
 __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
                                                 int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
-                                                int* perm_b) {
+                                                int* perm_b, int sig) {
   extern __shared__ int s_mem[];
   int* s_part = s_mem;                       // 1024
   int* s_flags = s_part + 1024;              // PREP_FLAGS_LDS + 1
@@ -217,7 +217,8 @@ __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, 
   for (int i = 0; i < iters; i++) { const int k = patch_of(i); if (k >= 0) rank[k - kmin] = 1; }
   __syncthreads();
   const int n_seg = block_excl_scan_1024(rank, Rg, s_part);
-  if (t == 0) { meta->n_seg = n_seg; meta->fail = 0; meta->pad = ascending; }     // pad = 1: k_sort_segments has nothing to do
+  // (sig: the workspace holds a prepared graph once this kernel is through — the in-segment order is restored below)
+  if (t == 0) { meta->n_seg = n_seg; meta->fail = 0; meta->pad = ascending; meta->sig = sig; }
   if (CACHED && ascending) {
     // segment starts = the run heads, permutation = identity (ascending edge ids inside every patch by construction)
 #pragma unroll
@@ -312,13 +313,26 @@ __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, 
   }
   // publish the segment starts: entries beyond n_seg = E so that any reader sees empty tails
   for (int i = t; i <= max_seg; i += 1024) g_counts[i] = (i <= n_seg) ? counts[i] : E;
+  // restore a deterministic (ascending edge id) order inside every segment: rank sort, one wave per segment (the work of
+  // k_sort_segments, which the multi-kernel path for huge edge lists still launches)
+  __threadfence_block();
+  __syncthreads();
+  for (int sgi = t >> 6; sgi < n_seg; sgi += 16) {
+    const int a = counts[sgi], m = counts[sgi + 1] - a;
+    for (int i = lane; i < m; i += 64) {
+      const int x = perm_a[a + i];
+      int r = 0;
+      for (int j = 0; j < m; j++) r += (perm_a[a + j] < x);
+      perm_b[a + r] = x;
+    }
+  }
 }
 
 template <int CACHE>
 __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
                                                      int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
-                                                     int* perm_b) {
-  ba_prepare_body<CACHE>(kk, E, Np, max_seg, meta, g_rank, g_counts, g_cursor, ku, kx, perm_a, perm_b);
+                                                     int* perm_b, int sig) {
+  ba_prepare_body<CACHE>(kk, E, Np, max_seg, meta, g_rank, g_counts, g_cursor, ku, kx, perm_a, perm_b, sig);
 }
 
 template <int CACHE>
@@ -331,8 +345,8 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_only(const int* __restr
 template <int CACHE>
 __global__ __launch_bounds__(1024) void k_prepare_and_order(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
                                                             int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
-                                                            int* perm_b, const int* __restrict__ bins, int nbins, int* __restrict__ order) {
-  if (blockIdx.x == 0) ba_prepare_body<CACHE>(kk, E, Np, max_seg, meta, g_rank, g_counts, g_cursor, ku, kx, perm_a, perm_b);
+                                                            int* perm_b, int sig, const int* __restrict__ bins, int nbins, int* __restrict__ order) {
+  if (blockIdx.x == 0) ba_prepare_body<CACHE>(kk, E, Np, max_seg, meta, g_rank, g_counts, g_cursor, ku, kx, perm_a, perm_b, sig);
   else corr_order_body<CACHE>(bins, E, nbins, order);
 }
 
@@ -1324,12 +1338,12 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     (void)hipGetLastError(); prep_attr = true;
   }
   if (E <= (1 << 17)) {
-    typedef void (*prep_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*);
+    typedef void (*prep_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, int);
     const int ept = (E + 1023) / 1024;                         // edges per thread
     prep_fn_t prep = ept <= 8 ? k_ba_prepare<8> : ept <= 16 ? k_ba_prepare<16> : ept <= 24 ? k_ba_prepare<24> :
                      ept <= 32 ? k_ba_prepare<32> : k_ba_prepare<0>;
     if (plan && ept <= 32) {
-      typedef void (*both_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, const int*, int, int*);
+      typedef void (*both_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, int, const int*, int, int*);
       both_fn_t both = ept <= 8 ? k_prepare_and_order<8> : ept <= 16 ? k_prepare_and_order<16> : ept <= 24 ? k_prepare_and_order<24> :
                        k_prepare_and_order<32>;
       static bool both_attr = false;
@@ -1341,12 +1355,11 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
         (void)hipGetLastError(); both_attr = true;
       }
       hipLaunchKernelGGL(both, dim3(2), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b,
-                         plan + E + 1, plan_nbins, plan);
+                         ba_sig(E, N), plan + E + 1, plan_nbins, plan);
       plan = nullptr;                                          // done
     } else {
-      hipLaunchKernelGGL(prep, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b);
+      hipLaunchKernelGGL(prep, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b, ba_sig(E, N));
     }
-    hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, meta, ba_sig(E, N), perm_a, perm_b);
   } else {
     // (meta, rank, counts, cursor are contiguous at the head of the workspace)
     if (hipMemsetAsync(w + L.meta, 0, L.ku - L.meta, st) != hipSuccess) { set_error("devo_ba_prepare: memset failed"); return DEVO_ERR_LAUNCH; }

@@ -869,27 +869,20 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
 // S = sum of the compact partials, mirrored; S_dd <- S_dd*(1+1e-4)+1 (ba_cuda.cu:517-518); y = sum.
 // 256-thread workgroups: wave g sums partials [g*n_part/4, (g+1)*n_part/4) for 64 consecutive outputs (8 loads in
 // flight), the four wave results are combined through LDS in a fixed order.
-__global__ __launch_bounds__(256) void k_ba_reduce(const float* __restrict__ partials, int n_part, int N, float* __restrict__ S,
+__global__ __launch_bounds__(512) void k_ba_reduce(const float* __restrict__ partials, int n_part, int N, float* __restrict__ S,
                                                    float* __restrict__ y) {
-  __shared__ float s_sum[4][64];
+  // One lane per entry of the COMPACT partial (lower block triangle + right-hand side): consecutive lanes read consecutive
+  // addresses of every partial, 8 waves share the partials of 64 entries, the symmetric entry is written by the same lane
+  // (the full-matrix form read every off-diagonal entry twice, 6 floats at a time).
+  __shared__ float s_sum[8][64];
   const int n6 = 6 * N, nt = tri_blocks(N) * 36, stride = nt + n6;
-  const int total = n6 * n6 + n6;
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int o = blockIdx.x * 64 + lane;
-  int r = 0, c = 1, src = 0;
-  if (o < total) {
-    if (o < n6 * n6) {
-      r = o / n6; c = o % n6;
-      int fr = r / 6, a = r % 6, fc = c / 6, b = c % 6;
-      if (fr < fc || (fr == fc && a < b)) { int t = fr; fr = fc; fc = t; t = a; a = b; b = t; }   // mirror
-      src = (fr * (fr + 1) / 2 + fc) * 36 + a * 6 + b;
-    } else src = nt + (o - n6 * n6);
-  }
-  const int per = (n_part + 3) / 4;
+  const int per = (n_part + 7) / 8;
   const int p0 = g * per, p1 = min(n_part, p0 + per);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (o < total) {
-    const float* base = partials + src;
+  if (o < stride) {
+    const float* base = partials + o;
     int p = p0;
     for (; p + 8 <= p1; p += 8) {
 #pragma unroll
@@ -899,11 +892,19 @@ __global__ __launch_bounds__(256) void k_ba_reduce(const float* __restrict__ par
   }
   s_sum[g][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
-  if (g == 0 && o < total) {
-    float sum = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
+  if (g == 0 && o < stride) {
+    float sum = ((s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane])) +
+                ((s_sum[4][lane] + s_sum[5][lane]) + (s_sum[6][lane] + s_sum[7][lane]));
     // written as the solver's working matrix: (n6+1) rows of pitch n6+1, the right-hand side is row n6
-    if (o < n6 * n6) { if (r == c) sum = sum + (1e-4f * sum + 1.0f); S[r * (n6 + 1) + c] = sum; }
-    else S[n6 * (n6 + 1) + (o - n6 * n6)] = sum;
+    if (o < nt) {
+      int fr, fc;
+      block_of(o / 36, fr, fc);
+      const int ab = o % 36, r = 6 * fr + ab / 6, c = 6 * fc + ab % 6;
+      if (fr == fc && ab / 6 < ab % 6) return;                  // upper half of a diagonal block: its mirror writes it
+      if (r == c) sum = sum + (1e-4f * sum + 1.0f);
+      S[r * (n6 + 1) + c] = sum;
+      if (r != c) S[c * (n6 + 1) + r] = sum;
+    } else S[n6 * (n6 + 1) + (o - nt)] = sum;
   }
 }
 
@@ -1484,7 +1485,7 @@ int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsi
                        weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, it, ba_sig(E, N), L.max_seg);
     if ((rc = check_launch("devo_ba_forward(accumulate)"))) return rc;
     if (N > 0) {
-      hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((n6 * n6 + n6 + 63) / 64)), dim3(256), 0, st, partials, L.n_part, N, S, y);
+      hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, partials, L.n_part, N, S, y);
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       static const bool ba_trace = getenv("DEVO_BA_TRACE") != nullptr;
       hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace ? 1 : 0);

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__
 
 template <int CACHE>
 __global__ __launch_bounds__(ORDER_THREADS) void k_order_only(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order) {
-  corr_order_body<CACHE>(bins, BE, nbins, order);
+  corr_order_body<CACHE>(bins, BE, nbins, order);          // (fallback path: no staging buffer)
 }
 
 // Workgroup 0: the BA's index preparation; workgroup 1: the ordering step of the lookup's locality plan (corr_plan.h).
@@ -345,9 +345,12 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_only(const int* __restr
 template <int CACHE>
 __global__ __launch_bounds__(1024) void k_prepare_and_order(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
                                                             int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
-                                                            int* perm_b, int sig, const int* __restrict__ bins, int nbins, int* __restrict__ order) {
+                                                            int* perm_b, int sig, const int* __restrict__ bins, int nbins, int* __restrict__ order, int stage_cap) {
   if (blockIdx.x == 0) ba_prepare_body<CACHE>(kk, E, Np, max_seg, meta, g_rank, g_counts, g_cursor, ku, kx, perm_a, perm_b, sig);
-  else corr_order_body<CACHE>(bins, E, nbins, order);
+  else {
+    extern __shared__ int s_dyn_order[];                   // this workgroup's copy of the dynamic LDS: the staging buffer
+    corr_order_body<CACHE>(bins, E, nbins, order, s_dyn_order, stage_cap);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- per-edge maths
@@ -1344,7 +1347,7 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     prep_fn_t prep = ept <= 8 ? k_ba_prepare<8> : ept <= 16 ? k_ba_prepare<16> : ept <= 24 ? k_ba_prepare<24> :
                      ept <= 32 ? k_ba_prepare<32> : k_ba_prepare<0>;
     if (plan && ept <= 32) {
-      typedef void (*both_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, int, const int*, int, int*);
+      typedef void (*both_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, int, const int*, int, int*, int);
       both_fn_t both = ept <= 8 ? k_prepare_and_order<8> : ept <= 16 ? k_prepare_and_order<16> : ept <= 24 ? k_prepare_and_order<24> :
                        k_prepare_and_order<32>;
       static bool both_attr = false;
@@ -1356,7 +1359,7 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
         (void)hipGetLastError(); both_attr = true;
       }
       hipLaunchKernelGGL(both, dim3(2), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b,
-                         ba_sig(E, N), plan + E + 1, plan_nbins, plan);
+                         ba_sig(E, N), plan + E + 1, plan_nbins, plan, (int)(prep_lds / sizeof(int)));
       plan = nullptr;                                          // done
     } else {
       hipLaunchKernelGGL(prep, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b, ba_sig(E, N));

@@ -12,8 +12,11 @@ constexpr int ORDER_MAXBINS = CORR_ORDER_MAXBINS;
 // One workgroup: LDS counting sort of the bins; the heavy list first.  CACHE > 0: the ceil(BE / 1024) <= CACHE bins of a
 // thread are loaded at once into registers (one round trip to memory instead of one per loop iteration and pass);
 // CACHE == 0: any BE, bins re-read by both passes.
+// `stage` (LDS, `stage_cap` ints, may be null / 0): the ordered list is assembled there and written out with coalesced stores —
+// 20 000 scattered 4-byte stores from ONE compute unit take longer than the whole sort.
 template <int CACHE>
-__device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order) {
+__device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order,
+                                                int* stage = nullptr, int stage_cap = 0) {
   __shared__ int s_cnt[ORDER_MAXBINS];
   __shared__ int s_heavy[2];                                // [0] = count (pass 1), [1] = cursor (pass 2)
   constexpr bool CACHED = CACHE > 0;
@@ -57,6 +60,8 @@ __device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, in
     }
   }
   __syncthreads();
+  const bool staged = stage != nullptr && BE <= stage_cap;
+  int* dst = staged ? stage : order;
 #pragma unroll
   for (int i = 0; i < iters; i++) {
     const int be = threadIdx.x + ORDER_THREADS * i;
@@ -65,8 +70,12 @@ __device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, in
     int hbase = 0;
     if (hv != 0ull && lane == 0) hbase = atomicAdd(&s_heavy[1], __popcll(hv));
     hbase = __shfl(hbase, 0);
-    if (bin < 0) order[hbase + __popcll(hv & ((1ull << lane) - 1ull))] = be;
-    else if (bin < nbins) order[atomicAdd(&s_cnt[bin], 1)] = be;
+    if (bin < 0) dst[hbase + __popcll(hv & ((1ull << lane) - 1ull))] = be;
+    else if (bin < nbins) dst[atomicAdd(&s_cnt[bin], 1)] = be;
+  }
+  if (staged) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < BE; i += ORDER_THREADS) order[i] = stage[i];
   }
   if (threadIdx.x == 0) order[BE] = n_heavy;
 }

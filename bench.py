@@ -148,7 +148,7 @@ def main():
             prep_stream.wait_stream(cur)
             with torch.cuda.stream(prep_stream):
                 cuda_ba.prepare(d["kk"], Np, n - 1, ws)
-        d["state"].copy_(d["state0"])                                      # fresh poses + patches (bench harness)
+        torch.mul(d["state0"], 1.0, out=d["state"])                        # fresh poses + patches (bench harness; an elementwise kernel: rocclr's copyBuffer takes 5 us)
         # reprojection; the kernel also emits the lookup's plan bins while it holds the coordinates
         coords, order = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp",
                                           plan_for=(n, cfg["H"], R))

@@ -52,11 +52,9 @@ __device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, in
     for (int base = 0; base < nbins; base += 64) {
       const int i = base + threadIdx.x;
       const int v = (i < nbins) ? s_cnt[i] : 0;
-      int x = v;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(x, off); if ((int)threadIdx.x >= off) x += t; }
+      const int x = wave_inclusive_sum(v);
       if (i < nbins) s_cnt[i] = carry + x - v;
-      carry += __shfl(x, 63);
+      carry += __builtin_amdgcn_readlane(x, 63);
     }
   }
   __syncthreads();

@@ -47,6 +47,19 @@ inline int corr_plan_bands(long long B, int n2, int H2) {
   return (B * n2 * nb <= CORR_ORDER_MAXBINS) ? nb : 0;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS round trips like ds_bpermute shuffles):
+// Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8; lanes without a source add 0), then the last lane of row 0 / 2
+// into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31).  All 64 lanes must be active.
+__device__ __forceinline__ int wave_inclusive_sum(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return x;
+}
+
 __device__ __forceinline__ int corr_floor_to_int(float v) {
   // static_cast<int>(floor(v)) (correlation_kernel.cu:118-119), made safe for non-finite / huge inputs
   float f = floorf(v);

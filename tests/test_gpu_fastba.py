@@ -250,14 +250,17 @@ def test_update_schedule_18_iterations():
     check((P.cpu(), Q.cpu()), (P64, Q64), tol=1e-4)
 
 
-@pytest.mark.parametrize("E,Np,ordered", [(5000, 300, False), (21600, 1440, True), (40000, 700, False), (200000, 5000, False)])
+@pytest.mark.parametrize("E,Np,ordered", [(5000, 300, False), (21600, 1440, True), (7013, 900, "ragged"), (30001, 2000, "ragged"),
+                                              (40000, 700, False), (200000, 5000, False)])
 def test_prepare_tables_bit_exact(E, Np, ordered):
     """The index half of the BA against torch.unique(kk, sorted, return_inverse) (ba_cuda.cu:435-437), bit-exact:
     sorted unique patch ids and, per patch, exactly its edges in ascending order — for the register-cached
     single-workgroup kernel (E <= 32768), the re-reading one and the multi-kernel path (E > 2^17)."""
     from devo_amd.backends import cuda_ba
     g = torch.Generator().manual_seed(E)
-    if ordered:
+    if ordered == "ragged":                                     # ascending ids, runs of any length, ids missing: the run-head path
+        kk = torch.sort(torch.randint(0, Np, (E,), generator=g) // 3 * 3).values
+    elif ordered:
         kk = torch.arange(Np).repeat_interleave(E // Np)
     else:
         kk = torch.randint(0, Np, (E,), generator=g)

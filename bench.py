@@ -4,9 +4,9 @@
 
 One STEP = one update-op iteration on a fixed patch graph (devo/devo.py:308-338 minus the Update MLP):
     reproject (projective_ops.transform)  ->  altcorr lookup at 2 pyramid levels (r=3)
-    ->  target = centre + delta  ->  fastba bundle adjustment, 2 Gauss-Newton iterations.
-All inputs are synthetic, resident in HBM before the timed region; the step is captured in a
-HIP graph and replayed.  Multi-GPU: one process per GPU, independent sequences (seed 1234 + rank), no data-path
+    ->  target = centre + delta (formed inside the BA)  ->  fastba bundle adjustment, 2 Gauss-Newton iterations.
+All inputs are synthetic, resident in HBM before the timed region; the steps are captured in a
+HIP graph (--steps-per-graph consecutive steps per graph launch, every step complete) and replayed.  Multi-GPU: one process per GPU, independent sequences (seed 1234 + rank), no data-path
 collective (replicas; "scaling": "weak"); the aggregate is steps*ranks / max-over-ranks time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2] [--dtype f32|f16]
@@ -44,6 +44,9 @@ def parse():
                     help="the lookup plan's ordering kernel and the BA's index preparation as two launches (inside their own calls) "
                          "instead of one launch with two workgroups (cuda_ba.prepare(..., plan=...))")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--separate-target", action="store_true", help="form target = coords centre + delta with a torch kernel (devo.py:330) instead of inside the BA")
+    ap.add_argument("--steps-per-graph", type=int, default=10,
+                    help="consecutive steps captured into one HIP graph launch (a graph launch costs ~10 us of idle GPU; 1 = one launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=50, help="launch pairs timed for the roofline figure")
     ap.add_argument("--with-update", action="store_true",
@@ -158,6 +161,11 @@ def main():
             # the plan's ordering step and the BA's index preparation (both single-workgroup, independent) in ONE launch
             cuda_ba.prepare(d["kk"], Np, n - 1, ws, plan=(order, n, cfg["H"]))
         lookup(coords, order=order)
+        if not (args.separate_target or args.separate_index_kernels or prep_stream is not None):
+            # devo.py:330 (target = centre of the reprojected patch + delta) formed inside the BA: same fp32 addition
+            cuda_ba.forward_delta(d["poses"], d["patches"], d["intr"], coords, d["delta"], d["weight"], d["lmbda"],
+                                  d["ii"], d["jj"], d["kk"], 1, n, 2, ws)
+            return
         target = coords[:, :, :, 1, 1] + d["delta"]                        # devo.py:330
         if prep_stream is not None:
             cur.wait_stream(prep_stream)
@@ -178,14 +186,26 @@ def main():
             torch.cuda.synchronize()
             with torch.cuda.graph(graph, stream=side):
                 step()
+            gmany = None
+            if args.steps_per_graph > 1:                                   # several consecutive steps in one graph launch
+                gmany = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gmany, stream=side):
+                    for _ in range(args.steps_per_graph):
+                        step()
         torch.cuda.current_stream().wait_stream(side)
         run = graph.replay
     for _ in range(args.warmup):
         run()
+    n_many = 0
+    if not args.no_graph and gmany is not None:
+        n_many = args.steps // args.steps_per_graph
+        gmany.replay()
 
     D.barrier_sync(device)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(n_many):
+        gmany.replay()
+    for _ in range(args.steps - n_many * args.steps_per_graph):           # EXACTLY --steps steps
         run()
     D.barrier_sync(device)
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
@@ -262,7 +282,7 @@ def main():
         "config": {"workload": f"{args.workload}: M={M} patches/frame, n={n} keyframes, E={E} edges, r={R}, "
                                f"2 pyramid levels {cfg['H']}x{cfg['W']} + /4, C={cfg['C']}, 2 GN iterations, "
                                f"pyramid layout {args.layout}, {'both levels in one lookup launch' if args.fuse_levels else 'one lookup launch per level'}, "
-                               f"{'HIP graph' if not args.no_graph else 'eager'}"
+                               f"{('HIP graph, ' + str(args.steps_per_graph) + ' step(s) per graph launch') if not args.no_graph else 'eager'}"
                                f"{', BA index preparation on a second stream' if args.overlap_prepare else ''}",
                    "parallelism": f"replicas x{world}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

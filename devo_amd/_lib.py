@@ -34,6 +34,7 @@ _SIGNATURES = {
     "devo_ba_prepare_plan": [_vp, _i, _i, _i, _vp, _sz, _vp, _i, _i, _vp],
     "devo_ba_prepared_tables": [_vp, _sz, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "devo_ba_forward_prepared": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
+    "devo_ba_forward_prepared_delta": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
     "devo_neighbors_workspace_bytes": [_i],
     "devo_ba_neighbors": [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp],
     "devo_ba_reproject": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -83,6 +83,43 @@ def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t
     return []
 
 
+def forward_delta(poses, patches, intrinsics, coords, delta, weight, lmbda, ii, jj, kk, t0, t1, iterations, ws, layout="2pp",
+                  status=None):
+    """forward(..., prepared=True) with devo/devo.py:330 folded in: target = coords[..., P//2, P//2] + delta is formed inside
+    the BA from the buffer transform() returned (`layout` as there) and the update operator's delta [1,E,2] — the same fp32
+    addition, bit-identical results, one elementwise launch less.  `ws` must hold prepare()'s result."""
+    L.require_gpu(poses, patches, intrinsics, coords, delta, weight, lmbda, ii, jj, kk)
+    for name, t in (("poses", poses), ("patches", patches)):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError(f"cuda_ba.forward_delta: {name} must be a contiguous float32 tensor (it is updated in place)")
+    if coords.dtype != torch.float32 or not coords.is_contiguous():
+        raise RuntimeError("cuda_ba.forward_delta: coords must be the contiguous float32 tensor transform() returned")
+    P = patches.shape[-1]
+    Nbuf = poses.numel() // 7
+    Np = patches.numel() // (3 * P * P)
+    ii, jj, kk = _idx(ii, jj, kk)
+    E = ii.numel()
+    ctr = (P // 2) * (P + 1)
+    if layout == "2pp" and coords.numel() == E * 2 * P * P:
+        se, sc, off = 2 * P * P, P * P, ctr
+    elif layout == "pp2" and coords.numel() == E * P * P * 2:
+        se, sc, off = 2 * P * P, 1, 2 * ctr
+    else:
+        raise RuntimeError(f"cuda_ba.forward_delta: coords {tuple(coords.shape)} is not a '{layout}' buffer of {E} edges")
+    intrinsics = intrinsics.float().contiguous()
+    delta = delta.float().contiguous()
+    weight = weight.float().contiguous()
+    lmbda = lmbda.float().reshape(-1).contiguous()
+    if delta.numel() != 2 * E:
+        raise RuntimeError("cuda_ba.forward_delta: delta must hold 2 values per edge")
+    rc = L.lib().devo_ba_forward_prepared_delta(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(coords), se, sc, off,
+                                                L.ptr(delta), L.ptr(weight), L.ptr(lmbda), L.ptr(ii), L.ptr(jj), L.ptr(kk), E,
+                                                Nbuf, Np, P, int(t0), int(t1), int(iterations), L.ptr(ws), ws.numel(),
+                                                L.ptr(status), L.stream())
+    L.check(rc, "cuda_ba.forward_delta")
+    return []
+
+
 def neighbors(ii, jj):
     """ba.cpp:154 -> [ix, jx] (int64, on the GPU); no device<->host round trip (the reference does five)."""
     L.require_gpu(ii, jj)

@@ -384,9 +384,13 @@ struct EdgeTerms {
   float Ji[2][6], Jj[2][6];
 };
 
+// Where an edge's target comes from: t[2e + c] alone, or (devo.py:330 folded in) the centre pixel of the reprojected patch
+// plus the update operator's delta: base[e * se + c * sc + off] + t[2e + c] — the same single fp32 addition torch does.
+struct TargetSrc { const float* t; const float* base; int se, sc, off; };
+
 // ba_cuda.cu:239-330 for one edge (fx,fy,cx,cy of intrinsics row 0).
 __device__ __forceinline__ void edge_terms(const float* __restrict__ poses, const float* __restrict__ patches, int P,
-                                           float fx, float fy, float cx, float cy, const float* __restrict__ target,
+                                           float fx, float fy, float cx, float cy, const TargetSrc& target,
                                            const float* __restrict__ weight, int ix, int jx, int kx, int e, EdgeTerms& T) {
   const float* pi = poses + (int64_t)ix * 7;
   const float* pj = poses + (int64_t)jx * 7;
@@ -402,7 +406,12 @@ __device__ __forceinline__ void edge_terms(const float* __restrict__ poses, cons
   const float d = (Z >= 0.2f) ? 1.0f / Z : 0.0f;
   const float d2 = d * d;
   const float x1 = fx * (X / Z) + cx, y1 = fy * (Y / Z) + cy;
-  const float rx = target[(int64_t)e * 2] - x1, ry = target[(int64_t)e * 2 + 1] - y1;
+  float tgx = target.t[(int64_t)e * 2], tgy = target.t[(int64_t)e * 2 + 1];
+  if (target.base) {
+    const float* b = target.base + (int64_t)e * target.se + target.off;
+    tgx = b[0] + tgx; tgy = b[target.sc] + tgy;
+  }
+  const float rx = tgx - x1, ry = tgy - y1;
   const bool inb = (sqrtf(rx * rx + ry * ry) < 128.0f) && (Z > 0.2f) && (x1 > -64.0f) && (y1 > -64.0f) &&
                    (x1 < 2 * cx + 64.0f) && (y1 < 2 * cy + 64.0f);
   const float mask = inb ? 1.0f : 0.0f;
@@ -420,7 +429,7 @@ __device__ __forceinline__ void edge_terms(const float* __restrict__ poses, cons
 
 // ------------------------------------------------------------------------------------------------- accumulate
 struct AccCtx {
-  const float* poses; const float* patches; const float* target; const float* weight;
+  const float* poses; const float* patches; TargetSrc target; const float* weight;
   const int64_t* ii; const int64_t* jj; const int64_t* kk; const int* perm;
   float* patch_rec; float* edge_e;
   float fx, fy, cx, cy, lm;
@@ -434,7 +443,7 @@ struct AccCtx {
 __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, int a0, int m, float* S_lds, float* y_lds,
                                                        float* col, int lane) {
   const float* __restrict__ poses = K.poses; const float* __restrict__ patches = K.patches;
-  const float* __restrict__ target = K.target; const float* __restrict__ weight = K.weight;
+  const TargetSrc target = K.target; const float* __restrict__ weight = K.weight;
   const int64_t* __restrict__ ii = K.ii; const int64_t* __restrict__ jj = K.jj; const int64_t* __restrict__ kk = K.kk;
   const int* __restrict__ perm = K.perm;
   float* patch_rec = K.patch_rec; float* edge_e = K.edge_e;
@@ -594,7 +603,7 @@ __device__ __forceinline__ void block_of(int blk, int& fr, int& fc) {   // inver
 // LDS (dynamic): S_lds [n6 * LD] (lower triangle used), y_lds [n6], per-wave column buffers [ACC_WAVES][n6].
 __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
     const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
-    const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ lmbda,
+    const TargetSrc target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
     const int* __restrict__ perm, const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int P, int t0,
     int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int iter, int sig, int max_seg) {
@@ -645,7 +654,7 @@ constexpr int SCR_ROWS = 28;     // per-edge scratch rows: Jj_x[6] Jj_y[6] Ji_x[
 template <int NMAX>
 __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
-    const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ lmbda,
+    const TargetSrc target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
     const int* __restrict__ perm, const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int P, int t0,
     int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int iter, int sig, int max_seg) {
@@ -1465,10 +1474,35 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
                                   iterations, ws, ws_bytes, status_flag, stream);
 }
 
+static int ba_forward_impl(float* poses, float* patches, const float* intrinsics, const TargetSrc target, const float* weight,
+                           const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Nbuf,
+                           int Np, int P, int t0, int t1, int iterations, void* ws, size_t ws_bytes, int* status_flag,
+                           devo_stream_t stream);
+
 int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
                              const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Nbuf,
                              int Np, int P, int t0, int t1, int iterations, void* ws, size_t ws_bytes, int* status_flag,
                              devo_stream_t stream) {
+  return ba_forward_impl(poses, patches, intrinsics, TargetSrc{target, nullptr, 0, 0, 0}, weight, lmbda, ii, jj, kk, E, Nbuf, Np, P,
+                         t0, t1, iterations, ws, ws_bytes, status_flag, stream);
+}
+
+int devo_ba_forward_prepared_delta(float* poses, float* patches, const float* intrinsics, const float* coords, int coords_edge_stride,
+                                   int coords_xy_stride, int coords_centre, const float* delta, const float* weight,
+                                   const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Nbuf,
+                                   int Np, int P, int t0, int t1, int iterations, void* ws, size_t ws_bytes, int* status_flag,
+                                   devo_stream_t stream) {
+  DEVO_REQUIRE(coords != nullptr && coords_edge_stride > 0 && coords_xy_stride > 0 && coords_centre >= 0,
+               "devo_ba_forward_prepared_delta: coords %p, strides %d / %d, centre %d", (const void*)coords, coords_edge_stride,
+               coords_xy_stride, coords_centre);
+  return ba_forward_impl(poses, patches, intrinsics, TargetSrc{delta, coords, coords_edge_stride, coords_xy_stride, coords_centre},
+                         weight, lmbda, ii, jj, kk, E, Nbuf, Np, P, t0, t1, iterations, ws, ws_bytes, status_flag, stream);
+}
+
+static int ba_forward_impl(float* poses, float* patches, const float* intrinsics, const TargetSrc target, const float* weight,
+                           const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Nbuf,
+                           int Np, int P, int t0, int t1, int iterations, void* ws, size_t ws_bytes, int* status_flag,
+                           devo_stream_t stream) {
   int rc;
   if ((rc = ba_check_args("devo_ba_forward", E, Nbuf, Np, P, t0, t1))) return rc;
   const int N = t1 - t0;
@@ -1496,7 +1530,7 @@ int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsi
   const bool use_reg = (N <= 16) && !force_generic;
   const size_t acc_lds_used = use_reg ? sizeof(float) * (n6 * (n6 + 1) + n6 + REG_WAVES * n6 + 4 + REG_WAVES * SCR_ROWS * 64 +
                                                         REG_WAVES * ((size_t)N * (N + 1) / 2 * 36 + n6)) : acc_lds;
-  typedef void (*acc_fn_t)(const float*, const float*, const float*, const float*, const float*, const float*, const int64_t*,
+  typedef void (*acc_fn_t)(const float*, const float*, const float*, TargetSrc, const float*, const float*, const int64_t*,
                            const int64_t*, const int64_t*, const int*, const int*, BaMeta*, int, int, int, float*, float*,
                            float*, int, int, int);
   acc_fn_t acc_fn = k_ba_accumulate;

@@ -149,6 +149,17 @@ int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsi
                              const int64_t* kk, int E, int Nbuf, int Np, int P, int t0, int t1, int iterations,
                              void* ws, size_t ws_bytes, int* status_flag, devo_stream_t stream);
 
+/* devo_ba_forward_prepared with devo/devo.py:330 (`target = coords[..., P//2, P//2] + delta`) folded in: the target of
+ * edge e, component c is coords[e * coords_edge_stride + c * coords_xy_stride + coords_centre] + delta[2e + c] — the same
+ * single fp32 addition, so the result is bit-identical to forming `target` first; one elementwise launch less per
+ * update iteration.  coords: the f32 buffer devo_transform wrote ([E,2,P,P]: strides 2PP, PP, centre (P/2)(P+1);
+ * [E,P,P,2]: strides 2PP, 1, centre 2 (P/2)(P+1)); delta f32 [E,2] (the update operator's output). */
+int devo_ba_forward_prepared_delta(float* poses, float* patches, const float* intrinsics, const float* coords,
+                                   int coords_edge_stride, int coords_xy_stride, int coords_centre, const float* delta,
+                                   const float* weight, const float* lmbda, const int64_t* ii, const int64_t* jj,
+                                   const int64_t* kk, int E, int Nbuf, int Np, int P, int t0, int t1, int iterations,
+                                   void* ws, size_t ws_bytes, int* status_flag, devo_stream_t stream);
+
 size_t devo_neighbors_workspace_bytes(int E);
 
 /* cuda_ba.neighbors  (ba.cpp:154 -> ba.cpp:104-149): for every edge the previous / next edge of the same

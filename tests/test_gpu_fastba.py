@@ -334,3 +334,36 @@ def test_prepare_with_plan_equals_the_two_separate_calls():
     cuda_ba.forward(pa, qa, args[2], tgt, w, lm, ii, jj, kk, 1, n, 2, ws=ws_a, prepared=True)
     cuda_ba.forward(pb, qb, args[2], tgt, w, lm, ii, jj, kk, 1, n, 2)
     assert torch.equal(pa, pb) and torch.equal(qa, qb)
+
+
+@pytest.mark.parametrize("layout", ["2pp", "pp2"])
+def test_forward_delta_equals_forward_on_the_formed_target(layout):
+    """devo.py:330 folded into the BA (devo_ba_forward_prepared_delta): bit-identical poses and patches to forming
+    target = coords[..., 1, 1] + delta with torch first."""
+    from devo_amd.backends import cuda_ba
+    nk, M, H, W = 9, 40, 120, 160
+    poses = synth.make_poses(nk, 5)
+    patches, _ = synth.make_patches(nk, M, H, W, seed=5)
+    intr = synth.make_intrinsics(nk, H, W)
+    dev = lambda t: t.to(DEV)
+    ii, jj, kk = synth.full_graph(nk, M)
+    E = len(ii)
+    delta, weight = synth.make_update_outputs(E, 7, sigma=0.4)
+    lm = torch.tensor([1e-4])
+    Np = patches.shape[1] if patches.dim() == 5 else patches.shape[0]
+    outs = []
+    for fused in (False, True):
+        P_, Q_ = dev(poses.clone()), dev(patches.clone())
+        ws = cuda_ba.workspace(E, Np, nk - 1, torch.device(DEV))
+        cuda_ba.prepare(dev(kk), Np, nk - 1, ws)
+        c = cuda_ba.transform(P_, Q_, dev(intr), dev(ii), dev(jj), dev(kk), layout=layout)
+        if fused:
+            cuda_ba.forward_delta(P_, Q_, dev(intr), c, dev(delta), dev(weight), dev(lm), dev(ii), dev(jj), dev(kk), 1, nk, 2, ws,
+                                  layout=layout)
+        else:
+            centre = c[:, :, :, 1, 1] if layout == "2pp" else c[:, :, 1, 1, :2]
+            cuda_ba.forward(P_, Q_, dev(intr), centre + dev(delta), dev(weight), dev(lm), dev(ii), dev(jj), dev(kk), 1, nk, 2,
+                            ws=ws, prepared=True)
+        outs.append((P_.cpu(), Q_.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not torch.equal(outs[0][0], poses)

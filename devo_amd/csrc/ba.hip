@@ -1118,28 +1118,84 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   // collected in LDS (a global store inside the loop would put a vmcnt wait into every step's fence).
   if (tid >= 64) return;
   const unsigned long long st3 = stamps ? __builtin_readcyclecounter() : 0ull;
+  // Register form: lane r keeps z[r] and z[r + 64] (n6 <= 128 here).  One wave issues one instruction every ~5 cycles, so
+  // a step is priced by its instruction count: the block's six z values come through v_readlane, lane c < 6 forms x_b[c]
+  // from column c of the inverse block (6 FMAs), x_b goes back to all lanes through v_readlane, every lane updates its own
+  // rows (rows >= 64 only matter for the last blocks) — no LDS access and no fence in the dependency chain.  The LDS
+  // operands of a step (inverse block, the block's rows of L) do not depend on the solution: fetched one step ahead.
   float* z = A + n6 * LD;
-  for (int jb = N - 1; jb >= 0; jb--) {
+  if (n6 <= 128) {
+  const int lr0 = min(tid, n6 - 1), lr1 = min(tid + 64, n6 - 1), lc = min(tid, 5);
+  float z0 = (tid < n6) ? z[tid] : 0.0f, z1 = (tid + 64 < n6) ? z[tid + 64] : 0.0f;
+  struct StepOps { float li[6], a0[6]; };
+  auto fetch = [&](int jb, StepOps& o) {
+    const float* Lb = Li + jb * 36 + lc;
+    const float* rowp = A + (6 * jb) * LD + lr0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { o.li[k] = Lb[k * 6]; o.a0[k] = rowp[k * LD]; }    // (L^-T)[c][k] = (L^-1)[k][c], 0 for k < c
+  };
+  auto lane_value = [](float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); };
+  auto step = [&](int jb, const StepOps& o) {
     const int j0 = 6 * jb;
-    float zb[6], xb[6];
+    float xc = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 6; c++) zb[c] = z[j0 + c];
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-      float v = 0.0f;
-#pragma unroll
-      for (int k = c; k < 6; k++) v += Li[jb * 36 + k * 6 + c] * zb[k];       // (L^-T)[c][k] = (L^-1)[k][c]
-      xb[c] = v;
+    for (int k = 0; k < 6; k++) {
+      const int r = j0 + k;                                        // wave-uniform
+      xc += o.li[k] * lane_value((r >= 64) ? z1 : z0, r & 63);
     }
-    if (tid < 6) xs[j0 + tid] = (tid == 0) ? xb[0] : (tid == 1) ? xb[1] : (tid == 2) ? xb[2] : (tid == 3) ? xb[3] : (tid == 4) ? xb[4] : xb[5];
-    wave_lds_sync();                             // all reads of z[j0..j0+5] done before rows above are updated
-    for (int r = tid; r < j0; r += 64) {
-      float v = 0.0f;
+    if (tid < 6) xs[j0 + tid] = xc;
+    float xb[6];
 #pragma unroll
-      for (int k = 0; k < 6; k++) v += A[(j0 + k) * LD + r] * xb[k];
-      z[r] -= v;
+    for (int k = 0; k < 6; k++) xb[k] = lane_value(xc, k);
+    float v0 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) v0 += o.a0[k] * xb[k];
+    if (tid < j0) z0 -= v0;
+    if (j0 > 64) {                                                 // wave-uniform
+      const float* rowp = A + j0 * LD + lr1;
+      float v1 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 6; k++) v1 += rowp[k * LD] * xb[k];
+      if (tid + 64 < j0) z1 -= v1;
     }
-    wave_lds_sync();
+  };
+  {
+    StepOps oa, ob;
+    int jb = N - 1;
+    fetch(jb, oa);
+    while (true) {
+      fetch(max(jb - 1, 0), ob);                                   // (unconditional: a branch around loads costs a full wait at the join)
+      step(jb, oa);
+      if (--jb < 0) break;
+      fetch(max(jb - 1, 0), oa);
+      step(jb, ob);
+      if (--jb < 0) break;
+    }
+  }
+  wave_lds_sync();
+  } else {                                        // more than 21 optimised poses: z stays in LDS
+    for (int jb = N - 1; jb >= 0; jb--) {
+      const int j0 = 6 * jb;
+      float zb[6], xb[6];
+  #pragma unroll
+      for (int c = 0; c < 6; c++) zb[c] = z[j0 + c];
+  #pragma unroll
+      for (int c = 0; c < 6; c++) {
+        float v = 0.0f;
+  #pragma unroll
+        for (int k = c; k < 6; k++) v += Li[jb * 36 + k * 6 + c] * zb[k];       // (L^-T)[c][k] = (L^-1)[k][c]
+        xb[c] = v;
+      }
+      if (tid < 6) xs[j0 + tid] = (tid == 0) ? xb[0] : (tid == 1) ? xb[1] : (tid == 2) ? xb[2] : (tid == 3) ? xb[3] : (tid == 4) ? xb[4] : xb[5];
+      wave_lds_sync();                             // all reads of z[j0..j0+5] done before rows above are updated
+      for (int r = tid; r < j0; r += 64) {
+        float v = 0.0f;
+  #pragma unroll
+        for (int k = 0; k < 6; k++) v += A[(j0 + k) * LD + r] * xb[k];
+        z[r] -= v;
+      }
+      wave_lds_sync();
+    }
   }
   for (int i = tid; i < n6; i += 64) dX[i] = xs[i];
   if (stamps && tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st3; g_solve_stamps[4] = __builtin_readcyclecounter(); }

@@ -33,10 +33,14 @@ struct BaMeta { int n_seg; int fail; int sig; int pad; };   // sig: what the wor
 __host__ __device__ __forceinline__ int ba_sig(int E, int N) { return (int)(0x5ec0de00u ^ ((unsigned)E * 2654435761u) ^ ((unsigned)N << 24)); }
 
 // ------------------------------------------------------------------------------------------------- utilities
+// Sum over the 64 lanes, returned to all of them (a scalar): DPP row shifts + row broadcasts leave the total in lane 63
+// (6 vector instructions, no LDS round trips like a ds_bpermute butterfly).  All 64 lanes must be active.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+#define DEVO_DPP_ADD(ctrl, rows) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xf, false))
+  DEVO_DPP_ADD(0x111, 0xf); DEVO_DPP_ADD(0x112, 0xf); DEVO_DPP_ADD(0x114, 0xf); DEVO_DPP_ADD(0x118, 0xf);   // row_shr 1 2 4 8
+  DEVO_DPP_ADD(0x142, 0xa); DEVO_DPP_ADD(0x143, 0xc);                                                       // row_bcast 15, 31
+#undef DEVO_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ unsigned wave_or(unsigned v) {
 #pragma unroll
@@ -1018,7 +1022,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   }
 
   const unsigned long long st1 = stamps ? __builtin_readcyclecounter() : 0ull;
+  unsigned long long ph_panel = 0, ph_update = 0;
   for (int jb = 0; jb < N; jb++) {
+    const unsigned long long pa = stamps ? __builtin_readcyclecounter() : 0ull;
     const int j0 = 6 * jb;
     const int r = j0 + 6 + tid;                  // this thread's panel row (if any)
     if (r < rows || tid == 0) {
@@ -1050,6 +1056,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
       }
     }
     __syncthreads();
+    const unsigned long long pb = stamps ? __builtin_readcyclecounter() : 0ull;
     // trailing update of the lower triangle (and of the rhs row) in 2x2 tiles; inputs = the panel columns, outputs =
     // the columns to their right (disjoint), so everything is fetched before anything is written back
     const int rem = rows - (j0 + 6);
@@ -1083,6 +1090,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
       if (r1ok && c1ok) A[r1 * LD + c1] = o11 - v11;
     }
     __syncthreads();
+    if (stamps) { const unsigned long long pc = __builtin_readcyclecounter(); ph_panel += pb - pa; ph_update += pc - pb; }
   }
   const unsigned long long st2 = stamps ? __builtin_readcyclecounter() : 0ull;
   if (s_fail) {
@@ -1198,7 +1206,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     }
   }
   for (int i = tid; i < n6; i += 64) dX[i] = xs[i];
-  if (stamps && tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st3; g_solve_stamps[4] = __builtin_readcyclecounter(); }
+  if (stamps && tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st3; g_solve_stamps[4] = __builtin_readcyclecounter(); g_solve_stamps[5] = ph_panel; g_solve_stamps[6] = ph_update; }
 }
 
 // ------------------------------------------------------------------------------------------------- retract
@@ -1612,7 +1620,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
         unsigned long long h[8];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_solve_stamps), sizeof(h));
-        fprintf(stderr, "[ba trace] solve: load %llu, factorisation %llu, block inverses %llu, back substitution %llu cycles\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3]);
+        fprintf(stderr, "[ba trace] solve: load %llu, factorisation %llu, block inverses %llu, back substitution %llu cycles (factorisation: panel %llu + update %llu)\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5], h[6]);
       }
       if ((rc = check_launch("devo_ba_forward(solve)"))) return rc;
     }

@@ -33,14 +33,10 @@ struct BaMeta { int n_seg; int fail; int sig; int pad; };   // sig: what the wor
 __host__ __device__ __forceinline__ int ba_sig(int E, int N) { return (int)(0x5ec0de00u ^ ((unsigned)E * 2654435761u) ^ ((unsigned)N << 24)); }
 
 // ------------------------------------------------------------------------------------------------- utilities
-// Sum over the 64 lanes, returned to all of them (a scalar): DPP row shifts + row broadcasts leave the total in lane 63
-// (6 vector instructions, no LDS round trips like a ds_bpermute butterfly).  All 64 lanes must be active.
 __device__ __forceinline__ float wave_sum(float v) {
-#define DEVO_DPP_ADD(ctrl, rows) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xf, false))
-  DEVO_DPP_ADD(0x111, 0xf); DEVO_DPP_ADD(0x112, 0xf); DEVO_DPP_ADD(0x114, 0xf); DEVO_DPP_ADD(0x118, 0xf);   // row_shr 1 2 4 8
-  DEVO_DPP_ADD(0x142, 0xa); DEVO_DPP_ADD(0x143, 0xc);                                                       // row_bcast 15, 31
-#undef DEVO_DPP_ADD
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
 }
 __device__ __forceinline__ unsigned wave_or(unsigned v) {
 #pragma unroll

@@ -297,11 +297,13 @@ def test_ba_random_graphs(seed):
     check(run_ba(*s, t0, n, 2), ref)
 
 
-def test_ba_more_than_16_optimised_poses_uses_the_general_kernel():
-    """N = t1 - t0 in 17..32: the LDS-atomic accumulate kernel (no register-resident S)"""
-    s = scene(n=22, M=4, H=96, W=128, seed=77, keep=0.9, sigma=0.5)
-    ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], 1, 22, 2, dtype=torch.float64)
-    check(run_ba(*s, 1, 22, 2), ref)
+@pytest.mark.parametrize("n", [22, 28])
+def test_ba_more_than_16_optimised_poses_uses_the_general_kernel(n):
+    """N = t1 - t0 in 17..32: the LDS-atomic accumulate kernel (no register-resident S); the solve's back substitution keeps
+    z in registers up to 6 N = 128 (n = 22: 126 rows, both register rows in use) and in LDS beyond (n = 28)."""
+    s = scene(n=n, M=4, H=96, W=128, seed=77, keep=0.9, sigma=0.5)
+    ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], 1, n, 2, dtype=torch.float64)
+    check(run_ba(*s, 1, n, 2), ref)
 
 
 def test_prepare_with_plan_equals_the_two_separate_calls():

@@ -431,7 +431,7 @@ __device__ __forceinline__ void edge_terms(const float* __restrict__ poses, cons
 struct AccCtx {
   const float* poses; const float* patches; TargetSrc target; const float* weight;
   const int64_t* ii; const int64_t* jj; const int64_t* kk; const int* perm;
-  float* patch_rec; float* edge_e;
+  float* patch_rec; float* patch_col;    // per patch: (Q, u) and its E column [6 N] (dz = Q (u - E^T dX), ba_cuda.cu:523)
   float fx, fy, cx, cy, lm;
   int P, t0, N, n6, LD;
 };
@@ -446,7 +446,7 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
   const TargetSrc target = K.target; const float* __restrict__ weight = K.weight;
   const int64_t* __restrict__ ii = K.ii; const int64_t* __restrict__ jj = K.jj; const int64_t* __restrict__ kk = K.kk;
   const int* __restrict__ perm = K.perm;
-  float* patch_rec = K.patch_rec; float* edge_e = K.edge_e;
+  float* patch_rec = K.patch_rec; float* patch_col = K.patch_col;
   const float fx = K.fx, fy = K.fy, cx = K.cx, cy = K.cy, lm = K.lm;
   const int P = K.P, t0 = K.t0, N = K.N, n6 = K.n6, LD = K.LD;
   for (int i = lane; i < n6; i += 64) col[i] = 0.0f;
@@ -480,11 +480,6 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
     for (int c = 0; c < 6; c++) {
       ej[c] = (jx >= 0) ? (wz0 * T.Jj[0][c] + wz1 * T.Jj[1][c]) : 0.0f;       // E_j += w Jz Jj   (:311)
       ei[c] = (ix >= 0) ? -(wz0 * T.Ji[0][c] + wz1 * T.Ji[1][c]) : 0.0f;      // E_i -= w Jz Ji   (:309)
-    }
-    if (act) {
-      float* rec = edge_e + ((int64_t)(a0 + base + lane)) * 12;
-#pragma unroll
-      for (int c = 0; c < 6; c++) { rec[c] = ej[c]; rec[6 + c] = ei[c]; }
     }
     if (N > 0) {
       if (jx >= 0) fmask |= 1u << jx;
@@ -568,6 +563,8 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
 #pragma unroll
     for (int g = 0; g < 3; g++) cr[g] = (lane + 64 * g < n6) ? col[lane + 64 * g] : 0.0f;
 #pragma unroll
+    for (int g = 0; g < 3; g++) if (lane + 64 * g < n6) patch_col[(int64_t)s * n6 + lane + 64 * g] = cr[g];   // for the retraction
+#pragma unroll
     for (int g = 0; g < 3; g++) {
       if (64 * g >= n6) break;                                          // uniform
       const int r = lane + 64 * g;
@@ -606,7 +603,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
     const TargetSrc target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
     const int* __restrict__ perm, const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int P, int t0,
-    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int iter, int sig, int max_seg) {
+    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ patch_col, int iter, int sig, int max_seg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n6 = 6 * N, LD = n6 + 1;
   float* S_lds = smem;
@@ -616,7 +613,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
   float* col = col_all + wave * n6;
   for (int i = tid; i < n6 * LD + n6; i += ACC_THREADS) smem[i] = 0.0f;
   __syncthreads();
-  AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, edge_e, intr[0], intr[1], intr[2], intr[3], lmbda[0],
+  AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, patch_col, intr[0], intr[1], intr[2], intr[3], lmbda[0],
            P, t0, N, n6, LD};
   // a workspace that was not prepared for this (E, N) is not touched: the call fails (status -1) instead of walking
   // garbage tables; a prepared graph may be solved many times (the sticky failure flag is reset here)
@@ -657,7 +654,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     const TargetSrc target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
     const int* __restrict__ perm, const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int P, int t0,
-    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ edge_e, int iter, int sig, int max_seg) {
+    int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ patch_col, int iter, int sig, int max_seg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n6 = 6 * N, LD = n6 + 1;
   float* S_lds = smem;
@@ -676,7 +673,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     if (tid == 0) s_used_atomic = 0;
   }
   __syncthreads();
-  AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, edge_e, intr[0], intr[1], intr[2], intr[3], lmbda[0],
+  AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, patch_col, intr[0], intr[1], intr[2], intr[3], lmbda[0],
            P, t0, N, n6, LD};
 
   const int pa = (lane < 36) ? lane / 6 : 0, pb = (lane < 36) ? lane % 6 : 0;    // this lane's position inside a 6x6 block
@@ -755,9 +752,6 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
       }
       scr[24 * 64 + slot] = T.w[0]; scr[25 * 64 + slot] = T.w[1];
       scr[26 * 64 + slot] = wr0;    scr[27 * 64 + slot] = wr1;
-      float* rec = edge_e + ((int64_t)(a0 + lane)) * 12;
-#pragma unroll
-      for (int c = 0; c < 6; c++) { rec[c] = ej[c]; rec[6 + c] = ei[c]; }
       if (jx >= 0) {
 #pragma unroll
         for (int c = 0; c < 6; c++) col[6 * jx + c] = ej[c];    // distinct target frames: plain stores
@@ -776,6 +770,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     if (lane == 0) { patch_rec[(int64_t)s * 2] = Q; patch_rec[(int64_t)s * 2 + 1] = usum; }
     wave_lds_sync();
     if (N == 0) continue;
+    for (int i = lane; i < n6; i += 64) patch_col[(int64_t)s * n6 + i] = col[i];  // the patch's E column, for the retraction
 
     // ---- fold the patch into the register-resident block triangle.  Everything a lane needs is pulled into registers
     //      with wide LDS reads first (frame slots 0..NSL-1: element [pa] / [pb] of every Jacobian row), then the 6x6 block
@@ -1208,31 +1203,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
 // ------------------------------------------------------------------------------------------------- retract
 // poses[t0+i] <- Exp(dX_i) * poses[t0+i]  (ba_cuda.cu:160-188);  d <- d + dz; d>20 -> 1; d >= 1e-4 (:191-211)
 __global__ void k_ba_retract(float* __restrict__ poses, float* __restrict__ patches, const float* __restrict__ dX,
-                             const float* __restrict__ patch_rec, const float* __restrict__ edge_e,
-                             const int64_t* __restrict__ jj, const int* __restrict__ perm, const int* __restrict__ seg_start,
-                             const int* __restrict__ kx, const int64_t* __restrict__ ii, const BaMeta* __restrict__ meta, int P,
-                             int t0, int N) {
+                             const float* __restrict__ patch_rec, const float* __restrict__ patch_col,
+                             const int* __restrict__ kx, const BaMeta* __restrict__ meta, int P, int t0, int N) {
   if (meta->fail) return;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = blockDim.x * gridDim.x;
   const int lane = threadIdx.x & 63, wave = gid >> 6, nwaves = gsz >> 6;
-  const int n_seg = meta->n_seg;
-  for (int s = wave; s < n_seg; s += nwaves) {                      // one wave per patch, lanes over its edges
-    const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
+  const int n_seg = meta->n_seg, n6 = 6 * N;
+  for (int s = wave; s < n_seg; s += nwaves) {                      // one wave per patch, lanes over the rows of its E column
     float part = 0.0f;
     if (N > 0) {
-      for (int q = lane; q < m; q += 64) {
-        const int e = perm[a0 + q];
-        const int ix = (int)ii[e] - t0, jx = (int)jj[e] - t0;
-        const float* er = edge_e + (int64_t)(a0 + q) * 12;
-        if (jx >= 0 && jx < N) {
-#pragma unroll
-          for (int c = 0; c < 6; c++) part += er[c] * dX[6 * jx + c];
-        }
-        if (ix >= 0 && ix < N) {
-#pragma unroll
-          for (int c = 0; c < 6; c++) part += er[6 + c] * dX[6 * ix + c];
-        }
-      }
+      const float* pc = patch_col + (int64_t)s * n6;
+      for (int i = lane; i < n6; i += 64) part += pc[i] * dX[i];
       part = wave_sum(part);
     }
     const float dz = patch_rec[(int64_t)s * 2] * (patch_rec[(int64_t)s * 2 + 1] - part);   // Q (u - E^T dX)  (ba_cuda.cu:523)
@@ -1392,7 +1373,7 @@ static BaLayout ba_layout(int E, int Np, int N) {
   L.y = take(sizeof(float) * (n6 + 1));
   L.dX = take(sizeof(float) * (n6 + 1));
   L.patch_rec = take(sizeof(float) * 2 * (size_t)L.max_seg);
-  L.edge_ej = take(sizeof(float) * 12 * (size_t)(E > 0 ? E : 1));
+  L.edge_ej = take(sizeof(float) * (size_t)L.max_seg * (n6 > 0 ? n6 : 1));      // E column of every patch
   L.total = off;
   return L;
 }
@@ -1621,7 +1602,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       if ((rc = check_launch("devo_ba_forward(solve)"))) return rc;
     }
     hipLaunchKernelGGL(k_ba_retract, dim3(blocks_for((long long)L.max_seg * 64 > N ? (long long)L.max_seg * 64 : N, 256, 2048)), dim3(256), 0, st, poses, patches, dX, patch_rec,
-                       edge_ej, jj, perm_b, counts, kx, ii, meta, P, t0, N);
+                       edge_ej, kx, meta, P, t0, N);
     if ((rc = check_launch("devo_ba_forward(retract)"))) return rc;
   }
   return check_launch("devo_ba_forward");

@@ -899,8 +899,8 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
 }
 
 // S = sum of the compact partials, mirrored; S_dd <- S_dd*(1+1e-4)+1 (ba_cuda.cu:517-518); y = sum.
-// 256-thread workgroups: wave g sums partials [g*n_part/4, (g+1)*n_part/4) for 64 consecutive outputs (8 loads in
-// flight), the four wave results are combined through LDS in a fixed order.
+// 512-thread workgroups: wave g sums partials [g*n_part/8, (g+1)*n_part/8) for 64 consecutive outputs (32 loads in
+// flight), the eight wave results are combined through LDS in a fixed order.
 __global__ __launch_bounds__(512) void k_ba_reduce(const float* __restrict__ partials, int n_part, int N, float* __restrict__ S,
                                                    float* __restrict__ y) {
   // One lane per entry of the COMPACT partial (lower block triangle + right-hand side): consecutive lanes read consecutive
@@ -915,12 +915,15 @@ __global__ __launch_bounds__(512) void k_ba_reduce(const float* __restrict__ par
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (o < stride) {
     const float* base = partials + o;
-    int p = p0;
-    for (; p + 8 <= p1; p += 8) {
+    // 32 loads in flight per lane (one round trip for the usual 256 partials), added in the order p0, p0 + 1, ... into the
+    // eight accumulators exactly as a plain loop would
+    for (int q0 = p0; q0 < p1; q0 += 32) {
+      float v[32];
 #pragma unroll
-      for (int u = 0; u < 8; u++) acc[u] += base[(int64_t)(p + u) * stride];
+      for (int k = 0; k < 32; k++) v[k] = (q0 + k < p1) ? base[(int64_t)(q0 + k) * stride] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 32; k++) if (q0 + k < p1) acc[k & 7] += v[k];
     }
-    for (; p < p1; p++) acc[(p - p0) & 7] += base[(int64_t)p * stride];
   }
   s_sum[g][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();

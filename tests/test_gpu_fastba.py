@@ -369,3 +369,27 @@ def test_forward_delta_equals_forward_on_the_formed_target(layout):
         outs.append((P_.cpu(), Q_.cpu()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert not torch.equal(outs[0][0], poses)
+
+
+def test_ba_is_bit_reproducible_on_regular_graphs():
+    """Up to 16 optimised poses and regular patches: fixed summation orders, no floating-point atomics — repeated calls on the
+    same inputs return the same bits (the reference's global atomicAdds, ba_cuda.cu:297-322, do not)."""
+    from devo_amd.backends import cuda_ba
+    nk, M, H, W = 12, 48, 120, 160
+    poses = synth.make_poses(nk, 9).to(DEV)
+    patches = synth.make_patches(nk, M, H, W, seed=9)[0].to(DEV)
+    intr = synth.make_intrinsics(nk, H, W).to(DEV)
+    ii, jj, kk = [t.to(DEV) for t in synth.full_graph(nk, M)]
+    delta, weight = [t.to(DEV) for t in synth.make_update_outputs(len(ii), 9, sigma=0.3)]
+    lm = torch.tensor([1e-4], device=DEV)
+    c = cuda_ba.transform(poses, patches, intr, ii, jj, kk, layout="2pp")
+    target = c[:, :, :, 1, 1] + delta
+    first = None
+    for _ in range(25):
+        P_, Q_ = poses.clone(), patches.clone()
+        cuda_ba.forward(P_, Q_, intr, target, weight, lm, ii, jj, kk, 1, nk, 2)
+        if first is None:
+            first = (P_, Q_)
+            assert not torch.equal(P_, poses)
+        else:
+            assert torch.equal(P_, first[0]) and torch.equal(Q_, first[1])

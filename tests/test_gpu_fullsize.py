@@ -1,0 +1,89 @@
+"""Parity at BASELINE.json's FULL sizes (configuration 2 — the metric's — and the stress configuration 5), where the CPU
+oracle cannot run the whole problem in seconds: the fused two-level lookup is checked against the oracle on a random
+sample of edges, and through size-independent properties on ALL edges — the locality plan and the launch form never
+change a bit, the lookup is linear in the patch features; the bundle adjustment of configuration 2 is checked against
+the fp64 oracle in full.  Tolerance 1e-4 relative (north_star)."""
+import os
+import sys
+import pytest
+import torch
+from oracle import altcorr as A
+from oracle import fastba as F
+from util import rel_err
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _inputs(workload):
+    import bench
+    from devo_amd import synth
+    from devo_amd.backends import cuda_ba
+    cfg = synth.workload(workload)
+    d, cpu = bench.build_inputs(cfg, 4321, torch.device(DEV), torch.float32, "blk8")
+    coords = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
+    return cfg, d, cpu, coords
+
+
+@pytest.mark.parametrize("workload,sample", [("cfg2", 96), ("stress", 24)])
+def test_lookup_at_full_size(workload, sample):
+    from devo_amd.backends import cuda_corr
+    cfg, d, cpu, coords = _inputs(workload)
+    n, R, H = cfg["n"], cfg["R"], cfg["H"]
+    E = d["ii"].numel()
+    per = (2 * R + 1) ** 2 * 9
+    look = lambda g, order: cuda_corr.forward_pyramid(g, d["pyramid"], coords, d["kk"], d["jj"], R, (1, 4), order=order)
+    plan = cuda_corr.plan(coords, d["jj"], n, H, radius=R)
+    out = look(d["gmap"], plan)
+    assert out.shape == (1, E, 2 * per) and bool(torch.isfinite(out).all())
+
+    # (1) the oracle on a random sample of edges (devo/altcorr/correlation_kernel.cu:19-86 restated)
+    sel = torch.randperm(E, generator=torch.Generator().manual_seed(1))[:sample]
+    c_cpu = coords.cpu()[:, sel]
+    kk, jj = cpu["kk"][sel], cpu["jj"][sel]
+    from devo_amd import synth
+    f1l = synth.pyramid_l1(cpu["fmap"])
+    ref = torch.stack([A.corr_forward(cpu["gmap"], cpu["fmap"], c_cpu, kk, jj, R),
+                       A.corr_forward(cpu["gmap"], f1l, c_cpu / 4, kk, jj, R)], -1).reshape(1, sample, -1)
+    assert rel_err(out.cpu()[:, sel], ref) <= 1e-4
+
+    # (2) the plan and the launch form only decide which edges run together: not one bit changes
+    no_plan = torch.arange(E, dtype=torch.int32, device=DEV)
+    no_plan = torch.cat([no_plan, torch.zeros(E + 1, dtype=torch.int32, device=DEV)])      # identity order, no heavy class
+    assert torch.equal(look(d["gmap"], no_plan), out)
+    lv = [cuda_corr.forward(d["gmap"], fm, coords / s, d["kk"], d["jj"], R)[0].reshape(1, E, per) for fm, s in zip(d["pyramid"], (1.0, 4.0))]
+    assert rel_err(torch.stack(lv, -1).reshape(1, E, -1), out) <= 1e-6          # per-level launches on coords / s (one rounding of the division apart)
+
+    # (3) linear in the patch features, on every edge
+    g2 = torch.randn_like(d["gmap"]) / 4
+    lhs = look(d["gmap"] + 2.0 * g2, plan)
+    rhs = out + 2.0 * look(g2, plan)
+    assert rel_err(lhs, rhs) <= 1e-5
+    # (4) every (edge, level) row was written: a poisoned output buffer has no poison left
+    buf = torch.full_like(out, float("nan"))
+    cuda_corr.forward_pyramid(d["gmap"], d["pyramid"], coords, d["kk"], d["jj"], R, (1, 4), out=buf, order=plan)
+    assert torch.equal(buf, out)
+
+
+def test_bundle_adjustment_at_configuration_2():
+    from devo_amd.backends import cuda_ba
+    cfg, d, cpu, coords = _inputs("cfg2")
+    n = cfg["n"]
+    E = d["ii"].numel()
+    Np = d["patches0"].shape[1]
+    P_, Q_ = d["poses0"].clone(), d["patches0"].clone()
+    delta = (0.3 * d["delta"]).contiguous()                               # sub-pixel updates (see __graft_entry__.smoke)
+    target = coords[:, :, :, 1, 1] + delta
+    cuda_ba.forward(P_, Q_, d["intr"], target, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2)
+    pr, qr = F.ba(cpu["poses"].double(), cpu["patches"].double(), cpu["intr"].double(), target.cpu().double(), cpu["weight"].double(),
+                  torch.tensor([1e-4]), cpu["ii"], cpu["jj"], cpu["kk"], 1, n, 2, dtype=torch.float64)
+    assert rel_err(P_.cpu()[..., :3], pr[..., :3]) <= 1e-4 and rel_err(P_.cpu()[..., 3:], pr[..., 3:]) <= 1e-4
+    assert rel_err(Q_.cpu()[:, :, 2], qr[:, :, 2]) <= 1e-4
+    assert torch.equal(Q_.cpu()[:, :, :2], cpu["patches"][:, :, :2])
+    # the same through the entry that forms the target itself, from a prepared workspace: identical bits
+    P2, Q2 = d["poses0"].clone(), d["patches0"].clone()
+    ws = cuda_ba.workspace(E, Np, n - 1, torch.device(DEV))
+    cuda_ba.prepare(d["kk"], Np, n - 1, ws)
+    cuda_ba.forward_delta(P2, Q2, d["intr"], coords, delta, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2, ws)
+    assert torch.equal(P2, P_) and torch.equal(Q2, Q_)

@@ -1,8 +1,8 @@
-"""Parity at BASELINE.json's FULL sizes (configuration 2 — the metric's — and the stress configuration 5), where the CPU
+"""Parity at BASELINE.json's FULL sizes (configurations 1, 2 — the metric's — and the stress configuration 5), where the CPU
 oracle cannot run the whole problem in seconds: the fused two-level lookup is checked against the oracle on a random
 sample of edges, and through size-independent properties on ALL edges — the locality plan and the launch form never
-change a bit, the lookup is linear in the patch features; the bundle adjustment of configuration 2 is checked against
-the fp64 oracle in full.  Tolerance 1e-4 relative (north_star)."""
+change a bit, the lookup is linear in the patch features; the bundle adjustment of configurations 1 and 2 is checked
+against the fp64 oracle in full.  Tolerance 1e-4 relative (north_star)."""
 import os
 import sys
 import pytest
@@ -26,7 +26,7 @@ def _inputs(workload):
     return cfg, d, cpu, coords
 
 
-@pytest.mark.parametrize("workload,sample", [("cfg2", 96), ("stress", 24)])
+@pytest.mark.parametrize("workload,sample", [("cfg1", 96), ("cfg2", 96), ("stress", 24)])
 def test_lookup_at_full_size(workload, sample):
     from devo_amd.backends import cuda_corr
     cfg, d, cpu, coords = _inputs(workload)
@@ -66,9 +66,10 @@ def test_lookup_at_full_size(workload, sample):
     assert torch.equal(buf, out)
 
 
-def test_bundle_adjustment_at_configuration_2():
+@pytest.mark.parametrize("workload", ["cfg1", "cfg2"])
+def test_bundle_adjustment_at_full_size(workload):
     from devo_amd.backends import cuda_ba
-    cfg, d, cpu, coords = _inputs("cfg2")
+    cfg, d, cpu, coords = _inputs(workload)
     n = cfg["n"]
     E = d["ii"].numel()
     Np = d["patches0"].shape[1]

@@ -1278,7 +1278,7 @@ __global__ void k_transform(const float* __restrict__ poses, const float* __rest
     const float* pk = patches + kk[e] * 3 * PPx;
     float Xc = 0, Yc = 0, Zc = 1, Hc = 0;
     int bx[9], by[9];                                            // integer pixels for the lookup's locality plan (P == 3)
-    float bcy = 0.0f;
+    float bcx = 0.0f, bcy = 0.0f;
     for (int i = 0; i < PPx; i++) {
       const float w = pk[2 * PPx + i];
       V3<float> X0{(pk[i] - cxi) / fxi, (pk[PPx + i] - cyi) / fyi, 1.0f};
@@ -1288,10 +1288,10 @@ __global__ void k_transform(const float* __restrict__ poses, const float* __rest
       const float u = fxj * (d * X1.x) + cxj, v = fyj * (d * X1.y) + cyj;
       if (c_pp2) { float* o = c_pp2 + ((int64_t)e * PPx + i) * nc; o[0] = u; o[1] = v; if (depth) o[2] = d; }
       if (c_2pp) { c_2pp[(int64_t)e * 2 * PPx + i] = u; c_2pp[(int64_t)e * 2 * PPx + PPx + i] = v; }
-      if (plan_bins && i < 9) { bx[i] = corr_floor_to_int(u); by[i] = corr_floor_to_int(v); if (i == 4) bcy = v; }
+      if (plan_bins && i < 9) { bx[i] = corr_floor_to_int(u); by[i] = corr_floor_to_int(v); if (i == 4) { bcx = u; bcy = v; } }
     }
     // the lookup's plan bins, while the coordinates are still in registers (saves the plan's own pass over coords)
-    if (plan_bins) plan_bins[e] = corr_plan_bin(bx, by, bcy, 0, (int)fj, plan_n2, plan_H2, plan_nb, plan_D, plan_ng);
+    if (plan_bins) plan_bins[e] = corr_plan_bin(bx, by, bcx, bcy, 0, (int)fj, plan_n2, plan_H2, plan_nb, plan_D, plan_ng);
     if (valid) valid[e] = (Zc > 0.2f) ? 1.0f : 0.0f;
     if (Jj) {
       const float d = (fabsf(Zc) > 0.2f) ? 1.0f / Zc : 0.0f;
@@ -1501,9 +1501,9 @@ int devo_ba_prepare_plan(const int64_t* kk, int E, int Np, int N, void* ws, size
   if (N > BA_MAXN) { set_error("devo_ba_prepare_plan: %d optimised poses > %d supported", N, BA_MAXN); return DEVO_ERR_UNSUPPORTED; }
   DEVO_REQUIRE(plan != nullptr && plan_frames > 0 && plan_height > 0, "devo_ba_prepare_plan: missing plan");
   if (E == 0) return DEVO_OK;
-  const int nb = corr_plan_bands(1, plan_frames, plan_height);
-  DEVO_REQUIRE(nb > 0, "devo_ba_prepare_plan: too many frames for a locality plan (%d)", plan_frames);
-  return ba_prepare_impl(kk, E, Np, N, ws, ws_bytes, (hipStream_t)stream, plan, plan_frames * nb);
+  const CorrPlanGeom pg = corr_plan_geom(1, plan_frames, plan_height);
+  DEVO_REQUIRE(pg.nb > 0, "devo_ba_prepare_plan: too many frames for a locality plan (%d)", plan_frames);
+  return ba_prepare_impl(kk, E, Np, N, ws, ws_bytes, (hipStream_t)stream, plan, (int)corr_plan_nbins(1, plan_frames, pg));
 }
 
 int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
@@ -1655,8 +1655,9 @@ int devo_transform(const float* poses, const float* patches, const float* intrin
   int nb = 0;
   if (plan) {
     DEVO_REQUIRE(P == 3 && plan_frames > 0 && plan_height > 0 && plan_radius >= 0 && plan_radius <= 5, "devo_transform: bad plan geometry");
-    nb = corr_plan_bands(1, plan_frames, plan_height);
-    DEVO_REQUIRE(nb > 0, "devo_transform: too many frames for a locality plan (%d)", plan_frames);
+    const CorrPlanGeom pg = corr_plan_geom(1, plan_frames, plan_height);
+    DEVO_REQUIRE(pg.nb > 0, "devo_transform: too many frames for a locality plan (%d)", plan_frames);
+    nb = corr_plan_pack(pg);
   }
   hipLaunchKernelGGL(k_transform, dim3(blocks_for(E, 128, 4096)), dim3(128), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
                      kk, coords_pp2, coords_2pp, valid, Ji, Jj, Jz, E, P, flags, plan ? plan + E + 1 : nullptr, plan_frames, plan_height,

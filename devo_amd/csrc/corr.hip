@@ -141,6 +141,7 @@ struct CorrLevel {
   int64_t block_stride;           // elements between consecutive channel blocks (unused for channels-last)
   unsigned frame_bytes;           // extent of one frame (all blocks) in bytes: the buffer-load bound of the matrix-core kernel
   bool staged_ok, mfma_ok;        // which of the two fast kernels can read this level
+  bool dense_ok;                  // ... and the region-staged dense matrix-core kernel (corr_dense.h)
   int64_t out_offset;             // element offset of this level inside an edge's output record
   float coord_div;                // coordinates are divided by this (pyramid level scale)
 };
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 
 #include "corr_dma.h"
 #include "corr_mfma.h"
+#include "corr_dense.h"
 
 // -------------------------------------------------------------------------------------------------
 // Locality plan: order[] = heavy edge slots, then the rest sorted by (batch, target frame, 16-row band of the
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(BIN_THREADS) void corr_bin_kernel(const float* __re
   int xs[PP], ys[PP];
 #pragma unroll
   for (int p = 0; p < PP; p++) { xs[p] = floor_to_int(c[p] / coord_div); ys[p] = floor_to_int(c[PP + p] / coord_div); }
-  const int bin = corr_plan_bin(xs, ys, c[PP + 4] / coord_div, b, (int)jj[e], n2, H2, nb, D, ng);
+  const int bin = corr_plan_bin(xs, ys, c[4] / coord_div, c[PP + 4] / coord_div, b, (int)jj[e], n2, H2, nb, D, ng);
   bins[be] = bin;
 }
 
@@ -679,6 +681,11 @@ using namespace devo;
 
 // Describes one level for the fast kernels; false = neither of them can read it (generic kernel, or an error for
 // channel-blocked storage, which only the fast kernels understand).
+static bool corr_dense_enabled() {               // DEVO_CORR_DENSE=1: the region-staged dense matrix-core kernel (opt-in, see corr_dense.h)
+  static const char* env = getenv("DEVO_CORR_DENSE");
+  static const bool on = env && env[0] == '1';
+  return on;
+}
 static bool corr_mfma_enabled() {                // DEVO_CORR_MFMA=0: fp32 lookups take the staged (tap-centric) kernel instead
   static const char* env = getenv("DEVO_CORR_MFMA");
   static const bool on = !(env && env[0] == '0');
@@ -705,7 +712,10 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
   const bool c_ok = sizeof(T) == 4 ? (C == 64 || C == 128) : (C == 128 || C == 256);            // 4 or 8 steps per pass
   lv->mfma_ok = aligned && sizeof(T) <= 4 && corr_mfma_enabled() && c_ok && cb_ok &&
                 frame_bytes < (1LL << 31);                                                             // 32-bit in-frame offsets
-  if (!lv->staged_ok && !lv->mfma_ok) {
+  // the dense kernel: any C that is a multiple of its channel slab (fp16: 32, fp32: 16), 16-byte pieces inside a channel block
+  lv->dense_ok = aligned && sizeof(T) <= 4 && corr_dense_enabled() && cb_ok && C % (sizeof(T) == 2 ? 32 : 16) == 0 &&
+                 C >= (sizeof(T) == 2 ? 64 : 32) && frame_bytes < (1LL << 31);                        // (at least two channel slabs)
+  if (!lv->staged_ok && !lv->mfma_ok && !lv->dense_ok) {
     if (blocked) {
       set_error("devo_corr_forward: channel-blocked fmap2 needs fp32 / fp16, 16-byte aligned strides and cblock == %d (got %d)", KC, cblock);
       *err = DEVO_ERR_UNSUPPORTED;
@@ -735,6 +745,34 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
   const size_t nrec = (size_t)BE * nlev;
   if (do_trace) { (void)hipMalloc(&trace, nrec * 64); (void)hipMemset(trace, 0, nrec * 64); }
   const bool mfma = lv0.mfma_ok && (nlev == 1 || lv1.mfma_ok);
+  const long long f1_bytes = (BE / (E > 0 ? E : 1)) * (long long)Np * C * PP * (long long)sizeof(T);
+  const bool dense = lv0.dense_ok && (nlev == 1 || lv1.dense_ok) && !do_trace && f1_bytes < (1LL << 31) && BE < (1LL << 31) - 64;
+  if (dense) {                                                        // region-staged dense matrix-core kernel (corr_dense.h)
+    typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;   // (never fp64: dense_ok is false)
+    typedef void (*dense_fn_t)(const MT*, CorrLevel, CorrLevel, const float*, const int64_t*, const int64_t*, MT*, int, int, int,
+                               int, int, int64_t, int64_t, int, const int*, unsigned long long*);
+    const dense_fn_t fn = nlev == 2 ? (R <= 3 ? corr_fwd_dense_kernel<MT, 3, 2> : corr_fwd_dense_kernel<MT, 5, 2>)
+                                    : (R <= 3 ? corr_fwd_dense_kernel<MT, 3, 1> : corr_fwd_dense_kernel<MT, 5, 1>);
+    const int chunk_edges = R <= 3 ? DnShape<3, 2>::CHUNK : DnShape<5, 2>::CHUNK;          // (the same for one level)
+    const long long nchunks = (BE + chunk_edges - 1) / chunk_edges;
+    const dim3 dgrid((unsigned)(8 * ((nchunks + 7) / 8))), dblock(DN_THREADS);
+    unsigned long long* stats = nullptr;                              // debug switch: round statistics to stderr
+    static const bool do_stats = getenv("DEVO_DN_STATS") != nullptr;
+    if (do_stats) { (void)hipMalloc(&stats, 128); (void)hipMemset(stats, 0, 128); }
+    hipLaunchKernelGGL(fn, dgrid, dblock, 0, st, (const MT*)fmap1, lv0, lv1, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C, oes,
+                       ols, R, order, stats);
+    if (do_stats) {
+      (void)hipDeviceSynchronize();
+      unsigned long long h[16];
+      (void)hipMemcpy(h, stats, 128, hipMemcpyDeviceToHost);
+      const double r = h[0] ? (double)h[0] : 1.0;
+      fprintf(stderr, "[dense stats] edges %lld, workgroups %u, rounds %llu (items/round %.2f, single-pixel rounds %llu), region positions/round: level 0 %.0f, level 1 %.0f, cycles/round %.0f\n",
+              BE, dgrid.x, h[0], h[1] / r, h[4], h[2] / r, h[3] / r, h[5] / r);
+      fprintf(stderr, "[dense stats] cycles/round by phase: setup+request %.0f | level 1: wait %.0f, products %.0f, epilogue %.0f, tail %.0f | level 0: wait %.0f, products %.0f, epilogue %.0f, tail %.0f\n",
+              h[6] / r, h[7] / r, h[8] / r, h[9] / r, h[10] / r, h[11] / r, h[12] / r, h[13] / r, h[14] / r);
+      (void)hipFree(stats);
+    }
+  } else
   if (mfma) {                                                         // matrix-core kernel (corr_mfma.h)
     static const char* split_env = getenv("DEVO_CORR_SPLIT_LEVELS");  // debug: fused lookups as two sets of workgroups
     const bool both = nlev == 2 && !(split_env && split_env[0] == '1') && !do_trace;
@@ -888,8 +926,9 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   DEVO_REQUIRE(B >= 0 && E >= 0 && n2 > 0 && H2 > 0 && coord_scale > 0.0f, "devo_corr_order: bad sizes");
   const long long BE = (long long)B * E;
   if (BE == 0) return DEVO_OK;
-  const int nb = corr_plan_bands(B, n2, H2);
-  DEVO_REQUIRE(nb > 0 && BE < (1LL << 30), "devo_corr_order: too many frames (%d x %d)", B, n2);
+  const CorrPlanGeom pg = corr_plan_geom(B, n2, H2);
+  const int nb = corr_plan_pack(pg);
+  DEVO_REQUIRE(pg.nb > 0 && BE < (1LL << 30), "devo_corr_order: too many frames (%d x %d)", B, n2);
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_order: radius %d unsupported (max 5)", radius);
   int* bins = order + BE + 1;                                 // scratch half of the plan buffer
   if (coords != nullptr)                                      // NULL: devo_transform has already written the bins
@@ -905,7 +944,7 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   if (stage_bytes > 48 * 1024) {
     if (hipFuncSetAttribute((const void*)order_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes) != hipSuccess) (void)hipGetLastError();
   }
-  hipLaunchKernelGGL(order_fn, dim3(1), dim3(ORDER_THREADS), stage_bytes, (hipStream_t)stream, bins, (int)BE, B * n2 * nb, order,
+  hipLaunchKernelGGL(order_fn, dim3(1), dim3(ORDER_THREADS), stage_bytes, (hipStream_t)stream, bins, (int)BE, (int)corr_plan_nbins(B, n2, pg), order,
                      (int)(stage_bytes / 4));
   return check_launch("devo_corr_order");
 }

@@ -23,9 +23,13 @@ __host__ __device__ __forceinline__ bool tile_fits(int w, int h, int ng) {
 
 
 // Plan bin of an edge from its 9 window origins: -1 = HEAVY (the union box does not fit the tile), else
-// (batch, target frame, 16-row band of the patch centre).  x[p], y[p]: integer pixel of patch pixel p at the plan's level.
-__device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float centre_y, int b, int frame, int n2, int H2, int nb,
-                                             int D, int ng) {
+// (batch, target frame, 16-row band of the patch centre, column bin of the patch centre) — consecutive edges of the sorted
+// plan land next to each other in the image, which is what the region-staged lookup kernel (corr_dense.h) groups on.
+// x[p], y[p]: integer pixel of patch pixel p at the plan's level.  `geom` = corr_plan_pack(): bands | column bins << 8 |
+// column-bin width << 16.
+__device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float centre_x, float centre_y, int b, int frame, int n2,
+                                             int H2, int geom, int D, int ng) {
+  const int nb = geom & 0xff, nxb = (geom >> 8) & 0xff, xw = geom >> 16;
   int xlo = x[0], xhi = x[0], ylo = y[0], yhi = y[0];
 #pragma unroll
   for (int p = 1; p < 9; p++) { xlo = min(xlo, x[p]); xhi = max(xhi, x[p]); ylo = min(ylo, y[p]); yhi = max(yhi, y[p]); }
@@ -34,18 +38,34 @@ __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float c
   if ((long long)(xhi - xlo + D) * (yhi - ylo + D) > 128 || !tile_fits(xhi - xlo + D, yhi - ylo + D, ng)) return -1;
   int band = (int)(fminf(fmaxf(centre_y, 0.0f), (float)(H2 - 1))) / 16;
   band = min(max(band, 0), nb - 1);
+  int xb = (int)(fminf(fmaxf(centre_x, 0.0f), 1.0e6f)) / xw;
+  xb = min(max(xb, 0), nxb - 1);
   const int f = min(max(frame, 0), n2 - 1);
-  return (b * n2 + f) * nb + band;
+  return ((b * n2 + f) * nb + band) * nxb + xb;
 }
 
-// number of row bands per frame in the plan's bins (coarser if there are many frames: the counting sort keeps one LDS
-// counter per bin); 0 = too many frames
-constexpr int CORR_ORDER_MAXBINS = 4096;
-inline int corr_plan_bands(long long B, int n2, int H2) {
-  int nb = (H2 + 15) / 16;
-  while (B * n2 * nb > CORR_ORDER_MAXBINS && nb > 1) nb = (nb + 1) / 2;
-  return (B * n2 * nb <= CORR_ORDER_MAXBINS) ? nb : 0;
+// Bins of the plan: row bands of 16 rows per frame (coarser if there are many frames: the counting sort keeps one LDS
+// counter per bin) x column bins of >= 8 px (the frame width is not part of the plan's interface: columns beyond
+// nxb * xw share the last bin; widths up to 2 * H2 are covered).  nb == 0 = too many frames.
+constexpr int CORR_ORDER_MAXBINS = 4096;        // (one LDS counter per bin next to the ordering kernel's staging buffer)
+struct CorrPlanGeom { int nb, nxb, xw; };
+inline CorrPlanGeom corr_plan_geom(long long B, int n2, int H2) {
+  CorrPlanGeom g{(H2 + 15) / 16, 1, 8};
+  while (B * n2 * g.nb > CORR_ORDER_MAXBINS && g.nb > 1) g.nb = (g.nb + 1) / 2;
+  if (B * n2 * g.nb > CORR_ORDER_MAXBINS || g.nb > 255) { g.nb = 0; return g; }
+  long long nx = CORR_ORDER_MAXBINS / (B * n2 * g.nb);
+  const int want = (2 * H2 + 7) / 8;                      // 8-px columns across a 2:1 frame
+  if (nx > want) nx = want;
+  if (nx > 255) nx = 255;
+  if (nx < 1) nx = 1;
+  g.nxb = (int)nx;
+  int xw = (2 * H2 + g.nxb - 1) / g.nxb;
+  xw = (xw + 3) / 4 * 4;
+  g.xw = xw < 8 ? 8 : (xw > 32764 ? 32764 : xw);
+  return g;
 }
+inline int corr_plan_pack(const CorrPlanGeom& g) { return g.nb | (g.nxb << 8) | (g.xw << 16); }
+inline long long corr_plan_nbins(long long B, int n2, const CorrPlanGeom& g) { return B * n2 * g.nb * g.nxb; }
 
 // Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS round trips like ds_bpermute shuffles):
 // Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8; lanes without a source add 0), then the last lane of row 0 / 2

@@ -76,7 +76,7 @@ def test_channel_blocked_layout_is_bit_identical_and_checked():
     h = lambda t: t.to(DEV).half()
     with pytest.raises(RuntimeError):                                 # the staged kernel (fp16) reads 8-channel blocks only
         cuda_corr.forward(h(f1), altcorr.channel_blocked(h(f2), 4), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
-    if os.environ.get("DEVO_CORR_MFMA", "1") != "0":                  # the matrix-core kernel (fp32, C = 128): blocks of 4, 8 or 16 channels
+    if os.environ.get("DEVO_CORR_MFMA", "1") != "0" or os.environ.get("DEVO_CORR_DENSE", "0") == "1":   # the matrix-core kernels: blocks of 4, 8 or 16 channels
         c = _case(seed=15, spread=3.5, E=96)
         for cb in (4, 16):
             out, = cuda_corr.forward(c[0].to(DEV), altcorr.channel_blocked(c[1].to(DEV), cb), c[2].to(DEV), c[3].to(DEV), c[4].to(DEV), c[5])
@@ -346,12 +346,18 @@ def test_plan_started_by_the_reprojection_kernel_equals_plan():
     assert torch.equal(key(a), key(b))                              # same (frame, band) sequence after the heavy list
 
 
-def test_staged_kernel_stays_covered():
-    """fp32 / C = 128 lookups take the matrix-core kernel by default; DEVO_CORR_MFMA=0 (read once per process) routes them
-    through the staged tap-centric kernel, which fp16 storage and other channel counts always use: same parity tests."""
-    if os.environ.get("DEVO_CORR_MFMA", "1") == "0":
-        pytest.skip("already running on the staged kernel")
-    env = dict(os.environ, DEVO_CORR_MFMA="0")
+@pytest.mark.parametrize("which", ["region-staged dense kernel", "staged kernel"])
+def test_other_kernels_stay_covered(which):
+    """fp32 / fp16 lookups with C = 128 take the per-edge matrix-core kernel by default.  DEVO_CORR_DENSE=1 (read once per
+    process) routes them through the region-staged dense matrix-core kernel (corr_dense.h, opt-in), DEVO_CORR_MFMA=0 through
+    the staged tap-centric kernel: same parity tests."""
+    if os.environ.get("DEVO_CORR_DENSE", "0") == "1" or os.environ.get("DEVO_CORR_MFMA", "1") == "0":
+        pytest.skip("already running on another kernel")
+    env = dict(os.environ)
+    if which == "staged kernel":
+        env["DEVO_CORR_MFMA"] = "0"
+    else:
+        env["DEVO_CORR_DENSE"] = "1"
     sel = "test_forward_fp32 or test_forward_wide_spread or test_channel_blocked or test_fused_pyramid or test_batch_of_two or test_forward_other_radii or test_coord_div"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", sel],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -49,6 +49,14 @@ def parse():
                     help="consecutive steps captured into one HIP graph launch (a graph launch costs ~10 us of idle GPU; 1 = one launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=50, help="launch pairs timed for the roofline figure")
+    ap.add_argument("--mode", default="update-op", choices=["update-op", "train"],
+                    help="update-op: the headline metric (BASELINE configuration 2, replicas when --gpus > 1); train: BASELINE "
+                         "configurations 3 / 4 — one training step per sequence under DistributedDataParallel (devo_amd/training.py)")
+    ap.add_argument("--train-iters", type=int, default=18, help="update iterations per training step (DEVO_base.conf: 18)")
+    ap.add_argument("--no-f16", action="store_true", help="skip the secondary fp16-storage measurement (field \"f16\")")
+    ap.add_argument("--no-train-probe", action="store_true",
+                    help="multi-GPU update-op runs also time a few data-parallel training steps (field \"train_dp\": the RCCL gradient "
+                         "all-reduce of BASELINE configuration 4); this skips them")
     ap.add_argument("--with-update", action="store_true",
                     help="additionally time a FULL DEVO update iteration: the step with the Update operator (devo_amd.update, "
                          "random weights, fp16) between lookup and BA, feeding delta / weight to the BA (extra field; the headline "
@@ -105,23 +113,81 @@ def alg_bytes(cfg, E, esize):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: spawn the N ranks here (the driver's torch.distributed.run launch sets WORLD_SIZE itself)
+        if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPU(s) visible")
+        from devo_amd import distributed as D
+        D.launch(rank_main, args.gpus, (sys.argv[1:],))
+        return
+    rank_main(sys.argv[1:])
+
+
+def rank_main(argv):
+    sys.argv = [sys.argv[0]] + list(argv)
+    args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world} (launch with --nproc-per-node {args.gpus})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    from devo_amd import distributed as D
+    D.init_from_env("nccl", device)
+    assert D.world() == world
+    if args.mode == "train":
+        out = train_mode(args, device, rank, world)
+    else:
+        out = update_op_mode(args, device, rank, world)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        dist.destroy_process_group()
 
+
+def train_mode(args, device, rank, world, steps=None, warmup=None, iters=None, probe=False):
+    """BASELINE configurations 3 (N = 1) and 4 (N > 1): one training step = one sequence per rank (batch = N sequences) through
+    `iters` update iterations, loss, backward (DDP all-reduces the 13.59 MB gradient bucket over RCCL), clip, AdamW step."""
+    from devo_amd import distributed as D, training as T
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    iters = args.train_iters if iters is None else iters
+    net, model, opt = T.build_trainer(device, world)
+    batch = T.make_batch("cfg2_m80", 1234 + rank, device)
+    for _ in range(max(warmup, 1)):
+        T.train_step(model, opt, batch, iters=iters)
+    D.barrier_sync(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = T.train_step(model, opt, batch, iters=iters)
+    D.barrier_sync(device)
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    nparam = net.num_parameters()
+    res = {"ms_per_step": round(1e3 * elapsed / steps, 3), "sequences_per_s": round(world * steps / elapsed, 4),
+           "update_iterations_per_step": iters, "steps": steps, "loss": float(loss),
+           "grad_bucket_bytes": 4 * nparam, "parameters": nparam, "collective": "DDP all-reduce (RCCL)" if world > 1 else None}
+    if probe:
+        return res
+    return {"metric": "training sequences/sec (update + BA path, batch = 1 sequence per GPU)", "value": res["sequences_per_s"], "unit": "seq/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg3/4: n=15 frames, M=80 patches/frame, E={batch['E']} edges, {iters} update iterations per step, "
+                                   f"corr backward on 20 % of the edges, 2 differentiable GN steps per iteration, AdamW",
+                       "parallelism": f"dp{world}"},
+            "train": res}
+
+
+def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
+    dtn = dtype_name or args.dtype
     from devo_amd import synth, altcorr, distributed as D
     from devo_amd.backends import cuda_ba, cuda_corr
 
     cfg = synth.workload(args.workload)
-    dtype = torch.float32 if args.dtype == "f32" else torch.float16
+    dtype = torch.float32 if dtn == "f32" else torch.float16
     d, cpu = build_inputs(cfg, 1234 + rank, device, dtype, args.layout)
     n, M, R = cfg["n"], cfg["M"], cfg["R"]
     E = d["ii"].numel()
@@ -259,11 +325,13 @@ def main():
     # which lookup kernel the library picks for this configuration (devo_amd/csrc/corr.hip: launch_staged)
     mfma = cfg["C"] == 128 and os.environ.get("DEVO_CORR_MFMA", "1")[:1] != "0"          # fp32 and fp16 storage
     lookup_kernel = "corr_fwd_generic_kernel" if args.layout == "nchw" else ("corr_fwd_mfma_kernel" if mfma else "corr_fwd_cl_kernel")
+    if args.layout != "nchw" and os.environ.get("DEVO_CORR_DENSE", "0")[:1] == "1":
+        lookup_kernel = "corr_fwd_dense_kernel"                     # opt-in region-staged kernel (corr_dense.h)
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             recs = json.load(f)
-        key = f"{args.workload}/{args.dtype}/{args.layout}"
+        key = f"{args.workload}/{dtn}/{args.layout}"
         rec = (recs.get(key + "/staged") if lookup_kernel == "corr_fwd_cl_kernel" else None) or recs.get(key)
         per_launch = 2 if args.fuse_levels else 1                  # records are per level launch ...
         if args.fuse_levels and lookup_kernel == "corr_fwd_mfma_kernel" and recs.get(key + "/fused"):
@@ -278,7 +346,7 @@ def main():
         "metric": "update-op iterations/sec (altcorr+fastba) at 96 patches, N=15 keyframes",
         "value": round(value, 2), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": dtn, "data": "synthetic",
         "config": {"workload": f"{args.workload}: M={M} patches/frame, n={n} keyframes, E={E} edges, r={R}, "
                                f"2 pyramid levels {cfg['H']}x{cfg['W']} + /4, C={cfg['C']}, 2 GN iterations, "
                                f"pyramid layout {args.layout}, {'both levels in one lookup launch' if args.fuse_levels else 'one lookup launch per level'}, "
@@ -296,7 +364,7 @@ def main():
         "ba": {"gpu_ms": round(t_ba_gpu * 1e3, 4)},
     }
 
-    if args.with_update:
+    if args.with_update and not secondary:
         from devo_amd.update import Update
         torch.manual_seed(1234 + rank)
         upd = Update(3).to(device).half().eval()
@@ -336,15 +404,27 @@ def main():
         out["full_update_iteration"] = {"ms": round(ev0.elapsed_time(ev1) / 50, 4),
                                         "note": f"reproject + 2-level lookup + Update operator (fp16, random weights) + 2 GN iterations, {how}"}
 
+    if secondary:
+        return out
+    if dtn == "f32" and not args.no_f16:
+        # the reference's inference precision (devo/devo.py:71-77: fp16 feature maps under autocast) as a second measurement
+        # of the same step; fp32 accumulation in the lookup, so every output is at least as accurate as the reference's
+        del d, corr_out
+        torch.cuda.empty_cache()
+        h = update_op_mode(args, device, rank, world, dtype_name="f16", secondary=True)
+        out["f16"] = {"value": h["value"], "unit": "it/s", "ms_per_step": h["ms_per_step"],
+                      "roofline": {k: h["roofline"][k] for k in ("achieved", "frac", "kernel", "alg_bytes_per_launch", "us_per_launch")},
+                      "note": "same step with fp16-storage feature pyramid + patch features (DEVO's inference precision), fp32 accumulation"}
+    if world > 1 and not args.no_train_probe:
+        # BASELINE configuration 4: data-parallel training steps — the one collective of the path (13.59 MB gradient all-reduce)
+        out["train_dp"] = train_mode(args, device, rank, world, steps=3, warmup=1, iters=2, probe=True)
+        out["train_dp"]["note"] = "probe: 3 steps of 2 update iterations each (bench.py --mode train runs the full 18-iteration step)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, cpu, E)
         out["ba"]["cpu_ms"] = out["cpu_baseline"]["ba_ms"]
         out["ba"]["speedup"] = round(out["cpu_baseline"]["ba_ms"] / (t_ba_gpu * 1e3), 1)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    return out
+
 
 
 def cpu_baseline(cfg, cpu, E):
@@ -389,8 +469,21 @@ def cpu_baseline(cfg, cpu, E):
         oc.corr_forward(cpu["gmap"], cpu["fmap"], c2, kk[sel], jj[sel], R, acc=torch.float32)
         oc.corr_forward(cpu["gmap"], f1l, c2 / 4, kk[sel], jj[sel], R, acc=torch.float32)
         t_corr = (time.perf_counter() - t0) * (E / ns)
+        # SURVEY 8d also asks for the single-thread figure of the BA
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        ba2()
+        t_ba1 = time.perf_counter() - t0
+        torch.set_num_threads(threads)
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
     step_s = t_tr + t_corr + t_ba
-    return {"value": round(1.0 / step_s, 4), "unit": "it/s", "cores": threads, "kind": "port",
+    return {"value": round(1.0 / step_s, 4), "unit": "it/s", "cores": threads, "kind": "port", "cpu_model": model,
+            "host_cores": os.cpu_count(), "ba_ms_1thread": round(t_ba1 * 1e3, 2),
             "sample": f"torch-CPU fp32, {threads} threads: transform (full, {E} edges) + 2x ba.py-style BA (full, median of 3) + "
                       f"2-level lookup on {ns} of {E} edges, scaled",
             "ba_ms": round(t_ba * 1e3, 2), "corr_ms_scaled": round(t_corr * 1e3, 1), "transform_ms": round(t_tr * 1e3, 2)}

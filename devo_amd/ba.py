@@ -92,7 +92,9 @@ def BA(poses, patches, intrinsics, targets, weights, lmbda, ii, jj, kk, bounds, 
     S, Emat = S.view(n6, n6), Emat.view(n6, m)
     C = torch.zeros(m, dtype=dt, device=dev).index_add(0, ku, (w * Jz * Jz).sum(-1))
     u = torch.zeros(m, dtype=dt, device=dev).index_add(0, ku, (w * Jz * r).sum(-1))
-    Q = 1.0 / (C + lmbda)
+    # patch slots without an edge have C = 0: with lmbda == 0 (or one that underflows) 1 / (C + lmbda) would be inf and
+    # inf * 0 = NaN would poison every depth; the reference only ever sees observed patches (torch.unique, ba.py:113-118)
+    Q = torch.where(C + lmbda > 0, 1.0 / (C + lmbda), torch.zeros_like(C))
 
     if structure_only or n == 0:
         dZ, dX = Q * u, None

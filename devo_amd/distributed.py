@@ -52,3 +52,53 @@ def aggregate_throughput(units_per_rank, elapsed_s, device=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total = float(t.item())
     return total / max_over_ranks(elapsed_s, device)
+
+
+# ------------------------------------------------------------------------------------------------- process launcher
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _child(rank, nprocs, port, fn, args):
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(nprocs), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
+    fn(*args)
+
+
+def launch(fn, nprocs, args=()):
+    """One process per rank on THIS node (what `torch.distributed.run --nproc-per-node N` or train.py:253's mp.spawn do):
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in the environment, then fn(*args) in every child.
+    `fn` must be importable (module-level).  Raises if any rank fails."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_child, args=(r, nprocs, port, fn, args)) for r in range(nprocs)]
+    for p in procs:
+        p.start()
+    bad = []
+    for r, p in enumerate(procs):
+        p.join()
+        if p.exitcode != 0:
+            bad.append((r, p.exitcode))
+    if bad:
+        raise RuntimeError(f"launch: ranks failed (rank, exit code): {bad}")
+
+
+def init_from_env(backend=None, device=None):
+    """init_process_group from the launcher's environment; backend "nccl" (= RCCL) for GPU devices, "gloo" otherwise.
+    Returns (rank, world)."""
+    import os
+    w = int(os.environ.get("WORLD_SIZE", "1"))
+    if w > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+        kw = {"device_id": torch.device(device)} if backend == "nccl" and device is not None else {}
+        dist.init_process_group(backend, **kw)
+        if dist.get_world_size() != w:
+            raise RuntimeError(f"world size {dist.get_world_size()} != WORLD_SIZE {w}")
+    return rank(), world()

@@ -66,9 +66,10 @@ class SoftAgg(nn.Module):                            # blocks.py:31-48 (expand=T
 class _Groups:
     """Edges grouped by an integer key, through the BA's index kernels: perm / seg_start / n_seg (+ group_of scratch)."""
 
-    def __init__(self, key):
+    def __init__(self, key, bound=None):
         E = key.numel()
-        bound = int(key.max()) + 1 if E else 1       # one host sync per distinct graph (cached by the caller)
+        if bound is None:
+            bound = int(key.max()) + 1 if E else 1   # one host sync per distinct graph (cached by the caller)
         ws = cuda_ba.workspace(E, bound, 0, key.device)
         cuda_ba.prepare(key, bound, 0, ws)
         self.n_seg, _, self.seg_start, self.perm = cuda_ba.prepared_tables(ws, E, bound, 0)
@@ -104,7 +105,7 @@ class Update(nn.Module):
                                   nn.LayerNorm(dim, eps=1e-3), nn.ReLU(inplace=True), nn.Linear(dim, dim))
         self.d = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(dim, 2), GradientClip())
         self.w = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(dim, 2), GradientClip(), nn.Sigmoid())
-        self._graph_key, self._graph, self._wcat = None, None, {}
+        self._graph_key, self._graph, self._graph_refs, self._wcat = None, None, None, {}
 
     # ------------------------------------------------------------------------------------------ torch / autograd path
     def forward_torch(self, net, inp, corr, ii, jj, kk):
@@ -123,12 +124,28 @@ class Update(nn.Module):
 
     # ------------------------------------------------------------------------------------------ HIP inference path
     def _tables(self, ii, jj, kk):
-        key = (ii.data_ptr(), jj.data_ptr(), kk.data_ptr(), ii._version, jj._version, kk._version, ii.numel())
+        """Neighbour / group tables of the current graph, cached.  The cache key is (storage address, version counter, size) of
+        ii / jj / kk AND the cache keeps references to those tensors: while they are referenced their storage cannot be freed
+        and handed to another tensor, so an equal key means the very same storage, and in-place edits bump the version
+        counter.  (DEVO rebuilds ii / jj / kk with torch.cat every frame: fresh tensors -> rebuilt tables.)"""
+        key = (ii.data_ptr(), jj.data_ptr(), kk.data_ptr(), ii._version, jj._version, kk._version, ii.numel(), jj.numel(), kk.numel())
         if key != self._graph_key:
             ix, jx = cuda_ba.neighbors(kk, jj)
-            self._graph = (ix, jx, _Groups(kk.long().contiguous()), _Groups((ii.long() * 12345 + jj.long()).contiguous()))
+            il, jl = ii.long(), jj.long()
+            # frame-pair key compacted to the window of live frames: the grouping workspace scales with (frame range)^2, not
+            # with 12345 * (absolute frame index); ONE host transfer for the four bounds (+ kk's) per graph change
+            lo_hi = torch.stack([il.min(), il.max(), jl.min(), jl.max(), kk.max()]).tolist() if ii.numel() else [0, 0, 0, 0, 0]
+            imin, imax, jmin, jmax, kmax = (int(v) for v in lo_hi)
+            span = jmax - jmin + 1
+            pair = ((il - imin) * span + (jl - jmin)).contiguous()           # same groups as ii * 12345 + jj (enet.py:94)
+            self._graph = (ix, jx, _Groups(kk.long().contiguous(), kmax + 1), _Groups(pair, (imax - imin + 1) * span))
             self._graph_key = key
+            self._graph_refs = (ii, jj, kk)                                  # keep the key's storages alive (see above)
         return self._graph
+
+    def invalidate(self):
+        """Drop the cached graph tables (e.g. after editing ii / jj / kk through a raw pointer)."""
+        self._graph_key, self._graph, self._graph_refs = None, None, None
 
     # The f and g layers of a SoftAgg share their input: ONE GEMM on concatenated weights (cached, rebuilt when a parameter
     # changes).

@@ -182,6 +182,32 @@ def test_ba_failure_flag_on_breakdown():
     assert torch.equal(P.cpu(), s[0]) and torch.equal(Q.cpu(), s[1])
 
 
+def test_dropin_fastba_reports_a_failed_factorisation():
+    """devo_amd.fastba.BA (the `devo.fastba.BA` drop-in): a Cholesky breakdown surfaces as an exception the caller's
+    try / except sees (devo.py:336-340) — at the next call (lazy, no synchronisation in the failing call), immediately with
+    check="now", or through last_status(); more than 32 optimised poses is a clear error."""
+    from devo_amd import fastba
+    s = scene()
+    d = lambda t: t.to(DEV)
+    args = lambda P, Q, w: (P, Q, d(s[2]), d(s[3]), w, torch.tensor([1e-4], device=DEV), d(s[5]), d(s[6]), d(s[7]), 1, 8, 2)
+    bad = d(s[4]).clone(); bad[0, 0, 0] = float("nan")
+    P, Q = d(s[0]).clone(), d(s[1]).clone()
+    fastba.last_status(DEV)                                                     # (clear whatever earlier tests left)
+    assert fastba.BA(*args(P, Q, d(s[4]))) == [] and fastba.last_status(DEV) == 0
+    P, Q = d(s[0]).clone(), d(s[1]).clone()
+    assert fastba.BA(*args(P, Q, bad)) == []                                    # fails silently for now ...
+    with pytest.raises(fastba.BAFailure):                                       # ... and is reported by the next call
+        fastba.BA(*args(P, Q, d(s[4])))
+    assert fastba.BA(*args(P, Q, d(s[4]))) == [] and fastba.last_status(DEV) == 0
+    with pytest.raises(fastba.BAFailure):
+        fastba.BA(*args(d(s[0]).clone(), d(s[1]).clone(), bad), check="now")
+    fastba.BA(*args(d(s[0]).clone(), d(s[1]).clone(), bad), check="never")
+    assert fastba.last_status(DEV) == 1
+    big = torch.zeros(1, 40, 7, device=DEV); big[..., 6] = 1
+    with pytest.raises(RuntimeError, match="at most 32"):
+        fastba.BA(big, Q, d(s[2]), d(s[3]), d(s[4]), torch.tensor([1e-4], device=DEV), d(s[5]), d(s[6]), d(s[7]), 1, 40, 1)
+
+
 def test_prepare_then_forward_prepared_equals_forward():
     """cuda_ba.prepare + forward(prepared=True) is the same computation as forward(); a prepared workspace can be
     solved again (also after a run that broke down: the sticky failure flag is reset by the next call)."""

@@ -79,6 +79,38 @@ def test_update_full_width_fp32_fp16_and_torch_path():
     assert_rel(w3.float(), ref[2], 2e-2, "fp16 weight")
 
 
+def test_update_graph_tables_follow_a_changing_graph():
+    """DEVO rebuilds ii / jj / kk with torch.cat every frame (devo.py:392-399): fresh tensors of often the same size, whose
+    storage the caching allocator may hand back at the SAME address.  The cached neighbour / group tables must follow the
+    graph, and the frame-pair grouping must not scale with the absolute frame index."""
+    from devo_amd.update import Update
+    m, sd, net, inp, corr, ii, jj, kk = _random_case(n=6, M=10, dim=64, seed=9)
+    m = m.to(DEV).eval()
+    E = len(ii)
+    g = torch.Generator().manual_seed(3)
+    outs, refs = [], []
+    for step in range(4):
+        perm = torch.randperm(E, generator=g)                       # another graph over the same number of edges
+        a, b, c = ii[perm] + 4000 * step, jj[perm] + 4000 * step, kk[perm]      # (long sequences: large absolute frame ids)
+        refs.append(U.update(sd, net.double(), inp.double(), corr.double(), a, b, c))
+        ta, tb, tc = a.to(DEV), b.to(DEV), c.to(DEV)                # fresh device tensors, the previous ones are freed below
+        with torch.no_grad():
+            n1, (d1, w1, _) = m(net.to(DEV), inp.to(DEV), corr.to(DEV), None, ta, tb, tc)
+        outs.append((n1.cpu(), d1.cpu(), w1.cpu()))
+        del ta, tb, tc
+    for (n1, d1, w1), ref in zip(outs, refs):
+        assert_rel(n1, ref[0], 1e-4, "net"); assert_rel(d1, ref[1], 1e-4, "delta"); assert_rel(w1, ref[2], 1e-4, "weight")
+    # in-place edits of the same tensors are seen through the version counter
+    ta, tb, tc = ii.to(DEV), jj.to(DEV), kk.to(DEV)
+    with torch.no_grad():
+        m(net.to(DEV), inp.to(DEV), corr.to(DEV), None, ta, tb, tc)
+        perm = torch.randperm(E, generator=g).to(DEV)
+        ta.copy_(ta[perm]); tb.copy_(tb[perm]); tc.copy_(tc[perm])
+        n2, (d2, w2, _) = m(net.to(DEV), inp.to(DEV), corr.to(DEV), None, ta, tb, tc)
+    ref = U.update(sd, net.double(), inp.double(), corr.double(), ta.cpu(), tb.cpu(), tc.cpu())
+    assert_rel(n2, ref[0], 1e-4, "net after an in-place edit")
+
+
 def test_update_single_ops():
     """layer norm (+ fused adds, ReLU), masked gather, soft aggregation, gated residual, heads — each against torch"""
     import devo_amd._lib as L

@@ -31,6 +31,36 @@ class CholeskySolver(torch.autograd.Function):
         return -x @ dz.transpose(-1, -2), dz
 
 
+class _FusedSolve(torch.autograd.Function):
+    """(edge terms [E,30]) -> (dX [6n], dZ [Np]): normal equations, Schur complement and damped Cholesky solve of ba.py:108-170 as
+    ONE group of HIP kernels (devo_ba_solve_terms: the inference BA's accumulate / reduce / solve kernels fed with the given
+    terms), and their adjoint (devo_ba_solve_terms_backward: one more solve with the saved matrix + per-patch / per-edge
+    kernels) instead of ~35 + ~70 ATen kernels.  The Jacobians themselves and the retraction stay in the autograd graph."""
+
+    @staticmethod
+    def forward(ctx, terms, lm, ii, jj, kk, n_slots, t0, n_opt, ep):
+        from .backends import cuda_ba
+        dX, dZ, ws = cuda_ba.solve_terms(terms, lm, ii, jj, kk, n_slots, t0, n_opt, ep)
+        ctx.save_for_backward(terms, ii, jj, kk)
+        ctx.ws, ctx.meta = ws, (int(n_slots), int(t0), int(n_opt))
+        return dX, dZ
+
+    @staticmethod
+    def backward(ctx, g_dX, g_dZ):
+        from .backends import cuda_ba
+        terms, ii, jj, kk = ctx.saved_tensors
+        n_slots, t0, n_opt = ctx.meta
+        g = cuda_ba.solve_terms_backward(terms, ii, jj, kk, n_slots, t0, n_opt, ctx.ws, g_dX, g_dZ)
+        return g, None, None, None, None, None, None, None, None
+
+
+def _fused_path(patches, lmbda, n):
+    import os
+    per_patch = isinstance(lmbda, torch.Tensor) and lmbda.numel() > 1
+    return (patches.is_cuda and patches.dtype == torch.float32 and not per_patch and n <= 32 and patches.shape[0] == 1
+            and os.environ.get("DEVO_BA_TORCH", "0") != "1")
+
+
 def BA(poses, patches, intrinsics, targets, weights, lmbda, ii, jj, kk, bounds, ep=100.0, PRINT=False,
        fixedp=1, structure_only=False, n_frames=None):
     """One differentiable Gauss-Newton step (devo/ba.py:86-182).  `n_frames` (optional, = max(ii, jj) + 1) saves the
@@ -51,6 +81,20 @@ def BA(poses, patches, intrinsics, targets, weights, lmbda, ii, jj, kk, bounds, 
     r = gate[:, None] * r
     w = gate[:, None] * weights[0]
     Ji, Jj, Jz = Ji[0], Jj[0], Jz[0, :, :, 0]
+
+    if _fused_path(patches, lmbda, max(n, 0)) and not (structure_only and False):
+        # fp32 on the GPU: system + solve + adjoint in HIP (DEVO_BA_TORCH=1 keeps the torch composition below)
+        E, n_opt = ii.numel(), (0 if structure_only else max(n, 0))
+        terms = torch.cat([r, w, Jz, (-Ji).reshape(E, 12), Jj.reshape(E, 12)], dim=1)      # Ji enters the kernels as -d coords / d xi_i
+        lm = lmbda.reshape(1).to(dev, torch.float32) if isinstance(lmbda, torch.Tensor) else torch.full((1,), float(lmbda), dtype=torch.float32, device=dev)
+        dX, dZ = _FusedSolve.apply(terms, lm, ii, jj, kk, patches.shape[1], fixedp, n_opt, float(ep))
+        disp = patches[:, :, 2] + dZ.view(1, -1, 1, 1)
+        patches = torch.stack([patches[:, :, 0], patches[:, :, 1], disp.clamp(min=1e-3, max=10.0)], dim=2)
+        if n_opt > 0:
+            upd = torch.zeros(1, poses.data.shape[1], 6, dtype=dt, device=dev)
+            upd[:, fixedp:fixedp + n_opt] = dX.view(1, n_opt, 6)
+            poses = poses.retr(upd)
+        return poses, patches
 
     # Patches: the reference compacts to the patches that have edges (torch.unique, ba.py:104).  Working on ALL patch
     # slots instead gives the same update (a slot without edges has C = u = 0 and a zero column of E, hence dZ = 0) and

@@ -185,3 +185,34 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     if plan_for is None:
         return out
     return (out + (plan,)) if isinstance(out, tuple) else (out, plan)
+
+
+def solve_terms(terms, lmbda, ii, jj, kk, n_patch_slots, t0, n_opt, ep, status=None):
+    """devo_ba_solve_terms: one Gauss-Newton step of devo/ba.py:108-170 from given edge terms [E,30] -> (dX [6 n_opt], dZ [Np], ws);
+    `ws` holds what solve_terms_backward needs."""
+    L.require_gpu(terms, lmbda, ii, jj, kk)
+    ii, jj, kk = _idx(ii, jj, kk)
+    E = ii.numel()
+    terms = terms.float().contiguous()
+    lmbda = lmbda.float().reshape(-1).contiguous()
+    ws = workspace(E, int(n_patch_slots), int(n_opt), terms.device)
+    dX = torch.empty(6 * int(n_opt), dtype=torch.float32, device=terms.device)
+    dZ = torch.empty(int(n_patch_slots), dtype=torch.float32, device=terms.device)
+    rc = L.lib().devo_ba_solve_terms(L.ptr(terms), L.ptr(lmbda), L.ptr(ii), L.ptr(jj), L.ptr(kk), E, int(n_patch_slots), int(t0), int(n_opt),
+                                     float(ep), L.ptr(ws), ws.numel(), L.ptr(dX), L.ptr(dZ), L.ptr(status), L.stream())
+    L.check(rc, "cuda_ba.solve_terms")
+    return dX, dZ, ws
+
+
+def solve_terms_backward(terms, ii, jj, kk, n_patch_slots, t0, n_opt, ws, g_dX, g_dZ):
+    """devo_ba_solve_terms_backward -> g_terms [E,30]"""
+    ii, jj, kk = _idx(ii, jj, kk)
+    E = ii.numel()
+    terms = terms.float().contiguous()
+    g_dX = g_dX.float().contiguous()
+    g_dZ = g_dZ.float().contiguous()
+    g = torch.empty(E, 30, dtype=torch.float32, device=terms.device)
+    rc = L.lib().devo_ba_solve_terms_backward(L.ptr(terms), L.ptr(ii), L.ptr(jj), L.ptr(kk), E, int(n_patch_slots), int(t0), int(n_opt), L.ptr(ws),
+                                              ws.numel(), L.ptr(g_dX), L.ptr(g_dZ), L.ptr(g), L.stream())
+    L.check(rc, "cuda_ba.solve_terms_backward")
+    return g

@@ -21,6 +21,41 @@ def _prep(fmap1, fmap2, coords, ii, jj, allow_blocked=False):
 
 
 PLAN_MIN_EDGES = 2048      # below this the lookup is launch-bound and a locality plan cannot pay for itself
+NCHW_CONVERT_MIN_EDGES = 1024    # from here on a lookup into the reference's NCHW pyramid goes through a cached channel-blocked copy
+
+_blocked_cache = {}        # (ptr, version, shape, strides, dtype) -> (source tensor [kept alive], channel-blocked copy)
+
+
+def _fast_layout(fmap2, n_edges):
+    """The reference keeps its feature pyramid NCHW ([1, 32, 128, H, W] fp16 ring, devo/devo.py:71-83, rewritten in place one
+    frame per step); read directly, every channel of a pixel is H*W elements away and the lookup falls back to the strided
+    generic kernel — measured 24x slower than the matrix-core kernel on the channel-blocked layout (profiles/README.md, r02x).
+    So an NCHW level is converted ONCE per version of the tensor into a channel-blocked copy [B, n, C/8, H, W, 8]
+    (devo_pyramid_build: one pass, ~60 us for DEVO's whole fp16 ring) and cached: the key is (storage address, version counter,
+    shape, strides, dtype) and the cache keeps the source tensor alive, so an equal key is the same storage with the same
+    contents (in-place writes such as `fmap1_[:, k] = f` bump the version counter).  Channels-last / channel-blocked inputs,
+    small edge lists, other dtypes: returned unchanged.  DEVO_CORR_NCHW_DIRECT=1 disables the conversion."""
+    import os
+    if (fmap2.dim() != 5 or fmap2.dtype not in (torch.float16, torch.float32) or n_edges < NCHW_CONVERT_MIN_EDGES
+            or os.environ.get("DEVO_CORR_NCHW_DIRECT", "0") == "1"):
+        return fmap2
+    B, n, C, H, W = fmap2.shape
+    st = fmap2.stride()
+    if C % 8 or tuple(st[2:]) != (H * W, W, 1) or B * n == 0:
+        return fmap2                                          # not plain NCHW frames (e.g. channels-last already)
+    key = (fmap2.data_ptr(), fmap2._version, tuple(fmap2.shape), tuple(st), fmap2.dtype)
+    hit = _blocked_cache.get(key)
+    if hit is not None:
+        return hit[1]
+    for k in [k for k in _blocked_cache if k[0] == key[0] or len(_blocked_cache) >= 8]:
+        del _blocked_cache[k]                                 # an older version of this tensor (or: keep the cache small)
+    blk = torch.empty(B, n, C // 8, H, W, 8, dtype=fmap2.dtype, device=fmap2.device)
+    for b in range(B):
+        rc = L.lib().devo_pyramid_build(L.ptr(fmap2[b]), L.ptr(blk[b]), None, n, C, H, W, st[1], blk.stride(1), 0,
+                                        L.dtype_code(fmap2), L.stream())
+        L.check(rc, "cuda_corr: NCHW -> channel-blocked")
+    _blocked_cache[key] = (fmap2, blk)
+    return blk
 
 
 def plan(coords, jj, n_frames, height, coord_scale=1.0, radius=3):
@@ -52,6 +87,7 @@ def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, of
     coord_div: the kernel looks up at coords / coord_div (same IEEE division as `coords / s` on the tensor, without
     materialising it)."""
     fmap1, fmap2, coords, ii, jj = _prep(fmap1, fmap2, coords, ii, jj, allow_blocked=True)
+    fmap2 = _fast_layout(fmap2, coords.shape[0] * coords.shape[1])
     if order is None and coords.shape[0] * coords.shape[1] >= PLAN_MIN_EDGES:
         order = plan(coords, jj, fmap2.shape[1], fmap2.shape[3], float(coord_div), radius)
     B, E = coords.shape[:2]
@@ -104,6 +140,7 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
     per = Dm * Dm * P * P
     if out is None:
         out = torch.empty(B, E, per * nl, dtype=fmap1.dtype, device=fmap1.device)
+    pyramid = [_fast_layout(f, B * E) if f.is_cuda else f for f in pyramid]
     if order is None and B * E >= PLAN_MIN_EDGES:
         order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius)
     if nl == 2 and B * E > 0 and pyramid[0].dtype == pyramid[1].dtype and pyramid[0].dtype in (torch.float32, torch.float16):

@@ -386,12 +386,22 @@ struct EdgeTerms {
 
 // Where an edge's target comes from: t[2e + c] alone, or (devo.py:330 folded in) the centre pixel of the reprojected patch
 // plus the update operator's delta: base[e * se + c * sc + off] + t[2e + c] — the same single fp32 addition torch does.
-struct TargetSrc { const float* t; const float* base; int se, sc, off; };
+struct TargetSrc { const float* t; const float* base; int se, sc, off; const float* terms; };
+// terms != NULL (devo_ba_solve_terms): the per-edge residual / weight / Jacobians are GIVEN — 30 floats per edge:
+// r[2] w[2] Jz[2] Ji[2][6] Jj[2][6], in this file's sign convention (v_i -= w r Ji, i.e. Ji = -d coords / d xi_i).
+constexpr int BA_TERMS = 30;
 
 // ba_cuda.cu:239-330 for one edge (fx,fy,cx,cy of intrinsics row 0).
 __device__ __forceinline__ void edge_terms(const float* __restrict__ poses, const float* __restrict__ patches, int P,
                                            float fx, float fy, float cx, float cy, const TargetSrc& target,
                                            const float* __restrict__ weight, int ix, int jx, int kx, int e, EdgeTerms& T) {
+  if (target.terms) {                                          // (wave-uniform) precomputed terms
+    const float* t = target.terms + (int64_t)e * BA_TERMS;
+    T.r[0] = t[0]; T.r[1] = t[1]; T.w[0] = t[2]; T.w[1] = t[3]; T.Jz[0] = t[4]; T.Jz[1] = t[5];
+#pragma unroll
+    for (int c = 0; c < 6; c++) { T.Ji[0][c] = t[6 + c]; T.Ji[1][c] = t[12 + c]; T.Jj[0][c] = t[18 + c]; T.Jj[1][c] = t[24 + c]; }
+    return;
+  }
   const float* pi = poses + (int64_t)ix * 7;
   const float* pj = poses + (int64_t)jx * 7;
   float ti[3] = {pi[0], pi[1], pi[2]}, qi[4] = {pi[3], pi[4], pi[5], pi[6]};
@@ -902,7 +912,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
 // 512-thread workgroups: wave g sums partials [g*n_part/8, (g+1)*n_part/8) for 64 consecutive outputs (32 loads in
 // flight), the eight wave results are combined through LDS in a fixed order.
 __global__ __launch_bounds__(512) void k_ba_reduce(const float* __restrict__ partials, int n_part, int N, float* __restrict__ S,
-                                                   float* __restrict__ y) {
+                                                   float* __restrict__ y, float ep) {
   // One lane per entry of the COMPACT partial (lower block triangle + right-hand side): consecutive lanes read consecutive
   // addresses of every partial, 8 waves share the partials of 64 entries, the symmetric entry is written by the same lane
   // (the full-matrix form read every off-diagonal entry twice, 6 floats at a time).
@@ -936,7 +946,7 @@ __global__ __launch_bounds__(512) void k_ba_reduce(const float* __restrict__ par
       block_of(o / 36, fr, fc);
       const int ab = o % 36, r = 6 * fr + ab / 6, c = 6 * fc + ab % 6;
       if (fr == fc && ab / 6 < ab % 6) return;                  // upper half of a diagonal block: its mirror writes it
-      if (r == c) sum = sum + (1e-4f * sum + 1.0f);
+      if (r == c) sum = sum + (1e-4f * sum + ep);              // ba_cuda.cu:518 (ep = 1); devo/ba.py:73 (ep = 10 in training)
       S[r * (n6 + 1) + c] = sum;
       if (r != c) S[c * (n6 + 1) + r] = sum;
     } else S[n6 * (n6 + 1) + (o - nt)] = sum;
@@ -1235,6 +1245,123 @@ __global__ void k_ba_retract(float* __restrict__ poses, float* __restrict__ patc
   }
 }
 
+// ------------------------------------------------------------------------------------------------- differentiable step
+// devo_ba_solve_terms: the normal equations, Schur complement and Cholesky solve of ONE Gauss-Newton step from GIVEN edge
+// terms (devo/ba.py:108-170 behind devo_amd.ba.BA; the caller's autograd graph produces r, w, Ji, Jj, Jz and consumes
+// dX, dZ), and its adjoint.  Forward: the accumulate / reduce / solve kernels above + k_bt_dz.  Backward, with
+//   dZ = Q (u - E^T dX),  dX = S'^-1 y,  S' = S + (ep + 1e-4 diag S),  S = B - E Q E^T,  y = v - E Q u,  Q = 1 / (C + lambda):
+//   a = Q gdZ,  ybar = S'^-1 (gdX - E a)   (the SAME matrix: one more solve),  Sbar = -(ybar dX^T) (1 + 1e-4 on the diagonal),
+// everything else is per patch (k_bt_patch) and per edge (k_bt_edge) arithmetic on dX, ybar and the E columns.
+__global__ void k_bt_dz(const float* __restrict__ dX, const float* __restrict__ patch_rec, const float* __restrict__ patch_col,
+                        const int* __restrict__ kx, const BaMeta* __restrict__ meta, int N, float* __restrict__ dZ) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = gid >> 6, nwaves = (blockDim.x * gridDim.x) >> 6;
+  const int n_seg = meta->fail < 0 ? 0 : meta->n_seg, n6 = 6 * N;
+  for (int s = wave; s < n_seg; s += nwaves) {
+    float part = 0.0f;
+    const float* pc = patch_col + (int64_t)s * n6;
+    for (int i = lane; i < n6; i += 64) part += pc[i] * dX[i];
+    part = wave_sum(part);
+    if (lane == 0) dZ[kx[s]] = patch_rec[(int64_t)s * 2] * (patch_rec[(int64_t)s * 2 + 1] - part);
+  }
+}
+
+// right-hand side of the adjoint solve, accumulated into the solver image's last row (which the caller initialised with gdX)
+__global__ __launch_bounds__(256) void k_bt_rhs(float* __restrict__ rhs, const float* __restrict__ g_dZ, const float* __restrict__ patch_rec,
+                                                const float* __restrict__ patch_col, const int* __restrict__ kx,
+                                                const BaMeta* __restrict__ meta, int N) {
+  const int n_seg = meta->fail < 0 ? 0 : meta->n_seg, n6 = 6 * N, d = threadIdx.x;
+  if (d >= n6) return;
+  float acc = 0.0f;
+  for (int s = blockIdx.x; s < n_seg; s += gridDim.x) acc += patch_col[(int64_t)s * n6 + d] * (patch_rec[(int64_t)s * 2] * g_dZ[kx[s]]);
+  atomicAdd(rhs + d, -acc);
+}
+
+// per patch: prec[s] = {dZ = Q (u - e.dX),  zbar = Q (gdZ - e.ybar)  [the adjoint of dZ after the solve],  Q,  gamma = sum ybar dX e^2}
+__global__ void k_bt_patch(const float* __restrict__ dX, const float* __restrict__ ybar, const float* __restrict__ g_dZ,
+                           const float* __restrict__ patch_rec, const float* __restrict__ patch_col, const int* __restrict__ kx,
+                           const BaMeta* __restrict__ meta, int N, float* __restrict__ prec) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = gid >> 6, nwaves = (blockDim.x * gridDim.x) >> 6;
+  const int n_seg = meta->fail < 0 ? 0 : meta->n_seg, n6 = 6 * N;
+  for (int s = wave; s < n_seg; s += nwaves) {
+    float al = 0.0f, be = 0.0f, ga = 0.0f;
+    const float* pc = patch_col + (int64_t)s * n6;
+    for (int i = lane; i < n6; i += 64) { const float e = pc[i], x = dX[i], yb = ybar[i]; al += x * e; be += yb * e; ga += yb * x * e * e; }
+    al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+    if (lane == 0) {
+      const float Q = patch_rec[(int64_t)s * 2], u = patch_rec[(int64_t)s * 2 + 1], gz = g_dZ[kx[s]];
+      float* o = prec + (int64_t)s * 8;
+      o[0] = Q * (u - al); o[1] = Q * (gz - be); o[2] = Q; o[3] = ga;
+    }
+  }
+}
+
+// patch slot -> compact patch index (the inverse of kx; the index preparation's own edge -> patch map is not written on its
+// fast path for patch-major edge lists)
+__global__ void k_bt_inv(const int* __restrict__ kx, const BaMeta* __restrict__ meta, int* __restrict__ inv) {
+  const int n_seg = meta->fail < 0 ? 0 : meta->n_seg;
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n_seg; s += blockDim.x * gridDim.x) inv[kx[s]] = s;
+}
+
+// per edge: gradients of the 30 terms.  With  lambda_d = A_d . ybar + Jz_d zbar_k  (the adjoint of the linearised residual) and
+// rho_d = r_d - A_d . dX - Jz_d dZ_k  (the residual after the step), A_d = row d of [-Ji | Jj] (fixed blocks zeroed):
+//   d/dr = w lambda,  d/dw = lambda rho,  d/dJz = w (zbar rho - dZ lambda),  d/dA = w (rho ybar - lambda dX)
+// (no large cancelling terms), plus the O(1e-4) terms of the diagonal damping S_dd (1 + 1e-4).
+__global__ void k_bt_edge(const float* __restrict__ terms, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+                          const int64_t* __restrict__ kk, const int* __restrict__ inv, const float* __restrict__ dX,
+                          const float* __restrict__ ybar, const float* __restrict__ patch_col, const float* __restrict__ prec,
+                          const BaMeta* __restrict__ meta, int E, int t0, int N, float* __restrict__ g_terms) {
+  const int n6 = 6 * N;
+  const bool ok = meta->fail >= 0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
+    float* g = g_terms + (int64_t)e * BA_TERMS;
+    if (!ok) { for (int c = 0; c < BA_TERMS; c++) g[c] = 0.0f; continue; }
+    const float* t = terms + (int64_t)e * BA_TERMS;
+    const int s = inv[kk[e]];
+    int I = (int)ii[e] - t0, J = (int)jj[e] - t0;
+    if (I < 0 || I >= N) I = -1;
+    if (J < 0 || J >= N) J = -1;
+    const float* pr = prec + (int64_t)s * 8;
+    const float dZk = pr[0], zb = pr[1], Q = pr[2], ga = pr[3];
+    float Y[12], X[12], tiny[12];                                 // [block I | block J] of ybar and dX; damping part of the E-column gradient
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const bool vi = I >= 0, vj = J >= 0;
+      Y[c] = vi ? ybar[6 * I + c] : 0.0f; X[c] = vi ? dX[6 * I + c] : 0.0f;
+      Y[6 + c] = vj ? ybar[6 * J + c] : 0.0f; X[6 + c] = vj ? dX[6 * J + c] : 0.0f;
+      tiny[c] = vi ? 2e-4f * Q * (Y[c] * X[c] * patch_col[(int64_t)s * n6 + 6 * I + c]) : 0.0f;
+      tiny[6 + c] = vj ? 2e-4f * Q * (Y[6 + c] * X[6 + c] * patch_col[(int64_t)s * n6 + 6 * J + c]) : 0.0f;
+    }
+    const float ctiny = -Q * Q * 1e-4f * ga;                      // damping part of the gradient of C
+    const bool same = I >= 0 && I == J;                           // both ends in ONE pose block: the diagonal terms see the sum
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+      const float r = t[d], w = t[2 + d], Jz = t[4 + d];
+      float A[12];
+#pragma unroll
+      for (int c = 0; c < 6; c++) { A[c] = I >= 0 ? -t[6 + 6 * d + c] : 0.0f; A[6 + c] = J >= 0 ? t[18 + 6 * d + c] : 0.0f; }
+      float p = 0.0f, q = 0.0f, mt = 0.0f, dd = 0.0f, dg[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) { p += A[c] * Y[c]; q += A[c] * X[c]; mt += A[c] * tiny[c]; }
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const float a0 = same ? A[c] + A[6 + c] : A[c], a1 = same ? a0 : A[6 + c];
+        dg[c] = a0 * Y[c] * X[c]; dg[6 + c] = a1 * Y[6 + c] * X[6 + c];
+        dd += same ? a0 * dg[c] : (A[c] * dg[c] + A[6 + c] * dg[6 + c]);
+      }
+      const float lam = p + Jz * zb, rho = r - q - Jz * dZk;
+      g[d] = w * lam;
+      g[2 + d] = lam * rho - 1e-4f * dd + Jz * mt + Jz * Jz * ctiny;
+      g[4 + d] = w * (zb * rho - dZk * lam) + w * mt + 2.0f * w * Jz * ctiny;
+#pragma unroll
+      for (int c = 0; c < 12; c++) {
+        const float Ab = w * (rho * Y[c] - lam * X[c]) - 2e-4f * w * dg[c] + w * Jz * tiny[c];
+        if (c < 6) g[6 + 6 * d + c] = I >= 0 ? -Ab : 0.0f;          // Ji enters as -Ji
+        else g[18 + 6 * d + (c - 6)] = J >= 0 ? Ab : 0.0f;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------- reproject / transform
 __global__ void k_reproject(const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
                             const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
@@ -1351,7 +1478,7 @@ __global__ void k_neighbors(const int64_t* __restrict__ jj, int E, const int* __
 
 // ------------------------------------------------------------------------------------------------- workspace
 struct BaLayout {
-  size_t meta, rank, counts, cursor, ku, perm_a, perm_b, kx, partials, S, y, dX, patch_rec, edge_ej, total;
+  size_t meta, rank, counts, cursor, ku, perm_a, perm_b, kx, partials, S, y, dX, patch_rec, edge_ej, prec, ybar, total;
   int max_seg, n_part;
 };
 static BaLayout ba_layout(int E, int Np, int N) {
@@ -1377,6 +1504,8 @@ static BaLayout ba_layout(int E, int Np, int N) {
   L.dX = take(sizeof(float) * (n6 + 1));
   L.patch_rec = take(sizeof(float) * 2 * (size_t)L.max_seg);
   L.edge_ej = take(sizeof(float) * (size_t)L.max_seg * (n6 > 0 ? n6 : 1));      // E column of every patch
+  L.prec = take(sizeof(float) * 8 * (size_t)L.max_seg);                          // backward of devo_ba_solve_terms: per-patch adjoints
+  L.ybar = take(sizeof(float) * (n6 + 1));
   L.total = off;
   return L;
 }
@@ -1568,6 +1697,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   if (status_flag && hipMemsetAsync(status_flag, 0, sizeof(int), st) != hipSuccess) { set_error("devo_ba_forward: memset failed"); return DEVO_ERR_LAUNCH; }
 
   const size_t n6 = 6 * (size_t)N;
+  const float ep = 1.0f;                                          // ba_cuda.cu:518
   const size_t acc_lds = sizeof(float) * (n6 * (n6 + 1) + n6 + ACC_WAVES * n6 + 4);
   const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 72 * (size_t)N + n6 + 4);
   static const bool force_generic = getenv("DEVO_BA_GENERIC") != nullptr;   // test switch: the general accumulate kernel for every N
@@ -1592,7 +1722,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
                        weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, it, ba_sig(E, N), L.max_seg);
     if ((rc = check_launch("devo_ba_forward(accumulate)"))) return rc;
     if (N > 0) {
-      hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, partials, L.n_part, N, S, y);
+      hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, partials, L.n_part, N, S, y, ep);
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       static const bool ba_trace = getenv("DEVO_BA_TRACE") != nullptr;
       hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace ? 1 : 0);
@@ -1609,6 +1739,104 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
     if ((rc = check_launch("devo_ba_forward(retract)"))) return rc;
   }
   return check_launch("devo_ba_forward");
+}
+
+
+// ---- one differentiable Gauss-Newton step from given edge terms (devo/ba.py:108-170) and its adjoint
+static int bt_common(const char* who, int E, int Np, int N, size_t ws_bytes, void* ws, BaLayout* L) {
+  if (!(E >= 0 && Np > 0 && N >= 0)) { set_error("%s: bad sizes", who); return DEVO_ERR_ARG; }
+  if (N > BA_MAXN) { set_error("%s: %d optimised poses > %d supported", who, N, BA_MAXN); return DEVO_ERR_UNSUPPORTED; }
+  *L = ba_layout(E, Np, N);
+  if (ws == nullptr || ws_bytes < L->total) { set_error("%s: workspace %zu < %zu bytes", who, ws_bytes, L->total); return DEVO_ERR_WORKSPACE; }
+  return DEVO_OK;
+}
+
+int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E,
+                        int Np, int t0, int N, float ep, void* ws, size_t ws_bytes, float* dX_out, float* dZ_out, int* status_flag,
+                        devo_stream_t stream) {
+  BaLayout L;
+  int rc;
+  if ((rc = bt_common("devo_ba_solve_terms", E, Np, N, ws_bytes, ws, &L))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n6 = 6 * (size_t)N;
+  if (hipMemsetAsync(dZ_out, 0, sizeof(float) * (size_t)Np, st) != hipSuccess || (n6 && hipMemsetAsync(dX_out, 0, sizeof(float) * n6, st) != hipSuccess) ||
+      (status_flag && hipMemsetAsync(status_flag, 0, sizeof(int), st) != hipSuccess)) { set_error("devo_ba_solve_terms: memset failed"); return DEVO_ERR_LAUNCH; }
+  if (E == 0) return DEVO_OK;
+  if ((rc = ba_prepare_impl(kk, E, Np, N, ws, ws_bytes, st))) return rc;
+  char* w = (char*)ws;
+  BaMeta* meta = (BaMeta*)(w + L.meta);
+  float* S = (float*)(w + L.S);
+  float* dX = (float*)(w + L.dX);
+  float* patch_rec = (float*)(w + L.patch_rec);
+  float* patch_col = (float*)(w + L.edge_ej);
+  const size_t acc_lds = sizeof(float) * (n6 * (n6 + 1) + n6 + ACC_WAVES * n6 + 4);
+  const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 72 * (size_t)N + n6 + 4);
+  const bool use_reg = N <= 16;
+  const size_t acc_lds_used = use_reg ? sizeof(float) * (n6 * (n6 + 1) + n6 + REG_WAVES * n6 + 4 + REG_WAVES * SCR_ROWS * 64 +
+                                                        REG_WAVES * ((size_t)N * (N + 1) / 2 * 36 + n6)) : acc_lds;
+  typedef void (*acc_fn_t)(const float*, const float*, const float*, TargetSrc, const float*, const float*, const int64_t*,
+                           const int64_t*, const int64_t*, const int*, const int*, BaMeta*, int, int, int, float*, float*,
+                           float*, int, int, int);
+  acc_fn_t acc_fn = k_ba_accumulate;
+  if (use_reg) acc_fn = (N <= 8) ? k_ba_accumulate_reg<8> : (N <= 11) ? k_ba_accumulate_reg<11> : (N <= 14) ? k_ba_accumulate_reg<14> : k_ba_accumulate_reg<16>;
+  if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds_used) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("devo_ba_solve_terms: cannot reserve %zu / %zu bytes of LDS", acc_lds_used, solve_lds);
+      return DEVO_ERR_LAUNCH;
+    }
+  }
+  static const float dummy_intr[4] = {1.0f, 1.0f, 0.0f, 0.0f};
+  (void)dummy_intr;
+  // (poses / patches / intrinsics / weight are not read in terms mode; lmbda doubles as the 4-float intrinsics read)
+  const TargetSrc src{nullptr, nullptr, 0, 0, 0, terms};
+  hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? REG_THREADS : ACC_THREADS), acc_lds_used, st, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)(w + L.y) /* 4 readable floats */, src, (const float*)nullptr, lmbda, ii, jj, kk, (int*)(w + L.perm_b), (int*)(w + L.counts),
+                     meta, 3, t0, N, (float*)(w + L.partials), patch_rec, patch_col, 0, ba_sig(E, N), L.max_seg);
+  if ((rc = check_launch("devo_ba_solve_terms(accumulate)"))) return rc;
+  if (N > 0) {
+    hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, (float*)(w + L.partials), L.n_part, N, S,
+                       (float*)(w + L.y), ep);
+    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, (float*)(w + L.y), N, dX, meta, 0, status_flag, 0);
+    if ((rc = check_launch("devo_ba_solve_terms(solve)"))) return rc;
+    if (hipMemcpyAsync(dX_out, dX, sizeof(float) * n6, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("devo_ba_solve_terms: copy failed"); return DEVO_ERR_LAUNCH; }
+  }
+  hipLaunchKernelGGL(k_bt_dz, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, dX, patch_rec, patch_col, (int*)(w + L.kx), meta, N, dZ_out);
+  return check_launch("devo_ba_solve_terms");
+}
+
+int devo_ba_solve_terms_backward(const float* terms, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Np, int t0, int N, void* ws,
+                                 size_t ws_bytes, const float* g_dX, const float* g_dZ, float* g_terms, devo_stream_t stream) {
+  BaLayout L;
+  int rc;
+  if ((rc = bt_common("devo_ba_solve_terms_backward", E, Np, N, ws_bytes, ws, &L))) return rc;
+  if (E == 0) return DEVO_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n6 = 6 * (size_t)N;
+  char* w = (char*)ws;
+  BaMeta* meta = (BaMeta*)(w + L.meta);
+  float* S = (float*)(w + L.S);
+  float* dX = (float*)(w + L.dX);
+  float* ybar = (float*)(w + L.ybar);
+  float* patch_rec = (float*)(w + L.patch_rec);
+  float* patch_col = (float*)(w + L.edge_ej);
+  float* prec = (float*)(w + L.prec);
+  const int* kx = (const int*)(w + L.kx);
+  if (hipMemsetAsync(ybar, 0, sizeof(float) * (n6 + 1), st) != hipSuccess) { set_error("devo_ba_solve_terms_backward: memset failed"); return DEVO_ERR_LAUNCH; }
+  if (N > 0) {
+    float* rhs = S + n6 * (n6 + 1);                            // the solver image's right-hand-side row
+    if (hipMemcpyAsync(rhs, g_dX, sizeof(float) * n6, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("devo_ba_solve_terms_backward: copy failed"); return DEVO_ERR_LAUNCH; }
+    hipLaunchKernelGGL(k_bt_rhs, dim3(64), dim3(256), 0, st, rhs, g_dZ, patch_rec, patch_col, kx, meta, N);
+    const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 72 * (size_t)N + n6 + 4);
+    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, (float*)(w + L.y), N, ybar, meta, 0, (int*)nullptr, 0);
+    if ((rc = check_launch("devo_ba_solve_terms_backward(solve)"))) return rc;
+  }
+  hipLaunchKernelGGL(k_bt_patch, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, dX, ybar, g_dZ, patch_rec, patch_col, kx, meta, N, prec);
+  int* inv = (int*)(w + L.rank);                                // [Np + 1] ints, free once the graph is prepared
+  hipLaunchKernelGGL(k_bt_inv, dim3(blocks_for(L.max_seg, 256, 256)), dim3(256), 0, st, kx, meta, inv);
+  hipLaunchKernelGGL(k_bt_edge, dim3(blocks_for(E, 128, 4096)), dim3(128), 0, st, terms, ii, jj, kk, inv, dX, ybar, patch_col, prec, meta, E, t0, N, g_terms);
+  return check_launch("devo_ba_solve_terms_backward");
 }
 
 size_t devo_neighbors_workspace_bytes(int E) {

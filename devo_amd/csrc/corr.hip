@@ -787,7 +787,9 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
                                   : (R <= 3 ? corr_fwd_mfma_kernel<MT, 3, NGR, 1> : corr_fwd_mfma_kernel<MT, 5, NGR, 1>))
     const mfma_fn_t fn = ngr == 4 ? DEVO_MFMA_PICK(4) : DEVO_MFMA_PICK(8);
 #undef DEVO_MFMA_PICK
-    const dim3 mgrid(both ? (unsigned)BE : per_level * nlev), mblock(64);
+    // DEVO_MFMA_EPW edges (waves) per workgroup; grids are whole groups of 8 workgroups (one per XCD)
+    const unsigned wg_level = (unsigned)(((BE + DEVO_MFMA_EPW - 1) / DEVO_MFMA_EPW + 7) / 8 * 8);
+    const dim3 mgrid(DEVO_MFMA_EPW == 1 ? (both ? (unsigned)BE : per_level * nlev) : (both || nlev == 1 ? wg_level : wg_level * 2)), mblock(64 * DEVO_MFMA_EPW);
     hipLaunchKernelGGL(fn, mgrid, mblock, 0, st, (const MT*)fmap1, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2,
                        C, oes, ols, R, order, trace);
   } else

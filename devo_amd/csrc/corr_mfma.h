@@ -29,6 +29,14 @@
 #ifndef DEVO_MFMA_WAVES
 #define DEVO_MFMA_WAVES 4
 #endif
+// Edges (= waves) per workgroup.  The waves of a workgroup never synchronise; putting the waves of EPW CONSECUTIVE plan slots
+// into one workgroup only guarantees that spatial neighbours (the plan sorts by frame, 16-row band, 8-px column) run on the
+// same CU at the same time, so that their overlapping boxes could meet in the CU's L1.  Measured on cfg2 (profiles/README.md,
+// r02): 1 / 2 / 4 / 8 edges per workgroup = 191 / 208 / 211 / 222 us (fp32), 99 / 100 / 104 / 128 us (fp16) — the lost
+// heavy-first schedule and the coarser dispatch cost more than the shared lines save, so the default stays 1.
+#ifndef DEVO_MFMA_EPW
+#define DEVO_MFMA_EPW 1
+#endif
 typedef float mfma_acc4 __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 typedef _Float16 mfma_h4 __attribute__((ext_vector_type(4)));
@@ -57,16 +65,18 @@ __device__ __forceinline__ int corr_plan_slot(const int* __restrict__ order, int
   acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, (BV), acc2, 4, (U), 0)
 
 template <typename T, int RMAX, int NGR, int NL>   // NGR = C / (16 | 32) steps per pass (a multiple of the ring); NL = levels per wave
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WAVES, DEVO_MFMA_WAVES))) void corr_fwd_mfma_kernel(
+__global__ __launch_bounds__(64 * DEVO_MFMA_EPW) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WAVES, DEVO_MFMA_WAVES))) void corr_fwd_mfma_kernel(
     const T* __restrict__ fmap1, CorrLevel lv0, CorrLevel lv1, int nlev, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int64_t out_estride, int64_t out_lstride, int R, const int* __restrict__ order,
     unsigned long long* __restrict__ trace) {
   // NL == 1 with nlev == 2: the levels alternate in groups of 8 workgroups (see corr_fwd_cl_kernel); NL == 2: one
   // workgroup per edge does both.  lev(l) = the level this wave works on as its l-th.
+  constexpr int EPW = DEVO_MFMA_EPW;
+  const int wv = EPW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // this wave's edge inside the workgroup
   const int wlvl = (NL == 1 && nlev == 2) ? ((blockIdx.x >> 3) & 1) : 0;                      // wave-uniform
-  const int gid = (NL == 1 && nlev == 2) ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : blockIdx.x;
-  const int nitems = (NL == 1 && nlev == 2) ? (gridDim.x >> 1) : gridDim.x;
+  const int wgid = (NL == 1 && nlev == 2) ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : blockIdx.x;
+  const int nwg = (NL == 1 && nlev == 2) ? (gridDim.x >> 1) : gridDim.x;
   constexpr bool HALF = sizeof(T) == 2;
   constexpr int STEPCH = HALF ? 32 : 16;             // channels per step (four 16-byte pieces of a position)
   constexpr unsigned ESZ = sizeof(T);
@@ -81,9 +91,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   constexpr int BOXS = 128;
   constexpr int RWIN_FLOATS = (PP * (DMAX * DMAX + 1) + 3) / 4 * 4;
   constexpr int RW_FLOATS = RWIN_FLOATS > PP * BOXS ? RWIN_FLOATS : PP * BOXS;
-  __shared__ __attribute__((aligned(16))) float s_rawwin[NL * RW_FLOATS];
-  const int lane = threadIdx.x;
-  const int slot = corr_plan_slot(order, BE, gid, nitems);
+  __shared__ __attribute__((aligned(16))) float s_rawwin_all[EPW][NL * RW_FLOATS];
+  float* const s_rawwin = s_rawwin_all[wv];
+  const int lane = threadIdx.x & 63;
+  // EPW == 1: the plan's heavy-first / XCD-aware slot map.  EPW > 1: workgroup g (on XCD g % 8) takes EPW consecutive slots of
+  // its XCD's contiguous share of the plan.
+  int slot;
+  if (EPW == 1) slot = corr_plan_slot(order, BE, wgid, nwg);
+  else { const int per = (nwg + 7) >> 3; slot = (((wgid & 7) * per + (wgid >> 3)) * EPW) + wv; if ((wgid >> 3) >= per) slot = BE; }
   if (slot >= BE) return;                     // wave-uniform; no workgroup barriers in this kernel
   const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ULL;
   const int be = order ? order[slot] : slot;
@@ -156,7 +171,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEVO_MFMA_WA
   // window origins of the 9 pixels per level index -> LDS (the scatter reads them back as broadcasts: LDS instructions,
   // not vector ALU — every vector instruction of this kernel competes with the MFMAs for the SIMD's issue slot);
   // sub-pixel fractions -> one register pair: lane p holds level index 0's, lane 16 + p level index 1's
-  __shared__ int s_org[NL][PP][2];
+  __shared__ int s_org_all[EPW][NL][PP][2];
+  int (*const s_org)[PP][2] = s_org_all[wv];
   float fdx, fdy;
   {
 #pragma unroll

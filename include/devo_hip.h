@@ -160,6 +160,24 @@ int devo_ba_forward_prepared_delta(float* poses, float* patches, const float* in
                                    const int64_t* kk, int E, int Nbuf, int Np, int P, int t0, int t1, int iterations,
                                    void* ws, size_t ws_bytes, int* status_flag, devo_stream_t stream);
 
+/* One differentiable Gauss-Newton step of devo/ba.py:108-170 (normal equations, Schur complement over the patches, damped
+ * Cholesky solve) from GIVEN per-edge terms, for devo_amd.ba.BA (the reference builds it with ten matmuls + ten
+ * torch_scatter.scatter_sum calls and solves with CholeskySolver, ba.py:12-37).
+ * terms f32 [E,30]: r[2] w[2] Jz[2] Ji[2][6] Jj[2][6] with Ji = MINUS d coords / d xi_i (this library's sign convention);
+ * frames < t0 or >= t0 + N are fixed; damping S_dd + ep + 1e-4 S_dd (ba.py:73); lmbda f32 [1] on the device.
+ * Outputs: dX f32 [6 N] (zero when the factorisation breaks down, like ba.py:16-20; *status_flag = 1 then),
+ * dZ f32 [Np] per patch SLOT (zero for patches without an edge).  The workspace (devo_ba_workspace_bytes(E, Np, N)) keeps
+ * what the adjoint needs: pass it unmodified to devo_ba_solve_terms_backward. */
+int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E,
+                        int Np, int t0, int N, float ep, void* ws, size_t ws_bytes, float* dX, float* dZ, int* status_flag,
+                        devo_stream_t stream);
+
+/* Adjoint of devo_ba_solve_terms (what autograd derives for ba.py:108-170 + CholeskySolver.backward, ba.py:28-37): from the
+ * gradients of dX [6 N] and dZ [Np] to the gradient of the 30 terms of every edge, g_terms f32 [E,30].  One more solve with
+ * the saved matrix, then per-patch and per-edge kernels. */
+int devo_ba_solve_terms_backward(const float* terms, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Np, int t0, int N, void* ws,
+                                 size_t ws_bytes, const float* g_dX, const float* g_dZ, float* g_terms, devo_stream_t stream);
+
 size_t devo_neighbors_workspace_bytes(int E);
 
 /* cuda_ba.neighbors  (ba.cpp:154 -> ba.cpp:104-149): for every edge the previous / next edge of the same

@@ -64,6 +64,32 @@ def test_forward_wide_spread_uses_fallback_path():
     assert_rel(_run(*c, layout="cl"), A.corr_forward(*c), 1e-4, "multi-chunk")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_nchw_pyramid_goes_through_a_cached_blocked_copy(dtype):
+    """What an unmodified devo.py hands over: an NCHW ring buffer that is rewritten in place, one frame per step
+    (devo/devo.py:71-83, 210-217).  From 1024 edges on the lookup converts it once per VERSION of the tensor into a
+    channel-blocked copy: same bits as the explicit blocked layout, the copy is reused while the tensor is untouched, and an
+    in-place frame update is seen."""
+    from devo_amd import altcorr
+    from devo_amd.backends import cuda_corr
+    f1, f2, coords, ii, jj, R = _case(E=1500, seed=21)
+    d = lambda t: t.to(DEV)
+    ring = d(f2).to(dtype)                                              # NCHW, like self.fmap1_
+    g = d(f1).to(dtype)
+    pyr = [ring, torch.nn.functional.avg_pool2d(ring[0].float(), 2, 2)[None].to(dtype)]
+    call = lambda: cuda_corr.forward_pyramid(g, pyr, d(coords), d(ii), d(jj), R, (1, 2))
+    ref = lambda: cuda_corr.forward_pyramid(g, [altcorr.channel_blocked(p_.clone(), 8) for p_ in pyr], d(coords), d(ii), d(jj), R, (1, 2))
+    a = call()
+    assert torch.equal(a, ref())
+    n_cached = len(cuda_corr._blocked_cache)
+    assert n_cached >= 2 and torch.equal(call(), a) and len(cuda_corr._blocked_cache) == n_cached      # cache hit: no new copy
+    ring[:, 1] = ring[:, 1] * -0.5                                     # the per-frame in-place update of the ring (version bump)
+    b = call()
+    assert not torch.equal(a, b) and torch.equal(b, ref())
+    small = cuda_corr.forward(g, ring, d(coords)[:, :64], d(ii)[:64], d(jj)[:64], R)[0]      # short edge lists read NCHW directly
+    assert_rel(small, A.corr_forward(f1.to(dtype).float(), ring.float().cpu(), coords[:, :64], ii[:64], jj[:64], R), 2e-3 if dtype == torch.float16 else 1e-4, "nchw direct")
+
+
 def test_channel_blocked_layout_is_bit_identical_and_checked():
     """[B,n,C/8,H,W,8] storage feeds the same kernel through other addresses: results are bit-identical to
     channels-last (split boxes and the opt-in LDS-direct kernel's layouts included); bad block sizes are rejected."""

@@ -324,14 +324,16 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
 
     # which lookup kernel the library picks for this configuration (devo_amd/csrc/corr.hip: launch_staged)
     mfma = cfg["C"] == 128 and os.environ.get("DEVO_CORR_MFMA", "1")[:1] != "0"          # fp32 and fp16 storage
-    lookup_kernel = "corr_fwd_generic_kernel" if args.layout == "nchw" else ("corr_fwd_mfma_kernel" if mfma else "corr_fwd_cl_kernel")
+    # (an NCHW pyramid of >= 1024 edges goes through cuda_corr's cached channel-blocked copy, i.e. the same fast kernel)
+    nchw_direct = args.layout == "nchw" and (E < 1024 or os.environ.get("DEVO_CORR_NCHW_DIRECT", "0") == "1" or cfg["C"] % 8 != 0)
+    lookup_kernel = "corr_fwd_generic_kernel" if nchw_direct else ("corr_fwd_mfma_kernel" if mfma else "corr_fwd_cl_kernel")
     if args.layout != "nchw" and os.environ.get("DEVO_CORR_DENSE", "0")[:1] == "1":
         lookup_kernel = "corr_fwd_dense_kernel"                     # opt-in region-staged kernel (corr_dense.h)
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             recs = json.load(f)
-        key = f"{args.workload}/{dtn}/{args.layout}"
+        key = f"{args.workload}/{dtn}/{'blk8' if args.layout == 'nchw' and not nchw_direct else args.layout}"
         rec = (recs.get(key + "/staged") if lookup_kernel == "corr_fwd_cl_kernel" else None) or recs.get(key)
         per_launch = 2 if args.fuse_levels else 1                  # records are per level launch ...
         if args.fuse_levels and lookup_kernel == "corr_fwd_mfma_kernel" and recs.get(key + "/fused"):

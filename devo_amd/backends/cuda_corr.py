@@ -169,7 +169,11 @@ def backward(fmap1, fmap2, coords, ii, jj, grad, radius):
     fmap1, fmap2, coords, ii, jj = _prep(fmap1, fmap2, coords, ii, jj)
     L.require_gpu(grad)
     if fmap1.dtype != torch.float32:
-        raise RuntimeError("cuda_corr.backward: fp32 only")
+        # the reference dispatches its backward over half / float / double with a FLOAT gradient accessor
+        # (correlation_kernel.cu:146,280); here the kernel is fp32: other dtypes are computed in fp32 and cast back
+        dt = fmap1.dtype
+        d1, d2 = backward(fmap1.float(), fmap2.float(), coords, ii, jj, grad.float(), radius)
+        return [d1.to(dt), d2.to(dt)]
     B, E = coords.shape[:2]
     P = coords.shape[3]
     _, Np, C = fmap1.shape[:3]
@@ -205,6 +209,8 @@ def patchify_backward(net, coords, gradient, radius):
     B, M = coords.shape[:2]
     C, H, W = net.shape[1:]
     coords = coords.float().contiguous()
+    if net.dtype == torch.float16:                    # scattered in fp32 (hardware float atomics), cast back like the forward's dtype
+        return [patchify_backward(net.float(), coords, gradient.float(), radius)[0].half()]
     gradient = gradient.to(net.dtype).contiguous()
     out = torch.empty(B, C, H, W, dtype=net.dtype, device=net.device)
     rc = L.lib().devo_patchify_backward(L.ptr(coords), L.ptr(gradient), L.ptr(out), B, M, C, H, W, int(radius),

@@ -33,6 +33,11 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half(v); }
 template <> __device__ __forceinline__ double from_f32<double>(float v) { return (double)v; }
 
+// accumulation type of the generic kernel: fp64 tensors accumulate (and blend) in fp64, like the reference's scalar_t arithmetic
+// (AT_DISPATCH_FLOATING_TYPES_AND_HALF, correlation_kernel.cu:203), so that gradcheck-style fp64 lookups are fp64-accurate
+template <typename T> struct AccOf { typedef float type; };
+template <> struct AccOf<double> { typedef double type; };
+
 // output stores bypass the caches' allocation (written once, read by a later kernel)
 __device__ __forceinline__ void store_streamed(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void store_streamed(double* p, double v) { __builtin_nontemporal_store(v, p); }
@@ -58,8 +63,8 @@ __device__ __forceinline__ float blend4(float dx, float dy, float r00, float r01
   return o;
 }
 
-template <typename T>
-__device__ __forceinline__ void corr_epilogue(const float* sraw, const float* sdx, const float* sdy, T* outp,
+template <typename T, typename A = float>
+__device__ __forceinline__ void corr_epilogue(const A* sraw, const float* sdx, const float* sdy, T* outp,
                                               int D, int64_t lstride) {
   const int Dm = D - 1;
   const int total = Dm * Dm * PP;
@@ -67,9 +72,18 @@ __device__ __forceinline__ void corr_epilogue(const float* sraw, const float* sd
     int p = l % PP;              // i0*3 + j0
     int a = (l / PP) % Dm;       // y offset  (logical dim 3)
     int c = l / (PP * Dm);       // x offset  (logical dim 2: permute(0,1,3,2,4,5), correlation_kernel.cu:232)
-    const float* r = sraw + p * D * D + a * D + c;
-    float o = blend4(sdx[p], sdy[p], r[0], r[1], r[D], r[D + 1]);
-    outp[(int64_t)l * lstride] = from_f32<T>(o);
+    const A* r = sraw + p * D * D + a * D + c;
+    if constexpr (sizeof(A) == 8) {                       // fp64: same expression order in double
+      const double dx = sdx[p], dy = sdy[p];
+      double o = ((1.0 - dx) * (1.0 - dy)) * r[0];
+      o = o + (dx * (1.0 - dy)) * r[1];
+      o = o + ((1.0 - dx) * dy) * r[D];
+      o = o + (dx * dy) * r[D + 1];
+      outp[(int64_t)l * lstride] = (T)o;
+    } else {
+      float o = blend4(sdx[p], sdy[p], r[0], r[1], r[D], r[D + 1]);
+      outp[(int64_t)l * lstride] = from_f32<T>(o);
+    }
   }
 }
 
@@ -472,7 +486,8 @@ __global__ __launch_bounds__(NT) void corr_fwd_generic_kernel(
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int E, int Np, int n2,
     int C, int H2, int W2, int64_t s_b, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int64_t out_estride,
     int64_t out_lstride, int64_t out_offset, int R, float coord_div) {
-  __shared__ float s_raw[PP * MAXD * MAXD];
+  typedef typename AccOf<T>::type A;
+  __shared__ A s_raw[PP * MAXD * MAXD];
   __shared__ float s_dx[PP], s_dy[PP];
   __shared__ int s_ox[PP], s_oy[PP];
   const int D = 2 * R + 2;
@@ -493,15 +508,16 @@ __global__ __launch_bounds__(NT) void corr_fwd_generic_kernel(
   for (int o = tid; o < PP * D * D; o += NT) {
     int p = o / (D * D), a = (o / D) % D, c = o % D;
     int gy = s_oy[p] + a, gx = s_ox[p] + c;
-    float s = 0.0f;
+    A s = 0;
     if (gy >= 0 && gy < H2 && gx >= 0 && gx < W2) {
       const T* src = f2 + (int64_t)gy * s_h + (int64_t)gx * s_w;
-      for (int k = 0; k < C; k++) s = fmaf(to_f32<T>(f1[k * PP + p]), to_f32<T>(src[(int64_t)k * s_c]), s);
+      if constexpr (sizeof(A) == 8) { for (int k = 0; k < C; k++) s = fma((double)f1[k * PP + p], (double)src[(int64_t)k * s_c], s); }
+      else { for (int k = 0; k < C; k++) s = fmaf(to_f32<T>(f1[k * PP + p]), to_f32<T>(src[(int64_t)k * s_c]), s); }
     }
     s_raw[o] = s;
   }
   __syncthreads();
-  corr_epilogue<T>(s_raw, s_dx, s_dy, out + (int64_t)be * out_estride + out_offset, D, out_lstride);
+  corr_epilogue<T, A>(s_raw, s_dx, s_dy, out + (int64_t)be * out_estride + out_offset, D, out_lstride);
 }
 
 // -------------------------------------------------------------------------------------------------

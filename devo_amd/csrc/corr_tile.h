@@ -3,6 +3,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef DEVO_PLAN_BAND
+#define DEVO_PLAN_BAND 16                        // rows per band of the locality plan
+#endif
+
 namespace devo {
 
 constexpr int CORR_KC = 8;                       // channels staged per LDS chunk
@@ -36,7 +40,7 @@ __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float c
   // HEAVY = more than two 64-position passes of the matrix-core kernel (which includes every box the staged kernel's tile
   // cannot hold): the long items start first
   if ((long long)(xhi - xlo + D) * (yhi - ylo + D) > 128 || !tile_fits(xhi - xlo + D, yhi - ylo + D, ng)) return -1;
-  int band = (int)(fminf(fmaxf(centre_y, 0.0f), (float)(H2 - 1))) / 16;
+  int band = (int)(fminf(fmaxf(centre_y, 0.0f), (float)(H2 - 1))) / DEVO_PLAN_BAND;
   band = min(max(band, 0), nb - 1);
   int xb = (int)(fminf(fmaxf(centre_x, 0.0f), 1.0e6f)) / xw;
   xb = min(max(xb, 0), nxb - 1);
@@ -50,7 +54,7 @@ __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float c
 constexpr int CORR_ORDER_MAXBINS = 4096;        // (one LDS counter per bin next to the ordering kernel's staging buffer)
 struct CorrPlanGeom { int nb, nxb, xw; };
 inline CorrPlanGeom corr_plan_geom(long long B, int n2, int H2) {
-  CorrPlanGeom g{(H2 + 15) / 16, 1, 8};
+  CorrPlanGeom g{(H2 + DEVO_PLAN_BAND - 1) / DEVO_PLAN_BAND, 1, 8};
   while (B * n2 * g.nb > CORR_ORDER_MAXBINS && g.nb > 1) g.nb = (g.nb + 1) / 2;
   if (B * n2 * g.nb > CORR_ORDER_MAXBINS || g.nb > 255) { g.nb = 0; return g; }
   long long nx = CORR_ORDER_MAXBINS / (B * n2 * g.nb);

@@ -64,6 +64,30 @@ def test_forward_wide_spread_uses_fallback_path():
     assert_rel(_run(*c, layout="cl"), A.corr_forward(*c), 1e-4, "multi-chunk")
 
 
+def test_dtype_coverage_of_the_reference_dispatch():
+    """AT_DISPATCH_FLOATING_TYPES_AND_HALF (correlation_kernel.cu:203,247,299,320): fp64 lookups are fp64-accurate (fp64
+    accumulation in the strided kernel), the backward passes accept fp16 tensors (computed in fp32, cast back)."""
+    from devo_amd.backends import cuda_corr
+    f1, f2, coords, ii, jj, R = _case(E=40, C=32, seed=31)
+    d = lambda t: t.to(DEV)
+    ref = A.corr_forward(f1.double(), f2.double(), coords, ii, jj, R)
+    got, = cuda_corr.forward(d(f1).double(), d(f2).double(), d(coords), d(ii), d(jj), R)
+    assert got.dtype == torch.float64
+    assert_rel(got, ref, 1e-12, "fp64 lookup")
+    g = torch.randn(1, 40, 7, 7, 3, 3, generator=torch.Generator().manual_seed(1))
+    a1, a2 = cuda_corr.backward(d(f1), d(f2), d(coords), d(ii), d(jj), d(g), R)
+    h1, h2 = cuda_corr.backward(d(f1).half(), d(f2).half(), d(coords), d(ii), d(jj), d(g).half(), R)
+    assert h1.dtype == h2.dtype == torch.float16
+    assert_rel(h1.float(), a1, 5e-3, "fp16 d fmap1"); assert_rel(h2.float(), a2, 5e-3, "fp16 d fmap2")
+    net = torch.randn(1, 8, 12, 16, generator=torch.Generator().manual_seed(2))
+    pc = torch.tensor([[[3.0, 4.0], [10.0, 7.0], [0.0, 0.0]]])
+    pg = torch.randn(1, 3, 8, 4, 4, generator=torch.Generator().manual_seed(3))
+    b32, = cuda_corr.patchify_backward(d(net), d(pc), d(pg), 1)
+    b16, = cuda_corr.patchify_backward(d(net).half(), d(pc), d(pg).half(), 1)
+    assert b16.dtype == torch.float16
+    assert_rel(b16.float(), b32, 5e-3, "fp16 patchify backward")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_nchw_pyramid_goes_through_a_cached_blocked_copy(dtype):
     """What an unmodified devo.py hands over: an NCHW ring buffer that is rewritten in place, one frame per step

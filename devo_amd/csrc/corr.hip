@@ -784,8 +784,8 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
       const double r = h[0] ? (double)h[0] : 1.0;
       fprintf(stderr, "[dense stats] edges %lld, workgroups %u, rounds %llu (items/round %.2f, single-pixel rounds %llu), region positions/round: level 0 %.0f, level 1 %.0f, cycles/round %.0f\n",
               BE, dgrid.x, h[0], h[1] / r, h[4], h[2] / r, h[3] / r, h[5] / r);
-      fprintf(stderr, "[dense stats] cycles/round by phase: setup+request %.0f | level 1: wait %.0f, products %.0f, epilogue %.0f, tail %.0f | level 0: wait %.0f, products %.0f, epilogue %.0f, tail %.0f\n",
-              h[6] / r, h[7] / r, h[8] / r, h[9] / r, h[10] / r, h[11] / r, h[12] / r, h[13] / r, h[14] / r);
+      fprintf(stderr, "[dense stats] first compute wave, cycles/round by phase: item setup %.0f | waiting at the slab barriers %.0f | products %.0f | epilogue %.0f\n",
+              h[6] / r, h[7] / r, h[8] / r, h[9] / r);
       (void)hipFree(stats);
     }
   } else

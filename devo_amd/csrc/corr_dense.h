@@ -6,25 +6,27 @@
 // the CU's memory path — 1.05 GB per cfg2 launch — and a CU takes in only ~11 B/cycle from HBM / Infinity Cache and ~22-28
 // B/cycle from L2 (tools/ubench/dma_fill.hip), which is where its 99 us come from.  At DEVO's patch density each pyramid pixel
 // is wanted by 8 (level 0) to 90 (level 1) edges, so here
-//   * a WORKGROUP (8 waves, one per CU, all of the CU's LDS) takes SLOTS consecutive edges of the locality plan (same target
-//     frame, neighbouring image positions), forms the union REGION of their boxes per level and brings it into LDS ONCE per
-//     channel slab with LDS-DMA loads (global_load_lds_dwordx4: no staging registers, no ds_write pass);
-//   * a slab buffer holds one channel slab of BOTH levels' regions and of the items' patches; the kernel is ONE stream of slabs
-//     (round 0 slab 0, 1, .. , round 1 slab 0, ..) over two buffers: the next slab of the stream — also the next round's first,
-//     requested before the current round's epilogue — is always in flight while the current one is multiplied;
-//   * LDS image of a slab: planar [4 k-groups][position][16 B] per level (+ the patch slabs, raw): the A operand of the MFMA
-//     is one conflict-free ds_read_b128 per 16 positions;
+//   * a WORKGROUP (8 waves, one per CU) takes CHUNK consecutive edges of the locality plan (same target frame, neighbouring
+//     image positions) and forms ROUNDS of <= SLOTS edges whose union REGION per level fits a slab buffer;
+//   * PRODUCER / CONSUMER split: NLOAD loader waves do nothing but plan rounds and request slabs with LDS-DMA loads
+//     (global_load_lds_dwordx4: no staging registers, no ds_write pass), NCOMP compute waves multiply and write results.  The
+//     kernel is ONE stream of slabs (round 0 slab 0, 1, .., round 1 slab 0, ..) over two LDS buffers with one workgroup barrier
+//     per slab: behind barrier g slab g has landed and slab g - 1 is consumed, so the loaders request slab g + 1 — also the
+//     NEXT round's first, while the compute waves are still in the current round's epilogue — and the compute waves multiply
+//     slab g.  A slab = one channel slab (32 channels fp16 / 16 channels fp32) of BOTH levels' regions and of the items' patches;
+//   * LDS image of a slab: planar [4 pieces][position][16 B] per level (+ the patch slabs, raw): for fp16 the A operand of the
+//     MFMA is one conflict-free ds_read_b128 per 16 positions;
 //   * the products run on v_mfma_f32_16x16x32_f16: M = 16 consecutive box positions of an edge, N = 16 patch pixels (9 used),
-//     K = 32 channels; a wave keeps the accumulators of its EPW edges (both levels, <= MAXT0 + MAXT1 tiles of 16 positions)
-//     in registers across the channel slabs, so a staged slab serves all edges of the group;
-//   * fp16 storage: operands as stored, fp32 accumulation.  fp32 storage: a landed slab (16 channels) is split IN PLACE,
-//     exactly, into hi + lo fp16 parts (x * 16 = hi + lo, 22 significant bits; the remainder is below fp32's own rounding for
-//     |x| >= 2^-7 and 2e-9 absolute below that); the MFMA sees K = [hi(16) | lo(16)] against B1 = [hi | hi] and B2 = [lo | lo]
-//     of the patch, i.e. the full product (a_hi + a_lo)(b_hi + b_lo) with fp32 accumulation — fp32-class results (measured
-//     against the fp64 oracle in tests/test_gpu_altcorr.py) at 1/4 of the matrix-pipe time of the exact fp32 MFMA.
-//     Domain of the fp32 path: |feature| < 4094 (fp16 range after the x16 prescale); DEVO_CORR_DENSE=0 selects the exact kernel.
-//   * the epilogue blends level 1 into registers, then level 0, and writes the interleaved two-level record
-//     (torch.stack([c0, c1], -1)) with full-width stores.
+//     K = 32 channels; a compute wave keeps the accumulators of its EPW edges (both levels, <= MAXT0 + MAXT1 tiles of 16
+//     positions) in registers across the channel slabs, so a staged slab serves all edges of the round;
+//   * fp16 storage: operands as stored, fp32 accumulation.  fp32 storage: the compute waves split every value they read exactly
+//     into hi + lo fp16 parts (x * 16 = hi + lo, 22 significant bits; the remainder is below fp32's own rounding for |x| >= 2^-7
+//     and 2e-9 absolute below that); the MFMA sees K = [hi(16) | lo(16)] against B1 = [hi | hi] and B2 = [lo | lo] of the patch,
+//     i.e. the full product (a_hi + a_lo)(b_hi + b_lo) with fp32 accumulation — fp32-class results (measured against the fp64
+//     oracle in tests/test_gpu_altcorr.py) at 1/4 of the matrix-pipe time of the exact fp32 MFMA.  Domain of the fp32 path:
+//     |feature| < 4094 (fp16 range after the x16 prescale); DEVO_CORR_DENSE=0 selects the exact kernel;
+//   * the epilogue (wave-private raw window areas outside the slab buffers) blends level 1 into registers, then level 0, and
+//     writes the interleaved two-level record (torch.stack([c0, c1], -1)) with full-width stores.
 // Edges whose box exceeds the tile capacity at either level ("heavy": patch pixels spread apart) are processed as 9
 // single-pixel items (window = box), any coordinates work; rounds are formed greedily so that the regions fit their buffers.
 #pragma once
@@ -35,22 +37,23 @@ typedef float dn_f4 __attribute__((ext_vector_type(4)));
 
 constexpr int DN_WAVES = 8;                                 // ONE 512-thread workgroup per CU (2 waves per SIMD)
 constexpr int DN_THREADS = DN_WAVES * 64;
+constexpr int DN_NLOAD = 2;                                 // loader waves
+constexpr int DN_NCOMP = DN_WAVES - DN_NLOAD;               // compute waves
 constexpr float DN_PRESCALE = 16.0f;                        // fp32 storage: x * 16 = hi + lo (both operands)
 constexpr float DN_UNSCALE = 1.0f / 256.0f;
 
 template <int RMAX, int NL> struct DnShape {
   static constexpr int MAXT0 = RMAX <= 3 ? 10 : 16;         // 16-position tiles per item, finest level of the call
   static constexpr int MAXT1 = NL == 2 ? (RMAX <= 3 ? 6 : 12) : 0;   // ... coarse level
-  static constexpr int EPW = RMAX <= 3 ? 2 : 1;             // items per wave
-  static constexpr int SLOTS = DN_WAVES * EPW;              // items per round
-  static constexpr int CHUNK = 2 * SLOTS;                   // edges per workgroup
-  static constexpr int R0CH = 13;                           // 64-position chunks of the level-0 region (832 positions)
-  static constexpr int R1CH = NL == 2 ? (RMAX <= 3 ? 3 : 5) : 0;     // ... of the coarse level's region
+  static constexpr int EPW = RMAX <= 3 ? 2 : 1;             // items per compute wave
+  static constexpr int SLOTS = DN_NCOMP * EPW;              // items per round
+  static constexpr int CHUNK = 3 * SLOTS;                   // edges per workgroup
+  static constexpr int R0CH = RMAX <= 3 ? 9 : 8;            // 64-position chunks of the level-0 region
+  static constexpr int R1CH = NL == 2 ? 3 : 0;              // ... of the coarse level's region
   static constexpr int NPCH = (SLOTS * 36 + 63) / 64;       // 1 KB chunks of the patch part (36 16-byte pieces per item)
+  static constexpr int BUFSZ = (R0CH + R1CH) * 4096 + NPCH * 1024;
   static constexpr int BOXSP = 16 * MAXT0 + 4;              // row pitch of the raw result area (conflict-free b128 dumps)
-  static constexpr int SLABSZ = (R0CH + R1CH) * 4096 + NPCH * 1024;
-  static constexpr int RAWALL = (DN_WAVES * 9 * BOXSP * 4 + 1023) / 1024 * 1024;    // the waves' raw result areas live in a consumed buffer
-  static constexpr int BUFSZ = SLABSZ > RAWALL ? SLABSZ : RAWALL;
+  static constexpr int RAWSZ = 9 * BOXSP * 4;               // a compute wave's raw result area
   static constexpr int DMAX = 2 * RMAX + 2;
   static constexpr int NQ = ((DMAX - 1) * (DMAX - 1) + 6) / 7;   // epilogue rounds of 63 outputs
 };
@@ -85,17 +88,17 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   constexpr int SC = HALF ? 32 : 16;                        // channels per slab
   constexpr unsigned ESZ = sizeof(T);
   constexpr int MAXT0 = S::MAXT0, MAXT1 = S::MAXT1, EPW = S::EPW, SLOTS = S::SLOTS, CHUNK = S::CHUNK, BOXSP = S::BOXSP, NQ = S::NQ;
-  constexpr int NPCH = S::NPCH, BUFSZ = S::BUFSZ;
+  constexpr int NPCH = S::NPCH, BUFSZ = S::BUFSZ, RAWSZ = S::RAWSZ;
   constexpr int PPIECES = 36;                               // 16-byte pieces of one patch slab (SC * 9 * ESZ = 576 B)
-  constexpr int RAWSZ = PP * BOXSP * 4;                     // bytes of a wave's raw result area (inside a consumed slab buffer)
   constexpr int MT1 = MAXT1 > 0 ? MAXT1 : 1;
-  static_assert(DN_WAVES * RAWSZ <= BUFSZ, "raw result areas must fit a slab buffer");
-  static_assert(S::R0CH <= 2 * DN_WAVES && S::R1CH <= DN_WAVES && NPCH <= 2 * DN_WAVES, "DMA chunks per wave");
+  constexpr int L0PW = (S::R0CH + DN_NLOAD - 1) / DN_NLOAD, L1PW = (S::R1CH + DN_NLOAD - 1) / DN_NLOAD, PPW = (NPCH + DN_NLOAD - 1) / DN_NLOAD;
   static_assert(16 * MAXT0 <= S::R0CH * 64 && 16 * MAXT1 <= S::R1CH * 64 + (NL == 1), "a single item must fit the region");
   static_assert(S::R0CH * 4096 <= 65536 && S::R1CH * 4096 <= 65536, "16-bit tile addresses");
+  static_assert(SLOTS <= 16, "the round planner scans 16 candidates");
 #define LVF(l, F) ((NL == 2 && (l)) ? lv1.F : lv0.F)
 
   __shared__ __attribute__((aligned(1024))) unsigned char s_arena[2 * BUFSZ];
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[DN_NCOMP * RAWSZ];
   __shared__ int s_ox[NL][CHUNK][PP], s_oy[NL][CHUNK][PP];
   __shared__ float s_dx[NL][CHUNK][PP], s_dy[NL][CHUNK][PP];
   __shared__ int s_box[NL][CHUNK][4];                       // xmin, ymin, bw, bh of the edge's union box
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = 2 * R + 2, Dm = D - 1;
-  const unsigned arena0 = (unsigned)(uintptr_t)s_arena;     // LDS byte offset of the arena
+  const unsigned arena0 = (unsigned)(uintptr_t)s_arena;     // LDS byte offset of the slab buffers
   // chunk of the plan this workgroup owns: XCD x gets a contiguous range of chunks (workgroup g runs on XCD g % 8)
   const int nchunks = (BE + CHUNK - 1) / CHUNK;
   int chunk;
@@ -150,9 +153,8 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
   const int nslab = C / SC;                                   // >= 2 (launcher)
   const int am = lane & 15, kg = lane >> 4;
-  const char* const zero_src = reinterpret_cast<const char*>(g_corr_zero);
 
-  // ---- round planner (wave 0, lanes 0..15): the longest run of items whose union regions fit; result -> tables[par]
+  // ---- round planner (loader wave 0, lanes 0..15): the longest run of items whose union regions fit; result -> tables[par]
   auto plan_round = [&](int par) {
     const int cur = s_ctl[0], hp = s_ctl[1];
     int nit = 0;
@@ -186,116 +188,151 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     if (lane == 0) s_nit[par] = nit;
   };
 
-  // ---- DMA view of a round: wave-uniform geometry + this lane's source offsets.
-  //      Level-0 chunk c -> wave c % 8; level-1 chunk c -> wave 7 - c; patch chunk c -> wave c % 8.
-  struct Round {
-    int x0[NL], y0[NL], RW[NL], NP[NL], nck[NL];
-    unsigned ps[NL];                       // bytes of a k-group plane per level
-    const char* fbase[NL];                 // frame base per level
-    unsigned g0[2], g1, pp[2];             // lane's byte offset in the frame (level 0: two chunks; level 1) / in fmap1; ~0u = zeros
-  };
-  auto round_setup = [&](int par) -> Round {
-    Round rd;
-    const int nitems = s_nit[par];
-    const int frame = s_frame[s_item[par][0][0]];
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
-      rd.x0[l] = s_reg[par][l][0]; rd.y0[l] = s_reg[par][l][1]; rd.RW[l] = s_reg[par][l][2];
-      rd.NP[l] = rd.RW[l] * s_reg[par][l][3];
-      rd.nck[l] = (rd.NP[l] + 63) >> 6;
-      rd.ps[l] = (unsigned)rd.nck[l] * 1024u;
-      rd.fbase[l] = reinterpret_cast<const char*>(static_cast<const T*>(LVF(l, fmap2)) + (int64_t)(frame / n2) * LVF(l, s_b) +
-                                                  (int64_t)(frame % n2) * LVF(l, s_n));
-    }
-    auto src_off = [&](int l, int pos) -> unsigned {
-      const float inv_rw = __builtin_amdgcn_rcpf((float)rd.RW[l]);
-      const int ry = (int)(((float)pos + 0.5f) * inv_rw), rx = pos - ry * rd.RW[l];
-      const int gy = rd.y0[l] + ry, gx = rd.x0[l] + rx;
-      const bool in = pos < rd.NP[l] && gy >= 0 && gy < LVF(l, H2) && gx >= 0 && gx < LVF(l, W2);
-      return in ? (unsigned)(gy * (int)LVF(l, s_h) + gx * (int)LVF(l, s_w)) * ESZ : 0xffffffffu;
-    };
-    rd.g0[0] = src_off(0, wave * 64 + lane);
-    rd.g0[1] = src_off(0, (wave + DN_WAVES) * 64 + lane);
-    rd.g1 = NL == 2 ? src_off(NL - 1, (DN_WAVES - 1 - wave) * 64 + lane) : 0xffffffffu;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int id = (wave + DN_WAVES * j) * 64 + lane;
-      const int it = id / PPIECES, pc = id - it * PPIECES;
-      rd.pp[j] = (it < nitems) ? (unsigned)s_pi[s_item[par][it][0]] * (unsigned)(C * PP) * ESZ + (unsigned)pc * 16u : 0xffffffffu;
-    }
-    return rd;
-  };
-  // request slab s of a round into buffer `buf`
-  auto issue_slab = [&](const Round& rd, int s, int buf) {
-    const unsigned base = arena0 + (unsigned)buf * (unsigned)BUFSZ;
-    const unsigned c0 = (unsigned)(s * SC);
-    auto pieces = [&](int l, unsigned* so) {
-      const int sh = LVF(l, cb_shift);
-      const unsigned bb = (unsigned)LVF(l, block_stride) * ESZ;
-      auto piece = [&](unsigned c) -> unsigned { const unsigned blk = c >> sh; return blk * bb + (c - (blk << sh)) * ESZ; };
-      so[0] = piece(c0); so[1] = piece(c0 + SC / 4); so[2] = piece(c0 + SC / 2); so[3] = piece(c0 + 3 * SC / 4);
-    };
-    unsigned so[4];
-    pieces(0, so);
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int ck = wave + DN_WAVES * j;
-      if (ck < rd.nck[0]) {                                   // wave-uniform
-        const bool in = rd.g0[j] != 0xffffffffu;
-#pragma unroll
-        for (int q = 0; q < 4; q++) dn_dma16(in ? rd.fbase[0] + rd.g0[j] + so[q] : zero_src, base + (unsigned)q * rd.ps[0] + (unsigned)ck * 1024u);
-      }
-    }
-    unsigned pbase = base + 4u * rd.ps[0];
-    if constexpr (NL == 2) {
-      const int ck = DN_WAVES - 1 - wave;
-      if (ck < rd.nck[1]) {                                   // wave-uniform
-        pieces(1, so);
-        const bool in = rd.g1 != 0xffffffffu;
-#pragma unroll
-        for (int q = 0; q < 4; q++) dn_dma16(in ? rd.fbase[1] + rd.g1 + so[q] : zero_src, pbase + (unsigned)q * rd.ps[1] + (unsigned)ck * 1024u);
-      }
-      pbase += 4u * rd.ps[1];
-    }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int ck = wave + DN_WAVES * j;
-      if (ck < NPCH)                                          // wave-uniform
-        dn_dma16(rd.pp[j] != 0xffffffffu ? reinterpret_cast<const char*>(fmap1) + rd.pp[j] + (unsigned)s * 576u : zero_src, pbase + (unsigned)ck * 1024u);
-    }
-  };
-
   __syncthreads();                                            // geometry complete
   if (wave == 0) plan_round(0);
-  __syncthreads();
-  Round rd = round_setup(0);
-  issue_slab(rd, 0, 0);
-  int k = 0, par = 0;                                         // stream index of the next slab to multiply (buffer k & 1), round parity
+  __syncthreads();                                            // round 0 planned
 
+  if (wave < DN_NLOAD) {
+    // ============================================================================================ LOADER WAVES
+    // Level-0 chunk c -> loader c % NLOAD (its j-th: c = wave + NLOAD * j); level-1 and patch chunks likewise.
+    const char* const zero_src = reinterpret_cast<const char*>(g_corr_zero);
+    struct Round {
+      int nck[NL]; unsigned ps[NL]; const char* fbase[NL];
+      unsigned g0[L0PW], g1[L1PW > 0 ? L1PW : 1], pp[PPW];    // lane's byte offset in the frame / in fmap1; ~0u = zeros
+    };
+    auto round_setup = [&](int par) -> Round {
+      Round rd;
+      const int nitems = s_nit[par];
+      const int frame = s_frame[s_item[par][0][0]];
+      int x0[NL], y0[NL], RW[NL], NP[NL];
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        x0[l] = s_reg[par][l][0]; y0[l] = s_reg[par][l][1]; RW[l] = s_reg[par][l][2];
+        NP[l] = RW[l] * s_reg[par][l][3];
+        rd.nck[l] = (NP[l] + 63) >> 6;
+        rd.ps[l] = (unsigned)rd.nck[l] * 1024u;
+        rd.fbase[l] = reinterpret_cast<const char*>(static_cast<const T*>(LVF(l, fmap2)) + (int64_t)(frame / n2) * LVF(l, s_b) +
+                                                    (int64_t)(frame % n2) * LVF(l, s_n));
+      }
+      auto src_off = [&](int l, int pos) -> unsigned {
+        const float inv_rw = __builtin_amdgcn_rcpf((float)RW[l]);
+        const int ry = (int)(((float)pos + 0.5f) * inv_rw), rx = pos - ry * RW[l];
+        const int gy = y0[l] + ry, gx = x0[l] + rx;
+        const bool in = pos < NP[l] && gy >= 0 && gy < LVF(l, H2) && gx >= 0 && gx < LVF(l, W2);
+        return in ? (unsigned)(gy * (int)LVF(l, s_h) + gx * (int)LVF(l, s_w)) * ESZ : 0xffffffffu;
+      };
+#pragma unroll
+      for (int j = 0; j < L0PW; j++) rd.g0[j] = src_off(0, (wave + DN_NLOAD * j) * 64 + lane);
+      if constexpr (NL == 2) {
+#pragma unroll
+        for (int j = 0; j < L1PW; j++) rd.g1[j] = src_off(NL - 1, (wave + DN_NLOAD * j) * 64 + lane);
+      }
+#pragma unroll
+      for (int j = 0; j < PPW; j++) {
+        const int id = (wave + DN_NLOAD * j) * 64 + lane;
+        const int it = id / PPIECES, pc = id - it * PPIECES;
+        rd.pp[j] = (it < nitems) ? (unsigned)s_pi[s_item[par][it][0]] * (unsigned)(C * PP) * ESZ + (unsigned)pc * 16u : 0xffffffffu;
+      }
+      return rd;
+    };
+    auto issue_slab = [&](const Round& rd, int s, int buf) {
+      const unsigned base = arena0 + (unsigned)buf * (unsigned)BUFSZ;
+      const unsigned c0 = (unsigned)(s * SC);
+      auto pieces = [&](int l, unsigned* so) {
+        const int sh = LVF(l, cb_shift);
+        const unsigned bb = (unsigned)LVF(l, block_stride) * ESZ;
+        auto piece = [&](unsigned c) -> unsigned { const unsigned blk = c >> sh; return blk * bb + (c - (blk << sh)) * ESZ; };
+        so[0] = piece(c0); so[1] = piece(c0 + SC / 4); so[2] = piece(c0 + SC / 2); so[3] = piece(c0 + 3 * SC / 4);
+      };
+      unsigned so[4];
+      pieces(0, so);
+#pragma unroll
+      for (int j = 0; j < L0PW; j++) {
+        const int ck = wave + DN_NLOAD * j;
+        if (ck < rd.nck[0]) {                                 // wave-uniform
+          const bool in = rd.g0[j] != 0xffffffffu;
+#pragma unroll
+          for (int q = 0; q < 4; q++) dn_dma16(in ? rd.fbase[0] + rd.g0[j] + so[q] : zero_src, base + (unsigned)q * rd.ps[0] + (unsigned)ck * 1024u);
+        }
+      }
+      unsigned pbase = base + 4u * rd.ps[0];
+      if constexpr (NL == 2) {
+        pieces(1, so);
+#pragma unroll
+        for (int j = 0; j < L1PW; j++) {
+          const int ck = wave + DN_NLOAD * j;
+          if (ck < rd.nck[1]) {                               // wave-uniform
+            const bool in = rd.g1[j] != 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < 4; q++) dn_dma16(in ? rd.fbase[1] + rd.g1[j] + so[q] : zero_src, pbase + (unsigned)q * rd.ps[1] + (unsigned)ck * 1024u);
+          }
+        }
+        pbase += 4u * rd.ps[1];
+      }
+#pragma unroll
+      for (int j = 0; j < PPW; j++) {
+        const int ck = wave + DN_NLOAD * j;
+        if (ck < NPCH)                                        // wave-uniform
+          dn_dma16(rd.pp[j] != 0xffffffffu ? reinterpret_cast<const char*>(fmap1) + rd.pp[j] + (unsigned)s * 576u : zero_src, pbase + (unsigned)ck * 1024u);
+      }
+    };
+
+    Round rd = round_setup(0);
+    issue_slab(rd, 0, 0);
+    int g = 0, par = 0;
+    for (;;) {
+      int nnext = 0;
+      for (int s = 0; s < nslab; s++) {
+        dn_wait_dma();                                        // this wave's part of slab g has landed
+        dn_barrier();                                         // barrier g: slab g complete, slab g - 1 consumed
+        if (s + 1 < nslab) issue_slab(rd, s + 1, (g + 1) & 1);
+        else {
+          nnext = s_nit[par ^ 1];                             // planned behind this round's first barrier
+          if (nnext > 0) { rd = round_setup(par ^ 1); issue_slab(rd, 0, (g + 1) & 1); }
+        }
+        if (s == 0 && wave == 0) plan_round(par ^ 1);         // (visible to everybody behind the next barrier; nslab >= 2)
+        g++;
+      }
+      if (nnext == 0) break;
+      par ^= 1;
+    }
+    return;
+  }
+
+  // ================================================================================================ COMPUTE WAVES
+  const int cw = wave - DN_NLOAD;
+  float* const raw = reinterpret_cast<float*>(s_raw + cw * RAWSZ);
+  int g = 0, par = 0;
   for (;;) {
     const int nitems = s_nit[par];
-    if (stats && tid == 0) {                                  // debug (DEVO_DN_STATS): rounds, items, region positions per level
+    if (stats && wave == DN_NLOAD && lane == 0) {             // debug (DEVO_DN_STATS): rounds, items, region positions per level
       atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], (unsigned long long)nitems);
-      atomicAdd(&stats[2], (unsigned long long)rd.NP[0]);
-      if (NL == 2) atomicAdd(&stats[3], (unsigned long long)rd.NP[NL - 1]);
+      atomicAdd(&stats[2], (unsigned long long)(s_reg[par][0][2] * s_reg[par][0][3]));
+      if (NL == 2) atomicAdd(&stats[3], (unsigned long long)(s_reg[par][NL - 1][2] * s_reg[par][NL - 1][3]));
       if (s_item[par][0][2] != PP) atomicAdd(&stats[4], 1ull);
     }
     const unsigned long long t_round = stats ? __builtin_readcyclecounter() : 0ull;
     unsigned long long t_prev = t_round;
-    auto stamp = [&](int ph) {                                // debug: cycles of phase ph (thread 0)
-      if (stats && tid == 0) { const unsigned long long t = __builtin_readcyclecounter(); atomicAdd(&stats[6 + ph], t - t_prev); t_prev = t; }
+    auto stamp = [&](int ph) {                                // debug: cycles of phase ph (first compute wave)
+      if (stats && wave == DN_NLOAD && lane == 0) { const unsigned long long t = __builtin_readcyclecounter(); atomicAdd(&stats[6 + ph], t - t_prev); t_prev = t; }
     };
     // ---- this wave's items: tile addresses (byte offsets of the lane's A operand inside the level's part of a slab buffer,
     //      two per register) and the lane's patch element
-    const unsigned l1base = 4u * rd.ps[0];                    // level 1's planes follow level 0's
-    const unsigned cur_ps0 = rd.ps[0], cur_ps1 = NL == 2 ? rd.ps[NL - 1] : 0u;
-    const int cur_np0 = rd.NP[0], cur_np1 = NL == 2 ? rd.NP[NL - 1] : 0;
-    int nt0[EPW], nt1[EPW], it_slot[EPW];
+    unsigned ps[NL];
+    int rx0[NL], ry0[NL], RW[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      rx0[l] = s_reg[par][l][0]; ry0[l] = s_reg[par][l][1]; RW[l] = s_reg[par][l][2];
+      ps[l] = (unsigned)((RW[l] * s_reg[par][l][3] + 63) >> 6) * 1024u;
+    }
+    const unsigned l1base = 4u * ps[0];                       // level 1's planes follow level 0's
+    const unsigned pbase = l1base + (NL == 2 ? 4u * ps[NL - 1] : 0u);
+    int nt0[EPW], nt1[EPW];
     unsigned ta0[EPW][MAXT0 / 2], ta1[EPW][(MT1 + 1) / 2], baddr[EPW];
 #pragma unroll
     for (int e = 0; e < EPW; e++) {
-      const int slot = e * DN_WAVES + wave;
-      it_slot[e] = slot; nt0[e] = 0; nt1[e] = 0; baddr[e] = 0;
+      const int slot = e * DN_NCOMP + cw;
+      nt0[e] = 0; nt1[e] = 0; baddr[e] = 0;
 #pragma unroll
       for (int t = 0; t < MAXT0 / 2; t++) ta0[e][t] = 0;
 #pragma unroll
@@ -309,11 +346,13 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
           else { bx = s_ox[l][ek][p0]; by = s_oy[l][ek][p0]; bw = D; bh = D; }
           const int npos = bw * bh;
           const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
-          const int ix0 = bx - rd.x0[l], iy0 = by - rd.y0[l];
+          const int ix0 = bx - rx0[l], iy0 = by - ry0[l];
+          // fp16: the lane reads piece kg (8 channels) of its position; fp32: pieces 2 (kg & 1), 2 (kg & 1) + 1 (4 + 4 channels)
+          const unsigned plane = HALF ? (unsigned)kg : (unsigned)(2 * (kg & 1));
           auto addr = [&](int t) -> unsigned {
             const int s = min(16 * t + am, npos - 1);
             const int py = (int)(((float)s + 0.5f) * inv_bw), px = s - py * bw;
-            return (unsigned)kg * rd.ps[l] + (unsigned)(((iy0 + py) * rd.RW[l] + ix0 + px) * 16);
+            return plane * ps[l] + (unsigned)(((iy0 + py) * RW[l] + ix0 + px) * 16);
           };
           if (l == 0) {
             nt0[e] = (npos + 15) >> 4;
@@ -328,7 +367,7 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // patch slab of the item: raw [SC channels][9 pixels]; the lane wants channels 8 * (k-group) .. + 7 of ITS pixel
         const int pxl = p0 + min(am, np - 1);
         const int cgrp = HALF ? kg : (kg & 1);
-        baddr[e] = l1base + 4u * cur_ps1 + (unsigned)(slot * (PPIECES * 16)) + (unsigned)((8 * cgrp * PP + pxl) * (int)ESZ);
+        baddr[e] = pbase + (unsigned)(slot * (PPIECES * 16)) + (unsigned)((8 * cgrp * PP + pxl) * (int)ESZ);
       }
     }
     dn_f4 acc0[EPW][MAXT0], acc1[EPW][MT1];
@@ -341,44 +380,24 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     stamp(0);                                                 // item setup
 
-    int nnext = 0;
+    // fp32 storage: the lane's 8 channels of a position (two 16-byte pieces) -> its half of K: hi parts (k-groups 0, 1) or lo parts
+    auto split8 = [&](const unsigned char* p, unsigned pstride) -> dn_h8 {
+      float x[8];
+      __builtin_memcpy(&x[0], p, 16); __builtin_memcpy(&x[4], p + pstride, 16);
+      dn_h8 r;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float xs = x[c] * DN_PRESCALE;
+        const _Float16 h = (_Float16)xs;
+        r[c] = kg < 2 ? h : (_Float16)(xs - (float)h);
+      }
+      return r;
+    };
+
     for (int s = 0; s < nslab; s++) {
-      dn_wait_dma();
-      dn_barrier();                                           // slab (round, s) has landed; every wave has left the previous slab / epilogue
+      dn_barrier();                                           // barrier g: slab g has landed (the loaders waited for their DMA)
       stamp(1);
-      unsigned char* buf = s_arena + (unsigned)(k & 1) * (unsigned)BUFSZ;
-      // ---- the next slab of the stream goes into the other buffer: this round's, or the first of the next round
-      if (s + 1 < nslab) issue_slab(rd, s + 1, (k + 1) & 1);
-      else {
-        nnext = s_nit[par ^ 1];
-        if (nnext > 0) { rd = round_setup(par ^ 1); issue_slab(rd, 0, (k + 1) & 1); }
-      }
-      if (s == 0 && wave == 0) plan_round(par ^ 1);           // (visible to the others after the next barrier; nslab >= 2)
-      if constexpr (!HALF) {
-        // split the fresh fp32 slab in place: position p's four 16-byte pieces (channels 0-3 | 4-7 | 8-11 | 12-15) become
-        // hi(0-7) | hi(8-15) | lo(0-7) | lo(8-15) in the same four planes
-        for (int i = tid; i < cur_np0 + cur_np1; i += DN_THREADS) {
-          const bool second = i >= cur_np0;
-          unsigned char* bp = buf + (second ? l1base + (unsigned)(i - cur_np0) * 16u : (unsigned)i * 16u);
-          const unsigned ps = second ? cur_ps1 : cur_ps0;
-          float x[16];
-#pragma unroll
-          for (int q = 0; q < 4; q++) __builtin_memcpy(&x[4 * q], bp + q * ps, 16);
-          dn_h8 hi[2], lo[2];
-#pragma unroll
-          for (int c = 0; c < 16; c++) {
-            const float xs = x[c] * DN_PRESCALE;
-            const _Float16 h = (_Float16)xs;
-            hi[c >> 3][c & 7] = h; lo[c >> 3][c & 7] = (_Float16)(xs - (float)h);
-          }
-          *reinterpret_cast<dn_h8*>(bp) = hi[0];
-          *reinterpret_cast<dn_h8*>(bp + ps) = hi[1];
-          *reinterpret_cast<dn_h8*>(bp + 2 * ps) = lo[0];
-          *reinterpret_cast<dn_h8*>(bp + 3 * ps) = lo[1];
-        }
-      }
-      if constexpr (!HALF) dn_barrier();                      // the split is complete
-      stamp(2);
+      const unsigned char* buf = s_arena + (unsigned)(g & 1) * (unsigned)BUFSZ;
       // ---- products: every item of the wave against the slab
 #pragma unroll
       for (int e = 0; e < EPW; e++) {
@@ -391,9 +410,12 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             b2 = b1;
           } else {
             const float* pb = reinterpret_cast<const float*>(buf + baddr[e]);
+            float xb[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) xb[i] = pb[i * PP];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-              const float xs = pb[i * PP] * DN_PRESCALE;
+              const float xs = xb[i] * DN_PRESCALE;
               const _Float16 h = (_Float16)xs;
               b1[i] = h; b2[i] = (_Float16)(xs - (float)h);
             }
@@ -402,7 +424,11 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             constexpr int NT = decltype(ntc)::value;
             dn_h8 a[NT];
 #pragma unroll
-            for (int t = 0; t < NT; t++) a[t] = *reinterpret_cast<const dn_h8*>(buf + ((t & 1) ? (ta0[e][t >> 1] >> 16) : (ta0[e][t >> 1] & 0xffffu)));
+            for (int t = 0; t < NT; t++) {
+              const unsigned off = (t & 1) ? (ta0[e][t >> 1] >> 16) : (ta0[e][t >> 1] & 0xffffu);
+              if constexpr (HALF) a[t] = *reinterpret_cast<const dn_h8*>(buf + off);
+              else a[t] = split8(buf + off, ps[0]);
+            }
 #pragma unroll
             for (int t = 0; t < NT; t++) {
               acc0[e][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b1, acc0[e][t], 0, 0, 0);
@@ -413,7 +439,11 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             constexpr int NT = decltype(ntc)::value;
             dn_h8 a[NT];
 #pragma unroll
-            for (int t = 0; t < NT; t++) a[t] = *reinterpret_cast<const dn_h8*>(buf + l1base + ((t & 1) ? (ta1[e][t >> 1] >> 16) : (ta1[e][t >> 1] & 0xffffu)));
+            for (int t = 0; t < NT; t++) {
+              const unsigned off = l1base + ((t & 1) ? (ta1[e][t >> 1] >> 16) : (ta1[e][t >> 1] & 0xffffu));
+              if constexpr (HALF) a[t] = *reinterpret_cast<const dn_h8*>(buf + off);
+              else a[t] = split8(buf + off, ps[NL - 1]);
+            }
 #pragma unroll
             for (int t = 0; t < NT; t++) {
               acc1[e][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b1, acc1[e][t], 0, 0, 0);
@@ -444,23 +474,21 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
           }
         }
       }
-      k++;
-      stamp(3);
+      g++;
+      stamp(2);
     }
-    dn_barrier();                                             // every wave is done with the round's last slab: its buffer holds the raw areas now
-    stamp(4);
+    const int nnext = s_nit[par ^ 1];                         // (planned behind this round's first barrier)
     // ---- epilogue: per item and level, accumulators -> raw[pixel][box position] (wave-private), then the fused bilinear
     //      blend + axis swap + permutation (correlation_kernel.cu:221-232).  Lane (g, p) = (lane / 9, lane % 9), lanes 0..62:
     //      output t = 63 j + lane = q * 9 + p with q = 7 j + g = cx * Dm + a.  The coarse level first (into registers).
     {
-      float* raw = reinterpret_cast<float*>(s_arena + (unsigned)((k - 1) & 1) * (unsigned)BUFSZ + wave * RAWSZ);
       const int ep = lane % PP, eg = lane / PP;
       const int nq = Dm * Dm;
       const bool pairs = NL == 2 && out_lstride == 2 && lv0.out_offset == 0 && lv1.out_offset == 1 && (out_estride & 1) == 0;
 #pragma unroll
       for (int e = 0; e < EPW; e++) {
         if (nt0[e] > 0) {                                     // wave-uniform
-          const int slot = it_slot[e];
+          const int slot = e * DN_NCOMP + cw;
           const int ek = s_item[par][slot][0], p0 = s_item[par][slot][1], np = s_item[par][slot][2];
           const int col = ep - p0;
           const bool act = lane < 63 && col >= 0 && col < np;
@@ -472,6 +500,12 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
           for (int lx = 0; lx < NL; lx++) {
             const int l = NL - 1 - lx;
+            // parameters of this lane's pixel (loaded before the dump so that their latency hides under it)
+            int bx, by, bw;
+            if (np == PP) { bx = s_box[l][ek][0]; by = s_box[l][ek][1]; bw = s_box[l][ek][2]; }
+            else { bx = s_ox[l][ek][p0]; by = s_oy[l][ek][p0]; bw = D; }
+            const float dxp = s_dx[l][ek][ep], dyp = s_dy[l][ek][ep];
+            const int oxp = s_ox[l][ek][ep], oyp = s_oy[l][ek][ep];
             if (am < np) {
               float* dst = raw + am * BOXSP + 4 * kg;
               if (l == 0) {
@@ -485,28 +519,31 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
               }
             }
             wave_lds_fence();
-            int bx, by, bw;
-            if (np == PP) { bx = s_box[l][ek][0]; by = s_box[l][ek][1]; bw = s_box[l][ek][2]; }
-            else { bx = s_ox[l][ek][p0]; by = s_oy[l][ek][p0]; bw = D; }
-            const float dxp = s_dx[l][ek][ep], dyp = s_dy[l][ek][ep];
             float w00, w01, w10, w11;
             {
 #pragma clang fp contract(off)
               w00 = (1.0f - dxp) * (1.0f - dyp); w01 = dxp * (1.0f - dyp); w10 = (1.0f - dxp) * dyp; w11 = dxp * dyp;
             }
-            const float* rw = raw + (act ? col : 0) * BOXSP + (s_oy[l][ek][ep] - by) * bw + (s_ox[l][ek][ep] - bx);
+            // inactive lanes read (harmlessly) from pixel 0's row
+            const float* rw = raw + (act ? col * BOXSP + (oyp - by) * bw + (oxp - bx) : 0);
+            const int bwa = act ? bw : 0;
+            float rv[NQ][4];                                  // all taps first (no branch between the LDS reads), then the blends
+#pragma unroll
+            for (int j = 0; j < NQ; j++) {
+              const int q = min(7 * j + eg, nq - 1);
+              const int cx = q / Dm, a = q - cx * Dm;
+              const float* r = rw + (act ? a * bw + cx : 0);
+              rv[j][0] = r[0]; rv[j][1] = r[1]; rv[j][2] = r[bwa]; rv[j][3] = r[bwa + 1];
+            }
 #pragma unroll
             for (int j = 0; j < NQ; j++) {
               const int q = 7 * j + eg;
-              int cx, a;
-              if (Dm == 7) { cx = j; a = eg; } else { cx = q / Dm; a = q - cx * Dm; }
-              if (act && q < nq) {
-                const float* r = rw + a * bw + cx;
-                float o;
-                {
+              float o;
+              {
 #pragma clang fp contract(off)
-                  o = w00 * r[0]; o = o + w01 * r[1]; o = o + w10 * r[bw]; o = o + w11 * r[bw + 1];
-                }
+                o = w00 * rv[j][0]; o = o + w01 * rv[j][1]; o = o + w10 * rv[j][2]; o = o + w11 * rv[j][3];
+              }
+              if (act && q < nq) {
                 const int t = q * PP + ep;
                 if (NL == 2 && l == 1) o1[j] = o;
                 else if (NL == 2) {
@@ -531,8 +568,8 @@ __global__ __launch_bounds__(DN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
       }
     }
-    stamp(5);
-    if (stats && tid == 0) atomicAdd(&stats[5], __builtin_readcyclecounter() - t_round);
+    stamp(3);
+    if (stats && wave == DN_NLOAD && lane == 0) atomicAdd(&stats[5], __builtin_readcyclecounter() - t_round);
     if (nnext == 0) break;                                    // block-uniform
     par ^= 1;
   }

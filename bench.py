@@ -267,14 +267,27 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         n_many = args.steps // args.steps_per_graph
         gmany.replay()
 
-    D.barrier_sync(device)
-    t0 = time.perf_counter()
-    for _ in range(n_many):
-        gmany.replay()
-    for _ in range(args.steps - n_many * args.steps_per_graph):           # EXACTLY --steps steps
-        run()
-    D.barrier_sync(device)
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    def timed_region():
+        D.barrier_sync(device)
+        t0 = time.perf_counter()
+        for _ in range(n_many):
+            gmany.replay()
+        for _ in range(args.steps - n_many * args.steps_per_graph):       # EXACTLY --steps steps
+            run()
+        D.barrier_sync(device)
+        return D.max_over_ranks(time.perf_counter() - t0, device)
+
+    # The contract's timed region: exactly --steps steps between barrier + synchronize pairs, MAX over ranks.  A region shorter
+    # than ~50 ms (20 steps are 6 ms: two graph launches) is dominated by launch / synchronisation jitter, so short regions are
+    # measured several times and the MEDIAN region is reported ("timed_regions" in the JSON line says how many).
+    elapsed = timed_region()
+    regions = 1
+    if elapsed < 0.05:
+        regions = int(min(25, max(3, 0.25 / max(elapsed, 1e-4)))) | 1
+        if world > 1:
+            regions = int(D.max_over_ranks(float(regions), device))          # the same count on every rank (collectives inside)
+        samples = sorted([elapsed] + [timed_region() for _ in range(regions - 1)])
+        elapsed = samples[len(samples) // 2]
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
 
@@ -347,7 +360,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
     out = {
         "metric": "update-op iterations/sec (altcorr+fastba) at 96 patches, N=15 keyframes",
         "value": round(value, 2), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "timed_regions": regions, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dtn, "data": "synthetic",
         "config": {"workload": f"{args.workload}: M={M} patches/frame, n={n} keyframes, E={E} edges, r={R}, "
                                f"2 pyramid levels {cfg['H']}x{cfg['W']} + /4, C={cfg['C']}, 2 GN iterations, "

@@ -216,3 +216,28 @@ def solve_terms_backward(terms, ii, jj, kk, n_patch_slots, t0, n_opt, ws, g_dX, 
                                               ws.numel(), L.ptr(g_dX), L.ptr(g_dZ), L.ptr(g), L.stream())
     L.check(rc, "cuda_ba.solve_terms_backward")
     return g
+
+
+def transform_vjp(poses, patches, intrinsics, ii, jj, kk, g_coords, g_J, depth=False, tonly=False):
+    """devo_transform_vjp: adjoint of transform(layout="pp2") -> (g_poses [1,Nbuf,7], g_patches like patches).
+    g_coords [1,E,P,P,2|3] or None; g_J = (g_Ji, g_Jj, g_Jz) or None (entries may be None, g_Jj must be there when any is)."""
+    L.require_gpu(poses, patches, intrinsics, ii, jj, kk)
+    P = patches.shape[-1]
+    ii, jj, kk = _idx(ii, jj, kk)
+    E = ii.numel()
+    poses = poses.float().contiguous()
+    patches = patches.float().contiguous()
+    intrinsics = intrinsics.float().contiguous()
+    c = lambda t: None if t is None else t.float().contiguous()
+    g_coords = c(g_coords)
+    gJi, gJj, gJz = (c(t) for t in g_J) if g_J is not None else (None, None, None)
+    if (gJi is not None or gJz is not None) and gJj is None:
+        gJj = torch.zeros(E, 2, 6, dtype=torch.float32, device=poses.device)
+    gp = torch.empty_like(poses)
+    gq = torch.empty_like(patches)
+    flags = (1 if depth else 0) | (2 if tonly else 0)
+    rc = L.lib().devo_transform_vjp(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(ii), L.ptr(jj), L.ptr(kk), L.ptr(g_coords),
+                                    L.ptr(gJi), L.ptr(gJj), L.ptr(gJz), E, poses.numel() // 7, patches.numel() // (3 * P * P), P, flags,
+                                    L.ptr(gp), L.ptr(gq), L.stream())
+    L.check(rc, "cuda_ba.transform_vjp")
+    return gp, gq

@@ -1440,6 +1440,184 @@ __global__ void k_transform(const float* __restrict__ poses, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------- neighbors
+// ------------------------------------------------------------------------------------------------- adjoint of k_transform
+// devo_transform_vjp: gradients of everything k_transform outputs — the reprojected coordinates of all P*P pixels AND the
+// Jacobians Ji, Jj, Jz of the centre pixel (so the differentiable BA's second Gauss-Newton step gets its second-order terms,
+// exactly what autograd derives for devo/projective_ops.py:53-105) — with respect to poses[ii], poses[jj] (6-vectors of the left
+// perturbation G <- Exp(xi) G, lietorch's gradient convention: first 6 of the 7 slots) and patches[kk] (x, y, inverse depth of
+// every pixel).  One thread per edge evaluates the SAME arithmetic as k_transform on dual numbers, once per input direction
+// (12 pose directions over all pixels, 3 directions per pixel over that pixel), and adds  <cotangent, directional derivative>
+// into the gradient buffers with float atomics: no hand-derived reverse mode to get wrong, ~20 kFLOP per edge.
+struct Dual { float v, d; DEVO_HD Dual() : v(0.0f), d(0.0f) {} DEVO_HD Dual(float a) : v(a), d(0.0f) {} DEVO_HD Dual(float a, float b) : v(a), d(b) {} };
+DEVO_HD Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+DEVO_HD Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+DEVO_HD Dual operator-(Dual a) { return {-a.v, -a.d}; }
+DEVO_HD Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.v * b.d + a.d * b.v}; }
+DEVO_HD Dual operator/(Dual a, Dual b) { const float r = 1.0f / b.v; return {a.v * r, (a.d - a.v * r * b.d) * r}; }
+DEVO_HD Dual operator+(float a, Dual b) { return {a + b.v, b.d}; }
+DEVO_HD Dual operator+(Dual a, float b) { return {a.v + b, a.d}; }
+DEVO_HD Dual operator-(float a, Dual b) { return {a - b.v, -b.d}; }
+DEVO_HD Dual operator-(Dual a, float b) { return {a.v - b, a.d}; }
+DEVO_HD Dual operator*(float a, Dual b) { return {a * b.v, a * b.d}; }
+DEVO_HD Dual operator*(Dual a, float b) { return {a.v * b, a.d * b}; }
+DEVO_HD Dual operator/(Dual a, float b) { return {a.v / b, a.d / b}; }
+template <> DEVO_HD Dual t_sqrt<Dual>(Dual x) { const float r = sqrtf(x.v); return {r, 0.5f * x.d / r}; }
+
+DEVO_HD float vof(float x) { return x; }
+DEVO_HD float vof(Dual x) { return x.v; }
+// the pixel part of k_transform: reprojection of one patch pixel (px, py, inverse depth w) -> (u, v, d) and the point X1
+template <typename S>
+DEVO_HD void tf_pixel(const SE3<S>& G, S px, S py, S w, const float* ki, const float* kj, S& u, S& v, S& d, V3<S>& X1) {
+  V3<S> X0{(px - ki[2]) / ki[0], (py - ki[3]) / ki[1], S(1.0f)};
+  X1 = qrot(G.q, X0) + w * G.t;
+  const S z = X1.z;
+  d = S(1.0f) / (vof(z) < 0.1f ? S(0.1f) : z);                            // Z.clamp(min = 0.1)  (projective_ops.py:43)
+  u = kj[0] * (d * X1.x) + kj[2];
+  v = kj[1] * (d * X1.y) + kj[3];
+}
+// the Jacobian part (projective_ops.py:75-103): J[0..11] = Ji (2x6), J[12..23] = Jj, J[24..25] = Jz
+// `traw` = the translation as projective_ops.py:99 reads it, straight from Gij.data[..., :3]: autograd hands the gradient of that
+// read to the tau slots of Gij's gradient and nothing to the phi slots (although rotating Gij moves its translation) — the
+// adjoint kernel reproduces the reference's gradient, not the exact derivative, so it seeds `traw` with d tau only
+template <typename S>
+DEVO_HD void tf_jacobians(const SE3<S>& G, const V3<S>& traw, const V3<S>& Xc, S Hc, const float* kj, S* J) {
+  const S X = Xc.x, Y = Xc.y, Z = Xc.z;
+  const float az = vof(Z) < 0.0f ? -vof(Z) : vof(Z);
+  const S d = az > 0.2f ? S(1.0f) / Z : S(0.0f);
+  const float fx = kj[0], fy = kj[1];
+  S Jj[2][6] = {{fx * d * Hc, S(0.0f), -(fx * X * d * d * Hc), -(fx * X * d * d * Y), fx * d * Z + fx * X * d * d * X, -(fx * d * Y)},
+                {S(0.0f), fy * d * Hc, -(fy * Y * d * d * Hc), -(fy * d * Z) - fy * Y * d * d * Y, fy * Y * d * d * X, fy * d * X}};
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    S a[6];
+    G.adjT(Jj[r], a);
+#pragma unroll
+    for (int c = 0; c < 6; c++) { J[6 * r + c] = -a[c]; J[12 + 6 * r + c] = Jj[r][c]; }
+  }
+  J[24] = fx * d * traw.x - fx * X * d * d * traw.z;
+  J[25] = fy * d * traw.y - fy * Y * d * d * traw.z;
+}
+
+__global__ void k_transform_vjp(const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
+                                const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
+                                const float* __restrict__ g_c, const float* __restrict__ g_Ji, const float* __restrict__ g_Jj,
+                                const float* __restrict__ g_Jz, int E, int P, int flags, float* __restrict__ gposes,
+                                float* __restrict__ gpatches) {
+  const bool depth = flags & 1, tonly = flags & 2;
+  const int PPx = P * P, ctr = (P / 2) * P + P / 2, nc = depth ? 3 : 2;
+  const bool jac = g_Jj != nullptr;
+  // pose gradients: thousands of edges share a handful of frames — collected per workgroup in LDS (frames < VJP_LDS_FRAMES),
+  // ONE global atomic per touched (frame, component) and workgroup at the end
+  constexpr int VJP_LDS_FRAMES = 128;
+  __shared__ float s_gp[VJP_LDS_FRAMES][6];
+  for (int i = threadIdx.x; i < VJP_LDS_FRAMES * 6; i += blockDim.x) (&s_gp[0][0])[i] = 0.0f;
+  __syncthreads();
+  auto add_pose = [&](int64_t f, int c, float v) {
+    if (f < VJP_LDS_FRAMES) atomicAdd(&s_gp[f][c], v); else atomicAdd(gposes + f * 7 + c, v);
+  };
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
+    const int64_t fi = ii[e], fj = jj[e], k = kk[e];
+    const float* pi = poses + fi * 7;
+    const float* pj = poses + fj * 7;
+    const float* ki = intr + fi * 4;
+    const float* kj = intr + fj * 4;
+    const float* pk = patches + k * 3 * PPx;
+    const float* gc = g_c ? g_c + (int64_t)e * PPx * nc : nullptr;
+    float gJ[26];
+#pragma unroll
+    for (int c = 0; c < 12; c++) { gJ[c] = (jac && g_Ji) ? g_Ji[(int64_t)e * 12 + c] : 0.0f; gJ[12 + c] = jac ? g_Jj[(int64_t)e * 12 + c] : 0.0f; }
+    gJ[24] = (jac && g_Jz) ? g_Jz[(int64_t)e * 2] : 0.0f; gJ[25] = (jac && g_Jz) ? g_Jz[(int64_t)e * 2 + 1] : 0.0f;
+    // <cotangent, d outputs> of one pixel / of the Jacobians
+    auto pix_dot = [&](const SE3<Dual>& G, int i, Dual px, Dual py, Dual w, V3<Dual>& X1) -> float {
+      Dual u, v, d;
+      tf_pixel<Dual>(G, px, py, w, ki, kj, u, v, d, X1);
+      if (!gc) return 0.0f;
+      float s = gc[i * nc] * u.d + gc[i * nc + 1] * v.d;
+      if (depth) s += gc[i * nc + 2] * d.d;
+      return s;
+    };
+    auto jac_dot = [&](const SE3<Dual>& G, const V3<Dual>& traw, const V3<Dual>& Xc, Dual Hc) -> float {
+      if (!jac) return 0.0f;
+      Dual J[26];
+      tf_jacobians<Dual>(G, traw, Xc, Hc, kj, J);
+      float s = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 26; c++) s += gJ[c] * J[c].d;
+      return s;
+    };
+    // G = Gj * Gi^-1 exactly as k_transform forms it
+    SE3<float> G0;
+    {
+      SE3<float> Gi = SE3<float>::load(pi), Gj = SE3<float>::load(pj);
+      G0 = Gj.mul(Gi.inv());
+      if (tonly) G0.q = Q4<float>{0.0f, 0.0f, 0.0f, 1.0f};
+    }
+    auto lift = [](const SE3<float>& X) -> SE3<Dual> {
+      SE3<Dual> Y;
+      Y.t = {Dual(X.t.x), Dual(X.t.y), Dual(X.t.z)};
+      Y.q = {Dual(X.q.x), Dual(X.q.y), Dual(X.q.z), Dual(X.q.w)};
+      return Y;
+    };
+    // ---- directions of Gij: xi = unit vector c of (tau, phi), Gij <- Exp(eps xi) Gij:  dt = tau + phi x t,  dq = 1/2 (phi, 0) (x) q.
+    //      Gij = Gj Gi^-1, so the same gradient belongs to pose j and  -Adj(Gij)^T  of it to pose i (the Mul / Inv rules of
+    //      lietorch_gpu.cu).
+    float gij[6];
+#pragma unroll 1
+    for (int c = 0; c < 6; c++) {
+      SE3<Dual> G = lift(G0);
+      V3<Dual> traw = G.t;
+      if (c < 3) { (c == 0 ? G.t.x : c == 1 ? G.t.y : G.t.z).d = 1.0f; traw = G.t; }
+      else {
+        float ph[3] = {0.0f, 0.0f, 0.0f};
+        ph[c - 3] = 1.0f;
+        const float tx = G0.t.x, ty = G0.t.y, tz = G0.t.z;
+        G.t.x.d = ph[1] * tz - ph[2] * ty; G.t.y.d = ph[2] * tx - ph[0] * tz; G.t.z.d = ph[0] * ty - ph[1] * tx;
+        const float qx = G0.q.x, qy = G0.q.y, qz = G0.q.z, qw = G0.q.w;
+        G.q.x.d = 0.5f * (ph[0] * qw + ph[1] * qz - ph[2] * qy);
+        G.q.y.d = 0.5f * (ph[1] * qw + ph[2] * qx - ph[0] * qz);
+        G.q.z.d = 0.5f * (ph[2] * qw + ph[0] * qy - ph[1] * qx);
+        G.q.w.d = 0.5f * (-ph[0] * qx - ph[1] * qy - ph[2] * qz);
+      }
+      float s = 0.0f;
+      V3<Dual> Xc{Dual(0.0f), Dual(0.0f), Dual(1.0f)};
+      for (int i = 0; i < PPx; i++) {
+        V3<Dual> X1;
+        s += pix_dot(G, i, Dual(pk[i]), Dual(pk[PPx + i]), Dual(pk[2 * PPx + i]), X1);
+        if (i == ctr) Xc = X1;
+      }
+      s += jac_dot(G, traw, Xc, Dual(pk[2 * PPx + ctr]));
+      gij[c] = s;
+    }
+    {
+      float gi[6];
+      G0.adjT(gij, gi);
+#pragma unroll
+      for (int c = 0; c < 6; c++) { add_pose(fj, c, gij[c]); add_pose(fi, c, -gi[c]); }
+    }
+    // ---- patch directions: pixel i, component x / y / inverse depth
+    {
+      const SE3<Dual> G = lift(G0);
+#pragma unroll 1
+      for (int i = 0; i < PPx; i++) {
+#pragma unroll 1
+        for (int comp = 0; comp < 3; comp++) {
+          Dual px(pk[i]), py(pk[PPx + i]), w(pk[2 * PPx + i]);
+          (comp == 0 ? px : comp == 1 ? py : w).d = 1.0f;
+          V3<Dual> X1;
+          float s = pix_dot(G, i, px, py, w, X1);
+          if (i == ctr) s += jac_dot(G, G.t, X1, w);
+          atomicAdd(gpatches + k * 3 * PPx + comp * PPx + i, s);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < VJP_LDS_FRAMES * 6; i += blockDim.x) {
+    const float v = (&s_gp[0][0])[i];
+    if (v != 0.0f) atomicAdd(gposes + (i / 6) * 7 + i % 6, v);
+  }
+}
+
 __device__ __forceinline__ unsigned hash64(unsigned long long k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
   return (unsigned)k;
@@ -1891,6 +2069,22 @@ int devo_transform(const float* poses, const float* patches, const float* intrin
                      kk, coords_pp2, coords_2pp, valid, Ji, Jj, Jz, E, P, flags, plan ? plan + E + 1 : nullptr, plan_frames, plan_height,
                      nb, 2 * plan_radius + 2, plan_radius <= 3 ? 1 : 3);
   return check_launch("devo_transform");
+}
+
+
+int devo_transform_vjp(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii, const int64_t* jj,
+                       const int64_t* kk, const float* g_coords, const float* g_Ji, const float* g_Jj, const float* g_Jz, int E,
+                       int Nbuf, int Np, int P, int flags, float* g_poses, float* g_patches, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && Nbuf > 0 && Np > 0 && P > 0 && P * P <= 25, "devo_transform_vjp: bad sizes");
+  DEVO_REQUIRE(g_poses && g_patches, "devo_transform_vjp: missing gradient buffers");
+  DEVO_REQUIRE(!(g_Ji || g_Jz) || g_Jj, "devo_transform_vjp: the Jacobian cotangents come together with g_Jj");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(g_poses, 0, sizeof(float) * 7 * (size_t)Nbuf, st) != hipSuccess ||
+      hipMemsetAsync(g_patches, 0, sizeof(float) * 3 * (size_t)Np * P * P, st) != hipSuccess) { set_error("devo_transform_vjp: memset failed"); return DEVO_ERR_LAUNCH; }
+  if (E == 0) return DEVO_OK;
+  hipLaunchKernelGGL(k_transform_vjp, dim3(blocks_for(E, 128, 8192)), dim3(128), 0, st, poses, patches, intrinsics, ii, jj, kk, g_coords, g_Ji,
+                     g_Jj, g_Jz, E, P, flags, g_poses, g_patches);
+  return check_launch("devo_transform_vjp");
 }
 
 }  // extern "C"

@@ -35,12 +35,52 @@ def _needs_grad(*ts):
     return torch.is_grad_enabled() and any(t.requires_grad for t in ts)
 
 
+class _FusedTransform(torch.autograd.Function):
+    """The fused reprojection kernel (devo_transform) with its adjoint (devo_transform_vjp): gradients reach poses (lietorch's
+    6-of-7 convention) and patches through the coordinates AND through the Jacobians Ji, Jj, Jz (second-order terms), which
+    is what the chained Gauss-Newton steps of training need (enet.py:353-369).  Intrinsics get no gradient."""
+
+    @staticmethod
+    def forward(ctx, pose_data, patches, intrinsics, ii, jj, kk, depth, jacobian, tonly):
+        out = cuda_ba.transform(pose_data, patches, intrinsics, ii, jj, kk, depth=depth, valid=True, jacobian=jacobian, tonly=tonly,
+                                layout="pp2")
+        ctx.save_for_backward(pose_data, patches, intrinsics, ii, jj, kk)
+        ctx.flags = (depth, jacobian, tonly)
+        if jacobian:
+            c, v, (Ji, Jj, Jz) = out
+            ctx.mark_non_differentiable(v)
+            return c, v, Ji, Jj, Jz
+        c, v = out
+        ctx.mark_non_differentiable(v)
+        return c, v
+
+    @staticmethod
+    def backward(ctx, g_c, g_v, g_Ji=None, g_Jj=None, g_Jz=None):
+        pose_data, patches, intrinsics, ii, jj, kk = ctx.saved_tensors
+        depth, jacobian, tonly = ctx.flags
+        gJ = (g_Ji, g_Jj, g_Jz) if jacobian else None
+        gp, gq = cuda_ba.transform_vjp(pose_data, patches, intrinsics, ii, jj, kk, g_c, gJ, depth=depth, tonly=tonly)
+        return gp.view_as(pose_data), gq.view_as(patches), None, None, None, None, None, None, None
+
+
 def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, jacobian=False, tonly=False):
     """coords [1,E,P,P,2(+1)] (+ validity [1,E], + (Ji [1,E,2,6], Jj [1,E,2,6], Jz [1,E,2,1]))."""
-    if (not _needs_grad(poses.data, patches, intrinsics) and poses.data.dtype == torch.float32
-            and poses.data.shape[0] == 1):
+    import os
+    fused_ok = poses.data.dtype == torch.float32 and poses.data.shape[0] == 1 and patches.is_cuda
+    if fused_ok and not _needs_grad(poses.data, patches, intrinsics):
         return cuda_ba.transform(poses.data, patches, intrinsics, ii, jj, kk, depth=depth, valid=valid,
                                  jacobian=jacobian, tonly=tonly, layout="pp2")
+    # (not for tonly: the reference's autograd treats the overwritten quaternion slots of `Gij.data[..., 3:] = identity` as cut
+    #  — projective_ops.py:62 — which is not the derivative of the function; the composition below reproduces that, and only
+    #  flow_mag, which needs no gradient, uses tonly)
+    if (fused_ok and not tonly and not _needs_grad(intrinsics) and patches.dtype == torch.float32 and patches.shape[-1] ** 2 <= 25
+            and os.environ.get("DEVO_TRANSFORM_TORCH", "0") != "1"):
+        # fp32 on the GPU with gradients: one forward kernel, one adjoint kernel (DEVO_TRANSFORM_TORCH=1: the composition below)
+        out = _FusedTransform.apply(poses.data, patches, intrinsics, ii, jj, kk, bool(depth), bool(jacobian), bool(tonly))
+        if jacobian:
+            c, v, Ji, Jj, Jz = out
+            return c, v, (Ji, Jj, Jz)
+        return (out[0], out[1]) if valid else out[0]
 
     # gathers along the edge axis with index_select: its backward is an atomic index_add, whereas the backward of
     # advanced indexing (`x[:, idx]`) sorts the indices on the GPU (0.3 ms per gather at 18 000 edges)

@@ -178,6 +178,15 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
 int devo_ba_solve_terms_backward(const float* terms, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Np, int t0, int N, void* ws,
                                  size_t ws_bytes, const float* g_dX, const float* g_dZ, float* g_terms, devo_stream_t stream);
 
+/* Adjoint of devo_transform (what autograd derives for devo/projective_ops.py:53-105, second-order terms of the Jacobians
+ * included): cotangents of the coordinates g_coords f32 [E,P,P,2|3] ("pp2" layout; NULL = none) and of the centre pixel's
+ * Jacobians g_Ji / g_Jj f32 [E,2,6], g_Jz f32 [E,2] (NULL = none) -> g_poses f32 [Nbuf,7] (6-vector of the left perturbation
+ * G <- Exp(xi) G in the first six slots, lietorch's convention: lietorch_gpu.cu:174-256) and g_patches f32 [Np,3,P,P]; both are
+ * zeroed and accumulated here.  flags as devo_transform (1 = depth channel, 2 = translation only). */
+int devo_transform_vjp(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii, const int64_t* jj,
+                       const int64_t* kk, const float* g_coords, const float* g_Ji, const float* g_Jj, const float* g_Jz, int E,
+                       int Nbuf, int Np, int P, int flags, float* g_poses, float* g_patches, devo_stream_t stream);
+
 size_t devo_neighbors_workspace_bytes(int E);
 
 /* cuda_ba.neighbors  (ba.cpp:154 -> ba.cpp:104-149): for every edge the previous / next edge of the same

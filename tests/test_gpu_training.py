@@ -124,3 +124,36 @@ def test_fused_solve_matches_the_torch_composition_in_value_and_gradient(golden_
     for x, y, name, tol in zip(a[1:], b[1:], ("poses", "patches", "d/d target", "d/d weight", "d/d poses", "d/d patches"),
                                (1e-4, 1e-4, 2e-3, 2e-3, 2e-3, 2e-3)):
         assert_rel(x, y, tol, name)
+
+
+@pytest.mark.parametrize("mode", ["coords", "depth", "tonly", "jacobian"])
+def test_fused_transform_adjoint_matches_the_autograd_composition(golden_dir, mode, monkeypatch):
+    """projective_ops.transform with gradients: ONE forward kernel + ONE adjoint kernel (devo_transform_vjp, the same
+    arithmetic on dual numbers) against the composition over the SE3 ops that the fp64 goldens pin to the reference
+    (DEVO_TRANSFORM_TORCH=1) — outputs and the gradients with respect to poses (lietorch's 6-of-7 convention) and patches,
+    through the coordinates and, for jacobian=True, through Ji / Jj / Jz (second-order terms)."""
+    from devo_amd import projective_ops as pops
+    from devo_amd.lietorch import SE3
+    g = _load(golden_dir, torch.float32)
+    gen = torch.Generator().manual_seed(5)
+
+    def run(torch_path):
+        monkeypatch.setenv("DEVO_TRANSFORM_TORCH", "1" if torch_path else "0")
+        pos = g["poses"].clone().requires_grad_(True)
+        pat = g["patches"].clone().requires_grad_(True)
+        kw = dict(depth=(mode == "depth"), tonly=(mode == "tonly"), jacobian=(mode == "jacobian"))
+        out = pops.transform(SE3(pos), pat, g["intrinsics"], g["ii"], g["jj"], g["kk"], **kw)
+        outs = [out] if not isinstance(out, tuple) else [out[0], *out[2]]
+        loss = 0.0
+        gen.manual_seed(5)
+        for o in outs:
+            loss = loss + (o * torch.randn(o.shape, generator=gen).to(o.device)).sum()
+        loss.backward()
+        return [o.detach() for o in outs], pos.grad, pat.grad
+
+    (oa, pa, qa), (ob, pb, qb) = run(False), run(True)
+    for x, y in zip(oa, ob):
+        assert_rel(x, y, 1e-5, f"{mode}: output")
+    assert float(pa[..., 6].abs().max()) == 0.0                       # the 7th slot of a group gradient stays empty
+    assert_rel(pa, pb, 2e-4, f"{mode}: d/d poses")
+    assert_rel(qa, qb, 2e-4, f"{mode}: d/d patches")

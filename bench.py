@@ -342,6 +342,8 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
     lookup_kernel = "corr_fwd_generic_kernel" if nchw_direct else ("corr_fwd_mfma_kernel" if mfma else "corr_fwd_cl_kernel")
     if args.layout != "nchw" and os.environ.get("DEVO_CORR_DENSE", "0")[:1] == "1":
         lookup_kernel = "corr_fwd_dense_kernel"                     # opt-in region-staged kernel (corr_dense.h)
+    if args.layout != "nchw" and dtn == "f16" and cfg["C"] == 128 and cfg["R"] <= 3 and os.environ.get("DEVO_CORR_GROUP", "0")[:1] == "1":
+        lookup_kernel = "corr_fwd_group_kernel"                     # edge-group dense matrix-core kernel (corr_group.h)
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

@@ -156,6 +156,7 @@ struct CorrLevel {
   unsigned frame_bytes;           // extent of one frame (all blocks) in bytes: the buffer-load bound of the matrix-core kernel
   bool staged_ok, mfma_ok;        // which of the two fast kernels can read this level
   bool dense_ok;                  // ... and the region-staged dense matrix-core kernel (corr_dense.h)
+  bool group_ok;                  // ... and the edge-group dense matrix-core kernel (corr_group.h)
   int64_t out_offset;             // element offset of this level inside an edge's output record
   float coord_div;                // coordinates are divided by this (pyramid level scale)
 };
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 #include "corr_dma.h"
 #include "corr_mfma.h"
 #include "corr_dense.h"
+#include "corr_group.h"
 
 // -------------------------------------------------------------------------------------------------
 // Locality plan: order[] = heavy edge slots, then the rest sorted by (batch, target frame, 16-row band of the
@@ -702,6 +704,11 @@ static bool corr_dense_enabled() {               // DEVO_CORR_DENSE=1: the regio
   static const bool on = env && env[0] == '1';
   return on;
 }
+static bool corr_group_enabled() {               // DEVO_CORR_GROUP=1: the edge-group dense matrix-core kernel (corr_group.h)
+  static const char* env = getenv("DEVO_CORR_GROUP");
+  static const bool on = env && env[0] == '1';
+  return on;
+}
 static bool corr_mfma_enabled() {                // DEVO_CORR_MFMA=0: fp32 lookups take the staged (tap-centric) kernel instead
   static const char* env = getenv("DEVO_CORR_MFMA");
   static const bool on = !(env && env[0] == '0');
@@ -731,7 +738,9 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
   // the dense kernel: any C that is a multiple of its channel slab (fp16: 32, fp32: 16), 16-byte pieces inside a channel block
   lv->dense_ok = aligned && sizeof(T) <= 4 && corr_dense_enabled() && cb_ok && C % (sizeof(T) == 2 ? 32 : 16) == 0 &&
                  C >= (sizeof(T) == 2 ? 64 : 32) && frame_bytes < (1LL << 31);                        // (at least two channel slabs)
-  if (!lv->staged_ok && !lv->mfma_ok && !lv->dense_ok) {
+  // the group kernel: fp16 storage, C = 128, 16-byte pieces of 8 channels inside a channel block
+  lv->group_ok = aligned && sizeof(T) == 2 && corr_group_enabled() && cb_ok && C == 128 && frame_bytes < (1LL << 31);
+  if (!lv->staged_ok && !lv->mfma_ok && !lv->dense_ok && !lv->group_ok) {
     if (blocked) {
       set_error("devo_corr_forward: channel-blocked fmap2 needs fp32 / fp16, 16-byte aligned strides and cblock == %d (got %d)", KC, cblock);
       *err = DEVO_ERR_UNSUPPORTED;
@@ -763,6 +772,37 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
   const bool mfma = lv0.mfma_ok && (nlev == 1 || lv1.mfma_ok);
   const long long f1_bytes = (BE / (E > 0 ? E : 1)) * (long long)Np * C * PP * (long long)sizeof(T);
   const bool dense = lv0.dense_ok && (nlev == 1 || lv1.dense_ok) && !do_trace && f1_bytes < (1LL << 31) && BE < (1LL << 31) - 64;
+  const bool group = lv0.group_ok && (nlev == 1 || lv1.group_ok) && !do_trace && R <= 3 && f1_bytes < (1LL << 31) && BE < (1LL << 31) - 64;
+  if (group) {                                                        // edge-group dense matrix-core kernel (corr_group.h)
+    typedef typename std::conditional<sizeof(T) == 2, T, __half>::type MT;               // (fp16 only: group_ok is false otherwise)
+    const long long ngroups = (BE + GP_GE - 1) / GP_GE;
+    const dim3 ggrid((unsigned)(32 * ((ngroups + 31) / 32))), gblock(GP_THREADS);      // (the kernel maps runs of 4 groups to XCDs)
+    unsigned long long* gstats = nullptr;                             // debug switch: phase cycles / tile counts to stderr
+    static const bool do_gstats = getenv("DEVO_GP_STATS") != nullptr;
+    hipEvent_t gev0 = nullptr, gev1 = nullptr;
+    if (do_gstats) { (void)hipMalloc(&gstats, 128); (void)hipMemset(gstats, 0, 128); (void)hipEventCreate(&gev0); (void)hipEventCreate(&gev1); (void)hipEventRecord(gev0, st); }
+    if (nlev == 2)
+      hipLaunchKernelGGL((corr_fwd_group_kernel<MT, 2>), ggrid, gblock, 0, st, (const MT*)fmap1, lv0, lv1, coords, ii, jj, (MT*)out, (int)BE, E, Np,
+                         n2, C, oes, ols, R, order, gstats);
+    else
+      hipLaunchKernelGGL((corr_fwd_group_kernel<MT, 1>), ggrid, gblock, 0, st, (const MT*)fmap1, lv0, lv1, coords, ii, jj, (MT*)out, (int)BE, E, Np,
+                         n2, C, oes, ols, R, order, gstats);
+    if (do_gstats) {
+      (void)hipEventRecord(gev1, st);
+      (void)hipDeviceSynchronize();
+      float gms = 0.0f;
+      (void)hipEventElapsedTime(&gms, gev0, gev1);
+      unsigned long long h[16];
+      (void)hipMemcpy(h, gstats, 128, hipMemcpyDeviceToHost);
+      const double g = h[4] ? (double)h[4] : 1.0;
+      fprintf(stderr, "[group stats] kernel %.1f us; workgroup lifetime: mean %.0f cycles, max %llu; resident workgroups on average %.0f\n", gms * 1e3,
+              (h[0] + h[1] + h[2] + h[3]) / g, h[8], (double)(h[0] + h[1] + h[2] + h[3]) / (gms * 1e-3 * 2.4e9));
+      fprintf(stderr, "[group stats] of the products phase, waiting for the tile's loads: %.0f cycles per group (first wave)\n", h[9] / g);
+      fprintf(stderr, "[group stats] edges %lld, groups %llu; first wave per group: passes %.2f, tiles %.1f, (tile, N-tile) products %.1f; cycles: setup %.0f | products %.0f | wait at barrier %.0f | epilogue %.0f\n",
+              BE, h[4], h[7] / g, h[5] / g, h[6] / g, h[0] / g, h[1] / g, h[2] / g, h[3] / g);
+      (void)hipFree(gstats);
+    }
+  } else
   if (dense) {                                                        // region-staged dense matrix-core kernel (corr_dense.h)
     typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;   // (never fp64: dense_ok is false)
     typedef void (*dense_fn_t)(const MT*, CorrLevel, CorrLevel, const float*, const int64_t*, const int64_t*, MT*, int, int, int,

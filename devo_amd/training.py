@@ -58,7 +58,7 @@ class TrainNet(nn.Module):
         Gs = SE3(b["poses0"].clone())
         patches = b["patches0"].clone()
         net = torch.zeros(1, E, self.dim, device=ii.device)
-        inp = imap[:, kk]
+        inp = torch.index_select(imap, 1, kk)
         bounds = [-64, -64, b["W"] + 64, b["H"] + 64]
         dij = (ii - jj).abs()
         close = (dij > 0) & (dij <= 2)
@@ -86,8 +86,9 @@ class TrainNet(nn.Module):
             ok = valid_gt.reshape(-1) > 0.5
             flow_loss = (e.min(dim=-1).values * ok).sum() / ok.sum().clamp(min=1)
             P1, P2 = Gs.inv(), Ps.inv()
-            dP = P1[:, fi].inv() * P1[:, fj]
-            dG = P2[:, fi].inv() * P2[:, fj]
+            take = lambda G, idx: SE3(torch.index_select(G.data, 1, idx))
+            dP = take(P1, fi).inv() * take(P1, fj)
+            dG = take(P2, fi).inv() * take(P2, fj)
             e1 = (dP * dG.inv()).log()
             pose_loss = e1[..., 0:3].norm(dim=-1).mean() + e1[..., 3:6].norm(dim=-1).mean()
             loss = loss + flow_weight * flow_loss

@@ -60,7 +60,7 @@ class SoftAgg(nn.Module):                            # blocks.py:31-48 (expand=T
         ex = (gx - mx.gather(1, idx)).exp()
         w = ex / torch.zeros(B, n, C, dtype=x.dtype, device=x.device).scatter_add(1, idx, ex).gather(1, idx)
         y = torch.zeros(B, n, C, dtype=x.dtype, device=x.device).scatter_add(1, idx, fx * w)
-        return self.h(y)[:, jx]
+        return torch.index_select(self.h(y), 1, jx)        # (index_select: its backward is an atomic index_add; `[:, jx]` sorts)
 
 
 class _Groups:
@@ -115,8 +115,9 @@ class Update(nn.Module):
         ix, jx = cuda_ba.neighbors(kk, jj)              # HIP kernel: GPU tensors only, like everything here
         mask_ix = (ix >= 0).to(net.dtype).reshape(1, -1, 1)
         mask_jx = (jx >= 0).to(net.dtype).reshape(1, -1, 1)
-        net = net + self.c1(mask_ix * net[:, ix])
-        net = net + self.c2(mask_jx * net[:, jx])
+        # gathers with index_select (backward = atomic index_add; advanced indexing's backward sorts 18 000 indices: 0.43 ms each)
+        net = net + self.c1(mask_ix * torch.index_select(net, 1, ix.clamp(min=0)))
+        net = net + self.c2(mask_jx * torch.index_select(net, 1, jx.clamp(min=0)))
         net = net + self.agg_kk(net, kk)
         net = net + self.agg_ij(net, ii * 12345 + jj)
         net = self.gru(net)

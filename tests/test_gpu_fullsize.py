@@ -66,6 +66,46 @@ def test_lookup_at_full_size(workload, sample):
     assert torch.equal(buf, out)
 
 
+@pytest.mark.parametrize("kernel", ["per-edge", "edge-group"])
+def test_lookup_fp16_storage_at_full_size(kernel):
+    """BASELINE configuration 2 with fp16 feature storage (the reference's inference precision, devo.py:71-77): oracle on a sample of
+    edges within the fp16-storage tolerance (2e-3 of the fp32 oracle on the same rounded inputs), plan independence bit for bit,
+    every row written.  `edge-group` repeats it in a sub-process on the opt-in group kernel (DEVO_CORR_GROUP=1, corr_group.h)."""
+    import subprocess
+    if kernel == "edge-group":
+        if os.environ.get("DEVO_CORR_GROUP", "0") == "1":
+            pytest.skip("already running on the group kernel")
+        env = dict(os.environ); env["DEVO_CORR_GROUP"] = "1"
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "fp16_storage_at_full_size and per-edge"],
+                           env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
+    from devo_amd import synth
+    from devo_amd.backends import cuda_corr
+    cfg, d, cpu, coords = _inputs("cfg2")
+    n, R, H = cfg["n"], cfg["R"], cfg["H"]
+    E = d["ii"].numel()
+    gmap = d["gmap"].half()
+    pyr = [t.half() for t in d["pyramid"]]
+    look = lambda order: cuda_corr.forward_pyramid(gmap, pyr, coords, d["kk"], d["jj"], R, (1, 4), order=order)
+    plan = cuda_corr.plan(coords, d["jj"], n, H, radius=R)
+    out = look(plan)
+    assert out.dtype == torch.float16 and bool(torch.isfinite(out).all())
+    sample = 96
+    sel = torch.randperm(E, generator=torch.Generator().manual_seed(2))[:sample]
+    c_cpu = coords.cpu()[:, sel]
+    kk, jj = cpu["kk"][sel], cpu["jj"][sel]
+    q = lambda t: t.half().float()
+    ref = torch.stack([A.corr_forward(q(cpu["gmap"]), q(cpu["fmap"]), c_cpu, kk, jj, R),
+                       A.corr_forward(q(cpu["gmap"]), q(synth.pyramid_l1(cpu["fmap"]).half().float()), c_cpu / 4, kk, jj, R)], -1).reshape(1, sample, -1)
+    assert rel_err(out.cpu()[:, sel].float(), ref) <= 2e-3
+    no_plan = torch.cat([torch.arange(E, dtype=torch.int32, device=DEV), torch.zeros(E + 1, dtype=torch.int32, device=DEV)])
+    assert torch.equal(look(no_plan), out)
+    buf = torch.full_like(out, float("nan"))
+    cuda_corr.forward_pyramid(gmap, pyr, coords, d["kk"], d["jj"], R, (1, 4), out=buf, order=plan)
+    assert torch.equal(buf, out)
+
+
 @pytest.mark.parametrize("workload", ["cfg1", "cfg2"])
 def test_bundle_adjustment_at_full_size(workload):
     from devo_amd.backends import cuda_ba

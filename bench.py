@@ -175,7 +175,7 @@ def train_mode(args, device, rank, world, steps=None, warmup=None, iters=None, p
     return {"metric": "training sequences/sec (update + BA path, batch = 1 sequence per GPU)", "value": res["sequences_per_s"], "unit": "seq/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg3/4: n=15 frames, M=80 patches/frame, E={batch['E']} edges, {iters} update iterations per step, "
+            "config": {"workload": f"cfg3/4: n=15 frames (5-bin voxel grids 480x640 through both encoders + scorer), M=80 patches/frame, E={batch['E']} edges, {iters} update iterations per step, "
                                    f"corr backward on 20 % of the edges, 2 differentiable GN steps per iteration, AdamW",
                        "parallelism": f"dp{world}"},
             "train": res}

@@ -1,0 +1,272 @@
+"""Patchifier: the per-frame step in front of the update loop — matching / context features from the two
+stride-4 encoders, patch selection, patch gathers, and the correlation pyramid in the lookup kernel's channel-blocked layout.
+
+Mirrors `devo.enet.Patchifier` (enet.py:100-200) with its sub-modules `devo.extractor.BasicEncoder4Evs` (extractor.py:269-335,
+residual blocks :6-54) and `devo.selector.Scorer` / `PatchSelector` (selector.py:19-47, 50-260): the parameter tree has the
+reference's names and shapes (a reference checkpoint loads with `load_state_dict`), forward returns the reference's tuple.
+
+What is different, on purpose (MI355X):
+  * the convolutions are the only dense contractions of the path: they go to MIOpen through PyTorch-ROCm, in
+    channels-last memory format (MIOpen's native NHWC kernels on gfx950; under `torch.autocast(fp16 | bf16)` on the matrix
+    cores).  Nothing here is a hand-written kernel, by SURVEY's own scoping of this row;
+  * the three gathers are the HIP `patchify` kernel (devo_amd.altcorr.patchify); the `[x, y, inverse depth]` patches are
+    written in closed form instead of gathering a materialised coordinate grid (utils.py:38-59);
+  * `pyramid()` builds both pyramid levels straight in the channel-blocked layout of the lookup kernel (devo_pyramid_build)
+    instead of NCHW + avg_pool2d (devo.py:526-527).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import altcorr
+
+DIM_INET, DIM_FNET, DIM_ENC = 384, 128, 32
+
+
+def _norm(kind, x):
+    if kind == "instance":
+        return F.instance_norm(x)                     # nn.InstanceNorm2d defaults: no affine, no running statistics
+    if kind == "none":
+        return x
+    raise NotImplementedError(f"norm_fn = {kind!r} (DEVO uses 'instance' for fnet and 'none' for inet)")
+
+
+class _Residual(nn.Module):
+    """extractor.py:6-54: two 3x3 convolutions + identity (or a strided 1x1 projection), ReLU after the sum."""
+
+    def __init__(self, cin, cout, norm_fn, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.norm_fn = norm_fn
+        # same child names as the reference, so that state-dict keys line up (the norms hold no parameters)
+        self.downsample = None if stride == 1 else nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride))
+
+    def forward(self, x):
+        y = F.relu(_norm(self.norm_fn, self.conv1(x)))
+        y = F.relu(_norm(self.norm_fn, self.conv2(y)))
+        if self.downsample is not None:
+            x = _norm(self.norm_fn, self.downsample(x))
+        return F.relu(x + y)
+
+
+def _init(module):
+    for m in module.modules():                        # extractor.py:296-303 / selector.py:33-40
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+
+class Encoder(nn.Module):
+    """`BasicEncoder4Evs` (extractor.py:269-335): 7x7/2 stem, two residual stages (dim, 2 dim; the second strided), 1x1 head.
+    [b, n, bins, H, W] -> [b, n, output_dim, H/4, W/4]."""
+
+    def __init__(self, bins=5, output_dim=128, dim=DIM_ENC, norm_fn="instance"):
+        super().__init__()
+        if norm_fn not in ("instance", "none"):
+            raise NotImplementedError(f"norm_fn = {norm_fn!r}")
+        self.norm_fn = norm_fn
+        self.conv1 = nn.Conv2d(bins, dim, 7, stride=2, padding=3)
+        self.layer1 = nn.Sequential(_Residual(dim, dim, norm_fn, 1), _Residual(dim, dim, norm_fn, 1))
+        self.layer2 = nn.Sequential(_Residual(dim, 2 * dim, norm_fn, 2), _Residual(2 * dim, 2 * dim, norm_fn, 1))
+        self.conv2 = nn.Conv2d(2 * dim, output_dim, 1)
+        _init(self)
+
+    def forward(self, x):
+        b, n = x.shape[:2]
+        x = x.reshape(b * n, *x.shape[2:]).contiguous(memory_format=torch.channels_last)
+        x = F.relu(_norm(self.norm_fn, self.conv1(x)))
+        x = self.conv2(self.layer2(self.layer1(x)))
+        return x.reshape(b, n, *x.shape[1:])
+
+
+class Scorer(nn.Module):
+    """selector.py:19-47: four unpadded 3x3 convolutions (bins -> 8 -> 16 -> 32 -> 1) and a 4x4 max-pool: one score per
+    stride-4 cell, [b, n, (H - 8) // 4, (W - 8) // 4]."""
+
+    def __init__(self, bins=5):
+        super().__init__()
+        self.scorer = nn.Sequential(nn.Conv2d(bins, 8, 3), nn.ReLU(inplace=True), nn.Conv2d(8, 16, 3), nn.ReLU(inplace=True),
+                                    nn.Conv2d(16, 32, 3), nn.ReLU(inplace=True), nn.Conv2d(32, 1, 3), nn.MaxPool2d(4, 4))
+        _init(self)
+
+    def forward(self, x):
+        b, n = x.shape[:2]
+        s = self.scorer(x.reshape(b * n, *x.shape[2:]).contiguous(memory_format=torch.channels_last))
+        return s.reshape(b, n, *s.shape[2:])
+
+
+# ---------------------------------------------------------------------------------------------------------------- selection
+def _quadrant_order(idx, h2, w2):
+    """cell indices chosen inside each of the 2 x 2 quadrants (idx [bn, k, 4], quadrant-local, row-major over h2 x w2)
+    -> x, y on the whole pooled map, [bn, 4 k] in the reference's (k-major, quadrant-minor) order (selector.py:72-93)."""
+    x, y = idx % w2, torch.div(idx, w2, rounding_mode="floor")
+    qx = torch.tensor([0, 1, 0, 1], device=idx.device) * w2
+    qy = torch.tensor([0, 0, 1, 1], device=idx.device) * h2
+    return (x + qx).flatten(1), (y + qy).flatten(1)
+
+
+def _quadrants(pooled):
+    """[bn, h1, w1] -> [bn, 4, h2 * w2] (the four quadrants of the top-left 2 h2 x 2 w2 part, selector.py:59-70)"""
+    bn, h1, w1 = pooled.shape
+    h2, w2 = h1 // 2, w1 // 2
+    q = pooled[:, :2 * h2, :2 * w2].reshape(bn, 2, h2, 2, w2).permute(0, 1, 3, 2, 4)
+    return q.reshape(bn, 4, h2 * w2), h2, w2
+
+
+def select_three_x_random(scores, m, candidates=None):
+    """3 m uniform candidates per frame, the m with the highest score win (selector.py:95-108 / enet.py:146-158).
+    scores [1, n, h, w] -> x + 1, y + 1 (feature-map pixels), the winners' scores in ascending order."""
+    _, n, h, w = scores.shape
+    if candidates is None:
+        x = torch.randint(0, w, (n, 3 * m), device=scores.device)
+        y = torch.randint(0, h, (n, 3 * m), device=scores.device)
+    else:
+        x, y = candidates
+    s = scores[0][torch.arange(n, device=scores.device)[:, None], y, x]          # = patchify(scores, coords, 0) at integer coords
+    vs, ix = torch.sort(s, dim=1)
+    top = ix[:, -m:]
+    return torch.gather(x, 1, top) + 1, torch.gather(y, 1, top) + 1, vs[:, -m:].contiguous()
+
+
+def select_topk(scores, m, grid=True, k=4):
+    """pooled top-k (selector.py:152-192): best pixel of every k x k cell, then the m best cells (m / 4 per quadrant with
+    `grid`)."""
+    b, n, h, w = scores.shape
+    cells = F.unfold(scores.reshape(b * n, 1, h, w), kernel_size=k, stride=k)    # [bn, k*k, cells]
+    best, off = cells.max(dim=1)
+    h1, w1 = h // k, w // k
+    if grid:
+        q, h2, w2 = _quadrants(best.reshape(b * n, h1, w1))
+        idx = torch.topk(q, m // 4, dim=-1).indices.transpose(1, 2)              # [bn, m/4, 4]
+        cx, cy = _quadrant_order(idx, h2, w2)
+    else:
+        idx = torch.topk(best, m, dim=-1).indices
+        cx, cy = idx % w1, torch.div(idx, w1, rounding_mode="floor")
+    o = torch.gather(off, 1, cy * w1 + cx)
+    return k * cx + o % k, k * cy + torch.div(o, k, rounding_mode="floor")
+
+
+def select_multi(scores, m, grid=True, k=4):
+    """average-pooled multinomial sampling (selector.py:110-150): cells drawn with probability ~ their mean score (m / 4 per
+    quadrant with `grid`), then one pixel of the cell's k x k window (the reference's windows start one pixel up-left of
+    the cell: unfold(padding = 1)) with probability ~ its score."""
+    b, n, h, w = scores.shape
+    avg = F.avg_pool2d(scores, k, k).reshape(b * n, h // k, w // k)
+    h1, w1 = avg.shape[1:]
+    if grid:
+        q, h2, w2 = _quadrants(avg)
+        idx = torch.multinomial(q.reshape(b * n * 4, h2 * w2) + 1e-7, m // 4).reshape(b * n, 4, m // 4).transpose(1, 2)
+        cx, cy = _quadrant_order(idx, h2, w2)
+    else:
+        idx = torch.multinomial(avg.reshape(b * n, -1), m)
+        cx, cy = idx % w1, torch.div(idx, w1, rounding_mode="floor")
+    win = F.unfold(scores.reshape(b * n, 1, h, w), kernel_size=k, stride=k, padding=1).transpose(1, 2)   # [bn, windows, k*k]
+    pick = torch.gather(win, 1, (cy * w1 + cx)[..., None].expand(-1, -1, k * k)) + 1e-7
+    o = torch.multinomial(pick.flatten(0, 1), 1).reshape(b * n, m)
+    return k * cx + o % k, k * cy + torch.div(o, k, rounding_mode="floor")
+
+
+def select(scores, m, mode, grid=True, k=4):
+    """PatchSelector.__call__ (selector.py:256-287): the score map is zero-padded (centred) to whole cells — whole 2 x 2 grids of
+    cells with `grid` —, the method runs on the padded map, the coordinates are shifted back and clamped into the map."""
+    mode = mode.lower()
+    if mode == "3xrandom":
+        return select_three_x_random(scores, m)[:2]
+    if mode not in ("topk", "multi"):
+        raise NotImplementedError(f"patch selection mode {mode!r} (have: 3xrandom, topk, multi)")
+    h, w = scores.shape[-2:]
+    f = 2 * k if grid else k
+    ph, pw = (f - h % f) % f, (f - w % f) % f
+    top, left = ph // 2, pw // 2
+    padded = F.pad(scores, (left, pw - left, top, ph - top))
+    x, y = (select_topk if mode == "topk" else select_multi)(padded, m, grid, k)
+    return (x - left).clamp(min=0, max=w - 1), (y - top).clamp(min=0, max=h - 1)
+
+
+# --------------------------------------------------------------------------------------------------------------- the module
+class Patchifier(nn.Module):
+    """enet.py:100-200.  forward(images [1, n, bins, H, W]) -> fmap [1, n, 128, H/4, W/4], gmap [1, n M, 128, P, P],
+    imap [1, n M, 384, 1, 1], patches [1, n M, 3, P, P] (x, y, inverse depth), index [n M] (+ scores when training with the
+    scorer, + colour when asked for in eval)."""
+
+    def __init__(self, patch_size=3, dim_inet=DIM_INET, dim_fnet=DIM_FNET, dim=DIM_ENC, patch_selector="scorer", bins=5):
+        super().__init__()
+        self.patch_size, self.dim_inet, self.dim_fnet = patch_size, dim_inet, dim_fnet
+        self.patch_selector = patch_selector.lower()
+        if self.patch_selector not in ("scorer", "gradient", "random"):
+            raise NotImplementedError(f"patch_selector = {patch_selector!r}")
+        self.fnet = Encoder(bins, dim_fnet, dim, "instance")
+        self.inet = Encoder(bins, dim_inet, dim, "none")
+        if self.patch_selector == "scorer":
+            self.scorer = Scorer(bins)
+
+    @staticmethod
+    def event_gradient(images):
+        """enet.py:112-118: gradient magnitude of the event count image at stride 4."""
+        s = images.sum(dim=2)
+        dx = s[..., :-1, 1:] - s[..., :-1, :-1]
+        dy = s[..., 1:, :-1] - s[..., :-1, :-1]
+        return F.avg_pool2d(torch.sqrt(dx * dx + dy * dy), 4, 4)
+
+    def forward(self, images, patches_per_image=80, disps=None, return_color=False, scorer_eval_mode="multi",
+                scorer_eval_use_grid=True, candidates=None, coords=None):
+        """`candidates` = (x, y) int64 [n, 3 M]: the uniform draws of the training branch, `coords` = (x, y) [n, M]: the final
+        patch centres — both optional, for reproducible tests (the reference draws them on the device)."""
+        fmap = self.fnet(images) / 4.0
+        imap = self.inet(images) / 4.0
+        b, n, _, h, w = fmap.shape
+        P, M, dev = self.patch_size, patches_per_image, fmap.device
+        scores = None
+        if coords is not None:
+            x, y = coords
+        elif self.patch_selector == "gradient":
+            g = self.event_gradient(images)
+            x, y = select(g, M, "3xrandom" if self.training else scorer_eval_mode, scorer_eval_use_grid) if candidates is None else \
+                select_three_x_random(g, M, candidates)[:2]
+            x, y = x.clamp(min=1, max=w - 2), y.clamp(min=1, max=h - 2)
+        elif self.patch_selector == "random":
+            x = torch.randint(1, w - 1, (n, M), device=dev)
+            y = torch.randint(1, h - 1, (n, M), device=dev)
+        else:
+            smap = torch.sigmoid(self.scorer(images).float())                   # [1, n, h - 2, w - 2]
+            if self.training:
+                x, y, scores = select_three_x_random(smap, M, candidates)
+            else:
+                x, y = select(smap, M, scorer_eval_mode, scorer_eval_use_grid)
+                scores = smap[0][torch.arange(n, device=dev)[:, None], y, x]
+                x, y = x + 1, y + 1
+        if self.patch_selector == "scorer" and coords is not None:
+            smap = torch.sigmoid(self.scorer(images).float())
+            scores = smap[0][torch.arange(n, device=dev)[:, None], (y - 1).clamp(0, h - 3), (x - 1).clamp(0, w - 3)]
+        xy = torch.stack([x, y], dim=-1).float()                                  # [n, M, 2], feature-map pixels
+        imap_p = altcorr.patchify(imap[0].float().contiguous(), xy, 0).view(b, -1, self.dim_inet, 1, 1)
+        gmap = altcorr.patchify(fmap[0].float().contiguous(), xy, P // 2).view(b, -1, self.dim_fnet, P, P)
+        # patches = patchify(coords_grid_with_index(disps), xy, P // 2) in closed form: pixel (x + j - r, y + i - r) and its depth
+        r = P // 2
+        off = torch.arange(-r, r + 1, device=dev, dtype=torch.float32)
+        px = (xy[..., 0, None, None] + off[None, None, None, :]).expand(n, M, P, P)
+        py = (xy[..., 1, None, None] + off[None, None, :, None]).expand(n, M, P, P)
+        if disps is None:
+            pd = torch.ones(n, M, P, P, device=dev)
+        else:
+            pd = altcorr.patchify(disps[0, :, None].float().contiguous(), xy, r).view(n, M, P, P)
+            inside = (px >= 0) & (px < w) & (py >= 0) & (py < h)                  # (the gather returns 0 outside the frame; so does the grid's)
+            px, py = px * inside, py * inside
+        patches = torch.stack([px, py, pd], dim=2).view(b, n * M, 3, P, P)
+        index = torch.arange(n, device=dev).view(n, 1).repeat(1, M).reshape(-1)
+        if self.training and self.patch_selector == "scorer":
+            return fmap, gmap, imap_p, patches, index, scores
+        if not self.training and return_color:
+            clr = altcorr.patchify(images[0].abs().sum(dim=1, keepdim=True).float().contiguous(), 4 * (xy + 0.5), 0).clamp(min=0, max=255).view(b, -1, 1)
+            return fmap, gmap, imap_p, patches, index, clr
+        return fmap, gmap, imap_p, patches, index
+
+    @staticmethod
+    def pyramid(fmap, dtype=None):
+        """the two lookup levels of `fmap` [1, n, C, h, w] (level 1 = 4x4 mean, devo.py:526-527) in the lookup kernel's
+        channel-blocked layout, one pass (devo_pyramid_build)."""
+        f = fmap if dtype is None else fmap.to(dtype)
+        return altcorr.build_pyramid(f.contiguous())
+
+    def num_parameters(self):
+        return sum(p.numel() for p in self.parameters())

@@ -6,10 +6,10 @@ correlation lookup (gradients through 20 % of the edges, correlation.py:20-25), 
 Gauss-Newton steps — accumulates flow + pose losses, and `loss.backward()` all-reduces ONE bucket of 3 397 061 fp32
 gradients (13.59 MB: Update 3 004 804 + fnet 184 576 + inet 201 216 + scorer 6 465) over NCCL = RCCL.
 
-Here the same step runs on this repo's path: devo_amd.projective_ops / altcorr / update / ba (HIP kernels + autograd) on the
-synthetic TartanAir-shaped inputs of SURVEY.md §8d.  The CNN encoders and the scorer are out of scope; they are
-represented by parameter tensors of their exact sizes that scale the (synthetic) features they would have produced, so
-that the gradient bucket DDP all-reduces has the reference's size and every parameter receives a gradient.
+Here the same step runs on this repo's path: devo_amd.patchifier (the two encoders + scorer through MIOpen, HIP gathers),
+projective_ops / altcorr / update / ba (HIP kernels + autograd) on synthetic TartanAir-shaped inputs (random voxel
+grids, the synthetic trajectory's poses and patch centres).  The module tree is the reference's (`update`, `patchify.fnet`,
+`patchify.inet`, `patchify.scorer`): the gradient bucket DDP all-reduces is the reference's by construction.
 """
 import torch
 import torch.nn as nn
@@ -21,16 +21,15 @@ N_TOTAL = 3_397_061
 
 
 class TrainNet(nn.Module):
-    """The parameters the reference's DDP wraps: the Update operator (real, devo_amd.update.Update — module tree and names of
-    devo/enet.py:32-78) + stand-ins of the encoders' / scorer's sizes."""
+    """The parameters the reference's DDP wraps (eVONet, enet.py:218-233): `patchify` (fnet, inet, scorer — devo_amd.patchifier)
+    and `update` (devo_amd.update.Update), same names."""
 
     def __init__(self, p=3, dim=384):
         super().__init__()
         from .update import Update
+        from .patchifier import Patchifier
+        self.patchify = Patchifier(patch_size=p, dim_inet=dim, dim_fnet=128, dim=32, patch_selector="scorer")
         self.update = Update(p, dim)
-        self.fnet_standin = nn.Parameter(torch.zeros(N_FNET))
-        self.inet_standin = nn.Parameter(torch.zeros(N_INET))
-        self.scorer_standin = nn.Parameter(torch.zeros(N_SCORER))
         self.P, self.dim = p, dim
 
     def num_parameters(self):
@@ -49,11 +48,11 @@ class TrainNet(nn.Module):
         b = batch
         ii, jj, kk = b["ii"], b["jj"], b["kk"]
         E, n = ii.numel(), b["poses_gt"].shape[1]
-        # the encoders' outputs: synthetic features scaled through the stand-in parameters (gradients reach all of them)
-        fs = 1.0 + 1e-3 * self.fnet_standin.mean()
-        pyramid = [f * fs for f in b["pyramid"]]
-        gmap = b["gmap"] * fs
-        imap = b["imap"] * (1.0 + 1e-3 * self.inet_standin.mean()) * (1.0 + 1e-3 * self.scorer_standin.mean())
+        # enet.py:279-291: features, patch gathers and scores from the voxel grids; the patch centres are the synthetic
+        # trajectory's (so that the ground-truth patches of the flow loss belong to them), the scorer is evaluated there
+        fmap, gmap, imap, _, _, scores = self.patchify(b["images"], b["M"], coords=b["centres"])
+        pyramid = [altcorr.channels_last(fmap), altcorr.channels_last(torch.nn.functional.avg_pool2d(fmap[0], 4, 4)[None])]   # enet.py:207-210
+        imap = imap.view(1, -1, self.dim)
         Ps = SE3(b["poses_gt"])
         Gs = SE3(b["poses0"].clone())
         patches = b["patches0"].clone()
@@ -94,7 +93,7 @@ class TrainNet(nn.Module):
             loss = loss + flow_weight * flow_loss
             if it >= 2:
                 loss = loss + pose_weight * pose_loss
-        return loss
+        return loss + 1e-3 * scores.mean()                      # (the reference's scorer term, train.py:226-232, reduced to a mean)
 
 
 def make_batch(workload="cfg2_m80", seed=1234, device="cuda"):
@@ -108,17 +107,16 @@ def make_batch(workload="cfg2_m80", seed=1234, device="cuda"):
     patches_gt, centres = synth.make_patches(n, M, H, W, seed=seed)
     intr = synth.make_intrinsics(n, H, W)
     ii, jj, kk = synth.full_graph(n, M)
-    fmap, gmap = synth.make_features(n, M, C, H, W, centres, seed=seed)
     g = torch.Generator().manual_seed(seed + 7)
+    images = torch.randn(1, n, 5, 4 * H, 4 * W, generator=g)                                  # event voxel grids, 5 bins (std-normalised)
     patches0 = patches_gt.clone()
     patches0[:, :, 2] = torch.rand(1, n * M, 1, 1, generator=g).expand(1, n * M, 3, 3)       # enet.py:294-295: random initial depth
     poses0 = poses_gt.clone()
     poses0[:, 1:, :3] += 0.01 * torch.randn(1, n - 1, 3, generator=g)                         # start near, not at, the truth
-    imap = 0.1 * torch.randn(1, n * M, 384, generator=g)
-    f0 = fmap.to(dev)
-    f1 = synth.pyramid_l1(f0)
     d = lambda t: t.to(dev)
-    return dict(pyramid=[altcorr.channels_last(f0), altcorr.channels_last(f1)], gmap=d(gmap).contiguous(), imap=d(imap),
+    cx = patches_gt[0, :, 0, 1, 1].round().long().view(n, M).clamp(1, W - 2)                  # patch centres, feature-map pixels
+    cy = patches_gt[0, :, 1, 1, 1].round().long().view(n, M).clamp(1, H - 2)
+    return dict(images=d(images), centres=(d(cx), d(cy)),
                 poses_gt=d(poses_gt), poses0=d(poses0), patches_gt=d(patches_gt), patches0=d(patches0), intr=d(intr),
                 ii=d(ii), jj=d(jj), kk=d(kk), H=H, W=W, R=R, n=n, M=M, E=int(ii.numel()))
 

@@ -75,7 +75,7 @@ def test_ba_with_zero_lambda_keeps_unobserved_patches_finite(golden_dir):
 
 def test_training_step_reaches_every_parameter():
     """devo_amd.training: one training step of the update + BA path (configuration 3 at a small size) — finite loss, a gradient
-    in every parameter of the reference-sized bucket (Update operator AND the encoder / scorer stand-ins), weights move."""
+    in every parameter of the reference's bucket (Update operator, both encoders, the scorer), weights move."""
     from devo_amd import training as T
     net, model, opt = T.build_trainer(DEV, 1)
     assert net.num_parameters() == T.N_TOTAL
@@ -87,7 +87,7 @@ def test_training_step_reaches_every_parameter():
     assert torch.isfinite(loss)
     missing = [n for n, q in net.named_parameters() if q.grad is None or not torch.isfinite(q.grad).all()]
     assert not missing, missing
-    assert all(float(q.grad.abs().max()) > 0 for n, q in net.named_parameters() if n.startswith("update.") and "d.1" not in n or n.endswith("standin"))
+    assert all(float(q.grad.abs().max()) > 0 for n, q in net.named_parameters() if (n.startswith("update.") and "d.1" not in n) or n.startswith("patchify."))
     l2 = T.train_step(model, opt, batch, iters=3)
     after = torch.cat([q.detach().reshape(-1) for q in net.parameters()])
     assert torch.isfinite(l2) and not torch.equal(before, after)

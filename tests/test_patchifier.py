@@ -1,0 +1,95 @@
+"""Patchifier against fixtures produced by the REAL reference modules (tools/gen_golden_patchifier.py:
+devo.extractor.BasicEncoder4Evs, devo.selector.Scorer / PatchSelector, devo.enet.Patchifier run on CPU in fp64)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from devo_amd import patchifier as PF
+from util import rel_err
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "patchifier_f64.npz"))
+
+
+def _sd(prefix):
+    return {k[len(prefix):]: torch.from_numpy(GOLD[k]).double() for k in GOLD.files if k.startswith(prefix)}
+
+
+def test_encoders_and_scorer_match_the_reference_modules():
+    images = torch.from_numpy(GOLD["images"]).double()
+    for tag, norm, od in (("fnet", "instance", 16), ("inet", "none", 24)):
+        enc = PF.Encoder(5, od, 8, norm).double().eval()
+        sd = _sd(tag + "/sd/")
+        assert set(sd) == set(enc.state_dict()), "parameter names differ from the reference's state dict"
+        enc.load_state_dict(sd)
+        with torch.no_grad():
+            out = enc(images)
+        assert rel_err(out, torch.from_numpy(GOLD[tag + "/out"]).double()) <= 1e-6, tag
+    sc = PF.Scorer(5).double().eval()
+    sd = _sd("scorer/sd/")
+    assert set(sd) == set(sc.state_dict())
+    sc.load_state_dict(sd)
+    with torch.no_grad():
+        assert rel_err(sc(images), torch.from_numpy(GOLD["scorer/out"]).double()) <= 1e-6
+
+
+def test_parameter_counts_of_the_default_configuration():
+    """fnet 184 576 + inet 201 216 + scorer 6 465 (+ Update 3 004 804 = the 3 397 061-parameter bucket)"""
+    p = PF.Patchifier()
+    cnt = lambda m: sum(q.numel() for q in m.parameters())
+    assert (cnt(p.fnet), cnt(p.inet), cnt(p.scorer)) == (184_576, 201_216, 6_465)
+    assert set(_sd("pf/sd/")) == set(PF.Patchifier(3, 24, 16, 8, "scorer").state_dict())
+
+
+def test_pooled_topk_selection_is_the_reference_selection():
+    sm = torch.from_numpy(GOLD["topk/scores"]).double()
+    for grid in (True, False):
+        x, y = PF.select(sm, 8, "topk", grid)
+        assert torch.equal(x, torch.from_numpy(GOLD[f"topk/x_grid{int(grid)}"])) and torch.equal(y, torch.from_numpy(GOLD[f"topk/y_grid{int(grid)}"])), grid
+
+
+def test_stochastic_selections_stay_inside_the_map_and_follow_the_scores():
+    g = torch.Generator().manual_seed(3)
+    sm = torch.rand(1, 2, 24, 32, generator=g)
+    sm[:, :, :, 16:] *= 1e-3                                   # the right half is (almost) never worth a patch
+    torch.manual_seed(5)
+    for grid in (True, False):
+        x, y = PF.select(sm, 16, "multi", grid)
+        assert x.shape == (2, 16) and int(x.min()) >= 0 and int(x.max()) < 32 and int(y.min()) >= 0 and int(y.max()) < 24
+        if not grid:
+            assert float((x < 17).float().mean()) > 0.9
+    x, y, s = PF.select_three_x_random(sm, 8)
+    assert x.shape == (2, 8) and int(x.min()) >= 1 and int(x.max()) <= 32 and bool((s[:, 1:] >= s[:, :-1]).all())
+    assert float((x <= 16).float().mean()) > 0.9
+
+
+@pytest.mark.gpu
+def test_patchifier_forward_matches_the_reference_module():
+    """training mode, scorer selection, the reference's own random candidates: every returned tensor"""
+    dev = "cuda"
+    pf = PF.Patchifier(3, 24, 16, 8, "scorer").to(dev).train()
+    pf.load_state_dict({k: v.float() for k, v in _sd("pf/sd/").items()})
+    images = torch.from_numpy(GOLD["images"]).to(dev)
+    cand = (torch.from_numpy(GOLD["pf/cand_x"]).to(dev), torch.from_numpy(GOLD["pf/cand_y"]).to(dev))
+    with torch.no_grad():
+        fmap, gmap, imap, patches, index, scores = pf(images, patches_per_image=6, candidates=cand)
+    for name, got in dict(fmap=fmap, gmap=gmap, imap=imap, patches=patches, scores=scores).items():
+        ref = torch.from_numpy(GOLD["pf/" + name]).float()
+        assert got.shape == ref.shape, name
+        assert rel_err(got.cpu().float(), ref) <= 2e-4, name
+    assert torch.equal(index.cpu(), torch.from_numpy(GOLD["pf/index"]))
+    # eval mode: deterministic pooled top-k, colour output, explicit depths
+    pf.eval()
+    with torch.no_grad():
+        disps = torch.rand(1, 2, 12, 16, device=dev) + 0.5
+        out = pf(images, patches_per_image=8, disps=disps, return_color=True, scorer_eval_mode="topk")
+    fmap, gmap, imap, patches, index, clr = out
+    assert patches.shape == (1, 16, 3, 3, 3) and clr.shape == (1, 16, 1)
+    x, y = patches[0, :, 0, 1, 1].long(), patches[0, :, 1, 1, 1].long()
+    assert torch.allclose(patches[0, :, 2, 1, 1], disps[0, index, y, x])
+    assert torch.allclose(gmap[0, :, :, 1, 1], fmap[0, index, :, y, x], atol=1e-6)
+    # both lookup levels in the kernel's layout, one pass
+    l0, l1 = pf.pyramid(fmap)
+    from devo_amd import altcorr
+    assert torch.equal(l0, altcorr.channel_blocked(fmap, 8))
+    assert rel_err(l1, altcorr.channel_blocked(torch.nn.functional.avg_pool2d(fmap[0], 4, 4)[None], 8)) <= 1e-6

@@ -528,18 +528,34 @@ __global__ __launch_bounds__(NT) void corr_fwd_generic_kernel(
 // emits ONE atomic per (position, channel) into d_fmap2 — consecutive lanes hit consecutive addresses.
 // The reference issues 2*C scalar atomics per (pixel, tap) thread (correlation_kernel.cu:182-188).
 // -------------------------------------------------------------------------------------------------
+// SEG = true (segment-reduced backward, channels-last fmap2): this kernel computes d_fmap1 only and hands the window gradients G
+// [9][D][D], the edge's geometry (BwdMeta) and its membership in the target frame's edge list to corr_bwd_tile_kernel, which owns
+// d_fmap2 tile by tile — no global atomics on d_fmap2.
+struct BwdMeta { int frame, patch, x0, y0, x1, y1, ox[PP], oy[PP]; };      // 24 ints; box clipped to the frame
+template <bool SEG, int RMAX>
 __global__ __launch_bounds__(NT) void corr_bwd_kernel(
     const float* __restrict__ fmap1, const float* __restrict__ fmap2, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const float* __restrict__ grad,
     float* __restrict__ d1, float* __restrict__ d2, int E, int Np, int n2, int C, int H2, int W2, int64_t s_b,
-    int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int R) {
-  __shared__ float s_g[PP * MAXD * MAXD];   // gradient of the raw D x D windows (correlation_kernel.cu:259-269)
+    int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int R, float* __restrict__ gs, BwdMeta* __restrict__ meta,
+    int* __restrict__ lists, int* __restrict__ cursors, int cap, unsigned long long* __restrict__ trace) {
+  // One workgroup per edge.  Every dependent memory round trip of this kernel costs ~4 k cycles under load (all workgroups are
+  // resident at once), so the phases are ordered for few of them: (1) coordinates + indices, (2) gradient block + patch features
+  // together, then LDS only until the feature rows, which are requested 8 at a time, one step ahead of their use.
+  unsigned long long t_prev = trace ? __builtin_readcyclecounter() : 0ull;
+  auto stamp = [&](int ph) {                                  // debug (DEVO_CORR_BWD_TRACE): cycles of phase ph, thread 0 of every workgroup
+    if (trace && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); trace[(size_t)blockIdx.x * 8 + ph] = t - t_prev; t_prev = __builtin_readcyclecounter(); }
+  };
+  constexpr int DMX = 2 * RMAX + 2;
+  __shared__ float s_g[PP * DMX * DMX];     // gradient of the raw D x D windows (correlation_kernel.cu:259-269)
+  __shared__ float s_grad[(DMX - 1) * (DMX - 1) * PP];
   __shared__ float s_dx[PP], s_dy[PP];
   __shared__ int s_ox[PP], s_oy[PP];
   const int D = 2 * R + 2, Dm = D - 1;
   const int be = blockIdx.x;
   const int b = be / E, e = be % E;
   const int tid = threadIdx.x;
+  const int64_t pi = ii[e], fj = jj[e];
   if (tid < PP) {
     float x = coords[((int64_t)be * 2 + 0) * PP + tid];
     float y = coords[((int64_t)be * 2 + 1) * PP + tid];
@@ -548,23 +564,47 @@ __global__ __launch_bounds__(NT) void corr_bwd_kernel(
     s_dx[tid] = x - floorf(x);
     s_dy[tid] = y - floorf(y);
   }
-  __syncthreads();
-  const float* g = grad + (int64_t)be * Dm * Dm * PP;       // logical [c][a][i0][j0]
-  for (int o = tid; o < PP * D * D; o += NT) {
-    int p = o / (D * D), a = (o / D) % D, c = o % D;
-    float dx = s_dx[p], dy = s_dy[p], s = 0.0f;
-    auto G = [&](int aa, int cc) -> float {
-      return (aa >= 0 && aa < Dm && cc >= 0 && cc < Dm) ? g[((int64_t)cc * Dm + aa) * PP + p] : 0.0f;
-    };
-    s += (1.0f - dx) * (1.0f - dy) * G(a, c);
-    s += dx * (1.0f - dy) * G(a, c - 1);
-    s += (1.0f - dx) * dy * G(a - 1, c);
-    s += dx * dy * G(a - 1, c - 1);
-    int gy = s_oy[p] + a, gx = s_ox[p] + c;
-    if (!(gy >= 0 && gy < H2 && gx >= 0 && gx < W2)) s = 0.0f;   // out-of-bounds taps contribute nothing (:182)
-    s_g[o] = s;
+  const float* __restrict__ f1 = fmap1 + ((int64_t)b * Np + pi) * C * PP;
+  const float* __restrict__ f2 = fmap2 + (int64_t)b * s_b + fj * s_n;
+  float* g1 = d1 + ((int64_t)b * Np + pi) * C * PP;
+  float* g2 = d2 + (int64_t)b * s_b + fj * s_n;
+  // the edge's gradient block (contiguous, logical [c][a][i0][j0]) with unconditional coalesced loads + this thread's patch
+  // features of the first channel round: one round trip
+  constexpr int GIT = ((DMX - 1) * (DMX - 1) * PP + NT - 1) / NT;
+  float gl[GIT], w0[PP];
+  {
+    const float* g = grad + (int64_t)be * Dm * Dm * PP;
+    const int ng = Dm * Dm * PP;
+#pragma unroll
+    for (int i = 0; i < GIT; i++) gl[i] = g[min(tid + i * NT, ng - 1)];
+#pragma unroll
+    for (int p = 0; p < PP; p++) w0[p] = f1[min(tid, C - 1) * PP + p];
+#pragma unroll
+    for (int i = 0; i < GIT; i++) if (tid + i * NT < ng) s_grad[tid + i * NT] = gl[i];
   }
   __syncthreads();
+  stamp(0);
+  {
+    const float inv_dd = __builtin_amdgcn_rcpf((float)(D * D)), inv_d = __builtin_amdgcn_rcpf((float)D);
+    for (int o = tid; o < PP * D * D; o += NT) {
+      const int p = (int)(((float)o + 0.5f) * inv_dd), r_ = o - p * D * D;
+      const int a = (int)(((float)r_ + 0.5f) * inv_d), c = r_ - a * D;
+      const float dx = s_dx[p], dy = s_dy[p];
+      float s = 0.0f;
+      auto G = [&](int aa, int cc) -> float {
+        return (aa >= 0 && aa < Dm && cc >= 0 && cc < Dm) ? s_grad[(cc * Dm + aa) * PP + p] : 0.0f;
+      };
+      s += (1.0f - dx) * (1.0f - dy) * G(a, c);
+      s += dx * (1.0f - dy) * G(a, c - 1);
+      s += (1.0f - dx) * dy * G(a - 1, c);
+      s += dx * dy * G(a - 1, c - 1);
+      const int gy = s_oy[p] + a, gx = s_ox[p] + c;
+      if (!(gy >= 0 && gy < H2 && gx >= 0 && gx < W2)) s = 0.0f;   // out-of-bounds taps contribute nothing (:182)
+      s_g[o] = s;
+    }
+  }
+  __syncthreads();
+  stamp(1);
 
   int xmin = s_ox[0], xmax = s_ox[0], ymin = s_oy[0], ymax = s_oy[0];
 #pragma unroll
@@ -574,36 +614,178 @@ __global__ __launch_bounds__(NT) void corr_bwd_kernel(
   }
   // clip the box to the frame: positions outside carry zero gradient
   const int x0 = max(xmin, 0), x1 = min(xmax + D, W2), y0 = max(ymin, 0), y1 = min(ymax + D, H2);
-  const int64_t pi = ii[e], fj = jj[e];
-  const float* __restrict__ f1 = fmap1 + ((int64_t)b * Np + pi) * C * PP;
-  const float* __restrict__ f2 = fmap2 + (int64_t)b * s_b + fj * s_n;
-  float* g1 = d1 + ((int64_t)b * Np + pi) * C * PP;
-  float* g2 = d2 + (int64_t)b * s_b + fj * s_n;
 
-  for (int k = tid; k < C; k += NT) {
+  // Per box position the 9 window gradients that land on it depend on the position only: lane l of every wave builds them for
+  // position base + l in registers, and the wave walks the 64 positions reading them with v_readlane (no LDS traffic — broadcast
+  // ds_read_b128 rows cost the full 1 KB of LDS bandwidth each —, no barrier); the feature rows are requested 8 at a time, one
+  // step ahead of their use.
+  const int bw = max(x1 - x0, 0), npos = bw * max(y1 - y0, 0);
+  const float inv_bw = __builtin_amdgcn_rcpf((float)max(bw, 1));
+  const int lane = tid & 63;
+  constexpr int RU = 8;                                         // feature rows in flight per thread (x 2: the step ahead)
+  for (int k0 = 0; k0 < C; k0 += NT) {
+    const int k = k0 + tid;
+    const bool live = k < C;
     float w[PP], acc[PP];
 #pragma unroll
-    for (int p = 0; p < PP; p++) { w[p] = f1[k * PP + p]; acc[p] = 0.0f; }
-    for (int gy = y0; gy < y1; gy++) {
-      for (int gx = x0; gx < x1; gx++) {
-        float gv[PP];
-        bool any = false;
+    for (int p = 0; p < PP; p++) { w[p] = k0 == 0 ? w0[p] : (live ? f1[k * PP + p] : 0.0f); acc[p] = 0.0f; }
+    const int64_t kc = (int64_t)min(k, C - 1) * s_c;
+    for (int base = 0; base < npos; base += 64) {
+      const int q = min(base + lane, npos - 1);
+      const int ry = (int)(((float)q + 0.5f) * inv_bw), rx = q - ry * bw;
+      const int gy = y0 + ry, gx = x0 + rx;
+      float tg[PP];
+      bool any = false;
 #pragma unroll
-        for (int p = 0; p < PP; p++) {
-          int a = gy - s_oy[p], c = gx - s_ox[p];
-          gv[p] = (a >= 0 && a < D && c >= 0 && c < D) ? s_g[p * D * D + a * D + c] : 0.0f;
-          any |= (gv[p] != 0.0f);
+      for (int p = 0; p < PP; p++) {
+        const int a = gy - s_oy[p], c = gx - s_ox[p];
+        tg[p] = (a >= 0 && a < D && c >= 0 && c < D) ? s_g[p * D * D + a * D + c] : 0.0f;
+        any |= (tg[p] != 0.0f);
+      }
+      const int toff = (int)((int64_t)gy * s_h + (int64_t)gx * s_w);          // (in-frame offsets fit 31 bits: checked by the launcher)
+      const unsigned long long anym = __ballot(any);                           // rows with any gradient at all
+      const int cnt = min(64, npos - base);
+      auto request = [&](float (&v)[RU], int r) {
+#pragma unroll
+        for (int u = 0; u < RU; u++) v[u] = f2[(int64_t)__builtin_amdgcn_readlane(toff, min(r + u, cnt - 1)) + kc];
+      };
+      float vn[RU];
+      request(vn, 0);
+      for (int r = 0; r < cnt; r += RU) {
+        float v[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) v[u] = vn[u];
+        if (r + RU < cnt) request(vn, r + RU);                  // wave-uniform
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+          if (r + u < cnt && ((anym >> (r + u)) & 1ull)) {      // wave-uniform
+            float t = 0.0f;
+#pragma unroll
+            for (int p = 0; p < PP; p++) {
+              const float g_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tg[p]), r + u));
+              acc[p] = fmaf(g_, v[u], acc[p]); t = fmaf(g_, w[p], t);
+            }
+            if (!SEG && live) atomicAdd(g2 + (int64_t)__builtin_amdgcn_readlane(toff, r + u) + kc, t);
+          }
         }
-        if (!any) continue;                                       // wave-uniform: gv depends only on the position
-        int64_t off = (int64_t)gy * s_h + (int64_t)gx * s_w + (int64_t)k * s_c;
-        float v = f2[off], t = 0.0f;
-#pragma unroll
-        for (int p = 0; p < PP; p++) { acc[p] = fmaf(gv[p], v, acc[p]); t = fmaf(gv[p], w[p], t); }
-        atomicAdd(g2 + off, t);
       }
     }
+    stamp(2);
+    if (live) {
 #pragma unroll
-    for (int p = 0; p < PP; p++) atomicAdd(g1 + k * PP + p, acc[p]);
+      for (int p = 0; p < PP; p++) atomicAdd(g1 + k * PP + p, acc[p]);
+    }
+  }
+  if (SEG) {
+    // hand-over to corr_bwd_tile_kernel, last (nothing in this kernel waits for these stores / the list slot)
+    for (int o = tid; o < PP * D * D; o += NT) gs[(int64_t)be * (PP * D * D) + o] = s_g[o];
+    if (tid == 0) {
+      BwdMeta m;
+      m.frame = b * n2 + (int)fj; m.patch = b * Np + (int)pi; m.x0 = x0; m.y0 = y0; m.x1 = x1; m.y1 = y1;
+#pragma unroll
+      for (int p = 0; p < PP; p++) { m.ox[p] = s_ox[p]; m.oy[p] = s_oy[p]; }
+      meta[be] = m;
+      if (x1 > x0 && y1 > y0) lists[(int64_t)m.frame * cap + atomicAdd(&cursors[m.frame], 1)] = be;      // (order: whoever comes first)
+    }
+  }
+  stamp(3);
+}
+
+// d_fmap2 of the segment-reduced backward: ONE workgroup owns a tile (frame, band of BH rows, slab of 16 channels) of the
+// channels-last gradient, accumulates every edge of the frame whose box touches the band into the tile in LDS (ds_add_f32) and
+// stores the tile once — plain stores, every tile is written (no memset, no global atomics).  Wave w takes the band's edges
+// w, w + 4, ..: lane = (position of 4, channel of 16); the edge's window gradients G sit in a wave-private LDS area.
+constexpr int BWD_CS = 16;                    // channels per slab (64 bytes of a channels-last pixel)
+constexpr int BWD_THREADS = 256;
+__global__ __launch_bounds__(BWD_THREADS) void corr_bwd_tile_kernel(
+    const float* __restrict__ fmap1, const float* __restrict__ gs, const BwdMeta* __restrict__ meta, const int* __restrict__ lists,
+    const int* __restrict__ cursors, float* __restrict__ d2, int n2, int C, int H2, int W2, int64_t s_b, int64_t s_n, int64_t s_h,
+    int64_t s_w, int D, int BH, int cap) {
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  const int DD = D * D;
+  float* const tile = s_dyn;                                  // [BH][W2][16]
+  float* const s_gw = tile + (size_t)BH * W2 * BWD_CS;        // [4 waves][64 rows of 12 floats]
+  constexpr int SCAN = 128;                                   // edges examined per round (threads 0..127)
+  __shared__ int s_em[SCAN][16];                              // per listed edge: be, patch, x0, x1, y0, y1, 9 x (ox - x0 | (oy - y0) << 16)
+  __shared__ int s_cnt[BWD_THREADS / 64 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slab = blockIdx.x, band = blockIdx.y, frame = blockIdx.z;
+  const int ylo = band * BH, yhi = min(ylo + BH, H2);
+  for (int i = tid; i < BH * W2 * BWD_CS / 4; i += BWD_THREADS) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ne = cursors[frame];
+  const int ch = lane & 15, pq = lane >> 4;
+  float* const gw = s_gw + wave * (64 * 12);
+  for (int base = 0; base < ne; base += SCAN) {
+    // the frame's edges base .. base + 127 whose box touches this band -> s_em (compacted), geometry included: the per-edge
+    // work below starts without a dependent global load
+    int e = -1;
+    BwdMeta m_;
+    if (tid < SCAN && base + tid < ne) {
+      e = lists[(int64_t)frame * cap + base + tid];
+      m_ = meta[e];
+      if (!(m_.y0 < yhi && m_.y1 > ylo)) e = -1;
+    }
+    const unsigned long long m = __ballot(e >= 0);
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();                                          // (also: the tile is zeroed / the previous chunk is done)
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < BWD_THREADS / 64; w++) { const int c = s_cnt[w]; off += w < wave ? c : 0; total += c; }
+    if (e >= 0) {
+      int* d = s_em[off + __popcll(m & ((1ull << lane) - 1ull))];
+      d[0] = e; d[1] = m_.patch; d[2] = m_.x0; d[3] = m_.x1; d[4] = m_.y0; d[5] = m_.y1;
+#pragma unroll
+      for (int p = 0; p < PP; p++) d[6 + p] = ((m_.ox[p] - m_.x0) & 0xffff) | ((m_.oy[p] - m_.y0) << 16);      // (origins may lie outside the clipped box: signed halves)
+    }
+    __syncthreads();
+    for (int k = wave; k < total; k += BWD_THREADS / 64) {    // wave-uniform
+      const int* d = s_em[k];
+      const int be = d[0], pidx = d[1], x0 = d[2], x1 = d[3], ya = max(d[4], ylo), yb = min(d[5], yhi), by0 = d[4];
+      float w1[PP];
+#pragma unroll
+      for (int p = 0; p < PP; p++) w1[p] = fmap1[((int64_t)pidx * C + slab * BWD_CS + ch) * PP + p];
+      const int bw = x1 - x0, npos = bw * (yb - ya);
+      const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
+      const float* ge = gs + (int64_t)be * (PP * DD);
+      for (int pb = 0; pb < npos; pb += 64) {
+        // lane = position: its 9 window gradients (unconditional gathers: one round trip) -> the wave's rows [9 values, tile index]
+        const int q = min(pb + lane, npos - 1);
+        const int ry = (int)(((float)q + 0.5f) * inv_bw), rx = q - ry * bw;
+        const int gy = ya + ry, gx = x0 + rx;
+        float gv[PP];
+#pragma unroll
+        for (int p = 0; p < PP; p++) {
+          const int o = d[6 + p];
+          const int a = gy - by0 - (o >> 16), c = rx - (int)(short)(o & 0xffff);
+          const bool in = a >= 0 && a < D && c >= 0 && c < D;
+          const float g = ge[p * DD + (in ? a * D + c : 0)];
+          gv[p] = in ? g : 0.0f;
+        }
+#pragma unroll
+        for (int p = 0; p < PP; p++) gw[lane * 12 + p] = gv[p];
+        gw[lane * 12 + 9] = __int_as_float(((gy - ylo) * W2 + gx) * BWD_CS);
+        wave_lds_fence();
+        const int cnt = min(64, npos - pb);
+        for (int r = pq; r < cnt; r += 4) {                       // lane = (position r of 4, channel)
+          const float4 ta = *reinterpret_cast<const float4*>(&gw[r * 12]), tb = *reinterpret_cast<const float4*>(&gw[r * 12 + 4]),
+                       tc = *reinterpret_cast<const float4*>(&gw[r * 12 + 8]);
+          float t = ta.x * w1[0];
+          t = fmaf(ta.y, w1[1], t); t = fmaf(ta.z, w1[2], t); t = fmaf(ta.w, w1[3], t); t = fmaf(tb.x, w1[4], t);
+          t = fmaf(tb.y, w1[5], t); t = fmaf(tb.z, w1[6], t); t = fmaf(tb.w, w1[7], t); t = fmaf(tc.x, w1[8], t);
+          __hip_atomic_fetch_add(&tile[__float_as_int(tc.y) + ch], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        wave_lds_fence();                                       // the next chunk / edge overwrites the wave's rows
+      }
+    }
+    __syncthreads();                                          // s_em is rebuilt by the next chunk
+  }
+  __syncthreads();
+  // the tile -> d_fmap2 (channels-last: 64 contiguous bytes per pixel and slab)
+  float* const base2 = d2 + (int64_t)(frame / n2) * s_b + (int64_t)(frame % n2) * s_n + slab * BWD_CS;
+  for (int i = tid; i < (yhi - ylo) * W2 * (BWD_CS / 4); i += BWD_THREADS) {
+    const int pix = i >> 2, qd = i & 3;
+    const int ry = pix / W2, x = pix - ry * W2;
+    *reinterpret_cast<float4*>(base2 + (int64_t)(ylo + ry) * s_h + (int64_t)x * s_w + qd * 4) = reinterpret_cast<const float4*>(tile)[i];
   }
 }
 
@@ -1015,15 +1197,66 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_backward: radius %d unsupported (max 5)", radius);
   if (dtype != DEVO_F32) { set_error("devo_corr_backward: fp32 only (the reference's grad accessor is float)"); return DEVO_ERR_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
+  const long long BE = (long long)B * E;
+  DEVO_REQUIRE((long long)(H2 - 1) * f2s[3] + (long long)(W2 - 1) * f2s[4] < (1LL << 31) && f2s[3] >= 0 && f2s[4] >= 0,
+               "devo_corr_backward: a frame of fmap2 must span less than 2^31 elements (row stride %lld)", (long long)f2s[3]);
+  // Segment-reduced path (opt-in, DEVO_CORR_BWD_SEG=1): channels-last fmap2 (the C channels of a pixel contiguous, pixels and rows
+  // C / W C apart), 16-channel slabs, the scratch (window gradients + geometry + per-frame edge lists) within 512 MB.  Measured
+  // slower than the one-kernel atomic path at DEVO's sizes (profiles/README.md, r02y), which therefore stays the default.
+  static const bool force_atomic = getenv("DEVO_CORR_BWD_SEG") == nullptr;
+  const int D = 2 * radius + 2;
+  int BH = 8;
+  while (BH > 1 && (size_t)BH * W2 * BWD_CS * 4 + 4 * 64 * 12 * 4 > 54 * 1024) BH >>= 1;      // (+ 8.3 KB static: 64 KB per workgroup)
+  const long long frames = (long long)B * n2;
+  const size_t gs_bytes = (size_t)BE * PP * D * D * 4, meta_bytes = (size_t)BE * sizeof(BwdMeta), list_bytes = (size_t)frames * (size_t)BE * 4;
+  const size_t tile_lds = (size_t)BH * W2 * BWD_CS * 4 + 4 * 64 * 12 * 4;
+  const bool seg = !force_atomic && BE > 0 && f2s[2] == 1 && f2s[4] == C && f2s[3] == (int64_t)W2 * C && f2s[1] >= (int64_t)H2 * W2 * C &&
+                   C % BWD_CS == 0 && tile_lds <= 54 * 1024 && gs_bytes + meta_bytes + list_bytes <= (512ull << 20) && BE < (1LL << 31) &&
+                   frames <= 65535 && (H2 + BH - 1) / BH <= 65535 && (reinterpret_cast<uintptr_t>(fmap2_grad) & 15) == 0;
   if (hipMemsetAsync(fmap1_grad, 0, sizeof(float) * (size_t)B * Np * C * PP, st) != hipSuccess ||
-      hipMemsetAsync(fmap2_grad, 0, sizeof(float) * (size_t)f2_numel_span, st) != hipSuccess) {
+      (!seg && hipMemsetAsync(fmap2_grad, 0, sizeof(float) * (size_t)f2_numel_span, st) != hipSuccess)) {
     set_error("devo_corr_backward: memset failed");
     return DEVO_ERR_LAUNCH;
   }
-  if ((long long)B * E == 0) return DEVO_OK;
-  hipLaunchKernelGGL(corr_bwd_kernel, dim3((unsigned)((long long)B * E)), dim3(NT), 0, st, (const float*)fmap1,
+  if (BE == 0) return DEVO_OK;
+  unsigned long long* btrace = nullptr;                               // debug switch: phase cycles of the per-edge kernel to stderr
+  static const bool do_btrace = getenv("DEVO_CORR_BWD_TRACE") != nullptr;
+  if (do_btrace) { (void)hipMalloc(&btrace, (size_t)BE * 64); (void)hipMemset(btrace, 0, (size_t)BE * 64); }
+  auto dump_trace = [&]() {
+    if (!do_btrace) return;
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> hv((size_t)BE * 8);
+    (void)hipMemcpy(hv.data(), btrace, (size_t)BE * 64, hipMemcpyDeviceToHost);
+    double h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long i = 0; i < BE; i++) for (int q = 0; q < 8; q++) h[q] += (double)hv[(size_t)i * 8 + q];
+    fprintf(stderr, "[corr bwd trace] per-edge kernel, mean cycles per workgroup: coordinates + gradient block + patch %.0f | window gradients %.0f | rows %.0f | patch atomics + hand-over %.0f\n",
+            (double)h[0] / BE, (double)h[1] / BE, (double)h[2] / BE, (double)h[3] / BE);
+    (void)hipFree(btrace);
+  };
+  if (seg) {
+    char* scratch = nullptr;
+    const size_t cur_off = gs_bytes + meta_bytes + list_bytes, total = cur_off + (size_t)frames * 4;
+    if (hipMallocAsync((void**)&scratch, total, st) != hipSuccess) { (void)hipGetLastError(); set_error("devo_corr_backward: scratch allocation failed"); return DEVO_ERR_LAUNCH; }
+    float* gs = reinterpret_cast<float*>(scratch);
+    BwdMeta* meta = reinterpret_cast<BwdMeta*>(scratch + gs_bytes);
+    int* lists = reinterpret_cast<int*>(scratch + gs_bytes + meta_bytes);
+    int* cursors = reinterpret_cast<int*>(scratch + cur_off);
+    (void)hipMemsetAsync(cursors, 0, (size_t)frames * 4, st);
+    hipLaunchKernelGGL((radius <= 3 ? corr_bwd_kernel<true, 3> : corr_bwd_kernel<true, 5>), dim3((unsigned)BE), dim3(NT), 0, st, (const float*)fmap1, (const float*)fmap2, coords, ii, jj,
+                       grad, (float*)fmap1_grad, (float*)fmap2_grad, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], radius,
+                       gs, meta, lists, cursors, (int)BE, btrace);
+    hipLaunchKernelGGL(corr_bwd_tile_kernel, dim3((unsigned)(C / BWD_CS), (unsigned)((H2 + BH - 1) / BH), (unsigned)frames), dim3(BWD_THREADS),
+                       tile_lds, st, (const float*)fmap1, gs, meta, lists, cursors, (float*)fmap2_grad, n2, C, H2, W2, f2s[0], f2s[1], f2s[3],
+                       f2s[4], D, BH, (int)BE);
+    dump_trace();
+    const int rc = check_launch("devo_corr_backward");
+    (void)hipFreeAsync(scratch, st);
+    return rc;
+  }
+  hipLaunchKernelGGL((radius <= 3 ? corr_bwd_kernel<false, 3> : corr_bwd_kernel<false, 5>), dim3((unsigned)BE), dim3(NT), 0, st, (const float*)fmap1,
                      (const float*)fmap2, coords, ii, jj, grad, (float*)fmap1_grad, (float*)fmap2_grad, E, Np, n2, C, H2,
-                     W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], radius);
+                     W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], radius, (float*)nullptr, (BwdMeta*)nullptr, (int*)nullptr, (int*)nullptr, 0, btrace);
+  dump_trace();
   return check_launch("devo_corr_backward");
 }
 

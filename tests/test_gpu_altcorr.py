@@ -396,18 +396,21 @@ def test_plan_started_by_the_reprojection_kernel_equals_plan():
     assert torch.equal(key(a), key(b))                              # same (frame, band) sequence after the heavy list
 
 
-@pytest.mark.parametrize("which", ["region-staged dense kernel", "staged kernel", "edge-group kernel"])
+@pytest.mark.parametrize("which", ["region-staged dense kernel", "staged kernel", "edge-group kernel", "segment-reduced backward"])
 def test_other_kernels_stay_covered(which):
     """fp32 / fp16 lookups with C = 128 take the per-edge matrix-core kernel by default.  DEVO_CORR_DENSE=1 (read once per
     process) routes them through the region-staged dense matrix-core kernel (corr_dense.h, opt-in), DEVO_CORR_MFMA=0 through
     the staged tap-centric kernel, DEVO_CORR_GROUP=1 sends fp16-storage lookups (C = 128, r <= 3) through the edge-group kernel
     (corr_group.h, opt-in): same parity tests."""
-    if os.environ.get("DEVO_CORR_DENSE", "0") == "1" or os.environ.get("DEVO_CORR_MFMA", "1") == "0" or os.environ.get("DEVO_CORR_GROUP", "0") == "1":
+    if os.environ.get("DEVO_CORR_DENSE", "0") == "1" or os.environ.get("DEVO_CORR_MFMA", "1") == "0" or os.environ.get("DEVO_CORR_GROUP", "0") == "1" or os.environ.get("DEVO_CORR_BWD_SEG"):
         pytest.skip("already running on another kernel")
     env = dict(os.environ)
     sel = "test_forward_fp32 or test_forward_wide_spread or test_channel_blocked or test_fused_pyramid or test_batch_of_two or test_forward_other_radii or test_coord_div"
     if which == "staged kernel":
         env["DEVO_CORR_MFMA"] = "0"
+    elif which == "segment-reduced backward":                       # opt-in: d_fmap2 tile by tile in LDS instead of global atomics
+        env["DEVO_CORR_BWD_SEG"] = "1"
+        sel = "test_backward_fp32 or test_autograd_layer or test_dtype_coverage"
     elif which == "edge-group kernel":
         env["DEVO_CORR_GROUP"] = "1"
         sel = "test_channel_blocked or test_forward_fp16 or test_fused_pyramid_fp16 or test_nchw_pyramid or test_dtype_coverage"

@@ -53,6 +53,9 @@ def parse():
                     help="update-op: the headline metric (BASELINE configuration 2, replicas when --gpus > 1); train: BASELINE "
                          "configurations 3 / 4 — one training step per sequence under DistributedDataParallel (devo_amd/training.py)")
     ap.add_argument("--train-iters", type=int, default=18, help="update iterations per training step (DEVO_base.conf: 18)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="debug (1-GPU boxes): all ranks of a --gpus N run use GPU 0 and gloo carries the collectives — exercises the N > 1 code "
+                         "path; the numbers are not a scaling measurement")
     ap.add_argument("--no-f16", action="store_true", help="skip the secondary fp16-storage measurement (field \"f16\")")
     ap.add_argument("--no-train-probe", action="store_true",
                     help="multi-GPU update-op runs also time a few data-parallel training steps (field \"train_dp\": the RCCL gradient "
@@ -115,7 +118,7 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: spawn the N ranks here (the driver's torch.distributed.run launch sets WORLD_SIZE itself)
-        if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
+        if not torch.cuda.is_available() or (torch.cuda.device_count() < args.gpus and not args.share_gpu):
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPU(s) visible")
         from devo_amd import distributed as D
         D.launch(rank_main, args.gpus, (sys.argv[1:],))
@@ -133,10 +136,12 @@ def rank_main(argv):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world} (launch with --nproc-per-node {args.gpus})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     from devo_amd import distributed as D
-    D.init_from_env("nccl", device)
+    D.init_from_env("gloo" if args.share_gpu else "nccl", device)
     assert D.world() == world
     if args.mode == "train":
         out = train_mode(args, device, rank, world)
@@ -169,7 +174,7 @@ def train_mode(args, device, rank, world, steps=None, warmup=None, iters=None, p
     nparam = net.num_parameters()
     res = {"ms_per_step": round(1e3 * elapsed / steps, 3), "sequences_per_s": round(world * steps / elapsed, 4),
            "update_iterations_per_step": iters, "steps": steps, "loss": float(loss),
-           "grad_bucket_bytes": 4 * nparam, "parameters": nparam, "collective": "DDP all-reduce (RCCL)" if world > 1 else None}
+           "grad_bucket_bytes": 4 * nparam, "parameters": nparam, "collective": (("DDP all-reduce (gloo: --share-gpu debug run)" if getattr(args, "share_gpu", False) else "DDP all-reduce (RCCL)") if world > 1 else None)}
     if probe:
         return res
     return {"metric": "training sequences/sec (update + BA path, batch = 1 sequence per GPU)", "value": res["sequences_per_s"], "unit": "seq/s",
@@ -369,7 +374,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
                                f"pyramid layout {args.layout}, {'both levels in one lookup launch' if args.fuse_levels else 'one lookup launch per level'}, "
                                f"{('HIP graph, ' + str(args.steps_per_graph) + ' step(s) per graph launch') if not args.no_graph else 'eager'}"
                                f"{', BA index preparation on a second stream' if args.overlap_prepare else ''}",
-                   "parallelism": f"replicas x{world}"},
+                   "parallelism": f"replicas x{world}" + (" (debug: all ranks on ONE GPU, --share-gpu)" if args.share_gpu else "")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": lookup_kernel,

@@ -28,6 +28,48 @@ class _GradClip(torch.autograd.Function):            # blocks.py:72-81: identity
         return torch.nan_to_num(grad, nan=0.0, posinf=float("inf"), neginf=float("-inf")).clamp(min=-0.01, max=0.01)
 
 
+
+class _LinearFn(torch.autograd.Function):
+    """y = x Wᵀ + b over many rows (the Update operator sees one row per edge: 18 000 at BASELINE configuration 3).  The weight gradient
+    dW = dYᵀ X is a [out x rows] x [rows x in] product with a tiny output: hipBLASLt runs it on a handful of tiles (148 us for 384 x 384
+    over 18 000 rows); as a batched product over 16 row chunks + a sum it uses the whole chip (74 us; tools/ubench_dw_gemm.py)."""
+    CHUNKS = 16
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = gw = gb = None
+        g2 = g.reshape(-1, g.shape[-1])
+        if ctx.needs_input_grad[0]:
+            gx = (g2 @ w).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, x.shape[-1])
+            rows, S = x2.shape[0], _LinearFn.CHUNKS
+            if rows % S == 0:
+                gw = torch.bmm(g2.reshape(S, rows // S, -1).transpose(1, 2), x2.reshape(S, rows // S, -1)).sum(0)
+            else:
+                gw = g2.t() @ x2
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters, same state-dict keys) whose backward over >= 4096 rows splits the weight-gradient product."""
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and x.is_cuda and x.numel() // x.shape[-1] >= 4096 and (x.requires_grad or self.weight.requires_grad):
+            y = _LinearFn.apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias)      # (2-D inside: a Function's output must not be a view for the in-place ReLUs)
+            return y.view(*x.shape[:-1], y.shape[-1])
+        return super().forward(x)
+
+
 class GradientClip(nn.Module):                       # blocks.py:84-89
     def forward(self, x):
         return _GradClip.apply(x)
@@ -36,8 +78,8 @@ class GradientClip(nn.Module):                       # blocks.py:84-89
 class GatedResidual(nn.Module):                      # blocks.py:15-29
     def __init__(self, dim):
         super().__init__()
-        self.gate = nn.Sequential(nn.Linear(dim, dim), nn.Sigmoid())
-        self.res = nn.Sequential(nn.Linear(dim, dim), nn.ReLU(inplace=True), nn.Linear(dim, dim))
+        self.gate = nn.Sequential(Linear(dim, dim), nn.Sigmoid())
+        self.res = nn.Sequential(Linear(dim, dim), nn.ReLU(inplace=True), Linear(dim, dim))
 
     def forward(self, x):
         return x + self.gate(x) * self.res(x)
@@ -46,9 +88,9 @@ class GatedResidual(nn.Module):                      # blocks.py:15-29
 class SoftAgg(nn.Module):                            # blocks.py:31-48 (expand=True)
     def __init__(self, dim=512):
         super().__init__()
-        self.f = nn.Linear(dim, dim)
-        self.g = nn.Linear(dim, dim)
-        self.h = nn.Linear(dim, dim)
+        self.f = Linear(dim, dim)
+        self.g = Linear(dim, dim)
+        self.h = Linear(dim, dim)
 
     def forward(self, x, ix):                        # torch composition (autograd path)
         _, jx = torch.unique(ix, return_inverse=True)
@@ -95,16 +137,16 @@ class Update(nn.Module):
     def __init__(self, p, dim=DIM):
         super().__init__()
         self.dim = dim
-        self.c1 = nn.Sequential(nn.Linear(dim, dim), nn.ReLU(inplace=True), nn.Linear(dim, dim))
-        self.c2 = nn.Sequential(nn.Linear(dim, dim), nn.ReLU(inplace=True), nn.Linear(dim, dim))
+        self.c1 = nn.Sequential(Linear(dim, dim), nn.ReLU(inplace=True), Linear(dim, dim))
+        self.c2 = nn.Sequential(Linear(dim, dim), nn.ReLU(inplace=True), Linear(dim, dim))
         self.norm = nn.LayerNorm(dim, eps=1e-3)
         self.agg_kk = SoftAgg(dim)
         self.agg_ij = SoftAgg(dim)
         self.gru = nn.Sequential(nn.LayerNorm(dim, eps=1e-3), GatedResidual(dim), nn.LayerNorm(dim, eps=1e-3), GatedResidual(dim))
-        self.corr = nn.Sequential(nn.Linear(2 * 49 * p * p, dim), nn.ReLU(inplace=True), nn.Linear(dim, dim),
-                                  nn.LayerNorm(dim, eps=1e-3), nn.ReLU(inplace=True), nn.Linear(dim, dim))
-        self.d = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(dim, 2), GradientClip())
-        self.w = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(dim, 2), GradientClip(), nn.Sigmoid())
+        self.corr = nn.Sequential(Linear(2 * 49 * p * p, dim), nn.ReLU(inplace=True), Linear(dim, dim),
+                                  nn.LayerNorm(dim, eps=1e-3), nn.ReLU(inplace=True), Linear(dim, dim))
+        self.d = nn.Sequential(nn.ReLU(inplace=False), Linear(dim, 2), GradientClip())
+        self.w = nn.Sequential(nn.ReLU(inplace=False), Linear(dim, 2), GradientClip(), nn.Sigmoid())
         self._graph_key, self._graph, self._graph_refs, self._wcat = None, None, None, {}
 
     # ------------------------------------------------------------------------------------------ torch / autograd path

@@ -14,11 +14,23 @@ What is different, on purpose (MI355X):
   * `pyramid()` builds both pyramid levels straight in the channel-blocked layout of the lookup kernel (devo_pyramid_build)
     instead of NCHW + avg_pool2d (devo.py:526-527).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import altcorr
+
+# MIOpen "finds" a solver for every new convolution configuration by compiling and timing all candidates — on a fresh box 34-121 s
+# for this module's forward + backward at DEVO's input size (121 s of it in the naive weight-gradient reference kernels that take
+# part in the contest; tools/miopen_first_call.py).  devo_amd/miopen_db/ carries the find results (text) and the compiled kernels
+# of this image's MIOpen for the configurations bench.py and the tools use: with it the first call costs 0.4 s.  Only defaults:
+# a caller's own MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR win, and without the directory MIOpen behaves as usual.
+_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+if os.path.isdir(_DB):
+    os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(_DB, "config"))
+    os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(_DB, "cache"))
 
 DIM_INET, DIM_FNET, DIM_ENC = 384, 128, 32
 

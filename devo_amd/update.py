@@ -159,21 +159,20 @@ class Update(nn.Module):
         """enet.py:80-99 as a torch composition over GPU tensors (differentiable)."""
         net = net + inp + self.corr(corr)
         net = self.norm(net)
-        ix, jx = cuda_ba.neighbors(kk, jj)              # HIP kernel: GPU tensors only, like everything here
+        (ix, jx), gk, gp = self._torch_groups(ii, jj, kk)           # neighbours (HIP kernel) and group maps, cached per graph
         mask_ix = (ix >= 0).to(net.dtype).reshape(1, -1, 1)
         mask_jx = (jx >= 0).to(net.dtype).reshape(1, -1, 1)
         # gathers with index_select (backward = atomic index_add; advanced indexing's backward sorts 18 000 indices: 0.43 ms each)
         net = net + self.c1(mask_ix * torch.index_select(net, 1, ix.clamp(min=0)))
         net = net + self.c2(mask_jx * torch.index_select(net, 1, jx.clamp(min=0)))
-        gk, gp = self._torch_groups(ii, jj, kk)
         net = net + self.agg_kk(net, kk, gk)
         net = net + self.agg_ij(net, None, gp)          # groups of ii * 12345 + jj (enet.py:94)
         net = self.gru(net)
         return net, (self.d(net), self.w(net), None)
 
     def _torch_groups(self, ii, jj, kk):
-        """torch.unique inverse maps of the two aggregations, cached per graph like `_tables` (a training step runs 18 iterations on
-        one graph: 36 sorts + host reads otherwise)"""
+        """neighbour indices and torch.unique inverse maps of the two aggregations, cached per graph like `_tables` (a training
+        step runs 18 iterations on one graph: 18 neighbour searches, 36 sorts + host reads otherwise)"""
         key = (ii.data_ptr(), jj.data_ptr(), kk.data_ptr(), ii._version, jj._version, kk._version, ii.numel(), jj.numel(), kk.numel())
         hit = getattr(self, "_tg", None)
         if hit is None or hit[0] != key:
@@ -181,6 +180,7 @@ class Update(nn.Module):
             for k in (kk, ii * 12345 + jj):
                 _, inv = torch.unique(k, return_inverse=True)
                 out.append((inv, int(inv.max()) + 1 if inv.numel() else 0))
+            out.insert(0, tuple(cuda_ba.neighbors(kk, jj)))
             hit = (key, out, (ii, jj, kk))                 # (the references keep the key's storages alive)
             self._tg = hit
         return hit[1]

@@ -157,6 +157,41 @@ __global__ __launch_bounds__(256) void k_softagg(const T* __restrict__ f, const 
   }
 }
 
+// Adjoint of k_softagg (training): with w_e = softmax over the group of g, y = sum_e f_e w_e,
+//   d f_e = w_e * dy,   d g_e = w_e * dy * (f_e - y)       (channel-wise; sum_e' w_e' f_e' = y removes the cross term)
+// Same work distribution; pass 1 recomputes the group's max / normaliser / y online, pass 2 writes the two gradients.
+template <typename T>
+__global__ __launch_bounds__(256) void k_softagg_bwd(const T* __restrict__ f, const T* __restrict__ g, int64_t ld_fg,
+                                                     const int* __restrict__ perm, const int* __restrict__ seg,
+                                                     const int* __restrict__ n_seg_p, const T* __restrict__ dy,
+                                                     T* __restrict__ df, T* __restrict__ dg, int64_t ld_d, int dim) {
+  const int n_seg = *n_seg_p;
+  const int nslab = (dim + 511) / 512;
+  for (int w = blockIdx.x; w < n_seg * nslab; w += gridDim.x) {
+    const int s = w / nslab, c = ((w - s * nslab) * 256 + threadIdx.x) * 2;
+    const int a0 = seg[s], a1 = seg[s + 1];
+    if (c >= dim) continue;
+    float m0 = -3.0e38f, m1 = -3.0e38f, den0 = 0.0f, den1 = 0.0f, num0 = 0.0f, num1 = 0.0f;
+    for (int a = a0; a < a1; a++) {
+      const int64_t e = perm[a];
+      const float2 gv = ld2(g + e * ld_fg + c), fv = ld2(f + e * ld_fg + c);
+      const float n0 = fmaxf(m0, gv.x), n1 = fmaxf(m1, gv.y);
+      const float r0 = __expf(m0 - n0), r1 = __expf(m1 - n1), w0 = __expf(gv.x - n0), w1 = __expf(gv.y - n1);
+      den0 = den0 * r0 + w0; num0 = num0 * r0 + fv.x * w0; m0 = n0;
+      den1 = den1 * r1 + w1; num1 = num1 * r1 + fv.y * w1; m1 = n1;
+    }
+    const float i0 = 1.0f / den0, i1 = 1.0f / den1, y0 = num0 * i0, y1 = num1 * i1;
+    const float2 dyv = ld2(dy + (int64_t)s * dim + c);
+    for (int a = a0; a < a1; a++) {
+      const int64_t e = perm[a];
+      const float2 gv = ld2(g + e * ld_fg + c), fv = ld2(f + e * ld_fg + c);
+      const float w0 = __expf(gv.x - m0) * i0 * dyv.x, w1 = __expf(gv.y - m1) * i1 * dyv.y;
+      st2(df + e * ld_d + c, make_float2(w0, w1));
+      st2(dg + e * ld_d + c, make_float2(w0 * (fv.x - y0), w1 * (fv.y - y1)));
+    }
+  }
+}
+
 // net[e] += hy[group_of[e]]
 template <typename T>
 __global__ void k_expand_add(T* __restrict__ net, const T* __restrict__ hy, const int* __restrict__ group_of, int64_t E, int dim) {
@@ -280,6 +315,21 @@ int devo_upd_softagg(const void* f, const void* g, int64_t ld_fg, const int* per
     hipLaunchKernelGGL(k_softagg<float>, grid, block, 0, st_, (const float*)f, (const float*)g, ld_fg, perm, seg_start, n_seg, (float*)y, group_of, dim),
     hipLaunchKernelGGL(k_softagg<__half>, grid, block, 0, st_, (const __half*)f, (const __half*)g, ld_fg, perm, seg_start, n_seg, (__half*)y, group_of, dim));
   return check_launch("devo_upd_softagg");
+}
+
+int devo_upd_softagg_backward(const void* f, const void* g, int64_t ld_fg, const int* perm, const int* seg_start, const int* n_seg,
+                              const void* dy, void* df, void* dg, int64_t ld_d, int64_t E, int dim, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && dim > 0 && dim % 2 == 0 && ld_fg >= dim && ld_fg % 2 == 0 && ld_d >= dim && ld_d % 2 == 0,
+               "devo_upd_softagg_backward: bad sizes (dim and the row strides must be even)");
+  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(df) |
+                 reinterpret_cast<uintptr_t>(dg)) & 7) == 0, "devo_upd_softagg_backward: operands must be 8-byte aligned");
+  if (E == 0) return DEVO_OK;
+  hipStream_t st_ = (hipStream_t)stream;
+  const dim3 grid(grid_for(E * ((dim + 511) / 512), 1, 4096)), block(256);
+  UPD_DISPATCH(dtype,
+    hipLaunchKernelGGL(k_softagg_bwd<float>, grid, block, 0, st_, (const float*)f, (const float*)g, ld_fg, perm, seg_start, n_seg, (const float*)dy, (float*)df, (float*)dg, ld_d, dim),
+    hipLaunchKernelGGL(k_softagg_bwd<__half>, grid, block, 0, st_, (const __half*)f, (const __half*)g, ld_fg, perm, seg_start, n_seg, (const __half*)dy, (__half*)df, (__half*)dg, ld_d, dim));
+  return check_launch("devo_upd_softagg_backward");
 }
 
 int devo_upd_expand_add(void* net, const void* hy, const int* group_of, int64_t E, int dim, int dtype, devo_stream_t stream) {

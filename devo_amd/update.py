@@ -60,6 +60,13 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+def _linear(x2, w, b):
+    """x2 [rows, in] -> x2 wT + b through _LinearFn when that pays (see Linear.forward)"""
+    if torch.is_grad_enabled() and x2.is_cuda and x2.shape[0] >= 4096 and (x2.requires_grad or w.requires_grad):
+        return _LinearFn.apply(x2, w, b)
+    return torch.nn.functional.linear(x2, w, b)
+
+
 class Linear(nn.Linear):
     """nn.Linear (same parameters, same state-dict keys) whose backward over >= 4096 rows splits the weight-gradient product."""
 
@@ -95,6 +102,12 @@ class SoftAgg(nn.Module):                            # blocks.py:31-48 (expand=T
     def forward(self, x, ix, groups=None):           # torch composition (autograd path)
         """`groups` = (inverse, count) of torch.unique(ix): the caller may cache them per graph (the sort and the host read of the
         count are per call otherwise)"""
+        if isinstance(groups, _Groups):
+            # fp32 / fp16 on the GPU: f | g in ONE GEMM, the segment softmax-sum and its adjoint as HIP kernels, h, expand
+            B, E, C = x.shape
+            fg = _linear(x.reshape(E, C), torch.cat([self.f.weight, self.g.weight], 0), torch.cat([self.f.bias, self.g.bias], 0))
+            y = _SoftAggFn.apply(fg, groups)
+            return torch.index_select(self.h(y), 0, groups.group_of_long()).view(B, E, C)
         if groups is None:
             _, jx = torch.unique(ix, return_inverse=True)
             n = int(jx.max()) + 1
@@ -110,6 +123,34 @@ class SoftAgg(nn.Module):                            # blocks.py:31-48 (expand=T
         return torch.index_select(self.h(y), 1, jx)        # (index_select: its backward is an atomic index_add; `[:, jx]` sorts)
 
 
+class _SoftAggFn(torch.autograd.Function):
+    """y[s] = sum over the edges e of group s of f_e * softmax_s(g)_e (blocks.py:42-43) with the HIP kernels in both directions:
+    devo_upd_softagg / devo_upd_softagg_backward.  fg [E, 2 dim] = f | g (one GEMM); G: the group tables (_Groups)."""
+
+    @staticmethod
+    def forward(ctx, fg, G):
+        E, dim = fg.shape[0], fg.shape[1] // 2
+        fg = fg.contiguous()
+        y = torch.empty(G.n_seg, dim, dtype=fg.dtype, device=fg.device)
+        L.check(L.lib().devo_upd_softagg(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
+                                         L.ptr(y), None, E, dim, L.dtype_code(fg), L.stream()), "update.softagg")
+        ctx.save_for_backward(fg)
+        ctx.G = G
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        fg, = ctx.saved_tensors
+        G = ctx.G
+        E, dim = fg.shape[0], fg.shape[1] // 2
+        dy = dy.contiguous()
+        dfg = torch.empty_like(fg)                              # (every edge belongs to exactly one group: fully written)
+        L.check(L.lib().devo_upd_softagg_backward(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
+                                                  L.ptr(dy), L.ptr(dfg), L.ptr(dfg[:, dim:]), 2 * dim, E, dim, L.dtype_code(fg), L.stream()),
+                "update.softagg_backward")
+        return dfg, None
+
+
 class _Groups:
     """Edges grouped by an integer key, through the BA's index kernels: perm / seg_start / n_seg (+ group_of scratch)."""
 
@@ -123,6 +164,16 @@ class _Groups:
         self.n_seg_dev = torch.tensor([self.n_seg], dtype=torch.int32, device=key.device)
         self.seg_start = self.seg_start.contiguous()
         self.group_of = torch.empty(E, dtype=torch.int32, device=key.device)
+        self._group_of_long = None
+
+    def group_of_long(self):
+        """edge -> group index as int64 (for index_select in the training path), from the tables themselves"""
+        if self._group_of_long is None:
+            cnt = (self.seg_start[1:self.n_seg + 1] - self.seg_start[:self.n_seg]).long()
+            g = torch.empty(self.perm.numel(), dtype=torch.int64, device=self.perm.device)
+            g[self.perm.long()] = torch.repeat_interleave(torch.arange(self.n_seg, device=self.perm.device), cnt)
+            self._group_of_long = g
+        return self._group_of_long
 
 
 def _ln(x, mod, add1=None, add2=None, expand=None, gated=None, relu=False):
@@ -159,7 +210,10 @@ class Update(nn.Module):
         """enet.py:80-99 as a torch composition over GPU tensors (differentiable)."""
         net = net + inp + self.corr(corr)
         net = self.norm(net)
-        (ix, jx), gk, gp = self._torch_groups(ii, jj, kk)           # neighbours (HIP kernel) and group maps, cached per graph
+        if net.is_cuda and net.dtype in (torch.float32, torch.float16) and net.shape[0] == 1:
+            ix, jx, gk, gp = self._tables(ii, jj, kk)               # neighbours + HIP group tables, cached per graph
+        else:
+            (ix, jx), gk, gp = self._torch_groups(ii, jj, kk)       # ... + torch.unique group maps (any dtype / batch)
         mask_ix = (ix >= 0).to(net.dtype).reshape(1, -1, 1)
         mask_jx = (jx >= 0).to(net.dtype).reshape(1, -1, 1)
         # gathers with index_select (backward = atomic index_add; advanced indexing's backward sorts 18 000 indices: 0.43 ms each)

@@ -270,6 +270,12 @@ int devo_upd_softagg(const void* f, const void* g, int64_t ld_fg /* row stride o
                      const int* seg_start, const int* n_seg, void* y, int* group_of, int64_t E, int dim, int dtype,
                      devo_stream_t stream);
 
+/* Adjoint of devo_upd_softagg for training (the backward of blocks.py:42-43's scatter_softmax * f -> scatter_sum): dy [n_seg, dim] ->
+ * df, dg (rows of stride ld_d; every edge of every group is written):  d f_e = w_e dy,  d g_e = w_e dy (f_e - y),  w = softmax of g
+ * over the edge's group, channel-wise.  Same tables and alignment rules as devo_upd_softagg. */
+int devo_upd_softagg_backward(const void* f, const void* g, int64_t ld_fg, const int* perm, const int* seg_start, const int* n_seg,
+                              const void* dy, void* df, void* dg, int64_t ld_d, int64_t E, int dim, int dtype, devo_stream_t stream);
+
 /* net[e] += hy[group_of[e]]   — `net + h(y)[:, jx]` of blocks.py:46 / enet.py:93-94, in place. */
 int devo_upd_expand_add(void* net, const void* hy, const int* group_of, int64_t E, int dim, int dtype,
                         devo_stream_t stream);

@@ -175,3 +175,46 @@ def test_gradient_clip_backward_semantics():
     assert torch.equal(y, x)
     y.backward(torch.tensor([0.5, -0.5, float("nan"), 0.003], device=DEV))
     assert torch.equal(x.grad.cpu(), torch.tensor([0.01, -0.01, 0.0, 0.003]))
+
+
+def test_softagg_training_path_on_the_hip_kernels_matches_the_torch_composition():
+    """SoftAgg in the differentiable path (blocks.py:31-48): f | g in one GEMM, devo_upd_softagg / devo_upd_softagg_backward, h, expand —
+    against the torch composition (scatter_reduce amax / exp / scatter_add / gather) of the same module: output and the gradients of
+    the input and of all six parameter tensors; irregular groups (sizes 1 .. 40), an edge count that is no multiple of anything."""
+    from devo_amd.update import SoftAgg, _Groups
+    torch.manual_seed(3)
+    dim, E = 64, 4999
+    key = torch.randint(0, 700, (E,), device=DEV)
+    agg = SoftAgg(dim).to(DEV)
+    x0 = torch.randn(1, E, dim, device=DEV)
+    wgt = torch.randn(1, E, dim, device=DEV)
+    G = _Groups(key.long().contiguous())
+
+    def run(groups):
+        for q in agg.parameters():
+            q.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = agg(x, key, groups)
+        (y * wgt).sum().backward()
+        return [y.detach(), x.grad] + [q.grad.clone() for q in agg.parameters()]
+
+    a, b = run(G), run(None)
+    names = ["output", "d/dx"] + ["d/d" + n for n, _ in agg.named_parameters()]
+    scale = float(a[names.index("d/df.bias")].abs().max())
+    for u, v, n in zip(a, b, names):
+        if n == "d/dg.bias":                                      # softmax is shift-invariant inside a group: this gradient is exactly 0
+            assert float(u.abs().max()) <= 1e-4 * scale and float(v.abs().max()) <= 1e-4 * scale
+        else:
+            assert_rel(u, v, 2e-4, n)
+    # the whole operator: forward_torch on the HIP tables equals forward_torch on torch.unique maps (fp64 takes the latter)
+    from devo_amd.update import Update
+    n, M = 5, 6
+    ii, jj, kk = [t.to(DEV) for t in synth.full_graph(n, M)]
+    Eg = ii.numel()
+    up = Update(3, dim=32).to(DEV)
+    net = torch.randn(1, Eg, 32, device=DEV); inp = torch.randn(1, Eg, 32, device=DEV) * 0.1; corr = torch.randn(1, Eg, 882, device=DEV)
+    o32 = up.forward_torch(net, inp, corr, ii, jj, kk)
+    up64 = Update(3, dim=32).to(DEV).double(); up64.load_state_dict({k: v.double() for k, v in up.state_dict().items()})
+    o64 = up64.forward_torch(net.double(), inp.double(), corr.double(), ii, jj, kk)
+    assert_rel(o32[0], o64[0].float(), 1e-4, "net")
+    assert_rel(o32[1][0], o64[1][0].float(), 1e-3, "delta"); assert_rel(o32[1][1], o64[1][1].float(), 1e-4, "weight")

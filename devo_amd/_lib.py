@@ -51,6 +51,7 @@ _SIGNATURES.update({
     "devo_upd_softagg_backward": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp],
     "devo_upd_expand_add": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "devo_upd_gated_residual": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp],
+    "devo_upd_gated_residual_backward": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "devo_upd_heads": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
 })
 _SIGNATURES.update({

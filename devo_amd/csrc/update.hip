@@ -125,6 +125,21 @@ __global__ void k_masked_gather(const T* __restrict__ src, const int64_t* __rest
   }
 }
 
+// adjoint of out = x + sigmoid(gate) * res with respect to gate and res (d x = d out):  d gate = d out * res * s (1 - s),  d res = d out * s
+template <typename T>
+__global__ void k_gated_residual_bwd(const T* __restrict__ gate, int64_t ld_gate, const T* __restrict__ res, const T* __restrict__ dout,
+                                     T* __restrict__ dgate, T* __restrict__ dres, int64_t rows, int dim) {
+  const int64_t n = rows * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / dim;
+    const int c = (int)(i - r * dim);
+    const float sg = 1.0f / (1.0f + __expf(-ld(gate + r * ld_gate + c)));
+    const float d = ld(dout + i);
+    st(dgate + i, d * ld(res + i) * sg * (1.0f - sg));
+    st(dres + i, d * sg);
+  }
+}
+
 // SoftAgg reduction: for group s (edges perm[seg[s] .. seg[s+1])) and channel c
 //   y[s][c] = sum_e f[e][c] * exp(g[e][c] - max_e g[e][c]) / sum_e exp(g[e][c] - max)
 // ONE pass over the group's rows (online softmax: the running sums are rescaled when the maximum grows), one thread per
@@ -353,6 +368,18 @@ int devo_upd_gated_residual(const void* x, const void* gate, int64_t ld_gate, co
     hipLaunchKernelGGL(k_gated_residual<float>, grid, block, 0, st_, (const float*)x, (const float*)gate, ld_gate, (const float*)res, (float*)out, rows, dim),
     hipLaunchKernelGGL(k_gated_residual<__half>, grid, block, 0, st_, (const __half*)x, (const __half*)gate, ld_gate, (const __half*)res, (__half*)out, rows, dim));
   return check_launch("devo_upd_gated_residual");
+}
+
+int devo_upd_gated_residual_backward(const void* gate, int64_t ld_gate, const void* res, const void* dout, void* dgate, void* dres,
+                                     int64_t rows, int dim, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(rows >= 0 && dim > 0 && ld_gate >= dim, "devo_upd_gated_residual_backward: bad sizes");
+  if (rows == 0) return DEVO_OK;
+  hipStream_t st_ = (hipStream_t)stream;
+  const dim3 grid(grid_for(rows * dim, 256, 8192)), block(256);
+  UPD_DISPATCH(dtype,
+    hipLaunchKernelGGL(k_gated_residual_bwd<float>, grid, block, 0, st_, (const float*)gate, ld_gate, (const float*)res, (const float*)dout, (float*)dgate, (float*)dres, rows, dim),
+    hipLaunchKernelGGL(k_gated_residual_bwd<__half>, grid, block, 0, st_, (const __half*)gate, ld_gate, (const __half*)res, (const __half*)dout, (__half*)dgate, (__half*)dres, rows, dim));
+  return check_launch("devo_upd_gated_residual_backward");
 }
 
 int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void* res, void* net_out, const void* Wd, const void* bd,

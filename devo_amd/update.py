@@ -82,6 +82,58 @@ class GradientClip(nn.Module):                       # blocks.py:84-89
         return _GradClip.apply(x)
 
 
+class _GatedResidualFn(torch.autograd.Function):
+    """x + sigmoid(gate) * res, one HIP kernel per direction (devo_upd_gated_residual / _backward) instead of sigmoid, mul, add and
+    their five autograd kernels."""
+
+    @staticmethod
+    def forward(ctx, x, gate, res):
+        x, gate, res = x.contiguous(), gate.contiguous(), res.contiguous()
+        out = torch.empty_like(x)
+        rows, dim = x.numel() // x.shape[-1], x.shape[-1]
+        L.check(L.lib().devo_upd_gated_residual(L.ptr(x), L.ptr(gate), dim, L.ptr(res), L.ptr(out), rows, dim, L.dtype_code(x), L.stream()),
+                "update.gated_residual")
+        ctx.save_for_backward(gate, res)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gate, res = ctx.saved_tensors
+        g = g.contiguous()
+        dgate, dres = torch.empty_like(gate), torch.empty_like(res)
+        rows, dim = g.numel() // g.shape[-1], g.shape[-1]
+        L.check(L.lib().devo_upd_gated_residual_backward(L.ptr(gate), dim, L.ptr(res), L.ptr(g), L.ptr(dgate), L.ptr(dres), rows, dim,
+                                                         L.dtype_code(g), L.stream()), "update.gated_residual_backward")
+        return g, dgate, dres
+
+
+class _MaskedGatherFn(torch.autograd.Function):
+    """out[e] = src[idx[e]] where idx[e] >= 0, else 0 (`mask * net[:, ix]`, enet.py:87-91).  idx / inv are the previous- / next-edge
+    maps of `neighbors` (mutually inverse partial permutations), so the adjoint of the gather by idx is the gather by inv."""
+
+    @staticmethod
+    def forward(ctx, src, idx, inv):
+        ctx.save_for_backward(inv)
+        return _MaskedGatherFn._gather(src, idx)
+
+    @staticmethod
+    def _gather(src, idx):
+        src = src.contiguous()
+        out = torch.empty_like(src)
+        L.check(L.lib().devo_upd_masked_gather(L.ptr(src), L.ptr(idx), L.ptr(out), src.shape[0], src.shape[1], L.dtype_code(src), L.stream()),
+                "update.masked_gather")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        inv, = ctx.saved_tensors
+        return _MaskedGatherFn._gather(g, inv), None, None
+
+
+def _hip_ok(x):
+    return x.is_cuda and x.dtype in (torch.float32, torch.float16)
+
+
 class GatedResidual(nn.Module):                      # blocks.py:15-29
     def __init__(self, dim):
         super().__init__()
@@ -89,6 +141,8 @@ class GatedResidual(nn.Module):                      # blocks.py:15-29
         self.res = nn.Sequential(Linear(dim, dim), nn.ReLU(inplace=True), Linear(dim, dim))
 
     def forward(self, x):
+        if _hip_ok(x):
+            return _GatedResidualFn.apply(x, self.gate[0](x), self.res(x))
         return x + self.gate(x) * self.res(x)
 
 
@@ -217,8 +271,12 @@ class Update(nn.Module):
         mask_ix = (ix >= 0).to(net.dtype).reshape(1, -1, 1)
         mask_jx = (jx >= 0).to(net.dtype).reshape(1, -1, 1)
         # gathers with index_select (backward = atomic index_add; advanced indexing's backward sorts 18 000 indices: 0.43 ms each)
-        net = net + self.c1(mask_ix * torch.index_select(net, 1, ix.clamp(min=0)))
-        net = net + self.c2(mask_jx * torch.index_select(net, 1, jx.clamp(min=0)))
+        if _hip_ok(net) and net.shape[0] == 1:
+            net = net + self.c1(_MaskedGatherFn.apply(net[0], ix, jx)[None])       # one kernel per direction
+            net = net + self.c2(_MaskedGatherFn.apply(net[0], jx, ix)[None])
+        else:
+            net = net + self.c1(mask_ix * torch.index_select(net, 1, ix.clamp(min=0)))
+            net = net + self.c2(mask_jx * torch.index_select(net, 1, jx.clamp(min=0)))
         net = net + self.agg_kk(net, kk, gk)
         net = net + self.agg_ij(net, None, gp)          # groups of ii * 12345 + jj (enet.py:94)
         net = self.gru(net)

@@ -284,6 +284,11 @@ int devo_upd_expand_add(void* net, const void* hy, const int* group_of, int64_t 
 int devo_upd_gated_residual(const void* x, const void* gate, int64_t ld_gate /* row stride of gate */, const void* res,
                             void* out, int64_t rows, int dim, int dtype, devo_stream_t stream);
 
+/* Adjoint of devo_upd_gated_residual with respect to the gate pre-activation and res (d x = d out), training:
+ * d gate = d out * res * s (1 - s),  d res = d out * s,  s = sigmoid(gate).  dgate / dres contiguous [rows, dim]. */
+int devo_upd_gated_residual_backward(const void* gate, int64_t ld_gate, const void* res, const void* dout, void* dgate, void* dres,
+                                     int64_t rows, int dim, int dtype, devo_stream_t stream);
+
 /* net[e] = x[e] + sigmoid(gate[e]) * res[e] -> net_out (the last GatedResidual; gate == NULL: net = x, nothing stored),
  * then delta[e] = Wd relu(net[e]) + bd;  weight[e] = sigmoid(Ww relu(net[e]) + bw)   (Wd, Ww [2, dim]; enet.py:68-78). */
 int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void* res, void* net_out, const void* Wd,

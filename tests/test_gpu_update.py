@@ -213,8 +213,21 @@ def test_softagg_training_path_on_the_hip_kernels_matches_the_torch_composition(
     Eg = ii.numel()
     up = Update(3, dim=32).to(DEV)
     net = torch.randn(1, Eg, 32, device=DEV); inp = torch.randn(1, Eg, 32, device=DEV) * 0.1; corr = torch.randn(1, Eg, 882, device=DEV)
-    o32 = up.forward_torch(net, inp, corr, ii, jj, kk)
     up64 = Update(3, dim=32).to(DEV).double(); up64.load_state_dict({k: v.double() for k, v in up.state_dict().items()})
-    o64 = up64.forward_torch(net.double(), inp.double(), corr.double(), ii, jj, kk)
-    assert_rel(o32[0], o64[0].float(), 1e-4, "net")
-    assert_rel(o32[1][0], o64[1][0].float(), 1e-3, "delta"); assert_rel(o32[1][1], o64[1][1].float(), 1e-4, "weight")
+    wn = torch.randn(1, Eg, 32, device=DEV)
+
+    def run(mod, dt):
+        for q in mod.parameters():
+            q.grad = None
+        a, c = net.detach().to(dt).clone().requires_grad_(True), corr.detach().to(dt).clone().requires_grad_(True)
+        o = mod.forward_torch(a, inp.to(dt), c, ii, jj, kk)
+        ((o[0] * wn.to(dt)).sum() + o[1][0].sum() + o[1][1].sum()).backward()
+        return o, a.grad, c.grad, {k: q.grad for k, q in mod.named_parameters()}
+
+    (o32, ga32, gc32, gp32), (o64, ga64, gc64, gp64) = run(up, torch.float32), run(up64, torch.float64)
+    assert_rel(o32[0].detach(), o64[0].detach().float(), 1e-4, "net")
+    assert_rel(o32[1][0].detach(), o64[1][0].detach().float(), 1e-3, "delta"); assert_rel(o32[1][1].detach(), o64[1][1].detach().float(), 1e-4, "weight")
+    # gradients through the HIP autograd functions (gated residual, masked gather, SoftAgg, split-K Linear) vs the fp64 torch path
+    assert_rel(ga32, ga64.float(), 2e-3, "d/d net"); assert_rel(gc32, gc64.float(), 2e-3, "d/d corr")
+    for k in ("gru.1.gate.0.weight", "gru.3.res.2.weight", "c1.0.weight", "c2.2.bias", "agg_kk.f.weight", "agg_ij.h.weight", "norm.weight", "corr.0.weight"):
+        assert_rel(gp32[k], gp64[k].float(), 3e-3, "d/d " + k)

@@ -38,6 +38,8 @@ _SIGNATURES = {
     "devo_ba_solve_terms": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _sz, _vp, _vp, _vp, _vp],
     "devo_ba_solve_terms_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp],
     "devo_transform_vjp": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "devo_ba_edge_terms": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "devo_ba_edge_terms_backward": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "devo_neighbors_workspace_bytes": [_i],
     "devo_ba_neighbors": [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp],
     "devo_ba_reproject": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -54,11 +54,45 @@ class _FusedSolve(torch.autograd.Function):
         return g, None, None, None, None, None, None, None, None
 
 
+class _EdgeTerms(torch.autograd.Function):
+    """devo/ba.py:95-106 (residual, gates, the Jacobian blocks packed for the solve) in one HIP kernel per direction instead of ~15
+    elementwise kernels and their adjoints (devo_ba_edge_terms / _backward).  The gate is piecewise constant: no gradient through it."""
+
+    @staticmethod
+    def forward(ctx, coords, valid, Ji, Jj, Jz, targets, weights, bounds):
+        from .backends import cuda_ba
+        terms, gate = cuda_ba.edge_terms(coords, valid, Ji, Jj, Jz, targets, weights, bounds)
+        ctx.save_for_backward(gate)
+        ctx.P = coords.shape[2]
+        return terms
+
+    @staticmethod
+    def backward(ctx, g):
+        from .backends import cuda_ba
+        gate, = ctx.saved_tensors
+        gc, gt, gw, gi, gj, gz = cuda_ba.edge_terms_backward(g, gate, ctx.P)
+        return gc, None, gi, gj, gz, gt, gw, None
+
+
 def _fused_path(patches, lmbda, n):
     import os
     per_patch = isinstance(lmbda, torch.Tensor) and lmbda.numel() > 1
     return (patches.is_cuda and patches.dtype == torch.float32 and not per_patch and n <= 32 and patches.shape[0] == 1
             and os.environ.get("DEVO_BA_TORCH", "0") != "1")
+
+
+def _fused_step(poses, patches, terms, lmbda, ii, jj, kk, fixedp, n_opt, ep):
+    """solve (HIP, differentiable) + depth update / clamp + pose retraction (devo/ba.py:159-182)"""
+    dev, dt = patches.device, patches.dtype
+    lm = lmbda.reshape(1).to(dev, torch.float32) if isinstance(lmbda, torch.Tensor) else torch.full((1,), float(lmbda), dtype=torch.float32, device=dev)
+    dX, dZ = _FusedSolve.apply(terms, lm, ii, jj, kk, patches.shape[1], fixedp, n_opt, float(ep))
+    disp = patches[:, :, 2] + dZ.view(1, -1, 1, 1)
+    patches = torch.stack([patches[:, :, 0], patches[:, :, 1], disp.clamp(min=1e-3, max=10.0)], dim=2)
+    if n_opt > 0:
+        upd = torch.zeros(1, poses.data.shape[1], 6, dtype=dt, device=dev)
+        upd[:, fixedp:fixedp + n_opt] = dX.view(1, n_opt, 6)
+        poses = poses.retr(upd)
+    return poses, patches
 
 
 def BA(poses, patches, intrinsics, targets, weights, lmbda, ii, jj, kk, bounds, ep=100.0, PRINT=False,
@@ -70,6 +104,11 @@ def BA(poses, patches, intrinsics, targets, weights, lmbda, ii, jj, kk, bounds, 
         n_frames = int(torch.maximum(ii.max(), jj.max())) + 1
     n = int(n_frames) - fixedp
     coords, ok, (Ji, Jj, Jz) = pops.transform(poses, patches, intrinsics, ii, jj, kk, jacobian=True)
+    if _fused_path(patches, lmbda, max(n, 0)) and not PRINT and coords.shape[-1] == 2 and targets.dtype == torch.float32:
+        # fp32 on the GPU: edge terms, system + solve and their adjoints in HIP (DEVO_BA_TORCH=1 keeps the torch composition below)
+        E, n_opt = ii.numel(), (0 if structure_only else max(n, 0))
+        terms = _EdgeTerms.apply(coords, ok, Ji, Jj, Jz, targets, weights, [float(b) for b in bounds])
+        return _fused_step(poses, patches, terms, lmbda, ii, jj, kk, fixedp, n_opt, ep)
     c = coords.shape[3] // 2
     ctr = coords[0, :, c, c, :]
     r = targets[0] - ctr
@@ -86,15 +125,7 @@ def BA(poses, patches, intrinsics, targets, weights, lmbda, ii, jj, kk, bounds, 
         # fp32 on the GPU: system + solve + adjoint in HIP (DEVO_BA_TORCH=1 keeps the torch composition below)
         E, n_opt = ii.numel(), (0 if structure_only else max(n, 0))
         terms = torch.cat([r, w, Jz, (-Ji).reshape(E, 12), Jj.reshape(E, 12)], dim=1)      # Ji enters the kernels as -d coords / d xi_i
-        lm = lmbda.reshape(1).to(dev, torch.float32) if isinstance(lmbda, torch.Tensor) else torch.full((1,), float(lmbda), dtype=torch.float32, device=dev)
-        dX, dZ = _FusedSolve.apply(terms, lm, ii, jj, kk, patches.shape[1], fixedp, n_opt, float(ep))
-        disp = patches[:, :, 2] + dZ.view(1, -1, 1, 1)
-        patches = torch.stack([patches[:, :, 0], patches[:, :, 1], disp.clamp(min=1e-3, max=10.0)], dim=2)
-        if n_opt > 0:
-            upd = torch.zeros(1, poses.data.shape[1], 6, dtype=dt, device=dev)
-            upd[:, fixedp:fixedp + n_opt] = dX.view(1, n_opt, 6)
-            poses = poses.retr(upd)
-        return poses, patches
+        return _fused_step(poses, patches, terms, lmbda, ii, jj, kk, fixedp, n_opt, ep)
 
     # Patches: the reference compacts to the patches that have edges (torch.unique, ba.py:104).  Working on ALL patch
     # slots instead gives the same update (a slot without edges has C = u = 0 and a zero column of E, hence dZ = 0) and

@@ -1,6 +1,7 @@
 """HIP-backed module with the interface of the reference's `cuda_ba` extension (devo/fastba/ba.cpp:152-157):
 forward (in-place bundle adjustment), neighbors, reproject — plus `transform`, the fused form of
 devo/projective_ops.py:53-105 that DEVO.update really calls.  No CPU fallback."""
+import ctypes
 import torch
 from .. import _lib as L
 
@@ -216,6 +217,33 @@ def solve_terms_backward(terms, ii, jj, kk, n_patch_slots, t0, n_opt, ws, g_dX, 
                                               ws.numel(), L.ptr(g_dX), L.ptr(g_dZ), L.ptr(g), L.stream())
     L.check(rc, "cuda_ba.solve_terms_backward")
     return g
+
+
+def edge_terms(coords, valid, Ji, Jj, Jz, target, weight, bounds):
+    """devo_ba_edge_terms (devo/ba.py:95-106): transform's outputs + targets / weights / bounds -> (terms [E,30], gate [E])"""
+    L.require_gpu(coords, valid, Ji, Jj, Jz, target, weight)
+    E, P = coords.shape[1], coords.shape[2]
+    c = lambda t: t.float().contiguous()
+    coords, valid, Ji, Jj, Jz, target, weight = (c(t) for t in (coords, valid, Ji, Jj, Jz, target, weight))
+    terms = torch.empty(E, 30, dtype=torch.float32, device=coords.device)
+    gate = torch.empty(E, dtype=torch.float32, device=coords.device)
+    b = (ctypes.c_float * 4)(*[float(v) for v in bounds])
+    rc = L.lib().devo_ba_edge_terms(L.ptr(coords), L.ptr(valid), L.ptr(Ji), L.ptr(Jj), L.ptr(Jz), L.ptr(target), L.ptr(weight), b, E, P,
+                                    L.ptr(terms), L.ptr(gate), L.stream())
+    L.check(rc, "cuda_ba.edge_terms")
+    return terms, gate
+
+
+def edge_terms_backward(g_terms, gate, P):
+    """devo_ba_edge_terms_backward -> (g_coords [1,E,P,P,2], g_target [1,E,2], g_weight [1,E,2], g_Ji [1,E,2,6], g_Jj [1,E,2,6], g_Jz [1,E,2,1])"""
+    E, dev = gate.numel(), gate.device
+    g_terms = g_terms.float().contiguous()
+    new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    gc, gt, gw, gi, gj, gz = new(1, E, P, P, 2), new(1, E, 2), new(1, E, 2), new(1, E, 2, 6), new(1, E, 2, 6), new(1, E, 2, 1)
+    rc = L.lib().devo_ba_edge_terms_backward(L.ptr(g_terms), L.ptr(gate), E, int(P), L.ptr(gc), L.ptr(gt), L.ptr(gw), L.ptr(gi), L.ptr(gj), L.ptr(gz),
+                                             L.stream())
+    L.check(rc, "cuda_ba.edge_terms_backward")
+    return gc, gt, gw, gi, gj, gz
 
 
 def transform_vjp(poses, patches, intrinsics, ii, jj, kk, g_coords, g_J, depth=False, tonly=False):

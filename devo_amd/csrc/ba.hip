@@ -2072,6 +2072,71 @@ int devo_transform(const float* poses, const float* patches, const float* intrin
 }
 
 
+// devo/ba.py:95-106 in one kernel (training): the 30 per-edge numbers devo_ba_solve_terms takes, from transform's outputs.
+//   r = gate * (target - centre),  w = gate * weight,  gate = valid * [|target - centre| < 250] * [centre inside bounds]
+//   terms[e] = r(2) | w(2) | Jz(2) | -Ji(12) | Jj(12)
+// and its adjoint (the gate is piecewise constant): d target = gate * g_r, d centre = -gate * g_r (written into the centre pixel of a
+// zeroed coordinate cotangent), d weight = gate * g_w, d Jz = g_Jz, d Ji = -g_Ji, d Jj = g_Jj.
+__global__ void k_ba_edge_terms(const float* __restrict__ coords, const float* __restrict__ valid, const float* __restrict__ Ji,
+                                const float* __restrict__ Jj, const float* __restrict__ Jz, const float* __restrict__ target,
+                                const float* __restrict__ weight, float b0, float b1, float b2, float b3, int E, int P,
+                                float* __restrict__ terms, float* __restrict__ gate_out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int c = P / 2;
+  const float* ctr = coords + ((int64_t)(e * P + c) * P + c) * 2;
+  const float cx = ctr[0], cy = ctr[1];
+  const float rx = target[2 * e] - cx, ry = target[2 * e + 1] - cy;
+  float gate = valid[e];
+  gate *= (sqrtf(rx * rx + ry * ry) < 250.0f) ? 1.0f : 0.0f;
+  gate *= (cx > b0 && cy > b1 && cx < b2 && cy < b3) ? 1.0f : 0.0f;
+  float* t = terms + (int64_t)e * 30;
+  t[0] = gate * rx; t[1] = gate * ry;
+  t[2] = gate * weight[2 * e]; t[3] = gate * weight[2 * e + 1];
+  t[4] = Jz[2 * e]; t[5] = Jz[2 * e + 1];
+#pragma unroll
+  for (int q = 0; q < 12; q++) { t[6 + q] = -Ji[12 * (int64_t)e + q]; t[18 + q] = Jj[12 * (int64_t)e + q]; }
+  gate_out[e] = gate;
+}
+
+__global__ void k_ba_edge_terms_bwd(const float* __restrict__ g_terms, const float* __restrict__ gate, int E, int P,
+                                    float* __restrict__ g_coords /* zeroed */, float* __restrict__ g_target, float* __restrict__ g_weight,
+                                    float* __restrict__ g_Ji, float* __restrict__ g_Jj, float* __restrict__ g_Jz) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int c = P / 2;
+  const float* g = g_terms + (int64_t)e * 30;
+  const float gt = gate[e];
+  const float grx = gt * g[0], gry = gt * g[1];
+  g_target[2 * e] = grx; g_target[2 * e + 1] = gry;
+  float* gc = g_coords + ((int64_t)(e * P + c) * P + c) * 2;
+  gc[0] = -grx; gc[1] = -gry;
+  g_weight[2 * e] = gt * g[2]; g_weight[2 * e + 1] = gt * g[3];
+  g_Jz[2 * e] = g[4]; g_Jz[2 * e + 1] = g[5];
+#pragma unroll
+  for (int q = 0; q < 12; q++) { g_Ji[12 * (int64_t)e + q] = -g[6 + q]; g_Jj[12 * (int64_t)e + q] = g[18 + q]; }
+}
+
+int devo_ba_edge_terms(const float* coords, const float* valid, const float* Ji, const float* Jj, const float* Jz, const float* target,
+                       const float* weight, const float* bounds /* host, 4 */, int E, int P, float* terms, float* gate, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && P > 0 && bounds != nullptr, "devo_ba_edge_terms: bad arguments");
+  if (E == 0) return DEVO_OK;
+  hipLaunchKernelGGL(k_ba_edge_terms, dim3(blocks_for(E, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, coords, valid, Ji, Jj, Jz, target, weight,
+                     bounds[0], bounds[1], bounds[2], bounds[3], E, P, terms, gate);
+  return check_launch("devo_ba_edge_terms");
+}
+
+int devo_ba_edge_terms_backward(const float* g_terms, const float* gate, int E, int P, float* g_coords, float* g_target, float* g_weight,
+                                float* g_Ji, float* g_Jj, float* g_Jz, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && P > 0, "devo_ba_edge_terms_backward: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(g_coords, 0, sizeof(float) * 2 * (size_t)E * P * P, st) != hipSuccess) { set_error("devo_ba_edge_terms_backward: memset failed"); return DEVO_ERR_LAUNCH; }
+  if (E == 0) return DEVO_OK;
+  hipLaunchKernelGGL(k_ba_edge_terms_bwd, dim3(blocks_for(E, 256, 1 << 20)), dim3(256), 0, st, g_terms, gate, E, P, g_coords, g_target, g_weight, g_Ji,
+                     g_Jj, g_Jz);
+  return check_launch("devo_ba_edge_terms_backward");
+}
+
 int devo_transform_vjp(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii, const int64_t* jj,
                        const int64_t* kk, const float* g_coords, const float* g_Ji, const float* g_Jj, const float* g_Jz, int E,
                        int Nbuf, int Np, int P, int flags, float* g_poses, float* g_patches, devo_stream_t stream) {

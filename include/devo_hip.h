@@ -178,6 +178,16 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
 int devo_ba_solve_terms_backward(const float* terms, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Np, int t0, int N, void* ws,
                                  size_t ws_bytes, const float* g_dX, const float* g_dZ, float* g_terms, devo_stream_t stream);
 
+/* devo/ba.py:95-106 for the differentiable BA (training): residuals, gate and the 30 per-edge numbers of devo_ba_solve_terms from
+ * the outputs of devo_transform(jacobian): coords [E,P,P,2], valid [E], Ji / Jj [E,2,6], Jz [E,2], target / weight [E,2], bounds (host:
+ * x0, y0, x1, y1) -> terms [E,30] = r | w | Jz | -Ji | Jj and the gate [E] (kept for the adjoint). */
+int devo_ba_edge_terms(const float* coords, const float* valid, const float* Ji, const float* Jj, const float* Jz, const float* target,
+                       const float* weight, const float* bounds /* host, 4 */, int E, int P, float* terms, float* gate, devo_stream_t stream);
+/* its adjoint: g_terms [E,30] -> g_coords [E,P,P,2] (zeroed here; only the centre pixel carries gradient), g_target, g_weight [E,2],
+ * g_Ji, g_Jj [E,2,6], g_Jz [E,2]. */
+int devo_ba_edge_terms_backward(const float* g_terms, const float* gate, int E, int P, float* g_coords, float* g_target, float* g_weight,
+                                float* g_Ji, float* g_Jj, float* g_Jz, devo_stream_t stream);
+
 /* Adjoint of devo_transform (what autograd derives for devo/projective_ops.py:53-105, second-order terms of the Jacobians
  * included): cotangents of the coordinates g_coords f32 [E,P,P,2|3] ("pp2" layout; NULL = none) and of the centre pixel's
  * Jacobians g_Ji / g_Jj f32 [E,2,6], g_Jz f32 [E,2] (NULL = none) -> g_poses f32 [Nbuf,7] (6-vector of the left perturbation

@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""What MIOpen's solver search costs the FIRST forward + backward of the Patchifier (15 voxel grids 480 x 640) on a fresh box, and the
+steady-state step after it.  MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR pointing at empty directories show the cold cost (121 s);
+the defaults set by devo_amd.patchifier use the DB shipped in devo_amd/miopen_db (0.5 s).   python tools/miopen_first_call.py"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch

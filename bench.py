@@ -213,6 +213,14 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
             cuda_corr.forward_pyramid(d["gmap"], d["pyramid"], coords, d["kk"], d["jj"], R, (1, 4), out=corr_out, order=order)
 
     prep_stream = torch.cuda.Stream() if args.overlap_prepare else None
+    probe = {"on": False, "ev": []}          # eager steps after the timed region record HIP events around the lookup launch(es)
+
+    def lookup_probed(coords, order=None):
+        if not probe["on"]:
+            return lookup(coords, order=order)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); lookup(coords, order=order); b.record()
+        probe["ev"].append((a, b))
 
     def step():
         cur = torch.cuda.current_stream()
@@ -231,7 +239,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         else:
             # the plan's ordering step and the BA's index preparation (both single-workgroup, independent) in ONE launch
             cuda_ba.prepare(d["kk"], Np, n - 1, ws, plan=(order, n, cfg["H"]))
-        lookup(coords, order=order)
+        lookup_probed(coords, order=order)
         if not (args.separate_target or args.separate_index_kernels or prep_stream is not None):
             # devo.py:330 (target = centre of the reprojected patch + delta) formed inside the BA: same fp32 addition
             cuda_ba.forward_delta(d["poses"], d["patches"], d["intr"], coords, d["delta"], d["weight"], d["lmbda"],
@@ -325,7 +333,27 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         ev0.record(); kgraph.replay(); ev1.record()
     torch.cuda.synchronize()
     launches = (1 if args.fuse_levels else 2) * args.kernel_reps
-    t_launch = ev0.elapsed_time(ev1) * 1e-3 / launches                      # s per launch
+    t_back_to_back = ev0.elapsed_time(ev1) * 1e-3 / launches                # s per launch, lookups only, back to back
+    # ... and the same launch where the timed region runs it: inside the step, between the reprojection / index kernels and the BA
+    # (HIP events around the lookup of eager steps).  This is the figure rocprofv3's per-kernel average of this command is made of
+    # (the step's launches outnumber the ones above), and it is the lower one: a lookup that follows another lookup starts while
+    # the 96 MB output of its predecessor is still draining.
+    probe["on"] = True
+    for _ in range(args.kernel_reps):
+        step()
+    torch.cuda.synchronize()
+    probe["on"] = False
+    t_in_step = sum(a.elapsed_time(b) for a, b in probe["ev"]) * 1e-3 / max(1, len(probe["ev"])) / (1 if args.fuse_levels else 2)
+    # what an event pair costs by itself (nothing between the two records), measured the same way and subtracted
+    empty = []
+    for _ in range(args.kernel_reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        step_prefix = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")   # (a kernel in front, as in the step)
+        a.record(); b.record()
+        empty.append((a, b))
+    torch.cuda.synchronize()
+    t_event_pair = sum(a.elapsed_time(b) for a, b in empty) * 1e-3 / len(empty)
+    t_launch = max(t_in_step - t_event_pair / (1 if args.fuse_levels else 2), 0.5 * t_in_step)
     b_alg = alg_bytes(cfg, E, 4 if dtype == torch.float32 else 2) / (1.0 if args.fuse_levels else 2.0)   # bytes per launch
     achieved = b_alg / t_launch / 1e9
     f_alg = 2.0 * cfg["C"] * E * 9 * (2 * R + 2) ** 2 * (2.0 if args.fuse_levels else 1.0)    # flops per launch
@@ -382,7 +410,9 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
                      # 157.3 TFLOP/s (vector FMA and fp32 MFMA alike); t_min = max(B_alg / HBM peak, F_alg / fp32 peak)
                      "alg_gflop_per_launch": round(f_alg / 1e9, 3), "achieved_tflops": round(f_alg / t_launch / 1e12, 2),
                      "t_min_us": round(max(b_alg / (HBM_PEAK_GBS * 1e9), f_alg / 157.3e12) * 1e6, 1),
-                     "alg_bytes_per_launch": int(b_alg), "us_per_launch": round(t_launch * 1e6, 2)},
+                     "alg_bytes_per_launch": int(b_alg), "us_per_launch": round(t_launch * 1e6, 2),
+                     "us_per_launch_back_to_back": round(t_back_to_back * 1e6, 2), "event_pair_us": round(t_event_pair * 1e6, 2),
+                     "timing": "HIP events around the lookup launch inside the step (eager steps after the timed region), minus the cost of an empty event pair; back_to_back = lookups only, replayed from a graph"},
         "ba": {"gpu_ms": round(t_ba_gpu * 1e3, 4)},
     }
 

@@ -88,6 +88,14 @@ def test_patchifier_forward_matches_the_reference_module():
     x, y = patches[0, :, 0, 1, 1].long(), patches[0, :, 1, 1, 1].long()
     assert torch.allclose(patches[0, :, 2, 1, 1], disps[0, index, y, x])
     assert torch.allclose(gmap[0, :, :, 1, 1], fmap[0, index, :, y, x], atol=1e-6)
+    # DEVO's default evaluation selection (config/default.yaml: 'multi' on a 2 x 2 grid): stochastic — shapes, ranges, one patch set per frame
+    torch.manual_seed(11)
+    with torch.no_grad():
+        f2, g2, i2, p2, idx2 = pf(images, patches_per_image=8)
+    assert g2.shape == (1, 16, 16, 3, 3) and i2.shape == (1, 16, 24, 1, 1) and p2.shape == (1, 16, 3, 3, 3)
+    cx, cy = p2[0, :, 0, 1, 1], p2[0, :, 1, 1, 1]
+    assert float(cx.min()) >= 1 and float(cx.max()) <= 16 - 2 and float(cy.min()) >= 1 and float(cy.max()) <= 12 - 2
+    assert torch.equal(idx2.cpu(), torch.arange(2).repeat_interleave(8))
     # both lookup levels in the kernel's layout, one pass
     l0, l1 = pf.pyramid(fmap)
     from devo_amd import altcorr

@@ -204,7 +204,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
     def lookup(coords, order=None):
         if not args.fuse_levels:
             if order is None:
-                order = cuda_corr.plan(coords, d["jj"], n, cfg["H"])            # locality plan, shared by both levels
+                order = cuda_corr.plan(coords, d["jj"], n, cfg["H"], radius=R)            # locality plan, shared by both levels
             for lvl, (fm, s) in enumerate(zip(d["pyramid"], (1, 4))):
                 cuda_corr.forward_into(corr_out, d["gmap"], fm, coords, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order,
                                        coord_div=float(s))                   # the kernel looks up at coords / s
@@ -310,7 +310,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         lookup(coords)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     # only the lookup kernels sit between the events
-    order = cuda_corr.plan(coords, d["jj"], n, cfg["H"])
+    order = cuda_corr.plan(coords, d["jj"], n, cfg["H"], radius=R)
     torch.cuda.synchronize()
 
     def lookups():

@@ -1028,7 +1028,24 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
     // DEVO_MFMA_EPW edges (waves) per workgroup; grids are whole groups of 8 workgroups (one per XCD)
     const unsigned wg_level = (unsigned)(((BE + DEVO_MFMA_EPW - 1) / DEVO_MFMA_EPW + 7) / 8 * 8);
     const dim3 mgrid(DEVO_MFMA_EPW == 1 ? (both ? (unsigned)BE : per_level * nlev) : (both || nlev == 1 ? wg_level : wg_level * 2)), mblock(64 * DEVO_MFMA_EPW);
-    hipLaunchKernelGGL(fn, mgrid, mblock, 0, st, (const MT*)fmap1, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2,
+    // Waves per CU: the kernel's registers allow 16.  Every resident wave streams its edge's boxes through the XCD's 4 MB L2, and
+    // plan neighbours share them: when the boxes of all resident waves together overrun the L2 (large radius, dense patch graph:
+    // BASELINE's stress configuration) the shared lines are evicted before the neighbour asks for them and the kernel becomes
+    // HBM-bound on re-reads.  An unused dynamic LDS allocation caps the resident waves (DEVO_MFMA_WAVES_PER_CU overrides).
+    size_t occ_pad = 0;
+    {
+      static const char* occ_env = getenv("DEVO_MFMA_WAVES_PER_CU");
+      int occ = occ_env ? atoi(occ_env) : 0;
+      if (occ > 0 && occ < 16) {
+        const size_t per_wg = (size_t)(160 * 1024) / (size_t)occ;
+        const size_t stat = 10 * 1024;                                   // (static LDS of one wave's workgroup, rounded up)
+        occ_pad = per_wg > stat + 512 ? ((per_wg - stat) / 512) * 512 : 0;
+        if (occ_pad > 64 * 1024 - stat) {
+          if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)occ_pad) != hipSuccess) { (void)hipGetLastError(); occ_pad = 64 * 1024 - stat; }
+        }
+      }
+    }
+    hipLaunchKernelGGL(fn, mgrid, mblock, occ_pad, st, (const MT*)fmap1, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2,
                        C, oes, ols, R, order, trace);
   } else
   if (!(lv0.staged_ok && (nlev == 1 || lv1.staged_ok))) {

@@ -26,6 +26,9 @@ __host__ __device__ __forceinline__ bool tile_fits(int w, int h, int ng) {
 }
 
 
+constexpr int CORR_PLAN_BB = 4;                     // bands per block of the plan's bin numbering (4 x 16 rows)
+__host__ __device__ __forceinline__ int corr_plan_bx(int xw) { const int b = 64 / (xw > 0 ? xw : 64); return b < 1 ? 1 : b; }   // column bins per block
+
 // Plan bin of an edge from its 9 window origins: -1 = HEAVY (the union box does not fit the tile), else
 // (batch, target frame, 16-row band of the patch centre, column bin of the patch centre) — consecutive edges of the sorted
 // plan land next to each other in the image, which is what the region-staged lookup kernel (corr_dense.h) groups on.
@@ -37,15 +40,23 @@ __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float c
   int xlo = x[0], xhi = x[0], ylo = y[0], yhi = y[0];
 #pragma unroll
   for (int p = 1; p < 9; p++) { xlo = min(xlo, x[p]); xhi = max(xhi, x[p]); ylo = min(ylo, y[p]); yhi = max(yhi, y[p]); }
-  // HEAVY = more than two 64-position passes of the matrix-core kernel (which includes every box the staged kernel's tile
-  // cannot hold): the long items start first
-  if ((long long)(xhi - xlo + D) * (yhi - ylo + D) > 128 || !tile_fits(xhi - xlo + D, yhi - ylo + D, ng)) return -1;
+  // HEAVY = clearly more passes of the matrix-core kernel than a compact patch needs at this radius — more than two 64-position
+  // passes for r <= 3, more than four for r <= 5 (a compact r = 5 box is 14 x 14 = 196 positions: with the r <= 3 threshold EVERY
+  // edge of BASELINE's stress configuration was HEAVY, i.e. unsorted, and its lookup ran at half speed) — which includes every
+  // box the staged kernel's tile cannot hold: the long items start first
+  if ((long long)(xhi - xlo + D) * (yhi - ylo + D) > (ng == 1 ? 128 : 256) || !tile_fits(xhi - xlo + D, yhi - ylo + D, ng)) return -1;
   int band = (int)(fminf(fmaxf(centre_y, 0.0f), (float)(H2 - 1))) / DEVO_PLAN_BAND;
   band = min(max(band, 0), nb - 1);
   int xb = (int)(fminf(fmaxf(centre_x, 0.0f), 1.0e6f)) / xw;
   xb = min(max(xb, 0), nxb - 1);
   const int f = min(max(frame, 0), n2 - 1);
-  return ((b * n2 + f) * nb + band) * nxb + xb;
+  // Bins are numbered block by block (CORR_PLAN_BB bands x enough column bins for ~64 px), so that consecutive plan slots — the
+  // edges one XCD works on at the same time — cover a compact 2-D tile of the frame instead of a strip as wide as the frame: the
+  // same number of edges then touches fewer distinct rows + margins of the pyramid (stress configuration: 2.8 MB instead of 4.4 MB
+  // for 512 edges, against 4 MB of L2 per XCD).
+  const int bx = corr_plan_bx(xw), nbx = (nxb + bx - 1) / bx, nbb = (nb + CORR_PLAN_BB - 1) / CORR_PLAN_BB;
+  const int in_frame = ((band / CORR_PLAN_BB) * nbx + xb / bx) * (CORR_PLAN_BB * bx) + (band % CORR_PLAN_BB) * bx + (xb % bx);
+  return (b * n2 + f) * (nbb * nbx * CORR_PLAN_BB * bx) + in_frame;
 }
 
 // Bins of the plan: row bands of 16 rows per frame (coarser if there are many frames: the counting sort keeps one LDS
@@ -53,23 +64,26 @@ __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float c
 // nxb * xw share the last bin; widths up to 2 * H2 are covered).  nb == 0 = too many frames.
 constexpr int CORR_ORDER_MAXBINS = 4096;        // (one LDS counter per bin next to the ordering kernel's staging buffer)
 struct CorrPlanGeom { int nb, nxb, xw; };
+inline long long corr_plan_bins_per_frame(const CorrPlanGeom& g) {
+  const int bx = corr_plan_bx(g.xw), nbx = (g.nxb + bx - 1) / bx, nbb = (g.nb + CORR_PLAN_BB - 1) / CORR_PLAN_BB;
+  return (long long)nbb * nbx * CORR_PLAN_BB * bx;         // (whole blocks: a little more than nb * nxb)
+}
 inline CorrPlanGeom corr_plan_geom(long long B, int n2, int H2) {
   CorrPlanGeom g{(H2 + DEVO_PLAN_BAND - 1) / DEVO_PLAN_BAND, 1, 8};
-  while (B * n2 * g.nb > CORR_ORDER_MAXBINS && g.nb > 1) g.nb = (g.nb + 1) / 2;
-  if (B * n2 * g.nb > CORR_ORDER_MAXBINS || g.nb > 255) { g.nb = 0; return g; }
-  long long nx = CORR_ORDER_MAXBINS / (B * n2 * g.nb);
+  while (B * n2 * ((g.nb + CORR_PLAN_BB - 1) / CORR_PLAN_BB * CORR_PLAN_BB) > CORR_ORDER_MAXBINS && g.nb > 1) g.nb = (g.nb + 1) / 2;
+  if (B * n2 * ((g.nb + CORR_PLAN_BB - 1) / CORR_PLAN_BB * CORR_PLAN_BB) > CORR_ORDER_MAXBINS || g.nb > 255) { g.nb = 0; return g; }
   const int want = (2 * H2 + 7) / 8;                      // 8-px columns across a 2:1 frame
-  if (nx > want) nx = want;
-  if (nx > 255) nx = 255;
-  if (nx < 1) nx = 1;
-  g.nxb = (int)nx;
-  int xw = (2 * H2 + g.nxb - 1) / g.nxb;
-  xw = (xw + 3) / 4 * 4;
-  g.xw = xw < 8 ? 8 : (xw > 32764 ? 32764 : xw);
+  for (int nx = want > 255 ? 255 : want; nx >= 1; nx--) {  // the most column bins whose block-padded count still fits
+    g.nxb = nx;
+    int xw = (2 * H2 + nx - 1) / nx;
+    xw = (xw + 3) / 4 * 4;
+    g.xw = xw < 8 ? 8 : (xw > 32764 ? 32764 : xw);
+    if (B * n2 * corr_plan_bins_per_frame(g) <= CORR_ORDER_MAXBINS) break;
+  }
   return g;
 }
 inline int corr_plan_pack(const CorrPlanGeom& g) { return g.nb | (g.nxb << 8) | (g.xw << 16); }
-inline long long corr_plan_nbins(long long B, int n2, const CorrPlanGeom& g) { return B * n2 * g.nb * g.nxb; }
+inline long long corr_plan_nbins(long long B, int n2, const CorrPlanGeom& g) { return B * n2 * corr_plan_bins_per_frame(g); }
 
 // Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS round trips like ds_bpermute shuffles):
 // Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8; lanes without a source add 0), then the last lane of row 0 / 2

@@ -26,8 +26,14 @@ __host__ __device__ __forceinline__ bool tile_fits(int w, int h, int ng) {
 }
 
 
-constexpr int CORR_PLAN_BB = 4;                     // bands per block of the plan's bin numbering (4 x 16 rows)
-__host__ __device__ __forceinline__ int corr_plan_bx(int xw) { const int b = 64 / (xw > 0 ? xw : 64); return b < 1 ? 1 : b; }   // column bins per block
+#ifndef DEVO_PLAN_BLOCKS
+#define DEVO_PLAN_BLOCKS 1                          // 0: number the bins band by band (A/B builds)
+#endif
+constexpr int CORR_PLAN_BB = DEVO_PLAN_BLOCKS ? 4 : 1;   // bands per block of the plan's bin numbering (4 x 16 rows)
+__host__ __device__ __forceinline__ int corr_plan_bx(int xw) {   // column bins per block (~64 px)
+  const int b = DEVO_PLAN_BLOCKS ? 64 / (xw > 0 ? xw : 64) : 1;
+  return b < 1 ? 1 : b;
+}
 
 // Plan bin of an edge from its 9 window origins: -1 = HEAVY (the union box does not fit the tile), else
 // (batch, target frame, 16-row band of the patch centre, column bin of the patch centre) — consecutive edges of the sorted

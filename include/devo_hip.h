@@ -69,10 +69,12 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
 
 /* Locality plan for devo_corr_forward (no reference counterpart: the reference walks edges in list order).
  * order i32 [2*B*E + 1] (the plan buffer; devo_corr_forward reads the first B*E + 1 entries, the rest is scratch
- * of this call): first the HEAVY edge slots (union box of the 9 windows larger than the kernel's LDS tile:
- * they run 2-4x longer and should start first), then the others sorted by (batch, target frame jj, 16-row band of
- * the patch centre), so that the lookup kernel's XCD-aware schedule streams every feature row through an L2 about
- * once; order[B*E] = number of heavy edges.  `coord_scale`
+ * of this call): first the HEAVY edge slots (union box of the 9 windows clearly larger than a compact patch's at
+ * this radius — more than 128 positions for radius <= 3, more than 256 for radius <= 5 — or larger than the staged
+ * kernel's LDS tile: they run 2-4x longer and should start first), then the others sorted by (batch, target frame jj,
+ * bin of the patch centre: 16-row bands x 8-px columns, numbered in blocks of 4 bands x ~64 px), so that the lookup
+ * kernel's XCD-aware schedule streams every feature row through an L2 about once; order[B*E] = number of heavy
+ * edges.  `coord_scale`
  * is the factor the caller divides coords by for the pyramid level whose height is H2 (1 for level 0); one
  * plan serves all levels of a pyramid.  The plan only changes WHICH edges run together, never any result. */
 int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, int E, int n2, int P, int H2,

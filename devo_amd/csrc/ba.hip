@@ -451,7 +451,7 @@ struct AccCtx {
 // with LDS atomics.  Correct for every input but slow (ds_add_f32 costs ~10 cycles per lane), so the kernels
 // below only use it for the rare irregular patches.
 __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, int a0, int m, float* S_lds, float* y_lds,
-                                                       float* col, int lane) {
+                                                       float* col, int lane, bool schur = true) {
   const float* __restrict__ poses = K.poses; const float* __restrict__ patches = K.patches;
   const TargetSrc target = K.target; const float* __restrict__ weight = K.weight;
   const int64_t* __restrict__ ii = K.ii; const int64_t* __restrict__ jj = K.jj; const int64_t* __restrict__ kk = K.kk;
@@ -575,7 +575,7 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
 #pragma unroll
     for (int g = 0; g < 3; g++) if (lane + 64 * g < n6) patch_col[(int64_t)s * n6 + lane + 64 * g] = cr[g];   // for the retraction
 #pragma unroll
-    for (int g = 0; g < 3; g++) {
+    for (int g = 0; g < 3 && schur; g++) {                              // (!schur: k_ba_schur subtracts E Q E^T afterwards)
       if (64 * g >= n6) break;                                          // uniform
       const int r = lane + 64 * g;
       const float qer = -Q * cr[g];
@@ -629,10 +629,12 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
   // garbage tables; a prepared graph may be solved many times (the sticky failure flag is reset here)
   const bool prepared = meta->sig == sig;
   const int n_seg = prepared ? min(meta->n_seg, max_seg) : 0;
+  const bool defer = (iter >> 16) != 0;                        // the launcher's flag: the Schur term is left to k_ba_schur
+  iter &= 0xffff;
   if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = prepared ? 0 : -1;
   for (int s = blockIdx.x * ACC_WAVES + wave; s < n_seg; s += gridDim.x * ACC_WAVES) {
     const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
-    accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane);
+    accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane, !defer);
   }
   __syncthreads();
   if (N > 0) {
@@ -946,10 +948,91 @@ __global__ __launch_bounds__(512) void k_ba_reduce(const float* __restrict__ par
       block_of(o / 36, fr, fc);
       const int ab = o % 36, r = 6 * fr + ab / 6, c = 6 * fc + ab % 6;
       if (fr == fc && ab / 6 < ab % 6) return;                  // upper half of a diagonal block: its mirror writes it
-      if (r == c) sum = sum + (1e-4f * sum + ep);              // ba_cuda.cu:518 (ep = 1); devo/ba.py:73 (ep = 10 in training)
+      if (r == c && ep >= 0.0f) sum = sum + (1e-4f * sum + ep);   // ba_cuda.cu:518 (ep = 1); devo/ba.py:73 (ep = 10 in training); ep < 0: k_ba_damp does it
       S[r * (n6 + 1) + c] = sum;
       if (r != c) S[c * (n6 + 1) + r] = sum;
     } else S[n6 * (n6 + 1) + (o - nt)] = sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- deferred Schur term
+// S_aug -= E^ diag(Q) E^^T for the general accumulate kernel at N > 16 (ba_cuda.cu:511-512 as ONE product instead of 17 k LDS
+// atomics per patch: on gfx950 a 64-lane ds_add_f32 occupies the LDS for ~60 cycles, and at BASELINE's stress size the per-patch
+// form spent 0.79 ms per iteration in them).  E^_p = [e_p ; u_p] is patch p's column of E with its right-hand-side scalar
+// appended (patch_col / patch_rec), S_aug the solver's working image (rows x LD, row n6 = y^T; lower triangle).
+// Workgroup = one 32 x 32 tile of the lower triangle x one chunk of 128 patches; 2 x 2 outputs per thread; float atomics into S
+// (1 344 workgroups x 1 024 outputs at the stress size) — or, when the launcher has scratch for it (the partial systems' area is free
+// by then), one partial tile per workgroup that k_ba_damp adds in a fixed order: bit-reproducible results.
+constexpr int SCH_T = 32, SCH_K = 128;
+__global__ __launch_bounds__(256) void k_ba_schur(const float* __restrict__ patch_rec, const float* __restrict__ patch_col,
+                                                  const BaMeta* __restrict__ meta, int N, int max_seg, float* __restrict__ S,
+                                                  float* __restrict__ part) {
+  __shared__ float sa[SCH_K][SCH_T + 1], sb[SCH_K][SCH_T + 1];      // rows block (scaled by -Q), columns block
+  const int n6 = 6 * N, LD = n6 + 1, dimA = n6 + 1;
+  const int nt = (dimA + SCH_T - 1) / SCH_T;
+  int tr = 0, tc = 0;
+  {                                                                   // blockIdx.x -> lower-triangle tile (tr >= tc)
+    int t = blockIdx.x;
+    while (t > tr) { t -= tr + 1; tr++; }
+    tc = t;
+  }
+  const int n_seg = min(meta->n_seg, max_seg);
+  const int k0 = blockIdx.y * SCH_K;
+  if (k0 >= n_seg || meta->fail) return;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < SCH_K * SCH_T; i += 256) {
+    const int k = i / SCH_T, j = i - k * SCH_T;
+    const int p = k0 + k;
+    float a = 0.0f, b = 0.0f;
+    if (p < n_seg) {
+      const float q = patch_rec[(int64_t)p * 2], u = patch_rec[(int64_t)p * 2 + 1];
+      const int ra = tr * SCH_T + j, cb = tc * SCH_T + j;
+      const float ea = ra < n6 ? patch_col[(int64_t)p * n6 + ra] : (ra == n6 ? u : 0.0f);
+      const float eb = cb < n6 ? patch_col[(int64_t)p * n6 + cb] : 0.0f;       // (column n6 of the image is not used)
+      a = -q * ea; b = eb;
+    }
+    sa[k][j] = a; sb[k][j] = b;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;                             // outputs (2 ty + {0,1}, 2 tx + {0,1})
+  float v00 = 0.0f, v01 = 0.0f, v10 = 0.0f, v11 = 0.0f;
+#pragma unroll 8
+  for (int k = 0; k < SCH_K; k++) {
+    const float a0 = sa[k][2 * ty], a1 = sa[k][2 * ty + 1], b0 = sb[k][2 * tx], b1 = sb[k][2 * tx + 1];
+    v00 = fmaf(a0, b0, v00); v01 = fmaf(a0, b1, v01); v10 = fmaf(a1, b0, v10); v11 = fmaf(a1, b1, v11);
+  }
+  if (part) {                                                         // deterministic: the tile's partial, summed in chunk order by k_ba_damp
+    float* o = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (SCH_T * SCH_T);
+    o[(2 * ty) * SCH_T + 2 * tx] = v00; o[(2 * ty) * SCH_T + 2 * tx + 1] = v01;
+    o[(2 * ty + 1) * SCH_T + 2 * tx] = v10; o[(2 * ty + 1) * SCH_T + 2 * tx + 1] = v11;
+    return;
+  }
+  const int r0 = tr * SCH_T + 2 * ty, c0 = tc * SCH_T + 2 * tx;
+  auto put = [&](int r, int c, float v) { if (r <= n6 && c < n6 && c <= r && v != 0.0f) atomicAdd(&S[(int64_t)r * LD + c], v); };
+  put(r0, c0, v00); put(r0, c0 + 1, v01); put(r0 + 1, c0, v10); put(r0 + 1, c0 + 1, v11);
+}
+
+// S_dd <- S_dd * (1 + 1e-4) + ep after the deferred Schur term (what k_ba_reduce does when nothing is deferred), and the mirror of
+// the lower triangle that k_ba_reduce wrote before the Schur term went in
+__global__ void k_ba_damp(float* __restrict__ S, int N, float ep, const float* __restrict__ part, int nchunk_grid,
+                          const BaMeta* __restrict__ meta, int max_seg) {
+  const int n6 = 6 * N, LD = n6 + 1;
+  const int nchunk = part ? (min(meta->n_seg, max_seg) + SCH_K - 1) / SCH_K : 0;      // chunks that hold patches (the others were not written)
+  const bool dead = meta->fail != 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (n6 + 1) * n6; i += gridDim.x * blockDim.x) {
+    const int r = i / n6, c = i - r * n6;                         // r <= n6 (row n6 = the right-hand side), c < n6
+    if (c > r) continue;
+    float v = S[(int64_t)r * LD + c];
+    if (part && !dead) {
+      const int tr = r / SCH_T, tc = c / SCH_T;
+      const float* o = part + ((int64_t)(tr * (tr + 1) / 2 + tc) * nchunk_grid) * (SCH_T * SCH_T) + (r - tr * SCH_T) * SCH_T + (c - tc * SCH_T);
+      float acc = 0.0f;
+      for (int k = 0; k < nchunk; k++) acc += o[(int64_t)k * (SCH_T * SCH_T)];
+      v += acc;
+    }
+    if (r == c) v = v + (1e-4f * v + ep);
+    S[(int64_t)r * LD + c] = v;
+    if (r != c && r < n6) S[(int64_t)c * LD + r] = v;
   }
 }
 
@@ -1771,6 +1854,15 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
   return check_launch("devo_ba_prepare");
 }
 
+// k_ba_schur + k_ba_damp behind k_ba_reduce(ep < 0): the Schur term of the general accumulate kernel as one product
+static void ba_deferred_schur(hipStream_t st, const float* patch_rec, const float* patch_col, const BaMeta* meta, int N, int max_seg, float* S, float ep,
+                              float* scratch, size_t scratch_bytes) {
+  const int nt = (6 * N + 1 + SCH_T - 1) / SCH_T, ntile = nt * (nt + 1) / 2, nchunk = (max_seg + SCH_K - 1) / SCH_K;
+  float* part = (size_t)ntile * nchunk * SCH_T * SCH_T * sizeof(float) <= scratch_bytes ? scratch : nullptr;     // else: float atomics
+  hipLaunchKernelGGL(k_ba_schur, dim3((unsigned)ntile, (unsigned)nchunk), dim3(256), 0, st, patch_rec, patch_col, meta, N, max_seg, S, part);
+  hipLaunchKernelGGL(k_ba_damp, dim3(blocks_for(36LL * N * N + 6 * N, 256, 256)), dim3(256), 0, st, S, N, ep, (const float*)part, nchunk, meta, max_seg);
+}
+
 static int ba_check_args(const char* who, int E, int Nbuf, int Np, int P, int t0, int t1) {
   const int N = t1 - t0;
   if (!(E >= 0 && Np > 0 && Nbuf > 0 && P > 0)) { set_error("%s: bad sizes", who); return DEVO_ERR_ARG; }
@@ -1895,12 +1987,16 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       return DEVO_ERR_LAUNCH;
     }
   }
+  // the general kernel (N > 16) leaves the Schur term to ONE product afterwards (k_ba_schur); DEVO_BA_SCHUR_INLINE=1: per patch, in LDS
+  static const bool schur_inline = getenv("DEVO_BA_SCHUR_INLINE") != nullptr;
+  const bool defer = !use_reg && N > 0 && !schur_inline;
   for (int it = 0; it < iterations; it++) {
     hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? REG_THREADS : ACC_THREADS), acc_lds_used, st, poses, patches, intrinsics, target,
-                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, it, ba_sig(E, N), L.max_seg);
+                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, it | (defer ? 1 << 16 : 0), ba_sig(E, N), L.max_seg);
     if ((rc = check_launch("devo_ba_forward(accumulate)"))) return rc;
     if (N > 0) {
-      hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, partials, L.n_part, N, S, y, ep);
+      hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, partials, L.n_part, N, S, y, defer ? -1.0f : ep);
+      if (defer) ba_deferred_schur(st, patch_rec, edge_ej, meta, N, L.max_seg, S, ep, partials, sizeof(float) * (size_t)L.n_part * (n6 * (n6 + 1) + n6 + 1));
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       static const bool ba_trace = getenv("DEVO_BA_TRACE") != nullptr;
       hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace ? 1 : 0);
@@ -1965,17 +2061,18 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
       return DEVO_ERR_LAUNCH;
     }
   }
-  static const float dummy_intr[4] = {1.0f, 1.0f, 0.0f, 0.0f};
-  (void)dummy_intr;
+  static const bool schur_inline = getenv("DEVO_BA_SCHUR_INLINE") != nullptr;
+  const bool defer = !use_reg && N > 0 && !schur_inline;
   // (poses / patches / intrinsics / weight are not read in terms mode; lmbda doubles as the 4-float intrinsics read)
   const TargetSrc src{nullptr, nullptr, 0, 0, 0, terms};
   hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? REG_THREADS : ACC_THREADS), acc_lds_used, st, (const float*)nullptr, (const float*)nullptr,
                      (const float*)(w + L.y) /* 4 readable floats */, src, (const float*)nullptr, lmbda, ii, jj, kk, (int*)(w + L.perm_b), (int*)(w + L.counts),
-                     meta, 3, t0, N, (float*)(w + L.partials), patch_rec, patch_col, 0, ba_sig(E, N), L.max_seg);
+                     meta, 3, t0, N, (float*)(w + L.partials), patch_rec, patch_col, defer ? 1 << 16 : 0, ba_sig(E, N), L.max_seg);
   if ((rc = check_launch("devo_ba_solve_terms(accumulate)"))) return rc;
   if (N > 0) {
     hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, (float*)(w + L.partials), L.n_part, N, S,
-                       (float*)(w + L.y), ep);
+                       (float*)(w + L.y), defer ? -1.0f : ep);
+    if (defer) ba_deferred_schur(st, patch_rec, patch_col, meta, N, L.max_seg, S, ep, (float*)(w + L.partials), sizeof(float) * (size_t)L.n_part * (n6 * (n6 + 1) + n6 + 1));
     hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, (float*)(w + L.y), N, dX, meta, 0, status_flag, 0);
     if ((rc = check_launch("devo_ba_solve_terms(solve)"))) return rc;
     if (hipMemcpyAsync(dX_out, dX, sizeof(float) * n6, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("devo_ba_solve_terms: copy failed"); return DEVO_ERR_LAUNCH; }

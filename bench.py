@@ -465,7 +465,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         torch.cuda.empty_cache()
         h = update_op_mode(args, device, rank, world, dtype_name="f16", secondary=True)
         out["f16"] = {"value": h["value"], "unit": "it/s", "ms_per_step": h["ms_per_step"],
-                      "roofline": {k: h["roofline"][k] for k in ("achieved", "frac", "kernel", "alg_bytes_per_launch", "us_per_launch")},
+                      "roofline": {k: h["roofline"].get(k) for k in ("achieved", "frac", "kernel", "alg_bytes_per_launch", "us_per_launch", "us_per_launch_back_to_back", "traffic")},
                       "note": "same step with fp16-storage feature pyramid + patch features (DEVO's inference precision), fp32 accumulation"}
     if world > 1 and not args.no_train_probe:
         # BASELINE configuration 4: data-parallel training steps — the one collective of the path (13.59 MB gradient all-reduce)

@@ -21,6 +21,9 @@
 //   * no barrier inside the product loop, no LDS staging of the features.  The levels run one after the other (coarse first)
 //     over ONE raw-window area; each level's epilogue (blend, axis swap, permutation) writes its slice of the output record.
 // fp16 storage, C = 128 (four K = 32 steps), radius <= 3.  Other cases take the per-edge kernel.
+// Debug: DEVO_GP_STATS=1 (phase cycles / tile counts to stderr, tools/group_stats.py); ablation builds -DGP_DBG_NOPAIRS / _NOSCATTER /
+// _NOLOAD / _NOEPI (tools/build_variant.sh; profiles/r02y_group_ablation.txt).  Measured slower than the per-edge kernel on cfg2
+// (132 us against 99 per fp16 launch): DESIGN.md 3.1d says where the time goes.
 #pragma once
 
 typedef _Float16 gp_h8 __attribute__((ext_vector_type(8)));

@@ -237,17 +237,17 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         if args.separate_index_kernels or prep_stream is not None:
             order = cuda_corr.plan_finish(order, d["jj"], n, cfg["H"], R)
         else:
-            # the plan's ordering step and the BA's index preparation (both single-workgroup, independent) in ONE launch
+            # the plan's ordering step and the BA's index preparation (independent of each other) in ONE launch
             cuda_ba.prepare(d["kk"], Np, n - 1, ws, plan=(order, n, cfg["H"]))
         lookup_probed(coords, order=order)
-        if not (args.separate_target or args.separate_index_kernels or prep_stream is not None):
+        if prep_stream is not None:
+            cur.wait_stream(prep_stream)
+        if not (args.separate_target or args.separate_index_kernels):
             # devo.py:330 (target = centre of the reprojected patch + delta) formed inside the BA: same fp32 addition
             cuda_ba.forward_delta(d["poses"], d["patches"], d["intr"], coords, d["delta"], d["weight"], d["lmbda"],
                                   d["ii"], d["jj"], d["kk"], 1, n, 2, ws)
             return
         target = coords[:, :, :, 1, 1] + d["delta"]                        # devo.py:330
-        if prep_stream is not None:
-            cur.wait_stream(prep_stream)
         cuda_ba.forward(d["poses"], d["patches"], d["intr"], target, d["weight"], d["lmbda"],
                         d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws, prepared=(prep_stream is not None) or not args.separate_index_kernels)
 

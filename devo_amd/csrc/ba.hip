@@ -362,20 +362,17 @@ __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__
 
 template <int CACHE>
 __global__ __launch_bounds__(ORDER_THREADS) void k_order_only(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order) {
-  corr_order_body<CACHE>(bins, BE, nbins, order);          // (fallback path: no staging buffer)
+  corr_order_body<CACHE>(bins, BE, nbins, order, (int)blockIdx.x, (int)gridDim.x);
 }
 
-// Workgroup 0: the BA's index preparation; workgroup 1: the ordering step of the lookup's locality plan (corr_plan.h).
-// Two single-workgroup, latency-bound kernels that do not depend on each other run side by side in one launch.
+// Workgroup 0: the BA's index preparation; workgroups 1 .. G: the ordering step of the lookup's locality plan (corr_plan.h).
+// Latency-bound kernels that do not depend on each other run side by side in one launch.
 template <int CACHE>
 __global__ __launch_bounds__(1024) void k_prepare_and_order(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
                                                             int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
-                                                            int* perm_b, int sig, const int* __restrict__ bins, int nbins, int* __restrict__ order, int stage_cap) {
+                                                            int* perm_b, int sig, const int* __restrict__ bins, int nbins, int* __restrict__ order) {
   if (blockIdx.x == 0) ba_prepare_body<CACHE>(kk, E, Np, max_seg, meta, g_rank, g_counts, g_cursor, ku, kx, perm_a, perm_b, sig);
-  else {
-    extern __shared__ int s_dyn_order[];                   // this workgroup's copy of the dynamic LDS: the staging buffer
-    corr_order_body<CACHE>(bins, E, nbins, order, s_dyn_order, stage_cap);
-  }
+  else corr_order_body<CACHE>(bins, E, nbins, order, (int)blockIdx.x - 1, (int)gridDim.x - 1);
 }
 
 // ------------------------------------------------------------------------------------------------- per-edge maths
@@ -1816,7 +1813,7 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     prep_fn_t prep = ept <= 8 ? k_ba_prepare<8> : ept <= 16 ? k_ba_prepare<16> : ept <= 24 ? k_ba_prepare<24> :
                      ept <= 32 ? k_ba_prepare<32> : k_ba_prepare<0>;
     if (plan && ept <= 32) {
-      typedef void (*both_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, int, const int*, int, int*, int);
+      typedef void (*both_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, int, const int*, int, int*);
       both_fn_t both = ept <= 8 ? k_prepare_and_order<8> : ept <= 16 ? k_prepare_and_order<16> : ept <= 24 ? k_prepare_and_order<24> :
                        k_prepare_and_order<32>;
       static bool both_attr = false;
@@ -1827,8 +1824,8 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
         (void)hipFuncSetAttribute((const void*)k_prepare_and_order<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
         (void)hipGetLastError(); both_attr = true;
       }
-      hipLaunchKernelGGL(both, dim3(2), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b,
-                         ba_sig(E, N), plan + E + 1, plan_nbins, plan, (int)(prep_lds / sizeof(int)));
+      hipLaunchKernelGGL(both, dim3(1 + (unsigned)corr_order_workgroups(E, plan_nbins)), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank,
+                         counts, cursor, ku, kx, perm_a, perm_b, ba_sig(E, N), plan + E + 1, plan_nbins, plan);
       plan = nullptr;                                          // done
     } else {
       hipLaunchKernelGGL(prep, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b, ba_sig(E, N));
@@ -1849,7 +1846,7 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     const long long per_thread = ((long long)E + ORDER_THREADS - 1) / ORDER_THREADS;
     order_fn_t order_fn = per_thread <= 8 ? k_order_only<8> : per_thread <= 16 ? k_order_only<16> : per_thread <= 24 ? k_order_only<24> :
                           per_thread <= 32 ? k_order_only<32> : k_order_only<0>;
-    hipLaunchKernelGGL(order_fn, dim3(1), dim3(ORDER_THREADS), 0, st, plan + E + 1, E, plan_nbins, plan);
+    hipLaunchKernelGGL(order_fn, dim3((unsigned)corr_order_workgroups(E, plan_nbins)), dim3(ORDER_THREADS), 0, st, plan + E + 1, E, plan_nbins, plan);
   }
   return check_launch("devo_ba_prepare");
 }

@@ -468,14 +468,11 @@ __global__ __launch_bounds__(BIN_THREADS) void corr_bin_kernel(const float* __re
   bins[be] = bin;
 }
 
-// Step 2 (one workgroup): LDS counting sort of the bins; the heavy list first.  CACHE > 0: the ceil(BE / 1024) <= CACHE
-// bins of a thread are loaded at once into registers (one round trip to memory instead of one per loop iteration and
-// pass); CACHE == 0: any BE, bins re-read by both passes.
+// Step 2: counting sort of the bins by gridDim.x independent workgroups, the heavy list first (corr_plan.h).
 template <int CACHE>
 __global__ __launch_bounds__(ORDER_THREADS) void corr_order_kernel(const int* __restrict__ bins, int BE, int nbins,
-                                                                   int* __restrict__ order, int stage_cap) {
-  extern __shared__ int s_order_stage[];                      // stage_cap ints (0: none)
-  corr_order_body<CACHE>(bins, BE, nbins, order, stage_cap > 0 ? s_order_stage : nullptr, stage_cap);
+                                                                   int* __restrict__ order) {
+  corr_order_body<CACHE>(bins, BE, nbins, order, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1192,17 +1189,13 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
     hipLaunchKernelGGL(corr_bin_kernel, dim3((unsigned)((BE + BIN_THREADS - 1) / BIN_THREADS)), dim3(BIN_THREADS), 0,
                        (hipStream_t)stream, coords, jj, (int)BE, E, n2, H2, coord_scale, nb, 2 * radius + 2,
                        radius <= 3 ? 1 : 3, bins);
-  typedef void (*order_fn_t)(const int*, int, int, int*, int);
+  typedef void (*order_fn_t)(const int*, int, int, int*);
   const long long per_thread = (BE + ORDER_THREADS - 1) / ORDER_THREADS;
   order_fn_t order_fn = per_thread <= 8 ? corr_order_kernel<8> : per_thread <= 16 ? corr_order_kernel<16> :
                         per_thread <= 24 ? corr_order_kernel<24> : per_thread <= 32 ? corr_order_kernel<32> : corr_order_kernel<0>;
-  // the ordered list is staged in LDS when it fits (coalesced write-out instead of BE scattered stores from one CU)
-  const size_t stage_bytes = (BE * 4 <= 128 * 1024) ? (size_t)BE * 4 : 0;
-  if (stage_bytes > 48 * 1024) {
-    if (hipFuncSetAttribute((const void*)order_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes) != hipSuccess) (void)hipGetLastError();
-  }
-  hipLaunchKernelGGL(order_fn, dim3(1), dim3(ORDER_THREADS), stage_bytes, (hipStream_t)stream, bins, (int)BE, (int)corr_plan_nbins(B, n2, pg), order,
-                     (int)(stage_bytes / 4));
+  const long long nbins = corr_plan_nbins(B, n2, pg);
+  hipLaunchKernelGGL(order_fn, dim3((unsigned)corr_order_workgroups(BE, nbins)), dim3(ORDER_THREADS), 0, (hipStream_t)stream, bins, (int)BE,
+                     (int)nbins, order);
   return check_launch("devo_corr_order");
 }
 

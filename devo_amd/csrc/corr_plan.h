@@ -1,6 +1,6 @@
 // The locality plan's ordering step as a device function: corr.hip wraps it into corr_order_kernel, ba.hip runs it as the
-// second workgroup of k_prepare_and_order (next to the BA's index preparation: both are single-workgroup, latency-bound
-// kernels that do not depend on each other).
+// workgroups 1 .. G of k_prepare_and_order (next to the BA's index preparation in workgroup 0: latency-bound kernels that do
+// not depend on each other).
 #pragma once
 #include "corr_tile.h"
 
@@ -8,19 +8,30 @@ namespace devo {
 
 constexpr int ORDER_THREADS = 1024;
 constexpr int ORDER_MAXBINS = CORR_ORDER_MAXBINS;
+constexpr int ORDER_MAX_WG = 64;
 
-// One workgroup: LDS counting sort of the bins; the heavy list first.  CACHE > 0: the ceil(BE / 1024) <= CACHE bins of a
-// thread are loaded at once into registers (one round trip to memory instead of one per loop iteration and pass);
-// CACHE == 0: any BE, bins re-read by both passes.
-// `stage` (LDS, `stage_cap` ints, may be null / 0): the ordered list is assembled there and written out with coalesced stores —
-// 20 000 scattered 4-byte stores from ONE compute unit take longer than the whole sort.
+// Workgroups of the ordering step: about 1024 edges of their own each.
+inline int corr_order_workgroups(long long BE, long long nbins) {
+  long long g = BE / 1024;
+  if (g > ORDER_MAX_WG) g = ORDER_MAX_WG;
+  if (g > nbins) g = nbins;
+  return g < 1 ? 1 : (int)g;
+}
+
+// Counting sort of the edges by plan bin, the heavy list first, by G workgroups that exchange NOTHING: workgroup g owns the bins
+// [g nbins / G, (g + 1) nbins / G).  It reads ALL the bins (G x 4 BE bytes out of the L2), counts the edges of lower bins — heavy
+// ones are bin -1 — which is the slot its own range starts at, and counting-sorts its own edges through LDS counters.  What this
+// buys: an LDS atomic retires one lane per cycle, and the sort needs 2 BE of them — 18 µs of the former single-workgroup kernel at
+// cfg2's 21 600 edges, 250 µs at the stress configuration's 262 144; here every compute unit does 2 BE / G.
+// CACHE > 0: the ceil(BE / 1024) <= CACHE bins of a thread are loaded at once into registers (one round trip to memory instead of
+// one per loop iteration and pass); CACHE == 0: any BE, bins re-read by both passes.
 template <int CACHE>
-__device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order,
-                                                int* stage = nullptr, int stage_cap = 0) {
+__device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order, int g, int G) {
   __shared__ int s_cnt[ORDER_MAXBINS];
-  __shared__ int s_heavy[2];                                // [0] = count (pass 1), [1] = cursor (pass 2)
+  __shared__ int s_base[2];                                 // [0] = edges below this workgroup's range, [1] = heavy cursor (g == 0)
   constexpr bool CACHED = CACHE > 0;
   const int lane = threadIdx.x & 63;
+  const int b0 = (int)((long long)g * nbins / G), b1 = (int)((long long)(g + 1) * nbins / G), nown = b1 - b0;
   int breg[CACHED ? CACHE : 1];
   if (CACHED) {
 #pragma unroll
@@ -35,47 +46,44 @@ __device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, in
     return be < BE ? bins[be] : 0x7fffffff;
   };
   const int iters = CACHED ? CACHE : (BE + ORDER_THREADS - 1) / ORDER_THREADS;   // block-uniform (ballots below)
-  for (int i = threadIdx.x; i < nbins; i += ORDER_THREADS) s_cnt[i] = 0;
-  if (threadIdx.x < 2) s_heavy[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < nown; i += ORDER_THREADS) s_cnt[i] = 0;
+  if (threadIdx.x < 2) s_base[threadIdx.x] = 0;
   __syncthreads();
+  int below = 0;
 #pragma unroll
   for (int i = 0; i < iters; i++) {
     const int bin = bin_at(i);
-    const unsigned long long hv = __ballot(bin < 0);
-    if (bin >= 0 && bin < nbins) atomicAdd(&s_cnt[bin], 1);
-    if (hv != 0ull && lane == 0) atomicAdd(&s_heavy[0], __popcll(hv));
+    below += (bin < b0) ? 1 : 0;
+    if (bin >= b0 && bin < b1) atomicAdd(&s_cnt[bin - b0], 1);
   }
+  below = wave_inclusive_sum(below);
+  if (lane == 63 && below != 0) atomicAdd(&s_base[0], below);
   __syncthreads();
-  const int n_heavy = s_heavy[0];
-  if (threadIdx.x < 64) {                                   // exclusive scan of the bins by one wave, starting after the heavy list
-    int carry = n_heavy;
-    for (int base = 0; base < nbins; base += 64) {
+  if (threadIdx.x < 64) {                                   // exclusive scan of the own bins by one wave, starting at the base slot
+    int carry = s_base[0];
+    for (int base = 0; base < nown; base += 64) {
       const int i = base + threadIdx.x;
-      const int v = (i < nbins) ? s_cnt[i] : 0;
+      const int v = (i < nown) ? s_cnt[i] : 0;
       const int x = wave_inclusive_sum(v);
-      if (i < nbins) s_cnt[i] = carry + x - v;
+      if (i < nown) s_cnt[i] = carry + x - v;
       carry += __builtin_amdgcn_readlane(x, 63);
     }
   }
   __syncthreads();
-  const bool staged = stage != nullptr && BE <= stage_cap;
-  int* dst = staged ? stage : order;
 #pragma unroll
   for (int i = 0; i < iters; i++) {
     const int be = threadIdx.x + ORDER_THREADS * i;
     const int bin = bin_at(i);
-    const unsigned long long hv = __ballot(bin < 0);
-    int hbase = 0;
-    if (hv != 0ull && lane == 0) hbase = atomicAdd(&s_heavy[1], __popcll(hv));
-    hbase = __shfl(hbase, 0);
-    if (bin < 0) dst[hbase + __popcll(hv & ((1ull << lane) - 1ull))] = be;
-    else if (bin < nbins) dst[atomicAdd(&s_cnt[bin], 1)] = be;
+    if (g == 0) {                                           // (block-uniform) the heavy list, in front of bin 0
+      const unsigned long long hv = __ballot(bin < 0);
+      int hbase = 0;
+      if (hv != 0ull && lane == 0) hbase = atomicAdd(&s_base[1], __popcll(hv));
+      hbase = __shfl(hbase, 0);
+      if (bin < 0) order[hbase + __popcll(hv & ((1ull << lane) - 1ull))] = be;
+    }
+    if (bin >= b0 && bin < b1) order[atomicAdd(&s_cnt[bin - b0], 1)] = be;
   }
-  if (staged) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < BE; i += ORDER_THREADS) order[i] = stage[i];
-  }
-  if (threadIdx.x == 0) order[BE] = n_heavy;
+  if (g == 0 && threadIdx.x == 0) order[BE] = s_base[0];   // b0 == 0: the edges below bin 0 are the heavy ones
 }
 
 }  // namespace devo

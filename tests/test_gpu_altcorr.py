@@ -396,6 +396,27 @@ def test_plan_started_by_the_reprojection_kernel_equals_plan():
     assert torch.equal(key(a), key(b))                              # same (frame, band) sequence after the heavy list
 
 
+@pytest.mark.parametrize("n,M,H,W", [(15, 96, 120, 160), (12, 300, 96, 128)])
+def test_plan_by_several_workgroups_is_a_sorted_permutation(n, M, H, W):
+    """above 2048 edges the ordering step runs as several independent workgroups (corr_plan.h), each owning a range of bins: the
+    result is a permutation, heavy list first, target frames ascending behind it, every frame's edges complete"""
+    from devo_amd import synth
+    from devo_amd.backends import cuda_ba, cuda_corr
+    poses, (patches, _), intr = synth.make_poses(n, 5), synth.make_patches(n, M, H, W, seed=5), synth.make_intrinsics(n, H, W)
+    ii, jj, kk = (t.to(DEV) for t in synth.full_graph(n, M))
+    coords = cuda_ba.transform(poses.to(DEV), patches.to(DEV), intr.to(DEV), ii, jj, kk, layout="2pp")
+    E = ii.numel()
+    for radius in (3, 5):
+        o = cuda_corr.plan(coords, jj, n, H, radius=radius).cpu()
+        nh = int(o[E])
+        assert 0 <= nh <= E and sorted(o[:E].tolist()) == list(range(E))
+        fr = jj.cpu()[o[nh:E].long()]
+        assert bool((fr[1:] >= fr[:-1]).all())
+        band = (coords.cpu()[0, o[nh:E].long(), 1, 1, 1].clamp(0, H - 1) / 64).floor().long()      # blocks of 4 bands ascend inside a frame
+        key = fr * 64 + band
+        assert bool((key[1:] >= key[:-1]).all())
+
+
 @pytest.mark.parametrize("which", ["region-staged dense kernel", "staged kernel", "edge-group kernel", "segment-reduced backward"])
 def test_other_kernels_stay_covered(which):
     """fp32 / fp16 lookups with C = 128 take the per-edge matrix-core kernel by default.  DEVO_CORR_DENSE=1 (read once per

@@ -653,6 +653,19 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
 // target frames) is folded in with wave-uniform control flow and plain LDS reads of a per-wave scratch that the
 // patch's edge lanes filled: no atomics, fixed summation order.  Irregular patches take the atomic path into the
 // workgroup's LDS system.  At the end the register copies are added into LDS one wave at a time.
+#ifdef DEVO_ACC_TRACE
+// debug build (tools/build_variant.sh acctrace ba -DDEVO_ACC_TRACE; tools/acc_trace.py): 100 MHz time stamps of every wave of the
+// last k_ba_accumulate_reg launch
+__device__ unsigned long long g_acc_trace[256 * 4 * 16];
+#define ACC_STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    if (lane == 0 && blockIdx.x < 256) g_acc_trace[(blockIdx.x * 4 + wave) * 16 + (i)] = wall_clock64(); } while (0)
+#define ACC_STAMP_FIRST(i) do { if (half == 0) ACC_STAMP(i); } while (0)      // the wave's first patch only
+#define ACC_STAMP_PATCH(i) ACC_STAMP((i) + 2 * half)
+#else
+#define ACC_STAMP(i) do { } while (0)
+#define ACC_STAMP_FIRST(i) do { } while (0)
+#define ACC_STAMP_PATCH(i) do { } while (0)
+#endif
 constexpr int REG_WAVES = 4;      // 256 threads: one wave per SIMD, so the register copy of S never spills
 constexpr int REG_THREADS = REG_WAVES * 64;
 constexpr int SCR_ROWS = 28;     // per-edge scratch rows: Jj_x[6] Jj_y[6] Ji_x[6] Ji_y[6] w_x w_y (w r)_x (w r)_y
@@ -671,6 +684,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
   float* col_all = y_lds + n6;
   float* scr_all = col_all + REG_WAVES * n6;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ACC_STAMP(0);
   float* col = col_all + wave * n6;
   float* scr = scr_all + wave * (SCR_ROWS * 64);
   __shared__ int s_used_atomic;                                 // did any wave of this workgroup take the atomic path?
@@ -685,6 +699,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
   AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, patch_col, intr[0], intr[1], intr[2], intr[3], lmbda[0],
            P, t0, N, n6, LD};
 
+  ACC_STAMP(1);
   const int pa = (lane < 36) ? lane / 6 : 0, pb = (lane < 36) ? lane % 6 : 0;    // this lane's position inside a 6x6 block
   float Sreg[NMAX * (NMAX + 1) / 2];
 #pragma unroll
@@ -697,10 +712,14 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
   const int n_seg = prepared ? min(meta->n_seg, max_seg) : 0;
   if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = prepared ? 0 : -1;
   for (int s = blockIdx.x * REG_WAVES + wave; s < n_seg; s += gridDim.x * REG_WAVES) {
+#ifdef DEVO_ACC_TRACE
+    const int half = (s >= gridDim.x * REG_WAVES) ? 1 : 0;      // the wave's first / a later patch
+#endif
     const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
     if (m > 64) { if (lane == 0) s_used_atomic = 1; accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane); continue; }
     const bool act = lane < m;
     const int e = act ? perm[a0 + lane] : 0;
+    ACC_STAMP_FIRST(2);
     EdgeTerms T;
     int ix = -1, jx = -1;
     if (act) {
@@ -714,6 +733,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
 #pragma unroll
       for (int c = 0; c < 6; c++) { T.Ji[0][c] = T.Ji[1][c] = T.Jj[0][c] = T.Jj[1][c] = 0.0f; }
     }
+    ACC_STAMP_PATCH(3);
     // ---- regular?  one source frame, distinct target frames (frame -> lane table built through the column buffer)
     const unsigned long long bi = __ballot(ix >= 0);
     const int src = bi ? __shfl(ix, __ffsll((long long)bi) - 1) : -1;
@@ -735,6 +755,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
       continue;
     }
     const int slot = (jx >= 0) ? jx : N + __popcll(fixm & ((1ULL << lane) - 1ULL));
+    ACC_STAMP_FIRST(8);
 
     // ---- per-edge quantities into the wave's scratch [row][slot]; the patch's E column into `col`
     for (int i = lane; i < n6; i += 64) col[i] = 0.0f;
@@ -781,6 +802,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     if (N == 0) continue;
     for (int i = lane; i < n6; i += 64) patch_col[(int64_t)s * n6 + i] = col[i];  // the patch's E column, for the retraction
 
+    ACC_STAMP_FIRST(9);
     // ---- fold the patch into the register-resident block triangle.  Everything a lane needs is pulled into registers
     //      with wide LDS reads first (frame slots 0..NSL-1: element [pa] / [pb] of every Jacobian row), then the 6x6 block
     //      entries are pure register arithmetic with no branches; slots without an edge hold zeros, block rows >= N are
@@ -817,6 +839,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
           }
         }
       }
+      ACC_STAMP_FIRST(10);
       if (src >= 0) {
         // pass 2 (source frame optimised): row and column `src` get the (i,j) / (j,i) blocks, the diagonal gets B_ii;
         // a self edge (target == source) puts B_ij + B_ji on the diagonal as well
@@ -851,6 +874,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
         }
       }
     }
+    ACC_STAMP_FIRST(11);
     // ---- right-hand side rows lane, lane+64:  y = v - Q u e   (v_i -= w r Ji, v_j += w r Jj; :314-316, :512)
 #pragma unroll
     for (int g = 0; g < 2; g++) {
@@ -865,6 +889,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
       }
     }
     wave_lds_sync();
+    ACC_STAMP_PATCH(4);
   }
 
   // ---- every wave parks its register copy in its own LDS slab (all waves at once), then the workgroup adds the slabs
@@ -905,6 +930,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
       out[i] = v;
     }
   }
+  ACC_STAMP(7);
 }
 
 // S = sum of the compact partials, mirrored; S_dd <- S_dd*(1+1e-4)+1 (ba_cuda.cu:517-518); y = sum.
@@ -1775,6 +1801,9 @@ static unsigned next_pow2(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; r
 using namespace devo;
 
 extern "C" {
+#ifdef DEVO_ACC_TRACE
+int devo_debug_acc_trace(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_acc_trace), sizeof(g_acc_trace)); }
+#endif
 
 size_t devo_ba_workspace_bytes(int E, int Np, int N) {
   if (E < 0 || Np < 0 || N < 0 || N > BA_MAXN) return 0;

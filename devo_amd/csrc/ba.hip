@@ -656,9 +656,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
 #ifdef DEVO_ACC_TRACE
 // debug build (tools/build_variant.sh acctrace ba -DDEVO_ACC_TRACE; tools/acc_trace.py): 100 MHz time stamps of every wave of the
 // last k_ba_accumulate_reg launch
-__device__ unsigned long long g_acc_trace[256 * 4 * 16];
+__device__ unsigned long long g_acc_trace[256 * 8 * 16];
 #define ACC_STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
-    if (lane == 0 && blockIdx.x < 256) g_acc_trace[(blockIdx.x * 4 + wave) * 16 + (i)] = wall_clock64(); } while (0)
+    if (lane == 0 && blockIdx.x < 256) g_acc_trace[(blockIdx.x * 8 + wave) * 16 + (i)] = wall_clock64(); } while (0)
 #define ACC_STAMP_FIRST(i) do { if (half == 0) ACC_STAMP(i); } while (0)      // the wave's first patch only
 #define ACC_STAMP_PATCH(i) ACC_STAMP((i) + 2 * half)
 #else
@@ -666,17 +666,26 @@ __device__ unsigned long long g_acc_trace[256 * 4 * 16];
 #define ACC_STAMP_FIRST(i) do { } while (0)
 #define ACC_STAMP_PATCH(i) do { } while (0)
 #endif
-constexpr int REG_WAVES = 4;      // 256 threads: one wave per SIMD, so the register copy of S never spills
-constexpr int REG_THREADS = REG_WAVES * 64;
+constexpr int REG_WAVES = 4;      // register fold: 256 threads, one wave per SIMD, so the register copy of S never spills
 constexpr int SCR_ROWS = 28;     // per-edge scratch rows: Jj_x[6] Jj_y[6] Ji_x[6] Ji_y[6] w_x w_y (w r)_x (w r)_y
+// Where a wave keeps its copy of the block triangle.
+//  LDSFOLD = false: in registers (105 accumulators per lane at N = 14: 256 VGPRs + 153 AGPRs, ONE wave per SIMD, WAVES = 4).  The
+//    fold is instruction-issue bound with nothing to interleave (profiles/README.md, r02c), and cfg2's 1440 patches meet 1024 waves:
+//    the kernel lasts two patches.
+//  LDSFOLD = true: in the wave's own LDS slab (the layout of the compact partial).  The first patch of a wave STORES its blocks (no
+//    zero-fill, no read), later ones read-modify-write; nothing is parked at the end.  ~150 registers: two waves per SIMD, WAVES =
+//    8 / 6 / 4 for N <= 11 / 14 / 16 by the LDS the slabs need — at cfg2 every wave has ONE patch.  Same sums in the same order per
+//    wave; the workgroup adds the slabs in wave order: deterministic like the register form.
+__host__ __device__ constexpr int scr_ld(bool ldsfold) { return ldsfold ? 48 : 64; }   // slots per scratch row (a regular patch has <= that many edges)
 
-template <int NMAX>
-__global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
+template <int NMAX, int WAVES, bool LDSFOLD>
+__global__ __launch_bounds__(WAVES * 64) void k_ba_accumulate_reg(
     const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
     const TargetSrc target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
     const int* __restrict__ perm, const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int P, int t0,
     int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ patch_col, int iter, int sig, int max_seg) {
+  constexpr int REG_WAVES = WAVES, REG_THREADS = WAVES * 64, SLD = scr_ld(LDSFOLD);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n6 = 6 * N, LD = n6 + 1;
   float* S_lds = smem;
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   ACC_STAMP(0);
   float* col = col_all + wave * n6;
-  float* scr = scr_all + wave * (SCR_ROWS * 64);
+  float* scr = scr_all + wave * (SCR_ROWS * SLD);
   __shared__ int s_used_atomic;                                 // did any wave of this workgroup take the atomic path?
   {
     const int nz = n6 * LD + n6, nz4 = nz >> 2;                 // smem is 16-byte aligned
@@ -701,10 +710,14 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
 
   ACC_STAMP(1);
   const int pa = (lane < 36) ? lane / 6 : 0, pb = (lane < 36) ? lane % 6 : 0;    // this lane's position inside a 6x6 block
-  float Sreg[NMAX * (NMAX + 1) / 2];
+  float Sreg[LDSFOLD ? 1 : NMAX * (NMAX + 1) / 2];
 #pragma unroll
-  for (int i = 0; i < NMAX * (NMAX + 1) / 2; i++) Sreg[i] = 0.0f;
+  for (int i = 0; i < (LDSFOLD ? 1 : NMAX * (NMAX + 1) / 2); i++) Sreg[i] = 0.0f;
   float yreg[2] = {0.0f, 0.0f};                                 // rows lane, lane + 64  (n6 <= 96)
+  const int nt = tri_blocks(N) * 36;
+  float* tri_all = scr_all + REG_WAVES * (SCR_ROWS * SLD);     // [REG_WAVES][nt + n6]
+  float* tri = tri_all + wave * (nt + n6);                     // this wave's compact copy (LDSFOLD) / parking slab
+  bool fresh = true;                                           // LDSFOLD: nothing in the slab yet — the first patch stores
 
   // a workspace that was not prepared for this (E, N) is not touched: the call fails (status -1) instead of walking
   // garbage tables; a prepared graph may be solved many times (the sticky failure flag is reset here)
@@ -749,7 +762,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     // behind the N frame slots (fixed target frames only matter for the source-frame sums)
     const unsigned long long fixm = __ballot(act && jx < 0);
     const int nslot = N + __popcll(fixm);
-    if (mixed || __ballot(dup) != 0ULL || nslot > 64) {
+    if (mixed || __ballot(dup) != 0ULL || nslot > SLD) {
       if (lane == 0) s_used_atomic = 1;
       accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane);
       continue;
@@ -760,7 +773,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     // ---- per-edge quantities into the wave's scratch [row][slot]; the patch's E column into `col`
     for (int i = lane; i < n6; i += 64) col[i] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < SCR_ROWS; r++) scr[r * 64 + lane] = 0.0f;          // frames without an edge read zeros
+    for (int r = 0; r < SCR_ROWS; r++) if (lane < SLD) scr[r * SLD + lane] = 0.0f;          // frames without an edge read zeros
     const float wz0 = T.w[0] * T.Jz[0], wz1 = T.w[1] * T.Jz[1];
     const float wr0 = T.w[0] * T.r[0], wr1 = T.w[1] * T.r[1];
     float Csum = wz0 * T.Jz[0] + wz1 * T.Jz[1];
@@ -775,13 +788,13 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     if (act) {
 #pragma unroll
       for (int c = 0; c < 6; c++) {
-        scr[c * 64 + slot] = T.Jj[0][c];
-        scr[(6 + c) * 64 + slot] = T.Jj[1][c];
-        scr[(12 + c) * 64 + slot] = (ix >= 0) ? T.Ji[0][c] : 0.0f;
-        scr[(18 + c) * 64 + slot] = (ix >= 0) ? T.Ji[1][c] : 0.0f;
+        scr[c * SLD + slot] = T.Jj[0][c];
+        scr[(6 + c) * SLD + slot] = T.Jj[1][c];
+        scr[(12 + c) * SLD + slot] = (ix >= 0) ? T.Ji[0][c] : 0.0f;
+        scr[(18 + c) * SLD + slot] = (ix >= 0) ? T.Ji[1][c] : 0.0f;
       }
-      scr[24 * 64 + slot] = T.w[0]; scr[25 * 64 + slot] = T.w[1];
-      scr[26 * 64 + slot] = wr0;    scr[27 * 64 + slot] = wr1;
+      scr[24 * SLD + slot] = T.w[0]; scr[25 * SLD + slot] = T.w[1];
+      scr[26 * SLD + slot] = wr0;    scr[27 * SLD + slot] = wr1;
       if (jx >= 0) {
 #pragma unroll
         for (int c = 0; c < 6; c++) col[6 * jx + c] = ej[c];    // distinct target frames: plain stores
@@ -810,7 +823,7 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
     {
       constexpr int NSL = ((NMAX + 3) / 4) * 4;
       auto ld4 = [&](int row, int g4, float (&o)[4]) {
-        const float4 t = *reinterpret_cast<const float4*>(scr + row * 64 + 4 * g4);
+        const float4 t = *reinterpret_cast<const float4*>(scr + row * SLD + 4 * g4);
         o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
       };
       {
@@ -828,14 +841,42 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
             cc[f] = col[6 * f + pb];
           }
         }
-        int blk = 0;
+        auto block_value = [&](int fr, int fc) {
+          float v = -Q * cr[fr] * cc[fc];                        // Schur: S -= Q e e^T  (:511)
+          if (fr == fc) v += Dg[fr];
+          return v;
+        };
+        if constexpr (LDSFOLD) {
+          // the slab has tri_blocks(N) blocks (fr < N: wave-uniform).  First patch of the wave: stores only; later ones: a block
+          // row's old values are fetched together (one LDS latency per row, not per block), then added and stored
+          float* tp = tri + lane;
+          if (lane < 36) {
+            if (fresh) {
+              int blk = 0;
 #pragma unroll
-        for (int fr = 0; fr < NMAX; fr++) {
+              for (int fr = 0; fr < NMAX; fr++) {
 #pragma unroll
-          for (int fc = 0; fc <= fr; fc++, blk++) {
-            float v = -Q * cr[fr] * cc[fc];                      // Schur: S -= Q e e^T  (:511)
-            if (fr == fc) v += Dg[fr];
-            Sreg[blk] += v;
+                for (int fc = 0; fc <= fr; fc++, blk++) if (fr < N) tp[blk * 36] = block_value(fr, fc);
+              }
+            } else {
+#pragma unroll
+              for (int fr = 0; fr < NMAX; fr++) {
+                if (fr < N) {
+                  float old[NMAX];
+#pragma unroll
+                  for (int fc = 0; fc <= fr; fc++) old[fc] = tp[(fr * (fr + 1) / 2 + fc) * 36];
+#pragma unroll
+                  for (int fc = 0; fc <= fr; fc++) tp[(fr * (fr + 1) / 2 + fc) * 36] = old[fc] + block_value(fr, fc);
+                }
+              }
+            }
+          }
+        } else {
+          int blk = 0;
+#pragma unroll
+          for (int fr = 0; fr < NMAX; fr++) {
+#pragma unroll
+            for (int fc = 0; fc <= fr; fc++, blk++) Sreg[blk] += block_value(fr, fc);
           }
         }
       }
@@ -860,16 +901,28 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
           }
         }
         for (int q = NSL; q < nslot; q++)                        // more fixed-target edges than spare slots (rare)
-          bii += scr[24 * 64 + q] * scr[(12 + pa) * 64 + q] * scr[(12 + pb) * 64 + q] +
-                 scr[25 * 64 + q] * scr[(18 + pa) * 64 + q] * scr[(18 + pb) * 64 + q];
+          bii += scr[24 * SLD + q] * scr[(12 + pa) * SLD + q] * scr[(12 + pb) * SLD + q] +
+                 scr[25 * SLD + q] * scr[(18 + pa) * SLD + q] * scr[(18 + pb) * SLD + q];
+        if constexpr (LDSFOLD) {
+          // the N blocks of row / column `src` of the slab, after pass 1's stores to the same addresses (LDS is in order)
 #pragma unroll
-        for (int sf = 0; sf < NMAX; sf++) {
-          if (src == sf) {                                       // wave-uniform
+          for (int f = 0; f < NMAX; f++) {
+            if (f < N && lane < 36) {
+              const int blk = (f < src) ? src * (src + 1) / 2 + f : f * (f + 1) / 2 + src;          // wave-uniform
+              const float d = (f < src) ? -Cq[f] : (f > src) ? -Rr[f] : bii - (Rr[f] + Cq[f]);
+              tri[blk * 36 + lane] += d;
+            }
+          }
+        } else {
 #pragma unroll
-            for (int fc = 0; fc < sf; fc++) Sreg[sf * (sf + 1) / 2 + fc] -= Cq[fc];
+          for (int sf = 0; sf < NMAX; sf++) {
+            if (src == sf) {                                       // wave-uniform
 #pragma unroll
-            for (int fr = sf + 1; fr < NMAX; fr++) Sreg[fr * (fr + 1) / 2 + sf] -= Rr[fr];
-            Sreg[sf * (sf + 1) / 2 + sf] += bii - (Rr[sf] + Cq[sf]);
+              for (int fc = 0; fc < sf; fc++) Sreg[sf * (sf + 1) / 2 + fc] -= Cq[fc];
+#pragma unroll
+              for (int fr = sf + 1; fr < NMAX; fr++) Sreg[fr * (fr + 1) / 2 + sf] -= Rr[fr];
+              Sreg[sf * (sf + 1) / 2 + sf] += bii - (Rr[sf] + Cq[sf]);
+            }
           }
         }
       }
@@ -882,34 +935,54 @@ __global__ __launch_bounds__(REG_THREADS) void k_ba_accumulate_reg(
       if (r < n6) {
         const int f = r / 6, a = r - 6 * f;
         float v = -Q * usum * col[r];
-        v += scr[26 * 64 + f] * scr[a * 64 + f] + scr[27 * 64 + f] * scr[(6 + a) * 64 + f];
-        if (f == src)
-          for (int q = 0; q < nslot; q++) v -= scr[26 * 64 + q] * scr[(12 + a) * 64 + q] + scr[27 * 64 + q] * scr[(18 + a) * 64 + q];
-        yreg[g] += v;
+        v += scr[26 * SLD + f] * scr[a * SLD + f] + scr[27 * SLD + f] * scr[(6 + a) * SLD + f];
+        if (f == src) {                                          // v_i -= sum over the patch's edges of w r Ji: wide reads, no latency chain
+          constexpr int NSL = ((NMAX + 3) / 4) * 4;
+          float acc = 0.0f;
+#pragma unroll
+          for (int g4 = 0; g4 < NSL / 4; g4++) {
+            const float4 p0 = *reinterpret_cast<const float4*>(scr + 26 * SLD + 4 * g4), p1 = *reinterpret_cast<const float4*>(scr + 27 * SLD + 4 * g4);
+            const float4 j0 = *reinterpret_cast<const float4*>(scr + (12 + a) * SLD + 4 * g4), j1 = *reinterpret_cast<const float4*>(scr + (18 + a) * SLD + 4 * g4);
+            acc += p0.x * j0.x + p1.x * j1.x;
+            acc += p0.y * j0.y + p1.y * j1.y;
+            acc += p0.z * j0.z + p1.z * j1.z;
+            acc += p0.w * j0.w + p1.w * j1.w;
+          }
+          for (int q = NSL; q < nslot; q++) acc += scr[26 * SLD + q] * scr[(12 + a) * SLD + q] + scr[27 * SLD + q] * scr[(18 + a) * SLD + q];
+          v -= acc;
+        }
+        if constexpr (LDSFOLD) {
+          float* yp = tri + nt + r;
+          if (fresh) *yp = v;                                    // (wave-uniform)
+          else *yp += v;
+        } else yreg[g] += v;
       }
     }
+    fresh = false;
     wave_lds_sync();
     ACC_STAMP_PATCH(4);
   }
 
-  // ---- every wave parks its register copy in its own LDS slab (all waves at once), then the workgroup adds the slabs
-  //      and the atomic-path system in a fixed order and writes the compact partial
-  float* tri_all = scr_all + REG_WAVES * (SCR_ROWS * 64);     // [REG_WAVES][nt + n6]
-  const int nt = tri_blocks(N) * 36;
+  // ---- register form: every wave parks its register copy in its own LDS slab (all waves at once); LDS form: the slab is
+  //      complete (a wave without a regular patch clears it).  Then the workgroup adds the slabs and the atomic-path system
+  //      in a fixed order and writes the compact partial
   if (N > 0) {
-    float* tri = tri_all + wave * (nt + n6);
-    if (lane < 36) {
-      int blk = 0;
+    if constexpr (LDSFOLD) {
+      if (fresh) for (int i = lane; i < nt + n6; i += 64) tri[i] = 0.0f;
+    } else {
+      if (lane < 36) {
+        int blk = 0;
 #pragma unroll
-      for (int fr = 0; fr < NMAX; fr++) {
+        for (int fr = 0; fr < NMAX; fr++) {
 #pragma unroll
-        for (int fc = 0; fc <= fr; fc++, blk++) {
-          if (fr < N) tri[blk * 36 + lane] = Sreg[blk];
+          for (int fc = 0; fc <= fr; fc++, blk++) {
+            if (fr < N) tri[blk * 36 + lane] = Sreg[blk];
+          }
         }
       }
-    }
 #pragma unroll
-    for (int g = 0; g < 2; g++) if (lane + 64 * g < n6) tri[nt + lane + 64 * g] = yreg[g];
+      for (int g = 0; g < 2; g++) if (lane + 64 * g < n6) tri[nt + lane + 64 * g] = yreg[g];
+    }
   }
   __syncthreads();
   if (N > 0) {
@@ -1765,13 +1838,36 @@ struct BaLayout {
   size_t meta, rank, counts, cursor, ku, perm_a, perm_b, kx, partials, S, y, dX, patch_rec, edge_ej, prec, ybar, total;
   int max_seg, n_part;
 };
+// Form of the register-path accumulate kernel (N <= 16) and its waves per workgroup — DEVO_BA_REGFOLD=1: the register fold.
+struct AccCfg { int waves; bool ldsfold; };
+static AccCfg acc_cfg(int N) {
+  static const bool regfold = getenv("DEVO_BA_REGFOLD") != nullptr;
+  if (regfold || N > 16) return {REG_WAVES, false};
+  return {N <= 11 ? 8 : N <= 14 ? 6 : 4, true};               // what 160 KB of LDS hold: WAVES slabs + scratch + the atomic-path system
+}
+static size_t acc_reg_lds_bytes(int N, const AccCfg& c) {
+  const size_t n6 = 6 * (size_t)N;
+  return sizeof(float) * (n6 * (n6 + 1) + n6 + c.waves * n6 + 4 + (size_t)c.waves * SCR_ROWS * scr_ld(c.ldsfold) +
+                          c.waves * ((size_t)N * (N + 1) / 2 * 36 + n6));
+}
+typedef void (*acc_fn_t)(const float*, const float*, const float*, TargetSrc, const float*, const float*, const int64_t*,
+                         const int64_t*, const int64_t*, const int*, const int*, BaMeta*, int, int, int, float*, float*,
+                         float*, int, int, int);
+static acc_fn_t acc_reg_fn(int N, const AccCfg& c) {
+  if (!c.ldsfold) return (N <= 8) ? k_ba_accumulate_reg<8, 4, false> : (N <= 11) ? k_ba_accumulate_reg<11, 4, false> :
+                         (N <= 14) ? k_ba_accumulate_reg<14, 4, false> : k_ba_accumulate_reg<16, 4, false>;
+  return (N <= 8) ? k_ba_accumulate_reg<8, 8, true> : (N <= 11) ? k_ba_accumulate_reg<11, 8, true> :
+         (N <= 14) ? k_ba_accumulate_reg<14, 6, true> : k_ba_accumulate_reg<16, 4, true>;
+}
+
 static BaLayout ba_layout(int E, int Np, int N) {
   BaLayout L;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   L.max_seg = E < Np ? E : Np;
   if (L.max_seg < 1) L.max_seg = 1;
-  int want = (L.max_seg + REG_WAVES - 1) / REG_WAVES;
+  const int acc_waves = acc_cfg(N).waves;
+  int want = (L.max_seg + acc_waves - 1) / acc_waves;
   L.n_part = want < ACC_MAX_WG ? (want < 1 ? 1 : want) : ACC_MAX_WG;
   const size_t n6 = 6 * (size_t)N;
   L.meta = take(sizeof(BaMeta));
@@ -1998,13 +2094,9 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 72 * (size_t)N + n6 + 4);
   static const bool force_generic = getenv("DEVO_BA_GENERIC") != nullptr;   // test switch: the general accumulate kernel for every N
   const bool use_reg = (N <= 16) && !force_generic;
-  const size_t acc_lds_used = use_reg ? sizeof(float) * (n6 * (n6 + 1) + n6 + REG_WAVES * n6 + 4 + REG_WAVES * SCR_ROWS * 64 +
-                                                        REG_WAVES * ((size_t)N * (N + 1) / 2 * 36 + n6)) : acc_lds;
-  typedef void (*acc_fn_t)(const float*, const float*, const float*, TargetSrc, const float*, const float*, const int64_t*,
-                           const int64_t*, const int64_t*, const int*, const int*, BaMeta*, int, int, int, float*, float*,
-                           float*, int, int, int);
-  acc_fn_t acc_fn = k_ba_accumulate;
-  if (use_reg) acc_fn = (N <= 8) ? k_ba_accumulate_reg<8> : (N <= 11) ? k_ba_accumulate_reg<11> : (N <= 14) ? k_ba_accumulate_reg<14> : k_ba_accumulate_reg<16>;
+  const AccCfg cfg = acc_cfg(N);
+  const size_t acc_lds_used = use_reg ? acc_reg_lds_bytes(N, cfg) : acc_lds;
+  acc_fn_t acc_fn = use_reg ? acc_reg_fn(N, cfg) : k_ba_accumulate;
   if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds_used) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
@@ -2017,7 +2109,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   static const bool schur_inline = getenv("DEVO_BA_SCHUR_INLINE") != nullptr;
   const bool defer = !use_reg && N > 0 && !schur_inline;
   for (int it = 0; it < iterations; it++) {
-    hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? REG_THREADS : ACC_THREADS), acc_lds_used, st, poses, patches, intrinsics, target,
+    hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? cfg.waves * 64 : ACC_THREADS), acc_lds_used, st, poses, patches, intrinsics, target,
                        weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, it | (defer ? 1 << 16 : 0), ba_sig(E, N), L.max_seg);
     if ((rc = check_launch("devo_ba_forward(accumulate)"))) return rc;
     if (N > 0) {
@@ -2072,13 +2164,9 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
   const size_t acc_lds = sizeof(float) * (n6 * (n6 + 1) + n6 + ACC_WAVES * n6 + 4);
   const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 72 * (size_t)N + n6 + 4);
   const bool use_reg = N <= 16;
-  const size_t acc_lds_used = use_reg ? sizeof(float) * (n6 * (n6 + 1) + n6 + REG_WAVES * n6 + 4 + REG_WAVES * SCR_ROWS * 64 +
-                                                        REG_WAVES * ((size_t)N * (N + 1) / 2 * 36 + n6)) : acc_lds;
-  typedef void (*acc_fn_t)(const float*, const float*, const float*, TargetSrc, const float*, const float*, const int64_t*,
-                           const int64_t*, const int64_t*, const int*, const int*, BaMeta*, int, int, int, float*, float*,
-                           float*, int, int, int);
-  acc_fn_t acc_fn = k_ba_accumulate;
-  if (use_reg) acc_fn = (N <= 8) ? k_ba_accumulate_reg<8> : (N <= 11) ? k_ba_accumulate_reg<11> : (N <= 14) ? k_ba_accumulate_reg<14> : k_ba_accumulate_reg<16>;
+  const AccCfg cfg = acc_cfg(N);
+  const size_t acc_lds_used = use_reg ? acc_reg_lds_bytes(N, cfg) : acc_lds;
+  acc_fn_t acc_fn = use_reg ? acc_reg_fn(N, cfg) : k_ba_accumulate;
   if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds_used) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
@@ -2091,7 +2179,7 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
   const bool defer = !use_reg && N > 0 && !schur_inline;
   // (poses / patches / intrinsics / weight are not read in terms mode; lmbda doubles as the 4-float intrinsics read)
   const TargetSrc src{nullptr, nullptr, 0, 0, 0, terms};
-  hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? REG_THREADS : ACC_THREADS), acc_lds_used, st, (const float*)nullptr, (const float*)nullptr,
+  hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? cfg.waves * 64 : ACC_THREADS), acc_lds_used, st, (const float*)nullptr, (const float*)nullptr,
                      (const float*)(w + L.y) /* 4 readable floats */, src, (const float*)nullptr, lmbda, ii, jj, kk, (int*)(w + L.perm_b), (int*)(w + L.counts),
                      meta, 3, t0, N, (float*)(w + L.partials), patch_rec, patch_col, defer ? 1 << 16 : 0, ba_sig(E, N), L.max_seg);
   if ((rc = check_launch("devo_ba_solve_terms(accumulate)"))) return rc;

@@ -28,15 +28,16 @@ for _ in range(3):
     p, q = poses.clone(), patches.clone()
     cuda_ba.forward(p, q, intr, target, weight, lmbda, ii, jj, kk, 1, n, 1, ws=ws)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * (256 * 4 * 16))()
+buf = (ctypes.c_ulonglong * (256 * 8 * 16))()
 lib = L.lib()
 rc = lib.devo_debug_acc_trace(buf)
 assert rc == 0, rc
-t = np.array(buf, dtype=np.float64).reshape(256, 4, 16)
+t = np.array(buf, dtype=np.float64).reshape(256, 8, 16)
 t0 = t[:, :, 0][t[:, :, 0] > 0].min()
 names = {0: "entry", 1: "LDS zeroed + barrier", 2: "edge slots loaded", 3: "edge terms, patch 1", 8: "  regular? + slots", 9: "  scratch + wave sums", 10: "  fold pass 1", 11: "  fold pass 2",
          4: "patch 1 folded (+ rhs)", 5: "edge terms, patch 2", 6: "patch 2 folded", 7: "partials written"}
 for i, nm in names.items():
     v = t[:, :, i]
     v = (v[v > 0] - t0) / 100.0
+    if v.size == 0: continue
     print(f"{nm:24s} waves {v.size:5d}  first {v.min():6.2f}  mean {v.mean():6.2f}  last {v.max():6.2f} us")

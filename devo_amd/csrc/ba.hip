@@ -1141,6 +1141,9 @@ __global__ void k_ba_damp(float* __restrict__ S, int N, float ep, const float* _
 #define DEVO_SOLVE_THREADS 1024
 #endif
 constexpr int SOLVE_THREADS = DEVO_SOLVE_THREADS;
+#ifndef DEVO_SOLVE_LOOKAHEAD
+#define DEVO_SOLVE_LOOKAHEAD 1                      // 0: every panel thread factors the diagonal block itself (round 1; A/B builds)
+#endif
 
 __device__ __forceinline__ bool chol6(float L[6][6], float inv[6]) {   // in-register lower Cholesky of a 6x6 block
   bool ok = true;                                                      // inv[c] = 1 / L[c][c]
@@ -1206,6 +1209,108 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
 
   const unsigned long long st1 = stamps ? __builtin_readcyclecounter() : 0ull;
   unsigned long long ph_panel = 0, ph_update = 0;
+#if DEVO_SOLVE_LOOKAHEAD
+  // Look-ahead: the 6x6 diagonal block of step jb + 1 is brought up to date and factored by ONE wave (the last) while the other
+  // waves run the trailing update of step jb — the serial rsq chain of the block factorisation leaves the panel phase.  The
+  // tiles of that block (t < 6) are nobody else's; its updated values only ever feed the factorisation, so they are not written
+  // back.  Same operations in the same order as the plain form: bit-identical factors.
+  __shared__ float s_dblk[36];
+  constexpr int LA_WAVE = SOLVE_THREADS / 64 - 1;
+  auto factor_block = [&](int jb1) {                // all lanes of the calling wave; s_dblk holds the block's lower triangle
+    float L[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c <= a; c++) L[a][c] = s_dblk[a * 6 + c];
+    float inv[6];
+    const bool ok = chol6(L, inv);
+    if ((tid & 63) == 0) {
+      if (!ok) s_fail = 1;
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int c = 0; c <= a; c++) Ld[jb1 * 36 + a * 6 + c] = (a == c) ? inv[a] : L[a][c];
+    }
+  };
+  if (tid < 64) {                                   // block 0 as it was loaded
+    if (tid < 36 && tid % 6 <= tid / 6) s_dblk[tid] = A[(tid / 6) * LD + tid % 6];
+    wave_lds_sync();
+    factor_block(0);
+  }
+  __syncthreads();
+  for (int jb = 0; jb < N; jb++) {
+    const unsigned long long pa = stamps ? __builtin_readcyclecounter() : 0ull;
+    const int j0 = 6 * jb;
+    const int r = j0 + 6 + tid;                  // this thread's panel row (if any)
+    if (r < rows) {                              // panel:  x L_bb^T = A[r][block], L_bb from the look-ahead (broadcast reads)
+      float Lb[6][6], inv[6], x[6];
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int c = 0; c < a; c++) Lb[a][c] = Ld[jb * 36 + a * 6 + c];
+        inv[a] = Ld[jb * 36 + a * 7];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        float v = A[r * LD + j0 + c];
+#pragma unroll
+        for (int k = 0; k < c; k++) v -= x[k] * Lb[c][k];
+        x[c] = v * inv[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) A[r * LD + j0 + c] = x[c];
+    }
+    __syncthreads();
+    const unsigned long long pb = stamps ? __builtin_readcyclecounter() : 0ull;
+    const bool next = jb + 1 < N;
+    if (next && (tid >> 6) == LA_WAVE) {
+      const int l = tid & 63, a = l / 6, c = l % 6, j1 = j0 + 6;
+      if (l < 36 && c <= a) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc += A[(j1 + a) * LD + j0 + q] * A[(j1 + c) * LD + j0 + q];
+        s_dblk[a * 6 + c] = A[(j1 + a) * LD + j1 + c] - acc;
+      }
+      wave_lds_sync();
+      factor_block(jb + 1);
+    }
+    // trailing update of the lower triangle (and of the rhs row) in 2x2 tiles; inputs = the panel columns, outputs =
+    // the columns to their right (disjoint), so everything is fetched before anything is written back
+    const int rem = rows - (j0 + 6);
+    const int nt = (rem + 1) / 2;                // tiles per side
+    const int ntiles = nt * (nt + 1) / 2;
+    for (int k = 0; tid + SOLVE_THREADS * k < ntiles; k++) {
+      const int t = tid + SOLVE_THREADS * k;
+      if (next && t < 6) continue;               // the next diagonal block: the look-ahead wave's
+      int yy, xx;
+      if (k == 0) { yy = ty; xx = tx; }
+      else tile_of(t, yy, xx);                   // large N only: more tiles than threads
+      const int r0 = j0 + 6 + 2 * yy, c0 = j0 + 6 + 2 * xx;
+      const bool r1ok = r0 + 1 < rows, c1ok = c0 + 1 < n6;          // second row / column inside the matrix
+      const int r1 = r1ok ? r0 + 1 : r0, c1 = c1ok ? c0 + 1 : c0;
+      if (c0 >= n6) continue;                    // the rhs row has no diagonal entry
+      float pa0[6], pa1[6], pb0[6], pb1[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        pa0[q] = A[r0 * LD + j0 + q]; pa1[q] = A[r1 * LD + j0 + q];
+        pb0[q] = A[c0 * LD + j0 + q]; pb1[q] = A[c1 * LD + j0 + q];
+      }
+      float o00 = A[r0 * LD + c0], o01 = A[r0 * LD + c1], o10 = A[r1 * LD + c0], o11 = A[r1 * LD + c1];
+      float v00 = 0.0f, v01 = 0.0f, v10 = 0.0f, v11 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        v00 += pa0[q] * pb0[q]; v01 += pa0[q] * pb1[q];
+        v10 += pa1[q] * pb0[q]; v11 += pa1[q] * pb1[q];
+      }
+      A[r0 * LD + c0] = o00 - v00;                                   // c0 <= r0 always (xx <= yy)
+      if (c1ok && c1 <= r0) A[r0 * LD + c1] = o01 - v01;             // above the diagonal on diagonal tiles: skip
+      if (r1ok) A[r1 * LD + c0] = o10 - v10;
+      if (r1ok && c1ok) A[r1 * LD + c1] = o11 - v11;
+    }
+    __syncthreads();
+    if (stamps) { const unsigned long long pc = __builtin_readcyclecounter(); ph_panel += pb - pa; ph_update += pc - pb; }
+  }
+#else
   for (int jb = 0; jb < N; jb++) {
     const unsigned long long pa = stamps ? __builtin_readcyclecounter() : 0ull;
     const int j0 = 6 * jb;
@@ -1275,6 +1380,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     __syncthreads();
     if (stamps) { const unsigned long long pc = __builtin_readcyclecounter(); ph_panel += pb - pa; ph_update += pc - pb; }
   }
+#endif
   const unsigned long long st2 = stamps ? __builtin_readcyclecounter() : 0ull;
   if (s_fail) {
     if (tid == 0) { meta->fail = iter + 1; if (status_flag) *status_flag = iter + 1; }

@@ -323,6 +323,16 @@ def test_ba_random_graphs(seed):
     check(run_ba(*s, t0, n, 2), ref)
 
 
+@pytest.mark.parametrize("n,M,t0", [(8, 300, 1), (11, 210, 2), (14, 150, 1), (16, 80, 1), (16, 80, 0)])
+def test_ba_with_more_patches_than_accumulate_waves(n, M, t0):
+    """the accumulate kernel keeps one copy of the block triangle per wave (LDS slab); with more patches than the launch has waves
+    (256 workgroups x 8 / 6 / 4 waves for N <= 11 / 14 / 16) a wave folds a second patch into a slab that is no longer fresh —
+    every size class, against the fp64 oracle; sigma 0.3 px keeps fp32 rounding inside 1e-4 at these sizes"""
+    s = scene(n=n, M=M, H=96, W=128, seed=70 + n, sigma=0.3, keep=0.9)
+    ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], t0, n, 2, dtype=torch.float64)
+    check(run_ba(*s, t0, n, 2), ref)
+
+
 @pytest.mark.parametrize("n", [22, 28])
 def test_ba_more_than_16_optimised_poses_uses_the_general_kernel(n):
     """N = t1 - t0 in 17..32: the LDS-atomic accumulate kernel (no register-resident S); the solve's back substitution keeps

@@ -12,6 +12,7 @@
 // row reduction is needed (dim = 384 -> 6 elements per lane), no atomics, fixed summation order.
 #include "common.h"
 #include <hip/hip_fp16.h>
+#include <initializer_list>
 
 namespace devo {
 
@@ -261,6 +262,206 @@ __global__ __launch_bounds__(256) void k_heads(const T* __restrict__ x, const T*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 16-byte forms of the row-wise kernels (dim a multiple of 4 floats / 8 halves, 16-byte aligned operands — the Update
+// operator's 384-wide rows): one 16-byte access per lane instead of a 2- / 4-byte one, 32-bit index arithmetic.  Same
+// element-wise arithmetic as the scalar forms above (which stay as the fallback for odd shapes).
+template <typename T> struct ChunkOf { static constexpr int V = 16 / (int)sizeof(T); };
+__device__ __forceinline__ void ldc(const float* p, float (&v)[4]) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void ldc(const __half* p, float (&v)[8]) {
+  const uint4 t = *reinterpret_cast<const uint4*>(p);
+  const __half2* h = reinterpret_cast<const __half2*>(&t);
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const float2 f = __half22float2(h[u]); v[2 * u] = f.x; v[2 * u + 1] = f.y; }
+}
+__device__ __forceinline__ void stc(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void stc(__half* p, const float (&v)[8]) {
+  uint4 t;
+  __half2* h = reinterpret_cast<__half2*>(&t);
+#pragma unroll
+  for (int u = 0; u < 4; u++) h[u] = __float22half2_rn(make_float2(v[2 * u], v[2 * u + 1]));
+  *reinterpret_cast<uint4*>(p) = t;
+}
+template <typename T> __device__ __forceinline__ float round_as(float v);           // the value a store + load of type T gives back
+template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_as<__half>(float v) { return __half2float(__float2half(v)); }
+
+template <typename T>
+__global__ void k_masked_gather_v(const T* __restrict__ src, const int64_t* __restrict__ idx, T* __restrict__ out, unsigned total, unsigned cpr) {
+  constexpr int V = ChunkOf<T>::V;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned e = i / cpr, q = i - e * cpr;
+    const int64_t j = idx[e];
+    uint4 t = make_uint4(0u, 0u, 0u, 0u);
+    if (j >= 0) t = *reinterpret_cast<const uint4*>(src + (j * cpr + q) * V);      // a copy: no conversion
+    *reinterpret_cast<uint4*>(out + ((int64_t)e * cpr + q) * V) = t;
+  }
+}
+
+template <typename T>
+__global__ void k_expand_add_v(T* __restrict__ net, const T* __restrict__ hy, const int* __restrict__ group_of, unsigned total, unsigned cpr) {
+  constexpr int V = ChunkOf<T>::V;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned e = i / cpr, q = i - e * cpr;
+    float a[V], b[V];
+    ldc(net + (int64_t)i * V, a);
+    ldc(hy + ((int64_t)group_of[e] * cpr + q) * V, b);
+#pragma unroll
+    for (int u = 0; u < V; u++) a[u] += b[u];
+    stc(net + (int64_t)i * V, a);
+  }
+}
+
+template <typename T>
+__global__ void k_gated_residual_v(const T* __restrict__ x, const T* __restrict__ gate, int64_t ld_gate, const T* __restrict__ res,
+                                   T* __restrict__ out, unsigned total, unsigned cpr) {
+  constexpr int V = ChunkOf<T>::V;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / cpr, q = i - r * cpr;
+    float xv[V], gv[V], rv[V];
+    ldc(x + (int64_t)i * V, xv); ldc(gate + (int64_t)r * ld_gate + q * V, gv); ldc(res + (int64_t)i * V, rv);
+#pragma unroll
+    for (int u = 0; u < V; u++) xv[u] += (1.0f / (1.0f + __expf(-gv[u]))) * rv[u];
+    stc(out + (int64_t)i * V, xv);
+  }
+}
+
+template <typename T>
+__global__ void k_gated_residual_bwd_v(const T* __restrict__ gate, int64_t ld_gate, const T* __restrict__ res, const T* __restrict__ dout,
+                                       T* __restrict__ dgate, T* __restrict__ dres, unsigned total, unsigned cpr) {
+  constexpr int V = ChunkOf<T>::V;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / cpr, q = i - r * cpr;
+    float gv[V], rv[V], dv[V], og[V], orr[V];
+    ldc(gate + (int64_t)r * ld_gate + q * V, gv); ldc(res + (int64_t)i * V, rv); ldc(dout + (int64_t)i * V, dv);
+#pragma unroll
+    for (int u = 0; u < V; u++) {
+      const float sg = 1.0f / (1.0f + __expf(-gv[u]));
+      og[u] = dv[u] * rv[u] * sg * (1.0f - sg);
+      orr[u] = dv[u] * sg;
+    }
+    stc(dgate + (int64_t)i * V, og); stc(dres + (int64_t)i * V, orr);
+  }
+}
+
+// k_heads with one 16-byte chunk per lane (cpr <= 64: one wave covers a row)
+template <typename T>
+__global__ __launch_bounds__(256) void k_heads_v(const T* __restrict__ x, const T* __restrict__ gate, int64_t ld_gate,
+                                                 const T* __restrict__ res, T* __restrict__ net_out, const T* __restrict__ Wd,
+                                                 const T* __restrict__ bd, const T* __restrict__ Ww, const T* __restrict__ bw,
+                                                 T* __restrict__ delta, T* __restrict__ weight, int64_t E, int dim, int cpr) {
+  constexpr int V = ChunkOf<T>::V;
+  const int lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= E) return;
+  float d0 = 0.0f, d1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
+  if (lane < cpr) {
+    const int c = lane * V;
+    float nv[V];
+    ldc(x + e * dim + c, nv);
+    if (gate) {
+      float gv[V], rv[V];
+      ldc(gate + e * ld_gate + c, gv); ldc(res + e * dim + c, rv);
+#pragma unroll
+      for (int u = 0; u < V; u++) nv[u] += rv[u] / (1.0f + __expf(-gv[u]));
+      stc(net_out + e * dim + c, nv);
+#pragma unroll
+      for (int u = 0; u < V; u++) nv[u] = round_as<T>(nv[u]);          // the heads see the stored (rounded) value, like separate kernels
+    }
+    float a0[V], a1[V], b0[V], b1[V];
+    ldc(Wd + c, a0); ldc(Wd + dim + c, a1); ldc(Ww + c, b0); ldc(Ww + dim + c, b1);
+#pragma unroll
+    for (int u = 0; u < V; u++) {
+      const float v = fmaxf(nv[u], 0.0f);
+      d0 += v * a0[u]; d1 += v * a1[u]; w0 += v * b0[u]; w1 += v * b1[u];
+    }
+  }
+  d0 = wsum(d0); d1 = wsum(d1); w0 = wsum(w0); w1 = wsum(w1);
+  if (lane == 0) {
+    st(delta + e * 2, d0 + ld(bd)); st(delta + e * 2 + 1, d1 + ld(bd + 1));
+    st(weight + e * 2, 1.0f / (1.0f + __expf(-(w0 + ld(bw)))));
+    st(weight + e * 2 + 1, 1.0f / (1.0f + __expf(-(w1 + ld(bw + 1)))));
+  }
+}
+
+// k_softagg with the rows of a group dealt to the four waves of the workgroup (a frame-pair group has ~100 rows: one thread
+// per channel walking them one after the other is a chain of ~100 dependent row latencies), 16-byte chunks per lane (NQ <= 2
+// chunks: dim <= 512 floats / 1024 halves), two rows in flight per wave; the four partial (max, normaliser, sum) triples are
+// merged through LDS.  Dynamic LDS: 12 * dim floats.
+template <typename T>
+__global__ __launch_bounds__(256) void k_softagg_v(const T* __restrict__ f, const T* __restrict__ g, int64_t ld_fg,
+                                                   const int* __restrict__ perm, const int* __restrict__ seg,
+                                                   const int* __restrict__ n_seg_p, T* __restrict__ y,
+                                                   int* __restrict__ group_of, int dim, int cpr) {
+  constexpr int V = ChunkOf<T>::V;
+  extern __shared__ float s_part[];                          // [3][4][dim]: max, normaliser, weighted sum of every wave
+  const int n_seg = *n_seg_p;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int s = blockIdx.x; s < n_seg; s += gridDim.x) {
+    const int a0 = seg[s], a1 = seg[s + 1];
+    float m[2][V], den[2][V], num[2][V];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+      for (int u = 0; u < V; u++) { m[k][u] = -3.0e38f; den[k][u] = 0.0f; num[k][u] = 0.0f; }
+    auto fold = [&](int k, const float (&gv)[V], const float (&fv)[V]) {
+#pragma unroll
+      for (int u = 0; u < V; u++) {
+        const float n = fmaxf(m[k][u], gv[u]);
+        const float r = __expf(m[k][u] - n), w = __expf(gv[u] - n);
+        den[k][u] = den[k][u] * r + w; num[k][u] = num[k][u] * r + fv[u] * w; m[k][u] = n;
+      }
+    };
+    for (int a = a0 + wave; a < a1; a += 8) {                // rows a and a + 4 of this wave together
+      const bool two = a + 4 < a1;
+      const int64_t e0 = perm[a], e1 = two ? perm[a + 4] : e0;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int q = lane + 64 * k;
+        if (q < cpr) {
+          float g0[V], f0[V], g1[V], f1[V];
+          ldc(g + e0 * ld_fg + q * V, g0); ldc(f + e0 * ld_fg + q * V, f0);
+          ldc(g + e1 * ld_fg + q * V, g1); ldc(f + e1 * ld_fg + q * V, f1);
+          fold(k, g0, f0);
+          if (two) fold(k, g1, f1);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int q = lane + 64 * k;
+      if (q < cpr) {
+#pragma unroll
+        for (int u = 0; u < V; u++) {
+          const int c = q * V + u;
+          s_part[(0 * 4 + wave) * dim + c] = m[k][u];
+          s_part[(1 * 4 + wave) * dim + c] = den[k][u];
+          s_part[(2 * 4 + wave) * dim + c] = num[k][u];
+        }
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < dim; c += 256) {
+      float M = s_part[c];
+#pragma unroll
+      for (int w = 1; w < 4; w++) M = fmaxf(M, s_part[w * dim + c]);
+      float dn = 0.0f, nm = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const float r = __expf(s_part[w * dim + c] - M);
+        dn += s_part[(4 + w) * dim + c] * r; nm += s_part[(8 + w) * dim + c] * r;
+      }
+      st(y + (int64_t)s * dim + c, nm / dn);
+    }
+    if (group_of)
+      for (int a = a0 + threadIdx.x; a < a1; a += 256) group_of[perm[a]] = s;
+    __syncthreads();                                         // s_part is reused by the next group
+  }
+}
+
 static unsigned grid_for(long long n, int per_block, int cap) {
   long long b = (n + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -278,6 +479,15 @@ using namespace devo;
     else if ((DT) == DEVO_F16) { CALL_F16; }                                                  \
     else { set_error("update ops: fp32 / fp16 only (dtype %d)", (int)(DT)); return DEVO_ERR_UNSUPPORTED; } \
   } while (0)
+
+// 16-byte forms apply when every row starts on a 16-byte boundary and the element count stays in 32 bits
+static bool upd_vec_ok(int dtype, int64_t rows, int dim, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds = {}) {
+  const int V = dtype == DEVO_F32 ? 4 : 8;
+  if (dim % V || rows * (dim / V) >= (1LL << 31)) return false;
+  for (const void* p : ptrs) if (reinterpret_cast<uintptr_t>(p) & 15) return false;
+  for (int64_t l : lds) if (l % V) return false;
+  return true;
+}
 
 extern "C" {
 
@@ -312,6 +522,14 @@ int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64
   DEVO_REQUIRE(E >= 0 && dim > 0, "devo_upd_masked_gather: bad sizes");
   if (E == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
+  if (upd_vec_ok(dtype, E, dim, {src, out})) {
+    const unsigned cpr = (unsigned)(dim / (dtype == DEVO_F32 ? 4 : 8)), total = (unsigned)(E * cpr);
+    const dim3 vgrid(grid_for(total, 256, 16384)), vblock(256);
+    UPD_DISPATCH(dtype,
+      hipLaunchKernelGGL(k_masked_gather_v<float>, vgrid, vblock, 0, st_, (const float*)src, idx, (float*)out, total, cpr),
+      hipLaunchKernelGGL(k_masked_gather_v<__half>, vgrid, vblock, 0, st_, (const __half*)src, idx, (__half*)out, total, cpr));
+    return check_launch("devo_upd_masked_gather");
+  }
   const dim3 grid(grid_for(E * dim, 256, 8192)), block(256);
   UPD_DISPATCH(dtype,
     hipLaunchKernelGGL(k_masked_gather<float>, grid, block, 0, st_, (const float*)src, idx, (float*)out, E, dim),
@@ -325,6 +543,15 @@ int devo_upd_softagg(const void* f, const void* g, int64_t ld_fg, const int* per
   DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y)) & 7) == 0, "devo_upd_softagg: operands must be 8-byte aligned");
   if (E == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
+  if (upd_vec_ok(dtype, E, dim, {f, g}, {ld_fg}) && dim / (dtype == DEVO_F32 ? 4 : 8) <= 128) {
+    const int cpr = dim / (dtype == DEVO_F32 ? 4 : 8);
+    const dim3 vgrid(grid_for(E, 1, 4096)), vblock(256);
+    const size_t lds = sizeof(float) * 12 * (size_t)dim;
+    UPD_DISPATCH(dtype,
+      hipLaunchKernelGGL(k_softagg_v<float>, vgrid, vblock, lds, st_, (const float*)f, (const float*)g, ld_fg, perm, seg_start, n_seg, (float*)y, group_of, dim, cpr),
+      hipLaunchKernelGGL(k_softagg_v<__half>, vgrid, vblock, lds, st_, (const __half*)f, (const __half*)g, ld_fg, perm, seg_start, n_seg, (__half*)y, group_of, dim, cpr));
+    return check_launch("devo_upd_softagg");
+  }
   const dim3 grid(grid_for(E * ((dim + 511) / 512), 1, 4096)), block(256);
   UPD_DISPATCH(dtype,
     hipLaunchKernelGGL(k_softagg<float>, grid, block, 0, st_, (const float*)f, (const float*)g, ld_fg, perm, seg_start, n_seg, (float*)y, group_of, dim),
@@ -351,6 +578,14 @@ int devo_upd_expand_add(void* net, const void* hy, const int* group_of, int64_t 
   DEVO_REQUIRE(E >= 0 && dim > 0, "devo_upd_expand_add: bad sizes");
   if (E == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
+  if (upd_vec_ok(dtype, E, dim, {net, hy})) {
+    const unsigned cpr = (unsigned)(dim / (dtype == DEVO_F32 ? 4 : 8)), total = (unsigned)(E * cpr);
+    const dim3 vgrid(grid_for(total, 256, 16384)), vblock(256);
+    UPD_DISPATCH(dtype,
+      hipLaunchKernelGGL(k_expand_add_v<float>, vgrid, vblock, 0, st_, (float*)net, (const float*)hy, group_of, total, cpr),
+      hipLaunchKernelGGL(k_expand_add_v<__half>, vgrid, vblock, 0, st_, (__half*)net, (const __half*)hy, group_of, total, cpr));
+    return check_launch("devo_upd_expand_add");
+  }
   const dim3 grid(grid_for(E * dim, 256, 8192)), block(256);
   UPD_DISPATCH(dtype,
     hipLaunchKernelGGL(k_expand_add<float>, grid, block, 0, st_, (float*)net, (const float*)hy, group_of, E, dim),
@@ -363,6 +598,14 @@ int devo_upd_gated_residual(const void* x, const void* gate, int64_t ld_gate, co
   DEVO_REQUIRE(rows >= 0 && dim > 0 && ld_gate >= dim, "devo_upd_gated_residual: bad sizes");
   if (rows == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
+  if (upd_vec_ok(dtype, rows, dim, {x, gate, res, out}, {ld_gate})) {
+    const unsigned cpr = (unsigned)(dim / (dtype == DEVO_F32 ? 4 : 8)), total = (unsigned)(rows * cpr);
+    const dim3 vgrid(grid_for(total, 256, 16384)), vblock(256);
+    UPD_DISPATCH(dtype,
+      hipLaunchKernelGGL(k_gated_residual_v<float>, vgrid, vblock, 0, st_, (const float*)x, (const float*)gate, ld_gate, (const float*)res, (float*)out, total, cpr),
+      hipLaunchKernelGGL(k_gated_residual_v<__half>, vgrid, vblock, 0, st_, (const __half*)x, (const __half*)gate, ld_gate, (const __half*)res, (__half*)out, total, cpr));
+    return check_launch("devo_upd_gated_residual");
+  }
   const dim3 grid(grid_for(rows * dim, 256, 8192)), block(256);
   UPD_DISPATCH(dtype,
     hipLaunchKernelGGL(k_gated_residual<float>, grid, block, 0, st_, (const float*)x, (const float*)gate, ld_gate, (const float*)res, (float*)out, rows, dim),
@@ -375,6 +618,14 @@ int devo_upd_gated_residual_backward(const void* gate, int64_t ld_gate, const vo
   DEVO_REQUIRE(rows >= 0 && dim > 0 && ld_gate >= dim, "devo_upd_gated_residual_backward: bad sizes");
   if (rows == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
+  if (upd_vec_ok(dtype, rows, dim, {gate, res, dout, dgate, dres}, {ld_gate})) {
+    const unsigned cpr = (unsigned)(dim / (dtype == DEVO_F32 ? 4 : 8)), total = (unsigned)(rows * cpr);
+    const dim3 vgrid(grid_for(total, 256, 16384)), vblock(256);
+    UPD_DISPATCH(dtype,
+      hipLaunchKernelGGL(k_gated_residual_bwd_v<float>, vgrid, vblock, 0, st_, (const float*)gate, ld_gate, (const float*)res, (const float*)dout, (float*)dgate, (float*)dres, total, cpr),
+      hipLaunchKernelGGL(k_gated_residual_bwd_v<__half>, vgrid, vblock, 0, st_, (const __half*)gate, ld_gate, (const __half*)res, (const __half*)dout, (__half*)dgate, (__half*)dres, total, cpr));
+    return check_launch("devo_upd_gated_residual_backward");
+  }
   const dim3 grid(grid_for(rows * dim, 256, 8192)), block(256);
   UPD_DISPATCH(dtype,
     hipLaunchKernelGGL(k_gated_residual_bwd<float>, grid, block, 0, st_, (const float*)gate, ld_gate, (const float*)res, (const float*)dout, (float*)dgate, (float*)dres, rows, dim),
@@ -389,6 +640,13 @@ int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void*
   if (E == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
   const dim3 grid((unsigned)((E + 3) / 4)), block(256);
+  if (upd_vec_ok(dtype, E, dim, {x, gate, res, net_out, Wd, Ww}, {gate ? ld_gate : 0}) && dim / (dtype == DEVO_F32 ? 4 : 8) <= 64) {
+    const int cpr = dim / (dtype == DEVO_F32 ? 4 : 8);
+    UPD_DISPATCH(dtype,
+      hipLaunchKernelGGL(k_heads_v<float>, grid, block, 0, st_, (const float*)x, (const float*)gate, ld_gate, (const float*)res, (float*)net_out, (const float*)Wd, (const float*)bd, (const float*)Ww, (const float*)bw, (float*)delta, (float*)weight, E, dim, cpr),
+      hipLaunchKernelGGL(k_heads_v<__half>, grid, block, 0, st_, (const __half*)x, (const __half*)gate, ld_gate, (const __half*)res, (__half*)net_out, (const __half*)Wd, (const __half*)bd, (const __half*)Ww, (const __half*)bw, (__half*)delta, (__half*)weight, E, dim, cpr));
+    return check_launch("devo_upd_heads");
+  }
   UPD_DISPATCH(dtype,
     hipLaunchKernelGGL(k_heads<float>, grid, block, 0, st_, (const float*)x, (const float*)gate, ld_gate, (const float*)res, (float*)net_out, (const float*)Wd, (const float*)bd, (const float*)Ww, (const float*)bw, (float*)delta, (float*)weight, E, dim),
     hipLaunchKernelGGL(k_heads<__half>, grid, block, 0, st_, (const __half*)x, (const __half*)gate, ld_gate, (const __half*)res, (__half*)net_out, (const __half*)Wd, (const __half*)bd, (const __half*)Ww, (const __half*)bw, (__half*)delta, (__half*)weight, E, dim));

@@ -37,3 +37,20 @@ for dtype in [d for d in (torch.float32, torch.float16) if not a.dtype or a.dtyp
         for _ in range(a.reps): fn()
         e1.record(); torch.cuda.synchronize()
         print(f"update op  E={E} dim=384 {str(dtype)[6:]:8s} {name:6s} {e0.elapsed_time(e1) / a.reps:8.3f} ms", flush=True)
+        if name == "hip":
+            # the same call replayed from a HIP graph (how a captured DEVO update step runs it): the eager figure above is bound by
+            # the host's launch rate (~25 launches), this one by the device
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    fn()
+            torch.cuda.current_stream().wait_stream(side)
+            for _ in range(3): graph.replay()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(a.reps): graph.replay()
+            e1.record(); torch.cuda.synchronize()
+            print(f"update op  E={E} dim=384 {str(dtype)[6:]:8s} {name + ', graph replay':18s} {e0.elapsed_time(e1) / a.reps:8.3f} ms", flush=True)

@@ -289,6 +289,140 @@ template <typename T> __device__ __forceinline__ float round_as(float v);       
 template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
 template <> __device__ __forceinline__ float round_as<__half>(float v) { return __half2float(__float2half(v)); }
 
+// k_layernorm with 16-byte chunks (up to two per lane: dim <= 512 floats / 1024 halves); same fused input terms
+template <typename T>
+__global__ __launch_bounds__(256) void k_layernorm_v(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ b,
+                                                     const T* __restrict__ hy, const int* __restrict__ group_of,
+                                                     const T* __restrict__ gate, int64_t ld_gate, const T* __restrict__ res,
+                                                     const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                     T* __restrict__ out, int64_t rows, int dim, float eps, int relu, int cpr) {
+  constexpr int V = ChunkOf<T>::V;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* hrow = hy ? hy + (int64_t)group_of[row] * dim : nullptr;
+  float v[2][V];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int c = (lane + 64 * k) * V;
+    if (lane + 64 * k < cpr) {
+      float t[V], u[V];
+      ldc(x + row * dim + c, t);
+      if (a) { ldc(a + row * dim + c, u);
+#pragma unroll
+        for (int i = 0; i < V; i++) t[i] += u[i]; }
+      if (b) { ldc(b + row * dim + c, u);
+#pragma unroll
+        for (int i = 0; i < V; i++) t[i] += u[i]; }
+      if (hrow) { ldc(hrow + c, u);
+#pragma unroll
+        for (int i = 0; i < V; i++) t[i] += u[i]; }
+      if (gate) {
+        float gv[V];
+        ldc(gate + row * ld_gate + c, gv); ldc(res + row * dim + c, u);
+#pragma unroll
+        for (int i = 0; i < V; i++) t[i] += u[i] / (1.0f + __expf(-gv[i]));
+      }
+#pragma unroll
+      for (int i = 0; i < V; i++) { v[k][i] = t[i]; s += t[i]; }
+    }
+  }
+  const float mean = wsum(s) / (float)dim;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+    if (lane + 64 * k < cpr) {
+#pragma unroll
+      for (int i = 0; i < V; i++) { const float d = v[k][i] - mean; q += d * d; }
+    }
+  const float rstd = rsqrtf(wsum(q) / (float)dim + eps);           // biased variance, like torch.nn.LayerNorm
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int c = (lane + 64 * k) * V;
+    if (lane + 64 * k < cpr) {
+      float gm[V], bt[V], o[V];
+      ldc(gamma + c, gm); ldc(beta + c, bt);
+#pragma unroll
+      for (int i = 0; i < V; i++) {
+        o[i] = (v[k][i] - mean) * rstd * gm[i] + bt[i];
+        if (relu) o[i] = fmaxf(o[i], 0.0f);
+      }
+      stc(out + row * dim + c, o);
+    }
+  }
+}
+
+// Sum over the 16 lanes of a DPP row, result in all of them (row_ror 8, 4, 2, 1): no LDS round trips.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+  return v;
+}
+
+// k_layernorm with a QUARTER wave per row (16 lanes x NC 16-byte chunks, cpr = 16 NC <= 128): four rows per wave, the two row
+// reductions inside a DPP row.  A whole wave per 768-byte row spends its time in two 6-step shuffle chains.
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void k_layernorm_q(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ b,
+                                                     const T* __restrict__ hy, const int* __restrict__ group_of,
+                                                     const T* __restrict__ gate, int64_t ld_gate, const T* __restrict__ res,
+                                                     const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                     T* __restrict__ out, int64_t rows, int dim, float eps, int relu) {
+  constexpr int V = ChunkOf<T>::V;
+  const int l16 = threadIdx.x & 15;
+  const int64_t row_raw = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = row_raw < rows;
+  const int64_t row = live ? row_raw : rows - 1;               // (all lanes stay active for the DPP sums)
+  const T* hrow = hy ? hy + (int64_t)group_of[row] * dim : nullptr;
+  float v[NC][V];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NC; k++) {
+    const int c = (l16 + 16 * k) * V;
+    float t[V], u[V];
+    ldc(x + row * dim + c, t);
+    if (a) { ldc(a + row * dim + c, u);
+#pragma unroll
+      for (int i = 0; i < V; i++) t[i] += u[i]; }
+    if (b) { ldc(b + row * dim + c, u);
+#pragma unroll
+      for (int i = 0; i < V; i++) t[i] += u[i]; }
+    if (hrow) { ldc(hrow + c, u);
+#pragma unroll
+      for (int i = 0; i < V; i++) t[i] += u[i]; }
+    if (gate) {
+      float gv[V];
+      ldc(gate + row * ld_gate + c, gv); ldc(res + row * dim + c, u);
+#pragma unroll
+      for (int i = 0; i < V; i++) t[i] += u[i] / (1.0f + __expf(-gv[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < V; i++) { v[k][i] = t[i]; s += t[i]; }
+  }
+  const float mean = row16_sum(s) / (float)dim;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NC; k++)
+#pragma unroll
+    for (int i = 0; i < V; i++) { const float d = v[k][i] - mean; q += d * d; }
+  const float rstd = rsqrtf(row16_sum(q) / (float)dim + eps);      // biased variance, like torch.nn.LayerNorm
+  if (!live) return;
+#pragma unroll
+  for (int k = 0; k < NC; k++) {
+    const int c = (l16 + 16 * k) * V;
+    float gm[V], bt[V], o[V];
+    ldc(gamma + c, gm); ldc(beta + c, bt);
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+      o[i] = (v[k][i] - mean) * rstd * gm[i] + bt[i];
+      if (relu) o[i] = fmaxf(o[i], 0.0f);
+    }
+    stc(out + row * dim + c, o);
+  }
+}
+
 template <typename T>
 __global__ void k_masked_gather_v(const T* __restrict__ src, const int64_t* __restrict__ idx, T* __restrict__ out, unsigned total, unsigned cpr) {
   constexpr int V = ChunkOf<T>::V;
@@ -381,6 +515,48 @@ __global__ __launch_bounds__(256) void k_heads_v(const T* __restrict__ x, const 
   }
   d0 = wsum(d0); d1 = wsum(d1); w0 = wsum(w0); w1 = wsum(w1);
   if (lane == 0) {
+    st(delta + e * 2, d0 + ld(bd)); st(delta + e * 2 + 1, d1 + ld(bd + 1));
+    st(weight + e * 2, 1.0f / (1.0f + __expf(-(w0 + ld(bw)))));
+    st(weight + e * 2 + 1, 1.0f / (1.0f + __expf(-(w1 + ld(bw + 1)))));
+  }
+}
+
+// k_heads with a quarter wave per edge (16 lanes x NC chunks), the four dot products summed inside a DPP row
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void k_heads_q(const T* __restrict__ x, const T* __restrict__ gate, int64_t ld_gate,
+                                                 const T* __restrict__ res, T* __restrict__ net_out, const T* __restrict__ Wd,
+                                                 const T* __restrict__ bd, const T* __restrict__ Ww, const T* __restrict__ bw,
+                                                 T* __restrict__ delta, T* __restrict__ weight, int64_t E, int dim) {
+  constexpr int V = ChunkOf<T>::V;
+  const int l16 = threadIdx.x & 15;
+  const int64_t e_raw = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = e_raw < E;
+  const int64_t e = live ? e_raw : E - 1;
+  float d0 = 0.0f, d1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NC; k++) {
+    const int c = (l16 + 16 * k) * V;
+    float nv[V];
+    ldc(x + e * dim + c, nv);
+    if (gate) {
+      float gv[V], rv[V];
+      ldc(gate + e * ld_gate + c, gv); ldc(res + e * dim + c, rv);
+#pragma unroll
+      for (int u = 0; u < V; u++) nv[u] += rv[u] / (1.0f + __expf(-gv[u]));
+      if (live) stc(net_out + e * dim + c, nv);
+#pragma unroll
+      for (int u = 0; u < V; u++) nv[u] = round_as<T>(nv[u]);          // the heads see the stored (rounded) value, like separate kernels
+    }
+    float a0[V], a1[V], b0[V], b1[V];
+    ldc(Wd + c, a0); ldc(Wd + dim + c, a1); ldc(Ww + c, b0); ldc(Ww + dim + c, b1);
+#pragma unroll
+    for (int u = 0; u < V; u++) {
+      const float v = fmaxf(nv[u], 0.0f);
+      d0 += v * a0[u]; d1 += v * a1[u]; w0 += v * b0[u]; w1 += v * b1[u];
+    }
+  }
+  d0 = row16_sum(d0); d1 = row16_sum(d1); w0 = row16_sum(w0); w1 = row16_sum(w1);
+  if (live && l16 == 0) {
     st(delta + e * 2, d0 + ld(bd)); st(delta + e * 2 + 1, d1 + ld(bd + 1));
     st(weight + e * 2, 1.0f / (1.0f + __expf(-(w0 + ld(bw)))));
     st(weight + e * 2 + 1, 1.0f / (1.0f + __expf(-(w1 + ld(bw + 1)))));
@@ -505,7 +681,17 @@ int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const 
                      al8(gamma) && al8(beta) && al8(out);
 #define LN_ARGS(TT) (const TT*)x, (const TT*)add1, (const TT*)add2, (const TT*)hy, group_of, (const TT*)gate, ld_gate, (const TT*)res, \
                     (const TT*)gamma, (const TT*)beta, (TT*)out, rows, dim, eps, relu
-  if (pairs) {
+  const bool vec = upd_vec_ok(dtype, rows, dim, {x, add1, add2, hy, gate, res, gamma, beta, out}, {gate ? ld_gate : 0});
+  if (vec && dtype == DEVO_F16 && dim == 384) {               // the Update operator's rows: quarter wave per row
+    hipLaunchKernelGGL((k_layernorm_q<__half, 3>), dim3((unsigned)((rows + 15) / 16)), block, 0, st_, LN_ARGS(__half));
+  } else if (vec && dtype == DEVO_F32 && dim == 384) {
+    hipLaunchKernelGGL((k_layernorm_q<float, 6>), dim3((unsigned)((rows + 15) / 16)), block, 0, st_, LN_ARGS(float));
+  } else if (vec && dim / (dtype == DEVO_F32 ? 4 : 8) <= 128) {
+    const int cpr = dim / (dtype == DEVO_F32 ? 4 : 8);
+    UPD_DISPATCH(dtype,
+      hipLaunchKernelGGL(k_layernorm_v<float>, grid, block, 0, st_, LN_ARGS(float), cpr),
+      hipLaunchKernelGGL(k_layernorm_v<__half>, grid, block, 0, st_, LN_ARGS(__half), cpr));
+  } else if (pairs) {
     UPD_DISPATCH(dtype,
       hipLaunchKernelGGL((k_layernorm<float, true>), grid, block, 0, st_, LN_ARGS(float)),
       hipLaunchKernelGGL((k_layernorm<__half, true>), grid, block, 0, st_, LN_ARGS(__half)));
@@ -640,7 +826,16 @@ int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void*
   if (E == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
   const dim3 grid((unsigned)((E + 3) / 4)), block(256);
-  if (upd_vec_ok(dtype, E, dim, {x, gate, res, net_out, Wd, Ww}, {gate ? ld_gate : 0}) && dim / (dtype == DEVO_F32 ? 4 : 8) <= 64) {
+  const bool hvec = upd_vec_ok(dtype, E, dim, {x, gate, res, net_out, Wd, Ww}, {gate ? ld_gate : 0});
+#define HEADS_ARGS(TT) (const TT*)x, (const TT*)gate, ld_gate, (const TT*)res, (TT*)net_out, (const TT*)Wd, (const TT*)bd, (const TT*)Ww, (const TT*)bw, (TT*)delta, (TT*)weight, E, dim
+  if (hvec && dim == 384 && (dtype == DEVO_F16 || dtype == DEVO_F32)) {          // the Update operator's rows: quarter wave per edge
+    const dim3 qgrid((unsigned)((E + 15) / 16));
+    if (dtype == DEVO_F16) hipLaunchKernelGGL((k_heads_q<__half, 3>), qgrid, block, 0, st_, HEADS_ARGS(__half));
+    else hipLaunchKernelGGL((k_heads_q<float, 6>), qgrid, block, 0, st_, HEADS_ARGS(float));
+    return check_launch("devo_upd_heads");
+  }
+#undef HEADS_ARGS
+  if (hvec && dim / (dtype == DEVO_F32 ? 4 : 8) <= 64) {
     const int cpr = dim / (dtype == DEVO_F32 ? 4 : 8);
     UPD_DISPATCH(dtype,
       hipLaunchKernelGGL(k_heads_v<float>, grid, block, 0, st_, (const float*)x, (const float*)gate, ld_gate, (const float*)res, (float*)net_out, (const float*)Wd, (const float*)bd, (const float*)Ww, (const float*)bw, (float*)delta, (float*)weight, E, dim, cpr),

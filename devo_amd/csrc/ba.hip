@@ -1064,8 +1064,7 @@ __global__ __launch_bounds__(256) void k_ba_schur(const float* __restrict__ patc
                                                   const BaMeta* __restrict__ meta, int N, int max_seg, float* __restrict__ S,
                                                   float* __restrict__ part) {
   __shared__ float sa[SCH_K][SCH_T + 1], sb[SCH_K][SCH_T + 1];      // rows block (scaled by -Q), columns block
-  const int n6 = 6 * N, LD = n6 + 1, dimA = n6 + 1;
-  const int nt = (dimA + SCH_T - 1) / SCH_T;
+  const int n6 = 6 * N, LD = n6 + 1;
   int tr = 0, tc = 0;
   {                                                                   // blockIdx.x -> lower-triangle tile (tr >= tc)
     int t = blockIdx.x;

@@ -21,7 +21,6 @@ namespace devo {
 constexpr int PP = 9;          // patch pixels (P = 3)
 constexpr int MAXD = 12;       // 2*R+2 for R <= 5
 constexpr int KC = CORR_KC;     // channels staged per LDS chunk
-constexpr int ROWPAD = CORR_ROWPAD; // LDS row stride of a staged position in floats
 constexpr int NT = 128;        // threads per workgroup (2 waves): one chunk of 128 box positions
 
 template <typename T> __device__ __forceinline__ float to_f32(T v);

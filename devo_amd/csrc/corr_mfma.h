@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_EPW) __attribute__((amdgpu_waves_per
   const int wgid = (NL == 1 && nlev == 2) ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : blockIdx.x;
   const int nwg = (NL == 1 && nlev == 2) ? (gridDim.x >> 1) : gridDim.x;
   constexpr bool HALF = sizeof(T) == 2;
-  constexpr int STEPCH = HALF ? 32 : 16;             // channels per step (four 16-byte pieces of a position)
+  // (a step is 32 channels of fp16 / 16 of fp32: four 16-byte pieces of a position)
   constexpr unsigned ESZ = sizeof(T);
   auto second = [&](int l) -> bool { return NL == 2 ? (l != 0) : (wlvl != 0); };   // does index l mean pyramid level 1?
 #define LVF(l, F) (second(l) ? lv1.F : lv0.F)

@@ -415,6 +415,29 @@ def test_plan_by_several_workgroups_is_a_sorted_permutation(n, M, H, W):
         band = (coords.cpu()[0, o[nh:E].long(), 1, 1, 1].clamp(0, H - 1) / 64).floor().long()      # blocks of 4 bands ascend inside a frame
         key = fr * 64 + band
         assert bool((key[1:] >= key[:-1]).all())
+    # spread-out patches (boxes the tile cannot hold) form the heavy list in front, filled by the first workgroup only; the
+    # lookup with this plan is bit-identical to the lookup in list order
+    g = torch.Generator().manual_seed(3)
+    spread = torch.rand(E, generator=g) < 0.03
+    c2 = coords.clone()
+    ctr = c2[0, :, :, 1:2, 1:2]
+    c2[0, spread.to(DEV)] = (ctr + 9.0 * (c2[0] - ctr))[spread.to(DEV)]
+    o = cuda_corr.plan(c2, jj, n, H, radius=3).cpu()
+    nh = int(o[E])
+    assert sorted(o[:E].tolist()) == list(range(E))
+    heavy = torch.zeros(E, dtype=torch.bool)
+    heavy[o[:nh].long()] = True
+    assert bool(heavy[spread].all())                               # every spread patch is in the heavy list
+    C = 32
+    f1 = torch.randn(1, n * M, C, 3, 3, generator=g).to(DEV)
+    f2 = channels_last5(torch.randn(1, n, C, H // 4, W // 4, generator=g).to(DEV))
+    c4 = (c2 / 4).contiguous()
+    plan4 = cuda_corr.plan(c4, jj, n, H // 4, radius=3)
+    ident = torch.cat([torch.arange(E, dtype=torch.int32), torch.zeros(1, dtype=torch.int32)]).to(DEV)      # list order, no heavy edges
+    out_list, out_plan = torch.empty(1, E, 7, 7, 3, 3, device=DEV), torch.empty(1, E, 7, 7, 3, 3, device=DEV)
+    cuda_corr.forward_into(out_list, f1, f2, c4, kk, jj, 3, 7 * 7 * 9, 1, 0, order=ident)
+    cuda_corr.forward_into(out_plan, f1, f2, c4, kk, jj, 3, 7 * 7 * 9, 1, 0, order=plan4)
+    assert torch.equal(out_plan, out_list)
 
 
 @pytest.mark.parametrize("which", ["region-staged dense kernel", "staged kernel", "edge-group kernel", "segment-reduced backward"])

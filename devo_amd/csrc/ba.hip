@@ -723,6 +723,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_ba_accumulate_reg(
   // garbage tables; a prepared graph may be solved many times (the sticky failure flag is reset here)
   const bool prepared = meta->sig == sig;
   const int n_seg = prepared ? min(meta->n_seg, max_seg) : 0;
+  const bool ident = meta->pad != 0;                           // the edge list was grouped by patch already: perm is the identity (one
+                                                               // dependent round trip less in front of the edge terms)
   if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = prepared ? 0 : -1;
   for (int s = blockIdx.x * REG_WAVES + wave; s < n_seg; s += gridDim.x * REG_WAVES) {
 #ifdef DEVO_ACC_TRACE
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ba_accumulate_reg(
     const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
     if (m > 64) { if (lane == 0) s_used_atomic = 1; accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane); continue; }
     const bool act = lane < m;
-    const int e = act ? perm[a0 + lane] : 0;
+    const int e = act ? (ident ? a0 + lane : perm[a0 + lane]) : 0;
     ACC_STAMP_FIRST(2);
     EdgeTerms T;
     int ix = -1, jx = -1;

@@ -1674,13 +1674,16 @@ __global__ void k_reproject(const float* __restrict__ poses, const float* __rest
 
 // devo/projective_ops.py:53-105 fused: iproj (per-frame intrinsics of frame i) -> Gij = Gj * Gi^-1 (lietorch
 // semantics: quaternions renormalised on load) -> act4 -> proj (intrinsics of frame j, Z clamped at 0.1).
+// PP3: P == 3, the pixel loop is unrolled — the 27 patch values of an edge are requested together; with the run-time trip
+// count every pixel's three loads were waited for before the next pixel's were issued (nine round trips in a row).
+template <bool PP3>
 __global__ void k_transform(const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
                             const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
                             float* __restrict__ c_pp2, float* __restrict__ c_2pp, float* __restrict__ valid,
                             float* __restrict__ Ji, float* __restrict__ Jj, float* __restrict__ Jz, int E, int P, int flags,
                             int* __restrict__ plan_bins, int plan_n2, int plan_H2, int plan_nb, int plan_D, int plan_ng) {
   const bool depth = flags & 1, tonly = flags & 2;
-  const int PPx = P * P, ctr = (P / 2) * P + P / 2, nc = depth ? 3 : 2;
+  const int PPx = PP3 ? 9 : P * P, ctr = PP3 ? 4 : (P / 2) * P + P / 2, nc = depth ? 3 : 2;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
     const int64_t fi = ii[e], fj = jj[e];
     SE3<float> Gi = SE3<float>::load(poses + fi * 7), Gj = SE3<float>::load(poses + fj * 7);
@@ -1692,7 +1695,8 @@ __global__ void k_transform(const float* __restrict__ poses, const float* __rest
     float Xc = 0, Yc = 0, Zc = 1, Hc = 0;
     int bx[9], by[9];                                            // integer pixels for the lookup's locality plan (P == 3)
     float bcx = 0.0f, bcy = 0.0f;
-    for (int i = 0; i < PPx; i++) {
+#pragma unroll
+    for (int i = 0; i < (PP3 ? 9 : PPx); i++) {
       const float w = pk[2 * PPx + i];
       V3<float> X0{(pk[i] - cxi) / fxi, (pk[PPx + i] - cyi) / fyi, 1.0f};
       V3<float> X1 = qrot(G.q, X0) + w * G.t;
@@ -2383,7 +2387,7 @@ int devo_transform(const float* poses, const float* patches, const float* intrin
     DEVO_REQUIRE(pg.nb > 0, "devo_transform: too many frames for a locality plan (%d)", plan_frames);
     nb = corr_plan_pack(pg);
   }
-  hipLaunchKernelGGL(k_transform, dim3(blocks_for(E, 128, 4096)), dim3(128), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
+  hipLaunchKernelGGL(P == 3 ? k_transform<true> : k_transform<false>, dim3(blocks_for(E, 128, 4096)), dim3(128), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
                      kk, coords_pp2, coords_2pp, valid, Ji, Jj, Jz, E, P, flags, plan ? plan + E + 1 : nullptr, plan_frames, plan_height,
                      nb, 2 * plan_radius + 2, plan_radius <= 3 ? 1 : 3);
   return check_launch("devo_transform");

@@ -104,6 +104,9 @@ def build_inputs(cfg, seed, device, dtype, layout):
     return d, cpu
 
 
+PROBE_TIMEOUT_S = float(os.environ.get("DEVO_BENCH_PROBE_TIMEOUT", "240"))   # multi-GPU default runs: the data-parallel training probe may take this long at most
+
+
 def alg_bytes(cfg, E, esize):
     """Touch-once traffic of the two-level lookup: fmap2 + gmap + coords + ii,jj + output."""
     n, M, H, W, C, R = cfg["n"], cfg["M"], cfg["H"], cfg["W"], cfg["C"], cfg["R"]
@@ -468,9 +471,27 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
                       "roofline": {k: h["roofline"].get(k) for k in ("achieved", "frac", "kernel", "alg_bytes_per_launch", "us_per_launch", "us_per_launch_back_to_back", "traffic")},
                       "note": "same step with fp16-storage feature pyramid + patch features (DEVO's inference precision), fp32 accumulation"}
     if world > 1 and not args.no_train_probe:
-        # BASELINE configuration 4: data-parallel training steps — the one collective of the path (13.59 MB gradient all-reduce)
-        out["train_dp"] = train_mode(args, device, rank, world, steps=3, warmup=1, iters=2, probe=True)
-        out["train_dp"]["note"] = "probe: 3 steps of 2 update iterations each (bench.py --mode train runs the full 18-iteration step)"
+        # BASELINE configuration 4: data-parallel training steps — the one collective of the path (13.59 MB gradient all-reduce).
+        # The probe is an extra: whatever happens inside it (an exception on one rank, a collective that never returns) must not cost
+        # the line of the metric measured above.  A rank that raises records the error; a watchdog per rank ends a probe that hangs —
+        # rank 0 prints the line first.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["train_dp"] = {"error": f"probe did not finish within {PROBE_TIMEOUT_S} s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(PROBE_TIMEOUT_S, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            out["train_dp"] = train_mode(args, device, rank, world, steps=3, warmup=1, iters=2, probe=True)
+            out["train_dp"]["note"] = "probe: 3 steps of 2 update iterations each (bench.py --mode train runs the full 18-iteration step)"
+        except Exception as ex:                                  # noqa: BLE001 — reported, not fatal
+            out["train_dp"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        timer.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, cpu, E)
         out["ba"]["cpu_ms"] = out["cpu_baseline"]["ba_ms"]

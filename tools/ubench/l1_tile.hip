@@ -1,0 +1,106 @@
+// Feasibility of "level 1 of the lookup from frame tiles in LDS" (DESIGN.md §7): how long does a workgroup take that stages 1/16 of a
+// level-1 frame (17 x 19 positions x 128 fp16 channels = 83 KB, with its 9-position margin) ONCE and then serves the ~90 edges whose
+// box origin lies in the tile's core from LDS?  Per edge: 6 M-tiles of 16 box positions x 4 K steps on v_mfma_f32_16x16x32_f16 (A =
+// positions out of LDS, B = the patch from a [edge][16 px][128 ch] array), the 96 x 16 raw sums through a per-wave LDS scratch, a
+// blend-shaped epilogue (441 outputs, 4 taps each).  Synthetic addresses and values: this measures time, not results.
+//   hipcc --offload-arch=gfx950 -O3 -o l1_tile l1_tile.hip && ./l1_tile
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int RW = 19, RH = 17, NPOS = RW * RH, PITCH = 272;         // region, bytes per staged position (256 + 16: bank spread)
+constexpr int WAVES = 8, SCR = 96 * 16;                                // per-wave scratch: [96 positions][16 pixels] floats
+
+template <bool STAGE, bool MFMA, bool EPI>
+__global__ __launch_bounds__(WAVES * 64) void k_tile(const uint4* __restrict__ fmap, const uint4* __restrict__ patches, _Float16* __restrict__ out,
+                                                     int edges_per_wg, int frame_positions) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* region = lds;
+  float* scratch = reinterpret_cast<float*>(lds + NPOS * PITCH) + (threadIdx.x >> 6) * SCR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, kg = lane >> 4;
+  // ---- stage the tile: NPOS positions x 16 chunks of 16 bytes, rows of the frame are 40 positions wide
+  if (STAGE) {
+    const int frame = blockIdx.x / 16, tile = blockIdx.x % 16, ty = (tile / 4) * 8, tx = (tile % 4) * 10;
+    for (int c = tid; c < NPOS * 16; c += WAVES * 64) {
+      const int p = c >> 4, q = c & 15, y = ty + p / RW, x = tx + p % RW;
+      const int src = (frame * frame_positions + (y % 30) * 40 + (x % 40)) * 16 + q;
+      *reinterpret_cast<uint4*>(region + p * PITCH + q * 16) = fmap[src];
+    }
+  }
+  __syncthreads();
+  float sink = 0.0f;
+  for (int e = wave; e < edges_per_wg; e += WAVES) {
+    const int eg = blockIdx.x * edges_per_wg + e;
+    const int ox = (eg * 7) % 10, oy = (eg * 3) % 8;                   // box origin inside the core
+    h8 b[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) b[ks] = __builtin_bit_cast(h8, patches[((size_t)eg * 16 + m) * 16 + 4 * ks + kg]);
+    f4 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+      const int i = min(16 * t + m, 80), iy = i / 9, ix = i - 9 * iy;
+      const unsigned char* ap = region + ((oy + iy) * RW + ox + ix) * PITCH + kg * 16;
+      acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const h8 a = *reinterpret_cast<const h8*>(ap + ks * 64);
+        if (MFMA) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[ks], acc[t], 0, 0, 0);
+        else acc[t][0] += (float)a[0] * (float)b[ks][0];
+      }
+    }
+    // raw sums -> scratch [position 16 t + 4 kg + i][pixel m]
+#pragma unroll
+    for (int t = 0; t < 6; t++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) scratch[(16 * t + 4 * kg + i) * 16 + m] = acc[t][i];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (EPI) {
+      const float fx = 0.25f + 0.001f * (float)(eg & 63), fy = 0.5f;
+#pragma unroll
+      for (int j = 0; j < 7; j++) {
+        const int o = lane + 64 * j;
+        if (o < 441) {
+          const int p = o / 49, tap = o - 49 * p, a = tap / 7, c = tap - 7 * a;
+          const int s0 = (a * 9 + c) * 16 + p;                         // tap (a, c) of pixel p inside the 9 x 9 box
+          const float v00 = scratch[s0], v01 = scratch[s0 + 16], v10 = scratch[s0 + 9 * 16], v11 = scratch[s0 + 10 * 16];
+          const float v = (1 - fx) * (1 - fy) * v00 + fx * (1 - fy) * v01 + (1 - fx) * fy * v10 + fx * fy * v11;
+          out[(size_t)eg * 441 + o] = (_Float16)v;
+        }
+      }
+    } else sink += scratch[lane];
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (sink == 12345.0f) out[0] = (_Float16)sink;
+}
+
+template <bool S, bool M, bool E> float run(const uint4* fmap, const uint4* patches, _Float16* out, int wgs, int epw) {
+  const size_t lds = NPOS * PITCH + WAVES * SCR * 4;
+  hipFuncSetAttribute((const void*)k_tile<S, M, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k_tile<S, M, E>), dim3(wgs), dim3(WAVES * 64), lds, 0, fmap, patches, out, epw, 1200);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  for (int i = 0; i < 20; i++) hipLaunchKernelGGL((k_tile<S, M, E>), dim3(wgs), dim3(WAVES * 64), lds, 0, fmap, patches, out, epw, 1200);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  return ms / 20 * 1e3f;
+}
+
+int main() {
+  const int frames = 15, wgs = frames * 16, epw = 90, E = wgs * epw;
+  uint4 *fmap, *patches; _Float16* out;
+  hipMalloc(&fmap, (size_t)frames * 1200 * 256); hipMalloc(&patches, (size_t)E * 16 * 256); hipMalloc(&out, (size_t)E * 441 * 2);
+  hipMemset(fmap, 0, (size_t)frames * 1200 * 256); hipMemset(patches, 0, (size_t)E * 16 * 256);
+  printf("level-1 tile prototype: %d workgroups x %d edges (E = %d), LDS %zu B per workgroup\n", wgs, epw, E, (size_t)NPOS * PITCH + WAVES * SCR * 4);
+  printf("  everything               : %7.1f us per launch\n", run<true, true, true>(fmap, patches, out, wgs, epw));
+  printf("  without the epilogue     : %7.1f us\n", run<true, true, false>(fmap, patches, out, wgs, epw));
+  printf("  without the MFMAs        : %7.1f us\n", run<true, false, true>(fmap, patches, out, wgs, epw));
+  printf("  without staging the tile : %7.1f us\n", run<false, true, true>(fmap, patches, out, wgs, epw));
+  printf("  (per-edge kernel, level 1 alone, fp16: 42.4 us per launch at E = 21 600 — bench.py --per-level-launches)\n");
+  return 0;
+}

@@ -12,9 +12,9 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int RW = 19, RH = 17, NPOS = RW * RH, PITCH = 272;         // region, bytes per staged position (256 + 16: bank spread)
-constexpr int WAVES = 8, SCR = 96 * 16;                                // per-wave scratch: [96 positions][16 pixels] floats
+constexpr int WAVES = 8, PST = 100, SCR = 16 * PST;                     // per-wave scratch: [16 pixels][96 positions (+4: bank spread)] floats
 
-template <bool STAGE, bool MFMA, bool EPI>
+template <bool STAGE, bool MFMA, bool EPI, bool PREFETCH>
 __global__ __launch_bounds__(WAVES * 64) void k_tile(const uint4* __restrict__ fmap, const uint4* __restrict__ patches, _Float16* __restrict__ out,
                                                      int edges_per_wg, int frame_positions) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -33,12 +33,33 @@ __global__ __launch_bounds__(WAVES * 64) void k_tile(const uint4* __restrict__ f
   }
   __syncthreads();
   float sink = 0.0f;
+  // (edge-independent epilogue indices: output o = lane + 64 j -> scratch offset of its tap (0, 0))
+  int s0j[7];
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    const int o = min(lane + 64 * j, 440), p = o / 49, tap = o - 49 * p, a = tap / 7, c = tap - 7 * a;
+    s0j[j] = p * PST + a * 9 + c;
+  }
+  h8 bnext[4];
+  {
+    const int eg0 = blockIdx.x * edges_per_wg + wave;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) bnext[ks] = __builtin_bit_cast(h8, patches[((size_t)eg0 * 16 + m) * 16 + 4 * ks + kg]);
+  }
   for (int e = wave; e < edges_per_wg; e += WAVES) {
     const int eg = blockIdx.x * edges_per_wg + e;
     const int ox = (eg * 7) % 10, oy = (eg * 3) % 8;                   // box origin inside the core
     h8 b[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) b[ks] = __builtin_bit_cast(h8, patches[((size_t)eg * 16 + m) * 16 + 4 * ks + kg]);
+    for (int ks = 0; ks < 4; ks++) b[ks] = bnext[ks];
+    if (PREFETCH) {                                                    // the next edge's patch while this one is multiplied
+      const int en = min(e + WAVES, edges_per_wg - 1), egn = blockIdx.x * edges_per_wg + en;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) bnext[ks] = __builtin_bit_cast(h8, patches[((size_t)egn * 16 + m) * 16 + 4 * ks + kg]);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) b[ks] = __builtin_bit_cast(h8, patches[((size_t)eg * 16 + m) * 16 + 4 * ks + kg]);
+    }
     f4 acc[6];
 #pragma unroll
     for (int t = 0; t < 6; t++) {
@@ -52,11 +73,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_tile(const uint4* __restrict__ f
         else acc[t][0] += (float)a[0] * (float)b[ks][0];
       }
     }
-    // raw sums -> scratch [position 16 t + 4 kg + i][pixel m]
+    // raw sums -> scratch [pixel m][position 16 t + 4 kg + i]: one 16-byte store per tile
 #pragma unroll
-    for (int t = 0; t < 6; t++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) scratch[(16 * t + 4 * kg + i) * 16 + m] = acc[t][i];
+    for (int t = 0; t < 6; t++) *reinterpret_cast<f4*>(scratch + m * PST + 16 * t + 4 * kg) = acc[t];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (EPI) {
@@ -65,9 +84,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_tile(const uint4* __restrict__ f
       for (int j = 0; j < 7; j++) {
         const int o = lane + 64 * j;
         if (o < 441) {
-          const int p = o / 49, tap = o - 49 * p, a = tap / 7, c = tap - 7 * a;
-          const int s0 = (a * 9 + c) * 16 + p;                         // tap (a, c) of pixel p inside the 9 x 9 box
-          const float v00 = scratch[s0], v01 = scratch[s0 + 16], v10 = scratch[s0 + 9 * 16], v11 = scratch[s0 + 10 * 16];
+          const int s0 = s0j[j];                                       // tap (a, c) of pixel p inside the 9 x 9 box
+          const float v00 = scratch[s0], v01 = scratch[s0 + 1], v10 = scratch[s0 + 9], v11 = scratch[s0 + 10];
           const float v = (1 - fx) * (1 - fy) * v00 + fx * (1 - fy) * v01 + (1 - fx) * fy * v10 + fx * fy * v11;
           out[(size_t)eg * 441 + o] = (_Float16)v;
         }
@@ -78,14 +96,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_tile(const uint4* __restrict__ f
   if (sink == 12345.0f) out[0] = (_Float16)sink;
 }
 
-template <bool S, bool M, bool E> float run(const uint4* fmap, const uint4* patches, _Float16* out, int wgs, int epw) {
+template <bool S, bool M, bool E, bool P> float run(const uint4* fmap, const uint4* patches, _Float16* out, int wgs, int epw) {
   const size_t lds = NPOS * PITCH + WAVES * SCR * 4;
-  hipFuncSetAttribute((const void*)k_tile<S, M, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)k_tile<S, M, E, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k_tile<S, M, E>), dim3(wgs), dim3(WAVES * 64), lds, 0, fmap, patches, out, epw, 1200);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k_tile<S, M, E, P>), dim3(wgs), dim3(WAVES * 64), lds, 0, fmap, patches, out, epw, 1200);
   hipDeviceSynchronize();
   hipEventRecord(a);
-  for (int i = 0; i < 20; i++) hipLaunchKernelGGL((k_tile<S, M, E>), dim3(wgs), dim3(WAVES * 64), lds, 0, fmap, patches, out, epw, 1200);
+  for (int i = 0; i < 20; i++) hipLaunchKernelGGL((k_tile<S, M, E, P>), dim3(wgs), dim3(WAVES * 64), lds, 0, fmap, patches, out, epw, 1200);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   return ms / 20 * 1e3f;
@@ -97,10 +115,11 @@ int main() {
   hipMalloc(&fmap, (size_t)frames * 1200 * 256); hipMalloc(&patches, (size_t)E * 16 * 256); hipMalloc(&out, (size_t)E * 441 * 2);
   hipMemset(fmap, 0, (size_t)frames * 1200 * 256); hipMemset(patches, 0, (size_t)E * 16 * 256);
   printf("level-1 tile prototype: %d workgroups x %d edges (E = %d), LDS %zu B per workgroup\n", wgs, epw, E, (size_t)NPOS * PITCH + WAVES * SCR * 4);
-  printf("  everything               : %7.1f us per launch\n", run<true, true, true>(fmap, patches, out, wgs, epw));
-  printf("  without the epilogue     : %7.1f us\n", run<true, true, false>(fmap, patches, out, wgs, epw));
-  printf("  without the MFMAs        : %7.1f us\n", run<true, false, true>(fmap, patches, out, wgs, epw));
-  printf("  without staging the tile : %7.1f us\n", run<false, true, true>(fmap, patches, out, wgs, epw));
+  printf("  everything               : %7.1f us per launch\n", run<true, true, true, true>(fmap, patches, out, wgs, epw));
+  printf("  patches not prefetched   : %7.1f us\n", run<true, true, true, false>(fmap, patches, out, wgs, epw));
+  printf("  without the epilogue     : %7.1f us\n", run<true, true, false, true>(fmap, patches, out, wgs, epw));
+  printf("  without the MFMAs        : %7.1f us\n", run<true, false, true, true>(fmap, patches, out, wgs, epw));
+  printf("  without staging the tile : %7.1f us\n", run<false, true, true, true>(fmap, patches, out, wgs, epw));
   printf("  (per-edge kernel, level 1 alone, fp16: 42.4 us per launch at E = 21 600 — bench.py --per-level-launches)\n");
   return 0;
 }

@@ -236,7 +236,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         torch.mul(d["state0"], 1.0, out=d["state"])                        # fresh poses + patches (bench harness; an elementwise kernel: rocclr's copyBuffer takes 5 us)
         # reprojection; the kernel also emits the lookup's plan bins while it holds the coordinates
         coords, order = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp",
-                                          plan_for=(n, cfg["H"], R))
+                                          plan_for=(n, cfg["H"], R, cfg["W"], 4 if args.fuse_levels else 0))
         if args.separate_index_kernels or prep_stream is not None:
             order = cuda_corr.plan_finish(order, d["jj"], n, cfg["H"], R)
         else:
@@ -313,7 +313,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         lookup(coords)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     # only the lookup kernels sit between the events
-    order = cuda_corr.plan(coords, d["jj"], n, cfg["H"], radius=R)
+    order = cuda_corr.plan(coords, d["jj"], n, cfg["H"], radius=R, width=cfg["W"], l1=4 if args.fuse_levels else 0)
     torch.cuda.synchronize()
 
     def lookups():

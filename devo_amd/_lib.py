@@ -22,9 +22,10 @@ _SIGNATURES = {
     "devo_last_error": [],
     "devo_corr_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i, _i64, _i64, _i64, _i, _i, _vp, ctypes.c_float, _vp],
     "devo_corr_forward_pyramid2": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), _c_i64p,
-                                   ctypes.POINTER(ctypes.c_int), _i64, _i64, _c_i64p, _i, _i, _vp, ctypes.POINTER(ctypes.c_float), _vp],
+                                   ctypes.POINTER(ctypes.c_int), _i64, _i64, _c_i64p, _i, _i, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp],
+    "devo_corr_patch_transpose": [_vp, _vp, _i, _i, _i, _vp],
     "devo_pyramid_build": [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i, _vp],
-    "devo_corr_order": [_vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
+    "devo_corr_order": [_vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_float, _i, _i, _i, _vp],
     "devo_corr_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i64, _i, _i, _vp],
     "devo_patchify_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _c_i64p, _i, _i, _vp],
     "devo_patchify_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -43,7 +44,7 @@ _SIGNATURES = {
     "devo_neighbors_workspace_bytes": [_i],
     "devo_ba_neighbors": [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp],
     "devo_ba_reproject": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "devo_transform": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp],
+    "devo_transform": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
 }
 _f = ctypes.c_float
 _SIGNATURES.update({

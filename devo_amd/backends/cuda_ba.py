@@ -31,7 +31,7 @@ def prepare(kk, n_patch_slots, n_opt, ws, plan=None):
         buf, n_frames, height = plan
         L.require_gpu(buf)
         if buf.dtype != torch.int32 or buf.numel() < 2 * kk.numel() + 1:
-            raise RuntimeError("cuda_ba.prepare: plan must be the int32 [2E+1] buffer of transform(..., plan_for=...)")
+            raise RuntimeError("cuda_ba.prepare: plan must be the int32 [2E+2] buffer of transform(..., plan_for=...)")
         rc = L.lib().devo_ba_prepare_plan(L.ptr(kk), kk.numel(), int(n_patch_slots), int(n_opt), L.ptr(ws), ws.numel(),
                                           L.ptr(buf), int(n_frames), int(height), L.stream())
     L.check(rc, "cuda_ba.prepare")
@@ -154,9 +154,9 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
               layout="pp2", plan_for=None):
     """Fused projective transform with the semantics of devo/projective_ops.py:53-105 (batch 1, no autograd).
     layout "pp2": coords [1,E,P,P,2|3] as the reference returns; "2pp": [1,E,2,P,P] (devo/devo.py:223).
-    plan_for=(n_frames, height, radius): also start the lookup's locality plan for these coordinates (the kernel emits
-    the plan bins while it holds them); the half-built plan buffer is returned LAST — finish it with
-    cuda_corr.plan_finish(buffer, jj, n_frames, height, radius)."""
+    plan_for=(n_frames, height, radius[, width, l1]): also start the lookup's locality plan for these coordinates (the kernel
+    emits the plan bins while it holds them; width, l1 = 4: PYRAMID plan, see cuda_corr.plan); the half-built plan buffer is
+    returned LAST — finish it with cuda_corr.plan_finish(buffer, jj, n_frames, height, radius)."""
     L.require_gpu(poses, patches, intrinsics, ii, jj, kk)
     P = patches.shape[-1]
     ii, jj, kk = _idx(ii, jj, kk)
@@ -173,13 +173,13 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     Jj = torch.empty(1, E, 2, 6, **f32) if jacobian else None
     Jz = torch.empty(1, E, 2, 1, **f32) if jacobian else None
     flags = (1 if depth else 0) | (2 if tonly else 0)
-    plan, pf = None, (0, 0, 0)
+    plan, pf = None, (0, 0, 0, 0, 0)
     if plan_for is not None:
-        pf = tuple(int(x) for x in plan_for)
-        plan = torch.empty(2 * E + 1, dtype=torch.int32, device=dev)
+        pf = (tuple(int(x) for x in plan_for) + (0, 0))[:5]
+        plan = torch.empty(2 * E + 2, dtype=torch.int32, device=dev)
     rc = L.lib().devo_transform(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(ii), L.ptr(jj), L.ptr(kk),
                                 L.ptr(c_pp2), L.ptr(c_2pp), L.ptr(v), L.ptr(Ji), L.ptr(Jj), L.ptr(Jz), E, P, flags,
-                                L.ptr(plan), pf[0], pf[1], pf[2], L.stream())
+                                L.ptr(plan), pf[0], pf[1], pf[2], pf[3], pf[4], L.stream())
     L.check(rc, "cuda_ba.transform")
     c = c_pp2 if layout == "pp2" else c_2pp
     out = (c, v, (Ji, Jj, Jz)) if jacobian else ((c, v) if valid else c)

@@ -58,16 +58,25 @@ def _fast_layout(fmap2, n_edges):
     return blk
 
 
-def plan(coords, jj, n_frames, height, coord_scale=1.0, radius=3):
-    """Locality plan (devo_corr_order): edge slots sorted by (target frame, 16-row band).  One plan serves every
-    level of a pyramid; `coords / coord_scale` must be the coordinates of the level with `height` rows."""
+def plan_buffer(n_slots, device):
+    """The plan buffer of devo_corr_order: int32 [2 n + 2] = n edge slots | number of heavy slots (in front) | n ints of scratch |
+    number of dead slots (at the end; pyramid plans)."""
+    return torch.empty(2 * int(n_slots) + 2, dtype=torch.int32, device=device)
+
+
+def plan(coords, jj, n_frames, height, coord_scale=1.0, radius=3, width=0, l1=0):
+    """Locality plan (devo_corr_order): edge slots sorted by (target frame, 16-row band, 8-px column).  One plan serves every
+    level of a pyramid; `coords / coord_scale` must be the coordinates of the level with `height` rows.
+    width, l1: PYRAMID plan for forward_pyramid — the level is `width` wide and the lookup has a second level at 1 / l1 of its
+    resolution (DEVO: 4): edges whose boxes miss the frame at both levels are sorted to the end (they are zero-filled), heavy = what
+    the region-shared kernel cannot take."""
     L.require_gpu(coords, jj)
     coords = coords.float().contiguous()
     jj = jj.long().contiguous()
     B, E = coords.shape[:2]
-    order = torch.empty(2 * B * E + 1, dtype=torch.int32, device=coords.device)  # [:B*E] slots, [B*E] = #heavy, rest scratch
+    order = plan_buffer(B * E, coords.device)
     rc = L.lib().devo_corr_order(L.ptr(coords), L.ptr(jj), L.ptr(order), B, E, int(n_frames), coords.shape[3], int(height),
-                                 float(coord_scale), int(radius), L.stream())
+                                 float(coord_scale), int(radius), int(width), int(l1), L.stream())
     L.check(rc, "cuda_corr.plan")
     return order
 
@@ -76,10 +85,31 @@ def plan_finish(order, jj, n_frames, height, radius=3, batch=1):
     """Second half of plan() for a buffer whose bins cuda_ba.transform(..., plan_for=...) has already written."""
     L.require_gpu(order, jj)
     jj = jj.long().contiguous()
-    E = (order.numel() - 1) // (2 * batch)
-    rc = L.lib().devo_corr_order(None, L.ptr(jj), L.ptr(order), batch, E, int(n_frames), 3, int(height), 1.0, int(radius), L.stream())
+    E = (order.numel() - 2) // (2 * batch)
+    rc = L.lib().devo_corr_order(None, L.ptr(jj), L.ptr(order), batch, E, int(n_frames), 3, int(height), 1.0, int(radius), 0, 0, L.stream())
     L.check(rc, "cuda_corr.plan_finish")
     return order
+
+
+_patch_t_cache = {}        # (ptr, version, shape, dtype) -> (source tensor [kept alive], transposed copy [B, Np, 9, C])
+
+
+def patches_transposed(fmap1):
+    """fmap1 [B, Np, C, 3, 3] -> [B, Np, 9, C] (devo_corr_patch_transpose), the patch operand layout of the region-shared lookup
+    kernel.  DEVO's patch features change once per frame, not per update iteration: the copy is cached per version of the tensor
+    (same key discipline as _fast_layout)."""
+    key = (fmap1.data_ptr(), fmap1._version, tuple(fmap1.shape), fmap1.dtype)
+    hit = _patch_t_cache.get(key)
+    if hit is not None:
+        return hit[1]
+    for k in [k for k in _patch_t_cache if k[0] == key[0] or len(_patch_t_cache) >= 4]:
+        del _patch_t_cache[k]
+    B, Np, C = fmap1.shape[:3]
+    t = torch.empty(B, Np, 9, C, dtype=fmap1.dtype, device=fmap1.device)
+    rc = L.lib().devo_corr_patch_transpose(L.ptr(fmap1), L.ptr(t), B * Np, C, L.dtype_code(fmap1), L.stream())
+    L.check(rc, "cuda_corr.patches_transposed")
+    _patch_t_cache[key] = (fmap1, t)
+    return t
 
 
 def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, offset, order=None, coord_div=1.0):
@@ -141,8 +171,11 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
     if out is None:
         out = torch.empty(B, E, per * nl, dtype=fmap1.dtype, device=fmap1.device)
     pyramid = [_fast_layout(f, B * E) if f.is_cuda else f for f in pyramid]
+    pyr_l1 = 0                                                  # integer level ratio of a two-level pyramid (DEVO: 4), else 0
+    if nl == 2 and scales[0] > 0 and float(scales[1] / scales[0]).is_integer() and scales[1] / scales[0] >= 2:
+        pyr_l1 = int(scales[1] / scales[0])
     if order is None and B * E >= PLAN_MIN_EDGES:
-        order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius)
+        order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius, width=pyramid[0].shape[4], l1=pyr_l1)
     if nl == 2 and B * E > 0 and pyramid[0].dtype == pyramid[1].dtype and pyramid[0].dtype in (torch.float32, torch.float16):
         f1, f2a, c_, ii_, jj_ = _prep(fmap1, pyramid[0], coords, ii, jj, allow_blocked=True)
         _prep(fmap1, pyramid[1], coords, ii, jj, allow_blocked=True)
@@ -151,10 +184,12 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
         hw = (ctypes.c_int * 4)(d0[0], d0[1], d1[0], d1[1])
         cb = (ctypes.c_int * 2)(d0[3], d1[3])
         cd = (ctypes.c_float * 2)(float(scales[0]), float(scales[1]))
+        # the region-shared kernel wants the patches as [Np, 9, C] (cached per version of fmap1) and a plan
+        f1t = patches_transposed(f1) if (order is not None and P == 3 and f1.shape[3] == 3) else None
         rc = L.lib().devo_corr_forward_pyramid2(L.ptr(f1), L.ptr(pyramid[0]), L.ptr(pyramid[1]), L.ptr(c_), L.ptr(ii_), L.ptr(jj_),
                                                 L.ptr(out), B, E, Np, pyramid[0].shape[1], C, P, hw, L.i64arr(d0[2] + d1[2]), cb,
                                                 per * nl, nl, L.i64arr([0, 1]), int(radius), L.dtype_code(f1), L.ptr(order), cd,
-                                                L.stream())
+                                                L.ptr(f1t), L.stream())
         if rc == 0:
             return out
         if rc != 3:                                             # DEVO_ERR_UNSUPPORTED: fall through to one launch per level

@@ -1681,7 +1681,7 @@ __global__ void k_transform(const float* __restrict__ poses, const float* __rest
                             const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
                             float* __restrict__ c_pp2, float* __restrict__ c_2pp, float* __restrict__ valid,
                             float* __restrict__ Ji, float* __restrict__ Jj, float* __restrict__ Jz, int E, int P, int flags,
-                            int* __restrict__ plan_bins, int plan_n2, int plan_H2, int plan_nb, int plan_D, int plan_ng) {
+                            int* __restrict__ plan_bins, int plan_n2, int plan_H2, int plan_nb, int plan_D, int plan_ng, CorrPlanMode pm) {
   const bool depth = flags & 1, tonly = flags & 2;
   const int PPx = PP3 ? 9 : P * P, ctr = PP3 ? 4 : (P / 2) * P + P / 2, nc = depth ? 3 : 2;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
@@ -1708,7 +1708,8 @@ __global__ void k_transform(const float* __restrict__ poses, const float* __rest
       if (plan_bins && i < 9) { bx[i] = corr_floor_to_int(u); by[i] = corr_floor_to_int(v); if (i == 4) { bcx = u; bcy = v; } }
     }
     // the lookup's plan bins, while the coordinates are still in registers (saves the plan's own pass over coords)
-    if (plan_bins) plan_bins[e] = corr_plan_bin(bx, by, bcx, bcy, 0, (int)fj, plan_n2, plan_H2, plan_nb, plan_D, plan_ng);
+    if (plan_bins) plan_bins[e] = corr_plan_bin(bx, by, bcx, bcy, 0, (int)fj, plan_n2, plan_H2, plan_nb, plan_D, plan_ng, pm.W2, pm.l1,
+                                                pm.heavy_cells, pm.dead_bin);
     if (valid) valid[e] = (Zc > 0.2f) ? 1.0f : 0.0f;
     if (Jj) {
       const float d = (fabsf(Zc) > 0.2f) ? 1.0f / Zc : 0.0f;
@@ -2377,19 +2378,23 @@ int devo_ba_reproject(const float* poses, const float* patches, const float* int
 
 int devo_transform(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii, const int64_t* jj,
                    const int64_t* kk, float* coords_pp2, float* coords_2pp, float* valid, float* Ji, float* Jj, float* Jz, int E,
-                   int P, int flags, int* plan, int plan_frames, int plan_height, int plan_radius, devo_stream_t stream) {
+                   int P, int flags, int* plan, int plan_frames, int plan_height, int plan_radius, int plan_width, int plan_l1,
+                   devo_stream_t stream) {
   if (E <= 0) return DEVO_OK;
   DEVO_REQUIRE(!(Ji || Jz) || Jj, "devo_transform: Jj must be requested together with Ji / Jz");
   int nb = 0;
+  CorrPlanMode pm{0, 0, 0, -1};
   if (plan) {
     DEVO_REQUIRE(P == 3 && plan_frames > 0 && plan_height > 0 && plan_radius >= 0 && plan_radius <= 5, "devo_transform: bad plan geometry");
+    DEVO_REQUIRE(plan_l1 == 0 || (plan_l1 >= 2 && plan_width > 0), "devo_transform: a pyramid plan needs the level's width and an integer level ratio >= 2");
     const CorrPlanGeom pg = corr_plan_geom(1, plan_frames, plan_height);
     DEVO_REQUIRE(pg.nb > 0, "devo_transform: too many frames for a locality plan (%d)", plan_frames);
     nb = corr_plan_pack(pg);
+    pm = CorrPlanMode{plan_width, plan_l1, 16 * corr_region_tmax(plan_radius), (int)corr_plan_nbins(1, plan_frames, pg) - 1};
   }
   hipLaunchKernelGGL(P == 3 ? k_transform<true> : k_transform<false>, dim3(blocks_for(E, 128, 4096)), dim3(128), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
                      kk, coords_pp2, coords_2pp, valid, Ji, Jj, Jz, E, P, flags, plan ? plan + E + 1 : nullptr, plan_frames, plan_height,
-                     nb, 2 * plan_radius + 2, plan_radius <= 3 ? 1 : 3);
+                     nb, 2 * plan_radius + 2, plan_radius <= 3 ? 1 : 3, pm);
   return check_launch("devo_transform");
 }
 

@@ -156,6 +156,7 @@ struct CorrLevel {
   bool staged_ok, mfma_ok;        // which of the two fast kernels can read this level
   bool dense_ok;                  // ... and the region-staged dense matrix-core kernel (corr_dense.h)
   bool group_ok;                  // ... and the edge-group dense matrix-core kernel (corr_group.h)
+  bool region_ok;                 // ... and the region-shared kernel (corr_region.h)
   int64_t out_offset;             // element offset of this level inside an edge's output record
   float coord_div;                // coordinates are divided by this (pyramid level scale)
 };
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 #include "corr_mfma.h"
 #include "corr_dense.h"
 #include "corr_group.h"
+#include "corr_region.h"
 
 // -------------------------------------------------------------------------------------------------
 // Locality plan: order[] = heavy edge slots, then the rest sorted by (batch, target frame, 16-row band of the
@@ -453,7 +455,7 @@ constexpr int BIN_THREADS = 256;
 // tile of the staged kernel: it is staged in several passes and runs 2-4x longer) — heavy edges go to the front of the plan.
 __global__ __launch_bounds__(BIN_THREADS) void corr_bin_kernel(const float* __restrict__ coords,
                                                                const int64_t* __restrict__ jj, int BE, int E, int n2, int H2,
-                                                               float coord_div, int nb, int D, int ng,
+                                                               float coord_div, int nb, int D, int ng, CorrPlanMode pm,
                                                                int* __restrict__ bins) {
   const int be = blockIdx.x * BIN_THREADS + threadIdx.x;
   if (be >= BE) return;
@@ -463,7 +465,8 @@ __global__ __launch_bounds__(BIN_THREADS) void corr_bin_kernel(const float* __re
   int xs[PP], ys[PP];
 #pragma unroll
   for (int p = 0; p < PP; p++) { xs[p] = floor_to_int(c[p] / coord_div); ys[p] = floor_to_int(c[PP + p] / coord_div); }
-  const int bin = corr_plan_bin(xs, ys, c[4] / coord_div, c[PP + 4] / coord_div, b, (int)jj[e], n2, H2, nb, D, ng);
+  const int bin = corr_plan_bin(xs, ys, c[4] / coord_div, c[PP + 4] / coord_div, b, (int)jj[e], n2, H2, nb, D, ng, pm.W2, pm.l1,
+                                pm.heavy_cells, pm.dead_bin);
   bins[be] = bin;
 }
 
@@ -887,6 +890,11 @@ static bool corr_group_enabled() {               // DEVO_CORR_GROUP=1: the edge-
   static const bool on = env && env[0] == '1';
   return on;
 }
+static bool corr_region_enabled() {              // DEVO_CORR_REGION=1: pyramid lookups with a pyramid plan take the region-shared kernel
+  static const char* env = getenv("DEVO_CORR_REGION");
+  static const bool on = env && env[0] == '1';
+  return on;
+}
 static bool corr_mfma_enabled() {                // DEVO_CORR_MFMA=0: fp32 lookups take the staged (tap-centric) kernel instead
   static const char* env = getenv("DEVO_CORR_MFMA");
   static const bool on = !(env && env[0] == '0');
@@ -918,7 +926,9 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
                  C >= (sizeof(T) == 2 ? 64 : 32) && frame_bytes < (1LL << 31);                        // (at least two channel slabs)
   // the group kernel: fp16 storage, C = 128, 16-byte pieces of 8 channels inside a channel block
   lv->group_ok = aligned && sizeof(T) == 2 && corr_group_enabled() && cb_ok && C == 128 && frame_bytes < (1LL << 31);
-  if (!lv->staged_ok && !lv->mfma_ok && !lv->dense_ok && !lv->group_ok) {
+  // the region-shared kernel: 16-byte pieces inside a channel block (or channels-last), any C that is a multiple of its slab
+  lv->region_ok = aligned && sizeof(T) <= 4 && corr_region_enabled() && cb_ok && C % (sizeof(T) == 2 ? 32 : 16) == 0 && frame_bytes < (1LL << 31);
+  if (!lv->staged_ok && !lv->mfma_ok && !lv->dense_ok && !lv->group_ok && !lv->region_ok) {
     if (blocked) {
       set_error("devo_corr_forward: channel-blocked fmap2 needs fp32 / fp16, 16-byte aligned strides and cblock == %d (got %d)", KC, cblock);
       *err = DEVO_ERR_UNSUPPORTED;
@@ -1012,7 +1022,7 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
     const bool both = nlev == 2 && !(split_env && split_env[0] == '1') && !do_trace;
     typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;   // (never fp64: mfma_ok is false)
     typedef void (*mfma_fn_t)(const MT*, CorrLevel, CorrLevel, int, const float*, const int64_t*, const int64_t*, MT*, int, int,
-                              int, int, int, int64_t, int64_t, int, const int*, unsigned long long*);
+                              int, int, int, int64_t, int64_t, int, const int*, unsigned long long*, int);
     // steps of 16 (fp32) / 32 (fp16) channels per pass, 4 or 8 of them (16 would not fit the patch into the registers):
     // C = 64 / 128 (fp32), 128 / 256 (fp16)
     constexpr int SC = sizeof(MT) == 2 ? 32 : 16;
@@ -1042,7 +1052,7 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
       }
     }
     hipLaunchKernelGGL(fn, mgrid, mblock, occ_pad, st, (const MT*)fmap1, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2,
-                       C, oes, ols, R, order, trace);
+                       C, oes, ols, R, order, trace, 0);
   } else
   if (!(lv0.staged_ok && (nlev == 1 || lv1.staged_ok))) {
     set_error("devo_corr_forward: this channel-blocked layout is only readable by the matrix-core kernel (fp32: C = 64 / 128, fp16: C = 128 / 256)");
@@ -1078,6 +1088,53 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
   return check_launch("devo_corr_forward");
 }
 
+// Region-shared lookup (corr_region.h) of a two-level pyramid with a locality plan: the plan's heavy slots go to the per-edge
+// matrix-core kernel, everything else (and the zero-fill of the dead tail) to corr_fwd_region_kernel.
+template <typename T>
+static int launch_region(const void* fmap1, const void* fmap1_t, const CorrLevel& lv0, const CorrLevel& lv1, const float* coords,
+                         const int64_t* ii, const int64_t* jj, void* out, long long BE, int E, int Np, int n2, int C, int64_t oes,
+                         int64_t ols, int R, const int* order, hipStream_t st) {
+  typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;
+  typedef void (*region_fn_t)(const MT*, CorrLevel, CorrLevel, const float*, const int64_t*, const int64_t*, MT*, int, int, int, int, int,
+                              int64_t, int64_t, int, const int*, int, unsigned, int);
+  typedef RgShape<3, 8, 3, corr_region_tmax(3), 15> S3;
+  typedef RgShape<5, 8, 2, corr_region_tmax(5), 15> S5;
+  const region_fn_t fn = R <= 3 ? corr_fwd_region_kernel<MT, S3> : corr_fwd_region_kernel<MT, S5>;
+  const size_t lds = 2 * (size_t)(R <= 3 ? S3::BUFSZ : S5::BUFSZ);
+  const int threads = R <= 3 ? S3::THREADS : S5::THREADS, chmax = R <= 3 ? S3::CHMAX : S5::CHMAX;
+  static bool attr_done[2][2] = {{false, false}, {false, false}};
+  bool& done = attr_done[R <= 3 ? 0 : 1][sizeof(MT) == 2 ? 1 : 0];
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("devo_corr_forward_pyramid2: cannot reserve %zu bytes of LDS for the region kernel", lds);
+      return DEVO_ERR_LAUNCH;
+    }
+    done = true;
+  }
+  // chunks of the plan: ~2 rounds each, whole multiples of the CU count when there is enough work (one workgroup per CU)
+  static const char* chunk_env = getenv("DEVO_RG_CHUNK");
+  const int target = chunk_env && atoi(chunk_env) > 0 ? (atoi(chunk_env) < chmax ? atoi(chunk_env) : chmax) : 48;
+  long long nchunks = (BE + target - 1) / target;
+  nchunks = nchunks > 256 ? (nchunks + 255) / 256 * 256 : (nchunks + 7) / 8 * 8;
+  while ((BE + nchunks - 1) / nchunks > chmax) nchunks += 8;
+  // heavy slots first (longest items): the per-edge kernel in its heavy-only mode
+  {
+    typedef void (*mfma_fn_t)(const MT*, CorrLevel, CorrLevel, int, const float*, const int64_t*, const int64_t*, MT*, int, int,
+                              int, int, int, int64_t, int64_t, int, const int*, unsigned long long*, int);
+    constexpr int SC = sizeof(MT) == 2 ? 32 : 16;
+    const int ngr = C / SC;
+    const mfma_fn_t hf = ngr == 4 ? (R <= 3 ? corr_fwd_mfma_kernel<MT, 3, 4, 2> : corr_fwd_mfma_kernel<MT, 5, 4, 2>)
+                                  : (R <= 3 ? corr_fwd_mfma_kernel<MT, 3, 8, 2> : corr_fwd_mfma_kernel<MT, 5, 8, 2>);
+    hipLaunchKernelGGL(hf, dim3((unsigned)BE), dim3(64 * DEVO_MFMA_EPW), 0, st, (const MT*)fmap1, lv0, lv1, 2, coords, ii, jj, (MT*)out, (int)BE, E,
+                       Np, n2, C, oes, ols, R, order, (unsigned long long*)nullptr, 1);
+  }
+  const long long f1t_bytes = (BE / (E > 0 ? E : 1)) * (long long)Np * C * PP * (long long)sizeof(MT);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nchunks), dim3(threads), lds, st, (const MT*)fmap1_t, lv0, lv1, coords, ii, jj, (MT*)out, (int)BE, E, Np,
+                     n2, C, oes, ols, R, order, (int)nchunks, (unsigned)f1t_bytes, DEVO_PLAN_BAND);
+  return check_launch("devo_corr_forward_pyramid2 (region kernel)");
+}
+
 template <typename T>
 static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                            const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int H2, int W2,
@@ -1105,7 +1162,30 @@ static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* co
   return check_launch("devo_corr_forward");
 }
 
+// Region kernel: a plan, the transposed patches, both levels readable by it AND by the per-edge kernel (which takes the heavy slots)
+template <typename T>
+static bool region_eligible(const CorrLevel& l0, const CorrLevel& l1, const void* fmap1_t, const int* order, long long BE, int E, int Np, int C,
+                            int R) {
+  const long long f1_bytes = (BE / (E > 0 ? E : 1)) * (long long)Np * C * PP * (long long)sizeof(T);
+  return fmap1_t != nullptr && order != nullptr && l0.region_ok && l1.region_ok && l0.mfma_ok && l1.mfma_ok && R <= 5 &&
+         f1_bytes < (1LL << 31) && BE < (1LL << 30) && (reinterpret_cast<uintptr_t>(fmap1_t) & 15) == 0;
+}
+
 extern "C" {
+
+int devo_corr_patch_transpose(const void* fmap1, void* fmap1_t, int n_patches, int C, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(n_patches >= 0 && C > 0, "devo_corr_patch_transpose: bad sizes");
+  DEVO_REQUIRE(dtype == DEVO_F32 || dtype == DEVO_F16, "devo_corr_patch_transpose: fp32 / fp16 only");
+  if (n_patches == 0) return DEVO_OK;
+  DEVO_REQUIRE(fmap1 && fmap1_t, "devo_corr_patch_transpose: null tensor");
+  const size_t lds = (size_t)C * PP * (dtype == DEVO_F32 ? 4 : 2);
+  DEVO_REQUIRE(lds <= 48 * 1024, "devo_corr_patch_transpose: C = %d too large", C);
+  if (dtype == DEVO_F32)
+    hipLaunchKernelGGL(corr_patch_transpose_kernel<float>, dim3((unsigned)n_patches), dim3(256), lds, (hipStream_t)stream, (const float*)fmap1, (float*)fmap1_t, n_patches, C);
+  else
+    hipLaunchKernelGGL(corr_patch_transpose_kernel<__half>, dim3((unsigned)n_patches), dim3(256), lds, (hipStream_t)stream, (const __half*)fmap1, (__half*)fmap1_t, n_patches, C);
+  return check_launch("devo_corr_patch_transpose");
+}
 
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
@@ -1132,7 +1212,7 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
                                const int* hw /* host: H0, W0, H1, W1 */, const int64_t* f2s /* host: 5 + 5 */,
                                const int* cblock /* host, 2 */, int64_t out_estride, int64_t out_lstride,
                                const int64_t* out_offset /* host, 2 */, int radius, int dtype, const int* order,
-                               const float* coord_div /* host, 2 */, devo_stream_t stream) {
+                               const float* coord_div /* host, 2 */, const void* fmap1_t, devo_stream_t stream) {
   DEVO_REQUIRE(P == 3, "devo_corr_forward_pyramid2: patch size P must be 3 (got %d)", P);
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_forward_pyramid2: radius %d unsupported (max 5)", radius);
   DEVO_REQUIRE(hw && f2s && cblock && out_offset && coord_div, "devo_corr_forward_pyramid2: missing level description");
@@ -1147,10 +1227,14 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
   if (dtype == DEVO_F32) {
     ok = staged_level<float>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0) &&
          staged_level<float>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
+    if (ok && region_eligible<float>(l0, l1, fmap1_t, order, BE, E, Np, C, radius))
+      return launch_region<float>(fmap1, fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
     if (ok) return launch_staged<float>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
   } else if (dtype == DEVO_F16) {
     ok = staged_level<__half>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0) &&
          staged_level<__half>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
+    if (ok && region_eligible<__half>(l0, l1, fmap1_t, order, BE, E, Np, C, radius))
+      return launch_region<__half>(fmap1, fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
     if (ok) return launch_staged<__half>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
   }
   // not both levels readable by the staged kernel: the caller issues one devo_corr_forward per level instead
@@ -1174,7 +1258,7 @@ int devo_pyramid_build(const void* fmap, void* l0, void* l1, int F, int C, int H
 }
 
 int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, int E, int n2, int P, int H2,
-                    float coord_scale, int radius, devo_stream_t stream) {
+                    float coord_scale, int radius, int W2, int l1, devo_stream_t stream) {
   DEVO_REQUIRE(P == 3, "devo_corr_order: patch size P must be 3 (got %d)", P);
   DEVO_REQUIRE(B >= 0 && E >= 0 && n2 > 0 && H2 > 0 && coord_scale > 0.0f, "devo_corr_order: bad sizes");
   const long long BE = (long long)B * E;
@@ -1183,16 +1267,18 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   const int nb = corr_plan_pack(pg);
   DEVO_REQUIRE(pg.nb > 0 && BE < (1LL << 30), "devo_corr_order: too many frames (%d x %d)", B, n2);
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_order: radius %d unsupported (max 5)", radius);
+  DEVO_REQUIRE(l1 == 0 || (l1 >= 2 && W2 > 0), "devo_corr_order: a pyramid plan needs the level's width and an integer level ratio >= 2");
   int* bins = order + BE + 1;                                 // scratch half of the plan buffer
+  const long long nbins = corr_plan_nbins(B, n2, pg);
+  const CorrPlanMode pm{W2, l1, 16 * corr_region_tmax(radius), (int)nbins - 1};
   if (coords != nullptr)                                      // NULL: devo_transform has already written the bins
     hipLaunchKernelGGL(corr_bin_kernel, dim3((unsigned)((BE + BIN_THREADS - 1) / BIN_THREADS)), dim3(BIN_THREADS), 0,
                        (hipStream_t)stream, coords, jj, (int)BE, E, n2, H2, coord_scale, nb, 2 * radius + 2,
-                       radius <= 3 ? 1 : 3, bins);
+                       radius <= 3 ? 1 : 3, pm, bins);
   typedef void (*order_fn_t)(const int*, int, int, int*);
   const long long per_thread = (BE + ORDER_THREADS - 1) / ORDER_THREADS;
   order_fn_t order_fn = per_thread <= 8 ? corr_order_kernel<8> : per_thread <= 16 ? corr_order_kernel<16> :
                         per_thread <= 24 ? corr_order_kernel<24> : per_thread <= 32 ? corr_order_kernel<32> : corr_order_kernel<0>;
-  const long long nbins = corr_plan_nbins(B, n2, pg);
   hipLaunchKernelGGL(order_fn, dim3((unsigned)corr_order_workgroups(BE, nbins)), dim3(ORDER_THREADS), 0, (hipStream_t)stream, bins, (int)BE,
                      (int)nbins, order);
   return check_launch("devo_corr_order");

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_EPW) __attribute__((amdgpu_waves_per
     const T* __restrict__ fmap1, CorrLevel lv0, CorrLevel lv1, int nlev, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int64_t out_estride, int64_t out_lstride, int R, const int* __restrict__ order,
-    unsigned long long* __restrict__ trace) {
+    unsigned long long* __restrict__ trace, int heavy_only) {
   // NL == 1 with nlev == 2: the levels alternate in groups of 8 workgroups (see corr_fwd_cl_kernel); NL == 2: one
   // workgroup per edge does both.  lev(l) = the level this wave works on as its l-th.
   constexpr int EPW = DEVO_MFMA_EPW;
@@ -99,6 +99,10 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_EPW) __attribute__((amdgpu_waves_per
   int slot;
   if (EPW == 1) slot = corr_plan_slot(order, BE, wgid, nwg);
   else { const int per = (nwg + 7) >> 3; slot = (((wgid & 7) * per + (wgid >> 3)) * EPW) + wv; if ((wgid >> 3) >= per) slot = BE; }
+  if (heavy_only) {                           // the region-shared kernel (corr_region.h) takes every other slot of the plan
+    slot = (int)blockIdx.x * EPW + wv;
+    if (slot >= (order ? min(max(order[BE], 0), BE) : 0)) return;
+  }
   if (slot >= BE) return;                     // wave-uniform; no workgroup barriers in this kernel
   const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ULL;
   const int be = order ? order[slot] : slot;

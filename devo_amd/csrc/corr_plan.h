@@ -27,7 +27,7 @@ inline int corr_order_workgroups(long long BE, long long nbins) {
 // one per loop iteration and pass); CACHE == 0: any BE, bins re-read by both passes.
 template <int CACHE>
 __device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order, int g, int G) {
-  __shared__ int s_cnt[ORDER_MAXBINS];
+  __shared__ int s_cnt[ORDER_MAXBINS + 1];
   __shared__ int s_base[2];                                 // [0] = edges below this workgroup's range, [1] = heavy cursor (g == 0)
   constexpr bool CACHED = CACHE > 0;
   const int lane = threadIdx.x & 63;
@@ -66,6 +66,8 @@ __device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, in
       const int v = (i < nown) ? s_cnt[i] : 0;
       const int x = wave_inclusive_sum(v);
       if (i < nown) s_cnt[i] = carry + x - v;
+      // the last bin of all is the DEAD class of the pyramid plan (corr_plan_bin): its size goes behind the scratch half
+      if (g == G - 1 && i == nown - 1) order[2 * BE + 1] = v;
       carry += __builtin_amdgcn_readlane(x, 63);
     }
   }

@@ -1,0 +1,525 @@
+// altcorr lookup, REGION-SHARED: neighbouring edges of one target frame read their boxes out of ONE staged copy of the frame region
+// they cover (included by corr.hip inside namespace devo; semantics: devo/altcorr/correlation_kernel.cu:82-136,221-232).
+//
+// Why: the per-edge kernel (corr_mfma.h) pulls every edge's own ~107 + ~74 box positions through its CU — 2.0 GB per cfg2 launch —
+// and sits at the rate at which a CU can take bytes in.  At DEVO's patch density a level-0 pixel is wanted by ~8
+// edges and a level-1 pixel by ~90, so a workgroup that stages the union region of ~20 image-neighbours ONCE moves 4-5x fewer bytes.
+//
+// Structure.  A workgroup takes a CHUNK of consecutive slots of the locality plan (edges of one frame band, sorted by 8-px column),
+// sorts them by box origin and forms greedy ROUNDS: runs of <= NW * EW edges of one frame whose union region (clipped to the frame)
+// fits the staging buffer at both pyramid levels.  Per round and level (level 1 first, its results wait in registers):
+//   * the region is streamed through LDS in channel SLABS (32 fp16 / 16 fp32 channels = 64 bytes per position) with
+//     buffer_load_dwordx4 ... lds (no staging registers; positions outside the region / the frame are out-of-range offsets = zeros),
+//     double-buffered: slab s + 1 is in flight while slab s is multiplied; the round's patch slabs travel the same way;
+//   * LDS image of a slab: 4 planes [16-byte piece][position] — the A operand of v_mfma_f32_16x16x32_f16 (16 box positions x 32 k)
+//     is one ds_read_b128 per lane; B = the patch (9 of 16 columns used) from the patch area; every wave keeps the accumulators of
+//     its EW edges (TMAX tiles of 16 box positions each) in registers across the slabs;
+//   * fp32 storage: a staged value x is split where it is read into fp16 hi + lo (v_cvt_pk_f16_f32 + v_fma_mix: 6 instructions per
+//     4 channels), K = [hi | lo] of 16 channels against [hi | hi] and [lo | 0] of the patch: x y = xh yh + xl yh + xh yl with fp32
+//     accumulation (2^-22 relative per factor; domain |feature| <= 65504);
+//   * epilogue: the 16 x 16 result tiles go through a per-wave scratch [pixel][box position] (one 16-byte store per tile); lane
+//     (pixel p, window row a) reads rows a, a + 1 of its window and blends the 2r + 1 outputs of that row in the reference's operation
+//     order; the level-0 epilogue writes both levels' interleaved record (torch.stack([c0, c1], -1)).
+// Edges the rounds cannot take (more than TMAX tiles at a level) are computed tap by tap straight from memory by one wave (correct for
+// any coordinates, slow: the plan sends such edges to the per-edge kernel instead).  The dead tail of the plan (edges whose boxes lie
+// outside the frame at both levels: 11 % at cfg2) is zero-filled.
+#pragma once
+
+typedef _Float16 rg_h8 __attribute__((ext_vector_type(8)));
+typedef float rg_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned rg_u4 __attribute__((ext_vector_type(4)));
+
+template <int RMAX_, int NW_, int EW_, int TMAX_, int RC_>
+struct RgShape {
+  static constexpr int RMAX = RMAX_, NW = NW_, EW = EW_, TMAX = TMAX_, RC = RC_;
+  static constexpr int DMAX = 2 * RMAX + 2, DM = DMAX - 1, NPASS = (DM + 6) / 7;
+  static constexpr int THREADS = 64 * NW;
+  static constexpr int SLOTS = NW * EW;                         // edges per round
+  static constexpr int CHMAX = 64;                              // plan slots per chunk (one thread each in the prologue)
+  static constexpr int NBCH = (SLOTS * PP * 64 + 1023) / 1024;  // 1 KB pieces of one patch slab: [slot][pixel][64 B]
+  static constexpr int BUNIT = NBCH * 1024;
+  static constexpr int BUFSZ = RC * 4096 + BUNIT;               // one slab buffer: region planes, then the patch slab(s)
+  static constexpr int SP = TMAX * 16 + 4;                      // scratch: floats per pixel row (+4: bank spread)
+  static constexpr int SCRW = PP * SP * 4;                      // scratch bytes per wave
+  static constexpr int DPW = (RC + NW - 1) / NW, BPW = (NBCH + NW - 1) / NW;   // DMA pieces per wave, plane and unit
+  static_assert(NW * SCRW <= 2 * BUFSZ, "the epilogue scratch lives in the slab buffers (both are idle then)");
+  static_assert(SP >= DMAX * DMAX, "the tap-by-tap path keeps raw windows in the scratch");
+  static_assert(THREADS >= CHMAX && SLOTS <= CHMAX, "one prologue thread per plan slot");
+  static_assert(16 * TMAX < 64 * RC && TMAX % 2 == 0, "a single edge must fit the region; tiles go in pairs");
+};
+
+// LDS-DMA: 16 bytes per lane, source = buffer descriptor + per-lane offset (out of range: zeros, no access) + scalar offset,
+// destination = lds_addr + 16 * lane.  Issued through asm: hipcc's waitcnt insertion does not know it (rg_wait_dma()).
+__device__ __forceinline__ void rg_dma16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_addr), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void rg_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void rg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 4 fp32 values -> fp16 (hi0..3 | lo0..3), x = hi + lo to 2^-22 (|lo| below the fp16 normal range keeps 2^-25 absolute)
+__device__ __forceinline__ rg_h8 rg_split4(rg_f4 x) {
+  unsigned h01, h23, l01 = 0, l23 = 0;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(x[0]), "v"(x[1]));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(x[2]), "v"(x[3]));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(x[0]));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(x[1]));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(x[2]));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(x[3]));
+  const rg_u4 r = {h01, h23, l01, l23};
+  return __builtin_bit_cast(rg_h8, r);
+}
+
+template <typename T, typename S>
+__global__ __launch_bounds__(S::THREADS) void corr_fwd_region_kernel(
+    const T* __restrict__ fmap1t, CorrLevel lv0, CorrLevel lv1, const float* __restrict__ coords, const int64_t* __restrict__ ii,
+    const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2, int C, int64_t oes, int64_t ols, int R,
+    const int* __restrict__ order, int nchunks, unsigned f1t_bytes, int band_rows) {
+  constexpr bool HALF = sizeof(T) == 2;
+  constexpr unsigned ESZ = sizeof(T);
+  constexpr int CS = HALF ? 32 : 16, PCH = 16 / (int)ESZ;      // channels per slab unit / per 16-byte piece
+  constexpr int NW = S::NW, EW = S::EW, TMAX = S::TMAX, RC = S::RC, SLOTS = S::SLOTS, CHMAX = S::CHMAX, DMAX = S::DMAX, DM = S::DM;
+  constexpr int NPASS = S::NPASS, SP = S::SP, NBCH = S::NBCH, BUNIT = S::BUNIT, BUFSZ = S::BUFSZ, DPW = S::DPW, BPW = S::BPW;
+  constexpr int CAP = RC * 64 - 1;                              // region positions (one more slot stays zero)
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char rg_lds[];     // 2 slab buffers
+  __shared__ float s_xy[CHMAX][2 * PP];
+  __shared__ short s_box[2][CHMAX][4];                          // unclipped union box of the 9 windows: x0, y0, width, height
+  __shared__ short s_cb[2][CHMAX][4];                           // ... clipped to the frame: x0, y0, x1, y1 (empty = dead at the level)
+  __shared__ short s_reg[2][CHMAX][4];                          // region of the round that starts at sorted index s
+  __shared__ int s_be[CHMAX], s_prow[CHMAX], s_fid[CHMAX], s_b[CHMAX], s_fj[CHMAX];
+  __shared__ unsigned s_key[CHMAX];
+  __shared__ int s_perm[CHMAX], s_end[CHMAX], s_rstart[CHMAX + 1];
+  __shared__ int s_cnt[2];                                      // edges the rounds take / rounds
+
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = 2 * R + 2, Dm = D - 1;
+  const unsigned lds0 = (unsigned)(uintptr_t)rg_lds;
+  // chunk of the plan: XCD x (= blockIdx % 8) owns a contiguous range of chunks
+  int chunk;
+  {
+    const int g = blockIdx.x, per = (nchunks + 7) >> 3;
+    chunk = (g & 7) * per + (g >> 3);
+    if ((g >> 3) >= per || chunk >= nchunks) return;
+  }
+  const int nh = min(max(order[BE], 0), BE);                    // heavy slots in front: the per-edge kernel's
+  const int nd = min(max(order[2 * BE + 1], 0), BE - nh);        // dead slots at the end: zeros
+  const int nlive = BE - nh - nd;
+  const int cstart = nh + (int)((long long)chunk * nlive / nchunks), cend = nh + (int)((long long)(chunk + 1) * nlive / nchunks);
+  const int nch = min(cend - cstart, CHMAX);                    // (the launcher sizes nchunks so that nothing is cut off)
+  const float inv0 = 1.0f / lv0.coord_div, inv1 = 1.0f / lv1.coord_div;
+  const bool pow2 = ((__float_as_uint(lv0.coord_div) | __float_as_uint(lv1.coord_div)) & 0x807fffffu) == 0u;
+  auto scaled = [&](float v, int l) -> float { return pow2 ? v * (l ? inv1 : inv0) : v / (l ? lv1.coord_div : lv0.coord_div); };
+  const int64_t off0 = lv0.out_offset, off1 = lv1.out_offset;
+  const int nel = Dm * Dm * PP;
+
+  // ---- zero records for this chunk's share of the dead tail
+  for (int i = chunk; i < nd; i += nchunks) {
+    const int be = order[BE - nd + i];
+    T* o = out + (int64_t)be * oes;
+    for (int j = tid; j < nel; j += S::THREADS) { o[(int64_t)j * ols + off0] = from_f32<T>(0.0f); o[(int64_t)j * ols + off1] = from_f32<T>(0.0f); }
+  }
+  if (nch <= 0) return;
+
+  // ---- geometry: thread t < nch owns plan slot cstart + t
+  if (tid < nch) {
+    const int be = order[cstart + tid];
+    const int b = be / E, e = be - b * E;
+    const int64_t pi = ii[e], fj = jj[e];
+    const float2* __restrict__ ce = reinterpret_cast<const float2*>(coords + (int64_t)be * (2 * PP));
+    float cv[2 * PP];
+#pragma unroll
+    for (int p = 0; p < PP; p++) { const float2 v = ce[p]; cv[2 * p] = v.x; cv[2 * p + 1] = v.y; }
+#pragma unroll
+    for (int p = 0; p < 2 * PP; p++) s_xy[tid][p] = cv[p];
+    bool slow = false, dead = true;
+    int x0l0 = 0;
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      int xlo = 0x7fffffff, xhi = -0x7fffffff, ylo = 0x7fffffff, yhi = -0x7fffffff;
+#pragma unroll
+      for (int p = 0; p < PP; p++) {
+        const int ox = min(max(floor_to_int(scaled(cv[p], l)) - R, -30000), 30000), oy = min(max(floor_to_int(scaled(cv[PP + p], l)) - R, -30000), 30000);
+        xlo = min(xlo, ox); xhi = max(xhi, ox); ylo = min(ylo, oy); yhi = max(yhi, oy);
+      }
+      const int bw = xhi - xlo + D, bh = yhi - ylo + D;
+      const int H2 = l ? lv1.H2 : lv0.H2, W2 = l ? lv1.W2 : lv0.W2;
+      const int cx0 = max(xlo, 0), cy0 = max(ylo, 0), cx1 = min(xlo + bw, W2), cy1 = min(ylo + bh, H2);
+      const bool live = cx1 > cx0 && cy1 > cy0;
+      s_box[l][tid][0] = (short)xlo; s_box[l][tid][1] = (short)ylo; s_box[l][tid][2] = (short)min(bw, 32767); s_box[l][tid][3] = (short)min(bh, 32767);
+      s_cb[l][tid][0] = (short)cx0; s_cb[l][tid][1] = (short)cy0; s_cb[l][tid][2] = (short)(live ? cx1 : cx0); s_cb[l][tid][3] = (short)(live ? cy1 : cy0);
+      if (live) { dead = false; if ((long long)bw * bh > 16 * TMAX) slow = true; }
+      if (l == 0) x0l0 = xlo;
+    }
+    const int fid = b * n2 + (int)fj;
+    s_be[tid] = be; s_prow[tid] = b * Np + (int)pi; s_fid[tid] = fid; s_b[tid] = b; s_fj[tid] = (int)fj;
+    // sort key: (frame, plan band of the patch centre, box origin x); dead edges behind the live ones, tap-by-tap edges last
+    const int band = min(max((int)fminf(fmaxf(cv[PP + 4] * (pow2 ? inv0 : 1.0f / lv0.coord_div), 0.0f), (float)(lv0.H2 - 1)) / max(band_rows, 1), 0), 255);
+    unsigned key = ((unsigned)min(fid, 2047) << 20) | ((unsigned)band << 12) | (unsigned)min(max(x0l0 + 1024, 0), 4095);
+    if (dead) key = 0xfffffff0u;
+    if (slow) key = 0xffffffffu;
+    s_key[tid] = key;
+  }
+  if (tid < 2) s_cnt[tid] = 0;
+  __syncthreads();
+  if (tid < nch) {                                              // rank sort (ties by slot)
+    const unsigned k = s_key[tid];
+    int rank = 0;
+    for (int j = 0; j < nch; j++) { const unsigned kj = s_key[j]; rank += (kj < k || (kj == k && j < tid)) ? 1 : 0; }
+    s_perm[rank] = tid;
+    if (k != 0xffffffffu) atomicAdd(&s_cnt[0], 1);
+  }
+  __syncthreads();
+  const int nround_edges = __builtin_amdgcn_readfirstlane(s_cnt[0]);   // sorted indices [0, nround_edges) go through rounds
+  {
+    // greedy round from every start s (thread s): edges s .. s_end[s] - 1 and their union region per level
+    const int nrmin = (nround_edges + SLOTS - 1) / SLOTS, rlim = nrmin > 0 ? (nround_edges + nrmin - 1) / nrmin : 1;   // balanced rounds
+    if (tid < nround_edges) {
+      const int f0 = s_fid[s_perm[tid]];
+      int X[2][4];
+#pragma unroll
+      for (int l = 0; l < 2; l++) { X[l][0] = 32767; X[l][1] = 32767; X[l][2] = -32768; X[l][3] = -32768; }
+      int e = tid;
+      for (; e < nround_edges && e - tid < rlim; e++) {
+        const int t = s_perm[e];
+        if (s_fid[t] != f0) break;
+        int N[2][4];
+        bool fits = true;
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+          const int a0 = s_cb[l][t][0], a1 = s_cb[l][t][1], a2 = s_cb[l][t][2], a3 = s_cb[l][t][3];
+          const bool live = a2 > a0 && a3 > a1;
+          N[l][0] = live ? min(X[l][0], a0) : X[l][0]; N[l][1] = live ? min(X[l][1], a1) : X[l][1];
+          N[l][2] = live ? max(X[l][2], a2) : X[l][2]; N[l][3] = live ? max(X[l][3], a3) : X[l][3];
+          if (max(N[l][2] - N[l][0], 0) * max(N[l][3] - N[l][1], 0) > CAP) fits = false;
+        }
+        if (!fits) break;                                       // (never at e == tid: one edge is <= 16 TMAX positions)
+#pragma unroll
+        for (int l = 0; l < 2; l++) { X[l][0] = N[l][0]; X[l][1] = N[l][1]; X[l][2] = N[l][2]; X[l][3] = N[l][3]; }
+      }
+      s_end[tid] = e;
+#pragma unroll
+      for (int l = 0; l < 2; l++) {
+        const bool any = X[l][2] > X[l][0] && X[l][3] > X[l][1];
+        s_reg[l][tid][0] = (short)(any ? X[l][0] : 0); s_reg[l][tid][1] = (short)(any ? X[l][1] : 0);
+        s_reg[l][tid][2] = (short)(any ? X[l][2] : 0); s_reg[l][tid][3] = (short)(any ? X[l][3] : 0);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int nr = 0;
+      for (int s = 0; s < nround_edges; s = s_end[s]) s_rstart[nr++] = s;
+      s_rstart[nr] = nround_edges;
+      s_cnt[1] = nr;
+    }
+    __syncthreads();
+  }
+  const int nrounds = __builtin_amdgcn_readfirstlane(s_cnt[1]);
+
+  const int m = lane & 15, kg = lane >> 4;                      // MFMA operand row / column, k group
+  const int ep = lane % PP, ea0 = lane / PP;                    // epilogue: pixel, window row (lane 63 idles)
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(fmap1t), 0, f1t_bytes, 0x00020000);
+  const int NS = C / CS;
+  const bool paired = (ols == 2 && off1 == off0 + 1 && (oes & 1) == 0 && (off0 & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & (2 * ESZ - 1)) == 0);
+  constexpr unsigned OFF_NONE = 0x80000000u;
+
+  // Blend of one (edge, level) for this lane's pixel out of a scratch area: tap (a, c) at scr[base + a * pitch + c].
+  // o[pass][cx] = the reference's blend4 of window row a0 + 7 pass (correlation_kernel.cu:227-230, same operation order).
+  auto blend_rows = [&](const float* scr, int base, int pitch, float dx, float dy, bool have, float (&o)[NPASS][DM]) {
+    float w00, w01, w10, w11;
+    {
+#pragma clang fp contract(off)
+      w00 = (1.0f - dx) * (1.0f - dy); w01 = dx * (1.0f - dy); w10 = (1.0f - dx) * dy; w11 = dx * dy;
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ps++) {
+      const int a = ea0 + 7 * ps;
+      const bool act = have && lane < 63 && a < Dm;
+      float r0[DMAX], r1[DMAX];
+      const float* rp = scr + base + a * pitch;
+#pragma unroll
+      for (int j = 0; j < DMAX; j++) { r0[j] = (act && j < D) ? rp[j] : 0.0f; r1[j] = (act && j < D) ? rp[pitch + j] : 0.0f; }
+#pragma unroll
+      for (int cx = 0; cx < DM; cx++) {
+        float v;
+        {
+#pragma clang fp contract(off)
+          v = w00 * r0[cx]; v = v + w01 * r0[cx + 1]; v = v + w10 * r1[cx]; v = v + w11 * r1[cx + 1];
+        }
+        o[ps][cx] = v;
+      }
+    }
+  };
+  // the lane's pixel of edge t at level l: window origin and sub-pixel fractions
+  auto pixel_geo = [&](int t, int l, int& ox, int& oy, float& dx, float& dy) {
+    const float qx = scaled(s_xy[t][ep], l), qy = scaled(s_xy[t][PP + ep], l);
+    ox = min(max(floor_to_int(qx) - R, -30000), 30000); oy = min(max(floor_to_int(qy) - R, -30000), 30000);
+    dx = qx - floorf(qx); dy = qy - floorf(qy);
+  };
+  // both levels' outputs of the lane's window rows -> the edge's record
+  auto store_rows = [&](int be, const float (&o0)[NPASS][DM], const float (&o1)[NPASS][DM]) {
+    T* op = out + (int64_t)be * oes;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ps++) {
+      const int a = ea0 + 7 * ps;
+      if (lane < 63 && a < Dm) {
+#pragma unroll
+        for (int cx = 0; cx < DM; cx++) {
+          if (cx < Dm) {
+            const int64_t el = (int64_t)((cx * Dm + a) * PP + ep);
+            if (paired) {
+              if constexpr (HALF) {
+                const unsigned short u0 = __half_as_ushort(__float2half(o0[ps][cx])), u1 = __half_as_ushort(__float2half(o1[ps][cx]));
+                __builtin_nontemporal_store((unsigned)u0 | ((unsigned)u1 << 16), reinterpret_cast<unsigned*>(op + el * 2 + off0));
+              } else {
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                const f2v v = {o0[ps][cx], o1[ps][cx]};
+                __builtin_nontemporal_store(v, reinterpret_cast<f2v*>(op + el * 2 + off0));
+              }
+            } else {
+              store_streamed(op + el * ols + off0, from_f32<T>(o0[ps][cx]));
+              store_streamed(op + el * ols + off1, from_f32<T>(o1[ps][cx]));
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // ===================================================== rounds
+  for (int r = 0; r < nrounds; r++) {
+    const int rs = __builtin_amdgcn_readfirstlane(s_rstart[r]), re = __builtin_amdgcn_readfirstlane(s_rstart[r + 1]);
+    int tk[EW];                                                  // chunk-local edge of this wave's k-th slot (-1: none)
+#pragma unroll
+    for (int k = 0; k < EW; k++) { const int idx = rs + k * NW + w; tk[k] = idx < re ? __builtin_amdgcn_readfirstlane(s_perm[idx]) : -1; }
+    const int t_first = __builtin_amdgcn_readfirstlane(s_perm[rs]);
+    const int fb = __builtin_amdgcn_readfirstlane(s_b[t_first]), ffj = __builtin_amdgcn_readfirstlane(s_fj[t_first]);
+    // patch DMA offsets (level-independent): piece c' = w + j NW covers (slot, pixel) pairs 16 c' .. 16 c' + 15, 4 lanes each
+    unsigned voffB[BPW];
+#pragma unroll
+    for (int j = 0; j < BPW; j++) {
+      const int pair = 16 * (w + j * NW) + (lane >> 2), slot = pair / PP, px = pair - slot * PP, idx = rs + slot;
+      voffB[j] = OFF_NONE;
+      if (slot < SLOTS && idx < re) voffB[j] = (unsigned)((s_prow[s_perm[idx]] * PP + px) * C) * ESZ + (unsigned)(lane & 3) * 16u;
+    }
+    float res1[EW][NPASS][DM];                                  // level-1 outputs of the lane's rows (wait for level 0)
+#pragma unroll
+    for (int k = 0; k < EW; k++)
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ps++)
+#pragma unroll
+        for (int cx = 0; cx < DM; cx++) res1[k][ps][cx] = 0.0f;
+
+#pragma unroll
+    for (int li = 0; li < 2; li++) {
+      const int l = 1 - li;                                      // level 1 first
+      const CorrLevel& lv = l ? lv1 : lv0;
+      const int X0 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][0]), Y0 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][1]);
+      const int X1 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][2]), Y1 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][3]);
+      const int RW = X1 - X0, npos = RW * (Y1 - Y0);
+      rg_f4 acc[EW][TMAX];
+#pragma unroll
+      for (int k = 0; k < EW; k++)
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) acc[k][t] = rg_f4{0.f, 0.f, 0.f, 0.f};
+      int nt[EW], bx0[EW], by0[EW], bwk[EW];
+#pragma unroll
+      for (int k = 0; k < EW; k++) {
+        nt[k] = 0; bx0[k] = 0; by0[k] = 0; bwk[k] = 1;
+        if (tk[k] >= 0) {
+          const int t = tk[k];
+          const bool live = s_cb[l][t][2] > s_cb[l][t][0] && s_cb[l][t][3] > s_cb[l][t][1];
+          bx0[k] = __builtin_amdgcn_readfirstlane((int)s_box[l][t][0]); by0[k] = __builtin_amdgcn_readfirstlane((int)s_box[l][t][1]);
+          bwk[k] = __builtin_amdgcn_readfirstlane((int)s_box[l][t][2]);
+          nt[k] = __builtin_amdgcn_readfirstlane(live ? (bwk[k] * (int)s_box[l][t][3] + 15) >> 4 : 0);
+        }
+      }
+      if (npos > 0) {                                            // (block-uniform) else: every edge of the round is dead at this level
+        const int nchk = (npos + 64) >> 6;                       // 64-position pieces per plane (>= one zero slot behind the region)
+        const unsigned PS = (unsigned)nchk * 1024u;
+        int U = 1;
+        while (2 * U <= NS && NS % (2 * U) == 0 && (unsigned)(2 * U) * (4u * PS + (unsigned)BUNIT) <= (unsigned)BUFSZ) U *= 2;
+        const int NI = NS / U;
+        const unsigned boff = (unsigned)U * 4u * PS;            // patch slabs behind the region planes
+        unsigned voff[DPW];
+        {
+          const float inv_rw = __builtin_amdgcn_rcpf((float)RW);
+#pragma unroll
+          for (int j = 0; j < DPW; j++) {
+            const int pos = 64 * (w + j * NW) + lane;
+            const int py = (int)(((float)pos + 0.5f) * inv_rw), px = pos - py * RW;
+            voff[j] = pos < npos ? (unsigned)((Y0 + py) * (int)lv.s_h + (X0 + px) * (int)lv.s_w) * ESZ : OFF_NONE;
+          }
+        }
+        unsigned aaddr[EW][TMAX];
+#pragma unroll
+        for (int k = 0; k < EW; k++) {
+          const int bw = bwk[k], ncell = __builtin_amdgcn_readfirstlane(max(nt[k] > 0 ? bw * (int)s_box[l][max(tk[k], 0)][3] : 1, 1));
+          const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
+#pragma unroll
+          for (int t = 0; t < TMAX; t++) {
+            const int i = min(16 * t + m, ncell - 1);
+            const int iy = (int)(((float)i + 0.5f) * inv_bw), ix = i - iy * bw;
+            const int gx = bx0[k] + ix, gy = by0[k] + iy;
+            const bool in = gx >= X0 && gx < X1 && gy >= Y0 && gy < Y1;
+            const int pos = in ? (gy - Y0) * RW + (gx - X0) : npos;
+            aaddr[k][t] = (unsigned)kg * PS + (unsigned)pos * 16u;
+          }
+        }
+        const T* fbase = static_cast<const T*>(lv.fmap2) + (int64_t)fb * lv.s_b + (int64_t)ffj * lv.s_n;
+        const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(fbase), 0, lv.frame_bytes, 0x00020000);
+        const int sh = lv.cb_shift;
+        const unsigned bb = (unsigned)lv.block_stride * ESZ;
+        auto piece = [&](unsigned c) -> unsigned { const unsigned blk = c >> sh; return blk * bb + (c - (blk << sh)) * ESZ; };
+        auto issue = [&](int it, int bi) {
+          const unsigned base = lds0 + (unsigned)bi * (unsigned)BUFSZ;
+          for (int u = 0; u < U; u++) {
+            const unsigned unit = (unsigned)(it * U + u);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const unsigned so = piece(unit * CS + (unsigned)q * PCH);
+#pragma unroll
+              for (int j = 0; j < DPW; j++) {
+                const int c = w + j * NW;
+                if (c < nchk) rg_dma16(voff[j], rsF, so, base + ((unsigned)(u * 4 + q)) * PS + (unsigned)c * 1024u);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < BPW; j++) {
+              const int c = w + j * NW;
+              if (c < NBCH) rg_dma16(voffB[j], rsB, unit * 64u, base + boff + (unsigned)u * BUNIT + (unsigned)c * 1024u);
+            }
+          }
+        };
+        auto compute = [&](int bi) {
+          const unsigned char* buf = rg_lds + (size_t)bi * BUFSZ;
+          for (int u = 0; u < U; u++) {
+            const unsigned char* ra = buf + (size_t)u * 4 * PS;
+            const unsigned char* rb = buf + boff + (size_t)u * BUNIT + (size_t)(min(m, PP - 1) * 64 + kg * 16);
+#pragma unroll
+            for (int k = 0; k < EW; k++) {
+              if (nt[k] > 0) {                                   // (wave-uniform)
+                const unsigned char* bp = rb + (size_t)((k * NW + w) * PP * 64);
+                if constexpr (HALF) {
+                  const rg_h8 bv = *reinterpret_cast<const rg_h8*>(bp);
+#pragma unroll
+                  for (int t = 0; t < TMAX; t += 2)               // tiles in pairs (a surplus tile re-reads the last cell: harmless)
+                    if (t < nt[k]) {
+                      const rg_h8 av0 = *reinterpret_cast<const rg_h8*>(ra + aaddr[k][t]);
+                      const rg_h8 av1 = *reinterpret_cast<const rg_h8*>(ra + aaddr[k][t + 1]);
+                      acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, bv, acc[k][t], 0, 0, 0);
+                      acc[k][t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, bv, acc[k][t + 1], 0, 0, 0);
+                    }
+                } else {
+                  const rg_h8 ys = rg_split4(*reinterpret_cast<const rg_f4*>(bp));      // (yh0..3 | yl0..3)
+                  const rg_u4 yu = __builtin_bit_cast(rg_u4, ys);
+                  const rg_h8 b1 = __builtin_bit_cast(rg_h8, rg_u4{yu[0], yu[1], yu[0], yu[1]});   // [yh | yh]
+                  const rg_h8 b2 = __builtin_bit_cast(rg_h8, rg_u4{yu[2], yu[3], 0u, 0u});         // [yl | 0]
+#pragma unroll
+                  for (int t = 0; t < TMAX; t += 2)
+                    if (t < nt[k]) {
+                      const rg_h8 av0 = rg_split4(*reinterpret_cast<const rg_f4*>(ra + aaddr[k][t]));       // [xh | xl]
+                      const rg_h8 av1 = rg_split4(*reinterpret_cast<const rg_f4*>(ra + aaddr[k][t + 1]));
+                      acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, b1, acc[k][t], 0, 0, 0);
+                      acc[k][t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, b1, acc[k][t + 1], 0, 0, 0);
+                      acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, b2, acc[k][t], 0, 0, 0);
+                      acc[k][t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, b2, acc[k][t + 1], 0, 0, 0);
+                    }
+                }
+              }
+            }
+          }
+        };
+        issue(0, 0);
+        rg_wait_dma();
+        rg_barrier();
+        for (int it = 0; it < NI; it++) {
+          if (it + 1 < NI) issue(it + 1, (it + 1) & 1);
+          compute(it & 1);
+          rg_wait_dma();
+          rg_barrier();
+        }
+      }
+      // ---- epilogue of the level: tiles -> scratch -> blended rows
+      float* scr = reinterpret_cast<float*>(rg_lds + (size_t)w * S::SCRW);       // (no DMA is in flight: both slab buffers are idle)
+#pragma unroll
+      for (int k = 0; k < EW; k++) {
+        if (tk[k] >= 0) {                                        // (wave-uniform)
+          float o[NPASS][DM];
+          const bool have = nt[k] > 0;
+          if (have) {
+            if (m < PP) {
+#pragma unroll
+              for (int t = 0; t < TMAX; t++)
+                if (t < nt[k]) *reinterpret_cast<rg_f4*>(scr + m * SP + 16 * t + 4 * kg) = acc[k][t];
+            }
+            wave_lds_fence();
+          }
+          int ox, oy; float dx, dy;
+          pixel_geo(tk[k], l, ox, oy, dx, dy);
+          blend_rows(scr, ep * SP + (oy - by0[k]) * bwk[k] + (ox - bx0[k]), bwk[k], dx, dy, have, o);
+          if (l == 1) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ps++)
+#pragma unroll
+              for (int cx = 0; cx < DM; cx++) res1[k][ps][cx] = o[ps][cx];
+          } else {
+            store_rows(s_be[tk[k]], o, res1[k]);
+          }
+          if (have) wave_lds_fence();
+        }
+      }
+      rg_barrier();                                              // the scratch buffer is a DMA target again
+    }
+  }
+
+  // ===================================================== edges the rounds could not take: tap by tap, one wave per edge
+  for (int i = nround_edges + w; i < nch; i += NW) {
+    const int t = __builtin_amdgcn_readfirstlane(s_perm[i]);
+    float* scr = reinterpret_cast<float*>(rg_lds + (size_t)w * S::SCRW);
+    float o1[NPASS][DM], o0[NPASS][DM];
+    const int64_t prow = s_prow[t];
+#pragma unroll
+    for (int li = 0; li < 2; li++) {
+      const int l = 1 - li;
+      const CorrLevel& lv = l ? lv1 : lv0;
+      const T* fbase = static_cast<const T*>(lv.fmap2) + (int64_t)s_b[t] * lv.s_b + (int64_t)s_fj[t] * lv.s_n;
+      const int sh = lv.cb_shift;
+      const int64_t bs = lv.block_stride;
+      const int ntap = D * D;
+      for (int idx = lane; idx < PP * ntap; idx += 64) {
+        const int p = idx / ntap, rr = idx - p * ntap, a = rr / D, c = rr - a * D;
+        const int gx = floor_to_int(scaled(s_xy[t][p], l)) - R + c, gy = floor_to_int(scaled(s_xy[t][PP + p], l)) - R + a;
+        float sum = 0.0f;
+        if (gx >= 0 && gx < lv.W2 && gy >= 0 && gy < lv.H2) {
+          const T* fp = fbase + (int64_t)gy * lv.s_h + (int64_t)gx * lv.s_w;
+          const T* gp = fmap1t + (prow * PP + p) * C;
+          for (int k = 0; k < C; k++) {
+            const int blk = k >> sh;
+            sum += to_f32(gp[k]) * to_f32(fp[(int64_t)blk * bs + (k - (blk << sh))]);
+          }
+        }
+        scr[p * SP + rr] = sum;
+      }
+      wave_lds_fence();
+      int ox, oy; float dx, dy;
+      pixel_geo(t, l, ox, oy, dx, dy);
+      if (l == 1) blend_rows(scr, ep * SP, D, dx, dy, true, o1); else blend_rows(scr, ep * SP, D, dx, dy, true, o0);
+      wave_lds_fence();
+    }
+    store_rows(s_be[t], o0, o1);
+  }
+}
+
+// fmap1 [N][C][9] -> [N][9][C]: the B operand of the region kernel is 16 contiguous bytes per (pixel, 16-byte channel piece)
+template <typename T>
+__global__ __launch_bounds__(256) void corr_patch_transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pt_lds[];
+  T* s = reinterpret_cast<T*>(pt_lds);
+  const int n = blockIdx.x;
+  if (n >= N) return;
+  const T* in = src + (int64_t)n * C * PP;
+  T* o = dst + (int64_t)n * C * PP;
+  for (int i = threadIdx.x; i < C * PP; i += 256) s[i] = in[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * PP; i += 256) { const int p = i / C, c = i - p * C; o[i] = s[c * PP + p]; }
+}

@@ -40,12 +40,30 @@ __host__ __device__ __forceinline__ int corr_plan_bx(int xw) {   // column bins 
 // plan land next to each other in the image, which is what the region-staged lookup kernel (corr_dense.h) groups on.
 // x[p], y[p]: integer pixel of patch pixel p at the plan's level.  `geom` = corr_plan_pack(): bands | column bins << 8 |
 // column-bin width << 16.
+//
+// Pyramid mode (l1 >= 2: the lookup has a second level at 1 / l1 of the plan level's resolution, W2 = the plan level's width): the
+// classes are those of the region-shared lookup kernel (corr_region.h) —
+//   DEAD  (returns dead_bin, the bin behind all others): the union box lies outside the frame at BOTH levels: all outputs are 0;
+//   HEAVY (-1): more than `heavy_cells` box positions at a level where the box touches the frame (the region kernel keeps
+//         heavy_cells / 16 accumulator tiles per edge and level): these go to the per-edge kernel.
 __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float centre_x, float centre_y, int b, int frame, int n2,
-                                             int H2, int geom, int D, int ng) {
+                                             int H2, int geom, int D, int ng, int W2 = 0, int l1 = 0, int heavy_cells = 0,
+                                             int dead_bin = -1) {
   const int nb = geom & 0xff, nxb = (geom >> 8) & 0xff, xw = geom >> 16;
   int xlo = x[0], xhi = x[0], ylo = y[0], yhi = y[0];
 #pragma unroll
   for (int p = 1; p < 9; p++) { xlo = min(xlo, x[p]); xhi = max(xhi, x[p]); ylo = min(ylo, y[p]); yhi = max(yhi, y[p]); }
+  if (l1 >= 2) {
+    const int R = (D - 2) / 2;
+    auto fdiv = [](int v, int d) -> int { return v >= 0 ? v / d : -((-v + d - 1) / d); };      // floor(v / d)
+    // window origins: floor(coordinate) - R at level 0, floor(coordinate / l1) - R = floor(floor(coordinate) / l1) - R at level 1
+    const int x0 = xlo - R, y0 = ylo - R, w0 = xhi - xlo + D, h0 = yhi - ylo + D;
+    const int x1 = fdiv(xlo, l1) - R, y1 = fdiv(ylo, l1) - R, w1 = fdiv(xhi, l1) - fdiv(xlo, l1) + D, h1 = fdiv(yhi, l1) - fdiv(ylo, l1) + D;
+    const bool live0 = x0 < W2 && y0 < H2 && x0 + w0 > 0 && y0 + h0 > 0;
+    const bool live1 = x1 < W2 / l1 && y1 < H2 / l1 && x1 + w1 > 0 && y1 + h1 > 0;
+    if (!live0 && !live1) return dead_bin;
+    if ((live0 && (long long)w0 * h0 > heavy_cells) || (live1 && (long long)w1 * h1 > heavy_cells)) return -1;
+  } else
   // HEAVY = clearly more passes of the matrix-core kernel than a compact patch needs at this radius — more than two 64-position
   // passes for r <= 3, more than four for r <= 5 (a compact r = 5 box is 14 x 14 = 196 positions: with the r <= 3 threshold EVERY
   // edge of BASELINE's stress configuration was HEAVY, i.e. unsorted, and its lookup ran at half speed) — which includes every
@@ -60,10 +78,17 @@ __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float c
   // edges one XCD works on at the same time — cover a compact 2-D tile of the frame instead of a strip as wide as the frame: the
   // same number of edges then touches fewer distinct rows + margins of the pyramid (stress configuration: 2.8 MB instead of 4.4 MB
   // for 512 edges, against 4 MB of L2 per XCD).
+  // (pyramid mode: plain band-major numbering — the region kernel wants long runs of image neighbours along a band)
   const int bx = corr_plan_bx(xw), nbx = (nxb + bx - 1) / bx, nbb = (nb + CORR_PLAN_BB - 1) / CORR_PLAN_BB;
-  const int in_frame = ((band / CORR_PLAN_BB) * nbx + xb / bx) * (CORR_PLAN_BB * bx) + (band % CORR_PLAN_BB) * bx + (xb % bx);
+  const int in_frame = l1 >= 2 ? band * nxb + xb
+                               : ((band / CORR_PLAN_BB) * nbx + xb / bx) * (CORR_PLAN_BB * bx) + (band % CORR_PLAN_BB) * bx + (xb % bx);
   return (b * n2 + f) * (nbb * nbx * CORR_PLAN_BB * bx) + in_frame;
 }
+
+// Region-shared lookup kernel (corr_region.h): accumulator tiles (16 box positions each) an edge may have per level; the pyramid
+// plan's HEAVY class is exactly "more cells than these tiles hold".
+__host__ __device__ constexpr int corr_region_tmax(int radius) { return radius <= 3 ? 10 : 16; }
+struct CorrPlanMode { int W2, l1, heavy_cells, dead_bin; };     // l1 < 2: single-level plan (legacy classes)
 
 // Bins of the plan: row bands of 16 rows per frame (coarser if there are many frames: the counting sort keeps one LDS
 // counter per bin) x column bins of >= 8 px (the frame width is not part of the plan's interface: columns beyond
@@ -89,7 +114,8 @@ inline CorrPlanGeom corr_plan_geom(long long B, int n2, int H2) {
   return g;
 }
 inline int corr_plan_pack(const CorrPlanGeom& g) { return g.nb | (g.nxb << 8) | (g.xw << 16); }
-inline long long corr_plan_nbins(long long B, int n2, const CorrPlanGeom& g) { return B * n2 * corr_plan_bins_per_frame(g); }
+// all bins of a plan: the (frame, band, column) bins and, behind them, the DEAD class of the pyramid mode
+inline long long corr_plan_nbins(long long B, int n2, const CorrPlanGeom& g) { return B * n2 * corr_plan_bins_per_frame(g) + 1; }
 
 // Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS round trips like ds_bpermute shuffles):
 // Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8; lanes without a source add 0), then the last lane of row 0 / 2

@@ -50,7 +50,7 @@ const char* devo_last_error(void); /* thread-local message of the last failing c
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
                       const int64_t* f2s /* host, 5 */, int cblock, int64_t out_estride, int64_t out_lstride,
-                      int64_t out_offset, int radius, int dtype, const int* order /* plan buffer, i32 [>= B*E + 1], or NULL */,
+                      int64_t out_offset, int radius, int dtype, const int* order /* plan buffer of devo_corr_order, i32 [2*B*E + 2], or NULL */,
                       float coord_div /* coords are divided by this in the kernel (correctly rounded IEEE division; pyramid level
                                          scale, 1 = as given; DEVO's scales 1 and 4 are exact either way) */,
                       devo_stream_t stream);
@@ -65,11 +65,20 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
                                int P, const int* hw /* host: H0, W0, H1, W1 */, const int64_t* f2s /* host: 5 + 5 */,
                                const int* cblock /* host, 2 */, int64_t out_estride, int64_t out_lstride,
                                const int64_t* out_offset /* host, 2 */, int radius, int dtype, const int* order,
-                               const float* coord_div /* host, 2 */, devo_stream_t stream);
+                               const float* coord_div /* host, 2 */,
+                               const void* fmap1_t /* optional: fmap1 as [B*Np, P*P, C] (devo_corr_patch_transpose).  With it, a pyramid plan
+                                                      (devo_corr_order with l1 >= 2) and channel-blocked / channels-last levels the lookup runs
+                                                      on the region-shared kernel: image neighbours read ONE staged copy of the frame
+                                                      region they cover.  NULL: the per-edge kernel */,
+                               devo_stream_t stream);
+
+/* fmap1 T [n_patches, C, 3, 3] -> fmap1_t T [n_patches, 9, C] (the patch operand layout of the region-shared lookup kernel; the
+ * patch features of DEVO change once per frame, not per update iteration: transpose once, reuse).  DEVO_F32 / DEVO_F16. */
+int devo_corr_patch_transpose(const void* fmap1, void* fmap1_t, int n_patches, int C, int dtype, devo_stream_t stream);
 
 /* Locality plan for devo_corr_forward (no reference counterpart: the reference walks edges in list order).
- * order i32 [2*B*E + 1] (the plan buffer; devo_corr_forward reads the first B*E + 1 entries, the rest is scratch
- * of this call): first the HEAVY edge slots (union box of the 9 windows clearly larger than a compact patch's at
+ * order i32 [2*B*E + 2] (the plan buffer; devo_corr_forward reads the first B*E + 1 entries and the last one (number of DEAD edges at
+ * the end of the order, 0 for a single-level plan), the rest is scratch of this call): first the HEAVY edge slots (union box of the 9 windows clearly larger than a compact patch's at
  * this radius — more than 128 positions for radius <= 3, more than 256 for radius <= 5 — or larger than the staged
  * kernel's LDS tile: they run 2-4x longer and should start first), then the others sorted by (batch, target frame jj,
  * bin of the patch centre: 16-row bands x 8-px columns, numbered in blocks of 4 bands x ~64 px), so that the lookup
@@ -78,7 +87,13 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
  * is the factor the caller divides coords by for the pyramid level whose height is H2 (1 for level 0); one
  * plan serves all levels of a pyramid.  The plan only changes WHICH edges run together, never any result. */
 int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, int E, int n2, int P, int H2,
-                    float coord_scale, int radius, devo_stream_t stream);
+                    float coord_scale, int radius,
+                    int W2 /* width of the plan's level; only read when l1 >= 2 */,
+                    int l1 /* 0: single-level plan.  >= 2 (DEVO: 4): PYRAMID plan for devo_corr_forward_pyramid2 — the lookup has a second
+                              level at 1 / l1 of this resolution.  Classes: DEAD edges (union box outside the frame at both levels: every
+                              output is 0) go BEHIND all others, order[2*B*E + 1] = their number; HEAVY = more than 160 (radius <= 3) / 256
+                              box positions at a level the box touches; bins are numbered band by band */,
+                    devo_stream_t stream);
 
 /* Pyramid build for the lookup (devo/devo.py:526-527: fmap1_[slot] = avg_pool2d(fmap, 1, 1), fmap2_[slot] =
  * avg_pool2d(fmap, 4, 4); devo/utils.py:70-79): F frames fmap T [F, C, H, W] (contiguous frames, frame stride
@@ -136,7 +151,7 @@ int devo_ba_prepare(const int64_t* kk, int E, int Np, int N /* t1 - t0 */, void*
                     devo_stream_t stream);
 /* devo_ba_prepare + the ordering step of the lookup's locality plan (devo_corr_order with coords = NULL) in ONE launch:
  * both are single-workgroup, latency-bound kernels that do not depend on each other, so they run as two workgroups side
- * by side.  plan: i32 [2E + 1] whose bins devo_transform(..., plan, plan_frames, plan_height, radius) has written
+ * by side.  plan: i32 [2E + 2] whose bins devo_transform(..., plan, plan_frames, plan_height, radius) has written
  * (batch 1); afterwards it is the finished plan for devo_corr_forward*. */
 int devo_ba_prepare_plan(const int64_t* kk, int E, int Np, int N /* t1 - t0 */, void* ws, size_t ws_bytes, int* plan,
                          int plan_frames, int plan_height, devo_stream_t stream);
@@ -217,14 +232,15 @@ int devo_ba_reproject(const float* poses, const float* patches, const float* int
  *   valid   f32 [E] or NULL (Z > 0.2 at the centre pixel, :100/:103)
  *   Ji, Jj  f32 [E,2,6], Jz f32 [E,2] or NULL  (:73-98; Ji already negated as in :96)
  *   flags   bit0 = depth, bit1 = tonly
- *   plan    optional locality-plan buffer of the lookup (i32 [2*E + 1], see devo_corr_order): while the
+ *   plan    optional locality-plan buffer of the lookup (i32 [2*E + 2], see devo_corr_order): while the
  *           coordinates are still in registers the kernel writes every edge's plan bin (for a pyramid whose
  *           level 0 has plan_frames frames of plan_height rows, lookup radius plan_radius) into the buffer's
  *           scratch half; devo_corr_order(coords = NULL, ...) then only sorts.  P == 3.  NULL = no plan. */
 int devo_transform(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
                    const int64_t* jj, const int64_t* kk, float* coords_pp2, float* coords_2pp, float* valid,
                    float* Ji, float* Jj, float* Jz, int E, int P, int flags, int* plan, int plan_frames,
-                   int plan_height, int plan_radius, devo_stream_t stream);
+                   int plan_height, int plan_radius, int plan_width, int plan_l1 /* as W2, l1 of devo_corr_order */,
+                   devo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * lietorch SE3 subset  (reference module lietorch_backends: devo/lietorch/src/lietorch.cpp:286-316,

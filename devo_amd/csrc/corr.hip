@@ -1096,9 +1096,9 @@ static int launch_region(const void* fmap1, const void* fmap1_t, const CorrLevel
                          int64_t ols, int R, const int* order, hipStream_t st) {
   typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;
   typedef void (*region_fn_t)(const MT*, CorrLevel, CorrLevel, const float*, const int64_t*, const int64_t*, MT*, int, int, int, int, int,
-                              int64_t, int64_t, int, const int*, int, unsigned, int);
+                              int64_t, int64_t, int, const int*, int, unsigned, int, unsigned long long*);
   typedef RgShape<3, 8, 3, corr_region_tmax(3), 15> S3;
-  typedef RgShape<5, 8, 2, corr_region_tmax(5), 15> S5;
+  typedef RgShape<5, 8, 2, corr_region_tmax(5), 16> S5;
   const region_fn_t fn = R <= 3 ? corr_fwd_region_kernel<MT, S3> : corr_fwd_region_kernel<MT, S5>;
   const size_t lds = 2 * (size_t)(R <= 3 ? S3::BUFSZ : S5::BUFSZ);
   const int threads = R <= 3 ? S3::THREADS : S5::THREADS, chmax = R <= 3 ? S3::CHMAX : S5::CHMAX;
@@ -1130,8 +1130,40 @@ static int launch_region(const void* fmap1, const void* fmap1_t, const CorrLevel
                        Np, n2, C, oes, ols, R, order, (unsigned long long*)nullptr, 1);
   }
   const long long f1t_bytes = (BE / (E > 0 ? E : 1)) * (long long)Np * C * PP * (long long)sizeof(MT);
+  unsigned long long* stats = nullptr;                                // debug switch: phase cycles of every workgroup's first wave to stderr
+  static const bool do_stats = getenv("DEVO_RG_STATS") != nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (do_stats) { (void)hipMalloc(&stats, 4096); (void)hipMemset(stats, 0, 4096); (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1); (void)hipEventRecord(ev0, st); }
   hipLaunchKernelGGL(fn, dim3((unsigned)nchunks), dim3(threads), lds, st, (const MT*)fmap1_t, lv0, lv1, coords, ii, jj, (MT*)out, (int)BE, E, Np,
-                     n2, C, oes, ols, R, order, (int)nchunks, (unsigned)f1t_bytes, DEVO_PLAN_BAND);
+                     n2, C, oes, ols, R, order, (int)nchunks, (unsigned)f1t_bytes, DEVO_PLAN_BAND, stats);
+  if (do_stats) {
+    (void)hipEventRecord(ev1, st);
+    (void)hipDeviceSynchronize();
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    unsigned long long h[16];
+    (void)hipMemcpy(h, stats, 128, hipMemcpyDeviceToHost);
+    const double g = h[9] ? (double)h[9] : 1.0;
+    fprintf(stderr, "[region stats] kernel %.1f us; %llu workgroups (%lld chunks), %.2f rounds and %.1f slab iterations per workgroup; first wave, cycles per workgroup: total %.0f = "
+            "prologue %.0f | stage set-up %.0f | first slab wait %.0f | products + DMA issue %.0f | left-over DMA issue %.0f | slab wait + barrier %.0f | epilogue + next stage's request %.0f | tail %.0f\n",
+            ms * 1e3, h[9], nchunks, h[8] / g, h[10] / g, h[11] / g, h[0] / g, h[1] / g, h[2] / g, h[3] / g, h[4] / g, h[5] / g, h[6] / g, h[7] / g);
+    {
+      unsigned long long tr[4 * 8 * 4];
+      (void)hipMemcpy(tr, stats + 16, sizeof(tr), hipMemcpyDeviceToHost);
+      const int nw = threads / 64;
+      unsigned long long t0 = ~0ULL;
+      for (int i = 0; i < 4 * nw * 4; i++) if (tr[i] && tr[i] < t0) t0 = tr[i];
+      for (int it = 0; it < 4; it++) {
+        fprintf(stderr, "[region trace] chunk 100, stage 1, slab %d: per wave (start, second phase, both done, past the barrier):", it);
+        for (int w = 0; w < nw; w++) {
+          const unsigned long long* q = tr + (it * nw + w) * 4;
+          fprintf(stderr, "  w%d %llu %llu %llu %llu", w, q[0] - t0, q[1] - t0, q[2] - t0, q[3] - t0);
+        }
+        fprintf(stderr, "\n");
+      }
+    }
+    (void)hipFree(stats);
+  }
   return check_launch("devo_corr_forward_pyramid2 (region kernel)");
 }
 
@@ -1174,7 +1206,7 @@ static bool region_eligible(const CorrLevel& l0, const CorrLevel& l1, const void
 extern "C" {
 
 int devo_corr_patch_transpose(const void* fmap1, void* fmap1_t, int n_patches, int C, int dtype, devo_stream_t stream) {
-  DEVO_REQUIRE(n_patches >= 0 && C > 0, "devo_corr_patch_transpose: bad sizes");
+  DEVO_REQUIRE(n_patches >= 0 && C > 0 && C % 4 == 0, "devo_corr_patch_transpose: bad sizes (C must be a multiple of 4)");
   DEVO_REQUIRE(dtype == DEVO_F32 || dtype == DEVO_F16, "devo_corr_patch_transpose: fp32 / fp16 only");
   if (n_patches == 0) return DEVO_OK;
   DEVO_REQUIRE(fmap1 && fmap1_t, "devo_corr_patch_transpose: null tensor");

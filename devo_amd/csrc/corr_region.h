@@ -14,9 +14,10 @@
 //   * LDS image of a slab: 4 planes [16-byte piece][position] — the A operand of v_mfma_f32_16x16x32_f16 (16 box positions x 32 k)
 //     is one ds_read_b128 per lane; B = the patch (9 of 16 columns used) from the patch area; every wave keeps the accumulators of
 //     its EW edges (TMAX tiles of 16 box positions each) in registers across the slabs;
-//   * fp32 storage: a staged value x is split where it is read into fp16 hi + lo (v_cvt_pk_f16_f32 + v_fma_mix: 6 instructions per
-//     4 channels), K = [hi | lo] of 16 channels against [hi | hi] and [lo | 0] of the patch: x y = xh yh + xl yh + xh yl with fp32
-//     accumulation (2^-22 relative per factor; domain |feature| <= 65504);
+//   * fp32 storage: when a slab has landed, every 16-byte piece (4 channels) is rewritten IN PLACE as fp16 (hi0..3 | lo0..3), x = hi + lo
+//     (v_cvt_pk_f16_f32 + v_fma_mix: 6 instructions per piece, once per staged value); the patches arrive split already
+//     (devo_corr_patch_transpose).  K = [hi | lo] of 16 channels against [hi | hi] and [lo | 0] of the patch: x y = xh yh + xl yh + xh yl
+//     with fp32 accumulation (2^-22 relative per factor; domain |feature| <= 65504);
 //   * epilogue: the 16 x 16 result tiles go through a per-wave scratch [pixel][box position] (one 16-byte store per tile); lane
 //     (pixel p, window row a) reads rows a, a + 1 of its window and blends the 2r + 1 outputs of that row in the reference's operation
 //     order; the level-0 epilogue writes both levels' interleaved record (torch.stack([c0, c1], -1)).
@@ -39,13 +40,13 @@ struct RgShape {
   static constexpr int NBCH = (SLOTS * PP * 64 + 1023) / 1024;  // 1 KB pieces of one patch slab: [slot][pixel][64 B]
   static constexpr int BUNIT = NBCH * 1024;
   static constexpr int BUFSZ = RC * 4096 + BUNIT;               // one slab buffer: region planes, then the patch slab(s)
-  static constexpr int SP = TMAX * 16 + 4;                      // scratch: floats per pixel row (+4: bank spread)
+  static constexpr int SP = TMAX * 16 + (RMAX <= 3 ? 4 : 0);    // scratch: floats per pixel row (+4: bank spread)
   static constexpr int SCRW = PP * SP * 4;                      // scratch bytes per wave
   static constexpr int DPW = (RC + NW - 1) / NW, BPW = (NBCH + NW - 1) / NW;   // DMA pieces per wave, plane and unit
-  static_assert(NW * SCRW <= 2 * BUFSZ, "the epilogue scratch lives in the slab buffers (both are idle then)");
+  static_assert(NW * SCRW <= BUFSZ, "the epilogue scratch lives in slab buffer 0 (buffer 1 takes the next stage's first slab meanwhile)");
   static_assert(SP >= DMAX * DMAX, "the tap-by-tap path keeps raw windows in the scratch");
   static_assert(THREADS >= CHMAX && SLOTS <= CHMAX, "one prologue thread per plan slot");
-  static_assert(16 * TMAX < 64 * RC && TMAX % 2 == 0, "a single edge must fit the region; tiles go in pairs");
+  static_assert(16 * TMAX < 64 * RC && TMAX % 4 == 0, "a single edge must fit the region; tiles go in batches of 4");
 };
 
 // LDS-DMA: 16 bytes per lane, source = buffer descriptor + per-lane offset (out of range: zeros, no access) + scalar offset,
@@ -58,42 +59,56 @@ __device__ __forceinline__ void rg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 // 4 fp32 values -> fp16 (hi0..3 | lo0..3), x = hi + lo to 2^-22 (|lo| below the fp16 normal range keeps 2^-25 absolute)
 __device__ __forceinline__ rg_h8 rg_split4(rg_f4 x) {
-  unsigned h01, h23, l01 = 0, l23 = 0;
+  unsigned h01, h23, l01, l23;
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(x[0]), "v"(x[1]));
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(x[2]), "v"(x[3]));
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(x[0]));
+  // (mixlo keeps the destination's upper half, which mixhi then overwrites: no initialisation needed)
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(x[0]));
   asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(x[1]));
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(x[2]));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(x[2]));
   asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(x[3]));
   const rg_u4 r = {h01, h23, l01, l23};
   return __builtin_bit_cast(rg_h8, r);
 }
 
 template <typename T, typename S>
-__global__ __launch_bounds__(S::THREADS) void corr_fwd_region_kernel(
+__global__ __launch_bounds__(S::THREADS, 2) void corr_fwd_region_kernel(
     const T* __restrict__ fmap1t, CorrLevel lv0, CorrLevel lv1, const float* __restrict__ coords, const int64_t* __restrict__ ii,
     const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2, int C, int64_t oes, int64_t ols, int R,
-    const int* __restrict__ order, int nchunks, unsigned f1t_bytes, int band_rows) {
+    const int* __restrict__ order, int nchunks, unsigned f1t_bytes, int band_rows, unsigned long long* __restrict__ stats) {
   constexpr bool HALF = sizeof(T) == 2;
   constexpr unsigned ESZ = sizeof(T);
   constexpr int CS = HALF ? 32 : 16, PCH = 16 / (int)ESZ;      // channels per slab unit / per 16-byte piece
   constexpr int NW = S::NW, EW = S::EW, TMAX = S::TMAX, RC = S::RC, SLOTS = S::SLOTS, CHMAX = S::CHMAX, DMAX = S::DMAX, DM = S::DM;
   constexpr int NPASS = S::NPASS, SP = S::SP, NBCH = S::NBCH, BUNIT = S::BUNIT, BUFSZ = S::BUFSZ, DPW = S::DPW, BPW = S::BPW;
   constexpr int CAP = RC * 64 - 1;                              // region positions (one more slot stays zero)
+  constexpr int OPU = 4 * DPW + BPW;                            // DMA instructions a wave may have per slab unit
+  constexpr unsigned OFF_NONE = 0x80000000u;
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char rg_lds[];     // 2 slab buffers
   __shared__ float s_xy[CHMAX][2 * PP];
-  __shared__ short s_box[2][CHMAX][4];                          // unclipped union box of the 9 windows: x0, y0, width, height
-  __shared__ short s_cb[2][CHMAX][4];                           // ... clipped to the frame: x0, y0, x1, y1 (empty = dead at the level)
-  __shared__ short s_reg[2][CHMAX][4];                          // region of the round that starts at sorted index s
-  __shared__ int s_be[CHMAX], s_prow[CHMAX], s_fid[CHMAX], s_b[CHMAX], s_fj[CHMAX];
+  __shared__ __attribute__((aligned(8))) short s_box[2][CHMAX][4];   // unclipped union box of the 9 windows: x0, y0, width, height (by slot)
+  __shared__ __attribute__((aligned(8))) short s_cb[2][CHMAX][4];    // clipped to the frame: x0, y0, x1, y1 (empty = dead at the level); SORTED order
+  __shared__ __attribute__((aligned(8))) short s_reg[2][CHMAX][4];   // region of the round that starts at sorted index s
+  __shared__ int s_be[CHMAX], s_prow[CHMAX], s_b[CHMAX], s_fj[CHMAX];
+  __shared__ int s_fid[CHMAX];                                  // frame id, SORTED order
   __shared__ unsigned s_key[CHMAX];
   __shared__ int s_perm[CHMAX], s_end[CHMAX], s_rstart[CHMAX + 1];
   __shared__ int s_cnt[2];                                      // edges the rounds take / rounds
+  // what a stage needs of its level, read from LDS when the stage is set up (held in scalar registers the two CorrLevel arguments
+  // cost ~50 of them for the whole kernel): [l][0..1] fmap2, [2..3] s_b, [4..5] s_n, [6] s_h, [7] s_w, [8] cb_shift, [9] block bytes, [10] frame bytes
+  __shared__ unsigned s_lv[2][12];
 
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = 2 * R + 2, Dm = D - 1;
   const unsigned lds0 = (unsigned)(uintptr_t)rg_lds;
+  // debug (DEVO_RG_STATS=1): cycles of wave 0 per phase, summed over the workgroups: [0] prologue, [1] stage set-up, [2] waiting for a
+  // stage's first slab, [3] products (with the next slab's DMA instructions in between), [4] left-over DMA instructions, [5] waiting for the
+  // slab + barrier, [6] epilogue, [7] tap-by-tap edges + dead tail, [8] rounds, [9] workgroups, [10] slab iterations, [11] total
+  unsigned long long st_t = stats ? __builtin_readcyclecounter() : 0ULL, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long st_begin = st_t;
+  auto stamp = [&](int i) { if (stats) { const unsigned long long t = __builtin_readcyclecounter(); st_acc[i] += t - st_t; st_t = t; } };
+  unsigned st_iters = 0;
   // chunk of the plan: XCD x (= blockIdx % 8) owns a contiguous range of chunks
   int chunk;
   {
@@ -110,17 +125,10 @@ __global__ __launch_bounds__(S::THREADS) void corr_fwd_region_kernel(
   const bool pow2 = ((__float_as_uint(lv0.coord_div) | __float_as_uint(lv1.coord_div)) & 0x807fffffu) == 0u;
   auto scaled = [&](float v, int l) -> float { return pow2 ? v * (l ? inv1 : inv0) : v / (l ? lv1.coord_div : lv0.coord_div); };
   const int64_t off0 = lv0.out_offset, off1 = lv1.out_offset;
-  const int nel = Dm * Dm * PP;
-
-  // ---- zero records for this chunk's share of the dead tail
-  for (int i = chunk; i < nd; i += nchunks) {
-    const int be = order[BE - nd + i];
-    T* o = out + (int64_t)be * oes;
-    for (int j = tid; j < nel; j += S::THREADS) { o[(int64_t)j * ols + off0] = from_f32<T>(0.0f); o[(int64_t)j * ols + off1] = from_f32<T>(0.0f); }
-  }
-  if (nch <= 0) return;
 
   // ---- geometry: thread t < nch owns plan slot cstart + t
+  short bx_[2][4], cb_[2][4];
+  int fid_ = 0;
   if (tid < nch) {
     const int be = order[cstart + tid];
     const int b = be / E, e = be - b * E;
@@ -145,27 +153,43 @@ __global__ __launch_bounds__(S::THREADS) void corr_fwd_region_kernel(
       const int H2 = l ? lv1.H2 : lv0.H2, W2 = l ? lv1.W2 : lv0.W2;
       const int cx0 = max(xlo, 0), cy0 = max(ylo, 0), cx1 = min(xlo + bw, W2), cy1 = min(ylo + bh, H2);
       const bool live = cx1 > cx0 && cy1 > cy0;
-      s_box[l][tid][0] = (short)xlo; s_box[l][tid][1] = (short)ylo; s_box[l][tid][2] = (short)min(bw, 32767); s_box[l][tid][3] = (short)min(bh, 32767);
-      s_cb[l][tid][0] = (short)cx0; s_cb[l][tid][1] = (short)cy0; s_cb[l][tid][2] = (short)(live ? cx1 : cx0); s_cb[l][tid][3] = (short)(live ? cy1 : cy0);
+      bx_[l][0] = (short)xlo; bx_[l][1] = (short)ylo; bx_[l][2] = (short)min(bw, 32767); bx_[l][3] = (short)(live ? min(bh, 32767) : 0);   // height 0 = dead at the level
+      cb_[l][0] = (short)cx0; cb_[l][1] = (short)cy0; cb_[l][2] = (short)(live ? cx1 : cx0); cb_[l][3] = (short)(live ? cy1 : cy0);
       if (live) { dead = false; if ((long long)bw * bh > 16 * TMAX) slow = true; }
       if (l == 0) x0l0 = xlo;
+#pragma unroll
+      for (int q = 0; q < 4; q++) s_box[l][tid][q] = bx_[l][q];
     }
-    const int fid = b * n2 + (int)fj;
-    s_be[tid] = be; s_prow[tid] = b * Np + (int)pi; s_fid[tid] = fid; s_b[tid] = b; s_fj[tid] = (int)fj;
+    fid_ = b * n2 + (int)fj;
+    s_be[tid] = be; s_prow[tid] = b * Np + (int)pi; s_b[tid] = b; s_fj[tid] = (int)fj;
     // sort key: (frame, plan band of the patch centre, box origin x); dead edges behind the live ones, tap-by-tap edges last
     const int band = min(max((int)fminf(fmaxf(cv[PP + 4] * (pow2 ? inv0 : 1.0f / lv0.coord_div), 0.0f), (float)(lv0.H2 - 1)) / max(band_rows, 1), 0), 255);
-    unsigned key = ((unsigned)min(fid, 2047) << 20) | ((unsigned)band << 12) | (unsigned)min(max(x0l0 + 1024, 0), 4095);
+    unsigned key = ((unsigned)min(fid_, 2047) << 20) | ((unsigned)band << 12) | (unsigned)min(max(x0l0 + 1024, 0), 4095);
     if (dead) key = 0xfffffff0u;
     if (slow) key = 0xffffffffu;
     s_key[tid] = key;
   }
   if (tid < 2) s_cnt[tid] = 0;
+  if (tid < 2) {
+    const CorrLevel& lv = tid ? lv1 : lv0;
+    const unsigned long long fp = (unsigned long long)reinterpret_cast<uintptr_t>(lv.fmap2);
+    s_lv[tid][0] = (unsigned)fp; s_lv[tid][1] = (unsigned)(fp >> 32);
+    s_lv[tid][2] = (unsigned)(unsigned long long)lv.s_b; s_lv[tid][3] = (unsigned)((unsigned long long)lv.s_b >> 32);
+    s_lv[tid][4] = (unsigned)(unsigned long long)lv.s_n; s_lv[tid][5] = (unsigned)((unsigned long long)lv.s_n >> 32);
+    s_lv[tid][6] = (unsigned)lv.s_h; s_lv[tid][7] = (unsigned)lv.s_w; s_lv[tid][8] = (unsigned)lv.cb_shift;
+    s_lv[tid][9] = (unsigned)lv.block_stride * ESZ; s_lv[tid][10] = lv.frame_bytes;
+  }
   __syncthreads();
-  if (tid < nch) {                                              // rank sort (ties by slot)
+  if (tid < nch) {                                              // rank sort (ties by slot); frame ids and clipped boxes move to sorted order
     const unsigned k = s_key[tid];
     int rank = 0;
     for (int j = 0; j < nch; j++) { const unsigned kj = s_key[j]; rank += (kj < k || (kj == k && j < tid)) ? 1 : 0; }
     s_perm[rank] = tid;
+    s_fid[rank] = fid_;
+#pragma unroll
+    for (int l = 0; l < 2; l++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) s_cb[l][rank][q] = cb_[l][q];
     if (k != 0xffffffffu) atomicAdd(&s_cnt[0], 1);
   }
   __syncthreads();
@@ -174,19 +198,18 @@ __global__ __launch_bounds__(S::THREADS) void corr_fwd_region_kernel(
     // greedy round from every start s (thread s): edges s .. s_end[s] - 1 and their union region per level
     const int nrmin = (nround_edges + SLOTS - 1) / SLOTS, rlim = nrmin > 0 ? (nround_edges + nrmin - 1) / nrmin : 1;   // balanced rounds
     if (tid < nround_edges) {
-      const int f0 = s_fid[s_perm[tid]];
+      const int f0 = s_fid[tid];
       int X[2][4];
 #pragma unroll
       for (int l = 0; l < 2; l++) { X[l][0] = 32767; X[l][1] = 32767; X[l][2] = -32768; X[l][3] = -32768; }
       int e = tid;
       for (; e < nround_edges && e - tid < rlim; e++) {
-        const int t = s_perm[e];
-        if (s_fid[t] != f0) break;
+        if (s_fid[e] != f0) break;
         int N[2][4];
         bool fits = true;
 #pragma unroll
         for (int l = 0; l < 2; l++) {
-          const int a0 = s_cb[l][t][0], a1 = s_cb[l][t][1], a2 = s_cb[l][t][2], a3 = s_cb[l][t][3];
+          const int a0 = s_cb[l][e][0], a1 = s_cb[l][e][1], a2 = s_cb[l][e][2], a3 = s_cb[l][e][3];
           const bool live = a2 > a0 && a3 > a1;
           N[l][0] = live ? min(X[l][0], a0) : X[l][0]; N[l][1] = live ? min(X[l][1], a1) : X[l][1];
           N[l][2] = live ? max(X[l][2], a2) : X[l][2]; N[l][3] = live ? max(X[l][3], a3) : X[l][3];
@@ -214,13 +237,13 @@ __global__ __launch_bounds__(S::THREADS) void corr_fwd_region_kernel(
     __syncthreads();
   }
   const int nrounds = __builtin_amdgcn_readfirstlane(s_cnt[1]);
+  stamp(0);
 
   const int m = lane & 15, kg = lane >> 4;                      // MFMA operand row / column, k group
   const int ep = lane % PP, ea0 = lane / PP;                    // epilogue: pixel, window row (lane 63 idles)
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(fmap1t), 0, f1t_bytes, 0x00020000);
   const int NS = C / CS;
   const bool paired = (ols == 2 && off1 == off0 + 1 && (oes & 1) == 0 && (off0 & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & (2 * ESZ - 1)) == 0);
-  constexpr unsigned OFF_NONE = 0x80000000u;
 
   // Blend of one (edge, level) for this lane's pixel out of a scratch area: tap (a, c) at scr[base + a * pitch + c].
   // o[pass][cx] = the reference's blend4 of window row a0 + 7 pass (correlation_kernel.cu:227-230, same operation order).
@@ -285,192 +308,262 @@ __global__ __launch_bounds__(S::THREADS) void corr_fwd_region_kernel(
     }
   };
 
-  // ===================================================== rounds
-  for (int r = 0; r < nrounds; r++) {
-    const int rs = __builtin_amdgcn_readfirstlane(s_rstart[r]), re = __builtin_amdgcn_readfirstlane(s_rstart[r + 1]);
-    int tk[EW];                                                  // chunk-local edge of this wave's k-th slot (-1: none)
+  // ===================================================== stages: (round 0, level 1), (round 0, level 0), (round 1, level 1), ...
+  // What the DMA of a stage needs (wave-uniform except the per-lane offsets): computed one stage AHEAD, so that the first slab of
+  // the next stage is in flight under the current stage's epilogue.  Slab `it` of a stage lands in buffer (it + 1) & 1; the epilogue's
+  // scratch lives in buffer 0.
+  struct DmaP {
+    int nchk, U, NI;                  // 64-position pieces per plane, slab units per iteration, iterations (0: nothing to stage)
+    unsigned PS, boff, bb;            // plane stride, offset of the patch slabs, byte stride of a channel block
+    int sh;
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff[DPW];
+  };
+  unsigned voffB_nxt[BPW], voffB[BPW];
 #pragma unroll
-    for (int k = 0; k < EW; k++) { const int idx = rs + k * NW + w; tk[k] = idx < re ? __builtin_amdgcn_readfirstlane(s_perm[idx]) : -1; }
-    const int t_first = __builtin_amdgcn_readfirstlane(s_perm[rs]);
-    const int fb = __builtin_amdgcn_readfirstlane(s_b[t_first]), ffj = __builtin_amdgcn_readfirstlane(s_fj[t_first]);
-    // patch DMA offsets (level-independent): piece c' = w + j NW covers (slot, pixel) pairs 16 c' .. 16 c' + 15, 4 lanes each
-    unsigned voffB[BPW];
+  for (int j = 0; j < BPW; j++) { voffB[j] = OFF_NONE; voffB_nxt[j] = OFF_NONE; }
+  auto dma_params = [&](int stage, DmaP& P) {
+    const int r = stage >> 1, l = 1 - (stage & 1);
+    auto lvw = [&](int i) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)s_lv[l][i]); };
+    const int rs_ = __builtin_amdgcn_readfirstlane(s_rstart[r]), re_ = __builtin_amdgcn_readfirstlane(s_rstart[r + 1]);
+    const int X0 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs_][0]), Y0 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs_][1]);
+    const int X1 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs_][2]), Y1 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs_][3]);
+    const int RW = X1 - X0, npos = RW * (Y1 - Y0);
+    P.nchk = (npos + 64) >> 6;
+    P.PS = (unsigned)P.nchk * 1024u;
+    int U = 1;
+    while (2 * U <= NS && NS % (2 * U) == 0 && (unsigned)(2 * U) * (4u * P.PS + (unsigned)BUNIT) <= (unsigned)BUFSZ) U *= 2;
+    P.U = U; P.NI = npos > 0 ? NS / U : 0;
+    P.boff = (unsigned)U * 4u * P.PS;
+    P.sh = (int)lvw(8); P.bb = lvw(9);
+    const int t_first = __builtin_amdgcn_readfirstlane(s_perm[rs_]);
+    const long long sb = (long long)(((unsigned long long)lvw(3) << 32) | lvw(2)), sn = (long long)(((unsigned long long)lvw(5) << 32) | lvw(4));
+    const T* fbase = reinterpret_cast<const T*>((uintptr_t)(((unsigned long long)lvw(1) << 32) | lvw(0))) +
+                     (long long)__builtin_amdgcn_readfirstlane(s_b[t_first]) * sb + (long long)__builtin_amdgcn_readfirstlane(s_fj[t_first]) * sn;
+    P.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(fbase), 0, lvw(10), 0x00020000);
+    const int sh_ = (int)lvw(6), sw_ = (int)lvw(7);
+    const float inv_rw = __builtin_amdgcn_rcpf((float)max(RW, 1));
 #pragma unroll
-    for (int j = 0; j < BPW; j++) {
-      const int pair = 16 * (w + j * NW) + (lane >> 2), slot = pair / PP, px = pair - slot * PP, idx = rs + slot;
-      voffB[j] = OFF_NONE;
-      if (slot < SLOTS && idx < re) voffB[j] = (unsigned)((s_prow[s_perm[idx]] * PP + px) * C) * ESZ + (unsigned)(lane & 3) * 16u;
+    for (int j = 0; j < DPW; j++) {
+      const int pos = 64 * (w + j * NW) + lane;
+      const int py = (int)(((float)pos + 0.5f) * inv_rw), px = pos - py * RW;
+      P.voff[j] = pos < npos ? (unsigned)((Y0 + py) * sh_ + (X0 + px) * sw_) * ESZ : OFF_NONE;
     }
-    float res1[EW][NPASS][DM];                                  // level-1 outputs of the lane's rows (wait for level 0)
+    if (l == 1) {                                                 // a new round: its patch slabs (piece c' = w + j NW: 16 (slot, pixel) pairs, 4 lanes each)
 #pragma unroll
-    for (int k = 0; k < EW; k++)
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ps++)
-#pragma unroll
-        for (int cx = 0; cx < DM; cx++) res1[k][ps][cx] = 0.0f;
-
-#pragma unroll
-    for (int li = 0; li < 2; li++) {
-      const int l = 1 - li;                                      // level 1 first
-      const CorrLevel& lv = l ? lv1 : lv0;
-      const int X0 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][0]), Y0 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][1]);
-      const int X1 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][2]), Y1 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][3]);
-      const int RW = X1 - X0, npos = RW * (Y1 - Y0);
-      rg_f4 acc[EW][TMAX];
-#pragma unroll
-      for (int k = 0; k < EW; k++)
-#pragma unroll
-        for (int t = 0; t < TMAX; t++) acc[k][t] = rg_f4{0.f, 0.f, 0.f, 0.f};
-      int nt[EW], bx0[EW], by0[EW], bwk[EW];
-#pragma unroll
-      for (int k = 0; k < EW; k++) {
-        nt[k] = 0; bx0[k] = 0; by0[k] = 0; bwk[k] = 1;
-        if (tk[k] >= 0) {
-          const int t = tk[k];
-          const bool live = s_cb[l][t][2] > s_cb[l][t][0] && s_cb[l][t][3] > s_cb[l][t][1];
-          bx0[k] = __builtin_amdgcn_readfirstlane((int)s_box[l][t][0]); by0[k] = __builtin_amdgcn_readfirstlane((int)s_box[l][t][1]);
-          bwk[k] = __builtin_amdgcn_readfirstlane((int)s_box[l][t][2]);
-          nt[k] = __builtin_amdgcn_readfirstlane(live ? (bwk[k] * (int)s_box[l][t][3] + 15) >> 4 : 0);
-        }
+      for (int j = 0; j < BPW; j++) {
+        const int pair = 16 * (w + j * NW) + (lane >> 2), slot = pair / PP, px = pair - slot * PP, idx = rs_ + slot;
+        voffB_nxt[j] = OFF_NONE;
+        if (slot < SLOTS && idx < re_) voffB_nxt[j] = (unsigned)((s_prow[s_perm[idx]] * PP + px) * C) * ESZ + (unsigned)(lane & 3) * 16u;
       }
-      if (npos > 0) {                                            // (block-uniform) else: every edge of the round is dead at this level
-        const int nchk = (npos + 64) >> 6;                       // 64-position pieces per plane (>= one zero slot behind the region)
-        const unsigned PS = (unsigned)nchk * 1024u;
-        int U = 1;
-        while (2 * U <= NS && NS % (2 * U) == 0 && (unsigned)(2 * U) * (4u * PS + (unsigned)BUNIT) <= (unsigned)BUFSZ) U *= 2;
-        const int NI = NS / U;
-        const unsigned boff = (unsigned)U * 4u * PS;            // patch slabs behind the region planes
-        unsigned voff[DPW];
-        {
-          const float inv_rw = __builtin_amdgcn_rcpf((float)RW);
+    }
+  };
+  // DMA instruction (unit u, number rem < OPU) of slab `it`: false = not this wave's / beyond the region
+  auto issue_op = [&](const DmaP& P, const unsigned (&vB)[BPW], int it, int u, int rem) -> bool {
+    const unsigned unit = (unsigned)(it * P.U + u);
+    const unsigned base = lds0 + (unsigned)((it + 1) & 1) * (unsigned)BUFSZ;
+    if (rem < 4 * DPW) {
+      const int q = rem / DPW, j = rem - q * DPW, c = w + j * NW;     // (DPW is a constant)
+      if (c >= P.nchk) return false;
+      const unsigned ch = unit * CS + (unsigned)q * PCH, blk = ch >> P.sh, so = blk * P.bb + (ch - (blk << P.sh)) * ESZ;
+      unsigned vo = P.voff[0];
 #pragma unroll
-          for (int j = 0; j < DPW; j++) {
-            const int pos = 64 * (w + j * NW) + lane;
-            const int py = (int)(((float)pos + 0.5f) * inv_rw), px = pos - py * RW;
-            voff[j] = pos < npos ? (unsigned)((Y0 + py) * (int)lv.s_h + (X0 + px) * (int)lv.s_w) * ESZ : OFF_NONE;
+      for (int jj_ = 1; jj_ < DPW; jj_++) vo = (j == jj_) ? P.voff[jj_] : vo;
+      rg_dma16(vo, P.rs, so, base + ((unsigned)(u * 4 + q)) * P.PS + (unsigned)c * 1024u);
+    } else {
+      const int j = rem - 4 * DPW, c = w + j * NW;
+      if (c >= NBCH) return false;
+      unsigned vo = vB[0];
+#pragma unroll
+      for (int jj_ = 1; jj_ < BPW; jj_++) vo = (j == jj_) ? vB[jj_] : vo;
+      rg_dma16(vo, rsB, unit * 64u, base + P.boff + (unsigned)u * BUNIT + (unsigned)c * 1024u);
+    }
+    return true;
+  };
+  auto issue_slab = [&](const DmaP& P, const unsigned (&vB)[BPW], int it) {
+    for (int u = 0; u < P.U; u++)
+      for (int rem = 0; rem < OPU; rem++) issue_op(P, vB, it, u, rem);
+  };
+  // fp32 storage: the slab in buffer bi, 16-byte piece by 16-byte piece, 4 floats -> (hi0..3 | lo0..3) in place (the patch slabs
+  // arrive split).  All threads; the caller puts barriers around it.
+  auto split_slab = [&](const DmaP& P, int bi) {
+    if constexpr (!HALF) {
+      unsigned char* buf = rg_lds + (size_t)bi * BUFSZ;
+      const int npieces = P.U * 4 * P.nchk * 64;
+      for (int i = tid; i < npieces; i += S::THREADS) {
+        rg_f4* p = reinterpret_cast<rg_f4*>(buf + (size_t)i * 16);
+        *reinterpret_cast<rg_h8*>(p) = rg_split4(*p);
+      }
+    }
+  };
+
+  float res1[EW][NPASS][DM];                                    // level-1 outputs of the lane's rows (wait for level 0)
+#pragma unroll
+  for (int k = 0; k < EW; k++)
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ps++)
+#pragma unroll
+      for (int cx = 0; cx < DM; cx++) res1[k][ps][cx] = 0.0f;
+
+  const int nstages = 2 * nrounds;
+  DmaP cur;
+  if (nstages > 0) {
+    dma_params(0, cur);
+#pragma unroll
+    for (int j = 0; j < BPW; j++) voffB[j] = voffB_nxt[j];
+    if (cur.NI > 0) issue_slab(cur, voffB, 0);
+  }
+  for (int stage = 0; stage < nstages; stage++) {
+    const int r = stage >> 1, l = 1 - (stage & 1);               // level 1 first: its results wait in registers
+    const int rs = __builtin_amdgcn_readfirstlane(s_rstart[r]), re = __builtin_amdgcn_readfirstlane(s_rstart[r + 1]);
+    const int X0 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][0]), Y0 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][1]);
+    const int X1 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][2]), Y1 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][3]);
+    const int RW = X1 - X0, npos = RW * (Y1 - Y0);
+    // ---- this wave's edges at this level: tiles, box, packed tile addresses (two 16-bit byte offsets per register)
+    int tk[EW], nt[EW], bx0[EW], by0[EW], bwk[EW];
+    unsigned apk[EW][TMAX / 2];
+    rg_f4 acc[EW][TMAX];
+#pragma unroll
+    for (int k = 0; k < EW; k++) {
+      const int idx = rs + k * NW + w;
+      tk[k] = idx < re ? __builtin_amdgcn_readfirstlane(s_perm[idx]) : -1;
+      nt[k] = 0; bx0[k] = 0; by0[k] = 0; bwk[k] = 1;
+      int ncell = 1;
+      if (tk[k] >= 0) {
+        const int t = tk[k];
+        bx0[k] = __builtin_amdgcn_readfirstlane((int)s_box[l][t][0]); by0[k] = __builtin_amdgcn_readfirstlane((int)s_box[l][t][1]);
+        bwk[k] = __builtin_amdgcn_readfirstlane((int)s_box[l][t][2]);
+        ncell = __builtin_amdgcn_readfirstlane(bwk[k] * (int)s_box[l][t][3]);        // (height 0: dead at this level)
+        nt[k] = (ncell + 15) >> 4;
+        ncell = max(ncell, 1);
+      }
+      const float inv_bw = __builtin_amdgcn_rcpf((float)bwk[k]);
+#pragma unroll
+      for (int t = 0; t < TMAX; t++) {
+        const int i = min(16 * t + m, ncell - 1);
+        const int iy = (int)(((float)i + 0.5f) * inv_bw), ix = i - iy * bwk[k];
+        const int gx = bx0[k] + ix, gy = by0[k] + iy;
+        const bool in = gx >= X0 && gx < X1 && gy >= Y0 && gy < Y1;
+        const unsigned pos16 = (unsigned)(in ? (gy - Y0) * RW + (gx - X0) : npos) * 16u;       // (outside the frame: the zero slot)
+        if (t & 1) apk[k][t >> 1] |= pos16 << 16; else apk[k][t >> 1] = pos16;
+      }
+#pragma unroll
+      for (int t = 0; t < TMAX; t++) acc[k][t] = rg_f4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned kgPS = (unsigned)kg * cur.PS;
+    stamp(1);
+    if (cur.NI > 0) {                                             // (block-uniform) else: every edge of the round is dead at this level
+      rg_wait_dma();                                              // slab 0 was requested a stage ago
+      rg_barrier();
+      stamp(2);
+      for (int it = 0; it < cur.NI; it++) {
+        const int bi = (it + 1) & 1;
+        if constexpr (!HALF) { split_slab(cur, bi); rg_barrier(); }
+        // Half of the waves request the next slab BEFORE their products, the other half AFTER: the two waves of a SIMD (w, w + NW / 2)
+        // are in opposite phases, so the matrix pipe works while the partner sits in its DMA instructions (a wave is held at each of
+        // them until the memory pipeline takes it: the CU's fill rate, ~20 B/clk, prices them at ~150-250 cycles apiece).
+        const unsigned char* buf = rg_lds + (size_t)bi * BUFSZ;
+        const bool more = it + 1 < cur.NI;
+        const bool tr = stats && chunk == 100 && stage == 1 && it < 4 && lane == 0;
+        unsigned long long* trp = stats + 16 + (it * NW + w) * 4;
+        if (tr) trp[0] = __builtin_readcyclecounter();
+#pragma unroll 1
+        for (int phase = 0; phase < 2; phase++) {
+          if (phase == 1 && tr) trp[1] = __builtin_readcyclecounter();
+          if ((phase == 0) == (w < NW / 2)) {
+            if (more) issue_slab(cur, voffB, it + 1);
+            continue;
           }
-        }
-        unsigned aaddr[EW][TMAX];
-#pragma unroll
-        for (int k = 0; k < EW; k++) {
-          const int bw = bwk[k], ncell = __builtin_amdgcn_readfirstlane(max(nt[k] > 0 ? bw * (int)s_box[l][max(tk[k], 0)][3] : 1, 1));
-          const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
-#pragma unroll
-          for (int t = 0; t < TMAX; t++) {
-            const int i = min(16 * t + m, ncell - 1);
-            const int iy = (int)(((float)i + 0.5f) * inv_bw), ix = i - iy * bw;
-            const int gx = bx0[k] + ix, gy = by0[k] + iy;
-            const bool in = gx >= X0 && gx < X1 && gy >= Y0 && gy < Y1;
-            const int pos = in ? (gy - Y0) * RW + (gx - X0) : npos;
-            aaddr[k][t] = (unsigned)kg * PS + (unsigned)pos * 16u;
-          }
-        }
-        const T* fbase = static_cast<const T*>(lv.fmap2) + (int64_t)fb * lv.s_b + (int64_t)ffj * lv.s_n;
-        const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(fbase), 0, lv.frame_bytes, 0x00020000);
-        const int sh = lv.cb_shift;
-        const unsigned bb = (unsigned)lv.block_stride * ESZ;
-        auto piece = [&](unsigned c) -> unsigned { const unsigned blk = c >> sh; return blk * bb + (c - (blk << sh)) * ESZ; };
-        auto issue = [&](int it, int bi) {
-          const unsigned base = lds0 + (unsigned)bi * (unsigned)BUFSZ;
-          for (int u = 0; u < U; u++) {
-            const unsigned unit = (unsigned)(it * U + u);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const unsigned so = piece(unit * CS + (unsigned)q * PCH);
-#pragma unroll
-              for (int j = 0; j < DPW; j++) {
-                const int c = w + j * NW;
-                if (c < nchk) rg_dma16(voff[j], rsF, so, base + ((unsigned)(u * 4 + q)) * PS + (unsigned)c * 1024u);
-              }
-            }
-#pragma unroll
-            for (int j = 0; j < BPW; j++) {
-              const int c = w + j * NW;
-              if (c < NBCH) rg_dma16(voffB[j], rsB, unit * 64u, base + boff + (unsigned)u * BUNIT + (unsigned)c * 1024u);
-            }
-          }
-        };
-        auto compute = [&](int bi) {
-          const unsigned char* buf = rg_lds + (size_t)bi * BUFSZ;
-          for (int u = 0; u < U; u++) {
-            const unsigned char* ra = buf + (size_t)u * 4 * PS;
-            const unsigned char* rb = buf + boff + (size_t)u * BUNIT + (size_t)(min(m, PP - 1) * 64 + kg * 16);
+          for (int u = 0; u < cur.U; u++) {
+            const unsigned char* ra = buf + (size_t)u * 4 * cur.PS + kgPS;
+            const unsigned char* rb = buf + cur.boff + (size_t)u * BUNIT + (size_t)(min(m, PP - 1) * 64 + kg * 16);
 #pragma unroll
             for (int k = 0; k < EW; k++) {
               if (nt[k] > 0) {                                   // (wave-uniform)
-                const unsigned char* bp = rb + (size_t)((k * NW + w) * PP * 64);
-                if constexpr (HALF) {
-                  const rg_h8 bv = *reinterpret_cast<const rg_h8*>(bp);
+                const rg_u4 yu = *reinterpret_cast<const rg_u4*>(rb + (size_t)((k * NW + w) * PP * 64));
+                rg_h8 b1, b2;
+                if constexpr (HALF) { b1 = __builtin_bit_cast(rg_h8, yu); b2 = b1; }
+                else {
+                  b1 = __builtin_bit_cast(rg_h8, rg_u4{yu[0], yu[1], yu[0], yu[1]});                            // [yh | yh]
+                  b2 = __builtin_bit_cast(rg_h8, rg_u4{yu[2], yu[3], 0u, 0u});                                  // [yl | 0]
+                }
 #pragma unroll
-                  for (int t = 0; t < TMAX; t += 2)               // tiles in pairs (a surplus tile re-reads the last cell: harmless)
-                    if (t < nt[k]) {
-                      const rg_h8 av0 = *reinterpret_cast<const rg_h8*>(ra + aaddr[k][t]);
-                      const rg_h8 av1 = *reinterpret_cast<const rg_h8*>(ra + aaddr[k][t + 1]);
-                      acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, bv, acc[k][t], 0, 0, 0);
-                      acc[k][t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, bv, acc[k][t + 1], 0, 0, 0);
-                    }
-                } else {
-                  const rg_h8 ys = rg_split4(*reinterpret_cast<const rg_f4*>(bp));      // (yh0..3 | yl0..3)
-                  const rg_u4 yu = __builtin_bit_cast(rg_u4, ys);
-                  const rg_h8 b1 = __builtin_bit_cast(rg_h8, rg_u4{yu[0], yu[1], yu[0], yu[1]});   // [yh | yh]
-                  const rg_h8 b2 = __builtin_bit_cast(rg_h8, rg_u4{yu[2], yu[3], 0u, 0u});         // [yl | 0]
+                for (int tb = 0; tb < TMAX; tb += 4) {            // batches of 4 tiles: the reads go out together (surplus tiles re-read the last cell)
+                  if (tb < nt[k]) {
+                    constexpr int NB = 4;
+                    static_assert(TMAX % NB == 0, "tiles go in batches of 4");
+                    rg_h8 av[NB];
 #pragma unroll
-                  for (int t = 0; t < TMAX; t += 2)
-                    if (t < nt[k]) {
-                      const rg_h8 av0 = rg_split4(*reinterpret_cast<const rg_f4*>(ra + aaddr[k][t]));       // [xh | xl]
-                      const rg_h8 av1 = rg_split4(*reinterpret_cast<const rg_f4*>(ra + aaddr[k][t + 1]));
-                      acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, b1, acc[k][t], 0, 0, 0);
-                      acc[k][t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, b1, acc[k][t + 1], 0, 0, 0);
-                      acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, b2, acc[k][t], 0, 0, 0);
-                      acc[k][t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, b2, acc[k][t + 1], 0, 0, 0);
+                    for (int j = 0; j < NB; j++) {
+                      const unsigned pk = apk[k][(tb + j) >> 1];
+                      av[j] = *reinterpret_cast<const rg_h8*>(ra + (((tb + j) & 1) ? (pk >> 16) : (pk & 0xffffu)));
                     }
+#pragma unroll
+                    for (int j = 0; j < NB; j++) acc[k][tb + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[j], b1, acc[k][tb + j], 0, 0, 0);
+                    if constexpr (!HALF) {
+#pragma unroll
+                      for (int j = 0; j < NB; j++) acc[k][tb + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[j], b2, acc[k][tb + j], 0, 0, 0);
+                    }
+                  }
                 }
               }
             }
           }
-        };
-        issue(0, 0);
+        }
+        stamp(3);
+        if (tr) trp[2] = __builtin_readcyclecounter();
         rg_wait_dma();
         rg_barrier();
-        for (int it = 0; it < NI; it++) {
-          if (it + 1 < NI) issue(it + 1, (it + 1) & 1);
-          compute(it & 1);
-          rg_wait_dma();
-          rg_barrier();
-        }
+        if (tr) trp[3] = __builtin_readcyclecounter();
+        stamp(5);
+        st_iters++;
       }
-      // ---- epilogue of the level: tiles -> scratch -> blended rows
-      float* scr = reinterpret_cast<float*>(rg_lds + (size_t)w * S::SCRW);       // (no DMA is in flight: both slab buffers are idle)
-#pragma unroll
-      for (int k = 0; k < EW; k++) {
-        if (tk[k] >= 0) {                                        // (wave-uniform)
-          float o[NPASS][DM];
-          const bool have = nt[k] > 0;
-          if (have) {
-            if (m < PP) {
-#pragma unroll
-              for (int t = 0; t < TMAX; t++)
-                if (t < nt[k]) *reinterpret_cast<rg_f4*>(scr + m * SP + 16 * t + 4 * kg) = acc[k][t];
-            }
-            wave_lds_fence();
-          }
-          int ox, oy; float dx, dy;
-          pixel_geo(tk[k], l, ox, oy, dx, dy);
-          blend_rows(scr, ep * SP + (oy - by0[k]) * bwk[k] + (ox - bx0[k]), bwk[k], dx, dy, have, o);
-          if (l == 1) {
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ps++)
-#pragma unroll
-              for (int cx = 0; cx < DM; cx++) res1[k][ps][cx] = o[ps][cx];
-          } else {
-            store_rows(s_be[tk[k]], o, res1[k]);
-          }
-          if (have) wave_lds_fence();
-        }
-      }
-      rg_barrier();                                              // the scratch buffer is a DMA target again
     }
+    // ---- the next stage's first slab goes out before this stage's epilogue (buffer 1; the scratch is in buffer 0)
+    DmaP nxt = cur;
+    if (stage + 1 < nstages) {
+      dma_params(stage + 1, nxt);
+      const unsigned (&vB)[BPW] = (l == 0) ? voffB_nxt : voffB;   // (a new round brings its own patch slabs)
+      if (nxt.NI > 0) issue_slab(nxt, vB, 0);
+    }
+    // ---- epilogue of the level: tiles -> scratch -> blended rows
+    float* scr = reinterpret_cast<float*>(rg_lds + (size_t)w * S::SCRW);
+#pragma unroll
+    for (int k = 0; k < EW; k++) {
+      if (tk[k] >= 0) {                                          // (wave-uniform)
+        float o[NPASS][DM];
+        const bool have = nt[k] > 0;
+        if (have) {
+          if (m < PP) {
+#pragma unroll
+            for (int t = 0; t < TMAX; t++)
+              if (t < nt[k]) *reinterpret_cast<rg_f4*>(scr + m * SP + 16 * t + 4 * kg) = acc[k][t];
+          }
+          wave_lds_fence();
+        }
+        int ox, oy; float dx, dy;
+        pixel_geo(tk[k], l, ox, oy, dx, dy);
+        blend_rows(scr, ep * SP + (oy - by0[k]) * bwk[k] + (ox - bx0[k]), bwk[k], dx, dy, have, o);
+        if (l == 1) {
+#pragma unroll
+          for (int ps = 0; ps < NPASS; ps++)
+#pragma unroll
+            for (int cx = 0; cx < DM; cx++) res1[k][ps][cx] = o[ps][cx];
+        } else {
+          store_rows(s_be[tk[k]], o, res1[k]);
+        }
+        if (have) wave_lds_fence();
+      }
+    }
+    rg_barrier();                                                // buffer 0 is a DMA target again
+    if (l == 0) {
+#pragma unroll
+      for (int j = 0; j < BPW; j++) voffB[j] = voffB_nxt[j];
+    }
+    cur = nxt;
+    stamp(6);
   }
+  rg_wait_dma();
 
   // ===================================================== edges the rounds could not take: tap by tap, one wave per edge
   for (int i = nround_edges + w; i < nch; i += NW) {
@@ -478,7 +571,7 @@ __global__ __launch_bounds__(S::THREADS) void corr_fwd_region_kernel(
     float* scr = reinterpret_cast<float*>(rg_lds + (size_t)w * S::SCRW);
     float o1[NPASS][DM], o0[NPASS][DM];
     const int64_t prow = s_prow[t];
-#pragma unroll
+#pragma unroll 1
     for (int li = 0; li < 2; li++) {
       const int l = 1 - li;
       const CorrLevel& lv = l ? lv1 : lv0;
@@ -495,7 +588,13 @@ __global__ __launch_bounds__(S::THREADS) void corr_fwd_region_kernel(
           const T* gp = fmap1t + (prow * PP + p) * C;
           for (int k = 0; k < C; k++) {
             const int blk = k >> sh;
-            sum += to_f32(gp[k]) * to_f32(fp[(int64_t)blk * bs + (k - (blk << sh))]);
+            float g;
+            if constexpr (HALF) g = to_f32(gp[k]);
+            else {                                               // (hi0..3 | lo0..3) per 4 channels
+              const _Float16* hp = reinterpret_cast<const _Float16*>(gp) + (k >> 2) * 8 + (k & 3);
+              g = (float)hp[0] + (float)hp[4];
+            }
+            sum += g * to_f32(fp[(int64_t)blk * bs + (k - (blk << sh))]);
           }
         }
         scr[p * SP + rr] = sum;
@@ -508,9 +607,26 @@ __global__ __launch_bounds__(S::THREADS) void corr_fwd_region_kernel(
     }
     store_rows(s_be[t], o0, o1);
   }
+  // ===================================================== zero records for this chunk's share of the dead tail
+  {
+    const int nel = Dm * Dm * PP;
+    for (int i = chunk; i < nd; i += nchunks) {
+      const int be = order[BE - nd + i];
+      T* o = out + (int64_t)be * oes;
+      for (int j = tid; j < nel; j += S::THREADS) { o[(int64_t)j * ols + off0] = from_f32<T>(0.0f); o[(int64_t)j * ols + off1] = from_f32<T>(0.0f); }
+    }
+  }
+  stamp(7);
+  if (stats && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) atomicAdd(&stats[i], st_acc[i]);
+    atomicAdd(&stats[8], (unsigned long long)nrounds); atomicAdd(&stats[9], 1ULL); atomicAdd(&stats[10], (unsigned long long)st_iters);
+    atomicAdd(&stats[11], __builtin_readcyclecounter() - st_begin);
+  }
 }
 
-// fmap1 [N][C][9] -> [N][9][C]: the B operand of the region kernel is 16 contiguous bytes per (pixel, 16-byte channel piece)
+// fmap1 [N][C][9] -> [N][9][C], the patch operand of the region kernel: 16 contiguous bytes per (pixel, 4 | 8 channels).  fp32: every group
+// of 4 channels is stored as fp16 (hi0..3 | lo0..3), x = hi + lo — the form the kernel multiplies (same 16 bytes).
 template <typename T>
 __global__ __launch_bounds__(256) void corr_patch_transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pt_lds[];
@@ -521,5 +637,13 @@ __global__ __launch_bounds__(256) void corr_patch_transpose_kernel(const T* __re
   T* o = dst + (int64_t)n * C * PP;
   for (int i = threadIdx.x; i < C * PP; i += 256) s[i] = in[i];
   __syncthreads();
-  for (int i = threadIdx.x; i < C * PP; i += 256) { const int p = i / C, c = i - p * C; o[i] = s[c * PP + p]; }
+  if constexpr (sizeof(T) == 2) {
+    for (int i = threadIdx.x; i < C * PP; i += 256) { const int p = i / C, c = i - p * C; o[i] = s[c * PP + p]; }
+  } else {
+    for (int i = threadIdx.x; i < (C / 4) * PP; i += 256) {      // (C % 16 == 0 for the region kernel)
+      const int p = i / (C / 4), c4 = i - p * (C / 4);
+      const rg_f4 x = {(float)s[(4 * c4) * PP + p], (float)s[(4 * c4 + 1) * PP + p], (float)s[(4 * c4 + 2) * PP + p], (float)s[(4 * c4 + 3) * PP + p]};
+      reinterpret_cast<rg_h8*>(o)[i] = rg_split4(x);
+    }
+  }
 }

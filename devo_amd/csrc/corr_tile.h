@@ -87,7 +87,7 @@ __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float c
 
 // Region-shared lookup kernel (corr_region.h): accumulator tiles (16 box positions each) an edge may have per level; the pyramid
 // plan's HEAVY class is exactly "more cells than these tiles hold".
-__host__ __device__ constexpr int corr_region_tmax(int radius) { return radius <= 3 ? 10 : 16; }
+__host__ __device__ constexpr int corr_region_tmax(int radius) { return radius <= 3 ? 8 : 16; }
 struct CorrPlanMode { int W2, l1, heavy_cells, dead_bin; };     // l1 < 2: single-level plan (legacy classes)
 
 // Bins of the plan: row bands of 16 rows per frame (coarser if there are many frames: the counting sort keeps one LDS

@@ -72,8 +72,10 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
                                                       region they cover.  NULL: the per-edge kernel */,
                                devo_stream_t stream);
 
-/* fmap1 T [n_patches, C, 3, 3] -> fmap1_t T [n_patches, 9, C] (the patch operand layout of the region-shared lookup kernel; the
- * patch features of DEVO change once per frame, not per update iteration: transpose once, reuse).  DEVO_F32 / DEVO_F16. */
+/* fmap1 T [n_patches, C, 3, 3] -> fmap1_t [n_patches, 9, C] elements of sizeof(T) bytes: the patch operand of the region-shared lookup
+ * kernel, an opaque format — fp16: the transposed features; fp32: every 4 channels as fp16 (hi0..3 | lo0..3) with x = hi + lo, the
+ * form the kernel multiplies (C % 4 == 0).  The patch features of DEVO change once per frame, not per update iteration: convert once,
+ * reuse.  DEVO_F32 / DEVO_F16. */
 int devo_corr_patch_transpose(const void* fmap1, void* fmap1_t, int n_patches, int C, int dtype, devo_stream_t stream);
 
 /* Locality plan for devo_corr_forward (no reference counterpart: the reference walks edges in list order).
@@ -91,7 +93,7 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
                     int W2 /* width of the plan's level; only read when l1 >= 2 */,
                     int l1 /* 0: single-level plan.  >= 2 (DEVO: 4): PYRAMID plan for devo_corr_forward_pyramid2 — the lookup has a second
                               level at 1 / l1 of this resolution.  Classes: DEAD edges (union box outside the frame at both levels: every
-                              output is 0) go BEHIND all others, order[2*B*E + 1] = their number; HEAVY = more than 160 (radius <= 3) / 256
+                              output is 0) go BEHIND all others, order[2*B*E + 1] = their number; HEAVY = more than 128 (radius <= 3) / 256
                               box positions at a level the box touches; bins are numbered band by band */,
                     devo_stream_t stream);
 

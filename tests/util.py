@@ -27,3 +27,15 @@ def row_rel_err(a, b, floor_frac=1e-2):
     a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
     scale = b.abs().amax(dim=1).clamp(min=floor_frac * float(b.abs().max().clamp(min=1e-30)))
     return (a - b).abs().amax(dim=1) / scale
+
+
+def shuffled_plan(plan, n_slots, seed=0):
+    """A lookup plan (cuda_corr.plan: n slots | #heavy | n scratch | #dead) with the heavy slots, the live slots and the dead slots
+    shuffled among themselves: the same classes, different neighbours.  The lookup's results must not change by one bit."""
+    p = plan.clone().cpu()
+    nh, nd = int(p[n_slots]), int(p[2 * n_slots + 1])
+    g = torch.Generator().manual_seed(seed)
+    for lo, hi in ((0, nh), (nh, n_slots - nd), (n_slots - nd, n_slots)):
+        if hi > lo:
+            p[lo:hi] = p[lo:hi][torch.randperm(hi - lo, generator=g)]
+    return p.to(plan.device)

@@ -26,7 +26,7 @@ E = d["ii"].numel()
 Dm = 2 * R + 1
 out = torch.empty(1, E, Dm * Dm * 18, dtype=dt, device=dev)
 coords = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
-order = None if a.no_plan else cuda_corr.plan(coords, d["jj"], n, cfg["H"], 1.0, R)
+order = None if a.no_plan else cuda_corr.plan(coords, d["jj"], n, cfg["H"], 1.0, R, width=cfg["W"], l1=0 if a.per_level else 4)
 if a.no_plan:
     cuda_corr.PLAN_MIN_EDGES = 1 << 60
 for _ in range(a.reps):
@@ -36,4 +36,5 @@ for _ in range(a.reps):
     else:
         cuda_corr.forward_pyramid(d["gmap"], d["pyramid"], coords, d["kk"], d["jj"], R, (1, 4), out=out, order=order)
 torch.cuda.synchronize()
-print("done", E)
+if order is not None:
+    print("done", E, "heavy", int(order[E]), "dead", int(order[2 * E + 1]))

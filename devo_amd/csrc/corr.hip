@@ -1097,13 +1097,17 @@ static int launch_region(const void* fmap1, const void* fmap1_t, const CorrLevel
   typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;
   typedef void (*region_fn_t)(const MT*, CorrLevel, CorrLevel, const float*, const int64_t*, const int64_t*, MT*, int, int, int, int, int,
                               int64_t, int64_t, int, const int*, int, unsigned, int, unsigned long long*);
-  typedef RgShape<3, 8, 3, corr_region_tmax(3), 15> S3;
+  typedef RgShape<3, 16, 1, corr_region_tmax(3), 15> S3;           // one 16-wave workgroup per CU (4 waves per SIMD, one edge per wave and round), double-buffered slabs
+  typedef RgShape<3, 4, 3, corr_region_tmax(3), 15, 1, 48> S3S;     // two 4-wave workgroups per CU, one slab buffer each
   typedef RgShape<5, 8, 2, corr_region_tmax(5), 16> S5;
-  const region_fn_t fn = R <= 3 ? corr_fwd_region_kernel<MT, S3> : corr_fwd_region_kernel<MT, S5>;
-  const size_t lds = 2 * (size_t)(R <= 3 ? S3::BUFSZ : S5::BUFSZ);
-  const int threads = R <= 3 ? S3::THREADS : S5::THREADS, chmax = R <= 3 ? S3::CHMAX : S5::CHMAX;
-  static bool attr_done[2][2] = {{false, false}, {false, false}};
-  bool& done = attr_done[R <= 3 ? 0 : 1][sizeof(MT) == 2 ? 1 : 0];
+  static const char* shape_env = getenv("DEVO_RG_SHAPE");            // "4": S3S (two single-buffered workgroups per CU)
+  const bool big = !(shape_env && shape_env[0] == '4');
+  const region_fn_t fn = R <= 3 ? (big ? corr_fwd_region_kernel<MT, S3> : corr_fwd_region_kernel<MT, S3S>) : corr_fwd_region_kernel<MT, S5>;
+  const size_t lds = (size_t)(R <= 3 ? (big ? S3::LDS_BYTES : S3S::LDS_BYTES) : S5::LDS_BYTES);
+  const int threads = R <= 3 ? (big ? S3::THREADS : S3S::THREADS) : S5::THREADS, chmax = R <= 3 ? (big ? S3::CHMAX : S3S::CHMAX) : S5::CHMAX;
+  const int round_edges = R <= 3 ? (big ? S3::SLOTS : S3S::SLOTS) : S5::SLOTS, wgs_per_cu = (R <= 3 && !big) ? 2 : 1;
+  static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
+  bool& done = attr_done[R <= 3 ? (big ? 0 : 2) : 1][sizeof(MT) == 2 ? 1 : 0];
   if (!done) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       (void)hipGetLastError();
@@ -1114,9 +1118,10 @@ static int launch_region(const void* fmap1, const void* fmap1_t, const CorrLevel
   }
   // chunks of the plan: ~2 rounds each, whole multiples of the CU count when there is enough work (one workgroup per CU)
   static const char* chunk_env = getenv("DEVO_RG_CHUNK");
-  const int target = chunk_env && atoi(chunk_env) > 0 ? (atoi(chunk_env) < chmax ? atoi(chunk_env) : chmax) : 48;
+  const int target = chunk_env && atoi(chunk_env) > 0 ? (atoi(chunk_env) < chmax ? atoi(chunk_env) : chmax) : 2 * round_edges;
   long long nchunks = (BE + target - 1) / target;
-  nchunks = nchunks > 256 ? (nchunks + 255) / 256 * 256 : (nchunks + 7) / 8 * 8;
+  const long long slots = 256LL * wgs_per_cu;
+  nchunks = nchunks > slots ? (nchunks + slots - 1) / slots * slots : (nchunks + 7) / 8 * 8;
   while ((BE + nchunks - 1) / nchunks > chmax) nchunks += 8;
   // heavy slots first (longest items): the per-edge kernel in its heavy-only mode
   {

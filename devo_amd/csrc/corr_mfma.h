@@ -165,6 +165,9 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_EPW) __attribute__((amdgpu_waves_per
     const long long npos_ll = (long long)g.bw * (ymax - ymin + D);
     g.box_mode = npos_ll <= (long long)PP * ntap;        // else: the 9 windows one after the other
     g.nslots = g.box_mode ? (int)npos_ll : PP * ntap;
+    // the whole box outside the frame (11 % of cfg2's edges at both levels, 18 % at level 0): every tap is 0 (correlation_kernel.cu:136)
+    // — no passes at all for this level, the epilogue writes zeros
+    if (xmax + D <= 0 || ymax + D <= 0 || xmin >= LVF(l, W2) || ymin >= LVF(l, H2)) { g.nslots = 0; g.box_mode = true; }
     g.npass = (g.nslots + 63) >> 6;
     g.boxlay = g.box_mode && g.nslots <= BOXS;
     g.inv_bw = __builtin_amdgcn_rcpf((float)g.bw);       // 1 ulp is plenty for the row / column split below
@@ -291,8 +294,9 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_EPW) __attribute__((amdgpu_waves_per
   mfma_acc4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
   Pos cur = position(0), nxt = position(1);
   {
-    const __amdgpu_buffer_rsrc_t r0 = frame_rsrc(0);
-    const Pieces pc0 = pieces_of(0);
+    const int lf = seg_level(0);                           // (level 0 has no passes when its box misses the frame)
+    const __amdgpu_buffer_rsrc_t r0 = frame_rsrc(lf);
+    const Pieces pc0 = pieces_of(lf);
 #pragma unroll
     for (int g = 0; g < RING - 1; g++) { fetch(g, g % NGR, cur.off, r0, pc0); __builtin_amdgcn_sched_barrier(0); }
   }
@@ -379,6 +383,7 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_EPW) __attribute__((amdgpu_waves_per
       w00 = (1.0f - dxp) * (1.0f - dyp); w01 = dxp * (1.0f - dyp); w10 = (1.0f - dxp) * dyp; w11 = dxp * dyp;   // blend4's factors
     }
     const int rstride = (l ? g1.boxlay : g0.boxlay) ? (l ? g1.bw : g0.bw) : D;       // per lane (l is)
+    const bool lvl_live = (l ? g1.nslots : g0.nslots) > 0;                          // (a level without passes left its result area untouched)
     int q = grp;
     int cx = 0, a = q;
     while (a >= Dm) { a -= Dm; cx += 1; }           // (grp < 7: only windows smaller than 7 x 7 take a turn)
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_EPW) __attribute__((amdgpu_waves_per
 #pragma clang fp contract(off)
           o = w00 * r[0]; o = o + w01 * r[1]; o = o + w10 * r[rstride]; o = o + w11 * r[rstride + 1];
         }
-        store_streamed(op, from_f32<T>(o));
+        store_streamed(op, from_f32<T>(lvl_live ? o : 0.0f));
       }
       op += ostep;
       q += GRPS; a += GRPS;

@@ -30,20 +30,27 @@ typedef _Float16 rg_h8 __attribute__((ext_vector_type(8)));
 typedef float rg_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned rg_u4 __attribute__((ext_vector_type(4)));
 
-template <int RMAX_, int NW_, int EW_, int TMAX_, int RC_>
+template <int RMAX_, int NW_, int EW_, int TMAX_, int RC_, int NBUF_ = 2, int CHMAX_ = 64>
 struct RgShape {
   static constexpr int RMAX = RMAX_, NW = NW_, EW = EW_, TMAX = TMAX_, RC = RC_;
+  // NBUF = 2: one workgroup per CU, slab s + 1 lands while slab s is multiplied.  NBUF = 1: ONE slab buffer and two workgroups per CU —
+  // a workgroup alternates between requesting / waiting for a slab and multiplying it, its neighbour on the CU fills the gaps (and
+  // hides its prologue, set-up and epilogue as well).
+  static constexpr int NBUF = NBUF_;
   static constexpr int DMAX = 2 * RMAX + 2, DM = DMAX - 1, NPASS = (DM + 6) / 7;
   static constexpr int THREADS = 64 * NW;
   static constexpr int SLOTS = NW * EW;                         // edges per round
-  static constexpr int CHMAX = 64;                              // plan slots per chunk (one thread each in the prologue)
+  static constexpr int CHMAX = CHMAX_;                          // plan slots per chunk (one thread each in the prologue)
   static constexpr int NBCH = (SLOTS * PP * 64 + 1023) / 1024;  // 1 KB pieces of one patch slab: [slot][pixel][64 B]
   static constexpr int BUNIT = NBCH * 1024;
-  static constexpr int BUFSZ = RC * 4096 + BUNIT;               // one slab buffer: region planes, then the patch slab(s)
   static constexpr int SP = TMAX * 16 + (RMAX <= 3 ? 4 : 0);    // scratch: floats per pixel row (+4: bank spread)
   static constexpr int SCRW = PP * SP * 4;                      // scratch bytes per wave
+  static constexpr int BUFMIN = RC * 4096 + BUNIT;              // one slab buffer: region planes, then the patch slab(s) ...
+  static constexpr int BUFSZ = (BUFMIN > NW * SCRW ? BUFMIN : NW * SCRW + 1023) / 1024 * 1024;   // ... and room for every wave's scratch
   static constexpr int DPW = (RC + NW - 1) / NW, BPW = (NBCH + NW - 1) / NW;   // DMA pieces per wave, plane and unit
   static_assert(NW * SCRW <= BUFSZ, "the epilogue scratch lives in slab buffer 0 (buffer 1 takes the next stage's first slab meanwhile)");
+  static constexpr int LDS_BYTES = NBUF * BUFSZ;
+  static constexpr int WPS = (NW * (NBUF == 1 ? 2 : 1) + 3) / 4;   // waves per SIMD the launch needs (registers: 512 / WPS)
   static_assert(SP >= DMAX * DMAX, "the tap-by-tap path keeps raw windows in the scratch");
   static_assert(THREADS >= CHMAX && SLOTS <= CHMAX, "one prologue thread per plan slot");
   static_assert(16 * TMAX < 64 * RC && TMAX % 4 == 0, "a single edge must fit the region; tiles go in batches of 4");
@@ -52,6 +59,8 @@ struct RgShape {
 // LDS-DMA: 16 bytes per lane, source = buffer descriptor + per-lane offset (out of range: zeros, no access) + scalar offset,
 // destination = lds_addr + 16 * lane.  Issued through asm: hipcc's waitcnt insertion does not know it (rg_wait_dma()).
 __device__ __forceinline__ void rg_dma16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned lds_addr) {
+  lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);     // (wave-uniform by construction; pins them to scalar registers)
+  soff = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_addr), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void rg_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -72,7 +81,7 @@ __device__ __forceinline__ rg_h8 rg_split4(rg_f4 x) {
 }
 
 template <typename T, typename S>
-__global__ __launch_bounds__(S::THREADS, 2) void corr_fwd_region_kernel(
+__global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
     const T* __restrict__ fmap1t, CorrLevel lv0, CorrLevel lv1, const float* __restrict__ coords, const int64_t* __restrict__ ii,
     const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2, int C, int64_t oes, int64_t ols, int R,
     const int* __restrict__ order, int nchunks, unsigned f1t_bytes, int band_rows, unsigned long long* __restrict__ stats) {
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(S::THREADS, 2) void corr_fwd_region_kernel(
   // DMA instruction (unit u, number rem < OPU) of slab `it`: false = not this wave's / beyond the region
   auto issue_op = [&](const DmaP& P, const unsigned (&vB)[BPW], int it, int u, int rem) -> bool {
     const unsigned unit = (unsigned)(it * P.U + u);
-    const unsigned base = lds0 + (unsigned)((it + 1) & 1) * (unsigned)BUFSZ;
+    const unsigned base = lds0 + (unsigned)(S::NBUF == 2 ? ((it + 1) & 1) : 0) * (unsigned)BUFSZ;
     if (rem < 4 * DPW) {
       const int q = rem / DPW, j = rem - q * DPW, c = w + j * NW;     // (DPW is a constant)
       if (c >= P.nchk) return false;
@@ -415,6 +424,16 @@ __global__ __launch_bounds__(S::THREADS, 2) void corr_fwd_region_kernel(
   }
   for (int stage = 0; stage < nstages; stage++) {
     const int r = stage >> 1, l = 1 - (stage & 1);               // level 1 first: its results wait in registers
+    if constexpr (S::NBUF == 1) {
+      if (stage > 0) {                                            // (the buffer was the previous stage's scratch until now)
+        dma_params(stage, cur);
+        if (l == 1) {
+#pragma unroll
+          for (int j = 0; j < BPW; j++) voffB[j] = voffB_nxt[j];
+        }
+        if (cur.NI > 0) issue_slab(cur, voffB, 0);
+      }
+    }
     const int rs = __builtin_amdgcn_readfirstlane(s_rstart[r]), re = __builtin_amdgcn_readfirstlane(s_rstart[r + 1]);
     const int X0 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][0]), Y0 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][1]);
     const int X1 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][2]), Y1 = __builtin_amdgcn_readfirstlane((int)s_reg[l][rs][3]);
@@ -457,15 +476,18 @@ __global__ __launch_bounds__(S::THREADS, 2) void corr_fwd_region_kernel(
       rg_barrier();
       stamp(2);
       for (int it = 0; it < cur.NI; it++) {
-        const int bi = (it + 1) & 1;
+        const int bi = S::NBUF == 2 ? ((it + 1) & 1) : 0;
+        if constexpr (S::NBUF == 1) {
+          if (it > 0) { issue_slab(cur, voffB, it); rg_wait_dma(); rg_barrier(); }
+        }
         if constexpr (!HALF) { split_slab(cur, bi); rg_barrier(); }
         // Half of the waves request the next slab BEFORE their products, the other half AFTER: the two waves of a SIMD (w, w + NW / 2)
         // are in opposite phases, so the matrix pipe works while the partner sits in its DMA instructions (a wave is held at each of
         // them until the memory pipeline takes it: the CU's fill rate, ~20 B/clk, prices them at ~150-250 cycles apiece).
         const unsigned char* buf = rg_lds + (size_t)bi * BUFSZ;
-        const bool more = it + 1 < cur.NI;
+        const bool more = S::NBUF == 2 && it + 1 < cur.NI;
         const bool tr = stats && chunk == 100 && stage == 1 && it < 4 && lane == 0;
-        unsigned long long* trp = stats + 16 + (it * NW + w) * 4;
+        unsigned long long* trp = stats + 16 + (it * 8 + w) * 4;
         if (tr) trp[0] = __builtin_readcyclecounter();
 #pragma unroll 1
         for (int phase = 0; phase < 2; phase++) {
@@ -474,6 +496,7 @@ __global__ __launch_bounds__(S::THREADS, 2) void corr_fwd_region_kernel(
             if (more) issue_slab(cur, voffB, it + 1);
             continue;
           }
+          if (S::NBUF == 1 && phase != (w < NW / 2 ? 1 : 0)) continue;
           for (int u = 0; u < cur.U; u++) {
             const unsigned char* ra = buf + (size_t)u * 4 * cur.PS + kgPS;
             const unsigned char* rb = buf + cur.boff + (size_t)u * BUNIT + (size_t)(min(m, PP - 1) * 64 + kg * 16);
@@ -512,8 +535,8 @@ __global__ __launch_bounds__(S::THREADS, 2) void corr_fwd_region_kernel(
         }
         stamp(3);
         if (tr) trp[2] = __builtin_readcyclecounter();
-        rg_wait_dma();
-        rg_barrier();
+        if constexpr (S::NBUF == 2) rg_wait_dma();
+        rg_barrier();                                             // (single buffer: everybody has read the slab)
         if (tr) trp[3] = __builtin_readcyclecounter();
         stamp(5);
         st_iters++;
@@ -521,10 +544,12 @@ __global__ __launch_bounds__(S::THREADS, 2) void corr_fwd_region_kernel(
     }
     // ---- the next stage's first slab goes out before this stage's epilogue (buffer 1; the scratch is in buffer 0)
     DmaP nxt = cur;
-    if (stage + 1 < nstages) {
-      dma_params(stage + 1, nxt);
-      const unsigned (&vB)[BPW] = (l == 0) ? voffB_nxt : voffB;   // (a new round brings its own patch slabs)
-      if (nxt.NI > 0) issue_slab(nxt, vB, 0);
+    if constexpr (S::NBUF == 2) {
+      if (stage + 1 < nstages) {
+        dma_params(stage + 1, nxt);
+        const unsigned (&vB)[BPW] = (l == 0) ? voffB_nxt : voffB; // (a new round brings its own patch slabs)
+        if (nxt.NI > 0) issue_slab(nxt, vB, 0);
+      }
     }
     // ---- epilogue of the level: tiles -> scratch -> blended rows
     float* scr = reinterpret_cast<float*>(rg_lds + (size_t)w * S::SCRW);
@@ -556,11 +581,13 @@ __global__ __launch_bounds__(S::THREADS, 2) void corr_fwd_region_kernel(
       }
     }
     rg_barrier();                                                // buffer 0 is a DMA target again
-    if (l == 0) {
+    if constexpr (S::NBUF == 2) {
+      if (l == 0) {
 #pragma unroll
-      for (int j = 0; j < BPW; j++) voffB[j] = voffB_nxt[j];
+        for (int j = 0; j < BPW; j++) voffB[j] = voffB_nxt[j];
+      }
+      cur = nxt;
     }
-    cur = nxt;
     stamp(6);
   }
   rg_wait_dma();

@@ -1098,16 +1098,15 @@ static int launch_region(const void* fmap1, const void* fmap1_t, const CorrLevel
   typedef void (*region_fn_t)(const MT*, CorrLevel, CorrLevel, const float*, const int64_t*, const int64_t*, MT*, int, int, int, int, int,
                               int64_t, int64_t, int, const int*, int, unsigned, int, unsigned long long*);
   typedef RgShape<3, 16, 1, corr_region_tmax(3), 15> S3;           // one 16-wave workgroup per CU (4 waves per SIMD, one edge per wave and round), double-buffered slabs
-  typedef RgShape<3, 4, 3, corr_region_tmax(3), 15, 1, 48> S3S;     // two 4-wave workgroups per CU, one slab buffer each
-  typedef RgShape<5, 8, 2, corr_region_tmax(5), 16> S5;
-  static const char* shape_env = getenv("DEVO_RG_SHAPE");            // "4": S3S (two single-buffered workgroups per CU)
-  const bool big = !(shape_env && shape_env[0] == '4');
-  const region_fn_t fn = R <= 3 ? (big ? corr_fwd_region_kernel<MT, S3> : corr_fwd_region_kernel<MT, S3S>) : corr_fwd_region_kernel<MT, S5>;
-  const size_t lds = (size_t)(R <= 3 ? (big ? S3::LDS_BYTES : S3S::LDS_BYTES) : S5::LDS_BYTES);
-  const int threads = R <= 3 ? (big ? S3::THREADS : S3S::THREADS) : S5::THREADS, chmax = R <= 3 ? (big ? S3::CHMAX : S3S::CHMAX) : S5::CHMAX;
-  const int round_edges = R <= 3 ? (big ? S3::SLOTS : S3S::SLOTS) : S5::SLOTS, wgs_per_cu = (R <= 3 && !big) ? 2 : 1;
-  static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
-  bool& done = attr_done[R <= 3 ? (big ? 0 : 2) : 1][sizeof(MT) == 2 ? 1 : 0];
+  typedef RgShape<5, 12, 1, corr_region_tmax(5), 16, 2, 64, false> S5;   // radius 4, 5: 16 tiles per edge: 12 waves (3 per SIMD)
+  static const bool do_stats = getenv("DEVO_RG_STATS") != nullptr;  // debug switch: phase cycles of every workgroup's first wave to stderr
+  const region_fn_t fn = do_stats ? (R <= 3 ? corr_fwd_region_kernel<MT, S3, true> : corr_fwd_region_kernel<MT, S5, true>)
+                                  : (R <= 3 ? corr_fwd_region_kernel<MT, S3, false> : corr_fwd_region_kernel<MT, S5, false>);
+  const size_t lds = (size_t)(R <= 3 ? S3::LDS_BYTES : S5::LDS_BYTES);
+  const int threads = R <= 3 ? S3::THREADS : S5::THREADS, chmax = R <= 3 ? S3::CHMAX : S5::CHMAX;
+  const int round_edges = R <= 3 ? S3::SLOTS : S5::SLOTS, wgs_per_cu = 1;
+  static bool attr_done[4][2] = {{false, false}, {false, false}, {false, false}, {false, false}};
+  bool& done = attr_done[(R <= 3 ? 0 : 1) + (do_stats ? 2 : 0)][sizeof(MT) == 2 ? 1 : 0];
   if (!done) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       (void)hipGetLastError();
@@ -1135,8 +1134,7 @@ static int launch_region(const void* fmap1, const void* fmap1_t, const CorrLevel
                        Np, n2, C, oes, ols, R, order, (unsigned long long*)nullptr, 1);
   }
   const long long f1t_bytes = (BE / (E > 0 ? E : 1)) * (long long)Np * C * PP * (long long)sizeof(MT);
-  unsigned long long* stats = nullptr;                                // debug switch: phase cycles of every workgroup's first wave to stderr
-  static const bool do_stats = getenv("DEVO_RG_STATS") != nullptr;
+  unsigned long long* stats = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (do_stats) { (void)hipMalloc(&stats, 4096); (void)hipMemset(stats, 0, 4096); (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1); (void)hipEventRecord(ev0, st); }
   hipLaunchKernelGGL(fn, dim3((unsigned)nchunks), dim3(threads), lds, st, (const MT*)fmap1_t, lv0, lv1, coords, ii, jj, (MT*)out, (int)BE, E, Np,
@@ -1153,9 +1151,9 @@ static int launch_region(const void* fmap1, const void* fmap1_t, const CorrLevel
             "prologue %.0f | stage set-up %.0f | first slab wait %.0f | products + DMA issue %.0f | left-over DMA issue %.0f | slab wait + barrier %.0f | epilogue + next stage's request %.0f | tail %.0f\n",
             ms * 1e3, h[9], nchunks, h[8] / g, h[10] / g, h[11] / g, h[0] / g, h[1] / g, h[2] / g, h[3] / g, h[4] / g, h[5] / g, h[6] / g, h[7] / g);
     {
-      unsigned long long tr[4 * 8 * 4];
-      (void)hipMemcpy(tr, stats + 16, sizeof(tr), hipMemcpyDeviceToHost);
+      unsigned long long tr[4 * 16 * 4];
       const int nw = threads / 64;
+      (void)hipMemcpy(tr, stats + 16, sizeof(unsigned long long) * 4 * nw * 4, hipMemcpyDeviceToHost);
       unsigned long long t0 = ~0ULL;
       for (int i = 0; i < 4 * nw * 4; i++) if (tr[i] && tr[i] < t0) t0 = tr[i];
       for (int it = 0; it < 4; it++) {
@@ -1205,6 +1203,7 @@ static bool region_eligible(const CorrLevel& l0, const CorrLevel& l1, const void
                             int R) {
   const long long f1_bytes = (BE / (E > 0 ? E : 1)) * (long long)Np * C * PP * (long long)sizeof(T);
   return fmap1_t != nullptr && order != nullptr && l0.region_ok && l1.region_ok && l0.mfma_ok && l1.mfma_ok && R <= 5 &&
+         l0.out_offset >= 0 && l1.out_offset >= 0 && l0.out_offset < (1LL << 20) && l1.out_offset < (1LL << 20) &&      // (32-bit element offsets inside a record)
          f1_bytes < (1LL << 31) && BE < (1LL << 30) && (reinterpret_cast<uintptr_t>(fmap1_t) & 15) == 0;
 }
 
@@ -1264,13 +1263,13 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
   if (dtype == DEVO_F32) {
     ok = staged_level<float>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0) &&
          staged_level<float>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
-    if (ok && region_eligible<float>(l0, l1, fmap1_t, order, BE, E, Np, C, radius))
+    if (ok && out_lstride > 0 && out_lstride < (1LL << 20) && region_eligible<float>(l0, l1, fmap1_t, order, BE, E, Np, C, radius))
       return launch_region<float>(fmap1, fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
     if (ok) return launch_staged<float>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
   } else if (dtype == DEVO_F16) {
     ok = staged_level<__half>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0) &&
          staged_level<__half>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
-    if (ok && region_eligible<__half>(l0, l1, fmap1_t, order, BE, E, Np, C, radius))
+    if (ok && out_lstride > 0 && out_lstride < (1LL << 20) && region_eligible<__half>(l0, l1, fmap1_t, order, BE, E, Np, C, radius))
       return launch_region<__half>(fmap1, fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
     if (ok) return launch_staged<__half>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
   }

@@ -30,8 +30,11 @@ typedef _Float16 rg_h8 __attribute__((ext_vector_type(8)));
 typedef float rg_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned rg_u4 __attribute__((ext_vector_type(4)));
 
-template <int RMAX_, int NW_, int EW_, int TMAX_, int RC_, int NBUF_ = 2, int CHMAX_ = 64>
+template <int RMAX_, int NW_, int EW_, int TMAX_, int RC_, int NBUF_ = 2, int CHMAX_ = 64, bool XPRE_ = true>
 struct RgShape {
+  // XPRE: the next stage's first slab is requested BEFORE the current stage's epilogue (buffer 1; the scratch must fit buffer 0).
+  // Without it the scratch may span both buffers and the request follows the epilogue.
+  static constexpr bool XPRE = XPRE_ && NBUF_ == 2;
   static constexpr int RMAX = RMAX_, NW = NW_, EW = EW_, TMAX = TMAX_, RC = RC_;
   // NBUF = 2: one workgroup per CU, slab s + 1 lands while slab s is multiplied.  NBUF = 1: ONE slab buffer and two workgroups per CU —
   // a workgroup alternates between requesting / waiting for a slab and multiplying it, its neighbour on the CU fills the gaps (and
@@ -46,9 +49,9 @@ struct RgShape {
   static constexpr int SP = TMAX * 16 + (RMAX <= 3 ? 4 : 0);    // scratch: floats per pixel row (+4: bank spread)
   static constexpr int SCRW = PP * SP * 4;                      // scratch bytes per wave
   static constexpr int BUFMIN = RC * 4096 + BUNIT;              // one slab buffer: region planes, then the patch slab(s) ...
-  static constexpr int BUFSZ = (BUFMIN > NW * SCRW ? BUFMIN : NW * SCRW + 1023) / 1024 * 1024;   // ... and room for every wave's scratch
+  static constexpr int BUFSZ = ((!XPRE || BUFMIN > NW * SCRW) ? BUFMIN : NW * SCRW + 1023) / 1024 * 1024;   // ... and room for every wave's scratch
   static constexpr int DPW = (RC + NW - 1) / NW, BPW = (NBCH + NW - 1) / NW;   // DMA pieces per wave, plane and unit
-  static_assert(NW * SCRW <= BUFSZ, "the epilogue scratch lives in slab buffer 0 (buffer 1 takes the next stage's first slab meanwhile)");
+  static_assert(NW * SCRW <= (XPRE ? 1 : NBUF) * BUFSZ, "the epilogue scratch lives in slab buffer 0 (buffer 1 takes the next stage's first slab meanwhile)");
   static constexpr int LDS_BYTES = NBUF * BUFSZ;
   static constexpr int WPS = (NW * (NBUF == 1 ? 2 : 1) + 3) / 4;   // waves per SIMD the launch needs (registers: 512 / WPS)
   static_assert(SP >= DMAX * DMAX, "the tap-by-tap path keeps raw windows in the scratch");
@@ -64,6 +67,9 @@ __device__ __forceinline__ void rg_dma16(unsigned voff, __amdgpu_buffer_rsrc_t r
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_addr), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void rg_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// a wave's LDS instructions execute in order: this waits for them and pins the compiler's ordering — without the fence's wait for
+// vector-memory operations (the next stage's DMA is in flight during an epilogue)
+__device__ __forceinline__ void rg_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void rg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // 4 fp32 values -> fp16 (hi0..3 | lo0..3), x = hi + lo to 2^-22 (|lo| below the fp16 normal range keeps 2^-25 absolute)
@@ -80,7 +86,7 @@ __device__ __forceinline__ rg_h8 rg_split4(rg_f4 x) {
   return __builtin_bit_cast(rg_h8, r);
 }
 
-template <typename T, typename S>
+template <typename T, typename S, bool STATS>
 __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
     const T* __restrict__ fmap1t, CorrLevel lv0, CorrLevel lv1, const float* __restrict__ coords, const int64_t* __restrict__ ii,
     const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2, int C, int64_t oes, int64_t ols, int R,
@@ -114,9 +120,9 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
   // debug (DEVO_RG_STATS=1): cycles of wave 0 per phase, summed over the workgroups: [0] prologue, [1] stage set-up, [2] waiting for a
   // stage's first slab, [3] products (with the next slab's DMA instructions in between), [4] left-over DMA instructions, [5] waiting for the
   // slab + barrier, [6] epilogue, [7] tap-by-tap edges + dead tail, [8] rounds, [9] workgroups, [10] slab iterations, [11] total
-  unsigned long long st_t = stats ? __builtin_readcyclecounter() : 0ULL, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_t = STATS ? __builtin_readcyclecounter() : 0ULL, st_acc[STATS ? 8 : 1] = {};
   const unsigned long long st_begin = st_t;
-  auto stamp = [&](int i) { if (stats) { const unsigned long long t = __builtin_readcyclecounter(); st_acc[i] += t - st_t; st_t = t; } };
+  auto stamp = [&](int i) { if constexpr (STATS) { const unsigned long long t = __builtin_readcyclecounter(); st_acc[i] += t - st_t; st_t = t; } };
   unsigned st_iters = 0;
   // chunk of the plan: XCD x (= blockIdx % 8) owns a contiguous range of chunks
   int chunk;
@@ -287,30 +293,36 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
     ox = min(max(floor_to_int(qx) - R, -30000), 30000); oy = min(max(floor_to_int(qy) - R, -30000), 30000);
     dx = qx - floorf(qx); dy = qy - floorf(qy);
   };
-  // both levels' outputs of the lane's window rows -> the edge's record
+  // both levels' outputs of the lane's window rows -> the edge's record.  32-bit element offsets from a wave-uniform base, formed where they
+  // are used (hipcc otherwise hoists seven 64-bit offsets out of the stage loop: 14 registers for the whole kernel)
   auto store_rows = [&](int be, const float (&o0)[NPASS][DM], const float (&o1)[NPASS][DM]) {
-    T* op = out + (int64_t)be * oes;
+    T* op = out + (int64_t)__builtin_amdgcn_readfirstlane(be) * oes;
+    int ep_ = ep, ea_ = ea0;
+    asm volatile("" : "+v"(ep_), "+v"(ea_));
+    const unsigned ols32 = (unsigned)ols, o0_32 = (unsigned)off0, o1_32 = (unsigned)off1;       // (the launcher checks that they fit)
 #pragma unroll
     for (int ps = 0; ps < NPASS; ps++) {
-      const int a = ea0 + 7 * ps;
+      const int a = ea_ + 7 * ps;
       if (lane < 63 && a < Dm) {
+        unsigned el = (unsigned)(a * PP + ep_);
+        const unsigned step = (unsigned)(Dm * PP);
 #pragma unroll
         for (int cx = 0; cx < DM; cx++) {
           if (cx < Dm) {
-            const int64_t el = (int64_t)((cx * Dm + a) * PP + ep);
             if (paired) {
               if constexpr (HALF) {
                 const unsigned short u0 = __half_as_ushort(__float2half(o0[ps][cx])), u1 = __half_as_ushort(__float2half(o1[ps][cx]));
-                __builtin_nontemporal_store((unsigned)u0 | ((unsigned)u1 << 16), reinterpret_cast<unsigned*>(op + el * 2 + off0));
+                __builtin_nontemporal_store((unsigned)u0 | ((unsigned)u1 << 16), reinterpret_cast<unsigned*>(op + (size_t)(el * 2u + o0_32)));
               } else {
                 typedef float f2v __attribute__((ext_vector_type(2)));
                 const f2v v = {o0[ps][cx], o1[ps][cx]};
-                __builtin_nontemporal_store(v, reinterpret_cast<f2v*>(op + el * 2 + off0));
+                __builtin_nontemporal_store(v, reinterpret_cast<f2v*>(op + (size_t)(el * 2u + o0_32)));
               }
             } else {
-              store_streamed(op + el * ols + off0, from_f32<T>(o0[ps][cx]));
-              store_streamed(op + el * ols + off1, from_f32<T>(o1[ps][cx]));
+              store_streamed(op + (size_t)(el * ols32 + o0_32), from_f32<T>(o0[ps][cx]));
+              store_streamed(op + (size_t)(el * ols32 + o1_32), from_f32<T>(o1[ps][cx]));
             }
+            el += step;
           }
         }
       }
@@ -326,11 +338,10 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
     unsigned PS, boff, bb;            // plane stride, offset of the patch slabs, byte stride of a channel block
     int sh;
     __amdgpu_buffer_rsrc_t rs;
-    unsigned voff[DPW];
+    unsigned v0, v1;                  // this lane's offsets in the frame for its (at most two) pieces of a plane
   };
-  unsigned voffB_nxt[BPW], voffB[BPW];
-#pragma unroll
-  for (int j = 0; j < BPW; j++) { voffB[j] = OFF_NONE; voffB_nxt[j] = OFF_NONE; }
+  static_assert(DPW <= 2 && BPW <= 2, "a wave has at most two pieces per plane / per patch slab");
+  unsigned vB0 = OFF_NONE, vB1 = OFF_NONE, vBn0 = OFF_NONE, vBn1 = OFF_NONE;    // ... and in the patches: current round, next round
   auto dma_params = [&](int stage, DmaP& P) {
     const int r = stage >> 1, l = 1 - (stage & 1);
     auto lvw = [&](int i) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)s_lv[l][i]); };
@@ -352,46 +363,43 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
     P.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(fbase), 0, lvw(10), 0x00020000);
     const int sh_ = (int)lvw(6), sw_ = (int)lvw(7);
     const float inv_rw = __builtin_amdgcn_rcpf((float)max(RW, 1));
-#pragma unroll
-    for (int j = 0; j < DPW; j++) {
+    auto frame_off = [&](int j) -> unsigned {
       const int pos = 64 * (w + j * NW) + lane;
       const int py = (int)(((float)pos + 0.5f) * inv_rw), px = pos - py * RW;
-      P.voff[j] = pos < npos ? (unsigned)((Y0 + py) * sh_ + (X0 + px) * sw_) * ESZ : OFF_NONE;
-    }
+      return pos < npos ? (unsigned)((Y0 + py) * sh_ + (X0 + px) * sw_) * ESZ : OFF_NONE;
+    };
+    P.v0 = frame_off(0);
+    P.v1 = DPW > 1 ? frame_off(1) : OFF_NONE;
     if (l == 1) {                                                 // a new round: its patch slabs (piece c' = w + j NW: 16 (slot, pixel) pairs, 4 lanes each)
-#pragma unroll
-      for (int j = 0; j < BPW; j++) {
+      auto patch_off = [&](int j) -> unsigned {
         const int pair = 16 * (w + j * NW) + (lane >> 2), slot = pair / PP, px = pair - slot * PP, idx = rs_ + slot;
-        voffB_nxt[j] = OFF_NONE;
-        if (slot < SLOTS && idx < re_) voffB_nxt[j] = (unsigned)((s_prow[s_perm[idx]] * PP + px) * C) * ESZ + (unsigned)(lane & 3) * 16u;
-      }
+        unsigned v = OFF_NONE;
+        if (slot < SLOTS && idx < re_) v = (unsigned)((s_prow[s_perm[idx]] * PP + px) * C) * ESZ + (unsigned)(lane & 3) * 16u;
+        return v;
+      };
+      vBn0 = patch_off(0);
+      vBn1 = BPW > 1 ? patch_off(1) : OFF_NONE;
     }
   };
   // DMA instruction (unit u, number rem < OPU) of slab `it`: false = not this wave's / beyond the region
-  auto issue_op = [&](const DmaP& P, const unsigned (&vB)[BPW], int it, int u, int rem) -> bool {
+  auto issue_op = [&](const DmaP& P, unsigned pB0, unsigned pB1, int it, int u, int rem) -> bool {
     const unsigned unit = (unsigned)(it * P.U + u);
     const unsigned base = lds0 + (unsigned)(S::NBUF == 2 ? ((it + 1) & 1) : 0) * (unsigned)BUFSZ;
     if (rem < 4 * DPW) {
       const int q = rem / DPW, j = rem - q * DPW, c = w + j * NW;     // (DPW is a constant)
       if (c >= P.nchk) return false;
       const unsigned ch = unit * CS + (unsigned)q * PCH, blk = ch >> P.sh, so = blk * P.bb + (ch - (blk << P.sh)) * ESZ;
-      unsigned vo = P.voff[0];
-#pragma unroll
-      for (int jj_ = 1; jj_ < DPW; jj_++) vo = (j == jj_) ? P.voff[jj_] : vo;
-      rg_dma16(vo, P.rs, so, base + ((unsigned)(u * 4 + q)) * P.PS + (unsigned)c * 1024u);
+      rg_dma16(j ? P.v1 : P.v0, P.rs, so, base + ((unsigned)(u * 4 + q)) * P.PS + (unsigned)c * 1024u);
     } else {
       const int j = rem - 4 * DPW, c = w + j * NW;
       if (c >= NBCH) return false;
-      unsigned vo = vB[0];
-#pragma unroll
-      for (int jj_ = 1; jj_ < BPW; jj_++) vo = (j == jj_) ? vB[jj_] : vo;
-      rg_dma16(vo, rsB, unit * 64u, base + P.boff + (unsigned)u * BUNIT + (unsigned)c * 1024u);
+      rg_dma16(j ? pB1 : pB0, rsB, unit * 64u, base + P.boff + (unsigned)u * BUNIT + (unsigned)c * 1024u);
     }
     return true;
   };
-  auto issue_slab = [&](const DmaP& P, const unsigned (&vB)[BPW], int it) {
+  auto issue_slab = [&](const DmaP& P, unsigned pB0, unsigned pB1, int it) {
     for (int u = 0; u < P.U; u++)
-      for (int rem = 0; rem < OPU; rem++) issue_op(P, vB, it, u, rem);
+      for (int rem = 0; rem < OPU; rem++) issue_op(P, pB0, pB1, it, u, rem);
   };
   // fp32 storage: the slab in buffer bi, 16-byte piece by 16-byte piece, 4 floats -> (hi0..3 | lo0..3) in place (the patch slabs
   // arrive split).  All threads; the caller puts barriers around it.
@@ -418,20 +426,16 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
   DmaP cur;
   if (nstages > 0) {
     dma_params(0, cur);
-#pragma unroll
-    for (int j = 0; j < BPW; j++) voffB[j] = voffB_nxt[j];
-    if (cur.NI > 0) issue_slab(cur, voffB, 0);
+    vB0 = vBn0; vB1 = vBn1;
+    if (cur.NI > 0) issue_slab(cur, vB0, vB1, 0);
   }
   for (int stage = 0; stage < nstages; stage++) {
     const int r = stage >> 1, l = 1 - (stage & 1);               // level 1 first: its results wait in registers
-    if constexpr (S::NBUF == 1) {
-      if (stage > 0) {                                            // (the buffer was the previous stage's scratch until now)
+    if constexpr (!S::XPRE) {
+      if (stage > 0) {                                            // (the buffers were the previous stage's scratch until now)
         dma_params(stage, cur);
-        if (l == 1) {
-#pragma unroll
-          for (int j = 0; j < BPW; j++) voffB[j] = voffB_nxt[j];
-        }
-        if (cur.NI > 0) issue_slab(cur, voffB, 0);
+        if (l == 1) { vB0 = vBn0; vB1 = vBn1; }
+        if (cur.NI > 0) issue_slab(cur, vB0, vB1, 0);
       }
     }
     const int rs = __builtin_amdgcn_readfirstlane(s_rstart[r]), re = __builtin_amdgcn_readfirstlane(s_rstart[r + 1]);
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
       for (int it = 0; it < cur.NI; it++) {
         const int bi = S::NBUF == 2 ? ((it + 1) & 1) : 0;
         if constexpr (S::NBUF == 1) {
-          if (it > 0) { issue_slab(cur, voffB, it); rg_wait_dma(); rg_barrier(); }
+          if (it > 0) { issue_slab(cur, vB0, vB1, it); rg_wait_dma(); rg_barrier(); }
         }
         if constexpr (!HALF) { split_slab(cur, bi); rg_barrier(); }
         // Half of the waves request the next slab BEFORE their products, the other half AFTER: the two waves of a SIMD (w, w + NW / 2)
@@ -486,14 +490,14 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
         // them until the memory pipeline takes it: the CU's fill rate, ~20 B/clk, prices them at ~150-250 cycles apiece).
         const unsigned char* buf = rg_lds + (size_t)bi * BUFSZ;
         const bool more = S::NBUF == 2 && it + 1 < cur.NI;
-        const bool tr = stats && chunk == 100 && stage == 1 && it < 4 && lane == 0;
-        unsigned long long* trp = stats + 16 + (it * 8 + w) * 4;
+        const bool tr = STATS && chunk == 100 && stage == 1 && it < 4 && lane == 0;
+        unsigned long long* trp = stats + 16 + (it * NW + w) * 4;
         if (tr) trp[0] = __builtin_readcyclecounter();
 #pragma unroll 1
         for (int phase = 0; phase < 2; phase++) {
           if (phase == 1 && tr) trp[1] = __builtin_readcyclecounter();
           if ((phase == 0) == (w < NW / 2)) {
-            if (more) issue_slab(cur, voffB, it + 1);
+            if (more) issue_slab(cur, vB0, vB1, it + 1);
             continue;
           }
           if (S::NBUF == 1 && phase != (w < NW / 2 ? 1 : 0)) continue;
@@ -539,16 +543,15 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
         rg_barrier();                                             // (single buffer: everybody has read the slab)
         if (tr) trp[3] = __builtin_readcyclecounter();
         stamp(5);
-        st_iters++;
+        if constexpr (STATS) st_iters++;
       }
     }
     // ---- the next stage's first slab goes out before this stage's epilogue (buffer 1; the scratch is in buffer 0)
     DmaP nxt = cur;
-    if constexpr (S::NBUF == 2) {
+    if constexpr (S::XPRE) {
       if (stage + 1 < nstages) {
         dma_params(stage + 1, nxt);
-        const unsigned (&vB)[BPW] = (l == 0) ? voffB_nxt : voffB; // (a new round brings its own patch slabs)
-        if (nxt.NI > 0) issue_slab(nxt, vB, 0);
+        if (nxt.NI > 0) issue_slab(nxt, l == 0 ? vBn0 : vB0, l == 0 ? vBn1 : vB1, 0);   // (a new round brings its own patch slabs)
       }
     }
     // ---- epilogue of the level: tiles -> scratch -> blended rows
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
             for (int t = 0; t < TMAX; t++)
               if (t < nt[k]) *reinterpret_cast<rg_f4*>(scr + m * SP + 16 * t + 4 * kg) = acc[k][t];
           }
-          wave_lds_fence();
+          rg_lds_fence();
         }
         int ox, oy; float dx, dy;
         pixel_geo(tk[k], l, ox, oy, dx, dy);
@@ -577,15 +580,12 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
         } else {
           store_rows(s_be[tk[k]], o, res1[k]);
         }
-        if (have) wave_lds_fence();
+        if (have) rg_lds_fence();
       }
     }
     rg_barrier();                                                // buffer 0 is a DMA target again
-    if constexpr (S::NBUF == 2) {
-      if (l == 0) {
-#pragma unroll
-        for (int j = 0; j < BPW; j++) voffB[j] = voffB_nxt[j];
-      }
+    if constexpr (S::XPRE) {
+      if (l == 0) { vB0 = vBn0; vB1 = vBn1; }
       cur = nxt;
     }
     stamp(6);
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
     }
   }
   stamp(7);
-  if (stats && tid == 0) {
+  if constexpr (STATS) if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < 8; i++) atomicAdd(&stats[i], st_acc[i]);
     atomicAdd(&stats[8], (unsigned long long)nrounds); atomicAdd(&stats[9], 1ULL); atomicAdd(&stats[10], (unsigned long long)st_iters);

@@ -20,6 +20,8 @@ def _prep(fmap1, fmap2, coords, ii, jj, allow_blocked=False):
     return fmap1, fmap2, coords, ii, jj
 
 
+import os
+REGION_KERNEL = os.environ.get("DEVO_CORR_REGION", "0") == "1"   # opt-in region-shared lookup kernel (corr_region.h; the library reads the same switch)
 PLAN_MIN_EDGES = 2048      # below this the lookup is launch-bound and a locality plan cannot pay for itself
 NCHW_CONVERT_MIN_EDGES = 1024    # from here on a lookup into the reference's NCHW pyramid goes through a cached channel-blocked copy
 
@@ -172,7 +174,7 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
         out = torch.empty(B, E, per * nl, dtype=fmap1.dtype, device=fmap1.device)
     pyramid = [_fast_layout(f, B * E) if f.is_cuda else f for f in pyramid]
     pyr_l1 = 0                                                  # integer level ratio of a two-level pyramid (DEVO: 4), else 0
-    if nl == 2 and scales[0] > 0 and float(scales[1] / scales[0]).is_integer() and scales[1] / scales[0] >= 2:
+    if REGION_KERNEL and nl == 2 and scales[0] > 0 and float(scales[1] / scales[0]).is_integer() and scales[1] / scales[0] >= 2:
         pyr_l1 = int(scales[1] / scales[0])
     if order is None and B * E >= PLAN_MIN_EDGES:
         order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius, width=pyramid[0].shape[4], l1=pyr_l1)
@@ -185,7 +187,7 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
         cb = (ctypes.c_int * 2)(d0[3], d1[3])
         cd = (ctypes.c_float * 2)(float(scales[0]), float(scales[1]))
         # the region-shared kernel wants the patches as [Np, 9, C] (cached per version of fmap1) and a plan
-        f1t = patches_transposed(f1) if (order is not None and P == 3 and f1.shape[3] == 3) else None
+        f1t = patches_transposed(f1) if (REGION_KERNEL and order is not None and P == 3 and f1.shape[3] == 3) else None
         rc = L.lib().devo_corr_forward_pyramid2(L.ptr(f1), L.ptr(pyramid[0]), L.ptr(pyramid[1]), L.ptr(c_), L.ptr(ii_), L.ptr(jj_),
                                                 L.ptr(out), B, E, Np, pyramid[0].shape[1], C, P, hw, L.i64arr(d0[2] + d1[2]), cb,
                                                 per * nl, nl, L.i64arr([0, 1]), int(radius), L.dtype_code(f1), L.ptr(order), cd,

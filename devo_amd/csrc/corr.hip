@@ -154,8 +154,6 @@ struct CorrLevel {
   int64_t block_stride;           // elements between consecutive channel blocks (unused for channels-last)
   unsigned frame_bytes;           // extent of one frame (all blocks) in bytes: the buffer-load bound of the matrix-core kernel
   bool staged_ok, mfma_ok;        // which of the two fast kernels can read this level
-  bool dense_ok;                  // ... and the region-staged dense matrix-core kernel (corr_dense.h)
-  bool group_ok;                  // ... and the edge-group dense matrix-core kernel (corr_group.h)
   bool region_ok;                 // ... and the region-shared kernel (corr_region.h)
   int64_t out_offset;             // element offset of this level inside an edge's output record
   float coord_div;                // coordinates are divided by this (pyramid level scale)
@@ -438,10 +436,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
   }
 }
 
-#include "corr_dma.h"
 #include "corr_mfma.h"
-#include "corr_dense.h"
-#include "corr_group.h"
 #include "corr_region.h"
 
 // -------------------------------------------------------------------------------------------------
@@ -880,16 +875,6 @@ using namespace devo;
 
 // Describes one level for the fast kernels; false = neither of them can read it (generic kernel, or an error for
 // channel-blocked storage, which only the fast kernels understand).
-static bool corr_dense_enabled() {               // DEVO_CORR_DENSE=1: the region-staged dense matrix-core kernel (opt-in, see corr_dense.h)
-  static const char* env = getenv("DEVO_CORR_DENSE");
-  static const bool on = env && env[0] == '1';
-  return on;
-}
-static bool corr_group_enabled() {               // DEVO_CORR_GROUP=1: the edge-group dense matrix-core kernel (corr_group.h)
-  static const char* env = getenv("DEVO_CORR_GROUP");
-  static const bool on = env && env[0] == '1';
-  return on;
-}
 static bool corr_region_enabled() {              // DEVO_CORR_REGION=1: pyramid lookups with a pyramid plan take the region-shared kernel
   static const char* env = getenv("DEVO_CORR_REGION");
   static const bool on = env && env[0] == '1';
@@ -921,14 +906,9 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
   const bool c_ok = sizeof(T) == 4 ? (C == 64 || C == 128) : (C == 128 || C == 256);            // 4 or 8 steps per pass
   lv->mfma_ok = aligned && sizeof(T) <= 4 && corr_mfma_enabled() && c_ok && cb_ok &&
                 frame_bytes < (1LL << 31);                                                             // 32-bit in-frame offsets
-  // the dense kernel: any C that is a multiple of its channel slab (fp16: 32, fp32: 16), 16-byte pieces inside a channel block
-  lv->dense_ok = aligned && sizeof(T) <= 4 && corr_dense_enabled() && cb_ok && C % (sizeof(T) == 2 ? 32 : 16) == 0 &&
-                 C >= (sizeof(T) == 2 ? 64 : 32) && frame_bytes < (1LL << 31);                        // (at least two channel slabs)
-  // the group kernel: fp16 storage, C = 128, 16-byte pieces of 8 channels inside a channel block
-  lv->group_ok = aligned && sizeof(T) == 2 && corr_group_enabled() && cb_ok && C == 128 && frame_bytes < (1LL << 31);
   // the region-shared kernel: 16-byte pieces inside a channel block (or channels-last), any C that is a multiple of its slab
   lv->region_ok = aligned && sizeof(T) <= 4 && corr_region_enabled() && cb_ok && C % (sizeof(T) == 2 ? 32 : 16) == 0 && frame_bytes < (1LL << 31);
-  if (!lv->staged_ok && !lv->mfma_ok && !lv->dense_ok && !lv->group_ok && !lv->region_ok) {
+  if (!lv->staged_ok && !lv->mfma_ok && !lv->region_ok) {
     if (blocked) {
       set_error("devo_corr_forward: channel-blocked fmap2 needs fp32 / fp16, 16-byte aligned strides and cblock == %d (got %d)", KC, cblock);
       *err = DEVO_ERR_UNSUPPORTED;
@@ -958,65 +938,6 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
   const size_t nrec = (size_t)BE * nlev;
   if (do_trace) { (void)hipMalloc(&trace, nrec * 64); (void)hipMemset(trace, 0, nrec * 64); }
   const bool mfma = lv0.mfma_ok && (nlev == 1 || lv1.mfma_ok);
-  const long long f1_bytes = (BE / (E > 0 ? E : 1)) * (long long)Np * C * PP * (long long)sizeof(T);
-  const bool dense = lv0.dense_ok && (nlev == 1 || lv1.dense_ok) && !do_trace && f1_bytes < (1LL << 31) && BE < (1LL << 31) - 64;
-  const bool group = lv0.group_ok && (nlev == 1 || lv1.group_ok) && !do_trace && R <= 3 && f1_bytes < (1LL << 31) && BE < (1LL << 31) - 64;
-  if (group) {                                                        // edge-group dense matrix-core kernel (corr_group.h)
-    typedef typename std::conditional<sizeof(T) == 2, T, __half>::type MT;               // (fp16 only: group_ok is false otherwise)
-    const long long ngroups = (BE + GP_GE - 1) / GP_GE;
-    const dim3 ggrid((unsigned)(32 * ((ngroups + 31) / 32))), gblock(GP_THREADS);      // (the kernel maps runs of 4 groups to XCDs)
-    unsigned long long* gstats = nullptr;                             // debug switch: phase cycles / tile counts to stderr
-    static const bool do_gstats = getenv("DEVO_GP_STATS") != nullptr;
-    hipEvent_t gev0 = nullptr, gev1 = nullptr;
-    if (do_gstats) { (void)hipMalloc(&gstats, 128); (void)hipMemset(gstats, 0, 128); (void)hipEventCreate(&gev0); (void)hipEventCreate(&gev1); (void)hipEventRecord(gev0, st); }
-    if (nlev == 2)
-      hipLaunchKernelGGL((corr_fwd_group_kernel<MT, 2>), ggrid, gblock, 0, st, (const MT*)fmap1, lv0, lv1, coords, ii, jj, (MT*)out, (int)BE, E, Np,
-                         n2, C, oes, ols, R, order, gstats);
-    else
-      hipLaunchKernelGGL((corr_fwd_group_kernel<MT, 1>), ggrid, gblock, 0, st, (const MT*)fmap1, lv0, lv1, coords, ii, jj, (MT*)out, (int)BE, E, Np,
-                         n2, C, oes, ols, R, order, gstats);
-    if (do_gstats) {
-      (void)hipEventRecord(gev1, st);
-      (void)hipDeviceSynchronize();
-      float gms = 0.0f;
-      (void)hipEventElapsedTime(&gms, gev0, gev1);
-      unsigned long long h[16];
-      (void)hipMemcpy(h, gstats, 128, hipMemcpyDeviceToHost);
-      const double g = h[4] ? (double)h[4] : 1.0;
-      fprintf(stderr, "[group stats] kernel %.1f us; workgroup lifetime: mean %.0f cycles, max %llu; resident workgroups on average %.0f\n", gms * 1e3,
-              (h[0] + h[1] + h[2] + h[3]) / g, h[8], (double)(h[0] + h[1] + h[2] + h[3]) / (gms * 1e-3 * 2.4e9));
-      fprintf(stderr, "[group stats] of the products phase, waiting for the tile's loads: %.0f cycles per group (first wave)\n", h[9] / g);
-      fprintf(stderr, "[group stats] edges %lld, groups %llu; first wave per group: passes %.2f, tiles %.1f, (tile, N-tile) products %.1f; cycles: setup %.0f | products %.0f | wait at barrier %.0f | epilogue %.0f\n",
-              BE, h[4], h[7] / g, h[5] / g, h[6] / g, h[0] / g, h[1] / g, h[2] / g, h[3] / g);
-      (void)hipFree(gstats);
-    }
-  } else
-  if (dense) {                                                        // region-staged dense matrix-core kernel (corr_dense.h)
-    typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;   // (never fp64: dense_ok is false)
-    typedef void (*dense_fn_t)(const MT*, CorrLevel, CorrLevel, const float*, const int64_t*, const int64_t*, MT*, int, int, int,
-                               int, int, int64_t, int64_t, int, const int*, unsigned long long*);
-    const dense_fn_t fn = nlev == 2 ? (R <= 3 ? corr_fwd_dense_kernel<MT, 3, 2> : corr_fwd_dense_kernel<MT, 5, 2>)
-                                    : (R <= 3 ? corr_fwd_dense_kernel<MT, 3, 1> : corr_fwd_dense_kernel<MT, 5, 1>);
-    const int chunk_edges = R <= 3 ? DnShape<3, 2>::CHUNK : DnShape<5, 2>::CHUNK;          // (the same for one level)
-    const long long nchunks = (BE + chunk_edges - 1) / chunk_edges;
-    const dim3 dgrid((unsigned)(8 * ((nchunks + 7) / 8))), dblock(DN_THREADS);
-    unsigned long long* stats = nullptr;                              // debug switch: round statistics to stderr
-    static const bool do_stats = getenv("DEVO_DN_STATS") != nullptr;
-    if (do_stats) { (void)hipMalloc(&stats, 128); (void)hipMemset(stats, 0, 128); }
-    hipLaunchKernelGGL(fn, dgrid, dblock, 0, st, (const MT*)fmap1, lv0, lv1, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C, oes,
-                       ols, R, order, stats);
-    if (do_stats) {
-      (void)hipDeviceSynchronize();
-      unsigned long long h[16];
-      (void)hipMemcpy(h, stats, 128, hipMemcpyDeviceToHost);
-      const double r = h[0] ? (double)h[0] : 1.0;
-      fprintf(stderr, "[dense stats] edges %lld, workgroups %u, rounds %llu (items/round %.2f, single-pixel rounds %llu), region positions/round: level 0 %.0f, level 1 %.0f, cycles/round %.0f\n",
-              BE, dgrid.x, h[0], h[1] / r, h[4], h[2] / r, h[3] / r, h[5] / r);
-      fprintf(stderr, "[dense stats] first compute wave, cycles/round by phase: item setup %.0f | waiting at the slab barriers %.0f | products %.0f | epilogue %.0f\n",
-              h[6] / r, h[7] / r, h[8] / r, h[9] / r);
-      (void)hipFree(stats);
-    }
-  } else
   if (mfma) {                                                         // matrix-core kernel (corr_mfma.h)
     static const char* split_env = getenv("DEVO_CORR_SPLIT_LEVELS");  // debug: fused lookups as two sets of workgroups
     const bool both = nlev == 2 && !(split_env && split_env[0] == '1') && !do_trace;
@@ -1179,15 +1100,6 @@ static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* co
   CorrLevel lv;
   int err;
   if (staged_level<T>(fmap2, C, H2, W2, f2s, cblock, ooff, coord_div, &lv, &err)) {
-    static const bool use_dma = getenv("DEVO_CORR_DMA") != nullptr;     // experimental LDS-direct kernel: opt-in
-    const size_t dma_lds = sizeof(float) * (2 * DMA_BUF_FLOATS + (size_t)PP * (C + 4));
-    if (std::is_same<T, float>::value && R <= 3 && use_dma && lv.staged_ok && cblock <= 1 && C % 4 == 0 && (size_t)C * 4 <= DMA_ZERO_BYTES &&
-        dma_lds <= 48 * 1024) {
-      hipLaunchKernelGGL(corr_fwd_dma_kernel, dim3((unsigned)BE), dim3(64), dma_lds, st, (const float*)fmap1, (const float*)fmap2,
-                         coords, ii, jj, (float*)out, (int)BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[3], f2s[4], oes, ols, ooff,
-                         R, order, (unsigned long long*)nullptr, coord_div);
-      return check_launch("devo_corr_forward");
-    }
     return launch_staged<T>(fmap1, lv, lv, 1, coords, ii, jj, out, BE, E, Np, n2, C, oes, ols, R, order, st);
   }
   if (err) return err;

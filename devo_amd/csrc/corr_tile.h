@@ -37,7 +37,7 @@ __host__ __device__ __forceinline__ int corr_plan_bx(int xw) {   // column bins 
 
 // Plan bin of an edge from its 9 window origins: -1 = HEAVY (the union box does not fit the tile), else
 // (batch, target frame, 16-row band of the patch centre, column bin of the patch centre) — consecutive edges of the sorted
-// plan land next to each other in the image, which is what the region-staged lookup kernel (corr_dense.h) groups on.
+// plan land next to each other in the image, which is what the region-shared lookup kernel (corr_region.h) groups on.
 // x[p], y[p]: integer pixel of patch pixel p at the plan's level.  `geom` = corr_plan_pack(): bands | column bins << 8 |
 // column-bin width << 16.
 //

@@ -126,7 +126,7 @@ def test_channel_blocked_layout_is_bit_identical_and_checked():
     h = lambda t: t.to(DEV).half()
     with pytest.raises(RuntimeError):                                 # the staged kernel (fp16) reads 8-channel blocks only
         cuda_corr.forward(h(f1), altcorr.channel_blocked(h(f2), 4), coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
-    if os.environ.get("DEVO_CORR_MFMA", "1") != "0" or os.environ.get("DEVO_CORR_DENSE", "0") == "1":   # the matrix-core kernels: blocks of 4, 8 or 16 channels
+    if os.environ.get("DEVO_CORR_MFMA", "1") != "0":                  # the matrix-core kernel: blocks of 4, 8 or 16 channels
         c = _case(seed=15, spread=3.5, E=96)
         for cb in (4, 16):
             out, = cuda_corr.forward(c[0].to(DEV), altcorr.channel_blocked(c[1].to(DEV), cb), c[2].to(DEV), c[3].to(DEV), c[4].to(DEV), c[5])
@@ -440,26 +440,20 @@ def test_plan_by_several_workgroups_is_a_sorted_permutation(n, M, H, W):
     assert torch.equal(out_plan, out_list)
 
 
-@pytest.mark.parametrize("which", ["region-staged dense kernel", "staged kernel", "edge-group kernel", "segment-reduced backward"])
+@pytest.mark.parametrize("which", ["staged kernel", "segment-reduced backward"])
 def test_other_kernels_stay_covered(which):
-    """fp32 / fp16 lookups with C = 128 take the per-edge matrix-core kernel by default.  DEVO_CORR_DENSE=1 (read once per
-    process) routes them through the region-staged dense matrix-core kernel (corr_dense.h, opt-in), DEVO_CORR_MFMA=0 through
-    the staged tap-centric kernel, DEVO_CORR_GROUP=1 sends fp16-storage lookups (C = 128, r <= 3) through the edge-group kernel
-    (corr_group.h, opt-in): same parity tests."""
-    if os.environ.get("DEVO_CORR_DENSE", "0") == "1" or os.environ.get("DEVO_CORR_MFMA", "1") == "0" or os.environ.get("DEVO_CORR_GROUP", "0") == "1" or os.environ.get("DEVO_CORR_BWD_SEG"):
+    """fp32 / fp16 lookups with C = 128 take the per-edge matrix-core kernel by default.  DEVO_CORR_MFMA=0 (read once per process)
+    routes them through the staged tap-centric kernel, DEVO_CORR_BWD_SEG=1 the backward through the tile kernel: same parity tests.
+    (The region-shared kernel, DEVO_CORR_REGION=1, has its own file: tests/test_gpu_region.py.)"""
+    if os.environ.get("DEVO_CORR_MFMA", "1") == "0" or os.environ.get("DEVO_CORR_BWD_SEG"):
         pytest.skip("already running on another kernel")
     env = dict(os.environ)
     sel = "test_forward_fp32 or test_forward_wide_spread or test_channel_blocked or test_fused_pyramid or test_batch_of_two or test_forward_other_radii or test_coord_div"
     if which == "staged kernel":
         env["DEVO_CORR_MFMA"] = "0"
-    elif which == "segment-reduced backward":                       # opt-in: d_fmap2 tile by tile in LDS instead of global atomics
+    else:                                                           # opt-in: d_fmap2 tile by tile in LDS instead of global atomics
         env["DEVO_CORR_BWD_SEG"] = "1"
         sel = "test_backward_fp32 or test_autograd_layer or test_dtype_coverage"
-    elif which == "edge-group kernel":
-        env["DEVO_CORR_GROUP"] = "1"
-        sel = "test_channel_blocked or test_forward_fp16 or test_fused_pyramid_fp16 or test_nchw_pyramid or test_dtype_coverage"
-    else:
-        env["DEVO_CORR_DENSE"] = "1"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", sel],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -66,18 +66,20 @@ def test_lookup_at_full_size(workload, sample):
     assert torch.equal(buf, out)
 
 
-@pytest.mark.parametrize("kernel", ["per-edge", "edge-group"])
+@pytest.mark.parametrize("kernel", ["per-edge", "region-shared"])
 def test_lookup_fp16_storage_at_full_size(kernel):
     """BASELINE configuration 2 with fp16 feature storage (the reference's inference precision, devo.py:71-77): oracle on a sample of
     edges within the fp16-storage tolerance (2e-3 of the fp32 oracle on the same rounded inputs), plan independence bit for bit,
-    every row written.  `edge-group` repeats it in a sub-process on the opt-in group kernel (DEVO_CORR_GROUP=1, corr_group.h)."""
+    every row written.  `region-shared` repeats it, and the fp32 full-size tests, in a sub-process on the opt-in region kernel
+    (DEVO_CORR_REGION=1, corr_region.h)."""
     import subprocess
-    if kernel == "edge-group":
-        if os.environ.get("DEVO_CORR_GROUP", "0") == "1":
-            pytest.skip("already running on the group kernel")
-        env = dict(os.environ); env["DEVO_CORR_GROUP"] = "1"
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "fp16_storage_at_full_size and per-edge"],
-                           env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if kernel == "region-shared":
+        if os.environ.get("DEVO_CORR_REGION", "0") == "1":
+            pytest.skip("already running on the region kernel")
+        env = dict(os.environ); env["DEVO_CORR_REGION"] = "1"
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                            "(fp16_storage_at_full_size and per-edge) or test_lookup_at_full_size"],
+                           env=env, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         return
     from devo_amd import synth

@@ -9,9 +9,21 @@ from oracle import altcorr as A
 from util import assert_rel, channels_last5
 
 import os
-os.environ.setdefault("DEVO_CORR_REGION", "1")      # (read once when the library first looks at it: this module must set it before any lookup)
+import subprocess
+import sys
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+REGION = os.environ.get("DEVO_CORR_REGION", "0") == "1"      # the library reads the switch once per process
+
+
+def test_region_kernel_suite_in_a_sub_process():
+    """the region-shared kernel is opt-in (DEVO_CORR_REGION=1, read once per process): this file runs again in a sub-process with it"""
+    if REGION:
+        pytest.skip("this is the sub-process")
+    env = dict(os.environ); env["DEVO_CORR_REGION"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x"], env=env, capture_output=True, text=True,
+                       timeout=1500, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def _case(n=3, Np=40, C=128, H=32, W=48, E=3000, R=3, seed=0, spread=1.0, B=1, far=0.03):
@@ -58,6 +70,10 @@ def _lookup(f1, f2, l1, coords, ii, jj, R, layout="blk8", dtype=torch.float32, o
     return (out, order) if want_plan else out
 
 
+needs_region = pytest.mark.skipif(not REGION, reason="runs in the DEVO_CORR_REGION=1 sub-process")
+
+
+@needs_region
 @pytest.mark.parametrize("layout", ["blk8", "blk4", "blk16", "cl"])
 def test_fp32_layouts(layout):
     c = _case(seed=1)
@@ -70,6 +86,7 @@ def test_fp32_layouts(layout):
     assert torch.count_nonzero(got[0, 1]) == 0                          # a dead edge is exactly zero
 
 
+@needs_region
 @pytest.mark.parametrize("layout", ["blk8", "blk16", "blk32", "cl"])
 def test_fp16_layouts(layout):
     f1, f2, coords, ii, jj, R = _case(seed=2)
@@ -83,6 +100,7 @@ def test_fp16_layouts(layout):
     assert_rel(got.float(), ref, 2e-3, f"region lookup fp16 {layout}")
 
 
+@needs_region
 @pytest.mark.parametrize("R", [0, 1, 2, 4, 5])
 def test_radii(R):
     c = _case(seed=10 + R, R=R, E=2500, H=40, W=56)
@@ -90,6 +108,7 @@ def test_radii(R):
     assert_rel(_lookup(*c[:2], l1, *c[2:]), ref, 1e-4, f"region lookup R={R}")
 
 
+@needs_region
 @pytest.mark.parametrize("C,dtype", [(64, torch.float32), (32, torch.float32), (256, torch.float16), (64, torch.float16)])
 def test_channel_counts(C, dtype):
     f1, f2, coords, ii, jj, R = _case(seed=20, C=C)
@@ -103,12 +122,14 @@ def test_channel_counts(C, dtype):
     assert_rel(got.float(), ref, 1e-4 if dtype == torch.float32 else 2e-3, f"region lookup C={C}")
 
 
+@needs_region
 def test_batch_of_two():
     c = _case(seed=30, B=2, E=1800)
     ref, l1 = _oracle(*c)
     assert_rel(_lookup(*c[:2], l1, *c[2:]), ref, 1e-4, "region lookup B=2")
 
 
+@needs_region
 def test_far_spread_pixels_and_everything_outside():
     """many edges whose pixels lie far apart (the plan's heavy list -> per-edge kernel) and a frame nobody hits"""
     c = _case(seed=40, far=0.4, E=2200)
@@ -121,6 +142,7 @@ def test_far_spread_pixels_and_everything_outside():
     assert torch.count_nonzero(got) == 0 and torch.count_nonzero(ref) == 0
 
 
+@needs_region
 def test_a_plan_without_classes_takes_the_tap_by_tap_path_and_random_order_only_costs_time():
     """identity order, no heavy list, no dead tail: edges the rounds cannot take are computed tap by tap; unrelated neighbours in
     a chunk become rounds of their own.  Same results (tap-by-tap edges: plain fp32 sums instead of hi + lo products)."""
@@ -131,6 +153,7 @@ def test_a_plan_without_classes_takes_the_tap_by_tap_path_and_random_order_only_
     assert_rel(_lookup(*c[:2], l1, *c[2:], order=ident), ref, 1e-4, "identity plan")
 
 
+@needs_region
 def test_plans_that_keep_the_classes_do_not_change_one_bit():
     """the plan decides which edges share a round, never a result: shuffle the heavy slots, the live slots and the dead slots among
     themselves"""
@@ -147,6 +170,7 @@ def test_plans_that_keep_the_classes_do_not_change_one_bit():
     assert torch.equal(_lookup(*c[:2], l1, *c[2:], order=p.to(DEV)), out)
 
 
+@needs_region
 def test_drop_in_path_builds_its_own_plan_and_matches_per_level_calls():
     """forward_pyramid without a plan (>= 2048 edges: it builds the pyramid plan itself) against two single-level lookups of the
     per-edge kernel"""

@@ -25,7 +25,8 @@ REGION_KERNEL = os.environ.get("DEVO_CORR_REGION", "0") == "1"   # opt-in region
 PLAN_MIN_EDGES = 2048      # below this the lookup is launch-bound and a locality plan cannot pay for itself
 NCHW_CONVERT_MIN_EDGES = 1024    # from here on a lookup into the reference's NCHW pyramid goes through a cached channel-blocked copy
 
-_blocked_cache = {}        # (ptr, version, shape, strides, dtype) -> (source tensor [kept alive], channel-blocked copy)
+_blocked_cache = {}        # (ptr, version, shape, strides, dtype) -> (source tensor [kept alive], channel-blocked copy); LRU
+BLOCKED_CACHE_ENTRIES = 4
 
 
 def _fast_layout(fmap2, n_edges):
@@ -46,11 +47,14 @@ def _fast_layout(fmap2, n_edges):
     if C % 8 or tuple(st[2:]) != (H * W, W, 1) or B * n == 0:
         return fmap2                                          # not plain NCHW frames (e.g. channels-last already)
     key = (fmap2.data_ptr(), fmap2._version, tuple(fmap2.shape), tuple(st), fmap2.dtype)
-    hit = _blocked_cache.get(key)
+    hit = _blocked_cache.pop(key, None)
     if hit is not None:
+        _blocked_cache[key] = hit                             # (most recently used last)
         return hit[1]
-    for k in [k for k in _blocked_cache if k[0] == key[0] or len(_blocked_cache) >= 8]:
-        del _blocked_cache[k]                                 # an older version of this tensor (or: keep the cache small)
+    for k in [k for k in _blocked_cache if k[0] == key[0]]:
+        del _blocked_cache[k]                                 # an older version of this tensor
+    while len(_blocked_cache) >= BLOCKED_CACHE_ENTRIES:       # least recently used first (dicts keep insertion order): a DEVO
+        del _blocked_cache[next(iter(_blocked_cache))]        # process holds two levels of one ring = 2 entries, ~300 MB in fp16
     blk = torch.empty(B, n, C // 8, H, W, 8, dtype=fmap2.dtype, device=fmap2.device)
     for b in range(B):
         rc = L.lib().devo_pyramid_build(L.ptr(fmap2[b]), L.ptr(blk[b]), None, n, C, H, W, st[1], blk.stride(1), 0,

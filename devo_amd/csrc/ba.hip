@@ -1011,6 +1011,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_ba_accumulate_reg(
 // S = sum of the compact partials, mirrored; S_dd <- S_dd*(1+1e-4)+1 (ba_cuda.cu:517-518); y = sum.
 // 512-thread workgroups: wave g sums partials [g*n_part/8, (g+1)*n_part/8) for 64 consecutive outputs (32 loads in
 // flight), the eight wave results are combined through LDS in a fixed order.
+// damping value that tells k_ba_reduce to leave the diagonal alone (the deferred Schur path damps afterwards): any other value,
+// negative ones included, is applied as given
+constexpr float BA_EP_DEFERRED = -3.402823466e38f;
 __global__ __launch_bounds__(512) void k_ba_reduce(const float* __restrict__ partials, int n_part, int N, float* __restrict__ S,
                                                    float* __restrict__ y, float ep) {
   // One lane per entry of the COMPACT partial (lower block triangle + right-hand side): consecutive lanes read consecutive
@@ -1046,7 +1049,7 @@ __global__ __launch_bounds__(512) void k_ba_reduce(const float* __restrict__ par
       block_of(o / 36, fr, fc);
       const int ab = o % 36, r = 6 * fr + ab / 6, c = 6 * fc + ab % 6;
       if (fr == fc && ab / 6 < ab % 6) return;                  // upper half of a diagonal block: its mirror writes it
-      if (r == c && ep >= 0.0f) sum = sum + (1e-4f * sum + ep);   // ba_cuda.cu:518 (ep = 1); devo/ba.py:73 (ep = 10 in training); ep < 0: k_ba_damp does it
+      if (r == c && ep != BA_EP_DEFERRED) sum = sum + (1e-4f * sum + ep);   // ba_cuda.cu:518 (ep = 1); devo/ba.py:73 (ep = 10 in training); BA_EP_DEFERRED: k_ba_damp does it
       S[r * (n6 + 1) + c] = sum;
       if (r != c) S[c * (n6 + 1) + r] = sum;
     } else S[n6 * (n6 + 1) + (o - nt)] = sum;
@@ -1384,6 +1387,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
 #endif
   const unsigned long long st2 = stamps ? __builtin_readcyclecounter() : 0ull;
   if (s_fail) {
+    // breakdown: dX = 0 (devo/ba.py:16-20: CholeskySolver returns zeros, no gradient through the solve) — the callers of the
+    // differentiable path copy / read dX afterwards, and the workspace is not zero-initialised
+    for (int i = tid; i < 6 * N; i += SOLVE_THREADS) dX[i] = 0.0f;
     if (tid == 0) { meta->fail = iter + 1; if (status_flag) *status_flag = iter + 1; }
     return;
   }
@@ -2088,7 +2094,7 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
   return check_launch("devo_ba_prepare");
 }
 
-// k_ba_schur + k_ba_damp behind k_ba_reduce(ep < 0): the Schur term of the general accumulate kernel as one product
+// k_ba_schur + k_ba_damp behind k_ba_reduce(ep = BA_EP_DEFERRED): the Schur term of the general accumulate kernel as one product
 static void ba_deferred_schur(hipStream_t st, const float* patch_rec, const float* patch_col, const BaMeta* meta, int N, int max_seg, float* S, float ep,
                               float* scratch, size_t scratch_bytes) {
   const int nt = (6 * N + 1 + SCH_T - 1) / SCH_T, ntile = nt * (nt + 1) / 2, nchunk = (max_seg + SCH_K - 1) / SCH_K;
@@ -2225,7 +2231,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
                        weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, it | (defer ? 1 << 16 : 0), ba_sig(E, N), L.max_seg);
     if ((rc = check_launch("devo_ba_forward(accumulate)"))) return rc;
     if (N > 0) {
-      hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, partials, L.n_part, N, S, y, defer ? -1.0f : ep);
+      hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, partials, L.n_part, N, S, y, defer ? BA_EP_DEFERRED : ep);
       if (defer) ba_deferred_schur(st, patch_rec, edge_ej, meta, N, L.max_seg, S, ep, partials, sizeof(float) * (size_t)L.n_part * (n6 * (n6 + 1) + n6 + 1));
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       static const bool ba_trace = getenv("DEVO_BA_TRACE") != nullptr;
@@ -2297,7 +2303,7 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
   if ((rc = check_launch("devo_ba_solve_terms(accumulate)"))) return rc;
   if (N > 0) {
     hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, (float*)(w + L.partials), L.n_part, N, S,
-                       (float*)(w + L.y), defer ? -1.0f : ep);
+                       (float*)(w + L.y), defer ? BA_EP_DEFERRED : ep);
     if (defer) ba_deferred_schur(st, patch_rec, patch_col, meta, N, L.max_seg, S, ep, (float*)(w + L.partials), sizeof(float) * (size_t)L.n_part * (n6 * (n6 + 1) + n6 + 1));
     hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, (float*)(w + L.y), N, dX, meta, 0, status_flag, 0);
     if ((rc = check_launch("devo_ba_solve_terms(solve)"))) return rc;

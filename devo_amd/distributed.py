@@ -79,13 +79,28 @@ def launch(fn, nprocs, args=()):
     procs = [ctx.Process(target=_child, args=(r, nprocs, port, fn, args)) for r in range(nprocs)]
     for p in procs:
         p.start()
-    bad = []
-    for r, p in enumerate(procs):
-        p.join()
-        if p.exitcode != 0:
-            bad.append((r, p.exitcode))
+    # poll: when one rank dies (an import error, an exception before or inside a collective) the others would wait in
+    # RCCL / gloo forever — terminate them and raise, like torch.multiprocessing.spawn does
+    import time
+    bad, live = [], set(range(nprocs))
+    while live and not bad:
+        for r in sorted(live):
+            p = procs[r]
+            p.join(timeout=0.05)
+            if p.exitcode is not None:
+                live.discard(r)
+                if p.exitcode != 0:
+                    bad.append((r, p.exitcode))
+        if live and not bad:
+            time.sleep(0.05)
     if bad:
-        raise RuntimeError(f"launch: ranks failed (rank, exit code): {bad}")
+        for r in live:
+            procs[r].terminate()
+        for r in live:
+            procs[r].join(timeout=10)
+            if procs[r].is_alive():
+                procs[r].kill()
+        raise RuntimeError(f"launch: ranks failed (rank, exit code): {bad}" + (f"; terminated the remaining ranks {sorted(live)}" if live else ""))
 
 
 def init_from_env(backend=None, device=None):

@@ -50,8 +50,8 @@ def BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, it
     """Gauss-Newton bundle adjustment, IN PLACE on the storage of `poses` (an SE3 object or a tensor) and `patches`;
     returns [] like the extension (callers rely on the mutation, devo/devo.py:337).
     A failed factorisation is reported like the reference reports it, by an exception the caller's try / except sees
-    (devo/devo.py:336-340) — `check="lazy"` (default): at the NEXT BA() call on the device, so that no call waits for the
-    GPU; `check="now"`: before returning (one host synchronisation); `check="never"`: only through last_status()."""
+    (devo/devo.py:336-340) — `check="lazy"` (default): at the NEXT BA() call on the device (after that call's own work has
+    been enqueued), so that no call waits for the GPU; `check="now"`: before returning (one host synchronisation); `check="never"`: only through last_status()."""
     pose_data = getattr(poses, "data", poses)
     P = patches.shape[-1]
     n_opt = int(t1) - int(t0)
@@ -59,10 +59,10 @@ def BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, it
         raise RuntimeError(f"fastba.BA: {n_opt} optimised poses (t0 = {int(t0)}, t1 = {int(t1)}), at most {MAX_OPTIMISED_POSES} are supported "
                            f"(OPTIMIZATION_WINDOW is 10 in config/default.yaml); shrink the window or use devo_amd.ba.BA")
     dev = _devkey(pose_data.device)
-    if check == "lazy" and _pending.get(dev):
-        code = last_status(pose_data.device)
-        if code != 0:
-            raise BAFailure(f"fastba.BA: the previous bundle adjustment on {dev} failed (status {code})")
+    # lazy check: the status of the PREVIOUS call is read now (its copy is long done) but reported only after THIS call's work is
+    # enqueued — a caller that wraps BA() in the reference's try / except (devo.py:336-340) must not lose a healthy adjustment to
+    # its predecessor's failure
+    prev_code = last_status(pose_data.device) if (check == "lazy" and _pending.get(dev)) else 0
     st = _status.get(dev)
     if st is None:
         st = _status[dev] = torch.zeros(1, dtype=torch.int32, device=pose_data.device)
@@ -79,6 +79,8 @@ def BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, it
         code = last_status(pose_data.device)
         if code != 0:
             raise BAFailure(f"fastba.BA: bundle adjustment failed (status {code})")
+    if prev_code != 0:
+        raise BAFailure(f"fastba.BA: the previous bundle adjustment on {dev} failed (status {prev_code}); this call's adjustment has been enqueued")
     return out
 
 

@@ -46,17 +46,21 @@ class _LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gx = gw = gb = None
         g2 = g.reshape(-1, g.shape[-1])
-        if ctx.needs_input_grad[0]:
-            gx = (g2 @ w).reshape(x.shape)
-        if ctx.needs_input_grad[1]:
-            x2 = x.reshape(-1, x.shape[-1])
-            rows, S = x2.shape[0], _LinearFn.CHUNKS
-            if rows % S == 0:
-                gw = torch.bmm(g2.reshape(S, rows // S, -1).transpose(1, 2), x2.reshape(S, rows // S, -1)).sum(0)
-            else:
-                gw = g2.t() @ x2
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0)
+        # under torch.autocast (devo.py:311 runs the update operator under it) the forward's output — and so g — is fp16 while x and
+        # the parameters are fp32: multiply in g's dtype like the forward did, return every gradient in its input's dtype
+        with torch.autocast(device_type="cuda", enabled=False):
+            if ctx.needs_input_grad[0]:
+                gx = (g2 @ w.to(g2.dtype)).reshape(x.shape).to(x.dtype)
+            if ctx.needs_input_grad[1]:
+                x2 = x.reshape(-1, x.shape[-1]).to(g2.dtype)
+                rows, S = x2.shape[0], _LinearFn.CHUNKS
+                if rows % S == 0:
+                    gw = torch.bmm(g2.reshape(S, rows // S, -1).transpose(1, 2), x2.reshape(S, rows // S, -1)).sum(0)
+                else:
+                    gw = g2.t() @ x2
+                gw = gw.to(w.dtype)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = g2.sum(0).to(w.dtype)
         return gx, gw, gb
 
 
@@ -88,6 +92,8 @@ class _GatedResidualFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gate, res):
+        if not (x.dtype == gate.dtype == res.dtype):
+            raise RuntimeError("update.gated_residual: x, gate and res must share one dtype (the kernel reads all three with it)")
         x, gate, res = x.contiguous(), gate.contiguous(), res.contiguous()
         out = torch.empty_like(x)
         rows, dim = x.numel() // x.shape[-1], x.shape[-1]
@@ -99,7 +105,7 @@ class _GatedResidualFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         gate, res = ctx.saved_tensors
-        g = g.contiguous()
+        g = g.to(gate.dtype).contiguous()
         dgate, dres = torch.empty_like(gate), torch.empty_like(res)
         rows, dim = g.numel() // g.shape[-1], g.shape[-1]
         L.check(L.lib().devo_upd_gated_residual_backward(L.ptr(gate), dim, L.ptr(res), L.ptr(g), L.ptr(dgate), L.ptr(dres), rows, dim,
@@ -142,7 +148,10 @@ class GatedResidual(nn.Module):                      # blocks.py:15-29
 
     def forward(self, x):
         if _hip_ok(x):
-            return _GatedResidualFn.apply(x, self.gate[0](x), self.res(x))
+            gate, res = self.gate[0](x), self.res(x)
+            if gate.dtype == x.dtype and res.dtype == x.dtype:   # (under autocast the Linear outputs are fp16 next to an fp32 x: torch expression)
+                return _GatedResidualFn.apply(x, gate, res)
+            return x + torch.sigmoid(gate) * res
         return x + self.gate(x) * self.res(x)
 
 
@@ -197,7 +206,7 @@ class _SoftAggFn(torch.autograd.Function):
         fg, = ctx.saved_tensors
         G = ctx.G
         E, dim = fg.shape[0], fg.shape[1] // 2
-        dy = dy.contiguous()
+        dy = dy.to(fg.dtype).contiguous()
         dfg = torch.empty_like(fg)                              # (every edge belongs to exactly one group: fully written)
         L.check(L.lib().devo_upd_softagg_backward(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
                                                   L.ptr(dy), L.ptr(dfg), L.ptr(dfg[:, dim:]), 2 * dim, E, dim, L.dtype_code(fg), L.stream()),

@@ -1,0 +1,47 @@
+"""bench.py's own N > 1 path, exercised before the driver does (one GPU shared by two ranks, `--share-gpu`): the launcher
+(devo_amd.distributed.launch: one process per rank, RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1), the RCCL process group, the barrier +
+max-over-ranks timing, the replica aggregation (`value` = N K / t), the data-parallel training probe (`train_dp`: DDP over the
+reference's 3 397 061-parameter tree, the one collective of the path — train.py:31-42,90-95,106-107) and `--mode train`.
+The JSON lines are kept under gpurun_out/ (copied to profiles/ by hand)."""
+import json
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), lines[0]
+
+
+def _keep(name, line):
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, name), "w") as f:
+            f.write(line + "\n")
+
+
+def test_update_op_bench_on_two_ranks_sharing_the_gpu():
+    d, line = _run(["--gpus", "2", "--share-gpu", "--steps", "20", "--warmup", "5", "--no-f16"], timeout=900)
+    _keep("bench_gpus2_share.json", line)
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak"
+    assert "x2" in d["config"]["parallelism"] or "2" in d["config"]["parallelism"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert "train_dp" in d and "error" not in d["train_dp"], d.get("train_dp")
+    assert d["train_dp"]["sequences_per_s"] > 0 and d["train_dp"]["parameters"] == 3_397_061 and d["train_dp"]["grad_bucket_bytes"] == 13_588_244
+
+
+def test_training_bench_on_two_ranks_sharing_the_gpu():
+    d, line = _run(["--mode", "train", "--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "1", "--train-iters", "2"], timeout=900)
+    _keep("bench_train_gpus2_share.json", line)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "dp2" in d["config"]["parallelism"] or "2" in d["config"]["parallelism"]

@@ -43,12 +43,22 @@ def run_ba(poses, patches, intr, target, weight, ii, jj, kk, t0, t1, iters):
     return P.cpu(), Q.cpu()
 
 
-def check(got, ref64, tol=1e-4):
+def check(got, ref64, tol=1e-4, ref32=None):
+    """per ROW (tests/util.py:row_rel_err): every pose's translation and quaternion and every patch's inverse depth within `tol` of
+    ITSELF (down to 1 % of the tensor's scale) — not max-abs over the tensor's maximum, which lets a small component hide.
+    ref32 = the oracle run in fp32 on the same inputs: where fp32 arithmetic itself moves a row by more than tol / 2 (an ill-conditioned
+    patch), the bound for that row is twice the oracle's own fp32 error (the envelope of test_gpu_fullsize's 1-px test)."""
+    from util import row_rel_err
     p, q = got
     assert torch.isfinite(p).all() and torch.isfinite(q).all()
-    assert_rel(p[..., :3], ref64[0][..., :3], tol, "translation")
-    assert_rel(p[..., 3:], ref64[0][..., 3:], tol, "quaternion")
-    assert_rel(q[:, :, 2], ref64[1][:, :, 2], tol, "inverse depth")
+    rows = lambda P, Q: (("translation", P[0, :, :3]), ("quaternion", P[0, :, 3:]), ("inverse depth", Q[0, :, 2].reshape(-1)))
+    for i, (name, a) in enumerate(rows(p, q)):
+        b = rows(*ref64)[i][1]
+        err = row_rel_err(a, b)
+        bound = torch.full_like(err, tol)
+        if ref32 is not None:
+            bound = torch.maximum(bound, 2.0 * row_rel_err(rows(*ref32)[i][1].double(), b))
+        assert bool((err <= bound).all()), f"{name}: per-row relative error {float(err.max()):.3e}, worst error / bound {float((err / bound).max()):.2f} (tol {tol:.1e})"
     assert torch.equal(q[:, :, :2], ref64[1][:, :, :2].float())
 
 
@@ -88,7 +98,8 @@ def test_ba_patch_with_mixed_source_frames():
     g = torch.Generator().manual_seed(1)
     s[5] = torch.where(torch.rand(len(s[5]), generator=g) < 0.3, torch.randint(0, 8, (len(s[5]),), generator=g), s[5])
     ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], 1, 8, 1, dtype=torch.float64)
-    check(run_ba(*s, 1, 8, 1), ref, tol=2e-4)
+    ref32 = F.ba(*s[:5], torch.tensor([1e-4]), *s[5:], 1, 8, 1, dtype=torch.float32)
+    check(run_ba(*s, 1, 8, 1), ref, tol=2e-4, ref32=ref32)
 
 
 def test_ba_requires_contiguous_inplace_buffers():
@@ -196,9 +207,12 @@ def test_dropin_fastba_reports_a_failed_factorisation():
     assert fastba.BA(*args(P, Q, d(s[4]))) == [] and fastba.last_status(DEV) == 0
     P, Q = d(s[0]).clone(), d(s[1]).clone()
     assert fastba.BA(*args(P, Q, bad)) == []                                    # fails silently for now ...
-    with pytest.raises(fastba.BAFailure):                                       # ... and is reported by the next call
-        fastba.BA(*args(P, Q, d(s[4])))
-    assert fastba.BA(*args(P, Q, d(s[4]))) == [] and fastba.last_status(DEV) == 0
+    P2, Q2 = d(s[0]).clone(), d(s[1]).clone()
+    with pytest.raises(fastba.BAFailure):                                       # ... and is reported by the next call,
+        fastba.BA(*args(P2, Q2, d(s[4])))
+    Pr, Qr = d(s[0]).clone(), d(s[1]).clone()                                   # whose own (healthy) adjustment has still run
+    assert fastba.BA(*args(Pr, Qr, d(s[4]))) == [] and fastba.last_status(DEV) == 0
+    assert torch.equal(P2, Pr) and torch.equal(Q2, Qr) and not torch.equal(P2.cpu(), s[0])
     with pytest.raises(fastba.BAFailure):
         fastba.BA(*args(d(s[0]).clone(), d(s[1]).clone(), bad), check="now")
     fastba.BA(*args(d(s[0]).clone(), d(s[1]).clone(), bad), check="never")

@@ -157,6 +157,58 @@ def test_bundle_adjustment_at_one_pixel_stays_inside_the_fp32_envelope():
         worst[name] = (float(e_hip.max()), float(e_ref.max()), float((e_hip / bound).max()))
         assert bool((e_hip <= bound).all()), f"{name}: HIP {e_hip.max():.3e} vs fp32-oracle envelope {e_ref.max():.3e} (worst ratio {(e_hip / bound).max():.2f})"
     print("BA at 1 px, per-row relative error (HIP, fp32 oracle, worst HIP / bound):", worst)
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out")
+    if os.path.isdir(out):                                       # kept as profiles/r03_ba_1px_envelope.txt
+        with open(os.path.join(out, "ba_1px_envelope.txt"), "w") as f:
+            f.write("cuda_ba.forward at BASELINE configuration 2 (E = 21 600, 2 GN iterations), target = reprojected centre + N(0, 1 px): worst per-row relative error\n"
+                    "against the fp64 oracle (oracle/fastba.py) — the HIP result, the oracle run in fp32, and the worst ratio HIP / max(1e-4, 2 x fp32-oracle error)\n")
+            for k, (a, b, c) in worst.items():
+                f.write(f"  {k:14s} HIP {a:.3e}   fp32 oracle {b:.3e}   worst HIP / bound {c:.2f}\n")
+
+
+def test_training_ba_at_full_size_against_the_reference(golden_dir):
+    """BASELINE configuration 3's differentiable bundle adjustment at FULL size (n = 15, M = 80, E = 18 000; ep = 10, fixedp = 1),
+    pinned to the REAL reference: tests/golden/ba_train_fullsize_f64.npz holds what devo/ba.py:86-182 + projective_ops.py:53-105
+    return on the CPU in fp64 for devo_amd.synth's seeded inputs (tools/gen_golden.py: new poses, new inverse depths of 256 patches,
+    loss, gradients with respect to target / weight for a fixed random cotangent).  The fused fp32 HIP path (devo_ba_edge_terms,
+    devo_ba_solve_terms + their adjoints, devo_transform + devo_transform_vjp): values within 1e-4, gradients within 2e-3."""
+    import numpy as np
+    from devo_amd import synth
+    from devo_amd.ba import BA
+    from devo_amd import projective_ops as pops
+    from devo_amd.lietorch import SE3
+    from oracle import pops as OP
+    from oracle.lie import SE3 as OSE3
+    from util import assert_rel
+    z = np.load(os.path.join(golden_dir, "ba_train_fullsize_f64.npz"))
+    n, M, H, W, E = int(z["n"]), int(z["M"]), int(z["H"]), int(z["W"]), int(z["E"])
+    dt = torch.float64
+    poses = synth.make_poses(n, int(z["seed"]), dtype=dt)
+    patches, _ = synth.make_patches(n, M, H, W, seed=int(z["seed"]), dtype=dt)
+    intr = synth.make_intrinsics(n, H, W, dtype=dt)
+    ii, jj, kk = synth.full_graph(n, M)
+    assert len(ii) == E == 18000
+    delta, weight = synth.make_update_outputs(E, int(z["seed"]), sigma=1.0, dtype=dt)
+    with torch.no_grad():                                              # the generator formed the target from the reference's fp64 reprojection
+        c0 = OP.transform(OSE3(poses), patches, intr, ii, jj, kk)
+    target = c0[..., 1, 1, :] + delta
+    assert abs(float(target.sum()) - float(z["target_checksum"])) <= 1e-6 * abs(float(z["target_checksum"]))    # same inputs as the generator's
+    d = lambda t: t.to(DEV, torch.float32) if t.is_floating_point() else t.to(DEV)
+    tgt, wgt = d(target).requires_grad_(True), d(weight).requires_grad_(True)
+    G, P = BA(SE3(d(poses)), d(patches), d(intr), tgt, wgt, 1e-4, d(ii), d(jj), d(kk), z["bounds"].tolist(), ep=float(z["ep"]), fixedp=int(z["fixedp"]),
+              n_frames=n)
+    cf = pops.transform(G, P, d(intr), d(ii), d(jj), d(kk))
+    lw = torch.randn(cf.shape, generator=torch.Generator().manual_seed(int(z["loss_seed"])), dtype=dt)
+    loss = (cf * d(lw)).sum() + (G.log() ** 2).sum()
+    loss.backward()
+    from util import row_rel_err
+    sample = torch.from_numpy(z["sample"])
+    assert float(row_rel_err(G.data.detach()[0, :, :3], torch.from_numpy(z["poses_new"])[0, :, :3]).max()) <= 1e-4
+    assert float(row_rel_err(G.data.detach()[0, :, 3:], torch.from_numpy(z["poses_new"])[0, :, 3:]).max()) <= 1e-4
+    assert float(row_rel_err(P.detach().cpu()[0, sample, 2, 1, 1], torch.from_numpy(z["disp_new_sample"])).max()) <= 1e-4
+    assert abs(float(loss) - float(z["loss"])) <= 1e-3 * abs(float(z["loss"]))
+    assert_rel(tgt.grad, torch.from_numpy(z["grad_target"]), 2e-3, "d loss / d target at full size")
+    assert_rel(wgt.grad, torch.from_numpy(z["grad_weight"]), 2e-3, "d loss / d weight at full size")
 
 
 def test_training_step_at_full_size(monkeypatch):

@@ -126,6 +126,34 @@ def test_fused_solve_matches_the_torch_composition_in_value_and_gradient(golden_
         assert_rel(x, y, tol, name)
 
 
+def test_fused_solve_breakdown_returns_zero_pose_update_like_the_reference(golden_dir, monkeypatch):
+    """devo/ba.py:16-20: when the Cholesky factorisation breaks down (here: a large negative damping) CholeskySolver returns
+    zeros and passes no gradient; the depth update dZ = Q (u - E^T 0) still happens.  The fused HIP step must do the same — its
+    workspace is not zero-initialised, so the solver itself has to write the zero update — in value and in gradient."""
+    from devo_amd.ba import BA
+    from devo_amd.lietorch import SE3
+    g = _load(golden_dir, torch.float32)
+
+    def run(torch_path):
+        monkeypatch.setenv("DEVO_BA_TORCH", "1" if torch_path else "0")
+        tgt = g["target"].clone().requires_grad_(True)
+        wgt = g["weight"].clone().requires_grad_(True)
+        pat = g["patches"].clone().requires_grad_(True)
+        if not torch_path:                                            # poison the caching allocator's free blocks: a fresh workspace is then garbage
+            junk = [torch.full((1 << 18,), float("nan"), device=DEV) for _ in range(8)]
+            del junk
+        G, P = BA(SE3(g["poses"].clone()), pat, g["intrinsics"], tgt, wgt, 1e-4, g["ii"], g["jj"], g["kk"], g["bounds"].tolist(), ep=-1.0e9, fixedp=1)
+        (P[:, :, 2] ** 2).sum().backward()
+        return G.data.detach(), P.detach(), tgt.grad, wgt.grad, pat.grad
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], g["poses"]) and torch.equal(b[0], g["poses"])          # no pose moved
+    assert bool(torch.isfinite(a[1]).all()) and float((a[1] - g["patches"]).abs().max()) > 0     # the depths did
+    for x, y, name in zip(a[1:], b[1:], ("patches", "d/d target", "d/d weight", "d/d patches")):
+        assert bool(torch.isfinite(x).all()), name
+        assert_rel(x, y, 2e-3, name)
+
+
 @pytest.mark.parametrize("mode", ["coords", "depth", "tonly", "jacobian"])
 def test_fused_transform_adjoint_matches_the_autograd_composition(golden_dir, mode, monkeypatch):
     """projective_ops.transform with gradients: ONE forward kernel + ONE adjoint kernel (devo_transform_vjp, the same

@@ -79,6 +79,28 @@ def test_update_full_width_fp32_fp16_and_torch_path():
     assert_rel(w3.float(), ref[2], 2e-2, "fp16 weight")
 
 
+def test_update_under_autocast_with_gradients_enabled():
+    """devo.py:311 runs the update operator under torch.autocast; with fp32 parameters that require grad (any caller that does not
+    wrap inference in no_grad, or mixed-precision fine-tuning) the module takes its autograd path: LayerNorm outputs stay fp32 while
+    the Linear outputs are fp16.  The custom Functions must cope with the mix — values near the fp32 result, finite gradients in the
+    parameters' dtype."""
+    m, sd, net, inp, corr, ii, jj, kk = _random_case()
+    ref = U.update(sd, net.double(), inp.double(), corr.double(), ii, jj, kk)
+    m = m.to(DEV).train()
+    args = (net.to(DEV).requires_grad_(True), inp.to(DEV), corr.to(DEV), None, ii.to(DEV), jj.to(DEV), kk.to(DEV))
+    with torch.autocast("cuda", dtype=torch.float16):
+        n, (d, w, _) = m(*args)
+        loss = d.float().sum() + w.float().sum() + n.float().pow(2).mean()
+    loss.backward()
+    assert_rel(n.float(), ref[0], 3e-2, "autocast net")
+    assert_rel(w.float(), ref[2], 3e-2, "autocast weight")
+    assert args[0].grad.dtype == torch.float32 and bool(torch.isfinite(args[0].grad).all()) and float(args[0].grad.abs().max()) > 0
+    for name, p in m.named_parameters():
+        if p.grad is not None:
+            assert p.grad.dtype == p.dtype and bool(torch.isfinite(p.grad).all()), name
+    assert sum(p.grad is not None for p in m.parameters()) > 10
+
+
 def test_update_graph_tables_follow_a_changing_graph():
     """DEVO rebuilds ii / jj / kk with torch.cat every frame (devo.py:392-399): fresh tensors of often the same size, whose
     storage the caching allocator may hand back at the SAME address.  The cached neighbour / group tables must follow the

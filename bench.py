@@ -532,17 +532,26 @@ def cpu_baseline(cfg, cpu, E):
             ba2()
             ts.append(time.perf_counter() - t0)
         t_ba = sorted(ts)[1]
-        ns = E if E <= 32768 else 8192                                            # (in chunks of 512: the gather formulation's temporaries)
+        # lookup leg: a fixed random sample of 8192 edges (all of them below that), THREE timed passes, the median scaled to E — this
+        # leg swung 0.6 ... 2.5 s between boxes as a single pass (gather temporaries of the torch formulation: allocator and page-fault
+        # noise), which moved `value` by 7x while the BA leg stayed within 10 %
+        ns = min(E, 8192)                                                         # (in chunks of 512: the gather formulation's temporaries)
         sel = torch.randperm(E, generator=torch.Generator().manual_seed(0))[:ns]
         c2 = coords.permute(0, 1, 4, 2, 3).contiguous()[:, sel]
         f1l = synth.pyramid_l1(cpu["fmap"])
-        oc.corr_forward(cpu["gmap"], cpu["fmap"], c2[:, :64], kk[sel[:64]], jj[sel[:64]], R, acc=torch.float32)     # warm-up
-        t0 = time.perf_counter()
-        for c0 in range(0, ns, 512):
-            s_ = sel[c0:c0 + 512]
-            oc.corr_forward(cpu["gmap"], cpu["fmap"], c2[:, c0:c0 + 512], kk[s_], jj[s_], R, acc=torch.float32)
-            oc.corr_forward(cpu["gmap"], f1l, c2[:, c0:c0 + 512] / 4, kk[s_], jj[s_], R, acc=torch.float32)
-        t_corr = (time.perf_counter() - t0) * (E / ns)
+
+        def lookup_pass():
+            for c0 in range(0, ns, 512):
+                s_ = sel[c0:c0 + 512]
+                oc.corr_forward(cpu["gmap"], cpu["fmap"], c2[:, c0:c0 + 512], kk[s_], jj[s_], R, acc=torch.float32)
+                oc.corr_forward(cpu["gmap"], f1l, c2[:, c0:c0 + 512] / 4, kk[s_], jj[s_], R, acc=torch.float32)
+        lookup_pass()                                                             # warm-up (allocator, page faults)
+        tc = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            lookup_pass()
+            tc.append((time.perf_counter() - t0) * (E / ns))
+        t_corr = sorted(tc)[1]
         # SURVEY 8d also asks for the single-thread figure of the BA
         torch.set_num_threads(1)
         t0 = time.perf_counter()
@@ -558,9 +567,12 @@ def cpu_baseline(cfg, cpu, E):
     step_s = t_tr + t_corr + t_ba
     return {"value": round(1.0 / step_s, 4), "unit": "it/s", "cores": threads, "kind": "port", "cpu_model": model,
             "host_cores": os.cpu_count(), "ba_ms_1thread": round(t_ba1 * 1e3, 2),
-            "sample": f"torch-CPU fp32, {threads} threads: transform (full, {E} edges) + 2x ba.py-style BA (full, median of 3) + "
-                      f"2-level lookup on {ns} of {E} edges" + (", scaled" if ns < E else ""),
-            "ba_ms": round(t_ba * 1e3, 2), "corr_ms_scaled": round(t_corr * 1e3, 1), "transform_ms": round(t_tr * 1e3, 2)}
+            "sample": f"torch-CPU fp32, torch.set_num_threads({threads}): transform (full, {E} edges) + 2x ba.py-style BA (full, median of 3) + "
+                      f"2-level lookup on {ns} of {E} edges (median of 3 passes" + (", scaled to E)" if ns < E else ")"),
+            "ba_ms": round(t_ba * 1e3, 2), "ba_ms_samples": [round(t * 1e3, 2) for t in ts], "corr_ms_scaled": round(t_corr * 1e3, 1),
+            "corr_ms_samples": [round(t * 1e3, 1) for t in tc], "transform_ms": round(t_tr * 1e3, 2),
+            "headline": "ba.speedup (the ba.py-style solve on the host cores against cuda_ba on the GPU: north_star's >= 10x figure); `value` adds the "
+                        "lookup leg, for which the reference has no CPU implementation at all (a torch gather formulation stands in)"}
 
 
 if __name__ == "__main__":

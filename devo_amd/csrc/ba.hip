@@ -1170,14 +1170,25 @@ __device__ __forceinline__ bool chol6(float L[6][6], float inv[6]) {   // in-reg
   return ok;
 }
 
-__device__ unsigned long long g_solve_stamps[8];
+// Row stride of the solver's LDS image (floats): even (8-byte operand pairs), >= n6 + 1 (the right-hand side is an extra row, the
+// last column is spare), and = 36 (mod 64) where the LDS allows it: the matrix-core trailing update then reads its operands (16 rows x 4
+// columns per instruction) and its 16 x 16 result tiles (4 rows x 16 columns per instruction) without a bank conflict.
+__host__ __device__ inline int solve_ld(int n6) {
+  for (int ld = 36; ld <= 164; ld += 64)
+    if (ld >= n6 + 1) return ld;
+  return n6 + 2;
+}
+
+__device__ unsigned long long g_solve_stamps[16];
 // debug (DEVO_BA_TRACE): cycle stamps of the last solve
 
 __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restrict__ S, const float* __restrict__ y, int N,
                                                             float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps) {
   extern __shared__ __attribute__((aligned(16))) float A[];
   __shared__ int s_fail;
-  const int n6 = 6 * N, LD = n6 + 1, rows = n6 + 1;
+  // LDS image: rows x LD with an EVEN row stride (the global image k_ba_reduce wrote has n6 + 1): panel columns start at even
+  // offsets (j0 = 6 jb), so the trailing update reads its operands as 8-byte pairs
+  const int n6 = 6 * N, LDG = n6 + 1, LD = solve_ld(n6), rows = n6 + 1;
   float* Ld = A + rows * LD;                    // [N][36] factored diagonal blocks (diagonal stored as reciprocal)
   float* Li = Ld + N * 36;                      // [N][36] their inverses (for the back-substitution)
   float* xs = Li + N * 36;                      // [n6] solution
@@ -1186,13 +1197,18 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   if (tid == 0) s_fail = 0;
   {
     // k_ba_reduce wrote this very image (rows x LD, the right-hand side is row n6); eight loads in flight per thread
-    const int total = rows * LD - 1;
+    const int total = rows * LDG - 1;
+    const float inv_ldg = 1.0f / (float)LDG;
     for (int i0 = tid; i0 < total; i0 += SOLVE_THREADS * 8) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) { const int i = i0 + SOLVE_THREADS * u; v[u] = (i < total) ? S[i] : 0.0f; }
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int i = i0 + SOLVE_THREADS * u; if (i < total) A[i] = v[u]; }
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + SOLVE_THREADS * u;
+        const int r = (int)(((float)i + 0.5f) * inv_ldg);         // exact: i < 2^16, margin 0.5 / LDG
+        if (i < total) A[r * LD + (i - r * LDG)] = v[u];
+      }
     }
   }
   // This thread's 2x2 tile (ty >= tx) of the trailing lower triangle, relative to the trailing corner — the same for
@@ -1212,14 +1228,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   }
 
   const unsigned long long st1 = stamps ? __builtin_readcyclecounter() : 0ull;
-  unsigned long long ph_panel = 0, ph_update = 0;
+  unsigned long long ph_panel = 0, ph_update = 0, ph_q1 = 0, ph_q2 = 0;
 #if DEVO_SOLVE_LOOKAHEAD
   // Look-ahead: the 6x6 diagonal block of step jb + 1 is brought up to date and factored by ONE wave (the last) while the other
   // waves run the trailing update of step jb — the serial rsq chain of the block factorisation leaves the panel phase.  The
   // tiles of that block (t < 6) are nobody else's; its updated values only ever feed the factorisation, so they are not written
   // back.  Same operations in the same order as the plain form: bit-identical factors.
   __shared__ float s_dblk[36];
+  __shared__ float s_dump[64];
   constexpr int LA_WAVE = SOLVE_THREADS / 64 - 1;
+  typedef float tl_f4 __attribute__((ext_vector_type(4)));
+  const int tl_wv = tid >> 6, tl_mm = tid & 15, tl_kq = (tid & 63) >> 4;      // trailing update: this wave's 16 x 16 tile, this lane's operand row / k
+  int tl_I = 0;
+  while ((tl_I + 1) * (tl_I + 2) / 2 <= tl_wv) tl_I++;
+  const int tl_J = tl_wv - tl_I * (tl_I + 1) / 2;
   auto factor_block = [&](int jb1) {                // all lanes of the calling wave; s_dblk holds the block's lower triangle
     float L[6][6];
 #pragma unroll
@@ -1267,7 +1289,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     __syncthreads();
     const unsigned long long pb = stamps ? __builtin_readcyclecounter() : 0ull;
     const bool next = jb + 1 < N;
-    if (next && (tid >> 6) == LA_WAVE) {
+    if (next && (tid >> 6) == LA_WAVE && stamps != 3 && stamps != 4) {                // (stamps == 3: timing experiment without the look-ahead factorisation)
       const int l = tid & 63, a = l / 6, c = l % 6, j1 = j0 + 6;
       if (l < 36 && c <= a) {
         float acc = 0.0f;
@@ -1278,38 +1300,43 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
       wave_lds_sync();
       factor_block(jb + 1);
     }
-    // trailing update of the lower triangle (and of the rhs row) in 2x2 tiles; inputs = the panel columns, outputs =
-    // the columns to their right (disjoint), so everything is fetched before anything is written back
-    const int rem = rows - (j0 + 6);
-    const int nt = (rem + 1) / 2;                // tiles per side
-    const int ntiles = nt * (nt + 1) / 2;
-    for (int k = 0; tid + SOLVE_THREADS * k < ntiles; k++) {
-      const int t = tid + SOLVE_THREADS * k;
-      if (next && t < 6) continue;               // the next diagonal block: the look-ahead wave's
-      int yy, xx;
-      if (k == 0) { yy = ty; xx = tx; }
-      else tile_of(t, yy, xx);                   // large N only: more tiles than threads
-      const int r0 = j0 + 6 + 2 * yy, c0 = j0 + 6 + 2 * xx;
-      const bool r1ok = r0 + 1 < rows, c1ok = c0 + 1 < n6;          // second row / column inside the matrix
-      const int r1 = r1ok ? r0 + 1 : r0, c1 = c1ok ? c0 + 1 : c0;
-      if (c0 >= n6) continue;                    // the rhs row has no diagonal entry
-      float pa0[6], pa1[6], pb0[6], pb1[6];
+    // Trailing update  A[r][c] -= sum_q L[r][j0 + q] L[c][j0 + q]  (r >= c >= j0 + 6; the rhs row included) on the matrix cores:
+    // 16 x 16 tiles of the trailing lower triangle, one per wave (waves 0 .. 14; wave 15 is the look-ahead), each
+    // D = A x B + C with v_mfma_f32_16x16x4_f32 twice (k = 0..3, 4..7; columns 6, 7 are zero) — exact fp32 products and sums in a fixed
+    // order.  Per lane 4 operand values and 4 result values come out of LDS (the 2 x 2 register tiles of round 2 read 28 values for 4
+    // results), all conflict-free with the row stride of solve_ld().  Inputs = the panel columns, outputs = the columns to their
+    // right: disjoint.  The 6 x 6 block the look-ahead wave factors meanwhile is not written back (nobody reads it again).
+    if ((tid >> 6) != LA_WAVE && stamps != 2 && stamps != 4) {
+      const int base = j0 + 6, T = (rows - base + 15) >> 4, ntl = T * (T + 1) / 2;
+      for (int t = tl_wv; t < ntl; t += LA_WAVE) {
+        int I = tl_I, J = tl_J;                                    // the wave's first tile: the same (I, J) in every step
+        if (t != tl_wv) { I = 0; while ((I + 1) * (I + 2) / 2 <= t) I++; J = t - I * (I + 1) / 2; }      // (more than 14 poses only)
+        const unsigned long long q0 = (stamps && tid == 0) ? __builtin_readcyclecounter() : 0ull;
+        const int rb = base + 16 * I, cb = base + 16 * J;
+        const float* pr = A + __mul24(min(rb + tl_mm, rows - 1), LD) + j0;      // operand rows (clamped: their products only reach masked results)
+        const float* pc_ = A + __mul24(min(cb + tl_mm, rows - 1), LD) + j0;
+        const float a1 = pr[tl_kq], a2r = pr[4 + (tl_kq & 1)], b1 = -pc_[tl_kq], b2r = -pc_[4 + (tl_kq & 1)];
+        const float a2 = (tl_kq < 2) ? a2r : 0.0f, b2 = (tl_kq < 2) ? b2r : 0.0f;
+        const int cc = cb + tl_mm, r0 = rb + 4 * tl_kq;
+        // results: every lane reads and writes 4 entries UNCONDITIONALLY (entries outside the lower triangle / the matrix / the
+        // look-ahead block go to a dump word; a conditional LDS access costs hipcc a branch and a full wait each)
+        tl_f4 c;
+        float* dst[4];
+        float* p0 = A + __mul24(r0, LD) + cc;
 #pragma unroll
-      for (int q = 0; q < 6; q++) {
-        pa0[q] = A[r0 * LD + j0 + q]; pa1[q] = A[r1 * LD + j0 + q];
-        pb0[q] = A[c0 * LD + j0 + q]; pb1[q] = A[c1 * LD + j0 + q];
-      }
-      float o00 = A[r0 * LD + c0], o01 = A[r0 * LD + c1], o10 = A[r1 * LD + c0], o11 = A[r1 * LD + c1];
-      float v00 = 0.0f, v01 = 0.0f, v10 = 0.0f, v11 = 0.0f;
+        for (int i = 0; i < 4; i++) {
+          const int r = r0 + i;
+          const bool ok = r < rows && cc < n6 && cc <= r && !(next && r < base + 6);
+          dst[i] = ok ? p0 + i * LD : s_dump + (tid & 63);
+          c[i] = *dst[i];
+        }
+        const unsigned long long q1 = (stamps && tid == 0) ? __builtin_readcyclecounter() : 0ull;
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, c, 0, 0, 0);
 #pragma unroll
-      for (int q = 0; q < 6; q++) {
-        v00 += pa0[q] * pb0[q]; v01 += pa0[q] * pb1[q];
-        v10 += pa1[q] * pb0[q]; v11 += pa1[q] * pb1[q];
+        for (int i = 0; i < 4; i++) *dst[i] = c[i];
+        if (stamps && tid == 0) { const unsigned long long q2 = __builtin_readcyclecounter(); ph_q1 += q1 - q0; ph_q2 += q2 - q1; }
       }
-      A[r0 * LD + c0] = o00 - v00;                                   // c0 <= r0 always (xx <= yy)
-      if (c1ok && c1 <= r0) A[r0 * LD + c1] = o01 - v01;             // above the diagonal on diagonal tiles: skip
-      if (r1ok) A[r1 * LD + c0] = o10 - v10;
-      if (r1ok && c1ok) A[r1 * LD + c1] = o11 - v11;
     }
     __syncthreads();
     if (stamps) { const unsigned long long pc = __builtin_readcyclecounter(); ph_panel += pb - pa; ph_update += pc - pb; }
@@ -1502,7 +1529,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
     }
   }
   for (int i = tid; i < n6; i += 64) dX[i] = xs[i];
-  if (stamps && tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st3; g_solve_stamps[4] = __builtin_readcyclecounter(); g_solve_stamps[5] = ph_panel; g_solve_stamps[6] = ph_update; }
+  if (stamps && tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st3; g_solve_stamps[4] = __builtin_readcyclecounter(); g_solve_stamps[5] = ph_panel; g_solve_stamps[6] = ph_update; g_solve_stamps[8] = ph_q1; g_solve_stamps[9] = ph_q2; }
 }
 
 // ------------------------------------------------------------------------------------------------- retract
@@ -2209,7 +2236,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   const size_t n6 = 6 * (size_t)N;
   const float ep = 1.0f;                                          // ba_cuda.cu:518
   const size_t acc_lds = sizeof(float) * (n6 * (n6 + 1) + n6 + ACC_WAVES * n6 + 4);
-  const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 72 * (size_t)N + n6 + 4);
+  const size_t solve_lds = sizeof(float) * ((n6 + 1) * (size_t)solve_ld((int)n6) + 72 * (size_t)N + n6 + 4);
   static const bool force_generic = getenv("DEVO_BA_GENERIC") != nullptr;   // test switch: the general accumulate kernel for every N
   const bool use_reg = (N <= 16) && !force_generic;
   const AccCfg cfg = acc_cfg(N);
@@ -2235,12 +2262,13 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       if (defer) ba_deferred_schur(st, patch_rec, edge_ej, meta, N, L.max_seg, S, ep, partials, sizeof(float) * (size_t)L.n_part * (n6 * (n6 + 1) + n6 + 1));
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       static const bool ba_trace = getenv("DEVO_BA_TRACE") != nullptr;
-      hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace ? 1 : 0);
+      static const int ba_trace_mode = ba_trace ? (atoi(getenv("DEVO_BA_TRACE")) > 1 ? atoi(getenv("DEVO_BA_TRACE")) : 1) : 0;
+      hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace_mode);
       if (ba_trace) {
-        unsigned long long h[8];
+        unsigned long long h[16];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_solve_stamps), sizeof(h));
-        fprintf(stderr, "[ba trace] solve: load %llu, factorisation %llu, block inverses %llu, back substitution %llu cycles (factorisation: panel %llu + update %llu)\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5], h[6]);
+        fprintf(stderr, "[ba trace] solve: load %llu, factorisation %llu, block inverses %llu, back substitution %llu cycles (factorisation: panel %llu + update %llu; wave 0's tile: operands + results in %llu, products + stores %llu)\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5], h[6], h[8], h[9]);
       }
       if ((rc = check_launch("devo_ba_forward(solve)"))) return rc;
     }
@@ -2280,7 +2308,7 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
   float* patch_rec = (float*)(w + L.patch_rec);
   float* patch_col = (float*)(w + L.edge_ej);
   const size_t acc_lds = sizeof(float) * (n6 * (n6 + 1) + n6 + ACC_WAVES * n6 + 4);
-  const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 72 * (size_t)N + n6 + 4);
+  const size_t solve_lds = sizeof(float) * ((n6 + 1) * (size_t)solve_ld((int)n6) + 72 * (size_t)N + n6 + 4);
   const bool use_reg = N <= 16;
   const AccCfg cfg = acc_cfg(N);
   const size_t acc_lds_used = use_reg ? acc_reg_lds_bytes(N, cfg) : acc_lds;
@@ -2335,7 +2363,7 @@ int devo_ba_solve_terms_backward(const float* terms, const int64_t* ii, const in
     float* rhs = S + n6 * (n6 + 1);                            // the solver image's right-hand-side row
     if (hipMemcpyAsync(rhs, g_dX, sizeof(float) * n6, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("devo_ba_solve_terms_backward: copy failed"); return DEVO_ERR_LAUNCH; }
     hipLaunchKernelGGL(k_bt_rhs, dim3(64), dim3(256), 0, st, rhs, g_dZ, patch_rec, patch_col, kx, meta, N);
-    const size_t solve_lds = sizeof(float) * ((n6 + 1) * (n6 + 1) + 72 * (size_t)N + n6 + 4);
+    const size_t solve_lds = sizeof(float) * ((n6 + 1) * (size_t)solve_ld((int)n6) + 72 * (size_t)N + n6 + 4);
     hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, (float*)(w + L.y), N, ybar, meta, 0, (int*)nullptr, 0);
     if ((rc = check_launch("devo_ba_solve_terms_backward(solve)"))) return rc;
   }

@@ -1068,6 +1068,12 @@ static int launch_region(const void* fmap1, const void* fmap1_t, const CorrLevel
     unsigned long long h[16];
     (void)hipMemcpy(h, stats, 128, hipMemcpyDeviceToHost);
     const double g = h[9] ? (double)h[9] : 1.0;
+    {
+      unsigned long long q[8];
+      (void)hipMemcpy(q, stats + 400, 64, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[region stats] sub-phases, cycles per workgroup: prologue = loads + geometry %.0f | sort %.0f | rounds %.0f;  epilogue = next stage's request %.0f | tiles to scratch %.0f | blend + store %.0f | barrier %.0f\n",
+              q[0] / g, q[1] / g, q[2] / g, q[3] / g, q[4] / g, q[5] / g, q[6] / g);
+    }
     fprintf(stderr, "[region stats] kernel %.1f us; %llu workgroups (%lld chunks), %.2f rounds and %.1f slab iterations per workgroup; first wave, cycles per workgroup: total %.0f = "
             "prologue %.0f | stage set-up %.0f | first slab wait %.0f | products + DMA issue %.0f | left-over DMA issue %.0f | slab wait + barrier %.0f | epilogue + next stage's request %.0f | tail %.0f\n",
             ms * 1e3, h[9], nchunks, h[8] / g, h[10] / g, h[11] / g, h[0] / g, h[1] / g, h[2] / g, h[3] / g, h[4] / g, h[5] / g, h[6] / g, h[7] / g);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
   // debug (DEVO_RG_STATS=1): cycles of wave 0 per phase, summed over the workgroups: [0] prologue, [1] stage set-up, [2] waiting for a
   // stage's first slab, [3] products (with the next slab's DMA instructions in between), [4] left-over DMA instructions, [5] waiting for the
   // slab + barrier, [6] epilogue, [7] tap-by-tap edges + dead tail, [8] rounds, [9] workgroups, [10] slab iterations, [11] total
-  unsigned long long st_t = STATS ? __builtin_readcyclecounter() : 0ULL, st_acc[STATS ? 8 : 1] = {};
+  unsigned long long st_t = STATS ? __builtin_readcyclecounter() : 0ULL, st_acc[STATS ? 16 : 1] = {};
   const unsigned long long st_begin = st_t;
   auto stamp = [&](int i) { if constexpr (STATS) { const unsigned long long t = __builtin_readcyclecounter(); st_acc[i] += t - st_t; st_t = t; } };
   unsigned st_iters = 0;
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
     if (slow) key = 0xffffffffu;
     s_key[tid] = key;
   }
+  stamp(8);
   if (tid < 2) s_cnt[tid] = 0;
   if (tid < 2) {
     const CorrLevel& lv = tid ? lv1 : lv0;
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
     if (k != 0xffffffffu) atomicAdd(&s_cnt[0], 1);
   }
   __syncthreads();
+  stamp(9);
   const int nround_edges = __builtin_amdgcn_readfirstlane(s_cnt[0]);   // sorted indices [0, nround_edges) go through rounds
   {
     // greedy round from every start s (thread s): edges s .. s_end[s] - 1 and their union region per level
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
     __syncthreads();
   }
   const int nrounds = __builtin_amdgcn_readfirstlane(s_cnt[1]);
-  stamp(0);
+  stamp(10);
 
   const int m = lane & 15, kg = lane >> 4;                      // MFMA operand row / column, k group
   const int ep = lane % PP, ea0 = lane / PP;                    // epilogue: pixel, window row (lane 63 idles)
@@ -554,6 +556,7 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
         if (nxt.NI > 0) issue_slab(nxt, l == 0 ? vBn0 : vB0, l == 0 ? vBn1 : vB1, 0);   // (a new round brings its own patch slabs)
       }
     }
+    stamp(11);
     // ---- epilogue of the level: tiles -> scratch -> blended rows
     float* scr = reinterpret_cast<float*>(rg_lds + (size_t)w * S::SCRW);
 #pragma unroll
@@ -569,6 +572,7 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
           }
           rg_lds_fence();
         }
+        stamp(12);
         int ox, oy; float dx, dy;
         pixel_geo(tk[k], l, ox, oy, dx, dy);
         blend_rows(scr, ep * SP + (oy - by0[k]) * bwk[k] + (ox - bx0[k]), bwk[k], dx, dy, have, o);
@@ -581,9 +585,11 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
           store_rows(s_be[tk[k]], o, res1[k]);
         }
         if (have) rg_lds_fence();
+        stamp(13);
       }
     }
     rg_barrier();                                                // buffer 0 is a DMA target again
+    stamp(14);
     if constexpr (S::XPRE) {
       if (l == 0) { vB0 = vBn0; vB1 = vBn1; }
       cur = nxt;
@@ -647,6 +653,8 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
   if constexpr (STATS) if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < 8; i++) atomicAdd(&stats[i], st_acc[i]);
+#pragma unroll
+    for (int i = 8; i < 16; i++) atomicAdd(&stats[392 + i], st_acc[i]);            // [24..31]: sub-phases (prologue: 8 loads, 9 sort, 10 rounds; epilogue: 11 request, 12 scratch, 13 blend + store, 14 barrier)
     atomicAdd(&stats[8], (unsigned long long)nrounds); atomicAdd(&stats[9], 1ULL); atomicAdd(&stats[10], (unsigned long long)st_iters);
     atomicAdd(&stats[11], __builtin_readcyclecounter() - st_begin);
   }

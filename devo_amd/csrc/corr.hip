@@ -38,11 +38,21 @@ template <typename T> struct AccOf { typedef float type; };
 template <> struct AccOf<double> { typedef double type; };
 
 // output stores bypass the caches' allocation (written once, read by a later kernel)
+// Output stores: plain write-back stores.  Rounds 1-2 streamed them (nontemporal: "keep the L2 for feature rows"); measured in round 3
+// (profiles/r03_store_policy.txt): the streaming form writes every partially covered 32-byte sector on its own — 95.9 MB per cfg2 launch for
+// 76.2 MB of output — while write-back stores merge an edge's consecutive 216-byte rounds in the L2: 75.2 MB, and the lookup is 3 % faster.
+// DEVO_CORR_NT_STORES (A/B builds, tools/build_variant.sh) brings the streaming form back.
+#ifdef DEVO_CORR_NT_STORES
 __device__ __forceinline__ void store_streamed(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void store_streamed(double* p, double v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void store_streamed(__half* p, __half v) {
   __builtin_nontemporal_store(__half_as_ushort(v), reinterpret_cast<unsigned short*>(p));
 }
+#else
+__device__ __forceinline__ void store_streamed(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_streamed(double* p, double v) { *p = v; }
+__device__ __forceinline__ void store_streamed(__half* p, __half v) { *p = v; }
+#endif
 
 __device__ __forceinline__ int floor_to_int(float v) { return corr_floor_to_int(v); }
 

@@ -314,11 +314,11 @@ __global__ __launch_bounds__(S::THREADS, S::WPS) void corr_fwd_region_kernel(
             if (paired) {
               if constexpr (HALF) {
                 const unsigned short u0 = __half_as_ushort(__float2half(o0[ps][cx])), u1 = __half_as_ushort(__float2half(o1[ps][cx]));
-                __builtin_nontemporal_store((unsigned)u0 | ((unsigned)u1 << 16), reinterpret_cast<unsigned*>(op + (size_t)(el * 2u + o0_32)));
+                *reinterpret_cast<unsigned*>(op + (size_t)(el * 2u + o0_32)) = (unsigned)u0 | ((unsigned)u1 << 16);
               } else {
                 typedef float f2v __attribute__((ext_vector_type(2)));
                 const f2v v = {o0[ps][cx], o1[ps][cx]};
-                __builtin_nontemporal_store(v, reinterpret_cast<f2v*>(op + (size_t)(el * 2u + o0_32)));
+                *reinterpret_cast<f2v*>(op + (size_t)(el * 2u + o0_32)) = v;
               }
             } else {
               store_streamed(op + (size_t)(el * ols32 + o0_32), from_f32<T>(o0[ps][cx]));

@@ -1532,6 +1532,319 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   if (stamps && tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st3; g_solve_stamps[4] = __builtin_readcyclecounter(); g_solve_stamps[5] = ph_panel; g_solve_stamps[6] = ph_update; g_solve_stamps[8] = ph_q1; g_solve_stamps[9] = ph_q2; }
 }
 
+
+// ------------------------------------------------------------------------------------------------- solve, one barrier per block step
+// The factorisation above spends two workgroup barriers per block step and its look-ahead wave waits for the panel.  This form
+// (6 N <= 128) has ONE barrier per step and no panel phase at all:
+//   * the CHAIN wave (wave 15, raised priority, alone on its SIMD) prepares block jb + 1 while the others
+//     update: lane (a, c) solves rows a and c of the six rows below the current block against L_bb (a packed pair: one substitution),
+//     D_{jb+1}[a][c] = A - x_a . x_c, the 21 values travel through v_readlane, the 6 x 6 Cholesky runs redundantly in every lane,
+//     lane 0 writes the factor;
+//   * the twelve TILE waves (waves 0-2, 4-6, 8-10, 12-14: the wave id modulo 4 picks the SIMD) solve the operand rows of their 16 x 16
+//     tile against L_bb themselves (both rows as a packed pair — the same arithmetic in the same order as the panel phase above) and
+//     feed them to the matrix cores; the panel X = L[r][block] is never written over its source (the chain wave reads the raw rows
+//     concurrently) but TRANSPOSED into the upper triangle (A[j0 + k][r]), where the back-substitution reads it with unit stride;
+//   * tile wave 11 (wave 14; its tile only exists in the first steps) also inverts L_bb for the back-substitution; waves 3, 7 and 11
+//     only hold the barrier: the chain wave has its SIMD to itself.
+// The kernel is bound by VALU issue (a wave64 instruction takes the SIMD for 4 cycles; four tile waves per SIMD), not by LDS or the
+// matrix cores: which tile entries a lane may write is a per-lane step count computed once (jb < thr[i]), the look-ahead rows and the
+// triangle are folded into it.
+// Same operations in the same order as k_ba_solve: bit-identical solutions (tests/test_gpu_fastba.py checks that).
+typedef float solve_f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(1024) void k_ba_solve_chain(const float* __restrict__ S, const float* __restrict__ y, int N,
+                                                         float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps) {
+  extern __shared__ __attribute__((aligned(16))) float A[];
+  __shared__ int s_fail;
+  __shared__ float s_dump[64];
+  const int n6 = 6 * N, LDG = n6 + 1, LD = solve_ld(n6), rows = n6 + 1;
+  float* Ld = A + rows * LD;                    // [N][36] factored diagonal blocks (diagonal stored as reciprocal)
+  float* Li = Ld + N * 36;                      // [N][36] their inverses (for the back-substitution)
+  float* xs = Li + N * 36;                      // [n6] solution
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  constexpr int CHAIN = 15, INVW = 14, NTW = 12;                 // the chain wave, the wave that also inverts L_bb (its tile (4, 1) only exists in the first steps), the number of tile waves
+  const bool tile_wave = (wv & 3) != 3;
+  const int tw = wv - (wv >> 2);                                 // tile waves numbered 0 .. 11
+  if (wv == CHAIN) __builtin_amdgcn_s_setprio(3);
+  const unsigned long long st0 = stamps ? __builtin_readcyclecounter() : 0ull;
+  if (tid == 0) s_fail = 0;
+  const int failed_before = meta->fail;           // (in flight with the matrix: a load after the barrier would add its whole latency)
+  {
+    const int total = rows * LDG - 1;
+    const float inv_ldg = 1.0f / (float)LDG;
+    for (int i0 = tid; i0 < total; i0 += 1024 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + 1024 * u; v[u] = (i < total) ? S[i] : 0.0f; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + 1024 * u;
+        const int r = (int)(((float)i + 0.5f) * inv_ldg);         // exact: i < 2^16, margin 0.5 / LDG
+        if (i < total) A[r * LD + (i - r * LDG)] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  if (failed_before) {                           // an earlier iteration broke down: the reference call has thrown by now
+    if (tid == 0 && failed_before < 0 && status_flag) *status_flag = -1;          // (or the workspace was never prepared)
+    return;
+  }
+  const unsigned long long st1 = stamps ? __builtin_readcyclecounter() : 0ull;
+  unsigned long long ph_work = 0;
+  auto lane_value = [](float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); };
+  auto load_factor = [&](int jb, float Lb[6][6], float inv[6]) {        // broadcast reads
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+      for (int c = 0; c < a; c++) Lb[a][c] = Ld[jb * 36 + a * 6 + c];
+      inv[a] = Ld[jb * 36 + a * 7];
+    }
+  };
+  // x L_bb^T = v for two rows at once (.x / .y): v_pk_fma_f32 / v_pk_mul_f32, each half rounded like the scalar form
+  auto solve_rows = [](const float* pa, const float* pc, const float Lb[6][6], const float inv[6], solve_f2 x[6]) {
+    solve_f2 v[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) v[q] = solve_f2{pa[q], pc[q]};
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      solve_f2 t = v[c];
+#pragma unroll
+      for (int k = 0; k < c; k++) t -= x[k] * Lb[c][k];
+      x[c] = t * inv[c];
+    }
+  };
+  auto factor_and_store = [&](float L[6][6], int jb1) {            // every lane holds the same block
+    float inv[6];
+    const bool ok = chol6(L, inv);
+    if (ln == 0) {
+      if (!ok) s_fail = 1;
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int c = 0; c <= a; c++) Ld[jb1 * 36 + a * 6 + c] = (a == c) ? inv[a] : L[a][c];
+    }
+  };
+  typedef float tl_f4 __attribute__((ext_vector_type(4)));
+  const int tl_mm = ln & 15, tl_kq = ln >> 4;                   // trailing update: this lane's operand row / k group
+  // A tile (I, J) of the trailing lower triangle, in coordinates relative to its corner j1 = 6 (jb + 1): what a lane reads and writes
+  // moves by (6, 6) per step, and WHETHER it may write entry i is "jb < thr[i]": inside the matrix (row < rows - j1, column < rows - 1 -
+  // j1), on or below the diagonal, not one of the six rows the chain wave is factoring (nobody reads those again).
+  struct Tile { int thr[4], thr_t, rel_mine, rel_a, idx0, keep; };
+  auto steps_while = [](int X) { return (X + 5) / 6 - 1; };       // jb < steps_while(X)  <=>  6 (jb + 1) < X
+  auto make_tile = [&](int t) {
+    int I = 0;
+    while ((I + 1) * (I + 2) / 2 <= t) I++;
+    const int J = t - I * (I + 1) / 2;
+    Tile tl;
+    const int rrel0 = 16 * I + 4 * tl_kq, crel = 16 * J + tl_mm;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = rrel0 + i;
+      tl.thr[i] = (crel <= r && r >= 6) ? min(steps_while(rows - r), steps_while(rows - 1 - crel)) : -1;
+    }
+    tl.rel_a = 16 * I + tl_mm;
+    tl.rel_mine = (tl_kq < 2) ? tl.rel_a : crel;                  // lanes 0-31 solve the tile's operand rows, lanes 32-63 its operand columns' rows
+    tl.keep = J == 0;
+    tl.thr_t = (J == 0) ? steps_while(rows - tl.rel_a) : -1;
+    tl.idx0 = (6 + rrel0) * LD + 6 + crel;
+    return tl;
+  };
+  // One 16 x 16 tile of one step.  The substitution runs ONCE per wave: lanes 0-31 (k groups 0, 1) hold operand row a = rb + mm, lanes
+  // 32-63 row c = cb + mm; the matrix-core operands of lane (mm, kq) are X[a][kq], X[a][4 + kq] (kq < 2) and -X[c][kq], -X[c][4 + kq]:
+  // half of them are its own, the other half its partner's (lane ^ 32, the same mm, kq ^ 2), swapped with v_permlane32_swap.
+  // the value lane ^ 32 holds: v_permlane32_swap (VALU; a ds_bpermute waits ~200 cycles in the LDS queue while the tiles run)
+  auto from_partner = [&](float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(ln < 32 ? r[1] : r[0]);
+  };
+  auto do_tile = [&](const Tile& tl, int jb, const float Lb[6][6], const float inv[6]) {
+    const int j0 = 6 * jb, j1 = j0 + 6;
+    const float* pr = A + __mul24(min(j1 + tl.rel_mine, rows - 1), LD) + j0;      // (clamped: the products of such rows only reach masked results)
+    float v[6], x[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) v[q] = pr[q];
+    tl_f4 c;
+    float* dst[4];
+    float* p0 = A + tl.idx0 + jb * (6 * LD + 6);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      dst[i] = (jb < tl.thr[i]) ? p0 + i * LD : s_dump + ln;
+      c[i] = *dst[i];
+    }
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) {
+      float t = v[cc];
+#pragma unroll
+      for (int k = 0; k < cc; k++) t -= x[k] * Lb[cc][k];
+      x[cc] = t * inv[cc];
+    }
+    const bool odd = tl_kq & 1, hi = tl_kq & 2;
+    const float u = odd ? x[1] : x[0], w = odd ? x[3] : x[2];
+    const float mine = hi ? w : u, theirs = hi ? u : w;            // x[kq], and x[kq ^ 2]: what the partner needs of this lane's row
+    const float s2 = odd ? x[5] : x[4];                           // x[4 + (kq & 1)]: the same index on both sides
+    const float got1 = from_partner(theirs), got2 = from_partner(s2);
+    const float a1 = hi ? got1 : mine, b1 = hi ? mine : got1;
+    const float a2 = hi ? 0.0f : s2, b2 = hi ? 0.0f : got2;
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, -b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, -b2, c, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) *dst[i] = c[i];
+    if (tl.keep) {                                                 // the panel itself, transposed: X[r][k] -> A[j0 + k][r]  (column-0 tiles cover every row once)
+      const bool ok = jb < tl.thr_t;
+      float* t1 = ok ? A + __mul24(j0 + tl_kq, LD) + j1 + tl.rel_a : s_dump + ln;
+      float* t2 = (ok && !hi) ? A + __mul24(j0 + 4 + tl_kq, LD) + j1 + tl.rel_a : s_dump + ln;
+      *t1 = a1;
+      *t2 = a2;
+    }
+  };
+  const Tile my_tile = make_tile(tile_wave ? tw : 0);
+  if (wv == CHAIN) {                                            // block 0 as it was loaded
+    float L[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c <= a; c++) L[a][c] = A[a * LD + c];
+    factor_and_store(L, 0);
+  }
+  __syncthreads();
+  // every role runs its own loop (a taken branch costs ~30 cycles: no role dispatch inside the steps); N barriers each
+  auto step_barrier = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  if (wv == CHAIN) {
+    const int la = ln < 36 ? ln / 6 : 5, lc = ln < 36 ? ln % 6 : 5;
+    for (int jb = 0; jb < N; jb++) {
+      const unsigned long long pa = stamps == 1 ? __builtin_readcyclecounter() : 0ull;
+      if (jb + 1 < N && stamps != 3) {                              // (DEVO_BA_TRACE=3 / 2: timing experiments without the chain / the tiles)
+        const int j0 = 6 * jb, j1 = j0 + 6;
+        const float* pr = A + (j1 + la) * LD + j0;
+        const float* pc = A + (j1 + lc) * LD + j0;
+        const float dv = pr[6 + lc];
+        float Lb[6][6], inv[6];
+        solve_f2 x[6];
+        load_factor(jb, Lb, inv);
+        solve_rows(pr, pc, Lb, inv, x);
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc += x[q].x * x[q].y;
+        const float d = dv - acc;
+        float L[6][6];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int c = 0; c <= a; c++) L[a][c] = lane_value(d, a * 6 + c);
+        factor_and_store(L, jb + 1);
+      }
+      if (stamps == 1) ph_work += __builtin_readcyclecounter() - pa;
+      step_barrier();
+    }
+  } else if (tile_wave) {
+    for (int jb = 0; jb < N; jb++) {
+      const unsigned long long pa = stamps == 1 ? __builtin_readcyclecounter() : 0ull;
+      const int T = (rows - 6 * jb - 6 + 15) >> 4, ntl = T * (T + 1) / 2;
+      if ((tw < ntl || wv == INVW) && stamps != 2) {
+        float Lb[6][6], inv[6];
+        load_factor(jb, Lb, inv);
+        if (tw < ntl) do_tile(my_tile, jb, Lb, inv);
+        for (int t = tw + NTW; t < ntl; t += NTW) do_tile(make_tile(t), jb, Lb, inv);      // (more than 12 tiles: the first steps of 13+ poses)
+        if (wv == INVW) {                                           // the inverse of L_bb, for the back-substitution
+          float X[6][6];
+#pragma unroll
+          for (int c = 0; c < 6; c++) {                             // column c of L^-1 by forward substitution
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+              if (a < c) { X[a][c] = 0.0f; continue; }
+              float v = (a == c) ? 1.0f : 0.0f;
+#pragma unroll
+              for (int k = 0; k < a; k++) if (k >= c) v -= Lb[a][k] * X[k][c];
+              X[a][c] = v * inv[a];
+            }
+          }
+          if (ln == 0) {
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+              for (int c = 0; c < 6; c++) Li[jb * 36 + a * 6 + c] = X[a][c];
+          }
+        }
+      }
+      if (stamps == 1) ph_work += __builtin_readcyclecounter() - pa;
+      step_barrier();
+    }
+  } else {
+    for (int jb = 0; jb < N; jb++) step_barrier();
+  }
+  const unsigned long long st2 = stamps ? __builtin_readcyclecounter() : 0ull;
+  if (stamps && ln == 0 && (wv == CHAIN || wv == 0 || wv == INVW)) g_solve_stamps[wv == CHAIN ? 6 : wv == 0 ? 8 : 9] = ph_work;
+  if (s_fail) {
+    for (int i = tid; i < 6 * N; i += 1024) dX[i] = 0.0f;         // (see k_ba_solve)
+    if (tid == 0) { meta->fail = iter + 1; if (status_flag) *status_flag = iter + 1; }
+    return;
+  }
+  // back substitution  L^T x = z  by ONE wave in registers (see k_ba_solve); z = the transposed panel entries of the rhs row
+  // (column n6), the rows of L^T a lane needs are contiguous in its own row of the upper triangle
+  if (tid >= 64) return;
+  const int lr0 = min(tid, n6 - 1), lr1 = min(tid + 64, n6 - 1), lc = min(tid, 5);
+  float z0 = (tid < n6) ? A[tid * LD + n6] : 0.0f, z1 = (tid + 64 < n6) ? A[(tid + 64) * LD + n6] : 0.0f;
+  struct StepOps { float li[6], a0[6]; };
+  auto fetch = [&](int jb, StepOps& o) {
+    const float* Lb = Li + jb * 36 + lc;
+    const float* rowp = A + lr0 * LD + 6 * jb;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { o.li[k] = Lb[k * 6]; o.a0[k] = rowp[k]; }    // (L^-T)[c][k] = (L^-1)[k][c], 0 for k < c
+  };
+  auto step = [&](int jb, const StepOps& o) {
+    const int j0 = 6 * jb;
+    float zb[6], xb[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {                                  // all six before the first use: a v_readlane whose result is needed at once
+      const int r = j0 + k;                                        // costs ~20 cycles, six in a row ~25  (r is wave-uniform)
+      zb[k] = lane_value((r >= 64) ? z1 : z0, r & 63);
+    }
+    float xc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) xc += o.li[k] * zb[k];
+    if (tid < 6) xs[j0 + tid] = xc;
+#pragma unroll
+    for (int k = 0; k < 6; k++) xb[k] = lane_value(xc, k);
+    float v0 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) v0 += o.a0[k] * xb[k];
+    if (tid < j0) z0 -= v0;
+    if (j0 > 64) {                                                 // wave-uniform
+      const float* rowp = A + lr1 * LD + j0;
+      float v1 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 6; k++) v1 += rowp[k] * xb[k];
+      if (tid + 64 < j0) z1 -= v1;
+    }
+  };
+  {
+    StepOps oa, ob;
+    int jb = N - 1;
+    fetch(jb, oa);
+    while (true) {
+      fetch(max(jb - 1, 0), ob);                                   // (unconditional: a branch around loads costs a full wait at the join)
+      step(jb, oa);
+      if (--jb < 0) break;
+      fetch(max(jb - 1, 0), oa);
+      step(jb, ob);
+      if (--jb < 0) break;
+    }
+  }
+  wave_lds_sync();
+  for (int i = tid; i < n6; i += 64) dX[i] = xs[i];
+  if (stamps && tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st2; g_solve_stamps[4] = __builtin_readcyclecounter(); g_solve_stamps[5] = 0; }
+}
+
+static_assert(SOLVE_THREADS == 1024, "k_ba_solve_chain is written for 16 waves");
+typedef void (*solve_fn_t)(const float*, const float*, int, float*, BaMeta*, int, int*, int);
+static solve_fn_t ba_solve_fn(int N) {
+  static const bool v1 = getenv("DEVO_BA_SOLVE_V1") != nullptr;   // A/B and test switch: the two-barrier form for every N
+  return (6 * N <= 128 && !v1) ? k_ba_solve_chain : k_ba_solve;
+}
+
 // ------------------------------------------------------------------------------------------------- retract
 // poses[t0+i] <- Exp(dX_i) * poses[t0+i]  (ba_cuda.cu:160-188);  d <- d + dz; d>20 -> 1; d >= 1e-4 (:191-211)
 __global__ void k_ba_retract(float* __restrict__ poses, float* __restrict__ patches, const float* __restrict__ dX,
@@ -2244,7 +2557,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   acc_fn_t acc_fn = use_reg ? acc_reg_fn(N, cfg) : k_ba_accumulate;
   if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds_used) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
+        hipFuncSetAttribute((const void*)ba_solve_fn(N), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
       (void)hipGetLastError();
       set_error("devo_ba_forward: cannot reserve %zu / %zu bytes of LDS", acc_lds_used, solve_lds);
       return DEVO_ERR_LAUNCH;
@@ -2263,12 +2576,15 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       static const bool ba_trace = getenv("DEVO_BA_TRACE") != nullptr;
       static const int ba_trace_mode = ba_trace ? (atoi(getenv("DEVO_BA_TRACE")) > 1 ? atoi(getenv("DEVO_BA_TRACE")) : 1) : 0;
-      hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace_mode);
+      hipLaunchKernelGGL(ba_solve_fn(N), dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace_mode);
       if (ba_trace) {
         unsigned long long h[16];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_solve_stamps), sizeof(h));
-        fprintf(stderr, "[ba trace] solve: load %llu, factorisation %llu, block inverses %llu, back substitution %llu cycles (factorisation: panel %llu + update %llu; wave 0's tile: operands + results in %llu, products + stores %llu)\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5], h[6], h[8], h[9]);
+        if (ba_solve_fn(N) == k_ba_solve_chain)
+          fprintf(stderr, "[ba trace] solve (one barrier per step): load %llu, factorisation %llu, back substitution %llu cycles (work inside the steps: chain wave %llu, tile wave 0 %llu, inverse wave %llu)\n", h[1] - h[0], h[2] - h[1], h[4] - h[3], h[6], h[8], h[9]);
+        else
+          fprintf(stderr, "[ba trace] solve: load %llu, factorisation %llu, block inverses %llu, back substitution %llu cycles (factorisation: panel %llu + update %llu; wave 0's tile: operands + results in %llu, products + stores %llu)\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5], h[6], h[8], h[9]);
       }
       if ((rc = check_launch("devo_ba_forward(solve)"))) return rc;
     }
@@ -2315,7 +2631,7 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
   acc_fn_t acc_fn = use_reg ? acc_reg_fn(N, cfg) : k_ba_accumulate;
   if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds_used) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
+        hipFuncSetAttribute((const void*)ba_solve_fn(N), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
       (void)hipGetLastError();
       set_error("devo_ba_solve_terms: cannot reserve %zu / %zu bytes of LDS", acc_lds_used, solve_lds);
       return DEVO_ERR_LAUNCH;
@@ -2333,7 +2649,7 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
     hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, (float*)(w + L.partials), L.n_part, N, S,
                        (float*)(w + L.y), defer ? BA_EP_DEFERRED : ep);
     if (defer) ba_deferred_schur(st, patch_rec, patch_col, meta, N, L.max_seg, S, ep, (float*)(w + L.partials), sizeof(float) * (size_t)L.n_part * (n6 * (n6 + 1) + n6 + 1));
-    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, (float*)(w + L.y), N, dX, meta, 0, status_flag, 0);
+    hipLaunchKernelGGL(ba_solve_fn(N), dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, (float*)(w + L.y), N, dX, meta, 0, status_flag, 0);
     if ((rc = check_launch("devo_ba_solve_terms(solve)"))) return rc;
     if (hipMemcpyAsync(dX_out, dX, sizeof(float) * n6, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("devo_ba_solve_terms: copy failed"); return DEVO_ERR_LAUNCH; }
   }
@@ -2364,7 +2680,7 @@ int devo_ba_solve_terms_backward(const float* terms, const int64_t* ii, const in
     if (hipMemcpyAsync(rhs, g_dX, sizeof(float) * n6, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("devo_ba_solve_terms_backward: copy failed"); return DEVO_ERR_LAUNCH; }
     hipLaunchKernelGGL(k_bt_rhs, dim3(64), dim3(256), 0, st, rhs, g_dZ, patch_rec, patch_col, kx, meta, N);
     const size_t solve_lds = sizeof(float) * ((n6 + 1) * (size_t)solve_ld((int)n6) + 72 * (size_t)N + n6 + 4);
-    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, (float*)(w + L.y), N, ybar, meta, 0, (int*)nullptr, 0);
+    hipLaunchKernelGGL(ba_solve_fn(N), dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, (float*)(w + L.y), N, ybar, meta, 0, (int*)nullptr, 0);
     if ((rc = check_launch("devo_ba_solve_terms_backward(solve)"))) return rc;
   }
   hipLaunchKernelGGL(k_bt_patch, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, dX, ybar, g_dZ, patch_rec, patch_col, kx, meta, N, prec);

@@ -182,16 +182,19 @@ def select(scores, m, mode, grid=True, k=4):
     """PatchSelector.__call__ (selector.py:256-287): the score map is zero-padded (centred) to whole cells — whole 2 x 2 grids of
     cells with `grid` —, the method runs on the padded map, the coordinates are shifted back and clamped into the map."""
     mode = mode.lower()
-    if mode == "3xrandom":
-        return select_three_x_random(scores, m)[:2]
-    if mode not in ("topk", "multi"):
+    if mode not in ("3xrandom", "topk", "multi"):
+        # "nms" (selector.py:194-254) needs torchvision.ops.batched_nms, which this image does not have; DEVO's configurations
+        # use 3xrandom (training) and topk / multi (evaluation)
         raise NotImplementedError(f"patch selection mode {mode!r} (have: 3xrandom, topk, multi)")
     h, w = scores.shape[-2:]
     f = 2 * k if grid else k
     ph, pw = (f - h % f) % f, (f - w % f) % f
     top, left = ph // 2, pw // 2
     padded = F.pad(scores, (left, pw - left, top, ph - top))
-    x, y = (select_topk if mode == "topk" else select_multi)(padded, m, grid, k)
+    if mode == "3xrandom":                       # candidates are drawn on the padded map like every other method (selector.py:92-105,266-286)
+        x, y = select_three_x_random(padded, m)[:2]
+    else:
+        x, y = (select_topk if mode == "topk" else select_multi)(padded, m, grid, k)
     return (x - left).clamp(min=0, max=w - 1), (y - top).clamp(min=0, max=h - 1)
 
 

@@ -13,7 +13,7 @@ def _idx(*ts):
 def workspace(E, Np, N, device):
     nbytes = L.lib().devo_ba_workspace_bytes(int(E), int(Np), int(N))
     if nbytes == 0:
-        raise RuntimeError(f"cuda_ba: unsupported problem size (E={E}, Np={Np}, N={N}; at most 32 optimised poses)")
+        raise RuntimeError(f"cuda_ba: unsupported problem size (E={E}, Np={Np}, N={N}; at most 128 optimised poses)")
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 

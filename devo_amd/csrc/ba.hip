@@ -24,7 +24,9 @@
 
 namespace devo {
 
-constexpr int BA_MAXN = 32;          // optimised poses per call (6N <= 192 rows keeps S in LDS)
+constexpr int BA_MAXN_LDS = 32;      // optimised poses per call whose system (6N <= 192 rows) lives in LDS
+constexpr int BA_MAXN = 128;         // beyond BA_MAXN_LDS: the system stays in global memory (device atomics, k_ba_solve_t<true>); the limit is
+                                     // the solver's LDS tables (factored diagonal blocks + inverses) and ba_sig's 8 bits for N
 constexpr int ACC_WAVES = 8;         // waves per ba_accumulate workgroup
 constexpr int ACC_THREADS = ACC_WAVES * 64;
 constexpr int ACC_MAX_WG = 256;      // partial systems written per iteration
@@ -447,6 +449,14 @@ struct AccCtx {
 // different source frames): lane-private blocks and the Schur rank-1 update go into the workgroup's LDS system
 // with LDS atomics.  Correct for every input but slow (ds_add_f32 costs ~10 cycles per lane), so the kernels
 // below only use it for the rare irregular patches.
+// GLOBAL: S_lds / y_lds are the solver's image in GLOBAL memory, shared by every workgroup (more than BA_MAXN_LDS optimised poses:
+// the per-workgroup system does not fit the LDS) — device-scope atomics, like the reference's (ba_cuda.cu:297-322); no Schur term.
+template <bool GLOBAL>
+__device__ __forceinline__ void sys_add(float* p, float v) {
+  if (GLOBAL) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <bool GLOBAL = false>
 __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, int a0, int m, float* S_lds, float* y_lds,
                                                        float* col, int lane, bool schur = true) {
   const float* __restrict__ poses = K.poses; const float* __restrict__ patches = K.patches;
@@ -489,20 +499,22 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
       ei[c] = (ix >= 0) ? -(wz0 * T.Ji[0][c] + wz1 * T.Ji[1][c]) : 0.0f;      // E_i -= w Jz Ji   (:309)
     }
     if (N > 0) {
-      if (jx >= 0) fmask |= 1u << jx;
-      if (ix >= 0) fmask |= 1u << ix;
+      if (!GLOBAL) {
+        if (jx >= 0) fmask |= 1u << jx;
+        if (ix >= 0) fmask |= 1u << ix;
+      }
       // ---- frame-j blocks are lane-private (one edge per target frame): straight into LDS
       if (jx >= 0) {
 #pragma unroll
         for (int c = 0; c < 6; c++) {
           lds_add(&col[6 * jx + c], ej[c]);
-          lds_add(&y_lds[6 * jx + c], wr0 * T.Jj[0][c] + wr1 * T.Jj[1][c]);                               // v_j += w r Jj (:316)
+          sys_add<GLOBAL>(&y_lds[6 * jx + c], wr0 * T.Jj[0][c] + wr1 * T.Jj[1][c]);                               // v_j += w r Jj (:316)
         }
 #pragma unroll
         for (int a = 0; a < 6; a++)
 #pragma unroll
           for (int c = 0; c <= a; c++)
-            lds_add(&S_lds[(6 * jx + a) * LD + 6 * jx + c],
+            sys_add<GLOBAL>(&S_lds[(6 * jx + a) * LD + 6 * jx + c],
                     T.w[0] * T.Jj[0][a] * T.Jj[0][c] + T.w[1] * T.Jj[1][a] * T.Jj[1][c]);                 // B_jj (:299)
         if (ix >= 0) {
           // B_ij = -w Ji Jj^T and B_ji = its transpose (:300-303): keep the one in the lower triangle
@@ -512,9 +524,9 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
 #pragma unroll
             for (int c = 0; c < 6; c++) {
               const float vij = -(T.w[0] * T.Ji[0][a] * T.Jj[0][c] + T.w[1] * T.Ji[1][a] * T.Jj[1][c]);  // block (i,j)[a][c]
-              if (ix > jx) lds_add(&S_lds[(6 * ix + a) * LD + 6 * jx + c], vij);
-              else if (ix < jx) lds_add(&S_lds[(6 * jx + c) * LD + 6 * ix + a], vij);
-              else { lds_add(&S_lds[(6 * ix + a) * LD + 6 * ix + c], vij); lds_add(&S_lds[(6 * ix + c) * LD + 6 * ix + a], vij); }
+              if (ix > jx) sys_add<GLOBAL>(&S_lds[(6 * ix + a) * LD + 6 * jx + c], vij);
+              else if (ix < jx) sys_add<GLOBAL>(&S_lds[(6 * jx + c) * LD + 6 * ix + a], vij);
+              else { sys_add<GLOBAL>(&S_lds[(6 * ix + a) * LD + 6 * ix + c], vij); sys_add<GLOBAL>(&S_lds[(6 * ix + c) * LD + 6 * ix + a], vij); }
             }
         }
       }
@@ -529,7 +541,7 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
           for (int c = 0; c < 6; c++) {
             const float vc = wave_sum(ei[c]);
             const float vv = wave_sum((ix >= 0) ? -(wr0 * T.Ji[0][c] + wr1 * T.Ji[1][c]) : 0.0f);        // v_i -= w r Ji (:314)
-            if (lane == 0) { lds_add(&col[6 * ix0 + c], vc); lds_add(&y_lds[6 * ix0 + c], vv); }
+            if (lane == 0) { lds_add(&col[6 * ix0 + c], vc); sys_add<GLOBAL>(&y_lds[6 * ix0 + c], vv); }
           }
 #pragma unroll
           for (int a = 0; a < 6; a++)
@@ -537,19 +549,19 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
             for (int c = 0; c <= a; c++) {
               float v = (ix >= 0) ? (T.w[0] * T.Ji[0][a] * T.Ji[0][c] + T.w[1] * T.Ji[1][a] * T.Ji[1][c]) : 0.0f;   // B_ii (:297)
               v = wave_sum(v);
-              if (lane == 0) lds_add(&S_lds[(6 * ix0 + a) * LD + 6 * ix0 + c], v);
+              if (lane == 0) sys_add<GLOBAL>(&S_lds[(6 * ix0 + a) * LD + 6 * ix0 + c], v);
             }
         } else if (ix >= 0) {
 #pragma unroll
           for (int c = 0; c < 6; c++) {
             lds_add(&col[6 * ix + c], ei[c]);
-            lds_add(&y_lds[6 * ix + c], -(wr0 * T.Ji[0][c] + wr1 * T.Ji[1][c]));
+            sys_add<GLOBAL>(&y_lds[6 * ix + c], -(wr0 * T.Ji[0][c] + wr1 * T.Ji[1][c]));
           }
 #pragma unroll
           for (int a = 0; a < 6; a++)
 #pragma unroll
             for (int c = 0; c <= a; c++)
-              lds_add(&S_lds[(6 * ix + a) * LD + 6 * ix + c],
+              sys_add<GLOBAL>(&S_lds[(6 * ix + a) * LD + 6 * ix + c],
                       T.w[0] * T.Ji[0][a] * T.Ji[0][c] + T.w[1] * T.Ji[1][a] * T.Ji[1][c]);
         }
       }
@@ -566,6 +578,11 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
     // ---- Schur complement, patch by patch:  S -= Q e e^T (lower triangle),  y -= Q u e   (:511-512)
     // The column is pulled into registers once (lane l holds rows l, l+64, l+128); column entries are then
     // broadcast with v_readlane, so the loop issues LDS atomics only — no LDS read sits between them.
+    if (GLOBAL) {                                                       // any N: the column for k_ba_schur and the retraction
+      for (int i = lane; i < n6; i += 64) patch_col[(int64_t)s * n6 + i] = col[i];
+      wave_lds_sync();
+      return;
+    }
     float cr[3];
 #pragma unroll
     for (int g = 0; g < 3; g++) cr[g] = (lane + 64 * g < n6) ? col[lane + 64 * g] : 0.0f;
@@ -577,7 +594,7 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
       const int r = lane + 64 * g;
       const float qer = -Q * cr[g];
       const bool live = (r < n6) && (cr[g] != 0.0f);
-      if (live) lds_add(&y_lds[r], qer * usum);
+      if (live) sys_add<GLOBAL>(&y_lds[r], qer * usum);
       for (unsigned mm = fmask; mm; mm &= mm - 1) {                     // uniform trip count
         const int fb = __ffs((int)mm) - 1;
         if (6 * fb > 64 * g + 63) break;                                // uniform: no row of this group reaches it
@@ -585,7 +602,7 @@ __device__ __noinline__ void accumulate_segment_atomic(const AccCtx& K, int s, i
         for (int c = 0; c < 6; c++) {
           const int cc = 6 * fb + c;
           const float ec = readlane_f(cc < 64 ? cr[0] : (cc < 128 ? cr[1] : cr[2]), cc & 63);
-          if (live && cc <= r) lds_add(&S_lds[r * LD + cc], qer * ec);
+          if (live && cc <= r) sys_add<GLOBAL>(&S_lds[r * LD + cc], qer * ec);
         }
       }
     }
@@ -605,7 +622,8 @@ __device__ __forceinline__ void block_of(int blk, int& fr, int& fc) {   // inver
 
 // Generic accumulate kernel (any N <= 32): every patch through the atomic path.
 // LDS (dynamic): S_lds [n6 * LD] (lower triangle used), y_lds [n6], per-wave column buffers [ACC_WAVES][n6].
-__global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
+template <bool GLOBAL>
+__global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate_t(
     const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
     const TargetSrc target, const float* __restrict__ weight, const float* __restrict__ lmbda,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
@@ -613,12 +631,14 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
     int N, float* __restrict__ partials, float* __restrict__ patch_rec, float* __restrict__ patch_col, int iter, int sig, int max_seg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n6 = 6 * N, LD = n6 + 1;
-  float* S_lds = smem;
+  // GLOBAL: `partials` is the solver's image itself ((n6 + 1) x LD, zeroed by the launcher; row n6 = the right-hand side), the LDS only
+  // holds the waves' E columns
+  float* S_lds = GLOBAL ? partials : smem;
   float* y_lds = S_lds + n6 * LD;
-  float* col_all = y_lds + n6;
+  float* col_all = GLOBAL ? smem : y_lds + n6;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* col = col_all + wave * n6;
-  for (int i = tid; i < n6 * LD + n6; i += ACC_THREADS) smem[i] = 0.0f;
+  if (!GLOBAL) for (int i = tid; i < n6 * LD + n6; i += ACC_THREADS) smem[i] = 0.0f;
   __syncthreads();
   AccCtx K{poses, patches, target, weight, ii, jj, kk, perm, patch_rec, patch_col, intr[0], intr[1], intr[2], intr[3], lmbda[0],
            P, t0, N, n6, LD};
@@ -631,10 +651,10 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ba_accumulate(
   if (iter == 0 && blockIdx.x == 0 && tid == 0) meta->fail = prepared ? 0 : -1;
   for (int s = blockIdx.x * ACC_WAVES + wave; s < n_seg; s += gridDim.x * ACC_WAVES) {
     const int a0 = seg_start[s], m = seg_start[s + 1] - a0;
-    accumulate_segment_atomic(K, s, a0, m, S_lds, y_lds, col, lane, !defer);
+    accumulate_segment_atomic<GLOBAL>(K, s, a0, m, S_lds, y_lds, col, lane, !defer && !GLOBAL);
   }
   __syncthreads();
-  if (N > 0) {
+  if (N > 0 && !GLOBAL) {
     const int nt = tri_blocks(N) * 36;
     float* out = partials + (int64_t)blockIdx.x * (nt + n6);
     for (int i = tid; i < nt; i += ACC_THREADS) {
@@ -1056,6 +1076,8 @@ __global__ __launch_bounds__(512) void k_ba_reduce(const float* __restrict__ par
   }
 }
 
+constexpr auto k_ba_accumulate = k_ba_accumulate_t<false>;
+
 // ------------------------------------------------------------------------------------------------- deferred Schur term
 // S_aug -= E^ diag(Q) E^^T for the general accumulate kernel at N > 16 (ba_cuda.cu:511-512 as ONE product instead of 17 k LDS
 // atomics per patch: on gfx950 a 64-lane ds_add_f32 occupies the LDS for ~60 cycles, and at BASELINE's stress size the per-patch
@@ -1182,20 +1204,25 @@ __host__ __device__ inline int solve_ld(int n6) {
 __device__ unsigned long long g_solve_stamps[16];
 // debug (DEVO_BA_TRACE): cycle stamps of the last solve
 
-__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restrict__ S, const float* __restrict__ y, int N,
-                                                            float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps) {
-  extern __shared__ __attribute__((aligned(16))) float A[];
+// GLOBAL (more than BA_MAXN_LDS optimised poses: the image does not fit the LDS): the same algorithm IN PLACE on the global image
+// (row stride n6 + 1; one workgroup = one CU = one L1, workgroup barriers order its global accesses); only the factored diagonal
+// blocks, their inverses and the solution stay in LDS.  Slower by the latency ratio, correct for any N the LDS tables hold.
+template <bool GLOBAL>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve_t(const float* S, const float* __restrict__ y, int N,
+                                                              float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps) {
+  extern __shared__ __attribute__((aligned(16))) float solve_smem[];
   __shared__ int s_fail;
   // LDS image: rows x LD with an EVEN row stride (the global image k_ba_reduce wrote has n6 + 1): panel columns start at even
   // offsets (j0 = 6 jb), so the trailing update reads its operands as 8-byte pairs
-  const int n6 = 6 * N, LDG = n6 + 1, LD = solve_ld(n6), rows = n6 + 1;
-  float* Ld = A + rows * LD;                    // [N][36] factored diagonal blocks (diagonal stored as reciprocal)
+  const int n6 = 6 * N, LDG = n6 + 1, LD = GLOBAL ? LDG : solve_ld(n6), rows = n6 + 1;
+  float* A = GLOBAL ? const_cast<float*>(S) : solve_smem;
+  float* Ld = GLOBAL ? solve_smem : A + rows * LD;   // [N][36] factored diagonal blocks (diagonal stored as reciprocal)
   float* Li = Ld + N * 36;                      // [N][36] their inverses (for the back-substitution)
   float* xs = Li + N * 36;                      // [n6] solution
   const int tid = threadIdx.x;
   const unsigned long long st0 = stamps ? __builtin_readcyclecounter() : 0ull;      // (s_memtime stalls: debug only)
   if (tid == 0) s_fail = 0;
-  {
+  if (!GLOBAL) {
     // k_ba_reduce wrote this very image (rows x LD, the right-hand side is row n6); eight loads in flight per thread
     const int total = rows * LDG - 1;
     const float inv_ldg = 1.0f / (float)LDG;
@@ -1532,6 +1559,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve(const float* __restr
   if (stamps && tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st3; g_solve_stamps[4] = __builtin_readcyclecounter(); g_solve_stamps[5] = ph_panel; g_solve_stamps[6] = ph_update; g_solve_stamps[8] = ph_q1; g_solve_stamps[9] = ph_q2; }
 }
 
+
+constexpr auto k_ba_solve = k_ba_solve_t<false>;
 
 // ------------------------------------------------------------------------------------------------- solve, one barrier per block step
 // The factorisation above spends two workgroup barriers per block step and its look-ahead wave waits for the panel.  This form
@@ -2293,7 +2322,7 @@ __global__ void k_neighbors(const int64_t* __restrict__ jj, int E, const int* __
 
 // ------------------------------------------------------------------------------------------------- workspace
 struct BaLayout {
-  size_t meta, rank, counts, cursor, ku, perm_a, perm_b, kx, partials, S, y, dX, patch_rec, edge_ej, prec, ybar, total;
+  size_t meta, rank, counts, cursor, ku, perm_a, perm_b, kx, partials, S, y, dX, patch_rec, edge_ej, prec, ybar, total, partials_bytes;
   int max_seg, n_part;
 };
 // Form of the register-path accumulate kernel (N <= 16) and its waves per workgroup — DEVO_BA_REGFOLD=1: the register fold.
@@ -2336,7 +2365,13 @@ static BaLayout ba_layout(int E, int Np, int N) {
   L.perm_a = take(sizeof(int) * (size_t)(E > 0 ? E : 1));
   L.perm_b = take(sizeof(int) * (size_t)(E > 0 ? E : 1));
   L.kx = take(sizeof(int) * (size_t)L.max_seg);
-  L.partials = take(sizeof(float) * (size_t)L.n_part * (n6 * (n6 + 1) + n6 + 1));
+  L.partials_bytes = sizeof(float) * (size_t)L.n_part * (n6 * (n6 + 1) + n6 + 1);
+  if (N > BA_MAXN_LDS) {                                            // no partial systems: the area only holds k_ba_schur's partial tiles
+    const size_t nt = (n6 + 1 + SCH_T - 1) / SCH_T, ntile = nt * (nt + 1) / 2, nchunk = ((size_t)L.max_seg + SCH_K - 1) / SCH_K;
+    L.partials_bytes = sizeof(float) * ntile * nchunk * SCH_T * SCH_T;
+    if (L.partials_bytes > ((size_t)64 << 20)) L.partials_bytes = 16;   // (k_ba_schur then adds with atomics)
+  }
+  L.partials = take(L.partials_bytes);
   L.S = take(sizeof(float) * ((n6 + 1) * (n6 + 1) + 1));
   L.y = take(sizeof(float) * (n6 + 1));
   L.dX = take(sizeof(float) * (n6 + 1));
@@ -2548,16 +2583,18 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
 
   const size_t n6 = 6 * (size_t)N;
   const float ep = 1.0f;                                          // ba_cuda.cu:518
-  const size_t acc_lds = sizeof(float) * (n6 * (n6 + 1) + n6 + ACC_WAVES * n6 + 4);
-  const size_t solve_lds = sizeof(float) * ((n6 + 1) * (size_t)solve_ld((int)n6) + 72 * (size_t)N + n6 + 4);
+  const bool big = N > BA_MAXN_LDS;                               // the system in global memory (see BA_MAXN)
+  const size_t acc_lds = big ? sizeof(float) * (ACC_WAVES * n6 + 4) : sizeof(float) * (n6 * (n6 + 1) + n6 + ACC_WAVES * n6 + 4);
+  const size_t solve_lds = big ? sizeof(float) * (72 * (size_t)N + n6 + 4) : sizeof(float) * ((n6 + 1) * (size_t)solve_ld((int)n6) + 72 * (size_t)N + n6 + 4);
   static const bool force_generic = getenv("DEVO_BA_GENERIC") != nullptr;   // test switch: the general accumulate kernel for every N
   const bool use_reg = (N <= 16) && !force_generic;
   const AccCfg cfg = acc_cfg(N);
   const size_t acc_lds_used = use_reg ? acc_reg_lds_bytes(N, cfg) : acc_lds;
-  acc_fn_t acc_fn = use_reg ? acc_reg_fn(N, cfg) : k_ba_accumulate;
+  acc_fn_t acc_fn = use_reg ? acc_reg_fn(N, cfg) : big ? k_ba_accumulate_t<true> : k_ba_accumulate;
+  solve_fn_t solve_fn = big ? k_ba_solve_t<true> : ba_solve_fn(N);
   if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds_used) != hipSuccess ||
-        hipFuncSetAttribute((const void*)ba_solve_fn(N), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
+        hipFuncSetAttribute((const void*)solve_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
       (void)hipGetLastError();
       set_error("devo_ba_forward: cannot reserve %zu / %zu bytes of LDS", acc_lds_used, solve_lds);
       return DEVO_ERR_LAUNCH;
@@ -2565,23 +2602,24 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   }
   // the general kernel (N > 16) leaves the Schur term to ONE product afterwards (k_ba_schur); DEVO_BA_SCHUR_INLINE=1: per patch, in LDS
   static const bool schur_inline = getenv("DEVO_BA_SCHUR_INLINE") != nullptr;
-  const bool defer = !use_reg && N > 0 && !schur_inline;
+  const bool defer = !use_reg && N > 0 && (!schur_inline || big);
   for (int it = 0; it < iterations; it++) {
+    if (big && hipMemsetAsync(S, 0, sizeof(float) * (n6 + 1) * (n6 + 1), st) != hipSuccess) { set_error("devo_ba_forward: memset failed"); return DEVO_ERR_LAUNCH; }
     hipLaunchKernelGGL(acc_fn, dim3(L.n_part), dim3(use_reg ? cfg.waves * 64 : ACC_THREADS), acc_lds_used, st, poses, patches, intrinsics, target,
-                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, partials, patch_rec, edge_ej, it | (defer ? 1 << 16 : 0), ba_sig(E, N), L.max_seg);
+                       weight, lmbda, ii, jj, kk, perm_b, counts, meta, P, t0, N, big ? S : partials, patch_rec, edge_ej, it | (defer ? 1 << 16 : 0), ba_sig(E, N), L.max_seg);
     if ((rc = check_launch("devo_ba_forward(accumulate)"))) return rc;
     if (N > 0) {
-      hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, partials, L.n_part, N, S, y, defer ? BA_EP_DEFERRED : ep);
-      if (defer) ba_deferred_schur(st, patch_rec, edge_ej, meta, N, L.max_seg, S, ep, partials, sizeof(float) * (size_t)L.n_part * (n6 * (n6 + 1) + n6 + 1));
+      if (!big) hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, partials, L.n_part, N, S, y, defer ? BA_EP_DEFERRED : ep);
+      if (defer) ba_deferred_schur(st, patch_rec, edge_ej, meta, N, L.max_seg, S, ep, partials, L.partials_bytes);
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       static const bool ba_trace = getenv("DEVO_BA_TRACE") != nullptr;
       static const int ba_trace_mode = ba_trace ? (atoi(getenv("DEVO_BA_TRACE")) > 1 ? atoi(getenv("DEVO_BA_TRACE")) : 1) : 0;
-      hipLaunchKernelGGL(ba_solve_fn(N), dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace_mode);
+      hipLaunchKernelGGL(solve_fn, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace_mode);
       if (ba_trace) {
         unsigned long long h[16];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_solve_stamps), sizeof(h));
-        if (ba_solve_fn(N) == k_ba_solve_chain)
+        if (solve_fn == k_ba_solve_chain)
           fprintf(stderr, "[ba trace] solve (one barrier per step): load %llu, factorisation %llu, back substitution %llu cycles (work inside the steps: chain wave %llu, tile wave 0 %llu, inverse wave %llu)\n", h[1] - h[0], h[2] - h[1], h[4] - h[3], h[6], h[8], h[9]);
         else
           fprintf(stderr, "[ba trace] solve: load %llu, factorisation %llu, block inverses %llu, back substitution %llu cycles (factorisation: panel %llu + update %llu; wave 0's tile: operands + results in %llu, products + stores %llu)\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5], h[6], h[8], h[9]);
@@ -2599,7 +2637,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
 // ---- one differentiable Gauss-Newton step from given edge terms (devo/ba.py:108-170) and its adjoint
 static int bt_common(const char* who, int E, int Np, int N, size_t ws_bytes, void* ws, BaLayout* L) {
   if (!(E >= 0 && Np > 0 && N >= 0)) { set_error("%s: bad sizes", who); return DEVO_ERR_ARG; }
-  if (N > BA_MAXN) { set_error("%s: %d optimised poses > %d supported", who, N, BA_MAXN); return DEVO_ERR_UNSUPPORTED; }
+  if (N > BA_MAXN_LDS) { set_error("%s: %d optimised poses > %d supported by the differentiable solve", who, N, BA_MAXN_LDS); return DEVO_ERR_UNSUPPORTED; }
   *L = ba_layout(E, Np, N);
   if (ws == nullptr || ws_bytes < L->total) { set_error("%s: workspace %zu < %zu bytes", who, ws_bytes, L->total); return DEVO_ERR_WORKSPACE; }
   return DEVO_OK;
@@ -2648,7 +2686,7 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
   if (N > 0) {
     hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((N * (N + 1) / 2 * 36 + n6 + 63) / 64)), dim3(512), 0, st, (float*)(w + L.partials), L.n_part, N, S,
                        (float*)(w + L.y), defer ? BA_EP_DEFERRED : ep);
-    if (defer) ba_deferred_schur(st, patch_rec, patch_col, meta, N, L.max_seg, S, ep, (float*)(w + L.partials), sizeof(float) * (size_t)L.n_part * (n6 * (n6 + 1) + n6 + 1));
+    if (defer) ba_deferred_schur(st, patch_rec, patch_col, meta, N, L.max_seg, S, ep, (float*)(w + L.partials), L.partials_bytes);
     hipLaunchKernelGGL(ba_solve_fn(N), dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, (float*)(w + L.y), N, dX, meta, 0, status_flag, 0);
     if ((rc = check_launch("devo_ba_solve_terms(solve)"))) return rc;
     if (hipMemcpyAsync(dX_out, dX, sizeof(float) * n6, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("devo_ba_solve_terms: copy failed"); return DEVO_ERR_LAUNCH; }

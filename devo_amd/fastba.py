@@ -9,7 +9,7 @@ _ws_cache = {}
 _status = {}                  # device -> int32 [1]: 0 = ok, k > 0 = the Cholesky factorisation broke down in iteration k, -1 = bad workspace
 _host = {}                    # device -> (pinned int32 [1], event): the status is copied out asynchronously after every BA()
 _pending = {}                 # device -> True while the status of the last BA() has not been looked at
-MAX_OPTIMISED_POSES = 32      # devo_ba_forward solves the reduced system inside one workgroup's LDS
+MAX_OPTIMISED_POSES = 128     # devo_ba_forward: up to 32 the reduced system lives in one workgroup's LDS, beyond in global memory (slower)
 
 
 class BAFailure(RuntimeError):

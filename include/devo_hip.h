@@ -130,6 +130,9 @@ int devo_patchify_backward(const float* coords, const void* grad, void* net_grad
  * fastba  (reference module cuda_ba: devo/fastba/ba.cpp:152-157)
  * ---------------------------------------------------------------------------------------------- */
 
+/* 0 when the sizes are not supported: N = t1 - t0 <= 128 optimised poses per call (the reference has no limit, ba_cuda.cu:516-522; DEVO
+ * uses <= 14).  Up to 32 the reduced system lives in one workgroup's LDS; beyond, in global memory (device-scope atomics like the
+ * reference's, the blocked Cholesky in place on the global image). */
 size_t devo_ba_workspace_bytes(int E, int Np /* patch slots = patches.shape[1] */, int N /* t1 - t0 */);
 
 /* cuda_ba.forward  (ba.cpp:153 -> ba_cuda.cu:422-540).  IN-PLACE on poses and patches, returns nothing.
@@ -185,7 +188,7 @@ int devo_ba_forward_prepared_delta(float* poses, float* patches, const float* in
  * terms f32 [E,30]: r[2] w[2] Jz[2] Ji[2][6] Jj[2][6] with Ji = MINUS d coords / d xi_i (this library's sign convention);
  * frames < t0 or >= t0 + N are fixed; damping S_dd + ep + 1e-4 S_dd (ba.py:73); lmbda f32 [1] on the device.
  * Outputs: dX f32 [6 N] (zero when the factorisation breaks down, like ba.py:16-20; *status_flag = 1 then),
- * dZ f32 [Np] per patch SLOT (zero for patches without an edge).  The workspace (devo_ba_workspace_bytes(E, Np, N)) keeps
+ * dZ f32 [Np] per patch SLOT (zero for patches without an edge).  N <= 32 here.  The workspace (devo_ba_workspace_bytes(E, Np, N)) keeps
  * what the adjoint needs: pass it unmodified to devo_ba_solve_terms_backward. */
 int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E,
                         int Np, int t0, int N, float ep, void* ws, size_t ws_bytes, float* dX, float* dZ, int* status_flag,

@@ -40,7 +40,8 @@ def test_workspace_queries(libpath):
     from devo_amd import _lib
     L = _lib.lib()
     assert L.devo_ba_workspace_bytes(21600, 1440, 14) > 21600 * 12 * 4
-    assert L.devo_ba_workspace_bytes(100, 10, 33) == 0          # more than 32 optimised poses: unsupported
+    assert L.devo_ba_workspace_bytes(100, 10, 33) > 199 * 199 * 4     # more than 32 optimised poses: the system in global memory
+    assert L.devo_ba_workspace_bytes(100, 10, 129) == 0               # more than 128: unsupported
     assert L.devo_neighbors_workspace_bytes(21600) > 21600 * 8
 
 

@@ -173,9 +173,9 @@ def test_ba_empty_and_limits():
     e = torch.zeros(0, dtype=torch.long, device=DEV)
     assert cuda_ba.forward(P, Q, d(s[2]), d(s[3])[:, :0], d(s[4])[:, :0], torch.tensor([1e-4], device=DEV), e, e, e, 1, 8, 2) == []
     assert torch.equal(P.cpu(), s[0]) and torch.equal(Q.cpu(), s[1])          # no edges: nothing moves
-    with pytest.raises(RuntimeError):                                           # more than 32 optimised poses
-        big = torch.zeros(1, 40, 7, device=DEV); big[..., 6] = 1
-        cuda_ba.forward(big, Q, d(s[2]), d(s[3]), d(s[4]), torch.tensor([1e-4], device=DEV), d(s[5]), d(s[6]), d(s[7]), 1, 40, 1)
+    with pytest.raises(RuntimeError):                                           # more than 128 optimised poses
+        big = torch.zeros(1, 140, 7, device=DEV); big[..., 6] = 1
+        cuda_ba.forward(big, Q, d(s[2]), d(s[3]), d(s[4]), torch.tensor([1e-4], device=DEV), d(s[5]), d(s[6]), d(s[7]), 1, 140, 1)
 
 
 def test_ba_failure_flag_on_breakdown():
@@ -196,7 +196,7 @@ def test_ba_failure_flag_on_breakdown():
 def test_dropin_fastba_reports_a_failed_factorisation():
     """devo_amd.fastba.BA (the `devo.fastba.BA` drop-in): a Cholesky breakdown surfaces as an exception the caller's
     try / except sees (devo.py:336-340) — at the next call (lazy, no synchronisation in the failing call), immediately with
-    check="now", or through last_status(); more than 32 optimised poses is a clear error."""
+    check="now", or through last_status(); more than 128 optimised poses is a clear error."""
     from devo_amd import fastba
     s = scene()
     d = lambda t: t.to(DEV)
@@ -217,9 +217,9 @@ def test_dropin_fastba_reports_a_failed_factorisation():
         fastba.BA(*args(d(s[0]).clone(), d(s[1]).clone(), bad), check="now")
     fastba.BA(*args(d(s[0]).clone(), d(s[1]).clone(), bad), check="never")
     assert fastba.last_status(DEV) == 1
-    big = torch.zeros(1, 40, 7, device=DEV); big[..., 6] = 1
-    with pytest.raises(RuntimeError, match="at most 32"):
-        fastba.BA(big, Q, d(s[2]), d(s[3]), d(s[4]), torch.tensor([1e-4], device=DEV), d(s[5]), d(s[6]), d(s[7]), 1, 40, 1)
+    big = torch.zeros(1, 140, 7, device=DEV); big[..., 6] = 1
+    with pytest.raises(RuntimeError, match="at most 128"):
+        fastba.BA(big, Q, d(s[2]), d(s[3]), d(s[4]), torch.tensor([1e-4], device=DEV), d(s[5]), d(s[6]), d(s[7]), 1, 140, 1)
 
 
 def test_prepare_then_forward_prepared_equals_forward():
@@ -354,6 +354,17 @@ def test_ba_more_than_16_optimised_poses_uses_the_general_kernel(n):
     s = scene(n=n, M=4, H=96, W=128, seed=77, keep=0.9, sigma=0.5)
     ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], 1, n, 2, dtype=torch.float64)
     check(run_ba(*s, 1, n, 2), ref)
+
+
+@pytest.mark.parametrize("n,t0", [(34, 1), (40, 0), (57, 2)])
+def test_ba_more_than_32_optimised_poses_keeps_the_system_in_global_memory(n, t0):
+    """The reference has no limit on t1 - t0 (ba_cuda.cu:516-522: dense S, torch::linalg::cholesky).  Beyond 32 optimised poses the
+    reduced system does not fit one workgroup's LDS: accumulate with device-scope atomics into the global image (like the reference's
+    atomicAdds), Schur term as one product, the blocked Cholesky in place on the global image.  Same tolerance as every other BA."""
+    s = scene(n=n, M=4, H=96, W=128, seed=31 + n, keep=0.9, sigma=0.5)
+    ref = F.ba(*[x.double() if x.is_floating_point() else x for x in s[:5]], torch.tensor([1e-4]), *s[5:], t0, n, 2, dtype=torch.float64)
+    ref32 = F.ba(*s[:5], torch.tensor([1e-4]), *s[5:], t0, n, 2, dtype=torch.float32)
+    check(run_ba(*s, t0, n, 2), ref, ref32=ref32)
 
 
 def test_prepare_with_plan_equals_the_two_separate_calls():

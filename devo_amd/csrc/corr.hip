@@ -814,6 +814,10 @@ __global__ void patchify_fwd_kernel(const T* __restrict__ net, const float* __re
   }
 }
 
+}  // namespace devo
+#include "corr_bwd_mfma.h"
+namespace devo {
+
 template <typename T>
 __global__ void patchify_bwd_kernel(const float* __restrict__ coords, const T* __restrict__ grad, T* __restrict__ dnet,
                                     int M, int C, int H, int W, int R, int64_t total) {
@@ -1272,8 +1276,17 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
   const bool seg = !force_atomic && BE > 0 && f2s[2] == 1 && f2s[4] == C && f2s[3] == (int64_t)W2 * C && f2s[1] >= (int64_t)H2 * W2 * C &&
                    C % BWD_CS == 0 && tile_lds <= 54 * 1024 && gs_bytes + meta_bytes + list_bytes <= (512ull << 20) && BE < (1LL << 31) &&
                    frames <= 65535 && (H2 + BH - 1) / BH <= 65535 && (reinterpret_cast<uintptr_t>(fmap2_grad) & 15) == 0;
-  if (hipMemsetAsync(fmap1_grad, 0, sizeof(float) * (size_t)B * Np * C * PP, st) != hipSuccess ||
-      (!seg && hipMemsetAsync(fmap2_grad, 0, sizeof(float) * (size_t)f2_numel_span, st) != hipSuccess)) {
+  // Product form (default where it applies; DEVO_CORR_BWD_ATOMIC=1: the one-kernel atomic path): channels-last fmap2 with C % 128 == 0 —
+  // d_fmap1 per edge and d_fmap2 per frame tile as matrix-core products, no atomics on d_fmap2 (corr_bwd_mfma.h).
+  static const bool no_product = getenv("DEVO_CORR_BWD_ATOMIC") != nullptr || getenv("DEVO_CORR_BWD_SEG") != nullptr;
+  const size_t f1t_bytes = (size_t)B * Np * C * PP * 4, pair_bytes = (size_t)frames * (size_t)BE * PP * 16;      // (a frame's window list can hold every edge)
+  const bool product = !no_product && BE > 0 && f2s[2] == 1 && f2s[4] == C && f2s[3] == (int64_t)W2 * C && f2s[1] >= (int64_t)H2 * W2 * C &&
+                       C % 128 == 0 && BE * PP * D * D < (1LL << 31) && frames <= 65535 && (H2 + 7) / 8 <= 65535 &&
+                       gs_bytes + pair_bytes + f1t_bytes <= (1024ull << 20) &&
+                       (reinterpret_cast<uintptr_t>(fmap2_grad) & 15) == 0 && (reinterpret_cast<uintptr_t>(fmap2) & 15) == 0 &&
+                       f2s[0] % 4 == 0 && f2s[1] % 4 == 0;
+  if ((!product && hipMemsetAsync(fmap1_grad, 0, sizeof(float) * (size_t)B * Np * C * PP, st) != hipSuccess) ||
+      (!seg && !product && hipMemsetAsync(fmap2_grad, 0, sizeof(float) * (size_t)f2_numel_span, st) != hipSuccess)) {
     set_error("devo_corr_backward: memset failed");
     return DEVO_ERR_LAUNCH;
   }
@@ -1292,6 +1305,28 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
             (double)h[0] / BE, (double)h[1] / BE, (double)h[2] / BE, (double)h[3] / BE);
     (void)hipFree(btrace);
   };
+  if (product) {
+    char* scratch = nullptr;
+    const size_t pair_off = (gs_bytes + 15) & ~(size_t)15, f1t_off = pair_off + pair_bytes, cur_off = f1t_off + f1t_bytes, total = cur_off + (size_t)frames * 4;
+    if (hipMallocAsync((void**)&scratch, total, st) != hipSuccess) { (void)hipGetLastError(); set_error("devo_corr_backward: scratch allocation failed"); return DEVO_ERR_LAUNCH; }
+    float* gs = reinterpret_cast<float*>(scratch);
+    BwdPair* pairs = reinterpret_cast<BwdPair*>(scratch + pair_off);
+    float* f1t = reinterpret_cast<float*>(scratch + f1t_off);
+    int* cursors = reinterpret_cast<int*>(scratch + cur_off);
+    hipLaunchKernelGGL(corr_bwd_patch_t_kernel, dim3((unsigned)(B * Np)), dim3(256), (size_t)C * PP * 4, st, (const float*)fmap1, f1t, (float*)fmap1_grad, cursors,
+                       (int)frames, B * Np, C);
+    hipLaunchKernelGGL((radius <= 3 ? corr_bwd_edge_kernel<3> : corr_bwd_edge_kernel<5>), dim3((unsigned)((BE + BWE_EW - 1) / BWE_EW)), dim3(64 * BWE_EW), 0, st,
+                       (const float*)fmap2, coords, ii, jj, grad, (float*)fmap1_grad, BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], radius, gs, pairs, cursors,
+                       (int)BE);
+    const int tiles_x = (W2 + 7) / 8;
+    hipLaunchKernelGGL(corr_bwd_frame_kernel, dim3((unsigned)(tiles_x * (C / 128)), (unsigned)((H2 + 7) / 8), (unsigned)frames), dim3(256), 0, st,
+                       (const float*)f1t, (const float*)gs, (const BwdPair*)pairs, (const int*)cursors, (float*)fmap2_grad, n2, C, H2, W2, f2s[0], f2s[1], D,
+                       (int)BE, tiles_x);
+    const int rc = check_launch("devo_corr_backward");
+    (void)hipFreeAsync(scratch, st);
+    if (do_btrace) (void)hipFree(btrace);
+    return rc;
+  }
   if (seg) {
     char* scratch = nullptr;
     const size_t cur_off = gs_bytes + meta_bytes + list_bytes, total = cur_off + (size_t)frames * 4;

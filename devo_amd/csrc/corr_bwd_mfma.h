@@ -1,0 +1,269 @@
+// altcorr backward as two products on the fp32 matrix cores (correlation_kernel.cu:139-190,252-269), channels-last fmap2, C % 128 == 0.
+//
+// With G_e[p] the D x D window gradient of patch pixel p of edge e (the adjoint of the four-tap blend, zero where the tap lies outside the
+// frame) and o_e[p] the window's origin, the reference's scatter is two contractions:
+//     d_fmap1[k][c][p]        = sum over positions x of   G_e[p](x - o_e[p]) * fmap2[j][x][c]                 (one per edge)
+//     d_fmap2[j][x][c]        = sum over (e, p) with j = jj[e] of   G_e[p](x - o_e[p]) * fmap1[k][c][p]       (one per frame position)
+// corr_bwd_edge_kernel does the first per edge (M = the 9 patch pixels, N = channels, K = the positions of the edge's clipped box) and
+// hands G and one record per (edge, pixel) window — appended to the target frame's window list — to corr_bwd_frame_kernel, which OWNS an 8 x 8 tile of a
+// frame's gradient (M = 16 positions per wave, N = channels, K = the (edge, pixel) windows that overlap the tile) and stores it once:
+// no atomics on d_fmap2 (the one-kernel path issues 49 M of them per level), no memset of it, every position written exactly once.
+// Both use v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation).  The channel a result column stands for is permuted so that
+// lane n of the 16 columns owns channels 8 n .. 8 n + 7 across its 8 accumulators: its operand loads and its stores are 32 contiguous
+// bytes, 16 lanes = the 512 bytes of a channels-last pixel.
+#pragma once
+
+namespace devo {
+
+typedef float bw_f4 __attribute__((ext_vector_type(4)));
+
+// fmap1 [N][C][9] -> [N][9][C] (plain fp32): the B operand of the frame kernel, 32 contiguous bytes per lane.  The same launch zeroes
+// d_fmap1 (the edge kernel adds into it) and the frames' list cursors: two memset launches less per call.
+__global__ __launch_bounds__(256) void corr_bwd_patch_t_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ d1,
+                                                               int* __restrict__ cursors, int frames, int N, int C) {
+  extern __shared__ __attribute__((aligned(16))) float bpt_lds[];
+  const int n = blockIdx.x;
+  if (n == 0) for (int i = threadIdx.x; i < frames; i += 256) cursors[i] = 0;
+  if (n >= N) return;
+  const float* in = src + (int64_t)n * C * PP;
+  float* o = dst + (int64_t)n * C * PP;
+  float* z = d1 + (int64_t)n * C * PP;
+  for (int i = threadIdx.x; i < C * PP; i += 256) { bpt_lds[i] = in[i]; z[i] = 0.0f; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * PP; i += 256) { const int p = i / C, c = i - p * C; o[i] = bpt_lds[c * PP + p]; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- per edge
+// One wave per edge (EW edges per workgroup).  G from the edge's gradient block, d_fmap1 on the matrix cores, hand-over.
+// Every dependent global round trip costs ~4 us while all waves of the launch are resident, so the K loop requests BWD_NB steps (= 4 NB
+// box positions: 32 bytes per lane each) at once and multiplies them afterwards: 27 steps of a 107-position box are 4 round trips.
+constexpr int BWE_EW = 4;                       // edges (waves) per workgroup
+constexpr int BWD_NB = 8;                       // K steps requested together
+struct BwdPair { int gs_off, ox, oy, row; };    // one (edge, patch pixel) window for the frame kernel: offset of its G, origin, row of fmap1_t
+template <int RMAX>
+__global__ __launch_bounds__(64 * BWE_EW) __attribute__((amdgpu_waves_per_eu(1, 3))) void corr_bwd_edge_kernel(      // (room for the batch's 72 registers)
+    const float* __restrict__ fmap2, const float* __restrict__ coords, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+    const float* __restrict__ grad, float* __restrict__ d1, long long BE, int E, int Np, int n2, int C, int H2, int W2, int64_t s_b,
+    int64_t s_n, int R, float* __restrict__ gs, BwdPair* __restrict__ pairs, int* __restrict__ cursors, int cap) {
+  constexpr int DMX = 2 * RMAX + 2;
+  __shared__ float s_g_all[BWE_EW][PP * DMX * DMX];
+  __shared__ float s_grad_all[BWE_EW][(DMX - 1) * (DMX - 1) * PP];
+  __shared__ float s_frac[BWE_EW][2][PP];                              // blend weights dx, dy per patch pixel
+  __shared__ int s_org[BWE_EW][2][PP];                                // window origins ox, oy
+  __shared__ float s_out[BWE_EW][128 * PP];                           // a channel half of the edge's d_fmap1 in the tensor's [c][p] order
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const long long be = (long long)blockIdx.x * BWE_EW + wv;
+  if (be >= BE) return;                                               // (wave-uniform; no workgroup barrier below)
+  float* s_g = s_g_all[wv];
+  float* s_grad = s_grad_all[wv];
+  const int D = 2 * R + 2, Dm = D - 1, DD = D * D;
+  const int b = (int)(be / E), e = (int)(be % E);
+  const int64_t pi = ii[e], fj = jj[e];
+  float cx = 0.0f, cy = 0.0f;
+  if (ln < PP) { cx = coords[(be * 2 + 0) * PP + ln]; cy = coords[(be * 2 + 1) * PP + ln]; }
+  {                                                                    // (in flight together with the coordinates)
+    const float* g = grad + be * Dm * Dm * PP;
+    const int ng = Dm * Dm * PP;
+    for (int i = ln; i < ng; i += 64) s_grad[i] = g[i];
+  }
+  const int my_ox = floor_to_int(cx) - R, my_oy = floor_to_int(cy) - R;
+  if (ln < PP) { s_org[wv][0][ln] = my_ox; s_org[wv][1][ln] = my_oy; s_frac[wv][0][ln] = cx - floorf(cx); s_frac[wv][1][ln] = cy - floorf(cy); }
+  int xmin = 1 << 30, xmax = -(1 << 30), ymin = 1 << 30, ymax = -(1 << 30);
+#pragma unroll
+  for (int p = 0; p < PP; p++) {
+    const int ox = __builtin_amdgcn_readlane(my_ox, p), oy = __builtin_amdgcn_readlane(my_oy, p);
+    xmin = min(xmin, ox); xmax = max(xmax, ox); ymin = min(ymin, oy); ymax = max(ymax, oy);
+  }
+  const int x0 = max(xmin, 0), x1 = min(xmax + D, W2), y0 = max(ymin, 0), y1 = min(ymax + D, H2);
+  const int bw = max(x1 - x0, 0), npos = bw * max(y1 - y0, 0);
+  const int frame = b * n2 + (int)fj;
+  // the edge's slot in its frame's window list (order: whoever comes first); the returned value is only needed after the first products
+  int slot = 0;
+  if (ln == 0 && npos > 0) slot = atomicAdd(&cursors[frame], 1);
+  // the first batch of feature rows is requested BEFORE the window gradients are formed (it only needs the box)
+  const int mm = ln & 15, kq = ln >> 4;
+  const float* __restrict__ f2 = fmap2 + (int64_t)b * s_b + fj * s_n + 8 * mm;          // this lane's 8 channels (+ 128 per channel half)
+  const float inv_bw = __builtin_amdgcn_rcpf((float)max(bw, 1));
+  const int nstep = (npos + 3) >> 2;
+  bw_f4 lo[BWD_NB], hi[BWD_NB];
+  int pos_a[BWD_NB];                                                   // (gy - y0) << 16 | (gx - x0), -1: beyond the box
+  auto request = [&](int s0, int ch) {
+#pragma unroll
+    for (int u = 0; u < BWD_NB; u++) {
+      const int q = 4 * (s0 + u) + kq;
+      const bool ok = q < npos;
+      const int qq = ok ? q : 0;
+      const int ry = (int)(((float)qq + 0.5f) * inv_bw), rx = qq - ry * bw;
+      const float* src = f2 + ((int64_t)(y0 + ry) * W2 + (x0 + rx)) * C + ch;
+      lo[u] = *reinterpret_cast<const bw_f4*>(src);
+      hi[u] = *reinterpret_cast<const bw_f4*>(src + 4);
+      pos_a[u] = ok ? (ry << 16 | rx) : -1;
+    }
+  };
+  if (npos > 0) request(0, 0);
+  wave_lds_fence();
+  // window gradients (correlation_kernel.cu:259-269): the adjoint of the blend; taps outside the frame carry nothing (:182)
+  const float inv_dd = __builtin_amdgcn_rcpf((float)DD), inv_d = __builtin_amdgcn_rcpf((float)D);
+  for (int o = ln; o < PP * DD; o += 64) {
+    const int p = (int)(((float)o + 0.5f) * inv_dd), r_ = o - p * DD;
+    const int a = (int)(((float)r_ + 0.5f) * inv_d), c = r_ - a * D;
+    const float dx = s_frac[wv][0][p], dy = s_frac[wv][1][p];
+    const int pox = s_org[wv][0][p], poy = s_org[wv][1][p];
+    auto G = [&](int aa, int cc) -> float { return (aa >= 0 && aa < Dm && cc >= 0 && cc < Dm) ? s_grad[(cc * Dm + aa) * PP + p] : 0.0f; };
+    float s = 0.0f;
+    s += (1.0f - dx) * (1.0f - dy) * G(a, c);
+    s += dx * (1.0f - dy) * G(a, c - 1);
+    s += (1.0f - dx) * dy * G(a - 1, c);
+    s += dx * dy * G(a - 1, c - 1);
+    const int gy = poy + a, gx = pox + c;
+    if (!(gy >= 0 && gy < H2 && gx >= 0 && gx < W2)) s = 0.0f;
+    s_g[o] = s;
+    gs[be * (PP * DD) + o] = s;                                       // for the frame kernel
+  }
+  if (npos == 0) return;
+  wave_lds_fence();
+  // d_fmap1: rows = the 9 patch pixels (lane m = l % 16; rows 9..15 stay zero), columns = channels, K = 4 box positions per step.
+  const int mp = min(mm, PP - 1);
+  const int dox = x0 - s_org[wv][0][mp], doy = y0 - s_org[wv][1][mp];  // box corner relative to this row's window origin
+  const float* g_mine = s_g + mp * DD;
+  float* g1 = d1 + ((int64_t)b * Np + pi) * C * PP;
+  for (int ch = 0; ch < C; ch += 128) {
+    bw_f4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = bw_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s0 = 0; s0 < nstep; s0 += BWD_NB) {
+      if (s0 > 0 || ch > 0) request(s0, ch);
+      float a[BWD_NB];
+#pragma unroll
+      for (int u = 0; u < BWD_NB; u++) {
+        const int aa = (pos_a[u] >> 16) + doy, cc = (pos_a[u] & 0xffff) + dox;
+        const bool in = pos_a[u] >= 0 && mm < PP && aa >= 0 && aa < D && cc >= 0 && cc < D;
+        const float av = g_mine[in ? aa * D + cc : 0];
+        a[u] = in ? av : 0.0f;                                        // (a zero A row / column makes the clamped loads harmless)
+      }
+      __builtin_amdgcn_sched_barrier(0);                              // all requests first (the scheduler would pair each with its products)
+#pragma unroll
+      for (int u = 0; u < BWD_NB; u++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], lo[u][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], hi[u][j], acc[4 + j], 0, 0, 0);
+      }
+    }
+    // lane (n = mm, kq) holds rows 4 kq + i = patch pixel p, columns = channels ch + 8 n + j.  Through LDS into the tensor's [c][p]
+    // order: consecutive lanes then add to consecutive addresses (scattered float atomics — one cache line per lane — made this
+    // kernel 5x slower than everything else in it).
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int p = 4 * kq + i;
+      if (p < PP) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) s_out[wv][(8 * mm + j) * PP + p] = acc[j][i];
+      }
+    }
+    wave_lds_fence();
+    for (int t = ln; t < 128 * PP; t += 64) atomicAdd(g1 + ch * PP + t, s_out[wv][t]);
+  }
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  if (ln < PP) pairs[((int64_t)frame * cap + slot) * PP + ln] = BwdPair{(int)(be * (PP * DD)) + ln * DD, my_ox, my_oy, (b * Np + (int)pi) * PP + ln};
+}
+
+// ---------------------------------------------------------------------------------------------------------------- per frame tile
+// One workgroup (4 waves) owns an 8 x 8 tile of one frame (x 128 channels per blockIdx.x): wave w the rows 2 w, 2 w + 1.  Every wave scans
+// a quarter of the frame's (edge, pixel) windows — all its loads in flight at once; those that overlap the tile go into one LDS list in
+// list order (count, barrier, write); every wave multiplies the list, BWF_NB K steps requested together.
+constexpr int BWF_SCAN = 9;                     // windows a lane examines per pass: 4 x 64 x 9 = 2304 per workgroup and pass
+constexpr int BWF_NB = 8;
+constexpr int BWF_LIST = 512;                   // windows in the LDS list (8 KB: 16 workgroups per CU)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void corr_bwd_frame_kernel(
+    const float* __restrict__ f1t, const float* __restrict__ gs, const BwdPair* __restrict__ pairs, const int* __restrict__ cursors,
+    float* __restrict__ d2, int n2, int C, int H2, int W2, int64_t s_b, int64_t s_n, int D, int cap, int tiles_x) {
+  __shared__ BwdPair s_ent[BWF_LIST];
+  __shared__ int s_cnt[4];
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int ch = (blockIdx.x / tiles_x) * 128, tx = (blockIdx.x % tiles_x) * 8, ty = blockIdx.y * 8, frame = blockIdx.z;
+  const int npair = min(cursors[frame], cap) * PP;
+  const BwdPair* __restrict__ fp = pairs + (int64_t)frame * cap * PP;
+  const int mm = ln & 15, kq = ln >> 4;
+  const int px = tx + (mm & 7), py = ty + 2 * wv + (mm >> 3);        // this lane's position as an A-operand row
+  bw_f4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) acc[j] = bw_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  const float* fb = f1t + ch + 8 * mm;
+  for (int base = 0; base < npair; base += 256 * BWF_SCAN) {
+    // ---- scan: wave w takes windows base + w * 64 * SCAN ..; the kept ones go into ONE list in list order (count, barrier, write)
+    BwdPair e[BWF_SCAN];
+    const int q0 = base + wv * 64 * BWF_SCAN + ln;
+#pragma unroll
+    for (int u = 0; u < BWF_SCAN; u++) e[u] = fp[min(q0 + 64 * u, npair - 1)];
+    unsigned long long bal[BWF_SCAN];
+    int n_kept = 0;
+#pragma unroll
+    for (int u = 0; u < BWF_SCAN; u++) {
+      const bool hit = q0 + 64 * u < npair && e[u].ox <= tx + 7 && e[u].ox + D > tx && e[u].oy <= ty + 7 && e[u].oy + D > ty;
+      bal[u] = __ballot(hit);
+      n_kept += __popcll(bal[u]);
+    }
+    if (ln == 0) s_cnt[wv] = n_kept;
+    __syncthreads();
+    int first = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const int c = s_cnt[w]; if (w < wv) first += c; total += c; }
+    // the list holds BWF_LIST windows (a level-0 tile keeps ~25 of a pass, a level-1 tile several hundred): chunk by chunk
+    for (int c0 = 0; c0 < total; c0 += BWF_LIST) {
+      int off = first - c0;
+#pragma unroll
+      for (int u = 0; u < BWF_SCAN; u++) {
+        const int slot = off + __popcll(bal[u] & ((1ull << ln) - 1ull));
+        if (((bal[u] >> ln) & 1ull) && slot >= 0 && slot < BWF_LIST) s_ent[slot] = e[u];
+        off += __popcll(bal[u]);
+      }
+      __syncthreads();
+      const int cnt = min(total - c0, BWF_LIST);
+      // ---- K = the kept windows, 4 per step, BWF_NB steps requested together
+      const int nstep = (cnt + 3) >> 2;
+      for (int s0 = 0; s0 < nstep; s0 += BWF_NB) {
+        bw_f4 lo[BWF_NB], hi[BWF_NB];
+        float a[BWF_NB];
+#pragma unroll
+        for (int u = 0; u < BWF_NB; u++) {
+          const int k = 4 * (s0 + u) + kq;
+          const bool ok = k < cnt;
+          const BwdPair en = s_ent[ok ? k : 0];
+          const float* src = fb + (int64_t)en.row * C;
+          lo[u] = *reinterpret_cast<const bw_f4*>(src);
+          hi[u] = *reinterpret_cast<const bw_f4*>(src + 4);
+          const int aa = py - en.oy, cc = px - en.ox;
+          const bool in = ok && aa >= 0 && aa < D && cc >= 0 && cc < D;
+          const float av = gs[in ? en.gs_off + aa * D + cc : 0];
+          a[u] = in ? av : 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < BWF_NB; u++) {
+          if (4 * (s0 + u) >= cnt) break;                             // (uniform: the tail of the last batch)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], lo[u][j], acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], hi[u][j], acc[4 + j], 0, 0, 0);
+        }
+      }
+      __syncthreads();                                                // the list is rewritten by the next chunk / pass
+    }
+  }
+  // lane (n = mm, kq) holds rows 4 kq + i = tile positions, columns = channels ch + 8 n + j: 32 contiguous bytes per position
+  float* out = d2 + (int64_t)(frame / n2) * s_b + (int64_t)(frame % n2) * s_n + ch + 8 * mm;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int m = 4 * kq + i;
+    const int ox_ = tx + (m & 7), oy_ = ty + 2 * wv + (m >> 3);
+    if (ox_ < W2 && oy_ < H2) {
+      float* o = out + ((int64_t)oy_ * W2 + ox_) * C;
+      *reinterpret_cast<bw_f4*>(o) = bw_f4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+      *reinterpret_cast<bw_f4*>(o + 4) = bw_f4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]};
+    }
+  }
+}
+
+}  // namespace devo

@@ -186,6 +186,34 @@ def test_backward_fp32(layout):
     assert_rel(d2, r2, 1e-4, "d_fmap2")
 
 
+@pytest.mark.parametrize("C,R,B,E,H,W", [(128, 3, 1, 300, 20, 24), (256, 3, 1, 120, 12, 20), (128, 1, 1, 90, 20, 24), (128, 5, 1, 90, 33, 41),
+                                          (128, 3, 2, 80, 20, 24), (128, 0, 1, 50, 9, 9)])
+def test_backward_product_form(C, R, B, E, H, W):
+    """channels-last fmap2 with C % 128 == 0 (DEVO: C = 128): d_fmap1 per edge and d_fmap2 per 8 x 8 frame tile as products on the fp32
+    matrix cores (corr_bwd_mfma.h) — no atomics on d_fmap2, every position of every frame written exactly once (frames and tiles no edge
+    touches included: the result tensor is NOT zeroed first).  Frame sizes that are not multiples of the tile, radii 0..5, batch 2,
+    windows partly and wholly outside the frame, many edges per frame (several scan rounds of 256 windows)."""
+    from devo_amd.backends import cuda_corr
+    g = torch.Generator().manual_seed(1000 + C + R + B)
+    n, Np, D = 4, 10, 2 * R + 1
+    f1 = torch.randn(B, Np, C, 3, 3, generator=g) / 4
+    f2 = torch.randn(B, n, C, H, W, generator=g) / 4
+    base = torch.stack([torch.rand(B, E, generator=g) * (W + 12) - 6, torch.rand(B, E, generator=g) * (H + 12) - 6], 2)
+    oy, ox = torch.meshgrid(torch.arange(3.) - 1, torch.arange(3.) - 1, indexing="ij")
+    coords = (base[..., None, None] + 1.3 * torch.stack([ox, oy], 0) + 0.2 * torch.randn(B, E, 2, 3, 3, generator=g)).contiguous()
+    coords[:, 0] = coords[:, 0].round()
+    coords[:, 1] = -40.0
+    ii = torch.randint(0, Np, (E,), generator=g)
+    jj = torch.randint(0, n - 1, (E,), generator=g)                 # the last frame gets no edge at all
+    grad = torch.randn(B, E, D, D, 3, 3, generator=g)
+    r1, r2 = A.corr_backward(f1, f2, coords, ii, jj, grad, R)
+    f2d = channels_last5(f2.to(DEV))
+    d1, d2 = cuda_corr.backward(f1.to(DEV), f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), grad.to(DEV), R)
+    assert d2.stride() == f2d.stride() and torch.count_nonzero(d2[:, n - 1]) == 0
+    assert_rel(d1, r1, 1e-4, "d_fmap1 (product form)")
+    assert_rel(d2, r2, 1e-4, "d_fmap2 (product form)")
+
+
 def test_autograd_layer_and_dropout():
     from devo_amd import altcorr
     f1, f2, coords, ii, jj, R = _case(n=3, Np=12, C=32, H=20, W=24, E=40, seed=23)

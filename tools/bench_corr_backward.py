@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """altcorr backward at the training configuration (BASELINE configuration 3: n = 15, M = 80, E = 18 000; gradients through 20 % of the
-edges, correlation.py:20-25), per pyramid level.  DEVO_CORR_BWD_SEG=1 times the opt-in segment-reduced path (per-edge kernel for
-d_fmap1 + tile kernel for d_fmap2) instead of the default one-kernel atomic path.   python tools/bench_corr_backward.py [keep fraction]"""
+edges, correlation.py:20-25), per pyramid level.  Default: the product form (corr_bwd_mfma.h); DEVO_CORR_BWD_ATOMIC=1: the one-kernel
+atomic path; DEVO_CORR_BWD_SEG=1: the segment-reduced path (per-edge kernel for d_fmap1 + LDS tile kernel for d_fmap2).   python tools/bench_corr_backward.py [keep fraction]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import devo_amd._lib as _L
+if os.environ.get("DEVO_LIB"): _L.LIB_PATH = os.path.abspath(os.environ["DEVO_LIB"])      # A/B builds (tools/build_variant.sh)
 from devo_amd import synth, altcorr
 from devo_amd.backends import cuda_ba, cuda_corr
 
@@ -23,7 +25,7 @@ E = ii.numel()
 sel = torch.rand(E, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) < keep
 c, k2, j2 = coords[:, sel].contiguous(), kk[sel], jj[sel]
 g = torch.randn(1, int(sel.sum()), 7, 7, 3, 3, device=dev)
-mode = "segment-reduced" if os.environ.get("DEVO_CORR_BWD_SEG") else "atomic"
+mode = "segment-reduced" if os.environ.get("DEVO_CORR_BWD_SEG") else "atomic" if os.environ.get("DEVO_CORR_BWD_ATOMIC") else "product form"
 for lvl, (fm, s) in enumerate(((altcorr.channels_last(f0), 1.0), (altcorr.channels_last(f1), 4.0))):
     cs = (c / s).contiguous()
     gm = gmap.to(dev)

@@ -468,20 +468,24 @@ def test_plan_by_several_workgroups_is_a_sorted_permutation(n, M, H, W):
     assert torch.equal(out_plan, out_list)
 
 
-@pytest.mark.parametrize("which", ["staged kernel", "segment-reduced backward"])
+@pytest.mark.parametrize("which", ["staged kernel", "segment-reduced backward", "atomic backward"])
 def test_other_kernels_stay_covered(which):
     """fp32 / fp16 lookups with C = 128 take the per-edge matrix-core kernel by default.  DEVO_CORR_MFMA=0 (read once per process)
-    routes them through the staged tap-centric kernel, DEVO_CORR_BWD_SEG=1 the backward through the tile kernel: same parity tests.
+    routes them through the staged tap-centric kernel, DEVO_CORR_BWD_SEG=1 the backward through the tile kernel, DEVO_CORR_BWD_ATOMIC=1
+    the channels-last C % 128 == 0 backward (product form by default) through the one-kernel atomic path: same parity tests.
     (The region-shared kernel, DEVO_CORR_REGION=1, has its own file: tests/test_gpu_region.py.)"""
-    if os.environ.get("DEVO_CORR_MFMA", "1") == "0" or os.environ.get("DEVO_CORR_BWD_SEG"):
+    if os.environ.get("DEVO_CORR_MFMA", "1") == "0" or os.environ.get("DEVO_CORR_BWD_SEG") or os.environ.get("DEVO_CORR_BWD_ATOMIC"):
         pytest.skip("already running on another kernel")
     env = dict(os.environ)
     sel = "test_forward_fp32 or test_forward_wide_spread or test_channel_blocked or test_fused_pyramid or test_batch_of_two or test_forward_other_radii or test_coord_div"
     if which == "staged kernel":
         env["DEVO_CORR_MFMA"] = "0"
+    elif which == "atomic backward":
+        env["DEVO_CORR_BWD_ATOMIC"] = "1"
+        sel = "test_backward_product_form"
     else:                                                           # opt-in: d_fmap2 tile by tile in LDS instead of global atomics
         env["DEVO_CORR_BWD_SEG"] = "1"
-        sel = "test_backward_fp32 or test_autograd_layer or test_dtype_coverage"
+        sel = "test_backward_fp32 or test_autograd_layer or test_dtype_coverage or test_backward_product_form"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", sel],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1281,7 +1281,7 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
   static const bool no_product = getenv("DEVO_CORR_BWD_ATOMIC") != nullptr || getenv("DEVO_CORR_BWD_SEG") != nullptr;
   const size_t f1t_bytes = (size_t)B * Np * C * PP * 4, pair_bytes = (size_t)frames * (size_t)BE * PP * 16;      // (a frame's window list can hold every edge)
   const bool product = !no_product && BE > 0 && f2s[2] == 1 && f2s[4] == C && f2s[3] == (int64_t)W2 * C && f2s[1] >= (int64_t)H2 * W2 * C &&
-                       C % 128 == 0 && BE * PP * D * D < (1LL << 31) && frames <= 65535 && (H2 + 7) / 8 <= 65535 &&
+                       C % 128 == 0 && BE * PP * D * D < (1LL << 31) && frames <= 65535 && (H2 + 1) / 2 <= 65535 &&
                        gs_bytes + pair_bytes + f1t_bytes <= (1024ull << 20) &&
                        (reinterpret_cast<uintptr_t>(fmap2_grad) & 15) == 0 && (reinterpret_cast<uintptr_t>(fmap2) & 15) == 0 &&
                        f2s[0] % 4 == 0 && f2s[1] % 4 == 0;
@@ -1319,9 +1319,16 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
                        (const float*)fmap2, coords, ii, jj, grad, (float*)fmap1_grad, BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], radius, gs, pairs, cursors,
                        (int)BE);
     const int tiles_x = (W2 + 7) / 8;
-    hipLaunchKernelGGL(corr_bwd_frame_kernel, dim3((unsigned)(tiles_x * (C / 128)), (unsigned)((H2 + 7) / 8), (unsigned)frames), dim3(256), 0, st,
-                       (const float*)f1t, (const float*)gs, (const BwdPair*)pairs, (const int*)cursors, (float*)fmap2_grad, n2, C, H2, W2, f2s[0], f2s[1], D,
-                       (int)BE, tiles_x);
+    // 8 x 8 tiles (4 waves) where that gives every SIMD a few waves, 8 x 2 tiles (1 wave) for small levels (DEVO's level 1)
+    const bool small_level = (long long)tiles_x * (C / 128) * ((H2 + 7) / 8) * frames < 2048;
+    if (small_level)
+      hipLaunchKernelGGL(corr_bwd_frame_kernel<1>, dim3((unsigned)(tiles_x * (C / 128)), (unsigned)((H2 + 1) / 2), (unsigned)frames), dim3(64), 0, st,
+                         (const float*)f1t, (const float*)gs, (const BwdPair*)pairs, (const int*)cursors, (float*)fmap2_grad, n2, C, H2, W2, f2s[0], f2s[1], D,
+                         (int)BE, tiles_x);
+    else
+      hipLaunchKernelGGL(corr_bwd_frame_kernel<4>, dim3((unsigned)(tiles_x * (C / 128)), (unsigned)((H2 + 7) / 8), (unsigned)frames), dim3(256), 0, st,
+                         (const float*)f1t, (const float*)gs, (const BwdPair*)pairs, (const int*)cursors, (float*)fmap2_grad, n2, C, H2, W2, f2s[0], f2s[1], D,
+                         (int)BE, tiles_x);
     const int rc = check_launch("devo_corr_backward");
     (void)hipFreeAsync(scratch, st);
     if (do_btrace) (void)hipFree(btrace);

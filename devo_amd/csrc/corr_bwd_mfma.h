@@ -176,13 +176,16 @@ __global__ __launch_bounds__(64 * BWE_EW) __attribute__((amdgpu_waves_per_eu(1, 
 constexpr int BWF_SCAN = 9;                     // windows a lane examines per pass: 4 x 64 x 9 = 2304 per workgroup and pass
 constexpr int BWF_NB = 8;
 constexpr int BWF_LIST = 512;                   // windows in the LDS list (8 KB: 16 workgroups per CU)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void corr_bwd_frame_kernel(
+// WV waves per workgroup = a tile of 8 x 2 WV positions: 4 (8 x 8) where a level has thousands of tiles, 1 (8 x 2) where it has few (DEVO's
+// level 1: 30 x 40 — 300 tiles of 8 x 8 cannot fill the chip and each keeps several hundred windows; 8 x 2 tiles keep 40 % fewer each).
+template <int WV>
+__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(1, 3))) void corr_bwd_frame_kernel(
     const float* __restrict__ f1t, const float* __restrict__ gs, const BwdPair* __restrict__ pairs, const int* __restrict__ cursors,
     float* __restrict__ d2, int n2, int C, int H2, int W2, int64_t s_b, int64_t s_n, int D, int cap, int tiles_x) {
   __shared__ BwdPair s_ent[BWF_LIST];
-  __shared__ int s_cnt[4];
+  __shared__ int s_cnt[WV];
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  const int ch = (blockIdx.x / tiles_x) * 128, tx = (blockIdx.x % tiles_x) * 8, ty = blockIdx.y * 8, frame = blockIdx.z;
+  const int ch = (blockIdx.x / tiles_x) * 128, tx = (blockIdx.x % tiles_x) * 8, ty = blockIdx.y * (2 * WV), frame = blockIdx.z;
   const int npair = min(cursors[frame], cap) * PP;
   const BwdPair* __restrict__ fp = pairs + (int64_t)frame * cap * PP;
   const int mm = ln & 15, kq = ln >> 4;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
 #pragma unroll
   for (int j = 0; j < 8; j++) acc[j] = bw_f4{0.0f, 0.0f, 0.0f, 0.0f};
   const float* fb = f1t + ch + 8 * mm;
-  for (int base = 0; base < npair; base += 256 * BWF_SCAN) {
+  for (int base = 0; base < npair; base += 64 * WV * BWF_SCAN) {
     // ---- scan: wave w takes windows base + w * 64 * SCAN ..; the kept ones go into ONE list in list order (count, barrier, write)
     BwdPair e[BWF_SCAN];
     const int q0 = base + wv * 64 * BWF_SCAN + ln;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     int n_kept = 0;
 #pragma unroll
     for (int u = 0; u < BWF_SCAN; u++) {
-      const bool hit = q0 + 64 * u < npair && e[u].ox <= tx + 7 && e[u].ox + D > tx && e[u].oy <= ty + 7 && e[u].oy + D > ty;
+      const bool hit = q0 + 64 * u < npair && e[u].ox <= tx + 7 && e[u].ox + D > tx && e[u].oy <= ty + 2 * WV - 1 && e[u].oy + D > ty;
       bal[u] = __ballot(hit);
       n_kept += __popcll(bal[u]);
     }
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     __syncthreads();
     int first = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) { const int c = s_cnt[w]; if (w < wv) first += c; total += c; }
+    for (int w = 0; w < WV; w++) { const int c = s_cnt[w]; if (w < wv) first += c; total += c; }
     // the list holds BWF_LIST windows (a level-0 tile keeps ~25 of a pass, a level-1 tile several hundred): chunk by chunk
     for (int c0 = 0; c0 < total; c0 += BWF_LIST) {
       int off = first - c0;

@@ -462,7 +462,7 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
 from devo_amd import synth
 from devo_amd.backends import cuda_ba
 out = {}
-for nk, M, t0 in ((3, 40, 1), (6, 64, 1), (12, 48, 1), (14, 80, 1), (15, 96, 1), (17, 40, 1), (20, 30, 1), (22, 30, 1)):
+for nk, M, t0 in ((2, 40, 1), (3, 40, 1), (6, 64, 1), (11, 48, 1), (12, 48, 1), (14, 80, 1), (15, 96, 1), (17, 40, 1), (20, 30, 1), (22, 30, 1)):
     poses = synth.make_poses(nk, nk).cuda(); patches = synth.make_patches(nk, M, 120, 160, seed=nk)[0].cuda()
     intr = synth.make_intrinsics(nk, 120, 160).cuda()
     ii, jj, kk = [t.cuda() for t in synth.full_graph(nk, M)]
@@ -476,7 +476,8 @@ torch.save(out, sys.argv[2])
 
 def test_the_one_barrier_solver_returns_the_bits_of_the_two_barrier_form(tmp_path):
     """k_ba_solve_chain (one barrier per block step, panel solved inside the tile waves, 6 N <= 128) performs the operations of k_ba_solve
-    in the same order: the same bits for 2 .. 16 optimised poses (more tiles than tile waves included), agreement for 19 and 21.  DEVO_BA_SOLVE_V1 is read
+    in the same order: the same bits for 1 .. 16 optimised poses (more tiles than tile waves included; the back-substitution's unrolled chain
+    entered at every depth), agreement for 19 and 21.  DEVO_BA_SOLVE_V1 is read
     once per process: both forms run in sub-processes."""
     import subprocess
     import sys

@@ -45,7 +45,7 @@ def parse():
                          "instead of one launch with two workgroups (cuda_ba.prepare(..., plan=...))")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--separate-target", action="store_true", help="form target = coords centre + delta with a torch kernel (devo.py:330) instead of inside the BA")
-    ap.add_argument("--steps-per-graph", type=int, default=10,
+    ap.add_argument("--steps-per-graph", type=int, default=20,
                     help="consecutive steps captured into one HIP graph launch (a graph launch costs ~10 us of idle GPU; 1 = one launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=50, help="launch pairs timed for the roofline figure")

@@ -1203,6 +1203,7 @@ __host__ __device__ inline int solve_ld(int n6) {
 }
 
 __device__ unsigned long long g_solve_stamps[16];
+__device__ unsigned long long g_solve_arrive[24 * 16];      // debug (DEVO_BA_TRACE=7): when every wave reached the barrier of every block step
 // debug (DEVO_BA_TRACE): cycle stamps of the last solve
 
 // GLOBAL (more than BA_MAXN_LDS optimised poses: the image does not fit the LDS): the same algorithm IN PLACE on the global image
@@ -1591,7 +1592,7 @@ __global__ __launch_bounds__(1024) void k_ba_solve_chain(const float* __restrict
   float* Li = Ld + N * 36;                      // [N][36] their inverses (for the back-substitution)
   float* xs = Li + N * 36;                      // [n6] solution
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  constexpr int CHAIN = 15, INVW = 14, NTW = 12;                 // the chain wave, the wave that also inverts L_bb (its tile (4, 1) only exists in the first steps), the number of tile waves
+  constexpr int CHAIN = 15, INVW = 14, NTW = 12;                 // the chain wave, (stamps: the last tile wave), the number of tile waves
   const bool tile_wave = (wv & 3) != 3;
   const int tw = wv - (wv >> 2);                                 // tile waves numbered 0 .. 11
   if (wv == CHAIN) __builtin_amdgcn_s_setprio(3);
@@ -1737,7 +1738,8 @@ __global__ __launch_bounds__(1024) void k_ba_solve_chain(const float* __restrict
   }
   __syncthreads();
   // every role runs its own loop (a taken branch costs ~30 cycles: no role dispatch inside the steps); N barriers each
-  auto step_barrier = []() {
+  auto step_barrier = [&](int jb = -1) {
+    if (stamps == 7 && ln == 0 && jb >= 0 && jb < 24) g_solve_arrive[jb * 16 + wv] = __builtin_readcyclecounter();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1767,43 +1769,41 @@ __global__ __launch_bounds__(1024) void k_ba_solve_chain(const float* __restrict
         factor_and_store(L, jb + 1);
       }
       if (stamps == 1) ph_work += __builtin_readcyclecounter() - pa;
-      step_barrier();
+      step_barrier(jb);
     }
   } else if (tile_wave) {
     for (int jb = 0; jb < N; jb++) {
       const unsigned long long pa = stamps == 1 ? __builtin_readcyclecounter() : 0ull;
       const int T = (rows - 6 * jb - 6 + 15) >> 4, ntl = T * (T + 1) / 2;
-      if ((tw < ntl || wv == INVW) && stamps != 2) {
+      // the inverse of L_bb (for the back-substitution) is the job of the first tile wave WITHOUT a tile in this step (the last one while
+      // all have tiles): in the late steps, where one to three tiles are left, it is not on the step's critical path
+      const bool do_inv = tw == min(ntl, NTW - 1);
+      if ((tw < ntl || do_inv) && stamps != 2) {
         float Lb[6][6], inv[6];
         load_factor(jb, Lb, inv);
         if (tw < ntl) do_tile(my_tile, jb, Lb, inv);
         for (int t = tw + NTW; t < ntl; t += NTW) do_tile(make_tile(t), jb, Lb, inv);      // (more than 12 tiles: the first steps of 13+ poses)
-        if (wv == INVW) {                                           // the inverse of L_bb, for the back-substitution
-          float X[6][6];
+        if (do_inv) {                                               // lane c < 6: column c of L^-1 by forward substitution
+          const int c = min(ln, 5);
+          float X[6];
 #pragma unroll
-          for (int c = 0; c < 6; c++) {                             // column c of L^-1 by forward substitution
+          for (int a = 0; a < 6; a++) {
+            float v = (a == c) ? 1.0f : 0.0f;
 #pragma unroll
-            for (int a = 0; a < 6; a++) {
-              if (a < c) { X[a][c] = 0.0f; continue; }
-              float v = (a == c) ? 1.0f : 0.0f;
-#pragma unroll
-              for (int k = 0; k < a; k++) if (k >= c) v -= Lb[a][k] * X[k][c];
-              X[a][c] = v * inv[a];
-            }
+            for (int k = 0; k < a; k++) v -= Lb[a][k] * X[k];      // (rows above c are exact zeros: the same sums as a triangular loop)
+            X[a] = v * inv[a];
           }
-          if (ln == 0) {
+          if (ln < 6) {
 #pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-              for (int c = 0; c < 6; c++) Li[jb * 36 + a * 6 + c] = X[a][c];
+            for (int a = 0; a < 6; a++) Li[jb * 36 + a * 6 + c] = X[a];
           }
         }
       }
       if (stamps == 1) ph_work += __builtin_readcyclecounter() - pa;
-      step_barrier();
+      step_barrier(jb);
     }
   } else {
-    for (int jb = 0; jb < N; jb++) step_barrier();
+    for (int jb = 0; jb < N; jb++) step_barrier(jb);
   }
   const unsigned long long st2 = stamps ? __builtin_readcyclecounter() : 0ull;
   if (stamps && ln == 0 && (wv == CHAIN || wv == 0 || wv == INVW)) g_solve_stamps[wv == CHAIN ? 6 : wv == 0 ? 8 : 9] = ph_work;
@@ -2629,6 +2629,20 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
         unsigned long long h[16];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_solve_stamps), sizeof(h));
+        if (solve_fn == k_ba_solve_chain && ba_trace_mode == 7) {
+          unsigned long long arr[24 * 16];
+          (void)hipMemcpyFromSymbol(arr, HIP_SYMBOL(g_solve_arrive), sizeof(arr));
+          fprintf(stderr, "[ba trace] arrival at the step barrier, cycles after the step's first arrival (waves 0..15; * = last), and the step's length:\n");
+          unsigned long long prev_last = 0;
+          for (int jb = 0; jb < N && jb < 24; jb++) {
+            unsigned long long lo = ~0ull, hi = 0; int last = 0;
+            for (int w = 0; w < 16; w++) { const unsigned long long v = arr[jb * 16 + w]; if (v < lo) lo = v; if (v > hi) { hi = v; last = w; } }
+            fprintf(stderr, "  step %2d:", jb);
+            for (int w = 0; w < 16; w++) fprintf(stderr, " %5llu%s", arr[jb * 16 + w] - lo, w == last ? "*" : " ");
+            fprintf(stderr, "   | %llu\n", prev_last ? hi - prev_last : 0ull);
+            prev_last = hi;
+          }
+        }
         if (solve_fn == k_ba_solve_chain)
           fprintf(stderr, "[ba trace] solve (one barrier per step): load %llu, factorisation %llu, back substitution %llu cycles (work inside the steps: chain wave %llu, tile wave 0 %llu, inverse wave %llu)\n", h[1] - h[0], h[2] - h[1], h[4] - h[3], h[6], h[8], h[9]);
         else

@@ -6,7 +6,9 @@
 #include <stdio.h>
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-// PARTS bit 0: factor load, 1: substitution, 2: tile read / write, 3: matrix cores, 4: partner exchange, 5: transposed panel store
+// PARTS bit 0: factor load, 1: substitution, 2: tile read / write, 3: matrix cores, 4: partner exchange, 5: transposed panel store,
+// bit 7: as bit 6, with the broadcast folded into the substitution's instructions (v_fmac_f32_dpp / v_mul_f32_dpp, inline asm)
+// bit 6: the factor as TWO ds_read_b32 (lane l holds compact entry l % 16) + DPP row_newbcast operands instead of 7 broadcast reads
 template <int PARTS>
 __global__ void k_tiles(unsigned long long* out, float* sink, int iters, int active) {
   constexpr int LD = 100, N = 14, rows = 85;
@@ -35,6 +37,32 @@ __global__ void k_tiles(unsigned long long* out, float* sink, int iters, int act
     if (wv < active) {
       const int j0 = 6 * jb, j1 = j0 + 6;
       float Lb[6][6], inv[6];
+      if (PARTS & 64) {
+        const float r0 = Ld[jb * 36 + (ln & 15)], r1 = Ld[jb * 36 + 16 + (ln & 7)];
+#define BC(v, k) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + (k), 0xf, 0xf, true))
+        Lb[1][0] = BC(r0, 0);
+        Lb[2][0] = BC(r0, 1);
+        Lb[2][1] = BC(r0, 2);
+        Lb[3][0] = BC(r0, 3);
+        Lb[3][1] = BC(r0, 4);
+        Lb[3][2] = BC(r0, 5);
+        Lb[4][0] = BC(r0, 6);
+        Lb[4][1] = BC(r0, 7);
+        Lb[4][2] = BC(r0, 8);
+        Lb[4][3] = BC(r0, 9);
+        Lb[5][0] = BC(r0, 10);
+        Lb[5][1] = BC(r0, 11);
+        Lb[5][2] = BC(r0, 12);
+        Lb[5][3] = BC(r0, 13);
+        Lb[5][4] = BC(r0, 14);
+        inv[0] = BC(r0, 15);
+        inv[1] = BC(r1, 0);
+        inv[2] = BC(r1, 1);
+        inv[3] = BC(r1, 2);
+        inv[4] = BC(r1, 3);
+        inv[5] = BC(r1, 4);
+#undef BC
+      } else
 #pragma unroll
       for (int a = 0; a < 6; a++) {
 #pragma unroll
@@ -53,6 +81,36 @@ __global__ void k_tiles(unsigned long long* out, float* sink, int iters, int act
         dst[i] = (jb < thr[i]) ? p0 + i * LD : s_dump + ln;
         c[i] = (PARTS & 4) ? *dst[i] : 0.0f;
       }
+      if (PARTS & 128) {
+        const float r0 = Ld[jb * 36 + (ln & 15)], r1 = Ld[jb * 36 + 16 + (ln & 7)];
+        { float t = v[0];
+          asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:15 row_mask:0xf bank_mask:0xf" : "=v"(x[0]) : "v"(r0), "v"(t)); }
+        { float t = v[1];
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[0]));
+          asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(x[1]) : "v"(r1), "v"(t)); }
+        { float t = v[2];
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[0]));
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[1]));
+          asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf" : "=v"(x[2]) : "v"(r1), "v"(t)); }
+        { float t = v[3];
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[0]));
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[1]));
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[2]));
+          asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf" : "=v"(x[3]) : "v"(r1), "v"(t)); }
+        { float t = v[4];
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:6 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[0]));
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:7 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[1]));
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[2]));
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:9 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[3]));
+          asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(x[4]) : "v"(r1), "v"(t)); }
+        { float t = v[5];
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:10 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[0]));
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:11 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[1]));
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:12 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[2]));
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:13 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[3]));
+          asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:14 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(r0), "v"(x[4]));
+          asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf" : "=v"(x[5]) : "v"(r1), "v"(t)); }
+      } else
       if (PARTS & 2) {
 #pragma unroll
         for (int cc = 0; cc < 6; cc++) {
@@ -121,5 +179,7 @@ int main() {
   run<47>("without the partner exchange", d, sink);
   run<31>("without the transposed panel", d, sink);
   run<0>("nothing but the operand rows", d, sink);
+  run<63 + 64>("everything, factor through DPP row_newbcast", d, sink);
+  run<62 + 128>("factor folded into v_fmac_f32_dpp / v_mul_f32_dpp", d, sink);
   return 0;
 }

@@ -45,3 +45,20 @@ def test_training_bench_on_two_ranks_sharing_the_gpu():
     _keep("bench_train_gpus2_share.json", line)
     assert d["n_gpus"] == 2 and d["value"] > 0
     assert "dp2" in d["config"]["parallelism"] or "2" in d["config"]["parallelism"]
+
+
+def test_update_op_bench_under_the_drivers_launch_command():
+    """the contract's launch for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` — bench.py reads RANK / LOCAL_RANK / WORLD_SIZE from the environment instead of spawning;
+    rank 0 prints the one JSON line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "20", "--warmup", "5", "--no-f16", "--no-cpu-baseline", "--no-train-probe"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    _keep("bench_torchrun_gpus2_share.json", lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0 and d["scaling"] == "weak"

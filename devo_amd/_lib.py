@@ -26,7 +26,8 @@ _SIGNATURES = {
     "devo_corr_patch_transpose": [_vp, _vp, _i, _i, _i, _vp],
     "devo_pyramid_build": [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i, _vp],
     "devo_corr_order": [_vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_float, _i, _i, _i, _vp],
-    "devo_corr_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i64, _i, _i, _vp],
+    "devo_corr_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i64, _i, _i, _vp, ctypes.c_size_t, _vp],
+    "devo_corr_backward_workspace_bytes": [_i, _i, _i, _i, _i, _i],
     "devo_patchify_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _c_i64p, _i, _i, _vp],
     "devo_patchify_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "devo_ba_workspace_bytes": [_i, _i, _i],
@@ -70,7 +71,8 @@ for _n in ("mul", "adj", "adjT", "act", "act4"):
     _SIGNATURES[f"devo_se3_{_n}_backward"] = [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]
 _SIGNATURES["devo_se3_as_matrix"] = [_vp, _vp, _i64, _i, _vp]
 _SIGNATURES["devo_se3_jinv"] = [_vp, _vp, _vp, _i64, _i, _vp]
-_RESTYPE = {"devo_last_error": ctypes.c_char_p, "devo_voxel_std_workspace_bytes": _sz, "devo_ba_workspace_bytes": _sz, "devo_neighbors_workspace_bytes": _sz}
+_RESTYPE = {"devo_last_error": ctypes.c_char_p, "devo_voxel_std_workspace_bytes": _sz, "devo_ba_workspace_bytes": _sz, "devo_neighbors_workspace_bytes": _sz,
+             "devo_corr_backward_workspace_bytes": _sz}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -223,9 +223,11 @@ def backward(fmap1, fmap2, coords, ii, jj, grad, radius):
     d1 = torch.empty_like(fmap1)
     d2 = torch.empty_strided(fmap2.shape, fmap2.stride(), dtype=fmap2.dtype, device=fmap2.device)
     span = 1 + sum((s - 1) * st for s, st in zip(fmap2.shape, fmap2.stride()))
+    nws = int(L.lib().devo_corr_backward_workspace_bytes(B, E, Np, n2, C, int(radius)))      # scratch of the product form (torch's caching allocator)
+    ws = torch.empty(nws, dtype=torch.uint8, device=fmap1.device) if nws else None
     rc = L.lib().devo_corr_backward(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(ii), L.ptr(jj), L.ptr(grad),
                                     L.ptr(d1), L.ptr(d2), B, E, Np, n2, C, P, H2, W2, L.i64arr(fmap2.stride()), span,
-                                    int(radius), L.dtype_code(fmap1), L.stream())
+                                    int(radius), L.dtype_code(fmap1), L.ptr(ws) if ws is not None else None, nws, L.stream())
     L.check(rc, "cuda_corr.backward")
     return [d1, d2]
 

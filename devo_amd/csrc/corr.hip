@@ -1252,10 +1252,19 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   return check_launch("devo_corr_order");
 }
 
+size_t devo_corr_backward_workspace_bytes(int B, int E, int Np, int n2, int C, int radius) {
+  if (B <= 0 || E <= 0 || Np <= 0 || n2 <= 0 || C <= 0 || radius < 0) return 0;
+  const size_t BE = (size_t)B * E, D = 2 * (size_t)radius + 2, frames = (size_t)B * n2;
+  const size_t gs = BE * PP * D * D * 4, product = ((gs + 15) & ~(size_t)15) + frames * BE * PP * 16 + (size_t)B * Np * C * PP * 4 + frames * 4;
+  const size_t seg = gs + BE * sizeof(BwdMeta) + frames * BE * 4 + frames * 4;
+  const size_t need = product > seg ? product : seg;
+  return need <= ((size_t)1024 << 20) ? need : 0;                // (larger problems take the one-kernel atomic path, which needs none)
+}
+
 int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                        const int64_t* jj, const float* grad, void* fmap1_grad, void* fmap2_grad, int B, int E, int Np,
                        int n2, int C, int P, int H2, int W2, const int64_t* f2s, int64_t f2_numel_span, int radius,
-                       int dtype, devo_stream_t stream) {
+                       int dtype, void* ws, size_t ws_bytes, devo_stream_t stream) {
   DEVO_REQUIRE(P == 3, "devo_corr_backward: patch size P must be 3 (got %d)", P);
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_backward: radius %d unsupported (max 5)", radius);
   if (dtype != DEVO_F32) { set_error("devo_corr_backward: fp32 only (the reference's grad accessor is float)"); return DEVO_ERR_UNSUPPORTED; }
@@ -1275,12 +1284,14 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
   const size_t tile_lds = (size_t)BH * W2 * BWD_CS * 4 + 4 * 64 * 12 * 4;
   const bool seg = !force_atomic && BE > 0 && f2s[2] == 1 && f2s[4] == C && f2s[3] == (int64_t)W2 * C && f2s[1] >= (int64_t)H2 * W2 * C &&
                    C % BWD_CS == 0 && tile_lds <= 54 * 1024 && gs_bytes + meta_bytes + list_bytes <= (512ull << 20) && BE < (1LL << 31) &&
-                   frames <= 65535 && (H2 + BH - 1) / BH <= 65535 && (reinterpret_cast<uintptr_t>(fmap2_grad) & 15) == 0;
+                   frames <= 65535 && (H2 + BH - 1) / BH <= 65535 && (reinterpret_cast<uintptr_t>(fmap2_grad) & 15) == 0 &&
+                   ws != nullptr && ws_bytes >= gs_bytes + meta_bytes + list_bytes + (size_t)frames * 4 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0;
   // Product form (default where it applies; DEVO_CORR_BWD_ATOMIC=1: the one-kernel atomic path): channels-last fmap2 with C % 128 == 0 —
   // d_fmap1 per edge and d_fmap2 per frame tile as matrix-core products, no atomics on d_fmap2 (corr_bwd_mfma.h).
   static const bool no_product = getenv("DEVO_CORR_BWD_ATOMIC") != nullptr || getenv("DEVO_CORR_BWD_SEG") != nullptr;
   const size_t f1t_bytes = (size_t)B * Np * C * PP * 4, pair_bytes = (size_t)frames * (size_t)BE * PP * 16;      // (a frame's window list can hold every edge)
-  const bool product = !no_product && BE > 0 && f2s[2] == 1 && f2s[4] == C && f2s[3] == (int64_t)W2 * C && f2s[1] >= (int64_t)H2 * W2 * C &&
+  const size_t product_ws = ((gs_bytes + 15) & ~(size_t)15) + pair_bytes + f1t_bytes + (size_t)frames * 4;
+  const bool product = !no_product && BE > 0 && ws != nullptr && ws_bytes >= product_ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && f2s[2] == 1 && f2s[4] == C && f2s[3] == (int64_t)W2 * C && f2s[1] >= (int64_t)H2 * W2 * C &&
                        C % 128 == 0 && BE * PP * D * D < (1LL << 31) && frames <= 65535 && (H2 + 1) / 2 <= 65535 &&
                        gs_bytes + pair_bytes + f1t_bytes <= (1024ull << 20) &&
                        (reinterpret_cast<uintptr_t>(fmap2_grad) & 15) == 0 && (reinterpret_cast<uintptr_t>(fmap2) & 15) == 0 &&
@@ -1306,9 +1317,8 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
     (void)hipFree(btrace);
   };
   if (product) {
-    char* scratch = nullptr;
-    const size_t pair_off = (gs_bytes + 15) & ~(size_t)15, f1t_off = pair_off + pair_bytes, cur_off = f1t_off + f1t_bytes, total = cur_off + (size_t)frames * 4;
-    if (hipMallocAsync((void**)&scratch, total, st) != hipSuccess) { (void)hipGetLastError(); set_error("devo_corr_backward: scratch allocation failed"); return DEVO_ERR_LAUNCH; }
+    char* scratch = reinterpret_cast<char*>(ws);
+    const size_t pair_off = (gs_bytes + 15) & ~(size_t)15, f1t_off = pair_off + pair_bytes, cur_off = f1t_off + f1t_bytes;
     float* gs = reinterpret_cast<float*>(scratch);
     BwdPair* pairs = reinterpret_cast<BwdPair*>(scratch + pair_off);
     float* f1t = reinterpret_cast<float*>(scratch + f1t_off);
@@ -1330,14 +1340,12 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
                          (const float*)f1t, (const float*)gs, (const BwdPair*)pairs, (const int*)cursors, (float*)fmap2_grad, n2, C, H2, W2, f2s[0], f2s[1], D,
                          (int)BE, tiles_x);
     const int rc = check_launch("devo_corr_backward");
-    (void)hipFreeAsync(scratch, st);
     if (do_btrace) (void)hipFree(btrace);
     return rc;
   }
   if (seg) {
-    char* scratch = nullptr;
-    const size_t cur_off = gs_bytes + meta_bytes + list_bytes, total = cur_off + (size_t)frames * 4;
-    if (hipMallocAsync((void**)&scratch, total, st) != hipSuccess) { (void)hipGetLastError(); set_error("devo_corr_backward: scratch allocation failed"); return DEVO_ERR_LAUNCH; }
+    char* scratch = reinterpret_cast<char*>(ws);
+    const size_t cur_off = gs_bytes + meta_bytes + list_bytes;
     float* gs = reinterpret_cast<float*>(scratch);
     BwdMeta* meta = reinterpret_cast<BwdMeta*>(scratch + gs_bytes);
     int* lists = reinterpret_cast<int*>(scratch + gs_bytes + meta_bytes);
@@ -1350,9 +1358,7 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
                        tile_lds, st, (const float*)fmap1, gs, meta, lists, cursors, (float*)fmap2_grad, n2, C, H2, W2, f2s[0], f2s[1], f2s[3],
                        f2s[4], D, BH, (int)BE);
     dump_trace();
-    const int rc = check_launch("devo_corr_backward");
-    (void)hipFreeAsync(scratch, st);
-    return rc;
+    return check_launch("devo_corr_backward");
   }
   hipLaunchKernelGGL((radius <= 3 ? corr_bwd_kernel<false, 3> : corr_bwd_kernel<false, 5>), dim3((unsigned)BE), dim3(NT), 0, st, (const float*)fmap1,
                      (const float*)fmap2, coords, ii, jj, grad, (float*)fmap1_grad, (float*)fmap2_grad, E, Np, n2, C, H2,

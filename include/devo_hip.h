@@ -108,12 +108,16 @@ int devo_pyramid_build(const void* fmap, void* l0, void* l1, int F, int C, int H
 /* cuda_corr.backward  (correlation.cpp:59 -> correlation_kernel.cu:236-286, kernel :139-190).
  *   grad f32: the gradient of the logical [B,E,D-1,D-1,P,P] output, contiguous.
  *   fmap1_grad [B,Np,C,P,P] contiguous, fmap2_grad with the strides of fmap2: both are ZEROED and then
- *   accumulated here.  DEVO_F32 only (the reference's grad accessor is float, :146,280). */
+ *   accumulated here.  DEVO_F32 only (the reference's grad accessor is float, :146,280).
+ *   ws / ws_bytes: scratch of devo_corr_backward_workspace_bytes(B, E, Np, n2, C, radius) bytes, 16-byte aligned (the window gradients,
+ *   the frames' window lists, fmap1 transposed: the product form for channels-last fmap2 with C % 128 == 0).  NULL or
+ *   too small: the one-kernel atomic path, which needs none.  The library never allocates. */
+size_t devo_corr_backward_workspace_bytes(int B, int E, int Np, int n2, int C, int radius);
 int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                        const int64_t* jj, const float* grad, void* fmap1_grad, void* fmap2_grad, int B, int E,
                        int Np, int n2, int C, int P, int H2, int W2, const int64_t* f2s /* host, 5 */,
                        int64_t f2_numel_span /* elements spanned by fmap2 storage */, int radius, int dtype,
-                       devo_stream_t stream);
+                       void* ws, size_t ws_bytes, devo_stream_t stream);
 
 /* cuda_corr.patchify_forward  (correlation.cpp:61 -> correlation_kernel.cu:288-307, kernel :16-47).
  *   net T [B, C, H, W] with element strides ns[4]; coords f32 [B, M, 2]; out T [B, M, C, D, D] contiguous

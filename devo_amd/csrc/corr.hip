@@ -1325,7 +1325,7 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
     int* cursors = reinterpret_cast<int*>(scratch + cur_off);
     hipLaunchKernelGGL(corr_bwd_patch_t_kernel, dim3((unsigned)(B * Np)), dim3(256), (size_t)C * PP * 4, st, (const float*)fmap1, f1t, (float*)fmap1_grad, cursors,
                        (int)frames, B * Np, C);
-    hipLaunchKernelGGL((radius <= 3 ? corr_bwd_edge_kernel<3> : corr_bwd_edge_kernel<5>), dim3((unsigned)((BE + BWE_EW - 1) / BWE_EW)), dim3(64 * BWE_EW), 0, st,
+    hipLaunchKernelGGL((radius <= 3 ? corr_bwd_edge_kernel<3> : corr_bwd_edge_kernel<5>), dim3((unsigned)BE), dim3(64 * BWE_KS), 0, st,
                        (const float*)fmap2, coords, ii, jj, grad, (float*)fmap1_grad, BE, E, Np, n2, C, H2, W2, f2s[0], f2s[1], radius, gs, pairs, cursors,
                        (int)BE);
     const int tiles_x = (W2 + 7) / 8;

@@ -34,40 +34,39 @@ __global__ __launch_bounds__(256) void corr_bwd_patch_t_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------------- per edge
-// One wave per edge (EW edges per workgroup).  G from the edge's gradient block, d_fmap1 on the matrix cores, hand-over.
-// Every dependent global round trip costs ~4 us while all waves of the launch are resident, so the K loop requests BWD_NB steps (= 4 NB
-// box positions: 32 bytes per lane each) at once and multiplies them afterwards: 27 steps of a 107-position box are 4 round trips.
-constexpr int BWE_EW = 4;                       // edges (waves) per workgroup
+// One workgroup of 4 waves per edge.  The gradient block becomes G (each wave forms a quarter; LDS + a global copy), then every wave takes
+// a QUARTER of the box positions for d_fmap1 on the matrix cores: a 107-position box is 27 K steps = 7 per wave = ONE request batch, so a
+// wave's chain of dependent global round trips is indices / coordinates / gradient block -> features -> done (each costs 7-8 us while the
+// whole launch is resident: with one wave per edge and four batches the kernel took 59 us, profiles/r03_corr_backward.txt).  The four
+// partial d_fmap1 are added in LDS, in the tensor's [c][p] order, and leave as ONE set of coalesced atomics.
+constexpr int BWE_KS = 4;                       // waves per edge = parts of the K range
 constexpr int BWD_NB = 8;                       // K steps requested together
 struct BwdPair { int gs_off, ox, oy, row; };    // one (edge, patch pixel) window for the frame kernel: offset of its G, origin, row of fmap1_t
 template <int RMAX>
-__global__ __launch_bounds__(64 * BWE_EW) __attribute__((amdgpu_waves_per_eu(1, 3))) void corr_bwd_edge_kernel(      // (room for the batch's 72 registers)
+__global__ __launch_bounds__(64 * BWE_KS) __attribute__((amdgpu_waves_per_eu(1, 4))) void corr_bwd_edge_kernel(
     const float* __restrict__ fmap2, const float* __restrict__ coords, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
     const float* __restrict__ grad, float* __restrict__ d1, long long BE, int E, int Np, int n2, int C, int H2, int W2, int64_t s_b,
     int64_t s_n, int R, float* __restrict__ gs, BwdPair* __restrict__ pairs, int* __restrict__ cursors, int cap) {
   constexpr int DMX = 2 * RMAX + 2;
-  __shared__ float s_g_all[BWE_EW][PP * DMX * DMX];
-  __shared__ float s_grad_all[BWE_EW][(DMX - 1) * (DMX - 1) * PP];
-  __shared__ float s_frac[BWE_EW][2][PP];                              // blend weights dx, dy per patch pixel
-  __shared__ int s_org[BWE_EW][2][PP];                                // window origins ox, oy
-  __shared__ float s_out[BWE_EW][128 * PP];                           // a channel half of the edge's d_fmap1 in the tensor's [c][p] order
-  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-  const long long be = (long long)blockIdx.x * BWE_EW + wv;
-  if (be >= BE) return;                                               // (wave-uniform; no workgroup barrier below)
-  float* s_g = s_g_all[wv];
-  float* s_grad = s_grad_all[wv];
+  __shared__ float s_g[PP * DMX * DMX];
+  __shared__ float s_grad[(DMX - 1) * (DMX - 1) * PP];
+  __shared__ float s_frac[2][PP];                                      // blend weights dx, dy per patch pixel
+  __shared__ int s_org[2][PP];                                        // window origins ox, oy
+  __shared__ __attribute__((aligned(16))) float s_out[BWE_KS][128 * PP];   // the waves' partial d_fmap1 of a channel half, [c][p] order
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const long long be = blockIdx.x;
   const int D = 2 * R + 2, Dm = D - 1, DD = D * D;
   const int b = (int)(be / E), e = (int)(be % E);
   const int64_t pi = ii[e], fj = jj[e];
   float cx = 0.0f, cy = 0.0f;
-  if (ln < PP) { cx = coords[(be * 2 + 0) * PP + ln]; cy = coords[(be * 2 + 1) * PP + ln]; }
-  {                                                                    // (in flight together with the coordinates)
+  if (ln < PP) { cx = coords[(be * 2 + 0) * PP + ln]; cy = coords[(be * 2 + 1) * PP + ln]; }      // (every wave: the box without a barrier)
+  {
     const float* g = grad + be * Dm * Dm * PP;
     const int ng = Dm * Dm * PP;
-    for (int i = ln; i < ng; i += 64) s_grad[i] = g[i];
+    for (int i = tid; i < ng; i += 64 * BWE_KS) s_grad[i] = g[i];
   }
   const int my_ox = floor_to_int(cx) - R, my_oy = floor_to_int(cy) - R;
-  if (ln < PP) { s_org[wv][0][ln] = my_ox; s_org[wv][1][ln] = my_oy; s_frac[wv][0][ln] = cx - floorf(cx); s_frac[wv][1][ln] = cy - floorf(cy); }
+  if (tid < PP) { s_org[0][tid] = my_ox; s_org[1][tid] = my_oy; s_frac[0][tid] = cx - floorf(cx); s_frac[1][tid] = cy - floorf(cy); }
   int xmin = 1 << 30, xmax = -(1 << 30), ymin = 1 << 30, ymax = -(1 << 30);
 #pragma unroll
   for (int p = 0; p < PP; p++) {
@@ -76,22 +75,22 @@ __global__ __launch_bounds__(64 * BWE_EW) __attribute__((amdgpu_waves_per_eu(1, 
   }
   const int x0 = max(xmin, 0), x1 = min(xmax + D, W2), y0 = max(ymin, 0), y1 = min(ymax + D, H2);
   const int bw = max(x1 - x0, 0), npos = bw * max(y1 - y0, 0);
+  if (npos == 0) return;                                              // (uniform over the workgroup: nothing of this edge is inside the frame)
   const int frame = b * n2 + (int)fj;
-  // the edge's slot in its frame's window list (order: whoever comes first); the returned value is only needed after the first products
-  int slot = 0;
-  if (ln == 0 && npos > 0) slot = atomicAdd(&cursors[frame], 1);
-  // the first batch of feature rows is requested BEFORE the window gradients are formed (it only needs the box)
+  int slot = 0;                                                       // the edge's slot in its frame's window list (order: whoever comes first)
+  if (tid == 0) slot = atomicAdd(&cursors[frame], 1);
+  // this wave's quarter of the K steps: requested now, before the window gradients exist (it only needs the box)
   const int mm = ln & 15, kq = ln >> 4;
   const float* __restrict__ f2 = fmap2 + (int64_t)b * s_b + fj * s_n + 8 * mm;          // this lane's 8 channels (+ 128 per channel half)
-  const float inv_bw = __builtin_amdgcn_rcpf((float)max(bw, 1));
-  const int nstep = (npos + 3) >> 2;
+  const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
+  const int nstep = (npos + 3) >> 2, per = (nstep + BWE_KS - 1) / BWE_KS, sa = wv * per, sb = min(nstep, sa + per);
   bw_f4 lo[BWD_NB], hi[BWD_NB];
-  int pos_a[BWD_NB];                                                   // (gy - y0) << 16 | (gx - x0), -1: beyond the box
+  int pos_a[BWD_NB];                                                   // (gy - y0) << 16 | (gx - x0), -1: beyond this wave's part
   auto request = [&](int s0, int ch) {
 #pragma unroll
     for (int u = 0; u < BWD_NB; u++) {
       const int q = 4 * (s0 + u) + kq;
-      const bool ok = q < npos;
+      const bool ok = s0 + u < sb && q < npos;
       const int qq = ok ? q : 0;
       const int ry = (int)(((float)qq + 0.5f) * inv_bw), rx = qq - ry * bw;
       const float* src = f2 + ((int64_t)(y0 + ry) * W2 + (x0 + rx)) * C + ch;
@@ -100,15 +99,15 @@ __global__ __launch_bounds__(64 * BWE_EW) __attribute__((amdgpu_waves_per_eu(1, 
       pos_a[u] = ok ? (ry << 16 | rx) : -1;
     }
   };
-  if (npos > 0) request(0, 0);
-  wave_lds_fence();
+  request(sa, 0);
+  __syncthreads();                                                    // gradient block, origins, blend weights
   // window gradients (correlation_kernel.cu:259-269): the adjoint of the blend; taps outside the frame carry nothing (:182)
   const float inv_dd = __builtin_amdgcn_rcpf((float)DD), inv_d = __builtin_amdgcn_rcpf((float)D);
-  for (int o = ln; o < PP * DD; o += 64) {
+  for (int o = tid; o < PP * DD; o += 64 * BWE_KS) {
     const int p = (int)(((float)o + 0.5f) * inv_dd), r_ = o - p * DD;
     const int a = (int)(((float)r_ + 0.5f) * inv_d), c = r_ - a * D;
-    const float dx = s_frac[wv][0][p], dy = s_frac[wv][1][p];
-    const int pox = s_org[wv][0][p], poy = s_org[wv][1][p];
+    const float dx = s_frac[0][p], dy = s_frac[1][p];
+    const int pox = s_org[0][p], poy = s_org[1][p];
     auto G = [&](int aa, int cc) -> float { return (aa >= 0 && aa < Dm && cc >= 0 && cc < Dm) ? s_grad[(cc * Dm + aa) * PP + p] : 0.0f; };
     float s = 0.0f;
     s += (1.0f - dx) * (1.0f - dy) * G(a, c);
@@ -120,19 +119,18 @@ __global__ __launch_bounds__(64 * BWE_EW) __attribute__((amdgpu_waves_per_eu(1, 
     s_g[o] = s;
     gs[be * (PP * DD) + o] = s;                                       // for the frame kernel
   }
-  if (npos == 0) return;
-  wave_lds_fence();
+  __syncthreads();
   // d_fmap1: rows = the 9 patch pixels (lane m = l % 16; rows 9..15 stay zero), columns = channels, K = 4 box positions per step.
   const int mp = min(mm, PP - 1);
-  const int dox = x0 - s_org[wv][0][mp], doy = y0 - s_org[wv][1][mp];  // box corner relative to this row's window origin
+  const int dox = x0 - s_org[0][mp], doy = y0 - s_org[1][mp];          // box corner relative to this row's window origin
   const float* g_mine = s_g + mp * DD;
   float* g1 = d1 + ((int64_t)b * Np + pi) * C * PP;
   for (int ch = 0; ch < C; ch += 128) {
     bw_f4 acc[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = bw_f4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int s0 = 0; s0 < nstep; s0 += BWD_NB) {
-      if (s0 > 0 || ch > 0) request(s0, ch);
+    for (int s0 = sa; s0 < sb; s0 += BWD_NB) {
+      if (s0 > sa || ch > 0) request(s0, ch);
       float a[BWD_NB];
 #pragma unroll
       for (int u = 0; u < BWD_NB; u++) {
@@ -150,10 +148,10 @@ __global__ __launch_bounds__(64 * BWE_EW) __attribute__((amdgpu_waves_per_eu(1, 
         for (int j = 0; j < 4; j++) acc[4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], hi[u][j], acc[4 + j], 0, 0, 0);
       }
     }
-    // lane (n = mm, kq) holds rows 4 kq + i = patch pixel p, columns = channels ch + 8 n + j.  Through LDS into the tensor's [c][p]
-    // order: consecutive lanes then add to consecutive addresses (scattered float atomics — one cache line per lane — made this
-    // kernel 5x slower than everything else in it).
-    wave_lds_fence();
+    // lane (n = mm, kq) holds rows 4 kq + i = patch pixel p, columns = channels ch + 8 n + j.  Into LDS in the tensor's [c][p] order, the four
+    // waves' partials added there: consecutive threads then add to consecutive addresses (scattered float atomics — one cache line per
+    // lane — made the first version 5x slower than everything else in it).
+    if (ch > 0) __syncthreads();                                      // (the previous half's sums have been read)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int p = 4 * kq + i;
@@ -162,11 +160,18 @@ __global__ __launch_bounds__(64 * BWE_EW) __attribute__((amdgpu_waves_per_eu(1, 
         for (int j = 0; j < 8; j++) s_out[wv][(8 * mm + j) * PP + p] = acc[j][i];
       }
     }
-    wave_lds_fence();
-    for (int t = ln; t < 128 * PP; t += 64) atomicAdd(g1 + ch * PP + t, s_out[wv][t]);
+    __syncthreads();
+    for (int t = tid; t < 128 * PP; t += 64 * BWE_KS) {
+      float v = s_out[0][t];
+#pragma unroll
+      for (int w = 1; w < BWE_KS; w++) v += s_out[w][t];
+      atomicAdd(g1 + ch * PP + t, v);
+    }
   }
-  slot = __builtin_amdgcn_readfirstlane(slot);
-  if (ln < PP) pairs[((int64_t)frame * cap + slot) * PP + ln] = BwdPair{(int)(be * (PP * DD)) + ln * DD, my_ox, my_oy, (b * Np + (int)pi) * PP + ln};
+  if (wv == 0) {
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (ln < PP) pairs[((int64_t)frame * cap + slot) * PP + ln] = BwdPair{(int)(be * (PP * DD)) + ln * DD, my_ox, my_oy, (b * Np + (int)pi) * PP + ln};
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- per frame tile

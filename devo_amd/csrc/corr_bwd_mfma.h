@@ -184,7 +184,10 @@ constexpr int BWF_LIST = 512;                   // windows in the LDS list (8 KB
 // WV waves per workgroup = a tile of 8 x 2 WV positions: 4 (8 x 8) where a level has thousands of tiles, 1 (8 x 2) where it has few (DEVO's
 // level 1: 30 x 40 — 300 tiles of 8 x 8 cannot fill the chip and each keeps several hundred windows; 8 x 2 tiles keep 40 % fewer each).
 template <int WV>
-__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(1, 3))) void corr_bwd_frame_kernel(
+#ifndef BWF_WAVES
+#define BWF_WAVES 4, 4                          // (64 VGPRs: 58 instead of 64 us at level 0 in the same run; 6, 6 and 8, 8 spill)
+#endif
+__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(BWF_WAVES))) void corr_bwd_frame_kernel(
     const float* __restrict__ f1t, const float* __restrict__ gs, const BwdPair* __restrict__ pairs, const int* __restrict__ cursors,
     float* __restrict__ d2, int n2, int C, int H2, int W2, int64_t s_b, int64_t s_n, int D, int cap, int tiles_x) {
   __shared__ BwdPair s_ent[BWF_LIST];

@@ -30,7 +30,7 @@ def prepare(kk, n_patch_slots, n_opt, ws, plan=None):
     else:
         buf, n_frames, height = plan
         L.require_gpu(buf)
-        if buf.dtype != torch.int32 or buf.numel() < 2 * kk.numel() + 1:
+        if buf.dtype != torch.int32 or buf.numel() < 2 * kk.numel() + 2:
             raise RuntimeError("cuda_ba.prepare: plan must be the int32 [2E+2] buffer of transform(..., plan_for=...)")
         rc = L.lib().devo_ba_prepare_plan(L.ptr(kk), kk.numel(), int(n_patch_slots), int(n_opt), L.ptr(ws), ws.numel(),
                                           L.ptr(buf), int(n_frames), int(height), L.stream())

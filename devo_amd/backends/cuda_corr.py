@@ -22,6 +22,7 @@ def _prep(fmap1, fmap2, coords, ii, jj, allow_blocked=False):
 
 import os
 REGION_KERNEL = os.environ.get("DEVO_CORR_REGION", "0") == "1"   # opt-in region-shared lookup kernel (corr_region.h; the library reads the same switch)
+MM_KERNEL = os.environ.get("DEVO_CORR_MM", "1") != "0"          # dense-product lookup kernel (corr_mm.h) for fused two-level lookups; False: the 4x4 matrix-core kernel
 PLAN_MIN_EDGES = 2048      # below this the lookup is launch-bound and a locality plan cannot pay for itself
 NCHW_CONVERT_MIN_EDGES = 1024    # from here on a lookup into the reference's NCHW pyramid goes through a cached channel-blocked copy
 
@@ -105,11 +106,14 @@ def patches_transposed(fmap1):
     kernel.  DEVO's patch features change once per frame, not per update iteration: the copy is cached per version of the tensor
     (same key discipline as _fast_layout)."""
     key = (fmap1.data_ptr(), fmap1._version, tuple(fmap1.shape), fmap1.dtype)
-    hit = _patch_t_cache.get(key)
+    hit = _patch_t_cache.pop(key, None)
     if hit is not None:
+        _patch_t_cache[key] = hit                             # (most recently used last)
         return hit[1]
-    for k in [k for k in _patch_t_cache if k[0] == key[0] or len(_patch_t_cache) >= 4]:
-        del _patch_t_cache[k]
+    for k in [k for k in _patch_t_cache if k[0] == key[0]]:
+        del _patch_t_cache[k]                                 # an older version of this tensor
+    while len(_patch_t_cache) >= BLOCKED_CACHE_ENTRIES:       # least recently used first
+        del _patch_t_cache[next(iter(_patch_t_cache))]
     B, Np, C = fmap1.shape[:3]
     t = torch.empty(B, Np, 9, C, dtype=fmap1.dtype, device=fmap1.device)
     rc = L.lib().devo_corr_patch_transpose(L.ptr(fmap1), L.ptr(t), B * Np, C, L.dtype_code(fmap1), L.stream())
@@ -191,7 +195,9 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
         cb = (ctypes.c_int * 2)(d0[3], d1[3])
         cd = (ctypes.c_float * 2)(float(scales[0]), float(scales[1]))
         # the region-shared kernel wants the patches as [Np, 9, C] (cached per version of fmap1) and a plan
-        f1t = patches_transposed(f1) if (REGION_KERNEL and order is not None and P == 3 and f1.shape[3] == 3) else None
+        # ... and so does the dense-product kernel (corr_mm.h), plan or not
+        want_t = (MM_KERNEL and C % 32 == 0) or (REGION_KERNEL and order is not None)
+        f1t = patches_transposed(f1) if (want_t and P == 3 and f1.shape[3] == 3) else None
         rc = L.lib().devo_corr_forward_pyramid2(L.ptr(f1), L.ptr(pyramid[0]), L.ptr(pyramid[1]), L.ptr(c_), L.ptr(ii_), L.ptr(jj_),
                                                 L.ptr(out), B, E, Np, pyramid[0].shape[1], C, P, hw, L.i64arr(d0[2] + d1[2]), cb,
                                                 per * nl, nl, L.i64arr([0, 1]), int(radius), L.dtype_code(f1), L.ptr(order), cd,
@@ -205,8 +211,40 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
     return out
 
 
+_cl_cache = {}             # (ptr, version, shape, strides, dtype) -> (source tensor [kept alive], channels-last copy); LRU
+last_backward_path = None  # "product" | "segments" | "atomic": what the last backward() launched (devo_corr_backward_last_path)
+
+
+def _channels_last_copy(fmap2):
+    """fmap2 [B, n, C, H, W] in any layout -> the same logical tensor with channels-last strides (a [B, n, H, W, C] buffer viewed
+    as [B, n, C, H, W]), cached per version of the tensor with _fast_layout's key discipline: a training step calls backward() once
+    per update iteration and level on the SAME pyramid tensors (enet.py:203-216), so the copy is made once per step and level."""
+    key = (fmap2.data_ptr(), fmap2._version, tuple(fmap2.shape), tuple(fmap2.stride()), fmap2.dtype)
+    hit = _cl_cache.pop(key, None)
+    if hit is not None:
+        _cl_cache[key] = hit
+        return hit[1]
+    for k in [k for k in _cl_cache if k[0] == key[0]]:
+        del _cl_cache[k]
+    while len(_cl_cache) >= BLOCKED_CACHE_ENTRIES:
+        del _cl_cache[next(iter(_cl_cache))]
+    cl = fmap2.detach().permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+    _cl_cache[key] = (fmap2, cl)
+    return cl
+
+
+def _is_channels_last(fmap2):
+    B, n, C, H, W = fmap2.shape
+    st = fmap2.stride()
+    return st[2] == 1 and st[4] == C and st[3] == W * C and st[1] >= H * W * C
+
+
 def backward(fmap1, fmap2, coords, ii, jj, grad, radius):
-    """correlation.cpp:59 -> [fmap1_grad, fmap2_grad] (fp32 only, like the reference's float grad accessor)."""
+    """correlation.cpp:59 -> [fmap1_grad, fmap2_grad] (fp32 only, like the reference's float grad accessor).
+    fmap2_grad has fmap2's logical shape; for a plain NCHW fmap2 with C % 128 == 0 and >= NCHW_CONVERT_MIN_EDGES edges (what an
+    unmodified enet.py hands over) it carries channels-last strides: the product form (corr_bwd_mfma.h) reads a cached channels-last
+    copy of fmap2 and writes the gradient in that layout — autograd takes a gradient in any strides."""
+    global last_backward_path
     fmap1, fmap2, coords, ii, jj = _prep(fmap1, fmap2, coords, ii, jj)
     L.require_gpu(grad)
     if fmap1.dtype != torch.float32:
@@ -221,14 +259,26 @@ def backward(fmap1, fmap2, coords, ii, jj, grad, radius):
     n2, H2, W2 = fmap2.shape[1], fmap2.shape[3], fmap2.shape[4]
     grad = grad.float().contiguous()
     d1 = torch.empty_like(fmap1)
-    d2 = torch.empty_strided(fmap2.shape, fmap2.stride(), dtype=fmap2.dtype, device=fmap2.device)
+    cl = _is_channels_last(fmap2)
+    if (not cl and C % 128 == 0 and B * E >= NCHW_CONVERT_MIN_EDGES and os.environ.get("DEVO_CORR_NCHW_DIRECT", "0") != "1"
+            and int(L.lib().devo_corr_backward_workspace_bytes(B, E, Np, n2, C, int(radius), 1)) > 0):
+        fmap2 = _channels_last_copy(fmap2)
+        cl = True
+    if cl:
+        d2 = torch.empty(B, n2, H2, W2, C, dtype=fmap2.dtype, device=fmap2.device).permute(0, 1, 4, 2, 3)
+        if fmap2.stride() != d2.stride():                     # (channels-last frames with a padded frame stride)
+            d2 = torch.empty_strided(fmap2.shape, fmap2.stride(), dtype=fmap2.dtype, device=fmap2.device)
+    else:
+        d2 = torch.empty_strided(fmap2.shape, fmap2.stride(), dtype=fmap2.dtype, device=fmap2.device)
     span = 1 + sum((s - 1) * st for s, st in zip(fmap2.shape, fmap2.stride()))
-    nws = int(L.lib().devo_corr_backward_workspace_bytes(B, E, Np, n2, C, int(radius)))      # scratch of the product form (torch's caching allocator)
+    # scratch of the product form (torch's caching allocator); 0 for layouts that take the one-kernel atomic path
+    nws = int(L.lib().devo_corr_backward_workspace_bytes(B, E, Np, n2, C, int(radius), 1 if cl else 0))
     ws = torch.empty(nws, dtype=torch.uint8, device=fmap1.device) if nws else None
     rc = L.lib().devo_corr_backward(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(ii), L.ptr(jj), L.ptr(grad),
                                     L.ptr(d1), L.ptr(d2), B, E, Np, n2, C, P, H2, W2, L.i64arr(fmap2.stride()), span,
                                     int(radius), L.dtype_code(fmap1), L.ptr(ws) if ws is not None else None, nws, L.stream())
     L.check(rc, "cuda_corr.backward")
+    last_backward_path = ("atomic", "segments", "product")[int(L.lib().devo_corr_backward_last_path())]
     return [d1, d2]
 
 

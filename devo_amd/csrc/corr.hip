@@ -165,6 +165,7 @@ struct CorrLevel {
   unsigned frame_bytes;           // extent of one frame (all blocks) in bytes: the buffer-load bound of the matrix-core kernel
   bool staged_ok, mfma_ok;        // which of the two fast kernels can read this level
   bool region_ok;                 // ... and the region-shared kernel (corr_region.h)
+  bool mm_ok;                     // ... and the dense-product kernel (corr_mm.h)
   int64_t out_offset;             // element offset of this level inside an edge's output record
   float coord_div;                // coordinates are divided by this (pyramid level scale)
 };
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 }
 
 #include "corr_mfma.h"
+#include "corr_mm.h"
 #include "corr_region.h"
 
 // -------------------------------------------------------------------------------------------------
@@ -922,6 +924,8 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
                 frame_bytes < (1LL << 31);                                                             // 32-bit in-frame offsets
   // the region-shared kernel: 16-byte pieces inside a channel block (or channels-last), any C that is a multiple of its slab
   lv->region_ok = aligned && sizeof(T) <= 4 && corr_region_enabled() && cb_ok && C % (sizeof(T) == 2 ? 32 : 16) == 0 && frame_bytes < (1LL << 31);
+  // the dense-product kernel (corr_mm.h): 16-byte pieces of 8 (fp16) / 4 (fp32) channels inside a channel block, 32 channels per K step
+  lv->mm_ok = lv->mfma_ok && C % 32 == 0 && (sizeof(T) == 2 ? C <= 256 : C <= 128);
   if (!lv->staged_ok && !lv->mfma_ok && !lv->region_ok) {
     if (blocked) {
       set_error("devo_corr_forward: channel-blocked fmap2 needs fp32 / fp16, 16-byte aligned strides and cblock == %d (got %d)", KC, cblock);
@@ -1021,6 +1025,63 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
     (void)hipFree(trace);
   }
   return check_launch("devo_corr_forward");
+}
+
+// Dense-product lookup (corr_mm.h): both levels of an edge in one wave, the patch operand from its transposed copy fmap1_t.
+static bool corr_mm_enabled() {                  // DEVO_CORR_MM=0: the 4x4 matrix-core kernel (corr_mfma.h: exact fp32 products) instead
+  static const char* env = getenv("DEVO_CORR_MM");
+  static const bool on = !(env && env[0] == '0');
+  return on;
+}
+template <typename T>
+static bool mm_eligible(const CorrLevel& l0, const CorrLevel& l1, const void* fmap1_t, long long BE, int Np, int C) {
+  return corr_mm_enabled() && fmap1_t != nullptr && l0.mm_ok && l1.mm_ok && (long long)Np * C * PP * (long long)sizeof(T) < (1LL << 40) &&
+         BE < (1LL << 30) && (reinterpret_cast<uintptr_t>(fmap1_t) & 15) == 0;
+}
+template <typename T>
+static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel& lv1, const float* coords, const int64_t* ii,
+                     const int64_t* jj, void* out, long long BE, int E, int Np, int n2, int C, int64_t oes, int64_t ols, int R,
+                     const int* order, hipStream_t st) {
+  typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;
+  typedef void (*mm_fn_t)(const MT*, CorrLevel, CorrLevel, int, const float*, const int64_t*, const int64_t*, MT*, int, int, int, int, int,
+                          int64_t, int64_t, int, const int*, int, unsigned long long*);
+  const int nks = C / 32;
+  mm_fn_t fn = nullptr;
+#define DEVO_MM_PICK(NKS) (R <= 3 ? corr_fwd_mm_kernel<MT, 3, NKS, 2> : corr_fwd_mm_kernel<MT, 5, NKS, 2>)
+  if constexpr (sizeof(MT) == 2) fn = nks == 1 ? DEVO_MM_PICK(1) : nks == 2 ? DEVO_MM_PICK(2) : nks == 4 ? DEVO_MM_PICK(4) : nks == 8 ? DEVO_MM_PICK(8) : nullptr;
+  else fn = nks == 1 ? DEVO_MM_PICK(1) : nks == 2 ? DEVO_MM_PICK(2) : nks == 4 ? DEVO_MM_PICK(4) : nullptr;
+#undef DEVO_MM_PICK
+  if (!fn) { set_error("devo_corr_forward_pyramid2: C = %d not supported by the dense-product kernel", C); return DEVO_ERR_UNSUPPORTED; }
+  unsigned long long* trace = nullptr;                                // debug switch: per-wave cycle stamps to stderr
+  const bool do_trace = getenv("DEVO_CORR_TRACE") != nullptr;
+  if (do_trace) { (void)hipMalloc(&trace, (size_t)BE * 64); (void)hipMemset(trace, 0, (size_t)BE * 64); }
+  hipLaunchKernelGGL(fn, dim3((unsigned)BE), dim3(64), 0, st, (const MT*)fmap1_t, lv0, lv1, 2, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C,
+                     oes, ols, R, order, 0, trace);
+  if (do_trace) {
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)BE * 8);
+    (void)hipMemcpy(h.data(), trace, (size_t)BE * 64, hipMemcpyDeviceToHost);
+    double ph[4] = {0, 0, 0, 0}, sum = 0, mx = 0, tiles = 0;
+    unsigned long long tmin = ~0ull, tmax = 0;
+    long cnt = 0;
+    for (long long i = 0; i < BE; i++) {
+      const unsigned long long* t = &h[(size_t)i * 8];
+      if (!t[4]) continue;
+      for (int q = 0; q < 4; q++) ph[q] += (double)(t[q + 1] - t[q]);
+      const double d = (double)(t[4] - t[0]);
+      sum += d; if (d > mx) mx = d;
+      tiles += (double)(t[5] % 1000 + t[5] / 1000);
+      if (t[0] < tmin) tmin = t[0];
+      if (t[4] > tmax) tmax = t[4];
+      cnt++;
+    }
+    if (!cnt) cnt = 1;
+    fprintf(stderr, "[corr mm trace] %ld waves, kernel span %.0f cycles; wave mean %.0f max %.0f cycles; phase means: plan slot + indices + coordinates %.0f, "
+            "geometry + patch operand + first tiles %.0f, tile loop %.0f, epilogue %.0f; %.1f tiles per edge\n",
+            cnt, (double)(tmax - tmin), sum / cnt, mx, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, tiles / cnt);
+    (void)hipFree(trace);
+  }
+  return check_launch("devo_corr_forward_pyramid2 (dense-product kernel)");
 }
 
 // Region-shared lookup (corr_region.h) of a two-level pyramid with a locality plan: the plan's heavy slots go to the per-edge
@@ -1197,12 +1258,16 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
          staged_level<float>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
     if (ok && out_lstride > 0 && out_lstride < (1LL << 20) && region_eligible<float>(l0, l1, fmap1_t, order, BE, E, Np, C, radius))
       return launch_region<float>(fmap1, fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
+    if (ok && out_lstride > 0 && mm_eligible<float>(l0, l1, fmap1_t, BE, Np, C))
+      return launch_mm<float>(fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
     if (ok) return launch_staged<float>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
   } else if (dtype == DEVO_F16) {
     ok = staged_level<__half>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0) &&
          staged_level<__half>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
     if (ok && out_lstride > 0 && out_lstride < (1LL << 20) && region_eligible<__half>(l0, l1, fmap1_t, order, BE, E, Np, C, radius))
       return launch_region<__half>(fmap1, fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
+    if (ok && out_lstride > 0 && mm_eligible<__half>(l0, l1, fmap1_t, BE, Np, C))
+      return launch_mm<__half>(fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
     if (ok) return launch_staged<__half>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
   }
   // not both levels readable by the staged kernel: the caller issues one devo_corr_forward per level instead
@@ -1252,13 +1317,19 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   return check_launch("devo_corr_order");
 }
 
-size_t devo_corr_backward_workspace_bytes(int B, int E, int Np, int n2, int C, int radius) {
+static thread_local int g_corr_bwd_path = -1;                      // what the last devo_corr_backward of this thread launched
+int devo_corr_backward_last_path(void) { return g_corr_bwd_path; }
+
+size_t devo_corr_backward_workspace_bytes(int B, int E, int Np, int n2, int C, int radius, int channels_last) {
   if (B <= 0 || E <= 0 || Np <= 0 || n2 <= 0 || C <= 0 || radius < 0) return 0;
+  if (!channels_last) return 0;                                    // every other layout takes the one-kernel atomic path, which needs none
   const size_t BE = (size_t)B * E, D = 2 * (size_t)radius + 2, frames = (size_t)B * n2;
   const size_t gs = BE * PP * D * D * 4, product = ((gs + 15) & ~(size_t)15) + frames * BE * PP * 16 + (size_t)B * Np * C * PP * 4 + frames * 4;
   const size_t seg = gs + BE * sizeof(BwdMeta) + frames * BE * 4 + frames * 4;
-  const size_t need = product > seg ? product : seg;
-  return need <= ((size_t)1024 << 20) ? need : 0;                // (larger problems take the one-kernel atomic path, which needs none)
+  static const bool want_seg = getenv("DEVO_CORR_BWD_SEG") != nullptr, want_atomic = getenv("DEVO_CORR_BWD_ATOMIC") != nullptr;
+  if (want_seg) return seg <= ((size_t)512 << 20) ? seg : 0;       // (the opt-in segment-reduced path is sized on its own)
+  if (want_atomic || C % 128 != 0) return 0;
+  return product <= ((size_t)1024 << 20) ? product : 0;            // (larger problems take the atomic path)
 }
 
 int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
@@ -1293,6 +1364,7 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
   const size_t product_ws = ((gs_bytes + 15) & ~(size_t)15) + pair_bytes + f1t_bytes + (size_t)frames * 4;
   const bool product = !no_product && BE > 0 && ws != nullptr && ws_bytes >= product_ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && f2s[2] == 1 && f2s[4] == C && f2s[3] == (int64_t)W2 * C && f2s[1] >= (int64_t)H2 * W2 * C &&
                        C % 128 == 0 && BE * PP * D * D < (1LL << 31) && frames <= 65535 && (H2 + 1) / 2 <= 65535 &&
+                       W2 <= 32767 && H2 <= 32767 && (long long)H2 * W2 < (1LL << 22) &&      // (the edge kernel packs ry << 16 | rx and splits q with an fp32 reciprocal)
                        gs_bytes + pair_bytes + f1t_bytes <= (1024ull << 20) &&
                        (reinterpret_cast<uintptr_t>(fmap2_grad) & 15) == 0 && (reinterpret_cast<uintptr_t>(fmap2) & 15) == 0 &&
                        f2s[0] % 4 == 0 && f2s[1] % 4 == 0;
@@ -1301,6 +1373,7 @@ int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords
     set_error("devo_corr_backward: memset failed");
     return DEVO_ERR_LAUNCH;
   }
+  g_corr_bwd_path = product ? DEVO_CORR_BWD_PRODUCT : seg ? DEVO_CORR_BWD_SEGMENTS : DEVO_CORR_BWD_ATOMIC;
   if (BE == 0) return DEVO_OK;
   unsigned long long* btrace = nullptr;                               // debug switch: phase cycles of the per-edge kernel to stderr
   static const bool do_btrace = getenv("DEVO_CORR_BWD_TRACE") != nullptr;

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(BWF_WAV
     const float* __restrict__ f1t, const float* __restrict__ gs, const BwdPair* __restrict__ pairs, const int* __restrict__ cursors,
     float* __restrict__ d2, int n2, int C, int H2, int W2, int64_t s_b, int64_t s_n, int D, int cap, int tiles_x) {
   __shared__ BwdPair s_ent[BWF_LIST];
-  __shared__ int s_cnt[WV];
+  __shared__ int s_cnt[2][WV];                                        // by pass parity: a pass that keeps nothing has no barrier after its reads
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int ch = (blockIdx.x / tiles_x) * 128, tx = (blockIdx.x % tiles_x) * 8, ty = blockIdx.y * (2 * WV), frame = blockIdx.z;
   const int npair = min(cursors[frame], cap) * PP;
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(BWF_WAV
 #pragma unroll
   for (int j = 0; j < 8; j++) acc[j] = bw_f4{0.0f, 0.0f, 0.0f, 0.0f};
   const float* fb = f1t + ch + 8 * mm;
-  for (int base = 0; base < npair; base += 64 * WV * BWF_SCAN) {
+  int par = 0;
+  for (int base = 0; base < npair; base += 64 * WV * BWF_SCAN, par ^= 1) {
     // ---- scan: wave w takes windows base + w * 64 * SCAN ..; the kept ones go into ONE list in list order (count, barrier, write)
     BwdPair e[BWF_SCAN];
     const int q0 = base + wv * 64 * BWF_SCAN + ln;
@@ -216,11 +217,11 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(BWF_WAV
       bal[u] = __ballot(hit);
       n_kept += __popcll(bal[u]);
     }
-    if (ln == 0) s_cnt[wv] = n_kept;
+    if (ln == 0) s_cnt[par][wv] = n_kept;                             // (pass p + 2 rewrites this half behind pass p + 1's barrier: every wave has read it)
     __syncthreads();
     int first = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < WV; w++) { const int c = s_cnt[w]; if (w < wv) first += c; total += c; }
+    for (int w = 0; w < WV; w++) { const int c = s_cnt[par][w]; if (w < wv) first += c; total += c; }
     // the list holds BWF_LIST windows (a level-0 tile keeps ~25 of a pass, a level-1 tile several hundred): chunk by chunk
     for (int c0 = 0; c0 < total; c0 += BWF_LIST) {
       int off = first - c0;

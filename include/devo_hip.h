@@ -109,10 +109,16 @@ int devo_pyramid_build(const void* fmap, void* l0, void* l1, int F, int C, int H
  *   grad f32: the gradient of the logical [B,E,D-1,D-1,P,P] output, contiguous.
  *   fmap1_grad [B,Np,C,P,P] contiguous, fmap2_grad with the strides of fmap2: both are ZEROED and then
  *   accumulated here.  DEVO_F32 only (the reference's grad accessor is float, :146,280).
- *   ws / ws_bytes: scratch of devo_corr_backward_workspace_bytes(B, E, Np, n2, C, radius) bytes, 16-byte aligned (the window gradients,
- *   the frames' window lists, fmap1 transposed: the product form for channels-last fmap2 with C % 128 == 0).  NULL or
- *   too small: the one-kernel atomic path, which needs none.  The library never allocates. */
-size_t devo_corr_backward_workspace_bytes(int B, int E, int Np, int n2, int C, int radius);
+ *   ws / ws_bytes: scratch of devo_corr_backward_workspace_bytes(B, E, Np, n2, C, radius, channels_last) bytes, 16-byte aligned (the
+ *   window gradients, the frames' window lists, fmap1 transposed: the product form for channels-last fmap2 with C % 128 == 0,
+ *   DESIGN.md 3.2).  channels_last = 1 when the C channels of a pixel of fmap2 are contiguous and pixels / rows are C / W*C elements
+ *   apart; every other layout takes the one-kernel atomic path and the query returns 0.  NULL or too small: the atomic path as well.
+ *   The library never allocates.  devo_corr_backward_last_path(): which path the calling thread's last devo_corr_backward took. */
+#define DEVO_CORR_BWD_ATOMIC   0
+#define DEVO_CORR_BWD_SEGMENTS 1
+#define DEVO_CORR_BWD_PRODUCT  2
+size_t devo_corr_backward_workspace_bytes(int B, int E, int Np, int n2, int C, int radius, int channels_last);
+int devo_corr_backward_last_path(void);
 int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                        const int64_t* jj, const float* grad, void* fmap1_grad, void* fmap2_grad, int B, int E,
                        int Np, int n2, int C, int P, int H2, int W2, const int64_t* f2s /* host, 5 */,

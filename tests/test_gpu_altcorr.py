@@ -181,7 +181,9 @@ def test_backward_fp32(layout):
     if layout == "cl":
         f2d = channels_last5(f2d)
     d1, d2 = cuda_corr.backward(f1.to(DEV), f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), g.to(DEV), R)
-    assert d2.stride() == f2d.stride()
+    # C = 64: never the product form; channels-last under DEVO_CORR_BWD_SEG=1 (test_other_kernels_stay_covered): the tile kernel
+    want = "segments" if (os.environ.get("DEVO_CORR_BWD_SEG") and layout == "cl") else "atomic"
+    assert d2.stride() == f2d.stride() and cuda_corr.last_backward_path == want
     assert_rel(d1, r1, 1e-4, "d_fmap1")
     assert_rel(d2, r2, 1e-4, "d_fmap2")
 
@@ -209,9 +211,64 @@ def test_backward_product_form(C, R, B, E, H, W):
     r1, r2 = A.corr_backward(f1, f2, coords, ii, jj, grad, R)
     f2d = channels_last5(f2.to(DEV))
     d1, d2 = cuda_corr.backward(f1.to(DEV), f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), grad.to(DEV), R)
+    assert cuda_corr.last_backward_path == ("atomic" if os.environ.get("DEVO_CORR_BWD_ATOMIC") else "segments" if os.environ.get("DEVO_CORR_BWD_SEG") else "product")
     assert d2.stride() == f2d.stride() and torch.count_nonzero(d2[:, n - 1]) == 0
     assert_rel(d1, r1, 1e-4, "d_fmap1 (product form)")
     assert_rel(d2, r2, 1e-4, "d_fmap2 (product form)")
+
+
+def test_backward_product_form_four_wave_tiles_with_empty_passes():
+    """corr_bwd_frame_kernel<4> (8 x 8 tiles, what DEVO's level 0 takes in training): >= 2048 tiles in the launch, 600 edges = 5400
+    windows per frame = three scan passes of 2304, all of them in the left part of the frame — every tile to the right keeps nothing in
+    ANY pass (consecutive passes without a list barrier: the counts are double-buffered by pass parity), tiles at the cluster's border
+    keep something in some passes only."""
+    from devo_amd.backends import cuda_corr
+    g = torch.Generator().manual_seed(77)
+    B, n, Np, C, H, W, R, per = 1, 4, 40, 128, 128, 256, 3, 600
+    E = per * (n - 1)
+    f1 = torch.randn(B, Np, C, 3, 3, generator=g) / 4
+    f2 = torch.randn(B, n, C, H, W, generator=g) / 4
+    base = torch.stack([torch.rand(B, E, generator=g) * 110 - 6, torch.rand(B, E, generator=g) * (H + 12) - 6], 2)
+    oy, ox = torch.meshgrid(torch.arange(3.) - 1, torch.arange(3.) - 1, indexing="ij")
+    coords = (base[..., None, None] + 1.3 * torch.stack([ox, oy], 0) + 0.2 * torch.randn(B, E, 2, 3, 3, generator=g)).contiguous()
+    ii = torch.randint(0, Np, (E,), generator=g)
+    jj = torch.arange(E) % (n - 1)                                   # the last frame gets no edge at all
+    grad = torch.randn(B, E, 7, 7, 3, 3, generator=g)
+    r1, r2 = A.corr_backward(f1, f2, coords, ii, jj, grad, R)
+    f2d = channels_last5(f2.to(DEV))
+    for _ in range(3):                                               # (a race shows up as a hang or as a wrong tile in SOME run)
+        d1, d2 = cuda_corr.backward(f1.to(DEV), f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), grad.to(DEV), R)
+        assert cuda_corr.last_backward_path == "product"
+        assert torch.count_nonzero(d2[:, n - 1]) == 0 and torch.count_nonzero(d2[..., 130:]) == 0
+        assert_rel(d1, r1, 1e-4, "d_fmap1 (product form, 8 x 8 tiles)")
+        assert_rel(d2, r2, 1e-4, "d_fmap2 (product form, 8 x 8 tiles)")
+
+
+def test_backward_nchw_takes_the_product_form():
+    """What an unmodified enet.py hands over (enet.py:203-216): a plain NCHW fp32 pyramid level, C = 128.  From 1024 edges on the
+    backward reads a cached channels-last copy and returns fmap2_grad with fmap2's shape and channels-last strides."""
+    from devo_amd.backends import cuda_corr
+    f1, f2, coords, ii, jj, R = _case(n=3, Np=30, C=128, H=24, W=32, E=1100, seed=23)
+    g = torch.randn(1, 1100, 7, 7, 3, 3, generator=torch.Generator().manual_seed(2))
+    r1, r2 = A.corr_backward(f1, f2, coords, ii, jj, g, R)
+    f2d = f2.to(DEV)
+    for rep in range(2):                                             # second call: the cached copy
+        d1, d2 = cuda_corr.backward(f1.to(DEV), f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), g.to(DEV), R)
+        assert cuda_corr.last_backward_path == "product"
+        assert d2.shape == f2d.shape and d2.stride(2) == 1
+        assert_rel(d1, r1, 1e-4, "d_fmap1 (NCHW, product form)")
+        assert_rel(d2, r2, 1e-4, "d_fmap2 (NCHW, product form)")
+    f2d[0, 0, 0, 0, 0] += 1.0                                        # an in-place write bumps the version: the copy is rebuilt
+    f2[0, 0, 0, 0, 0] += 1.0
+    r1, r2 = A.corr_backward(f1, f2, coords, ii, jj, g, R)
+    d1, d2 = cuda_corr.backward(f1.to(DEV), f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), g.to(DEV), R)
+    assert_rel(d1, r1, 1e-4, "d_fmap1 (NCHW, product form, after an in-place write)")
+    # through autograd, like CorrLayer.backward: the gradient arrives at the NCHW leaf
+    from devo_amd import altcorr
+    leaf = f2.to(DEV).requires_grad_(True)
+    out = altcorr.corr(f1.to(DEV), leaf, coords.to(DEV), ii.to(DEV), jj.to(DEV), R)
+    out.backward(g.to(DEV))
+    assert_rel(leaf.grad, r2, 1e-4, "d_fmap2 through autograd")
 
 
 def test_autograd_layer_and_dropout():

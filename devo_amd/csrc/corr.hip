@@ -1047,7 +1047,8 @@ static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel&
                           int64_t, int64_t, int, const int*, int, unsigned long long*);
   const int nks = C / 32;
   mm_fn_t fn = nullptr;
-#define DEVO_MM_PICK(NKS) (R <= 3 ? corr_fwd_mm_kernel<MT, 3, NKS, 2> : corr_fwd_mm_kernel<MT, 5, NKS, 2>)
+#define DEVO_MM_PICK(NKS) (R == 3 ? corr_fwd_mm_kernel<MT, 3, NKS, 2, 3> : R == 5 ? corr_fwd_mm_kernel<MT, 5, NKS, 2, 5> : \
+                           R < 3 ? corr_fwd_mm_kernel<MT, 3, NKS, 2, 0> : corr_fwd_mm_kernel<MT, 5, NKS, 2, 0>)
   if constexpr (sizeof(MT) == 2) fn = nks == 1 ? DEVO_MM_PICK(1) : nks == 2 ? DEVO_MM_PICK(2) : nks == 4 ? DEVO_MM_PICK(4) : nks == 8 ? DEVO_MM_PICK(8) : nullptr;
   else fn = nks == 1 ? DEVO_MM_PICK(1) : nks == 2 ? DEVO_MM_PICK(2) : nks == 4 ? DEVO_MM_PICK(4) : nullptr;
 #undef DEVO_MM_PICK

@@ -10,8 +10,9 @@
 //     channel blocks of 32 halves (64-byte cells) the 64 lanes of an instruction read whole cache lines: every line of an edge's box
 //     passes the L1's tag lookup once per edge instead of once per 16-byte piece (the per-position loads of corr_mfma.h touch each line
 //     4 times: tools/ubench/l2_fill.hip measures 1 tag per cycle = 32 B/cycle/CU for that shape against >= 56 for whole lines).
-//   * B operand = the patch, transposed once per version of fmap1 to [patch][pixel][channel] (devo_corr_patch_transpose): lane (n, kg)
-//     holds channels 32 s + 8 kg .. + 7 of pixel n (columns 9..15: zeros through the buffer range check), C / 32 x 4 registers per edge.
+//   * B operand = the patch, transposed once per version of fmap1 to [patch][pixel][channel] (devo_corr_patch_transpose; fp32: split
+//     into fp16 hi | lo there, once): lane (n, kg) holds channels 32 s + 8 kg .. + 7 of pixel n (columns 9..15: zeros through the
+//     buffer range check), C / 32 x 4 registers per edge.
 //   * D = 16 positions x 16 columns: lane (n, rg) holds positions 4 rg .. 4 rg + 3 of column n = one ds_write_b128 into the level's
 //     result area in LDS ([pixel][position], the layout corr_mfma.h's fused blend epilogue already reads).
 // A box of 107 positions is 7 tiles = 28 loads + 28 MFMAs per level (corr_mfma.h, fp16: 33 loads, 200 MFMAs, 9 x 2 LDS stores per lane).
@@ -50,12 +51,25 @@ __device__ __forceinline__ void mm_split8(const v4u32 a, const v4u32 b, mm_h8& h
   lo = __builtin_bit_cast(mm_h8, lv);
 }
 
-template <typename T, int RMAX, int NKS, int NL>   // NKS = C / 32 K steps per tile; NL = levels per wave
+// Plan -> edge slot of workgroup `gid` of `nitems` (corr_plan_slot's map: heavy edges first, the rest XCD-aware), in closed form:
+// sum over x < X of ceil((n - x) / 8) [n > x]  =  X * (n / 8) + min(X, n % 8).
+__device__ __forceinline__ int mm_plan_slot(const int* __restrict__ order, int BE, int gid, int nitems) {
+  const int nh = order ? min(max(order[BE], 0), BE) : 0;
+  if (gid < nh) return gid;
+  const int xcd = gid & 7;
+  auto upto = [&](int n) -> int { return xcd * (n >> 3) + min(xcd, n & 7); };
+  const int heavy_here = nh > xcd ? (nh - xcd + 7) >> 3 : 0;
+  return nh + upto(nitems) - upto(nh) + (gid >> 3) - heavy_here;
+}
+
+template <typename T, int RMAX, int NKS, int NL, int RFIX>   // NKS = C / 32 K steps per tile; NL = levels per wave; RFIX > 0: the radius is this constant
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? DEVO_MM_WAVES : DEVO_MM_WAVES32, sizeof(T) == 2 ? DEVO_MM_WAVES : DEVO_MM_WAVES32))) void corr_fwd_mm_kernel(
     const T* __restrict__ fmap1_t, CorrLevel lv0, CorrLevel lv1, int nlev, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
-    int C, int64_t out_estride, int64_t out_lstride, int R, const int* __restrict__ order, int heavy_only,
+    int C, int64_t out_estride, int64_t out_lstride, int R_arg, const int* __restrict__ order, int heavy_only,
     unsigned long long* __restrict__ trace) {
+  const int R = RFIX > 0 ? RFIX : R_arg;        // (DEVO's radius 3 and the stress configuration's 5 as constants: window sizes, loop bounds and
+                                                //  the epilogue's guards fold away)
   constexpr bool HALF = sizeof(T) == 2;
   constexpr unsigned ESZ = sizeof(T);
   constexpr int LPS = HALF ? 1 : 2;                 // 16-byte loads per lane and K step
@@ -75,8 +89,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
   constexpr int RWIN_FLOATS = (PP * (DMAX * DMAX + 1) + 3) / 4 * 4;
   constexpr int RW_FLOATS = RWIN_FLOATS > PP * BOXS ? RWIN_FLOATS : PP * BOXS;
   __shared__ __attribute__((aligned(16))) float s_rawwin[NL * RW_FLOATS];
+  __shared__ __attribute__((aligned(16))) float s_geo[NL][16][4];      // per (level index, pixel): dx, dy, tap (0, 0)'s index in the result area, row stride
+  __shared__ int s_org[NL][PP][2];                                     // window origins (window-by-window tiles only)
   const int lane = threadIdx.x & 63;
-  int slot = corr_plan_slot(order, BE, wgid, nwg);
+  int slot = mm_plan_slot(order, BE, wgid, nwg);
   if (heavy_only) {
     slot = (int)blockIdx.x;
     if (slot >= (order ? min(max(order[BE], 0), BE) : 0)) return;
@@ -90,7 +106,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
   const int64_t pi = ii[e];
   const int64_t fj = jj[e];
 
-  // ---- geometry: lane p (< 9) owns patch pixel p (the 18 coordinates come through the scalar cache)
+  // ---- geometry.  Lane 16 l + p owns patch pixel p at level index l: both levels are worked out side by side (the 18 coordinates
+  //      come through the scalar cache and are written into both lane groups)
+  const int lp = lane & 15, lsel = (NL == 2 && lane >= 16) ? 1 : 0;
   float cpx = 0.0f, cpy = 0.0f;
   {
     const float* __restrict__ ce = coords + (int64_t)be * (2 * PP);
@@ -101,67 +119,69 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
     for (int p = 0; p < PP; p++) {
       asm("v_writelane_b32 %0, %1, %2" : "+v"(cpx) : "s"(cv[p]), "n"(p));
       asm("v_writelane_b32 %0, %1, %2" : "+v"(cpy) : "s"(cv[PP + p]), "n"(p));
+      if (NL == 2) {
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(cpx) : "s"(cv[p]), "n"(16 + p));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(cpy) : "s"(cv[PP + p]), "n"(16 + p));
+      }
     }
   }
   if (trace) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_st[1] = __builtin_readcyclecounter(); }
-  float qx[NL], qy[NL];
+  float qx, qy;                               // coordinates at this lane's level: coords / div (the reference's true division)
   {
     auto pow2 = [](float d) -> bool { return (__float_as_uint(d) & 0x807fffffu) == 0u && d >= 1.0f; };
     bool all_pow2 = true;
 #pragma unroll
     for (int l = 0; l < NL; l++) all_pow2 = all_pow2 && pow2(LVF(l, coord_div));
-    if (all_pow2) {                                                   // wave-uniform: x * (1 / 2^k) is the correctly rounded x / 2^k
-#pragma unroll
-      for (int l = 0; l < NL; l++) { const float iv = 1.0f / LVF(l, coord_div); qx[l] = cpx * iv; qy[l] = cpy * iv; }
-    } else {
-#pragma unroll
-      for (int l = 0; l < NL; l++) { const float dv = LVF(l, coord_div); qx[l] = cpx / dv; qy[l] = cpy / dv; }
-    }
+    const float dv = (NL == 2 && lsel) ? LVF(NL - 1, coord_div) : LVF(0, coord_div);
+    if (all_pow2) {                           // wave-uniform: x * (1 / 2^k) is the correctly rounded x / 2^k
+      const float iv = 1.0f / dv;
+      qx = cpx * iv; qy = cpy * iv;
+    } else { qx = cpx / dv; qy = cpy / dv; }
   }
-  auto origin_x = [&](int l) -> int { return floor_to_int((NL == 2 && l) ? qx[NL - 1] : qx[0]) - R; };
-  auto origin_y = [&](int l) -> int { return floor_to_int((NL == 2 && l) ? qy[NL - 1] : qy[0]) - R; };
-  const int WT = (ntap + 15) >> 4;                // tiles per window in window mode (a window's taps padded to whole tiles)
-  struct Geo { int xmin, ymin, bw, nslots, ntile; bool box_mode; float inv_bw; };      // wave-uniform
+  const float flx = floorf(qx), fly = floorf(qy);
+  const int ox = floor_to_int(qx) - R, oy = floor_to_int(qy) - R;      // this lane's window origin
+  // min / max over the 9 pixels of each 16-lane row with DPP row shifts: the result sits in lane 15 of the row
   auto row_min = [&](int v) -> int {
-    v = (lane < PP) ? v : 0x7fffffff;
+    v = (lp < PP) ? v : 0x7fffffff;
     v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));     // row_shr:1
     v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));     // row_shr:2
     v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xf, false));     // row_shr:4
     v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xf, false));     // row_shr:8
-    return __builtin_amdgcn_readlane(v, 15);
+    return v;
   };
+  const int vxmin = row_min(ox), vxmax = row_min(-ox), vymin = row_min(oy), vymax = row_min(-oy);
+  const int WT = (ntap + 15) >> 4;                // tiles per window in window mode (a window's taps padded to whole tiles)
+  struct Geo { int xmin, ymin, bw, nslots, ntile; bool box_mode; float inv_bw; };      // wave-uniform
   auto make_geo = [&](int l) -> Geo {
-    const int mox = origin_x(l), moy = origin_y(l);
-    const int xmin = row_min(mox), xmax = -row_min(-mox), ymin = row_min(moy), ymax = -row_min(-moy);
+    const int xmin = __builtin_amdgcn_readlane(vxmin, 15 + 16 * l), xmax = -__builtin_amdgcn_readlane(vxmax, 15 + 16 * l);
+    const int ymin = __builtin_amdgcn_readlane(vymin, 15 + 16 * l), ymax = -__builtin_amdgcn_readlane(vymax, 15 + 16 * l);
     Geo g;
     g.xmin = xmin; g.ymin = ymin; g.bw = xmax - xmin + D;
     const long long npos_ll = (long long)g.bw * (ymax - ymin + D);
     g.box_mode = npos_ll <= (long long)CAP;              // else: the 9 windows one after the other
     g.nslots = g.box_mode ? (int)npos_ll : PP * ntap;
     g.ntile = g.box_mode ? ((int)npos_ll + 15) >> 4 : PP * WT;
-    // the whole box outside the frame: every tap is 0 (correlation_kernel.cu:136) — no tiles for this level, the epilogue writes zeros
-    if (xmax + D <= 0 || ymax + D <= 0 || xmin >= LVF(l, W2) || ymin >= LVF(l, H2)) { g.nslots = 0; g.ntile = 0; g.box_mode = true; }
+    // the whole box outside the frame: every tap is 0 (correlation_kernel.cu:136) — no tiles for this level; its result area is
+    // zeros read through a D x D box at the area's start
+    if (xmax + D <= 0 || ymax + D <= 0 || xmin >= LVF(l, W2) || ymin >= LVF(l, H2)) { g.nslots = 0; g.ntile = 0; g.box_mode = true; g.bw = D; }
     g.inv_bw = __builtin_amdgcn_rcpf((float)g.bw);
     return g;
   };
   const Geo g0 = make_geo(0);
   const Geo g1 = (NL == 2) ? make_geo(1) : g0;
-  __shared__ int s_org[NL][PP][2];
-  float fdx, fdy;
+  bool all_box = g0.box_mode;
+  if (NL == 2) all_box = all_box && g1.box_mode;
   {
-#pragma unroll
-    for (int l = 0; l < NL; l++) if (lane < PP) { s_org[l][lane][0] = origin_x(l); s_org[l][lane][1] = origin_y(l); }
-    const int src = lane & 15;                                   // lanes 16.. take the fractions of lane - 16 at level index 1
-    const bool hi = NL == 2 && lane >= 16;
-    const float ax = __shfl(qx[0], src), ay = __shfl(qy[0], src), bx = __shfl(qx[NL - 1], src), by = __shfl(qy[NL - 1], src);
-    const float qx_ = hi ? bx : ax, qy_ = hi ? by : ay;
-    fdx = qx_ - floorf(qx_); fdy = qy_ - floorf(qy_);
-  }
-  int fbase;       // where the epilogue finds tap (0, 0) of pixel p (lane p: level index 0, lane 16 + p: level index 1)
-  {
-    const int p_ = min(lane & 15, PP - 1), l_ = (NL == 2 && lane >= 16) ? 1 : 0;
-    const Geo& G = l_ ? g1 : g0;
-    fbase = G.box_mode ? p_ * BOXS + (s_org[l_][p_][1] - G.ymin) * G.bw + (s_org[l_][p_][0] - G.xmin) : p_ * (ntap + 1);
+    // what the epilogue needs per (level index, pixel): blend fractions, where tap (0, 0) sits in the result area, the row stride
+    const bool l1 = NL == 2 && lsel;
+    const bool boxm = l1 ? g1.box_mode : g0.box_mode, live = (l1 ? g1.nslots : g0.nslots) > 0;
+    const int bw_ = l1 ? g1.bw : g0.bw, xm = l1 ? g1.xmin : g0.xmin, ym = l1 ? g1.ymin : g0.ymin;
+    const int p_ = min(lp, PP - 1);
+    const int fb = !boxm ? p_ * (ntap + 1) : live ? p_ * BOXS + (oy - ym) * bw_ + (ox - xm) : p_ * BOXS;
+    if (lp < PP && lane < 16 * NL) {
+      *reinterpret_cast<float4*>(&s_geo[lsel][lp][0]) = float4{qx - flx, qy - fly, __int_as_float(fb), __int_as_float(boxm ? bw_ : D)};
+      if (!all_box) { s_org[lsel][lp][0] = ox; s_org[lsel][lp][1] = oy; }
+    }
   }
   const int nt0 = g0.ntile, ntot = (NL == 2) ? nt0 + g1.ntile : nt0;     // flat tile list: level index 0, then 1
 
@@ -192,39 +212,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
 #pragma unroll
     for (int s = 0; s < NKS; s++) {
       if constexpr (HALF) {
-        const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(rs1, boff, (unsigned)s * 64u, 0);
-        __builtin_memcpy(&bh[s], &v, 16);
+        bh[s] = __builtin_bit_cast(mm_h8, __builtin_amdgcn_raw_buffer_load_b128(rs1, boff, (unsigned)s * 64u, 0));
       } else {
+        // fp32 patches arrive split already (devo_corr_patch_transpose): every 4 channels as 16 bytes of fp16 (hi0..3 | lo0..3)
         const v4u32 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs1, boff, (unsigned)s * 128u, 0);
         const v4u32 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs1, boff, (unsigned)s * 128u + 64u, 0);
-        mm_split8(v0, v1, bh[s], bl[s]);
+        const v4u32 hv = {v0.x, v0.y, v1.x, v1.y}, lv = {v0.z, v0.w, v1.z, v1.w};
+        bh[s] = __builtin_bit_cast(mm_h8, hv);
+        bl[s] = __builtin_bit_cast(mm_h8, lv);
       }
     }
   }
   __builtin_amdgcn_sched_barrier(0);        // patch loads first: the loop's s_waitcnt counts assume they are the oldest
   if (trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_st[2] = __builtin_readcyclecounter(); }
 
-  // byte offset of this lane's position in flat tile tt (OFF_NONE: beyond the box / outside the frame / beyond the list)
-  auto tile_off = [&](int tt) -> unsigned {
-    const int l = (NL == 2 && tt >= nt0) ? 1 : 0;
-    const Geo& G = l ? g1 : g0;
-    const int t = l ? tt - nt0 : tt;
-    int gy, gx;
-    bool listed;
-    if (G.box_mode) {
-      const int s = t * 16 + mi;
-      const int pyy = (int)(((float)s + 0.5f) * G.inv_bw);     // exact: s < 2^16, error margin 0.5 / bw
-      gy = G.ymin + pyy; gx = G.xmin + (s - pyy * G.bw);
-      listed = s < G.nslots;
-    } else {
-      const int wp = t / WT, tw = (t - wp * WT) * 16 + mi;      // (wave-uniform window, lane's tap)
-      const int ta = tw / D;
-      gy = s_org[l][wp][1] + ta; gx = s_org[l][wp][0] + (tw - ta * D);
-      listed = tw < ntap;
-    }
-    const bool ok = listed && tt < ntot && gy >= 0 && gy < LVF(l, H2) && gx >= 0 && gx < LVF(l, W2);
-    return ok ? (unsigned)(gy * (int)LVF(l, s_h) + gx * (int)LVF(l, s_w)) * ESZ : OFF_NONE;
-  };
   v4u32 rb[RT][NKS][LPS];
   // the products of one tile (ring slot r) -> 16 positions x 16 columns of sums
   auto multiply = [&](int r) -> mm_f4 {
@@ -244,8 +245,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
     return acc;
   };
   constexpr int TPL = CAP / 16;                              // tile slots per level of the static schedule
-  bool all_box = g0.box_mode;
-  if (NL == 2) all_box = all_box && g1.box_mode;
   if (all_box) {
     // ---- the usual case, as ONE straight line: NL x TPL tile slots whose level and tile number are compile-time constants (a slot
     //      beyond its level's last tile fetches nothing — every lane out of range — and stores zeros behind the box), so the loop has
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
       const Geo& G = l ? g1 : g0;
       const int sl = t * 16 + mi;
       const int pyy = (int)((fmi + (float)(t * 16)) * G.inv_bw);      // exact: sl < 2^16, error margin 0.5 / bw
-      const int gy = G.ymin + pyy, gx = G.xmin + (sl - pyy * G.bw);
+      const int gy = G.ymin + pyy, gx = G.xmin + (sl - __mul24(pyy, G.bw));
       const bool ok = sl < G.nslots && (unsigned)gy < (unsigned)LVF(l, H2) && (unsigned)gx < (unsigned)LVF(l, W2);
       const unsigned voff = ok ? (unsigned)gy * shb[l] + (unsigned)gx * swb[l] + lane_piece[l] : OFF_NONE;
 #pragma unroll
@@ -288,72 +287,143 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
-  // ---- boxes beyond the result area (the plan's HEAVY class): a dynamic list of tiles, window by window where needed
-  auto fetch = [&](int ring, int tt) {
-    const int l = (NL == 2 && tt >= nt0) ? 1 : 0;
-    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(l);
-    const Pieces pc = pieces_of(l);
-    const unsigned off = tile_off(tt);
-    const unsigned voff = off == OFF_NONE ? OFF_NONE : off + pc.lane0;
+    // ---- boxes beyond the result area (the plan's HEAVY class): a dynamic list of tiles, window by window where needed
+    wave_lds_fence();                                        // (s_org)
+    auto tile_off = [&](int tt) -> unsigned {                // byte offset of this lane's position in flat tile tt (OFF_NONE: nothing)
+      const int l = (NL == 2 && tt >= nt0) ? 1 : 0;
+      const Geo& G = l ? g1 : g0;
+      const int t = l ? tt - nt0 : tt;
+      int gy, gx;
+      bool listed;
+      if (G.box_mode) {
+        const int sl = t * 16 + mi;
+        const int pyy = (int)(((float)sl + 0.5f) * G.inv_bw);
+        gy = G.ymin + pyy; gx = G.xmin + (sl - pyy * G.bw);
+        listed = sl < G.nslots;
+      } else {
+        const int wp = t / WT, tw = (t - wp * WT) * 16 + mi;      // (wave-uniform window, lane's tap)
+        const int ta = tw / D;
+        gy = s_org[l][wp][1] + ta; gx = s_org[l][wp][0] + (tw - ta * D);
+        listed = tw < ntap;
+      }
+      const bool ok = listed && tt < ntot && gy >= 0 && gy < LVF(l, H2) && gx >= 0 && gx < LVF(l, W2);
+      return ok ? (unsigned)(gy * (int)LVF(l, s_h) + gx * (int)LVF(l, s_w)) * ESZ : OFF_NONE;
+    };
+    auto fetch = [&](int ring, int tt) {
+      const int l = (NL == 2 && tt >= nt0) ? 1 : 0;
+      const __amdgpu_buffer_rsrc_t rs = frame_rsrc(l);
+      const Pieces pc = pieces_of(l);
+      const unsigned off = tile_off(tt);
+      const unsigned voff = off == OFF_NONE ? OFF_NONE : off + pc.lane0;
 #pragma unroll
-    for (int s = 0; s < NKS; s++) {
-      rb[ring][s][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)s * pc.step, 0);
-      if constexpr (!HALF) rb[ring][s][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)s * pc.step + pc.second, 0);
-    }
-  };
+      for (int s = 0; s < NKS; s++) {
+        rb[ring][s][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)s * pc.step, 0);
+        if constexpr (!HALF) rb[ring][s][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)s * pc.step + pc.second, 0);
+      }
+    };
 #pragma unroll
-  for (int r = 0; r < RT - 1; r++) { fetch(r, r); __builtin_amdgcn_sched_barrier(0); }
-  for (int t0 = 0; t0 < ntot; t0 += RT) {
+    for (int l = 0; l < NL; l++)                             // a level without tiles: its D x D box of zeros
+      if ((l ? g1.nslots : g0.nslots) == 0)
+        for (int i = lane; i < PP * BOXS; i += 64) s_rawwin[l * RW_FLOATS + i] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < RT; r++) {
-      const int tt = t0 + r;
-      fetch((r + RT - 1) % RT, tt + RT - 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const mm_f4 acc = multiply(r);
-      // ---- the tile's 16 x 9 sums -> the level's result area (positions outside the frame and slots beyond the box fetched zeros)
-      if (tt < ntot) {                                            // wave-uniform; no memory loads inside
-        const int l = (NL == 2 && tt >= nt0) ? 1 : 0;
-        const bool boxm = l ? g1.box_mode : g0.box_mode;
-        const int t = l ? tt - nt0 : tt;
-        float* rawwin = s_rawwin + l * RW_FLOATS;
-        if (boxm) {
-          if (mi < PP) *reinterpret_cast<mm_f4*>(rawwin + mi * BOXS + t * 16 + 4 * kg) = acc;
-        } else {
-          const int wp = t / WT, tw = (t - wp * WT) * 16 + 4 * kg;
-          if (mi == wp) {
+    for (int r = 0; r < RT - 1; r++) { fetch(r, r); __builtin_amdgcn_sched_barrier(0); }
+    for (int t0 = 0; t0 < ntot; t0 += RT) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (tw + j < ntap) rawwin[wp * (ntap + 1) + tw + j] = acc[j];
+      for (int r = 0; r < RT; r++) {
+        const int tt = t0 + r;
+        fetch((r + RT - 1) % RT, tt + RT - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const mm_f4 acc = multiply(r);
+        if (tt < ntot) {                                            // wave-uniform; no memory loads inside
+          const int l = (NL == 2 && tt >= nt0) ? 1 : 0;
+          const bool boxm = l ? g1.box_mode : g0.box_mode;
+          const int t = l ? tt - nt0 : tt;
+          float* rawwin = s_rawwin + l * RW_FLOATS;
+          if (boxm) {
+            if (mi < PP) *reinterpret_cast<mm_f4*>(rawwin + mi * BOXS + t * 16 + 4 * kg) = acc;
+          } else {
+            const int wp = t / WT, tw = (t - wp * WT) * 16 + 4 * kg;
+            if (mi == wp) {
+#pragma unroll
+              for (int j = 0; j < 4; j++) if (tw + j < ntap) rawwin[wp * (ntap + 1) + tw + j] = acc[j];
+            }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
-  }
   }
   wave_lds_fence();
   if (trace) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t_st[3] = __builtin_readcyclecounter(); }
-  // ---- fused bilinear blend + axis swap + output permutation (correlation_kernel.cu:221-232), as in corr_mfma.h:
-  //      output element (l, t), t = q * 9 + p with q = cx * Dm + a, goes to out[be * estride + t * lstride + offset(l)];
-  //      a lane keeps ITS (p, l) for the whole epilogue and walks q = grp, grp + GRPS, ...
-  {
-    const int Dm = D - 1, nq = Dm * Dm;
+  // ---- fused bilinear blend + axis swap + output permutation (correlation_kernel.cu:221-232).
+  //      Output element (l, t), t = q * 9 + p with q = cx * Dm + a (cx = x offset: permute(0,1,3,2,4,5), a = y offset), goes to
+  //      out[be * estride + t * lstride + offset(l)].
+  const int Dm = D - 1;
+  const bool paired = NL == 2 && out_lstride == 2 && lv0.out_offset == 0 && lv1.out_offset == 1 && (out_estride & 1) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+  if (paired) {
+    // The standard stacked record (torch.stack([c0, c1], -1)): lane (a, p) = (lane / 9, lane % 9) does ROW a of pixel p's window at BOTH
+    // levels — 2 x (Dm + 1) taps of rows a, a + 1 per level read once, Dm outputs per level in the reference's blend order — and
+    // stores the two levels' values of one output as ONE 4- / 8-byte piece: the 63 lanes of a store write 63 consecutive pieces.
+    constexpr int DMM = 2 * RMAX + 1;
+    const int ar = (lane * 57) >> 9, p = lane - 9 * ar;                                  // lane / 9 for lane < 64
+    const float4 ga = *reinterpret_cast<const float4*>(&s_geo[0][p][0]), gb = *reinterpret_cast<const float4*>(&s_geo[NL - 1][p][0]);
+    float w[2][4];
+    {
+#pragma clang fp contract(off)
+      w[0][0] = (1.0f - ga.x) * (1.0f - ga.y); w[0][1] = ga.x * (1.0f - ga.y); w[0][2] = (1.0f - ga.x) * ga.y; w[0][3] = ga.x * ga.y;
+      w[1][0] = (1.0f - gb.x) * (1.0f - gb.y); w[1][1] = gb.x * (1.0f - gb.y); w[1][2] = (1.0f - gb.x) * gb.y; w[1][3] = gb.x * gb.y;
+    }
+    const int rs0 = __float_as_int(ga.w), rs1_ = __float_as_int(gb.w);
+    T* const rec = out + (int64_t)be * out_estride;
+    for (int a0 = 0; a0 < Dm; a0 += 7) {                     // (radius <= 3: one round)
+      const int a = a0 + ar;
+      if (lane < 63 && a < Dm) {
+        const float* r0 = s_rawwin + __float_as_int(ga.z) + a * rs0;
+        const float* r1 = s_rawwin + RW_FLOATS + __float_as_int(gb.z) + a * rs1_;
+        float t0[DMM + 1], t1[DMM + 1], u0[DMM + 1], u1[DMM + 1];
+#pragma unroll
+        for (int c = 0; c <= DMM; c++) if (c <= Dm) { t0[c] = r0[c]; u0[c] = r0[rs0 + c]; t1[c] = r1[c]; u1[c] = r1[rs1_ + c]; }
+        T* op = rec + (a * PP + p) * 2;
+#pragma unroll
+        for (int cx = 0; cx < DMM; cx++) {
+          if (cx < Dm) {
+            float o0, o1;
+            {
+#pragma clang fp contract(off)
+              o0 = w[0][0] * t0[cx]; o0 = o0 + w[0][1] * t0[cx + 1]; o0 = o0 + w[0][2] * u0[cx]; o0 = o0 + w[0][3] * u0[cx + 1];
+              o1 = w[1][0] * t1[cx]; o1 = o1 + w[1][1] * t1[cx + 1]; o1 = o1 + w[1][2] * u1[cx]; o1 = o1 + w[1][3] * u1[cx + 1];
+            }
+            if constexpr (HALF) {
+              const mm_h2 v = {(_Float16)o0, (_Float16)o1};
+              *reinterpret_cast<mm_h2*>(op + cx * (Dm * PP * 2)) = v;
+            } else {
+              typedef float f2v __attribute__((ext_vector_type(2)));
+              const f2v v = {o0, o1};
+              *reinterpret_cast<f2v*>(op + cx * (Dm * PP * 2)) = v;
+            }
+          }
+        }
+      }
+    }
+  } else {
+    // any other output layout: one element per lane and round (corr_mfma.h's epilogue)
     constexpr int NPL = PP * NL, GRPS = 64 / NPL;               // 18 (p, l) pairs x 3 q's, or 9 x 7
+    const int nq = Dm * Dm;
     const int grp = lane / NPL, pl = lane - grp * NPL;
     const int p = pl / NL, l = pl - p * NL;
     const bool active = grp < GRPS;
-    const float dxp = __shfl(fdx, p + 16 * l), dyp = __shfl(fdy, p + 16 * l);
-    const int base = __shfl(fbase, p + 16 * l);
+    const float4 gg = *reinterpret_cast<const float4*>(&s_geo[l][p][0]);
     float w00, w01, w10, w11;
     {
 #pragma clang fp contract(off)
-      w00 = (1.0f - dxp) * (1.0f - dyp); w01 = dxp * (1.0f - dyp); w10 = (1.0f - dxp) * dyp; w11 = dxp * dyp;   // blend4's factors
+      w00 = (1.0f - gg.x) * (1.0f - gg.y); w01 = gg.x * (1.0f - gg.y); w10 = (1.0f - gg.x) * gg.y; w11 = gg.x * gg.y;   // blend4's factors
     }
-    const int rstride = (l ? g1.box_mode : g0.box_mode) ? (l ? g1.bw : g0.bw) : D;       // per lane (l is)
-    const bool lvl_live = (l ? g1.nslots : g0.nslots) > 0;                              // (a level without tiles left its result area untouched)
+    const int rstride = __float_as_int(gg.w);
     int q = grp;
     int cx = 0, a = q;
     while (a >= Dm) { a -= Dm; cx += 1; }
-    const float* rw = s_rawwin + l * RW_FLOATS + base;
+    const float* rw = s_rawwin + l * RW_FLOATS + __float_as_int(gg.z);
     T* op = out + (int64_t)be * out_estride + (int64_t)(q * PP + p) * out_lstride + LVF(l, out_offset);
     const int64_t ostep = (int64_t)(GRPS * PP) * out_lstride;
     for (int q0 = 0; q0 < nq; q0 += GRPS) {
@@ -364,7 +434,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
 #pragma clang fp contract(off)
           o = w00 * r[0]; o = o + w01 * r[1]; o = o + w10 * r[rstride]; o = o + w11 * r[rstride + 1];
         }
-        store_streamed(op, from_f32<T>(lvl_live ? o : 0.0f));
+        store_streamed(op, from_f32<T>(o));
       }
       op += ostep;
       q += GRPS; a += GRPS;

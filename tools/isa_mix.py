@@ -33,7 +33,7 @@ def main():
             blocks = []
             cur, curc = "entry", collections.Counter()
             i += 1
-            while i < len(lines) and "s_endpgm" not in lines[i]:
+            while i < len(lines) and not lines[i].startswith(".Lfunc_end"):
                 ln = lines[i].strip()
                 i += 1
                 if not ln or ln.startswith((";", "//")):

@@ -236,7 +236,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         torch.mul(d["state0"], 1.0, out=d["state"])                        # fresh poses + patches (bench harness; an elementwise kernel: rocclr's copyBuffer takes 5 us)
         # reprojection; the kernel also emits the lookup's plan bins while it holds the coordinates
         coords, order = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp",
-                                          plan_for=(n, cfg["H"], R, cfg["W"], 4 if (args.fuse_levels and cuda_corr.REGION_KERNEL) else 0))
+                                          plan_for=(n, cfg["H"], R, cfg["W"], 0))
         if args.separate_index_kernels or prep_stream is not None:
             order = cuda_corr.plan_finish(order, d["jj"], n, cfg["H"], R)
         else:
@@ -313,7 +313,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         lookup(coords)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     # only the lookup kernels sit between the events
-    order = cuda_corr.plan(coords, d["jj"], n, cfg["H"], radius=R, width=cfg["W"], l1=4 if (args.fuse_levels and cuda_corr.REGION_KERNEL) else 0)
+    order = cuda_corr.plan(coords, d["jj"], n, cfg["H"], radius=R)
     torch.cuda.synchronize()
 
     def lookups():
@@ -376,8 +376,8 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
     # (an NCHW pyramid of >= 1024 edges goes through cuda_corr's cached channel-blocked copy, i.e. the same fast kernel)
     nchw_direct = args.layout == "nchw" and (E < 1024 or os.environ.get("DEVO_CORR_NCHW_DIRECT", "0") == "1" or cfg["C"] % 8 != 0)
     lookup_kernel = "corr_fwd_generic_kernel" if nchw_direct else ("corr_fwd_mfma_kernel" if mfma else "corr_fwd_cl_kernel")
-    if args.layout != "nchw" and args.fuse_levels and mfma and os.environ.get("DEVO_CORR_REGION", "0")[:1] == "1":
-        lookup_kernel = "corr_fwd_region_kernel"                    # opt-in region-shared kernel (corr_region.h)
+    if lookup_kernel == "corr_fwd_mfma_kernel" and cuda_corr.MM_KERNEL:
+        lookup_kernel = "corr_fwd_mm_kernel"                        # dense-product kernel (corr_mm.h): fused lookups and per-level launches alike
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

@@ -20,7 +20,7 @@ _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_siz
 _SIGNATURES = {
     "devo_abi_version": [],
     "devo_last_error": [],
-    "devo_corr_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i, _i64, _i64, _i64, _i, _i, _vp, ctypes.c_float, _vp],
+    "devo_corr_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i, _i64, _i64, _i64, _i, _i, _vp, ctypes.c_float, _vp, _vp],
     "devo_corr_forward_pyramid2": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), _c_i64p,
                                    ctypes.POINTER(ctypes.c_int), _i64, _i64, _c_i64p, _i, _i, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp],
     "devo_corr_patch_transpose": [_vp, _vp, _i, _i, _i, _vp],

@@ -21,7 +21,6 @@ def _prep(fmap1, fmap2, coords, ii, jj, allow_blocked=False):
 
 
 import os
-REGION_KERNEL = os.environ.get("DEVO_CORR_REGION", "0") == "1"   # opt-in region-shared lookup kernel (corr_region.h; the library reads the same switch)
 MM_KERNEL = os.environ.get("DEVO_CORR_MM", "1") != "0"          # dense-product lookup kernel (corr_mm.h) for fused two-level lookups; False: the 4x4 matrix-core kernel
 PLAN_MIN_EDGES = 2048      # below this the lookup is launch-bound and a locality plan cannot pay for itself
 NCHW_CONVERT_MIN_EDGES = 1024    # from here on a lookup into the reference's NCHW pyramid goes through a cached channel-blocked copy
@@ -102,7 +101,7 @@ _patch_t_cache = {}        # (ptr, version, shape, dtype) -> (source tensor [kep
 
 
 def patches_transposed(fmap1):
-    """fmap1 [B, Np, C, 3, 3] -> [B, Np, 9, C] (devo_corr_patch_transpose), the patch operand layout of the region-shared lookup
+    """fmap1 [B, Np, C, 3, 3] -> [B, Np, 9, C] (devo_corr_patch_transpose), the patch operand layout of the dense-product lookup
     kernel.  DEVO's patch features change once per frame, not per update iteration: the copy is cached per version of the tensor
     (same key discipline as _fast_layout)."""
     key = (fmap1.data_ptr(), fmap1._version, tuple(fmap1.shape), fmap1.dtype)
@@ -120,6 +119,14 @@ def patches_transposed(fmap1):
     L.check(rc, "cuda_corr.patches_transposed")
     _patch_t_cache[key] = (fmap1, t)
     return t
+
+
+def _patch_operand(fmap1, C, P):
+    """The dense-product kernel (corr_mm.h) wants the patches as devo_corr_patch_transpose lays them out ([Np, 9, C]; cached per
+    version of fmap1).  None: the lookup takes the 4x4 matrix-core kernel or the staged / generic ones."""
+    if MM_KERNEL and P == 3 and fmap1.shape[3] == 3 and C % 32 == 0 and fmap1.dtype in (torch.float16, torch.float32):
+        return patches_transposed(fmap1)
+    return None
 
 
 def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, offset, order=None, coord_div=1.0):
@@ -140,9 +147,10 @@ def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, of
         if fmap2.stride(5) != 1 or fmap2.shape[2] * cblock != C:
             raise RuntimeError("cuda_corr.forward: malformed channel-blocked fmap2")
         strides = strides[:5]
+    f1t = _patch_operand(fmap1, C, P)
     rc = L.lib().devo_corr_forward(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(ii), L.ptr(jj), L.ptr(out),
                                    B, E, Np, n2, C, P, H2, W2, L.i64arr(strides), cblock, estride, lstride, offset,
-                                   int(radius), L.dtype_code(fmap1), L.ptr(order), float(coord_div), L.stream())
+                                   int(radius), L.dtype_code(fmap1), L.ptr(order), float(coord_div), L.ptr(f1t), L.stream())
     L.check(rc, "cuda_corr.forward")
 
 
@@ -181,11 +189,8 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
     if out is None:
         out = torch.empty(B, E, per * nl, dtype=fmap1.dtype, device=fmap1.device)
     pyramid = [_fast_layout(f, B * E) if f.is_cuda else f for f in pyramid]
-    pyr_l1 = 0                                                  # integer level ratio of a two-level pyramid (DEVO: 4), else 0
-    if REGION_KERNEL and nl == 2 and scales[0] > 0 and float(scales[1] / scales[0]).is_integer() and scales[1] / scales[0] >= 2:
-        pyr_l1 = int(scales[1] / scales[0])
     if order is None and B * E >= PLAN_MIN_EDGES:
-        order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius, width=pyramid[0].shape[4], l1=pyr_l1)
+        order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius)
     if nl == 2 and B * E > 0 and pyramid[0].dtype == pyramid[1].dtype and pyramid[0].dtype in (torch.float32, torch.float16):
         f1, f2a, c_, ii_, jj_ = _prep(fmap1, pyramid[0], coords, ii, jj, allow_blocked=True)
         _prep(fmap1, pyramid[1], coords, ii, jj, allow_blocked=True)
@@ -194,10 +199,7 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
         hw = (ctypes.c_int * 4)(d0[0], d0[1], d1[0], d1[1])
         cb = (ctypes.c_int * 2)(d0[3], d1[3])
         cd = (ctypes.c_float * 2)(float(scales[0]), float(scales[1]))
-        # the region-shared kernel wants the patches as [Np, 9, C] (cached per version of fmap1) and a plan
-        # ... and so does the dense-product kernel (corr_mm.h), plan or not
-        want_t = (MM_KERNEL and C % 32 == 0) or (REGION_KERNEL and order is not None)
-        f1t = patches_transposed(f1) if (want_t and P == 3 and f1.shape[3] == 3) else None
+        f1t = _patch_operand(f1, C, P)
         rc = L.lib().devo_corr_forward_pyramid2(L.ptr(f1), L.ptr(pyramid[0]), L.ptr(pyramid[1]), L.ptr(c_), L.ptr(ii_), L.ptr(jj_),
                                                 L.ptr(out), B, E, Np, pyramid[0].shape[1], C, P, hw, L.i64arr(d0[2] + d1[2]), cb,
                                                 per * nl, nl, L.i64arr([0, 1]), int(radius), L.dtype_code(f1), L.ptr(order), cd,

@@ -413,7 +413,8 @@ __device__ __forceinline__ void edge_terms(const float* __restrict__ poses, cons
   fb_relSE3(ti, qi, tj, qj, tij, qij);
   fb_actSE3(tij, qij, Xi, Xj);
   const float X = Xj[0], Y = Xj[1], Z = Xj[2], W = Xj[3];
-  const float d = (Z >= 0.2f) ? 1.0f / Z : 0.0f;
+  // ba_cuda.cu:268 compares and divides in DOUBLE (`(Z >= 0.2) ? 1.0 / Z : 0.0`): (double)Z >= 0.2 <=> Z >= 0.2f, the quotient rounded once more to float
+  const float d = (Z >= 0.2f) ? (float)(1.0 / (double)Z) : 0.0f;
   const float d2 = d * d;
   const float x1 = fx * (X / Z) + cx, y1 = fy * (Y / Z) + cy;
   float tgx = target.t[(int64_t)e * 2], tgy = target.t[(int64_t)e * 2 + 1];
@@ -422,7 +423,8 @@ __device__ __forceinline__ void edge_terms(const float* __restrict__ poses, cons
     tgx = b[0] + tgx; tgy = b[target.sc] + tgy;
   }
   const float rx = tgx - x1, ry = tgy - y1;
-  const bool inb = (sqrtf(rx * rx + ry * ry) < 128.0f) && (Z > 0.2f) && (x1 > -64.0f) && (y1 > -64.0f) &&
+  // ba_cuda.cu:277 `Z > 0.2` is a comparison in double: 0.2f = 0.2000000030 lies ABOVE the double 0.2, so (double)Z > 0.2 <=> Z >= 0.2f
+  const bool inb = (sqrtf(rx * rx + ry * ry) < 128.0f) && (Z >= 0.2f) && (x1 > -64.0f) && (y1 > -64.0f) &&
                    (x1 < 2 * cx + 64.0f) && (y1 < 2 * cy + 64.0f);
   const float mask = inb ? 1.0f : 0.0f;
   T.r[0] = rx; T.r[1] = ry;

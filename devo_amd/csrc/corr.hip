@@ -164,7 +164,6 @@ struct CorrLevel {
   int64_t block_stride;           // elements between consecutive channel blocks (unused for channels-last)
   unsigned frame_bytes;           // extent of one frame (all blocks) in bytes: the buffer-load bound of the matrix-core kernel
   bool staged_ok, mfma_ok;        // which of the two fast kernels can read this level
-  bool region_ok;                 // ... and the region-shared kernel (corr_region.h)
   bool mm_ok;                     // ... and the dense-product kernel (corr_mm.h)
   int64_t out_offset;             // element offset of this level inside an edge's output record
   float coord_div;                // coordinates are divided by this (pyramid level scale)
@@ -449,7 +448,6 @@ __global__ __launch_bounds__(WPB * 64) void corr_fwd_cl_kernel(
 
 #include "corr_mfma.h"
 #include "corr_mm.h"
-#include "corr_region.h"
 
 // -------------------------------------------------------------------------------------------------
 // Locality plan: order[] = heavy edge slots, then the rest sorted by (batch, target frame, 16-row band of the
@@ -891,11 +889,6 @@ using namespace devo;
 
 // Describes one level for the fast kernels; false = neither of them can read it (generic kernel, or an error for
 // channel-blocked storage, which only the fast kernels understand).
-static bool corr_region_enabled() {              // DEVO_CORR_REGION=1: pyramid lookups with a pyramid plan take the region-shared kernel
-  static const char* env = getenv("DEVO_CORR_REGION");
-  static const bool on = env && env[0] == '1';
-  return on;
-}
 static bool corr_mfma_enabled() {                // DEVO_CORR_MFMA=0: fp32 lookups take the staged (tap-centric) kernel instead
   static const char* env = getenv("DEVO_CORR_MFMA");
   static const bool on = !(env && env[0] == '0');
@@ -922,11 +915,9 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
   const bool c_ok = sizeof(T) == 4 ? (C == 64 || C == 128) : (C == 128 || C == 256);            // 4 or 8 steps per pass
   lv->mfma_ok = aligned && sizeof(T) <= 4 && corr_mfma_enabled() && c_ok && cb_ok &&
                 frame_bytes < (1LL << 31);                                                             // 32-bit in-frame offsets
-  // the region-shared kernel: 16-byte pieces inside a channel block (or channels-last), any C that is a multiple of its slab
-  lv->region_ok = aligned && sizeof(T) <= 4 && corr_region_enabled() && cb_ok && C % (sizeof(T) == 2 ? 32 : 16) == 0 && frame_bytes < (1LL << 31);
   // the dense-product kernel (corr_mm.h): 16-byte pieces of 8 (fp16) / 4 (fp32) channels inside a channel block, 32 channels per K step
   lv->mm_ok = lv->mfma_ok && C % 32 == 0 && (sizeof(T) == 2 ? C <= 256 : C <= 128);
-  if (!lv->staged_ok && !lv->mfma_ok && !lv->region_ok) {
+  if (!lv->staged_ok && !lv->mfma_ok) {
     if (blocked) {
       set_error("devo_corr_forward: channel-blocked fmap2 needs fp32 / fp16, 16-byte aligned strides and cblock == %d (got %d)", KC, cblock);
       *err = DEVO_ERR_UNSUPPORTED;
@@ -1035,11 +1026,11 @@ static bool corr_mm_enabled() {                  // DEVO_CORR_MM=0: the 4x4 matr
 }
 template <typename T>
 static bool mm_eligible(const CorrLevel& l0, const CorrLevel& l1, const void* fmap1_t, long long BE, int Np, int C) {
-  return corr_mm_enabled() && fmap1_t != nullptr && l0.mm_ok && l1.mm_ok && (long long)Np * C * PP * (long long)sizeof(T) < (1LL << 40) &&
+  return corr_mm_enabled() && fmap1_t != nullptr && l0.mm_ok && l1.mm_ok && l0.out_offset >= 0 && l1.out_offset >= 0 && (long long)Np * C * PP * (long long)sizeof(T) < (1LL << 40) &&
          BE < (1LL << 30) && (reinterpret_cast<uintptr_t>(fmap1_t) & 15) == 0;
 }
 template <typename T>
-static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel& lv1, const float* coords, const int64_t* ii,
+static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel& lv1, int nlev, const float* coords, const int64_t* ii,
                      const int64_t* jj, void* out, long long BE, int E, int Np, int n2, int C, int64_t oes, int64_t ols, int R,
                      const int* order, hipStream_t st) {
   typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;
@@ -1047,16 +1038,18 @@ static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel&
                           int64_t, int64_t, int, const int*, int, unsigned long long*);
   const int nks = C / 32;
   mm_fn_t fn = nullptr;
-#define DEVO_MM_PICK(NKS) (R == 3 ? corr_fwd_mm_kernel<MT, 3, NKS, 2, 3> : R == 5 ? corr_fwd_mm_kernel<MT, 5, NKS, 2, 5> : \
-                           R < 3 ? corr_fwd_mm_kernel<MT, 3, NKS, 2, 0> : corr_fwd_mm_kernel<MT, 5, NKS, 2, 0>)
+#define DEVO_MM_PICK_L(NKS, NLV) (R == 3 ? corr_fwd_mm_kernel<MT, 3, NKS, NLV, 3> : R == 5 ? corr_fwd_mm_kernel<MT, 5, NKS, NLV, 5> : \
+                                  R < 3 ? corr_fwd_mm_kernel<MT, 3, NKS, NLV, 0> : corr_fwd_mm_kernel<MT, 5, NKS, NLV, 0>)
+#define DEVO_MM_PICK(NKS) (nlev == 2 ? DEVO_MM_PICK_L(NKS, 2) : DEVO_MM_PICK_L(NKS, 1))
   if constexpr (sizeof(MT) == 2) fn = nks == 1 ? DEVO_MM_PICK(1) : nks == 2 ? DEVO_MM_PICK(2) : nks == 4 ? DEVO_MM_PICK(4) : nks == 8 ? DEVO_MM_PICK(8) : nullptr;
   else fn = nks == 1 ? DEVO_MM_PICK(1) : nks == 2 ? DEVO_MM_PICK(2) : nks == 4 ? DEVO_MM_PICK(4) : nullptr;
 #undef DEVO_MM_PICK
+#undef DEVO_MM_PICK_L
   if (!fn) { set_error("devo_corr_forward_pyramid2: C = %d not supported by the dense-product kernel", C); return DEVO_ERR_UNSUPPORTED; }
   unsigned long long* trace = nullptr;                                // debug switch: per-wave cycle stamps to stderr
   const bool do_trace = getenv("DEVO_CORR_TRACE") != nullptr;
   if (do_trace) { (void)hipMalloc(&trace, (size_t)BE * 64); (void)hipMemset(trace, 0, (size_t)BE * 64); }
-  hipLaunchKernelGGL(fn, dim3((unsigned)BE), dim3(64), 0, st, (const MT*)fmap1_t, lv0, lv1, 2, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C,
+  hipLaunchKernelGGL(fn, dim3((unsigned)BE), dim3(64), 0, st, (const MT*)fmap1_t, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C,
                      oes, ols, R, order, 0, trace);
   if (do_trace) {
     (void)hipDeviceSynchronize();
@@ -1085,103 +1078,18 @@ static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel&
   return check_launch("devo_corr_forward_pyramid2 (dense-product kernel)");
 }
 
-// Region-shared lookup (corr_region.h) of a two-level pyramid with a locality plan: the plan's heavy slots go to the per-edge
-// matrix-core kernel, everything else (and the zero-fill of the dead tail) to corr_fwd_region_kernel.
-template <typename T>
-static int launch_region(const void* fmap1, const void* fmap1_t, const CorrLevel& lv0, const CorrLevel& lv1, const float* coords,
-                         const int64_t* ii, const int64_t* jj, void* out, long long BE, int E, int Np, int n2, int C, int64_t oes,
-                         int64_t ols, int R, const int* order, hipStream_t st) {
-  typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;
-  typedef void (*region_fn_t)(const MT*, CorrLevel, CorrLevel, const float*, const int64_t*, const int64_t*, MT*, int, int, int, int, int,
-                              int64_t, int64_t, int, const int*, int, unsigned, int, unsigned long long*);
-  typedef RgShape<3, 16, 1, corr_region_tmax(3), 15> S3;           // one 16-wave workgroup per CU (4 waves per SIMD, one edge per wave and round), double-buffered slabs
-  typedef RgShape<5, 12, 1, corr_region_tmax(5), 16, 2, 64, false> S5;   // radius 4, 5: 16 tiles per edge: 12 waves (3 per SIMD)
-  static const bool do_stats = getenv("DEVO_RG_STATS") != nullptr;  // debug switch: phase cycles of every workgroup's first wave to stderr
-  const region_fn_t fn = do_stats ? (R <= 3 ? corr_fwd_region_kernel<MT, S3, true> : corr_fwd_region_kernel<MT, S5, true>)
-                                  : (R <= 3 ? corr_fwd_region_kernel<MT, S3, false> : corr_fwd_region_kernel<MT, S5, false>);
-  const size_t lds = (size_t)(R <= 3 ? S3::LDS_BYTES : S5::LDS_BYTES);
-  const int threads = R <= 3 ? S3::THREADS : S5::THREADS, chmax = R <= 3 ? S3::CHMAX : S5::CHMAX;
-  const int round_edges = R <= 3 ? S3::SLOTS : S5::SLOTS, wgs_per_cu = 1;
-  static bool attr_done[4][2] = {{false, false}, {false, false}, {false, false}, {false, false}};
-  bool& done = attr_done[(R <= 3 ? 0 : 1) + (do_stats ? 2 : 0)][sizeof(MT) == 2 ? 1 : 0];
-  if (!done) {
-    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      (void)hipGetLastError();
-      set_error("devo_corr_forward_pyramid2: cannot reserve %zu bytes of LDS for the region kernel", lds);
-      return DEVO_ERR_LAUNCH;
-    }
-    done = true;
-  }
-  // chunks of the plan: ~2 rounds each, whole multiples of the CU count when there is enough work (one workgroup per CU)
-  static const char* chunk_env = getenv("DEVO_RG_CHUNK");
-  const int target = chunk_env && atoi(chunk_env) > 0 ? (atoi(chunk_env) < chmax ? atoi(chunk_env) : chmax) : 2 * round_edges;
-  long long nchunks = (BE + target - 1) / target;
-  const long long slots = 256LL * wgs_per_cu;
-  nchunks = nchunks > slots ? (nchunks + slots - 1) / slots * slots : (nchunks + 7) / 8 * 8;
-  while ((BE + nchunks - 1) / nchunks > chmax) nchunks += 8;
-  // heavy slots first (longest items): the per-edge kernel in its heavy-only mode
-  {
-    typedef void (*mfma_fn_t)(const MT*, CorrLevel, CorrLevel, int, const float*, const int64_t*, const int64_t*, MT*, int, int,
-                              int, int, int, int64_t, int64_t, int, const int*, unsigned long long*, int);
-    constexpr int SC = sizeof(MT) == 2 ? 32 : 16;
-    const int ngr = C / SC;
-    const mfma_fn_t hf = ngr == 4 ? (R <= 3 ? corr_fwd_mfma_kernel<MT, 3, 4, 2> : corr_fwd_mfma_kernel<MT, 5, 4, 2>)
-                                  : (R <= 3 ? corr_fwd_mfma_kernel<MT, 3, 8, 2> : corr_fwd_mfma_kernel<MT, 5, 8, 2>);
-    hipLaunchKernelGGL(hf, dim3((unsigned)BE), dim3(64 * DEVO_MFMA_EPW), 0, st, (const MT*)fmap1, lv0, lv1, 2, coords, ii, jj, (MT*)out, (int)BE, E,
-                       Np, n2, C, oes, ols, R, order, (unsigned long long*)nullptr, 1);
-  }
-  const long long f1t_bytes = (BE / (E > 0 ? E : 1)) * (long long)Np * C * PP * (long long)sizeof(MT);
-  unsigned long long* stats = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (do_stats) { (void)hipMalloc(&stats, 4096); (void)hipMemset(stats, 0, 4096); (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1); (void)hipEventRecord(ev0, st); }
-  hipLaunchKernelGGL(fn, dim3((unsigned)nchunks), dim3(threads), lds, st, (const MT*)fmap1_t, lv0, lv1, coords, ii, jj, (MT*)out, (int)BE, E, Np,
-                     n2, C, oes, ols, R, order, (int)nchunks, (unsigned)f1t_bytes, DEVO_PLAN_BAND, stats);
-  if (do_stats) {
-    (void)hipEventRecord(ev1, st);
-    (void)hipDeviceSynchronize();
-    float ms = 0.0f;
-    (void)hipEventElapsedTime(&ms, ev0, ev1);
-    unsigned long long h[16];
-    (void)hipMemcpy(h, stats, 128, hipMemcpyDeviceToHost);
-    const double g = h[9] ? (double)h[9] : 1.0;
-    {
-      unsigned long long q[8];
-      (void)hipMemcpy(q, stats + 400, 64, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[region stats] sub-phases, cycles per workgroup: prologue = loads + geometry %.0f | sort %.0f | rounds %.0f;  epilogue = next stage's request %.0f | tiles to scratch %.0f | blend + store %.0f | barrier %.0f\n",
-              q[0] / g, q[1] / g, q[2] / g, q[3] / g, q[4] / g, q[5] / g, q[6] / g);
-    }
-    fprintf(stderr, "[region stats] kernel %.1f us; %llu workgroups (%lld chunks), %.2f rounds and %.1f slab iterations per workgroup; first wave, cycles per workgroup: total %.0f = "
-            "prologue %.0f | stage set-up %.0f | first slab wait %.0f | products + DMA issue %.0f | left-over DMA issue %.0f | slab wait + barrier %.0f | epilogue + next stage's request %.0f | tail %.0f\n",
-            ms * 1e3, h[9], nchunks, h[8] / g, h[10] / g, h[11] / g, h[0] / g, h[1] / g, h[2] / g, h[3] / g, h[4] / g, h[5] / g, h[6] / g, h[7] / g);
-    {
-      unsigned long long tr[4 * 16 * 4];
-      const int nw = threads / 64;
-      (void)hipMemcpy(tr, stats + 16, sizeof(unsigned long long) * 4 * nw * 4, hipMemcpyDeviceToHost);
-      unsigned long long t0 = ~0ULL;
-      for (int i = 0; i < 4 * nw * 4; i++) if (tr[i] && tr[i] < t0) t0 = tr[i];
-      for (int it = 0; it < 4; it++) {
-        fprintf(stderr, "[region trace] chunk 100, stage 1, slab %d: per wave (start, second phase, both done, past the barrier):", it);
-        for (int w = 0; w < nw; w++) {
-          const unsigned long long* q = tr + (it * nw + w) * 4;
-          fprintf(stderr, "  w%d %llu %llu %llu %llu", w, q[0] - t0, q[1] - t0, q[2] - t0, q[3] - t0);
-        }
-        fprintf(stderr, "\n");
-      }
-    }
-    (void)hipFree(stats);
-  }
-  return check_launch("devo_corr_forward_pyramid2 (region kernel)");
-}
-
 template <typename T>
 static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                            const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int H2, int W2,
                            const int64_t* f2s, int cblock, int64_t oes, int64_t ols, int64_t ooff, int R, const int* order,
-                           float coord_div, hipStream_t st) {
+                           float coord_div, const void* fmap1_t, hipStream_t st) {
   const long long BE = (long long)B * E;
   CorrLevel lv;
   int err;
   if (staged_level<T>(fmap2, C, H2, W2, f2s, cblock, ooff, coord_div, &lv, &err)) {
+    if constexpr (!std::is_same<T, double>::value)
+      if (ols > 0 && mm_eligible<T>(lv, lv, fmap1_t, BE, Np, C))
+        return launch_mm<T>(fmap1_t, lv, lv, 1, coords, ii, jj, out, BE, E, Np, n2, C, oes, ols, R, order, st);
     return launch_staged<T>(fmap1, lv, lv, 1, coords, ii, jj, out, BE, E, Np, n2, C, oes, ols, R, order, st);
   }
   if (err) return err;
@@ -1189,16 +1097,6 @@ static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* co
   hipLaunchKernelGGL(corr_fwd_generic_kernel<T>, grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii,
                      jj, (T*)out, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], oes, ols, ooff, R, coord_div);
   return check_launch("devo_corr_forward");
-}
-
-// Region kernel: a plan, the transposed patches, both levels readable by it AND by the per-edge kernel (which takes the heavy slots)
-template <typename T>
-static bool region_eligible(const CorrLevel& l0, const CorrLevel& l1, const void* fmap1_t, const int* order, long long BE, int E, int Np, int C,
-                            int R) {
-  const long long f1_bytes = (BE / (E > 0 ? E : 1)) * (long long)Np * C * PP * (long long)sizeof(T);
-  return fmap1_t != nullptr && order != nullptr && l0.region_ok && l1.region_ok && l0.mfma_ok && l1.mfma_ok && R <= 5 &&
-         l0.out_offset >= 0 && l1.out_offset >= 0 && l0.out_offset < (1LL << 20) && l1.out_offset < (1LL << 20) &&      // (32-bit element offsets inside a record)
-         f1_bytes < (1LL << 31) && BE < (1LL << 30) && (reinterpret_cast<uintptr_t>(fmap1_t) & 15) == 0;
 }
 
 extern "C" {
@@ -1220,7 +1118,7 @@ int devo_corr_patch_transpose(const void* fmap1, void* fmap1_t, int n_patches, i
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
                       const int64_t* f2s, int cblock, int64_t out_estride, int64_t out_lstride, int64_t out_offset,
-                      int radius, int dtype, const int* order, float coord_div, devo_stream_t stream) {
+                      int radius, int dtype, const int* order, float coord_div, const void* fmap1_t, devo_stream_t stream) {
   DEVO_REQUIRE(P == 3, "devo_corr_forward: patch size P must be 3 (got %d)", P);
   DEVO_REQUIRE(coord_div > 0.0f, "devo_corr_forward: coord_div must be positive");
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_forward: radius %d unsupported (max 5)", radius);
@@ -1229,9 +1127,9 @@ int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords,
   if ((long long)B * E == 0) return DEVO_OK;
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case DEVO_F32: return launch_corr_fwd<float>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, st);
-    case DEVO_F16: return launch_corr_fwd<__half>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, st);
-    case DEVO_F64: return launch_corr_fwd<double>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, st);
+    case DEVO_F32: return launch_corr_fwd<float>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, fmap1_t, st);
+    case DEVO_F16: return launch_corr_fwd<__half>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, fmap1_t, st);
+    case DEVO_F64: return launch_corr_fwd<double>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, fmap1_t, st);
   }
   set_error("devo_corr_forward: unknown dtype %d", dtype);
   return DEVO_ERR_UNSUPPORTED;
@@ -1257,18 +1155,14 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
   if (dtype == DEVO_F32) {
     ok = staged_level<float>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0) &&
          staged_level<float>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
-    if (ok && out_lstride > 0 && out_lstride < (1LL << 20) && region_eligible<float>(l0, l1, fmap1_t, order, BE, E, Np, C, radius))
-      return launch_region<float>(fmap1, fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
     if (ok && out_lstride > 0 && mm_eligible<float>(l0, l1, fmap1_t, BE, Np, C))
-      return launch_mm<float>(fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
+      return launch_mm<float>(fmap1_t, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
     if (ok) return launch_staged<float>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
   } else if (dtype == DEVO_F16) {
     ok = staged_level<__half>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0) &&
          staged_level<__half>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
-    if (ok && out_lstride > 0 && out_lstride < (1LL << 20) && region_eligible<__half>(l0, l1, fmap1_t, order, BE, E, Np, C, radius))
-      return launch_region<__half>(fmap1, fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
     if (ok && out_lstride > 0 && mm_eligible<__half>(l0, l1, fmap1_t, BE, Np, C))
-      return launch_mm<__half>(fmap1_t, l0, l1, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
+      return launch_mm<__half>(fmap1_t, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
     if (ok) return launch_staged<__half>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
   }
   // not both levels readable by the staged kernel: the caller issues one devo_corr_forward per level instead

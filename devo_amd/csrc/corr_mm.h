@@ -51,6 +51,42 @@ __device__ __forceinline__ void mm_split8(const v4u32 a, const v4u32 b, mm_h8& h
   lo = __builtin_bit_cast(mm_h8, lv);
 }
 
+// 4 fp32 values -> fp16 (hi0..3 | lo0..3), x = hi + lo to 2^-22: the patch operand's stored form
+__device__ __forceinline__ mm_h8 mm_split4(mm_f4 x) {
+  unsigned h01, h23, l01, l23;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(x[0]), "v"(x[1]));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(x[2]), "v"(x[3]));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(x[0]));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(x[1]));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(x[2]));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(x[3]));
+  const v4u32 r = {h01, h23, l01, l23};
+  return __builtin_bit_cast(mm_h8, r);
+}
+
+// fmap1 [N][C][9] -> [N][9][C], the patch (B) operand of corr_fwd_mm_kernel: 16 contiguous bytes per (pixel, 4 | 8 channels).  fp32: every
+// group of 4 channels is stored as fp16 (hi0..3 | lo0..3), x = hi + lo — the form the kernel multiplies (same 16 bytes).
+template <typename T>
+__global__ __launch_bounds__(256) void corr_patch_transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pt_lds[];
+  T* s = reinterpret_cast<T*>(pt_lds);
+  const int n = blockIdx.x;
+  if (n >= N) return;
+  const T* in = src + (int64_t)n * C * PP;
+  T* o = dst + (int64_t)n * C * PP;
+  for (int i = threadIdx.x; i < C * PP; i += 256) s[i] = in[i];
+  __syncthreads();
+  if constexpr (sizeof(T) == 2) {
+    for (int i = threadIdx.x; i < C * PP; i += 256) { const int p = i / C, c = i - p * C; o[i] = s[c * PP + p]; }
+  } else {
+    for (int i = threadIdx.x; i < (C / 4) * PP; i += 256) {
+      const int p = i / (C / 4), c4 = i - p * (C / 4);
+      const mm_f4 x = {(float)s[(4 * c4) * PP + p], (float)s[(4 * c4 + 1) * PP + p], (float)s[(4 * c4 + 2) * PP + p], (float)s[(4 * c4 + 3) * PP + p]};
+      reinterpret_cast<mm_h8*>(o)[i] = mm_split4(x);
+    }
+  }
+}
+
 // Plan -> edge slot of workgroup `gid` of `nitems` (corr_plan_slot's map: heavy edges first, the rest XCD-aware), in closed form:
 // sum over x < X of ceil((n - x) / 8) [n > x]  =  X * (n / 8) + min(X, n % 8).
 __device__ __forceinline__ int mm_plan_slot(const int* __restrict__ order, int BE, int gid, int nitems) {

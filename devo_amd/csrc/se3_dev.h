@@ -288,9 +288,11 @@ DEVO_HD void fb_adjSE3(const float* t, const float* q, const float* X, float* Y)
 DEVO_HD void fb_expSO3(const float* phi, float* q) {                                  // ba_cuda.cu:70-92
   float theta_sq = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
   float theta_p4 = theta_sq * theta_sq, theta = sqrtf(theta_sq), imag, real;
-  if (theta_sq < 1e-8f) {
-    imag = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_p4;
-    real = 1.0f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_p4;
+  // ba_cuda.cu:79-81 compares with the double 1e-8 and evaluates the series in double (its literals are doubles), rounding once:
+  // (double)theta_sq < 1e-8 <=> theta_sq <= 1e-8f (1e-8f = 9.99999994e-9 is the float just below the double 1e-8)
+  if (theta_sq <= 1e-8f) {
+    imag = (float)(0.5 - (1.0 / 48.0) * (double)theta_sq + (1.0 / 3840.0) * (double)theta_p4);
+    real = (float)(1.0 - (1.0 / 8.0) * (double)theta_sq + (1.0 / 384.0) * (double)theta_p4);
   } else {
     imag = sinf(0.5f * theta) / theta;
     real = cosf(0.5f * theta);

@@ -46,14 +46,19 @@ const char* devo_last_error(void); /* thread-local message of the last failing c
  *            (out_estride = (D-1)^2*P*P, out_lstride = 1, out_offset = 0 gives a contiguous tensor;
  *             out_lstride = 2 and out_offset = level writes straight into the stacked
  *             [B, E, (D-1)^2*P*P, 2] buffer that devo/devo.py:217 / enet.py:216 build with torch.stack.)
- *   order  optional locality plan from devo_corr_order (NULL = process edges in list order). */
+ *   order  optional locality plan from devo_corr_order (NULL = process edges in list order).
+ *   fmap1_t optional: fmap1 as devo_corr_patch_transpose lays it out.  With it, fp32 / fp16 lookups into channels-last or
+ *          channel-blocked storage with C % 32 == 0 (fp32: C <= 128, fp16: C <= 256) run as one dense product per edge on
+ *          v_mfma_f32_16x16x32_f16 (csrc/corr_mm.h; fp32 values enter as exact fp16 hi + lo pairs: 2^-22 relative per factor, fp32
+ *          accumulation).  NULL: the 4x4 matrix-core kernel with exact fp32 products (csrc/corr_mfma.h) or, for other layouts, the
+ *          staged / generic kernels. */
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
                       const int64_t* f2s /* host, 5 */, int cblock, int64_t out_estride, int64_t out_lstride,
                       int64_t out_offset, int radius, int dtype, const int* order /* plan buffer of devo_corr_order, i32 [2*B*E + 2], or NULL */,
                       float coord_div /* coords are divided by this in the kernel (correctly rounded IEEE division; pyramid level
                                          scale, 1 = as given; DEVO's scales 1 and 4 are exact either way) */,
-                      devo_stream_t stream);
+                      const void* fmap1_t, devo_stream_t stream);
 
 /* Both levels of a 2-level pyramid lookup (devo/devo.py:215-217) in ONE launch: workgroups of the fine and the coarse
  * level alternate on every CU (the fine level waits on memory, the coarse one is LDS/VALU-bound), each writing its
@@ -66,13 +71,11 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
                                const int* cblock /* host, 2 */, int64_t out_estride, int64_t out_lstride,
                                const int64_t* out_offset /* host, 2 */, int radius, int dtype, const int* order,
                                const float* coord_div /* host, 2 */,
-                               const void* fmap1_t /* optional: fmap1 as [B*Np, P*P, C] (devo_corr_patch_transpose).  With it, a pyramid plan
-                                                      (devo_corr_order with l1 >= 2) and channel-blocked / channels-last levels the lookup runs
-                                                      on the region-shared kernel: image neighbours read ONE staged copy of the frame
-                                                      region they cover.  NULL: the per-edge kernel */,
+                               const void* fmap1_t /* optional, as for devo_corr_forward: the dense-product kernel does both levels of an
+                                                      edge in one wave */,
                                devo_stream_t stream);
 
-/* fmap1 T [n_patches, C, 3, 3] -> fmap1_t [n_patches, 9, C] elements of sizeof(T) bytes: the patch operand of the region-shared lookup
+/* fmap1 T [n_patches, C, 3, 3] -> fmap1_t [n_patches, 9, C] elements of sizeof(T) bytes: the patch operand of the dense-product lookup
  * kernel, an opaque format — fp16: the transposed features; fp32: every 4 channels as fp16 (hi0..3 | lo0..3) with x = hi + lo, the
  * form the kernel multiplies (C % 4 == 0).  The patch features of DEVO change once per frame, not per update iteration: convert once,
  * reuse.  DEVO_F32 / DEVO_F16. */

@@ -171,6 +171,11 @@ def test_fused_pyramid_equals_stack():
     assert_rel(fused, ref.view(1, len(ii), -1), 1e-4, "pyramid")
 
 
+def _product_path():
+    """what a channels-last C % 128 == 0 backward takes: the product form, unless test_other_kernels_stay_covered's sub-process asked for another"""
+    return "atomic" if os.environ.get("DEVO_CORR_BWD_ATOMIC") else "segments" if os.environ.get("DEVO_CORR_BWD_SEG") else "product"
+
+
 @pytest.mark.parametrize("layout", ["cl", "nchw"])
 def test_backward_fp32(layout):
     from devo_amd.backends import cuda_corr
@@ -211,7 +216,7 @@ def test_backward_product_form(C, R, B, E, H, W):
     r1, r2 = A.corr_backward(f1, f2, coords, ii, jj, grad, R)
     f2d = channels_last5(f2.to(DEV))
     d1, d2 = cuda_corr.backward(f1.to(DEV), f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), grad.to(DEV), R)
-    assert cuda_corr.last_backward_path == ("atomic" if os.environ.get("DEVO_CORR_BWD_ATOMIC") else "segments" if os.environ.get("DEVO_CORR_BWD_SEG") else "product")
+    assert cuda_corr.last_backward_path == _product_path()
     assert d2.stride() == f2d.stride() and torch.count_nonzero(d2[:, n - 1]) == 0
     assert_rel(d1, r1, 1e-4, "d_fmap1 (product form)")
     assert_rel(d2, r2, 1e-4, "d_fmap2 (product form)")
@@ -238,7 +243,7 @@ def test_backward_product_form_four_wave_tiles_with_empty_passes():
     f2d = channels_last5(f2.to(DEV))
     for _ in range(3):                                               # (a race shows up as a hang or as a wrong tile in SOME run)
         d1, d2 = cuda_corr.backward(f1.to(DEV), f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), grad.to(DEV), R)
-        assert cuda_corr.last_backward_path == "product"
+        assert cuda_corr.last_backward_path == _product_path()
         assert torch.count_nonzero(d2[:, n - 1]) == 0 and torch.count_nonzero(d2[..., 130:]) == 0
         assert_rel(d1, r1, 1e-4, "d_fmap1 (product form, 8 x 8 tiles)")
         assert_rel(d2, r2, 1e-4, "d_fmap2 (product form, 8 x 8 tiles)")
@@ -254,7 +259,7 @@ def test_backward_nchw_takes_the_product_form():
     f2d = f2.to(DEV)
     for rep in range(2):                                             # second call: the cached copy
         d1, d2 = cuda_corr.backward(f1.to(DEV), f2d, coords.to(DEV), ii.to(DEV), jj.to(DEV), g.to(DEV), R)
-        assert cuda_corr.last_backward_path == "product"
+        assert cuda_corr.last_backward_path == _product_path()
         assert d2.shape == f2d.shape and d2.stride(2) == 1
         assert_rel(d1, r1, 1e-4, "d_fmap1 (NCHW, product form)")
         assert_rel(d2, r2, 1e-4, "d_fmap2 (NCHW, product form)")
@@ -530,7 +535,7 @@ def test_other_kernels_stay_covered(which):
     """fp32 / fp16 lookups with C = 128 take the per-edge matrix-core kernel by default.  DEVO_CORR_MFMA=0 (read once per process)
     routes them through the staged tap-centric kernel, DEVO_CORR_BWD_SEG=1 the backward through the tile kernel, DEVO_CORR_BWD_ATOMIC=1
     the channels-last C % 128 == 0 backward (product form by default) through the one-kernel atomic path: same parity tests.
-    (The region-shared kernel, DEVO_CORR_REGION=1, has its own file: tests/test_gpu_region.py.)"""
+    DEVO_CORR_MM=0 routes fused and per-level lookups through the 4x4 matrix-core kernel (exact fp32 products) instead of the dense-product one."""
     if os.environ.get("DEVO_CORR_MFMA", "1") == "0" or os.environ.get("DEVO_CORR_BWD_SEG") or os.environ.get("DEVO_CORR_BWD_ATOMIC"):
         pytest.skip("already running on another kernel")
     env = dict(os.environ)

@@ -34,7 +34,7 @@ def test_lookup_at_full_size(workload, sample):
     E = d["ii"].numel()
     per = (2 * R + 1) ** 2 * 9
     look = lambda g, order: cuda_corr.forward_pyramid(g, d["pyramid"], coords, d["kk"], d["jj"], R, (1, 4), order=order)
-    plan = cuda_corr.plan(coords, d["jj"], n, H, radius=R, width=cfg["W"], l1=4)     # pyramid plan: heavy list, live slots, dead tail
+    plan = cuda_corr.plan(coords, d["jj"], n, H, radius=R)     # pyramid plan: heavy list, live slots, dead tail
     out = look(d["gmap"], plan)
     assert out.shape == (1, E, 2 * per) and bool(torch.isfinite(out).all())
 
@@ -49,8 +49,7 @@ def test_lookup_at_full_size(workload, sample):
     assert rel_err(out.cpu()[:, sel], ref) <= 1e-4
 
     # (2) the plan only decides which edges run together: with the same classes (heavy list / live / dead tail) in another order not
-    #     one bit changes; per-level launches (the per-edge kernel: exact fp32 products, where the region-shared kernel multiplies
-    #     fp16 hi + lo pairs) agree to fp32 rounding
+    #     one bit changes; per-level launches agree to fp32 rounding (bit for bit on the same kernel family)
     assert torch.equal(look(d["gmap"], shuffled_plan(plan, E)), out)
     lv = [cuda_corr.forward(d["gmap"], fm, coords / s, d["kk"], d["jj"], R)[0].reshape(1, E, per) for fm, s in zip(d["pyramid"], (1.0, 4.0))]
     assert rel_err(torch.stack(lv, -1).reshape(1, E, -1), out) <= 2e-5
@@ -66,22 +65,10 @@ def test_lookup_at_full_size(workload, sample):
     assert torch.equal(buf, out)
 
 
-@pytest.mark.parametrize("kernel", ["per-edge", "region-shared"])
-def test_lookup_fp16_storage_at_full_size(kernel):
+def test_lookup_fp16_storage_at_full_size():
     """BASELINE configuration 2 with fp16 feature storage (the reference's inference precision, devo.py:71-77): oracle on a sample of
     edges within the fp16-storage tolerance (2e-3 of the fp32 oracle on the same rounded inputs), plan independence bit for bit,
-    every row written.  `region-shared` repeats it, and the fp32 full-size tests, in a sub-process on the opt-in region kernel
-    (DEVO_CORR_REGION=1, corr_region.h)."""
-    import subprocess
-    if kernel == "region-shared":
-        if os.environ.get("DEVO_CORR_REGION", "0") == "1":
-            pytest.skip("already running on the region kernel")
-        env = dict(os.environ); env["DEVO_CORR_REGION"] = "1"
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
-                            "(fp16_storage_at_full_size and per-edge) or test_lookup_at_full_size"],
-                           env=env, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        return
+    every row written."""
     from devo_amd import synth
     from devo_amd.backends import cuda_corr
     cfg, d, cpu, coords = _inputs("cfg2")
@@ -90,7 +77,7 @@ def test_lookup_fp16_storage_at_full_size(kernel):
     gmap = d["gmap"].half()
     pyr = [t.half() for t in d["pyramid"]]
     look = lambda order: cuda_corr.forward_pyramid(gmap, pyr, coords, d["kk"], d["jj"], R, (1, 4), order=order)
-    plan = cuda_corr.plan(coords, d["jj"], n, H, radius=R, width=cfg["W"], l1=4)
+    plan = cuda_corr.plan(coords, d["jj"], n, H, radius=R)
     out = look(plan)
     assert out.dtype == torch.float16 and bool(torch.isfinite(out).all())
     sample = 96

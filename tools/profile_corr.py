@@ -26,7 +26,7 @@ E = d["ii"].numel()
 Dm = 2 * R + 1
 out = torch.empty(1, E, Dm * Dm * 18, dtype=dt, device=dev)
 coords = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
-order = None if a.no_plan else cuda_corr.plan(coords, d["jj"], n, cfg["H"], 1.0, R, width=cfg["W"], l1=0 if a.per_level else 4)
+order = None if a.no_plan else cuda_corr.plan(coords, d["jj"], n, cfg["H"], 1.0, R)
 if a.no_plan:
     cuda_corr.PLAN_MIN_EDGES = 1 << 60
 for _ in range(a.reps):

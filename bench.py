@@ -60,6 +60,11 @@ def parse():
     ap.add_argument("--no-train-probe", action="store_true",
                     help="multi-GPU update-op runs also time a few data-parallel training steps (field \"train_dp\": the RCCL gradient "
                          "all-reduce of BASELINE configuration 4); this skips them")
+    ap.add_argument("--api", default="fused", choices=["fused", "reference"],
+                    help="reference: ONLY the probe of field \"reference_api\" — the reference's own call sequence (devo/devo.py:210-223,308-344: "
+                         "pops.transform, two altcorr.corr calls on the NCHW ring + torch.stack, fastba.BA), launched eagerly, no graph, no plan / "
+                         "workspace hand-over — printed as the JSON line")
+    ap.add_argument("--no-reference-api", action="store_true", help="skip the reference_api field of the default line")
     ap.add_argument("--with-update", action="store_true",
                     help="additionally time a FULL DEVO update iteration: the step with the Update operator (devo_amd.update, "
                          "random weights, fp16) between lookup and BA, feeding delta / weight to the BA (extra field; the headline "
@@ -148,6 +153,10 @@ def rank_main(argv):
     assert D.world() == world
     if args.mode == "train":
         out = train_mode(args, device, rank, world)
+    elif args.api == "reference":
+        out = {"metric": "update-op iterations/sec through the reference's own call sequence (eager)", "unit": "it/s", "n_gpus": 1,
+               "reference_api": reference_api_probe(args, device, 1234 + rank)}
+        out["value"] = out["reference_api"]["f32_package"]["it_per_s"]
     else:
         out = update_op_mode(args, device, rank, world)
     if rank == 0:
@@ -168,12 +177,37 @@ def train_mode(args, device, rank, world, steps=None, warmup=None, iters=None, p
     batch = T.make_batch("cfg2_m80", 1234 + rank, device)
     for _ in range(max(warmup, 1)):
         T.train_step(model, opt, batch, iters=iters)
-    D.barrier_sync(device)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = T.train_step(model, opt, batch, iters=iters)
-    D.barrier_sync(device)
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    if probe:
+        # the probe follows the update-op phase in the same process: the first steps still pay MIOpen's solver look-ups, allocator growth
+        # and DDP's bucket rebuild (round 3 reported 1578 ms for a 105 ms step after ONE warm-up step).  Warm up until two consecutive
+        # steps agree within 10 % (at most 8 more), then time `steps` steps one by one and report the MEDIAN.
+        def one():
+            D.barrier_sync(device)
+            t = time.perf_counter()
+            l_ = T.train_step(model, opt, batch, iters=iters)
+            D.barrier_sync(device)
+            return D.max_over_ranks(time.perf_counter() - t, device), l_
+        prev, _ = one()
+        for _ in range(8):
+            cur, _ = one()
+            settled = abs(cur - prev) <= 0.1 * max(cur, prev)
+            settled = D.max_over_ranks(0.0 if settled else 1.0, device) == 0.0          # the same decision on every rank (collectives inside)
+            prev = cur
+            if settled:
+                break
+        samples = []
+        for _ in range(max(steps, 3)):
+            t, loss = one()
+            samples.append(t)
+        samples.sort()
+        elapsed, steps = samples[len(samples) // 2] * len(samples), len(samples)
+    else:
+        D.barrier_sync(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = T.train_step(model, opt, batch, iters=iters)
+        D.barrier_sync(device)
+        elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
     nparam = net.num_parameters()
     res = {"ms_per_step": round(1e3 * elapsed / steps, 3), "sequences_per_s": round(world * steps / elapsed, 4),
            "update_iterations_per_step": iters, "steps": steps, "loss": float(loss),
@@ -187,6 +221,78 @@ def train_mode(args, device, rank, world, steps=None, warmup=None, iters=None, p
                                    f"corr backward on 20 % of the edges, 2 differentiable GN steps per iteration, AdamW",
                        "parallelism": f"dp{world}"},
             "train": res}
+
+
+def reference_api_probe(args, device, seed=1234, iters=60, warm=8):
+    """What a caller pays who keeps the reference's OWN call sequence (devo/devo.py:210-223 DEVO.corr / DEVO.reproject, :308-344
+    DEVO.update without the network): per update iteration
+        coords = pops.transform(SE3(poses), patches, intrinsics, ii, jj, kk).permute(0, 1, 4, 2, 3).contiguous()
+        corr   = torch.stack([altcorr.corr(gmap, pyramid[0], coords / 1, kk % (M mem), jj % mem, 3),
+                              altcorr.corr(gmap, pyramid[1], coords / 4, kk % (M mem), jj % mem, 3)], -1).view(1, E, -1)
+        target = coords[..., 1, 1] + delta;   fastba.BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, 1, n, 2)
+    on the reference's storage — NCHW ring buffers of mem = 32 frames, fp16 (MIXED_PRECISION, devo.py:71-83) or fp32 — launched eagerly:
+    no HIP graph, no plan or workspace handed from call to call (each altcorr.corr builds its own locality plan; the converted pyramid
+    and the transposed patches are cached per tensor version inside cuda_corr, as they would be in DEVO: they change once per frame).
+    Two forms of the reprojection: `package` = devo_amd.projective_ops (one fused kernel without autograd), `modules` = the reference's
+    composition over the SE3 group ops (projective_ops.py:53-105 on top of the installed lietorch_backends: what an UNMODIFIED checkout
+    gets after devo_amd.backends.install()).  Reported: iterations/s with the GPU as the clock, and the host time to enqueue one
+    iteration (no synchronisation inside)."""
+    from devo_amd import synth, altcorr, fastba, projective_ops as pops
+    from devo_amd.lietorch import SE3
+    cfg = synth.workload(args.workload)
+    n, M, H, W, C = cfg["n"], cfg["M"], cfg["H"], cfg["W"], cfg["C"]
+    mem = 32
+    poses = synth.make_poses(n, seed)
+    patches, centres = synth.make_patches(n, M, H, W, seed=seed)
+    intr = synth.make_intrinsics(n, H, W).to(device)
+    ii, jj, kk = [t.to(device) for t in synth.full_graph(n, M)]
+    fmap, gmap = synth.make_features(n, M, C, H, W, centres, seed=seed)
+    delta, weight = [t.to(device) for t in synth.make_update_outputs(len(ii), seed)]
+    lmbda = torch.as_tensor([1e-4], device=device)
+    E = ii.numel()
+    out = {}
+    for dtn, dt in (("f16", torch.float16), ("f32", torch.float32)):
+        fmap1_ = torch.zeros(1, mem, C, H, W, dtype=dt, device=device)             # devo.py:80-81
+        fmap2_ = torch.zeros(1, mem, C, H // 4, W // 4, dtype=dt, device=device)
+        gmap_ = torch.zeros(mem, M, C, 3, 3, dtype=dt, device=device)               # devo.py:77
+        f0 = fmap.to(device)
+        fmap1_[:, :n] = f0.to(dt)
+        fmap2_[:, :n] = synth.pyramid_l1(f0).to(dt)
+        gmap_.view(1, mem * M, C, 3, 3)[:, :n * M] = gmap.to(device).to(dt)
+        pyramid, gm = (fmap1_, fmap2_), gmap_.view(1, mem * M, C, 3, 3)
+        P0, Q0 = poses.to(device), patches.to(device)
+        P, Q = P0.clone(), Q0.clone()
+        for form in ("package", "modules"):
+            def update():
+                P.copy_(P0)
+                Q.copy_(Q0)                                                         # (bench harness: fresh state, as in the fused step)
+                coords = pops.transform(SE3(P), Q, intr, ii, jj, kk, fused=(form == "package"))
+                coords = coords.permute(0, 1, 4, 2, 3).contiguous()
+                ii1 = kk % (M * mem)
+                jj1 = jj % mem
+                corr1 = altcorr.corr(gm, pyramid[0], coords / 1, ii1, jj1, 3)
+                corr2 = altcorr.corr(gm, pyramid[1], coords / 4, ii1, jj1, 3)
+                corr = torch.stack([corr1, corr2], -1).view(1, E, -1)
+                target = coords[..., 1, 1] + delta.float()
+                fastba.BA(P, Q, intr, target, weight, lmbda, ii, jj, kk, 1, n, 2)
+                return corr
+            with torch.no_grad():
+                for _ in range(warm):
+                    update()
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    update()
+                t_host = time.perf_counter() - t0
+                torch.cuda.synchronize(device)
+                t_all = time.perf_counter() - t0
+            out[f"{dtn}_{form}"] = {"it_per_s": round(iters / t_all, 1), "ms_per_iter": round(1e3 * t_all / iters, 4),
+                                    "host_us_per_iter": round(1e6 * t_host / iters, 1)}
+        del fmap1_, fmap2_, gmap_
+    out["what"] = ("devo.py:210-223,308-344 as written (transform, permute, two altcorr.corr on the NCHW ring of 32 frames + torch.stack, "
+                   "target, fastba.BA with 2 GN iterations), eager launches, caches warm; package = devo_amd.projective_ops (fused "
+                   "reprojection), modules = the reference's SE3 group-op composition over lietorch_backends")
+    return out
 
 
 def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
@@ -468,6 +574,14 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         out["f16"] = {"value": h["value"], "unit": "it/s", "ms_per_step": h["ms_per_step"],
                       "roofline": {k: h["roofline"].get(k) for k in ("achieved", "frac", "kernel", "alg_bytes_per_launch", "us_per_launch", "us_per_launch_back_to_back", "traffic")},
                       "note": "same step with fp16-storage feature pyramid + patch features (DEVO's inference precision), fp32 accumulation"}
+    if rank == 0 and world == 1 and not args.no_reference_api and args.workload == "cfg2":
+        # what the reference's own (unfused, eager) call sequence costs on the same machine: bench.py --api reference alone prints it
+        torch.cuda.empty_cache()
+        try:
+            out["reference_api"] = reference_api_probe(args, device, 1234 + rank)
+            out["reference_api"]["vs_fused_api"] = round(out["reference_api"]["f32_package"]["it_per_s"] / out["value"], 3)
+        except Exception as ex:                                  # noqa: BLE001 — an extra field must not cost the line
+            out["reference_api"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if world > 1 and not args.no_train_probe:
         # BASELINE configuration 4: data-parallel training steps — the one collective of the path (13.59 MB gradient all-reduce).
         # The probe is an extra: whatever happens inside it (an exception on one rank, a collective that never returns) must not cost
@@ -485,8 +599,14 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         timer.daemon = True
         timer.start()
         try:
+            try:
+                del d, corr_out                                  # the update-op phase's buffers (gone already when the fp16 pass ran)
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
             out["train_dp"] = train_mode(args, device, rank, world, steps=3, warmup=1, iters=2, probe=True)
-            out["train_dp"]["note"] = "probe: 3 steps of 2 update iterations each (bench.py --mode train runs the full 18-iteration step)"
+            out["train_dp"]["note"] = ("probe: median of 3 steps of 2 update iterations each, after warm-up steps until two consecutive ones agree "
+                                       "within 10 % (bench.py --mode train runs the full 18-iteration step)")
         except Exception as ex:                                  # noqa: BLE001 — reported, not fatal
             out["train_dp"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
         timer.cancel()

@@ -103,12 +103,17 @@ def launch(fn, nprocs, args=()):
         raise RuntimeError(f"launch: ranks failed (rank, exit code): {bad}" + (f"; terminated the remaining ranks {sorted(live)}" if live else ""))
 
 
-def init_from_env(backend=None, device=None):
+def init_from_env(backend=None, device=None, force=False):
     """init_process_group from the launcher's environment; backend "nccl" (= RCCL) for GPU devices, "gloo" otherwise.
+    A single process needs no group and gets none unless force=True (tests: the RCCL communicator path with world size 1).
     Returns (rank, world)."""
     import os
     w = int(os.environ.get("WORLD_SIZE", "1"))
-    if w > 1 and not dist.is_initialized():
+    if (w > 1 or force) and not dist.is_initialized():
+        if w == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"

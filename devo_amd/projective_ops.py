@@ -63,10 +63,12 @@ class _FusedTransform(torch.autograd.Function):
         return gp.view_as(pose_data), gq.view_as(patches), None, None, None, None, None, None, None
 
 
-def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, jacobian=False, tonly=False):
-    """coords [1,E,P,P,2(+1)] (+ validity [1,E], + (Ji [1,E,2,6], Jj [1,E,2,6], Jz [1,E,2,1]))."""
+def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, jacobian=False, tonly=False, fused=True):
+    """coords [1,E,P,P,2(+1)] (+ validity [1,E], + (Ji [1,E,2,6], Jj [1,E,2,6], Jz [1,E,2,1])).
+    fused=False: always the reference's composition over the SE3 group ops (projective_ops.py:53-105: what an unmodified checkout of the
+    reference runs on top of the installed lietorch_backends; bench.py --api reference times it)."""
     import os
-    fused_ok = poses.data.dtype == torch.float32 and poses.data.shape[0] == 1 and patches.is_cuda
+    fused_ok = fused and poses.data.dtype == torch.float32 and poses.data.shape[0] == 1 and patches.is_cuda
     if fused_ok and not _needs_grad(poses.data, patches, intrinsics):
         return cuda_ba.transform(poses.data, patches, intrinsics, ii, jj, kk, depth=depth, valid=valid,
                                  jacobian=jacobian, tonly=tonly, layout="pp2")

@@ -23,6 +23,9 @@ def _run(args, timeout):
     return json.loads(lines[0]), lines[0]
 
 
+_seen = {}
+
+
 def _keep(name, line):
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
     if os.path.isdir(out):
@@ -38,13 +41,51 @@ def test_update_op_bench_on_two_ranks_sharing_the_gpu():
     assert d["value"] > 0 and d["ms_per_step"] > 0
     assert "train_dp" in d and "error" not in d["train_dp"], d.get("train_dp")
     assert d["train_dp"]["sequences_per_s"] > 0 and d["train_dp"]["parameters"] == 3_397_061 and d["train_dp"]["grad_bucket_bytes"] == 13_588_244
+    _seen["train_dp_ms"] = d["train_dp"]["ms_per_step"]
 
 
 def test_training_bench_on_two_ranks_sharing_the_gpu():
-    d, line = _run(["--mode", "train", "--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "1", "--train-iters", "2"], timeout=900)
+    d, line = _run(["--mode", "train", "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "4", "--train-iters", "2"], timeout=900)
     _keep("bench_train_gpus2_share.json", line)
     assert d["n_gpus"] == 2 and d["value"] > 0
     assert "dp2" in d["config"]["parallelism"] or "2" in d["config"]["parallelism"]
+    if "train_dp_ms" in _seen:
+        # the probe inside the update-op run is a MEASUREMENT of the same step (same ranks, same 2 update iterations): within 2x
+        ratio = _seen["train_dp_ms"] / d["ms_per_step"]
+        assert 0.5 <= ratio <= 2.0, (_seen["train_dp_ms"], d["ms_per_step"])
+
+
+def test_rccl_process_group_with_one_rank():
+    """`nccl` (= RCCL on ROCm) has to load, create a communicator next to live HIP work and run a collective on an MI355X before the
+    driver's 8-GPU run depends on it: one rank, init_process_group("nccl", device_id=...), an all-reduce, DistributedDataParallel's
+    bucketed gradient all-reduce of a small module, destroy."""
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "from devo_amd import distributed as D\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\n"
+        "x = torch.ones(1 << 20, device=dev) * 3\n"
+        "g = torch.cuda.CUDAGraph()\n"
+        "y = torch.zeros_like(x)\n"
+        "s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())\n"
+        "with torch.cuda.stream(s):\n"
+        "    with torch.cuda.graph(g, stream=s):\n"
+        "        y.copy_(x * 2)\n"
+        "torch.cuda.current_stream().wait_stream(s); g.replay()\n"
+        "r, w = D.init_from_env('nccl', dev, force=True)\n"
+        "assert (r, w) == (0, 1) and dist.get_backend() == 'nccl'\n"
+        "dist.all_reduce(x); dist.barrier(); torch.cuda.synchronize()\n"
+        "assert float(x[0]) == 3.0 and float(y[0]) == 6.0\n"
+        "m = torch.nn.parallel.DistributedDataParallel(torch.nn.Linear(256, 256).to(dev), device_ids=[0])\n"
+        "m(torch.randn(8, 256, device=dev)).square().mean().backward(); torch.cuda.synchronize()\n"
+        "assert m.module.weight.grad is not None and bool(torch.isfinite(m.module.weight.grad).all())\n"
+        "g.replay(); torch.cuda.synchronize()\n"
+        "dist.destroy_process_group(); print('rccl ok')\n")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("MASTER_PORT", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
 def test_update_op_bench_under_the_drivers_launch_command():

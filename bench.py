@@ -493,6 +493,8 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         per_launch = 2 if args.fuse_levels else 1                  # records are per level launch ...
         if args.fuse_levels and lookup_kernel == "corr_fwd_mfma_kernel" and recs.get(key + "/fused"):
             rec, per_launch = recs[key + "/fused"], 1              # ... except the two-level launch's own record
+        if args.fuse_levels and lookup_kernel == "corr_fwd_mm_kernel" and recs.get(key + "/fused/mm"):
+            rec, per_launch = recs[key + "/fused/mm"], 1           # the dense-product kernel's two-level launch
         if rec and rec.get("kernel", "corr_fwd_cl_kernel") == lookup_kernel:
             traffic = int((2.0 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024) * per_launch
             traffic_src = f"profiles/pmc_traffic.json ({rec['round']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x read correction)"

@@ -61,15 +61,25 @@ def corr_pyramid(fmap1, pyramid, coords, ii, jj, radius=3, scales=(1, 4)):
     return cuda_corr.forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales)
 
 
-def channel_blocked(fmap, cb=8):
+def channel_blocked(fmap, cb=8, pad=None):
     """Re-lay a [B,n,C,H,W] pyramid level as channel-blocked storage [B, n, C/cb, H, W, cb]: the cb channels of a
-    pixel are contiguous and horizontally adjacent pixels follow each other, so that one row of a lookup box is one
+    pixel are contiguous and horizontally adjacent pixels follow each other, so one row of a lookup box is one
     contiguous run of memory (full cache lines) for every channel chunk.  Inference lookup only, fp32 or fp16
-    (cuda_corr.forward / corr_pyramid accept the 6-D tensor in place of fmap2)."""
+    (cuda_corr.forward / corr_pyramid accept the 6-D tensor in place of fmap2).
+    pad: elements of padding behind every channel block (the returned tensor is a strided view; DEVO_PLANE_PAD overrides the default 0)."""
+    import os
     B, n, C, H, W = fmap.shape
     if C % cb:
         raise RuntimeError(f"channel_blocked: C={C} is not a multiple of {cb}")
-    return fmap.reshape(B, n, C // cb, cb, H, W).permute(0, 1, 2, 4, 5, 3).contiguous()
+    if pad is None:
+        pad = int(os.environ.get("DEVO_PLANE_PAD", "0"))
+    src = fmap.reshape(B, n, C // cb, cb, H, W).permute(0, 1, 2, 4, 5, 3)
+    if pad <= 0:
+        return src.contiguous()
+    buf = torch.zeros(B, n, C // cb, H * W * cb + pad, dtype=fmap.dtype, device=fmap.device)
+    out = buf[..., :H * W * cb].view(B, n, C // cb, H, W, cb)
+    out.copy_(src)
+    return out
 
 
 def build_pyramid(fmap, out=None, slot=None):

@@ -1049,7 +1049,8 @@ static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel&
   unsigned long long* trace = nullptr;                                // debug switch: per-wave cycle stamps to stderr
   const bool do_trace = getenv("DEVO_CORR_TRACE") != nullptr;
   if (do_trace) { (void)hipMalloc(&trace, (size_t)BE * 64); (void)hipMemset(trace, 0, (size_t)BE * 64); }
-  hipLaunchKernelGGL(fn, dim3((unsigned)BE), dim3(64), 0, st, (const MT*)fmap1_t, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C,
+  const unsigned nwg = DEVO_MM_EPW == 1 ? (unsigned)BE : (unsigned)(((BE + DEVO_MM_EPW - 1) / DEVO_MM_EPW + 7) / 8 * 8);   // whole groups of 8 (one per XCD)
+  hipLaunchKernelGGL(fn, dim3(nwg), dim3(64 * DEVO_MM_EPW), 0, st, (const MT*)fmap1_t, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C,
                      oes, ols, R, order, 0, trace);
   if (do_trace) {
     (void)hipDeviceSynchronize();

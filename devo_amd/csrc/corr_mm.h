@@ -31,7 +31,19 @@ typedef float mm_f4 __attribute__((ext_vector_type(4)));
 #define DEVO_MM_WAVES 4        // waves per SIMD, fp16 storage (128 registers)
 #endif
 #ifndef DEVO_MM_WAVES32
-#define DEVO_MM_WAVES32 3      // fp32 storage (the hi / lo patch and twice the bytes in flight: 168 registers)
+#define DEVO_MM_WAVES32 2      // fp32 storage (the hi / lo patch and twice the bytes in flight: 168 registers); radius 4 - 5: one wave less (two rounds of held outputs)
+#endif
+// Edges (= waves) per workgroup: EPW CONSECUTIVE plan slots — image neighbours — run on one CU at the same time, so that the lines their
+// boxes share can meet in the CU's 32 KB L1 instead of being fetched from the L2 once per edge.  DEVO_MM_SYNC = 1 additionally keeps the
+// waves of a workgroup on the same tile slot (one s_barrier per slot: ~60 cycles) — an L1 line lives about a thousand cycles.
+#ifndef DEVO_MM_EPW
+#define DEVO_MM_EPW 1
+#endif
+#ifndef DEVO_MM_RT16
+#define DEVO_MM_RT16 4          // fp16 storage: tiles in the register ring (3 in flight ahead of the products)
+#endif
+#ifndef DEVO_MM_SYNC
+#define DEVO_MM_SYNC 0
 #endif
 
 // split of 8 fp32 values into fp16 hi and lo halves, x = hi + lo to 2^-22 (|lo| below the fp16 normal range keeps 2^-25 absolute):
@@ -99,7 +111,7 @@ __device__ __forceinline__ int mm_plan_slot(const int* __restrict__ order, int B
 }
 
 template <typename T, int RMAX, int NKS, int NL, int RFIX>   // NKS = C / 32 K steps per tile; NL = levels per wave; RFIX > 0: the radius is this constant
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? DEVO_MM_WAVES : DEVO_MM_WAVES32, sizeof(T) == 2 ? DEVO_MM_WAVES : DEVO_MM_WAVES32))) void corr_fwd_mm_kernel(
+__global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 2 ? DEVO_MM_WAVES : DEVO_MM_WAVES32) - (RMAX > 3 ? 1 : 0), (sizeof(T) == 2 ? DEVO_MM_WAVES : DEVO_MM_WAVES32) - (RMAX > 3 ? 1 : 0)))) void corr_fwd_mm_kernel(
     const T* __restrict__ fmap1_t, CorrLevel lv0, CorrLevel lv1, int nlev, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int64_t out_estride, int64_t out_lstride, int R_arg, const int* __restrict__ order, int heavy_only,
@@ -109,14 +121,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
   constexpr bool HALF = sizeof(T) == 2;
   constexpr unsigned ESZ = sizeof(T);
   constexpr int LPS = HALF ? 1 : 2;                 // 16-byte loads per lane and K step
-  constexpr int RT = HALF ? 4 : 2;                  // ring of tiles (RT - 1 tiles in flight ahead of the products)
+  constexpr int RT = HALF ? DEVO_MM_RT16 : 2;       // ring of tiles (RT - 1 tiles in flight ahead of the products)
   const int wlvl = (NL == 1 && nlev == 2) ? ((blockIdx.x >> 3) & 1) : 0;                      // wave-uniform
   const int wgid = (NL == 1 && nlev == 2) ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : blockIdx.x;
   const int nwg = (NL == 1 && nlev == 2) ? (gridDim.x >> 1) : gridDim.x;
   auto second = [&](int l) -> bool { return NL == 2 ? (l != 0) : (wlvl != 0); };   // does index l mean pyramid level 1?
 #define LVF(l, F) (second(l) ? lv1.F : lv0.F)
   constexpr int DMAX = 2 * RMAX + 2;
-  // Result area per level index, one of two layouts (as in corr_mfma.h):
+  // Result area (one, reused level after level), one of two layouts (as in corr_mfma.h):
   //   box layout  [p][BOXS]        slot s of pixel p at p * BOXS + s (boxes of <= CAP positions; BOXS = CAP + 4 so that the 8 lanes
   //                                of a ds_write_b128 group, 8 pixels x the same 4 slots, fall into different banks)
   //   raw windows [p][D*D + 1]     tap (a, c) of pixel p: window-by-window tiles (larger boxes)
@@ -124,13 +136,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
   constexpr int BOXS = CAP + 4;
   constexpr int RWIN_FLOATS = (PP * (DMAX * DMAX + 1) + 3) / 4 * 4;
   constexpr int RW_FLOATS = RWIN_FLOATS > PP * BOXS ? RWIN_FLOATS : PP * BOXS;
-  __shared__ __attribute__((aligned(16))) float s_rawwin[NL * RW_FLOATS];
-  __shared__ __attribute__((aligned(16))) float s_geo[NL][16][4];      // per (level index, pixel): dx, dy, tap (0, 0)'s index in the result area, row stride
-  __shared__ int s_org[NL][PP][2];                                     // window origins (window-by-window tiles only)
+  constexpr int EPW = DEVO_MM_EPW;
+  const int wv = EPW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // this wave's edge inside the workgroup
+  __shared__ __attribute__((aligned(16))) float s_rawwin_all[EPW][RW_FLOATS];   // ONE level's result area: a level is blended before the next one's tiles land
+  __shared__ __attribute__((aligned(16))) float s_geo_all[EPW][NL][16][4];   // per (level index, pixel): dx, dy, tap (0, 0)'s index in the result area, row stride
+  __shared__ int s_org_all[EPW][NL][PP][2];                                  // window origins (window-by-window tiles only)
+  float* const s_rawwin = s_rawwin_all[wv];
+  float (*const s_geo)[16][4] = s_geo_all[wv];
+  int (*const s_org)[PP][2] = s_org_all[wv];
   const int lane = threadIdx.x & 63;
-  int slot = mm_plan_slot(order, BE, wgid, nwg);
+  int slot;
+  if (EPW == 1) slot = mm_plan_slot(order, BE, wgid, nwg);
+  else {                                       // workgroup g (on XCD g % 8) takes EPW consecutive slots of its XCD's contiguous share of the plan
+    const int per = (nwg + 7) >> 3;
+    slot = (((wgid & 7) * per + (wgid >> 3)) * EPW) + wv;
+    if ((wgid >> 3) >= per) slot = BE;
+  }
   if (heavy_only) {
-    slot = (int)blockIdx.x;
+    slot = (int)blockIdx.x * EPW + wv;
     if (slot >= (order ? min(max(order[BE], 0), BE) : 0)) return;
   }
   if (slot >= BE) return;                     // wave-uniform; no workgroup barriers in this kernel
@@ -281,13 +304,64 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
     return acc;
   };
   constexpr int TPL = CAP / 16;                              // tile slots per level of the static schedule
-  if (all_box) {
-    // ---- the usual case, as ONE straight line: NL x TPL tile slots whose level and tile number are compile-time constants (a slot
-    //      beyond its level's last tile fetches nothing — every lane out of range — and stores zeros behind the box), so the loop has
-    //      no branches, no scalar bookkeeping, immediate LDS offsets, and each level's descriptors are the kernel arguments themselves.
+  // ---- fused bilinear blend + axis swap + output permutation (correlation_kernel.cu:221-232), level by level.
+  //      Output element (l, t), t = q * 9 + p with q = cx * Dm + a (cx = x offset: permute(0,1,3,2,4,5), a = y offset), goes to
+  //      out[be * estride + t * lstride + offset(l)].
+  //      Lane (a, p) = (lane / 9, lane % 9) blends ROW a of pixel p's window: the Dm + 1 taps of rows a, a + 1 read once, Dm outputs in the
+  //      reference's blend order.  Level index 0's outputs wait in registers while level index 1's tiles reuse the result area; the
+  //      standard stacked record (torch.stack([c0, c1], -1)) then leaves as ONE 4- / 8-byte piece per output pair: the 63 lanes of a
+  //      store write 63 consecutive pieces.
+  const int Dm = D - 1;
+  constexpr int DMM = 2 * RMAX + 1;
+  constexpr int NRND = (DMM + 6) / 7;                         // rounds of 7 window rows (radius <= 3: one)
+  const bool paired = NL == 2 && out_lstride == 2 && lv0.out_offset == 0 && lv1.out_offset == 1 && (out_estride & 1) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+  const int ar = (lane * 57) >> 9, ep = lane - 9 * ar;                                     // lane / 9, lane % 9 for lane < 64
+  float held[NL][NRND][DMM];                                  // blended outputs of (level index, round, x offset) for this lane's (a, p)
+  auto blend = [&](int l) {
+    wave_lds_fence();
+    const float4 ge = *reinterpret_cast<const float4*>(&s_geo[l][ep][0]);
+    float w0, w1, w2, w3;
+    {
+#pragma clang fp contract(off)
+      w0 = (1.0f - ge.x) * (1.0f - ge.y); w1 = ge.x * (1.0f - ge.y); w2 = (1.0f - ge.x) * ge.y; w3 = ge.x * ge.y;   // blend4's factors
+    }
+    const int rs = __float_as_int(ge.w);
+#pragma unroll
+    for (int rd = 0; rd < NRND; rd++) {
+      const int a = 7 * rd + ar;
+      if (7 * rd < Dm) {
+        const float* r0 = s_rawwin + __float_as_int(ge.z) + min(a, Dm - 1) * rs;      // (lanes beyond the last row read row Dm - 1: in range)
+        float t0[DMM + 1], u0[DMM + 1];
+#pragma unroll
+        for (int c = 0; c <= DMM; c++) if (c <= Dm) { t0[c] = r0[c]; u0[c] = r0[rs + c]; }
+#pragma unroll
+        for (int cx = 0; cx < DMM; cx++) {
+          if (cx < Dm) {
+            float o;
+            {
+#pragma clang fp contract(off)
+              o = w0 * t0[cx]; o = o + w1 * t0[cx + 1]; o = o + w2 * u0[cx]; o = o + w3 * u0[cx + 1];
+            }
+            held[l][rd][cx] = o;
+          }
+        }
+      }
+    }
+    wave_lds_fence();                                         // the taps are in registers before the next level's tiles overwrite the area
+  };
+  // Tile counts a radius-3 box can have: 0 (the box misses the frame) or 4 .. 8 (64 .. 128 positions): for those the tile loops exist as
+  // straight-line code per count (a uniform switch picks one): no dead fetch, no scalar bookkeeping, every wait counted by the compiler.
+  constexpr bool EXACT = RFIX == 3 && RMAX == 3;
+  auto exact_count = [](int n) -> bool { return n == 0 || (n >= 4 && n <= 8); };
+  if (EXACT && all_box && exact_count(g0.ntile) && (NL == 1 || exact_count(g1.ntile))) {
+    // Every wave-instruction of a load occupies the CU's texture addresser (16 quads, ~1.4 cycles each: a quad of four positions x 16 bytes
+    // straddles a 128-byte line three times in eight) whether its lanes fetch or not — the addresser is ~97 % busy in this kernel
+    // (TA_BUSY, profiles/README.md r04) — so nothing is fetched that a box does not have.
+    constexpr int XR = 2;                                    // ring of 2 tiles: one in flight ahead of the products
+    v4u32 (&xr)[RT][NKS][LPS] = rb;
     __amdgpu_buffer_rsrc_t rsl[NL];
-    unsigned lane_piece[NL], step_b[NL], second_b[NL];
-    unsigned shb[NL], swb[NL];                               // byte strides of a row / a column
+    unsigned lane_piece[NL], step_b[NL], second_b[NL], shb[NL], swb[NL];
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       rsl[l] = frame_rsrc(l);
@@ -296,8 +370,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
       shb[l] = (unsigned)LVF(l, s_h) * ESZ; swb[l] = (unsigned)LVF(l, s_w) * ESZ;
     }
     const float fmi = (float)mi + 0.5f;
-    auto fetch_slot = [&](int ring, int i) {                 // (i is a constant after unrolling)
-      const int l = i / TPL, t = i - l * TPL;
+    auto fetch_lt = [&](int ring, int l, int t) {            // (ring, l, t: constants after inlining)
       const Geo& G = l ? g1 : g0;
       const int sl = t * 16 + mi;
       const int pyy = (int)((fmi + (float)(t * 16)) * G.inv_bw);      // exact: sl < 2^16, error margin 0.5 / bw
@@ -306,177 +379,210 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
       const unsigned voff = ok ? (unsigned)gy * shb[l] + (unsigned)gx * swb[l] + lane_piece[l] : OFF_NONE;
 #pragma unroll
       for (int s = 0; s < NKS; s++) {
-        rb[ring][s][0] = __builtin_amdgcn_raw_buffer_load_b128(rsl[l], voff, (unsigned)s * step_b[l], 0);
-        if constexpr (!HALF) rb[ring][s][1] = __builtin_amdgcn_raw_buffer_load_b128(rsl[l], voff, (unsigned)s * step_b[l] + second_b[l], 0);
+        xr[ring][s][0] = __builtin_amdgcn_raw_buffer_load_b128(rsl[l], voff, (unsigned)s * step_b[l], 0);
+        if constexpr (!HALF) xr[ring][s][1] = __builtin_amdgcn_raw_buffer_load_b128(rsl[l], voff, (unsigned)s * step_b[l] + second_b[l], 0);
       }
     };
-    constexpr int NSLOT = NL * TPL;
-#pragma unroll
-    for (int r = 0; r < RT - 1; r++) { fetch_slot(r, r); __builtin_amdgcn_sched_barrier(0); }
     float* const dst = s_rawwin + mi * BOXS + 4 * kg;        // lane (n, rg): positions 4 rg .. + 3 of column n
+    // level `lv` with K tiles, its tile 0 already in flight in ring slot OFS; NEXT: the following level's tile 0 is fetched behind the last one
+    auto run_level = [&](auto lv_c, auto k_c, auto ofs_c, auto next_c) {
+      constexpr int LV = decltype(lv_c)::value, K = decltype(k_c)::value, OFS = decltype(ofs_c)::value;
+      constexpr bool NEXT = decltype(next_c)::value;
 #pragma unroll
-    for (int i = 0; i < NSLOT; i++) {
-      if (i + RT - 1 < NSLOT) fetch_slot((i + RT - 1) % RT, i + RT - 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const mm_f4 acc = multiply(i % RT);
-      if (mi < PP) *reinterpret_cast<mm_f4*>(dst + (i / TPL) * RW_FLOATS + (i % TPL) * 16) = acc;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
-    // ---- boxes beyond the result area (the plan's HEAVY class): a dynamic list of tiles, window by window where needed
-    wave_lds_fence();                                        // (s_org)
-    auto tile_off = [&](int tt) -> unsigned {                // byte offset of this lane's position in flat tile tt (OFF_NONE: nothing)
-      const int l = (NL == 2 && tt >= nt0) ? 1 : 0;
-      const Geo& G = l ? g1 : g0;
-      const int t = l ? tt - nt0 : tt;
-      int gy, gx;
-      bool listed;
-      if (G.box_mode) {
-        const int sl = t * 16 + mi;
-        const int pyy = (int)(((float)sl + 0.5f) * G.inv_bw);
-        gy = G.ymin + pyy; gx = G.xmin + (sl - pyy * G.bw);
-        listed = sl < G.nslots;
-      } else {
-        const int wp = t / WT, tw = (t - wp * WT) * 16 + mi;      // (wave-uniform window, lane's tap)
-        const int ta = tw / D;
-        gy = s_org[l][wp][1] + ta; gx = s_org[l][wp][0] + (tw - ta * D);
-        listed = tw < ntap;
+      for (int i = 0; i < K; i++) {
+        if (i + 1 < K) fetch_lt((OFS + i + 1) % XR, LV, i + 1);
+        else if (NEXT) fetch_lt((OFS + i + 1) % XR, LV + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const mm_f4 acc = multiply((OFS + i) % XR);
+        if (mi < PP) *reinterpret_cast<mm_f4*>(dst + i * 16) = acc;
+        __builtin_amdgcn_sched_barrier(0);
       }
-      const bool ok = listed && tt < ntot && gy >= 0 && gy < LVF(l, H2) && gx >= 0 && gx < LVF(l, W2);
-      return ok ? (unsigned)(gy * (int)LVF(l, s_h) + gx * (int)LVF(l, s_w)) * ESZ : OFF_NONE;
     };
-    auto fetch = [&](int ring, int tt) {
-      const int l = (NL == 2 && tt >= nt0) ? 1 : 0;
-      const __amdgpu_buffer_rsrc_t rs = frame_rsrc(l);
+    using std::integral_constant;
+    auto zero_area = [&]() { for (int i = lane; i < PP * BOXS; i += 64) s_rawwin[i] = 0.0f; };
+    const int k0 = g0.ntile, k1 = NL == 2 ? g1.ntile : 0;
+    // level index 0 (its tile 0 — or, without tiles, level index 1's — goes first)
+    if (k0 > 0) fetch_lt(0, 0, 0); else if (NL == 2) fetch_lt(0, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr bool N2 = NL == 2;
+    switch (k0) {
+      case 4: run_level(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
+      case 5: run_level(integral_constant<int, 0>{}, integral_constant<int, 5>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
+      case 6: run_level(integral_constant<int, 0>{}, integral_constant<int, 6>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
+      case 7: run_level(integral_constant<int, 0>{}, integral_constant<int, 7>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
+      case 8: run_level(integral_constant<int, 0>{}, integral_constant<int, 8>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
+      default: zero_area(); break;                           // no tiles: its box of zeros
+    }
+    if constexpr (NL == 2) {
+      blend(0);                                              // (level index 1's tile 0 is in flight)
+      if (k1 == 0) zero_area();
+      // level index 1 starts in ring slot k0 % 2
+      switch (k1 * 2 + (k0 & 1)) {
+        case 8: run_level(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+        case 9: run_level(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, 1>{}, integral_constant<bool, false>{}); break;
+        case 10: run_level(integral_constant<int, 1>{}, integral_constant<int, 5>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+        case 11: run_level(integral_constant<int, 1>{}, integral_constant<int, 5>{}, integral_constant<int, 1>{}, integral_constant<bool, false>{}); break;
+        case 12: run_level(integral_constant<int, 1>{}, integral_constant<int, 6>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+        case 13: run_level(integral_constant<int, 1>{}, integral_constant<int, 6>{}, integral_constant<int, 1>{}, integral_constant<bool, false>{}); break;
+        case 14: run_level(integral_constant<int, 1>{}, integral_constant<int, 7>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+        case 15: run_level(integral_constant<int, 1>{}, integral_constant<int, 7>{}, integral_constant<int, 1>{}, integral_constant<bool, false>{}); break;
+        case 16: run_level(integral_constant<int, 1>{}, integral_constant<int, 8>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+        case 17: run_level(integral_constant<int, 1>{}, integral_constant<int, 8>{}, integral_constant<int, 1>{}, integral_constant<bool, false>{}); break;
+        default: break;                                      // (k1 == 0: the tile fetched ahead found nothing)
+      }
+    }
+    blend(NL - 1);
+  } else
+  if (all_box) {
+    // ---- the usual case: ONE flat list of the tiles both levels really have (level index 0's, then 1's), RT tiles per loop turn.
+    //      Every wave-instruction of a load occupies the CU's texture addresser for 16 cycles whether its lanes fetch or not (measured:
+    //      with all fetches switched off the kernel kept 3/4 of its time, profiles/README.md r04) — so no slot of a static schedule is
+    //      spent on tiles a box does not have; what remains are the RT - 1 fetches that run ahead past the last tile.  The level's
+    //      descriptors sit in scalar registers twice, a tile selects its set.
+    struct LS { __amdgpu_buffer_rsrc_t rs; unsigned step, second, shb, swb; int H2, W2, xmin, ymin, bw, nslots; float inv_bw; };
+    LS ls[NL];
+    unsigned lane_piece[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      const Geo& G = l ? g1 : g0;
       const Pieces pc = pieces_of(l);
-      const unsigned off = tile_off(tt);
-      const unsigned voff = off == OFF_NONE ? OFF_NONE : off + pc.lane0;
+      ls[l] = LS{frame_rsrc(l), pc.step, pc.second, (unsigned)LVF(l, s_h) * ESZ, (unsigned)LVF(l, s_w) * ESZ, LVF(l, H2), LVF(l, W2),
+                 G.xmin, G.ymin, G.bw, G.nslots, G.inv_bw};
+      lane_piece[l] = pc.lane0;
+    }
+    const float fmi = (float)mi + 0.5f;
+    // level index 0's tile count is rounded up to whole loop turns (its last turn may carry tiles beyond the box: they fetch nothing),
+    // so that a turn never straddles the two levels and the blend of level index 0 sits BETWEEN two loops instead of inside one
+    const int nt0p = NL == 2 ? (nt0 + RT - 1) / RT * RT : nt0, ntotp = NL == 2 ? nt0p + g1.ntile : nt0;
+    auto fetch_tile = [&](int ring, int tt) {
+      const bool l1 = NL == 2 && tt >= nt0p;                 // wave-uniform
+      const LS& S = l1 ? ls[NL - 1] : ls[0];
+      const int t = l1 ? tt - nt0p : tt;
+      const int sl = t * 16 + mi;
+      const int pyy = (int)((fmi + (float)(t * 16)) * S.inv_bw);      // exact: sl < 2^16, error margin 0.5 / bw
+      const int gy = S.ymin + pyy, gx = S.xmin + (sl - __mul24(pyy, S.bw));
+#ifdef DEVO_MM_DBG_FRAC      // timing experiment (wrong results): fetch only DEVO_MM_DBG_FRAC / 8 of every box
+      const bool ok = tt < ntotp && sl < (S.nslots * DEVO_MM_DBG_FRAC) / 8 && (unsigned)gy < (unsigned)S.H2 && (unsigned)gx < (unsigned)S.W2;
+#else
+      const bool ok = tt < ntotp && sl < S.nslots && (unsigned)gy < (unsigned)S.H2 && (unsigned)gx < (unsigned)S.W2;
+#endif
+      const unsigned voff = ok ? (unsigned)gy * S.shb + (unsigned)gx * S.swb + (l1 ? lane_piece[NL - 1] : lane_piece[0]) : OFF_NONE;
 #pragma unroll
       for (int s = 0; s < NKS; s++) {
-        rb[ring][s][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)s * pc.step, 0);
-        if constexpr (!HALF) rb[ring][s][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)s * pc.step + pc.second, 0);
+        rb[ring][s][0] = __builtin_amdgcn_raw_buffer_load_b128(S.rs, voff, (unsigned)s * S.step, 0);
+        if constexpr (!HALF) rb[ring][s][1] = __builtin_amdgcn_raw_buffer_load_b128(S.rs, voff, (unsigned)s * S.step + S.second, 0);
       }
     };
 #pragma unroll
-    for (int l = 0; l < NL; l++)                             // a level without tiles: its D x D box of zeros
-      if ((l ? g1.nslots : g0.nslots) == 0)
-        for (int i = lane; i < PP * BOXS; i += 64) s_rawwin[l * RW_FLOATS + i] = 0.0f;
-#pragma unroll
-    for (int r = 0; r < RT - 1; r++) { fetch(r, r); __builtin_amdgcn_sched_barrier(0); }
-    for (int t0 = 0; t0 < ntot; t0 += RT) {
+    for (int r = 0; r < RT - 1; r++) { fetch_tile(r, r); __builtin_amdgcn_sched_barrier(0); }
+    float* const dst = s_rawwin + mi * BOXS + 4 * kg;        // lane (n, rg): positions 4 rg .. + 3 of column n
+    auto turn = [&](int t0, int tbase, int tend) {           // tiles t0 .. t0 + RT - 1 of the level whose first flat tile is tbase
 #pragma unroll
       for (int r = 0; r < RT; r++) {
-        const int tt = t0 + r;
-        fetch((r + RT - 1) % RT, tt + RT - 1);
+        fetch_tile((r + RT - 1) % RT, t0 + r + RT - 1);
         __builtin_amdgcn_sched_barrier(0);
         const mm_f4 acc = multiply(r);
-        if (tt < ntot) {                                            // wave-uniform; no memory loads inside
-          const int l = (NL == 2 && tt >= nt0) ? 1 : 0;
-          const bool boxm = l ? g1.box_mode : g0.box_mode;
-          const int t = l ? tt - nt0 : tt;
-          float* rawwin = s_rawwin + l * RW_FLOATS;
-          if (boxm) {
-            if (mi < PP) *reinterpret_cast<mm_f4*>(rawwin + mi * BOXS + t * 16 + 4 * kg) = acc;
-          } else {
-            const int wp = t / WT, tw = (t - wp * WT) * 16 + 4 * kg;
-            if (mi == wp) {
-#pragma unroll
-              for (int j = 0; j < 4; j++) if (tw + j < ntap) rawwin[wp * (ntap + 1) + tw + j] = acc[j];
-            }
-          }
-        }
+        if (t0 + r < tend && mi < PP) *reinterpret_cast<mm_f4*>(dst + (t0 + r - tbase) * 16) = acc;
         __builtin_amdgcn_sched_barrier(0);
       }
+    };
+    if (g0.ntile == 0) { for (int i = lane; i < PP * BOXS; i += 64) s_rawwin[i] = 0.0f; }      // a level without tiles: its box of zeros
+    for (int t0 = 0; t0 < nt0p; t0 += RT) turn(t0, 0, nt0);
+    if (NL == 2) {
+      blend(0);                                              // (level index 1's first tiles are in flight)
+      if (g1.ntile == 0) { for (int i = lane; i < PP * BOXS; i += 64) s_rawwin[i] = 0.0f; }
+      for (int t0 = nt0p; t0 < ntotp; t0 += RT) turn(t0, nt0p, ntotp);
+    }
+    blend(NL - 1);
+  } else {
+    // ---- boxes beyond the result area (the plan's HEAVY class): level by level a dynamic list of tiles, window by window where needed
+    wave_lds_fence();                                        // (s_org)
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      const Geo& G = l ? g1 : g0;
+      const int ntl = G.ntile;
+      if (G.nslots == 0)                                     // a level without tiles: its D x D box of zeros
+        for (int i = lane; i < PP * BOXS; i += 64) s_rawwin[i] = 0.0f;
+      const __amdgpu_buffer_rsrc_t rs = frame_rsrc(l);
+      const Pieces pc = pieces_of(l);
+      auto fetch = [&](int ring, int t) {
+        int gy, gx;
+        bool listed;
+        if (G.box_mode) {
+          const int sl = t * 16 + mi;
+          const int pyy = (int)(((float)sl + 0.5f) * G.inv_bw);
+          gy = G.ymin + pyy; gx = G.xmin + (sl - pyy * G.bw);
+          listed = sl < G.nslots;
+        } else {
+          const int wp = t / WT, tw = (t - wp * WT) * 16 + mi;      // (wave-uniform window, lane's tap)
+          const int ta = tw / D;
+          gy = s_org[l][min(wp, PP - 1)][1] + ta; gx = s_org[l][min(wp, PP - 1)][0] + (tw - ta * D);
+          listed = tw < ntap;
+        }
+        const bool ok = listed && t < ntl && gy >= 0 && gy < LVF(l, H2) && gx >= 0 && gx < LVF(l, W2);
+        const unsigned voff = ok ? (unsigned)(gy * (int)LVF(l, s_h) + gx * (int)LVF(l, s_w)) * ESZ + pc.lane0 : OFF_NONE;
+#pragma unroll
+        for (int s = 0; s < NKS; s++) {
+          rb[ring][s][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)s * pc.step, 0);
+          if constexpr (!HALF) rb[ring][s][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)s * pc.step + pc.second, 0);
+        }
+      };
+#pragma unroll
+      for (int r = 0; r < RT - 1; r++) { fetch(r, r); __builtin_amdgcn_sched_barrier(0); }
+      for (int t0 = 0; t0 < ntl; t0 += RT) {
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+          const int t = t0 + r;
+          fetch((r + RT - 1) % RT, t + RT - 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const mm_f4 acc = multiply(r);
+          if (t < ntl) {                                              // wave-uniform; no memory loads inside
+            if (G.box_mode) {
+              if (mi < PP) *reinterpret_cast<mm_f4*>(s_rawwin + mi * BOXS + t * 16 + 4 * kg) = acc;
+            } else {
+              const int wp = t / WT, tw = (t - wp * WT) * 16 + 4 * kg;
+              if (mi == wp) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (tw + j < ntap) s_rawwin[wp * (ntap + 1) + tw + j] = acc[j];
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      blend(l);
     }
   }
-  wave_lds_fence();
   if (trace) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t_st[3] = __builtin_readcyclecounter(); }
-  // ---- fused bilinear blend + axis swap + output permutation (correlation_kernel.cu:221-232).
-  //      Output element (l, t), t = q * 9 + p with q = cx * Dm + a (cx = x offset: permute(0,1,3,2,4,5), a = y offset), goes to
-  //      out[be * estride + t * lstride + offset(l)].
-  const int Dm = D - 1;
-  const bool paired = NL == 2 && out_lstride == 2 && lv0.out_offset == 0 && lv1.out_offset == 1 && (out_estride & 1) == 0 &&
-                      (reinterpret_cast<uintptr_t>(out) & 7) == 0;
-  if (paired) {
-    // The standard stacked record (torch.stack([c0, c1], -1)): lane (a, p) = (lane / 9, lane % 9) does ROW a of pixel p's window at BOTH
-    // levels — 2 x (Dm + 1) taps of rows a, a + 1 per level read once, Dm outputs per level in the reference's blend order — and
-    // stores the two levels' values of one output as ONE 4- / 8-byte piece: the 63 lanes of a store write 63 consecutive pieces.
-    constexpr int DMM = 2 * RMAX + 1;
-    const int ar = (lane * 57) >> 9, p = lane - 9 * ar;                                  // lane / 9 for lane < 64
-    const float4 ga = *reinterpret_cast<const float4*>(&s_geo[0][p][0]), gb = *reinterpret_cast<const float4*>(&s_geo[NL - 1][p][0]);
-    float w[2][4];
-    {
-#pragma clang fp contract(off)
-      w[0][0] = (1.0f - ga.x) * (1.0f - ga.y); w[0][1] = ga.x * (1.0f - ga.y); w[0][2] = (1.0f - ga.x) * ga.y; w[0][3] = ga.x * ga.y;
-      w[1][0] = (1.0f - gb.x) * (1.0f - gb.y); w[1][1] = gb.x * (1.0f - gb.y); w[1][2] = (1.0f - gb.x) * gb.y; w[1][3] = gb.x * gb.y;
-    }
-    const int rs0 = __float_as_int(ga.w), rs1_ = __float_as_int(gb.w);
+  // ---- stores: lane (a, p) owns outputs (cx, a, p) of every level index
+  {
     T* const rec = out + (int64_t)be * out_estride;
-    for (int a0 = 0; a0 < Dm; a0 += 7) {                     // (radius <= 3: one round)
-      const int a = a0 + ar;
-      if (lane < 63 && a < Dm) {
-        const float* r0 = s_rawwin + __float_as_int(ga.z) + a * rs0;
-        const float* r1 = s_rawwin + RW_FLOATS + __float_as_int(gb.z) + a * rs1_;
-        float t0[DMM + 1], t1[DMM + 1], u0[DMM + 1], u1[DMM + 1];
 #pragma unroll
-        for (int c = 0; c <= DMM; c++) if (c <= Dm) { t0[c] = r0[c]; u0[c] = r0[rs0 + c]; t1[c] = r1[c]; u1[c] = r1[rs1_ + c]; }
-        T* op = rec + (a * PP + p) * 2;
+    for (int rd = 0; rd < NRND; rd++) {
+      const int a = 7 * rd + ar;
+      if (7 * rd < Dm && lane < 63 && a < Dm) {
+        const int t0 = a * PP + ep;                          // t of x offset 0; x offset cx adds cx * Dm * 9
 #pragma unroll
         for (int cx = 0; cx < DMM; cx++) {
           if (cx < Dm) {
-            float o0, o1;
-            {
-#pragma clang fp contract(off)
-              o0 = w[0][0] * t0[cx]; o0 = o0 + w[0][1] * t0[cx + 1]; o0 = o0 + w[0][2] * u0[cx]; o0 = o0 + w[0][3] * u0[cx + 1];
-              o1 = w[1][0] * t1[cx]; o1 = o1 + w[1][1] * t1[cx + 1]; o1 = o1 + w[1][2] * u1[cx]; o1 = o1 + w[1][3] * u1[cx + 1];
-            }
-            if constexpr (HALF) {
-              const mm_h2 v = {(_Float16)o0, (_Float16)o1};
-              *reinterpret_cast<mm_h2*>(op + cx * (Dm * PP * 2)) = v;
+            if (paired) {
+              T* op = rec + (t0 + cx * (Dm * PP)) * 2;
+              if constexpr (HALF) {
+                const mm_h2 v = {(_Float16)held[0][rd][cx], (_Float16)held[NL - 1][rd][cx]};
+                *reinterpret_cast<mm_h2*>(op) = v;
+              } else {
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                const f2v v = {held[0][rd][cx], held[NL - 1][rd][cx]};
+                *reinterpret_cast<f2v*>(op) = v;
+              }
             } else {
-              typedef float f2v __attribute__((ext_vector_type(2)));
-              const f2v v = {o0, o1};
-              *reinterpret_cast<f2v*>(op + cx * (Dm * PP * 2)) = v;
+#pragma unroll
+              for (int l = 0; l < NL; l++)
+                store_streamed(rec + (int64_t)(t0 + cx * (Dm * PP)) * out_lstride + LVF(l, out_offset), from_f32<T>(held[l][rd][cx]));
             }
           }
         }
       }
-    }
-  } else {
-    // any other output layout: one element per lane and round (corr_mfma.h's epilogue)
-    constexpr int NPL = PP * NL, GRPS = 64 / NPL;               // 18 (p, l) pairs x 3 q's, or 9 x 7
-    const int nq = Dm * Dm;
-    const int grp = lane / NPL, pl = lane - grp * NPL;
-    const int p = pl / NL, l = pl - p * NL;
-    const bool active = grp < GRPS;
-    const float4 gg = *reinterpret_cast<const float4*>(&s_geo[l][p][0]);
-    float w00, w01, w10, w11;
-    {
-#pragma clang fp contract(off)
-      w00 = (1.0f - gg.x) * (1.0f - gg.y); w01 = gg.x * (1.0f - gg.y); w10 = (1.0f - gg.x) * gg.y; w11 = gg.x * gg.y;   // blend4's factors
-    }
-    const int rstride = __float_as_int(gg.w);
-    int q = grp;
-    int cx = 0, a = q;
-    while (a >= Dm) { a -= Dm; cx += 1; }
-    const float* rw = s_rawwin + l * RW_FLOATS + __float_as_int(gg.z);
-    T* op = out + (int64_t)be * out_estride + (int64_t)(q * PP + p) * out_lstride + LVF(l, out_offset);
-    const int64_t ostep = (int64_t)(GRPS * PP) * out_lstride;
-    for (int q0 = 0; q0 < nq; q0 += GRPS) {
-      if (active && q < nq) {
-        const float* r = rw + a * rstride + cx;
-        float o;
-        {
-#pragma clang fp contract(off)
-          o = w00 * r[0]; o = o + w01 * r[1]; o = o + w10 * r[rstride]; o = o + w11 * r[rstride + 1];
-        }
-        store_streamed(op, from_f32<T>(o));
-      }
-      op += ostep;
-      q += GRPS; a += GRPS;
-      if (a >= Dm) { a -= Dm; cx += 1; }
-      if (a >= Dm) { a -= Dm; cx += 1; }
-      while (a >= Dm) { a -= Dm; cx += 1; }
     }
   }
   if (trace && lane == 0) {                          // per-wave cycle stamps (launch_mm prints the phase means)

@@ -102,13 +102,21 @@ def test_bundle_adjustment_at_full_size(workload):
     E = d["ii"].numel()
     Np = d["patches0"].shape[1]
     P_, Q_ = d["poses0"].clone(), d["patches0"].clone()
-    delta = (0.3 * d["delta"]).contiguous()                               # sub-pixel updates (see __graft_entry__.smoke)
+    # cfg2 runs the bench's own update noise (sigma = 1 px) under the strict per-row bound (profiles/r03_ba_1px_envelope.txt: 1.6e-6).
+    # cfg1 (n = 8, M = 48: a sixth of the edges per pose, the system is that much worse conditioned) keeps sub-pixel updates: at 1 px the
+    # fp32 rounding of ANY summation order lands between 1e-5 and 1.5e-4 of the fp64 oracle depending on the seed (__graft_entry__.smoke)
+    sigma = 1.0 if workload == "cfg2" else 0.3
+    delta = (sigma * d["delta"]).contiguous()
     target = coords[:, :, :, 1, 1] + delta
     cuda_ba.forward(P_, Q_, d["intr"], target, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2)
     pr, qr = F.ba(cpu["poses"].double(), cpu["patches"].double(), cpu["intr"].double(), target.cpu().double(), cpu["weight"].double(),
                   torch.tensor([1e-4]), cpu["ii"], cpu["jj"], cpu["kk"], 1, n, 2, dtype=torch.float64)
     assert rel_err(P_.cpu()[..., :3], pr[..., :3]) <= 1e-4 and rel_err(P_.cpu()[..., 3:], pr[..., 3:]) <= 1e-4
     assert rel_err(Q_.cpu()[:, :, 2], qr[:, :, 2]) <= 1e-4
+    if workload == "cfg2":                                                 # ... and row by row: every pose, every patch depth
+        from util import row_rel_err
+        assert float(row_rel_err(P_.cpu()[0, :, :3], pr[0, :, :3]).max()) <= 1e-4 and float(row_rel_err(P_.cpu()[0, :, 3:], pr[0, :, 3:]).max()) <= 1e-4
+        assert float(row_rel_err(Q_.cpu()[0, :, 2, 1, 1], qr[0, :, 2, 1, 1]).max()) <= 1e-4
     assert torch.equal(Q_.cpu()[:, :, :2], cpu["patches"][:, :, :2])
     # the same through the entry that forms the target itself, from a prepared workspace: identical bits
     P2, Q2 = d["poses0"].clone(), d["patches0"].clone()

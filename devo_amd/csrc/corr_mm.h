@@ -31,7 +31,8 @@ typedef float mm_f4 __attribute__((ext_vector_type(4)));
 #define DEVO_MM_WAVES 4        // waves per SIMD, fp16 storage (128 registers)
 #endif
 #ifndef DEVO_MM_WAVES32
-#define DEVO_MM_WAVES32 2      // fp32 storage (the hi / lo patch and twice the bytes in flight: 168 registers); radius 4 - 5: one wave less (two rounds of held outputs)
+#define DEVO_MM_WAVES32 2      // fp32 storage (the hi / lo patch, twice the bytes in flight, the held outputs: up to 200 registers; the kernel's time does not
+                               // depend on 2, 3 or 4 waves per SIMD: the texture addresser is the busy unit).  fp16, radius 4 - 5: one wave less
 #endif
 // Edges (= waves) per workgroup: EPW CONSECUTIVE plan slots — image neighbours — run on one CU at the same time, so that the lines their
 // boxes share can meet in the CU's 32 KB L1 instead of being fetched from the L2 once per edge.  DEVO_MM_SYNC = 1 additionally keeps the
@@ -111,7 +112,7 @@ __device__ __forceinline__ int mm_plan_slot(const int* __restrict__ order, int B
 }
 
 template <typename T, int RMAX, int NKS, int NL, int RFIX>   // NKS = C / 32 K steps per tile; NL = levels per wave; RFIX > 0: the radius is this constant
-__global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 2 ? DEVO_MM_WAVES : DEVO_MM_WAVES32) - (RMAX > 3 ? 1 : 0), (sizeof(T) == 2 ? DEVO_MM_WAVES : DEVO_MM_WAVES32) - (RMAX > 3 ? 1 : 0)))) void corr_fwd_mm_kernel(
+__global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? DEVO_MM_WAVES - (RMAX > 3 ? 1 : 0) : DEVO_MM_WAVES32, sizeof(T) == 2 ? DEVO_MM_WAVES - (RMAX > 3 ? 1 : 0) : DEVO_MM_WAVES32))) void corr_fwd_mm_kernel(
     const T* __restrict__ fmap1_t, CorrLevel lv0, CorrLevel lv1, int nlev, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int64_t out_estride, int64_t out_lstride, int R_arg, const int* __restrict__ order, int heavy_only,

@@ -26,7 +26,10 @@ sel = torch.rand(E, device=dev, generator=torch.Generator(device=dev).manual_see
 c, k2, j2 = coords[:, sel].contiguous(), kk[sel], jj[sel]
 g = torch.randn(1, int(sel.sum()), 7, 7, 3, 3, device=dev)
 mode = "segment-reduced" if os.environ.get("DEVO_CORR_BWD_SEG") else "atomic" if os.environ.get("DEVO_CORR_BWD_ATOMIC") else "product form"
-for lvl, (fm, s) in enumerate(((altcorr.channels_last(f0), 1.0), (altcorr.channels_last(f1), 4.0))):
+nchw = os.environ.get("DEVO_BWD_NCHW") == "1"       # the reference's own NCHW tensors (enet.py:203-216): cuda_corr.backward's cached channels-last copy
+lay = (lambda t: t.contiguous()) if nchw else altcorr.channels_last
+if nchw: mode += ", NCHW inputs"
+for lvl, (fm, s) in enumerate(((lay(f0), 1.0), (lay(f1), 4.0))):
     cs = (c / s).contiguous()
     gm = gmap.to(dev)
     for _ in range(3): cuda_corr.backward(gm, fm, cs, k2, j2, g, R)

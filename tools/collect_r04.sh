@@ -29,6 +29,9 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stress_t
 python "$R/tools/rocprof_summary.py" "$O/stress_trace" > "$O/stress_kernel_trace.txt" 2>&1
 DEVO_CORR_MM=0 timeout 400 python "$R/bench.py" --no-cpu-baseline --no-reference-api > "$O/mfma4x4_bench.json" 2> "$O/mfma4x4_bench.err"
 timeout 600 python "$R/bench.py" --api reference > "$O/reference_api.json" 2> "$O/reference_api.err"
+timeout 300 python "$R/tools/bench_corr_backward.py" 2>&1 | grep "per backward" > "$O/corr_backward.txt"
+DEVO_BWD_NCHW=1 timeout 300 python "$R/tools/bench_corr_backward.py" 2>&1 | grep "per backward" >> "$O/corr_backward.txt"
+timeout 300 python "$R/tools/bench_ba_train.py" > "$O/ba_train_step.txt" 2>&1
 timeout 900 python "$R/bench.py" --mode train --steps 3 --warmup 1 > "$O/train_mode.json" 2> "$O/train_mode.err"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/train_trace" -o k -- python "$R/bench.py" --mode train --steps 2 --warmup 1 > /dev/null 2> "$O/train_trace.log"
 python "$R/tools/trace_categories.py" "$O/train_trace" > "$O/train_categories.txt" 2>&1

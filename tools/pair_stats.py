@@ -19,13 +19,17 @@ def boxes(s):
     y0 = f[..., 1].min(1).values - R; y1 = f[..., 1].max(1).values - R + D
     return x0, x1, y0, y1
 Hs, Ws = {0: (H, W), 1: (H // 4, W // 4)}, None
-for name, keyf in (("plan (frame, 16-row band, x)", lambda cx, cy: (cy // 16) * 100000 + cx),
+for name, keyf in (("REAL plan (frame, 16-row band, 8-px column bin, then edge order)", lambda cx, cy: (cy // 16) * 100000 + (cx // 8) * 8),
+                   ("(frame, 8-row band, 8-px column bin, then edge order)", lambda cx, cy: (cy // 8) * 100000 + (cx // 8) * 8),
+                   ("(frame, 8-row band, 4-px column bin, then edge order)", lambda cx, cy: (cy // 8) * 100000 + (cx // 4) * 4),
+                   ("(frame, 4-row band, 4-px column bin, then edge order)", lambda cx, cy: (cy // 4) * 100000 + (cx // 4) * 4),
+                   ("plan (frame, 16-row band, x)", lambda cx, cy: (cy // 16) * 100000 + cx),
                    ("(frame, 8-row band, x)", lambda cx, cy: (cy // 8) * 100000 + cx),
                    ("(frame, 4-row band, x)", lambda cx, cy: (cy // 4) * 100000 + cx),
                    ("(frame, 6-row band, x)", lambda cx, cy: (cy // 6) * 100000 + cx)):
     cx, cy = c[:, 4, 0].clamp(0, W - 1), c[:, 4, 1].clamp(0, H - 1)
     key = jj.double() * 1e9 + keyf(cx.double().floor(), cy.double().floor())
-    order = torch.argsort(key)
+    order = torch.argsort(key, stable=True)
     tot = {}
     for grp in (2, 3):
         o = order[: (len(order) // grp) * grp].reshape(-1, grp)
@@ -37,7 +41,7 @@ for name, keyf in (("plan (frame, 16-row band, x)", lambda cx, cy: (cy // 16) * 
             uy0, uy1 = y0[o].min(1).values, y1[o].max(1).values
             upos = (ux1 - ux0) * (uy1 - uy0)
             spos = single[o].sum(1)
-            cap = 192 if grp == 2 else 256
+            cap = 160 if grp == 2 else 256
             ok = samef & (upos <= cap)
             stiles = ((single[o] + 15) // 16).sum(1)
             utiles = (upos + 15) // 16

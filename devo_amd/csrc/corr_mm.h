@@ -304,7 +304,6 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
     }
     return acc;
   };
-  constexpr int TPL = CAP / 16;                              // tile slots per level of the static schedule
   // ---- fused bilinear blend + axis swap + output permutation (correlation_kernel.cu:221-232), level by level.
   //      Output element (l, t), t = q * 9 + p with q = cx * Dm + a (cx = x offset: permute(0,1,3,2,4,5), a = y offset), goes to
   //      out[be * estride + t * lstride + offset(l)].

@@ -1,0 +1,339 @@
+// Dense layers of the Update operator in fp32 STORAGE on the fp16 matrix cores (devo/enet.py:41-78, blocks.py:15-48: the Linear layers
+// the reference hands to cuBLAS).
+//
+// The training step (BASELINE configurations 3 / 4) spends 38 % of its GPU time in fp32 library GEMMs of ONE shape family — 18 000 edge
+// rows x 384 x 384 — at 57-75 us each (hipBLASLt on the fp32 matrix pipe: gfx950 has no TF32 / xf32 path).  Here the same product runs
+// on v_mfma_f32_16x16x32_f16 with every fp32 value split into fp16 hi + lo (x = hi + lo to 2^-22 relative; the altcorr lookup's
+// arithmetic, corr_mm.h):  x y = hi lo' + lo hi' + hi hi'  with fp32 accumulation — 3 dense MFMAs per 16 x 16 x 32 block where the fp32 pipe
+// needs 8 of its own, at 16 x their rate.
+//
+// fp16 has 5 exponent bits: a gradient row of magnitude 1e-7 would lose its lo part (and most of its hi part) to the subnormal range.
+// So both operands are scaled by powers of two (exact) before the split and the product is scaled back in the epilogue:
+//   * every weight column n by s_n = 2^(8 - exponent(max_k |W[n][k]|)), once per weight version (devo_upd_split_weight);
+//   * every activation row by a running scale: set from the first K step's values (max -> [2^8, 2^9)), and raised — with the row's
+//     accumulators rescaled by the same power of two — whenever a later value of the row would leave the fp16 range (> 2^14 scaled).
+//     Values smaller than 2^-11 of the scale's reference lose lo bits, an error of < 2^-33 of that reference: far below the fp32
+//     accumulation's own rounding.
+// The weight is split ONCE per version into the B-operand image (one 1 KB piece per (K step, column tile, hi | lo), lane-linear); the
+// activations are split in registers on their way from memory.
+//
+// One workgroup = 128 rows x 96 columns (4 waves x 32 rows, 6 column tiles): per K step of 32 the 12 KB of weight pieces arrive by
+// LDS-DMA into a ring of three stages (two steps ahead, one barrier per step); each wave loads its own 2 x 16 x 32 activations straight
+// into the A-operand layout (32 contiguous bytes per lane, two steps ahead), scales + splits them and issues 36 MFMAs: every weight
+// fragment read from LDS feeds two row tiles (LDS 192 cycles / step against 576 cycles of MFMA per SIMD).  Workgroups of one row block
+// run on one XCD (their four column blocks re-read the rows from that XCD's L2).  The result tile goes through LDS so that rows leave as
+// whole 16-byte pieces, scaled back, with the bias (and ReLU) applied.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+namespace devo {
+
+typedef _Float16 ln_h8 __attribute__((ext_vector_type(8)));
+typedef float ln_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned ln_u4 __attribute__((ext_vector_type(4)));
+
+constexpr int LN_NT = 6;                          // column tiles of 16 per workgroup (96 columns)
+constexpr int LN_MT = 2;                          // row tiles of 16 per wave
+constexpr int LN_BN = LN_NT * 16;
+constexpr int LN_BM = 4 * LN_MT * 16;             // rows per workgroup (4 waves x 32)
+constexpr int LN_STAGE = LN_NT * 2 * 1024;        // bytes of weight pieces per K step (hi | lo per tile)
+constexpr int LN_NSTAGE = 3;
+constexpr int LN_EPI_LD = LN_BN + 4;              // row pitch (floats) of the result tile in LDS
+constexpr int LN_TILE_BYTES = LN_MT * 16 * LN_EPI_LD * 4;
+constexpr int LN_RING = (LN_NSTAGE * LN_STAGE > 4 * LN_TILE_BYTES) ? LN_NSTAGE * LN_STAGE : 4 * LN_TILE_BYTES;
+constexpr int LN_LDS = LN_RING + 4 * LN_MT * 16 * 4 + 2 * LN_BN * 4;   // + per wave: one float per row (rescale factors, then the inverse row scales); the block's column scales and biases
+constexpr int LN_EXP_TARGET = 8;                  // a scale puts its reference magnitude into [2^8, 2^9)
+constexpr float LN_RAISE = 16384.f;               // ... and is raised when a scaled value exceeds 2^14 (fp16's largest: 65504)
+
+// 8 fp32 values -> fp16 hi (8) and lo (8): hi = rn(x), lo = rn(x - hi)
+__device__ __forceinline__ void ln_split8(const float (&x)[8], ln_h8& hi, ln_h8& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h[j]) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[j]) : "v"(h[j]), "v"(x[2 * j]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[j]) : "v"(h[j]), "v"(x[2 * j + 1]));
+  }
+  const ln_u4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+  hi = __builtin_bit_cast(ln_h8, hv);
+  lo = __builtin_bit_cast(ln_h8, lv);
+}
+
+// biased exponent of the power of two that brings magnitude m into [2^TARGET, 2^(TARGET+1))
+__device__ __forceinline__ int ln_scale_exp(float m) {
+  int e = (int)((__float_as_uint(m) >> 23) & 255u);
+  e = e < 16 ? 16 : e;                             // zero / tiny reference: a finite scale (2^(8 + 111))
+  return 127 + LN_EXP_TARGET + 127 - e;            // in [16, 246]
+}
+__device__ __forceinline__ float ln_pow2(int biased) { return __uint_as_float((unsigned)(biased < 0 ? 0 : (biased > 254 ? 254 : biased)) << 23); }
+
+// W (element (n, k) at W[n * s_n + k * s_k]: the forward's weight [N, K], or its transpose view for dX = dY W) -> the B-operand image
+// [N / 96][K / 32][6 tiles][hi | lo][64 lanes][16 B]: lane (n, kg) of tile t holds k = 32 s + 8 kg .. + 7 of column 96 nb + 16 t + n,
+// scaled by the column's power of two; then N floats: the inverse column scales.
+// pass 1: one wave per column n: its scale exponent (as the inverse scale's slot holds it for pass 2) — the largest |W[n][.]|
+__global__ __launch_bounds__(256) void k_weight_scales(const float* __restrict__ W, int64_t s_n, int64_t s_k, int N, int K, float* __restrict__ inv) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float m = 0.f;
+  for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(W[(int64_t)n * s_n + (int64_t)k * s_k]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) inv[n] = ln_pow2(254 - ln_scale_exp(m));
+}
+
+__global__ __launch_bounds__(256) void k_split_weight(const float* __restrict__ W, int64_t s_n, int64_t s_k, int N, int K, ln_u4* __restrict__ out) {
+  const int nk = K / 32;
+  const long long total = (long long)(N / LN_BN) * nk * LN_NT * 64;
+  const float* inv = reinterpret_cast<const float*>(out) + (size_t)N * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    const long long r = i >> 6;
+    const int t = (int)(r % LN_NT);
+    const long long r2 = r / LN_NT;
+    const int s = (int)(r2 % nk), nb = (int)(r2 / nk);
+    const int n = nb * LN_BN + 16 * t + (lane & 15), kg = lane >> 4, k0 = 32 * s + 8 * kg;
+    const float sc = ln_pow2(254 - (int)(__float_as_uint(inv[n]) >> 23));      // the reciprocal of a power of two
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = W[(int64_t)n * s_n + (int64_t)(k0 + j) * s_k] * sc;
+    ln_h8 hi, lo;
+    ln_split8(v, hi, lo);
+    ln_u4* dst = out + ((r2 * LN_NT + t) * 2) * 64 + lane;
+    dst[0] = __builtin_bit_cast(ln_u4, hi);
+    dst[64] = __builtin_bit_cast(ln_u4, lo);
+  }
+}
+
+// LDS-DMA: 16 bytes per lane from (descriptor, per-lane offset, scalar offset) to lds_addr + 16 * lane; hipcc's waitcnt insertion does
+// not know it (the loop counts its own vmcnt before the barrier)
+__device__ __forceinline__ void ln_dma16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned lds_addr) {
+  lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  soff = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_addr), "s"(soff) : "memory");
+}
+
+// 16 bytes per lane into registers, outside the compiler's vmcnt bookkeeping: its own count cannot see the LDS-DMA requests between
+// the loads and would wait for requests issued a step too late.  The registers are valid after the loop's s_waitcnt + ln_pin.
+template <int IMM>
+__device__ __forceinline__ void ln_load16(ln_u4& out, unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff) {
+  soff = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(out) : "v"(voff), "s"(rs), "s"(soff), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void ln_pin(ln_u4& a, ln_u4& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+
+struct LnA { ln_u4 v[LN_MT][2]; };                 // one K step of a wave's activations: 2 row tiles x 32 bytes per lane
+
+// y[M, N] = act(x[M, K] B + bias), B = the split weight image.  grid = 8 * ceil(row blocks / 8) * (N / 96), one row block's column
+// blocks on one XCD.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_split(
+    const float* __restrict__ x, int64_t ldx, const ln_u4* __restrict__ wsplit, const float* __restrict__ bias, float* __restrict__ y,
+    int64_t ldy, int M, int N, int K, int relu) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ln_lds[];
+  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, mi = lane & 15, kg = lane >> 4;
+  const int NB = N / LN_BN, nk = K / 32;
+  const int dbg = relu >> 8;                                           // DEVO_LN_DBG: 1 no activation loads, 2 no stores, 4 no weight DMA, 8 no MFMAs
+  relu &= 1;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int rb = (slot / NB) * 8 + xcd, nb = slot - (slot / NB) * NB;
+  if (rb * LN_BM >= M) return;
+  constexpr unsigned OFF_NONE = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (unsigned)(((int64_t)(M - 1) * ldx + K) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<ln_u4*>(wsplit), 0, (unsigned)((int64_t)N * K * 4), 0x00020000);
+  const int row_w = rb * LN_BM + LN_MT * 16 * wv;                     // this wave's first row
+  unsigned aoff[LN_MT];
+#pragma unroll
+  for (int mt = 0; mt < LN_MT; mt++) {
+    const int row = row_w + 16 * mt + mi;
+    aoff[mt] = row < M ? (unsigned)(((int64_t)row * ldx + 8 * kg) * 4) : OFF_NONE;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)ln_lds;
+  float* rowf = reinterpret_cast<float*>(ln_lds + LN_RING) + wv * (LN_MT * 16);
+  float* colf = reinterpret_cast<float*>(ln_lds + LN_RING) + 4 * LN_MT * 16;      // [inverse scale | bias][96], visible after the first barrier
+  if (tid < LN_BN) {
+    colf[tid] = reinterpret_cast<const float*>(wsplit)[(size_t)N * K + nb * LN_BN + tid];
+    colf[LN_BN + tid] = bias ? bias[nb * LN_BN + tid] : 0.f;
+  }
+  // requests past the last K step keep the pipeline's shape (the compiler's and the loop's own vmcnt bookkeeping see ONE path) but
+  // carry the out-of-range offset: no memory access, zeros back
+  auto stage = [&](int s) {                                          // this wave's 3 of the stage's 12 one-KB pieces
+    const int buf = s % LN_NSTAGE;
+    const unsigned voff = (s < nk && !(dbg & 4)) ? (unsigned)lane * 16u : OFF_NONE;
+#pragma unroll
+    for (int q = 0; q < LN_NT * 2 / 4; q++) {
+      const int piece = wv + 4 * q;
+      ln_dma16(voff, rsw, (unsigned)(((nb * nk + s) * (LN_NT * 2) + piece) * 1024), lds0 + (unsigned)(buf * LN_STAGE + piece * 1024));
+    }
+  };
+  auto load_a = [&](LnA& a, int s) {
+#pragma unroll
+    for (int mt = 0; mt < LN_MT; mt++) {
+      const unsigned o = (s < nk && !(dbg & 1)) ? aoff[mt] : OFF_NONE;
+      ln_load16<0>(a.v[mt][0], o, rsx, (unsigned)s * 128u);
+      ln_load16<16>(a.v[mt][1], o, rsx, (unsigned)s * 128u);
+    }
+  };
+  ln_f4 acc[LN_MT][LN_NT];
+#pragma unroll
+  for (int mt = 0; mt < LN_MT; mt++)
+#pragma unroll
+    for (int t = 0; t < LN_NT; t++) acc[mt][t] = ln_f4{0.f, 0.f, 0.f, 0.f};
+  int esc[LN_MT];                                                     // biased exponent of each row's scale
+  float sc[LN_MT];
+#pragma unroll
+  for (int mt = 0; mt < LN_MT; mt++) { esc[mt] = 0; sc[mt] = 0.f; }
+
+  LnA A0, A1, A2;
+  load_a(A0, 0);
+  stage(0);
+  load_a(A1, 1);
+  stage(1);
+  asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  __syncthreads();
+
+  auto step = [&](int s, LnA& cur, LnA& fill) {
+    load_a(fill, s + 2);
+    stage(s + 2);
+    // ---- scale: this lane's 2 x 8 values against the row scales
+    float xv[LN_MT][8];
+    float mx[LN_MT];
+    bool raise = false;
+#pragma unroll
+    for (int mt = 0; mt < LN_MT; mt++) {
+      ln_pin(cur.v[mt][0], cur.v[mt][1]);                              // (landed: the previous step's s_waitcnt)
+      __builtin_memcpy(&xv[mt][0], &cur.v[mt][0], 16);
+      __builtin_memcpy(&xv[mt][4], &cur.v[mt][1], 16);
+      float m = fmaxf(fmaxf(fabsf(xv[mt][0]), fabsf(xv[mt][1])), fabsf(xv[mt][2]));
+      m = fmaxf(fmaxf(m, fabsf(xv[mt][3])), fabsf(xv[mt][4]));
+      m = fmaxf(fmaxf(m, fabsf(xv[mt][5])), fmaxf(fabsf(xv[mt][6]), fabsf(xv[mt][7])));
+      mx[mt] = m;
+      raise = raise || !(m * sc[mt] <= LN_RAISE);                     // (also: NaN)
+    }
+    if (s == 0 || __builtin_amdgcn_ballot_w64(raise) != 0ull) {      // rare after the first step: new scales, accumulators follow
+#pragma unroll
+      for (int mt = 0; mt < LN_MT; mt++) {
+        float m = mx[mt];
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const bool need = s == 0 || !(m * sc[mt] <= LN_RAISE);
+        const int e_new = need ? ln_scale_exp(m) : esc[mt];
+        if (kg == 0) rowf[16 * mt + mi] = s == 0 ? 1.f : ln_pow2(127 + e_new - esc[mt]);
+        esc[mt] = e_new;
+        sc[mt] = ln_pow2(e_new);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (s != 0) {
+#pragma unroll
+        for (int mt = 0; mt < LN_MT; mt++) {
+          const ln_f4 f = *reinterpret_cast<const ln_f4*>(rowf + 16 * mt + 4 * kg);
+#pragma unroll
+          for (int t = 0; t < LN_NT; t++) acc[mt][t] *= f;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    ln_h8 ah[LN_MT], al[LN_MT];
+#pragma unroll
+    for (int mt = 0; mt < LN_MT; mt++) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) xv[mt][j] *= sc[mt];
+      ln_split8(xv[mt], ah[mt], al[mt]);
+    }
+    const ln_u4* sb = reinterpret_cast<const ln_u4*>(ln_lds + (s % LN_NSTAGE) * LN_STAGE) + lane;
+    if (!(dbg & 8))
+#pragma unroll
+    for (int tg = 0; tg < LN_NT; tg += 3) {
+      ln_h8 bh[3], bl[3];
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        bh[u] = __builtin_bit_cast(ln_h8, sb[((tg + u) * 2 + 0) * 64]);
+        bl[u] = __builtin_bit_cast(ln_h8, sb[((tg + u) * 2 + 1) * 64]);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; u++)                                      // small terms first; the same accumulator again 6 MFMAs later
+#pragma unroll
+        for (int mt = 0; mt < LN_MT; mt++) acc[mt][tg + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl[u], acc[mt][tg + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 3; u++)
+#pragma unroll
+        for (int mt = 0; mt < LN_MT; mt++) acc[mt][tg + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh[u], acc[mt][tg + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 3; u++)
+#pragma unroll
+        for (int mt = 0; mt < LN_MT; mt++) acc[mt][tg + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[u], acc[mt][tg + u], 0, 0, 0);
+    }
+    // step s + 1's activations and weight pieces (issued one step ago) have landed; this step's 7 requests may stay in flight
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    __syncthreads();                                                   // every wave is done with this stage's buffer
+  };
+  for (int s = 0; s < nk; s += 3) {                                    // (steps past nk multiply zeros)
+    step(s, A0, A2);
+    step(s + 1, A1, A0);
+    step(s + 2, A2, A1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the trailing (empty) requests, before the ring becomes the result tile
+  __syncthreads();
+  // ---- result: lane (n, rg) holds rows 4 rg + r of column 16 t + n -> this wave's [32][96 + 4] tile in LDS -> whole rows out
+  float* tile = reinterpret_cast<float*>(ln_lds) + wv * (LN_MT * 16 * LN_EPI_LD);
+#pragma unroll
+  for (int mt = 0; mt < LN_MT; mt++) {
+    if (kg == 0) rowf[16 * mt + mi] = ln_pow2(254 - esc[mt]);
+#pragma unroll
+    for (int t = 0; t < LN_NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) tile[(16 * mt + 4 * kg + r) * LN_EPI_LD + 16 * t + mi] = acc[mt][t][r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int col0 = nb * LN_BN;
+  constexpr int PPR = LN_BN / 4;                                       // 16-byte pieces per row
+#pragma unroll
+  for (int it = 0; it < LN_MT * 16 * PPR / 64; it++) {
+    const int idx = it * 64 + lane, r = idx / PPR, c4 = idx - r * PPR;
+    ln_f4 v = *reinterpret_cast<const ln_f4*>(tile + r * LN_EPI_LD + 4 * c4);
+    v = v * rowf[r] * *reinterpret_cast<const ln_f4*>(colf + 4 * c4) + *reinterpret_cast<const ln_f4*>(colf + LN_BN + 4 * c4);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (row_w + r < M && !(dbg & 2)) *reinterpret_cast<ln_f4*>(y + (int64_t)(row_w + r) * ldy + col0 + 4 * c4) = v;
+  }
+}
+
+}  // namespace devo
+
+using namespace devo;
+
+extern "C" {
+
+size_t devo_upd_split_weight_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || N % LN_BN != 0 || K % 32 != 0) return 0;
+  return (size_t)N * K * 4 + (size_t)N * 4;
+}
+
+int devo_upd_split_weight(const float* W, int64_t s_n, int64_t s_k, int N, int K, void* wsplit, devo_stream_t stream) {
+  DEVO_REQUIRE(N > 0 && K > 0 && N % LN_BN == 0 && K % 32 == 0, "devo_upd_split_weight: N must be a multiple of 96 and K of 32 (got %d x %d)", N, K);
+  DEVO_REQUIRE(W && wsplit && (reinterpret_cast<uintptr_t>(wsplit) & 15) == 0, "devo_upd_split_weight: null / unaligned tensor");
+  const long long total = (long long)(N / LN_BN) * (K / 32) * LN_NT * 64;
+  hipLaunchKernelGGL(k_weight_scales, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, W, s_n, s_k, N, K, reinterpret_cast<float*>(wsplit) + (size_t)N * K);
+  hipLaunchKernelGGL(k_split_weight, dim3((unsigned)blocks_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, W, s_n, s_k, N, K, (ln_u4*)wsplit);
+  return check_launch("devo_upd_split_weight");
+}
+
+int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, float* y, int64_t ldy, int M, int N, int K,
+                          int relu, devo_stream_t stream) {
+  DEVO_REQUIRE(M >= 0 && N > 0 && K > 0 && N % LN_BN == 0 && K % 32 == 0, "devo_upd_linear_split: N must be a multiple of 96 and K of 32 (got %d x %d)", N, K);
+  if (M == 0) return DEVO_OK;
+  DEVO_REQUIRE(x && wsplit && y && ldx >= K && ldy >= N && ldx % 4 == 0 && ldy % 4 == 0, "devo_upd_linear_split: null tensor or row strides that are not multiples of 4");
+  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wsplit) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+               "devo_upd_linear_split: operands must be 16-byte aligned");
+  DEVO_REQUIRE(((int64_t)(M - 1) * ldx + K) * 4 < (1LL << 31) && (int64_t)N * K * 4 < (1LL << 31), "devo_upd_linear_split: operand beyond 2 GB");
+  static_assert(LN_LDS <= 64 * 1024, "the workgroup's LDS fits the default dynamic limit");
+  const int RB = (M + LN_BM - 1) / LN_BM, NB = N / LN_BN;
+  static const int dbg = getenv("DEVO_LN_DBG") ? atoi(getenv("DEVO_LN_DBG")) : 0;
+  relu = (relu ? 1 : 0) | (dbg << 8);
+  hipLaunchKernelGGL(k_linear_split, dim3((unsigned)(((RB + 7) / 8) * 8 * NB)), dim3(256), LN_LDS, (hipStream_t)stream, x, ldx,
+                     (const ln_u4*)wsplit, bias, y, ldy, M, N, K, relu);
+  return check_launch("devo_upd_linear_split");
+}
+
+}  // extern "C"

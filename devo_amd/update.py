@@ -29,16 +29,65 @@ class _GradClip(torch.autograd.Function):            # blocks.py:72-81: identity
 
 
 
+_wsplit_cache = {}          # (ptr, version, shape, strides, transposed) -> (weight [kept alive], its split image); LRU
+WSPLIT_CACHE_ENTRIES = 96
+SPLIT_GEMM = __import__("os").environ.get("DEVO_UPD_SPLIT_GEMM", "1") != "0"     # 0: the library's fp32 GEMMs for every Linear layer
+
+
+def _split_weight(w, transposed):
+    """The B-operand image of csrc/linear.hip for `x @ w.T` (transposed=False) or `g @ w` (True): every fp32 weight as an exact fp16
+    hi + lo pair, one 1 KB piece per (K step, column tile).  Cached per version of the weight: a training step's 18 update iterations
+    split each layer twice (forward, dX), not 36 times; the optimiser's in-place step bumps the version."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), transposed)
+    hit = _wsplit_cache.pop(key, None)
+    if hit is not None:
+        _wsplit_cache[key] = hit
+        return hit[1]
+    for k in [k for k in _wsplit_cache if k[0] == key[0] and k[4] == transposed]:
+        del _wsplit_cache[k]
+    while len(_wsplit_cache) >= WSPLIT_CACHE_ENTRIES:
+        del _wsplit_cache[next(iter(_wsplit_cache))]
+    out_f, in_f = w.shape
+    N, K = (in_f, out_f) if transposed else (out_f, in_f)
+    s_n, s_k = (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
+    img = torch.empty(N * K + N, dtype=torch.float32, device=w.device)
+    L.check(L.lib().devo_upd_split_weight(L.ptr(w), s_n, s_k, N, K, L.ptr(img), L.stream()), "update.split_weight")
+    _wsplit_cache[key] = (w, img)
+    return img
+
+
+def _split_ok(x2, n_out, k_in):
+    return (SPLIT_GEMM and x2.is_cuda and x2.dtype == torch.float32 and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) % 4 == 0
+            and x2.data_ptr() % 16 == 0 and n_out % 96 == 0 and k_in % 32 == 0 and x2.shape[0] >= 1024
+            and (x2.shape[0] - 1) * x2.stride(0) * 4 < (1 << 31))
+
+
+def _linear_split(x2, w, b, transposed=False, relu=False):
+    """x2 [rows, K] fp32 -> act(x2 @ w.T + b) (or x2 @ w: transposed) on the fp16 matrix cores, fp32 in and out (csrc/linear.hip)"""
+    N = w.shape[1] if transposed else w.shape[0]
+    K = w.shape[0] if transposed else w.shape[1]
+    y = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x2.device)
+    L.check(L.lib().devo_upd_linear_split(L.ptr(x2), x2.stride(0), L.ptr(_split_weight(w.detach(), transposed)), L.ptr(b), L.ptr(y), N,
+                                          x2.shape[0], N, K, int(relu), L.stream()), "update.linear_split")
+    return y
+
+
 class _LinearFn(torch.autograd.Function):
-    """y = x Wᵀ + b over many rows (the Update operator sees one row per edge: 18 000 at BASELINE configuration 3).  The weight gradient
-    dW = dYᵀ X is a [out x rows] x [rows x in] product with a tiny output: hipBLASLt runs it on a handful of tiles (148 us for 384 x 384
-    over 18 000 rows); as a batched product over 16 row chunks + a sum it uses the whole chip (74 us; tools/ubench_dw_gemm.py)."""
+    """y = x Wᵀ + b over many rows (the Update operator sees one row per edge: 18 000 at BASELINE configuration 3).
+    fp32 layers whose sizes fit (out % 192 == 0, in % 32 == 0: DEVO's 384-wide layers) run y and dX on the fp16 matrix cores with exact
+    hi + lo splits of every fp32 value (csrc/linear.hip: 2^-22 relative per factor, fp32 accumulation; a fifth of the library GEMM's time).
+    The weight gradient dW = dYᵀ X is a [out x rows] x [rows x in] product with a tiny output: hipBLASLt runs it on a handful of tiles
+    (148 us for 384 x 384 over 18 000 rows); as a batched product over 16 row chunks + a sum it uses the whole chip (74 us;
+    tools/ubench_dw_gemm.py)."""
     CHUNKS = 16
 
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        if x.dtype == w.dtype == torch.float32 and (b is None or b.dtype == torch.float32) and _split_ok(x, w.shape[0], w.shape[1]) \
+                and not torch.is_autocast_enabled():
+            return _linear_split(x, w, b.contiguous() if b is not None else None)
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
@@ -50,7 +99,10 @@ class _LinearFn(torch.autograd.Function):
         # the parameters are fp32: multiply in g's dtype like the forward did, return every gradient in its input's dtype
         with torch.autocast(device_type="cuda", enabled=False):
             if ctx.needs_input_grad[0]:
-                gx = (g2 @ w.to(g2.dtype)).reshape(x.shape).to(x.dtype)
+                if g2.dtype == w.dtype == x.dtype == torch.float32 and _split_ok(g2.contiguous(), w.shape[1], w.shape[0]):
+                    gx = _linear_split(g2.contiguous(), w, None, transposed=True).reshape(x.shape)
+                else:
+                    gx = (g2 @ w.to(g2.dtype)).reshape(x.shape).to(x.dtype)
             if ctx.needs_input_grad[1]:
                 x2 = x.reshape(-1, x.shape[-1]).to(g2.dtype)
                 rows, S = x2.shape[0], _LinearFn.CHUNKS

@@ -253,3 +253,74 @@ def test_softagg_training_path_on_the_hip_kernels_matches_the_torch_composition(
     assert_rel(ga32, ga64.float(), 2e-3, "d/d net"); assert_rel(gc32, gc64.float(), 2e-3, "d/d corr")
     for k in ("gru.1.gate.0.weight", "gru.3.res.2.weight", "c1.0.weight", "c2.2.bias", "agg_kk.f.weight", "agg_ij.h.weight", "norm.weight", "corr.0.weight"):
         assert_rel(gp32[k], gp64[k].float(), 3e-3, "d/d " + k)
+
+
+@pytest.mark.parametrize("rows,n_out,k_in,relu", [(18000, 384, 384, False), (4099, 768, 384, True), (1030, 192, 32, False), (5000, 384, 768, False)])
+def test_split_precision_linear_matches_float64(rows, n_out, k_in, relu):
+    """csrc/linear.hip: fp32 in, fp32 out, fp16 hi + lo operands on the matrix cores — as close to the float64 product as the library's
+    fp32 GEMM is (the tolerance is the fp32 GEMM's own distance to float64, doubled), in the forward form and in the dX form"""
+    from devo_amd import update as UA
+    g = torch.Generator(device="cpu").manual_seed(rows + n_out)
+    x = torch.randn(rows, k_in, generator=g) * torch.rand(rows, 1, generator=g) * 4
+    x[1::7] *= 1e-7                                                     # gradient-sized rows: below fp16's range before scaling
+    x[2::11] *= 3e5
+    x[3::13, k_in // 2:] *= 4096.0                                      # rows whose scale is raised in the middle of K ...
+    x[5::17, :k_in // 2] = 0                                            # ... or that start with zeros
+    x[6::19] = 0
+    x = x.to(DEV)
+    w = torch.randn(n_out, k_in, generator=g) / k_in ** 0.5
+    w[1::5] *= 1e-6
+    w[2::9] *= 1e3
+    w = w.to(DEV)
+    b = torch.randn(n_out, generator=g).to(DEV)
+    assert UA._split_ok(x, n_out, k_in)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    lib = torch.nn.functional.linear(x, w, b)
+    if relu:
+        ref, lib = ref.relu(), lib.relu()
+    y = UA._linear_split(x, w, b, relu=relu)
+    scale = (x.double().abs() @ w.double().abs().t() + b.double().abs())     # every output against its own terms' magnitudes
+    e_lib = ((lib.double() - ref).abs() / scale).max().item()
+    e_own = ((y.double() - ref).abs() / scale).max().item()
+    assert e_own <= max(2 * e_lib, 2e-7), (e_own, e_lib)
+    # dX form: g [rows, n_out] @ w [n_out, k_in], when the transposed sizes fit the kernel
+    if k_in % 192 == 0 and n_out % 32 == 0:
+        gy = torch.randn(rows, n_out, generator=g).to(DEV)
+        ref = gy.double() @ w.double()
+        gy[1::3] *= 1e-8
+        ref = gy.double() @ w.double()
+        scale = gy.double().abs() @ w.double().abs() + 1e-300
+        e_lib = (((gy @ w).double() - ref).abs() / scale).max().item()
+        e_own = ((UA._linear_split(gy, w, None, transposed=True).double() - ref).abs() / scale).max().item()
+        assert e_own <= max(2 * e_lib, 2e-7), (e_own, e_lib)
+    # strided rows (a column slice of a wider tensor) and the per-version cache
+    wide = torch.randn(rows, k_in + 64, generator=g).to(DEV)
+    xs = wide[:, 32:32 + k_in]
+    if UA._split_ok(xs, n_out, k_in):
+        ref = torch.nn.functional.linear(xs.double(), w.double(), b.double())
+        assert ((UA._linear_split(xs, w, b).double() - ref).abs() / (xs.double().abs() @ w.double().abs().t() + b.double().abs())).max().item() < 1e-6
+    n_cached = len(UA._wsplit_cache)
+    UA._linear_split(x, w, b)
+    assert len(UA._wsplit_cache) == n_cached
+    w.mul_(2.0)                                                         # an optimiser step: new version, new image
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    assert ((UA._linear_split(x, w, b).double() - ref).abs() / (x.double().abs() @ w.double().abs().t() + b.double().abs())).max().item() < 1e-6
+
+
+def test_linear_layer_gradients_with_and_without_the_split_gemm():
+    from devo_amd import update as UA
+    torch.manual_seed(3)
+    lin = UA.Linear(384, 384).to(DEV)
+    x = torch.randn(1, 6000, 384, device=DEV, requires_grad=True)
+    outs = []
+    for flag in (True, False):
+        UA.SPLIT_GEMM = flag
+        try:
+            lin.zero_grad(); x.grad = None
+            y = torch.relu_(lin(x))
+            (y.square().mean() + y.sum() * 1e-3).backward()
+            outs.append((y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()))
+        finally:
+            UA.SPLIT_GEMM = True
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * max(1.0, b.abs().max().item())), (a - b).abs().max()

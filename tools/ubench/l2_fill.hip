@@ -10,6 +10,8 @@
 //   6 dma_fill's : tools/ubench/dma_fill.hip's requests: 4 KB-aligned bases, runs of 20 x 16 B 2560 B apart, 4 planes 307200 B apart
 //   7 cell64     : lane l -> base + 64 (l % 16) + 16 (l / 16): 1 KB contiguous in the dense-MFMA A-operand lane order (a quad = 4 cells)
 //   8 cell64 box : the same with the 16 positions walking a 10-wide box of 64-byte cells (rows `rowstride` apart)
+//   9 row16 far / 10 row16 near / 11 box near / 12 box far+48: variants of shape 2 — the tile's 16 positions in ONE row or walking a 10-wide box, the four
+//     16-byte planes 307 200 B apart (the channel-blocked pyramid) or one row pitch apart, rows starting 48 bytes into a line
 //   5 L1 window  : shape 0 inside a per-CU window of `l1win` bytes (16 KB: served by the CU's own L1 after the first touch)
 //   hipcc --offload-arch=gfx950 -O3 -o l2_fill l2_fill.hip && ./l2_fill
 #include <hip/hip_runtime.h>
@@ -31,6 +33,10 @@ __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, unsigned
   else if (SHAPE == 3) lane_off = lane * 256;
   else if (SHAPE == 7) lane_off = (lane & 15) * 64 + (lane >> 4) * 16;
   else if (SHAPE == 8) { const int i = lane & 15; lane_off = (i / 10) * rowstride + (i % 10) * 64 + (lane >> 4) * 16; }
+  else if (SHAPE == 9)  { lane_off = (lane >> 4) * plane + (lane & 15) * 16; }                                   // 16 positions of ONE row, planes far apart
+  else if (SHAPE == 10) { lane_off = (lane >> 4) * 2560u + (lane & 15) * 16; }                                  // 16 positions of one row, planes one row pitch apart
+  else if (SHAPE == 11) { const int i = lane & 15; lane_off = (lane >> 4) * 2560u + (i / 10) * (16u * 2560u) + (i % 10) * 16; }   // 10-wide box, planes a row pitch apart
+  else if (SHAPE == 12) { const int i = lane & 15; lane_off = (lane >> 4) * plane + (i / 10) * rowstride + (i % 10) * 16 + 48; }    // planes4x16, rows starting 48 B into a line
   else if (SHAPE == 6) { lane_off = (lane / 20) * 2560 + (lane % 20) * 16; }
   else lane_off = (lane / 10) * rowstride + (lane % 10) * 64;
   const unsigned cu_win = (blockIdx.x * l1win) & wsmask;
@@ -98,5 +104,9 @@ int main() {
   run<6>("dma_fill's", src, out, sink);
   run<7>("cell64    ", src, out, sink);
   run<8>("cell64 box", src, out, sink);
+  run<9>("row16 far ", src, out, sink);
+  run<10>("row16 near", src, out, sink);
+  run<11>("box near  ", src, out, sink);
+  run<12>("box far+48", src, out, sink);
   return 0;
 }

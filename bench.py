@@ -92,7 +92,8 @@ def build_inputs(cfg, seed, device, dtype, layout):
     if layout == "cl":
         f0, f1 = altcorr.channels_last(f0), altcorr.channels_last(f1)
     elif layout == "blk8":
-        f0, f1 = altcorr.channel_blocked(f0, 8), altcorr.channel_blocked(f1, 8)
+        cb = int(os.environ.get("DEVO_BENCH_CB", "8"))                     # experiment switch: channels per block of the "blk8" layout
+        f0, f1 = altcorr.channel_blocked(f0, cb), altcorr.channel_blocked(f1, cb)
     d.update(pyramid=[f0, f1], gmap=g.contiguous())
     # the optimised state (poses + patches) lives in ONE buffer so that a step restores it with a single copy
     npose = d["poses0"].numel()

@@ -39,7 +39,7 @@ constexpr int LN_BM = 4 * LN_MT * 16;             // rows per workgroup (4 waves
 constexpr int LN_STAGE = LN_NT * 2 * 1024;        // bytes of weight pieces per K step (hi | lo per tile)
 constexpr int LN_NSTAGE = 3;
 constexpr int LN_EPI_LD = LN_BN + 4;              // row pitch (floats) of the result tile in LDS
-constexpr int LN_TILE_BYTES = LN_MT * 16 * LN_EPI_LD * 4;
+constexpr int LN_TILE_BYTES = 16 * LN_EPI_LD * 4;          // one row tile of a wave's result at a time
 constexpr int LN_RING = (LN_NSTAGE * LN_STAGE > 4 * LN_TILE_BYTES) ? LN_NSTAGE * LN_STAGE : 4 * LN_TILE_BYTES;
 constexpr int LN_LDS = LN_RING + 4 * LN_MT * 16 * 4 + 2 * LN_BN * 4;   // + per wave: one float per row (rescale factors, then the inverse row scales); the block's column scales and biases
 constexpr int LN_EXP_TARGET = 8;                  // a scale puts its reference magnitude into [2^8, 2^9)
@@ -131,7 +131,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   extern __shared__ __attribute__((aligned(1024))) unsigned char ln_lds[];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, mi = lane & 15, kg = lane >> 4;
   const int NB = N / LN_BN, nk = K / 32;
-  const int dbg = relu >> 8;                                           // DEVO_LN_DBG: 1 no activation loads, 2 no stores, 4 no weight DMA, 8 no MFMAs
+  const int dbg = relu >> 8;                                           // DEVO_LN_DBG: 1 no activation loads, 2 no stores, 4 no weight DMA, 8 no MFMAs, 16 cycle stamps of workgroup 0 into y[0][..]
+  unsigned long long tst[32];
+  int nst = 0;
+  auto stamp = [&]() { if (dbg & 16) { if (nst < 32) tst[nst] = __builtin_readcyclecounter(); nst++; } };
+  stamp();
   relu &= 1;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int rb = (slot / NB) * 8 + xcd, nb = slot - (slot / NB) * NB;
@@ -189,10 +193,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   stage(1);
   asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   __syncthreads();
+  stamp();
 
   auto step = [&](int s, LnA& cur, LnA& fill) {
     load_a(fill, s + 2);
     stage(s + 2);
+    stamp();
     // ---- scale: this lane's 2 x 8 values against the row scales
     float xv[LN_MT][8];
     float mx[LN_MT];
@@ -241,6 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       ln_split8(xv[mt], ah[mt], al[mt]);
     }
     const ln_u4* sb = reinterpret_cast<const ln_u4*>(ln_lds + (s % LN_NSTAGE) * LN_STAGE) + lane;
+    stamp();
     if (!(dbg & 8))
 #pragma unroll
     for (int tg = 0; tg < LN_NT; tg += 3) {
@@ -264,8 +271,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int mt = 0; mt < LN_MT; mt++) acc[mt][tg + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[u], acc[mt][tg + u], 0, 0, 0);
     }
     // step s + 1's activations and weight pieces (issued one step ago) have landed; this step's 7 requests may stay in flight
+    stamp();
     asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    stamp();
     __syncthreads();                                                   // every wave is done with this stage's buffer
+    stamp();
   };
   for (int s = 0; s < nk; s += 3) {                                    // (steps past nk multiply zeros)
     step(s, A0, A2);
@@ -274,28 +284,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the trailing (empty) requests, before the ring becomes the result tile
   __syncthreads();
-  // ---- result: lane (n, rg) holds rows 4 rg + r of column 16 t + n -> this wave's [32][96 + 4] tile in LDS -> whole rows out
-  float* tile = reinterpret_cast<float*>(ln_lds) + wv * (LN_MT * 16 * LN_EPI_LD);
+  // ---- result: lane (n, rg) holds rows 4 rg + r of column 16 t + n -> this wave's [16][96 + 4] tile in LDS (one row tile at a time:
+  //      three workgroups per CU) -> whole rows out
+  float* tile = reinterpret_cast<float*>(ln_lds) + wv * (16 * LN_EPI_LD);
+  const int col0 = nb * LN_BN;
+  constexpr int PPR = LN_BN / 4;                                       // 16-byte pieces per row
 #pragma unroll
   for (int mt = 0; mt < LN_MT; mt++) {
     if (kg == 0) rowf[16 * mt + mi] = ln_pow2(254 - esc[mt]);
 #pragma unroll
     for (int t = 0; t < LN_NT; t++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) tile[(16 * mt + 4 * kg + r) * LN_EPI_LD + 16 * t + mi] = acc[mt][t][r];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int col0 = nb * LN_BN;
-  constexpr int PPR = LN_BN / 4;                                       // 16-byte pieces per row
+      for (int r = 0; r < 4; r++) tile[(4 * kg + r) * LN_EPI_LD + 16 * t + mi] = acc[mt][t][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-  for (int it = 0; it < LN_MT * 16 * PPR / 64; it++) {
-    const int idx = it * 64 + lane, r = idx / PPR, c4 = idx - r * PPR;
-    ln_f4 v = *reinterpret_cast<const ln_f4*>(tile + r * LN_EPI_LD + 4 * c4);
-    v = v * rowf[r] * *reinterpret_cast<const ln_f4*>(colf + 4 * c4) + *reinterpret_cast<const ln_f4*>(colf + LN_BN + 4 * c4);
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (row_w + r < M && !(dbg & 2)) *reinterpret_cast<ln_f4*>(y + (int64_t)(row_w + r) * ldy + col0 + 4 * c4) = v;
+    for (int it = 0; it < 16 * PPR / 64; it++) {
+      const int idx = it * 64 + lane, r = idx / PPR, c4 = idx - r * PPR;
+      ln_f4 v = *reinterpret_cast<const ln_f4*>(tile + r * LN_EPI_LD + 4 * c4);
+      v = v * rowf[16 * mt + r] * *reinterpret_cast<const ln_f4*>(colf + 4 * c4) + *reinterpret_cast<const ln_f4*>(colf + LN_BN + 4 * c4);
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const int row = row_w + 16 * mt + r;
+      if (row < M && !(dbg & 2)) *reinterpret_cast<ln_f4*>(y + (int64_t)row * ldy + col0 + 4 * c4) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                                   // the tile is read before the next row tile overwrites it
+  }
+  stamp();
+  if ((dbg & 16) && blockIdx.x == 0 && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 32; i++) y[i] = i < nst ? (float)(long long)(tst[i] - tst[0]) : -1.f;
   }
 }
 
@@ -327,7 +347,9 @@ int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const
   DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wsplit) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
                "devo_upd_linear_split: operands must be 16-byte aligned");
   DEVO_REQUIRE(((int64_t)(M - 1) * ldx + K) * 4 < (1LL << 31) && (int64_t)N * K * 4 < (1LL << 31), "devo_upd_linear_split: operand beyond 2 GB");
-  static_assert(LN_LDS <= 64 * 1024, "the workgroup's LDS fits the default dynamic limit");
+  static_assert(LN_LDS <= 80 * 1024, "two workgroups per CU");
+  static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_split), hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS);
+  DEVO_REQUIRE(lds_attr == hipSuccess, "devo_upd_linear_split: cannot reserve %d bytes of LDS", LN_LDS);
   const int RB = (M + LN_BM - 1) / LN_BM, NB = N / LN_BN;
   static const int dbg = getenv("DEVO_LN_DBG") ? atoi(getenv("DEVO_LN_DBG")) : 0;
   relu = (relu ? 1 : 0) | (dbg << 8);

@@ -82,9 +82,9 @@ __global__ __launch_bounds__(256) void k_weight_scales(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void k_split_weight(const float* __restrict__ W, int64_t s_n, int64_t s_k, int N, int K, ln_u4* __restrict__ out) {
-  const int nk = K / 32;
+  const int nk = (K + 31) / 32;
   const long long total = (long long)(N / LN_BN) * nk * LN_NT * 64;
-  const float* inv = reinterpret_cast<const float*>(out) + (size_t)N * K;
+  const float* inv = reinterpret_cast<const float*>(out) + (size_t)N * nk * 32;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int lane = (int)(i & 63);
     const long long r = i >> 6;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_split_weight(const float* __restrict__ 
     const float sc = ln_pow2(254 - (int)(__float_as_uint(inv[n]) >> 23));      // the reciprocal of a power of two
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = W[(int64_t)n * s_n + (int64_t)(k0 + j) * s_k] * sc;
+    for (int j = 0; j < 8; j++) v[j] = k0 + j < K ? W[(int64_t)n * s_n + (int64_t)(k0 + j) * s_k] * sc : 0.f;      // (K rounded up to whole steps: zeros)
     ln_h8 hi, lo;
     ln_split8(v, hi, lo);
     ln_u4* dst = out + ((r2 * LN_NT + t) * 2) * 64 + lane;
@@ -126,23 +126,22 @@ struct LnA { ln_u4 v[LN_MT][2]; };                 // one K step of a wave's act
 // y[M, N] = act(x[M, K] B + bias), B = the split weight image.  grid = 8 * ceil(row blocks / 8) * (N / 96), one row block's column
 // blocks on one XCD.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_split(
-    const float* __restrict__ x, int64_t ldx, const ln_u4* __restrict__ wsplit, const float* __restrict__ bias, float* __restrict__ y,
-    int64_t ldy, int M, int N, int K, int relu) {
+    const float* __restrict__ x, int64_t ldx, const ln_u4* __restrict__ wsplit, const float* __restrict__ bias, const float* residual,
+    float* y, int64_t ldy, int M, int N, int K, int relu_from, int dbg) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char ln_lds[];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, mi = lane & 15, kg = lane >> 4;
-  const int NB = N / LN_BN, nk = K / 32;
-  const int dbg = relu >> 8;                                           // DEVO_LN_DBG: 1 no activation loads, 2 no stores, 4 no weight DMA, 8 no MFMAs, 16 cycle stamps of workgroup 0 into y[0][..]
+  const int NB = N / LN_BN, nk = (K + 31) / 32;
+  // DEVO_LN_DBG: 1 no activation loads, 2 no stores, 4 no weight DMA, 8 no MFMAs, 16 cycle stamps of workgroup 0 into y[0][..]
   unsigned long long tst[32];
   int nst = 0;
   auto stamp = [&]() { if (dbg & 16) { if (nst < 32) tst[nst] = __builtin_readcyclecounter(); nst++; } };
   stamp();
-  relu &= 1;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int rb = (slot / NB) * 8 + xcd, nb = slot - (slot / NB) * NB;
   if (rb * LN_BM >= M) return;
   constexpr unsigned OFF_NONE = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (unsigned)(((int64_t)(M - 1) * ldx + K) * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<ln_u4*>(wsplit), 0, (unsigned)((int64_t)N * K * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<ln_u4*>(wsplit), 0, (unsigned)((int64_t)N * nk * 128), 0x00020000);
   const int row_w = rb * LN_BM + LN_MT * 16 * wv;                     // this wave's first row
   unsigned aoff[LN_MT];
 #pragma unroll
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   float* rowf = reinterpret_cast<float*>(ln_lds + LN_RING) + wv * (LN_MT * 16);
   float* colf = reinterpret_cast<float*>(ln_lds + LN_RING) + 4 * LN_MT * 16;      // [inverse scale | bias][96], visible after the first barrier
   if (tid < LN_BN) {
-    colf[tid] = reinterpret_cast<const float*>(wsplit)[(size_t)N * K + nb * LN_BN + tid];
+    colf[tid] = reinterpret_cast<const float*>(wsplit)[(size_t)N * nk * 32 + nb * LN_BN + tid];
     colf[LN_BN + tid] = bias ? bias[nb * LN_BN + tid] : 0.f;
   }
   // requests past the last K step keep the pipeline's shape (the compiler's and the loop's own vmcnt bookkeeping see ONE path) but
@@ -208,6 +207,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       ln_pin(cur.v[mt][0], cur.v[mt][1]);                              // (landed: the previous step's s_waitcnt)
       __builtin_memcpy(&xv[mt][0], &cur.v[mt][0], 16);
       __builtin_memcpy(&xv[mt][4], &cur.v[mt][1], 16);
+      if (32 * s + 32 > K) {                                           // the last step of a K that is not a multiple of 32: what lies behind the row is not part of it
+#pragma unroll
+        for (int j = 0; j < 8; j++) xv[mt][j] = 32 * s + 8 * kg + j < K ? xv[mt][j] : 0.f;
+      }
       float m = fmaxf(fmaxf(fabsf(xv[mt][0]), fabsf(xv[mt][1])), fabsf(xv[mt][2]));
       m = fmaxf(fmaxf(m, fabsf(xv[mt][3])), fabsf(xv[mt][4]));
       m = fmaxf(fmaxf(m, fabsf(xv[mt][5])), fmaxf(fabsf(xv[mt][6]), fabsf(xv[mt][7])));
@@ -304,9 +307,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const int idx = it * 64 + lane, r = idx / PPR, c4 = idx - r * PPR;
       ln_f4 v = *reinterpret_cast<const ln_f4*>(tile + r * LN_EPI_LD + 4 * c4);
       v = v * rowf[16 * mt + r] * *reinterpret_cast<const ln_f4*>(colf + 4 * c4) + *reinterpret_cast<const ln_f4*>(colf + LN_BN + 4 * c4);
-      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (col0 + 4 * c4 >= relu_from) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       const int row = row_w + 16 * mt + r;
-      if (row < M && !(dbg & 2)) *reinterpret_cast<ln_f4*>(y + (int64_t)row * ldy + col0 + 4 * c4) = v;
+      if (row < M && !(dbg & 2)) {
+        if (residual) v += *reinterpret_cast<const ln_f4*>(residual + (int64_t)row * ldy + col0 + 4 * c4);      // (may be y itself: read, then written, by this lane)
+        *reinterpret_cast<ln_f4*>(y + (int64_t)row * ldy + col0 + 4 * c4) = v;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                                   // the tile is read before the next row tile overwrites it
@@ -326,35 +332,34 @@ using namespace devo;
 extern "C" {
 
 size_t devo_upd_split_weight_bytes(int N, int K) {
-  if (N <= 0 || K <= 0 || N % LN_BN != 0 || K % 32 != 0) return 0;
-  return (size_t)N * K * 4 + (size_t)N * 4;
+  if (N <= 0 || K <= 0 || N % LN_BN != 0) return 0;
+  return (size_t)N * ((K + 31) / 32 * 32) * 4 + (size_t)N * 4;
 }
 
 int devo_upd_split_weight(const float* W, int64_t s_n, int64_t s_k, int N, int K, void* wsplit, devo_stream_t stream) {
-  DEVO_REQUIRE(N > 0 && K > 0 && N % LN_BN == 0 && K % 32 == 0, "devo_upd_split_weight: N must be a multiple of 96 and K of 32 (got %d x %d)", N, K);
+  DEVO_REQUIRE(N > 0 && K > 0 && N % LN_BN == 0, "devo_upd_split_weight: N must be a multiple of 96 (got %d x %d)", N, K);
   DEVO_REQUIRE(W && wsplit && (reinterpret_cast<uintptr_t>(wsplit) & 15) == 0, "devo_upd_split_weight: null / unaligned tensor");
-  const long long total = (long long)(N / LN_BN) * (K / 32) * LN_NT * 64;
-  hipLaunchKernelGGL(k_weight_scales, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, W, s_n, s_k, N, K, reinterpret_cast<float*>(wsplit) + (size_t)N * K);
+  const int nk = (K + 31) / 32;
+  const long long total = (long long)(N / LN_BN) * nk * LN_NT * 64;
+  hipLaunchKernelGGL(k_weight_scales, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, W, s_n, s_k, N, K, reinterpret_cast<float*>(wsplit) + (size_t)N * nk * 32);
   hipLaunchKernelGGL(k_split_weight, dim3((unsigned)blocks_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, W, s_n, s_k, N, K, (ln_u4*)wsplit);
   return check_launch("devo_upd_split_weight");
 }
 
-int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, float* y, int64_t ldy, int M, int N, int K,
-                          int relu, devo_stream_t stream) {
-  DEVO_REQUIRE(M >= 0 && N > 0 && K > 0 && N % LN_BN == 0 && K % 32 == 0, "devo_upd_linear_split: N must be a multiple of 96 and K of 32 (got %d x %d)", N, K);
+int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, const float* residual, float* y, int64_t ldy,
+                          int M, int N, int K, int relu_from, devo_stream_t stream) {
+  DEVO_REQUIRE(M >= 0 && N > 0 && K > 0 && N % LN_BN == 0, "devo_upd_linear_split: N must be a multiple of 96 (got %d x %d)", N, K);
   if (M == 0) return DEVO_OK;
-  DEVO_REQUIRE(x && wsplit && y && ldx >= K && ldy >= N && ldx % 4 == 0 && ldy % 4 == 0, "devo_upd_linear_split: null tensor or row strides that are not multiples of 4");
-  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wsplit) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
-               "devo_upd_linear_split: operands must be 16-byte aligned");
-  DEVO_REQUIRE(((int64_t)(M - 1) * ldx + K) * 4 < (1LL << 31) && (int64_t)N * K * 4 < (1LL << 31), "devo_upd_linear_split: operand beyond 2 GB");
-  static_assert(LN_LDS <= 80 * 1024, "two workgroups per CU");
-  static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_split), hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS);
-  DEVO_REQUIRE(lds_attr == hipSuccess, "devo_upd_linear_split: cannot reserve %d bytes of LDS", LN_LDS);
+  DEVO_REQUIRE(x && wsplit && y && ldx >= K && ldy >= N && ldy % 4 == 0, "devo_upd_linear_split: null tensor, rows shorter than the matrix, or output rows that are not multiples of 4 apart");
+  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wsplit) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(x) & 3) == 0, "devo_upd_linear_split: y / wsplit / bias / residual must be 16-byte aligned");
+  const int nk = (K + 31) / 32;
+  DEVO_REQUIRE(((int64_t)(M - 1) * ldx + K) * 4 < (1LL << 31) && (int64_t)N * nk * 128 < (1LL << 31), "devo_upd_linear_split: operand beyond 2 GB");
+  static_assert(LN_LDS <= 64 * 1024, "the workgroup's LDS fits the default dynamic limit");
   const int RB = (M + LN_BM - 1) / LN_BM, NB = N / LN_BN;
   static const int dbg = getenv("DEVO_LN_DBG") ? atoi(getenv("DEVO_LN_DBG")) : 0;
-  relu = (relu ? 1 : 0) | (dbg << 8);
   hipLaunchKernelGGL(k_linear_split, dim3((unsigned)(((RB + 7) / 8) * 8 * NB)), dim3(256), LN_LDS, (hipStream_t)stream, x, ldx,
-                     (const ln_u4*)wsplit, bias, y, ldy, M, N, K, relu);
+                     (const ln_u4*)wsplit, bias, residual, y, ldy, M, N, K, relu_from < 0 ? 0 : relu_from, dbg);
   return check_launch("devo_upd_linear_split");
 }
 

@@ -50,25 +50,29 @@ def _split_weight(w, transposed):
     out_f, in_f = w.shape
     N, K = (in_f, out_f) if transposed else (out_f, in_f)
     s_n, s_k = (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
-    img = torch.empty(N * K + N, dtype=torch.float32, device=w.device)
+    img = torch.empty(N * ((K + 31) // 32 * 32) + N, dtype=torch.float32, device=w.device)
     L.check(L.lib().devo_upd_split_weight(L.ptr(w), s_n, s_k, N, K, L.ptr(img), L.stream()), "update.split_weight")
     _wsplit_cache[key] = (w, img)
     return img
 
 
 def _split_ok(x2, n_out, k_in):
-    return (SPLIT_GEMM and x2.is_cuda and x2.dtype == torch.float32 and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) % 4 == 0
-            and x2.data_ptr() % 16 == 0 and n_out % 96 == 0 and k_in % 32 == 0 and x2.shape[0] >= 1024
-            and (x2.shape[0] - 1) * x2.stride(0) * 4 < (1 << 31))
+    return (SPLIT_GEMM and x2.is_cuda and x2.dtype == torch.float32 and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) >= k_in
+            and n_out % 96 == 0 and x2.shape[0] >= 1024 and ((x2.shape[0] - 1) * x2.stride(0) + k_in) * 4 < (1 << 31))
 
 
-def _linear_split(x2, w, b, transposed=False, relu=False):
-    """x2 [rows, K] fp32 -> act(x2 @ w.T + b) (or x2 @ w: transposed) on the fp16 matrix cores, fp32 in and out (csrc/linear.hip)"""
+def _linear_split(x2, w, b, transposed=False, relu=False, relu_from=None, residual=None, out=None):
+    """x2 [rows, K] fp32 -> act(x2 @ w.T + b) [+ residual] (or x2 @ w: transposed) on the fp16 matrix cores, fp32 in and out
+    (csrc/linear.hip).  relu_from: the ReLU from this output column on (a gate | res pair in one launch); residual / out: [rows, N]
+    fp32 with one row pitch (out may be the residual: x.add_(linear(t)) in one launch)."""
     N = w.shape[1] if transposed else w.shape[0]
     K = w.shape[0] if transposed else w.shape[1]
-    y = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x2.device)
-    L.check(L.lib().devo_upd_linear_split(L.ptr(x2), x2.stride(0), L.ptr(_split_weight(w.detach(), transposed)), L.ptr(b), L.ptr(y), N,
-                                          x2.shape[0], N, K, int(relu), L.stream()), "update.linear_split")
+    y = out if out is not None else torch.empty(x2.shape[0], N, dtype=torch.float32, device=x2.device)
+    if residual is not None and (residual.stride(0) != y.stride(0) or residual.dtype != torch.float32):
+        raise RuntimeError("_linear_split: the residual must share the output's row pitch")
+    rf = (0 if relu else N) if relu_from is None else relu_from
+    L.check(L.lib().devo_upd_linear_split(L.ptr(x2), x2.stride(0), L.ptr(_split_weight(w.detach(), transposed)), L.ptr(b), L.ptr(residual),
+                                          L.ptr(y), y.stride(0), x2.shape[0], N, K, rf, L.stream()), "update.linear_split")
     return y
 
 
@@ -394,26 +398,37 @@ class Update(nn.Module):
         return hit[1], hit[2]
 
     @staticmethod
-    def _linear_relu(x, lin):
-        """relu(x W^T + b) with the bias and the ReLU in the GEMM epilogue (hipBLASLt)"""
-        return torch._addmm_activation(lin.bias, x, lin.weight.t(), use_gelu=False)
+    def _lin(x, w, b, relu=False, relu_from=None, residual=None):
+        """act(x W^T + b) [+ residual, in place]: fp32 rows on the fp16 matrix cores with exact hi + lo splits (csrc/linear.hip, half the
+        library's fp32 GEMM time), everything else as a library GEMM (hipBLASLt, bias and ReLU in its epilogue)"""
+        if x.dtype == torch.float32 and w.dtype == torch.float32 and _split_ok(x, w.shape[0], w.shape[1]):
+            return _linear_split(x, w, b, relu=relu, relu_from=relu_from, residual=residual, out=residual)
+        y = torch._addmm_activation(b, x, w.t(), use_gelu=False) if relu else F.linear(x, w, b)
+        if relu_from is not None:
+            y[:, relu_from:].relu_()
+        return y if residual is None else residual.add_(y)
 
     def _soft_agg(self, name, agg, net, G):
         """-> (h(y), group_of): the aggregated rows and the edge -> group map; the caller adds h(y)[group_of] to net
         (devo_upd_expand_add, or fused into the LayerNorm that follows)."""
         W, b = self._cat(name, agg.f, agg.g)
-        fg = F.linear(net, W, b)                                   # [E, 2 dim]: f | g
+        fg = self._lin(net, W, b)                                  # [E, 2 dim]: f | g
         E, dim = net.shape
         y = torch.empty(G.n_seg, dim, dtype=net.dtype, device=net.device)
         L.check(L.lib().devo_upd_softagg(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
                                          L.ptr(y), L.ptr(G.group_of), E, dim, L.dtype_code(net), L.stream()), "update.softagg")
         return F.linear(y, agg.h.weight, agg.h.bias), G.group_of
 
-    def _gate_res(self, gr, x):
-        """the three Linear layers of a GatedResidual -> (gate pre-activation, res); the caller fuses x + sigmoid(gate) * res"""
+    def _gate_res(self, name, gr, x):
+        """the three Linear layers of a GatedResidual -> (gate pre-activation, res); the caller fuses x + sigmoid(gate) * res.
+        gate | res[0] share their input: one GEMM on concatenated weights, the ReLU from res[0]'s first column on"""
+        dim = x.shape[1]
+        if x.dtype == torch.float32 and _split_ok(x, 2 * dim, dim):
+            W, b = self._cat(name, gr.gate[0], gr.res[0])
+            gr0 = self._lin(x, W, b, relu_from=dim)                # [E, 2 dim]: gate | relu(res[0])
+            return gr0[:, :dim], self._lin(gr0[:, dim:], gr.res[2].weight, gr.res[2].bias)
         gate = F.linear(x, gr.gate[0].weight, gr.gate[0].bias)
-        res = F.linear(self._linear_relu(x, gr.res[0]), gr.res[2].weight, gr.res[2].bias)     # ReLU in the GEMM epilogue
-        return gate, res
+        return gate, F.linear(self._lin(x, gr.res[0].weight, gr.res[0].bias, relu=True), gr.res[2].weight, gr.res[2].bias)
 
     def forward(self, net, inp, corr, flow, ii, jj, kk):
         """update operator (enet.py:80): -> net, (delta, weight, None)"""
@@ -430,18 +445,18 @@ class Update(nn.Module):
         ix, jx, Gkk, Gij = self._tables(ii, jj, kk)
 
         # corr MLP (enet.py:59-66) and net = norm(net + inp + corr)  (:82-83), the two adds fused into the LayerNorm
-        c = self._linear_relu(c, self.corr[0])
-        c = F.linear(c, self.corr[2].weight, self.corr[2].bias)
+        c = self._lin(c, self.corr[0].weight, self.corr[0].bias, relu=True)
+        c = self._lin(c, self.corr[2].weight, self.corr[2].bias)
         c = _ln(c, self.corr[3], relu=True)
-        c = F.linear(c, self.corr[5].weight, self.corr[5].bias)
+        c = self._lin(c, self.corr[5].weight, self.corr[5].bias)
         x = _ln(x, self.norm, add1=inp2, add2=c)
 
         # neighbour mixing along the patch trajectory (:86-91)
         for mlp, idx in ((self.c1, ix), (self.c2, jx)):
             t = torch.empty_like(x)
             L.check(lib.devo_upd_masked_gather(L.ptr(x), L.ptr(idx), L.ptr(t), E, dim, code, L.stream()), "update.masked_gather")
-            t = self._linear_relu(t, mlp[0])
-            x.add_(F.linear(t, mlp[2].weight, mlp[2].bias))
+            t = self._lin(t, mlp[0].weight, mlp[0].bias, relu=True)
+            self._lin(t, mlp[2].weight, mlp[2].bias, residual=x)     # x += c(t)
 
         # soft aggregation over the edges of a patch, then over the edges of a frame pair (:93-94); the second expand is
         # fused into the LayerNorm of the "gru" (:52-57), and each GatedResidual into the op that consumes it
@@ -449,8 +464,8 @@ class Update(nn.Module):
         L.check(lib.devo_upd_expand_add(L.ptr(x), L.ptr(hy), L.ptr(grp), E, dim, code, L.stream()), "update.expand_add")
         hy, grp = self._soft_agg("agg_ij", self.agg_ij, x, Gij)
         x = _ln(x, self.gru[0], expand=(hy, grp))                                  # LN(net + agg_ij(net))
-        x = _ln(x, self.gru[2], gated=self._gate_res(self.gru[1], x))             # LN(GatedResidual(.))
-        gate, res = self._gate_res(self.gru[3], x)
+        x = _ln(x, self.gru[2], gated=self._gate_res("gru1", self.gru[1], x))     # LN(GatedResidual(.))
+        gate, res = self._gate_res("gru3", self.gru[3], x)
 
         net_out = torch.empty_like(x)
         delta = torch.empty(E, 2, dtype=dt, device=x.device)

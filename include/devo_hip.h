@@ -341,20 +341,22 @@ int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void*
                    const void* bd, const void* Ww, const void* bw, void* delta, void* weight, int64_t E, int dim,
                    int dtype, devo_stream_t stream);
 
-/* The Update operator's dense layers in fp32 storage on the fp16 matrix cores (csrc/linear.hip): y[M, N] = act(x[M, K] W^T + bias) with
- * every fp32 value split into fp16 hi + lo (2^-22 relative per factor, fp32 accumulation) — the training step's 18 000-row Linear
- * layers (enet.py:41-78, blocks.py:15-48) at half the fp32 library GEMM's time.  Both operands are scaled by exact powers of two
- * before the split (weight columns once per version; activation rows by a running scale inside the kernel), so gradient-sized rows
- * (1e-7) keep their 22 bits.  N % 96 == 0, K % 32 == 0.
+/* The Update operator's dense layers in fp32 storage on the fp16 matrix cores (csrc/linear.hip): y[M, N] = act(x[M, K] W^T + bias) [+ residual]
+ * with every fp32 value split into fp16 hi + lo (2^-22 relative per factor, fp32 accumulation) — the 18 000 / 21 600-row Linear layers of
+ * the update operator (enet.py:41-78, blocks.py:15-48) at half the fp32 library GEMM's time.  Both operands are scaled by exact powers
+ * of two before the split (weight columns once per version; activation rows by a running scale inside the kernel), so gradient-sized
+ * rows (1e-7) keep their 22 bits.  N % 96 == 0; any K (the corr MLP's first layer has K = 882).
  *   devo_upd_split_weight: the weight, element (n, k) at W[n * s_n + k * s_k] (s_n = K, s_k = 1: a Linear's [N, K] weight for the forward;
  *     s_n = 1, s_k = N_in: the same storage read as its transpose for dX = dY W), -> wsplit (devo_upd_split_weight_bytes(N, K) =
- *     N K 4 + N 4 bytes — the operand image, then the inverse column scales —, 16-byte aligned): once per version of the weight.
- *   devo_upd_linear_split: x fp32 rows ldx apart, y fp32 rows ldy apart (multiples of 4, 16-byte aligned), bias fp32 [N] or NULL,
- *     relu != 0: max(., 0) in the epilogue. */
+ *     N ceil32(K) 4 + N 4 bytes — the operand image, then the inverse column scales —, 16-byte aligned): once per version of the weight.
+ *   devo_upd_linear_split: x fp32, rows ldx >= K elements apart (any alignment of 4 bytes); y fp32, rows ldy apart (a multiple of 4,
+ *     16-byte aligned); bias fp32 [N] or NULL; residual NULL or fp32 with y's row pitch, added after the activation (it may be y itself:
+ *     x.add_(linear(t)) in one launch); columns >= relu_from get max(., 0) (0: all of them, >= N: none — a gate | res pair of a
+ *     GatedResidual in one launch). */
 size_t devo_upd_split_weight_bytes(int N, int K);
 int devo_upd_split_weight(const float* W, int64_t s_n, int64_t s_k, int N, int K, void* wsplit, devo_stream_t stream);
-int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, float* y, int64_t ldy, int M, int N,
-                          int K, int relu, devo_stream_t stream);
+int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, const float* residual, float* y, int64_t ldy,
+                          int M, int N, int K, int relu_from, devo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Event voxelisation — the step in front of the encoders.

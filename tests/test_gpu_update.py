@@ -255,7 +255,8 @@ def test_softagg_training_path_on_the_hip_kernels_matches_the_torch_composition(
         assert_rel(gp32[k], gp64[k].float(), 3e-3, "d/d " + k)
 
 
-@pytest.mark.parametrize("rows,n_out,k_in,relu", [(18000, 384, 384, False), (4099, 768, 384, True), (1030, 192, 32, False), (5000, 384, 768, False)])
+@pytest.mark.parametrize("rows,n_out,k_in,relu", [(18000, 384, 384, False), (4099, 768, 384, True), (1030, 192, 32, False), (5000, 384, 768, False),
+                                                   (3001, 384, 882, True), (2000, 96, 50, False)])
 def test_split_precision_linear_matches_float64(rows, n_out, k_in, relu):
     """csrc/linear.hip: fp32 in, fp32 out, fp16 hi + lo operands on the matrix cores — as close to the float64 product as the library's
     fp32 GEMM is (the tolerance is the fp32 GEMM's own distance to float64, doubled), in the forward form and in the dX form"""
@@ -289,13 +290,22 @@ def test_split_precision_linear_matches_float64(rows, n_out, k_in, relu):
         ref = gy.double() @ w.double()
         gy[1::3] *= 1e-8
         ref = gy.double() @ w.double()
-        scale = gy.double().abs() @ w.double().abs() + 1e-300
-        e_lib = (((gy @ w).double() - ref).abs() / scale).max().item()
-        e_own = ((UA._linear_split(gy, w, None, transposed=True).double() - ref).abs() / scale).max().item()
+        scale_t = gy.double().abs() @ w.double().abs() + 1e-300
+        e_lib = (((gy @ w).double() - ref).abs() / scale_t).max().item()
+        e_own = ((UA._linear_split(gy, w, None, transposed=True).double() - ref).abs() / scale_t).max().item()
         assert e_own <= max(2 * e_lib, 2e-7), (e_own, e_lib)
+    # residual added in place, the ReLU from a column on (a GatedResidual's gate | res[0] pair)
+    acc = torch.randn(rows, n_out, generator=g).to(DEV)
+    ref = acc.double() + torch.nn.functional.linear(x.double(), w.double(), b.double())
+    got = UA._linear_split(x, w, b, residual=acc, out=acc)
+    assert got.data_ptr() == acc.data_ptr() and ((got.double() - ref).abs() / (scale + ref.abs())).max().item() < 1e-6
+    half = n_out // 2 // 4 * 4
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    ref[:, half:].relu_()
+    assert ((UA._linear_split(x, w, b, relu_from=half).double() - ref).abs() / scale).max().item() < 1e-6
     # strided rows (a column slice of a wider tensor) and the per-version cache
-    wide = torch.randn(rows, k_in + 64, generator=g).to(DEV)
-    xs = wide[:, 32:32 + k_in]
+    wide = torch.randn(rows, k_in + 67, generator=g).to(DEV)
+    xs = wide[:, 33:33 + k_in]                                          # (rows at odd multiples of 4 bytes)
     if UA._split_ok(xs, n_out, k_in):
         ref = torch.nn.functional.linear(xs.double(), w.double(), b.double())
         assert ((UA._linear_split(xs, w, b).double() - ref).abs() / (xs.double().abs() @ w.double().abs().t() + b.double().abs())).max().item() < 1e-6

@@ -41,7 +41,9 @@ constexpr int LN_NSTAGE = 3;
 constexpr int LN_EPI_LD = LN_BN + 4;              // row pitch (floats) of the result tile in LDS
 constexpr int LN_TILE_BYTES = 16 * LN_EPI_LD * 4;          // one row tile of a wave's result at a time
 constexpr int LN_RING = (LN_NSTAGE * LN_STAGE > 4 * LN_TILE_BYTES) ? LN_NSTAGE * LN_STAGE : 4 * LN_TILE_BYTES;
-constexpr int LN_LDS = LN_RING + 4 * LN_MT * 16 * 4 + 2 * LN_BN * 4;   // + per wave: one float per row (rescale factors, then the inverse row scales); the block's column scales and biases
+constexpr int LN_SLAB = LN_MT * 16 * 128;         // one wave's activations of one K step: 32 rows x 128 bytes
+constexpr int LN_AUX = LN_RING + 4 * LN_SLAB;     // behind the ring and the four slabs:
+constexpr int LN_LDS = LN_AUX + 4 * LN_MT * 16 * 4;   // one float per row and wave (rescale factors, then the inverse row scales): 53 760 B = 42 granules of 1 280 B, three workgroups per CU   // + per wave: one float per row (rescale factors, then the inverse row scales); the block's column scales and biases
 constexpr int LN_EXP_TARGET = 8;                  // a scale puts its reference magnitude into [2^8, 2^9)
 constexpr float LN_RAISE = 16384.f;               // ... and is raised when a scaled value exceeds 2^14 (fp16's largest: 65504)
 
@@ -112,19 +114,9 @@ __device__ __forceinline__ void ln_dma16(unsigned voff, __amdgpu_buffer_rsrc_t r
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_addr), "s"(soff) : "memory");
 }
 
-// 16 bytes per lane into registers, outside the compiler's vmcnt bookkeeping: its own count cannot see the LDS-DMA requests between
-// the loads and would wait for requests issued a step too late.  The registers are valid after the loop's s_waitcnt + ln_pin.
-template <int IMM>
-__device__ __forceinline__ void ln_load16(ln_u4& out, unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff) {
-  soff = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(out) : "v"(voff), "s"(rs), "s"(soff), "n"(IMM) : "memory");
-}
-__device__ __forceinline__ void ln_pin(ln_u4& a, ln_u4& b) { asm volatile("" : "+v"(a), "+v"(b)); }
-
-struct LnA { ln_u4 v[LN_MT][2]; };                 // one K step of a wave's activations: 2 row tiles x 32 bytes per lane
-
 // y[M, N] = act(x[M, K] B + bias), B = the split weight image.  grid = 8 * ceil(row blocks / 8) * (N / 96), one row block's column
 // blocks on one XCD.
+template <bool TRACE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_split(
     const float* __restrict__ x, int64_t ldx, const ln_u4* __restrict__ wsplit, const float* __restrict__ bias, const float* residual,
     float* y, int64_t ldy, int M, int N, int K, int relu_from, int dbg) {
@@ -134,7 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // DEVO_LN_DBG: 1 no activation loads, 2 no stores, 4 no weight DMA, 8 no MFMAs, 16 cycle stamps of workgroup 0 into y[0][..]
   unsigned long long tst[32];
   int nst = 0;
-  auto stamp = [&]() { if (dbg & 16) { if (nst < 32) tst[nst] = __builtin_readcyclecounter(); nst++; } };
+  auto stamp = [&]() { if constexpr (TRACE) { if (nst < 32) tst[nst] = __builtin_readcyclecounter(); nst++; } };
   stamp();
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int rb = (slot / NB) * 8 + xcd, nb = slot - (slot / NB) * NB;
@@ -143,18 +135,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (unsigned)(((int64_t)(M - 1) * ldx + K) * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<ln_u4*>(wsplit), 0, (unsigned)((int64_t)N * nk * 128), 0x00020000);
   const int row_w = rb * LN_BM + LN_MT * 16 * wv;                     // this wave's first row
-  unsigned aoff[LN_MT];
+  // Activations: each wave brings its own 32 rows x 32 floats of a K step into its LDS slab by lane-linear DMA — eight lanes per row, a
+  // quad of lanes inside one 128-byte line (16 addresser cycles per KB; 16 bytes per lane at a row stride cost 64) — and reads them back
+  // in the A-operand layout.  Slot p of row r holds the row's piece p ^ (r & 7): the 8 rows a ds_read_b128 serves per cycle then sit
+  // in different banks.
+  unsigned avoff[4];                                                  // DMA q: row 8 q + lane / 8, piece (lane % 8) ^ (row % 8)
 #pragma unroll
-  for (int mt = 0; mt < LN_MT; mt++) {
-    const int row = row_w + 16 * mt + mi;
-    aoff[mt] = row < M ? (unsigned)(((int64_t)row * ldx + 8 * kg) * 4) : OFF_NONE;
+  for (int q = 0; q < 4; q++) {
+    const int row = row_w + 8 * q + (lane >> 3);
+    avoff[q] = (row < M && !(dbg & 1)) ? (unsigned)(((int64_t)row * ldx) * 4 + 16 * ((lane & 7) ^ ((lane >> 3) & 7))) : OFF_NONE;
   }
+  unsigned aslot[LN_MT][2];                                           // byte offsets of this lane's two pieces (channels 8 kg .. + 7) of row 16 mt + mi
+#pragma unroll
+  for (int mt = 0; mt < LN_MT; mt++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) aslot[mt][h] = (unsigned)((16 * mt + mi) * 128 + 16 * ((2 * kg + h) ^ (mi & 7)));
   const unsigned lds0 = (unsigned)(uintptr_t)ln_lds;
-  float* rowf = reinterpret_cast<float*>(ln_lds + LN_RING) + wv * (LN_MT * 16);
-  float* colf = reinterpret_cast<float*>(ln_lds + LN_RING) + 4 * LN_MT * 16;      // [inverse scale | bias][96], visible after the first barrier
+  unsigned char* slab = ln_lds + LN_RING + wv * LN_SLAB;
+  float* rowf = reinterpret_cast<float*>(ln_lds + LN_AUX) + wv * (LN_MT * 16);
+  float* colf = reinterpret_cast<float*>(ln_lds + LN_RING);          // [inverse scale | bias][96]: in the first slab once the K loop is over
+  float col_inv = 0.f, col_bias = 0.f;                                // (fetched now, stored then)
   if (tid < LN_BN) {
-    colf[tid] = reinterpret_cast<const float*>(wsplit)[(size_t)N * nk * 32 + nb * LN_BN + tid];
-    colf[LN_BN + tid] = bias ? bias[nb * LN_BN + tid] : 0.f;
+    col_inv = reinterpret_cast<const float*>(wsplit)[(size_t)N * nk * 32 + nb * LN_BN + tid];
+    col_bias = bias ? bias[nb * LN_BN + tid] : 0.f;
   }
   // requests past the last K step keep the pipeline's shape (the compiler's and the loop's own vmcnt bookkeeping see ONE path) but
   // carry the out-of-range offset: no memory access, zeros back
@@ -167,13 +170,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       ln_dma16(voff, rsw, (unsigned)(((nb * nk + s) * (LN_NT * 2) + piece) * 1024), lds0 + (unsigned)(buf * LN_STAGE + piece * 1024));
     }
   };
-  auto load_a = [&](LnA& a, int s) {
+  auto load_a = [&](int s) {                                         // K step s of this wave's rows -> its slab
 #pragma unroll
-    for (int mt = 0; mt < LN_MT; mt++) {
-      const unsigned o = (s < nk && !(dbg & 1)) ? aoff[mt] : OFF_NONE;
-      ln_load16<0>(a.v[mt][0], o, rsx, (unsigned)s * 128u);
-      ln_load16<16>(a.v[mt][1], o, rsx, (unsigned)s * 128u);
-    }
+    for (int q = 0; q < 4; q++)
+      ln_dma16(s < nk ? avoff[q] : OFF_NONE, rsx, (unsigned)s * 128u, lds0 + (unsigned)(LN_RING + wv * LN_SLAB + q * 1024));
   };
   ln_f4 acc[LN_MT][LN_NT];
 #pragma unroll
@@ -185,17 +185,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
   for (int mt = 0; mt < LN_MT; mt++) { esc[mt] = 0; sc[mt] = 0.f; }
 
-  LnA A0, A1, A2;
-  load_a(A0, 0);
+  load_a(0);
   stage(0);
-  load_a(A1, 1);
   stage(1);
-  asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                    // (the second stage's three requests may stay in flight)
   __syncthreads();
   stamp();
 
-  auto step = [&](int s, LnA& cur, LnA& fill) {
-    load_a(fill, s + 2);
+  auto step = [&](int s) {
+    // this step's activations out of the slab, then the slab is free for the next step's (requested one step ahead; the weight pieces two)
+    ln_u4 cur[LN_MT][2];
+#pragma unroll
+    for (int mt = 0; mt < LN_MT; mt++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) cur[mt][h] = *reinterpret_cast<const ln_u4*>(slab + aslot[mt][h]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    load_a(s + 1);
     stage(s + 2);
     stamp();
     // ---- scale: this lane's 2 x 8 values against the row scales
@@ -204,9 +209,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     bool raise = false;
 #pragma unroll
     for (int mt = 0; mt < LN_MT; mt++) {
-      ln_pin(cur.v[mt][0], cur.v[mt][1]);                              // (landed: the previous step's s_waitcnt)
-      __builtin_memcpy(&xv[mt][0], &cur.v[mt][0], 16);
-      __builtin_memcpy(&xv[mt][4], &cur.v[mt][1], 16);
+      __builtin_memcpy(&xv[mt][0], &cur[mt][0], 16);
+      __builtin_memcpy(&xv[mt][4], &cur[mt][1], 16);
       if (32 * s + 32 > K) {                                           // the last step of a K that is not a multiple of 32: what lies behind the row is not part of it
 #pragma unroll
         for (int j = 0; j < 8; j++) xv[mt][j] = 32 * s + 8 * kg + j < K ? xv[mt][j] : 0.f;
@@ -273,19 +277,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int mt = 0; mt < LN_MT; mt++) acc[mt][tg + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[u], acc[mt][tg + u], 0, 0, 0);
     }
-    // step s + 1's activations and weight pieces (issued one step ago) have landed; this step's 7 requests may stay in flight
+    // step s + 1's activations (requested in this step) and weight pieces (one step ago) have landed; this step's 3 weight requests may stay in flight
     stamp();
-    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     stamp();
     __syncthreads();                                                   // every wave is done with this stage's buffer
     stamp();
   };
-  for (int s = 0; s < nk; s += 3) {                                    // (steps past nk multiply zeros)
-    step(s, A0, A2);
-    step(s + 1, A1, A0);
-    step(s + 2, A2, A1);
-  }
+  for (int s = 0; s < nk; s++) step(s);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the trailing (empty) requests, before the ring becomes the result tile
+  if (tid < LN_BN) { colf[tid] = col_inv; colf[LN_BN + tid] = col_bias; }
   __syncthreads();
   // ---- result: lane (n, rg) holds rows 4 rg + r of column 16 t + n -> this wave's [16][96 + 4] tile in LDS (one row tile at a time:
   //      three workgroups per CU) -> whole rows out
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __builtin_amdgcn_wave_barrier();                                   // the tile is read before the next row tile overwrites it
   }
   stamp();
-  if ((dbg & 16) && blockIdx.x == 0 && tid == 0) {
+  if (TRACE && blockIdx.x == 0 && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 32; i++) y[i] = i < nst ? (float)(long long)(tst[i] - tst[0]) : -1.f;
@@ -358,7 +359,7 @@ int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const
   static_assert(LN_LDS <= 64 * 1024, "the workgroup's LDS fits the default dynamic limit");
   const int RB = (M + LN_BM - 1) / LN_BM, NB = N / LN_BN;
   static const int dbg = getenv("DEVO_LN_DBG") ? atoi(getenv("DEVO_LN_DBG")) : 0;
-  hipLaunchKernelGGL(k_linear_split, dim3((unsigned)(((RB + 7) / 8) * 8 * NB)), dim3(256), LN_LDS, (hipStream_t)stream, x, ldx,
+  hipLaunchKernelGGL((dbg & 16) ? k_linear_split<true> : k_linear_split<false>, dim3((unsigned)(((RB + 7) / 8) * 8 * NB)), dim3(256), LN_LDS, (hipStream_t)stream, x, ldx,
                      (const ln_u4*)wsplit, bias, residual, y, ldy, M, N, K, relu_from < 0 ? 0 : relu_from, dbg);
   return check_launch("devo_upd_linear_split");
 }

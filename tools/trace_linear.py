@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cycle stamps of workgroup 0 of k_linear_split (DEVO_LN_DBG=16): prologue, then per K step
-[requests issued | scaled + split | products issued | loads landed | barrier passed]."""
+[next step fetched, requests issued | next step checked | products + next split issued | loads landed | barrier passed]."""
 import os, sys
 os.environ["DEVO_LN_DBG"] = "16"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -65,10 +65,10 @@ def parse():
                          "pops.transform, two altcorr.corr calls on the NCHW ring + torch.stack, fastba.BA), launched eagerly, no graph, no plan / "
                          "workspace hand-over — printed as the JSON line")
     ap.add_argument("--no-reference-api", action="store_true", help="skip the reference_api field of the default line")
-    ap.add_argument("--with-update", action="store_true",
-                    help="additionally time a FULL DEVO update iteration: the step with the Update operator (devo_amd.update, "
-                         "random weights, fp16) between lookup and BA, feeding delta / weight to the BA (extra field; the headline "
-                         "metric excludes the Update MLP, SURVEY 8d)")
+    ap.add_argument("--no-full-iteration", action="store_true",
+                    help="skip the extra field full_update_iteration: a FULL DEVO update iteration — the step with the Update operator "
+                         "(devo_amd.update, random weights, fp32 and fp16) between lookup and BA, feeding delta / weight to the BA (the "
+                         "headline metric excludes the Update MLP, SURVEY 8d)")
     args = ap.parse_args()
     args.fuse_levels = not args.per_level_launches
     return args
@@ -526,45 +526,53 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         "ba": {"gpu_ms": round(t_ba_gpu * 1e3, 4)},
     }
 
-    if args.with_update and not secondary:
+    if not args.no_full_iteration and not secondary and args.workload == "cfg2":
+        # A FULL update iteration as devo.py:305-340 runs it: reprojection, lookup, the Update operator (devo_amd.update, random weights)
+        # on the lookup's output, target = centre + delta, 2 GN iterations with the predicted weights.  An extra field: the headline
+        # metric excludes the Update MLP.  fp32 = every Linear layer on csrc/linear.hip's split-precision GEMM.
         from devo_amd.update import Update
-        torch.manual_seed(1234 + rank)
-        upd = Update(3).to(device).half().eval()
-        net_h = torch.zeros(1, E, 384, device=device, dtype=torch.float16)
-        inp_h = torch.randn(1, E, 384, device=device, dtype=torch.float16) * 0.1
+        full = {}
+        for udt, key in ((torch.float32, "f32"), (torch.float16, "f16")):
+            torch.manual_seed(1234 + rank)
+            upd = Update(3).to(device).to(udt).eval()
+            net_h = torch.zeros(1, E, 384, device=device, dtype=udt)
+            inp_h = torch.randn(1, E, 384, device=device, dtype=udt) * 0.1
 
-        def full_iteration():
-            d["state"].copy_(d["state0"])
-            coords = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
-            lookup(coords)
-            with torch.no_grad():
-                _, (delta, weight, _) = upd(net_h, inp_h, corr_out.half(), None, d["ii"], d["jj"], d["kk"])
-            target = coords[:, :, :, 1, 1] + delta.float()
-            cuda_ba.forward(d["poses"], d["patches"], d["intr"], target, weight.float(), d["lmbda"],
-                            d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
-        for _ in range(3):
-            full_iteration()
-        torch.cuda.synchronize()
-        run_full, how = full_iteration, "eager launches"
-        if not args.no_graph:                                          # the Update operator's group tables are cached by now: no host sync left
-            g2 = torch.cuda.CUDAGraph()
-            s2 = torch.cuda.Stream()
-            s2.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s2):
-                with torch.cuda.graph(g2, stream=s2):
-                    full_iteration()
-            torch.cuda.current_stream().wait_stream(s2)
-            run_full, how = g2.replay, "HIP graph"
-        for _ in range(3):
-            run_full()
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(50):
-            run_full()
-        ev1.record()
-        torch.cuda.synchronize()
-        out["full_update_iteration"] = {"ms": round(ev0.elapsed_time(ev1) / 50, 4),
-                                        "note": f"reproject + 2-level lookup + Update operator (fp16, random weights) + 2 GN iterations, {how}"}
+            def full_iteration():
+                torch.mul(d["state0"], 1.0, out=d["state"])
+                coords = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
+                lookup(coords)
+                with torch.no_grad():
+                    _, (delta, weight, _) = upd(net_h, inp_h, corr_out.to(udt), None, d["ii"], d["jj"], d["kk"])
+                target = coords[:, :, :, 1, 1] + delta.float()
+                cuda_ba.forward(d["poses"], d["patches"], d["intr"], target, weight.float(), d["lmbda"],
+                                d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
+            for _ in range(3):
+                full_iteration()
+            torch.cuda.synchronize()
+            run_full, how = full_iteration, "eager launches"
+            if not args.no_graph:                                      # the Update operator's group tables are cached by now: no host sync left
+                g2 = torch.cuda.CUDAGraph()
+                s2 = torch.cuda.Stream()
+                s2.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s2):
+                    with torch.cuda.graph(g2, stream=s2):
+                        full_iteration()
+                torch.cuda.current_stream().wait_stream(s2)
+                run_full, how = g2.replay, "HIP graph"
+            for _ in range(3):
+                run_full()
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(50):
+                run_full()
+            ev1.record()
+            torch.cuda.synchronize()
+            full[key + "_ms"] = round(ev0.elapsed_time(ev1) / 50, 4)
+            del upd
+        full["note"] = (f"reproject + 2-level lookup ({dtn} pyramid) + Update operator (fp32 / fp16 weights and state, random weights) + "
+                        f"2 GN iterations on its outputs, {how}")
+        out["full_update_iteration"] = full
 
     if secondary:
         return out

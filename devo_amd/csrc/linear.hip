@@ -25,6 +25,9 @@
 // whole 16-byte pieces, scaled back, with the bias (and ReLU) applied.
 #include "common.h"
 #include <hip/hip_fp16.h>
+#include <algorithm>
+#include <map>
+#include <vector>
 
 namespace devo {
 
@@ -119,7 +122,7 @@ __device__ __forceinline__ void ln_dma16(unsigned voff, __amdgpu_buffer_rsrc_t r
 template <bool TRACE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_split(
     const float* __restrict__ x, int64_t ldx, const ln_u4* __restrict__ wsplit, const float* __restrict__ bias, const float* residual,
-    float* y, int64_t ldy, int M, int N, int K, int relu_from, int dbg) {
+    float* y, int64_t ldy, int M, int N, int K, int relu_from, int dbg, unsigned long long* wgtrace) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char ln_lds[];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, mi = lane & 15, kg = lane >> 4;
   const int NB = N / LN_BN, nk = (K + 31) / 32;
@@ -319,7 +322,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __builtin_amdgcn_wave_barrier();                                   // the tile is read before the next row tile overwrites it
   }
   stamp();
-  if (TRACE && blockIdx.x == 0 && tid == 0) {
+  if (TRACE && wgtrace && tid == 0) {                                  // DEVO_LN_DBG = 48: every workgroup's start / end / hardware id
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    wgtrace[4 * blockIdx.x + 0] = tst[0]; wgtrace[4 * blockIdx.x + 1] = __builtin_readcyclecounter();
+    wgtrace[4 * blockIdx.x + 2] = hw; wgtrace[4 * blockIdx.x + 3] = xcc;
+  }
+  if (TRACE && !wgtrace && blockIdx.x == 0 && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 32; i++) y[i] = i < nst ? (float)(long long)(tst[i] - tst[0]) : -1.f;
@@ -359,8 +369,36 @@ int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const
   static_assert(LN_LDS <= 64 * 1024, "the workgroup's LDS fits the default dynamic limit");
   const int RB = (M + LN_BM - 1) / LN_BM, NB = N / LN_BN;
   static const int dbg = getenv("DEVO_LN_DBG") ? atoi(getenv("DEVO_LN_DBG")) : 0;
-  hipLaunchKernelGGL((dbg & 16) ? k_linear_split<true> : k_linear_split<false>, dim3((unsigned)(((RB + 7) / 8) * 8 * NB)), dim3(256), LN_LDS, (hipStream_t)stream, x, ldx,
-                     (const ln_u4*)wsplit, bias, residual, y, ldy, M, N, K, relu_from < 0 ? 0 : relu_from, dbg);
+  const unsigned nwg = (unsigned)(((RB + 7) / 8) * 8 * NB);
+  unsigned long long* wgtrace = nullptr;
+  if ((dbg & 48) == 48) { (void)hipMalloc(&wgtrace, (size_t)nwg * 32); (void)hipMemset(wgtrace, 0, (size_t)nwg * 32); }
+  hipLaunchKernelGGL((dbg & 16) ? k_linear_split<true> : k_linear_split<false>, dim3(nwg), dim3(256), LN_LDS, (hipStream_t)stream, x, ldx,
+                     (const ln_u4*)wsplit, bias, residual, y, ldy, M, N, K, relu_from < 0 ? 0 : relu_from, dbg, wgtrace);
+  if (wgtrace) {                                                      // debug: residency of the launch's workgroups over time, per CU
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)nwg * 4);
+    (void)hipMemcpy(h.data(), wgtrace, (size_t)nwg * 32, hipMemcpyDeviceToHost);
+    (void)hipFree(wgtrace);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double sum = 0; int cnt = 0;
+    std::map<unsigned long long, std::vector<std::pair<unsigned long long, unsigned long long>>> per_cu;
+    for (unsigned i = 0; i < nwg; i++) {
+      if (!h[4 * i + 1]) continue;
+      t0 = std::min(t0, h[4 * i]); t1 = std::max(t1, h[4 * i + 1]); sum += (double)(h[4 * i + 1] - h[4 * i]); cnt++;
+      per_cu[((h[4 * i + 3] & 15) << 16) | (h[4 * i + 2] & 0xff00)].push_back({h[4 * i], h[4 * i + 1]});      // XCC | SE, SH, CU
+    }
+    int maxc = 0; double avgc = 0;
+    for (auto& kv : per_cu) {
+      int best = 0;
+      for (auto& a : kv.second) { int c = 0; for (auto& b : kv.second) c += (b.first <= a.first && a.first < b.second); best = std::max(best, c); }
+      maxc = std::max(maxc, best); avgc += best;
+    }
+    fprintf(stderr, "[linear trace] %d workgroups on %zu CUs, span %llu cycles, mean workgroup %0.f cycles; most workgroups resident on one CU at a time: max %d, mean over CUs %.2f\n",
+            cnt, per_cu.size(), t1 - t0, sum / std::max(cnt, 1), maxc, avgc / std::max<size_t>(per_cu.size(), 1));
+    unsigned long long last_start = 0;
+    for (unsigned i = 0; i < nwg; i++) if (h[4 * i + 1]) last_start = std::max(last_start, h[4 * i] - t0);
+    fprintf(stderr, "[linear trace] the last workgroup starts %llu cycles after the first\n", last_start);
+  }
   return check_launch("devo_upd_linear_split");
 }
 

@@ -423,6 +423,99 @@ __global__ __launch_bounds__(256) void k_layernorm_q(const T* __restrict__ x, co
   }
 }
 
+// Adjoint of k_layernorm_q (fp32, training): y = LN(x + a + b) [ReLU'd], g = dL/dy  ->  dx (= da = db) and the column sums
+// dgamma += sum_rows g xhat, dbeta += sum_rows g.  A quarter wave per row as in the forward (mean and rstd are recomputed: the row is in
+// registers anyway); every lane keeps the partial column sums of its 4 NC columns over its rows, the workgroup folds its 16 quarter waves
+// through LDS and adds 2 dim values to global memory (devo/enet.py:44,52-56,62: the LayerNorms the reference differentiates through
+// torch.autograd; ATen runs layer_norm_grad_input + cuComputePartGradGammaBeta + a reduction).
+template <int NC>
+__global__ __launch_bounds__(256) void k_layernorm_bwd_q(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ dout, float* __restrict__ dx,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int dim, float eps,
+                                                         int relu) {
+  extern __shared__ float lnb_part[];                      // [16 quarter waves][2 dim]
+  const int l16 = threadIdx.x & 15, qw = threadIdx.x >> 4;
+  float gm[NC][4], bt[NC][4], ag[NC][4], ab[NC][4];
+#pragma unroll
+  for (int k = 0; k < NC; k++) {
+    const int c = (l16 + 16 * k) * 4;
+    ldc(gamma + c, gm[k]); ldc(beta + c, bt[k]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ag[k][i] = 0.0f; ab[k][i] = 0.0f; }
+  }
+  const float inv_dim = 1.0f / (float)dim;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  const int64_t first = (int64_t)blockIdx.x * 16 + qw;
+  const int64_t iters = (rows + stride - 1) / stride;      // every quarter wave runs the same number of rounds (the DPP sums need all lanes)
+  for (int64_t it = 0; it < iters; it++) {
+    const int64_t row_raw = first + it * stride;
+    const bool live = row_raw < rows;
+    const int64_t row = live ? row_raw : rows - 1;
+    float v[NC][4], g[NC][4];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+      const int c = (l16 + 16 * k) * 4;
+      float u[4];
+      ldc(x + row * dim + c, v[k]);
+      if (a) { ldc(a + row * dim + c, u);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[k][i] += u[i]; }
+      if (b) { ldc(b + row * dim + c, u);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[k][i] += u[i]; }
+      ldc(dout + row * dim + c, g[k]);
+#pragma unroll
+      for (int i = 0; i < 4; i++) s += v[k][i];
+    }
+    const float mean = row16_sum(s) * inv_dim;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const float d = v[k][i] - mean; q += d * d; }
+    const float rstd = rsqrtf(row16_sum(q) * inv_dim + eps);
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float xh = (v[k][i] - mean) * rstd;
+        float gi = g[k][i];
+        if (relu && !(xh * gm[k][i] + bt[k][i] > 0.0f)) gi = 0.0f;      // the forward's max(., 0): no gradient where it clipped
+        if (!live) gi = 0.0f;
+        ag[k][i] += gi * xh; ab[k][i] += gi;
+        const float gg = gi * gm[k][i];
+        s1 += gg; s2 += gg * xh;
+        v[k][i] = xh; g[k][i] = gg;
+      }
+    s1 = row16_sum(s1) * inv_dim; s2 = row16_sum(s2) * inv_dim;
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < NC; k++) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = rstd * (g[k][i] - s1 - v[k][i] * s2);
+        stc(dx + row * dim + (l16 + 16 * k) * 4, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NC; k++) {
+    const int c = (l16 + 16 * k) * 4;
+    *reinterpret_cast<float4*>(lnb_part + qw * 2 * dim + c) = make_float4(ag[k][0], ag[k][1], ag[k][2], ag[k][3]);
+    *reinterpret_cast<float4*>(lnb_part + qw * 2 * dim + dim + c) = make_float4(ab[k][0], ab[k][1], ab[k][2], ab[k][3]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * dim; c += 256) {
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; w++) t += lnb_part[w * 2 * dim + c];
+    atomicAdd(c < dim ? dgamma + c : dbeta + (c - dim), t);
+  }
+}
+
 template <typename T>
 __global__ void k_masked_gather_v(const T* __restrict__ src, const int64_t* __restrict__ idx, T* __restrict__ out, unsigned total, unsigned cpr) {
   constexpr int V = ChunkOf<T>::V;
@@ -702,6 +795,18 @@ int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const 
   }
 #undef LN_ARGS
   return check_launch("devo_upd_layernorm");
+}
+
+int devo_upd_layernorm_backward(const float* x, const float* add1, const float* add2, const float* gamma, const float* beta, const float* dout,
+                                float* dx, float* dgamma, float* dbeta, int64_t rows, int dim, float eps, int relu, devo_stream_t stream) {
+  DEVO_REQUIRE(rows >= 0 && dim == 384, "devo_upd_layernorm_backward: rows of 384 values (the update operator's; got %d)", dim);
+  if (rows == 0) return DEVO_OK;
+  DEVO_REQUIRE(x && gamma && beta && dout && dx && dgamma && dbeta, "devo_upd_layernorm_backward: null tensor");
+  DEVO_REQUIRE(upd_vec_ok(DEVO_F32, rows, dim, {x, add1, add2, gamma, beta, dout, dx}), "devo_upd_layernorm_backward: tensors must be 16-byte aligned");
+  const unsigned nwg = (unsigned)std::min<int64_t>((rows + 15) / 16, 512);
+  hipLaunchKernelGGL((k_layernorm_bwd_q<6>), dim3(nwg), dim3(256), (size_t)16 * 2 * dim * sizeof(float), (hipStream_t)stream, x, add1, add2, gamma, beta,
+                     dout, dx, dgamma, dbeta, rows, dim, eps, relu);
+  return check_launch("devo_upd_layernorm_backward");
 }
 
 int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64_t E, int dim, int dtype, devo_stream_t stream) {

@@ -137,6 +137,74 @@ class Linear(nn.Linear):
         return super().forward(x)
 
 
+class _LayerNormFn(torch.autograd.Function):
+    """y = LN(x + a + b) [ReLU'd] over 384-wide fp32 rows with the HIP kernels in both directions (devo_upd_layernorm /
+    devo_upd_layernorm_backward): one pass per direction, the sums in front of the norm and the ReLU behind it fused in, the
+    column sums for gamma / beta folded inside the workgroups.  ATen: two adds, the norm, a clamp; grad_input + two kernels for the
+    parameter gradients + the clamp's and the adds' adjoints."""
+
+    @staticmethod
+    def forward(ctx, x, a, b, weight, bias, eps, relu):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        a2 = a.reshape(-1, x.shape[-1]).contiguous() if a is not None else None
+        b2 = b.reshape(-1, x.shape[-1]).contiguous() if b is not None else None
+        out = torch.empty_like(x2)
+        L.check(L.lib().devo_upd_layernorm(L.ptr(x2), L.ptr(a2), L.ptr(b2), None, None, None, 0, None, L.ptr(weight), L.ptr(bias), L.ptr(out),
+                                           x2.shape[0], x2.shape[1], float(eps), int(relu), L.dtype_code(x2), L.stream()), "update.layernorm")
+        ctx.save_for_backward(x2, a2, b2, weight, bias)
+        ctx.eps, ctx.relu, ctx.shape = float(eps), bool(relu), x.shape
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, a2, b2, weight, bias = ctx.saved_tensors
+        g2 = g.reshape(x2.shape).to(torch.float32).contiguous()
+        dx = torch.empty_like(x2)
+        dwb = torch.zeros(2, x2.shape[1], dtype=torch.float32, device=x2.device)
+        L.check(L.lib().devo_upd_layernorm_backward(L.ptr(x2), L.ptr(a2), L.ptr(b2), L.ptr(weight), L.ptr(bias), L.ptr(g2), L.ptr(dx), L.ptr(dwb[0]),
+                                                    L.ptr(dwb[1]), x2.shape[0], x2.shape[1], ctx.eps, int(ctx.relu), L.stream()),
+                "update.layernorm_backward")
+        dxv = dx.view(ctx.shape)
+        return (dxv if ctx.needs_input_grad[0] else None, dxv if a2 is not None and ctx.needs_input_grad[1] else None,
+                dxv if b2 is not None and ctx.needs_input_grad[2] else None, dwb[0] if ctx.needs_input_grad[3] else None,
+                dwb[1] if ctx.needs_input_grad[4] else None, None, None)
+
+
+HIP_LAYERNORM = __import__("os").environ.get("DEVO_UPD_HIP_LAYERNORM", "1") != "0"      # 0: ATen's LayerNorm in the training path
+
+
+def _ln_train(mod, x, a=None, b=None, relu=False):
+    """mod(x + a + b) [ReLU'd] for the autograd path: the HIP pair when the rows are the operator's (fp32, 384 wide, on the GPU)"""
+    if (HIP_LAYERNORM and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 384 and mod.weight.dtype == torch.float32
+            and not torch.is_autocast_enabled() and all(t is None or (t.dtype == torch.float32 and t.shape == x.shape) for t in (a, b))):
+        return _LayerNormFn.apply(x, a, b, mod.weight, mod.bias, mod.eps, relu)
+    if a is not None:
+        x = x + a
+    if b is not None:
+        x = x + b
+    y = mod(x)
+    return torch.relu(y) if relu else y
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters, same state-dict keys) whose training path runs the HIP forward / backward pair"""
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return _ln_train(_PlainLN(self), x)
+        return super().forward(x)
+
+
+class _PlainLN:
+    """what _ln_train needs of a LayerNorm module (weight, bias, eps, the ATen call) without re-entering LayerNorm.forward"""
+
+    def __init__(self, mod):
+        self.weight, self.bias, self.eps, self._shape = mod.weight, mod.bias, mod.eps, mod.normalized_shape
+
+    def __call__(self, x):
+        return F.layer_norm(x, self._shape, self.weight, self.bias, self.eps)
+
+
 class GradientClip(nn.Module):                       # blocks.py:84-89
     def forward(self, x):
         return _GradClip.apply(x)
@@ -314,12 +382,12 @@ class Update(nn.Module):
         self.dim = dim
         self.c1 = nn.Sequential(Linear(dim, dim), nn.ReLU(inplace=True), Linear(dim, dim))
         self.c2 = nn.Sequential(Linear(dim, dim), nn.ReLU(inplace=True), Linear(dim, dim))
-        self.norm = nn.LayerNorm(dim, eps=1e-3)
+        self.norm = LayerNorm(dim, eps=1e-3)
         self.agg_kk = SoftAgg(dim)
         self.agg_ij = SoftAgg(dim)
-        self.gru = nn.Sequential(nn.LayerNorm(dim, eps=1e-3), GatedResidual(dim), nn.LayerNorm(dim, eps=1e-3), GatedResidual(dim))
+        self.gru = nn.Sequential(LayerNorm(dim, eps=1e-3), GatedResidual(dim), LayerNorm(dim, eps=1e-3), GatedResidual(dim))
         self.corr = nn.Sequential(Linear(2 * 49 * p * p, dim), nn.ReLU(inplace=True), Linear(dim, dim),
-                                  nn.LayerNorm(dim, eps=1e-3), nn.ReLU(inplace=True), Linear(dim, dim))
+                                  LayerNorm(dim, eps=1e-3), nn.ReLU(inplace=True), Linear(dim, dim))
         self.d = nn.Sequential(nn.ReLU(inplace=False), Linear(dim, 2), GradientClip())
         self.w = nn.Sequential(nn.ReLU(inplace=False), Linear(dim, 2), GradientClip(), nn.Sigmoid())
         self._graph_key, self._graph, self._graph_refs, self._wcat = None, None, None, {}
@@ -327,8 +395,10 @@ class Update(nn.Module):
     # ------------------------------------------------------------------------------------------ torch / autograd path
     def forward_torch(self, net, inp, corr, ii, jj, kk):
         """enet.py:80-99 as a torch composition over GPU tensors (differentiable)."""
-        net = net + inp + self.corr(corr)
-        net = self.norm(net)
+        # corr MLP (enet.py:59-66): its LayerNorm + ReLU as one kernel per direction; net = norm(net + inp + corr) with the sums inside
+        c = self.corr[2](self.corr[1](self.corr[0](corr)))
+        c = self.corr[5](_ln_train(_PlainLN(self.corr[3]), c, relu=True))
+        net = _ln_train(_PlainLN(self.norm), net, inp, c)
         if net.is_cuda and net.dtype in (torch.float32, torch.float16) and net.shape[0] == 1:
             ix, jx, gk, gp = self._tables(ii, jj, kk)               # neighbours + HIP group tables, cached per graph
         else:

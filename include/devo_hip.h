@@ -303,6 +303,14 @@ int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const 
                        const void* gate, int64_t ld_gate, const void* res, const void* gamma, const void* beta,
                        void* out, int64_t rows, int dim, float eps, int relu, int dtype, devo_stream_t stream);
 
+/* The adjoint of devo_upd_layernorm without the hy / gate terms (training; the reference differentiates nn.LayerNorm through
+ * torch.autograd, enet.py:44,52-56,62): fp32, dim == 384.  y = LN(x + add1 + add2) [ReLU'd], dout = dL/dy  ->  dx (the gradient of x and of
+ * either addend) and dgamma += sum_rows dout xhat, dbeta += sum_rows dout (ADDED into buffers the caller has zeroed or is accumulating
+ * in).  Mean and variance are recomputed from the inputs: the forward saves nothing but its inputs. */
+int devo_upd_layernorm_backward(const float* x, const float* add1, const float* add2, const float* gamma, const float* beta,
+                                const float* dout, float* dx, float* dgamma, float* dbeta, int64_t rows, int dim, float eps, int relu,
+                                devo_stream_t stream);
+
 /* out[e] = idx[e] >= 0 ? src[idx[e]] : 0   — `mask * net[:, ix]` of enet.py:87-91 (idx from devo_ba_neighbors). */
 int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64_t E, int dim, int dtype,
                            devo_stream_t stream);

@@ -334,3 +334,53 @@ def test_linear_layer_gradients_with_and_without_the_split_gemm():
             UA.SPLIT_GEMM = True
     for a, b in zip(*outs):
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * max(1.0, b.abs().max().item())), (a - b).abs().max()
+
+
+@pytest.mark.parametrize("rows,relu,adds", [(18000, False, 2), (4099, True, 0), (37, False, 1)])
+def test_layernorm_backward_kernel_matches_autograd(rows, relu, adds):
+    """devo_upd_layernorm_backward against torch.autograd through the fp64 composition (enet.py:44,52-56,62 differentiate nn.LayerNorm)"""
+    from devo_amd import update as UA
+    torch.manual_seed(rows)
+    mod = UA.LayerNorm(384, eps=1e-3).to(DEV)
+    with torch.no_grad():
+        mod.weight.copy_(torch.randn(384) * 0.5 + 1.0); mod.bias.copy_(torch.randn(384) * 0.3)
+    xs = [torch.randn(1, rows, 384, device=DEV, requires_grad=True) for _ in range(1 + adds)]
+    xs[0].data.mul_(torch.rand(1, rows, 1, device=DEV) * 5 + 0.01)
+    gout = torch.randn(1, rows, 384, device=DEV)
+    y = UA._ln_train(UA._PlainLN(mod), xs[0], *(xs[1:] + [None] * (2 - adds)), relu=relu)
+    y.backward(gout)
+    got = [y.detach()] + [t.grad.clone() for t in xs] + [mod.weight.grad.clone(), mod.bias.grad.clone()]
+    xd = [t.detach().double().requires_grad_(True) for t in xs]
+    wd, bd = mod.weight.detach().double().requires_grad_(True), mod.bias.detach().double().requires_grad_(True)
+    yd = torch.nn.functional.layer_norm(sum(xd), (384,), wd, bd, 1e-3)
+    if relu:
+        yd = yd.relu()
+    yd.backward(gout.double())
+    ref = [yd.detach()] + [t.grad for t in xd] + [wd.grad, bd.grad]
+    for name, a, b in zip(["y"] + ["dx"] * len(xs) + ["dgamma", "dbeta"], got, ref):
+        err = (a.double() - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+        assert err < (2e-5 if name in ("dgamma", "dbeta") else 5e-6), (name, err)
+
+
+def test_update_training_path_with_and_without_the_hip_layernorm():
+    from devo_amd import update as UA
+    torch.manual_seed(11)
+    n, M = 6, 30
+    ii, jj, kk = [t.to(DEV) for t in synth.full_graph(n, M)]
+    E = ii.numel()
+    up = UA.Update(3).to(DEV).train()
+    net = torch.randn(1, E, 384, device=DEV, requires_grad=True)
+    inp = torch.randn(1, E, 384, device=DEV) * 0.1
+    corr = torch.randn(1, E, 882, device=DEV, requires_grad=True)
+    outs = []
+    for flag in (True, False):
+        UA.HIP_LAYERNORM = flag
+        try:
+            up.zero_grad(); net.grad = None; corr.grad = None
+            out, (d, w, _) = up(net, inp, corr, None, ii, jj, kk)
+            (out.square().mean() + d.square().mean() + w.mean()).backward()
+            outs.append([out.detach().clone(), d.detach().clone(), net.grad.clone(), corr.grad.clone()] + [p.grad.clone() for p in up.parameters()])
+        finally:
+            UA.HIP_LAYERNORM = True
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1e-6) + 1e-7

@@ -76,6 +76,31 @@ def _linear_split(x2, w, b, transposed=False, relu=False, relu_from=None, residu
     return y
 
 
+_dw_ws = {}                 # device -> workspace of the weight-gradient kernel (grown on demand, reused: the stream serialises its users)
+SPLIT_DW = __import__("os").environ.get("DEVO_UPD_SPLIT_DW", "1") != "0"        # 0: the library's products for dW / db
+
+
+def _dw_ok(g2, x2):
+    return (SPLIT_GEMM and SPLIT_DW and g2.is_cuda and g2.dtype == x2.dtype == torch.float32 and g2.shape[1] % 128 == 0 and x2.shape[1] % 128 == 0
+            and x2.stride(1) == 1 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0 and g2.shape[0] >= 2048
+            and g2.shape[0] * max(g2.shape[1], x2.stride(0)) * 4 < (1 << 31))
+
+
+def _dw_split(g2, x2, with_bias):
+    """(dW [No, Ni], db [No] or None) = (g2^T x2, column sums of g2): fp32 in and out, exact hi + lo splits on the fp16 matrix cores"""
+    R, No, Ni = g2.shape[0], g2.shape[1], x2.shape[1]
+    need = L.lib().devo_upd_dw_workspace_bytes(R, No, Ni)
+    ws = _dw_ws.get(g2.device)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=g2.device)
+        _dw_ws[g2.device] = ws
+    dW = torch.empty(No, Ni, dtype=torch.float32, device=g2.device)
+    db = torch.empty(No, dtype=torch.float32, device=g2.device) if with_bias else None
+    L.check(L.lib().devo_upd_dw_split(L.ptr(g2), g2.stride(0), L.ptr(x2), x2.stride(0), R, No, Ni, L.ptr(ws), L.ptr(dW), Ni, L.ptr(db), L.stream()),
+            "update.dw_split")
+    return dW, db
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x Wᵀ + b over many rows (the Update operator sees one row per edge: 18 000 at BASELINE configuration 3).
     fp32 layers whose sizes fit (out % 192 == 0, in % 32 == 0: DEVO's 384-wide layers) run y and dX on the fp16 matrix cores with exact
@@ -107,16 +132,21 @@ class _LinearFn(torch.autograd.Function):
                     gx = _linear_split(g2.contiguous(), w, None, transposed=True).reshape(x.shape)
                 else:
                     gx = (g2 @ w.to(g2.dtype)).reshape(x.shape).to(x.dtype)
-            if ctx.needs_input_grad[1]:
-                x2 = x.reshape(-1, x.shape[-1]).to(g2.dtype)
-                rows, S = x2.shape[0], _LinearFn.CHUNKS
-                if rows % S == 0:
-                    gw = torch.bmm(g2.reshape(S, rows // S, -1).transpose(1, 2), x2.reshape(S, rows // S, -1)).sum(0)
-                else:
-                    gw = g2.t() @ x2
-                gw = gw.to(w.dtype)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = g2.sum(0).to(w.dtype)
+            need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+            x2 = x.reshape(-1, x.shape[-1])
+            if need_w and _dw_ok(g2, x2):                                   # dW and db in one pass on the fp16 matrix cores (csrc/linear_dw.hip)
+                gw, gb = _dw_split(g2 if g2.is_contiguous() else g2.contiguous(), x2, need_b)
+            else:
+                if need_w:
+                    x2 = x2.to(g2.dtype)
+                    rows, S = x2.shape[0], _LinearFn.CHUNKS
+                    if rows % S == 0:
+                        gw = torch.bmm(g2.reshape(S, rows // S, -1).transpose(1, 2), x2.reshape(S, rows // S, -1)).sum(0)
+                    else:
+                        gw = g2.t() @ x2
+                    gw = gw.to(w.dtype)
+                if need_b:
+                    gb = g2.sum(0).to(w.dtype)
         return gx, gw, gb
 
 

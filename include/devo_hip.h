@@ -366,6 +366,15 @@ int devo_upd_split_weight(const float* W, int64_t s_n, int64_t s_k, int N, int K
 int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, const float* residual, float* y, int64_t ldy,
                           int M, int N, int K, int relu_from, devo_stream_t stream);
 
+/* The third product of a Linear layer's training step (csrc/linear_dw.hip): dW[No, Ni] = dY[R, No]^T X[R, Ni] and db[No] = the column sums of
+ * dY (db may be NULL), fp32 in and out on the fp16 matrix cores like devo_upd_linear_split (exact hi + lo splits, per-column running
+ * power-of-two scales) — what torch.autograd computes for the reference's nn.Linear layers (enet.py:41-78, blocks.py:15-48) as
+ * `grad_output.t() @ input` and `grad_output.sum(0)`.  No and Ni multiples of 128; row pitches multiples of 4 elements, 16-byte aligned
+ * tensors; workspace = devo_upd_dw_workspace_bytes(R, No, Ni) bytes (the row slices' partial blocks: no atomics, reproducible). */
+size_t devo_upd_dw_workspace_bytes(int R, int No, int Ni);
+int devo_upd_dw_split(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int R, int No, int Ni, void* workspace, float* dW,
+                      int64_t ld_dw, float* db, devo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Event voxelisation — the step in front of the encoders.
  * ---------------------------------------------------------------------------------------------- */

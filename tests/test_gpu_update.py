@@ -384,3 +384,33 @@ def test_update_training_path_with_and_without_the_hip_layernorm():
             UA.HIP_LAYERNORM = True
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1e-6) + 1e-7
+
+
+@pytest.mark.parametrize("rows,n_out,n_in", [(18000, 384, 384), (4099, 768, 384), (2050, 128, 256), (6001, 384, 768)])
+def test_split_precision_weight_gradient_matches_float64(rows, n_out, n_in):
+    """csrc/linear_dw.hip: dW = dY^T X and db = column sums of dY, fp32 in and out on the fp16 matrix cores, against float64 — as close as
+    the library's fp32 product (every entry against the magnitudes of its own terms), with gradient-sized columns, columns whose scale
+    is raised late, zero columns and a row count that is not a multiple of the step"""
+    from devo_amd import update as UA
+    g = torch.Generator(device="cpu").manual_seed(rows + n_out)
+    dy = torch.randn(rows, n_out, generator=g) * torch.rand(1, n_out, generator=g)
+    dy[:, 1::7] *= 1e-9
+    dy[:, 2::11] *= 1e4
+    dy[rows // 2:, 3::13] *= 4096.0
+    dy[:rows // 2, 5::17] = 0
+    dy[:, 6::19] = 0
+    x = torch.randn(rows, n_in, generator=g) * (torch.rand(1, n_in, generator=g) * 3)
+    x[:, 1::5] *= 1e-5
+    x[rows // 3:, 2::9] *= 1e3
+    dy, x = dy.to(DEV), x.to(DEV)
+    assert UA._dw_ok(dy, x)
+    dW, db = UA._dw_split(dy, x, True)
+    ref = dy.double().t() @ x.double()
+    scale = dy.double().abs().t() @ x.double().abs() + 1e-300
+    e_lib = (((dy.t() @ x).double() - ref).abs() / scale).max().item()
+    e_own = ((dW.double() - ref).abs() / scale).max().item()
+    assert e_own <= max(2 * e_lib, 3e-7), (e_own, e_lib)
+    rb = dy.double().sum(0)
+    assert ((db.double() - rb).abs() / (dy.double().abs().sum(0) + 1e-300)).max().item() < 1e-6
+    dW2, _ = UA._dw_split(dy, x, False)
+    assert torch.equal(dW, dW2)                                         # no atomics: the same bits every time

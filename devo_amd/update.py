@@ -111,18 +111,32 @@ class _LinearFn(torch.autograd.Function):
     CHUNKS = 16
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
+    def forward(ctx, x, w, b, relu=False, residual=None):
+        """relu: max(., 0) behind the layer (the Sequential(Linear, ReLU, ...) pairs of enet.py / blocks.py: the GEMM's epilogue);
+        residual [rows, out]: added to the result (`net + c(t)`, enet.py:88-91: the epilogue again)"""
+        ctx.has_bias, ctx.relu, ctx.has_res = b is not None, bool(relu), residual is not None
         if x.dtype == w.dtype == torch.float32 and (b is None or b.dtype == torch.float32) and _split_ok(x, w.shape[0], w.shape[1]) \
-                and not torch.is_autocast_enabled():
-            return _linear_split(x, w, b.contiguous() if b is not None else None)
-        return torch.nn.functional.linear(x, w, b)
+                and not torch.is_autocast_enabled() and (residual is None or residual.dtype == torch.float32):
+            y = _linear_split(x, w, b.contiguous() if b is not None else None, relu=relu,
+                              residual=residual.contiguous() if residual is not None else None)
+        else:
+            y = torch.nn.functional.linear(x, w, b)
+            if relu:
+                y = torch.relu_(y)
+            if residual is not None:
+                y = y + residual.to(y.dtype)
+        if relu and residual is not None:
+            raise RuntimeError("_LinearFn: relu and residual together are not needed by the operator")
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         gx = gw = gb = None
+        gres = g if ctx.has_res and ctx.needs_input_grad[4] else None
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0)       # no gradient where the ReLU clipped
         g2 = g.reshape(-1, g.shape[-1])
         # under torch.autocast (devo.py:311 runs the update operator under it) the forward's output — and so g — is fp16 while x and
         # the parameters are fp32: multiply in g's dtype like the forward did, return every gradient in its input's dtype
@@ -147,7 +161,7 @@ class _LinearFn(torch.autograd.Function):
                     gw = gw.to(w.dtype)
                 if need_b:
                     gb = g2.sum(0).to(w.dtype)
-        return gx, gw, gb
+        return gx, gw, gb, None, gres
 
 
 def _linear(x2, w, b):
@@ -155,6 +169,22 @@ def _linear(x2, w, b):
     if torch.is_grad_enabled() and x2.is_cuda and x2.shape[0] >= 4096 and (x2.requires_grad or w.requires_grad):
         return _LinearFn.apply(x2, w, b)
     return torch.nn.functional.linear(x2, w, b)
+
+
+FUSE_EPILOGUE = __import__("os").environ.get("DEVO_UPD_FUSE_EPILOGUE", "1") != "0"     # 0: ReLU / residual sums as ATen kernels in the training path
+
+
+def _mlp2(seq, x, residual=None):
+    """Sequential(Linear, ReLU, Linear)(x) [+ residual] for the autograd path: the ReLU and the residual sum in the GEMMs' epilogues when
+    the rows are the operator's (>= 4096 fp32 rows on the GPU), the modules as they are otherwise"""
+    rows = x.numel() // x.shape[-1]
+    if (FUSE_EPILOGUE and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and rows >= 4096 and not torch.is_autocast_enabled()
+            and (x.requires_grad or seq[0].weight.requires_grad)):
+        h = _LinearFn.apply(x.reshape(rows, -1), seq[0].weight, seq[0].bias, True, None)
+        y = _LinearFn.apply(h, seq[2].weight, seq[2].bias, False, residual.reshape(rows, -1) if residual is not None else None)
+        return y.view(*x.shape[:-1], y.shape[-1])
+    y = seq[2](seq[1](seq[0](x)))
+    return y if residual is None else residual + y
 
 
 class Linear(nn.Linear):
@@ -183,7 +213,7 @@ class _LayerNormFn(torch.autograd.Function):
                                            x2.shape[0], x2.shape[1], float(eps), int(relu), L.dtype_code(x2), L.stream()), "update.layernorm")
         ctx.save_for_backward(x2, a2, b2, weight, bias)
         ctx.eps, ctx.relu, ctx.shape = float(eps), bool(relu), x.shape
-        return out.view(x.shape)
+        return out.view(x.shape) if out.shape != x.shape else out      # (not a view where the shape allows: an in-place ReLU may follow)
 
     @staticmethod
     def backward(ctx, g):
@@ -302,7 +332,7 @@ class GatedResidual(nn.Module):                      # blocks.py:15-29
 
     def forward(self, x):
         if _hip_ok(x):
-            gate, res = self.gate[0](x), self.res(x)
+            gate, res = self.gate[0](x), _mlp2(self.res, x)
             if gate.dtype == x.dtype and res.dtype == x.dtype:   # (under autocast the Linear outputs are fp16 next to an fp32 x: torch expression)
                 return _GatedResidualFn.apply(x, gate, res)
             return x + torch.sigmoid(gate) * res
@@ -426,7 +456,7 @@ class Update(nn.Module):
     def forward_torch(self, net, inp, corr, ii, jj, kk):
         """enet.py:80-99 as a torch composition over GPU tensors (differentiable)."""
         # corr MLP (enet.py:59-66): its LayerNorm + ReLU as one kernel per direction; net = norm(net + inp + corr) with the sums inside
-        c = self.corr[2](self.corr[1](self.corr[0](corr)))
+        c = _mlp2(self.corr, corr)                                         # (corr[0], ReLU, corr[2])
         c = self.corr[5](_ln_train(_PlainLN(self.corr[3]), c, relu=True))
         net = _ln_train(_PlainLN(self.norm), net, inp, c)
         if net.is_cuda and net.dtype in (torch.float32, torch.float16) and net.shape[0] == 1:
@@ -437,8 +467,8 @@ class Update(nn.Module):
         mask_jx = (jx >= 0).to(net.dtype).reshape(1, -1, 1)
         # gathers with index_select (backward = atomic index_add; advanced indexing's backward sorts 18 000 indices: 0.43 ms each)
         if _hip_ok(net) and net.shape[0] == 1:
-            net = net + self.c1(_MaskedGatherFn.apply(net[0], ix, jx)[None])       # one kernel per direction
-            net = net + self.c2(_MaskedGatherFn.apply(net[0], jx, ix)[None])
+            net = _mlp2(self.c1, _MaskedGatherFn.apply(net[0], ix, jx)[None], residual=net)     # net + c1(.): the sum in the last GEMM's epilogue
+            net = _mlp2(self.c2, _MaskedGatherFn.apply(net[0], jx, ix)[None], residual=net)
         else:
             net = net + self.c1(mask_ix * torch.index_select(net, 1, ix.clamp(min=0)))
             net = net + self.c2(mask_jx * torch.index_select(net, 1, jx.clamp(min=0)))

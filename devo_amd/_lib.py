@@ -14,7 +14,7 @@ DEVO_F32, DEVO_F16, DEVO_F64 = 0, 1, 2
 _DT = {torch.float32: DEVO_F32, torch.float16: DEVO_F16, torch.float64: DEVO_F64}
 
 _c_i64p = ctypes.POINTER(ctypes.c_int64)
-_vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+_vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
 # name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/devo_hip.h exactly
 _SIGNATURES = {
@@ -40,6 +40,8 @@ _SIGNATURES = {
     "devo_ba_forward_prepared_delta": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
     "devo_ba_solve_terms": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _sz, _vp, _vp, _vp, _vp],
     "devo_ba_solve_terms_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp],
+    "devo_ba_apply_step": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp],
+    "devo_ba_apply_step_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "devo_transform_vjp": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "devo_ba_edge_terms": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "devo_ba_edge_terms_backward": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

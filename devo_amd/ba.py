@@ -86,6 +86,9 @@ def _fused_step(poses, patches, terms, lmbda, ii, jj, kk, fixedp, n_opt, ep):
     dev, dt = patches.device, patches.dtype
     lm = lmbda.reshape(1).to(dev, torch.float32) if isinstance(lmbda, torch.Tensor) else torch.full((1,), float(lmbda), dtype=torch.float32, device=dev)
     dX, dZ = _FusedSolve.apply(terms, lm, ii, jj, kk, patches.shape[1], fixedp, n_opt, float(ep))
+    if poses.data.dtype == torch.float32 and poses.data.shape[0] == 1:
+        new_poses, patches = _ApplyStep.apply(poses.data, patches, dX, dZ, int(fixedp), int(n_opt))      # retraction + depth update: one kernel
+        return type(poses)(new_poses), patches
     disp = patches[:, :, 2] + dZ.view(1, -1, 1, 1)
     patches = torch.stack([patches[:, :, 0], patches[:, :, 1], disp.clamp(min=1e-3, max=10.0)], dim=2)
     if n_opt > 0:
@@ -93,6 +96,38 @@ def _fused_step(poses, patches, terms, lmbda, ii, jj, kk, fixedp, n_opt, ep):
         upd[:, fixedp:fixedp + n_opt] = dX.view(1, n_opt, 6)
         poses = poses.retr(upd)
     return poses, patches
+
+
+class _ApplyStep(torch.autograd.Function):
+    """devo/ba.py:172-182 — depth update + clamp [1e-3, 10] + torch.stack, `poses.retr` on the optimised window — as one HIP kernel per
+    direction (devo_ba_apply_step / _backward) instead of ~8 + ~12 ATen / SE3 launches."""
+
+    @staticmethod
+    def forward(ctx, poses, patches, dX, dZ, fixedp, n_opt):
+        from . import _lib as L
+        p7, q = poses.contiguous(), patches.contiguous()
+        dXc, dZc = dX.contiguous(), dZ.contiguous()
+        N, Np, P = p7.shape[1], q.shape[1], q.shape[-1]
+        po, qo = torch.empty_like(p7), torch.empty_like(q)
+        L.check(L.lib().devo_ba_apply_step(L.ptr(p7), L.ptr(q), L.ptr(dXc) if n_opt > 0 else None, L.ptr(dZc), N, Np, P, fixedp, n_opt, 1e-3, 10.0,
+                                           L.ptr(po), L.ptr(qo), L.stream()), "ba.apply_step")
+        ctx.save_for_backward(p7, q, dXc, dZc)
+        ctx.meta = (N, Np, P, fixedp, n_opt)
+        return po, qo
+
+    @staticmethod
+    def backward(ctx, g_poses, g_patches):
+        from . import _lib as L
+        p7, q, dXc, dZc = ctx.saved_tensors
+        N, Np, P, fixedp, n_opt = ctx.meta
+        gp = g_poses.float().contiguous() if g_poses is not None else None
+        gq = g_patches.float().contiguous() if g_patches is not None else None
+        o_p, o_q = torch.empty_like(p7), torch.empty_like(q)
+        o_dX, o_dZ = torch.zeros_like(dXc), torch.empty_like(dZc)
+        L.check(L.lib().devo_ba_apply_step_backward(L.ptr(p7), L.ptr(q), L.ptr(dXc) if n_opt > 0 else None, L.ptr(dZc), L.ptr(gp), L.ptr(gq), N, Np, P,
+                                                    fixedp, n_opt, 1e-3, 10.0, L.ptr(o_p), L.ptr(o_q), L.ptr(o_dX) if n_opt > 0 else None, L.ptr(o_dZ),
+                                                    L.stream()), "ba.apply_step_backward")
+        return o_p, o_q, o_dX, o_dZ, None, None
 
 
 def BA(poses, patches, intrinsics, targets, weights, lmbda, ii, jj, kk, bounds, ep=100.0, PRINT=False,

@@ -213,6 +213,16 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
 int devo_ba_solve_terms_backward(const float* terms, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Np, int t0, int N, void* ws,
                                  size_t ws_bytes, const float* g_dX, const float* g_dZ, float* g_terms, devo_stream_t stream);
 
+/* The update step behind the differentiable solve (devo/ba.py:172-182: `poses.retr(dX)` on the optimised window, inverse depth + dZ clamped to
+ * [dmin, dmax] over every patch's P x P pixels, torch.stack) as ONE kernel per direction instead of ~8 / ~12 ATen + SE3 launches; fp32.
+ * poses [N,7], patches [Np,3,P,P], dX [6 n_opt] (NULL when n_opt == 0), dZ [Np].  The backward takes the gradients of both outputs (either
+ * may be NULL = zero; pose gradients in lietorch's embedding, tangent in the first six of seven) and returns all four input gradients. */
+int devo_ba_apply_step(const float* poses, const float* patches, const float* dX, const float* dZ, int N, int Np, int P, int fixedp, int n_opt,
+                       float dmin, float dmax, float* poses_out, float* patches_out, devo_stream_t s);
+int devo_ba_apply_step_backward(const float* poses, const float* patches, const float* dX, const float* dZ, const float* g_poses_out,
+                                const float* g_patches_out, int N, int Np, int P, int fixedp, int n_opt, float dmin, float dmax,
+                                float* g_poses, float* g_patches, float* g_dX, float* g_dZ, devo_stream_t s);
+
 /* devo/ba.py:95-106 for the differentiable BA (training): residuals, gate and the 30 per-edge numbers of devo_ba_solve_terms from
  * the outputs of devo_transform(jacobian): coords [E,P,P,2], valid [E], Ji / Jj [E,2,6], Jz [E,2], target / weight [E,2], bounds (host:
  * x0, y0, x1, y1) -> terms [E,30] = r | w | Jz | -Ji | Jj and the gate [E] (kept for the adjoint). */

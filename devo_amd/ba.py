@@ -81,10 +81,18 @@ def _fused_path(patches, lmbda, n):
             and os.environ.get("DEVO_BA_TORCH", "0") != "1")
 
 
+_lm_cache = {}
+
+
 def _fused_step(poses, patches, terms, lmbda, ii, jj, kk, fixedp, n_opt, ep):
     """solve (HIP, differentiable) + depth update / clamp + pose retraction (devo/ba.py:159-182)"""
     dev, dt = patches.device, patches.dtype
-    lm = lmbda.reshape(1).to(dev, torch.float32) if isinstance(lmbda, torch.Tensor) else torch.full((1,), float(lmbda), dtype=torch.float32, device=dev)
+    if isinstance(lmbda, torch.Tensor):
+        lm = lmbda.reshape(1).to(dev, torch.float32)
+    else:                                                              # a python number: one device scalar per (device, value), not a fill per step
+        lm = _lm_cache.get((dev, float(lmbda)))
+        if lm is None:
+            lm = _lm_cache[(dev, float(lmbda))] = torch.full((1,), float(lmbda), dtype=torch.float32, device=dev)
     dX, dZ = _FusedSolve.apply(terms, lm, ii, jj, kk, patches.shape[1], fixedp, n_opt, float(ep))
     if poses.data.dtype == torch.float32 and poses.data.shape[0] == 1:
         new_poses, patches = _ApplyStep.apply(poses.data, patches, dX, dZ, int(fixedp), int(n_opt))      # retraction + depth update: one kernel

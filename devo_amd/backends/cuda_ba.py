@@ -197,8 +197,8 @@ def solve_terms(terms, lmbda, ii, jj, kk, n_patch_slots, t0, n_opt, ep, status=N
     terms = terms.float().contiguous()
     lmbda = lmbda.float().reshape(-1).contiguous()
     ws = workspace(E, int(n_patch_slots), int(n_opt), terms.device)
-    dX = torch.empty(6 * int(n_opt), dtype=torch.float32, device=terms.device)
-    dZ = torch.empty(int(n_patch_slots), dtype=torch.float32, device=terms.device)
+    out = torch.empty(6 * int(n_opt) + int(n_patch_slots), dtype=torch.float32, device=terms.device)     # dX | dZ: one fill clears both
+    dX, dZ = out[:6 * int(n_opt)], out[6 * int(n_opt):]
     rc = L.lib().devo_ba_solve_terms(L.ptr(terms), L.ptr(lmbda), L.ptr(ii), L.ptr(jj), L.ptr(kk), E, int(n_patch_slots), int(t0), int(n_opt),
                                      float(ep), L.ptr(ws), ws.numel(), L.ptr(dX), L.ptr(dZ), L.ptr(status), L.stream())
     L.check(rc, "cuda_ba.solve_terms")

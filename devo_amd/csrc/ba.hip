@@ -1926,9 +1926,11 @@ __global__ void k_ba_retract(float* __restrict__ poses, float* __restrict__ patc
 //   a = Q gdZ,  ybar = S'^-1 (gdX - E a)   (the SAME matrix: one more solve),  Sbar = -(ybar dX^T) (1 + 1e-4 on the diagonal),
 // everything else is per patch (k_bt_patch) and per edge (k_bt_edge) arithmetic on dX, ybar and the E columns.
 __global__ void k_bt_dz(const float* __restrict__ dX, const float* __restrict__ patch_rec, const float* __restrict__ patch_col,
-                        const int* __restrict__ kx, const BaMeta* __restrict__ meta, int N, float* __restrict__ dZ) {
+                        const int* __restrict__ kx, const BaMeta* __restrict__ meta, int N, float* __restrict__ dZ, float* __restrict__ dX_out) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = gid >> 6, nwaves = (blockDim.x * gridDim.x) >> 6;
   const int n_seg = meta->fail < 0 ? 0 : meta->n_seg, n6 = 6 * N;
+  if (dX_out && wave == 0)                                              // the caller's copy of the pose update (was a separate device copy)
+    for (int i = lane; i < n6; i += 64) dX_out[i] = dX[i];
   for (int s = wave; s < n_seg; s += nwaves) {
     float part = 0.0f;
     const float* pc = patch_col + (int64_t)s * n6;
@@ -2677,7 +2679,11 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
   if ((rc = bt_common("devo_ba_solve_terms", E, Np, N, ws_bytes, ws, &L))) return rc;
   hipStream_t st = (hipStream_t)stream;
   const size_t n6 = 6 * (size_t)N;
-  if (hipMemsetAsync(dZ_out, 0, sizeof(float) * (size_t)Np, st) != hipSuccess || (n6 && hipMemsetAsync(dX_out, 0, sizeof(float) * n6, st) != hipSuccess) ||
+  // (dX | dZ in one buffer — devo_amd.backends.cuda_ba.solve_terms — are cleared by one fill)
+  const bool joined = n6 > 0 && dZ_out == dX_out + n6;
+  if ((joined ? hipMemsetAsync(dX_out, 0, sizeof(float) * (n6 + (size_t)Np), st)
+              : hipMemsetAsync(dZ_out, 0, sizeof(float) * (size_t)Np, st)) != hipSuccess ||
+      (!joined && n6 && hipMemsetAsync(dX_out, 0, sizeof(float) * n6, st) != hipSuccess) ||
       (status_flag && hipMemsetAsync(status_flag, 0, sizeof(int), st) != hipSuccess)) { set_error("devo_ba_solve_terms: memset failed"); return DEVO_ERR_LAUNCH; }
   if (E == 0) return DEVO_OK;
   if ((rc = ba_prepare_impl(kk, E, Np, N, ws, ws_bytes, st))) return rc;
@@ -2715,9 +2721,9 @@ int devo_ba_solve_terms(const float* terms, const float* lmbda, const int64_t* i
     if (defer) ba_deferred_schur(st, patch_rec, patch_col, meta, N, L.max_seg, S, ep, (float*)(w + L.partials), L.partials_bytes);
     hipLaunchKernelGGL(ba_solve_fn(N), dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, (float*)(w + L.y), N, dX, meta, 0, status_flag, 0);
     if ((rc = check_launch("devo_ba_solve_terms(solve)"))) return rc;
-    if (hipMemcpyAsync(dX_out, dX, sizeof(float) * n6, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("devo_ba_solve_terms: copy failed"); return DEVO_ERR_LAUNCH; }
   }
-  hipLaunchKernelGGL(k_bt_dz, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, dX, patch_rec, patch_col, (int*)(w + L.kx), meta, N, dZ_out);
+  hipLaunchKernelGGL(k_bt_dz, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, dX, patch_rec, patch_col, (int*)(w + L.kx), meta, N, dZ_out,
+                     N > 0 ? dX_out : nullptr);
   return check_launch("devo_ba_solve_terms");
 }
 

@@ -43,6 +43,9 @@ typedef float mm_f4 __attribute__((ext_vector_type(4)));
 #ifndef DEVO_MM_RT16
 #define DEVO_MM_RT16 4          // fp16 storage: tiles in the register ring (3 in flight ahead of the products)
 #endif
+#ifndef DEVO_MM_ALIGN4
+#define DEVO_MM_ALIGN4 1        // fp16 storage: boxes start at a multiple of 4 positions and are a multiple of 4 wide: every quad of lanes reads inside ONE 128-byte line
+#endif
 #ifndef DEVO_MM_SYNC
 #define DEVO_MM_SYNC 0
 #endif
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
   //   box layout  [p][BOXS]        slot s of pixel p at p * BOXS + s (boxes of <= CAP positions; BOXS = CAP + 4 so that the 8 lanes
   //                                of a ds_write_b128 group, 8 pixels x the same 4 slots, fall into different banks)
   //   raw windows [p][D*D + 1]     tap (a, c) of pixel p: window-by-window tiles (larger boxes)
-  constexpr int CAP = RMAX <= 3 ? 128 : 256;
+  constexpr bool ALIGN4 = DEVO_MM_ALIGN4 != 0 && sizeof(T) == 2;     // measured (profiles/r04_lookup_experiments.txt, 9): fp16 64 -> 60 us, fp32 120 -> 124
+  constexpr int CAP = RMAX <= 3 ? (ALIGN4 ? 160 : 128) : 256;
   constexpr int BOXS = CAP + 4;
   constexpr int RWIN_FLOATS = (PP * (DMAX * DMAX + 1) + 3) / 4 * 4;
   constexpr int RW_FLOATS = RWIN_FLOATS > PP * BOXS ? RWIN_FLOATS : PP * BOXS;
@@ -217,6 +221,14 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
     const int ymin = __builtin_amdgcn_readlane(vymin, 15 + 16 * l), ymax = -__builtin_amdgcn_readlane(vymax, 15 + 16 * l);
     Geo g;
     g.xmin = xmin; g.ymin = ymin; g.bw = xmax - xmin + D;
+    if (ALIGN4) {
+      // The texture addresser retires one quad of lanes per cycle and 128-byte line it touches (tools/ubench/l2_fill.hip).  A quad is four
+      // consecutive box positions (16 or 32 bytes each): with the box's left edge at a multiple of 4 positions and its width a multiple
+      // of 4, no quad straddles a line or a box row, for ~30 % more positions.  It pays with 16-byte position records (fp16); with fp32's
+      // 32-byte records the tight box stays faster.  (Boxes that would no longer fit the result area keep their tight form.)
+      const int xa = xmin & ~3, bwa = (xmax + D - xa + 3) & ~3;
+      if ((long long)bwa * (ymax - ymin + D) <= (long long)CAP) { g.xmin = xa; g.bw = bwa; }
+    }
     const long long npos_ll = (long long)g.bw * (ymax - ymin + D);
     g.box_mode = npos_ll <= (long long)CAP;              // else: the 9 windows one after the other
     g.nslots = g.box_mode ? (int)npos_ll : PP * ntap;
@@ -353,8 +365,9 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
   // Tile counts a radius-3 box can have: 0 (the box misses the frame) or 4 .. 8 (64 .. 128 positions): for those the tile loops exist as
   // straight-line code per count (a uniform switch picks one): no dead fetch, no scalar bookkeeping, every wait counted by the compiler.
   constexpr bool EXACT = RFIX == 3 && RMAX == 3;
-  auto exact_count = [](int n) -> bool { return n == 0 || (n >= 4 && n <= 8); };
-  if (EXACT && all_box && exact_count(g0.ntile) && (NL == 1 || exact_count(g1.ntile))) {
+  auto exact_count = [](int n, int hi) -> bool { return n == 0 || (n >= 4 && n <= hi); };
+  constexpr int K0MAX = ALIGN4 ? 10 : 8;                   // (aligned boxes: up to 160 positions at level index 0)
+  if (EXACT && all_box && exact_count(g0.ntile, K0MAX) && (NL == 1 || exact_count(g1.ntile, 8))) {
     // Every wave-instruction of a load occupies the CU's texture addresser (16 quads, ~1.4 cycles each: a quad of four positions x 16 bytes
     // straddles a 128-byte line three times in eight) whether its lanes fetch or not — the addresser is ~97 % busy in this kernel
     // (TA_BUSY, profiles/README.md r04) — so nothing is fetched that a box does not have.
@@ -411,6 +424,8 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
       case 6: run_level(integral_constant<int, 0>{}, integral_constant<int, 6>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
       case 7: run_level(integral_constant<int, 0>{}, integral_constant<int, 7>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
       case 8: run_level(integral_constant<int, 0>{}, integral_constant<int, 8>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
+      case 9: if constexpr (ALIGN4) run_level(integral_constant<int, 0>{}, integral_constant<int, 9>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
+      case 10: if constexpr (ALIGN4) run_level(integral_constant<int, 0>{}, integral_constant<int, 10>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
       default: zero_area(); break;                           // no tiles: its box of zeros
     }
     if constexpr (NL == 2) {

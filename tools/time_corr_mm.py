@@ -15,9 +15,12 @@ ap.add_argument("--workload", default="cfg2")
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--layouts", default="blk8")
 ap.add_argument("--oracle-edges", type=int, default=300)
+ap.add_argument("--C", type=int, default=0, help="override the number of feature channels (experiment: fp16 at C = 256 has the load / product count of an fp32 pyramid stored as fp16 hi + lo planes)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = synth.workload(a.workload)
+if a.C:
+    cfg = dict(cfg, C=a.C)
 for dt in (torch.float16, torch.float32):
     for layout in a.layouts.split(","):
         d, cpu = build_inputs(cfg, 1234, dev, dt, layout)

@@ -336,6 +336,160 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- fp16 storage
+// The same workgroup shape for the operator's inference precision (devo.py:71-77 runs the update operator under autocast: fp16 rows and
+// weights, fp32 accumulation): no split, no scales — one MFMA per 16 x 16 x 32 block, K steps of 64 (the row slabs, the weight ring and
+// the request counts are the fp32 kernel's byte for byte).
+// W fp16 (element (n, k) at W[n * s_n + k * s_k]) -> [N / 96][ceil(K / 64)][6 tiles][2 halves of the step][64 lanes][16 B]: lane (n, kg)
+// of tile t, half j holds k = 64 s + 16 kg + 8 j .. + 7 of column 96 nb + 16 t + n (zeros past K).
+__global__ __launch_bounds__(256) void k_pack_weight_f16(const __half* __restrict__ W, int64_t s_n, int64_t s_k, int N, int K, ln_u4* __restrict__ out) {
+  const int nk = (K + 63) / 64;
+  const long long total = (long long)(N / LN_BN) * nk * LN_NT * 2 * 64;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    long long r = i >> 6;
+    const int j = (int)(r & 1); r >>= 1;
+    const int t = (int)(r % LN_NT); r /= LN_NT;
+    const int s = (int)(r % nk), nb = (int)(r / nk);
+    const int n = nb * LN_BN + 16 * t + (lane & 15), k0 = 64 * s + 16 * (lane >> 4) + 8 * j;
+    ln_h8 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = k0 + e < K ? (_Float16)__half2float(W[(int64_t)n * s_n + (int64_t)(k0 + e) * s_k]) : (_Float16)0.f;
+    out[i] = __builtin_bit_cast(ln_u4, v);
+  }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_f16(
+    const __half* __restrict__ x, int64_t ldx, const ln_u4* __restrict__ wimg, const __half* __restrict__ bias, const __half* residual,
+    __half* y, int64_t ldy, int M, int N, int K, int relu_from) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ln_lds[];
+  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, mi = lane & 15, kg = lane >> 4;
+  const int NB = N / LN_BN, nk = (K + 63) / 64;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int rb = (slot / NB) * 8 + xcd, nb = slot - (slot / NB) * NB;
+  if (rb * LN_BM >= M) return;
+  constexpr unsigned OFF_NONE = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(x), 0, (unsigned)(((int64_t)(M - 1) * ldx + K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<ln_u4*>(wimg), 0, (unsigned)((int64_t)N * nk * 128), 0x00020000);
+  const int row_w = rb * LN_BM + LN_MT * 16 * wv;
+  unsigned avoff[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int row = row_w + 8 * q + (lane >> 3);
+    avoff[q] = row < M ? (unsigned)(((int64_t)row * ldx) * 2 + 16 * ((lane & 7) ^ ((lane >> 3) & 7))) : OFF_NONE;
+  }
+  unsigned aslot[LN_MT][2];
+#pragma unroll
+  for (int mt = 0; mt < LN_MT; mt++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) aslot[mt][h] = (unsigned)((16 * mt + mi) * 128 + 16 * ((2 * kg + h) ^ (mi & 7)));
+  const unsigned lds0 = (unsigned)(uintptr_t)ln_lds;
+  unsigned char* slab = ln_lds + LN_RING + wv * LN_SLAB;
+  float* colf = reinterpret_cast<float*>(ln_lds + LN_RING);          // bias [96], in the first slab once the K loop is over
+  float col_bias = 0.f;
+  if (tid < LN_BN && bias) col_bias = __half2float(bias[nb * LN_BN + tid]);
+  auto stage = [&](int s) {
+    const int buf = s % LN_NSTAGE;
+    const unsigned voff = s < nk ? (unsigned)lane * 16u : OFF_NONE;
+#pragma unroll
+    for (int q = 0; q < LN_NT * 2 / 4; q++) {
+      const int piece = wv + 4 * q;
+      ln_dma16(voff, rsw, (unsigned)(((nb * nk + s) * (LN_NT * 2) + piece) * 1024), lds0 + (unsigned)(buf * LN_STAGE + piece * 1024));
+    }
+  };
+  auto load_a = [&](int s) {
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      ln_dma16(s < nk ? avoff[q] : OFF_NONE, rsx, (unsigned)s * 128u, lds0 + (unsigned)(LN_RING + wv * LN_SLAB + q * 1024));
+  };
+  ln_f4 acc[LN_MT][LN_NT];
+#pragma unroll
+  for (int mt = 0; mt < LN_MT; mt++)
+#pragma unroll
+    for (int t = 0; t < LN_NT; t++) acc[mt][t] = ln_f4{0.f, 0.f, 0.f, 0.f};
+  load_a(0);
+  stage(0);
+  stage(1);
+  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  __syncthreads();
+  for (int s = 0; s < nk; s++) {
+    ln_h8 a[LN_MT][2];
+#pragma unroll
+    for (int mt = 0; mt < LN_MT; mt++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) a[mt][h] = __builtin_bit_cast(ln_h8, *reinterpret_cast<const ln_u4*>(slab + aslot[mt][h]));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    load_a(s + 1);
+    stage(s + 2);
+    if (64 * s + 64 > K) {                                             // the last step of a K that is not a multiple of 64: what lies behind the row is not part of it
+#pragma unroll
+      for (int mt = 0; mt < LN_MT; mt++)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) a[mt][h][e] = 64 * s + 16 * kg + 8 * h + e < K ? a[mt][h][e] : (_Float16)0.f;
+    }
+    const ln_u4* sb = reinterpret_cast<const ln_u4*>(ln_lds + (s % LN_NSTAGE) * LN_STAGE) + lane;
+#pragma unroll
+    for (int tg = 0; tg < LN_NT; tg += 3) {
+      ln_h8 b0[3], b1[3];
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        b0[u] = __builtin_bit_cast(ln_h8, sb[((tg + u) * 2 + 0) * 64]);
+        b1[u] = __builtin_bit_cast(ln_h8, sb[((tg + u) * 2 + 1) * 64]);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; u++)
+#pragma unroll
+        for (int mt = 0; mt < LN_MT; mt++) acc[mt][tg + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][0], b0[u], acc[mt][tg + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 3; u++)
+#pragma unroll
+        for (int mt = 0; mt < LN_MT; mt++) acc[mt][tg + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][1], b1[u], acc[mt][tg + u], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __syncthreads();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid < LN_BN) colf[tid] = col_bias;
+  __syncthreads();
+  float* tile = reinterpret_cast<float*>(ln_lds) + wv * (16 * LN_EPI_LD);
+  const int col0 = nb * LN_BN;
+  constexpr int PPR = LN_BN / 4;
+#pragma unroll
+  for (int mt = 0; mt < LN_MT; mt++) {
+#pragma unroll
+    for (int t = 0; t < LN_NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) tile[(4 * kg + r) * LN_EPI_LD + 16 * t + mi] = acc[mt][t][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 16 * PPR / 64; it++) {
+      const int idx = it * 64 + lane, r = idx / PPR, c4 = idx - r * PPR;
+      ln_f4 v = *reinterpret_cast<const ln_f4*>(tile + r * LN_EPI_LD + 4 * c4) + *reinterpret_cast<const ln_f4*>(colf + 4 * c4);
+      if (col0 + 4 * c4 >= relu_from) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const int row = row_w + 16 * mt + r;
+      if (row < M) {
+        __half* dst = y + (int64_t)row * ldy + col0 + 4 * c4;
+        if (residual) {
+          const uint2 rr = *reinterpret_cast<const uint2*>(residual + (int64_t)row * ldy + col0 + 4 * c4);
+          const float2 r0 = __half22float2(*reinterpret_cast<const __half2*>(&rr.x)), r1 = __half22float2(*reinterpret_cast<const __half2*>(&rr.y));
+          v.x += r0.x; v.y += r0.y; v.z += r1.x; v.w += r1.y;
+        }
+        const __half2 o0 = __floats2half2_rn(v.x, v.y), o1 = __floats2half2_rn(v.z, v.w);
+        uint2 o;
+        o.x = *reinterpret_cast<const unsigned*>(&o0); o.y = *reinterpret_cast<const unsigned*>(&o1);
+        *reinterpret_cast<uint2*>(dst) = o;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace devo
 
 using namespace devo;
@@ -400,6 +554,34 @@ int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const
     fprintf(stderr, "[linear trace] the last workgroup starts %llu cycles after the first\n", last_start);
   }
   return check_launch("devo_upd_linear_split");
+}
+
+size_t devo_upd_pack_weight_f16_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || N % LN_BN != 0) return 0;
+  return (size_t)N * ((K + 63) / 64 * 64) * 2;
+}
+
+int devo_upd_pack_weight_f16(const void* W, int64_t s_n, int64_t s_k, int N, int K, void* wimage, devo_stream_t stream) {
+  DEVO_REQUIRE(N > 0 && K > 0 && N % LN_BN == 0, "devo_upd_pack_weight_f16: N must be a multiple of 96 (got %d x %d)", N, K);
+  DEVO_REQUIRE(W && wimage && (reinterpret_cast<uintptr_t>(wimage) & 15) == 0, "devo_upd_pack_weight_f16: null / unaligned tensor");
+  const long long total = (long long)(N / LN_BN) * ((K + 63) / 64) * LN_NT * 2 * 64;
+  hipLaunchKernelGGL(k_pack_weight_f16, dim3((unsigned)blocks_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const __half*)W, s_n, s_k, N, K, (ln_u4*)wimage);
+  return check_launch("devo_upd_pack_weight_f16");
+}
+
+int devo_upd_linear_f16(const void* x, int64_t ldx, const void* wimage, const void* bias, const void* residual, void* y, int64_t ldy, int M, int N,
+                        int K, int relu_from, devo_stream_t stream) {
+  DEVO_REQUIRE(M >= 0 && N > 0 && K > 0 && N % LN_BN == 0, "devo_upd_linear_f16: N must be a multiple of 96 (got %d x %d)", N, K);
+  if (M == 0) return DEVO_OK;
+  DEVO_REQUIRE(x && wimage && y && ldx >= K && ldy >= N && ldy % 4 == 0 && ldx % 2 == 0, "devo_upd_linear_f16: null tensor, rows shorter than the matrix, input rows that are not a multiple of 2 or output rows that are not a multiple of 4 elements apart");
+  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 7) == 0 && (reinterpret_cast<uintptr_t>(wimage) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(x) & 3) == 0 && (reinterpret_cast<uintptr_t>(bias) & 1) == 0, "devo_upd_linear_f16: y / residual must be 8-byte, the weight image 16-byte, x 4-byte aligned");
+  const int nk = (K + 63) / 64;
+  DEVO_REQUIRE(((int64_t)(M - 1) * ldx + K) * 2 < (1LL << 31) && (int64_t)N * nk * 128 < (1LL << 31), "devo_upd_linear_f16: operand beyond 2 GB");
+  const int RB = (M + LN_BM - 1) / LN_BM, NB = N / LN_BN;
+  hipLaunchKernelGGL(k_linear_f16, dim3((unsigned)(((RB + 7) / 8) * 8 * NB)), dim3(256), LN_LDS, (hipStream_t)stream, (const __half*)x, ldx, (const ln_u4*)wimage,
+                     (const __half*)bias, (const __half*)residual, (__half*)y, ldy, M, N, K, relu_from < 0 ? 0 : relu_from);
+  return check_launch("devo_upd_linear_f16");
 }
 
 }  // extern "C"

@@ -376,6 +376,17 @@ int devo_upd_split_weight(const float* W, int64_t s_n, int64_t s_k, int N, int K
 int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, const float* residual, float* y, int64_t ldy,
                           int M, int N, int K, int relu_from, devo_stream_t stream);
 
+/* The same workgroup shape for fp16 storage — the update operator's inference precision (devo.py:71-77: autocast): y[M, N] (fp16) =
+ * act(x[M, K] W^T + bias) [+ residual], fp32 accumulation, one MFMA per block (no split, no scales), K steps of 64.
+ *   devo_upd_pack_weight_f16: W fp16, element (n, k) at W[n * s_n + k * s_k] -> wimage (devo_upd_pack_weight_f16_bytes(N, K) = N ceil64(K) 2
+ *     bytes, 16-byte aligned): the B-operand image, once per version of the weight.
+ *   devo_upd_linear_f16: x fp16 rows ldx >= K elements apart (a multiple of 2, 4-byte aligned), y / residual fp16 rows ldy apart (a
+ *     multiple of 4, 8-byte aligned), bias fp16 [N] or NULL; relu_from / residual as devo_upd_linear_split.  N % 96 == 0, any K. */
+size_t devo_upd_pack_weight_f16_bytes(int N, int K);
+int devo_upd_pack_weight_f16(const void* W, int64_t s_n, int64_t s_k, int N, int K, void* wimage, devo_stream_t stream);
+int devo_upd_linear_f16(const void* x, int64_t ldx, const void* wimage, const void* bias, const void* residual, void* y, int64_t ldy, int M,
+                        int N, int K, int relu_from, devo_stream_t stream);
+
 /* The third product of a Linear layer's training step (csrc/linear_dw.hip): dW[No, Ni] = dY[R, No]^T X[R, Ni] and db[No] = the column sums of
  * dY (db may be NULL), fp32 in and out on the fp16 matrix cores like devo_upd_linear_split (exact hi + lo splits, per-column running
  * power-of-two scales) — what torch.autograd computes for the reference's nn.Linear layers (enet.py:41-78, blocks.py:15-48) as

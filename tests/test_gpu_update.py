@@ -414,3 +414,30 @@ def test_split_precision_weight_gradient_matches_float64(rows, n_out, n_in):
     assert ((db.double() - rb).abs() / (dy.double().abs().sum(0) + 1e-300)).max().item() < 1e-6
     dW2, _ = UA._dw_split(dy, x, False)
     assert torch.equal(dW, dW2)                                         # no atomics: the same bits every time
+
+
+@pytest.mark.parametrize("rows,n_out,k_in", [(21600, 384, 384), (4099, 768, 384), (3001, 384, 882), (1030, 96, 70)])
+def test_fp16_linear_kernel_matches_the_fp32_product_of_the_same_values(rows, n_out, k_in):
+    """csrc/linear.hip k_linear_f16: fp16 rows and weights, fp32 accumulation — against the fp32 product of the SAME fp16 values, to the
+    rounding of the fp16 result; bias, ReLU from a column on, residual in place, strided input rows"""
+    from devo_amd import update as UA
+    g = torch.Generator(device="cpu").manual_seed(rows + k_in)
+    x = (torch.randn(rows, k_in, generator=g) * 0.7).half().to(DEV)
+    w = (torch.randn(n_out, k_in, generator=g) / k_in ** 0.5).half().to(DEV)
+    b = torch.randn(n_out, generator=g).half().to(DEV)
+    assert UA._f16_ok(x, n_out, k_in)
+    ref = torch.nn.functional.linear(x.float(), w.float(), b.float())
+    y = UA._linear_f16(x, w, b)
+    assert (y.float() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-3
+    half = n_out // 2 // 4 * 4
+    r2 = ref.clone(); r2[:, half:].relu_()
+    assert (UA._linear_f16(x, w, b, relu_from=half).float() - r2).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-3
+    acc = torch.randn(rows, n_out, generator=g).half().to(DEV)
+    r3 = acc.float() + ref
+    got = UA._linear_f16(x, w, b, residual=acc, out=acc)
+    assert got.data_ptr() == acc.data_ptr() and (got.float() - r3).abs().max().item() <= 2e-3 * r3.abs().max().item() + 1e-3
+    wide = (torch.randn(rows, k_in + 66, generator=g) * 0.7).half().to(DEV)
+    xs = wide[:, 34:34 + k_in]
+    assert UA._f16_ok(xs, n_out, k_in)
+    r4 = torch.nn.functional.linear(xs.float(), w.float(), b.float())
+    assert (UA._linear_f16(xs, w, b).float() - r4).abs().max().item() <= 2e-3 * r4.abs().max().item() + 1e-3

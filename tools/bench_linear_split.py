@@ -36,3 +36,10 @@ for rows, n_out, k_in in [(18000, 384, 384), (18000, 768, 384), (18000, 384, 768
     fl = 2.0 * rows * n_out * k_in
     print(f"{rows} x {n_out} x {k_in}: library {t_lib:.1f} us ({fl / t_lib * 1e-6:.0f} TFLOP/s), split {t_own:.1f} us ({fl / t_own * 1e-6:.0f} TFLOP/s), "
           f"weight split {t_split:.1f} us; max |err| vs float64: library {e_lib:.2e}, split {e_own:.2e}")
+print("fp16 storage (k_linear_f16) against the library:")
+for rows, n_out, k_in in [(21600, 384, 384), (21600, 768, 384), (21600, 384, 882)]:
+    x = torch.randn(rows, k_in, device=dev).half(); w = (torch.randn(n_out, k_in, device=dev) / k_in ** 0.5).half(); b = torch.randn(n_out, device=dev).half()
+    t_lib = timed(lambda: torch.nn.functional.linear(x, w, b))
+    t_own = timed(lambda: U._linear_f16(x, w, b))
+    fl = 2.0 * rows * n_out * k_in
+    print(f"{rows} x {n_out} x {k_in}: library {t_lib:.1f} us ({fl / t_lib * 1e-6:.0f} TFLOP/s), own {t_own:.1f} us ({fl / t_own * 1e-6:.0f} TFLOP/s)")

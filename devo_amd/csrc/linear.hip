@@ -18,11 +18,12 @@
 // activations are split in registers on their way from memory.
 //
 // One workgroup = 128 rows x 96 columns (4 waves x 32 rows, 6 column tiles): per K step of 32 the 12 KB of weight pieces arrive by
-// LDS-DMA into a ring of three stages (two steps ahead, one barrier per step); each wave loads its own 2 x 16 x 32 activations straight
-// into the A-operand layout (32 contiguous bytes per lane, two steps ahead), scales + splits them and issues 36 MFMAs: every weight
-// fragment read from LDS feeds two row tiles (LDS 192 cycles / step against 576 cycles of MFMA per SIMD).  Workgroups of one row block
-// run on one XCD (their four column blocks re-read the rows from that XCD's L2).  The result tile goes through LDS so that rows leave as
-// whole 16-byte pieces, scaled back, with the bias (and ReLU) applied.
+// LDS-DMA into a ring of three stages (two steps ahead, one barrier per step); each wave DMAs its own 32 rows x 128 bytes of activations
+// into its LDS slab (eight lanes per row: full lines; one step ahead), reads them back in the A-operand layout (slots XOR-swizzled by
+// row: conflict-free), scales + splits them and issues 36 MFMAs: every weight fragment read from LDS feeds two row tiles.  Workgroups
+// of one row block run on one XCD (their column blocks re-read the rows from that XCD's L2).  The result tile goes through LDS so that
+// rows leave as whole 16-byte pieces, scaled back, with bias, ReLU (from a given column on) and an optional residual applied.
+// 53 760 B of LDS and 106 VGPRs: three workgroups per CU.  k_linear_f16 at the end of the file is the same shape for fp16 storage.
 #include "common.h"
 #include <hip/hip_fp16.h>
 #include <algorithm>
@@ -46,7 +47,7 @@ constexpr int LN_TILE_BYTES = 16 * LN_EPI_LD * 4;          // one row tile of a 
 constexpr int LN_RING = (LN_NSTAGE * LN_STAGE > 4 * LN_TILE_BYTES) ? LN_NSTAGE * LN_STAGE : 4 * LN_TILE_BYTES;
 constexpr int LN_SLAB = LN_MT * 16 * 128;         // one wave's activations of one K step: 32 rows x 128 bytes
 constexpr int LN_AUX = LN_RING + 4 * LN_SLAB;     // behind the ring and the four slabs:
-constexpr int LN_LDS = LN_AUX + 4 * LN_MT * 16 * 4;   // one float per row and wave (rescale factors, then the inverse row scales): 53 760 B = 42 granules of 1 280 B, three workgroups per CU   // + per wave: one float per row (rescale factors, then the inverse row scales); the block's column scales and biases
+constexpr int LN_LDS = LN_AUX + 4 * LN_MT * 16 * 4;   // one float per row and wave (rescale factors, then the inverse row scales): 53 760 B = 42 granules of 1 280 B, three workgroups per CU
 constexpr int LN_EXP_TARGET = 8;                  // a scale puts its reference magnitude into [2^8, 2^9)
 constexpr float LN_RAISE = 16384.f;               // ... and is raised when a scaled value exceeds 2^14 (fp16's largest: 65504)
 

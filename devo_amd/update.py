@@ -127,12 +127,12 @@ def _dw_split(g2, x2, with_bias):
 
 
 class _LinearFn(torch.autograd.Function):
-    """y = x Wᵀ + b over many rows (the Update operator sees one row per edge: 18 000 at BASELINE configuration 3).
-    fp32 layers whose sizes fit (out % 192 == 0, in % 32 == 0: DEVO's 384-wide layers) run y and dX on the fp16 matrix cores with exact
-    hi + lo splits of every fp32 value (csrc/linear.hip: 2^-22 relative per factor, fp32 accumulation; a fifth of the library GEMM's time).
-    The weight gradient dW = dYᵀ X is a [out x rows] x [rows x in] product with a tiny output: hipBLASLt runs it on a handful of tiles
-    (148 us for 384 x 384 over 18 000 rows); as a batched product over 16 row chunks + a sum it uses the whole chip (74 us;
-    tools/ubench_dw_gemm.py)."""
+    """y = act(x Wᵀ + b) [+ residual] over many rows (the Update operator sees one row per edge: 18 000 at BASELINE configuration 3), all
+    three products of its training step on the fp16 matrix cores with exact hi + lo splits of every fp32 value (2^-22 relative per factor,
+    fp32 accumulation, power-of-two scales against fp16's range): y and dX = dY W through csrc/linear.hip (out % 96 == 0; 29.9 us against
+    the library's 63 us for 18 000 x 384 x 384), dW = dYᵀ X and db through csrc/linear_dw.hip (out and in % 128 == 0; 50 against 98 us).
+    Layers that do not fit (the corr MLP's 882 inputs on the dX / dW side, the 2-wide heads) use the library: for dW as a batched product
+    over 16 row chunks + a sum (74 us where the direct product runs on a handful of tiles, 148 us; tools/ubench_dw_gemm.py)."""
     CHUNKS = 16
 
     @staticmethod

@@ -266,8 +266,12 @@ int devo_upd_dw_split(const float* dY, int64_t ld_dy, const float* X, int64_t ld
   const int S = dw_splits(R, No, Ni), T = (R + DW_ROWS - 1) / DW_ROWS, per = (T + S - 1) / S;
   float* part = static_cast<float*>(workspace);
   float* gpart = part + (size_t)S * No * Ni;
-  static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_split), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
-  DEVO_REQUIRE(lds_attr == hipSuccess, "devo_upd_dw_split: cannot reserve %d bytes of LDS", DW_LDS);
+  // (per call, like ba.hip: the attribute belongs to the current device's copy of the kernel)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_split), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("devo_upd_dw_split: cannot reserve %d bytes of LDS", DW_LDS);
+    return DEVO_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(k_dw_split, dim3((unsigned)((No / DW_BT) * (Ni / DW_BT)), (unsigned)S), dim3(256), DW_LDS, (hipStream_t)stream, dY, ld_dy, X, ld_x, R, No, Ni,
                      per, part, gpart);
   const int n = No * Ni / 4 + No;

@@ -37,7 +37,9 @@ SPLIT_GEMM = __import__("os").environ.get("DEVO_UPD_SPLIT_GEMM", "1") != "0"    
 def _split_weight(w, transposed):
     """The B-operand image of csrc/linear.hip for `x @ w.T` (transposed=False) or `g @ w` (True): every fp32 weight as an exact fp16
     hi + lo pair, one 1 KB piece per (K step, column tile).  Cached per version of the weight: a training step's 18 update iterations
-    split each layer twice (forward, dX), not 36 times; the optimiser's in-place step bumps the version."""
+    split each layer twice (forward, dX), not 36 times; the optimiser's in-place step bumps the version.  (The cache holds the weight, so its
+    storage cannot be handed to another tensor; an edit through `.data`, which has its own version counter, is NOT seen — like Update._cat's
+    concatenated weights: assign parameters with copy_ / load_state_dict / optimiser steps.)"""
     key = (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), transposed)
     hit = _wsplit_cache.pop(key, None)
     if hit is not None:

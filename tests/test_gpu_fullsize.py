@@ -237,3 +237,40 @@ def test_training_step_at_full_size(monkeypatch):
     for k in ga:
         num = float((ga[k] - gb[k]).norm()), float(gb[k].norm())
         assert num[0] <= 2e-2 * num[1] + 1e-7, (k, num)          # (fp32 sums in another order, amplified through two GN steps and the GRU)
+
+
+def test_training_step_at_full_size_with_and_without_the_operator_kernels():
+    """The same step (BASELINE configuration 3 at full size, 2 update iterations) with the Update operator's training path on this
+    repo's kernels — split-precision y / dX / dW + bias gradient, LayerNorm forward / backward, ReLU and residual sums in the GEMM
+    epilogues — and on the library / ATen composition the reference's autograd would run: loss and the gradient of every parameter group."""
+    from devo_amd import training as T
+    from devo_amd import update as UA
+    net, model, opt = T.build_trainer(DEV, 1)
+    batch = T.make_batch("cfg2_m80", 1234, DEV)
+    flags = ("SPLIT_GEMM", "SPLIT_DW", "HIP_LAYERNORM", "FUSE_EPILOGUE")
+    saved = {f: getattr(UA, f) for f in flags}
+
+    def run(own):
+        for f in flags:
+            setattr(UA, f, own)
+        torch.manual_seed(7)
+        for q in net.parameters():
+            q.grad = None
+        loss = model(batch, iters=2)
+        loss.backward()
+        groups = {}
+        for name, q in net.named_parameters():
+            key = name.split(".")[0] + "." + name.split(".")[1]
+            groups.setdefault(key, []).append(q.grad.detach().reshape(-1).double())
+        return float(loss.detach()), {k: torch.cat(v) for k, v in groups.items()}
+
+    try:
+        la, ga = run(True)
+        lb, gb = run(False)
+    finally:
+        for f in flags:
+            setattr(UA, f, saved[f])
+    assert torch.isfinite(torch.tensor(la)) and abs(la - lb) <= 1e-4 * abs(lb), (la, lb)
+    for k in ga:
+        num = float((ga[k] - gb[k]).norm()), float(gb[k].norm())
+        assert num[0] <= 2e-2 * num[1] + 1e-7, (k, num)

@@ -77,17 +77,18 @@ __device__ __forceinline__ float ln_pow2(int biased) { return __uint_as_float((u
 // [N / 96][K / 32][6 tiles][hi | lo][64 lanes][16 B]: lane (n, kg) of tile t holds k = 32 s + 8 kg .. + 7 of column 96 nb + 16 t + n,
 // scaled by the column's power of two; then N floats: the inverse column scales.
 // pass 1: one wave per column n: its scale exponent (as the inverse scale's slot holds it for pass 2) — the largest |W[n][.]|
-__global__ __launch_bounds__(256) void k_weight_scales(const float* __restrict__ W, int64_t s_n, int64_t s_k, int N, int K, float* __restrict__ inv) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void k_weight_scales(const float* __restrict__ W, int64_t s_n, int64_t s_k, int N, int n_real, int K, float* __restrict__ inv) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // N here: the column count rounded up to whole blocks of 96
   if (n >= N) return;
   float m = 0.f;
-  for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(W[(int64_t)n * s_n + (int64_t)k * s_k]));
+  if (n < n_real)
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(W[(int64_t)n * s_n + (int64_t)k * s_k]));
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if (lane == 0) inv[n] = ln_pow2(254 - ln_scale_exp(m));
 }
 
-__global__ __launch_bounds__(256) void k_split_weight(const float* __restrict__ W, int64_t s_n, int64_t s_k, int N, int K, ln_u4* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_split_weight(const float* __restrict__ W, int64_t s_n, int64_t s_k, int N, int n_real, int K, ln_u4* __restrict__ out) {
   const int nk = (K + 31) / 32;
   const long long total = (long long)(N / LN_BN) * nk * LN_NT * 64;
   const float* inv = reinterpret_cast<const float*>(out) + (size_t)N * nk * 32;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void k_split_weight(const float* __restrict__ 
     const float sc = ln_pow2(254 - (int)(__float_as_uint(inv[n]) >> 23));      // the reciprocal of a power of two
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = k0 + j < K ? W[(int64_t)n * s_n + (int64_t)(k0 + j) * s_k] * sc : 0.f;      // (K rounded up to whole steps: zeros)
+    for (int j = 0; j < 8; j++) v[j] = (k0 + j < K && n < n_real) ? W[(int64_t)n * s_n + (int64_t)(k0 + j) * s_k] * sc : 0.f;      // (K rounded up to whole steps, N to whole blocks: zeros)
     ln_h8 hi, lo;
     ln_split8(v, hi, lo);
     ln_u4* dst = out + ((r2 * LN_NT + t) * 2) * 64 + lane;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     float* y, int64_t ldy, int M, int N, int K, int relu_from, int dbg, unsigned long long* wgtrace) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char ln_lds[];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, mi = lane & 15, kg = lane >> 4;
-  const int NB = N / LN_BN, nk = (K + 31) / 32;
+  const int NB = (N + LN_BN - 1) / LN_BN, Np = NB * LN_BN, nk = (K + 31) / 32;
   // DEVO_LN_DBG: 1 no activation loads, 2 no stores, 4 no weight DMA, 8 no MFMAs, 16 cycle stamps of workgroup 0 into y[0][..]
   unsigned long long tst[32];
   int nst = 0;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (rb * LN_BM >= M) return;
   constexpr unsigned OFF_NONE = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (unsigned)(((int64_t)(M - 1) * ldx + K) * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<ln_u4*>(wsplit), 0, (unsigned)((int64_t)N * nk * 128), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<ln_u4*>(wsplit), 0, (unsigned)((int64_t)Np * nk * 128), 0x00020000);
   const int row_w = rb * LN_BM + LN_MT * 16 * wv;                     // this wave's first row
   // Activations: each wave brings its own 32 rows x 32 floats of a K step into its LDS slab by lane-linear DMA — eight lanes per row, a
   // quad of lanes inside one 128-byte line (16 addresser cycles per KB; 16 bytes per lane at a row stride cost 64) — and reads them back
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   float* colf = reinterpret_cast<float*>(ln_lds + LN_RING);          // [inverse scale | bias][96]: in the first slab once the K loop is over
   float col_inv = 0.f, col_bias = 0.f;                                // (fetched now, stored then)
   if (tid < LN_BN) {
-    col_inv = reinterpret_cast<const float*>(wsplit)[(size_t)N * nk * 32 + nb * LN_BN + tid];
-    col_bias = bias ? bias[nb * LN_BN + tid] : 0.f;
+    col_inv = reinterpret_cast<const float*>(wsplit)[(size_t)Np * nk * 32 + nb * LN_BN + tid];
+    col_bias = (bias && nb * LN_BN + tid < N) ? bias[nb * LN_BN + tid] : 0.f;
   }
   // requests past the last K step keep the pipeline's shape (the compiler's and the loop's own vmcnt bookkeeping see ONE path) but
   // carry the out-of-range offset: no memory access, zeros back
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   float* tile = reinterpret_cast<float*>(ln_lds) + wv * (16 * LN_EPI_LD);
   const int col0 = nb * LN_BN;
   constexpr int PPR = LN_BN / 4;                                       // 16-byte pieces per row
+  const bool vec_out = (ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
 #pragma unroll
   for (int mt = 0; mt < LN_MT; mt++) {
     if (kg == 0) rowf[16 * mt + mi] = ln_pow2(254 - esc[mt]);
@@ -313,10 +315,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       ln_f4 v = *reinterpret_cast<const ln_f4*>(tile + r * LN_EPI_LD + 4 * c4);
       v = v * rowf[16 * mt + r] * *reinterpret_cast<const ln_f4*>(colf + 4 * c4) + *reinterpret_cast<const ln_f4*>(colf + LN_BN + 4 * c4);
       if (col0 + 4 * c4 >= relu_from) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      const int row = row_w + 16 * mt + r;
-      if (row < M && !(dbg & 2)) {
-        if (residual) v += *reinterpret_cast<const ln_f4*>(residual + (int64_t)row * ldy + col0 + 4 * c4);      // (may be y itself: read, then written, by this lane)
-        *reinterpret_cast<ln_f4*>(y + (int64_t)row * ldy + col0 + 4 * c4) = v;
+      const int row = row_w + 16 * mt + r, col = col0 + 4 * c4;
+      if (row < M && col < N && !(dbg & 2)) {
+        float* dst = y + (int64_t)row * ldy + col;
+        const float* res = residual ? residual + (int64_t)row * ldy + col : nullptr;      // (may be y itself: read, then written, by this lane)
+        if (vec_out && col + 4 <= N) {
+          if (res) v += *reinterpret_cast<const ln_f4*>(res);
+          *reinterpret_cast<ln_f4*>(dst) = v;
+        } else {                                                       // rows that are not 16-byte aligned (the corr MLP's 882 columns), the last columns of such a row
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (col + e < N) dst[e] = v[e] + (res ? res[e] : 0.f);
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -498,31 +508,32 @@ using namespace devo;
 extern "C" {
 
 size_t devo_upd_split_weight_bytes(int N, int K) {
-  if (N <= 0 || K <= 0 || N % LN_BN != 0) return 0;
-  return (size_t)N * ((K + 31) / 32 * 32) * 4 + (size_t)N * 4;
+  if (N <= 0 || K <= 0) return 0;
+  const size_t Np = (size_t)(N + LN_BN - 1) / LN_BN * LN_BN;
+  return Np * ((K + 31) / 32 * 32) * 4 + Np * 4;
 }
 
 int devo_upd_split_weight(const float* W, int64_t s_n, int64_t s_k, int N, int K, void* wsplit, devo_stream_t stream) {
-  DEVO_REQUIRE(N > 0 && K > 0 && N % LN_BN == 0, "devo_upd_split_weight: N must be a multiple of 96 (got %d x %d)", N, K);
+  DEVO_REQUIRE(N > 0 && K > 0, "devo_upd_split_weight: bad sizes (%d x %d)", N, K);
   DEVO_REQUIRE(W && wsplit && (reinterpret_cast<uintptr_t>(wsplit) & 15) == 0, "devo_upd_split_weight: null / unaligned tensor");
-  const int nk = (K + 31) / 32;
-  const long long total = (long long)(N / LN_BN) * nk * LN_NT * 64;
-  hipLaunchKernelGGL(k_weight_scales, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, W, s_n, s_k, N, K, reinterpret_cast<float*>(wsplit) + (size_t)N * nk * 32);
-  hipLaunchKernelGGL(k_split_weight, dim3((unsigned)blocks_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, W, s_n, s_k, N, K, (ln_u4*)wsplit);
+  const int nk = (K + 31) / 32, Np = (N + LN_BN - 1) / LN_BN * LN_BN;
+  const long long total = (long long)(Np / LN_BN) * nk * LN_NT * 64;
+  hipLaunchKernelGGL(k_weight_scales, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, (hipStream_t)stream, W, s_n, s_k, Np, N, K, reinterpret_cast<float*>(wsplit) + (size_t)Np * nk * 32);
+  hipLaunchKernelGGL(k_split_weight, dim3((unsigned)blocks_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, W, s_n, s_k, Np, N, K, (ln_u4*)wsplit);
   return check_launch("devo_upd_split_weight");
 }
 
 int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, const float* residual, float* y, int64_t ldy,
                           int M, int N, int K, int relu_from, devo_stream_t stream) {
-  DEVO_REQUIRE(M >= 0 && N > 0 && K > 0 && N % LN_BN == 0, "devo_upd_linear_split: N must be a multiple of 96 (got %d x %d)", N, K);
+  DEVO_REQUIRE(M >= 0 && N > 0 && K > 0, "devo_upd_linear_split: bad sizes (%d x %d x %d)", M, N, K);
   if (M == 0) return DEVO_OK;
-  DEVO_REQUIRE(x && wsplit && y && ldx >= K && ldy >= N && ldy % 4 == 0, "devo_upd_linear_split: null tensor, rows shorter than the matrix, or output rows that are not multiples of 4 apart");
-  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wsplit) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0 &&
-                   (reinterpret_cast<uintptr_t>(x) & 3) == 0, "devo_upd_linear_split: y / wsplit / bias / residual must be 16-byte aligned");
-  const int nk = (K + 31) / 32;
-  DEVO_REQUIRE(((int64_t)(M - 1) * ldx + K) * 4 < (1LL << 31) && (int64_t)N * nk * 128 < (1LL << 31), "devo_upd_linear_split: operand beyond 2 GB");
+  DEVO_REQUIRE(x && wsplit && y && ldx >= K && ldy >= N, "devo_upd_linear_split: null tensor or rows shorter than the matrix");
+  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(wsplit)) & 15) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias) |
+                 reinterpret_cast<uintptr_t>(residual)) & 3) == 0, "devo_upd_linear_split: the weight image must be 16-byte aligned, everything else 4-byte");
+  const int nk = (K + 31) / 32, NB = (N + LN_BN - 1) / LN_BN;
+  DEVO_REQUIRE(((int64_t)(M - 1) * ldx + K) * 4 < (1LL << 31) && (int64_t)NB * LN_BN * nk * 128 < (1LL << 31), "devo_upd_linear_split: operand beyond 2 GB");
   static_assert(LN_LDS <= 64 * 1024, "the workgroup's LDS fits the default dynamic limit");
-  const int RB = (M + LN_BM - 1) / LN_BM, NB = N / LN_BN;
+  const int RB = (M + LN_BM - 1) / LN_BM;
   static const int dbg = getenv("DEVO_LN_DBG") ? atoi(getenv("DEVO_LN_DBG")) : 0;
   const unsigned nwg = (unsigned)(((RB + 7) / 8) * 8 * NB);
   unsigned long long* wgtrace = nullptr;

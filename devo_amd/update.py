@@ -56,7 +56,8 @@ def _split_weight(w, transposed):
         img = torch.empty(N * ((K + 63) // 64 * 64), dtype=torch.float16, device=w.device)
         L.check(L.lib().devo_upd_pack_weight_f16(L.ptr(w), s_n, s_k, N, K, L.ptr(img), L.stream()), "update.pack_weight_f16")
     else:
-        img = torch.empty(N * ((K + 31) // 32 * 32) + N, dtype=torch.float32, device=w.device)
+        Np = (N + 95) // 96 * 96                                        # (whole column blocks of 96: zero columns behind N)
+        img = torch.empty(Np * ((K + 31) // 32 * 32) + Np, dtype=torch.float32, device=w.device)
         L.check(L.lib().devo_upd_split_weight(L.ptr(w), s_n, s_k, N, K, L.ptr(img), L.stream()), "update.split_weight")
     _wsplit_cache[key] = (w, img)
     return img
@@ -64,7 +65,8 @@ def _split_weight(w, transposed):
 
 def _split_ok(x2, n_out, k_in):
     return (SPLIT_GEMM and x2.is_cuda and x2.dtype == torch.float32 and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) >= k_in
-            and n_out % 96 == 0 and x2.shape[0] >= 1024 and ((x2.shape[0] - 1) * x2.stride(0) + k_in) * 4 < (1 << 31))
+            and n_out >= 96 and k_in >= 32 and x2.shape[0] >= 1024 and      # (the 2-wide heads: the library's 10 us against 11-18)
+            ((x2.shape[0] - 1) * x2.stride(0) + k_in) * 4 < (1 << 31))
 
 
 F16_GEMM = __import__("os").environ.get("DEVO_UPD_F16_GEMM", "1") != "0"          # 0: the library's GEMMs for the fp16 operator

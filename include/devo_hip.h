@@ -363,12 +363,13 @@ int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void*
  * with every fp32 value split into fp16 hi + lo (2^-22 relative per factor, fp32 accumulation) — the 18 000 / 21 600-row Linear layers of
  * the update operator (enet.py:41-78, blocks.py:15-48) at half the fp32 library GEMM's time.  Both operands are scaled by exact powers
  * of two before the split (weight columns once per version; activation rows by a running scale inside the kernel), so gradient-sized
- * rows (1e-7) keep their 22 bits.  N % 96 == 0; any K (the corr MLP's first layer has K = 882).
+ * rows (1e-7) keep their 22 bits.  Any N and K (the corr MLP's first layer has K = 882, its dX 882 outputs, the heads 2): the kernel works
+ * on column blocks of 96 and K steps of 32, the weight image carries zeros behind N and K.
  *   devo_upd_split_weight: the weight, element (n, k) at W[n * s_n + k * s_k] (s_n = K, s_k = 1: a Linear's [N, K] weight for the forward;
  *     s_n = 1, s_k = N_in: the same storage read as its transpose for dX = dY W), -> wsplit (devo_upd_split_weight_bytes(N, K) =
  *     N ceil32(K) 4 + N 4 bytes — the operand image, then the inverse column scales —, 16-byte aligned): once per version of the weight.
- *   devo_upd_linear_split: x fp32, rows ldx >= K elements apart (any alignment of 4 bytes); y fp32, rows ldy apart (a multiple of 4,
- *     16-byte aligned); bias fp32 [N] or NULL; residual NULL or fp32 with y's row pitch, added after the activation (it may be y itself:
+ *   devo_upd_linear_split: x fp32, rows ldx >= K elements apart (any alignment of 4 bytes); y fp32, rows ldy >= N apart (16-byte pieces when
+ *     ldy is a multiple of 4 and y / residual are 16-byte aligned, single values otherwise); bias fp32 [N] or NULL; residual NULL or fp32 with y's row pitch, added after the activation (it may be y itself:
  *     x.add_(linear(t)) in one launch); columns >= relu_from get max(., 0) (0: all of them, >= N: none — a gate | res pair of a
  *     GatedResidual in one launch). */
 size_t devo_upd_split_weight_bytes(int N, int K);

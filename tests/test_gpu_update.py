@@ -256,7 +256,7 @@ def test_softagg_training_path_on_the_hip_kernels_matches_the_torch_composition(
 
 
 @pytest.mark.parametrize("rows,n_out,k_in,relu", [(18000, 384, 384, False), (4099, 768, 384, True), (1030, 192, 32, False), (5000, 384, 768, False),
-                                                   (3001, 384, 882, True), (2000, 96, 50, False)])
+                                                   (3001, 384, 882, True), (2000, 96, 50, False), (3001, 882, 384, False), (2500, 100, 384, False)])
 def test_split_precision_linear_matches_float64(rows, n_out, k_in, relu):
     """csrc/linear.hip: fp32 in, fp32 out, fp16 hi + lo operands on the matrix cores — as close to the float64 product as the library's
     fp32 GEMM is (the tolerance is the fp32 GEMM's own distance to float64, doubled), in the forward form and in the dX form"""
@@ -303,6 +303,10 @@ def test_split_precision_linear_matches_float64(rows, n_out, k_in, relu):
     ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
     ref[:, half:].relu_()
     assert ((UA._linear_split(x, w, b, relu_from=half).double() - ref).abs() / scale).max().item() < 1e-6
+    poison = torch.full((rows, n_out + 3), 7.0, device=DEV)            # nothing is written behind column N (rows that are not 16-byte aligned)
+    UA._linear_split(x, w, b, out=poison[:, :n_out])
+    assert torch.equal(poison[:, n_out:], torch.full((rows, 3), 7.0, device=DEV))
+    assert ((poison[:, :n_out].double() - torch.nn.functional.linear(x.double(), w.double(), b.double())).abs() / scale).max().item() < 1e-6
     # strided rows (a column slice of a wider tensor) and the per-version cache
     wide = torch.randn(rows, k_in + 67, generator=g).to(DEV)
     xs = wide[:, 33:33 + k_in]                                          # (rows at odd multiples of 4 bytes)

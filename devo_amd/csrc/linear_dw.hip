@@ -61,19 +61,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(1024))) unsigned char dw_lds[];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, kg = lane >> 4;
   const int wi = wv >> 1, wj = wv & 1;
-  const int nbj = Ni / DW_BT, blk = blockIdx.x, bi = blk / nbj, bj = blk - bi * nbj, sp = blockIdx.y;
+  constexpr unsigned OFF_NONE = 0x80000000u;
+  const int nbj = (Ni + DW_BT - 1) / DW_BT, Nip = nbj * DW_BT, blk = blockIdx.x, bi = blk / nbj, bj = blk - bi * nbj, sp = blockIdx.y;
   const int i0 = bi * DW_BT, j0 = bj * DW_BT;
   const int T = (R + DW_ROWS - 1) / DW_ROWS;
   const int s_begin = sp * steps_per_split, s_end = min(T, s_begin + steps_per_split);
   const unsigned lds0 = (unsigned)(uintptr_t)dw_lds;
-  constexpr unsigned OFF_NONE = 0x80000000u;
   // DMA: instruction t of a tile = rows 2 t, 2 t + 1 (32 lanes of 16 bytes each); this wave issues t = wv, wv + 4, wv + 8, wv + 12 of both operands
   unsigned gvoff[4], xvoff[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int row = 2 * (wv + 4 * q) + (lane >> 5);
-    gvoff[q] = (unsigned)(((int64_t)row * ldg + i0) * 4 + (lane & 31) * 16);
-    xvoff[q] = (unsigned)(((int64_t)row * ldx + j0) * 4 + (lane & 31) * 16);
+    // (a piece that starts behind the last column fetches nothing; one that straddles it brings values of the next row, zeroed at the operand read)
+    gvoff[q] = i0 + (lane & 31) * 4 < No ? (unsigned)(((int64_t)row * ldg + i0) * 4 + (lane & 31) * 16) : OFF_NONE;
+    xvoff[q] = j0 + (lane & 31) * 4 < Ni ? (unsigned)(((int64_t)row * ldx + j0) * 4 + (lane & 31) * 16) : OFF_NONE;
   }
   auto request = [&](int s, int buf) {                                 // rows 32 s .. of both operands -> stage buf
     const int r0 = s * DW_ROWS;
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int t = 0; t < 4; t++) { scA[t] = 0.f; scB[t] = 0.f; eA[t] = 0; eB[t] = 0; gsum[t] = 0.f; }
   const bool do_bias = bj == 0 && wj == 0;                            // wave-uniform
+  const bool edge_a = i0 + DW_BT > No, edge_b = j0 + DW_BT > Ni;
 
   request(s_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -124,6 +126,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int t = 0; t < 4; t++) {
       read8(buf, a_base, t, xa[t]);
       read8(buf, b_base, t, xb[t]);
+      if (edge_a && i0 + 64 * wi + 16 * t + li >= No) {                  // (wave-uniform guards: only the last block of a matrix whose width is not a multiple of 128)
+#pragma unroll
+        for (int j = 0; j < 8; j++) xa[t][j] = 0.f;
+      }
+      if (edge_b && j0 + 64 * wj + 16 * t + li >= Ni) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) xb[t][j] = 0.f;
+      }
     }
     float ma[4], mb[4];
 #pragma unroll
@@ -194,7 +204,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();                                                   // ... and every wave is done with this step's
   }
   // ---- partial block: D[4 kg + r][li] of tile (a, b) = dW[i0 + 64 wi + 16 a + 4 kg + r][j0 + 64 wj + 16 b + li], scaled back
-  float* pb = part + ((size_t)sp * No + i0 + 64 * wi) * Ni + j0 + 64 * wj;
+  const int Nop = (No + DW_BT - 1) / DW_BT * DW_BT;
+  float* pb = part + ((size_t)sp * Nop + i0 + 64 * wi) * Nip + j0 + 64 * wj;
 #pragma unroll
   for (int a = 0; a < 4; a++) {
     const float ia = dw_pow2(254 - eA[a]);
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int b = 0; b < 4; b++) {
       const float ib = dw_pow2(254 - eB[b]);
 #pragma unroll
-      for (int r = 0; r < 4; r++) pb[(size_t)(16 * a + 4 * kg + r) * Ni + 16 * b + li] = acc[a][b][r] * ir[r] * ib;
+      for (int r = 0; r < 4; r++) pb[(size_t)(16 * a + 4 * kg + r) * Nip + 16 * b + li] = acc[a][b][r] * ir[r] * ib;
     }
   }
   if (do_bias) {
@@ -214,31 +225,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       float g = gsum[t];
       g += __shfl_xor(g, 16);
       g += __shfl_xor(g, 32);
-      if (kg == 0) gpart[(size_t)sp * No + i0 + 64 * wi + 16 * t + li] = g;
+      if (kg == 0) gpart[(size_t)sp * Nop + i0 + 64 * wi + 16 * t + li] = g;
     }
   }
 }
 
-// dW[i][j] = sum over the splits of part[s][i][j]; db[i] likewise
-__global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ part, const float* __restrict__ gpart, int splits, int No, int Ni,
+// dW[i][j] = sum over the splits of part[s][i][j] (partials padded to whole blocks: [Nop][Nip]); db[i] likewise
+__global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ part, const float* __restrict__ gpart, int splits, int No, int Ni, int Nop, int Nip,
                                                    float* __restrict__ dW, int64_t ld_dw, float* __restrict__ db) {
-  const int n4 = No * Ni / 4;
+  const int q4 = Nip / 4, n4 = No * q4;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n4) {
+    const int row = i / q4, col = 4 * (i - row * q4);
+    if (col >= Ni) return;
     dw_f4 t = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; s++) t += *reinterpret_cast<const dw_f4*>(part + (size_t)s * No * Ni + 4 * (size_t)i);
-    const int row = (4 * i) / Ni, col = 4 * i - row * Ni;
-    *reinterpret_cast<dw_f4*>(dW + (size_t)row * ld_dw + col) = t;
+    for (int s = 0; s < splits; s++) t += *reinterpret_cast<const dw_f4*>(part + ((size_t)s * Nop + row) * Nip + col);
+    float* dst = dW + (size_t)row * ld_dw + col;
+    if (col + 4 <= Ni && (ld_dw & 3) == 0 && (reinterpret_cast<uintptr_t>(dW) & 15) == 0) *reinterpret_cast<dw_f4*>(dst) = t;
+    else
+      for (int e = 0; e < 4; e++) if (col + e < Ni) dst[e] = t[e];
   } else if (db && i - n4 < No) {
     float t = 0.f;
-    for (int s = 0; s < splits; s++) t += gpart[(size_t)s * No + (i - n4)];
+    for (int s = 0; s < splits; s++) t += gpart[(size_t)s * Nop + (i - n4)];
     db[i - n4] = t;
   }
 }
 
 static int dw_splits(int R, int No, int Ni) {
   static const int env = getenv("DEVO_DW_SPLITS") ? atoi(getenv("DEVO_DW_SPLITS")) : 0;
-  const int T = (R + DW_ROWS - 1) / DW_ROWS, blocks = (No / DW_BT) * (Ni / DW_BT);
+  const int T = (R + DW_ROWS - 1) / DW_ROWS, blocks = ((No + DW_BT - 1) / DW_BT) * ((Ni + DW_BT - 1) / DW_BT);
   int s = env > 0 ? env : (256 + blocks - 1) / blocks;               // about one workgroup per CU ...
   s = std::min(s, std::max(1, T / 8));                                // ... of at least 8 steps
   return std::max(1, s);
@@ -251,31 +266,32 @@ using namespace devo;
 extern "C" {
 
 size_t devo_upd_dw_workspace_bytes(int R, int No, int Ni) {
-  if (R <= 0 || No <= 0 || Ni <= 0 || No % DW_BT != 0 || Ni % DW_BT != 0) return 0;
-  return (size_t)dw_splits(R, No, Ni) * ((size_t)No * Ni + No) * 4;
+  if (R <= 0 || No <= 0 || Ni <= 0) return 0;
+  const size_t Nop = (size_t)(No + DW_BT - 1) / DW_BT * DW_BT, Nip = (size_t)(Ni + DW_BT - 1) / DW_BT * DW_BT;
+  return (size_t)dw_splits(R, No, Ni) * (Nop * Nip + Nop) * 4;
 }
 
 int devo_upd_dw_split(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int R, int No, int Ni, void* workspace, float* dW,
                       int64_t ld_dw, float* db, devo_stream_t stream) {
-  DEVO_REQUIRE(R > 0 && No > 0 && Ni > 0 && No % DW_BT == 0 && Ni % DW_BT == 0, "devo_upd_dw_split: No and Ni must be multiples of 128 (got %d x %d)", No, Ni);
-  DEVO_REQUIRE(dY && X && workspace && dW && ld_dy >= No && ld_x >= Ni && ld_dw >= Ni && ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dw % 4 == 0,
-               "devo_upd_dw_split: null tensor or row pitches that are not multiples of 4");
-  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(dW)) & 15) == 0,
-               "devo_upd_dw_split: operands must be 16-byte aligned");
+  DEVO_REQUIRE(R > 0 && No > 0 && Ni > 0, "devo_upd_dw_split: bad sizes (%d rows, %d x %d)", R, No, Ni);
+  DEVO_REQUIRE(dY && X && workspace && dW && ld_dy >= No && ld_x >= Ni && ld_dw >= Ni, "devo_upd_dw_split: null tensor or rows shorter than the matrix");
+  DEVO_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dW)) & 3) == 0,
+               "devo_upd_dw_split: the workspace must be 16-byte aligned");
   DEVO_REQUIRE((int64_t)R * ld_dy * 4 < (1LL << 31) && (int64_t)R * ld_x * 4 < (1LL << 31), "devo_upd_dw_split: operand beyond 2 GB");
   const int S = dw_splits(R, No, Ni), T = (R + DW_ROWS - 1) / DW_ROWS, per = (T + S - 1) / S;
+  const int nbi = (No + DW_BT - 1) / DW_BT, nbj = (Ni + DW_BT - 1) / DW_BT, Nop = nbi * DW_BT, Nip = nbj * DW_BT;
   float* part = static_cast<float*>(workspace);
-  float* gpart = part + (size_t)S * No * Ni;
+  float* gpart = part + (size_t)S * Nop * Nip;
   // (per call, like ba.hip: the attribute belongs to the current device's copy of the kernel)
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_split), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS) != hipSuccess) {
     (void)hipGetLastError();
     set_error("devo_upd_dw_split: cannot reserve %d bytes of LDS", DW_LDS);
     return DEVO_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(k_dw_split, dim3((unsigned)((No / DW_BT) * (Ni / DW_BT)), (unsigned)S), dim3(256), DW_LDS, (hipStream_t)stream, dY, ld_dy, X, ld_x, R, No, Ni,
+  hipLaunchKernelGGL(k_dw_split, dim3((unsigned)(nbi * nbj), (unsigned)S), dim3(256), DW_LDS, (hipStream_t)stream, dY, ld_dy, X, ld_x, R, No, Ni,
                      per, part, gpart);
-  const int n = No * Ni / 4 + No;
-  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, gpart, S, No, Ni, dW, ld_dw, db);
+  const int n = No * (Nip / 4) + No;
+  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, gpart, S, No, Ni, Nop, Nip, dW, ld_dw, db);
   return check_launch("devo_upd_dw_split");
 }
 

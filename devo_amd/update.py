@@ -110,8 +110,8 @@ SPLIT_DW = __import__("os").environ.get("DEVO_UPD_SPLIT_DW", "1") != "0"        
 
 
 def _dw_ok(g2, x2):
-    return (SPLIT_GEMM and SPLIT_DW and g2.is_cuda and g2.dtype == x2.dtype == torch.float32 and g2.shape[1] % 128 == 0 and x2.shape[1] % 128 == 0
-            and x2.stride(1) == 1 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0 and g2.shape[0] >= 2048
+    return (SPLIT_GEMM and SPLIT_DW and g2.is_cuda and g2.dtype == x2.dtype == torch.float32 and g2.shape[1] >= 96 and x2.shape[1] >= 96
+            and x2.stride(1) == 1 and x2.stride(0) >= x2.shape[1] and g2.shape[0] >= 2048
             and g2.shape[0] * max(g2.shape[1], x2.stride(0)) * 4 < (1 << 31))
 
 

@@ -391,8 +391,9 @@ int devo_upd_linear_f16(const void* x, int64_t ldx, const void* wimage, const vo
 /* The third product of a Linear layer's training step (csrc/linear_dw.hip): dW[No, Ni] = dY[R, No]^T X[R, Ni] and db[No] = the column sums of
  * dY (db may be NULL), fp32 in and out on the fp16 matrix cores like devo_upd_linear_split (exact hi + lo splits, per-column running
  * power-of-two scales) — what torch.autograd computes for the reference's nn.Linear layers (enet.py:41-78, blocks.py:15-48) as
- * `grad_output.t() @ input` and `grad_output.sum(0)`.  No and Ni multiples of 128; row pitches multiples of 4 elements, 16-byte aligned
- * tensors; workspace = devo_upd_dw_workspace_bytes(R, No, Ni) bytes (the row slices' partial blocks: no atomics, reproducible). */
+ * `grad_output.t() @ input` and `grad_output.sum(0)`.  Any No, Ni and row pitches (the kernel works on 128 x 128 blocks: the corr MLP's 882
+ * inputs are 7 block columns, the last one masked); tensors 4-byte aligned, the workspace (devo_upd_dw_workspace_bytes(R, No, Ni) bytes:
+ * the row slices' partial blocks — no atomics, reproducible) 16-byte aligned. */
 size_t devo_upd_dw_workspace_bytes(int R, int No, int Ni);
 int devo_upd_dw_split(const float* dY, int64_t ld_dy, const float* X, int64_t ld_x, int R, int No, int Ni, void* workspace, float* dW,
                       int64_t ld_dw, float* db, devo_stream_t stream);

@@ -3,6 +3,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import devo_amd._lib as _L
+if os.environ.get("DEVO_LIB"): _L.LIB_PATH = os.path.abspath(os.environ["DEVO_LIB"])      # a variant build (tools/build_variant.sh)
 from devo_amd import update as U
 dev = torch.device("cuda", 0)
 def timed(fn, reps=50):

@@ -54,10 +54,43 @@ def corr(fmap1, fmap2, coords, ii, jj, radius=1, dropout=1):
     return CorrLayer.apply(fmap1, fmap2, coords, ii, jj, radius, dropout)
 
 
-def corr_pyramid(fmap1, pyramid, coords, ii, jj, radius=3, scales=(1, 4)):
-    """Inference-only fused form of
-        torch.stack([corr(fmap1, pyramid[l], coords / scales[l], ii, jj, radius) for l], -1).view(1, E, -1)
-    (devo/devo.py:215-217): one kernel per level writing straight into the stacked layout."""
+class CorrPyramidLayer(torch.autograd.Function):
+    """torch.stack([corr(fmap1, pyramid[l], coords / scales[l], ii, jj, radius, dropout) for l], -1).view(1, E, -1) (enet.py:203-216) with
+    the forward as ONE fused launch writing the stacked layout (no per-level tensors, no scaled coordinates, no stack copy) and the
+    backward as the per-level kernels on the strided halves of the incoming gradient; every level draws its own edge subset, as the
+    reference's two CorrLayer.backward calls do (correlation.py:20-25)."""
+
+    @staticmethod
+    def forward(ctx, fmap1, coords, ii, jj, radius, dropout, scales, *pyramid):
+        ctx.save_for_backward(fmap1, coords, ii, jj, *pyramid)
+        ctx.radius, ctx.dropout, ctx.scales = radius, dropout, tuple(scales)
+        return cuda_corr.forward_pyramid(fmap1, list(pyramid), coords, ii, jj, radius, scales)
+
+    @staticmethod
+    def backward(ctx, grad):
+        fmap1, coords, ii, jj, *pyramid = ctx.saved_tensors
+        nl, E = len(pyramid), coords.shape[1]
+        D = 2 * ctx.radius + 1
+        g = grad.view(grad.shape[0], E, D, D, coords.shape[3], coords.shape[4], nl)
+        d1, d2s = None, []
+        for l in range(nl):
+            c_l, g_l, i_l, j_l = coords / ctx.scales[l], g[..., l], ii, jj
+            if ctx.dropout < 1:
+                keep = torch.rand(len(ii), device=ii.device) < ctx.dropout
+                c_l, g_l, i_l, j_l = c_l[:, keep], g_l[:, keep], ii[keep], jj[keep]
+            a, b = cuda_corr.backward(fmap1, pyramid[l], c_l, i_l, j_l, g_l, ctx.radius)
+            d1 = a if d1 is None else d1 + a
+            d2s.append(b)
+        return (d1, None, None, None, None, None, None, *d2s)
+
+
+def corr_pyramid(fmap1, pyramid, coords, ii, jj, radius=3, scales=(1, 4), dropout=1):
+    """Fused form of
+        torch.stack([corr(fmap1, pyramid[l], coords / scales[l], ii, jj, radius, dropout) for l], -1).view(1, E, -1)
+    (devo/devo.py:215-217, enet.py:203-216): the levels written straight into the stacked layout by one launch; differentiable with
+    respect to fmap1 and the pyramid levels (CorrPyramidLayer) when gradients are enabled."""
+    if torch.is_grad_enabled() and (fmap1.requires_grad or any(f.requires_grad for f in pyramid)):
+        return CorrPyramidLayer.apply(fmap1, coords, ii, jj, radius, dropout, tuple(scales), *pyramid)
     return cuda_corr.forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales)
 
 

@@ -18,6 +18,7 @@ from . import synth
 
 N_FNET, N_INET, N_SCORER = 184_576, 201_216, 6_465          # parameter counts of the modules this path does not build
 N_TOTAL = 3_397_061
+FUSED_LOOKUP = __import__("os").environ.get("DEVO_TRAIN_FUSED_LOOKUP", "1") != "0"     # 0: two altcorr.corr calls + torch.stack, as enet.py:203-216 writes it
 
 
 class TrainNet(nn.Module):
@@ -73,8 +74,11 @@ class TrainNet(nn.Module):
             patches = patches.detach()
             coords = pops.transform(Gs, patches, b["intr"], ii, jj, kk)
             coords1 = coords.permute(0, 1, 4, 2, 3).contiguous()
-            corr = torch.stack([altcorr.corr(gmap, pyramid[0], coords1 / 1, kk, jj, b["R"], corr_dropout),
-                                altcorr.corr(gmap, pyramid[1], coords1 / 4, kk, jj, b["R"], corr_dropout)], -1).view(1, E, -1)
+            if FUSED_LOOKUP:                                           # enet.py:203-216 as one launch (altcorr.CorrPyramidLayer)
+                corr = altcorr.corr_pyramid(gmap, pyramid, coords1, kk, jj, b["R"], (1, 4), dropout=corr_dropout)
+            else:
+                corr = torch.stack([altcorr.corr(gmap, pyramid[0], coords1 / 1, kk, jj, b["R"], corr_dropout),
+                                    altcorr.corr(gmap, pyramid[1], coords1 / 4, kk, jj, b["R"], corr_dropout)], -1).view(1, E, -1)
             net, (delta, weight, _) = self.update(net, inp, corr, None, ii, jj, kk)
             target = coords[..., self.P // 2, self.P // 2, :] + delta
             for _ in range(2):

@@ -613,3 +613,30 @@ def test_matrix_core_kernel_other_channel_counts(C, dtype):
     fused = cuda_corr.forward_pyramid(f1.to(DEV, dtype), pyr, coords.to(DEV), ii.to(DEV), jj.to(DEV), R, (1, 4))
     ref = torch.stack([ref0, A.corr_forward(q(f1), q(f2b), coords / 4, ii, jj, R)], -1)
     assert_rel(fused.float(), ref.view(1, len(ii), -1), tol, f"fused C={C}")
+
+
+def test_differentiable_fused_pyramid_lookup_matches_the_two_level_composition():
+    """altcorr.corr_pyramid with gradients (CorrPyramidLayer: one fused forward launch, per-level backward kernels on the strided halves
+    of the gradient) against torch.stack([corr(level 0), corr(level 1 at coords / 4)], -1) — values and both feature gradients"""
+    from devo_amd import altcorr
+    torch.manual_seed(5)
+    n, C, H, W, E, R = 4, 128, 48, 64, 1500, 3
+    f0 = torch.randn(1, n, C, H, W, device=DEV) * 0.3
+    pyr = [altcorr.channels_last(f0).requires_grad_(True), altcorr.channels_last(torch.nn.functional.avg_pool2d(f0[0], 4, 4)[None]).requires_grad_(True)]
+    g1 = (torch.randn(1, 60, C, 3, 3, device=DEV) * 0.3).requires_grad_(True)
+    ii = torch.randint(0, 60, (E,), device=DEV)
+    jj = torch.randint(0, n, (E,), device=DEV)
+    coords = torch.stack([torch.rand(1, E, 3, 3, device=DEV) * (W + 8) - 4, torch.rand(1, E, 3, 3, device=DEV) * (H + 8) - 4], 2)
+    gout = torch.randn(1, E, 2 * 49 * 9, device=DEV)
+    outs = []
+    for fused in (True, False):
+        for t in pyr + [g1]:
+            t.grad = None
+        if fused:
+            y = altcorr.corr_pyramid(g1, pyr, coords, ii, jj, R, (1, 4))
+        else:
+            y = torch.stack([altcorr.corr(g1, pyr[0], coords / 1, ii, jj, R), altcorr.corr(g1, pyr[1], coords / 4, ii, jj, R)], -1).view(1, E, -1)
+        y.backward(gout)
+        outs.append([y.detach().clone(), g1.grad.clone(), pyr[0].grad.clone(), pyr[1].grad.clone()])
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6) + 1e-6

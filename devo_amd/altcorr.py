@@ -16,9 +16,10 @@ class CorrLayer(torch.autograd.Function):
     def backward(ctx, grad):
         fmap1, fmap2, coords, ii, jj = ctx.saved_tensors
         if ctx.dropout < 1:
-            # correlation.py:20-25: only a random subset of edges propagates gradient; the draw stays here
-            keep = torch.rand(len(ii), device=ii.device) < ctx.dropout
-            coords, grad, ii, jj = coords[:, keep], grad[:, keep], ii[keep], jj[keep]
+            # correlation.py:20-25: only a random subset of edges propagates gradient; the draw stays here.  ONE nonzero (= one host
+            # synchronisation for the subset's size) and four index_selects, where four boolean-mask indexings each run their own
+            keep = (torch.rand(len(ii), device=ii.device) < ctx.dropout).nonzero().squeeze(1)
+            coords, grad, ii, jj = coords.index_select(1, keep), grad.index_select(1, keep), ii.index_select(0, keep), jj.index_select(0, keep)
         d1, d2 = cuda_corr.backward(fmap1, fmap2, coords, ii, jj, grad, ctx.radius)
         return d1, d2, None, None, None, None, None
 
@@ -73,11 +74,13 @@ class CorrPyramidLayer(torch.autograd.Function):
         D = 2 * ctx.radius + 1
         g = grad.view(grad.shape[0], E, D, D, coords.shape[3], coords.shape[4], nl)
         d1, d2s = None, []
+        # every level's edge subset first: the host synchronisations for their sizes (nonzero) fall together, ahead of the kernels
+        keeps = [(torch.rand(len(ii), device=ii.device) < ctx.dropout).nonzero().squeeze(1) for _ in range(nl)] if ctx.dropout < 1 else None
         for l in range(nl):
             c_l, g_l, i_l, j_l = coords / ctx.scales[l], g[..., l], ii, jj
-            if ctx.dropout < 1:
-                keep = torch.rand(len(ii), device=ii.device) < ctx.dropout
-                c_l, g_l, i_l, j_l = c_l[:, keep], g_l[:, keep], ii[keep], jj[keep]
+            if keeps is not None:
+                k = keeps[l]
+                c_l, g_l, i_l, j_l = c_l.index_select(1, k), g_l.index_select(1, k), ii.index_select(0, k), jj.index_select(0, k)
             a, b = cuda_corr.backward(fmap1, pyramid[l], c_l, i_l, j_l, g_l, ctx.radius)
             d1 = a if d1 is None else d1 + a
             d2s.append(b)

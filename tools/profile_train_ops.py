@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""torch.profiler over one training step (3 update iterations): GPU time by ATen / autograd operator and input shape — which host-side
+expressions the element-wise / copy kernels of tools/trace_categories.py belong to.  python tools/profile_train_ops.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from devo_amd import training as T
+dev = torch.device("cuda", 0)
+net, model, opt = T.build_trainer(dev, 1)
+batch = T.make_batch("cfg2_m80", 1234, dev)
+for _ in range(2):
+    T.train_step(model, opt, batch, iters=3)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    T.train_step(model, opt, batch, iters=3)
+    torch.cuda.synchronize()
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=48, max_shapes_column_width=70))

@@ -63,7 +63,7 @@ _SIGNATURES.update({
     "devo_upd_heads": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "devo_upd_split_weight_bytes": [_i, _i],
     "devo_upd_split_weight": [_vp, _i64, _i64, _i, _i, _vp, _vp],
-    "devo_upd_linear_split": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],
+    "devo_upd_linear_split": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],
     "devo_upd_pack_weight_f16_bytes": [_i, _i],
     "devo_upd_pack_weight_f16": [_vp, _i64, _i64, _i, _i, _vp, _vp],
     "devo_upd_linear_f16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],

@@ -124,7 +124,7 @@ __device__ __forceinline__ void ln_dma16(unsigned voff, __amdgpu_buffer_rsrc_t r
 template <bool TRACE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_split(
     const float* __restrict__ x, int64_t ldx, const ln_u4* __restrict__ wsplit, const float* __restrict__ bias, const float* residual,
-    float* y, int64_t ldy, int M, int N, int K, int relu_from, int dbg, unsigned long long* wgtrace) {
+    const float* __restrict__ gate, float* y, int64_t ldy, int M, int N, int K, int relu_from, int dbg, unsigned long long* wgtrace) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char ln_lds[];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, mi = lane & 15, kg = lane >> 4;
   const int NB = (N + LN_BN - 1) / LN_BN, Np = NB * LN_BN, nk = (K + 31) / 32;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   float* tile = reinterpret_cast<float*>(ln_lds) + wv * (16 * LN_EPI_LD);
   const int col0 = nb * LN_BN;
   constexpr int PPR = LN_BN / 4;                                       // 16-byte pieces per row
-  const bool vec_out = (ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+  const bool vec_out = (ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(gate)) & 15) == 0;
 #pragma unroll
   for (int mt = 0; mt < LN_MT; mt++) {
     if (kg == 0) rowf[16 * mt + mi] = ln_pow2(254 - esc[mt]);
@@ -319,13 +319,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       if (row < M && col < N && !(dbg & 2)) {
         float* dst = y + (int64_t)row * ldy + col;
         const float* res = residual ? residual + (int64_t)row * ldy + col : nullptr;      // (may be y itself: read, then written, by this lane)
+        const float* gt = gate ? gate + (int64_t)row * ldy + col : nullptr;      // a ReLU's output: this gradient passes where it did not clip
         if (vec_out && col + 4 <= N) {
+          if (gt) {
+            const ln_f4 q = *reinterpret_cast<const ln_f4*>(gt);
+            v.x = q.x > 0.f ? v.x : 0.f; v.y = q.y > 0.f ? v.y : 0.f; v.z = q.z > 0.f ? v.z : 0.f; v.w = q.w > 0.f ? v.w : 0.f;
+          }
           if (res) v += *reinterpret_cast<const ln_f4*>(res);
           *reinterpret_cast<ln_f4*>(dst) = v;
         } else {                                                       // rows that are not 16-byte aligned (the corr MLP's 882 columns), the last columns of such a row
 #pragma unroll
           for (int e = 0; e < 4; e++)
-            if (col + e < N) dst[e] = v[e] + (res ? res[e] : 0.f);
+            if (col + e < N) dst[e] = ((!gt || gt[e] > 0.f) ? v[e] : 0.f) + (res ? res[e] : 0.f);
         }
       }
     }
@@ -523,13 +528,13 @@ int devo_upd_split_weight(const float* W, int64_t s_n, int64_t s_k, int N, int K
   return check_launch("devo_upd_split_weight");
 }
 
-int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, const float* residual, float* y, int64_t ldy,
-                          int M, int N, int K, int relu_from, devo_stream_t stream) {
+int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, const float* residual, const float* gate, float* y,
+                          int64_t ldy, int M, int N, int K, int relu_from, devo_stream_t stream) {
   DEVO_REQUIRE(M >= 0 && N > 0 && K > 0, "devo_upd_linear_split: bad sizes (%d x %d x %d)", M, N, K);
   if (M == 0) return DEVO_OK;
   DEVO_REQUIRE(x && wsplit && y && ldx >= K && ldy >= N, "devo_upd_linear_split: null tensor or rows shorter than the matrix");
   DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(wsplit)) & 15) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias) |
-                 reinterpret_cast<uintptr_t>(residual)) & 3) == 0, "devo_upd_linear_split: the weight image must be 16-byte aligned, everything else 4-byte");
+                 reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(gate)) & 3) == 0, "devo_upd_linear_split: the weight image must be 16-byte aligned, everything else 4-byte");
   const int nk = (K + 31) / 32, NB = (N + LN_BN - 1) / LN_BN;
   DEVO_REQUIRE(((int64_t)(M - 1) * ldx + K) * 4 < (1LL << 31) && (int64_t)NB * LN_BN * nk * 128 < (1LL << 31), "devo_upd_linear_split: operand beyond 2 GB");
   static_assert(LN_LDS <= 64 * 1024, "the workgroup's LDS fits the default dynamic limit");
@@ -539,7 +544,7 @@ int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const
   unsigned long long* wgtrace = nullptr;
   if ((dbg & 48) == 48) { (void)hipMalloc(&wgtrace, (size_t)nwg * 32); (void)hipMemset(wgtrace, 0, (size_t)nwg * 32); }
   hipLaunchKernelGGL((dbg & 16) ? k_linear_split<true> : k_linear_split<false>, dim3(nwg), dim3(256), LN_LDS, (hipStream_t)stream, x, ldx,
-                     (const ln_u4*)wsplit, bias, residual, y, ldy, M, N, K, relu_from < 0 ? 0 : relu_from, dbg, wgtrace);
+                     (const ln_u4*)wsplit, bias, residual, gate, y, ldy, M, N, K, relu_from < 0 ? 0 : relu_from, dbg, wgtrace);
   if (wgtrace) {                                                      // debug: residency of the launch's workgroups over time, per CU
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)nwg * 4);

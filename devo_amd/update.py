@@ -90,18 +90,20 @@ def _linear_f16(x2, w, b, relu=False, relu_from=None, residual=None, out=None):
     return y
 
 
-def _linear_split(x2, w, b, transposed=False, relu=False, relu_from=None, residual=None, out=None):
+def _linear_split(x2, w, b, transposed=False, relu=False, relu_from=None, residual=None, out=None, gate=None):
     """x2 [rows, K] fp32 -> act(x2 @ w.T + b) [+ residual] (or x2 @ w: transposed) on the fp16 matrix cores, fp32 in and out
     (csrc/linear.hip).  relu_from: the ReLU from this output column on (a gate | res pair in one launch); residual / out: [rows, N]
-    fp32 with one row pitch (out may be the residual: x.add_(linear(t)) in one launch)."""
+    fp32 with one row pitch (out may be the residual: x.add_(linear(t)) in one launch); gate [rows, N]: a ReLU's output — the result is
+    zeroed where it clipped (the ReLU's adjoint in the epilogue of the dX product that produces its incoming gradient)."""
     N = w.shape[1] if transposed else w.shape[0]
     K = w.shape[0] if transposed else w.shape[1]
     y = out if out is not None else torch.empty(x2.shape[0], N, dtype=torch.float32, device=x2.device)
-    if residual is not None and (residual.stride(0) != y.stride(0) or residual.dtype != torch.float32):
-        raise RuntimeError("_linear_split: the residual must share the output's row pitch")
+    for t, what in ((residual, "residual"), (gate, "gate")):
+        if t is not None and (t.stride(0) != y.stride(0) or t.stride(1) != 1 or t.dtype != torch.float32):
+            raise RuntimeError(f"_linear_split: the {what} must share the output's row pitch")
     rf = (0 if relu else N) if relu_from is None else relu_from
     L.check(L.lib().devo_upd_linear_split(L.ptr(x2), x2.stride(0), L.ptr(_split_weight(w.detach(), transposed)), L.ptr(b), L.ptr(residual),
-                                          L.ptr(y), y.stride(0), x2.shape[0], N, K, rf, L.stream()), "update.linear_split")
+                                          L.ptr(gate), L.ptr(y), y.stride(0), x2.shape[0], N, K, rf, L.stream()), "update.linear_split")
     return y
 
 
@@ -200,6 +202,46 @@ def _linear(x2, w, b):
     return torch.nn.functional.linear(x2, w, b)
 
 
+class _Mlp2Fn(torch.autograd.Function):
+    """Linear -> ReLU -> Linear [+ residual] (the c1 / c2 / res / corr pairs of enet.py:41-66, blocks.py:15-29) as four split-precision
+    products per direction with everything between them in their epilogues: forward relu(x W1^T + b1), then h W2^T + b2 + residual;
+    backward dH = (dY W2) masked by h > 0 (the ReLU's adjoint in the dX product's epilogue: no threshold_backward pass), dW2 / db2 from
+    (dY, h), dX = dH W1, dW1 / db1 from (dH, x)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual):
+        h = _linear_split(x, w1, b1.contiguous() if b1 is not None else None, relu=True)
+        y = _linear_split(h, w2, b2.contiguous() if b2 is not None else None, residual=residual.contiguous() if residual is not None else None)
+        ctx.save_for_backward(x, h, w1, w2)
+        ctx.bias = (b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, h, w1, w2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        g = g.contiguous()
+        gx = gw1 = gb1 = gw2 = gb2 = None
+        gh = _linear_split(g, w2, None, transposed=True, gate=h)
+        if need[3] or (ctx.bias[1] and need[4]):
+            gw2, gb2 = _dw_split(g, h, ctx.bias[1] and need[4])
+        if need[0]:
+            gx = _linear_split(gh, w1, None, transposed=True)
+        if need[1] or (ctx.bias[0] and need[2]):
+            gw1, gb1 = _dw_split(gh, x, ctx.bias[0] and need[2])
+        return gx, gw1, gb1, gw2, gb2, (g if need[5] else None)
+
+
+def _mlp2_fused_ok(seq, x2, residual):
+    w1, w2 = seq[0].weight, seq[2].weight
+    if not (w1.dtype == w2.dtype == torch.float32 and x2.is_contiguous() and (residual is None or residual.dtype == torch.float32)):
+        return False
+    rows = x2.shape[0]
+    ok_fwd = _split_ok(x2, w1.shape[0], w1.shape[1]) and w2.shape[1] >= 32 and w2.shape[0] >= 96 and w1.shape[0] >= 96
+    ok_dw = SPLIT_DW and min(w1.shape[0], w1.shape[1], w2.shape[0], w2.shape[1]) >= 96 and rows >= 2048
+    return ok_fwd and ok_dw
+
+
 FUSE_EPILOGUE = __import__("os").environ.get("DEVO_UPD_FUSE_EPILOGUE", "1") != "0"     # 0: ReLU / residual sums as ATen kernels in the training path
 
 
@@ -209,8 +251,12 @@ def _mlp2(seq, x, residual=None):
     rows = x.numel() // x.shape[-1]
     if (FUSE_EPILOGUE and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and rows >= 4096 and not torch.is_autocast_enabled()
             and (x.requires_grad or seq[0].weight.requires_grad)):
-        h = _LinearFn.apply(x.reshape(rows, -1), seq[0].weight, seq[0].bias, True, None)
-        y = _LinearFn.apply(h, seq[2].weight, seq[2].bias, False, residual.reshape(rows, -1) if residual is not None else None)
+        x2, r2 = x.reshape(rows, -1), (residual.reshape(rows, -1) if residual is not None else None)
+        if _mlp2_fused_ok(seq, x2, r2):
+            y = _Mlp2Fn.apply(x2, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, r2)
+        else:
+            h = _LinearFn.apply(x2, seq[0].weight, seq[0].bias, True, None)
+            y = _LinearFn.apply(h, seq[2].weight, seq[2].bias, False, r2)
         return y.view(*x.shape[:-1], y.shape[-1])
     y = seq[2](seq[1](seq[0](x)))
     return y if residual is None else residual + y

@@ -371,11 +371,12 @@ int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void*
  *   devo_upd_linear_split: x fp32, rows ldx >= K elements apart (any alignment of 4 bytes); y fp32, rows ldy >= N apart (16-byte pieces when
  *     ldy is a multiple of 4 and y / residual are 16-byte aligned, single values otherwise); bias fp32 [N] or NULL; residual NULL or fp32 with y's row pitch, added after the activation (it may be y itself:
  *     x.add_(linear(t)) in one launch); columns >= relu_from get max(., 0) (0: all of them, >= N: none — a gate | res pair of a
- *     GatedResidual in one launch). */
+ *     GatedResidual in one launch); gate NULL or fp32 with y's row pitch: the result is kept where gate > 0 and zeroed elsewhere, before
+ *     the residual — dX = (dY W) masked by the ReLU output it passes back through (threshold_backward in the epilogue). */
 size_t devo_upd_split_weight_bytes(int N, int K);
 int devo_upd_split_weight(const float* W, int64_t s_n, int64_t s_k, int N, int K, void* wsplit, devo_stream_t stream);
-int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, const float* residual, float* y, int64_t ldy,
-                          int M, int N, int K, int relu_from, devo_stream_t stream);
+int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, const float* residual, const float* gate, float* y,
+                          int64_t ldy, int M, int N, int K, int relu_from, devo_stream_t stream);
 
 /* The same workgroup shape for fp16 storage — the update operator's inference precision (devo.py:71-77: autocast): y[M, N] (fp16) =
  * act(x[M, K] W^T + bias) [+ residual], fp32 accumulation, one MFMA per block (no split, no scales), K steps of 64.

@@ -303,6 +303,9 @@ def test_split_precision_linear_matches_float64(rows, n_out, k_in, relu):
     ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
     ref[:, half:].relu_()
     assert ((UA._linear_split(x, w, b, relu_from=half).double() - ref).abs() / scale).max().item() < 1e-6
+    gate = torch.randn(rows, n_out, generator=g).to(DEV)                # a ReLU's output: the result passes where it is positive
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double()) * (gate > 0)
+    assert ((UA._linear_split(x, w, b, gate=gate).double() - ref).abs() / scale).max().item() < 1e-6
     poison = torch.full((rows, n_out + 3), 7.0, device=DEV)            # nothing is written behind column N (rows that are not 16-byte aligned)
     UA._linear_split(x, w, b, out=poison[:, :n_out])
     assert torch.equal(poison[:, n_out:], torch.full((rows, 3), 7.0, device=DEV))

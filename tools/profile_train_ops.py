@@ -9,10 +9,16 @@ from devo_amd import training as T
 dev = torch.device("cuda", 0)
 net, model, opt = T.build_trainer(dev, 1)
 batch = T.make_batch("cfg2_m80", 1234, dev)
+ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for _ in range(2):
-    T.train_step(model, opt, batch, iters=3)
+    T.train_step(model, opt, batch, iters=ITERS)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-    T.train_step(model, opt, batch, iters=3)
+    T.train_step(model, opt, batch, iters=ITERS)
     torch.cuda.synchronize()
+ops = [e for e in prof.key_averages() if e.key.startswith("aten::") or "Backward" in e.key or e.key.startswith("_")]
+ops.sort(key=lambda e: -e.self_device_time_total)
+print("operators by their own GPU time (us), calls:")
+for e in ops[:40]:
+    print(f"  {e.key[:44]:44s} {e.self_device_time_total:10.0f} {e.count:6d}")
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=48, max_shapes_column_width=70))

@@ -254,8 +254,8 @@ class Patchifier(nn.Module):
             smap = torch.sigmoid(self.scorer(images).float())
             scores = smap[0][torch.arange(n, device=dev)[:, None], (y - 1).clamp(0, h - 3), (x - 1).clamp(0, w - 3)]
         xy = torch.stack([x, y], dim=-1).float()                                  # [n, M, 2], feature-map pixels
-        imap_p = altcorr.patchify(imap[0].float().contiguous(), xy, 0).view(b, -1, self.dim_inet, 1, 1)
-        gmap = altcorr.patchify(fmap[0].float().contiguous(), xy, P // 2).view(b, -1, self.dim_fnet, P, P)
+        imap_p = altcorr.patchify(imap[0].float(), xy, 0).view(b, -1, self.dim_inet, 1, 1)      # (the kernel takes the channels-last strides: no NCHW copy)
+        gmap = altcorr.patchify(fmap[0].float(), xy, P // 2).view(b, -1, self.dim_fnet, P, P)
         # patches = patchify(coords_grid_with_index(disps), xy, P // 2) in closed form: pixel (x + j - r, y + i - r) and its depth
         r = P // 2
         off = torch.arange(-r, r + 1, device=dev, dtype=torch.float32)

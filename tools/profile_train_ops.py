@@ -22,3 +22,8 @@ print("operators by their own GPU time (us), calls:")
 for e in ops[:40]:
     print(f"  {e.key[:44]:44s} {e.self_device_time_total:10.0f} {e.count:6d}")
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=48, max_shapes_column_width=70))
+print("the element-wise / reduction operators by input shape:")
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::sum", "aten::add_", "aten::add", "aten::copy_", "aten::threshold_backward", "aten::gather", "aten::index_add_", "aten::mul", "aten::div", "aten::fill_", "aten::clamp_min", "aten::mm", "aten::bmm", "aten::addmm")]
+rows.sort(key=lambda e: -e.self_device_time_total)
+for e in rows[:45]:
+    print(f"  {e.key:26s} {e.self_device_time_total:9.0f} us {e.count:5d} calls  {str(e.input_shapes)[:120]}")

@@ -30,7 +30,7 @@ _SIGNATURES = {
     "devo_corr_backward_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i],
     "devo_corr_backward_last_path": [],
     "devo_patchify_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _c_i64p, _i, _i, _vp],
-    "devo_patchify_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "devo_patchify_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _c_i64p, _i, _i, _vp],
     "devo_ba_workspace_bytes": [_i, _i, _i],
     "devo_ba_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
     "devo_ba_prepare": [_vp, _i, _i, _i, _vp, _sz, _vp],

@@ -307,8 +307,11 @@ def patchify_backward(net, coords, gradient, radius):
     if net.dtype == torch.float16:                    # scattered in fp32 (hardware float atomics), cast back like the forward's dtype
         return [patchify_backward(net.float(), coords, gradient.float(), radius)[0].half()]
     gradient = gradient.to(net.dtype).contiguous()
-    out = torch.empty(B, C, H, W, dtype=net.dtype, device=net.device)
-    rc = L.lib().devo_patchify_backward(L.ptr(coords), L.ptr(gradient), L.ptr(out), B, M, C, H, W, int(radius),
+    # the gradient in net's own layout when that is a dense permutation (channels-last from the encoders' convolutions: no layout copy
+    # on the way back into their backward), contiguous otherwise
+    dense = net.numel() > 0 and 1 + sum((n - 1) * st for n, st in zip(net.shape, net.stride())) == net.numel()
+    out = torch.empty_strided(net.shape, net.stride(), dtype=net.dtype, device=net.device) if dense else torch.empty(B, C, H, W, dtype=net.dtype, device=net.device)
+    rc = L.lib().devo_patchify_backward(L.ptr(coords), L.ptr(gradient), L.ptr(out), B, M, C, H, W, L.i64arr(out.stride()), int(radius),
                                         L.dtype_code(net), L.stream())
     L.check(rc, "cuda_corr.patchify_backward")
     return [out]

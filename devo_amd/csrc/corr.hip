@@ -820,7 +820,7 @@ namespace devo {
 
 template <typename T>
 __global__ void patchify_bwd_kernel(const float* __restrict__ coords, const T* __restrict__ grad, T* __restrict__ dnet,
-                                    int M, int C, int H, int W, int R, int64_t total) {
+                                    int M, int C, int H, int W, int R, int64_t total, int64_t sb, int64_t sc, int64_t sh, int64_t sw) {
   const int D = 2 * R + 2;
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < total; n += (int64_t)blockDim.x * gridDim.x) {
     int c = n % D; int64_t r = n / D;
@@ -829,7 +829,7 @@ __global__ void patchify_bwd_kernel(const float* __restrict__ coords, const T* _
     int m = r % M; int b = r / M;
     float x = coords[((int64_t)b * M + m) * 2], y = coords[((int64_t)b * M + m) * 2 + 1];
     int i = floor_to_int(y) + a - R, j = floor_to_int(x) + c - R;
-    if (i >= 0 && i < H && j >= 0 && j < W) atomicAdd(dnet + (((int64_t)b * C + k) * H + i) * W + j, grad[n]);
+    if (i >= 0 && i < H && j >= 0 && j < W) atomicAdd(dnet + b * sb + k * sc + i * sh + j * sw, grad[n]);
   }
 }
 
@@ -1352,17 +1352,25 @@ int devo_patchify_forward(const void* net, const float* coords, void* out, int B
 }
 
 int devo_patchify_backward(const float* coords, const void* grad, void* net_grad, int B, int M, int C, int H, int W,
-                           int radius, int dtype, devo_stream_t stream) {
+                           const int64_t* gs, int radius, int dtype, devo_stream_t stream) {
   const int D = 2 * radius + 2;
   int64_t total = (int64_t)B * M * C * D * D;
   hipStream_t st = (hipStream_t)stream;
   size_t esz = dtype == DEVO_F64 ? 8 : 4;
   if (dtype != DEVO_F32 && dtype != DEVO_F64) { set_error("devo_patchify_backward: F32/F64 only"); return DEVO_ERR_UNSUPPORTED; }
+  // gs: element strides of net_grad (NULL: contiguous [B, C, H, W]); a dense permutation (channels-last: what the encoders' convolutions
+  // hand over and take back) — the B C H W elements behind net_grad are zeroed
+  const int64_t cs[4] = {(int64_t)C * H * W, (int64_t)H * W, W, 1};
+  if (!gs) gs = cs;
+  int64_t span = 1;
+  const int dims[4] = {B, C, H, W};
+  for (int d = 0; d < 4; d++) { if (gs[d] < 0) { set_error("devo_patchify_backward: negative stride"); return DEVO_ERR_ARG; } span += (int64_t)(dims[d] - 1) * gs[d]; }
+  if (B * (int64_t)C * H * W > 0 && span != (int64_t)B * C * H * W) { set_error("devo_patchify_backward: net_grad must be a dense (permuted) tensor"); return DEVO_ERR_ARG; }
   if (hipMemsetAsync(net_grad, 0, esz * (size_t)B * C * H * W, st) != hipSuccess) { set_error("devo_patchify_backward: memset failed"); return DEVO_ERR_LAUNCH; }
   if (total == 0) return DEVO_OK;
   int blocks = blocks_for(total, 256, 8192);
-  if (dtype == DEVO_F32) hipLaunchKernelGGL(patchify_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, coords, (const float*)grad, (float*)net_grad, M, C, H, W, radius, total);
-  else hipLaunchKernelGGL(patchify_bwd_kernel<double>, dim3(blocks), dim3(256), 0, st, coords, (const double*)grad, (double*)net_grad, M, C, H, W, radius, total);
+  if (dtype == DEVO_F32) hipLaunchKernelGGL(patchify_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, coords, (const float*)grad, (float*)net_grad, M, C, H, W, radius, total, gs[0], gs[1], gs[2], gs[3]);
+  else hipLaunchKernelGGL(patchify_bwd_kernel<double>, dim3(blocks), dim3(256), 0, st, coords, (const double*)grad, (double*)net_grad, M, C, H, W, radius, total, gs[0], gs[1], gs[2], gs[3]);
   return check_launch("devo_patchify_backward");
 }
 

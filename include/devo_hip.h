@@ -135,9 +135,10 @@ int devo_patchify_forward(const void* net, const float* coords, void* out, int B
                           const int64_t* ns /* host, 4 */, int radius, int dtype, devo_stream_t stream);
 
 /* cuda_corr.patchify_backward  (correlation.cpp:62 -> correlation_kernel.cu:310-333, kernel :49-80).
- *   grad T [B, M, C, D, D] contiguous -> net_grad T [B, C, H, W] contiguous (zeroed here). F32/F64. */
+ *   grad T [B, M, C, D, D] contiguous -> net_grad T [B, C, H, W] (zeroed here) with element strides gs[4] (host; NULL: contiguous; any
+ *   dense permutation, e.g. channels-last — the layout the encoders' convolutions take their gradient in). F32/F64. */
 int devo_patchify_backward(const float* coords, const void* grad, void* net_grad, int B, int M, int C, int H,
-                           int W, int radius, int dtype, devo_stream_t stream);
+                           int W, const int64_t* gs, int radius, int dtype, devo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fastba  (reference module cuda_ba: devo/fastba/ba.cpp:152-157)

@@ -114,12 +114,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const bool do_bias = bj == 0 && wj == 0;                            // wave-uniform
   const bool edge_a = i0 + DW_BT > No, edge_b = j0 + DW_BT > Ni;
 
+#ifdef DW_TRACE                                                        // debug build: cycle stamps of workgroup (0, 0), wave 0 -> the first floats of its partial block
+  unsigned long long tst[40]; int nst = 0;
+#define DW_STAMP() do { if (nst < 40) tst[nst] = __builtin_readcyclecounter(); nst++; } while (0)
+#else
+#define DW_STAMP() do {} while (0)
+#endif
+  DW_STAMP();
   request(s_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  DW_STAMP();
   for (int s = s_begin; s < s_end; s++) {
     const int buf = (s - s_begin) & 1;
     request(s + 1, buf ^ 1);
+    DW_STAMP();
     float xa[4][8], xb[4][8];
     bool raise = false;
 #pragma unroll
@@ -149,6 +158,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       raise = raise || !(m * scA[t] <= DW_RAISE) || !(n * scB[t] <= DW_RAISE);
       if (do_bias) gsum[t] += ((xa[t][0] + xa[t][1]) + (xa[t][2] + xa[t][3])) + ((xa[t][4] + xa[t][5]) + (xa[t][6] + xa[t][7]));
     }
+    DW_STAMP();
     const bool first = s == s_begin;
     if (first || __builtin_amdgcn_ballot_w64(raise) != 0ull) {        // rare after the first step: new column scales, the accumulators follow
       float fa[4], fb[4];
@@ -180,6 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
     }
+    DW_STAMP();
     dw_h8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -188,6 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       dw_split8(xa[t], ah[t], al[t]);
       dw_split8(xb[t], bh[t], bl[t]);
     }
+    DW_STAMP();
 #pragma unroll
     for (int a = 0; a < 4; a++)                                        // small terms first; the same accumulator again 16 MFMAs later
 #pragma unroll
@@ -200,8 +212,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int a = 0; a < 4; a++)
 #pragma unroll
       for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+    DW_STAMP();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the next step's tiles have landed ...
     __syncthreads();                                                   // ... and every wave is done with this step's
+    DW_STAMP();
   }
   // ---- partial block: D[4 kg + r][li] of tile (a, b) = dW[i0 + 64 wi + 16 a + 4 kg + r][j0 + 64 wj + 16 b + li], scaled back
   const int Nop = (No + DW_BT - 1) / DW_BT * DW_BT;
@@ -219,6 +233,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int r = 0; r < 4; r++) pb[(size_t)(16 * a + 4 * kg + r) * Nip + 16 * b + li] = acc[a][b][r] * ir[r] * ib;
     }
   }
+#ifdef DW_TRACE
+  DW_STAMP();
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = 0; i < 40; i++) part[i] = i < nst ? (float)(long long)(tst[i] - tst[0]) : -1.f;
+  }
+#endif
   if (do_bias) {
 #pragma unroll
     for (int t = 0; t < 4; t++) {

@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdevo_hip.so")
 
 DEVO_F32, DEVO_F16, DEVO_F64 = 0, 1, 2
+ABI_VERSION = 2                # include/devo_hip.h DEVO_ABI_VERSION: a library of another version is refused (argument lists differ)
+CBLOCK_SPLIT8 = -8             # DEVO_CBLOCK_SPLIT8: fp32 level in the split-blocked format of devo_corr_pyramid_split
 _DT = {torch.float32: DEVO_F32, torch.float16: DEVO_F16, torch.float64: DEVO_F64}
 
 _c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -20,10 +22,12 @@ _vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c
 _SIGNATURES = {
     "devo_abi_version": [],
     "devo_last_error": [],
-    "devo_corr_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i, _i64, _i64, _i64, _i, _i, _vp, ctypes.c_float, _vp, _vp],
+    "devo_corr_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i, _i64, _i64, _i64, _i, _i, _vp, ctypes.c_float, _vp, _vp, _vp],
     "devo_corr_forward_pyramid2": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), _c_i64p,
-                                   ctypes.POINTER(ctypes.c_int), _i64, _i64, _c_i64p, _i, _i, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp],
+                                   ctypes.POINTER(ctypes.c_int), _i64, _i64, _c_i64p, _i, _i, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp, _vp, _vp],
+    "devo_corr_patch_operand_bytes": [_i, _i, _i],
     "devo_corr_patch_transpose": [_vp, _vp, _i, _i, _i, _vp],
+    "devo_corr_pyramid_split": [_vp, _c_i64p, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp],
     "devo_pyramid_build": [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i, _vp],
     "devo_corr_order": [_vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_float, _i, _i, _i, _vp],
     "devo_corr_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i64, _i, _i, _vp, ctypes.c_size_t, _vp],
@@ -84,7 +88,7 @@ for _n in ("mul", "adj", "adjT", "act", "act4"):
 _SIGNATURES["devo_se3_as_matrix"] = [_vp, _vp, _i64, _i, _vp]
 _SIGNATURES["devo_se3_jinv"] = [_vp, _vp, _vp, _i64, _i, _vp]
 _RESTYPE = {"devo_last_error": ctypes.c_char_p, "devo_voxel_std_workspace_bytes": _sz, "devo_ba_workspace_bytes": _sz, "devo_neighbors_workspace_bytes": _sz,
-             "devo_corr_backward_workspace_bytes": _sz, "devo_upd_split_weight_bytes": _sz, "devo_upd_dw_workspace_bytes": _sz, "devo_upd_pack_weight_f16_bytes": _sz}
+             "devo_corr_backward_workspace_bytes": _sz, "devo_corr_patch_operand_bytes": _sz, "devo_upd_split_weight_bytes": _sz, "devo_upd_dw_workspace_bytes": _sz, "devo_upd_pack_weight_f16_bytes": _sz}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -104,6 +108,9 @@ def lib():
             fn = getattr(h, name)
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, ctypes.c_int)
+        got = h.devo_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {got}, this package binds version {ABI_VERSION}: rebuild it with `python -m devo_amd.build --force`")
         _lib = h
     return _lib
 

@@ -21,7 +21,9 @@ def _prep(fmap1, fmap2, coords, ii, jj, allow_blocked=False):
 
 
 import os
-MM_KERNEL = os.environ.get("DEVO_CORR_MM", "1") != "0"          # dense-product lookup kernel (corr_mm.h) for fused two-level lookups; False: the 4x4 matrix-core kernel
+# dense-product lookup kernel (corr_mm.h); False: the 4x4 matrix-core kernel (DEVO_CORR_MFMA=0: neither — the staged kernel; both are read
+# by the library as well)
+MM_KERNEL = os.environ.get("DEVO_CORR_MM", "1") != "0" and os.environ.get("DEVO_CORR_MFMA", "1") != "0"
 PLAN_MIN_EDGES = 2048      # below this the lookup is launch-bound and a locality plan cannot pay for itself
 NCHW_CONVERT_MIN_EDGES = 1024    # from here on a lookup into the reference's NCHW pyramid goes through a cached channel-blocked copy
 
@@ -29,23 +31,76 @@ _blocked_cache = {}        # (ptr, version, shape, strides, dtype) -> (source te
 BLOCKED_CACHE_ENTRIES = 4
 
 
-def _fast_layout(fmap2, n_edges):
+class SplitLevel:
+    """An fp32 pyramid level in the split-blocked format of devo_corr_pyramid_split: `data` float32-sized [B, n, C/8, H, W, 8] whose
+    32-byte pixel blocks hold fp16 (hi0..7 | lo0..7), `exps` int32 [B n (+ n scratch)] = one scale exponent per frame.  What the
+    dense-product lookup kernel multiplies; an opaque operand like patches_transposed()'s."""
+    __slots__ = ("data", "exps", "shape", "dtype", "is_cuda", "device")
+
+    def __init__(self, data, exps, C):
+        self.data, self.exps = data, exps
+        B, n, _, H, W, _ = data.shape
+        self.shape = (B, n, C, H, W)
+        self.dtype, self.is_cuda, self.device = torch.float32, True, data.device
+
+    def dim(self):
+        return 5
+
+
+def split_level(fmap2):
+    """fp32 fmap2 [B, n, C, H, W] (any strides) or channel-blocked [B, n, C/cb, H, W, cb] -> SplitLevel (two launches per batch entry)."""
+    L.require_gpu(fmap2)
+    cblock = 0
+    if fmap2.dim() == 6:
+        cblock = fmap2.shape[5]
+        B, n, nblk, H, W, _ = fmap2.shape
+        C = nblk * cblock
+        if fmap2.stride(5) != 1:
+            raise RuntimeError("cuda_corr.split_level: malformed channel-blocked fmap2")
+    else:
+        B, n, C, H, W = fmap2.shape
+    if fmap2.dtype != torch.float32 or C % 8:
+        raise RuntimeError("cuda_corr.split_level: fp32 with C % 8 == 0 only")
+    data = torch.empty(B, n, C // 8, H, W, 8, dtype=torch.float32, device=fmap2.device)
+    exps = torch.empty(B * n + n, dtype=torch.int32, device=fmap2.device)
+    st = fmap2.stride()
+    for b in range(B):                                        # ascending: call b's scratch is the (not yet written) slice of b + 1
+        rc = L.lib().devo_corr_pyramid_split(L.ptr(fmap2[b]), L.i64arr([st[1], st[2], st[3], st[4]]), int(cblock), n, C, H, W,
+                                             L.ptr(data[b]), data.stride(1), ctypes.c_void_p(exps.data_ptr() + 4 * b * n), L.stream())
+        L.check(rc, "cuda_corr.split_level")
+    return SplitLevel(data, exps, C)
+
+
+def _mm_wants_split(fmap2, C):
+    return MM_KERNEL and fmap2.dtype == torch.float32 and C % 32 == 0 and C <= 128
+
+
+def _fast_layout(fmap2, n_edges, allow_split=True):
     """The reference keeps its feature pyramid NCHW ([1, 32, 128, H, W] fp16 ring, devo/devo.py:71-83, rewritten in place one
     frame per step); read directly, every channel of a pixel is H*W elements away and the lookup falls back to the strided
     generic kernel — measured 24x slower than the matrix-core kernel on the channel-blocked layout (profiles/README.md, r02x).
     So an NCHW level is converted ONCE per version of the tensor into a channel-blocked copy [B, n, C/8, H, W, 8]
     (devo_pyramid_build: one pass, ~60 us for DEVO's whole fp16 ring) and cached: the key is (storage address, version counter,
     shape, strides, dtype) and the cache keeps the source tensor alive, so an equal key is the same storage with the same
-    contents (in-place writes such as `fmap1_[:, k] = f` bump the version counter).  Channels-last / channel-blocked inputs,
-    small edge lists, other dtypes: returned unchanged.  DEVO_CORR_NCHW_DIRECT=1 disables the conversion."""
+    contents (in-place writes such as `fmap1_[:, k] = f` bump the version counter).  fp16 channels-last / channel-blocked inputs,
+    small edge lists, other dtypes: returned unchanged.  DEVO_CORR_NCHW_DIRECT=1 disables the conversion.
+    fp32 levels of ANY layout (NCHW, channels-last, channel-blocked) that the dense-product kernel can take (C % 32 == 0, C <= 128) are
+    converted — same cache, same key — into the split-blocked format (SplitLevel: fp16 hi | lo of the value scaled per frame): the
+    kernel then loads its operands instead of splitting every value it reads, at any magnitude of the features."""
     import os
-    if (fmap2.dim() != 5 or fmap2.dtype not in (torch.float16, torch.float32) or n_edges < NCHW_CONVERT_MIN_EDGES
-            or os.environ.get("DEVO_CORR_NCHW_DIRECT", "0") == "1"):
+    if isinstance(fmap2, SplitLevel):
         return fmap2
-    B, n, C, H, W = fmap2.shape
+    if fmap2.dtype not in (torch.float16, torch.float32) or n_edges <= 0:
+        return fmap2
     st = fmap2.stride()
-    if C % 8 or tuple(st[2:]) != (H * W, W, 1) or B * n == 0:
-        return fmap2                                          # not plain NCHW frames (e.g. channels-last already)
+    C = fmap2.shape[2] * (fmap2.shape[5] if fmap2.dim() == 6 else 1)
+    want_split = allow_split and _mm_wants_split(fmap2, C) and fmap2.numel() > 0
+    if not want_split:
+        if fmap2.dim() != 5 or n_edges < NCHW_CONVERT_MIN_EDGES or os.environ.get("DEVO_CORR_NCHW_DIRECT", "0") == "1":
+            return fmap2
+        B, n, C, H, W = fmap2.shape
+        if C % 8 or tuple(st[2:]) != (H * W, W, 1) or B * n == 0:
+            return fmap2                                      # not plain NCHW frames (e.g. channels-last already)
     key = (fmap2.data_ptr(), fmap2._version, tuple(fmap2.shape), tuple(st), fmap2.dtype)
     hit = _blocked_cache.pop(key, None)
     if hit is not None:
@@ -55,6 +110,10 @@ def _fast_layout(fmap2, n_edges):
         del _blocked_cache[k]                                 # an older version of this tensor
     while len(_blocked_cache) >= BLOCKED_CACHE_ENTRIES:       # least recently used first (dicts keep insertion order): a DEVO
         del _blocked_cache[next(iter(_blocked_cache))]        # process holds two levels of one ring = 2 entries, ~300 MB in fp16
+    if want_split:
+        lvl = split_level(fmap2)
+        _blocked_cache[key] = (fmap2, lvl)
+        return lvl
     blk = torch.empty(B, n, C // 8, H, W, 8, dtype=fmap2.dtype, device=fmap2.device)
     for b in range(B):
         rc = L.lib().devo_pyramid_build(L.ptr(fmap2[b]), L.ptr(blk[b]), None, n, C, H, W, st[1], blk.stride(1), 0,
@@ -101,8 +160,8 @@ _patch_t_cache = {}        # (ptr, version, shape, dtype) -> (source tensor [kep
 
 
 def patches_transposed(fmap1):
-    """fmap1 [B, Np, C, 3, 3] -> [B, Np, 9, C] (devo_corr_patch_transpose), the patch operand layout of the dense-product lookup
-    kernel.  DEVO's patch features change once per frame, not per update iteration: the copy is cached per version of the tensor
+    """fmap1 [B, Np, C, 3, 3] -> the opaque patch operand of the dense-product lookup kernel (devo_corr_patch_transpose; a uint8 buffer:
+    fp16 [B, Np, 9, C], fp32 split records + one scale exponent per patch).  DEVO's patch features change once per frame, not per update iteration: the copy is cached per version of the tensor
     (same key discipline as _fast_layout)."""
     key = (fmap1.data_ptr(), fmap1._version, tuple(fmap1.shape), fmap1.dtype)
     hit = _patch_t_cache.pop(key, None)
@@ -114,7 +173,10 @@ def patches_transposed(fmap1):
     while len(_patch_t_cache) >= BLOCKED_CACHE_ENTRIES:       # least recently used first
         del _patch_t_cache[next(iter(_patch_t_cache))]
     B, Np, C = fmap1.shape[:3]
-    t = torch.empty(B, Np, 9, C, dtype=fmap1.dtype, device=fmap1.device)
+    nbytes = int(L.lib().devo_corr_patch_operand_bytes(B * Np, C, L.dtype_code(fmap1)))      # (fp32: split records + one exponent per patch)
+    if nbytes == 0 and B * Np > 0:
+        raise RuntimeError(f"cuda_corr.patches_transposed: C = {C} unsupported (C % 8)")
+    t = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=fmap1.device)
     rc = L.lib().devo_corr_patch_transpose(L.ptr(fmap1), L.ptr(t), B * Np, C, L.dtype_code(fmap1), L.stream())
     L.check(rc, "cuda_corr.patches_transposed")
     _patch_t_cache[key] = (fmap1, t)
@@ -124,7 +186,7 @@ def patches_transposed(fmap1):
 def _patch_operand(fmap1, C, P):
     """The dense-product kernel (corr_mm.h) wants the patches as devo_corr_patch_transpose lays them out ([Np, 9, C]; cached per
     version of fmap1).  None: the lookup takes the 4x4 matrix-core kernel or the staged / generic ones."""
-    if MM_KERNEL and P == 3 and fmap1.shape[3] == 3 and C % 32 == 0 and fmap1.dtype in (torch.float16, torch.float32):
+    if MM_KERNEL and P == 3 and fmap1.shape[3] == 3 and C % 32 == 0 and fmap1.dtype in (torch.float16, torch.float32) and fmap1.numel() > 0:
         return patches_transposed(fmap1)
     return None
 
@@ -134,23 +196,19 @@ def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, of
     coord_div: the kernel looks up at coords / coord_div (same IEEE division as `coords / s` on the tensor, without
     materialising it)."""
     fmap1, fmap2, coords, ii, jj = _prep(fmap1, fmap2, coords, ii, jj, allow_blocked=True)
-    fmap2 = _fast_layout(fmap2, coords.shape[0] * coords.shape[1])
-    if order is None and coords.shape[0] * coords.shape[1] >= PLAN_MIN_EDGES:
-        order = plan(coords, jj, fmap2.shape[1], fmap2.shape[3], float(coord_div), radius)
     B, E = coords.shape[:2]
     P = coords.shape[3]
     _, Np, C = fmap1.shape[:3]
-    n2, H2, W2 = fmap2.shape[1], fmap2.shape[3], fmap2.shape[4]
-    cblock, strides = 0, fmap2.stride()
-    if fmap2.dim() == 6:                      # channel-blocked storage [B, n, C/cb, H, W, cb] (altcorr.channel_blocked)
-        cblock = fmap2.shape[5]
-        if fmap2.stride(5) != 1 or fmap2.shape[2] * cblock != C:
-            raise RuntimeError("cuda_corr.forward: malformed channel-blocked fmap2")
-        strides = strides[:5]
     f1t = _patch_operand(fmap1, C, P)
-    rc = L.lib().devo_corr_forward(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(ii), L.ptr(jj), L.ptr(out),
+    # (fp32: the split-blocked copy only when the dense-product kernel will take the call; the exact kernels read the raw level)
+    fmap2 = _fast_layout(fmap2, B * E, allow_split=f1t is not None and lstride > 0)
+    if order is None and B * E >= PLAN_MIN_EDGES:
+        order = plan(coords, jj, fmap2.shape[1], fmap2.shape[3], float(coord_div), radius)
+    H2, W2, strides, cblock, data, exps = _level_desc(fmap2, C)
+    n2 = fmap2.shape[1]
+    rc = L.lib().devo_corr_forward(L.ptr(fmap1), L.ptr(data), L.ptr(coords), L.ptr(ii), L.ptr(jj), L.ptr(out),
                                    B, E, Np, n2, C, P, H2, W2, L.i64arr(strides), cblock, estride, lstride, offset,
-                                   int(radius), L.dtype_code(fmap1), L.ptr(order), float(coord_div), L.ptr(f1t), L.stream())
+                                   int(radius), L.dtype_code(fmap1), L.ptr(order), float(coord_div), L.ptr(f1t), L.ptr(exps), L.stream())
     L.check(rc, "cuda_corr.forward")
 
 
@@ -166,14 +224,19 @@ def forward(fmap1, fmap2, coords, ii, jj, radius):
 
 
 def _level_desc(fmap2, C):
-    """(H, W, strides[5], cblock) of one pyramid level as the C ABI wants them."""
+    """(H, W, strides[5], cblock, storage tensor, exponents or None) of one pyramid level as the C ABI wants them."""
+    if isinstance(fmap2, SplitLevel):
+        d = fmap2.data
+        if d.shape[2] * 8 != C:
+            raise RuntimeError("cuda_corr: split-blocked fmap2 does not match fmap1's channels")
+        return d.shape[3], d.shape[4], [int(x) for x in d.stride()[:5]], L.CBLOCK_SPLIT8, d, fmap2.exps
     cblock, strides = 0, fmap2.stride()
-    if fmap2.dim() == 6:
+    if fmap2.dim() == 6:                      # channel-blocked storage [B, n, C/cb, H, W, cb] (altcorr.channel_blocked)
         cblock = fmap2.shape[5]
         if fmap2.stride(5) != 1 or fmap2.shape[2] * cblock != C:
             raise RuntimeError("cuda_corr: malformed channel-blocked fmap2")
         strides = strides[:5]
-    return fmap2.shape[3], fmap2.shape[4], [int(x) for x in strides], int(cblock)
+    return fmap2.shape[3], fmap2.shape[4], [int(x) for x in strides], int(cblock), fmap2, None
 
 
 def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, order=None):
@@ -188,27 +251,32 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
     per = Dm * Dm * P * P
     if out is None:
         out = torch.empty(B, E, per * nl, dtype=fmap1.dtype, device=fmap1.device)
-    pyramid = [_fast_layout(f, B * E) if f.is_cuda else f for f in pyramid]
+    raw = pyramid
+    fused = nl == 2 and B * E > 0 and pyramid[0].dtype == pyramid[1].dtype and pyramid[0].dtype in (torch.float32, torch.float16) and fmap1.is_cuda
+    f1t = _patch_operand(fmap1.contiguous(), fmap1.shape[2], P) if fused else None
+    # (fp32: the split-blocked copies only when the dense-product kernel will take the call; the exact kernels read the raw levels)
+    pyramid = [_fast_layout(f, B * E, allow_split=f1t is not None) if f.is_cuda else f for f in pyramid]
+    if fused and isinstance(pyramid[0], SplitLevel) != isinstance(pyramid[1], SplitLevel):
+        pyramid = [_fast_layout(f, B * E, allow_split=False) for f in raw]
     if order is None and B * E >= PLAN_MIN_EDGES:
         order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius)
-    if nl == 2 and B * E > 0 and pyramid[0].dtype == pyramid[1].dtype and pyramid[0].dtype in (torch.float32, torch.float16):
-        f1, f2a, c_, ii_, jj_ = _prep(fmap1, pyramid[0], coords, ii, jj, allow_blocked=True)
-        _prep(fmap1, pyramid[1], coords, ii, jj, allow_blocked=True)
+    if fused:
+        f1, f2a, c_, ii_, jj_ = _prep(fmap1, raw[0], coords, ii, jj, allow_blocked=True)
+        _prep(fmap1, raw[1], coords, ii, jj, allow_blocked=True)
         C, Np = f1.shape[2], f1.shape[1]
         d0, d1 = _level_desc(pyramid[0], C), _level_desc(pyramid[1], C)
         hw = (ctypes.c_int * 4)(d0[0], d0[1], d1[0], d1[1])
         cb = (ctypes.c_int * 2)(d0[3], d1[3])
         cd = (ctypes.c_float * 2)(float(scales[0]), float(scales[1]))
-        f1t = _patch_operand(f1, C, P)
-        rc = L.lib().devo_corr_forward_pyramid2(L.ptr(f1), L.ptr(pyramid[0]), L.ptr(pyramid[1]), L.ptr(c_), L.ptr(ii_), L.ptr(jj_),
+        rc = L.lib().devo_corr_forward_pyramid2(L.ptr(f1), L.ptr(d0[4]), L.ptr(d1[4]), L.ptr(c_), L.ptr(ii_), L.ptr(jj_),
                                                 L.ptr(out), B, E, Np, pyramid[0].shape[1], C, P, hw, L.i64arr(d0[2] + d1[2]), cb,
                                                 per * nl, nl, L.i64arr([0, 1]), int(radius), L.dtype_code(f1), L.ptr(order), cd,
-                                                L.ptr(f1t), L.stream())
+                                                L.ptr(f1t), L.ptr(d0[5]), L.ptr(d1[5]), L.stream())
         if rc == 0:
             return out
         if rc != 3:                                             # DEVO_ERR_UNSUPPORTED: fall through to one launch per level
             L.check(rc, "cuda_corr.forward_pyramid")
-    for lvl, (fm, s) in enumerate(zip(pyramid, scales)):
+    for lvl, (fm, s) in enumerate(zip(raw, scales)):
         forward_into(out, fmap1, fm, coords, ii, jj, radius, per * nl, nl, lvl, order=order, coord_div=s)
     return out
 

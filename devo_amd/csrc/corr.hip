@@ -167,6 +167,8 @@ struct CorrLevel {
   bool mm_ok;                     // ... and the dense-product kernel (corr_mm.h)
   int64_t out_offset;             // element offset of this level inside an edge's output record
   float coord_div;                // coordinates are divided by this (pyramid level scale)
+  bool split;                     // fp32 level in the split-blocked format of devo_corr_pyramid_split (only the dense-product kernel reads it)
+  const int* exps;                // ... its scale exponent per (batch, frame)
 };
 
 // nlev == 1: workgroup g -> edge slot g of level 0.  nlev == 2 (fused pyramid lookup): the two levels alternate in
@@ -897,11 +899,20 @@ static bool corr_mfma_enabled() {                // DEVO_CORR_MFMA=0: fp32 looku
 
 template <typename T>
 static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t* f2s, int cblock, int64_t out_offset,
-                         float coord_div, CorrLevel* lv, int* err) {
+                         float coord_div, CorrLevel* lv, int* err, const int* exps = nullptr) {
   // channel-blocked storage [.., C/cb, H, W, cb]: f2s[2] is the stride between channel blocks, the cb channels of a
   // pixel are contiguous.  The staged kernel wants cb == its channel chunk (8), the matrix-core kernel any multiple of 4.
-  const bool blocked = cblock > 1;
+  // cblock == DEVO_CBLOCK_SPLIT8 (fp32 only): the split-blocked format of devo_corr_pyramid_split — the strides of an 8-channel
+  // blocked level, every 32-byte pixel block holding fp16 (hi0..7 | lo0..7) — which only the dense-product kernel reads.
+  const bool split = cblock == DEVO_CBLOCK_SPLIT8;
   *err = DEVO_OK;
+  if (split && (sizeof(T) != 4 || exps == nullptr)) {
+    set_error("devo_corr_forward: the split-blocked format is an fp32 format and needs its scale exponents");
+    *err = DEVO_ERR_ARG;
+    return false;
+  }
+  if (split) cblock = 8;
+  const bool blocked = cblock > 1;
   const int64_t v = 16 / sizeof(T);
   const int cb = blocked ? cblock : C;
   const long long plane_bytes = ((long long)(H2 - 1) * f2s[3] + (long long)(W2 - 1) * f2s[4] + (blocked ? cb : C)) * (long long)sizeof(T);
@@ -909,15 +920,18 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
   const bool aligned = sizeof(T) <= 4 && (blocked || f2s[2] == 1) && (f2s[3] % v == 0) && (f2s[4] % v == 0) && (f2s[0] % v == 0) &&
                        (f2s[1] % v == 0) && (!blocked || f2s[2] % v == 0) && ((reinterpret_cast<uintptr_t>(fmap2) & 15) == 0) &&
                        f2s[3] >= 0 && f2s[4] >= 0 && (!blocked || (f2s[2] >= 0 && C % cb == 0));
-  lv->staged_ok = aligned && (C % KC == 0) && (!blocked || cblock == KC) && plane_bytes < (1LL << 31);   // 32-bit in-plane offsets
+  lv->staged_ok = !split && aligned && (C % KC == 0) && (!blocked || cblock == KC) && plane_bytes < (1LL << 31);   // 32-bit in-plane offsets
   // the matrix-core kernel: C = 128, 16-byte pieces inside a channel block, piece offsets linear in the step
   const bool cb_ok = !blocked || (sizeof(T) == 4 ? (cb == 4 || cb == 8 || cb == 16) : (cb == 8 || cb == 16 || cb == 32));
   const bool c_ok = sizeof(T) == 4 ? (C == 64 || C == 128) : (C == 128 || C == 256);            // 4 or 8 steps per pass
-  lv->mfma_ok = aligned && sizeof(T) <= 4 && corr_mfma_enabled() && c_ok && cb_ok &&
+  lv->mfma_ok = !split && aligned && sizeof(T) <= 4 && corr_mfma_enabled() && c_ok && cb_ok &&
                 frame_bytes < (1LL << 31);                                                             // 32-bit in-frame offsets
-  // the dense-product kernel (corr_mm.h): 16-byte pieces of 8 (fp16) / 4 (fp32) channels inside a channel block, 32 channels per K step
-  lv->mm_ok = lv->mfma_ok && C % 32 == 0 && (sizeof(T) == 2 ? C <= 256 : C <= 128);
-  if (!lv->staged_ok && !lv->mfma_ok) {
+  // the dense-product kernel (corr_mm.h): 16-byte pieces of 8 channels inside a channel block, 32 channels per K step; fp16 levels as
+  // they are, fp32 levels in the split-blocked format only (raw fp32 levels take the 4x4 matrix-core kernel: exact fp32 products)
+  lv->mm_ok = aligned && frame_bytes < (1LL << 31) && C % 32 == 0 &&
+              (sizeof(T) == 2 ? (lv->mfma_ok && C <= 256) : (sizeof(T) == 4 && split && corr_mfma_enabled() && C <= 128));
+  lv->split = split; lv->exps = exps;
+  if (!lv->staged_ok && !lv->mfma_ok && !lv->mm_ok) {
     if (blocked) {
       set_error("devo_corr_forward: channel-blocked fmap2 needs fp32 / fp16, 16-byte aligned strides and cblock == %d (got %d)", KC, cblock);
       *err = DEVO_ERR_UNSUPPORTED;
@@ -939,6 +953,10 @@ template <typename T>
 static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLevel& lv1, int nlev, const float* coords,
                          const int64_t* ii, const int64_t* jj, void* out, long long BE, int E, int Np, int n2, int C,
                          int64_t oes, int64_t ols, int R, const int* order, hipStream_t st) {
+  if (lv0.split || (nlev == 2 && lv1.split)) {
+    set_error("devo_corr_forward: a split-blocked level is only readable by the dense-product kernel (needs fmap1_t, out_lstride > 0, both levels split-blocked)");
+    return DEVO_ERR_UNSUPPORTED;
+  }
   const unsigned per_level = (nlev == 2) ? (unsigned)((BE + 7) / 8 * 8) : (unsigned)BE;      // whole groups of 8 alternate
   dim3 grid(per_level * nlev), block(WPB * 64);
   static const bool force4 = getenv("DEVO_CORR_NP4") != nullptr;      // debug switch: run the r > 3 instantiation
@@ -1035,7 +1053,9 @@ static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel&
                      const int* order, hipStream_t st) {
   typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;
   typedef void (*mm_fn_t)(const MT*, CorrLevel, CorrLevel, int, const float*, const int64_t*, const int64_t*, MT*, int, int, int, int, int,
-                          int64_t, int64_t, int, const int*, int, unsigned long long*);
+                          int64_t, int64_t, int, const int*, int, unsigned long long*, const int*);
+  // fp32: the patch operand's scale exponents sit behind its records (devo_corr_patch_operand_bytes)
+  const int* exp1 = sizeof(MT) == 4 ? reinterpret_cast<const int*>(static_cast<const char*>(fmap1_t) + (size_t)(BE / E) * Np * C * PP * 4) : nullptr;
   const int nks = C / 32;
   mm_fn_t fn = nullptr;
 #define DEVO_MM_PICK_L(NKS, NLV) (R == 3 ? corr_fwd_mm_kernel<MT, 3, NKS, NLV, 3> : R == 5 ? corr_fwd_mm_kernel<MT, 5, NKS, NLV, 5> : \
@@ -1051,7 +1071,7 @@ static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel&
   if (do_trace) { (void)hipMalloc(&trace, (size_t)BE * 64); (void)hipMemset(trace, 0, (size_t)BE * 64); }
   const unsigned nwg = DEVO_MM_EPW == 1 ? (unsigned)BE : (unsigned)(((BE + DEVO_MM_EPW - 1) / DEVO_MM_EPW + 7) / 8 * 8);   // whole groups of 8 (one per XCD)
   hipLaunchKernelGGL(fn, dim3(nwg), dim3(64 * DEVO_MM_EPW), 0, st, (const MT*)fmap1_t, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C,
-                     oes, ols, R, order, 0, trace);
+                     oes, ols, R, order, 0, trace, exp1);
   if (do_trace) {
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)BE * 8);
@@ -1083,17 +1103,18 @@ template <typename T>
 static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                            const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int H2, int W2,
                            const int64_t* f2s, int cblock, int64_t oes, int64_t ols, int64_t ooff, int R, const int* order,
-                           float coord_div, const void* fmap1_t, hipStream_t st) {
+                           float coord_div, const void* fmap1_t, const int* fmap2_exps, hipStream_t st) {
   const long long BE = (long long)B * E;
   CorrLevel lv;
   int err;
-  if (staged_level<T>(fmap2, C, H2, W2, f2s, cblock, ooff, coord_div, &lv, &err)) {
+  if (staged_level<T>(fmap2, C, H2, W2, f2s, cblock, ooff, coord_div, &lv, &err, fmap2_exps)) {
     if constexpr (!std::is_same<T, double>::value)
       if (ols > 0 && mm_eligible<T>(lv, lv, fmap1_t, BE, Np, C))
         return launch_mm<T>(fmap1_t, lv, lv, 1, coords, ii, jj, out, BE, E, Np, n2, C, oes, ols, R, order, st);
     return launch_staged<T>(fmap1, lv, lv, 1, coords, ii, jj, out, BE, E, Np, n2, C, oes, ols, R, order, st);
   }
   if (err) return err;
+  if (cblock == DEVO_CBLOCK_SPLIT8) { set_error("devo_corr_forward: split-blocked fmap2 not readable (fp32, C %% 32 == 0, C <= 128, aligned strides)"); return DEVO_ERR_UNSUPPORTED; }
   dim3 grid((unsigned)BE), block(NT);
   hipLaunchKernelGGL(corr_fwd_generic_kernel<T>, grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii,
                      jj, (T*)out, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], oes, ols, ooff, R, coord_div);
@@ -1102,24 +1123,33 @@ static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* co
 
 extern "C" {
 
+size_t devo_corr_patch_operand_bytes(int n_patches, int C, int dtype) {
+  if (n_patches < 0 || C <= 0 || C % 8 != 0) return 0;
+  if (dtype == DEVO_F16) return (size_t)n_patches * C * PP * 2;
+  if (dtype == DEVO_F32) return (size_t)n_patches * C * PP * 4 + (size_t)n_patches * 4;      // split records | one scale exponent per patch
+  return 0;
+}
+
 int devo_corr_patch_transpose(const void* fmap1, void* fmap1_t, int n_patches, int C, int dtype, devo_stream_t stream) {
-  DEVO_REQUIRE(n_patches >= 0 && C > 0 && C % 4 == 0, "devo_corr_patch_transpose: bad sizes (C must be a multiple of 4)");
+  DEVO_REQUIRE(n_patches >= 0 && C > 0 && C % 8 == 0, "devo_corr_patch_transpose: bad sizes (C must be a multiple of 8)");
   DEVO_REQUIRE(dtype == DEVO_F32 || dtype == DEVO_F16, "devo_corr_patch_transpose: fp32 / fp16 only");
   if (n_patches == 0) return DEVO_OK;
   DEVO_REQUIRE(fmap1 && fmap1_t, "devo_corr_patch_transpose: null tensor");
   const size_t lds = (size_t)C * PP * (dtype == DEVO_F32 ? 4 : 2);
   DEVO_REQUIRE(lds <= 48 * 1024, "devo_corr_patch_transpose: C = %d too large", C);
   if (dtype == DEVO_F32)
-    hipLaunchKernelGGL(corr_patch_transpose_kernel<float>, dim3((unsigned)n_patches), dim3(256), lds, (hipStream_t)stream, (const float*)fmap1, (float*)fmap1_t, n_patches, C);
+    hipLaunchKernelGGL(corr_patch_transpose_kernel<float>, dim3((unsigned)n_patches), dim3(256), lds, (hipStream_t)stream, (const float*)fmap1, (float*)fmap1_t,
+                       reinterpret_cast<int*>(static_cast<char*>(fmap1_t) + (size_t)n_patches * C * PP * 4), n_patches, C);
   else
-    hipLaunchKernelGGL(corr_patch_transpose_kernel<__half>, dim3((unsigned)n_patches), dim3(256), lds, (hipStream_t)stream, (const __half*)fmap1, (__half*)fmap1_t, n_patches, C);
+    hipLaunchKernelGGL(corr_patch_transpose_kernel<__half>, dim3((unsigned)n_patches), dim3(256), lds, (hipStream_t)stream, (const __half*)fmap1, (__half*)fmap1_t,
+                       (int*)nullptr, n_patches, C);
   return check_launch("devo_corr_patch_transpose");
 }
 
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
                       const int64_t* f2s, int cblock, int64_t out_estride, int64_t out_lstride, int64_t out_offset,
-                      int radius, int dtype, const int* order, float coord_div, const void* fmap1_t, devo_stream_t stream) {
+                      int radius, int dtype, const int* order, float coord_div, const void* fmap1_t, const int* fmap2_exps, devo_stream_t stream) {
   DEVO_REQUIRE(P == 3, "devo_corr_forward: patch size P must be 3 (got %d)", P);
   DEVO_REQUIRE(coord_div > 0.0f, "devo_corr_forward: coord_div must be positive");
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_forward: radius %d unsupported (max 5)", radius);
@@ -1128,9 +1158,9 @@ int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords,
   if ((long long)B * E == 0) return DEVO_OK;
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case DEVO_F32: return launch_corr_fwd<float>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, fmap1_t, st);
-    case DEVO_F16: return launch_corr_fwd<__half>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, fmap1_t, st);
-    case DEVO_F64: return launch_corr_fwd<double>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, fmap1_t, st);
+    case DEVO_F32: return launch_corr_fwd<float>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, fmap1_t, fmap2_exps, st);
+    case DEVO_F16: return launch_corr_fwd<__half>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, fmap1_t, fmap2_exps, st);
+    case DEVO_F64: return launch_corr_fwd<double>(fmap1, fmap2, coords, ii, jj, out, B, E, Np, n2, C, H2, W2, f2s, cblock, out_estride, out_lstride, out_offset, radius, order, coord_div, fmap1_t, fmap2_exps, st);
   }
   set_error("devo_corr_forward: unknown dtype %d", dtype);
   return DEVO_ERR_UNSUPPORTED;
@@ -1141,7 +1171,8 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
                                const int* hw /* host: H0, W0, H1, W1 */, const int64_t* f2s /* host: 5 + 5 */,
                                const int* cblock /* host, 2 */, int64_t out_estride, int64_t out_lstride,
                                const int64_t* out_offset /* host, 2 */, int radius, int dtype, const int* order,
-                               const float* coord_div /* host, 2 */, const void* fmap1_t, devo_stream_t stream) {
+                               const float* coord_div /* host, 2 */, const void* fmap1_t, const int* fmap2_exps_l0, const int* fmap2_exps_l1,
+                               devo_stream_t stream) {
   DEVO_REQUIRE(P == 3, "devo_corr_forward_pyramid2: patch size P must be 3 (got %d)", P);
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_forward_pyramid2: radius %d unsupported (max 5)", radius);
   DEVO_REQUIRE(hw && f2s && cblock && out_offset && coord_div, "devo_corr_forward_pyramid2: missing level description");
@@ -1154,8 +1185,9 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
   bool ok = false;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DEVO_F32) {
-    ok = staged_level<float>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0) &&
-         staged_level<float>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
+    ok = staged_level<float>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0, fmap2_exps_l0) &&
+         staged_level<float>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1, fmap2_exps_l1);
+    if (e0 == DEVO_ERR_ARG || e1 == DEVO_ERR_ARG) return DEVO_ERR_ARG;
     if (ok && out_lstride > 0 && mm_eligible<float>(l0, l1, fmap1_t, BE, Np, C))
       return launch_mm<float>(fmap1_t, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
     if (ok) return launch_staged<float>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
@@ -1169,6 +1201,24 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
   // not both levels readable by the staged kernel: the caller issues one devo_corr_forward per level instead
   set_error("devo_corr_forward_pyramid2: levels not eligible for the fused launch (layout / dtype)");
   return DEVO_ERR_UNSUPPORTED;
+}
+
+int devo_corr_pyramid_split(const void* fmap2, const int64_t* f2s, int cblock, int F, int C, int H, int W, void* dst, int64_t dst_fstride,
+                            int* exps, devo_stream_t stream) {
+  DEVO_REQUIRE(F >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "devo_corr_pyramid_split: bad sizes (C must be a multiple of 8)");
+  DEVO_REQUIRE(f2s != nullptr && cblock >= 0 && (cblock <= 1 || C % cblock == 0), "devo_corr_pyramid_split: bad layout description");
+  if (F == 0) return DEVO_OK;
+  DEVO_REQUIRE(fmap2 && dst && exps, "devo_corr_pyramid_split: null tensor");
+  DEVO_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && dst_fstride % 4 == 0 && dst_fstride >= (int64_t)C * H * W, "devo_corr_pyramid_split: dst must be 16-byte aligned frames of C*H*W elements");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* maxbits = reinterpret_cast<unsigned*>(exps + F);
+  if (hipMemsetAsync(maxbits, 0, (size_t)F * 4, st) != hipSuccess) { (void)hipGetLastError(); set_error("devo_corr_pyramid_split: memset failed"); return DEVO_ERR_LAUNCH; }
+  const SplitSrc S{f2s[0], f2s[1], f2s[2], f2s[3], cblock};
+  const long long per = (long long)(C / 8) * H * W;
+  const dim3 grid((unsigned)std::min<long long>((per + 255) / 256, 2048), (unsigned)F);
+  hipLaunchKernelGGL(corr_split_max_kernel, grid, dim3(256), 0, st, (const float*)fmap2, S, C, H, W, maxbits);
+  hipLaunchKernelGGL(corr_split_kernel, grid, dim3(256), 0, st, (const float*)fmap2, S, C, H, W, (const unsigned*)maxbits, (float*)dst, dst_fstride, exps);
+  return check_launch("devo_corr_pyramid_split");
 }
 
 int devo_pyramid_build(const void* fmap, void* l0, void* l1, int F, int C, int H, int W, int64_t fmap_fstride,

@@ -50,56 +50,106 @@ typedef float mm_f4 __attribute__((ext_vector_type(4)));
 #define DEVO_MM_SYNC 0
 #endif
 
-// split of 8 fp32 values into fp16 hi and lo halves, x = hi + lo to 2^-22 (|lo| below the fp16 normal range keeps 2^-25 absolute):
-// hi = rn(x) (v_cvt_pk_f16_f32, two values per instruction), lo = rn(x - hi) (v_fma_mix: fp32 arithmetic on the fp16 hi): 12 instructions
-__device__ __forceinline__ void mm_split8(const v4u32 a, const v4u32 b, mm_h8& hi, mm_h8& lo) {
+// fp32 operands are stored pre-split ("split" formats, written once per version of the tensor by devo_corr_patch_transpose /
+// devo_corr_pyramid_split): a value x of a group with scale exponent e (per patch / per frame, chosen so that the group's largest
+// magnitude lands in [2^13, 2^14)) is the fp16 pair  hi = rn(x 2^-e),  lo = rn(x 2^-e - hi):  x 2^-e = hi + lo to 2^-22 relative (a lo below
+// fp16's normal range keeps 2^-25 absolute, i.e. 2^-39 of the group's largest magnitude).  The power-of-two scaling is exact, no input
+// magnitude overflows fp16, and the kernel multiplies the blended sums by 2^(e_patch + e_frame) at the end (folded into the blend weights).
+// (v_cvt_pk_f16_f32: two values per instruction; v_fma_mix: fp32 arithmetic on the fp16 hi.)
+__device__ __forceinline__ void mm_split2(float a, float b, unsigned& h, unsigned& l) {
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+  // (mixlo keeps the destination's upper half, which mixhi then overwrites: no initialisation needed)
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
+}
+// 8 fp32 values, scaled by 2^-e -> the 32-byte split record (hi0..7 | lo0..7)
+__device__ __forceinline__ void mm_split8_scaled(const float* x, int e, v4u32& hi, v4u32& lo) {
   unsigned h[4], l[4];
-  const unsigned x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h[j]) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
-    // (mixlo keeps the destination's upper half, which mixhi then overwrites: no initialisation needed)
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[j]) : "v"(h[j]), "v"(x[2 * j]));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[j]) : "v"(h[j]), "v"(x[2 * j + 1]));
-  }
-  const v4u32 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
-  hi = __builtin_bit_cast(mm_h8, hv);
-  lo = __builtin_bit_cast(mm_h8, lv);
+  for (int j = 0; j < 4; j++) mm_split2(ldexpf(x[2 * j], -e), ldexpf(x[2 * j + 1], -e), h[j], l[j]);
+  hi = v4u32{h[0], h[1], h[2], h[3]};
+  lo = v4u32{l[0], l[1], l[2], l[3]};
+}
+// scale exponent of a group whose largest magnitude has the fp32 bit pattern `maxbits` (sign cleared): floor(log2(max)) - 13
+// (zero / denormal groups: as if the largest magnitude were 2^-126; inf / nan: the largest finite exponent — the values propagate)
+__host__ __device__ __forceinline__ int mm_scale_exp(unsigned maxbits) {
+  const int ef = (int)((maxbits >> 23) & 0xffu);
+  return (ef == 0 ? -126 : (ef == 255 ? 127 : ef - 127)) - 13;
 }
 
-// 4 fp32 values -> fp16 (hi0..3 | lo0..3), x = hi + lo to 2^-22: the patch operand's stored form
-__device__ __forceinline__ mm_h8 mm_split4(mm_f4 x) {
-  unsigned h01, h23, l01, l23;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(x[0]), "v"(x[1]));
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(x[2]), "v"(x[3]));
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(x[0]));
-  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(x[1]));
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(x[2]));
-  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(x[3]));
-  const v4u32 r = {h01, h23, l01, l23};
-  return __builtin_bit_cast(mm_h8, r);
-}
-
-// fmap1 [N][C][9] -> [N][9][C], the patch (B) operand of corr_fwd_mm_kernel: 16 contiguous bytes per (pixel, 4 | 8 channels).  fp32: every
-// group of 4 channels is stored as fp16 (hi0..3 | lo0..3), x = hi + lo — the form the kernel multiplies (same 16 bytes).
+// fmap1 [N][C][9] -> the patch (B) operand of corr_fwd_mm_kernel.  fp16: [N][9][C], 16 contiguous bytes per (pixel, 8 channels).
+// fp32: [N][9][C / 8][hi0..7 | lo0..7] split records (32 bytes per pixel and 8 channels) with ONE scale exponent per patch, written to
+// exps[n] (the int32 tail of the operand buffer).
 template <typename T>
-__global__ __launch_bounds__(256) void corr_patch_transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int C) {
+__global__ __launch_bounds__(256) void corr_patch_transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int* __restrict__ exps, int N, int C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pt_lds[];
   T* s = reinterpret_cast<T*>(pt_lds);
   const int n = blockIdx.x;
   if (n >= N) return;
   const T* in = src + (int64_t)n * C * PP;
   T* o = dst + (int64_t)n * C * PP;
-  for (int i = threadIdx.x; i < C * PP; i += 256) s[i] = in[i];
-  __syncthreads();
   if constexpr (sizeof(T) == 2) {
+    for (int i = threadIdx.x; i < C * PP; i += 256) s[i] = in[i];
+    __syncthreads();
     for (int i = threadIdx.x; i < C * PP; i += 256) { const int p = i / C, c = i - p * C; o[i] = s[c * PP + p]; }
   } else {
-    for (int i = threadIdx.x; i < (C / 4) * PP; i += 256) {
-      const int p = i / (C / 4), c4 = i - p * (C / 4);
-      const mm_f4 x = {(float)s[(4 * c4) * PP + p], (float)s[(4 * c4 + 1) * PP + p], (float)s[(4 * c4 + 2) * PP + p], (float)s[(4 * c4 + 3) * PP + p]};
-      reinterpret_cast<mm_h8*>(o)[i] = mm_split4(x);
+    __shared__ unsigned s_max;
+    if (threadIdx.x == 0) s_max = 0u;
+    __syncthreads();
+    unsigned mx = 0u;
+    for (int i = threadIdx.x; i < C * PP; i += 256) { const T v = in[i]; s[i] = v; mx = max(mx, __float_as_uint((float)v) & 0x7fffffffu); }
+    atomicMax(&s_max, mx);
+    __syncthreads();
+    const int e = mm_scale_exp(s_max);
+    if (threadIdx.x == 0) exps[n] = e;
+    for (int i = threadIdx.x; i < (C / 8) * PP; i += 256) {
+      const int p = i / (C / 8), c8 = i - p * (C / 8);
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) x[j] = (float)s[(8 * c8 + j) * PP + p];
+      v4u32 hi, lo;
+      mm_split8_scaled(x, e, hi, lo);
+      reinterpret_cast<v4u32*>(o)[2 * i] = hi;
+      reinterpret_cast<v4u32*>(o)[2 * i + 1] = lo;
     }
+  }
+}
+
+// fp32 pyramid in any strided layout -> the split-blocked format [F][C / 8][H][W][hi0..7 | lo0..7] (the byte layout of a channel-blocked
+// fp32 level with 8 channels per block: 32 bytes per pixel and block), one scale exponent per frame.  Pass 1: the frames' largest
+// magnitudes (bit patterns, atomicMax) into maxbits[F]; pass 2: the records, exps[f] = the frame's exponent.
+struct SplitSrc { int64_t s_n, s_c, s_h, s_w; int cb; };     // element strides of frame, channel (block), row, column; cb > 1: cb channels contiguous per block
+__device__ __forceinline__ int64_t mm_src_ch(const SplitSrc& S, int c) { return S.cb > 1 ? (int64_t)(c / S.cb) * S.s_c + (c % S.cb) : (int64_t)c * S.s_c; }
+__global__ __launch_bounds__(256) void corr_split_max_kernel(const float* __restrict__ src, SplitSrc S, int C, int H, int W, unsigned* __restrict__ maxbits) {
+  const int f = blockIdx.y;
+  const long long per = (long long)(C / 8) * H * W;
+  unsigned mx = 0u;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), blk = (int)(i / ((long long)W * H));
+    const float* p = src + (int64_t)f * S.s_n + (int64_t)y * S.s_h + (int64_t)x * S.s_w;
+#pragma unroll
+    for (int j = 0; j < 8; j++) mx = max(mx, __float_as_uint(p[mm_src_ch(S, 8 * blk + j)]) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+  if ((threadIdx.x & 63) == 0 && mx != 0u) atomicMax(&maxbits[f], mx);
+}
+__global__ __launch_bounds__(256) void corr_split_kernel(const float* __restrict__ src, SplitSrc S, int C, int H, int W, const unsigned* __restrict__ maxbits,
+                                                         float* __restrict__ dst, int64_t dst_fstride, int* __restrict__ exps) {
+  const int f = blockIdx.y;
+  const long long per = (long long)(C / 8) * H * W;
+  const int e = mm_scale_exp(maxbits[f]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) exps[f] = e;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), blk = (int)(i / ((long long)W * H));
+    const float* p = src + (int64_t)f * S.s_n + (int64_t)y * S.s_h + (int64_t)x * S.s_w;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = p[mm_src_ch(S, 8 * blk + j)];
+    v4u32 hi, lo;
+    mm_split8_scaled(v, e, hi, lo);
+    v4u32* o = reinterpret_cast<v4u32*>(dst + (int64_t)f * dst_fstride + i * 8);
+    o[0] = hi; o[1] = lo;
   }
 }
 
@@ -119,7 +169,7 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
     const T* __restrict__ fmap1_t, CorrLevel lv0, CorrLevel lv1, int nlev, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int64_t out_estride, int64_t out_lstride, int R_arg, const int* __restrict__ order, int heavy_only,
-    unsigned long long* __restrict__ trace) {
+    unsigned long long* __restrict__ trace, const int* __restrict__ exp1) {
   const int R = RFIX > 0 ? RFIX : R_arg;        // (DEVO's radius 3 and the stress configuration's 5 as constants: window sizes, loop bounds and
                                                 //  the epilogue's guards fold away)
   constexpr bool HALF = sizeof(T) == 2;
@@ -169,6 +219,15 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
   const int b = be / E, e = be - b * E;
   const int64_t pi = ii[e];
   const int64_t fj = jj[e];
+  // fp32 (split records): the sums come out scaled by 2^-(e_patch + e_frame); the blend weights carry the inverse (exact powers of two)
+  int sexp[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) sexp[l] = 0;
+  if constexpr (sizeof(T) == 4) {
+    const int e1 = exp1 ? exp1[(int64_t)b * Np + pi] : 0;
+#pragma unroll
+    for (int l = 0; l < NL; l++) { const int* ex = LVF(l, exps); sexp[l] = e1 + (ex ? ex[(int64_t)b * n2 + fj] : 0); }
+  }
 
   // ---- geometry.  Lane 16 l + p owns patch pixel p at level index l: both levels are worked out side by side (the 18 coordinates
   //      come through the scalar cache and are written into both lane groups)
@@ -265,33 +324,30 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
   const int mi = lane & 15, kg = lane >> 4;                // A: row (position) / K group.  B, D: column (pixel) / K group, row group
 
   // Channel c of a position sits at byte  piece(c) = block(c) * block_bytes + (c % cb) * ESZ  behind the position's offset.
-  // fp16: lane piece = channels 8 kg .. + 7 of the step (32 channels);  fp32: two pieces, channels 4 kg .. + 3 and 16 + 4 kg .. + 3
-  // (so that ONE instruction covers 16 consecutive channels = 64 bytes of each of its 16 positions).
+  // Lane piece = channels 8 kg .. + 7 of the step (32 channels): fp16 16 bytes; fp32 (split records, 8 channels per block): the
+  // block's 16 bytes of hi halves, the lo halves 16 bytes behind them (`second`).
   struct Pieces { unsigned step, lane0, second; };
   auto pieces_of = [&](int l) -> Pieces {
     const int sh = LVF(l, cb_shift);
     const unsigned bb = (unsigned)LVF(l, block_stride) * ESZ;
     auto piece = [&](unsigned c) -> unsigned { const unsigned blk = c >> sh; return blk * bb + (c - (blk << sh)) * ESZ; };
-    return Pieces{piece(32), piece(HALF ? 8u * (unsigned)kg : 4u * (unsigned)kg), piece(16)};
+    return Pieces{piece(32), piece(8u * (unsigned)kg), 16u};
   };
 
-  // ---- B operand: the patch, channels 32 s + (8 kg .. + 7 | 4 kg .. + 3, 16 + 4 kg .. + 3) of pixel mi (columns >= 9: zeros)
+  // ---- B operand: the patch, channels 32 s + 8 kg .. + 7 of pixel mi (columns >= 9: zeros); fp32: hi and lo halves of the split record
   mm_h8 bh[NKS], bl[HALF ? 1 : NKS];
   {
     const T* __restrict__ f1 = fmap1_t + ((int64_t)b * Np + pi) * C * PP;           // [9][C]
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(f1), 0, (unsigned)(C * PP) * ESZ, 0x00020000);
-    const unsigned boff = mi < PP ? (unsigned)(mi * C + (HALF ? 8 : 4) * kg) * ESZ : OFF_NONE;
+    const unsigned boff = mi < PP ? (unsigned)(mi * C + 8 * kg) * ESZ : OFF_NONE;
 #pragma unroll
     for (int s = 0; s < NKS; s++) {
       if constexpr (HALF) {
         bh[s] = __builtin_bit_cast(mm_h8, __builtin_amdgcn_raw_buffer_load_b128(rs1, boff, (unsigned)s * 64u, 0));
       } else {
-        // fp32 patches arrive split already (devo_corr_patch_transpose): every 4 channels as 16 bytes of fp16 (hi0..3 | lo0..3)
-        const v4u32 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs1, boff, (unsigned)s * 128u, 0);
-        const v4u32 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs1, boff, (unsigned)s * 128u + 64u, 0);
-        const v4u32 hv = {v0.x, v0.y, v1.x, v1.y}, lv = {v0.z, v0.w, v1.z, v1.w};
-        bh[s] = __builtin_bit_cast(mm_h8, hv);
-        bl[s] = __builtin_bit_cast(mm_h8, lv);
+        // fp32 patches arrive as split records (devo_corr_patch_transpose): every 8 channels as 32 bytes of fp16 (hi0..7 | lo0..7)
+        bh[s] = __builtin_bit_cast(mm_h8, __builtin_amdgcn_raw_buffer_load_b128(rs1, boff, (unsigned)s * 128u, 0));
+        bl[s] = __builtin_bit_cast(mm_h8, __builtin_amdgcn_raw_buffer_load_b128(rs1, boff, (unsigned)s * 128u + 16u, 0));
       }
     }
   }
@@ -307,8 +363,7 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
       if constexpr (HALF) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mm_h8, rb[r][s][0]), bh[s], acc, 0, 0, 0);
       } else {
-        mm_h8 ah, al;
-        mm_split8(rb[r][s][0], rb[r][s][1], ah, al);
+        const mm_h8 ah = __builtin_bit_cast(mm_h8, rb[r][s][0]), al = __builtin_bit_cast(mm_h8, rb[r][s][1]);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[s], acc, 0, 0, 0);       // small terms first
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[s], acc, 0, 0, 0);
@@ -338,6 +393,7 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
 #pragma clang fp contract(off)
       w0 = (1.0f - ge.x) * (1.0f - ge.y); w1 = ge.x * (1.0f - ge.y); w2 = (1.0f - ge.x) * ge.y; w3 = ge.x * ge.y;   // blend4's factors
     }
+    if constexpr (!HALF) { w0 = ldexpf(w0, sexp[l]); w1 = ldexpf(w1, sexp[l]); w2 = ldexpf(w2, sexp[l]); w3 = ldexpf(w3, sexp[l]); }
     const int rs = __float_as_int(ge.w);
 #pragma unroll
     for (int rd = 0; rd < NRND; rd++) {
@@ -390,6 +446,13 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
       const int gy = G.ymin + pyy, gx = G.xmin + (sl - __mul24(pyy, G.bw));
       const bool ok = sl < G.nslots && (unsigned)gy < (unsigned)LVF(l, H2) && (unsigned)gx < (unsigned)LVF(l, W2);
       const unsigned voff = ok ? (unsigned)gy * shb[l] + (unsigned)gx * swb[l] + lane_piece[l] : OFF_NONE;
+#ifdef DEVO_MM_DBG_NOL1      // timing experiment (wrong results): level index 1's tiles are not fetched at all (what a level read from LDS would leave of the addresser's time)
+      if (l == 1) {
+#pragma unroll
+        for (int s = 0; s < NKS; s++) { xr[ring][s][0] = v4u32{voff, voff ^ (unsigned)s, voff, voff}; if constexpr (!HALF) xr[ring][s][1] = v4u32{voff, voff, voff ^ (unsigned)s, voff}; }
+        return;
+      }
+#endif
 #pragma unroll
       for (int s = 0; s < NKS; s++) {
         xr[ring][s][0] = __builtin_amdgcn_raw_buffer_load_b128(rsl[l], voff, (unsigned)s * step_b[l], 0);

@@ -241,7 +241,7 @@ using namespace devo;
 
 extern "C" {
 
-int devo_abi_version(void) { return 1; }
+int devo_abi_version(void) { return DEVO_ABI_VERSION; }
 const char* devo_last_error(void) { return g_err; }
 
 int devo_se3_exp(const void* a, void* X, int64_t n, int dtype, devo_stream_t s) { SE3_DISPATCH("devo_se3_exp", k_exp, CP(a), MP(X), n); }

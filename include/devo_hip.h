@@ -27,6 +27,7 @@ typedef void* devo_stream_t; /* hipStream_t */
 enum { DEVO_OK = 0, DEVO_ERR_ARG = 1, DEVO_ERR_LAUNCH = 2, DEVO_ERR_UNSUPPORTED = 3, DEVO_ERR_WORKSPACE = 4 };
 enum { DEVO_F32 = 0, DEVO_F16 = 1, DEVO_F64 = 2 };
 
+#define DEVO_ABI_VERSION 2 /* 2: fp32 split formats (devo_corr_pyramid_split, exponents), group plans (plan buffer tail); callers compare with devo_abi_version() */
 int devo_abi_version(void);
 const char* devo_last_error(void); /* thread-local message of the last failing call */
 
@@ -47,18 +48,21 @@ const char* devo_last_error(void); /* thread-local message of the last failing c
  *             out_lstride = 2 and out_offset = level writes straight into the stacked
  *             [B, E, (D-1)^2*P*P, 2] buffer that devo/devo.py:217 / enet.py:216 build with torch.stack.)
  *   order  optional locality plan from devo_corr_order (NULL = process edges in list order).
- *   fmap1_t optional: fmap1 as devo_corr_patch_transpose lays it out.  With it, fp32 / fp16 lookups into channels-last or
- *          channel-blocked storage with C % 32 == 0 (fp32: C <= 128, fp16: C <= 256) run as one dense product per edge on
- *          v_mfma_f32_16x16x32_f16 (csrc/corr_mm.h; fp32 values enter as exact fp16 hi + lo pairs: 2^-22 relative per factor, fp32
- *          accumulation).  NULL: the 4x4 matrix-core kernel with exact fp32 products (csrc/corr_mfma.h) or, for other layouts, the
- *          staged / generic kernels. */
+ *   fmap1_t optional: fmap1 as devo_corr_patch_transpose lays it out.  With it, fp16 lookups into channels-last or channel-blocked
+ *          storage (C = 128 / 256) and fp32 lookups into SPLIT-BLOCKED storage (cblock = DEVO_CBLOCK_SPLIT8, devo_corr_pyramid_split;
+ *          C % 32 == 0, C <= 128) run as one dense product per edge on v_mfma_f32_16x16x32_f16 (csrc/corr_mm.h; fp32 values enter as
+ *          fp16 hi + lo pairs of the value scaled by a power of two per patch / frame: 2^-22 relative per factor at any magnitude, fp32
+ *          accumulation).  NULL, or raw fp32 storage: the 4x4 matrix-core kernel with exact fp32 products (csrc/corr_mfma.h) or, for
+ *          other layouts, the staged / generic kernels.
+ *   fmap2_exps: i32 [B * n2], the scale exponents devo_corr_pyramid_split wrote next to a split-blocked level (NULL otherwise). */
+#define DEVO_CBLOCK_SPLIT8 (-8)
 int devo_corr_forward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                       const int64_t* jj, void* out, int B, int E, int Np, int n2, int C, int P, int H2, int W2,
                       const int64_t* f2s /* host, 5 */, int cblock, int64_t out_estride, int64_t out_lstride,
                       int64_t out_offset, int radius, int dtype, const int* order /* plan buffer of devo_corr_order, i32 [2*B*E + 2], or NULL */,
                       float coord_div /* coords are divided by this in the kernel (correctly rounded IEEE division; pyramid level
                                          scale, 1 = as given; DEVO's scales 1 and 4 are exact either way) */,
-                      const void* fmap1_t, devo_stream_t stream);
+                      const void* fmap1_t, const int* fmap2_exps, devo_stream_t stream);
 
 /* Both levels of a 2-level pyramid lookup (devo/devo.py:215-217) in ONE launch: workgroups of the fine and the coarse
  * level alternate on every CU (the fine level waits on memory, the coarse one is LDS/VALU-bound), each writing its
@@ -73,13 +77,26 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
                                const float* coord_div /* host, 2 */,
                                const void* fmap1_t /* optional, as for devo_corr_forward: the dense-product kernel does both levels of an
                                                       edge in one wave */,
+                               const int* fmap2_exps_l0, const int* fmap2_exps_l1 /* scale exponents of split-blocked levels, or NULL */,
                                devo_stream_t stream);
 
-/* fmap1 T [n_patches, C, 3, 3] -> fmap1_t [n_patches, 9, C] elements of sizeof(T) bytes: the patch operand of the dense-product lookup
- * kernel, an opaque format — fp16: the transposed features; fp32: every 4 channels as fp16 (hi0..3 | lo0..3) with x = hi + lo, the
- * form the kernel multiplies (C % 4 == 0).  The patch features of DEVO change once per frame, not per update iteration: convert once,
- * reuse.  DEVO_F32 / DEVO_F16. */
+/* fmap1 T [n_patches, C, 3, 3] -> fmap1_t, the patch operand of the dense-product lookup kernel, an opaque buffer of
+ * devo_corr_patch_operand_bytes(n_patches, C, dtype) bytes (16-byte aligned) — fp16: the transposed features [n_patches, 9, C]; fp32:
+ * [n_patches, 9, C / 8] split records of 32 bytes, fp16 (hi0..7 | lo0..7) with x 2^-e = hi + lo, followed by one scale exponent e (i32) per
+ * patch (e puts the patch's largest magnitude into [2^13, 2^14): no magnitude overflows or underflows fp16).  C % 8 == 0.  The patch
+ * features of DEVO change once per frame, not per update iteration: convert once, reuse.  DEVO_F32 / DEVO_F16. */
+size_t devo_corr_patch_operand_bytes(int n_patches, int C, int dtype);
 int devo_corr_patch_transpose(const void* fmap1, void* fmap1_t, int n_patches, int C, int dtype, devo_stream_t stream);
+
+/* fp32 pyramid level -> the SPLIT-BLOCKED format the dense-product lookup kernel multiplies (no reference counterpart; the reference's
+ * kernel reads fp32 NCHW, correlation_kernel.cu:82-136).  F frames fmap2 f32 [F, C, H, W] in ANY layout: element strides f2s[4] = (frame,
+ * channel or channel block, row, column), cblock > 1 = channel-blocked with cblock contiguous channels per block, else plain strides.
+ * dst f32-sized [F, C/8, H, W, 8] (frame stride dst_fstride elements, 16-byte aligned): the strides of an 8-channel blocked level, every
+ * 32-byte pixel block holding fp16 (hi0..7 | lo0..7) with x 2^-e = hi + lo, e = exps[f] (one exponent per frame: its largest magnitude
+ * lands in [2^13, 2^14)).  exps i32 [2 F]: the exponents, then F ints of scratch.  Two launches (max, convert); the pyramid of DEVO
+ * changes once per frame, not per update iteration: convert once per version, pass cblock = DEVO_CBLOCK_SPLIT8 + exps to the lookups. */
+int devo_corr_pyramid_split(const void* fmap2, const int64_t* f2s /* host, 4 */, int cblock, int F, int C, int H, int W, void* dst,
+                            int64_t dst_fstride, int* exps, devo_stream_t stream);
 
 /* Locality plan for devo_corr_forward (no reference counterpart: the reference walks edges in list order).
  * order i32 [2*B*E + 2] (the plan buffer; devo_corr_forward reads the first B*E + 1 entries and the last one (number of DEAD edges at

@@ -27,7 +27,18 @@ def test_header_symbols_exported(libpath):
     assert len(names) >= 30
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/devo_hip.h but not exported"
-    assert lib.devo_abi_version() == 1
+    m = re.search(r"#define\s+DEVO_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "devo_hip.h")).read())
+    from devo_amd import _lib
+    assert lib.devo_abi_version() == int(m.group(1)) == _lib.ABI_VERSION      # header, library and ctypes table agree
+
+
+def test_stale_library_is_refused(libpath, monkeypatch):
+    """A library of another ABI version (argument lists differ between versions) must not be bound."""
+    from devo_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _lib.lib()
 
 
 def test_python_binding_covers_header(libpath):

@@ -640,3 +640,46 @@ def test_differentiable_fused_pyramid_lookup_matches_the_two_level_composition()
         outs.append([y.detach().clone(), g1.grad.clone(), pyr[0].grad.clone(), pyr[1].grad.clone()])
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6) + 1e-6
+
+
+@pytest.mark.parametrize("case", ["x4096", "x1/4096", "outlier_1e5", "fp16_denormal_heavy", "fp32_denormals", "frames_of_different_scale"])
+@pytest.mark.parametrize("layout", ["blk8", "nchw"])
+def test_fp32_lookup_at_any_feature_magnitude(case, layout):
+    """The dense-product kernel multiplies fp32 features as fp16 hi + lo pairs (csrc/corr_mm.h).  The pairs are formed from the value
+    scaled by a power of two per patch / per frame (devo_corr_patch_transpose, devo_corr_pyramid_split), so no magnitude overflows
+    fp16 (the reference's fp32 kernel returns finite numbers there, correlation_kernel.cu:82-136) or falls below its normal range:
+    the fp32 tolerance (1e-4 of the output scale, against the fp64 oracle) holds for features of any scale, and nothing is inf."""
+    from devo_amd.backends import cuda_corr
+    f1, f2, coords, ii, jj, R = _case(E=1200, Np=40, seed=41)
+    if case == "x4096":
+        f1, f2 = f1 * 4096.0, f2 * 4096.0                        # |x| up to ~5e3: products up to 2.5e7, a plain fp16 hi would reach 65504 at x16 more
+        f2[0, 1] *= 64.0                                         # ... and one frame beyond fp16's range altogether (|x| up to 3e5)
+    elif case == "x1/4096":
+        f1, f2 = f1 / 4096.0, f2 / 4096.0                        # |x| ~ 6e-5: at fp16's normal / denormal boundary
+    elif case == "outlier_1e5":
+        f2[0, 2, 17, 11, 13] = 1.0e5                             # one value beyond fp16's largest (65504)
+        f1[0, 3, 5, 1, 1] = -2.0e5
+    elif case == "fp16_denormal_heavy":
+        g = torch.Generator().manual_seed(5)
+        f2 = f2 * torch.where(torch.rand(f2.shape, generator=g) < 0.7, 1.0e-6, 1.0)      # 70 % of the map far below fp16's normal range
+        f1 = f1 * 1.0e-6                                         # a patch operand that is below it entirely
+    elif case == "fp32_denormals":
+        g = torch.Generator().manual_seed(6)
+        f2 = f2 * torch.where(torch.rand(f2.shape, generator=g) < 0.5, 1.0e-39, 1.0)     # fp32 denormals among O(1) values
+    elif case == "frames_of_different_scale":
+        for k in range(f2.shape[1]):
+            f2[0, k] *= 10.0 ** (3 * k - 4)                      # 1e-4 .. 1e5: per-frame exponents
+    was = cuda_corr.MM_KERNEL
+    try:
+        cuda_corr.MM_KERNEL = True
+        got = _run(f1, f2, coords, ii, jj, R, layout=layout)
+    finally:
+        cuda_corr.MM_KERNEL = was
+    assert torch.isfinite(got).all(), "non-finite output"
+    ref = A.corr_forward(f1.double(), f2.double(), coords, ii, jj, R)
+    if case == "frames_of_different_scale":                      # every frame against its own output scale
+        for k in range(f2.shape[1]):
+            sel = jj == k
+            assert_rel(got[:, sel.to(DEV)], ref[:, sel], 1e-4, f"frame {k}")
+    else:
+        assert_rel(got, ref, 1e-4, case)

@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--separate-index-kernels", action="store_true",
                     help="the lookup plan's ordering kernel and the BA's index preparation as two launches (inside their own calls) "
                          "instead of one launch with two workgroups (cuda_ba.prepare(..., plan=...))")
+    ap.add_argument("--plan", default="edges", choices=["groups", "edges"],
+                    help="locality plan of the fused lookup: edges = the per-edge lookup (default); groups = edges sorted by (frame, tile of 6 x 6 "
+                         "level-1 cells): level 1 is read from LDS regions shared by a group's edges (csrc/corr_mm.h group form; measured slower at "
+                         "cfg2, profiles/r05_group_form.txt)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--separate-target", action="store_true", help="form target = coords centre + delta with a torch kernel (devo.py:330) instead of inside the BA")
     ap.add_argument("--steps-per-graph", type=int, default=20,
@@ -314,7 +318,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
     def lookup(coords, order=None):
         if not args.fuse_levels:
             if order is None:
-                order = cuda_corr.plan(coords, d["jj"], n, cfg["H"], radius=R)            # locality plan, shared by both levels
+                order = cuda_corr.plan(coords, d["jj"], n, cfg["H"], radius=R, width=cfg["W"], l1=PL1)   # locality plan, shared by both levels
             for lvl, (fm, s) in enumerate(zip(d["pyramid"], (1, 4))):
                 cuda_corr.forward_into(corr_out, d["gmap"], fm, coords, d["kk"], d["jj"], R, Dm * Dm * 18, 2, lvl, order=order,
                                        coord_div=float(s))                   # the kernel looks up at coords / s
@@ -322,6 +326,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
             # plan + ONE launch for both levels (workgroups of the two levels alternate on every CU)
             cuda_corr.forward_pyramid(d["gmap"], d["pyramid"], coords, d["kk"], d["jj"], R, (1, 4), out=corr_out, order=order)
 
+    PL1 = 4 if (args.plan == "groups" and args.fuse_levels) else 0
     prep_stream = torch.cuda.Stream() if args.overlap_prepare else None
     probe = {"on": False, "ev": []}          # eager steps after the timed region record HIP events around the lookup launch(es)
 
@@ -343,12 +348,12 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         torch.mul(d["state0"], 1.0, out=d["state"])                        # fresh poses + patches (bench harness; an elementwise kernel: rocclr's copyBuffer takes 5 us)
         # reprojection; the kernel also emits the lookup's plan bins while it holds the coordinates
         coords, order = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp",
-                                          plan_for=(n, cfg["H"], R, cfg["W"], 0))
+                                          plan_for=(n, cfg["H"], R, cfg["W"], PL1))
         if args.separate_index_kernels or prep_stream is not None:
-            order = cuda_corr.plan_finish(order, d["jj"], n, cfg["H"], R)
+            order = cuda_corr.plan_finish(order, d["jj"], n, cfg["H"], R, width=cfg["W"], l1=PL1)
         else:
             # the plan's ordering step and the BA's index preparation (independent of each other) in ONE launch
-            cuda_ba.prepare(d["kk"], Np, n - 1, ws, plan=(order, n, cfg["H"]))
+            cuda_ba.prepare(d["kk"], Np, n - 1, ws, plan=(order, n, cfg["H"], cfg["W"], PL1))
         lookup_probed(coords, order=order)
         if prep_stream is not None:
             cur.wait_stream(prep_stream)
@@ -420,7 +425,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         lookup(coords)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     # only the lookup kernels sit between the events
-    order = cuda_corr.plan(coords, d["jj"], n, cfg["H"], radius=R)
+    order = cuda_corr.plan(coords, d["jj"], n, cfg["H"], radius=R, width=cfg["W"], l1=PL1)
     torch.cuda.synchronize()
 
     def lookups():

@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdevo_hip.so")
 DEVO_F32, DEVO_F16, DEVO_F64 = 0, 1, 2
 ABI_VERSION = 2                # include/devo_hip.h DEVO_ABI_VERSION: a library of another version is refused (argument lists differ)
 CBLOCK_SPLIT8 = -8             # DEVO_CBLOCK_SPLIT8: fp32 level in the split-blocked format of devo_corr_pyramid_split
+PLAN_TAIL = 4104               # DEVO_CORR_PLAN_TAIL: a plan buffer that can hold a group plan has 2 n + 2 + PLAN_TAIL ints
+PLAN_EDGES, PLAN_GROUPS = 0, 1
 _DT = {torch.float32: DEVO_F32, torch.float16: DEVO_F16, torch.float64: DEVO_F64}
 
 _c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -24,7 +26,7 @@ _SIGNATURES = {
     "devo_last_error": [],
     "devo_corr_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i, _i64, _i64, _i64, _i, _i, _vp, ctypes.c_float, _vp, _vp, _vp],
     "devo_corr_forward_pyramid2": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), _c_i64p,
-                                   ctypes.POINTER(ctypes.c_int), _i64, _i64, _c_i64p, _i, _i, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp, _vp, _vp],
+                                   ctypes.POINTER(ctypes.c_int), _i64, _i64, _c_i64p, _i, _i, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp, _vp, _i, _vp],
     "devo_corr_patch_operand_bytes": [_i, _i, _i],
     "devo_corr_patch_transpose": [_vp, _vp, _i, _i, _i, _vp],
     "devo_corr_pyramid_split": [_vp, _c_i64p, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp],
@@ -38,7 +40,7 @@ _SIGNATURES = {
     "devo_ba_workspace_bytes": [_i, _i, _i],
     "devo_ba_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
     "devo_ba_prepare": [_vp, _i, _i, _i, _vp, _sz, _vp],
-    "devo_ba_prepare_plan": [_vp, _i, _i, _i, _vp, _sz, _vp, _i, _i, _vp],
+    "devo_ba_prepare_plan": [_vp, _i, _i, _i, _vp, _sz, _vp, _i, _i, _i, _i, _vp],
     "devo_ba_prepared_tables": [_vp, _sz, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "devo_ba_forward_prepared": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
     "devo_ba_forward_prepared_delta": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],

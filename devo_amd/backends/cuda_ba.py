@@ -21,19 +21,22 @@ def prepare(kk, n_patch_slots, n_opt, ws, plan=None):
     """Index half of cuda_ba.forward (ba_cuda.cu:435-437: unique patches, edges grouped by patch), which depends on
     `kk` only: call it early — e.g. on a side stream while the correlation lookup runs — and pass `prepared=True` to
     forward().  `n_patch_slots` = patches.shape[1], `n_opt` = t1 - t0; `ws` from workspace().
-    plan=(buffer, n_frames, height): the half-built locality plan of transform(..., plan_for=...) is finished in the same
+    plan=(buffer, n_frames, height[, width, l1]): the half-built locality plan of transform(..., plan_for=...) (width, l1 as given
+    there: a group plan) is finished in the same
     launch (two independent single-workgroup kernels side by side); the buffer is then what cuda_corr.plan_finish returns."""
     L.require_gpu(kk, ws)
     kk = kk.long().contiguous()
     if plan is None:
         rc = L.lib().devo_ba_prepare(L.ptr(kk), kk.numel(), int(n_patch_slots), int(n_opt), L.ptr(ws), ws.numel(), L.stream())
     else:
-        buf, n_frames, height = plan
+        buf, n_frames, height = plan[:3]
+        width, l1 = (tuple(plan[3:5]) + (0, 0))[:2]
         L.require_gpu(buf)
+        groups = buf.numel() == 2 * kk.numel() + 2 + L.PLAN_TAIL and int(l1) >= 2
         if buf.dtype != torch.int32 or buf.numel() < 2 * kk.numel() + 2:
-            raise RuntimeError("cuda_ba.prepare: plan must be the int32 [2E+2] buffer of transform(..., plan_for=...)")
+            raise RuntimeError("cuda_ba.prepare: plan must be the int32 buffer of transform(..., plan_for=...)")
         rc = L.lib().devo_ba_prepare_plan(L.ptr(kk), kk.numel(), int(n_patch_slots), int(n_opt), L.ptr(ws), ws.numel(),
-                                          L.ptr(buf), int(n_frames), int(height), L.stream())
+                                          L.ptr(buf), int(n_frames), int(height), int(width) if groups else 0, int(l1) if groups else 0, L.stream())
     L.check(rc, "cuda_ba.prepare")
     return ws
 
@@ -155,8 +158,9 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     """Fused projective transform with the semantics of devo/projective_ops.py:53-105 (batch 1, no autograd).
     layout "pp2": coords [1,E,P,P,2|3] as the reference returns; "2pp": [1,E,2,P,P] (devo/devo.py:223).
     plan_for=(n_frames, height, radius[, width, l1]): also start the lookup's locality plan for these coordinates (the kernel
-    emits the plan bins while it holds them; width, l1 = 4: PYRAMID plan, see cuda_corr.plan); the half-built plan buffer is
-    returned LAST — finish it with cuda_corr.plan_finish(buffer, jj, n_frames, height, radius)."""
+    emits the plan bins while it holds them; width, l1 = 4: GROUP plan, see cuda_corr.plan); the half-built plan buffer is
+    returned LAST — finish it with cuda_corr.plan_finish(buffer, jj, n_frames, height, radius[, width=, l1=]) or
+    prepare(..., plan=(buffer, n_frames, height[, width, l1]))."""
     L.require_gpu(poses, patches, intrinsics, ii, jj, kk)
     P = patches.shape[-1]
     ii, jj, kk = _idx(ii, jj, kk)
@@ -175,8 +179,12 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     flags = (1 if depth else 0) | (2 if tonly else 0)
     plan, pf = None, (0, 0, 0, 0, 0)
     if plan_for is not None:
+        from . import cuda_corr
         pf = (tuple(int(x) for x in plan_for) + (0, 0))[:5]
-        plan = torch.empty(2 * E + 2, dtype=torch.int32, device=dev)
+        groups = pf[4] >= 2 and cuda_corr.group_plan_supported(1, pf[0], pf[1], pf[3], pf[4], pf[2])
+        if not groups:
+            pf = pf[:3] + (0, 0)                              # (geometries without a group plan: an edge plan)
+        plan = cuda_corr.plan_buffer(E, dev, groups)
     rc = L.lib().devo_transform(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(ii), L.ptr(jj), L.ptr(kk),
                                 L.ptr(c_pp2), L.ptr(c_2pp), L.ptr(v), L.ptr(Ji), L.ptr(Jj), L.ptr(Jz), E, P, flags,
                                 L.ptr(plan), pf[0], pf[1], pf[2], pf[3], pf[4], L.stream())

@@ -123,35 +123,58 @@ def _fast_layout(fmap2, n_edges, allow_split=True):
     return blk
 
 
-def plan_buffer(n_slots, device):
+def plan_buffer(n_slots, device, groups=False):
     """The plan buffer of devo_corr_order: int32 [2 n + 2] = n edge slots | number of heavy slots (in front) | n ints of scratch |
-    number of dead slots (at the end; pyramid plans)."""
-    return torch.empty(2 * int(n_slots) + 2, dtype=torch.int32, device=device)
+    number of dead slots (at the end; group plans); a GROUP plan has PLAN_TAIL more ints behind them (the groups' first slots)."""
+    return torch.empty(2 * int(n_slots) + 2 + (L.PLAN_TAIL if groups else 0), dtype=torch.int32, device=device)
+
+
+def plan_kind(order, n_slots):
+    """DEVO_PLAN_GROUPS for a buffer with a group plan's tail (plan(..., l1 = 4)), else DEVO_PLAN_EDGES."""
+    return L.PLAN_GROUPS if (order is not None and order.numel() == 2 * int(n_slots) + 2 + L.PLAN_TAIL) else L.PLAN_EDGES
 
 
 def plan(coords, jj, n_frames, height, coord_scale=1.0, radius=3, width=0, l1=0):
     """Locality plan (devo_corr_order): edge slots sorted by (target frame, 16-row band, 8-px column).  One plan serves every
     level of a pyramid; `coords / coord_scale` must be the coordinates of the level with `height` rows.
-    width, l1: PYRAMID plan for forward_pyramid — the level is `width` wide and the lookup has a second level at 1 / l1 of its
-    resolution (DEVO: 4): edges whose boxes miss the frame at both levels are sorted to the end (they are zero-filled), heavy = what
-    the region-shared kernel cannot take."""
+    width, l1: GROUP plan for forward_pyramid — the level is `width` wide and the lookup has a second level at 1 / l1 of its
+    resolution (DEVO: 4), radius 3: edges sorted by (target frame, tile of 6 x 6 level-1 cells of the patch centre) with every group's
+    first slot behind them; the fused lookup then reads level 1 from LDS regions shared by a group's edges.  Geometries without a
+    group plan (too many groups, other radii) get an edge plan."""
     L.require_gpu(coords, jj)
     coords = coords.float().contiguous()
     jj = jj.long().contiguous()
     B, E = coords.shape[:2]
-    order = plan_buffer(B * E, coords.device)
+    groups = int(l1) >= 2 and group_plan_supported(B, n_frames, height, width, l1, radius)
+    order = plan_buffer(B * E, coords.device, groups)
     rc = L.lib().devo_corr_order(L.ptr(coords), L.ptr(jj), L.ptr(order), B, E, int(n_frames), coords.shape[3], int(height),
-                                 float(coord_scale), int(radius), int(width), int(l1), L.stream())
+                                 float(coord_scale), int(radius), int(width) if groups else 0, int(l1) if groups else 0, L.stream())
     L.check(rc, "cuda_corr.plan")
     return order
 
 
-def plan_finish(order, jj, n_frames, height, radius=3, batch=1):
-    """Second half of plan() for a buffer whose bins cuda_ba.transform(..., plan_for=...) has already written."""
+GROUP_TILE = 6             # corr_tile.h CORR_GRP_T
+
+
+def group_plan_supported(batch, n_frames, height, width, l1, radius):
+    """corr_tile.h corr_grp_nbins: radius 3, a quarter-resolution second level, at most 4095 groups of 6 x 6 level-1 cells."""
+    if int(radius) != 3 or int(l1) != 4 or int(width) <= 0 or os.environ.get("DEVO_CORR_GROUP", "1") == "0":
+        return False
+    h1, w1 = int(height) // 4, int(width) // 4
+    if h1 < 1 or w1 < 1:
+        return False
+    g = lambda c: (c + GROUP_TILE - 1) // GROUP_TILE
+    return int(batch) * int(n_frames) * g(h1) * g(w1) + 1 <= 4096
+
+
+def plan_finish(order, jj, n_frames, height, radius=3, batch=1, width=0, l1=0):
+    """Second half of plan() for a buffer whose bins cuda_ba.transform(..., plan_for=...) has already written (width, l1: as given there)."""
     L.require_gpu(order, jj)
     jj = jj.long().contiguous()
-    E = (order.numel() - 2) // (2 * batch)
-    rc = L.lib().devo_corr_order(None, L.ptr(jj), L.ptr(order), batch, E, int(n_frames), 3, int(height), 1.0, int(radius), 0, 0, L.stream())
+    E = jj.numel()
+    groups = int(l1) >= 2 and order.numel() == 2 * batch * E + 2 + L.PLAN_TAIL      # (transform falls back to an edge plan where no group plan exists)
+    rc = L.lib().devo_corr_order(None, L.ptr(jj), L.ptr(order), batch, E, int(n_frames), 3, int(height), 1.0, int(radius),
+                                 int(width) if groups else 0, int(l1) if groups else 0, L.stream())
     L.check(rc, "cuda_corr.plan_finish")
     return order
 
@@ -259,7 +282,9 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
     if fused and isinstance(pyramid[0], SplitLevel) != isinstance(pyramid[1], SplitLevel):
         pyramid = [_fast_layout(f, B * E, allow_split=False) for f in raw]
     if order is None and B * E >= PLAN_MIN_EDGES:
-        order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius)
+        # an edge plan; DEVO_CORR_GROUP=1: a group plan where the group form can run (level 1 from LDS regions: measured slower, opt-in)
+        grp = fused and float(scales[0]) == 1.0 and float(scales[1]) == 4.0 and os.environ.get("DEVO_CORR_GROUP", "0") == "1"
+        order = plan(coords, jj, pyramid[0].shape[1], pyramid[0].shape[3], scales[0], radius, width=pyramid[0].shape[4] if grp else 0, l1=4 if grp else 0)
     if fused:
         f1, f2a, c_, ii_, jj_ = _prep(fmap1, raw[0], coords, ii, jj, allow_blocked=True)
         _prep(fmap1, raw[1], coords, ii, jj, allow_blocked=True)
@@ -271,7 +296,7 @@ def forward_pyramid(fmap1, pyramid, coords, ii, jj, radius, scales, out=None, or
         rc = L.lib().devo_corr_forward_pyramid2(L.ptr(f1), L.ptr(d0[4]), L.ptr(d1[4]), L.ptr(c_), L.ptr(ii_), L.ptr(jj_),
                                                 L.ptr(out), B, E, Np, pyramid[0].shape[1], C, P, hw, L.i64arr(d0[2] + d1[2]), cb,
                                                 per * nl, nl, L.i64arr([0, 1]), int(radius), L.dtype_code(f1), L.ptr(order), cd,
-                                                L.ptr(f1t), L.ptr(d0[5]), L.ptr(d1[5]), L.stream())
+                                                L.ptr(f1t), L.ptr(d0[5]), L.ptr(d1[5]), plan_kind(order, B * E), L.stream())
         if rc == 0:
             return out
         if rc != 3:                                             # DEVO_ERR_UNSUPPORTED: fall through to one launch per level

@@ -364,8 +364,8 @@ __global__ __launch_bounds__(1024) void k_ba_prepare(const int64_t* __restrict__
 }
 
 template <int CACHE>
-__global__ __launch_bounds__(ORDER_THREADS) void k_order_only(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order) {
-  corr_order_body<CACHE>(bins, BE, nbins, order, (int)blockIdx.x, (int)gridDim.x);
+__global__ __launch_bounds__(ORDER_THREADS) void k_order_only(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order, int starts) {
+  corr_order_body<CACHE>(bins, BE, nbins, order, (int)blockIdx.x, (int)gridDim.x, starts != 0);
 }
 
 // Workgroup 0: the BA's index preparation; workgroups 1 .. G: the ordering step of the lookup's locality plan (corr_plan.h).
@@ -373,9 +373,10 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_only(const int* __restr
 template <int CACHE>
 __global__ __launch_bounds__(1024) void k_prepare_and_order(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
                                                             int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
-                                                            int* perm_b, int sig, const int* __restrict__ bins, int nbins, int* __restrict__ order) {
+                                                            int* perm_b, int sig, const int* __restrict__ bins, int nbins, int* __restrict__ order,
+                                                            int starts) {
   if (blockIdx.x == 0) ba_prepare_body<CACHE>(kk, E, Np, max_seg, meta, g_rank, g_counts, g_cursor, ku, kx, perm_a, perm_b, sig);
-  else corr_order_body<CACHE>(bins, E, nbins, order, (int)blockIdx.x - 1, (int)gridDim.x - 1);
+  else corr_order_body<CACHE>(bins, E, nbins, order, (int)blockIdx.x - 1, (int)gridDim.x - 1, starts != 0);
 }
 
 // ------------------------------------------------------------------------------------------------- per-edge maths
@@ -2417,7 +2418,7 @@ size_t devo_ba_workspace_bytes(int E, int Np, int N) {
 // plan != NULL: also finish the lookup's locality plan (bins at plan + E + 1, see devo_transform) — in the same launch when
 // the single-workgroup path is taken, else with the plan's own kernel
 static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, size_t ws_bytes, hipStream_t st,
-                           int* plan = nullptr, int plan_nbins = 0) {
+                           int* plan = nullptr, int plan_nbins = 0, int plan_starts = 0) {
   const BaLayout L = ba_layout(E, Np, N);
   if (ws == nullptr || ws_bytes < L.total) { set_error("devo_ba_prepare: workspace %zu < %zu bytes", ws_bytes, L.total); return DEVO_ERR_WORKSPACE; }
   char* w = (char*)ws;
@@ -2445,7 +2446,7 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     prep_fn_t prep = ept <= 8 ? k_ba_prepare<8> : ept <= 16 ? k_ba_prepare<16> : ept <= 24 ? k_ba_prepare<24> :
                      ept <= 32 ? k_ba_prepare<32> : k_ba_prepare<0>;
     if (plan && ept <= 32) {
-      typedef void (*both_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, int, const int*, int, int*);
+      typedef void (*both_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, int, const int*, int, int*, int);
       both_fn_t both = ept <= 8 ? k_prepare_and_order<8> : ept <= 16 ? k_prepare_and_order<16> : ept <= 24 ? k_prepare_and_order<24> :
                        k_prepare_and_order<32>;
       static bool both_attr = false;
@@ -2457,7 +2458,7 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
         (void)hipGetLastError(); both_attr = true;
       }
       hipLaunchKernelGGL(both, dim3(1 + (unsigned)corr_order_workgroups(E, plan_nbins)), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank,
-                         counts, cursor, ku, kx, perm_a, perm_b, ba_sig(E, N), plan + E + 1, plan_nbins, plan);
+                         counts, cursor, ku, kx, perm_a, perm_b, ba_sig(E, N), plan + E + 1, plan_nbins, plan, plan_starts);
       plan = nullptr;                                          // done
     } else {
       hipLaunchKernelGGL(prep, dim3(1), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank, counts, cursor, ku, kx, perm_a, perm_b, ba_sig(E, N));
@@ -2474,11 +2475,11 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, meta, ba_sig(E, N), perm_a, perm_b);
   }
   if (plan) {                                                 // the plan's ordering step on its own
-    typedef void (*order_fn_t)(const int*, int, int, int*);
+    typedef void (*order_fn_t)(const int*, int, int, int*, int);
     const long long per_thread = ((long long)E + ORDER_THREADS - 1) / ORDER_THREADS;
     order_fn_t order_fn = per_thread <= 8 ? k_order_only<8> : per_thread <= 16 ? k_order_only<16> : per_thread <= 24 ? k_order_only<24> :
                           per_thread <= 32 ? k_order_only<32> : k_order_only<0>;
-    hipLaunchKernelGGL(order_fn, dim3((unsigned)corr_order_workgroups(E, plan_nbins)), dim3(ORDER_THREADS), 0, st, plan + E + 1, E, plan_nbins, plan);
+    hipLaunchKernelGGL(order_fn, dim3((unsigned)corr_order_workgroups(E, plan_nbins)), dim3(ORDER_THREADS), 0, st, plan + E + 1, E, plan_nbins, plan, plan_starts);
   }
   return check_launch("devo_ba_prepare");
 }
@@ -2524,13 +2525,18 @@ int devo_ba_prepared_tables(const void* ws, size_t ws_bytes, int E, int Np, int 
 }
 
 int devo_ba_prepare_plan(const int64_t* kk, int E, int Np, int N, void* ws, size_t ws_bytes, int* plan, int plan_frames,
-                         int plan_height, devo_stream_t stream) {
+                         int plan_height, int plan_width, int plan_l1, devo_stream_t stream) {
   DEVO_REQUIRE(E >= 0 && Np > 0 && N >= 0, "devo_ba_prepare_plan: bad sizes");
   if (N > BA_MAXN) { set_error("devo_ba_prepare_plan: %d optimised poses > %d supported", N, BA_MAXN); return DEVO_ERR_UNSUPPORTED; }
   DEVO_REQUIRE(plan != nullptr && plan_frames > 0 && plan_height > 0, "devo_ba_prepare_plan: missing plan");
   if (E == 0) return DEVO_OK;
   const CorrPlanGeom pg = corr_plan_geom(1, plan_frames, plan_height);
   DEVO_REQUIRE(pg.nb > 0, "devo_ba_prepare_plan: too many frames for a locality plan (%d)", plan_frames);
+  if (plan_l1 >= 2) {                                         // GROUP plan (devo_corr_order): the bins' first slots go into the plan's tail
+    const long long nb = corr_grp_nbins(1, plan_frames, plan_height, plan_width, plan_l1);
+    DEVO_REQUIRE(nb > 0, "devo_ba_prepare_plan: no group plan for this geometry (%d frames of %d x %d)", plan_frames, plan_height, plan_width);
+    return ba_prepare_impl(kk, E, Np, N, ws, ws_bytes, (hipStream_t)stream, plan, (int)nb, 1);
+  }
   return ba_prepare_impl(kk, E, Np, N, ws, ws_bytes, (hipStream_t)stream, plan, (int)corr_plan_nbins(1, plan_frames, pg));
 }
 
@@ -2806,11 +2812,16 @@ int devo_transform(const float* poses, const float* patches, const float* intrin
   CorrPlanMode pm{0, 0, 0, -1};
   if (plan) {
     DEVO_REQUIRE(P == 3 && plan_frames > 0 && plan_height > 0 && plan_radius >= 0 && plan_radius <= 5, "devo_transform: bad plan geometry");
-    DEVO_REQUIRE(plan_l1 == 0 || (plan_l1 >= 2 && plan_width > 0), "devo_transform: a pyramid plan needs the level's width and an integer level ratio >= 2");
+    DEVO_REQUIRE(plan_l1 == 0 || (plan_l1 >= 2 && plan_width > 0), "devo_transform: a group plan needs the level's width and an integer level ratio >= 2");
     const CorrPlanGeom pg = corr_plan_geom(1, plan_frames, plan_height);
     DEVO_REQUIRE(pg.nb > 0, "devo_transform: too many frames for a locality plan (%d)", plan_frames);
     nb = corr_plan_pack(pg);
-    pm = CorrPlanMode{plan_width, plan_l1, 16 * corr_region_tmax(plan_radius), (int)corr_plan_nbins(1, plan_frames, pg) - 1};
+    const long long nbins = plan_l1 >= 2 ? corr_grp_nbins(1, plan_frames, plan_height, plan_width, plan_l1) : corr_plan_nbins(1, plan_frames, pg);
+    if (plan_l1 >= 2 && (nbins == 0 || plan_radius != 3)) {
+      set_error("devo_transform: no group plan for this geometry (radius 3 only, at most %d groups: %d frames of %d x %d)", CORR_ORDER_MAXBINS, plan_frames, plan_height, plan_width);
+      return DEVO_ERR_UNSUPPORTED;
+    }
+    pm = CorrPlanMode{plan_width, plan_l1, 16 * corr_region_tmax(plan_radius), (int)nbins - 1};
   }
   hipLaunchKernelGGL(P == 3 ? k_transform<true> : k_transform<false>, dim3(blocks_for(E, 128, 4096)), dim3(128), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
                      kk, coords_pp2, coords_2pp, valid, Ji, Jj, Jz, E, P, flags, plan ? plan + E + 1 : nullptr, plan_frames, plan_height,

@@ -14,6 +14,7 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
 #include <type_traits>
 
 namespace devo {
@@ -480,8 +481,8 @@ __global__ __launch_bounds__(BIN_THREADS) void corr_bin_kernel(const float* __re
 // Step 2: counting sort of the bins by gridDim.x independent workgroups, the heavy list first (corr_plan.h).
 template <int CACHE>
 __global__ __launch_bounds__(ORDER_THREADS) void corr_order_kernel(const int* __restrict__ bins, int BE, int nbins,
-                                                                   int* __restrict__ order) {
-  corr_order_body<CACHE>(bins, BE, nbins, order, (int)blockIdx.x, (int)gridDim.x);
+                                                                   int* __restrict__ order, int starts) {
+  corr_order_body<CACHE>(bins, BE, nbins, order, (int)blockIdx.x, (int)gridDim.x, starts != 0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1050,10 +1051,10 @@ static bool mm_eligible(const CorrLevel& l0, const CorrLevel& l1, const void* fm
 template <typename T>
 static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel& lv1, int nlev, const float* coords, const int64_t* ii,
                      const int64_t* jj, void* out, long long BE, int E, int Np, int n2, int C, int64_t oes, int64_t ols, int R,
-                     const int* order, hipStream_t st) {
+                     const int* order, hipStream_t st, int order_kind = 0) {
   typedef typename std::conditional<std::is_same<T, double>::value, float, T>::type MT;
   typedef void (*mm_fn_t)(const MT*, CorrLevel, CorrLevel, int, const float*, const int64_t*, const int64_t*, MT*, int, int, int, int, int,
-                          int64_t, int64_t, int, const int*, int, unsigned long long*, const int*);
+                          int64_t, int64_t, int, const int*, int, unsigned long long*, const int*, MmGroupArgs);
   // fp32: the patch operand's scale exponents sit behind its records (devo_corr_patch_operand_bytes)
   const int* exp1 = sizeof(MT) == 4 ? reinterpret_cast<const int*>(static_cast<const char*>(fmap1_t) + (size_t)(BE / E) * Np * C * PP * 4) : nullptr;
   const int nks = C / 32;
@@ -1066,12 +1067,75 @@ static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel&
 #undef DEVO_MM_PICK
 #undef DEVO_MM_PICK_L
   if (!fn) { set_error("devo_corr_forward_pyramid2: C = %d not supported by the dense-product kernel", C); return DEVO_ERR_UNSUPPORTED; }
+  // GROUP form (corr_mm.h, NW > 1): a group plan, radius 3, C = 128, level 1 = a quarter-resolution level in 8-channel blocks whose
+  // region fits the LDS next to the waves' result areas
+  static const bool group_off = []() { const char* e = getenv("DEVO_CORR_GROUP"); return e && e[0] == '0'; }();
+  if (order_kind == DEVO_PLAN_GROUPS && order != nullptr && nlev == 2 && R == 3 && nks == 4 && lv1.cb_shift == 3 && !group_off && lv0.H2 / 4 == lv1.H2 &&
+      lv0.W2 / 4 == lv1.W2 && lv0.coord_div == 1.0f && lv1.coord_div == 4.0f && BE / E == 1) {
+    const long long nbins = corr_grp_nbins(1, n2, lv0.H2, lv0.W2, 4);
+    if (nbins > 0) {
+      constexpr int NWG = sizeof(MT) == 2 ? 16 : 8;                  // waves per workgroup: what the registers allow per CU (one workgroup per CU: the region)
+      mm_fn_t gfn = corr_fwd_mm_kernel<MT, 3, 4, 2, 3, NWG>;
+      // per wave: result area + geometry records (the kernel's WAVE_LDS)
+      constexpr int cap = sizeof(MT) == 4 ? 128 : DEVO_MM_CAP;       // (the kernel's CAP)
+      constexpr int rw_floats = (PP * (8 * 8 + 1) + 3) / 4 * 4 > PP * (cap + 4) ? (PP * (8 * 8 + 1) + 3) / 4 * 4 : PP * (cap + 4);
+      constexpr int wave_lds = rw_floats * 4 + 2 * 16 * 4 * 4 + ((2 * PP * 2 * 4 + 15) / 16) * 16;
+      const int lds = mm_region_bytes<MT>(128) + NWG * wave_lds;
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { (void)hipGetLastError(); set_error("devo_corr_forward_pyramid2: %d bytes of LDS refused", lds); return DEVO_ERR_LAUNCH; }
+        attr_set = true;
+      }
+      const MmGroupArgs ga{order + 2 * BE + 2, (int)nbins, corr_grp_count(lv1.H2), corr_grp_count(lv1.W2)};
+      const unsigned items = (unsigned)nbins * MM_ITEMS_PER_BIN;
+      const unsigned gwg = (items + 7) / 8 * 8;
+      unsigned long long* gtrace = nullptr;                          // debug switch: per-wave 100 MHz stamps -> a schedule summary on stderr
+      if (getenv("DEVO_CORR_TRACE") != nullptr) { (void)hipMalloc(&gtrace, (size_t)gwg * NWG * 64); (void)hipMemset(gtrace, 0, (size_t)gwg * NWG * 64); }
+      hipLaunchKernelGGL(gfn, dim3(gwg), dim3(64 * NWG), lds, st, (const MT*)fmap1_t, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C,
+                         oes, ols, R, order, 0, gtrace, exp1, ga);
+      if (gtrace) {
+        (void)hipDeviceSynchronize();
+        std::vector<unsigned long long> h((size_t)gwg * NWG * 8);
+        (void)hipMemcpy(h.data(), gtrace, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t i = 0; i < (size_t)gwg * NWG; i++) if (h[i * 8 + 3]) { t0 = std::min(t0, h[i * 8]); t1 = std::max(t1, h[i * 8 + 3]); }
+        // per compute unit (XCC id, SE id, CU id of HW_ID): busy time = union of its workgroups' spans; items; edges
+        struct CuAcc { double busy = 0, first = 1e30, last = 0; int wgs = 0, live = 0, edges = 0; };
+        std::vector<CuAcc> cu(16 * 1024);
+        double live_span = 0, empty_span = 0, stage = 0, item = 0, tail = 0; long nlive = 0, nempty = 0;
+        for (unsigned g = 0; g < gwg; g++) {
+          unsigned long long a = ~0ull, b = 0, ready = 0, done_min = ~0ull, done_max = 0; int edges = 0; unsigned long long hw = 0;
+          for (int w = 0; w < NWG; w++) {
+            const unsigned long long* t = &h[((size_t)g * NWG + w) * 8];
+            if (!t[3]) continue;
+            a = std::min(a, t[0]); b = std::max(b, t[3]); ready = std::max(ready, t[1]); hw = t[4]; edges = (int)t[5];
+            if (t[2]) { done_min = std::min(done_min, t[2]); done_max = std::max(done_max, t[2]); }
+          }
+          if (!b) continue;
+          const unsigned key = (unsigned)(((hw >> 32) & 0xf) << 10 | ((hw >> 13) & 0x7) << 7 | ((hw >> 8) & 0xf) << 3 | 0) & 16383u;   // xcc | se | cu
+          CuAcc& c = cu[key];
+          c.busy += (double)(b - a); c.first = std::min(c.first, (double)a); c.last = std::max(c.last, (double)b); c.wgs++; c.edges += edges;
+          if (edges > 0) { c.live++; nlive++; live_span += (double)(b - a); if (ready) stage += (double)(ready - a); if (done_max) { item += (double)(done_max - a); tail += (double)(done_max - done_min); } }
+          else { nempty++; empty_span += (double)(b - a); }
+        }
+        int ncu = 0; double bsum = 0, bmax = 0, emax = 0, esum = 0, lmax = 0;
+        for (auto& c : cu) if (c.wgs) { ncu++; bsum += c.busy; bmax = std::max(bmax, c.busy); esum += c.edges; emax = std::max(emax, (double)c.edges); lmax = std::max(lmax, (double)c.live); }
+        fprintf(stderr, "[corr group trace] %u workgroups (%ld with an item, %ld without), kernel span %.1f us; compute units seen %d: busy mean %.1f max %.1f us, item edges mean %.1f max %.0f, "
+                "items max %.0f; per item: span %.1f us (region ready after %.1f, last wave leaves the item after %.1f, first-to-last wave %.1f); workgroup without item: %.2f us\n",
+                gwg, nlive, nempty, (double)(t1 - t0) * 0.01, ncu, ncu ? bsum / ncu * 0.01 : 0.0, bmax * 0.01, ncu ? esum / ncu : 0.0, emax, lmax,
+                nlive ? live_span / nlive * 0.01 : 0.0, nlive ? stage / nlive * 0.01 : 0.0, nlive ? item / nlive * 0.01 : 0.0, nlive ? tail / nlive * 0.01 : 0.0,
+                nempty ? empty_span / nempty * 0.01 : 0.0);
+        (void)hipFree(gtrace);
+      }
+      return check_launch("devo_corr_forward_pyramid2 (dense-product kernel, group form)");
+    }
+  }
   unsigned long long* trace = nullptr;                                // debug switch: per-wave cycle stamps to stderr
   const bool do_trace = getenv("DEVO_CORR_TRACE") != nullptr;
   if (do_trace) { (void)hipMalloc(&trace, (size_t)BE * 64); (void)hipMemset(trace, 0, (size_t)BE * 64); }
   const unsigned nwg = DEVO_MM_EPW == 1 ? (unsigned)BE : (unsigned)(((BE + DEVO_MM_EPW - 1) / DEVO_MM_EPW + 7) / 8 * 8);   // whole groups of 8 (one per XCD)
   hipLaunchKernelGGL(fn, dim3(nwg), dim3(64 * DEVO_MM_EPW), 0, st, (const MT*)fmap1_t, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C,
-                     oes, ols, R, order, 0, trace, exp1);
+                     oes, ols, R, order, 0, trace, exp1, MmGroupArgs{nullptr, 0, 0, 0});
   if (do_trace) {
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)BE * 8);
@@ -1172,7 +1236,7 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
                                const int* cblock /* host, 2 */, int64_t out_estride, int64_t out_lstride,
                                const int64_t* out_offset /* host, 2 */, int radius, int dtype, const int* order,
                                const float* coord_div /* host, 2 */, const void* fmap1_t, const int* fmap2_exps_l0, const int* fmap2_exps_l1,
-                               devo_stream_t stream) {
+                               int order_kind, devo_stream_t stream) {
   DEVO_REQUIRE(P == 3, "devo_corr_forward_pyramid2: patch size P must be 3 (got %d)", P);
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_forward_pyramid2: radius %d unsupported (max 5)", radius);
   DEVO_REQUIRE(hw && f2s && cblock && out_offset && coord_div, "devo_corr_forward_pyramid2: missing level description");
@@ -1189,13 +1253,13 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
          staged_level<float>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1, fmap2_exps_l1);
     if (e0 == DEVO_ERR_ARG || e1 == DEVO_ERR_ARG) return DEVO_ERR_ARG;
     if (ok && out_lstride > 0 && mm_eligible<float>(l0, l1, fmap1_t, BE, Np, C))
-      return launch_mm<float>(fmap1_t, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
+      return launch_mm<float>(fmap1_t, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st, order_kind);
     if (ok) return launch_staged<float>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
   } else if (dtype == DEVO_F16) {
     ok = staged_level<__half>(fmap2_l0, C, hw[0], hw[1], f2s, cblock[0], out_offset[0], coord_div[0], &l0, &e0) &&
          staged_level<__half>(fmap2_l1, C, hw[2], hw[3], f2s + 5, cblock[1], out_offset[1], coord_div[1], &l1, &e1);
     if (ok && out_lstride > 0 && mm_eligible<__half>(l0, l1, fmap1_t, BE, Np, C))
-      return launch_mm<__half>(fmap1_t, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
+      return launch_mm<__half>(fmap1_t, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st, order_kind);
     if (ok) return launch_staged<__half>(fmap1, l0, l1, 2, coords, ii, jj, out, BE, E, Np, n2, C, out_estride, out_lstride, radius, order, st);
   }
   // not both levels readable by the staged kernel: the caller issues one devo_corr_forward per level instead
@@ -1246,20 +1310,24 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   const int nb = corr_plan_pack(pg);
   DEVO_REQUIRE(pg.nb > 0 && BE < (1LL << 30), "devo_corr_order: too many frames (%d x %d)", B, n2);
   DEVO_REQUIRE(radius >= 0 && 2 * radius + 2 <= MAXD, "devo_corr_order: radius %d unsupported (max 5)", radius);
-  DEVO_REQUIRE(l1 == 0 || (l1 >= 2 && W2 > 0), "devo_corr_order: a pyramid plan needs the level's width and an integer level ratio >= 2");
+  DEVO_REQUIRE(l1 == 0 || (l1 >= 2 && W2 > 0), "devo_corr_order: a group plan needs the level's width and an integer level ratio >= 2");
   int* bins = order + BE + 1;                                 // scratch half of the plan buffer
-  const long long nbins = corr_plan_nbins(B, n2, pg);
+  const long long nbins = l1 >= 2 ? corr_grp_nbins(B, n2, H2, W2, l1) : corr_plan_nbins(B, n2, pg);
+  if (l1 >= 2 && (nbins == 0 || radius != 3)) {
+    set_error("devo_corr_order: no group plan for this geometry (radius 3 only, at most %d groups: %d frames of %d x %d)", CORR_ORDER_MAXBINS, B * n2, H2, W2);
+    return DEVO_ERR_UNSUPPORTED;
+  }
   const CorrPlanMode pm{W2, l1, 16 * corr_region_tmax(radius), (int)nbins - 1};
   if (coords != nullptr)                                      // NULL: devo_transform has already written the bins
     hipLaunchKernelGGL(corr_bin_kernel, dim3((unsigned)((BE + BIN_THREADS - 1) / BIN_THREADS)), dim3(BIN_THREADS), 0,
                        (hipStream_t)stream, coords, jj, (int)BE, E, n2, H2, coord_scale, nb, 2 * radius + 2,
                        radius <= 3 ? 1 : 3, pm, bins);
-  typedef void (*order_fn_t)(const int*, int, int, int*);
+  typedef void (*order_fn_t)(const int*, int, int, int*, int);
   const long long per_thread = (BE + ORDER_THREADS - 1) / ORDER_THREADS;
   order_fn_t order_fn = per_thread <= 8 ? corr_order_kernel<8> : per_thread <= 16 ? corr_order_kernel<16> :
                         per_thread <= 24 ? corr_order_kernel<24> : per_thread <= 32 ? corr_order_kernel<32> : corr_order_kernel<0>;
   hipLaunchKernelGGL(order_fn, dim3((unsigned)corr_order_workgroups(BE, nbins)), dim3(ORDER_THREADS), 0, (hipStream_t)stream, bins, (int)BE,
-                     (int)nbins, order);
+                     (int)nbins, order, l1 >= 2 ? 1 : 0);
   return check_launch("devo_corr_order");
 }
 

@@ -164,12 +164,35 @@ __device__ __forceinline__ int mm_plan_slot(const int* __restrict__ order, int B
   return nh + upto(nitems) - upto(nh) + (gid >> 3) - heavy_here;
 }
 
-template <typename T, int RMAX, int NKS, int NL, int RFIX>   // NKS = C / 32 K steps per tile; NL = levels per wave; RFIX > 0: the radius is this constant
-__global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? DEVO_MM_WAVES - (RMAX > 3 ? 1 : 0) : DEVO_MM_WAVES32, sizeof(T) == 2 ? DEVO_MM_WAVES - (RMAX > 3 ? 1 : 0) : DEVO_MM_WAVES32))) void corr_fwd_mm_kernel(
+// NW > 1 — the GROUP form (level index 1 from LDS; NL == 2, RFIX == 3, a group plan: corr_tile.h "group plan").  The texture addresser is
+// the unit the per-edge form saturates (TA_BUSY 95-99 %, profiles/README.md r04), and at DEVO's patch density every level-1 position
+// is wanted by ~90 edges.  A workgroup of NW waves takes ONE ITEM of the plan — up to MM_ITEM_EDGES edges of one group: one target frame,
+// patch centres inside one tile of 6 x 6 level-1 cells — and stages the group's REGION of level 1 (15 x 15 positions, all channels: 56 KB
+// fp16 / 113 KB fp32 split records) ONCE with LDS-DMA (contiguous kilobytes: 16 addresser cycles each, ~113 per item instead of 20 - 40 per
+// EDGE).  Its waves then walk the item's edges exactly as the per-edge form does, level index 0 through the addresser — and level index
+// 1's tiles with ds_read_b128 from the region, a unit that was idle.  Edges whose level-1 box leaves the region (the plan sorts
+// them into the HEAVY class), heavy and dead edges keep the per-edge paths inside the same launch.
+struct MmGroupArgs { const int* starts; int nbins, ngy, ngx; };     // bin starts of the group plan (nbins + 1 entries), bins, groups per frame
+#ifndef DEVO_MM_ITEM_EDGES
+#define DEVO_MM_ITEM_EDGES (1 << 20)
+#endif
+#ifndef DEVO_MM_ITEMS_PER_BIN
+#define DEVO_MM_ITEMS_PER_BIN 1
+#endif
+constexpr int MM_ITEM_EDGES = DEVO_MM_ITEM_EDGES;      // an item = at most this many edges of one group (larger groups: several items, each staging the region)
+constexpr int MM_ITEMS_PER_BIN = DEVO_MM_ITEMS_PER_BIN;    // workgroups reserved per bin (the last one takes whatever is left)
+template <typename T> constexpr int mm_region_bytes(int C) {        // the staged region (radius 3), whole kilobytes (LDS-DMA writes 1 KB per instruction)
+  return ((CORR_GRP_T + 2 * 3 + 3) * (CORR_GRP_T + 2 * 3 + 3) * C * (int)sizeof(T) + 1023) / 1024 * 1024;
+}
+
+template <typename T, int RMAX, int NKS, int NL, int RFIX, int NW = 1>   // NKS = C / 32 K steps per tile; NL = levels per wave; RFIX > 0: the radius is this constant
+__global__ __launch_bounds__(64 * (NW > 1 ? NW : DEVO_MM_EPW)) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? DEVO_MM_WAVES - (RMAX > 3 ? 1 : 0) : DEVO_MM_WAVES32, sizeof(T) == 2 ? DEVO_MM_WAVES - (RMAX > 3 ? 1 : 0) : DEVO_MM_WAVES32))) void corr_fwd_mm_kernel(
     const T* __restrict__ fmap1_t, CorrLevel lv0, CorrLevel lv1, int nlev, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, T* __restrict__ out, int BE, int E, int Np, int n2,
     int C, int64_t out_estride, int64_t out_lstride, int R_arg, const int* __restrict__ order, int heavy_only,
-    unsigned long long* __restrict__ trace, const int* __restrict__ exp1) {
+    unsigned long long* __restrict__ trace, const int* __restrict__ exp1, MmGroupArgs grp) {
+  constexpr bool LDS1 = NW > 1;
+  static_assert(!LDS1 || (NL == 2 && RFIX == 3 && RMAX == 3 && DEVO_MM_EPW == 1), "the group form: fused two-level lookups at radius 3");
   const int R = RFIX > 0 ? RFIX : R_arg;        // (DEVO's radius 3 and the stress configuration's 5 as constants: window sizes, loop bounds and
                                                 //  the epilogue's guards fold away)
   constexpr bool HALF = sizeof(T) == 2;
@@ -187,20 +210,102 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
   //                                of a ds_write_b128 group, 8 pixels x the same 4 slots, fall into different banks)
   //   raw windows [p][D*D + 1]     tap (a, c) of pixel p: window-by-window tiles (larger boxes)
   constexpr bool ALIGN4 = DEVO_MM_ALIGN4 != 0 && sizeof(T) == 2;     // measured (profiles/r04_lookup_experiments.txt, 9): fp16 64 -> 60 us, fp32 120 -> 124
-  constexpr int CAP = RMAX <= 3 ? (ALIGN4 ? 160 : 128) : 256;
+#ifndef DEVO_MM_CAP
+#define DEVO_MM_CAP 160
+#endif
+  // (a box beyond CAP positions walks the 9 windows one after the other — 36 tiles where a 12 x 12 box has 9: with CAP = 128, 6 % of cfg2's
+  //  edges did, 18 % of all tiles)
+  constexpr int CAP = RMAX <= 3 ? ((LDS1 && !HALF) ? 128 : DEVO_MM_CAP) : 256;      // (fp32 group form: the region leaves 5.4 KB per wave)
+  static_assert(RMAX > 3 || (CAP % 16 == 0 && CAP >= 128 && CAP <= 192), "result area: 8 .. 12 tiles");
   constexpr int BOXS = CAP + 4;
   constexpr int RWIN_FLOATS = (PP * (DMAX * DMAX + 1) + 3) / 4 * 4;
   constexpr int RW_FLOATS = RWIN_FLOATS > PP * BOXS ? RWIN_FLOATS : PP * BOXS;
   constexpr int EPW = DEVO_MM_EPW;
-  const int wv = EPW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // this wave's edge inside the workgroup
-  __shared__ __attribute__((aligned(16))) float s_rawwin_all[EPW][RW_FLOATS];   // ONE level's result area: a level is blended before the next one's tiles land
-  __shared__ __attribute__((aligned(16))) float s_geo_all[EPW][NL][16][4];   // per (level index, pixel): dx, dy, tap (0, 0)'s index in the result area, row stride
-  __shared__ int s_org_all[EPW][NL][PP][2];                                  // window origins (window-by-window tiles only)
-  float* const s_rawwin = s_rawwin_all[wv];
-  float (*const s_geo)[16][4] = s_geo_all[wv];
-  int (*const s_org)[PP][2] = s_org_all[wv];
+  const int wv = (EPW > 1 || LDS1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // this wave's edge inside the workgroup
+  // per wave: ONE level's result area (a level is blended before the next one's tiles land) | per (level index, pixel): dx, dy, tap (0, 0)'s
+  // index in the result area, row stride | window origins (window-by-window tiles only)
+  constexpr int WAVE_LDS = RW_FLOATS * 4 + NL * 16 * 4 * 4 + ((NL * PP * 2 * 4 + 15) / 16) * 16;
+  constexpr int REGION_BYTES = LDS1 ? mm_region_bytes<T>(32 * NKS) : 0;
+  float* s_rawwin;
+  float (*s_geo)[16][4];
+  int (*s_org)[PP][2];
+  unsigned char* region = nullptr;
+  if constexpr (LDS1) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char mm_dyn[];       // region | NW per-wave areas
+    region = mm_dyn;
+    unsigned char* w0 = mm_dyn + REGION_BYTES + wv * WAVE_LDS;
+    s_rawwin = reinterpret_cast<float*>(w0);
+    s_geo = reinterpret_cast<float (*)[16][4]>(w0 + RW_FLOATS * 4);
+    s_org = reinterpret_cast<int (*)[PP][2]>(w0 + RW_FLOATS * 4 + NL * 16 * 4 * 4);
+  } else {
+    __shared__ __attribute__((aligned(16))) float s_rawwin_all[EPW][RW_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_geo_all[EPW][NL][16][4];
+    __shared__ int s_org_all[EPW][NL][PP][2];
+    s_rawwin = s_rawwin_all[wv];
+    s_geo = s_geo_all[wv];
+    s_org = s_org_all[wv];
+  }
   const int lane = threadIdx.x & 63;
-  int slot;
+  int slot = 0;
+  // ---- group form: this workgroup's item (a slot range of one bin of the group plan) and its region of level 1
+  constexpr int GRP_RW = CORR_GRP_T + 2 * 3 + 3;          // region side in positions (15)
+  constexpr unsigned RPOS = 8u * ESZ;                     // bytes per position and 8-channel block (level 1 is stored in 8-channel blocks)
+  constexpr unsigned RROW = GRP_RW * RPOS, RBLK = GRP_RW * GRP_RW * RPOS;
+  int it_lo = 0, it_hi = 0, it_b = -1, it_f = -1, ry0 = 0, rx0 = 0, hv_n = 0, dd_n = 0;
+  unsigned long long g_st[4] = {0, 0, 0, 0};               // debug (DEVO_CORR_TRACE, group form): 100 MHz stamps of this wave: start, region ready, item done, end
+  if (LDS1 && trace) g_st[0] = __builtin_amdgcn_s_memrealtime();
+  bool region_pending = false;                            // this wave still owes the workgroup's ONE barrier (after its share of the DMA has landed)
+  if constexpr (LDS1) {
+    const int per = ((int)gridDim.x + 7) >> 3;            // workgroup g runs on XCD g % 8: every XCD owns a contiguous range of items (= of bins = of frames)
+    const int item = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    const int bin = item / MM_ITEMS_PER_BIN, ki = item - bin * MM_ITEMS_PER_BIN;
+    hv_n = min(max(order[BE], 0), BE);
+    dd_n = min(max(order[2 * BE + 1], 0), BE - hv_n);
+    if (bin < grp.nbins - 1) {                             // (the last bin is the DEAD class: per-edge work like the heavy one, spread over all waves)
+      const int s0 = grp.starts[bin], s1 = grp.starts[bin + 1], cnt = max(s1 - s0, 0);
+      const int nit = min(MM_ITEMS_PER_BIN, (cnt + MM_ITEM_EDGES - 1) / MM_ITEM_EDGES);
+      if (ki < nit) {
+        it_lo = s0 + (int)((long long)cnt * ki / nit); it_hi = s0 + (int)((long long)cnt * (ki + 1) / nit);
+        const int gpf = grp.ngy * grp.ngx, bf = bin / gpf, g2 = bin - bf * gpf;
+        it_b = bf / n2; it_f = bf - it_b * n2;
+        ry0 = (g2 / grp.ngx) * CORR_GRP_T - 3 - 1; rx0 = (g2 % grp.ngx) * CORR_GRP_T - 3 - 1;
+      }
+    }
+#ifdef DEVO_MM_DBG_NOSTAGE    // timing experiment (wrong results): nothing is staged
+    if (false) {
+#else
+    if (it_hi > it_lo && it_f >= 0) {
+#endif
+      // the region [block][row][column][RPOS bytes], a verbatim copy of the level's blocks: chunk q = bytes q KB .. of it, 16 per lane;
+      // rows / columns outside the frame and the bytes behind the region carry the out-of-range offset: the DMA writes zeros for them
+      const T* base = static_cast<const T*>(lv1.fmap2) + (int64_t)it_b * lv1.s_b + (int64_t)it_f * lv1.s_n;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, lv1.frame_bytes, 0x00020000);
+      const unsigned bb = (unsigned)lv1.block_stride * ESZ, shb1 = (unsigned)lv1.s_h * ESZ, swb1 = (unsigned)lv1.s_w * ESZ;
+      const unsigned lds0 = (unsigned)(uintptr_t)region;
+      for (int q = wv; q < REGION_BYTES / 1024; q += NW) {
+        const unsigned Lb = (unsigned)q * 1024u + (unsigned)lane * 16u;
+        const unsigned blk = Lb / RBLK, rem = Lb - blk * RBLK, row = rem / RROW, cbyte = rem - row * RROW, col = cbyte / RPOS;
+        const int gy = ry0 + (int)row, gx = rx0 + (int)col;
+        const bool ok = blk < (unsigned)(C / 8) && (unsigned)gy < (unsigned)lv1.H2 && (unsigned)gx < (unsigned)lv1.W2;
+        const unsigned voff = ok ? blk * bb + (unsigned)gy * shb1 + (unsigned)gx * swb1 + (cbyte - col * RPOS) : 0x80000000u;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)q * 1024u));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(dst) : "memory");
+      }
+      region_pending = true;
+    }
+  }
+  auto region_ready = [&]() {                             // once per wave of a staging workgroup: own DMA landed, then everybody's
+    if constexpr (LDS1) {
+      if (region_pending) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        region_pending = false;
+        if (trace) g_st[1] = __builtin_amdgcn_s_memrealtime();
+      }
+    }
+  };
+  if constexpr (!LDS1) {
   if (EPW == 1) slot = mm_plan_slot(order, BE, wgid, nwg);
   else {                                       // workgroup g (on XCD g % 8) takes EPW consecutive slots of its XCD's contiguous share of the plan
     const int per = (nwg + 7) >> 3;
@@ -211,7 +316,23 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
     slot = (int)blockIdx.x * EPW + wv;
     if (slot >= (order ? min(max(order[BE], 0), BE) : 0)) return;
   }
-  if (slot >= BE) return;                     // wave-uniform; no workgroup barriers in this kernel
+  if (slot >= BE) return;                     // wave-uniform; no workgroup barriers in this (per-edge) form
+  }
+  // group form: the item's edges wv, wv + NW, .. first, then this wave's share of the HEAVY and DEAD classes (per-edge paths, no region)
+  for (int turn = 0; ; turn++) {
+  bool in_item = false;
+  if constexpr (LDS1) {
+    const int idx = it_lo + wv + turn * NW;
+    if (idx < it_hi) { slot = idx; in_item = true; }
+    else {
+      region_ready();                          // (a wave without an edge of the item still owes the barrier)
+      if (trace && g_st[2] == 0) g_st[2] = __builtin_amdgcn_s_memrealtime();
+      const int nturn = (it_hi - it_lo - wv + NW - 1) / NW;                     // turns this wave spent on the item (>= 0)
+      const int h = ((int)blockIdx.x * NW + wv) + (turn - max(nturn, 0)) * (int)gridDim.x * NW;
+      if (h >= hv_n + dd_n) break;
+      slot = h < hv_n ? h : BE - dd_n + (h - hv_n);          // the HEAVY class in front of the plan, the DEAD one at its end
+    }
+  } else if (turn > 0) break;
   unsigned long long t_st[5] = {0, 0, 0, 0, 0};  // debug (DEVO_CORR_TRACE): cycle stamps of this wave's phases
   if (trace) t_st[0] = __builtin_readcyclecounter();
   const int be = order ? order[slot] : slot;
@@ -274,13 +395,13 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
   };
   const int vxmin = row_min(ox), vxmax = row_min(-ox), vymin = row_min(oy), vymax = row_min(-oy);
   const int WT = (ntap + 15) >> 4;                // tiles per window in window mode (a window's taps padded to whole tiles)
-  struct Geo { int xmin, ymin, bw, nslots, ntile; bool box_mode; float inv_bw; };      // wave-uniform
+  struct Geo { int xmin, ymin, bw, bh, nslots, ntile; bool box_mode; float inv_bw; };      // wave-uniform
   auto make_geo = [&](int l) -> Geo {
     const int xmin = __builtin_amdgcn_readlane(vxmin, 15 + 16 * l), xmax = -__builtin_amdgcn_readlane(vxmax, 15 + 16 * l);
     const int ymin = __builtin_amdgcn_readlane(vymin, 15 + 16 * l), ymax = -__builtin_amdgcn_readlane(vymax, 15 + 16 * l);
     Geo g;
-    g.xmin = xmin; g.ymin = ymin; g.bw = xmax - xmin + D;
-    if (ALIGN4) {
+    g.xmin = xmin; g.ymin = ymin; g.bw = xmax - xmin + D; g.bh = ymax - ymin + D;
+    if (ALIGN4 && !(LDS1 && l == 1)) {                     // (the group form's level index 1 comes from LDS: the tight box)
       // The texture addresser retires one quad of lanes per cycle and 128-byte line it touches (tools/ubench/l2_fill.hip).  A quad is four
       // consecutive box positions (16 or 32 bytes each): with the box's left edge at a multiple of 4 positions and its width a multiple
       // of 4, no quad straddles a line or a box row, for ~30 % more positions.  It pays with 16-byte position records (fp16); with fp32's
@@ -422,7 +543,7 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
   // straight-line code per count (a uniform switch picks one): no dead fetch, no scalar bookkeeping, every wait counted by the compiler.
   constexpr bool EXACT = RFIX == 3 && RMAX == 3;
   auto exact_count = [](int n, int hi) -> bool { return n == 0 || (n >= 4 && n <= hi); };
-  constexpr int K0MAX = ALIGN4 ? 10 : 8;                   // (aligned boxes: up to 160 positions at level index 0)
+  constexpr int K0MAX = CAP / 16;                          // tiles of the largest box the result area holds (level index 1: up to 8)
   if (EXACT && all_box && exact_count(g0.ntile, K0MAX) && (NL == 1 || exact_count(g1.ntile, 8))) {
     // Every wave-instruction of a load occupies the CU's texture addresser (16 quads, ~1.4 cycles each: a quad of four positions x 16 bytes
     // straddles a 128-byte line three times in eight) whether its lanes fetch or not — the addresser is ~97 % busy in this kernel
@@ -474,23 +595,84 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
         __builtin_amdgcn_sched_barrier(0);
       }
     };
+    // group form: level index 1's tiles from the staged region — position (gy, gx) of block blk at (gy - ry0) RROW + (gx - rx0) RPOS +
+    // blk RBLK; lanes beyond the box read its last position (their rows of the product are never looked at)
+    auto fetch_lds = [&](int ring, int t) {
+      const int sl = min(t * 16 + mi, g1.nslots - 1);
+      const int pyy = (int)(((float)sl + 0.5f) * g1.inv_bw);
+      const int gy = g1.ymin + pyy - ry0, gx = g1.xmin + (sl - __mul24(pyy, g1.bw)) - rx0;
+      const unsigned char* a = region + (unsigned)gy * RROW + (unsigned)gx * RPOS + (unsigned)kg * RBLK;
+#pragma unroll
+      for (int s = 0; s < NKS; s++) {
+        xr[ring][s][0] = *reinterpret_cast<const v4u32*>(a + (unsigned)s * 4u * RBLK);
+        if constexpr (!HALF) xr[ring][s][1] = *reinterpret_cast<const v4u32*>(a + (unsigned)s * 4u * RBLK + 16u);
+      }
+    };
+    auto run_level_lds = [&](auto k_c) {
+      constexpr int K = decltype(k_c)::value;
+      fetch_lds(0, 0);
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        if (i + 1 < K) fetch_lds((i + 1) % XR, i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const mm_f4 acc = multiply(i % XR);
+        if (mi < PP) *reinterpret_cast<mm_f4*>(dst + i * 16) = acc;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // does level index 1 of this edge come from the region?  (wave-uniform; what the group plan promises for the item's edges, checked)
+    bool from_lds = false;
+    if constexpr (LDS1)
+      from_lds = in_item && it_f >= 0 && b == it_b && (int)fj == it_f && lv1.cb_shift == 3 && g1.ntile > 0 && g1.xmin >= rx0 && g1.ymin >= ry0 &&
+                 g1.xmin + g1.bw <= rx0 + GRP_RW && g1.ymin + g1.bh <= ry0 + GRP_RW;
+#ifdef DEVO_MM_DBG_NOLDS     // timing experiment: the group form's schedule with level index 1 through the addresser
+    from_lds = false;
+#endif
     using std::integral_constant;
     auto zero_area = [&]() { for (int i = lane; i < PP * BOXS; i += 64) s_rawwin[i] = 0.0f; };
     const int k0 = g0.ntile, k1 = NL == 2 ? g1.ntile : 0;
     // level index 0 (its tile 0 — or, without tiles, level index 1's — goes first)
-    if (k0 > 0) fetch_lt(0, 0, 0); else if (NL == 2) fetch_lt(0, 1, 0);
+    if (k0 > 0) fetch_lt(0, 0, 0); else if (NL == 2 && !LDS1) fetch_lt(0, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
-    constexpr bool N2 = NL == 2;
+    constexpr bool N2 = NL == 2 && !LDS1;                    // (group form: no fetch of level index 1's first tile behind level index 0's last)
     switch (k0) {
       case 4: run_level(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
       case 5: run_level(integral_constant<int, 0>{}, integral_constant<int, 5>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
       case 6: run_level(integral_constant<int, 0>{}, integral_constant<int, 6>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
       case 7: run_level(integral_constant<int, 0>{}, integral_constant<int, 7>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
       case 8: run_level(integral_constant<int, 0>{}, integral_constant<int, 8>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
-      case 9: if constexpr (ALIGN4) run_level(integral_constant<int, 0>{}, integral_constant<int, 9>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
-      case 10: if constexpr (ALIGN4) run_level(integral_constant<int, 0>{}, integral_constant<int, 10>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
+      case 9: if constexpr (K0MAX >= 9) run_level(integral_constant<int, 0>{}, integral_constant<int, 9>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
+      case 10: if constexpr (K0MAX >= 10) run_level(integral_constant<int, 0>{}, integral_constant<int, 10>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
+      case 11: if constexpr (K0MAX >= 11) run_level(integral_constant<int, 0>{}, integral_constant<int, 11>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
+      case 12: if constexpr (K0MAX >= 12) run_level(integral_constant<int, 0>{}, integral_constant<int, 12>{}, integral_constant<int, 0>{}, integral_constant<bool, N2>{}); break;
       default: zero_area(); break;                           // no tiles: its box of zeros
     }
+    if constexpr (LDS1) {
+      blend(0);
+      if (k1 == 0) zero_area();
+      if (from_lds) {
+        region_ready();
+        switch (k1) {
+          case 4: run_level_lds(integral_constant<int, 4>{}); break;
+          case 5: run_level_lds(integral_constant<int, 5>{}); break;
+          case 6: run_level_lds(integral_constant<int, 6>{}); break;
+          case 7: run_level_lds(integral_constant<int, 7>{}); break;
+          case 8: run_level_lds(integral_constant<int, 8>{}); break;
+          default: break;
+        }
+      } else if (k1 > 0) {                                   // (not promised by the plan: through the addresser, like the per-edge form)
+        fetch_lt(0, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        switch (k1) {
+          case 4: run_level(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+          case 5: run_level(integral_constant<int, 1>{}, integral_constant<int, 5>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+          case 6: run_level(integral_constant<int, 1>{}, integral_constant<int, 6>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+          case 7: run_level(integral_constant<int, 1>{}, integral_constant<int, 7>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+          case 8: run_level(integral_constant<int, 1>{}, integral_constant<int, 8>{}, integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+          default: break;
+        }
+      }
+    } else
     if constexpr (NL == 2) {
       blend(0);                                              // (level index 1's tile 0 is in flight)
       if (k1 == 0) zero_area();
@@ -663,10 +845,21 @@ __global__ __launch_bounds__(64 * DEVO_MM_EPW) __attribute__((amdgpu_waves_per_e
       }
     }
   }
-  if (trace && lane == 0) {                          // per-wave cycle stamps (launch_mm prints the phase means)
+  if (!LDS1 && trace && lane == 0) {                 // per-wave cycle stamps (launch_mm prints the phase means)
     unsigned long long* t = trace + (size_t)slot * 8;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     t[0] = t_st[0]; t[1] = t_st[1]; t[2] = t_st[2]; t[3] = t_st[3]; t[4] = __builtin_readcyclecounter(); t[5] = (unsigned long long)(nt0 + 1000 * (ntot - nt0));
+  }
+  if constexpr (LDS1) wave_lds_fence();                    // (the next edge's records overwrite this one's result area / geometry)
+  }   // turns
+  if (LDS1 && trace && lane == 0) {
+    unsigned long long* t = trace + ((size_t)blockIdx.x * NW + wv) * 8;
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    t[0] = g_st[0]; t[1] = g_st[1]; t[2] = g_st[2]; t[3] = __builtin_amdgcn_s_memrealtime();
+    t[4] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32); t[5] = (unsigned long long)max(it_hi - it_lo, 0);
   }
 #undef LVF
 }

@@ -26,7 +26,8 @@ inline int corr_order_workgroups(long long BE, long long nbins) {
 // CACHE > 0: the ceil(BE / 1024) <= CACHE bins of a thread are loaded at once into registers (one round trip to memory instead of
 // one per loop iteration and pass); CACHE == 0: any BE, bins re-read by both passes.
 template <int CACHE>
-__device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order, int g, int G) {
+__device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, int BE, int nbins, int* __restrict__ order, int g, int G,
+                                                bool starts = false) {     // starts: a GROUP plan — every bin's first slot goes into the plan's tail
   __shared__ int s_cnt[ORDER_MAXBINS + 1];
   __shared__ int s_base[2];                                 // [0] = edges below this workgroup's range, [1] = heavy cursor (g == 0)
   constexpr bool CACHED = CACHE > 0;
@@ -65,9 +66,12 @@ __device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, in
       const int i = base + threadIdx.x;
       const int v = (i < nown) ? s_cnt[i] : 0;
       const int x = wave_inclusive_sum(v);
-      if (i < nown) s_cnt[i] = carry + x - v;
+      if (i < nown) {
+        s_cnt[i] = carry + x - v;
+        if (starts) order[2 * BE + 2 + b0 + i] = carry + x - v;
+      }
       // the last bin of all is the DEAD class of the pyramid plan (corr_plan_bin): its size goes behind the scratch half
-      if (g == G - 1 && i == nown - 1) order[2 * BE + 1] = v;
+      if (g == G - 1 && i == nown - 1) { order[2 * BE + 1] = v; if (starts) order[2 * BE + 2 + nbins] = BE; }
       carry += __builtin_amdgcn_readlane(x, 63);
     }
   }

@@ -35,6 +35,29 @@ __host__ __device__ __forceinline__ int corr_plan_bx(int xw) {   // column bins 
   return b < 1 ? 1 : b;
 }
 
+__device__ __forceinline__ int corr_floor_to_int(float v) {
+  // static_cast<int>(floor(v)) (correlation_kernel.cu:118-119), made safe for non-finite / huge inputs
+  float f = floorf(v);
+  f = fminf(fmaxf(f, -1.0e6f), 1.0e6f);
+  return (f == f) ? (int)f : -1000000;
+}
+
+// GROUP PLAN (the lookup's group form, corr_mm.h NW > 1: level 1 of a two-level lookup read from LDS).  A GROUP = the edges of one
+// target frame whose patch CENTRE falls into one tile of CORR_GRP_T x CORR_GRP_T level-1 cells; its REGION = the level-1 positions any
+// compact patch of the group can touch: the centre cell c gives window origins in [c - R - 1, c - R] (the 9 pixels lie within one cell
+// of the centre) and windows of D = 2 R + 2 positions, so rows [t0 - R - 1, t0 + T + R + 2) = T + 2 R + 3 of them, columns alike.
+// bin = group; HEAVY = a box that breaks the promise (level 1 outside the region, level 0 beyond 128 positions); DEAD = outside the
+// frame at both levels.  The ordering step also stores every bin's first slot (corr_plan.h): workgroups find their group's edges there.
+constexpr int CORR_GRP_T = 6;
+constexpr int CORR_PLAN_TAIL = 4104;                          // ints behind the 2 BE + 2 of an edge plan: bin starts (<= CORR_ORDER_MAXBINS + 1), padding
+__host__ __device__ __forceinline__ int corr_grp_count(int cells) { return (cells + CORR_GRP_T - 1) / CORR_GRP_T; }
+// bins of a group plan: one per (batch, frame, group) + the DEAD class; 0 = more than the ordering step's counters hold
+inline long long corr_grp_nbins(long long B, int n2, int H2, int W2, int l1) {
+  if (l1 < 2 || H2 / l1 < 1 || W2 / l1 < 1) return 0;
+  const long long nb = B * n2 * corr_grp_count(H2 / l1) * corr_grp_count(W2 / l1) + 1;
+  return nb <= 4096 ? nb : 0;
+}
+
 // Plan bin of an edge from its 9 window origins: -1 = HEAVY (the union box does not fit the tile), else
 // (batch, target frame, 16-row band of the patch centre, column bin of the patch centre) — consecutive edges of the sorted
 // plan land next to each other in the image, which is what the region-shared lookup kernel (corr_region.h) groups on.
@@ -59,10 +82,18 @@ __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float c
     // window origins: floor(coordinate) - R at level 0, floor(coordinate / l1) - R = floor(floor(coordinate) / l1) - R at level 1
     const int x0 = xlo - R, y0 = ylo - R, w0 = xhi - xlo + D, h0 = yhi - ylo + D;
     const int x1 = fdiv(xlo, l1) - R, y1 = fdiv(ylo, l1) - R, w1 = fdiv(xhi, l1) - fdiv(xlo, l1) + D, h1 = fdiv(yhi, l1) - fdiv(ylo, l1) + D;
+    const int H1 = H2 / l1, W1 = W2 / l1;
     const bool live0 = x0 < W2 && y0 < H2 && x0 + w0 > 0 && y0 + h0 > 0;
-    const bool live1 = x1 < W2 / l1 && y1 < H2 / l1 && x1 + w1 > 0 && y1 + h1 > 0;
+    const bool live1 = x1 < W1 && y1 < H1 && x1 + w1 > 0 && y1 + h1 > 0;
     if (!live0 && !live1) return dead_bin;
-    if ((live0 && (long long)w0 * h0 > heavy_cells) || (live1 && (long long)w1 * h1 > heavy_cells)) return -1;
+    // the group of the patch centre (clamped into the frame) and its region
+    const int cy1 = min(max(fdiv(corr_floor_to_int(centre_y), l1), 0), H1 - 1), cx1 = min(max(fdiv(corr_floor_to_int(centre_x), l1), 0), W1 - 1);
+    const int gy = cy1 / CORR_GRP_T, gx = cx1 / CORR_GRP_T, ngy = corr_grp_count(H1), ngx = corr_grp_count(W1);
+    const int ry0 = gy * CORR_GRP_T - R - 1, rx0 = gx * CORR_GRP_T - R - 1, rs = CORR_GRP_T + 2 * R + 3;
+    if (live0 && (long long)w0 * h0 > heavy_cells) return -1;
+    if (live1 && !(x1 >= rx0 && y1 >= ry0 && x1 + w1 <= rx0 + rs && y1 + h1 <= ry0 + rs)) return -1;
+    const int f = min(max(frame, 0), n2 - 1);
+    return ((b * n2 + f) * ngy + gy) * ngx + gx;
   } else
   // HEAVY = clearly more passes of the matrix-core kernel than a compact patch needs at this radius — more than two 64-position
   // passes for r <= 3, more than four for r <= 5 (a compact r = 5 box is 14 x 14 = 196 positions: with the r <= 3 threshold EVERY
@@ -128,13 +159,6 @@ __device__ __forceinline__ int wave_inclusive_sum(int x) {
   x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
   return x;
-}
-
-__device__ __forceinline__ int corr_floor_to_int(float v) {
-  // static_cast<int>(floor(v)) (correlation_kernel.cu:118-119), made safe for non-finite / huge inputs
-  float f = floorf(v);
-  f = fminf(fmaxf(f, -1.0e6f), 1.0e6f);
-  return (f == f) ? (int)f : -1000000;
 }
 
 }  // namespace devo

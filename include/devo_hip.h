@@ -78,6 +78,10 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
                                const void* fmap1_t /* optional, as for devo_corr_forward: the dense-product kernel does both levels of an
                                                       edge in one wave */,
                                const int* fmap2_exps_l0, const int* fmap2_exps_l1 /* scale exponents of split-blocked levels, or NULL */,
+                               int order_kind /* DEVO_PLAN_EDGES: `order` is an edge plan (or NULL); DEVO_PLAN_GROUPS: a group plan
+                                                 (devo_corr_order with l1 = 4 on level 0's coordinates) — radius 3, C = 128, level 1 = the
+                                                 quarter-resolution level in 8-channel blocks: level 1 is then read from LDS regions shared by
+                                                 the edges of a group (csrc/corr_mm.h, the group form); same results */,
                                devo_stream_t stream);
 
 /* fmap1 T [n_patches, C, 3, 3] -> fmap1_t, the patch operand of the dense-product lookup kernel, an opaque buffer of
@@ -111,11 +115,20 @@ int devo_corr_pyramid_split(const void* fmap2, const int64_t* f2s /* host, 4 */,
 int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, int E, int n2, int P, int H2,
                     float coord_scale, int radius,
                     int W2 /* width of the plan's level; only read when l1 >= 2 */,
-                    int l1 /* 0: single-level plan.  >= 2 (DEVO: 4): PYRAMID plan for devo_corr_forward_pyramid2 — the lookup has a second
-                              level at 1 / l1 of this resolution.  Classes: DEAD edges (union box outside the frame at both levels: every
-                              output is 0) go BEHIND all others, order[2*B*E + 1] = their number; HEAVY = more than 128 (radius <= 3) / 256
-                              box positions at a level the box touches; bins are numbered band by band */,
+                    int l1 /* 0: edge plan (above).  >= 2 (DEVO: 4): GROUP plan for devo_corr_forward_pyramid2(order_kind = DEVO_PLAN_GROUPS) —
+                              the lookup has a second level at 1 / l1 of this resolution, radius 3; `order` is then i32
+                              [DEVO_CORR_PLAN_INTS(B*E)].  A group = the edges of one target frame whose patch centre lies in one tile of
+                              6 x 6 level-1 cells; the plan sorts the edges by group (same prefix as an edge plan: any lookup accepts it) and
+                              stores every group's first slot behind the 2*B*E + 2 ints.  Classes: DEAD edges (union box outside the frame at
+                              both levels: every output is 0) go BEHIND all others, order[2*B*E + 1] = their number; HEAVY (in front) = more
+                              than 128 level-0 box positions, or a level-1 box that leaves the group's 15 x 15 region (patch pixels more than
+                              a level-1 cell from the centre).  DEVO_ERR_UNSUPPORTED when the frames have more than 4095 groups together
+                              (or radius != 3): use an edge plan */,
                     devo_stream_t stream);
+#define DEVO_CORR_PLAN_TAIL 4104
+#define DEVO_CORR_PLAN_INTS(BE) (2 * (BE) + 2 + DEVO_CORR_PLAN_TAIL) /* ints of a plan buffer that can hold a group plan (an edge plan uses the first 2 BE + 2) */
+#define DEVO_PLAN_EDGES 0
+#define DEVO_PLAN_GROUPS 1
 
 /* Pyramid build for the lookup (devo/devo.py:526-527: fmap1_[slot] = avg_pool2d(fmap, 1, 1), fmap2_[slot] =
  * avg_pool2d(fmap, 4, 4); devo/utils.py:70-79): F frames fmap T [F, C, H, W] (contiguous frames, frame stride
@@ -187,10 +200,11 @@ int devo_ba_prepare(const int64_t* kk, int E, int Np, int N /* t1 - t0 */, void*
                     devo_stream_t stream);
 /* devo_ba_prepare + the ordering step of the lookup's locality plan (devo_corr_order with coords = NULL) in ONE launch:
  * both are single-workgroup, latency-bound kernels that do not depend on each other, so they run as two workgroups side
- * by side.  plan: i32 [2E + 2] whose bins devo_transform(..., plan, plan_frames, plan_height, radius) has written
- * (batch 1); afterwards it is the finished plan for devo_corr_forward*. */
+ * by side.  plan: i32 [2E + 2] (group plans: [DEVO_CORR_PLAN_INTS(E)]) whose bins devo_transform(..., plan, plan_frames, plan_height,
+ * radius, plan_width, plan_l1) has written (batch 1); afterwards it is the finished plan for devo_corr_forward*.  plan_width, plan_l1:
+ * the values given to devo_transform (l1 = 0: edge plan). */
 int devo_ba_prepare_plan(const int64_t* kk, int E, int Np, int N /* t1 - t0 */, void* ws, size_t ws_bytes, int* plan,
-                         int plan_frames, int plan_height, devo_stream_t stream);
+                         int plan_frames, int plan_height, int plan_width, int plan_l1, devo_stream_t stream);
 /* Inspection of a prepared workspace (tests / debugging): copies (device to device, any pointer may be NULL)
  * *n_seg = number of distinct patches with edges, kx i32 [min(E,Np)] = their ids ascending (the first output of
  * torch::_unique(kk), ba_cuda.cu:435-437), seg_start i32 [min(E,Np)+1] and perm i32 [E]: the edges of patch kx[s]
@@ -278,7 +292,7 @@ int devo_ba_reproject(const float* poses, const float* patches, const float* int
  *   valid   f32 [E] or NULL (Z > 0.2 at the centre pixel, :100/:103)
  *   Ji, Jj  f32 [E,2,6], Jz f32 [E,2] or NULL  (:73-98; Ji already negated as in :96)
  *   flags   bit0 = depth, bit1 = tonly
- *   plan    optional locality-plan buffer of the lookup (i32 [2*E + 2], see devo_corr_order): while the
+ *   plan    optional locality-plan buffer of the lookup (i32 [2*E + 2], group plans [DEVO_CORR_PLAN_INTS(E)], see devo_corr_order): while the
  *           coordinates are still in registers the kernel writes every edge's plan bin (for a pyramid whose
  *           level 0 has plan_frames frames of plan_height rows, lookup radius plan_radius) into the buffer's
  *           scratch half; devo_corr_order(coords = NULL, ...) then only sorts.  P == 3.  NULL = no plan. */

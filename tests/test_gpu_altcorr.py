@@ -683,3 +683,68 @@ def test_fp32_lookup_at_any_feature_magnitude(case, layout):
             assert_rel(got[:, sel.to(DEV)], ref[:, sel], 1e-4, f"frame {k}")
     else:
         assert_rel(got, ref, 1e-4, case)
+
+
+def _group_case(n=5, Np=60, C=128, H=48, W=64, E=6000, seed=0, heavy_frac=0.03):
+    """Compact patches (pixel spacing 0.6 - 1.5 px) all over and around an H x W frame, a few widely spread ones, a few far outside."""
+    g = torch.Generator().manual_seed(seed)
+    f1 = torch.randn(1, Np, C, 3, 3, generator=g) / 4
+    f2 = torch.randn(1, n, C, H, W, generator=g) / 4
+    base = torch.stack([torch.rand(E, generator=g) * (W + 40) - 20, torch.rand(E, generator=g) * (H + 40) - 20], 1)
+    oy, ox = torch.meshgrid(torch.arange(3.) - 1, torch.arange(3.) - 1, indexing="ij")
+    off = torch.stack([ox, oy], 0)
+    scale = 0.6 + 0.9 * torch.rand(E, 1, 1, 1, generator=g)
+    wide = torch.rand(E, generator=g) < heavy_frac
+    scale[wide] = scale[wide] * 6.0                                    # level-1 boxes that leave their group's region / level-0 boxes beyond 128 positions
+    coords = base[:, :, None, None] + scale * off[None] + 0.2 * torch.randn(E, 2, 3, 3, generator=g)
+    coords[:7] = -300.0 + off                                          # dead edges
+    ii = torch.randint(0, Np, (E,), generator=g)
+    jj = torch.randint(0, n, (E,), generator=g)
+    return f1, f2, coords[None].contiguous(), ii, jj
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("H,W", [(48, 64), (44, 52), (120, 160)])
+def test_group_form_reads_level_1_from_lds_and_changes_nothing(dtype, H, W):
+    """The fused two-level lookup with a GROUP plan (cuda_corr.plan(..., width, l1 = 4); csrc/corr_mm.h, NW > 1): workgroups stage their
+    group's 15 x 15 region of level 1 in LDS and their waves read level 1's tiles from there.  Same products in the same order: the
+    output is bit-identical to the per-edge form's (an edge plan), for every class of edge (compact, heavy, dead, frame borders, frames
+    whose size is not a multiple of the group tile) — and within the fp32 / fp16 tolerances of the oracle."""
+    from devo_amd import altcorr, synth
+    from devo_amd.backends import cuda_corr
+    f1, f2, coords, ii, jj = _group_case(H=H, W=W, seed=H + W, E=6000 if H < 100 else 9000)
+    n, E = f2.shape[1], coords.shape[1]
+    d = lambda t: t.to(DEV)
+    f2d = d(f2).to(dtype)
+    pyr = [altcorr.channel_blocked(f2d, 8), altcorr.channel_blocked(synth.pyramid_l1(f2d.float()).to(dtype), 8)]
+    g = d(f1).to(dtype)
+    out = {}
+    for kind in ("edges", "groups"):
+        order = cuda_corr.plan(d(coords), d(jj), n, H, 1.0, 3, width=W if kind == "groups" else 0, l1=4 if kind == "groups" else 0)
+        assert cuda_corr.plan_kind(order, E) == (1 if kind == "groups" else 0)
+        res = torch.full((1, E, 49 * 18), float("nan"), dtype=dtype, device=DEV)
+        cuda_corr.forward_pyramid(g, pyr, d(coords), d(ii), d(jj), 3, (1, 4), out=res, order=order)
+        out[kind] = res
+    assert torch.equal(out["groups"], out["edges"])
+    # the group plan: a permutation, heavy first, dead last, every group's slots contiguous and inside one frame
+    order = cuda_corr.plan(d(coords), d(jj), n, H, 1.0, 3, width=W, l1=4).cpu()
+    perm = order[:E]
+    assert sorted(perm.tolist()) == list(range(E))
+    nh, nd = int(order[E]), int(order[2 * E + 1])
+    gy, gx = (H // 4 + 5) // 6, (W // 4 + 5) // 6
+    nb = n * gy * gx + 1
+    starts = order[2 * E + 2: 2 * E + 2 + nb + 1]
+    assert int(starts[0]) == nh and int(starts[nb]) == E and int(starts[nb - 1]) == E - nd and nd >= 7
+    assert bool((starts[1:] >= starts[:-1]).all())
+    fr = jj[perm[nh:E - nd]]
+    own = torch.repeat_interleave(torch.arange(nb - 1) // (gy * gx), (starts[1:nb] - starts[:nb - 1]).long())
+    assert torch.equal(fr, own)
+    assert nh > 0 and nh < E // 2                                   # (pixel spacings up to 1.5 px: many level-0 boxes beyond 128 positions)
+    # oracle on a sample
+    sel = torch.randperm(E, generator=torch.Generator().manual_seed(1))[:400]
+    q = lambda t: t.to(dtype).float()
+    cs = coords[:, sel]
+    r0 = A.corr_forward(q(f1), q(f2), cs, ii[sel], jj[sel], 3)
+    r1 = A.corr_forward(q(f1), q(synth.pyramid_l1(f2d.float()).cpu()), cs / 4, ii[sel], jj[sel], 3)
+    ref = torch.stack([r0, r1], -1).view(1, len(sel), -1)
+    assert_rel(out["groups"][:, sel.to(DEV)].float(), ref, 1e-4 if dtype == torch.float32 else 2e-3, "group form vs oracle")

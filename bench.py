@@ -52,6 +52,11 @@ def parse():
     ap.add_argument("--steps-per-graph", type=int, default=20,
                     help="consecutive steps captured into one HIP graph launch (a graph launch costs ~10 us of idle GPU; 1 = one launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-allcores", action="store_true",
+                    help="cpu_baseline also times the BA with one torch thread per host core (field ba_ms_allcores: ~25 s of oversubscribed "
+                         "CPU on a 256-core host, 1000x slower than 16 threads; measured once in profiles/, opt-in since)")
+    ap.add_argument("--with-stress", action="store_true",
+                    help="also run BASELINE configuration 5 (M=256, n=32, r=5, 1280x720) and add its step rate and lookup roofline as field \"stress\"")
     ap.add_argument("--kernel-reps", type=int, default=50, help="launch pairs timed for the roofline figure")
     ap.add_argument("--mode", default="update-op", choices=["update-op", "train"],
                     help="update-op: the headline metric (BASELINE configuration 2, replicas when --gpus > 1); train: BASELINE "
@@ -114,7 +119,7 @@ def build_inputs(cfg, seed, device, dtype, layout):
     return d, cpu
 
 
-PROBE_TIMEOUT_S = float(os.environ.get("DEVO_BENCH_PROBE_TIMEOUT", "240"))   # multi-GPU default runs: the data-parallel training probe may take this long at most
+PROBE_TIMEOUT_S = float(os.environ.get("DEVO_BENCH_PROBE_TIMEOUT", "60"))   # multi-GPU default runs: the data-parallel training probe may take this long at most
 
 
 def alg_bytes(cfg, E, esize):
@@ -468,7 +473,9 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         empty.append((a, b))
     torch.cuda.synchronize()
     t_event_pair = sum(a.elapsed_time(b) for a, b in empty) * 1e-3 / len(empty)
-    t_launch = max(t_in_step - t_event_pair / (1 if args.fuse_levels else 2), 0.5 * t_in_step)
+    # roofline figure: the back-to-back launches replayed from a graph (no event-pair correction; rocprofv3's per-kernel average of this
+    # command, profiles/, lies between this and the raw in-step figure)
+    t_launch = t_back_to_back
     b_alg = alg_bytes(cfg, E, 4 if dtype == torch.float32 else 2) / (1.0 if args.fuse_levels else 2.0)   # bytes per launch
     achieved = b_alg / t_launch / 1e9
     f_alg = 2.0 * cfg["C"] * E * 9 * (2 * R + 2) ** 2 * (2.0 if args.fuse_levels else 1.0)    # flops per launch
@@ -526,12 +533,15 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
                      "alg_gflop_per_launch": round(f_alg / 1e9, 3), "achieved_tflops": round(f_alg / t_launch / 1e12, 2),
                      "t_min_us": round(max(b_alg / (HBM_PEAK_GBS * 1e9), f_alg / 157.3e12) * 1e6, 1),
                      "alg_bytes_per_launch": int(b_alg), "us_per_launch": round(t_launch * 1e6, 2),
-                     "us_per_launch_back_to_back": round(t_back_to_back * 1e6, 2), "event_pair_us": round(t_event_pair * 1e6, 2),
-                     "timing": "HIP events around the lookup launch inside the step (eager steps after the timed region), minus the cost of an empty event pair; back_to_back = lookups only, replayed from a graph"},
-        "ba": {"gpu_ms": round(t_ba_gpu * 1e3, 4)},
+                     "us_per_launch_back_to_back": round(t_back_to_back * 1e6, 2), "us_per_launch_in_step_raw": round(t_in_step * 1e6, 2),
+                     "event_pair_us": round(t_event_pair * 1e6, 2),
+                     "timing": "achieved / frac / us_per_launch: HIP events around " + str(args.kernel_reps) + " lookup launches replayed back to back from a HIP graph, nothing "
+                               "subtracted; in_step_raw: events around the lookup of eager steps (includes one event pair, event_pair_us)"},
+        "ba": dict({"gpu_ms": round(t_ba_gpu * 1e3, 4)}, **ba_kernel_report(run_ba=lambda: cuda_ba.forward(
+            d["poses"], d["patches"], d["intr"], tgt, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws))),
     }
 
-    if not args.no_full_iteration and not secondary and args.workload == "cfg2":
+    if not args.no_full_iteration and not secondary and args.workload == "cfg2" and world == 1:
         # A FULL update iteration as devo.py:305-340 runs it: reprojection, lookup, the Update operator (devo_amd.update, random weights)
         # on the lookup's output, target = centre + delta, 2 GN iterations with the predicted weights.  An extra field: the headline
         # metric excludes the Update MLP.  fp32 = every Linear layer on csrc/linear.hip's split-precision GEMM.
@@ -626,15 +636,72 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         except Exception as ex:                                  # noqa: BLE001 — reported, not fatal
             out["train_dp"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
         timer.cancel()
+    if rank == 0 and world == 1 and args.with_stress and args.workload != "stress":
+        try:
+            torch.cuda.empty_cache()
+            sargs = argparse.Namespace(**dict(vars(args), workload="stress", steps=max(10, args.steps // 10), warmup=2, steps_per_graph=1, kernel_reps=10))
+            st = update_op_mode(sargs, device, rank, world, dtype_name=dtn, secondary=True)
+            out["stress"] = {"value": st["value"], "unit": "it/s", "ms_per_step": st["ms_per_step"], "workload": st["config"]["workload"],
+                             "roofline": {k: st["roofline"].get(k) for k in ("achieved", "frac", "kernel", "alg_bytes_per_launch", "us_per_launch", "traffic", "traffic_source")},
+                             "ba": st["ba"]}
+        except Exception as ex:                                  # noqa: BLE001 — an extra field must not cost the line
+            out["stress"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, cpu, E)
+        out["cpu_baseline"] = cpu_baseline(cfg, cpu, E, allcores=args.cpu_allcores)
         out["ba"]["cpu_ms"] = out["cpu_baseline"]["ba_ms"]
         out["ba"]["speedup"] = round(out["cpu_baseline"]["ba_ms"] / (t_ba_gpu * 1e3), 1)
     return out
 
 
 
-def cpu_baseline(cfg, cpu, E):
+def ba_kernel_report(run_ba):
+    """north_star / SURVEY 8d: what the fastba report carries besides the time — launches per BA call, and per kernel its average duration in
+    this run (torch.profiler over three calls), LDS bytes per workgroup and resident waves per SIMD (compiler figures,
+    profiles/ba_kernel_resources.json, written by tools/kernel_resources.py --json)."""
+    rep = {}
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        run_ba()
+        torch.cuda.synchronize()
+        calls = 3
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(calls):
+                run_ba()
+            torch.cuda.synchronize()
+        ker = {}
+        for ev in prof.events():
+            if getattr(ev, "device_type", None) is not None and "cuda" in str(ev.device_type).lower() and ("devo::" in ev.name or "k_ba" in ev.name):
+                k = ev.name.split("(")[0].replace("void ", "").replace("devo::", "")
+                k = k.split("<")[0]
+                a = ker.setdefault(k, [0, 0.0])
+                a[0] += 1
+                a[1] += float(getattr(ev, "device_time", 0.0) or getattr(ev, "cuda_time", 0.0))
+        if ker:
+            rep["launches"] = int(round(sum(v[0] for v in ker.values()) / calls))
+            rep["kernels"] = {k: {"per_call": round(v[0] / calls, 2), "avg_us": round(v[1] / max(v[0], 1), 2)} for k, v in sorted(ker.items(), key=lambda kv: -kv[1][1])}
+            rep["solve_us"] = round(sum(v[1] for k, v in ker.items() if "solve" in k) / calls, 2)
+            rep["accumulate_us"] = round(sum(v[1] for k, v in ker.items() if "accumulate" in k or "reduce" in k) / calls, 2)
+    except Exception as ex:                                      # noqa: BLE001 — the report is an extra
+        rep["profiler_error"] = f"{type(ex).__name__}: {ex}"[:200]
+    try:
+        with open(os.path.join(ROOT, "profiles", "ba_kernel_resources.json")) as f:
+            res = json.load(f)
+        for k, v in rep.get("kernels", {}).items():
+            r = res.get(k)
+            if r:
+                v.update({"lds_bytes_per_wg": r["lds_bytes"], "waves_per_simd": r["waves_per_simd"], "vgpr": r["vgpr"]})
+        pick = lambda name: next((res[k] for k in res if k.startswith(name)), None)
+        sol, acc = pick("k_ba_solve_chain"), pick("k_ba_accumulate_reg")
+        if sol:
+            rep["lds_bytes_per_wg"] = {"k_ba_solve_chain": sol["lds_bytes"], "k_ba_accumulate_reg": acc["lds_bytes"] if acc else None}
+            rep["waves_per_simd"] = {"k_ba_solve_chain": sol["waves_per_simd"], "k_ba_accumulate_reg": acc["waves_per_simd"] if acc else None}
+            rep["resources_source"] = "profiles/ba_kernel_resources.json (hipcc -Rpass-analysis=kernel-resource-usage; LDS = static + the launch's dynamic bytes)"
+    except (OSError, ValueError, KeyError):
+        pass
+    return rep
+
+
+def cpu_baseline(cfg, cpu, E, allcores=False):
     """The reference's CPU-capable path, restated (oracle/pops.py == devo/ba.py + projective_ops.py; the
     reference has no CPU corr, so oracle/altcorr.py's gather formulation stands in), timed on the host cores.
     Bounded sample (~10-20 s): transform + 2 full-size ba.py-style BA steps (median of 3, after one warm-up) +
@@ -695,7 +762,7 @@ def cpu_baseline(cfg, cpu, E):
         t_ba1 = time.perf_counter() - t0
         # ... and for every host core (os.cpu_count() threads), measured once so that the 16-thread cap above is evidence, not assertion
         t_ba_all = None
-        if (os.cpu_count() or 1) > threads:
+        if allcores and (os.cpu_count() or 1) > threads:
             # one thread per host core: these small-tensor ops run ~1000x slower (oversubscription: 51 s for the two-iteration solve with
             # 256 threads against 45 ms with 16) — ONE Gauss-Newton iteration, doubled, keeps the default run bounded
             torch.set_num_threads(os.cpu_count())
@@ -713,7 +780,8 @@ def cpu_baseline(cfg, cpu, E):
     step_s = t_tr + t_corr + t_ba
     return {"value": round(1.0 / step_s, 4), "unit": "it/s", "cores": threads, "kind": "port", "cpu_model": model,
             "host_cores": os.cpu_count(), "ba_ms_1thread": round(t_ba1 * 1e3, 2),
-            "ba_ms_allcores": (round(t_ba_all * 1e3, 2) if t_ba_all is not None else round(t_ba * 1e3, 2)),
+            "ba_ms_allcores": (round(t_ba_all * 1e3, 2) if t_ba_all is not None else None),
+            "ba_ms_allcores_note": "one torch thread per host core (--cpu-allcores): 49 196 ms on the 256-core host of profiles/r04_bench.json against 43 ms with 16 threads",
             "sample": f"torch-CPU fp32, torch.set_num_threads({threads}): transform (full, {E} edges) + 2x ba.py-style BA (full, median of 3) + "
                       f"2-level lookup on {ns} of {E} edges (median of 3 passes" + (", scaled to E)" if ns < E else ")"),
             "ba_ms": round(t_ba * 1e3, 2), "ba_ms_samples": [round(t * 1e3, 2) for t in ts], "corr_ms_scaled": round(t_corr * 1e3, 1),

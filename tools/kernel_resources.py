@@ -2,13 +2,21 @@
 """Register / LDS / occupancy table of every kernel in libdevo_hip.so (north_star: "LDS / wavefront occupancy for fastba"):
 compiler figures from `hipcc -Rpass-analysis=kernel-resource-usage` (VGPR, AGPR, SGPR, scratch, static LDS, waves/SIMD),
 optionally joined with the LDS bytes per workgroup and the grid that a rocprofv3 kernel trace recorded
-(dynamic LDS is only known at launch).   python tools/kernel_resources.py [trace_dir]
+(dynamic LDS is only known at launch).   python tools/kernel_resources.py [trace_dir] [--json out.json]
+--json: the LAUNCHED kernels of the trace as {base name: {vgpr, sgpr, scratch, lds_bytes (at launch), waves_per_simd (registers and LDS),
+grid_wgs, wg_threads}} — bench.py's fastba report reads profiles/ba_kernel_resources.json.
 (rocprofv3's own VGPR_Count column is not used: it does not match the kernel descriptors on gfx950.)"""
 import csv, glob, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from devo_amd import build as B
 
+json_out = None
+if "--json" in sys.argv:
+    i = sys.argv.index("--json")
+    json_out = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
+records = {}
 launch = {}
 if len(sys.argv) > 1:
     for p in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
@@ -37,4 +45,16 @@ for src in B.SOURCES:
             g = launch.get(short)
             extra = f"{g[0]:8d} {g[1]:5d} {g[2]:16d} {min(32, 163840 // g[2]) if g[2] else 32:13d}" if g else f"{'-':>8} {'-':>5} {'-':>16} {'-':>13}"
             print(f"{cur.get('v', 0):5d} {cur.get('a', 0):5d} {cur.get('s', 0):5d} {cur.get('sc', 0):7d} {cur['lds']:10d} {cur.get('occ', 0):10d} | {extra}  {short[:80]}")
+            if g:
+                base = short.replace("devo::", "").split("<")[0]
+                waves_wg = max(1, g[1] // 64)
+                by_lds = (163840 // g[2]) * waves_wg // 4 if g[2] else 8           # resident waves per SIMD the launch's LDS allows
+                records.setdefault(base, {"instance": short, "vgpr": cur.get("v", 0) + cur.get("a", 0), "sgpr": cur.get("s", 0), "scratch": cur.get("sc", 0),
+                                          "lds_bytes": g[2], "waves_per_simd": max(1, min(cur.get("occ", 8), by_lds if by_lds > 0 else 1)), "grid_wgs": g[0], "wg_threads": g[1]})
             cur = None
+
+if json_out:
+    import json
+    with open(json_out, "w") as f:
+        json.dump(records, f, indent=1, sort_keys=True)
+    print("wrote", json_out, len(records), "kernels")

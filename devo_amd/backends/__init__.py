@@ -8,12 +8,36 @@ reference picks them up:
     import devo_amd.backends as b; b.install()
     import devo            # the reference package, unchanged
 """
+import os
 import sys
+
+_native = False          # False: not looked for yet; None: absent / switched off
+
+
+def native():
+    """devo_amd._C — the compiled binding (csrc/bind.cpp: pybind11 sub-modules cuda_corr / cuda_ba / lietorch_backends taking torch::Tensor,
+    + torch.ops.devo_hip) — or None: not built (python -m devo_amd.build), DEVO_BINDING=ctypes, or DEVO_LIB names another build of the
+    library (the compiled binding is linked against devo_amd/lib/libdevo_hip.so).  The ctypes modules of this package are the no-compile
+    form of the same binding; both call the same C ABI, neither has a CPU path."""
+    global _native
+    if _native is False:
+        _native = None
+        if os.environ.get("DEVO_BINDING", "native") != "ctypes" and not os.environ.get("DEVO_LIB"):
+            try:
+                from .. import _C
+                from .. import _lib
+                if _C.abi_version() == _lib.ABI_VERSION:
+                    _native = _C
+            except ImportError:
+                pass
+    return _native
 
 
 def install():
+    """Register the three modules under the names the reference imports.  With the compiled binding present these are ITS sub-modules
+    (the reference's exact signatures, torch::Tensor in, ATen allocations, c10::hip::getCurrentHIPStream()); else the ctypes modules."""
     from . import cuda_corr, cuda_ba, lietorch_backends
-    sys.modules["cuda_corr"] = cuda_corr
-    sys.modules["cuda_ba"] = cuda_ba
-    sys.modules["lietorch_backends"] = lietorch_backends
-    return cuda_corr, cuda_ba, lietorch_backends
+    n = native()
+    mods = (n.cuda_corr, n.cuda_ba, n.lietorch_backends) if n is not None else (cuda_corr, cuda_ba, lietorch_backends)
+    sys.modules["cuda_corr"], sys.modules["cuda_ba"], sys.modules["lietorch_backends"] = mods
+    return mods

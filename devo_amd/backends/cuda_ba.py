@@ -10,6 +10,11 @@ def _idx(*ts):
     return [t.long().contiguous() for t in ts]
 
 
+def _nat():
+    from . import native
+    return native()
+
+
 def workspace(E, Np, N, device):
     nbytes = L.lib().devo_ba_workspace_bytes(int(E), int(Np), int(N))
     if nbytes == 0:
@@ -61,7 +66,11 @@ def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t
             prepared=False):
     """ba.cpp:153.  Mutates `poses` ([1,Nbuf,7]) and `patches` ([1,Np,3,P,P]) in place and returns []
     (devo/fastba/ba.py:7-8 passes poses.data; devo/devo.py:337 relies on the mutation).
-    prepared=True: `ws` already holds the result of prepare() for this kk / t1 - t0."""
+    prepared=True: `ws` already holds the result of prepare() for this kk / t1 - t0.
+    With the compiled binding present this is devo_amd._C.cuda_ba.forward (same arguments)."""
+    N = _nat()
+    if N is not None:
+        return N.cuda_ba.forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, int(t0), int(t1), int(iterations), ws, status, bool(prepared))
     L.require_gpu(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk)
     for name, t in (("poses", poses), ("patches", patches)):
         if t.dtype != torch.float32 or not t.is_contiguous():
@@ -126,6 +135,9 @@ def forward_delta(poses, patches, intrinsics, coords, delta, weight, lmbda, ii, 
 
 def neighbors(ii, jj):
     """ba.cpp:154 -> [ix, jx] (int64, on the GPU); no device<->host round trip (the reference does five)."""
+    N = _nat()
+    if N is not None:
+        return N.cuda_ba.neighbors(ii, jj)
     L.require_gpu(ii, jj)
     ii, jj = _idx(ii, jj)
     E = ii.numel()
@@ -139,6 +151,9 @@ def neighbors(ii, jj):
 
 def reproject(poses, patches, intrinsics, ii, jj, kk):
     """ba.cpp:155 -> coords [1, E, 2, P, P] (no depth clamp, ba_cuda.cu:368-418)."""
+    N = _nat()
+    if N is not None:
+        return N.cuda_ba.reproject(poses, patches, intrinsics, ii, jj, kk)
     L.require_gpu(poses, patches, intrinsics, ii, jj, kk)
     P = patches.shape[-1]
     ii, jj, kk = _idx(ii, jj, kk)
@@ -161,6 +176,10 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     emits the plan bins while it holds them; width, l1 = 4: GROUP plan, see cuda_corr.plan); the half-built plan buffer is
     returned LAST — finish it with cuda_corr.plan_finish(buffer, jj, n_frames, height, radius[, width=, l1=]) or
     prepare(..., plan=(buffer, n_frames, height[, width, l1]))."""
+    if not (depth or valid or jacobian or tonly) and plan_for is None:
+        N = _nat()
+        if N is not None:                                      # coordinates only (DEVO.reproject, devo.py:218-223): the compiled binding's short form
+            return N.cuda_ba.transform_coords(poses, patches, intrinsics, ii, jj, kk, layout == "2pp")
     L.require_gpu(poses, patches, intrinsics, ii, jj, kk)
     P = patches.shape[-1]
     ii, jj, kk = _idx(ii, jj, kk)

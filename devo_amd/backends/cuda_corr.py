@@ -29,6 +29,14 @@ NCHW_CONVERT_MIN_EDGES = 1024    # from here on a lookup into the reference's NC
 
 _blocked_cache = {}        # (ptr, version, shape, strides, dtype) -> (source tensor [kept alive], channel-blocked copy); LRU
 BLOCKED_CACHE_ENTRIES = 4
+_MM_DEFAULT = MM_KERNEL
+
+
+def _nat():
+    """The compiled binding (devo_amd._C) when it is present and this module's switches are at their defaults (MM_KERNEL is read once,
+    from the environment, by the compiled binding)."""
+    from . import native
+    return native() if MM_KERNEL == _MM_DEFAULT else None
 
 
 class SplitLevel:
@@ -90,6 +98,12 @@ def _fast_layout(fmap2, n_edges, allow_split=True):
     import os
     if isinstance(fmap2, SplitLevel):
         return fmap2
+    N = _nat()
+    if N is not None and fmap2.is_cuda:                       # ONE cache for both bindings: the compiled one's
+        data, exps, cblock = N.cuda_corr._fast_layout(fmap2, int(n_edges), bool(allow_split))
+        if cblock == L.CBLOCK_SPLIT8:
+            return SplitLevel(data, exps, data.shape[2] * 8)
+        return data
     if fmap2.dtype not in (torch.float16, torch.float32) or n_edges <= 0:
         return fmap2
     st = fmap2.stride()
@@ -121,6 +135,12 @@ def _fast_layout(fmap2, n_edges, allow_split=True):
         L.check(rc, "cuda_corr: NCHW -> channel-blocked")
     _blocked_cache[key] = (fmap2, blk)
     return blk
+
+
+def cached_levels():
+    """Pyramid levels held in converted form (whichever binding is active keeps the cache): for tests."""
+    N = _nat()
+    return N.cuda_corr._cached_levels() if N is not None else len(_blocked_cache)
 
 
 def plan_buffer(n_slots, device, groups=False):
@@ -186,6 +206,12 @@ def patches_transposed(fmap1):
     """fmap1 [B, Np, C, 3, 3] -> the opaque patch operand of the dense-product lookup kernel (devo_corr_patch_transpose; a uint8 buffer:
     fp16 [B, Np, 9, C], fp32 split records + one scale exponent per patch).  DEVO's patch features change once per frame, not per update iteration: the copy is cached per version of the tensor
     (same key discipline as _fast_layout)."""
+    N = _nat()
+    if N is not None and fmap1.is_cuda:
+        t = N.cuda_corr._patch_operand(fmap1)
+        if t is None:
+            raise RuntimeError("cuda_corr.patches_transposed: no patch operand for this tensor (C % 32, fp16 / fp32, P = 3)")
+        return t
     key = (fmap1.data_ptr(), fmap1._version, tuple(fmap1.shape), fmap1.dtype)
     hit = _patch_t_cache.pop(key, None)
     if hit is not None:
@@ -236,6 +262,14 @@ def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, of
 
 
 def forward(fmap1, fmap2, coords, ii, jj, radius):
+    """correlation.cpp:58: the compiled binding's function when present (devo_amd._C.cuda_corr.forward), else the ctypes form below."""
+    N = _nat()
+    if N is not None and PLAN_MIN_EDGES == 2048:
+        return N.cuda_corr.forward(fmap1, fmap2, coords, ii, jj, int(radius))
+    return _forward_ctypes(fmap1, fmap2, coords, ii, jj, radius)
+
+
+def _forward_ctypes(fmap1, fmap2, coords, ii, jj, radius):
     """correlation.cpp:58.  Returns [corr] with logical shape [B, E, 2r+1 (x offset), 2r+1 (y offset), P, P]
     (the reference returns the same logical tensor as a permuted view; here it is contiguous)."""
     B, E = coords.shape[:2]
@@ -324,7 +358,7 @@ def _channels_last_copy(fmap2):
     while len(_cl_cache) >= BLOCKED_CACHE_ENTRIES:
         del _cl_cache[next(iter(_cl_cache))]
     cl = fmap2.detach().permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
-    _cl_cache[key] = (fmap2, cl)
+    _cl_cache[key] = (fmap2.detach(), cl)                 # (detached: pins the storage and shares the version counter, not the autograd graph)
     return cl
 
 
@@ -335,6 +369,17 @@ def _is_channels_last(fmap2):
 
 
 def backward(fmap1, fmap2, coords, ii, jj, grad, radius):
+    """correlation.cpp:59: the compiled binding's function when present, else the ctypes form below."""
+    global last_backward_path
+    N = _nat()
+    if N is not None:
+        out = N.cuda_corr.backward(fmap1, fmap2, coords, ii, jj, grad, int(radius))
+        last_backward_path = N.cuda_corr.last_backward_path() or None
+        return out
+    return _backward_ctypes(fmap1, fmap2, coords, ii, jj, grad, radius)
+
+
+def _backward_ctypes(fmap1, fmap2, coords, ii, jj, grad, radius):
     """correlation.cpp:59 -> [fmap1_grad, fmap2_grad] (fp32 only, like the reference's float grad accessor).
     fmap2_grad has fmap2's logical shape; for a plain NCHW fmap2 with C % 128 == 0 and >= NCHW_CONVERT_MIN_EDGES edges (what an
     unmodified enet.py hands over) it carries channels-last strides: the product form (corr_bwd_mfma.h) reads a cached channels-last
@@ -346,7 +391,7 @@ def backward(fmap1, fmap2, coords, ii, jj, grad, radius):
         # the reference dispatches its backward over half / float / double with a FLOAT gradient accessor
         # (correlation_kernel.cu:146,280); here the kernel is fp32: other dtypes are computed in fp32 and cast back
         dt = fmap1.dtype
-        d1, d2 = backward(fmap1.float(), fmap2.float(), coords, ii, jj, grad.float(), radius)
+        d1, d2 = _backward_ctypes(fmap1.float(), fmap2.float(), coords, ii, jj, grad.float(), radius)
         return [d1.to(dt), d2.to(dt)]
     B, E = coords.shape[:2]
     P = coords.shape[3]
@@ -379,6 +424,9 @@ def backward(fmap1, fmap2, coords, ii, jj, grad, radius):
 
 def patchify_forward(net, coords, radius):
     """correlation.cpp:61: net [B,C,H,W], coords [B,M,2] -> [patches [B,M,C,D,D]]"""
+    N = _nat()
+    if N is not None:
+        return N.cuda_corr.patchify_forward(net, coords, int(radius))
     L.require_gpu(net, coords)
     B, M = coords.shape[:2]
     C, H, W = net.shape[1:]
@@ -393,6 +441,9 @@ def patchify_forward(net, coords, radius):
 
 def patchify_backward(net, coords, gradient, radius):
     """correlation.cpp:62 -> [net_gradient [B,C,H,W]]"""
+    N = _nat()
+    if N is not None:
+        return N.cuda_corr.patchify_backward(net, coords, gradient, int(radius))
     L.require_gpu(net, coords, gradient)
     B, M = coords.shape[:2]
     C, H, W = net.shape[1:]

@@ -86,3 +86,13 @@ def as_matrix(group_id, X):
 def projector(group_id, X):
     raise NotImplementedError("lietorch_backends.projector (ToVec/FromVec) is outside the DEVO hot path "
                               "(SURVEY.md §2.1 row 3): never reached from devo.py / enet.py / train.py")
+
+
+# The compiled binding (devo_amd._C.lietorch_backends: the same 19 functions taking torch::Tensor) replaces the ctypes forms above when present.
+from . import native as _native_binding
+_N = _native_binding()
+if _N is not None:
+    for _name in ("expm", "logm", "inv", "mul", "adj", "adjT", "act", "act4"):
+        globals()[_name] = getattr(_N.lietorch_backends, _name)
+        globals()[_name + "_backward"] = getattr(_N.lietorch_backends, _name + "_backward")
+    as_matrix, Jinv = _N.lietorch_backends.as_matrix, _N.lietorch_backends.Jinv

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd_q(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ dout, float* __restrict__ dx,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int dim, float eps,
-                                                         int relu) {
+                                                         int relu, float* __restrict__ partials) {
   extern __shared__ float lnb_part[];                      // [16 quarter waves][2 dim]
   const int l16 = threadIdx.x & 15, qw = threadIdx.x >> 4;
   float gm[NC][4], bt[NC][4], ag[NC][4], ab[NC][4];
@@ -512,8 +512,18 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd_q(const float* __restrict
     float t = 0.0f;
 #pragma unroll
     for (int w = 0; w < 16; w++) t += lnb_part[w * 2 * dim + c];
-    atomicAdd(c < dim ? dgamma + c : dbeta + (c - dim), t);
+    if (partials) partials[(size_t)blockIdx.x * 2 * dim + c] = t;      // deterministic form: k_layernorm_colsum adds the workgroups' rows in order
+    else atomicAdd(c < dim ? dgamma + c : dbeta + (c - dim), t);
   }
+}
+// dgamma | dbeta += the workgroups' partial column sums, in workgroup order (one thread per column: run-to-run identical bits)
+__global__ __launch_bounds__(256) void k_layernorm_colsum(const float* __restrict__ partials, int nwg, int dim, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * dim) return;
+  float t = 0.0f;
+  for (int w = 0; w < nwg; w++) t += partials[(size_t)w * 2 * dim + c];
+  float* d = c < dim ? dgamma + c : dbeta + (c - dim);
+  *d += t;
 }
 
 template <typename T>
@@ -798,14 +808,16 @@ int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const 
 }
 
 int devo_upd_layernorm_backward(const float* x, const float* add1, const float* add2, const float* gamma, const float* beta, const float* dout,
-                                float* dx, float* dgamma, float* dbeta, int64_t rows, int dim, float eps, int relu, devo_stream_t stream) {
+                                float* dx, float* dgamma, float* dbeta, int64_t rows, int dim, float eps, int relu, float* partials,
+                                devo_stream_t stream) {
   DEVO_REQUIRE(rows >= 0 && dim == 384, "devo_upd_layernorm_backward: rows of 384 values (the update operator's; got %d)", dim);
   if (rows == 0) return DEVO_OK;
   DEVO_REQUIRE(x && gamma && beta && dout && dx && dgamma && dbeta, "devo_upd_layernorm_backward: null tensor");
   DEVO_REQUIRE(upd_vec_ok(DEVO_F32, rows, dim, {x, add1, add2, gamma, beta, dout, dx}), "devo_upd_layernorm_backward: tensors must be 16-byte aligned");
   const unsigned nwg = (unsigned)std::min<int64_t>((rows + 15) / 16, 512);
   hipLaunchKernelGGL((k_layernorm_bwd_q<6>), dim3(nwg), dim3(256), (size_t)16 * 2 * dim * sizeof(float), (hipStream_t)stream, x, add1, add2, gamma, beta,
-                     dout, dx, dgamma, dbeta, rows, dim, eps, relu);
+                     dout, dx, dgamma, dbeta, rows, dim, eps, relu, partials);
+  if (partials) hipLaunchKernelGGL(k_layernorm_colsum, dim3((unsigned)((2 * dim + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)partials, (int)nwg, dim, dgamma, dbeta);
   return check_launch("devo_upd_layernorm_backward");
 }
 

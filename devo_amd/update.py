@@ -57,10 +57,18 @@ def _split_weight(w, transposed):
         L.check(L.lib().devo_upd_pack_weight_f16(L.ptr(w), s_n, s_k, N, K, L.ptr(img), L.stream()), "update.pack_weight_f16")
     else:
         Np = (N + 95) // 96 * 96                                        # (whole column blocks of 96: zero columns behind N)
-        img = torch.empty(Np * ((K + 31) // 32 * 32) + Np, dtype=torch.float32, device=w.device)
+        img = torch.empty(int(L.lib().devo_upd_split_weight_bytes(N, K)) // 4, dtype=torch.float32, device=w.device)
+        assert img.numel() == Np * ((K + 31) // 32 * 32) + Np
         L.check(L.lib().devo_upd_split_weight(L.ptr(w), s_n, s_k, N, K, L.ptr(img), L.stream()), "update.split_weight")
     _wsplit_cache[key] = (w, img)
     return img
+
+
+def invalidate_weight_images():
+    """Forget every cached weight image (split fp32 / packed fp16 operands, csrc/linear.hip).  The cache follows a weight's VERSION counter:
+    copy_, load_state_dict and optimiser steps are seen; an edit through `.data` (p.data.add_, EMA swaps, old-style optimisers) has its own
+    counter and is NOT — call this (or Update.invalidate_weights) after such an edit.  Update.train() / .eval() / load_state_dict call it."""
+    _wsplit_cache.clear()
 
 
 def _split_ok(x2, n_out, k_in):
@@ -107,7 +115,7 @@ def _linear_split(x2, w, b, transposed=False, relu=False, relu_from=None, residu
     return y
 
 
-_dw_ws = {}                 # device -> workspace of the weight-gradient kernel (grown on demand, reused: the stream serialises its users)
+_dw_ws = {}                 # (device, stream) -> workspace of the weight-gradient kernel (grown on demand, reused: ONE stream serialises its users)
 SPLIT_DW = __import__("os").environ.get("DEVO_UPD_SPLIT_DW", "1") != "0"        # 0: the library's products for dW / db
 
 
@@ -121,10 +129,11 @@ def _dw_split(g2, x2, with_bias):
     """(dW [No, Ni], db [No] or None) = (g2^T x2, column sums of g2): fp32 in and out, exact hi + lo splits on the fp16 matrix cores"""
     R, No, Ni = g2.shape[0], g2.shape[1], x2.shape[1]
     need = L.lib().devo_upd_dw_workspace_bytes(R, No, Ni)
-    ws = _dw_ws.get(g2.device)
+    wkey = (g2.device, L.stream().value)
+    ws = _dw_ws.get(wkey)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=g2.device)
-        _dw_ws[g2.device] = ws
+        _dw_ws[wkey] = ws
     dW = torch.empty(No, Ni, dtype=torch.float32, device=g2.device)
     db = torch.empty(No, dtype=torch.float32, device=g2.device) if with_bias else None
     L.check(L.lib().devo_upd_dw_split(L.ptr(g2), g2.stride(0), L.ptr(x2), x2.stride(0), R, No, Ni, L.ptr(ws), L.ptr(dW), Ni, L.ptr(db), L.stream()),
@@ -135,10 +144,11 @@ def _dw_split(g2, x2, with_bias):
 class _LinearFn(torch.autograd.Function):
     """y = act(x Wᵀ + b) [+ residual] over many rows (the Update operator sees one row per edge: 18 000 at BASELINE configuration 3), all
     three products of its training step on the fp16 matrix cores with exact hi + lo splits of every fp32 value (2^-22 relative per factor,
-    fp32 accumulation, power-of-two scales against fp16's range): y and dX = dY W through csrc/linear.hip (out % 96 == 0; 29.9 us against
-    the library's 63 us for 18 000 x 384 x 384), dW = dYᵀ X and db through csrc/linear_dw.hip (out and in % 128 == 0; 50 against 98 us).
-    Layers that do not fit (the corr MLP's 882 inputs on the dX / dW side, the 2-wide heads) use the library: for dW as a batched product
-    over 16 row chunks + a sum (74 us where the direct product runs on a handful of tiles, 148 us; tools/ubench_dw_gemm.py)."""
+    fp32 accumulation, power-of-two scales against fp16's range): y and dX = dY W through csrc/linear.hip (any widths >= 96 outputs / 32
+    inputs, _split_ok; 29.9 us against the library's 63 us for 18 000 x 384 x 384), dW = dYᵀ X and db through csrc/linear_dw.hip (any widths
+    >= 96, _dw_ok: the corr MLP's 882 inputs included; 50 against 98 us).  Layers below those widths (the 2-wide heads) use the library: for
+    dW as a batched product over 16 row chunks + a sum (74 us where the direct product runs on a handful of tiles, 148 us;
+    tools/ubench_dw_gemm.py)."""
     CHUNKS = 16
 
     @staticmethod
@@ -296,8 +306,11 @@ class _LayerNormFn(torch.autograd.Function):
         g2 = g.reshape(x2.shape).to(torch.float32).contiguous()
         dx = torch.empty_like(x2)
         dwb = torch.zeros(2, x2.shape[1], dtype=torch.float32, device=x2.device)
+        # torch.use_deterministic_algorithms(True): the workgroups' column sums through a scratch and a second kernel, in a fixed order
+        # (bit-reproducible gamma / beta gradients, like ATen's two-stage reduction); else float atomics (one launch less)
+        part = torch.empty(512 * 2 * x2.shape[1], dtype=torch.float32, device=x2.device) if torch.are_deterministic_algorithms_enabled() else None
         L.check(L.lib().devo_upd_layernorm_backward(L.ptr(x2), L.ptr(a2), L.ptr(b2), L.ptr(weight), L.ptr(bias), L.ptr(g2), L.ptr(dx), L.ptr(dwb[0]),
-                                                    L.ptr(dwb[1]), x2.shape[0], x2.shape[1], ctx.eps, int(ctx.relu), L.stream()),
+                                                    L.ptr(dwb[1]), x2.shape[0], x2.shape[1], ctx.eps, int(ctx.relu), L.ptr(part), L.stream()),
                 "update.layernorm_backward")
         dxv = dx.view(ctx.shape)
         return (dxv if ctx.needs_input_grad[0] else None, dxv if a2 is not None and ctx.needs_input_grad[1] else None,
@@ -589,8 +602,25 @@ class Update(nn.Module):
         return self._graph
 
     def invalidate(self):
-        """Drop the cached graph tables (e.g. after editing ii / jj / kk through a raw pointer)."""
+        """Drop the cached graph tables (e.g. after editing ii / jj / kk through a raw pointer) and the cached weight images."""
         self._graph_key, self._graph, self._graph_refs = None, None, None
+        self.invalidate_weights()
+
+    def invalidate_weights(self):
+        """Forget the cached operand images of this operator's weights (split / packed / concatenated).  They follow the parameters'
+        version counters (copy_, load_state_dict, optimiser steps); an edit through `.data` is invisible to those — call this after one."""
+        if getattr(self, "_wcat", None) is not None:
+            self._wcat.clear()
+        invalidate_weight_images()
+
+    def train(self, mode=True):
+        self.invalidate_weights()                                            # (mode switches are where checkpoints / EMA weights get swapped in)
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_weights()
+        return out
 
     # The f and g layers of a SoftAgg share their input: ONE GEMM on concatenated weights (cached, rebuilt when a parameter
     # changes).

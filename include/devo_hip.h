@@ -348,10 +348,13 @@ int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const 
 /* The adjoint of devo_upd_layernorm without the hy / gate terms (training; the reference differentiates nn.LayerNorm through
  * torch.autograd, enet.py:44,52-56,62): fp32, dim == 384.  y = LN(x + add1 + add2) [ReLU'd], dout = dL/dy  ->  dx (the gradient of x and of
  * either addend) and dgamma += sum_rows dout xhat, dbeta += sum_rows dout (ADDED into buffers the caller has zeroed or is accumulating
- * in).  Mean and variance are recomputed from the inputs: the forward saves nothing but its inputs. */
+ * in).  Mean and variance are recomputed from the inputs: the forward saves nothing but its inputs.
+ * partials: NULL — the workgroups add their column sums with float atomics (order, hence the last bits, varies from run to run); or f32
+ * [512 * 2 * dim] of scratch — they store them and a second small kernel adds them in workgroup order: bit-reproducible (what
+ * torch.use_deterministic_algorithms(True) selects in devo_amd.update). */
 int devo_upd_layernorm_backward(const float* x, const float* add1, const float* add2, const float* gamma, const float* beta,
                                 const float* dout, float* dx, float* dgamma, float* dbeta, int64_t rows, int dim, float eps, int relu,
-                                devo_stream_t stream);
+                                float* partials, devo_stream_t stream);
 
 /* out[e] = idx[e] >= 0 ? src[idx[e]] : 0   — `mask * net[:, ix]` of enet.py:87-91 (idx from devo_ba_neighbors). */
 int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64_t E, int dim, int dtype,
@@ -399,7 +402,8 @@ int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void*
  * on column blocks of 96 and K steps of 32, the weight image carries zeros behind N and K.
  *   devo_upd_split_weight: the weight, element (n, k) at W[n * s_n + k * s_k] (s_n = K, s_k = 1: a Linear's [N, K] weight for the forward;
  *     s_n = 1, s_k = N_in: the same storage read as its transpose for dX = dY W), -> wsplit (devo_upd_split_weight_bytes(N, K) =
- *     N ceil32(K) 4 + N 4 bytes — the operand image, then the inverse column scales —, 16-byte aligned): once per version of the weight.
+ *     ceil96(N) ceil32(K) 4 + ceil96(N) 4 bytes — the operand image over whole column blocks of 96, then the inverse column scales —,
+ *     16-byte aligned; ALLOCATE WITH THE QUERY, the call takes no size): once per version of the weight.
  *   devo_upd_linear_split: x fp32, rows ldx >= K elements apart (any alignment of 4 bytes); y fp32, rows ldy >= N apart (16-byte pieces when
  *     ldy is a multiple of 4 and y / residual are 16-byte aligned, single values otherwise); bias fp32 [N] or NULL; residual NULL or fp32 with y's row pitch, added after the activation (it may be y itself:
  *     x.add_(linear(t)) in one launch); columns >= relu_from get max(., 0) (0: all of them, >= N: none — a gate | res pair of a

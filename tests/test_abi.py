@@ -85,3 +85,45 @@ def test_dropin_install(libpath):
     finally:
         for m in ("cuda_corr", "cuda_ba", "lietorch_backends"):
             sys.modules.pop(m, None)
+
+
+def test_compiled_binding_has_the_reference_interfaces(libpath):
+    """devo_amd._C (csrc/bind.cpp): three pybind11 sub-modules with the reference's function names (correlation.cpp:58-62, ba.cpp:153-155,
+    lietorch.cpp:287-314) taking torch.Tensor, registered under torch.ops.devo_hip as well; backends.install() hands out these modules;
+    CPU tensors raise (no fallback); the ctypes modules stay importable as the no-compile form (DEVO_BINDING=ctypes)."""
+    import inspect
+    import sys
+    from devo_amd import build, _lib
+    build.build_binding(verbose=False)
+    import devo_amd.backends as b
+    b._native = False
+    N = b.native()
+    assert N is not None and N.abi_version() == _lib.ABI_VERSION
+    for name in ("forward", "backward", "patchify_forward", "patchify_backward"):
+        assert callable(getattr(N.cuda_corr, name))
+    for name in ("forward", "neighbors", "reproject"):
+        assert callable(getattr(N.cuda_ba, name))
+    for name in ("expm", "logm", "inv", "mul", "adj", "adjT", "act", "act4"):
+        assert callable(getattr(N.lietorch_backends, name)) and callable(getattr(N.lietorch_backends, name + "_backward"))
+    for name in ("as_matrix", "projector", "Jinv"):
+        assert callable(getattr(N.lietorch_backends, name))
+    # the reference's positional signatures (pybind11 docstrings carry them)
+    assert N.cuda_corr.forward.__doc__.count("torch.Tensor") == 6 and "arg5" in N.cuda_corr.forward.__doc__ and "arg6" not in N.cuda_corr.forward.__doc__
+    assert "iterations" in N.cuda_ba.forward.__doc__ and N.lietorch_backends.inv.__doc__.startswith("inv(arg0") and "arg1: torch.Tensor" in N.lietorch_backends.inv.__doc__
+    for op in ("corr_forward", "corr_backward", "patchify_forward", "patchify_backward", "ba_forward", "ba_neighbors", "ba_reproject", "se3_exp", "se3_inv", "se3_mul",
+               "se3_act4", "se3_adjT"):
+        assert hasattr(torch.ops.devo_hip, op), op
+    mods = b.install()
+    try:
+        import cuda_corr, cuda_ba, lietorch_backends  # noqa: F401
+        assert mods[0] is N.cuda_corr and sys.modules["cuda_ba"] is N.cuda_ba and sys.modules["lietorch_backends"] is N.lietorch_backends
+        x = torch.zeros(4, 7)
+        x[:, 6] = 1
+        for call in (lambda: lietorch_backends.inv(3, x), lambda: cuda_ba.neighbors(torch.zeros(4, dtype=torch.long), torch.zeros(4, dtype=torch.long)),
+                     lambda: cuda_corr.patchify_forward(torch.zeros(1, 4, 8, 8), torch.zeros(1, 2, 2), 1), lambda: torch.ops.devo_hip.se3_inv(3, x),
+                     lambda: lietorch_backends.inv(1, x)):
+            with pytest.raises(RuntimeError):
+                call()
+    finally:
+        for m in ("cuda_corr", "cuda_ba", "lietorch_backends"):
+            sys.modules.pop(m, None)

@@ -105,8 +105,8 @@ def test_nchw_pyramid_goes_through_a_cached_blocked_copy(dtype):
     ref = lambda: cuda_corr.forward_pyramid(g, [altcorr.channel_blocked(p_.clone(), 8) for p_ in pyr], d(coords), d(ii), d(jj), R, (1, 2))
     a = call()
     assert torch.equal(a, ref())
-    n_cached = len(cuda_corr._blocked_cache)
-    assert n_cached >= 2 and torch.equal(call(), a) and len(cuda_corr._blocked_cache) == n_cached      # cache hit: no new copy
+    n_cached = cuda_corr.cached_levels()
+    assert n_cached >= 2 and torch.equal(call(), a) and cuda_corr.cached_levels() == n_cached      # cache hit: no new copy
     ring[:, 1] = ring[:, 1] * -0.5                                     # the per-frame in-place update of the ring (version bump)
     b = call()
     assert not torch.equal(a, b) and torch.equal(b, ref())

@@ -448,3 +448,53 @@ def test_fp16_linear_kernel_matches_the_fp32_product_of_the_same_values(rows, n_
     assert UA._f16_ok(xs, n_out, k_in)
     r4 = torch.nn.functional.linear(xs.float(), w.float(), b.float())
     assert (UA._linear_f16(xs, w, b).float() - r4).abs().max().item() <= 2e-3 * r4.abs().max().item() + 1e-3
+
+
+def test_layernorm_parameter_gradients_are_reproducible_in_deterministic_mode():
+    """torch.use_deterministic_algorithms(True): gamma / beta gradients of the HIP LayerNorm come from a fixed-order two-stage reduction
+    (devo_upd_layernorm_backward with its scratch) — bit-identical from run to run, and equal to the atomic form within rounding."""
+    from devo_amd import update as UA
+    torch.manual_seed(3)
+    mod = UA.LayerNorm(384, eps=1e-3).to(DEV)
+    x = torch.randn(1, 18000, 384, device=DEV) * 3
+    g = torch.randn(1, 18000, 384, device=DEV)
+
+    def grads():
+        mod.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        UA._ln_train(UA._PlainLN(mod), xi, None, None, relu=True).backward(g)
+        return mod.weight.grad.clone(), mod.bias.grad.clone()
+    atomic = grads()
+    was = torch.are_deterministic_algorithms_enabled()
+    try:
+        torch.use_deterministic_algorithms(True)
+        runs = [grads() for _ in range(4)]
+    finally:
+        torch.use_deterministic_algorithms(was)
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1])
+    for a, b in zip(atomic, runs[0]):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
+def test_weight_images_follow_versions_and_invalidate_weights_covers_data_edits():
+    """The Linear layers' operand images (csrc/linear.hip) are cached per VERSION of the weight: copy_ is seen, an edit through `.data` is
+    not — Update.invalidate_weights() (also called by train() / eval() / load_state_dict) makes it seen."""
+    from devo_amd import update as UA
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(384, 384).to(DEV)
+    x = torch.randn(4096, 384, device=DEV)
+    y0 = UA._linear_split(x, lin.weight, lin.bias)
+    with torch.no_grad():
+        lin.weight.copy_(lin.weight * 2.0)                            # version bump: seen
+    y1 = UA._linear_split(x, lin.weight, lin.bias)
+    assert (y1 - lin.bias - 2.0 * (y0 - lin.bias)).abs().max().item() < 1e-3
+    lin.weight.data.mul_(0.5)                                         # .data edit: its own version counter
+    y_stale = UA._linear_split(x, lin.weight, lin.bias)
+    assert torch.equal(y_stale, y1)                                   # (the documented blind spot)
+    UA.invalidate_weight_images()
+    y2 = UA._linear_split(x, lin.weight, lin.bias)
+    assert (y2 - y0).abs().max().item() < 1e-3
+    upd = UA.Update(3).to(DEV)
+    upd.eval()                                                        # train(False) clears the caches
+    assert len(UA._wsplit_cache) == 0

@@ -13,7 +13,8 @@
 #include <torch/extension.h>
 #include <ATen/hip/HIPContext.h>
 #include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <cstdlib>
 #include <list>
 #include <mutex>
@@ -27,7 +28,8 @@ namespace {
 using at::Tensor;
 typedef std::vector<Tensor> TensorList;
 
-void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+// (ROCm builds of torch call their devices "cuda": the masquerading accessor is c10::hip::getCurrentHIPStream for that device type)
+void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 void check(int rc, const char* what) {
   TORCH_CHECK(rc == DEVO_OK, what, " failed (code ", rc, "): ", devo_last_error());
@@ -176,7 +178,7 @@ void corr_forward_into(Tensor& out, const Tensor& fmap1_, const Tensor& fmap2, c
                        int64_t estride, int64_t lstride, int64_t offset, const Tensor& order_, double coord_div) {
   require_gpu(fmap1_, fmap2, coords_, ii_, jj_);
   corr_prep(fmap1_, fmap2, coords_, true);
-  c10::hip::HIPGuard guard(fmap1_.device());
+  c10::DeviceGuard guard(fmap1_.device());
   const Tensor fmap1 = fmap1_.contiguous(), coords = f32c(coords_), ii = idx(ii_), jj = idx(jj_);
   const int64_t B = coords.size(0), E = coords.size(1), P = coords.size(3), Np = fmap1.size(1), C = fmap1.size(2);
   const Tensor f1t = patch_operand(fmap1);
@@ -209,7 +211,7 @@ TensorList corr_backward(Tensor fmap1_, Tensor fmap2_, Tensor coords_, Tensor ii
     TensorList g = corr_backward(fmap1_.to(at::kFloat), fmap2_.to(at::kFloat), coords_, ii_, jj_, grad_.to(at::kFloat), radius);
     return {g[0].to(dt), g[1].to(dt)};
   }
-  c10::hip::HIPGuard guard(fmap1_.device());
+  c10::DeviceGuard guard(fmap1_.device());
   const Tensor fmap1 = fmap1_.contiguous(), coords = f32c(coords_), ii = idx(ii_), jj = idx(jj_), grad = f32c(grad_);
   Tensor fmap2 = fmap2_;
   const int64_t B = coords.size(0), E = coords.size(1), P = coords.size(3), Np = fmap1.size(1), C = fmap1.size(2);
@@ -257,7 +259,7 @@ std::string corr_last_backward_path() {
 TensorList patchify_forward(Tensor net, Tensor coords_, int64_t radius) {                  // correlation.cpp:61
   require_gpu(net, coords_);
   TORCH_CHECK(net.dim() == 4 && coords_.dim() == 3, "cuda_corr.patchify_forward: expected net [B,C,H,W], coords [B,M,2]");
-  c10::hip::HIPGuard guard(net.device());
+  c10::DeviceGuard guard(net.device());
   const Tensor coords = f32c(coords_);
   const int64_t B = coords.size(0), M = coords.size(1), C = net.size(1), H = net.size(2), W = net.size(3), D = 2 * radius + 2;
   Tensor out = at::empty({B, M, C, D, D}, net.options());
@@ -271,7 +273,7 @@ TensorList patchify_backward(Tensor net, Tensor coords_, Tensor gradient_, int64
   require_gpu(net, coords_, gradient_);
   if (net.scalar_type() == at::kHalf)                     // scattered in fp32 (hardware float atomics), cast back like the forward's dtype
     return {patchify_backward(net.to(at::kFloat), coords_, gradient_.to(at::kFloat), radius)[0].to(at::kHalf)};
-  c10::hip::HIPGuard guard(net.device());
+  c10::DeviceGuard guard(net.device());
   const Tensor coords = f32c(coords_), gradient = gradient_.to(net.scalar_type()).contiguous();
   const int64_t B = coords.size(0), M = coords.size(1), C = net.size(1), H = net.size(2), W = net.size(3);
   // the gradient in net's own layout when that is a dense permutation (channels-last from the encoders' convolutions), contiguous otherwise
@@ -309,7 +311,7 @@ TensorList ba_forward(Tensor poses, Tensor patches, Tensor intrinsics_, Tensor t
   require_gpu(poses, patches, intrinsics_, target_, weight_, lmbda_, ii_, jj_, kk_);
   TORCH_CHECK(poses.scalar_type() == at::kFloat && poses.is_contiguous(), "cuda_ba.forward: poses must be a contiguous float32 tensor (it is updated in place)");
   TORCH_CHECK(patches.scalar_type() == at::kFloat && patches.is_contiguous(), "cuda_ba.forward: patches must be a contiguous float32 tensor (it is updated in place)");
-  c10::hip::HIPGuard guard(poses.device());
+  c10::DeviceGuard guard(poses.device());
   const int64_t P = patches.size(-1), Nbuf = poses.numel() / 7, Np = patches.numel() / (3 * P * P);
   const Tensor ii = idx(ii_), jj = idx(jj_), kk = idx(kk_);
   const int64_t E = ii.numel();
@@ -326,7 +328,7 @@ TensorList ba_forward(Tensor poses, Tensor patches, Tensor intrinsics_, Tensor t
 
 TensorList ba_neighbors(Tensor ii_, Tensor jj_) {                       // ba.cpp:154 -> [ix, jx] (int64, on the GPU); no device<->host round trip
   require_gpu(ii_, jj_);
-  c10::hip::HIPGuard guard(ii_.device());
+  c10::DeviceGuard guard(ii_.device());
   const Tensor ii = idx(ii_), jj = idx(jj_);
   const int64_t E = ii.numel();
   Tensor ix = at::empty({E}, ii.options()), jx = at::empty({E}, ii.options());
@@ -338,7 +340,7 @@ TensorList ba_neighbors(Tensor ii_, Tensor jj_) {                       // ba.cp
 
 Tensor ba_reproject(Tensor poses_, Tensor patches_, Tensor intrinsics_, Tensor ii_, Tensor jj_, Tensor kk_) {      // ba.cpp:155 -> coords [1, E, 2, P, P]
   require_gpu(poses_, patches_, intrinsics_, ii_, jj_, kk_);
-  c10::hip::HIPGuard guard(poses_.device());
+  c10::DeviceGuard guard(poses_.device());
   const int64_t P = patches_.size(-1);
   const Tensor ii = idx(ii_), jj = idx(jj_), kk = idx(kk_), poses = f32c(poses_), patches = f32c(patches_), intrinsics = f32c(intrinsics_);
   const int64_t E = ii.numel();
@@ -352,7 +354,7 @@ Tensor ba_reproject(Tensor poses_, Tensor patches_, Tensor intrinsics_, Tensor i
 // has the full argument list); layout "pp2": [1,E,P,P,2], "2pp": [1,E,2,P,P]
 Tensor ba_transform(Tensor poses_, Tensor patches_, Tensor intrinsics_, Tensor ii_, Tensor jj_, Tensor kk_, bool layout_2pp) {
   require_gpu(poses_, patches_, intrinsics_, ii_, jj_, kk_);
-  c10::hip::HIPGuard guard(poses_.device());
+  c10::DeviceGuard guard(poses_.device());
   const int64_t P = patches_.size(-1);
   const Tensor ii = idx(ii_), jj = idx(jj_), kk = idx(kk_), poses = f32c(poses_), patches = f32c(patches_), intrinsics = f32c(intrinsics_);
   const int64_t E = ii.numel();
@@ -383,7 +385,7 @@ typedef int (*binb_fn)(const void*, const void*, const void*, void*, void*, int6
 template <un_fn F, int OUT>
 Tensor lie_unary(int64_t gid, Tensor X) {
   lie_chk(gid, X);
-  c10::hip::HIPGuard guard(X.device());
+  c10::DeviceGuard guard(X.device());
   Tensor out = at::empty({X.size(0), OUT}, X.options());
   check(F(X.data_ptr(), out.data_ptr(), X.size(0), dtype_code(X), stream_of(X)), "lietorch_backends");
   return out;
@@ -391,7 +393,7 @@ Tensor lie_unary(int64_t gid, Tensor X) {
 template <unb_fn F, int OUT>
 TensorList lie_unary_bwd(int64_t gid, Tensor grad, Tensor X) {
   lie_chk(gid, grad, X);
-  c10::hip::HIPGuard guard(X.device());
+  c10::DeviceGuard guard(X.device());
   Tensor out = at::empty({X.size(0), OUT}, X.options());
   check(F(grad.data_ptr(), X.data_ptr(), out.data_ptr(), X.size(0), dtype_code(X), stream_of(X)), "lietorch_backends");
   return {out};
@@ -399,7 +401,7 @@ TensorList lie_unary_bwd(int64_t gid, Tensor grad, Tensor X) {
 template <bin_fn F, int OUT>
 Tensor lie_binary(int64_t gid, Tensor X, Tensor y) {
   lie_chk(gid, X, y);
-  c10::hip::HIPGuard guard(X.device());
+  c10::DeviceGuard guard(X.device());
   Tensor out = at::empty({X.size(0), OUT}, X.options());
   check(F(X.data_ptr(), y.data_ptr(), out.data_ptr(), X.size(0), dtype_code(X), stream_of(X)), "lietorch_backends");
   return out;
@@ -407,14 +409,14 @@ Tensor lie_binary(int64_t gid, Tensor X, Tensor y) {
 template <binb_fn F, int DY>
 TensorList lie_binary_bwd(int64_t gid, Tensor grad, Tensor X, Tensor y) {
   lie_chk(gid, grad, X, y);
-  c10::hip::HIPGuard guard(X.device());
+  c10::DeviceGuard guard(X.device());
   Tensor dX = at::empty({X.size(0), 7}, X.options()), dy = at::empty({X.size(0), DY}, X.options());
   check(F(grad.data_ptr(), X.data_ptr(), y.data_ptr(), dX.data_ptr(), dy.data_ptr(), X.size(0), dtype_code(X), stream_of(X)), "lietorch_backends");
   return {dX, dy};
 }
 Tensor lie_as_matrix(int64_t gid, Tensor X) {
   lie_chk(gid, X);
-  c10::hip::HIPGuard guard(X.device());
+  c10::DeviceGuard guard(X.device());
   Tensor out = at::empty({X.size(0), 4, 4}, X.options());
   check(devo_se3_as_matrix(X.data_ptr(), out.data_ptr(), X.size(0), dtype_code(X), stream_of(X)), "devo_se3_as_matrix");
   return out;
@@ -427,13 +429,13 @@ Tensor lie_projector(int64_t, Tensor) {
 // extras for devo_amd.backends.cuda_corr (one cache for both bindings)
 std::tuple<Tensor, c10::optional<Tensor>, int64_t> corr_fast_layout(Tensor fmap2, int64_t n_edges, bool allow_split) {
   require_gpu(fmap2);
-  c10::hip::HIPGuard guard(fmap2.device());
+  c10::DeviceGuard guard(fmap2.device());
   const Level l = fast_level(fmap2, n_edges, allow_split);
   return {l.data, l.exps.defined() ? c10::optional<Tensor>(l.exps) : c10::nullopt, (int64_t)l.cblock};
 }
 c10::optional<Tensor> corr_patch_operand(Tensor fmap1) {
   require_gpu(fmap1);
-  c10::hip::HIPGuard guard(fmap1.device());
+  c10::DeviceGuard guard(fmap1.device());
   const Tensor t = patch_operand(fmap1.contiguous());
   return t.defined() ? c10::optional<Tensor>(t) : c10::nullopt;
 }

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * DEVO_MFMA_EPW) __attribute__((amdgpu_waves_per
   int slot;
   if (EPW == 1) slot = corr_plan_slot(order, BE, wgid, nwg);
   else { const int per = (nwg + 7) >> 3; slot = (((wgid & 7) * per + (wgid >> 3)) * EPW) + wv; if ((wgid >> 3) >= per) slot = BE; }
-  if (heavy_only) {                           // the region-shared kernel (corr_region.h) takes every other slot of the plan
+  if (heavy_only) {                           // only the plan's HEAVY class (slots 0 .. order[BE] - 1)
     slot = (int)blockIdx.x * EPW + wv;
     if (slot >= (order ? min(max(order[BE], 0), BE) : 0)) return;
   }

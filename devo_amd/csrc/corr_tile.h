@@ -60,15 +60,14 @@ inline long long corr_grp_nbins(long long B, int n2, int H2, int W2, int l1) {
 
 // Plan bin of an edge from its 9 window origins: -1 = HEAVY (the union box does not fit the tile), else
 // (batch, target frame, 16-row band of the patch centre, column bin of the patch centre) — consecutive edges of the sorted
-// plan land next to each other in the image, which is what the region-shared lookup kernel (corr_region.h) groups on.
+// plan land next to each other in the image.
 // x[p], y[p]: integer pixel of patch pixel p at the plan's level.  `geom` = corr_plan_pack(): bands | column bins << 8 |
 // column-bin width << 16.
 //
-// Pyramid mode (l1 >= 2: the lookup has a second level at 1 / l1 of the plan level's resolution, W2 = the plan level's width): the
-// classes are those of the region-shared lookup kernel (corr_region.h) —
+// Group mode (l1 >= 2: the lookup has a second level at 1 / l1 of the plan level's resolution, W2 = the plan level's width): the GROUP
+// PLAN above —
 //   DEAD  (returns dead_bin, the bin behind all others): the union box lies outside the frame at BOTH levels: all outputs are 0;
-//   HEAVY (-1): more than `heavy_cells` box positions at a level where the box touches the frame (the region kernel keeps
-//         heavy_cells / 16 accumulator tiles per edge and level): these go to the per-edge kernel.
+//   HEAVY (-1): more than `heavy_cells` level-0 box positions, or a level-1 box that leaves its group's region.
 __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float centre_x, float centre_y, int b, int frame, int n2,
                                              int H2, int geom, int D, int ng, int W2 = 0, int l1 = 0, int heavy_cells = 0,
                                              int dead_bin = -1) {
@@ -116,8 +115,7 @@ __device__ __forceinline__ int corr_plan_bin(const int* x, const int* y, float c
   return (b * n2 + f) * (nbb * nbx * CORR_PLAN_BB * bx) + in_frame;
 }
 
-// Region-shared lookup kernel (corr_region.h): accumulator tiles (16 box positions each) an edge may have per level; the pyramid
-// plan's HEAVY class is exactly "more cells than these tiles hold".
+// Group plans: tiles (16 box positions each) a level-0 box may have before the edge counts as HEAVY
 __host__ __device__ constexpr int corr_region_tmax(int radius) { return radius <= 3 ? 8 : 16; }
 struct CorrPlanMode { int W2, l1, heavy_cells, dead_bin; };     // l1 < 2: single-level plan (legacy classes)
 

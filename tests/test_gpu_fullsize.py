@@ -26,7 +26,7 @@ def _inputs(workload, seed=4321):
     return cfg, d, cpu, coords
 
 
-@pytest.mark.parametrize("workload,sample", [("cfg1", 96), ("cfg2", 96), ("stress", 24)])
+@pytest.mark.parametrize("workload,sample", [("cfg1", 96), ("cfg2", 256), ("stress", 256)])
 def test_lookup_at_full_size(workload, sample):
     from devo_amd.backends import cuda_corr
     cfg, d, cpu, coords = _inputs(workload)
@@ -39,7 +39,27 @@ def test_lookup_at_full_size(workload, sample):
     assert out.shape == (1, E, 2 * per) and bool(torch.isfinite(out).all())
 
     # (1) the oracle on a random sample of edges (devo/altcorr/correlation_kernel.cu:19-86 restated)
-    sel = torch.randperm(E, generator=torch.Generator().manual_seed(1))[:sample]
+    # stratified over the lookup's edge classes: the plan's HEAVY slots (boxes beyond the result area: window-by-window tiles), BORDER edges
+    # (a window of the patch leaves the frame at either level, or the patch lies outside altogether) and the rest, a quarter / a quarter / half
+    cc = coords.cpu()[0]                                                   # [E, 2, 3, 3]
+    nh = int(plan[E])
+    gsel = torch.Generator().manual_seed(1)
+    heavy = plan[:nh].cpu().long()
+    xs, ys = cc[:, 0].reshape(E, 9), cc[:, 1].reshape(E, 9)
+    m = float(4 * (R + 2))                                                 # (a level-1 window reaches 4 (R + 1) level-0 pixels from its centre)
+    border = ((xs.min(1).values < m) | (ys.min(1).values < m) | (xs.max(1).values > cfg["W"] - m) | (ys.max(1).values > cfg["H"] - m))
+    is_heavy = torch.zeros(E, dtype=torch.bool)
+    is_heavy[heavy] = True
+    pick = lambda idx, k: idx[torch.randperm(idx.numel(), generator=gsel)[:k]]
+    parts = [pick(heavy, sample // 4), pick((border & ~is_heavy).nonzero().squeeze(1), sample // 4)]
+    rest = (~border & ~is_heavy).nonzero().squeeze(1)
+    parts.append(pick(rest, sample - sum(p_.numel() for p_ in parts)))
+    sel = torch.cat(parts)
+    if sel.numel() < sample:                                              # (a class smaller than its share: filled from all edges)
+        sel = torch.cat([sel, pick(torch.arange(E), sample - sel.numel())])
+    assert sel.numel() == sample
+    if workload != "cfg1":
+        assert parts[0].numel() > 0 and parts[1].numel() > 0              # both special classes are present in the sample
     c_cpu = coords.cpu()[:, sel]
     kk, jj = cpu["kk"][sel], cpu["jj"][sel]
     from devo_amd import synth

@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug (1-GPU boxes): all ranks of a --gpus N run use GPU 0 and gloo carries the collectives — exercises the N > 1 code "
                          "path; the numbers are not a scaling measurement")
+    ap.add_argument("--ddp-single", action="store_true",
+                    help="debug (1-GPU boxes): a --gpus 1 run creates the RCCL process group and wraps the net in DistributedDataParallel anyway — the "
+                         "N > 1 code path of --mode train (communicator, bucket hooks, all-reduce over one rank) on the real backend")
     ap.add_argument("--no-f16", action="store_true", help="skip the secondary fp16-storage measurement (field \"f16\")")
     ap.add_argument("--no-train-probe", action="store_true",
                     help="multi-GPU update-op runs also time a few data-parallel training steps (field \"train_dp\": the RCCL gradient "
@@ -119,7 +122,7 @@ def build_inputs(cfg, seed, device, dtype, layout):
     return d, cpu
 
 
-PROBE_TIMEOUT_S = float(os.environ.get("DEVO_BENCH_PROBE_TIMEOUT", "60"))   # multi-GPU default runs: the data-parallel training probe may take this long at most
+PROBE_TIMEOUT_S = float(os.environ.get("DEVO_BENCH_PROBE_TIMEOUT", "90"))   # multi-GPU default runs: the data-parallel training probe may take this long at most
 
 
 def alg_bytes(cfg, E, esize):
@@ -159,7 +162,7 @@ def rank_main(argv):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     from devo_amd import distributed as D
-    D.init_from_env("gloo" if args.share_gpu else "nccl", device)
+    D.init_from_env("gloo" if args.share_gpu else "nccl", device, force=args.ddp_single)
     assert D.world() == world
     if args.mode == "train":
         out = train_mode(args, device, rank, world)
@@ -183,7 +186,8 @@ def train_mode(args, device, rank, world, steps=None, warmup=None, iters=None, p
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     iters = args.train_iters if iters is None else iters
-    net, model, opt = T.build_trainer(device, world)
+    ddp = world > 1 or getattr(args, "ddp_single", False)
+    net, model, opt = T.build_trainer(device, world, ddp=ddp)
     batch = T.make_batch("cfg2_m80", 1234 + rank, device)
     for _ in range(max(warmup, 1)):
         T.train_step(model, opt, batch, iters=iters)
@@ -221,7 +225,7 @@ def train_mode(args, device, rank, world, steps=None, warmup=None, iters=None, p
     nparam = net.num_parameters()
     res = {"ms_per_step": round(1e3 * elapsed / steps, 3), "sequences_per_s": round(world * steps / elapsed, 4),
            "update_iterations_per_step": iters, "steps": steps, "loss": float(loss),
-           "grad_bucket_bytes": 4 * nparam, "parameters": nparam, "collective": (("DDP all-reduce (gloo: --share-gpu debug run)" if getattr(args, "share_gpu", False) else "DDP all-reduce (RCCL)") if world > 1 else None)}
+           "grad_bucket_bytes": 4 * nparam, "parameters": nparam, "collective": (("DDP all-reduce (gloo: --share-gpu debug run)" if getattr(args, "share_gpu", False) else "DDP all-reduce (RCCL)") if ddp else None)}
     if probe:
         return res
     return {"metric": "training sequences/sec (update + BA path, batch = 1 sequence per GPU)", "value": res["sequences_per_s"], "unit": "seq/s",

@@ -4,6 +4,24 @@ import torch
 from .backends import cuda_corr
 
 
+DROPOUT_SIGMAS = 6.0         # capacity of an edge subset: its expected size + this many standard deviations of the binomial count
+
+
+def _edge_subset(n_edges, dropout, device):
+    """correlation.py:20-25 draws `torch.rand(len(ii)) < dropout` and indexes with the boolean mask — a host synchronisation for the subset's
+    size, twice per update iteration of a training step.  Here the SAME Bernoulli draw is compacted into a list of FIXED capacity (expected
+    size + 6 sigma of the binomial count: 3 930 slots for 18 000 edges at 0.2, 9 % more than the 3 600 expected) without leaving the device:
+    a stable sort of the mask puts the kept edges first (in edge order), `valid` marks the slots that hold one; the others carry OTHER
+    (distinct, not drawn) edges with a zero gradient — spread over the frames like real ones, where copies of one edge would pile their
+    windows onto one tile of the backward's frame kernel.  (A draw beyond the capacity — probability ~1e-9 — would drop its last edges.)
+    Returns (keep [K] int64, valid [K] bool)."""
+    mask = torch.rand(n_edges, device=device) < dropout
+    cap = min(n_edges, int(n_edges * dropout + DROPOUT_SIGMAS * (n_edges * dropout * (1.0 - dropout)) ** 0.5) + 1)
+    order = torch.sort((~mask).to(torch.uint8), stable=True).indices[:cap]
+    valid = mask[order]
+    return order, valid
+
+
 class CorrLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fmap1, fmap2, coords, ii, jj, radius, dropout):
@@ -16,10 +34,10 @@ class CorrLayer(torch.autograd.Function):
     def backward(ctx, grad):
         fmap1, fmap2, coords, ii, jj = ctx.saved_tensors
         if ctx.dropout < 1:
-            # correlation.py:20-25: only a random subset of edges propagates gradient; the draw stays here.  ONE nonzero (= one host
-            # synchronisation for the subset's size) and four index_selects, where four boolean-mask indexings each run their own
-            keep = (torch.rand(len(ii), device=ii.device) < ctx.dropout).nonzero().squeeze(1)
-            coords, grad, ii, jj = coords.index_select(1, keep), grad.index_select(1, keep), ii.index_select(0, keep), jj.index_select(0, keep)
+            # correlation.py:20-25: only a random subset of edges propagates gradient; the draw stays here, its compaction on the device
+            keep, valid = _edge_subset(len(ii), ctx.dropout, ii.device)
+            coords, ii, jj = coords.index_select(1, keep), ii.index_select(0, keep), jj.index_select(0, keep)
+            grad = grad.index_select(1, keep) * valid.view(1, -1, *([1] * (grad.dim() - 2))).to(grad.dtype)
         d1, d2 = cuda_corr.backward(fmap1, fmap2, coords, ii, jj, grad, ctx.radius)
         return d1, d2, None, None, None, None, None
 
@@ -74,13 +92,14 @@ class CorrPyramidLayer(torch.autograd.Function):
         D = 2 * ctx.radius + 1
         g = grad.view(grad.shape[0], E, D, D, coords.shape[3], coords.shape[4], nl)
         d1, d2s = None, []
-        # every level's edge subset first: the host synchronisations for their sizes (nonzero) fall together, ahead of the kernels
-        keeps = [(torch.rand(len(ii), device=ii.device) < ctx.dropout).nonzero().squeeze(1) for _ in range(nl)] if ctx.dropout < 1 else None
+        # every level draws its own edge subset (the reference's two CorrLayer.backward calls do); compacted on the device: no host sync
+        keeps = [_edge_subset(len(ii), ctx.dropout, ii.device) for _ in range(nl)] if ctx.dropout < 1 else None
         for l in range(nl):
             c_l, g_l, i_l, j_l = coords / ctx.scales[l], g[..., l], ii, jj
             if keeps is not None:
-                k = keeps[l]
-                c_l, g_l, i_l, j_l = c_l.index_select(1, k), g_l.index_select(1, k), ii.index_select(0, k), jj.index_select(0, k)
+                k, valid = keeps[l]
+                c_l, i_l, j_l = c_l.index_select(1, k), ii.index_select(0, k), jj.index_select(0, k)
+                g_l = g_l.index_select(1, k) * valid.view(1, -1, 1, 1, 1, 1).to(g_l.dtype)
             a, b = cuda_corr.backward(fmap1, pyramid[l], c_l, i_l, j_l, g_l, ctx.radius)
             d1 = a if d1 is None else d1 + a
             d2s.append(b)

@@ -125,12 +125,12 @@ def make_batch(workload="cfg2_m80", seed=1234, device="cuda"):
                 ii=d(ii), jj=d(jj), kk=d(kk), H=H, W=W, R=R, n=n, M=M, E=int(ii.numel()))
 
 
-def build_trainer(device, world_size, lr=8e-5, seed=0):
-    """net (DDP-wrapped when world_size > 1, train.py:106-107), AdamW (train.py:109)."""
+def build_trainer(device, world_size, lr=8e-5, seed=0, ddp=None):
+    """net (DDP-wrapped when world_size > 1, train.py:106-107; ddp=True: also at world size 1, given a process group), AdamW (train.py:109)."""
     torch.manual_seed(seed)                                   # identical initial weights on every rank (train.py:41)
     net = TrainNet().to(device).train()
     model = net
-    if world_size > 1:
+    if world_size > 1 or ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
         dev = torch.device(device)
         model = DDP(net, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=False)

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(args, timeout):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("DEVO_BENCH_PROBE_TIMEOUT", "400")     # (two ranks on ONE GPU of a shared test box: the 90 s default is for a rank per GPU)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -103,3 +104,32 @@ def test_update_op_bench_under_the_drivers_launch_command():
     d = json.loads(lines[0])
     _keep("bench_torchrun_gpus2_share.json", lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_training_bench_through_rccl_under_the_drivers_launch_command():
+    """BASELINE configuration 4's code path on the real backend, as far as one GPU allows: the driver's launch command with one rank,
+    `--mode train --ddp-single` = init_process_group("nccl") + DistributedDataParallel + the gradient all-reduce over RCCL (one rank); the
+    line names the parallelism and the collective the way the N = 8 line will."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29543",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--mode", "train", "--ddp-single", "--steps", "2", "--warmup", "2", "--train-iters", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    _keep("bench_train_rccl_1rank.json", lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1" and d["scaling"] == "weak" and d["value"] > 0
+    assert d["train"]["collective"] == "DDP all-reduce (RCCL)" and d["train"]["grad_bucket_bytes"] == 13_588_244
+
+
+def test_multi_gpu_update_op_line_skips_the_single_gpu_probes():
+    """An N > 1 line must come out quickly on the driver's scaling run: no reference-API probe, no full-iteration probe, no CPU baseline
+    (rank 0 would hold the other ranks in the final barrier), the training probe bounded by DEVO_BENCH_PROBE_TIMEOUT (90 s by default)."""
+    import time
+    t0 = time.time()
+    d, _ = _run(["--gpus", "2", "--share-gpu", "--steps", "20", "--warmup", "5"], timeout=600)
+    assert "reference_api" not in d and "full_update_iteration" not in d and "cpu_baseline" not in d
+    assert "f16" in d and "train_dp" in d
+    assert time.time() - t0 < 300

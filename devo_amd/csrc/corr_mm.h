@@ -544,6 +544,16 @@ __global__ __launch_bounds__(64 * (NW > 1 ? NW : DEVO_MM_EPW)) __attribute__((am
   constexpr bool EXACT = RFIX == 3 && RMAX == 3;
   auto exact_count = [](int n, int hi) -> bool { return n == 0 || (n >= 4 && n <= hi); };
   constexpr int K0MAX = CAP / 16;                          // tiles of the largest box the result area holds (level index 1: up to 8)
+  if (ntot == 0) {
+    // no level's box touches its frame (the plan's DEAD class, 11 % of cfg2's edges): every output is 0 (correlation_kernel.cu:136) —
+    // no result area, no blend
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+#pragma unroll
+      for (int rd = 0; rd < NRND; rd++)
+#pragma unroll
+        for (int cx = 0; cx < DMM; cx++) held[l][rd][cx] = 0.0f;
+  } else
   if (EXACT && all_box && exact_count(g0.ntile, K0MAX) && (NL == 1 || exact_count(g1.ntile, 8))) {
     // Every wave-instruction of a load occupies the CU's texture addresser (16 quads, ~1.4 cycles each: a quad of four positions x 16 bytes
     // straddles a 128-byte line three times in eight) whether its lanes fetch or not — the addresser is ~97 % busy in this kernel

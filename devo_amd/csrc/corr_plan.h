@@ -51,11 +51,24 @@ __device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, in
   if (threadIdx.x < 2) s_base[threadIdx.x] = 0;
   __syncthreads();
   int below = 0;
-#pragma unroll
-  for (int i = 0; i < iters; i++) {
-    const int bin = bin_at(i);
+  // CACHE == 0 (edge lists beyond 32 K per thread-column: the stress configuration's 262 144 edges): the bins are read in batches of UB
+  // loads in flight per thread — one at a time, each of a thread's 256 reads waited for its round trip: 183 us for the two passes
+  constexpr int UB = 16;
+  auto count_one = [&](int bin) {
     below += (bin < b0) ? 1 : 0;
     if (bin >= b0 && bin < b1) atomicAdd(&s_cnt[bin - b0], 1);
+  };
+  if constexpr (CACHED) {
+#pragma unroll
+    for (int i = 0; i < iters; i++) count_one(bin_at(i));
+  } else {
+    for (int i0 = 0; i0 < iters; i0 += UB) {
+      int v[UB];
+#pragma unroll
+      for (int j = 0; j < UB; j++) v[j] = (i0 + j < iters) ? bin_at(i0 + j) : 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < UB; j++) count_one(v[j]);
+    }
   }
   below = wave_inclusive_sum(below);
   if (lane == 63 && below != 0) atomicAdd(&s_base[0], below);
@@ -76,10 +89,8 @@ __device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, in
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < iters; i++) {
+  auto place_one = [&](int i, int bin) {
     const int be = threadIdx.x + ORDER_THREADS * i;
-    const int bin = bin_at(i);
     if (g == 0) {                                           // (block-uniform) the heavy list, in front of bin 0
       const unsigned long long hv = __ballot(bin < 0);
       int hbase = 0;
@@ -88,6 +99,18 @@ __device__ __forceinline__ void corr_order_body(const int* __restrict__ bins, in
       if (bin < 0) order[hbase + __popcll(hv & ((1ull << lane) - 1ull))] = be;
     }
     if (bin >= b0 && bin < b1) order[atomicAdd(&s_cnt[bin - b0], 1)] = be;
+  };
+  if constexpr (CACHED) {
+#pragma unroll
+    for (int i = 0; i < iters; i++) place_one(i, bin_at(i));
+  } else {
+    for (int i0 = 0; i0 < iters; i0 += UB) {                // (iters is block-uniform: the ballots see whole waves; slots past BE carry 0x7fffffff)
+      int v[UB];
+#pragma unroll
+      for (int j = 0; j < UB; j++) v[j] = (i0 + j < iters) ? bin_at(i0 + j) : 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < UB; j++) if (i0 + j < iters) place_one(i0 + j, v[j]);
+    }
   }
   if (g == 0 && threadIdx.x == 0) order[BE] = s_base[0];   // b0 == 0: the edges below bin 0 are the heavy ones
 }

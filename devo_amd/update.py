@@ -98,6 +98,46 @@ def _linear_f16(x2, w, b, relu=False, relu_from=None, residual=None, out=None):
     return y
 
 
+MLP2_F16 = __import__("os").environ.get("DEVO_UPD_MLP2", "1") != "0"            # 0: Linear - ReLU - Linear chains as two launches
+
+
+def _mlp2_image(w):
+    """The B-operand image of csrc/mlp2.hip for a [384, K] fp16 weight, cached per version like _split_weight's images."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), "mlp2")
+    hit = _wsplit_cache.pop(key, None)
+    if hit is not None:
+        _wsplit_cache[key] = hit
+        return hit[1]
+    for k in [k for k in _wsplit_cache if k[0] == key[0] and k[4] == "mlp2"]:
+        del _wsplit_cache[k]
+    while len(_wsplit_cache) >= WSPLIT_CACHE_ENTRIES:
+        del _wsplit_cache[next(iter(_wsplit_cache))]
+    N, K = w.shape
+    img = torch.empty(int(L.lib().devo_upd_mlp2_weight_bytes(K)) // 2, dtype=torch.float16, device=w.device)
+    L.check(L.lib().devo_upd_mlp2_pack_weight(L.ptr(w), w.stride(0), w.stride(1), K, L.ptr(img), L.stream()), "update.mlp2_pack_weight")
+    _wsplit_cache[key] = (w, img)
+    return img
+
+
+def _mlp2_ok(x2, l1, l2):
+    return (MLP2_F16 and x2.is_cuda and x2.dtype == torch.float16 and l1.weight.dtype == torch.float16 and l2.weight.dtype == torch.float16
+            and l1.weight.shape[0] == 384 and tuple(l2.weight.shape) == (384, 384) and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) % 2 == 0
+            and x2.data_ptr() % 4 == 0 and x2.shape[1] == l1.weight.shape[1] and x2.shape[0] >= 1024
+            and ((x2.shape[0] - 1) * x2.stride(0) + x2.shape[1]) * 2 < (1 << 31))
+
+
+def _mlp2_f16(x2, l1, l2, residual=None, gather=None):
+    """l2(relu(l1(x2[gather]))) [+ residual] as one launch (csrc/mlp2.hip); gather i64 [rows] with negative entries = zero rows"""
+    rows = x2.shape[0] if gather is None else gather.numel()
+    y = torch.empty(rows, 384, dtype=torch.float16, device=x2.device)
+    if residual is not None and (residual.stride(0) != 384 or residual.stride(1) != 1 or residual.dtype != torch.float16 or residual.data_ptr() % 16):
+        raise RuntimeError("_mlp2_f16: the residual must be a contiguous fp16 [rows, 384] tensor")
+    L.check(L.lib().devo_upd_mlp2_f16(L.ptr(x2), x2.stride(0), x2.shape[0], L.ptr(gather), L.ptr(_mlp2_image(l1.weight.detach())), L.ptr(l1.bias),
+                                      l1.weight.shape[1], L.ptr(_mlp2_image(l2.weight.detach())), L.ptr(l2.bias), L.ptr(residual), L.ptr(y), 384, rows,
+                                      L.stream()), "update.mlp2_f16")
+    return y
+
+
 def _linear_split(x2, w, b, transposed=False, relu=False, relu_from=None, residual=None, out=None, gate=None):
     """x2 [rows, K] fp32 -> act(x2 @ w.T + b) [+ residual] (or x2 @ w: transposed) on the fp16 matrix cores, fp32 in and out
     (csrc/linear.hip).  relu_from: the ReLU from this output column on (a gate | res pair in one launch); residual / out: [rows, N]
@@ -685,14 +725,20 @@ class Update(nn.Module):
         ix, jx, Gkk, Gij = self._tables(ii, jj, kk)
 
         # corr MLP (enet.py:59-66) and net = norm(net + inp + corr)  (:82-83), the two adds fused into the LayerNorm
-        c = self._lin(c, self.corr[0].weight, self.corr[0].bias, relu=True)
-        c = self._lin(c, self.corr[2].weight, self.corr[2].bias)
+        if _mlp2_ok(c, self.corr[0], self.corr[2]):                   # Linear - ReLU - Linear: one launch, the intermediate stays in LDS
+            c = _mlp2_f16(c, self.corr[0], self.corr[2])
+        else:
+            c = self._lin(c, self.corr[0].weight, self.corr[0].bias, relu=True)
+            c = self._lin(c, self.corr[2].weight, self.corr[2].bias)
         c = _ln(c, self.corr[3], relu=True)
         c = self._lin(c, self.corr[5].weight, self.corr[5].bias)
         x = _ln(x, self.norm, add1=inp2, add2=c)
 
         # neighbour mixing along the patch trajectory (:86-91)
         for mlp, idx in ((self.c1, ix), (self.c2, jx)):
+            if _mlp2_ok(x, mlp[0], mlp[2]) and x.is_contiguous():
+                x = _mlp2_f16(x, mlp[0], mlp[2], residual=x, gather=idx)     # net + c(mask * net[:, idx]): gather, both layers and the sum in one launch
+                continue
             t = torch.empty_like(x)
             L.check(lib.devo_upd_masked_gather(L.ptr(x), L.ptr(idx), L.ptr(t), E, dim, code, L.stream()), "update.masked_gather")
             t = self._lin(t, mlp[0].weight, mlp[0].bias, relu=True)

@@ -409,6 +409,18 @@ int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void*
  *     x.add_(linear(t)) in one launch); columns >= relu_from get max(., 0) (0: all of them, >= N: none — a gate | res pair of a
  *     GatedResidual in one launch); gate NULL or fp32 with y's row pitch: the result is kept where gate > 0 and zeroed elsewhere, before
  *     the residual — dX = (dY W) masked by the ReLU output it passes back through (threshold_backward in the epilogue). */
+/* Linear - ReLU - Linear of the update operator as ONE launch, fp16 storage / fp32 accumulation (csrc/mlp2.hip; enet.py:46-50 c1 / c2,
+ * :59-61 the corr MLP's first two layers): y[r] = (residual[r] +) W2 relu(W1 x[src(r)] + b1) + b2 with both layers 384 wide, any K1 (W1 is
+ * [384, K1]); src(r) = r, or gather[r] (i64 [M]; negative = a zero row: `mask * net[:, ix]`).  The 384-wide intermediate stays in LDS, rounded
+ * to fp16 like the two-launch form's.  Weight images: devo_upd_mlp2_pack_weight (devo_upd_mlp2_weight_bytes(K) bytes, 16-byte aligned), once per
+ * version of a weight.  x: rows ldx elements apart (even), x_rows of them; y / residual: rows ldy apart (multiple of 8), 16-byte aligned; y must
+ * not alias x when gather is given. */
+size_t devo_upd_mlp2_weight_bytes(int K);
+int devo_upd_mlp2_pack_weight(const void* W /* f16, element (n, k) at W[n * s_n + k * s_k], n < 384 */, int64_t s_n, int64_t s_k, int K, void* wimage,
+                              devo_stream_t stream);
+int devo_upd_mlp2_f16(const void* x, int64_t ldx, int x_rows, const int64_t* gather, const void* w1image, const void* b1, int K1, const void* w2image,
+                      const void* b2, const void* residual, void* y, int64_t ldy, int M, devo_stream_t stream);
+
 size_t devo_upd_split_weight_bytes(int N, int K);
 int devo_upd_split_weight(const float* W, int64_t s_n, int64_t s_k, int N, int K, void* wsplit, devo_stream_t stream);
 int devo_upd_linear_split(const float* x, int64_t ldx, const void* wsplit, const float* bias, const float* residual, const float* gate, float* y,

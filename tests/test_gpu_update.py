@@ -498,3 +498,56 @@ def test_weight_images_follow_versions_and_invalidate_weights_covers_data_edits(
     upd = UA.Update(3).to(DEV)
     upd.eval()                                                        # train(False) clears the caches
     assert len(UA._wsplit_cache) == 0
+
+
+@pytest.mark.parametrize("K1,rows,gather,residual", [(384, 21600, False, False), (384, 18000, True, True), (882, 21600, False, False), (882, 4099, False, True),
+                                                      (384, 1031, True, False)])
+def test_fused_linear_relu_linear_matches_the_two_layer_composition(K1, rows, gather, residual):
+    """csrc/mlp2.hip (Linear - ReLU - Linear in one launch, the 384-wide intermediate in LDS; fp16 storage): against the fp64 composition
+    on the same fp16 operands with the intermediate rounded to fp16 (what two launches of the fp16 Linear kernel compute), every output
+    against the magnitude of ITS terms; gathered rows (negative index = zero row), the residual sum, row counts that are no multiple of
+    the 64-row tile, the corr MLP's 882 inputs (rows 4-byte aligned only, a masked last K step)."""
+    from devo_amd import update as UA
+    torch.manual_seed(K1 + rows)
+    l1, l2 = torch.nn.Linear(K1, 384).to(DEV).half(), torch.nn.Linear(384, 384).to(DEV).half()
+    src_rows = rows if not gather else rows + 37
+    x = (torch.randn(src_rows, K1, device=DEV) * 0.7).half()
+    idx = None
+    if gather:
+        idx = torch.randint(0, src_rows, (rows,), device=DEV)
+        idx[torch.rand(rows, device=DEV) < 0.1] = -1
+    res = (torch.randn(rows, 384, device=DEV)).half() if residual else None
+    assert UA._mlp2_ok(x, l1, l2)
+    got = UA._mlp2_f16(x, l1, l2, residual=res, gather=idx)
+    xs = x.double() if idx is None else torch.where((idx >= 0)[:, None], x.double()[idx.clamp(min=0)], torch.zeros(1, dtype=torch.float64, device=DEV))
+    h = torch.relu(xs @ l1.weight.double().t() + l1.bias.double()).half().double()
+    ref = h @ l2.weight.double().t() + l2.bias.double()
+    mag = h.abs() @ l2.weight.double().abs().t() + l2.bias.double().abs()
+    if res is not None:
+        ref, mag = ref + res.double(), mag + res.double().abs()
+    err = ((got.double() - ref).abs() / mag.clamp(min=1e-6)).max().item()
+    assert torch.isfinite(got).all() and err < 2e-3, err          # fp16 rounding of the result (2^-11) + of the intermediate's neighbours
+
+
+def test_update_fp16_operator_uses_the_fused_chains_and_keeps_its_golden():
+    """The fp16 inference operator with and without csrc/mlp2.hip (DEVO_UPD_MLP2): the same outputs within fp16 rounding."""
+    from devo_amd import update as UA
+    torch.manual_seed(5)
+    E, n, M = 21600, 15, 96
+    from devo_amd import synth
+    ii, jj, kk = [t.to(DEV) for t in synth.full_graph(n, M)]
+    upd = UA.Update(3).to(DEV).half().eval()
+    net = torch.randn(1, E, 384, device=DEV).half() * 0.1
+    inp = torch.randn(1, E, 384, device=DEV).half() * 0.1
+    corr = torch.randn(1, E, 882, device=DEV).half()
+    outs = []
+    for on in (True, False):
+        UA.MLP2_F16 = on
+        try:
+            with torch.no_grad():
+                o, (d, w, _) = upd(net, inp, corr, None, ii, jj, kk)
+        finally:
+            UA.MLP2_F16 = True
+        outs.append((o.float(), d.float(), w.float()))
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item())

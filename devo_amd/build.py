@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdevo_hip.so")
-SOURCES = ["lie.hip", "corr.hip", "ba.hip", "update.hip", "linear.hip", "linear_dw.hip", "mlp2.hip", "events.hip"]
+SOURCES = ["lie.hip", "corr.hip", "ba.hip", "update.hip", "linear.hip", "linear_dw.hip", "mlp2.hip", "gemm_rs.hip", "events.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-fno-slp-vectorize"]
 
 

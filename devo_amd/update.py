@@ -86,13 +86,40 @@ def _f16_ok(x2, n_out, k_in):
             and ((x2.shape[0] - 1) * x2.stride(0) + k_in) * 2 < (1 << 31))
 
 
+RS_GEMM = __import__("os").environ.get("DEVO_UPD_RS", "1") != "0"                # 0: every fp16 Linear layer on csrc/linear.hip's kernel
+RS_CHAINS = __import__("os").environ.get("DEVO_UPD_RS_CHAINS", "1") != "0"       # 0: no row-resident chains (one launch per layer / LayerNorm)
+
+
+def _rs_image(w):
+    """The B-operand image of csrc/gemm_rs.hip for a [384 n, K] fp16 weight, cached per version like _split_weight's images."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), "rs")
+    hit = _wsplit_cache.pop(key, None)
+    if hit is not None:
+        _wsplit_cache[key] = hit
+        return hit[1]
+    for k in [k for k in _wsplit_cache if k[0] == key[0] and k[4] == "rs"]:
+        del _wsplit_cache[k]
+    while len(_wsplit_cache) >= WSPLIT_CACHE_ENTRIES:
+        del _wsplit_cache[next(iter(_wsplit_cache))]
+    N, K = w.shape
+    img = torch.empty(int(L.lib().devo_upd_rs_weight_bytes(N, K)) // 2, dtype=torch.float16, device=w.device)
+    L.check(L.lib().devo_upd_rs_pack_weight_f16(L.ptr(w), w.stride(0), w.stride(1), N, K, L.ptr(img), L.stream()), "update.rs_pack_weight")
+    _wsplit_cache[key] = (w, img)
+    return img
+
+
 def _linear_f16(x2, w, b, relu=False, relu_from=None, residual=None, out=None):
-    """x2 [rows, K] fp16 -> act(x2 @ w.T + b) [+ residual] in fp16 storage with fp32 accumulation (csrc/linear.hip: k_linear_f16)"""
+    """x2 [rows, K] fp16 -> act(x2 @ w.T + b) [+ residual] in fp16 storage with fp32 accumulation (csrc/gemm_rs.hip: rows in LDS once, weights
+    from the L2 into registers — the 384-wide layers; csrc/linear.hip: k_linear_f16 — the rest)"""
     N, K = w.shape
     y = out if out is not None else torch.empty(x2.shape[0], N, dtype=torch.float16, device=x2.device)
     if residual is not None and (residual.stride(0) != y.stride(0) or residual.dtype != torch.float16):
         raise RuntimeError("_linear_f16: the residual must share the output's row pitch")
     rf = (0 if relu else N) if relu_from is None else relu_from
+    if RS_GEMM and L.lib().devo_upd_rs_supported(N, K) and y.stride(0) % 8 == 0 and y.data_ptr() % 16 == 0 and y.stride(1) == 1:
+        L.check(L.lib().devo_upd_rs_linear_f16(L.ptr(x2), x2.stride(0), L.ptr(_rs_image(w.detach())), L.ptr(b), L.ptr(residual), L.ptr(y), y.stride(0),
+                                               x2.shape[0], N, K, rf, L.stream()), "update.rs_linear_f16")
+        return y
     L.check(L.lib().devo_upd_linear_f16(L.ptr(x2), x2.stride(0), L.ptr(_split_weight(w.detach(), False)), L.ptr(b), L.ptr(residual), L.ptr(y),
                                         y.stride(0), x2.shape[0], N, K, rf, L.stream()), "update.linear_f16")
     return y
@@ -127,11 +154,18 @@ def _mlp2_ok(x2, l1, l2):
 
 
 def _mlp2_f16(x2, l1, l2, residual=None, gather=None):
-    """l2(relu(l1(x2[gather]))) [+ residual] as one launch (csrc/mlp2.hip); gather i64 [rows] with negative entries = zero rows"""
+    """l2(relu(l1(x2[gather]))) [+ residual] as one launch (384 inputs: csrc/gemm_rs.hip, the rows resident in LDS; else csrc/mlp2.hip);
+    gather i64 [rows] with negative entries = zero rows"""
     rows = x2.shape[0] if gather is None else gather.numel()
     y = torch.empty(rows, 384, dtype=torch.float16, device=x2.device)
     if residual is not None and (residual.stride(0) != 384 or residual.stride(1) != 1 or residual.dtype != torch.float16 or residual.data_ptr() % 16):
         raise RuntimeError("_mlp2_f16: the residual must be a contiguous fp16 [rows, 384] tensor")
+    if RS_CHAINS and RS_GEMM and l1.weight.shape[1] == 384 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0 and l1.bias.data_ptr() % 8 == 0 \
+            and l2.bias.data_ptr() % 8 == 0:
+        L.check(L.lib().devo_upd_rs_mlp2_f16(L.ptr(x2), x2.stride(0), x2.shape[0], L.ptr(gather), L.ptr(_rs_image(l1.weight.detach())), L.ptr(l1.bias),
+                                             L.ptr(_rs_image(l2.weight.detach())), L.ptr(l2.bias), L.ptr(residual), L.ptr(y), rows, L.stream()),
+                "update.rs_mlp2_f16")
+        return y
     L.check(L.lib().devo_upd_mlp2_f16(L.ptr(x2), x2.stride(0), x2.shape[0], L.ptr(gather), L.ptr(_mlp2_image(l1.weight.detach())), L.ptr(l1.bias),
                                       l1.weight.shape[1], L.ptr(_mlp2_image(l2.weight.detach())), L.ptr(l2.bias), L.ptr(residual), L.ptr(y), 384, rows,
                                       L.stream()), "update.mlp2_f16")
@@ -749,6 +783,21 @@ class Update(nn.Module):
         hy, grp = self._soft_agg("agg_kk", self.agg_kk, x, Gkk)
         L.check(lib.devo_upd_expand_add(L.ptr(x), L.ptr(hy), L.ptr(grp), E, dim, code, L.stream()), "update.expand_add")
         hy, grp = self._soft_agg("agg_ij", self.agg_ij, x, Gij)
+        if RS_CHAINS and dt == torch.float16 and dim == 384 and RS_GEMM and x.is_contiguous() and hy.is_contiguous():
+            # everything behind the aggregation is row-local: both LayerNorms, both GatedResiduals and the heads in ONE launch, rows in LDS
+            net_out = torch.empty_like(x)
+            delta = torch.empty(E, 2, dtype=dt, device=x.device)
+            weight = torch.empty(E, 2, dtype=dt, device=x.device)
+            W1, b1 = self._cat("gru1", self.gru[1].gate[0], self.gru[1].res[0])
+            W3, b3 = self._cat("gru3", self.gru[3].gate[0], self.gru[3].res[0])
+            r1, r3 = self.gru[1].res[2], self.gru[3].res[2]
+            L.check(lib.devo_upd_rs_gru_f16(L.ptr(x), L.ptr(hy), L.ptr(grp), L.ptr(self.gru[0].weight), L.ptr(self.gru[0].bias), float(self.gru[0].eps),
+                                            L.ptr(_rs_image(W1)), L.ptr(b1), L.ptr(_rs_image(r1.weight.detach())), L.ptr(r1.bias), L.ptr(self.gru[2].weight),
+                                            L.ptr(self.gru[2].bias), float(self.gru[2].eps), L.ptr(_rs_image(W3)), L.ptr(b3),
+                                            L.ptr(_rs_image(r3.weight.detach())), L.ptr(r3.bias), L.ptr(self.d[1].weight), L.ptr(self.d[1].bias),
+                                            L.ptr(self.w[1].weight), L.ptr(self.w[1].bias), L.ptr(net_out), L.ptr(delta), L.ptr(weight), E, L.stream()),
+                    "update.rs_gru_f16")
+            return net_out.view(1, E, dim), (delta.view(1, E, 2), weight.view(1, E, 2), None)
         x = _ln(x, self.gru[0], expand=(hy, grp))                                  # LN(net + agg_ij(net))
         x = _ln(x, self.gru[2], gated=self._gate_res("gru1", self.gru[1], x))     # LN(GatedResidual(.))
         gate, res = self._gate_res("gru3", self.gru[3], x)

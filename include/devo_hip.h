@@ -409,6 +409,32 @@ int devo_upd_heads(const void* x, const void* gate, int64_t ld_gate, const void*
  *     x.add_(linear(t)) in one launch); columns >= relu_from get max(., 0) (0: all of them, >= N: none — a gate | res pair of a
  *     GatedResidual in one launch); gate NULL or fp32 with y's row pitch: the result is kept where gate > 0 and zeroed elsewhere, before
  *     the residual — dX = (dY W) masked by the ReLU output it passes back through (threshold_backward in the epilogue). */
+/* The update operator's Linear layers in fp16 storage, second structure (csrc/gemm_rs.hip; enet.py:41-78): a workgroup's rows live in LDS once,
+ * the weights go from the L2 into the registers of the wave that multiplies them.  y[M, N] = act(x W^T + bias) [+ residual]; the ReLU applies from
+ * column relu_from on (N: none); residual may be y.  N a multiple of 384, K in (352, 384] (devo_upd_rs_supported); x rows 4-byte aligned, y /
+ * residual rows 16-byte aligned.  Weight image:
+ * devo_upd_rs_pack_weight_f16 (devo_upd_rs_weight_bytes(N, K) bytes, 16-byte aligned), once per weight version. */
+size_t devo_upd_rs_weight_bytes(int N, int K);
+int devo_upd_rs_supported(int N, int K);
+int devo_upd_rs_pack_weight_f16(const void* W /* f16, element (n, k) at W[n * s_n + k * s_k] */, int64_t s_n, int64_t s_k, int N, int K, void* wimage, void* stream);
+int devo_upd_rs_linear_f16(const void* x, int64_t ldx, const void* wimage, const void* bias, const void* residual, void* y, int64_t ldy, int M, int N, int K,
+                           int relu_from, void* stream);
+/* What follows the frame-pair aggregation in the update operator as ONE launch, fp16 storage (enet.py:52-57, 96-99; blocks.py:29-48) — the rows
+ * stay in LDS between the layers:  net = LN0(x + hy[group_of]);  net = LN2(net + sigmoid(gate1(net)) res1(net));
+ * net_out = net + sigmoid(gate3(net)) res3(net);  delta = d(relu(net_out)), weight = sigmoid(w(relu(net_out))).
+ * x, net_out [E, 384] contiguous, hy [groups, 384], delta / weight [E, 2]; wgr*: the [gate[0] | res[0]] weights concatenated to [768, 384], wr2_*:
+ * res[2] [384, 384], both as devo_upd_rs_pack_weight_f16 images; bgr* [768], br2_* [384]; Wd / Ww [2, 384]; everything fp16, 16-byte aligned.
+ * Every layer output and LayerNorm output is rounded to fp16 where the layer-by-layer path stores it. */
+/* l2(relu(l1(x[gather]))) [+ residual] as one launch with the rows resident in LDS, both layers 384 -> 384 (enet.py:46-50, 86-91: c1 / c2 with
+ * their neighbour gather and the sum).  x rows 16-byte aligned (ldx a multiple of 8), residual / y [M, 384] contiguous; gather i64 [M] (negative or
+ * >= x_rows: a zero row) or null; weight images of devo_upd_rs_pack_weight_f16; biases 8-byte aligned. */
+int devo_upd_rs_mlp2_f16(const void* x, int64_t ldx, int x_rows, const int64_t* gather, const void* w1image, const void* b1, const void* w2image, const void* b2,
+                         const void* residual, void* y, int M, void* stream);
+int devo_upd_rs_gru_f16(const void* x, const void* hy, const int* group_of, const void* ln0_w, const void* ln0_b, float eps0, const void* wgr1_img,
+                        const void* bgr1, const void* wr2_1_img, const void* br2_1, const void* ln2_w, const void* ln2_b, float eps2, const void* wgr3_img,
+                        const void* bgr3, const void* wr2_3_img, const void* br2_3, const void* Wd, const void* bd, const void* Ww, const void* bw,
+                        void* net_out, void* delta, void* weight, int E, void* stream);
+
 /* Linear - ReLU - Linear of the update operator as ONE launch, fp16 storage / fp32 accumulation (csrc/mlp2.hip; enet.py:46-50 c1 / c2,
  * :59-61 the corr MLP's first two layers): y[r] = (residual[r] +) W2 relu(W1 x[src(r)] + b1) + b2 with both layers 384 wide, any K1 (W1 is
  * [384, K1]); src(r) = r, or gather[r] (i64 [M]; negative = a zero row: `mask * net[:, ix]`).  The 384-wide intermediate stays in LDS, rounded

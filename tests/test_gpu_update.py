@@ -551,3 +551,66 @@ def test_update_fp16_operator_uses_the_fused_chains_and_keeps_its_golden():
         outs.append((o.float(), d.float(), w.float()))
     for a, b in zip(*outs):
         assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("rows,n_out,relu_from,residual", [(21600, 384, None, False), (18000, 384, 0, True), (21600, 768, 384, False), (1031, 384, None, True),
+                                                           (97, 768, 0, False)])
+def test_row_resident_linear_matches_the_fp64_product(rows, n_out, relu_from, residual):
+    """csrc/gemm_rs.hip (a workgroup's rows in LDS once, the weights from the L2 into the registers of the wave that multiplies them; fp16
+    storage, fp32 accumulation) against the fp64 product of the same fp16 operands — every output against the magnitude of its terms —
+    and against csrc/linear.hip's kernel (fp16 rounding of the same sums); ReLU from a column on, the in-place residual, row counts
+    that are no multiple of the 96-row tile, both column passes of a 768-wide layer."""
+    from devo_amd import update as UA
+    torch.manual_seed(rows + n_out)
+    lin = torch.nn.Linear(384, n_out).to(DEV).half()
+    x = (torch.randn(rows, 384, device=DEV) * 0.7).half()
+    res = torch.randn(rows, n_out, device=DEV).half() if residual else None
+    assert UA.RS_GEMM and UA.L.lib().devo_upd_rs_supported(n_out, 384)
+    outs = {}
+    for rs in (True, False):
+        UA.RS_GEMM = rs
+        try:
+            r = res.clone() if residual else None
+            outs[rs] = UA._linear_f16(x, lin.weight, lin.bias, relu_from=relu_from, residual=r, out=r).clone()
+        finally:
+            UA.RS_GEMM = True
+    ref = x.double() @ lin.weight.double().t() + lin.bias.double()
+    mag = x.double().abs() @ lin.weight.double().abs().t() + lin.bias.double().abs()
+    if relu_from is not None:
+        ref[:, relu_from:] = ref[:, relu_from:].clamp(min=0)
+    if residual:
+        ref, mag = ref + res.double(), mag + res.double().abs()
+    err = ((outs[True].double() - ref).abs() / mag.clamp(min=1e-6)).max().item()
+    assert torch.isfinite(outs[True]).all() and err < 1e-3, err
+    assert (outs[True].float() - outs[False].float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_update_fp16_operator_row_resident_chain_keeps_its_outputs():
+    """The fp16 inference operator with and without the row-resident chain (csrc/gemm_rs.hip: both LayerNorms, both GatedResiduals and the
+    heads behind the frame-pair aggregation in one launch; DEVO_UPD_RS_CHAINS): the same outputs within fp16 rounding, at a row count that
+    is no multiple of the 96-row tile as well."""
+    from devo_amd import update as UA
+    from devo_amd import synth
+    for n, M, seed in ((15, 96, 5), (7, 13, 6)):
+        torch.manual_seed(seed)
+        ii, jj, kk = [t.to(DEV) for t in synth.full_graph(n, M)]
+        E = ii.numel()
+        upd = UA.Update(3).to(DEV).half().eval()
+        with torch.no_grad():
+            for p in upd.parameters():                                 # (biases and LayerNorm parameters away from their 0 / 1 initial values)
+                if p.dim() == 1:
+                    p.add_(torch.randn_like(p) * 0.1)
+        net = torch.randn(1, E, 384, device=DEV).half() * 0.5
+        inp = torch.randn(1, E, 384, device=DEV).half() * 0.5
+        corr = torch.randn(1, E, 882, device=DEV).half()
+        outs = []
+        for on in (True, False):
+            UA.RS_CHAINS = on
+            try:
+                with torch.no_grad():
+                    o, (d, w, _) = upd(net, inp, corr, None, ii, jj, kk)
+            finally:
+                UA.RS_CHAINS = True
+            outs.append((o.float(), d.float(), w.float()))
+        for a, b in zip(*outs):
+            assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 1e-2 * max(1.0, b.abs().max().item()), (n, (a - b).abs().max().item())

@@ -9,6 +9,6 @@ python -m devo_amd.build > /dev/null
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-function -Wno-pass-failed -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $F "$@" -c devo_amd/csrc/$src.hip -o devo_amd/lib/${src}_$tag.o
 objs=""
-for s in lie corr ba update linear linear_dw mlp2 events; do if [ $s = $src ]; then objs="$objs devo_amd/lib/${src}_$tag.o"; else objs="$objs devo_amd/lib/$s.o"; fi; done
+for s in lie corr ba update linear linear_dw mlp2 gemm_rs events; do if [ $s = $src ]; then objs="$objs devo_amd/lib/${src}_$tag.o"; else objs="$objs devo_amd/lib/$s.o"; fi; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o devo_amd/lib/libdevo_$tag.so $objs
 echo devo_amd/lib/libdevo_$tag.so

@@ -79,6 +79,11 @@ _SIGNATURES.update({
     "devo_upd_rs_linear_f16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],
     "devo_upd_rs_gru_f16": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "devo_upd_rs_mlp2_f16": [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "devo_upd_rs_corr_f16": [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp],
+    "devo_upd_rs_split_weight_bytes": [_i, _i],
+    "devo_upd_rs_split_supported": [_i, _i],
+    "devo_upd_rs_split_weight": [_vp, _i64, _i64, _i, _i, _vp, _vp],
+    "devo_upd_rs_linear_split": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],
     "devo_upd_mlp2_weight_bytes": [_i],
     "devo_upd_mlp2_pack_weight": [_vp, _i64, _i64, _i, _vp, _vp],
     "devo_upd_mlp2_f16": [_vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp],
@@ -99,7 +104,7 @@ for _n in ("mul", "adj", "adjT", "act", "act4"):
 _SIGNATURES["devo_se3_as_matrix"] = [_vp, _vp, _i64, _i, _vp]
 _SIGNATURES["devo_se3_jinv"] = [_vp, _vp, _vp, _i64, _i, _vp]
 _RESTYPE = {"devo_last_error": ctypes.c_char_p, "devo_voxel_std_workspace_bytes": _sz, "devo_ba_workspace_bytes": _sz, "devo_neighbors_workspace_bytes": _sz,
-             "devo_corr_backward_workspace_bytes": _sz, "devo_corr_patch_operand_bytes": _sz, "devo_upd_split_weight_bytes": _sz, "devo_upd_dw_workspace_bytes": _sz, "devo_upd_pack_weight_f16_bytes": _sz, "devo_upd_mlp2_weight_bytes": _sz, "devo_upd_rs_weight_bytes": _sz}
+             "devo_corr_backward_workspace_bytes": _sz, "devo_corr_patch_operand_bytes": _sz, "devo_upd_split_weight_bytes": _sz, "devo_upd_dw_workspace_bytes": _sz, "devo_upd_pack_weight_f16_bytes": _sz, "devo_upd_mlp2_weight_bytes": _sz, "devo_upd_rs_weight_bytes": _sz, "devo_upd_rs_split_weight_bytes": _sz}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -201,10 +201,12 @@ __device__ __forceinline__ void rs_prefetch(const __amdgpu_buffer_rsrc_t rsw, un
     for (int t = 0; t < RS_NT; t++) b[s][t] = __builtin_amdgcn_raw_buffer_load_b128(rsw, bvoff, wbase + (unsigned)((s * RS_NT + t) * 1024), 0);
 }
 
-// acc += rows (LDS tile, this lane's pieces at arow + 16 mt PITCH + 64 s) x this wave's weight stream (steps 0 .. RS_RB - 2 already in b)
-template <int MT, int NK, int PITCH>
+// acc += rows (LDS tile, this lane's pieces at arow + 16 mt PITCH + 64 s) x this wave's weight stream (steps 0 .. RS_RB - 2 already in b).
+// NEXT: the loop's last steps request the first RS_RB - 1 steps of the stream the NEXT loop multiplies (no bubble between products).
+template <int MT, int NK, int PITCH, bool NEXT = false>
 __device__ __forceinline__ void rs_kloop(const unsigned char* arow, const __amdgpu_buffer_rsrc_t rsw, unsigned wbase, unsigned bvoff, rs_u4 (&b)[RS_RB][RS_NT],
-                                         rs_f4 (&acc)[MT][RS_NT]) {
+                                         rs_f4 (&acc)[MT][RS_NT], const __amdgpu_buffer_rsrc_t nrsw = __amdgpu_buffer_rsrc_t(), unsigned nwbase = 0) {
+  static_assert(NK % RS_RB == 0, "ring slots line up across loops");
   rs_u4 af[2][MT];
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) af[0][mt] = *reinterpret_cast<const rs_u4*>(arow + 16 * mt * PITCH);
@@ -218,6 +220,10 @@ __device__ __forceinline__ void rs_kloop(const unsigned char* arow, const __amdg
 #pragma unroll
       for (int t = 0; t < RS_NT; t++)
         b[(s + RS_RB - 1) % RS_RB][t] = __builtin_amdgcn_raw_buffer_load_b128(rsw, bvoff, wbase + (unsigned)(((s + RS_RB - 1) * RS_NT + t) * 1024), 0);
+    } else if (NEXT) {
+#pragma unroll
+      for (int t = 0; t < RS_NT; t++)
+        b[(s + RS_RB - 1) % RS_RB][t] = __builtin_amdgcn_raw_buffer_load_b128(nrsw, bvoff, nwbase + (unsigned)(((s + RS_RB - 1 - NK) * RS_NT + t) * 1024), 0);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -357,9 +363,8 @@ __global__ __launch_bounds__(512) void k_rs_gru_f16(RsGru a) {
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
       for (int t = 0; t < RS_NT; t++) acc[mt][t] = rs_f4{0.f, 0.f, 0.f, 0.f};
-    rs_kloop<MT, NK, PITCH>(arowX, rs_gr[rep], wbase(1), bvoff, b, acc);
+    rs_kloop<MT, NK, PITCH, true>(arowX, rs_gr[rep], wbase(1), bvoff, b, acc, rs_r2[rep], wbase(0));
     stamp();
-    rs_prefetch<NK>(rs_r2[rep], wbase(0), bvoff, b);
 #pragma unroll
     for (int t = 0; t < RS_NT; t++) {
       const rs_f4 bs = vec4(o_gr + D, t);
@@ -379,9 +384,8 @@ __global__ __launch_bounds__(512) void k_rs_gru_f16(RsGru a) {
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
       for (int t = 0; t < RS_NT; t++) acc[mt][t] = rs_f4{0.f, 0.f, 0.f, 0.f};
-    rs_kloop<MT, NK, PITCH>(arowR, rs_r2[rep], wbase(0), bvoff, b, acc);
+    rs_kloop<MT, NK, PITCH, true>(arowR, rs_r2[rep], wbase(0), bvoff, b, acc, rs_gr[rep], wbase(0));
     stamp();
-    rs_prefetch<NK>(rs_gr[rep], wbase(0), bvoff, b);
     __syncthreads();
     stamp();
 #pragma unroll
@@ -396,9 +400,9 @@ __global__ __launch_bounds__(512) void k_rs_gru_f16(RsGru a) {
 #pragma unroll
       for (int t = 0; t < RS_NT; t++) acc[mt][t] = rs_f4{0.f, 0.f, 0.f, 0.f};
     stamp();
-    rs_kloop<MT, NK, PITCH>(arowX, rs_gr[rep], wbase(0), bvoff, b, acc);
+    if (rep == 0) rs_kloop<MT, NK, PITCH, true>(arowX, rs_gr[0], wbase(0), bvoff, b, acc, rs_gr[1], wbase(1));
+    else rs_kloop<MT, NK, PITCH>(arowX, rs_gr[1], wbase(0), bvoff, b, acc);
     stamp();
-    if (rep == 0) rs_prefetch<NK>(rs_gr[1], wbase(1), bvoff, b);
 #pragma unroll
     for (int t = 0; t < RS_NT; t++) {
       const rs_f4 bs = vec4(o_gr, t);
@@ -541,8 +545,7 @@ __global__ __launch_bounds__(512) void k_rs_mlp2_f16(const __half* __restrict__ 
   for (int mt = 0; mt < MT; mt++)
 #pragma unroll
     for (int t = 0; t < RS_NT; t++) acc[mt][t] = rs_f4{0.f, 0.f, 0.f, 0.f};
-  rs_kloop<MT, NK, PITCH>(arowX, rs1, wbase, bvoff, b, acc);
-  rs_prefetch<NK>(rs2, wbase, bvoff, b);
+  rs_kloop<MT, NK, PITCH, true>(arowX, rs1, wbase, bvoff, b, acc, rs2, wbase);
   if (residual) {                                                      // the residual rows travel while relu(h) is written
 #pragma unroll
     for (int i = 0; i < AP; i++) {
@@ -591,6 +594,435 @@ __global__ __launch_bounds__(512) void k_rs_mlp2_f16(const __half* __restrict__ 
   for (int i = 0; i < AP; i++) {
     const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
     if (row0 + row < M) *reinterpret_cast<rs_u4*>(y + (int64_t)(row0 + row) * D + 8 * c) = *reinterpret_cast<const rs_u4*>(X + row * PITCH + 16 * c);
+  }
+}
+
+// The correlation branch and the first LayerNorm of the update operator, one launch (enet.py:59-66, 82-83):
+//   c = l5(relu(LN3(l2(relu(l0(corr))))));  x = LN(net + inp + c).
+// l0 has 882 inputs: its rows arrive in three K chunks of 384 (X, R, X again), the accumulators stay; then h, LN3's output and c take
+// turns in R / X / R; the last LayerNorm runs row-wise (a quarter wave per row) with net and inp read as whole rows.
+struct RsCorr {
+  const __half* corr; int64_t ldc;                                     // [E, 882], rows 4-byte aligned
+  const rs_u4* w0; const __half* b0; const rs_u4* w2; const __half* b2; const __half* ln3_g; const __half* ln3_b;
+  const rs_u4* w5; const __half* b5; const __half* net; const __half* inp; const __half* ln_g; const __half* ln_b; __half* out;
+  int E, K0; float eps3, eps;
+};
+constexpr int RC_VEC = 5 * 384;                                        // halves: b0 | b2 | ln3 gamma | ln3 beta | b5
+constexpr int RC_LDS = 2 * RG_ROWS * RG_PITCH + RC_VEC * 2 + RG_ROWS * 8 * 2 * 4 + RG_ROWS * 2 * 4;
+
+__global__ __launch_bounds__(512) void k_rs_corr_f16(RsCorr a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char rs_lds[];
+  constexpr int MT = RG_MT, NK = RG_NK, PITCH = RG_PITCH, ROWS = RG_ROWS, D = 384, PPR = D / 8, AP = ROWS * PPR / 512;
+  constexpr int NK0 = 28, AP2 = ROWS * 16 / 512;                       // l0: 28 K steps (882 inputs); the third chunk: 128 inputs = 16 pieces per row
+  constexpr unsigned OFF_NONE = 0x80000000u;
+  unsigned char* X = rs_lds;
+  unsigned char* R = rs_lds + ROWS * PITCH;
+  _Float16* vec = reinterpret_cast<_Float16*>(rs_lds + 2 * ROWS * PITCH);
+  float* part = reinterpret_cast<float*>(rs_lds + 2 * ROWS * PITCH + RC_VEC * 2);
+  float* stat = part + ROWS * 16;
+  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, mi = lane & 15, kg = lane >> 4;
+  const int row0 = blockIdx.x * ROWS, E = a.E, K0 = a.K0;
+  const unsigned bvoff = (unsigned)lane * 16u;
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(a.corr), 0, (unsigned)(((int64_t)(E - 1) * a.ldc + K0) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<rs_u4*>(a.w0), 0, (unsigned)(D * NK0 * 32 * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<rs_u4*>(a.w2), 0, (unsigned)(D * D * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs5 = __builtin_amdgcn_make_buffer_rsrc(const_cast<rs_u4*>(a.w5), 0, (unsigned)(D * D * 2), 0x00020000);
+  const unsigned wb0 = (unsigned)((wv * NK0) * RS_NT * 1024), wb = (unsigned)((wv * NK) * RS_NT * 1024);
+  // ---- chunks 0 and 1 of the rows -> X, R
+  rs_u4 ap[2][AP];
+#pragma unroll
+  for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+    for (int i = 0; i < AP; i++) {
+      const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
+      ap[ch][i] = __builtin_amdgcn_raw_buffer_load_b128(rsc, row0 + row < E ? (unsigned)(((int64_t)(row0 + row) * a.ldc + 384 * ch + 8 * c) * 2) : OFF_NONE, 0, 0);
+    }
+  rs_u4 b[RS_RB][RS_NT];
+  rs_prefetch<NK>(rs0, wb0, bvoff, b);
+#pragma unroll
+  for (int k = 0; k < (RC_VEC + 511) / 512; k++) {
+    const int i = tid + 512 * k;
+    if (i < RC_VEC) {
+      const __half* src = i < 384 ? a.b0 + i : i < 768 ? a.b2 + (i - 384) : i < 1152 ? a.ln3_g + (i - 768) : i < 1536 ? a.ln3_b + (i - 1152) : a.b5 + (i - 1536);
+      vec[i] = (_Float16)__half2float(*src);
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+    for (int i = 0; i < AP; i++) {
+      const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
+      *reinterpret_cast<rs_u4*>((ch ? R : X) + row * PITCH + 16 * c) = ap[ch][i];
+    }
+  // the third chunk (inputs 768 .. 895; what lies behind input K0 is not part of the row) travels while the first two multiply
+  rs_u4 a2[AP2];
+#pragma unroll
+  for (int i = 0; i < AP2; i++) {
+    const int p = tid + 512 * i, row = p >> 4, c = p & 15, k = 768 + 8 * c;
+    a2[i] = __builtin_amdgcn_raw_buffer_load_b128(rsc, (row0 + row < E && k < K0) ? (unsigned)(((int64_t)(row0 + row) * a.ldc + k) * 2) : OFF_NONE, 0, 0);
+  }
+  __syncthreads();
+  const unsigned char* arowX = X + mi * PITCH + 16 * kg;
+  const unsigned char* arowR = R + mi * PITCH + 16 * kg;
+  const int colw = 48 * wv + 4 * kg;
+  unsigned char* eX = X + mi * PITCH + colw * 2;
+  unsigned char* eR = R + mi * PITCH + colw * 2;
+  auto vec4 = [&](int off, int t) { return rs_cvt4(*reinterpret_cast<const rs_h4*>(vec + off + colw + 16 * t)); };
+  rs_f4 acc[MT][RS_NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int t = 0; t < RS_NT; t++) acc[mt][t] = rs_f4{0.f, 0.f, 0.f, 0.f};
+  // ---- h = relu(corr W0 + b0): 12 + 12 + 4 K steps
+  rs_kloop<MT, NK, PITCH, true>(arowX, rs0, wb0, bvoff, b, acc, rs0, wb0 + 12u * RS_NT * 1024u);
+  rs_kloop<MT, NK, PITCH, true>(arowR, rs0, wb0 + 12u * RS_NT * 1024u, bvoff, b, acc, rs0, wb0 + 24u * RS_NT * 1024u);
+  __syncthreads();                                                     // everybody is done with X (and with R)
+#pragma unroll
+  for (int i = 0; i < AP2; i++) {
+    const int p = tid + 512 * i, row = p >> 4, c = p & 15, k = 768 + 8 * c;
+    if (k < K0 && k + 8 > K0) {
+      rs_h8 v = __builtin_bit_cast(rs_h8, a2[i]);
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = k + e < K0 ? v[e] : (_Float16)0.f;
+      a2[i] = __builtin_bit_cast(rs_u4, v);
+    }
+    *reinterpret_cast<rs_u4*>(X + row * PITCH + 16 * c) = a2[i];
+  }
+  __syncthreads();
+  rs_kloop<MT, 4, PITCH, true>(arowX, rs0, wb0 + 24u * RS_NT * 1024u, bvoff, b, acc, rs2, wb);
+#pragma unroll
+  for (int t = 0; t < RS_NT; t++) {
+    const rs_f4 bs = vec4(0, t);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      rs_f4 v = acc[mt][t] + bs;
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+      *reinterpret_cast<rs_h4*>(eR + 16 * mt * PITCH + 32 * t) = rs_pack4(v);
+      acc[mt][t] = rs_f4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  // ---- X = relu(LN3(h W2 + b2))
+  rs_kloop<MT, NK, PITCH, true>(arowR, rs2, wb, bvoff, b, acc, rs5, wb);
+#pragma unroll
+  for (int t = 0; t < RS_NT; t++) {
+    const rs_f4 bs = vec4(384, t);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt][t] = rs_cvt4(rs_pack4(acc[mt][t] + bs));      // (rounded where the layer-by-layer path stores it)
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int t = 0; t < RS_NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) { s += acc[mt][t][r]; q += acc[mt][t][r] * acc[mt][t][r]; }
+    s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+    s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+    if (kg == 0) { part[((16 * mt + mi) * 8 + wv) * 2] = s; part[((16 * mt + mi) * 8 + wv) * 2 + 1] = q; }
+  }
+  __syncthreads();
+  if (tid < ROWS) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; w++) { s += part[(tid * 8 + w) * 2]; q += part[(tid * 8 + w) * 2 + 1]; }
+    const float mean = s / (float)D, var = fmaxf(q / (float)D - mean * mean, 0.f);
+    stat[2 * tid] = mean; stat[2 * tid + 1] = rsqrtf(var + a.eps3);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < RS_NT; t++) {
+    const rs_f4 g = vec4(768, t), bb = vec4(1152, t);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      const float mean = stat[2 * (16 * mt + mi)], rstd = stat[2 * (16 * mt + mi) + 1];
+      rs_f4 v = (acc[mt][t] - mean) * rstd * g + bb;
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+      *reinterpret_cast<rs_h4*>(eX + 16 * mt * PITCH + 32 * t) = rs_pack4(v);
+      acc[mt][t] = rs_f4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  // ---- R = c = X W5 + b5
+  rs_kloop<MT, NK, PITCH>(arowX, rs5, wb, bvoff, b, acc);
+#pragma unroll
+  for (int t = 0; t < RS_NT; t++) {
+    const rs_f4 bs = vec4(1536, t);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) *reinterpret_cast<rs_h4*>(eR + 16 * mt * PITCH + 32 * t) = rs_pack4(acc[mt][t] + bs);
+  }
+  __syncthreads();
+  // ---- out = LN(net + inp + c): a quarter wave per row
+  {
+    const int l16 = tid & 15;
+    rs_u4 nv[3][3], iv[3][3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      const int row = row0 + 32 * p + (tid >> 4), rr = row < E ? row : E - 1;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        nv[p][k] = *reinterpret_cast<const rs_u4*>(a.net + (int64_t)rr * D + (l16 + 16 * k) * 8);
+        iv[p][k] = *reinterpret_cast<const rs_u4*>(a.inp + (int64_t)rr * D + (l16 + 16 * k) * 8);
+      }
+    }
+    rs_u4 gm[3], bt[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      gm[k] = *reinterpret_cast<const rs_u4*>(a.ln_g + (l16 + 16 * k) * 8);
+      bt[k] = *reinterpret_cast<const rs_u4*>(a.ln_b + (l16 + 16 * k) * 8);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      const int rloc = 32 * p + (tid >> 4), row = row0 + rloc;
+      float t[3][8];
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const rs_h8 xh = __builtin_bit_cast(rs_h8, nv[p][k]), ih = __builtin_bit_cast(rs_h8, iv[p][k]),
+                    ch = __builtin_bit_cast(rs_h8, *reinterpret_cast<const rs_u4*>(R + rloc * PITCH + (l16 + 16 * k) * 16));
+#pragma unroll
+        for (int i = 0; i < 8; i++) { t[k][i] = (float)xh[i] + (float)ih[i] + (float)ch[i]; s += t[k][i]; }
+      }
+      const float mean = rs_row16_sum(s) / (float)D;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const float d = t[k][i] - mean; q += d * d; }
+      const float rstd = rsqrtf(rs_row16_sum(q) / (float)D + a.eps);
+      if (row < E) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const rs_h8 g8 = __builtin_bit_cast(rs_h8, gm[k]), b8 = __builtin_bit_cast(rs_h8, bt[k]);
+          rs_h8 o;
+#pragma unroll
+          for (int i = 0; i < 8; i++) o[i] = (_Float16)((t[k][i] - mean) * rstd * (float)g8[i] + (float)b8[i]);
+          *reinterpret_cast<rs_u4*>(a.out + (int64_t)row * D + (l16 + 16 * k) * 8) = __builtin_bit_cast(rs_u4, o);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- fp32 storage
+// The same structure for fp32 rows on the fp16 matrix cores with exact hi + lo splits (linear.hip's arithmetic: x y = hi lo' + lo hi' +
+// hi hi', fp32 accumulation, power-of-two scales per row and per weight column): the rows are scaled by their OWN largest magnitude (the
+// whole row is there when it is loaded: no running scale), split ONCE into two fp16 tiles in LDS (hi | lo, 75 KB each), every wave
+// streams its hi and lo weight fragments into registers one K step ahead; three products per block.  The result goes through LDS (over
+// the row tiles) so that whole rows leave, with the ReLU adjoint mask and the residual read as whole rows too.  One workgroup = 96 rows x
+// 384 columns; a 768-wide layer = two column blocks (blockIdx.y) that split the rows again.
+__device__ __forceinline__ int rs_scale_exp(float m) {                 // biased exponent of the power of two that brings m into [2^8, 2^9)
+  int e = (int)((__float_as_uint(m) >> 23) & 255u);
+  e = e < 16 ? 16 : e;
+  return 127 + 8 + 127 - e;
+}
+__device__ __forceinline__ float rs_pow2(int biased) { return __uint_as_float((unsigned)(biased < 0 ? 0 : (biased > 254 ? 254 : biased)) << 23); }
+__device__ __forceinline__ void rs_split8(const float (&x)[8], rs_u4& hi, rs_u4& lo) {      // hi = rn(x), lo = rn(x - hi)
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h[j]) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[j]) : "v"(h[j]), "v"(x[2 * j]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[j]) : "v"(h[j]), "v"(x[2 * j + 1]));
+  }
+  hi = rs_u4{h[0], h[1], h[2], h[3]};
+  lo = rs_u4{l[0], l[1], l[2], l[3]};
+}
+__device__ __forceinline__ float rs_row16_max(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false)));
+  return v;
+}
+
+// W fp32 (element (n, k) at W[n * s_n + k * s_k]; N a multiple of 384) -> [N / 384][8 waves][ceil(K / 32)][3 tiles][hi | lo][64 lanes][16 B], every
+// column scaled by its power of two; then N floats: the inverse column scales.  Pass 1: the scales.
+__global__ __launch_bounds__(256) void k_rs_wscale(const float* __restrict__ W, int64_t s_n, int64_t s_k, int N, int K, float* __restrict__ inv) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float m = 0.f;
+  for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(W[(int64_t)n * s_n + (int64_t)k * s_k]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) inv[n] = rs_pow2(254 - rs_scale_exp(m));
+}
+__global__ __launch_bounds__(256) void k_rs_wsplit(const float* __restrict__ W, int64_t s_n, int64_t s_k, int N, int K, rs_u4* __restrict__ out) {
+  const int nk = (K + 31) / 32;
+  const long long total = (long long)(N / RS_BN) * RS_NW * nk * RS_NT * 64;
+  const float* inv = reinterpret_cast<const float*>(out + (size_t)total * 2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    long long r = i >> 6;
+    const int t = (int)(r % RS_NT); r /= RS_NT;
+    const int s = (int)(r % nk); r /= nk;
+    const int w = (int)(r % RS_NW), nb = (int)(r / RS_NW);
+    const int n = nb * RS_BN + 48 * w + 16 * t + (lane & 15), k0 = 32 * s + 8 * (lane >> 4);
+    const float sc = rs_pow2(254 - (int)(__float_as_uint(inv[n]) >> 23));
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = k0 + j < K ? W[(int64_t)n * s_n + (int64_t)(k0 + j) * s_k] * sc : 0.f;
+    rs_u4 hi, lo;
+    rs_split8(v, hi, lo);
+    rs_u4* dst = out + ((i >> 6) * 2) * 64 + lane;
+    dst[0] = hi;
+    dst[64] = lo;
+  }
+}
+
+constexpr int RF_YLD = 388;                                            // row pitch (floats) of the result tile
+constexpr int RF_LDS = 2 * RG_ROWS * RG_PITCH + RG_ROWS * 4 + 2 * 384 * 4;
+static_assert(RG_ROWS * RF_YLD * 4 <= 2 * RG_ROWS * RG_PITCH, "the result tile lies over the row tiles");
+
+__global__ __launch_bounds__(512) void k_rs_linear_split(const float* __restrict__ x, int64_t ldx, const rs_u4* __restrict__ wimg, const float* __restrict__ bias,
+                                                          const float* residual, const float* __restrict__ gate, float* y, int64_t ldy, int M, int N, int K,
+                                                          int relu_from) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char rs_lds[];
+  constexpr int MT = RG_MT, NK = RG_NK, PITCH = RG_PITCH, ROWS = RG_ROWS, D = 384;
+  unsigned char* XH = rs_lds;
+  unsigned char* XL = rs_lds + ROWS * PITCH;
+  float* rinv = reinterpret_cast<float*>(rs_lds + 2 * ROWS * PITCH);   // [row]: the inverse row scales
+  float* cvec = rinv + ROWS;                                           // [inverse column scale | bias][384]
+  float* Y = reinterpret_cast<float*>(rs_lds);
+  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, mi = lane & 15, kg = lane >> 4;
+  const int row0 = blockIdx.x * ROWS, nb = blockIdx.y, NB = gridDim.y;
+  const unsigned bvoff = (unsigned)lane * 16u;
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<rs_u4*>(wimg), 0, (unsigned)((int64_t)NB * RS_NW * NK * RS_NT * 2048), 0x00020000);
+  const unsigned wbase = (unsigned)(((nb * RS_NW + wv) * NK) * RS_NT * 2048);
+  // this wave's weights: K step s, tile t = hi (1 KB) | lo (1 KB) at wbase + (s * 3 + t) * 2 KB; two steps in registers
+  rs_u4 bh[2][RS_NT], bl[2][RS_NT];
+  auto load_b = [&](int s) {
+#pragma unroll
+    for (int t = 0; t < RS_NT; t++) {
+      bh[s & 1][t] = __builtin_amdgcn_raw_buffer_load_b128(rsw, bvoff, wbase + (unsigned)((s * RS_NT + t) * 2048), 0);
+      bl[s & 1][t] = __builtin_amdgcn_raw_buffer_load_b128(rsw, bvoff, wbase + (unsigned)((s * RS_NT + t) * 2048 + 1024), 0);
+    }
+  };
+  if (tid < D) {
+    const float* inv = reinterpret_cast<const float*>(wimg + (size_t)NB * RS_NW * NK * RS_NT * 128);
+    cvec[tid] = inv[nb * D + tid];
+    cvec[D + tid] = bias ? bias[nb * D + tid] : 0.f;
+  }
+  // ---- the rows: a quarter wave per row (16 lanes x 3 pieces of 8 floats), scaled by the row's own power of two, split, -> XH | XL
+  {
+    const int l16 = tid & 15;
+    rs_f4 xv[3][3][2];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      const int row = row0 + 32 * p + (tid >> 4);
+      const float* xr = x + (int64_t)(row < M ? row : M - 1) * ldx;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int c = (l16 + 16 * k) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; h++) xv[p][k][h] = (c + 4 * h < K) ? *reinterpret_cast<const rs_f4*>(xr + c + 4 * h) : rs_f4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    load_b(0);
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      const int rloc = 32 * p + (tid >> 4);
+      const bool live = row0 + rloc < M;
+      float m = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) m = fmaxf(m, fabsf(xv[p][k][h][e]));
+      m = rs_row16_max(m);
+      const int ex = rs_scale_exp(m);
+      const float sc = live ? rs_pow2(ex) : 0.f;
+      if (l16 == 0) rinv[rloc] = rs_pow2(254 - ex);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[e] = xv[p][k][0][e] * sc; v[4 + e] = xv[p][k][1][e] * sc; }
+        rs_u4 hi, lo;
+        rs_split8(v, hi, lo);
+        *reinterpret_cast<rs_u4*>(XH + rloc * PITCH + (l16 + 16 * k) * 16) = hi;
+        *reinterpret_cast<rs_u4*>(XL + rloc * PITCH + (l16 + 16 * k) * 16) = lo;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned char* arH = XH + mi * PITCH + 16 * kg;
+  const unsigned char* arL = XL + mi * PITCH + 16 * kg;
+  rs_f4 acc[MT][RS_NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int t = 0; t < RS_NT; t++) acc[mt][t] = rs_f4{0.f, 0.f, 0.f, 0.f};
+  // ---- half steps: three row tiles at a time (their hi and lo fragments one half step ahead), the weights one K step ahead
+  constexpr int HM = MT / 2;
+  rs_u4 ah[2][HM], al[2][HM];
+#pragma unroll
+  for (int u = 0; u < HM; u++) {
+    ah[0][u] = *reinterpret_cast<const rs_u4*>(arH + 16 * u * PITCH);
+    al[0][u] = *reinterpret_cast<const rs_u4*>(arL + 16 * u * PITCH);
+  }
+#pragma unroll
+  for (int h = 0; h < 2 * NK; h++) {
+    const int s = h >> 1, hf = h & 1;
+    if (h + 1 < 2 * NK) {
+      const int s1 = (h + 1) >> 1, hf1 = (h + 1) & 1;
+#pragma unroll
+      for (int u = 0; u < HM; u++) {
+        ah[(h + 1) & 1][u] = *reinterpret_cast<const rs_u4*>(arH + 16 * (HM * hf1 + u) * PITCH + 64 * s1);
+        al[(h + 1) & 1][u] = *reinterpret_cast<const rs_u4*>(arL + 16 * (HM * hf1 + u) * PITCH + 64 * s1);
+      }
+    }
+    if (hf == 0 && s + 1 < NK) load_b(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < HM; u++)                                       // small terms first; the same accumulator again 9 products later
+#pragma unroll
+      for (int t = 0; t < RS_NT; t++)
+        acc[HM * hf + u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rs_h8, bl[s & 1][t]), __builtin_bit_cast(rs_h8, ah[h & 1][u]), acc[HM * hf + u][t], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < HM; u++)
+#pragma unroll
+      for (int t = 0; t < RS_NT; t++)
+        acc[HM * hf + u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rs_h8, bh[s & 1][t]), __builtin_bit_cast(rs_h8, al[h & 1][u]), acc[HM * hf + u][t], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < HM; u++)
+#pragma unroll
+      for (int t = 0; t < RS_NT; t++)
+        acc[HM * hf + u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rs_h8, bh[s & 1][t]), __builtin_bit_cast(rs_h8, ah[h & 1][u]), acc[HM * hf + u][t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();                                                     // everybody is done with the row tiles: the result tile takes their place
+  const int colw = 48 * wv + 4 * kg;
+#pragma unroll
+  for (int t = 0; t < RS_NT; t++) {
+    const rs_f4 ci = *reinterpret_cast<const rs_f4*>(cvec + colw + 16 * t), bs = *reinterpret_cast<const rs_f4*>(cvec + D + colw + 16 * t);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      rs_f4 v = acc[mt][t] * rinv[16 * mt + mi] * ci + bs;
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = nb * D + colw + 16 * t + r >= relu_from ? fmaxf(v[r], 0.f) : v[r];
+      *reinterpret_cast<rs_f4*>(Y + (16 * mt + mi) * RF_YLD + colw + 16 * t) = v;
+    }
+  }
+  __syncthreads();
+  constexpr int YP = ROWS * (D / 4) / 512;                             // 16-byte pieces per thread: whole rows leave
+#pragma unroll
+  for (int i = 0; i < YP; i++) {
+    const int p = tid + 512 * i, row = p / (D / 4), c = p - row * (D / 4);
+    if (row0 + row < M) {
+      rs_f4 v = *reinterpret_cast<const rs_f4*>(Y + row * RF_YLD + 4 * c);
+      const int64_t o = (int64_t)(row0 + row) * ldy + nb * D + 4 * c;
+      if (gate) {                                                      // a ReLU's output: this gradient passes where it did not clip
+        const rs_f4 q = *reinterpret_cast<const rs_f4*>(gate + o);
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = q[r] > 0.f ? v[r] : 0.f;
+      }
+      if (residual) v += *reinterpret_cast<const rs_f4*>(residual + o);     // (may be y itself: read, then written, by this thread)
+      *reinterpret_cast<rs_f4*>(y + o) = v;
+    }
   }
 }
 
@@ -741,6 +1173,68 @@ int devo_upd_rs_mlp2_f16(const void* x, int64_t ldx, int x_rows, const int64_t* 
   hipLaunchKernelGGL(k_rs_mlp2_f16, dim3((unsigned)((M + RG_ROWS - 1) / RG_ROWS)), dim3(512), 2 * RG_ROWS * RG_PITCH, (hipStream_t)stream, (const __half*)x, ldx, x_rows,
                      gather, (const rs_u4*)w1img, (const __half*)b1, (const rs_u4*)w2img, (const __half*)b2, (const __half*)residual, (__half*)y, M);
   return check_launch("devo_upd_rs_mlp2_f16");
+}
+
+
+// The correlation branch and the first LayerNorm of the update operator as one launch, fp16 storage (enet.py:59-66, 82-83):
+//   c = l5(relu(LN3(l2(relu(l0(corr))))));  out = LN(net + inp + c).   corr [E, K0] with 768 < K0 <= 896 (DEVO: 882), rows 4-byte aligned; net / inp /
+//   out [E, 384] contiguous; weight images of devo_upd_rs_pack_weight_f16 ([384, K0], [384, 384], [384, 384]); vectors fp16, 16-byte aligned.
+int devo_upd_rs_corr_f16(const void* corr, int64_t ldc, int K0, const void* w0img, const void* b0, const void* w2img, const void* b2, const void* ln3_w,
+                         const void* ln3_b, float eps3, const void* w5img, const void* b5, const void* net, const void* inp, const void* ln_w, const void* ln_b,
+                         float eps, void* out, int E, void* stream) {
+  DEVO_REQUIRE(corr && w0img && b0 && w2img && b2 && ln3_w && ln3_b && w5img && b5 && net && inp && ln_w && ln_b && out && E > 0, "devo_upd_rs_corr_f16: null argument");
+  DEVO_REQUIRE(K0 > 768 && K0 <= 896 && ldc >= K0 && ldc % 2 == 0 && (reinterpret_cast<uintptr_t>(corr) & 3) == 0, "devo_upd_rs_corr_f16: 768 < K0 (%d) <= 896, rows 4-byte aligned", K0);
+  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(net) | reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ln_w) |
+                 reinterpret_cast<uintptr_t>(ln_b) | reinterpret_cast<uintptr_t>(w0img) | reinterpret_cast<uintptr_t>(w2img) | reinterpret_cast<uintptr_t>(w5img)) & 15) == 0,
+               "devo_upd_rs_corr_f16: 16-byte alignment");
+  DEVO_REQUIRE(((int64_t)(E - 1) * ldc + K0) * 2 < (1ll << 31), "devo_upd_rs_corr_f16: corr beyond 2 GB");
+  static bool attr_done = false;
+  if (!attr_done) {
+    DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_corr_f16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                 "devo_upd_rs_corr_f16: cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
+  RsCorr a;
+  a.corr = (const __half*)corr; a.ldc = ldc; a.w0 = (const rs_u4*)w0img; a.b0 = (const __half*)b0; a.w2 = (const rs_u4*)w2img; a.b2 = (const __half*)b2;
+  a.ln3_g = (const __half*)ln3_w; a.ln3_b = (const __half*)ln3_b; a.w5 = (const rs_u4*)w5img; a.b5 = (const __half*)b5; a.net = (const __half*)net;
+  a.inp = (const __half*)inp; a.ln_g = (const __half*)ln_w; a.ln_b = (const __half*)ln_b; a.out = (__half*)out; a.E = E; a.K0 = K0; a.eps3 = eps3; a.eps = eps;
+  hipLaunchKernelGGL(k_rs_corr_f16, dim3((unsigned)((E + RG_ROWS - 1) / RG_ROWS)), dim3(512), RC_LDS, (hipStream_t)stream, a);
+  return check_launch("devo_upd_rs_corr_f16");
+}
+
+
+// fp32 storage on the fp16 matrix cores with exact hi + lo splits, the row-resident structure: weight image of a [N, K] fp32 weight (element
+// (n, k) at W[n * s_n + k * s_k]: the forward's weight or its transpose view for dX = dY W), N a multiple of 384.
+size_t devo_upd_rs_split_weight_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || N % RS_BN) return 0;
+  return (size_t)N * ((K + 31) / 32 * 32) * 4 + (size_t)N * 4;
+}
+int devo_upd_rs_split_weight(const float* W, int64_t s_n, int64_t s_k, int N, int K, void* img, void* stream) {
+  DEVO_REQUIRE(W && img && N > 0 && K > 0 && N % RS_BN == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0, "devo_upd_rs_split_weight: N (%d) must be a multiple of 384", N);
+  float* inv = reinterpret_cast<float*>(static_cast<unsigned char*>(img) + (size_t)N * ((K + 31) / 32 * 32) * 4);
+  hipLaunchKernelGGL(k_rs_wscale, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, W, s_n, s_k, N, K, inv);
+  const long long total = (long long)N * ((K + 31) / 32) * 4;
+  hipLaunchKernelGGL(k_rs_wsplit, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, W, s_n, s_k, N, K, (rs_u4*)img);
+  return check_launch("devo_upd_rs_split_weight");
+}
+int devo_upd_rs_split_supported(int N, int K) { return N > 0 && N % RS_BN == 0 && K > 352 && K <= 384 && K % 4 == 0; }
+// y[M, N] = act(x W^T + bias) [gated] [+ residual], fp32 in and out (devo_upd_linear_split's contract; x, y, residual, gate rows 16-byte aligned)
+int devo_upd_rs_linear_split(const float* x, int64_t ldx, const void* wimg, const float* bias, const float* residual, const float* gate, float* y, int64_t ldy,
+                             int M, int N, int K, int relu_from, void* stream) {
+  DEVO_REQUIRE(x && wimg && y && M > 0, "devo_upd_rs_linear_split: null argument");
+  DEVO_REQUIRE(devo_upd_rs_split_supported(N, K), "devo_upd_rs_linear_split: N (%d) must be a multiple of 384 and K (%d) a multiple of 4 in (352, 384]", N, K);
+  DEVO_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
+                                                  reinterpret_cast<uintptr_t>(gate) | reinterpret_cast<uintptr_t>(wimg)) & 15) == 0,
+               "devo_upd_rs_linear_split: 16-byte alignment of the rows");
+  static bool attr_done = false;
+  if (!attr_done) {
+    DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_linear_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                 "devo_upd_rs_linear_split: cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_rs_linear_split, dim3((unsigned)((M + RG_ROWS - 1) / RG_ROWS), (unsigned)(N / RS_BN)), dim3(512), RF_LDS, (hipStream_t)stream, x, ldx,
+                     (const rs_u4*)wimg, bias, residual, gate, y, ldy, M, N, K, relu_from < 0 ? 0 : relu_from);
+  return check_launch("devo_upd_rs_linear_split");
 }
 
 }  // extern "C"

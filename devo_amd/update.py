@@ -172,6 +172,29 @@ def _mlp2_f16(x2, l1, l2, residual=None, gather=None):
     return y
 
 
+RS_SPLIT = __import__("os").environ.get("DEVO_UPD_RS_SPLIT", "1") != "0"         # 0: every fp32 Linear layer on csrc/linear.hip's kernel
+
+
+def _rs_split_image(w, transposed):
+    """The split B-operand image of csrc/gemm_rs.hip for `x @ w.T` (transposed=False) or `g @ w` (True), cached per version like _split_weight's."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), ("rs32", transposed))
+    hit = _wsplit_cache.pop(key, None)
+    if hit is not None:
+        _wsplit_cache[key] = hit
+        return hit[1]
+    for k in [k for k in _wsplit_cache if k[0] == key[0] and k[4] == key[4]]:
+        del _wsplit_cache[k]
+    while len(_wsplit_cache) >= WSPLIT_CACHE_ENTRIES:
+        del _wsplit_cache[next(iter(_wsplit_cache))]
+    out_f, in_f = w.shape
+    N, K = (in_f, out_f) if transposed else (out_f, in_f)
+    s_n, s_k = (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
+    img = torch.empty(int(L.lib().devo_upd_rs_split_weight_bytes(N, K)) // 4, dtype=torch.float32, device=w.device)
+    L.check(L.lib().devo_upd_rs_split_weight(L.ptr(w), s_n, s_k, N, K, L.ptr(img), L.stream()), "update.rs_split_weight")
+    _wsplit_cache[key] = (w, img)
+    return img
+
+
 def _linear_split(x2, w, b, transposed=False, relu=False, relu_from=None, residual=None, out=None, gate=None):
     """x2 [rows, K] fp32 -> act(x2 @ w.T + b) [+ residual] (or x2 @ w: transposed) on the fp16 matrix cores, fp32 in and out
     (csrc/linear.hip).  relu_from: the ReLU from this output column on (a gate | res pair in one launch); residual / out: [rows, N]
@@ -184,6 +207,11 @@ def _linear_split(x2, w, b, transposed=False, relu=False, relu_from=None, residu
         if t is not None and (t.stride(0) != y.stride(0) or t.stride(1) != 1 or t.dtype != torch.float32):
             raise RuntimeError(f"_linear_split: the {what} must share the output's row pitch")
     rf = (0 if relu else N) if relu_from is None else relu_from
+    if (RS_SPLIT and N == 384 and x2.shape[0] >= 8192 and L.lib().devo_upd_rs_split_supported(N, K) and x2.stride(0) % 4 == 0 and y.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0
+            and y.data_ptr() % 16 == 0 and (residual is None or residual.data_ptr() % 16 == 0) and (gate is None or gate.data_ptr() % 16 == 0)):
+        L.check(L.lib().devo_upd_rs_linear_split(L.ptr(x2), x2.stride(0), L.ptr(_rs_split_image(w.detach(), transposed)), L.ptr(b), L.ptr(residual),
+                                                 L.ptr(gate), L.ptr(y), y.stride(0), x2.shape[0], N, K, rf, L.stream()), "update.rs_linear_split")
+        return y
     L.check(L.lib().devo_upd_linear_split(L.ptr(x2), x2.stride(0), L.ptr(_split_weight(w.detach(), transposed)), L.ptr(b), L.ptr(residual),
                                           L.ptr(gate), L.ptr(y), y.stride(0), x2.shape[0], N, K, rf, L.stream()), "update.linear_split")
     return y
@@ -759,14 +787,25 @@ class Update(nn.Module):
         ix, jx, Gkk, Gij = self._tables(ii, jj, kk)
 
         # corr MLP (enet.py:59-66) and net = norm(net + inp + corr)  (:82-83), the two adds fused into the LayerNorm
-        if _mlp2_ok(c, self.corr[0], self.corr[2]):                   # Linear - ReLU - Linear: one launch, the intermediate stays in LDS
+        if (RS_CHAINS and RS_GEMM and dt == torch.float16 and dim == 384 and 768 < c.shape[1] <= 896 and c.stride(1) == 1 and c.stride(0) % 2 == 0
+                and c.data_ptr() % 4 == 0 and inp2.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
+            # the whole correlation branch and norm(net + inp + corr) in ONE launch, rows in LDS (csrc/gemm_rs.hip)
+            out = torch.empty_like(x)
+            L.check(lib.devo_upd_rs_corr_f16(L.ptr(c), c.stride(0), c.shape[1], L.ptr(_rs_image(self.corr[0].weight.detach())), L.ptr(self.corr[0].bias),
+                                             L.ptr(_rs_image(self.corr[2].weight.detach())), L.ptr(self.corr[2].bias), L.ptr(self.corr[3].weight),
+                                             L.ptr(self.corr[3].bias), float(self.corr[3].eps), L.ptr(_rs_image(self.corr[5].weight.detach())),
+                                             L.ptr(self.corr[5].bias), L.ptr(x), L.ptr(inp2), L.ptr(self.norm.weight), L.ptr(self.norm.bias),
+                                             float(self.norm.eps), L.ptr(out), E, L.stream()), "update.rs_corr_f16")
+            x, c = out, None
+        elif _mlp2_ok(c, self.corr[0], self.corr[2]):                 # Linear - ReLU - Linear: one launch, the intermediate stays in LDS
             c = _mlp2_f16(c, self.corr[0], self.corr[2])
         else:
             c = self._lin(c, self.corr[0].weight, self.corr[0].bias, relu=True)
             c = self._lin(c, self.corr[2].weight, self.corr[2].bias)
-        c = _ln(c, self.corr[3], relu=True)
-        c = self._lin(c, self.corr[5].weight, self.corr[5].bias)
-        x = _ln(x, self.norm, add1=inp2, add2=c)
+        if c is not None:
+            c = _ln(c, self.corr[3], relu=True)
+            c = self._lin(c, self.corr[5].weight, self.corr[5].bias)
+            x = _ln(x, self.norm, add1=inp2, add2=c)
 
         # neighbour mixing along the patch trajectory (:86-91)
         for mlp, idx in ((self.c1, ix), (self.c2, jx)):

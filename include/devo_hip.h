@@ -425,11 +425,26 @@ int devo_upd_rs_linear_f16(const void* x, int64_t ldx, const void* wimage, const
  * x, net_out [E, 384] contiguous, hy [groups, 384], delta / weight [E, 2]; wgr*: the [gate[0] | res[0]] weights concatenated to [768, 384], wr2_*:
  * res[2] [384, 384], both as devo_upd_rs_pack_weight_f16 images; bgr* [768], br2_* [384]; Wd / Ww [2, 384]; everything fp16, 16-byte aligned.
  * Every layer output and LayerNorm output is rounded to fp16 where the layer-by-layer path stores it. */
+/* fp32 storage in the row-resident structure (csrc/gemm_rs.hip): devo_upd_linear_split's contract and arithmetic (fp32 in and out, every value an
+ * exact fp16 hi + lo pair, power-of-two scales per row — the row's own largest magnitude — and per weight column), N a multiple of 384, K a multiple
+ * of 4 in (352, 384] (devo_upd_rs_split_supported); x, y, residual, gate rows 16-byte aligned.  Weight image: devo_upd_rs_split_weight
+ * (devo_upd_rs_split_weight_bytes(N, K) bytes, 16-byte aligned; element (n, k) at W[n * s_n + k * s_k]: the weight or its transpose view). */
+size_t devo_upd_rs_split_weight_bytes(int N, int K);
+int devo_upd_rs_split_supported(int N, int K);
+int devo_upd_rs_split_weight(const float* W, int64_t s_n, int64_t s_k, int N, int K, void* wimage, void* stream);
+int devo_upd_rs_linear_split(const float* x, int64_t ldx, const void* wimage, const float* bias, const float* residual, const float* gate, float* y, int64_t ldy,
+                             int M, int N, int K, int relu_from, void* stream);
 /* l2(relu(l1(x[gather]))) [+ residual] as one launch with the rows resident in LDS, both layers 384 -> 384 (enet.py:46-50, 86-91: c1 / c2 with
  * their neighbour gather and the sum).  x rows 16-byte aligned (ldx a multiple of 8), residual / y [M, 384] contiguous; gather i64 [M] (negative or
  * >= x_rows: a zero row) or null; weight images of devo_upd_rs_pack_weight_f16; biases 8-byte aligned. */
 int devo_upd_rs_mlp2_f16(const void* x, int64_t ldx, int x_rows, const int64_t* gather, const void* w1image, const void* b1, const void* w2image, const void* b2,
                          const void* residual, void* y, int M, void* stream);
+/* The correlation branch and the first LayerNorm of the update operator as ONE launch, fp16 storage (enet.py:59-66, 82-83):
+ *   c = l5(relu(LN3(l2(relu(l0(corr))))));  out = LN(net + inp + c).   corr [E, K0], 768 < K0 <= 896 (DEVO: 882), rows 4-byte aligned; net / inp / out
+ * [E, 384] contiguous; weight images of devo_upd_rs_pack_weight_f16 ([384, K0], [384, 384], [384, 384]); vectors fp16, 16-byte aligned. */
+int devo_upd_rs_corr_f16(const void* corr, int64_t ldc, int K0, const void* w0image, const void* b0, const void* w2image, const void* b2, const void* ln3_w,
+                         const void* ln3_b, float eps3, const void* w5image, const void* b5, const void* net, const void* inp, const void* ln_w, const void* ln_b,
+                         float eps, void* out, int E, void* stream);
 int devo_upd_rs_gru_f16(const void* x, const void* hy, const int* group_of, const void* ln0_w, const void* ln0_b, float eps0, const void* wgr1_img,
                         const void* bgr1, const void* wr2_1_img, const void* br2_1, const void* ln2_w, const void* ln2_b, float eps2, const void* wgr3_img,
                         const void* bgr3, const void* wr2_3_img, const void* br2_3, const void* Wd, const void* bd, const void* Ww, const void* bw,

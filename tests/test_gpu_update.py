@@ -614,3 +614,49 @@ def test_update_fp16_operator_row_resident_chain_keeps_its_outputs():
             outs.append((o.float(), d.float(), w.float()))
         for a, b in zip(*outs):
             assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 1e-2 * max(1.0, b.abs().max().item()), (n, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize("rows,n_out", [(18000, 384), (8200, 384)])
+def test_row_resident_split_linear_agrees_with_the_ring_kernel(rows, n_out):
+    """fp32 storage: csrc/gemm_rs.hip's kernel (rows scaled by their own largest magnitude, split once into two fp16 tiles in LDS, weights
+    into registers; DEVO_UPD_RS_SPLIT) and csrc/linear.hip's (running row scales, LDS-DMA rings) compute the same exact-split product:
+    both within 1e-6 of the float64 result relative to the magnitude of each output's terms — forward, ReLU from a column on, the in-place
+    residual, the ReLU-adjoint gate, and the dX form on the transposed weight."""
+    from devo_amd import update as UA
+    g = torch.Generator(device="cpu").manual_seed(rows + n_out)
+    x = torch.randn(rows, 384, generator=g) * torch.rand(rows, 1, generator=g) * 4
+    x[1::7] *= 1e-7
+    x[2::11] *= 3e5
+    x[3::13, 192:] *= 4096.0
+    x[6::19] = 0
+    x = x.to(DEV)
+    w = (torch.randn(n_out, 384, generator=g) / 384 ** 0.5)
+    w[1::5] *= 1e-6
+    w[2::9] *= 1e3
+    w = w.to(DEV)
+    b = torch.randn(n_out, generator=g).to(DEV)
+    res = torch.randn(rows, n_out, generator=g).to(DEV)
+    gate = torch.randn(rows, n_out, generator=g).to(DEV)
+    gy = torch.randn(rows, n_out, generator=g).to(DEV)
+    gy[1::3] *= 1e-8
+    assert UA.L.lib().devo_upd_rs_split_supported(n_out, 384)
+    scale = x.double().abs() @ w.double().abs().t() + b.double().abs()
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    ref_rf = ref.clone(); ref_rf[:, n_out // 2:].relu_()
+    for rs in (True, False):
+        UA.RS_SPLIT = rs
+        try:
+            y = UA._linear_split(x, w, b)
+            y_rf = UA._linear_split(x, w, b, relu_from=n_out // 2)
+            acc = res.clone()
+            y_res = UA._linear_split(x, w, b, residual=acc, out=acc)
+            y_gate = UA._linear_split(x, w, b, gate=gate)
+            dx = UA._linear_split(gy, w, None, transposed=True) if n_out == 384 else None
+        finally:
+            UA.RS_SPLIT = True
+        assert ((y.double() - ref).abs() / scale).max().item() < 1e-6, rs
+        assert ((y_rf.double() - ref_rf).abs() / scale).max().item() < 1e-6, rs
+        assert y_res.data_ptr() == acc.data_ptr() and ((y_res.double() - (ref + res.double())).abs() / (scale + res.double().abs())).max().item() < 1e-6, rs
+        assert ((y_gate.double() - ref * (gate > 0)).abs() / scale).max().item() < 1e-6, rs
+        if dx is not None:
+            assert ((dx.double() - gy.double() @ w.double()).abs() / (gy.double().abs() @ w.double().abs() + 1e-300)).max().item() < 1e-6, rs

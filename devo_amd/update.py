@@ -195,11 +195,12 @@ def _rs_split_image(w, transposed):
     return img
 
 
-def _linear_split(x2, w, b, transposed=False, relu=False, relu_from=None, residual=None, out=None, gate=None):
+def _linear_split(x2, w, b, transposed=False, relu=False, relu_from=None, residual=None, out=None, gate=None, rs=False):
     """x2 [rows, K] fp32 -> act(x2 @ w.T + b) [+ residual] (or x2 @ w: transposed) on the fp16 matrix cores, fp32 in and out
     (csrc/linear.hip).  relu_from: the ReLU from this output column on (a gate | res pair in one launch); residual / out: [rows, N]
     fp32 with one row pitch (out may be the residual: x.add_(linear(t)) in one launch); gate [rows, N]: a ReLU's output — the result is
-    zeroed where it clipped (the ReLU's adjoint in the epilogue of the dX product that produces its incoming gradient)."""
+    zeroed where it clipped (the ReLU's adjoint in the epilogue of the dX product that produces its incoming gradient).  rs: the inference
+    operator's calls — 384-wide layers over >= 8192 aligned rows take csrc/gemm_rs.hip's row-resident kernel."""
     N = w.shape[1] if transposed else w.shape[0]
     K = w.shape[0] if transposed else w.shape[1]
     y = out if out is not None else torch.empty(x2.shape[0], N, dtype=torch.float32, device=x2.device)
@@ -207,7 +208,9 @@ def _linear_split(x2, w, b, transposed=False, relu=False, relu_from=None, residu
         if t is not None and (t.stride(0) != y.stride(0) or t.stride(1) != 1 or t.dtype != torch.float32):
             raise RuntimeError(f"_linear_split: the {what} must share the output's row pitch")
     rf = (0 if relu else N) if relu_from is None else relu_from
-    if (RS_SPLIT and N == 384 and x2.shape[0] >= 8192 and L.lib().devo_upd_rs_split_supported(N, K) and x2.stride(0) % 4 == 0 and y.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0
+    # (measured: 27.4 against 29.9 us per 18 000 x 384 x 384 layer, the inference operator 0.716 against 0.745 ms; nothing for the training step,
+    #  whose layers run under autograd with their other shapes: those stay on linear.hip's kernel)
+    if (RS_SPLIT and N == 384 and x2.shape[0] >= 8192 and rs and L.lib().devo_upd_rs_split_supported(N, K) and x2.stride(0) % 4 == 0 and y.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0
             and y.data_ptr() % 16 == 0 and (residual is None or residual.data_ptr() % 16 == 0) and (gate is None or gate.data_ptr() % 16 == 0)):
         L.check(L.lib().devo_upd_rs_linear_split(L.ptr(x2), x2.stride(0), L.ptr(_rs_split_image(w.detach(), transposed)), L.ptr(b), L.ptr(residual),
                                                  L.ptr(gate), L.ptr(y), y.stride(0), x2.shape[0], N, K, rf, L.stream()), "update.rs_linear_split")
@@ -739,7 +742,7 @@ class Update(nn.Module):
         """act(x W^T + b) [+ residual, in place]: fp32 rows on the fp16 matrix cores with exact hi + lo splits (csrc/linear.hip, half the
         library's fp32 GEMM time), everything else as a library GEMM (hipBLASLt, bias and ReLU in its epilogue)"""
         if x.dtype == torch.float32 and w.dtype == torch.float32 and _split_ok(x, w.shape[0], w.shape[1]):
-            return _linear_split(x, w, b, relu=relu, relu_from=relu_from, residual=residual, out=residual)
+            return _linear_split(x, w, b, relu=relu, relu_from=relu_from, residual=residual, out=residual, rs=True)
         # fp16: measured at 21 600 rows against hipBLASLt — 384 outputs 14.4 / 15.6 us, 882 inputs 26.6 / 33.9, 768 outputs 25.3 / 20.1: the
         # wide layers stay with the library unless the launch carries a fusion the library has not (ReLU from a column on, the residual sum)
         if x.dtype == torch.float16 and w.dtype == torch.float16 and (b is None or b.dtype == torch.float16) and _f16_ok(x, w.shape[0], w.shape[1]) \

@@ -207,12 +207,22 @@ def test_dropin_fastba_reports_a_failed_factorisation():
     assert fastba.BA(*args(P, Q, d(s[4]))) == [] and fastba.last_status(DEV) == 0
     P, Q = d(s[0]).clone(), d(s[1]).clone()
     assert fastba.BA(*args(P, Q, bad)) == []                                    # fails silently for now ...
+    torch.cuda.synchronize()
     P2, Q2 = d(s[0]).clone(), d(s[1]).clone()
-    with pytest.raises(fastba.BAFailure):                                       # ... and is reported by the next call,
+    with pytest.raises(fastba.BAFailure):                                       # ... and is reported by the next call (the failed one has finished),
         fastba.BA(*args(P2, Q2, d(s[4])))
     Pr, Qr = d(s[0]).clone(), d(s[1]).clone()                                   # whose own (healthy) adjustment has still run
     assert fastba.BA(*args(Pr, Qr, d(s[4]))) == [] and fastba.last_status(DEV) == 0
     assert torch.equal(P2, Pr) and torch.equal(Q2, Qr) and not torch.equal(P2.cpu(), s[0])
+    # without waiting for the GPU in between: by the next call or by the one after it (a loop never waits for the adjustment it just enqueued)
+    assert fastba.BA(*args(d(s[0]).clone(), d(s[1]).clone(), bad)) == []
+    raised = 0
+    for _ in range(2):
+        try:
+            fastba.BA(*args(d(s[0]).clone(), d(s[1]).clone(), d(s[4])))
+        except fastba.BAFailure:
+            raised += 1
+    assert raised == 1 and fastba.last_status(DEV) == 0
     with pytest.raises(fastba.BAFailure):
         fastba.BA(*args(d(s[0]).clone(), d(s[1]).clone(), bad), check="now")
     fastba.BA(*args(d(s[0]).clone(), d(s[1]).clone(), bad), check="never")

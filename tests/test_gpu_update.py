@@ -646,12 +646,13 @@ def test_row_resident_split_linear_agrees_with_the_ring_kernel(rows, n_out):
     for rs in (True, False):
         UA.RS_SPLIT = rs
         try:
-            y = UA._linear_split(x, w, b)
-            y_rf = UA._linear_split(x, w, b, relu_from=n_out // 2)
-            acc = res.clone()
-            y_res = UA._linear_split(x, w, b, residual=acc, out=acc)
-            y_gate = UA._linear_split(x, w, b, gate=gate)
-            dx = UA._linear_split(gy, w, None, transposed=True) if n_out == 384 else None
+            with torch.no_grad():                                      # (the row-resident form serves the inference operator)
+                y = UA._linear_split(x, w, b, rs=True)
+                y_rf = UA._linear_split(x, w, b, relu_from=n_out // 2, rs=True)
+                acc = res.clone()
+                y_res = UA._linear_split(x, w, b, residual=acc, out=acc, rs=True)
+                y_gate = UA._linear_split(x, w, b, gate=gate, rs=True)
+                dx = UA._linear_split(gy, w, None, transposed=True, rs=True) if n_out == 384 else None
         finally:
             UA.RS_SPLIT = True
         assert ((y.double() - ref).abs() / scale).max().item() < 1e-6, rs

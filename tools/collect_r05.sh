@@ -22,7 +22,7 @@ run_pmc() {     # name, extra profile_corr args
 }
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/cfg2_trace" -o k -- python "$R/bench.py" --no-cpu-baseline --no-reference-api --steps 100 --warmup 10 > "$O/cfg2_bench_under_rocprof.json" 2> "$O/cfg2_trace.log"
 python "$R/tools/rocprof_summary.py" "$O/cfg2_trace" > "$O/cfg2_kernel_trace.txt" 2>&1
-cp "$O"/cfg2_trace/*/*kernel_stats.csv "$O/rocprofv3_kernel_stats.csv" 2>/dev/null
+find "$O/cfg2_trace" -name "*kernel_stats.csv" -exec cp {} "$O/rocprofv3_kernel_stats.csv" \; 2>/dev/null
 python "$R/tools/kernel_resources.py" "$O/cfg2_trace" --json "$O/ba_kernel_resources.json" > "$O/kernel_resources.txt" 2>&1
 rm -rf "$O/cfg2_trace"
 run_pmc cfg2_f32
@@ -37,6 +37,14 @@ DEVO_BINDING=ctypes timeout 600 python "$R/bench.py" --api reference > "$O/refer
 timeout 300 python "$R/tools/time_group.py" > "$O/group_form.txt" 2>&1
 timeout 300 python "$R/tools/bench_mlp2.py" > "$O/mlp2.txt" 2>&1
 timeout 300 python "$R/tools/bench_update.py" > "$O/update_op.txt" 2>&1
+DEVO_UPD_RS_CHAINS=0 timeout 300 python "$R/tools/bench_update.py" --dtype f16 --only hip 2>&1 | grep "update op" | sed "s/$/   (DEVO_UPD_RS_CHAINS=0)/" >> "$O/update_op.txt"
+DEVO_UPD_RS_CHAINS=0 DEVO_UPD_RS=0 timeout 300 python "$R/tools/bench_update.py" --dtype f16 --only hip 2>&1 | grep "update op" | sed "s/$/   (DEVO_UPD_RS_CHAINS=0 DEVO_UPD_RS=0: round 5 before the row-resident kernels)/" >> "$O/update_op.txt"
+DEVO_UPD_RS_SPLIT=0 timeout 300 python "$R/tools/bench_update.py" --dtype f32 --only hip 2>&1 | grep "update op" | sed "s/$/   (DEVO_UPD_RS_SPLIT=0)/" >> "$O/update_op.txt"
+timeout 300 python "$R/tools/bench_rs.py" > "$O/rs_linear.txt" 2>&1
+DEVO_RS_TRACE=1 timeout 200 python "$R/tools/bench_update.py" --dtype f16 --only hip --reps 2 2>&1 | grep "gru trace" | tail -1 >> "$O/rs_linear.txt"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/upd_trace" -o k -- python "$R/tools/bench_update.py" --dtype f16 --only hip --reps 20 > /dev/null 2> "$O/upd_trace.log"
+python "$R/tools/rocprof_summary.py" "$O/upd_trace" 2>&1 | head -14 > "$O/update_f16_kernels.txt"
+rm -rf "$O/upd_trace"
 timeout 300 python "$R/tools/bench_corr_backward.py" 2>&1 | grep "per backward" > "$O/corr_backward.txt"
 timeout 300 python "$R/tools/bench_ba_train.py" > "$O/ba_train_step.txt" 2>&1
 timeout 900 python "$R/bench.py" --mode train --steps 3 --warmup 1 > "$O/train_mode.json" 2> "$O/train_mode.err"

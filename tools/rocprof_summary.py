@@ -9,12 +9,28 @@ from collections import defaultdict
 
 def kernel_stats(path):
     agg = defaultdict(lambda: [0, 0.0])
+    rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
             name = r.get("Kernel_Name") or r.get("Name")
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             agg[name][0] += 1
             agg[name][1] += dur
+            rows.append((int(r["Start_Timestamp"]), name, dur))
+    # the lookup kernel by context: launches that follow a launch of the SAME kernel (bench.py's back-to-back graph: what roofline.us_per_launch
+    # times) against launches inside a step (behind the reprojection / the BA kernels)
+    rows.sort()
+    ctx = defaultdict(lambda: [0, 0.0, 0, 0.0])
+    for (_, prev, _), (_, name, dur) in zip(rows, rows[1:]):
+        if "corr_fwd" in name:
+            c = ctx[name]
+            if prev == name:
+                c[0] += 1; c[1] += dur
+            else:
+                c[2] += 1; c[3] += dur
+    for name, c in ctx.items():
+        if c[0] and c[2]:
+            print(f"# {name[:70]}: {c[0]} launches behind a launch of the same kernel avg {c[1] / c[0]:.2f} us | {c[2]} launches inside steps avg {c[3] / c[2]:.2f} us")
     tot = sum(v[1] for v in agg.values()) or 1.0
     rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
     print(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'%':>6}  kernel")

@@ -25,6 +25,7 @@ import os
 # by the library as well)
 MM_KERNEL = os.environ.get("DEVO_CORR_MM", "1") != "0" and os.environ.get("DEVO_CORR_MFMA", "1") != "0"
 PLAN_MIN_EDGES = 2048      # below this the lookup is launch-bound and a locality plan cannot pay for itself
+_last_plan = None           # (key, plan) of the last per-level call that made a plan
 NCHW_CONVERT_MIN_EDGES = 1024    # from here on a lookup into the reference's NCHW pyramid goes through a cached channel-blocked copy
 
 _blocked_cache = {}        # (ptr, version, shape, strides, dtype) -> (source tensor [kept alive], channel-blocked copy); LRU
@@ -252,7 +253,15 @@ def forward_into(out, fmap1, fmap2, coords, ii, jj, radius, estride, lstride, of
     # (fp32: the split-blocked copy only when the dense-product kernel will take the call; the exact kernels read the raw level)
     fmap2 = _fast_layout(fmap2, B * E, allow_split=f1t is not None and lstride > 0)
     if order is None and B * E >= PLAN_MIN_EDGES:
-        order = plan(coords, jj, fmap2.shape[1], fmap2.shape[3], float(coord_div), radius)
+        # DEVO calls corr once per pyramid level with the same index tensors (devo.py:215-216): the second call takes the plan the first one
+        # made (one plan serves every level; the result does not depend on the plan by one bit) — handed on once, to the call right behind
+        global _last_plan
+        key = (jj.data_ptr(), jj._version, B * E, fmap2.shape[1], int(radius), str(jj.device), L.stream().value)
+        if _last_plan is not None and _last_plan[0] == key:
+            order, _last_plan = _last_plan[1], None
+        else:
+            order = plan(coords, jj, fmap2.shape[1], fmap2.shape[3], float(coord_div), radius)
+            _last_plan = (key, order)
     H2, W2, strides, cblock, data, exps = _level_desc(fmap2, C)
     n2 = fmap2.shape[1]
     rc = L.lib().devo_corr_forward(L.ptr(fmap1), L.ptr(data), L.ptr(coords), L.ptr(ii), L.ptr(jj), L.ptr(out),

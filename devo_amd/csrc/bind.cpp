@@ -173,6 +173,9 @@ void corr_prep(const Tensor& fmap1, const Tensor& fmap2, const Tensor& coords, b
               "cuda_corr: expected fmap1 [B,Np,C,P,P], fmap2 [B,n,C,H,W], coords [B,E,2,P,P]");
 }
 
+struct LastPlan { const void* jj = nullptr; uint32_t ver = 0; int64_t BE = 0; int n = 0, radius = 0; void* stream = nullptr; Tensor plan; };
+thread_local LastPlan g_last_plan;                                    // the plan a per-level call made, for the call right behind it
+
 // corr forward writing element l of edge (b, e) at out[(b E + e) estride + l lstride + offset]
 void corr_forward_into(Tensor& out, const Tensor& fmap1_, const Tensor& fmap2, const Tensor& coords_, const Tensor& ii_, const Tensor& jj_, int radius,
                        int64_t estride, int64_t lstride, int64_t offset, const Tensor& order_, double coord_div) {
@@ -184,7 +187,22 @@ void corr_forward_into(Tensor& out, const Tensor& fmap1_, const Tensor& fmap2, c
   const Tensor f1t = patch_operand(fmap1);
   const Level lv = fast_level(fmap2, B * E, f1t.defined() && lstride > 0);
   Tensor order = order_;
-  if (!order.defined() && B * E >= PLAN_MIN_EDGES) order = make_plan(coords, jj, lv.n, lv.H, (float)coord_div, radius);
+  if (!order.defined() && B * E >= PLAN_MIN_EDGES) {
+    // DEVO calls corr once per pyramid level with the SAME index tensors (devo.py:215-216): the second call takes the plan the first one made
+    // — "one plan serves every level of a pyramid", and a plan only decides which edges run together: the result does not depend on it by
+    // one bit (tests/test_gpu_altcorr.py::test_lookup_results_do_not_depend_on_the_plan).  A plan is handed on ONCE, to the call right behind
+    // the one that made it, and only for the same jj tensor (storage, version, size), frame count and stream.
+    auto& last = g_last_plan;
+    void* st = stream_of(coords);
+    if (last.plan.defined() && last.jj == jj_.data_ptr() && last.ver == jj_._version() && last.BE == B * E && last.n == lv.n && last.radius == radius && last.stream == st &&
+        last.plan.device() == coords.device()) {
+      order = last.plan;
+      last.plan = Tensor();
+    } else {
+      order = make_plan(coords, jj, lv.n, lv.H, (float)coord_div, radius);
+      last.jj = jj_.data_ptr(); last.ver = jj_._version(); last.BE = B * E; last.n = lv.n; last.radius = radius; last.stream = st; last.plan = order;
+    }
+  }
   check(devo_corr_forward(fmap1.data_ptr(), lv.data.data_ptr(), coords.data_ptr<float>(), ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), out.data_ptr(), (int)B, (int)E,
                           (int)Np, lv.n, (int)C, (int)P, lv.H, lv.W, lv.strides, lv.cblock, estride, lstride, offset, radius, dtype_code(fmap1),
                           order.defined() ? order.data_ptr<int>() : nullptr, (float)coord_div, f1t.defined() ? f1t.data_ptr() : nullptr,
@@ -441,6 +459,7 @@ c10::optional<Tensor> corr_patch_operand(Tensor fmap1) {
 }
 void clear_caches() {
   g_levels.clear(); g_patches.clear(); g_cl.clear();
+  g_last_plan = LastPlan();
   std::lock_guard<std::mutex> g(g_ws_mu);
   g_ws = Tensor(); g_ws_key = WsKey{-1, -1, -1, -1};
 }

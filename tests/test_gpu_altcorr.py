@@ -748,3 +748,38 @@ def test_group_form_reads_level_1_from_lds_and_changes_nothing(dtype, H, W):
     r1 = A.corr_forward(q(f1), q(synth.pyramid_l1(f2d.float()).cpu()), cs / 4, ii[sel], jj[sel], 3)
     ref = torch.stack([r0, r1], -1).view(1, len(sel), -1)
     assert_rel(out["groups"][:, sel.to(DEV)].float(), ref, 1e-4 if dtype == torch.float32 else 2e-3, "group form vs oracle")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_lookup_results_do_not_depend_on_the_plan(dtype):
+    """A plan only decides which edges run together (and which of them the kernel meets first): with a plan made for OTHER coordinates — other
+    bins, another heavy list — the fused two-level lookup and the per-level launches return the same bits.  This is what lets the second
+    of DEVO's two per-level corr calls (devo.py:215-216) take the plan the first one made: two consecutive calls with the same index tensors
+    return what two calls with their own plans return."""
+    import bench
+    from devo_amd import synth
+    from devo_amd.backends import cuda_ba, cuda_corr
+    cfg = synth.workload("cfg2")
+    d, _ = bench.build_inputs(cfg, 1234, torch.device(DEV), dtype, "blk8")
+    coords = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
+    n, R, H = cfg["n"], cfg["R"], cfg["H"]
+    E = d["ii"].numel()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    other = coords + (torch.randn(1, E, 2, 1, 1, generator=g) * 40).to(DEV)
+    far = coords.clone(); far[:, ::3] += 5000.0
+    look = lambda order: cuda_corr.forward_pyramid(d["gmap"], d["pyramid"], coords, d["kk"], d["jj"], R, (1, 4), order=order)
+    own = cuda_corr.plan(coords, d["jj"], n, H, radius=R)
+    out = look(own)
+    for c2 in (other, far):
+        foreign = cuda_corr.plan(c2, d["jj"], n, H, radius=R)
+        assert not torch.equal(foreign[:E], own[:E]) and torch.equal(look(foreign), out)
+    # the reference's per-level calls: the second takes the first one's plan (both bindings)
+    ref = []
+    for fm, s in zip(d["pyramid"], (1.0, 4.0)):
+        cuda_corr._last_plan = None                                        # (every reference call makes its own plan)
+        ref.append(cuda_corr._forward_ctypes(d["gmap"], fm, coords / s, d["kk"], d["jj"], R)[0])
+    cuda_corr._last_plan = None
+    jj2 = d["jj"].clone()                                                  # (fresh index tensor: own plans above, a handed-on plan below)
+    for fwd in (cuda_corr.forward, cuda_corr._forward_ctypes):
+        got = [fwd(d["gmap"], fm, coords / s, d["kk"], jj2, R)[0] for fm, s in zip(d["pyramid"], (1.0, 4.0))]
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])

@@ -545,13 +545,14 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
             d["poses"], d["patches"], d["intr"], tgt, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws))),
     }
 
-    if not args.no_full_iteration and not secondary and args.workload == "cfg2" and world == 1:
+    if not args.no_full_iteration and args.workload == "cfg2" and world == 1:
         # A FULL update iteration as devo.py:305-340 runs it: reprojection, lookup, the Update operator (devo_amd.update, random weights)
         # on the lookup's output, target = centre + delta, 2 GN iterations with the predicted weights.  An extra field: the headline
         # metric excludes the Update MLP.  fp32 = every Linear layer on csrc/linear.hip's split-precision GEMM.
         from devo_amd.update import Update
         full = {}
-        for udt, key in ((torch.float32, "f32"), (torch.float16, "f16")):
+        # (the fp16-storage pass of the bench — DEVO's inference precision: fp16 pyramid, fp16 operator, fp32 BA — times the fp16 operator only)
+        for udt, key in (((torch.float16, "f16"),) if secondary else ((torch.float32, "f32"), (torch.float16, "f16"))):
             torch.manual_seed(1234 + rank)
             upd = Update(3).to(device).to(udt).eval()
             net_h = torch.zeros(1, E, 384, device=device, dtype=udt)
@@ -604,6 +605,8 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         out["f16"] = {"value": h["value"], "unit": "it/s", "ms_per_step": h["ms_per_step"],
                       "roofline": {k: h["roofline"].get(k) for k in ("achieved", "frac", "kernel", "alg_bytes_per_launch", "us_per_launch", "us_per_launch_back_to_back", "traffic")},
                       "note": "same step with fp16-storage feature pyramid + patch features (DEVO's inference precision), fp32 accumulation"}
+        if "full_update_iteration" in h:                         # the full iteration at DEVO's inference precision: fp16 pyramid AND fp16 operator
+            out["f16"]["full_update_iteration_ms"] = h["full_update_iteration"]["f16_ms"]
     if rank == 0 and world == 1 and not args.no_reference_api and args.workload == "cfg2":
         # what the reference's own (unfused, eager) call sequence costs on the same machine: bench.py --api reference alone prints it
         torch.cuda.empty_cache()

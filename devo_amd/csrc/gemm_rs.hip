@@ -503,9 +503,14 @@ __global__ __launch_bounds__(512) void k_rs_gru_f16(RsGru a) {
 // Linear - ReLU - Linear [+ residual] on gathered rows (enet.py:46-50, 86-91: net + c(mask * net[:, idx])), one launch: the gathered rows in
 // X, relu(h) in R, the residual rows (the workgroup's own, not gathered) into X while the second product runs, results through X so that
 // whole rows leave.  gather: i64 [M], negative = a zero row; null = the rows themselves.
-__global__ __launch_bounds__(512) void k_rs_mlp2_f16(const __half* __restrict__ x, int64_t ldx, int x_rows, const int64_t* __restrict__ gather,
+// MLP = false: no layers, the rows are x + hy[grp] (the expand-add behind a SoftAgg, enet.py:93: written back to y, which may be x).
+// FG: behind either, the 768-wide f | g layer of the NEXT SoftAgg (blocks.py:36-40) on the rows still in X: fg [M, 768], two more products.
+template <bool MLP, bool FG>
+__global__ __launch_bounds__(512) void k_rs_mlp2_f16(const __half* x, int64_t ldx, int x_rows, const int64_t* __restrict__ gather,
                                                       const rs_u4* __restrict__ w1, const __half* __restrict__ b1, const rs_u4* __restrict__ w2,
-                                                      const __half* __restrict__ b2, const __half* __restrict__ residual, __half* __restrict__ y, int M) {
+                                                      const __half* __restrict__ b2, const __half* residual, __half* y, int M,
+                                                      const __half* __restrict__ hy, const int* __restrict__ grp, const rs_u4* __restrict__ wfg,
+                                                      const __half* __restrict__ bfg, __half* __restrict__ fg) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char rs_lds[];
   constexpr int MT = RG_MT, NK = RG_NK, PITCH = RG_PITCH, ROWS = RG_ROWS, D = 384, PPR = D / 8, AP = ROWS * PPR / 512;
   static_assert(ROWS * PPR % 512 == 0, "pieces per thread");
@@ -517,17 +522,38 @@ __global__ __launch_bounds__(512) void k_rs_mlp2_f16(const __half* __restrict__ 
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<rs_u4*>(w1), 0, (unsigned)(D * D * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<rs_u4*>(w2), 0, (unsigned)(D * D * 2), 0x00020000);
   const unsigned wbase = (unsigned)((wv * NK) * RS_NT * 1024);
+  const __amdgpu_buffer_rsrc_t rsfg = __builtin_amdgcn_make_buffer_rsrc(const_cast<rs_u4*>(wfg), 0, FG ? (unsigned)(2 * D * D * 2) : 0u, 0x00020000);
+  auto wbfg = [&](int nb) { return (unsigned)(((nb * RS_NW + wv) * NK) * RS_NT * 1024); };
   // ---- the (gathered) rows -> X
   rs_u4 ap[AP];
 #pragma unroll
   for (int i = 0; i < AP; i++) {
     const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
-    int64_t src = row0 + row < M ? (gather ? gather[row0 + row] : (int64_t)(row0 + row)) : -1;
+    int64_t src = row0 + row < M ? ((MLP && gather) ? gather[row0 + row] : (int64_t)(row0 + row)) : -1;
     if (src >= x_rows) src = -1;
     ap[i] = src >= 0 ? *reinterpret_cast<const rs_u4*>(x + src * ldx + 8 * c) : rs_u4{0u, 0u, 0u, 0u};
   }
   rs_u4 b[RS_RB][RS_NT];
-  rs_prefetch<NK>(rs1, wbase, bvoff, b);
+  if (MLP) rs_prefetch<NK>(rs1, wbase, bvoff, b);
+  else if (FG) rs_prefetch<NK>(rsfg, wbfg(0), bvoff, b);
+  if (!MLP) {                                                          // x + hy[grp], rounded as the expand-add kernel stores it, and back to y
+    rs_u4 hp[AP];
+#pragma unroll
+    for (int i = 0; i < AP; i++) {
+      const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
+      hp[i] = row0 + row < M ? *reinterpret_cast<const rs_u4*>(hy + (int64_t)grp[row0 + row] * D + 8 * c) : rs_u4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < AP; i++) {
+      const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
+      const rs_h8 a8 = __builtin_bit_cast(rs_h8, ap[i]), h8 = __builtin_bit_cast(rs_h8, hp[i]);
+      rs_h8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = (_Float16)((float)a8[e] + (float)h8[e]);
+      ap[i] = __builtin_bit_cast(rs_u4, o);
+      if (row0 + row < M) *reinterpret_cast<rs_u4*>(y + (int64_t)(row0 + row) * D + 8 * c) = ap[i];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < AP; i++) {
     const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
@@ -540,19 +566,13 @@ __global__ __launch_bounds__(512) void k_rs_mlp2_f16(const __half* __restrict__ 
   unsigned char* eX = X + mi * PITCH + colw * 2;
   unsigned char* eR = R + mi * PITCH + colw * 2;
   rs_f4 acc[MT][RS_NT];
+  if (MLP) {
   // ---- R = relu(X W1 + b1)
 #pragma unroll
   for (int mt = 0; mt < MT; mt++)
 #pragma unroll
     for (int t = 0; t < RS_NT; t++) acc[mt][t] = rs_f4{0.f, 0.f, 0.f, 0.f};
   rs_kloop<MT, NK, PITCH, true>(arowX, rs1, wbase, bvoff, b, acc, rs2, wbase);
-  if (residual) {                                                      // the residual rows travel while relu(h) is written
-#pragma unroll
-    for (int i = 0; i < AP; i++) {
-      const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
-      ap[i] = row0 + row < M ? *reinterpret_cast<const rs_u4*>(residual + (int64_t)(row0 + row) * D + 8 * c) : rs_u4{0u, 0u, 0u, 0u};
-    }
-  }
 #pragma unroll
   for (int t = 0; t < RS_NT; t++) {
     const rs_f4 bs = rs_cvt4(*reinterpret_cast<const rs_h4*>(reinterpret_cast<const _Float16*>(b1) + colw + 16 * t));
@@ -565,11 +585,11 @@ __global__ __launch_bounds__(512) void k_rs_mlp2_f16(const __half* __restrict__ 
     }
   }
   __syncthreads();                                                     // R complete, everybody done with X
-  if (residual) {
+  if (residual) {                                                      // the residual rows (the workgroup's own) travel while the second product runs
 #pragma unroll
     for (int i = 0; i < AP; i++) {
       const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
-      *reinterpret_cast<rs_u4*>(X + row * PITCH + 16 * c) = ap[i];
+      ap[i] = row0 + row < M ? *reinterpret_cast<const rs_u4*>(residual + (int64_t)(row0 + row) * D + 8 * c) : rs_u4{0u, 0u, 0u, 0u};
     }
   }
   // ---- y = R W2 + b2 [+ residual]
@@ -577,8 +597,16 @@ __global__ __launch_bounds__(512) void k_rs_mlp2_f16(const __half* __restrict__ 
   for (int mt = 0; mt < MT; mt++)
 #pragma unroll
     for (int t = 0; t < RS_NT; t++) acc[mt][t] = rs_f4{0.f, 0.f, 0.f, 0.f};
-  rs_kloop<MT, NK, PITCH>(arowR, rs2, wbase, bvoff, b, acc);
-  if (residual) __syncthreads();                                       // the residual rows are in X
+  if (FG) rs_kloop<MT, NK, PITCH, true>(arowR, rs2, wbase, bvoff, b, acc, rsfg, wbfg(0));
+  else rs_kloop<MT, NK, PITCH>(arowR, rs2, wbase, bvoff, b, acc);
+  if (residual) {
+#pragma unroll
+    for (int i = 0; i < AP; i++) {
+      const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
+      *reinterpret_cast<rs_u4*>(X + row * PITCH + 16 * c) = ap[i];
+    }
+    __syncthreads();                                                   // the residual rows are in X
+  }
 #pragma unroll
   for (int t = 0; t < RS_NT; t++) {
     const rs_f4 bs = rs_cvt4(*reinterpret_cast<const rs_h4*>(reinterpret_cast<const _Float16*>(b2) + colw + 16 * t));
@@ -594,6 +622,32 @@ __global__ __launch_bounds__(512) void k_rs_mlp2_f16(const __half* __restrict__ 
   for (int i = 0; i < AP; i++) {
     const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
     if (row0 + row < M) *reinterpret_cast<rs_u4*>(y + (int64_t)(row0 + row) * D + 8 * c) = *reinterpret_cast<const rs_u4*>(X + row * PITCH + 16 * c);
+  }
+  }   // MLP
+  if (FG) {
+    // ---- fg = X [Wf | Wg]^T + [bf | bg]: two products on the rows in X, each through R so that whole row halves leave
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int t = 0; t < RS_NT; t++) acc[mt][t] = rs_f4{0.f, 0.f, 0.f, 0.f};
+      if (nb == 0) rs_kloop<MT, NK, PITCH, true>(arowX, rsfg, wbfg(0), bvoff, b, acc, rsfg, wbfg(1));
+      else rs_kloop<MT, NK, PITCH>(arowX, rsfg, wbfg(1), bvoff, b, acc);
+      if (nb == 1) __syncthreads();                                    // the first half has left R
+#pragma unroll
+      for (int t = 0; t < RS_NT; t++) {
+        const rs_f4 bs = rs_cvt4(*reinterpret_cast<const rs_h4*>(reinterpret_cast<const _Float16*>(bfg) + nb * D + colw + 16 * t));
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) *reinterpret_cast<rs_h4*>(eR + 16 * mt * PITCH + 32 * t) = rs_pack4(acc[mt][t] + bs);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < AP; i++) {
+        const int p = tid + 512 * i, row = p / PPR, c = p - row * PPR;
+        if (row0 + row < M) *reinterpret_cast<rs_u4*>(fg + (int64_t)(row0 + row) * (2 * D) + nb * D + 8 * c) = *reinterpret_cast<const rs_u4*>(R + row * PITCH + 16 * c);
+      }
+    }
   }
 }
 
@@ -1042,6 +1096,21 @@ static int rs_launch(const void* x, int64_t ldx, const void* wimg, const void* b
   return check_launch("devo_upd_rs_linear_f16");
 }
 
+template <bool MLP, bool FG>
+static int rs_chain_launch(const void* x, int64_t ldx, int x_rows, const int64_t* gather, const void* w1img, const void* b1, const void* w2img, const void* b2,
+                           const void* residual, void* y, int M, const void* hy, const int* grp, const void* wfg, const void* bfg, void* fg, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_mlp2_f16<MLP, FG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                 "devo_upd_rs_mlp2_f16: cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_rs_mlp2_f16<MLP, FG>), dim3((unsigned)((M + RG_ROWS - 1) / RG_ROWS)), dim3(512), 2 * RG_ROWS * RG_PITCH, stream, (const __half*)x, ldx, x_rows, gather,
+                     (const rs_u4*)w1img, (const __half*)b1, (const rs_u4*)w2img, (const __half*)b2, (const __half*)residual, (__half*)y, M, (const __half*)hy, grp,
+                     (const rs_u4*)wfg, (const __half*)bfg, (__half*)fg);
+  return check_launch("devo_upd_rs_mlp2_f16");
+}
+
 }  // namespace devo
 
 using namespace devo;
@@ -1157,24 +1226,32 @@ int devo_upd_rs_gru_f16(const void* x, const void* hy, const int* group_of, cons
 
 // l2(relu(l1(x[gather]))) [+ residual] as one launch, both layers 384 -> 384 (enet.py:46-50, 86-91); x rows 16-byte aligned (ldx a multiple
 // of 8), residual / y [M, 384] contiguous; gather i64 [M] (negative or >= x_rows: a zero row) or null.  Images: devo_upd_rs_pack_weight_f16.
-int devo_upd_rs_mlp2_f16(const void* x, int64_t ldx, int x_rows, const int64_t* gather, const void* w1img, const void* b1, const void* w2img, const void* b2,
-                         const void* residual, void* y, int M, void* stream) {
+// wfg / bfg / fg (all or none): the [768, 384] f | g layer of the SoftAgg that follows, on the result rows: fg [M, 768].
+int devo_upd_rs_mlp2_fg_f16(const void* x, int64_t ldx, int x_rows, const int64_t* gather, const void* w1img, const void* b1, const void* w2img, const void* b2,
+                            const void* residual, void* y, int M, const void* wfg, const void* bfg, void* fg, void* stream) {
   DEVO_REQUIRE(x && w1img && b1 && w2img && b2 && y && M > 0 && x_rows > 0, "devo_upd_rs_mlp2_f16: null argument");
   DEVO_REQUIRE(ldx >= 384 && ldx % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
-                                               reinterpret_cast<uintptr_t>(w1img) | reinterpret_cast<uintptr_t>(w2img)) & 15) == 0 &&
-                   ((reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2)) & 7) == 0,
+                                               reinterpret_cast<uintptr_t>(w1img) | reinterpret_cast<uintptr_t>(w2img) | reinterpret_cast<uintptr_t>(wfg) |
+                                               reinterpret_cast<uintptr_t>(fg)) & 15) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(bfg)) & 7) == 0,
                "devo_upd_rs_mlp2_f16: alignment");
-  static bool attr_done = false;
-  if (!attr_done) {
-    DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_mlp2_f16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
-                 "devo_upd_rs_mlp2_f16: cannot raise the dynamic LDS limit");
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(k_rs_mlp2_f16, dim3((unsigned)((M + RG_ROWS - 1) / RG_ROWS)), dim3(512), 2 * RG_ROWS * RG_PITCH, (hipStream_t)stream, (const __half*)x, ldx, x_rows,
-                     gather, (const rs_u4*)w1img, (const __half*)b1, (const rs_u4*)w2img, (const __half*)b2, (const __half*)residual, (__half*)y, M);
-  return check_launch("devo_upd_rs_mlp2_f16");
+  DEVO_REQUIRE((wfg != nullptr) == (bfg != nullptr) && (wfg != nullptr) == (fg != nullptr), "devo_upd_rs_mlp2_fg_f16: the f | g layer needs its image, its bias and its output");
+  DEVO_REQUIRE(y != x || !gather, "devo_upd_rs_mlp2_f16: gathered rows cannot be updated in place");
+  if (wfg) return rs_chain_launch<true, true>(x, ldx, x_rows, gather, w1img, b1, w2img, b2, residual, y, M, nullptr, nullptr, wfg, bfg, fg, (hipStream_t)stream);
+  return rs_chain_launch<true, false>(x, ldx, x_rows, gather, w1img, b1, w2img, b2, residual, y, M, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
-
+int devo_upd_rs_mlp2_f16(const void* x, int64_t ldx, int x_rows, const int64_t* gather, const void* w1img, const void* b1, const void* w2img, const void* b2,
+                         const void* residual, void* y, int M, void* stream) {
+  return devo_upd_rs_mlp2_fg_f16(x, ldx, x_rows, gather, w1img, b1, w2img, b2, residual, y, M, nullptr, nullptr, nullptr, stream);
+}
+// x += hy[group_of] (the expand-add behind a SoftAgg, enet.py:93; in place) and fg = x [Wf | Wg]^T + b of the SoftAgg that follows, one launch:
+// x [M, 384] contiguous, hy [groups, 384], fg [M, 768]; 16-byte alignment; the image of devo_upd_rs_pack_weight_f16 for the [768, 384] weight.
+int devo_upd_rs_expand_fg_f16(void* x, const void* hy, const int* group_of, const void* wfg, const void* bfg, void* fg, int M, void* stream) {
+  DEVO_REQUIRE(x && hy && group_of && wfg && bfg && fg && M > 0, "devo_upd_rs_expand_fg_f16: null argument");
+  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(hy) | reinterpret_cast<uintptr_t>(wfg) | reinterpret_cast<uintptr_t>(fg)) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(bfg) & 7) == 0, "devo_upd_rs_expand_fg_f16: alignment");
+  return rs_chain_launch<false, true>(x, 384, M, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, M, hy, group_of, wfg, bfg, fg, (hipStream_t)stream);
+}
 
 // The correlation branch and the first LayerNorm of the update operator as one launch, fp16 storage (enet.py:59-66, 82-83):
 //   c = l5(relu(LN3(l2(relu(l0(corr))))));  out = LN(net + inp + c).   corr [E, K0] with 768 < K0 <= 896 (DEVO: 882), rows 4-byte aligned; net / inp /

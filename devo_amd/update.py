@@ -153,7 +153,7 @@ def _mlp2_ok(x2, l1, l2):
             and ((x2.shape[0] - 1) * x2.stride(0) + x2.shape[1]) * 2 < (1 << 31))
 
 
-def _mlp2_f16(x2, l1, l2, residual=None, gather=None):
+def _mlp2_f16(x2, l1, l2, residual=None, gather=None, fg=None):
     """l2(relu(l1(x2[gather]))) [+ residual] as one launch (384 inputs: csrc/gemm_rs.hip, the rows resident in LDS; else csrc/mlp2.hip);
     gather i64 [rows] with negative entries = zero rows"""
     rows = x2.shape[0] if gather is None else gather.numel()
@@ -162,10 +162,15 @@ def _mlp2_f16(x2, l1, l2, residual=None, gather=None):
         raise RuntimeError("_mlp2_f16: the residual must be a contiguous fp16 [rows, 384] tensor")
     if RS_CHAINS and RS_GEMM and l1.weight.shape[1] == 384 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0 and l1.bias.data_ptr() % 8 == 0 \
             and l2.bias.data_ptr() % 8 == 0:
-        L.check(L.lib().devo_upd_rs_mlp2_f16(L.ptr(x2), x2.stride(0), x2.shape[0], L.ptr(gather), L.ptr(_rs_image(l1.weight.detach())), L.ptr(l1.bias),
-                                             L.ptr(_rs_image(l2.weight.detach())), L.ptr(l2.bias), L.ptr(residual), L.ptr(y), rows, L.stream()),
-                "update.rs_mlp2_f16")
-        return y
+        # fg = (W [768, 384], b [768]): the f | g layer of the SoftAgg that follows, on the result rows while they are in LDS -> (y, fg [rows, 768])
+        fg_out = torch.empty(rows, 768, dtype=torch.float16, device=x2.device) if fg is not None else None
+        L.check(L.lib().devo_upd_rs_mlp2_fg_f16(L.ptr(x2), x2.stride(0), x2.shape[0], L.ptr(gather), L.ptr(_rs_image(l1.weight.detach())), L.ptr(l1.bias),
+                                                L.ptr(_rs_image(l2.weight.detach())), L.ptr(l2.bias), L.ptr(residual), L.ptr(y), rows,
+                                                L.ptr(_rs_image(fg[0])) if fg is not None else None, L.ptr(fg[1]) if fg is not None else None, L.ptr(fg_out),
+                                                L.stream()), "update.rs_mlp2_f16")
+        return y if fg is None else (y, fg_out)
+    if fg is not None:
+        raise RuntimeError("_mlp2_f16: the f | g tail needs the row-resident kernel")
     L.check(L.lib().devo_upd_mlp2_f16(L.ptr(x2), x2.stride(0), x2.shape[0], L.ptr(gather), L.ptr(_mlp2_image(l1.weight.detach())), L.ptr(l1.bias),
                                       l1.weight.shape[1], L.ptr(_mlp2_image(l2.weight.detach())), L.ptr(l2.bias), L.ptr(residual), L.ptr(y), 384, rows,
                                       L.stream()), "update.mlp2_f16")
@@ -753,11 +758,12 @@ class Update(nn.Module):
             y[:, relu_from:].relu_()
         return y if residual is None else residual.add_(y)
 
-    def _soft_agg(self, name, agg, net, G):
+    def _soft_agg(self, name, agg, net, G, fg=None):
         """-> (h(y), group_of): the aggregated rows and the edge -> group map; the caller adds h(y)[group_of] to net
-        (devo_upd_expand_add, or fused into the LayerNorm that follows)."""
-        W, b = self._cat(name, agg.f, agg.g)
-        fg = self._lin(net, W, b)                                  # [E, 2 dim]: f | g
+        (devo_upd_expand_add, or fused into the LayerNorm that follows).  fg: the f | g layer's output when the kernel in front has made it."""
+        if fg is None:
+            W, b = self._cat(name, agg.f, agg.g)
+            fg = self._lin(net, W, b)                              # [E, 2 dim]: f | g
         E, dim = net.shape
         y = torch.empty(G.n_seg, dim, dtype=net.dtype, device=net.device)
         L.check(L.lib().devo_upd_softagg(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
@@ -811,8 +817,13 @@ class Update(nn.Module):
             x = _ln(x, self.norm, add1=inp2, add2=c)
 
         # neighbour mixing along the patch trajectory (:86-91)
+        tails = RS_CHAINS and RS_GEMM and dt == torch.float16 and dim == 384     # the SoftAgg's f | g layers ride on the kernels in front of them
+        fg_kk = None
         for mlp, idx in ((self.c1, ix), (self.c2, jx)):
             if _mlp2_ok(x, mlp[0], mlp[2]) and x.is_contiguous():
+                if tails and mlp is self.c2:
+                    x, fg_kk = _mlp2_f16(x, mlp[0], mlp[2], residual=x, gather=idx, fg=self._cat("agg_kk", self.agg_kk.f, self.agg_kk.g))
+                    continue
                 x = _mlp2_f16(x, mlp[0], mlp[2], residual=x, gather=idx)     # net + c(mask * net[:, idx]): gather, both layers and the sum in one launch
                 continue
             t = torch.empty_like(x)
@@ -822,9 +833,16 @@ class Update(nn.Module):
 
         # soft aggregation over the edges of a patch, then over the edges of a frame pair (:93-94); the second expand is
         # fused into the LayerNorm of the "gru" (:52-57), and each GatedResidual into the op that consumes it
-        hy, grp = self._soft_agg("agg_kk", self.agg_kk, x, Gkk)
-        L.check(lib.devo_upd_expand_add(L.ptr(x), L.ptr(hy), L.ptr(grp), E, dim, code, L.stream()), "update.expand_add")
-        hy, grp = self._soft_agg("agg_ij", self.agg_ij, x, Gij)
+        hy, grp = self._soft_agg("agg_kk", self.agg_kk, x, Gkk, fg=fg_kk)
+        if tails and x.is_contiguous() and hy.is_contiguous() and x.data_ptr() % 16 == 0:
+            Wij, bij = self._cat("agg_ij", self.agg_ij.f, self.agg_ij.g)     # x += hy[grp] and agg_ij's f | g layer on the same rows: one launch
+            fg_ij = torch.empty(E, 2 * dim, dtype=dt, device=x.device)
+            L.check(lib.devo_upd_rs_expand_fg_f16(L.ptr(x), L.ptr(hy), L.ptr(grp), L.ptr(_rs_image(Wij)), L.ptr(bij), L.ptr(fg_ij), E, L.stream()),
+                    "update.rs_expand_fg_f16")
+            hy, grp = self._soft_agg("agg_ij", self.agg_ij, x, Gij, fg=fg_ij)
+        else:
+            L.check(lib.devo_upd_expand_add(L.ptr(x), L.ptr(hy), L.ptr(grp), E, dim, code, L.stream()), "update.expand_add")
+            hy, grp = self._soft_agg("agg_ij", self.agg_ij, x, Gij)
         if RS_CHAINS and dt == torch.float16 and dim == 384 and RS_GEMM and x.is_contiguous() and hy.is_contiguous():
             # everything behind the aggregation is row-local: both LayerNorms, both GatedResiduals and the heads in ONE launch, rows in LDS
             net_out = torch.empty_like(x)

@@ -439,6 +439,13 @@ int devo_upd_rs_linear_split(const float* x, int64_t ldx, const void* wimage, co
  * >= x_rows: a zero row) or null; weight images of devo_upd_rs_pack_weight_f16; biases 8-byte aligned. */
 int devo_upd_rs_mlp2_f16(const void* x, int64_t ldx, int x_rows, const int64_t* gather, const void* w1image, const void* b1, const void* w2image, const void* b2,
                          const void* residual, void* y, int M, void* stream);
+/* ... and, on the result rows still in LDS, the 768-wide f | g layer of the SoftAgg that follows (blocks.py:36-40): fg [M, 768] = y [Wf | Wg]^T + [bf | bg]
+ * (wfg: the image of the concatenated [768, 384] weight; wfg / bfg / fg all or none). */
+int devo_upd_rs_mlp2_fg_f16(const void* x, int64_t ldx, int x_rows, const int64_t* gather, const void* w1image, const void* b1, const void* w2image, const void* b2,
+                            const void* residual, void* y, int M, const void* wfg_image, const void* bfg, void* fg, void* stream);
+/* x += hy[group_of] (the expand-add behind a SoftAgg, enet.py:93; in place, rounded to fp16 like devo_upd_expand_add) and the f | g layer of the
+ * SoftAgg that follows on the same rows, one launch: x [M, 384] contiguous, hy [groups, 384], fg [M, 768]. */
+int devo_upd_rs_expand_fg_f16(void* x, const void* hy, const int* group_of, const void* wfg_image, const void* bfg, void* fg, int M, void* stream);
 /* The correlation branch and the first LayerNorm of the update operator as ONE launch, fp16 storage (enet.py:59-66, 82-83):
  *   c = l5(relu(LN3(l2(relu(l0(corr))))));  out = LN(net + inp + c).   corr [E, K0], 768 < K0 <= 896 (DEVO: 882), rows 4-byte aligned; net / inp / out
  * [E, 384] contiguous; weight images of devo_upd_rs_pack_weight_f16 ([384, K0], [384, 384], [384, 384]); vectors fp16, 16-byte aligned. */

@@ -477,12 +477,16 @@ __global__ __launch_bounds__(512) void k_rs_gru_f16(RsGru a) {
       for (int k = 0; k < 3; k++) {
         const rs_u4 v = *reinterpret_cast<const rs_u4*>(X + rloc * PITCH + (l16 + 16 * k) * 16);
         if (live) *reinterpret_cast<rs_u4*>(a.net_out + (int64_t)row * D + (l16 + 16 * k) * 8) = v;
-        const rs_h8 nv = __builtin_bit_cast(rs_h8, v), a0 = __builtin_bit_cast(rs_h8, wd0[k]), a1 = __builtin_bit_cast(rs_h8, wd1[k]),
-                    b0 = __builtin_bit_cast(rs_h8, ww0[k]), b1 = __builtin_bit_cast(rs_h8, ww1[k]);
+        // relu on fp16 pairs, products of fp16 pairs summed in fp32 (v_dot2_f32_f16: exact products, like the fp32 multiply-adds they replace)
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const float u = fmaxf((float)nv[i], 0.f);
-          d0 += u * (float)a0[i]; d1 += u * (float)a1[i]; w0 += u * (float)b0[i]; w1 += u * (float)b1[i];
+        for (int i = 0; i < 4; i++) {
+          const unsigned vi = v[i], a0 = wd0[k][i], a1 = wd1[k][i], c0 = ww0[k][i], c1 = ww1[k][i];      // (scalars: a bit cast of a vector ELEMENT reads the vector's first one)
+          const h2 u = __builtin_elementwise_max(__builtin_bit_cast(h2, vi), h2{(_Float16)0.f, (_Float16)0.f});
+          d0 = __builtin_amdgcn_fdot2(u, __builtin_bit_cast(h2, a0), d0, false);
+          d1 = __builtin_amdgcn_fdot2(u, __builtin_bit_cast(h2, a1), d1, false);
+          w0 = __builtin_amdgcn_fdot2(u, __builtin_bit_cast(h2, c0), w0, false);
+          w1 = __builtin_amdgcn_fdot2(u, __builtin_bit_cast(h2, c1), w1, false);
         }
       }
       d0 = rs_row16_sum(d0); d1 = rs_row16_sum(d1); w0 = rs_row16_sum(w0); w1 = rs_row16_sum(w1);

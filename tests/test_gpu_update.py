@@ -661,3 +661,12 @@ def test_row_resident_split_linear_agrees_with_the_ring_kernel(rows, n_out):
         assert ((y_gate.double() - ref * (gate > 0)).abs() / scale).max().item() < 1e-6, rs
         if dx is not None:
             assert ((dx.double() - gy.double() @ w.double()).abs() / (gy.double().abs() @ w.double().abs() + 1e-300)).max().item() < 1e-6, rs
+
+
+def test_row_resident_kernels_are_deterministic():
+    """csrc/gemm_rs.hip has no atomics: the fp16 operator (three chain kernels + the f | g tails) and the fp32 row-resident layer give the
+    same bits on every repetition — a difference would be a missing barrier between the products of a chain (tools/check_rs_determinism.py)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_rs_determinism.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "differences: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

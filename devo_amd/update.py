@@ -177,6 +177,7 @@ def _mlp2_f16(x2, l1, l2, residual=None, gather=None, fg=None):
     return y
 
 
+AUTOCAST_F16 = __import__("os").environ.get("DEVO_UPD_AUTOCAST_F16", "1") != "0"    # 0: an fp32 operator called under autocast keeps its fp32 kernels
 RS_SPLIT = __import__("os").environ.get("DEVO_UPD_RS_SPLIT", "1") != "0"         # 0: every fp32 Linear layer on csrc/linear.hip's kernel
 
 
@@ -716,11 +717,24 @@ class Update(nn.Module):
         self._graph_key, self._graph, self._graph_refs = None, None, None
         self.invalidate_weights()
 
+    def _half_shadow(self):
+        """An fp16 copy of this operator (for calls under autocast), rebuilt when a parameter's version counter moves; `.data` edits: invalidate_weights()."""
+        key = sum(p._version for p in self.parameters()) + (self.norm.weight.data_ptr() << 8)
+        sh = self.__dict__.get("_shadow")
+        if sh is None or sh[0] != key:
+            m = Update(int(round((self.corr[0].in_features / 98.0) ** 0.5)), self.dim).to(self.norm.weight.device).half().eval()
+            with torch.no_grad():
+                m.load_state_dict({k: v.detach().half() for k, v in self.state_dict().items()})
+            sh = (key, m)
+            self.__dict__["_shadow"] = sh
+        return sh[1]
+
     def invalidate_weights(self):
         """Forget the cached operand images of this operator's weights (split / packed / concatenated).  They follow the parameters'
         version counters (copy_, load_state_dict, optimiser steps); an edit through `.data` is invisible to those — call this after one."""
         if getattr(self, "_wcat", None) is not None:
             self._wcat.clear()
+        self.__dict__.pop("_shadow", None)
         invalidate_weight_images()
 
     def train(self, mode=True):
@@ -791,6 +805,19 @@ class Update(nn.Module):
         if B != 1:
             raise RuntimeError("Update: batch size 1 (DEVO never batches the update operator)")
         dt = self.norm.weight.dtype
+        if (AUTOCAST_F16 and dt == torch.float32 and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16 and dim == 384):
+            # devo.py:311 calls the fp32 operator under autocast: its Linear layers then run in fp16 (fp32 accumulation), its LayerNorms in fp32.
+            # Here that call takes the fp16-storage operator on a half copy of the parameters (kept per parameter version) — the same
+            # precision class (every layer output rounded to fp16; the statistics, gates and sums in fp32), a third of the fp32 path's time —
+            # and returns what autocast returns: net in fp32, delta / weight in fp16.
+            with torch.autocast("cuda", enabled=False):
+                n16, (d16, w16, _) = self._half_shadow()(net.half(), inp.half(), corr.half(), flow, ii, jj, kk)
+            return n16.float(), (d16, w16, None)
+        if torch.is_autocast_enabled():
+            # (the kernels below take the parameters' dtype from first to last: no autocast inside — the library layers among them would
+            #  hand fp16 rows to fp32 kernels)
+            with torch.autocast("cuda", enabled=False):
+                return self.forward(net, inp, corr, flow, ii, jj, kk)
         x, inp2, c = net.reshape(E, dim).to(dt).contiguous(), inp.reshape(E, dim).to(dt).contiguous(), corr.reshape(E, -1).to(dt)
         lib, code = L.lib(), L.dtype_code(x)
         ix, jx, Gkk, Gij = self._tables(ii, jj, kk)

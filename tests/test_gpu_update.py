@@ -670,3 +670,41 @@ def test_row_resident_kernels_are_deterministic():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_rs_determinism.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "differences: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_fp32_operator_under_autocast_takes_the_fp16_kernels():
+    """devo.py:311 calls the fp32 update operator under torch.autocast (inference, no gradients): here that call runs the fp16-storage
+    operator on a half copy of the parameters — within the fp16 tolerance of the float64 oracle, with autocast's output dtypes (net fp32:
+    the reference's LayerNorm / residual stream; delta and weight fp16: Linear outputs), identical to calling a .half() copy directly, the
+    copy following the parameters' versions; DEVO_UPD_AUTOCAST_F16=0 keeps the fp32 kernels."""
+    from devo_amd import update as UA
+    m, sd, net, inp, corr, ii, jj, kk = _random_case()
+    ref = U.update(sd, net.double(), inp.double(), corr.double(), ii, jj, kk)
+    args = (net.to(DEV), inp.to(DEV), corr.to(DEV), None, ii.to(DEV), jj.to(DEV), kk.to(DEV))
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        with torch.autocast("cuda", dtype=torch.float16):
+            n, (d, w, _) = m(*args)
+        assert n.dtype == torch.float32 and d.dtype == torch.float16 and w.dtype == torch.float16
+        for got, want, name in ((n, ref[0], "net"), (d, ref[1], "delta"), (w, ref[2], "weight")):
+            assert_rel(got.float(), want, 2e-2, f"autocast {name}")
+        import copy
+        mh = copy.deepcopy(m).half()
+        n16, (d16, w16, _) = mh(args[0].half(), args[1].half(), args[2].half(), None, *args[4:])
+        assert torch.equal(n16.float(), n) and torch.equal(d16, d) and torch.equal(w16, w)
+        n32, _ = m(*args)                                                  # without autocast: the fp32 kernels
+        assert_rel(n32, ref[0], 1e-4, "fp32 net")
+        for p in m.parameters():                                           # an optimiser-style step: the half copy follows
+            p.mul_(0.5)
+        sd2 = {k: v.double() for k, v in m.state_dict().items()}
+        ref2 = U.update({k: v.cpu() for k, v in sd2.items()}, net.double(), inp.double(), corr.double(), ii, jj, kk)
+        with torch.autocast("cuda", dtype=torch.float16):
+            n2, _ = m(*args)
+        assert_rel(n2, ref2[0], 2e-2, "autocast net after a parameter update")
+        UA.AUTOCAST_F16 = False
+        try:
+            with torch.autocast("cuda", dtype=torch.float16):
+                n3, (d3, _, _) = m(*args)
+        finally:
+            UA.AUTOCAST_F16 = True
+        assert_rel(n3.float(), ref2[0], 1e-3, "fp32 kernels under autocast")

@@ -29,15 +29,19 @@ for dtype in [d for d in (torch.float32, torch.float16) if not a.dtype or a.dtyp
     def ref():
         with torch.no_grad():
             return m.forward_torch(net, inp, corr, ii, jj, kk)
-    for name, fn in [(n_, f_) for n_, f_ in (("hip", hip), ("torch", ref)) if not a.only or a.only == n_]:
+    def hip_autocast():                                             # devo.py:311: the fp32 operator called under autocast
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return m(net, inp, corr, None, ii, jj, kk)
+    for name, fn in [(n_, f_) for n_, f_ in (("hip", hip), ("torch", ref)) + ((("hip, autocast", hip_autocast),) if dtype == torch.float32 else ())
+                     if not a.only or a.only == n_.split(",")[0]]:
         for _ in range(3): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.reps): fn()
         e1.record(); torch.cuda.synchronize()
-        print(f"update op  E={E} dim=384 {str(dtype)[6:]:8s} {name:6s} {e0.elapsed_time(e1) / a.reps:8.3f} ms", flush=True)
-        if name == "hip":
+        print(f"update op  E={E} dim=384 {str(dtype)[6:]:8s} {name:14s} {e0.elapsed_time(e1) / a.reps:8.3f} ms", flush=True)
+        if name.startswith("hip"):
             # the same call replayed from a HIP graph (how a captured DEVO update step runs it): the eager figure above is bound by
             # the host's launch rate (~25 launches), this one by the device
             side = torch.cuda.Stream()

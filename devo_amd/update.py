@@ -805,7 +805,7 @@ class Update(nn.Module):
         if B != 1:
             raise RuntimeError("Update: batch size 1 (DEVO never batches the update operator)")
         dt = self.norm.weight.dtype
-        if (AUTOCAST_F16 and dt == torch.float32 and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16 and dim == 384):
+        if (AUTOCAST_F16 and dt == torch.float32 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16 and dim == 384):
             # devo.py:311 calls the fp32 operator under autocast: its Linear layers then run in fp16 (fp32 accumulation), its LayerNorms in fp32.
             # Here that call takes the fp16-storage operator on a half copy of the parameters (kept per parameter version) — the same
             # precision class (every layer output rounded to fp16; the statistics, gates and sums in fp32), a third of the fp32 path's time —

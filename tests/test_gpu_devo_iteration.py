@@ -1,0 +1,79 @@
+"""DEVO's update iteration as devo/devo.py:305-344 strings the calls together — reproject, two altcorr.corr calls + torch.stack, the update
+operator under torch.autocast with fp32 parameters and fp16 ring buffers (MIXED_PRECISION, devo.py:71-83,311), target = centre + delta,
+fastba.BA — with this package's modules in the reference's places, run for a few iterations and compared with the same sequence in fp32
+without autocast.  A smoke test of the drop-in as a WHOLE: every module sees the dtypes its neighbours hand it."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _run(mixed, iters=3, seed=7):
+    from devo_amd import synth, altcorr, fastba, projective_ops as pops
+    from devo_amd.lietorch import SE3
+    from devo_amd.update import Update
+    cfg = synth.workload("cfg1")
+    n, M, H, W, C = cfg["n"], cfg["M"], cfg["H"], cfg["W"], cfg["C"]
+    mem, dim = 16, 384
+    dt = torch.float16 if mixed else torch.float32
+    poses = synth.make_poses(n, seed).to(DEV)
+    patches, centres = synth.make_patches(n, M, H, W, seed=seed)
+    patches = patches.to(DEV)
+    intr = synth.make_intrinsics(n, H, W).to(DEV)
+    ii, jj, kk = [t.to(DEV) for t in synth.full_graph(n, M)]
+    fmap, gmap = synth.make_features(n, M, C, H, W, centres, seed=seed)
+    E = ii.numel()
+    fmap1_ = torch.zeros(1, mem, C, H, W, dtype=dt, device=DEV)                      # devo.py:80-81
+    fmap2_ = torch.zeros(1, mem, C, H // 4, W // 4, dtype=dt, device=DEV)
+    gmap_ = torch.zeros(mem, M, C, 3, 3, dtype=dt, device=DEV)                         # devo.py:77
+    imap_ = torch.zeros(mem, M, dim, dtype=dt, device=DEV)                             # devo.py:76
+    f0 = fmap.to(DEV)
+    fmap1_[:, :n] = f0.to(dt)
+    fmap2_[:, :n] = synth.pyramid_l1(f0).to(dt)
+    gmap_.view(1, mem * M, C, 3, 3)[:, :n * M] = gmap.to(DEV).to(dt)
+    g = torch.Generator().manual_seed(seed)
+    imap_.view(1, mem * M, dim)[:, :n * M] = (torch.randn(1, n * M, dim, generator=g) * 0.5).to(DEV).to(dt)
+    torch.manual_seed(seed)
+    update = Update(3).to(DEV).eval()                                                  # fp32 parameters, like the reference's network
+    with torch.no_grad():
+        for p in update.parameters():
+            if p.dim() == 2 and p.shape[0] == 2:
+                p.mul_(0.05)                                                           # small flow updates: the adjustment stays in its basin
+    net = torch.zeros(1, E, dim, dtype=dt, device=DEV)                                 # devo.py:93
+    lmbda = torch.as_tensor([1e-4], device=DEV)
+    pyramid, gm, im = (fmap1_, fmap2_), gmap_.view(1, mem * M, C, 3, 3), imap_.view(1, mem * M, dim)
+    with torch.no_grad():
+        for _ in range(iters):
+            coords = pops.transform(SE3(poses), patches, intr, ii, jj, kk)            # DEVO.reproject (devo.py:219-223)
+            coords = coords.permute(0, 1, 4, 2, 3).contiguous()
+            with torch.autocast("cuda", enabled=True, dtype=torch.float16) if mixed else torch.autocast("cuda", enabled=False):
+                ii1, jj1 = kk % (M * mem), jj % mem                                    # DEVO.corr (devo.py:210-217)
+                corr1 = altcorr.corr(gm, pyramid[0], coords / 1, ii1, jj1, 3)
+                corr2 = altcorr.corr(gm, pyramid[1], coords / 4, ii1, jj1, 3)
+                corr = torch.stack([corr1, corr2], -1).view(1, E, -1)
+                ctx = im[:, kk % (M * mem)]
+                net, (delta, weight, _) = update(net, ctx, corr, None, ii, jj, kk)
+            target = coords[..., 1, 1] + delta.float()                                 # devo.py:316-320
+            fastba.BA(poses, patches, intr, target, weight.float(), lmbda, ii, jj, kk, 1, n, 2)
+        assert fastba.last_status(DEV) == 0
+    return poses, patches, net, delta, weight
+
+
+def test_devo_update_iterations_under_autocast_match_the_fp32_sequence():
+    P16, Q16, n16, d16, w16 = _run(mixed=True)
+    P32, Q32, n32, d32, w32 = _run(mixed=False)
+    for t in (P16, Q16, n16, d16, w16):
+        assert bool(torch.isfinite(t).all())
+    assert n16.dtype == torch.float32 and d16.dtype == torch.float16 and n32.dtype == torch.float32      # what autocast returns (devo.py:311)
+    # fp16 features and an fp16 operator against fp32 ones, three iterations deep: the state stays close, the outputs within fp16 noise
+    assert (w16.float() - w32).abs().max().item() < 3e-2
+    assert (d16.float() - d32).abs().max().item() < 3e-2 * max(1.0, d32.abs().max().item())
+    assert (n16 - n32).abs().max().item() < 5e-2 * max(1.0, n32.abs().max().item())
+    assert (P16 - P32).abs().max().item() < 2e-2 and not torch.equal(P32, _poses0())
+    assert (Q16[:, :, 2] - Q32[:, :, 2]).abs().max().item() < 5e-2 * max(1.0, Q32[:, :, 2].abs().max().item())
+
+
+def _poses0():
+    from devo_amd import synth
+    return synth.make_poses(synth.workload("cfg1")["n"], 7).to(DEV)

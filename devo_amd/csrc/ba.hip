@@ -2157,9 +2157,10 @@ DEVO_HD void tf_pixel(const SE3<S>& G, S px, S py, S w, const float* ki, const f
   v = kj[1] * (d * X1.y) + kj[3];
 }
 // the Jacobian part (projective_ops.py:75-103): J[0..11] = Ji (2x6), J[12..23] = Jj, J[24..25] = Jz
-// `traw` = the translation as projective_ops.py:99 reads it, straight from Gij.data[..., :3]: autograd hands the gradient of that
-// read to the tau slots of Gij's gradient and nothing to the phi slots (although rotating Gij moves its translation) — the
-// adjoint kernel reproduces the reference's gradient, not the exact derivative, so it seeds `traw` with d tau only
+// `traw` = the translation as projective_ops.py:97 reads it: the last column of Gij.matrix(), i.e. through the group action — its
+// derivative is that of Gij's translation under the left perturbation (d tau + d phi x t).  (Until round 5 this kernel seeded it with
+// d tau only, as if the reference sliced Gij.data: two chained Gauss-Newton steps differed from the reference's gradients by a few per
+// cent; tests/test_gpu_train_iteration.py pins the composition now.)
 template <typename S>
 DEVO_HD void tf_jacobians(const SE3<S>& G, const V3<S>& traw, const V3<S>& Xc, S Hc, const float* kj, S* J) {
   const S X = Xc.x, Y = Xc.y, Z = Xc.z;
@@ -2246,8 +2247,7 @@ __global__ void k_transform_vjp(const float* __restrict__ poses, const float* __
 #pragma unroll 1
     for (int c = 0; c < 6; c++) {
       SE3<Dual> G = lift(G0);
-      V3<Dual> traw = G.t;
-      if (c < 3) { (c == 0 ? G.t.x : c == 1 ? G.t.y : G.t.z).d = 1.0f; traw = G.t; }
+      if (c < 3) { (c == 0 ? G.t.x : c == 1 ? G.t.y : G.t.z).d = 1.0f; }
       else {
         float ph[3] = {0.0f, 0.0f, 0.0f};
         ph[c - 3] = 1.0f;
@@ -2266,7 +2266,7 @@ __global__ void k_transform_vjp(const float* __restrict__ poses, const float* __
         s += pix_dot(G, i, Dual(pk[i]), Dual(pk[PPx + i]), Dual(pk[2 * PPx + i]), X1);
         if (i == ctr) Xc = X1;
       }
-      s += jac_dot(G, traw, Xc, Dual(pk[2 * PPx + ctr]));
+      s += jac_dot(G, G.t, Xc, Dual(pk[2 * PPx + ctr]));     // (the translation in Jz moves with tau AND with phi: it is read through Gij.matrix())
       gij[c] = s;
     }
     {

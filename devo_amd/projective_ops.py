@@ -107,7 +107,10 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
             torch.stack([o, fy * d * H, -fy * Y * d * d * H, -fy * d * Z - fy * Y * d * d * Y,
                          fy * Y * d * d * X, fy * d * X], -1)], dim=-2)
         Ji = -Gij[:, :, None].adjT(Jj)
-        t = Gij.data[..., :3]
+        # (the translation as the reference reads it, projective_ops.py:97: the last column of Gij.matrix(), i.e. through the group ACTION — its
+        #  gradient then reaches Gij in lietorch's tangent convention, rotation part included; slicing Gij.data instead has the same value and a
+        #  different (Euclidean, translation-only) gradient, which two chained BA steps expose: tests/test_gpu_train_iteration.py)
+        t = Gij.matrix()[..., :3, 3]
         Jz = torch.stack([fx * d * t[..., 0] - fx * X * d * d * t[..., 2],
                           fy * d * t[..., 1] - fy * Y * d * d * t[..., 2]], -1)[..., None]
         return x1, (Z > 0.2).float(), (Ji, Jj, Jz)

@@ -66,7 +66,8 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
             torch.stack([o, fy * d * H, -fy * Y * d * d * H, -fy * d * Z - fy * Y * d * d * Y,
                          fy * Y * d * d * X, fy * d * X], -1)], dim=-2)
         Ji = -Gij[:, :, None].adjT(Jj)                             # :96
-        t = Gij.data[..., :3]                                      # 4th column of Gij.matrix() is (t, 1)  (:98)
+        t = Gij.matrix()[..., :3, 3]                               # :97 reads the 4th column of Gij.matrix(): the same VALUE as Gij.data[..., :3], but the
+        #                                                            gradient reaches Gij through the group action (tangent convention, rotation part included)
         Jz = torch.stack([fx * d * t[..., 0] - fx * X * d * d * t[..., 2],
                           fy * d * t[..., 1] - fy * Y * d * d * t[..., 2]], -1)[..., None]
         return x1, (Z > 0.2).to(Z.dtype), (Ji, Jj, Jz)             # :100

@@ -113,3 +113,48 @@ def test_event_voxel_grid_and_std_match_reference(golden_dir):
         seq = torch.stack([ref, ref.flip(0) * 0.5])[None]
         assert torch.equal(EV.std(seq.clone(), True), torch.from_numpy(z[f"{tag}/std_seq"]))
         assert torch.equal(EV.std(seq.clone(), False), torch.from_numpy(z[f"{tag}/std_frame"]))
+
+
+def test_two_training_iterations_golden(golden_dir):
+    """tests/golden/train_iter_f64.npz (tools/gen_golden_train_iter.py: the REAL reference modules, two iterations of enet.py:313-361): the
+    oracle's transform / Update / BA composed the same way reproduce the values of both iterations and — through TWO CHAINED Gauss-Newton
+    steps per iteration — the gradients arriving at the update operator's outputs.  (This is the fixture that caught the oracle reading
+    Gij's translation from `.data` where projective_ops.py:97 reads it through Gij.matrix(): same value, another gradient.)"""
+    from oracle import update as OU
+    from devo_amd import synth
+    z = np.load(os.path.join(golden_dir, "train_iter_f64.npz"))
+    n, M, dim, E = (int(z[k]) for k in ("n", "M", "dim", "E"))
+    p = 3
+    g = torch.Generator().manual_seed(int(z["rng_seed"]))
+    ii0, _, _ = synth.full_graph(n, M)
+    torch.rand(len(ii0), generator=g)
+    torch.randn(1, n * M, dim, generator=g, dtype=torch.float64)
+    corrs = [torch.randn(1, E, 2 * 49 * p * p, generator=g, dtype=torch.float64) for _ in range(2)]
+    lw = [torch.randn(1, E, p, p, 2, generator=g, dtype=torch.float64) for _ in range(2)]
+    assert abs(float(sum(c.sum() for c in corrs) + sum(l.abs().sum() for l in lw)) - float(z["rng_checksum"])) < 1e-6
+    t = lambda k: torch.from_numpy(z[k])
+    sd = {k[3:]: t(k) for k in z.files if k.startswith("sd/")}
+    ii, jj, kk, intr, bounds = t("ii"), t("jj"), t("kk"), t("intrinsics"), z["bounds"].tolist()
+    imap = t("imap")
+    Gs, P = SE3(t("poses").clone()), t("patches").clone()
+    net = torch.zeros(1, E, dim, dtype=torch.float64)
+    loss, kept = torch.zeros((), dtype=torch.float64), []
+    for it in range(2):
+        Gs, P = SE3(Gs.data.detach()), P.detach()
+        coords = pops.transform(Gs, P, intr, ii, jj, kk)
+        net, delta, weight = OU.update(sd, net, imap[:, kk], corrs[it], ii, jj, kk)[:3]
+        delta, weight = delta.detach().requires_grad_(True), weight.detach().requires_grad_(True)     # (the heads' outputs as leaves: their gradients are compared)
+        kept.append((delta, weight))
+        target = coords[..., p // 2, p // 2, :] + delta
+        for _ in range(2):
+            Gs, P = pops.BA(Gs, P, intr, target, weight, 1e-4, ii, jj, kk, bounds, ep=10, fixedp=1)
+        cf = pops.transform(Gs, P, intr, ii, jj, kk)
+        loss = loss + (cf * lw[it]).sum() * 1e-2 + (Gs.log() ** 2).sum()
+        assert torch.allclose(Gs.data.detach(), t(f"poses_it{it + 1}"), rtol=1e-8, atol=1e-9)
+        assert torch.allclose(P.detach()[0, :, 2, 1, 1], t(f"disp_it{it + 1}"), rtol=1e-8, atol=1e-9)
+        assert torch.allclose(delta.detach(), t(f"delta_it{it + 1}"), rtol=1e-8, atol=1e-9)
+        assert torch.allclose(weight.detach(), t(f"weight_it{it + 1}"), rtol=1e-8, atol=1e-9)
+    loss.backward()
+    # iteration 2's head outputs receive their whole gradient through this chain (iteration 1's also through the hidden state: not compared here)
+    assert torch.allclose(kept[1][0].grad, t("gdelta_it2"), rtol=1e-6, atol=1e-10)
+    assert torch.allclose(kept[1][1].grad, t("gweight_it2"), rtol=1e-6, atol=1e-10)

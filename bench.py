@@ -237,7 +237,7 @@ def train_mode(args, device, rank, world, steps=None, warmup=None, iters=None, p
             "train": res}
 
 
-def reference_api_probe(args, device, seed=1234, iters=60, warm=8):
+def reference_api_probe(args, device, seed=1234, iters=60, warm=40):
     """What a caller pays who keeps the reference's OWN call sequence (devo/devo.py:210-223 DEVO.corr / DEVO.reproject, :308-344
     DEVO.update without the network): per update iteration
         coords = pops.transform(SE3(poses), patches, intrinsics, ii, jj, kk).permute(0, 1, 4, 2, 3).contiguous()
@@ -250,7 +250,8 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=8):
     Two forms of the reprojection: `package` = devo_amd.projective_ops (one fused kernel without autograd), `modules` = the reference's
     composition over the SE3 group ops (projective_ops.py:53-105 on top of the installed lietorch_backends: what an UNMODIFIED checkout
     gets after devo_amd.backends.install()).  Reported: iterations/s with the GPU as the clock, and the host time to enqueue one
-    iteration (no synchronisation inside)."""
+    iteration (no synchronisation inside).  40 untimed iterations first: the host runs ahead of the GPU and the caching allocator keeps growing
+    its pool (synchronous hipMallocs) until as many iterations' temporaries are in flight as the run-ahead allows."""
     from devo_amd import synth, altcorr, fastba, projective_ops as pops
     from devo_amd.lietorch import SE3
     cfg = synth.workload(args.workload)
@@ -294,12 +295,16 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=8):
                 for _ in range(warm):
                     update()
                 torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
-                for _ in range(iters):
-                    update()
-                t_host = time.perf_counter() - t0
-                torch.cuda.synchronize(device)
-                t_all = time.perf_counter() - t0
+                t_all, t_host = float("inf"), 0.0
+                for _ in range(3):                                                   # the best of three blocks: allocator growth (synchronous
+                    t0 = time.perf_counter()                                         # hipMallocs) can still fall into one
+                    for _ in range(iters):
+                        update()
+                    th = time.perf_counter() - t0
+                    torch.cuda.synchronize(device)
+                    ta = time.perf_counter() - t0
+                    if ta < t_all:
+                        t_all, t_host = ta, th
             out[f"{dtn}_{form}"] = {"it_per_s": round(iters / t_all, 1), "ms_per_iter": round(1e3 * t_all / iters, 4),
                                     "host_us_per_iter": round(1e6 * t_host / iters, 1)}
         del fmap1_, fmap2_, gmap_

@@ -64,7 +64,7 @@ def _run(golden_dir, dt):
     return z, up, imap, loss, seen
 
 
-@pytest.mark.parametrize("dt,tol,gtol", [(torch.float64, 1e-8, 1e-6), (torch.float32, 2e-4, 5e-3)])
+@pytest.mark.parametrize("dt,tol,gtol", [(torch.float64, 1e-8, 1e-6), (torch.float32, 2e-5, 3e-4)])      # (measured in fp32: values 1e-6, gradients 3e-5)
 def test_two_training_iterations_match_the_reference_modules(golden_dir, dt, tol, gtol):
     z, up, imap, loss, seen = _run(golden_dir, dt)
     for k, v in seen.items():                                            # values; then what arrives at the heads' outputs on the way back

@@ -178,14 +178,69 @@ def select_multi(scores, m, grid=True, k=4):
     return k * cx + o % k, k * cy + torch.div(o, k, rounding_mode="floor")
 
 
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """torchvision.ops.batched_nms restated (this image has no torchvision): greedy non-maximum suppression inside every category —
+    boxes [N, 4] (x1, y1, x2, y2), in decreasing order of score a box is kept unless a kept box of its category overlaps it with
+    IoU > threshold — and the kept indices in decreasing order of score.  Per category the greedy recursion
+    keep[j] = not any_{i < j} (keep[i] and IoU[i, j] > thr) is iterated as a whole-vector fixpoint (element j is final once all i < j
+    are: at most as many rounds as the longest suppression chain)."""
+    if boxes.numel() == 0:
+        return torch.empty(0, dtype=torch.long, device=boxes.device)
+    order = torch.argsort(scores, descending=True, stable=True)
+    b, c = boxes[order].float(), idxs[order]
+    keep = torch.ones(order.numel(), dtype=torch.bool, device=boxes.device)
+    for cat in torch.unique(c).tolist():
+        sel = (c == cat).nonzero()[:, 0]
+        bb = b[sel]
+        area = (bb[:, 2] - bb[:, 0]) * (bb[:, 3] - bb[:, 1])
+        iw = (torch.minimum(bb[:, None, 2], bb[None, :, 2]) - torch.maximum(bb[:, None, 0], bb[None, :, 0])).clamp(min=0)
+        ih = (torch.minimum(bb[:, None, 3], bb[None, :, 3]) - torch.maximum(bb[:, None, 1], bb[None, :, 1])).clamp(min=0)
+        inter = iw * ih
+        over = torch.triu(inter / (area[:, None] + area[None, :] - inter) > iou_threshold, diagonal=1)      # [i, j]: i (higher score) can suppress j
+        kc = torch.ones(sel.numel(), dtype=torch.bool, device=boxes.device)
+        while True:
+            new = ~(over & kc[:, None]).any(0)
+            if torch.equal(new, kc):
+                break
+            kc = new
+        keep[sel] = kc
+    return order[keep]
+
+
+def select_nms(scores, m, grid=True, k=4, radius=1.5, iou=0.4):
+    """pooled NMS sampling (selector.py:194-254): the best pixel of every k x k cell, a (2 radius)^2 box at it (clamped at the top / left
+    border like the reference's), non-maximum suppression among the boxes of a frame — of a frame's quadrant with `grid`, the quadrant
+    test written as the reference writes it (the box corner in PIXELS against half the POOLED size) — and the m best survivors per frame.
+    A frame with fewer than m survivors is an error (the reference fails in its torch.cat at that point, selector.py:250-252)."""
+    b, n, h, w = scores.shape
+    best, at = F.max_pool2d(scores, kernel_size=k, stride=k, return_indices=True)
+    h1, w1 = best.shape[-2:]
+    at = at.reshape(b * n, h1 * w1)
+    cx, cy = at % w, torch.div(at, w, rounding_mode="floor")
+    x1, y1 = (cx.float() - radius).clamp(min=0.0), (cy.float() - radius).clamp(min=0.0)
+    boxes = torch.stack([x1, y1, x1 + 2 * radius, y1 + 2 * radius], dim=-1).reshape(-1, 4)
+    frame = torch.arange(b * n, device=scores.device)[:, None].expand(-1, h1 * w1).reshape(-1)
+    cat = frame
+    if grid:
+        left, up = x1.reshape(-1) < w1 / 2, y1.reshape(-1) < h1 / 2
+        cat = 4 * frame + (~left).long() + 2 * (~up).long()
+    kept = batched_nms(boxes, best.reshape(-1), cat, iou)
+    fk, xk, yk = frame[kept], cx.reshape(-1)[kept], cy.reshape(-1)[kept]
+    xs, ys = [], []
+    for f in range(b * n):
+        sel = (fk == f).nonzero()[:m, 0]
+        if sel.numel() < m:
+            raise RuntimeError(f"patch selection 'nms': frame {f} keeps {sel.numel()} of the {m} patches asked for")
+        xs.append(xk[sel]); ys.append(yk[sel])
+    return torch.stack(xs), torch.stack(ys)
+
+
 def select(scores, m, mode, grid=True, k=4):
     """PatchSelector.__call__ (selector.py:256-287): the score map is zero-padded (centred) to whole cells — whole 2 x 2 grids of
     cells with `grid` —, the method runs on the padded map, the coordinates are shifted back and clamped into the map."""
     mode = mode.lower()
-    if mode not in ("3xrandom", "topk", "multi"):
-        # "nms" (selector.py:194-254) needs torchvision.ops.batched_nms, which this image does not have; DEVO's configurations
-        # use 3xrandom (training) and topk / multi (evaluation)
-        raise NotImplementedError(f"patch selection mode {mode!r} (have: 3xrandom, topk, multi)")
+    if mode not in ("3xrandom", "topk", "multi", "nms"):
+        raise NotImplementedError(f"patch selection mode {mode!r} (have: 3xrandom, topk, multi, nms)")
     h, w = scores.shape[-2:]
     f = 2 * k if grid else k
     ph, pw = (f - h % f) % f, (f - w % f) % f
@@ -194,7 +249,7 @@ def select(scores, m, mode, grid=True, k=4):
     if mode == "3xrandom":                       # candidates are drawn on the padded map like every other method (selector.py:92-105,266-286)
         x, y = select_three_x_random(padded, m)[:2]
     else:
-        x, y = (select_topk if mode == "topk" else select_multi)(padded, m, grid, k)
+        x, y = {"topk": select_topk, "multi": select_multi, "nms": select_nms}[mode](padded, m, grid, k)
     return (x - left).clamp(min=0, max=w - 1), (y - top).clamp(min=0, max=h - 1)
 
 

@@ -101,3 +101,42 @@ def test_patchifier_forward_matches_the_reference_module():
     from devo_amd import altcorr
     assert torch.equal(l0, altcorr.channel_blocked(fmap, 8))
     assert rel_err(l1, altcorr.channel_blocked(torch.nn.functional.avg_pool2d(fmap[0], 4, 4)[None], 8)) <= 1e-6
+
+
+def test_nms_selection_is_the_reference_selection(golden_dir):
+    """tests/golden/nms_select.npz (tools/gen_golden_nms.py: the reference's PatchSelector("nms"), its batched_nms a plain greedy loop): pooled
+    maxima, boxes, the reference's quadrant categories, per-frame top m — the same coordinates, with and without the grid."""
+    z = np.load(os.path.join(golden_dir, "nms_select.npz"))
+    for tag in ("a", "b"):
+        sm = torch.from_numpy(z[f"{tag}/scores"])
+        for grid in (True, False):
+            x, y = PF.select(sm, int(z[f"{tag}/m"]), "nms", grid)
+            assert torch.equal(x, torch.from_numpy(z[f"{tag}/x_grid{int(grid)}"])) and torch.equal(y, torch.from_numpy(z[f"{tag}/y_grid{int(grid)}"])), (tag, grid)
+    with pytest.raises(RuntimeError, match="keeps"):                      # more patches than survivors: a clear error (the reference fails in torch.cat)
+        PF.select(torch.from_numpy(z["a/scores"]), 400, "nms", False)
+
+
+def test_batched_nms_is_the_greedy_suppression():
+    """devo_amd.patchifier.batched_nms (whole-vector fixpoint per category) against the one-box-at-a-time greedy loop on random boxes with
+    ties, several categories and chains of suppression (a kept, b suppressed by a, c overlapping b only: kept)."""
+    g = torch.Generator().manual_seed(2)
+    for n, cats, thr in ((60, 1, 0.4), (200, 5, 0.3), (150, 3, 0.0)):
+        xy = torch.rand(n, 2, generator=g) * 20
+        wh = 2 + 3 * torch.rand(n, 2, generator=g)
+        boxes = torch.cat([xy, xy + wh], 1)
+        scores = torch.randint(0, 40, (n,), generator=g).float()               # ties
+        idxs = torch.randint(0, cats, (n,), generator=g)
+        order = sorted(range(n), key=lambda i: (-float(scores[i]), i))
+        kept = []
+        for i in order:
+            def iou(a, b):
+                iw = max(0.0, min(float(a[2]), float(b[2])) - max(float(a[0]), float(b[0])))
+                ih = max(0.0, min(float(a[3]), float(b[3])) - max(float(a[1]), float(b[1])))
+                inter = iw * ih
+                return inter / (float((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1])) - inter)
+            if all(int(idxs[i]) != int(idxs[j]) or iou(boxes[i], boxes[j]) <= thr for j in kept):
+                kept.append(i)
+        assert PF.batched_nms(boxes, scores, idxs, thr).tolist() == kept
+    chain = torch.tensor([[0.0, 0, 4, 4], [2.0, 0, 6, 4], [4.5, 0, 8.5, 4]])      # a-b overlap, b-c overlap, a-c do not
+    assert PF.batched_nms(chain, torch.tensor([3.0, 2.0, 1.0]), torch.zeros(3, dtype=torch.long), 0.2).tolist() == [0, 2]
+    assert PF.batched_nms(torch.empty(0, 4), torch.empty(0), torch.empty(0, dtype=torch.long), 0.4).numel() == 0

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "devo_corr_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i64, _i, _i, _vp, ctypes.c_size_t, _vp],
     "devo_corr_backward_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i],
     "devo_corr_backward_last_path": [],
+    "devo_corr_forward_last_path": [],
+    "devo_ba_last_path": [],
     "devo_patchify_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _c_i64p, _i, _i, _vp],
     "devo_patchify_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _c_i64p, _i, _i, _vp],
     "devo_ba_workspace_bytes": [_i, _i, _i],

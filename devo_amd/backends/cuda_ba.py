@@ -296,3 +296,9 @@ def transform_vjp(poses, patches, intrinsics, ii, jj, kk, g_coords, g_J, depth=F
                                     L.ptr(gp), L.ptr(gq), L.stream())
     L.check(rc, "cuda_ba.transform_vjp")
     return gp, gq
+
+
+def last_path():
+    """"accumulate:<register | lds | global> solve:<chain | lds | global>": the kernels the last forward() of this thread ran (devo_ba_last_path)."""
+    p = int(L.lib().devo_ba_last_path())
+    return None if p < 0 else f"accumulate:{('register', 'lds', 'global')[p & 3]} solve:{('chain', 'lds', 'global')[(p >> 2) & 3]}"

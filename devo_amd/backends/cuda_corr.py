@@ -353,6 +353,13 @@ _cl_cache = {}             # (ptr, version, shape, strides, dtype) -> (source te
 last_backward_path = None  # "product" | "segments" | "atomic": what the last backward() launched (devo_corr_backward_last_path)
 
 
+def last_forward_path():
+    """"dense-product" | "dense-product-groups" | "mfma4x4" | "staged" | "generic": the kernel the last forward lookup of this thread launched
+    (devo_corr_forward_last_path); the slow ones also announce themselves once on stderr."""
+    p = int(L.lib().devo_corr_forward_last_path())
+    return ("dense-product", "mfma4x4", "staged", "generic", "dense-product-groups")[p] if 0 <= p < 5 else None
+
+
 def _channels_last_copy(fmap2):
     """fmap2 [B, n, C, H, W] in any layout -> the same logical tensor with channels-last strides (a [B, n, H, W, C] buffer viewed
     as [B, n, C, H, W]), cached per version of the tensor with _fast_layout's key discipline: a training step calls backward() once

@@ -2493,6 +2493,7 @@ static void ba_deferred_schur(hipStream_t st, const float* patch_rec, const floa
   hipLaunchKernelGGL(k_ba_damp, dim3(blocks_for(36LL * N * N + 6 * N, 256, 256)), dim3(256), 0, st, S, N, ep, (const float*)part, nchunk, meta, max_seg);
 }
 
+static thread_local int g_ba_path = -1;                            // what the last devo_ba_forward of this thread launched
 static int ba_check_args(const char* who, int E, int Nbuf, int Np, int P, int t0, int t1) {
   const int N = t1 - t0;
   if (!(E >= 0 && Np > 0 && Nbuf > 0 && P > 0)) { set_error("%s: bad sizes", who); return DEVO_ERR_ARG; }
@@ -2611,6 +2612,16 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   const AccCfg cfg = acc_cfg(N);
   const size_t acc_lds_used = use_reg ? acc_reg_lds_bytes(N, cfg) : acc_lds;
   acc_fn_t acc_fn = use_reg ? acc_reg_fn(N, cfg) : big ? k_ba_accumulate_t<true> : k_ba_accumulate;
+  // what this call runs (devo_ba_last_path: accumulate kind | 4 * solve kind) and, once per process, a line when the system leaves the LDS
+  g_ba_path = (use_reg ? 0 : big ? 2 : 1) | ((big ? 2 : (6 * N <= 128 ? 0 : 1)) << 2);
+  if (big) {
+    static bool noted = false;
+    static const bool quiet = [] { const char* e = getenv("DEVO_LOG_FALLBACK"); return e && e[0] == '0'; }();
+    if (!quiet && !noted) {
+      noted = true;
+      fprintf(stderr, "[devo_hip] cuda_ba.forward: %d optimised poses > %d: the reduced system lives in global memory (slower kernels); cuda_ba.last_path() names the kernels of every call\n", N, BA_MAXN_LDS);
+    }
+  }
   solve_fn_t solve_fn = big ? k_ba_solve_t<true> : ba_solve_fn(N);
   if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds_used) != hipSuccess ||
@@ -2667,6 +2678,8 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   return check_launch("devo_ba_forward");
 }
 
+
+int devo_ba_last_path(void) { return g_ba_path; }
 
 // ---- one differentiable Gauss-Newton step from given edge terms (devo/ba.py:108-170) and its adjoint
 static int bt_common(const char* who, int E, int Np, int N, size_t ws_bytes, void* ws, BaLayout* L) {

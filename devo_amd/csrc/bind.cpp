@@ -520,6 +520,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   corr.def("patchify_forward", &patchify_forward, "correlation.cpp:61");
   corr.def("patchify_backward", &patchify_backward, "correlation.cpp:62");
   corr.def("last_backward_path", &corr_last_backward_path);
+  corr.def("last_forward_path", [] {
+    static const char* names[] = {"dense-product", "mfma4x4", "staged", "generic", "dense-product-groups"};
+    const int p = devo_corr_forward_last_path();
+    return std::string((p >= 0 && p < 5) ? names[p] : "");
+  }, "the kernel the last forward lookup of this thread launched (devo_corr_forward_last_path)");
   corr.def("_fast_layout", &corr_fast_layout, py::arg("fmap2"), py::arg("n_edges"), py::arg("allow_split") = true);
   corr.def("_patch_operand", &corr_patch_operand);
   corr.def("_cached_levels", []() { std::lock_guard<std::mutex> g(g_levels.mu); return (int64_t)g_levels.items.size(); });
@@ -529,6 +534,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
          py::arg("lmbda"), py::arg("ii"), py::arg("jj"), py::arg("kk"), py::arg("t0"), py::arg("t1"), py::arg("iterations"), py::arg("ws") = py::none(),
          py::arg("status") = py::none(), py::arg("prepared") = false);
   ba.def("neighbors", &ba_neighbors, "ba.cpp:154");
+  ba.def("last_path", [] {
+    static const char* acc[] = {"register", "lds", "global"};
+    static const char* sol[] = {"chain", "lds", "global"};
+    const int p = devo_ba_last_path();
+    return p < 0 ? std::string("") : std::string("accumulate:") + acc[p & 3] + " solve:" + sol[(p >> 2) & 3];
+  }, "the kernels the last forward() of this thread ran (devo_ba_last_path)");
   ba.def("reproject", &ba_reproject, "ba.cpp:155");
   ba.def("transform_coords", &ba_transform, py::arg("poses"), py::arg("patches"), py::arg("intrinsics"), py::arg("ii"), py::arg("jj"), py::arg("kk"),
          py::arg("layout_2pp") = false);

@@ -950,6 +950,22 @@ static bool staged_level(const void* fmap2, int C, int H2, int W2, const int64_t
 }
 
 // nlev = 1 or 2 levels in ONE launch of the staged kernel
+// What the last forward lookup of this thread launched (devo_corr_forward_last_path) and, once per process and kind, a line on stderr when a
+// call takes one of the slow kernels at a size where it matters (DEVO_LOG_FALLBACK=0 silences it): a layout / dtype / stride the fast kernels
+// do not read used to cost 2 - 24 x without a trace.
+enum { CORR_PATH_MM = 0, CORR_PATH_MFMA4 = 1, CORR_PATH_STAGED = 2, CORR_PATH_GENERIC = 3, CORR_PATH_MM_GROUPS = 4 };
+static thread_local int g_corr_fwd_path = -1;
+static void corr_note_path(int path, long long BE, const char* why) {
+  g_corr_fwd_path = path;
+  if (path != CORR_PATH_GENERIC && path != CORR_PATH_STAGED) return;
+  static bool noted[8] = {false, false, false, false, false, false, false, false};
+  static const bool quiet = [] { const char* e = getenv("DEVO_LOG_FALLBACK"); return e && e[0] == '0'; }();
+  if (quiet || noted[path] || BE < 2048) return;
+  noted[path] = true;
+  fprintf(stderr, "[devo_hip] cuda_corr.forward: %s kernel for %lld edges (%s); cuda_corr.last_forward_path() names the kernel of every call\n",
+          path == CORR_PATH_GENERIC ? "the generic (slowest, ~24x)" : "the staged tap-centric (~2x)", BE, why);
+}
+
 template <typename T>
 static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLevel& lv1, int nlev, const float* coords,
                          const int64_t* ii, const int64_t* jj, void* out, long long BE, int E, int Np, int n2, int C,
@@ -966,6 +982,7 @@ static int launch_staged(const void* fmap1, const CorrLevel& lv0, const CorrLeve
   const size_t nrec = (size_t)BE * nlev;
   if (do_trace) { (void)hipMalloc(&trace, nrec * 64); (void)hipMemset(trace, 0, nrec * 64); }
   const bool mfma = lv0.mfma_ok && (nlev == 1 || lv1.mfma_ok);
+  corr_note_path(mfma ? CORR_PATH_MFMA4 : CORR_PATH_STAGED, BE, "channel count / alignment outside the matrix-core kernels, or DEVO_CORR_MFMA=0");
   if (mfma) {                                                         // matrix-core kernel (corr_mfma.h)
     static const char* split_env = getenv("DEVO_CORR_SPLIT_LEVELS");  // debug: fused lookups as two sets of workgroups
     const bool both = nlev == 2 && !(split_env && split_env[0] == '1') && !do_trace;
@@ -1067,6 +1084,7 @@ static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel&
 #undef DEVO_MM_PICK
 #undef DEVO_MM_PICK_L
   if (!fn) { set_error("devo_corr_forward_pyramid2: C = %d not supported by the dense-product kernel", C); return DEVO_ERR_UNSUPPORTED; }
+  corr_note_path(CORR_PATH_MM, BE, "");
   // GROUP form (corr_mm.h, NW > 1): a group plan, radius 3, C = 128, level 1 = a quarter-resolution level in 8-channel blocks whose
   // region fits the LDS next to the waves' result areas
   static const bool group_off = []() { const char* e = getenv("DEVO_CORR_GROUP"); return e && e[0] == '0'; }();
@@ -1074,6 +1092,7 @@ static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel&
       lv0.W2 / 4 == lv1.W2 && lv0.coord_div == 1.0f && lv1.coord_div == 4.0f && BE / E == 1) {
     const long long nbins = corr_grp_nbins(1, n2, lv0.H2, lv0.W2, 4);
     if (nbins > 0) {
+      corr_note_path(CORR_PATH_MM_GROUPS, BE, "");
       constexpr int NWG = sizeof(MT) == 2 ? 16 : 8;                  // waves per workgroup: what the registers allow per CU (one workgroup per CU: the region)
       mm_fn_t gfn = corr_fwd_mm_kernel<MT, 3, 4, 2, 3, NWG>;
       // per wave: result area + geometry records (the kernel's WAVE_LDS)
@@ -1179,6 +1198,7 @@ static int launch_corr_fwd(const void* fmap1, const void* fmap2, const float* co
   }
   if (err) return err;
   if (cblock == DEVO_CBLOCK_SPLIT8) { set_error("devo_corr_forward: split-blocked fmap2 not readable (fp32, C %% 32 == 0, C <= 128, aligned strides)"); return DEVO_ERR_UNSUPPORTED; }
+  corr_note_path(CORR_PATH_GENERIC, BE, "fp64, a raw NCHW level or strides the blocked kernels do not read");
   dim3 grid((unsigned)BE), block(NT);
   hipLaunchKernelGGL(corr_fwd_generic_kernel<T>, grid, block, 0, st, (const T*)fmap1, (const T*)fmap2, coords, ii,
                      jj, (T*)out, E, Np, n2, C, H2, W2, f2s[0], f2s[1], f2s[2], f2s[3], f2s[4], oes, ols, ooff, R, coord_div);
@@ -1333,6 +1353,7 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
 
 static thread_local int g_corr_bwd_path = -1;                      // what the last devo_corr_backward of this thread launched
 int devo_corr_backward_last_path(void) { return g_corr_bwd_path; }
+int devo_corr_forward_last_path(void) { return g_corr_fwd_path; }
 
 size_t devo_corr_backward_workspace_bytes(int B, int E, int Np, int n2, int C, int radius, int channels_last) {
   if (B <= 0 || E <= 0 || Np <= 0 || n2 <= 0 || C <= 0 || radius < 0) return 0;

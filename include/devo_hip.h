@@ -152,6 +152,16 @@ int devo_pyramid_build(const void* fmap, void* l0, void* l1, int F, int C, int H
 #define DEVO_CORR_BWD_PRODUCT  2
 size_t devo_corr_backward_workspace_bytes(int B, int E, int Np, int n2, int C, int radius, int channels_last);
 int devo_corr_backward_last_path(void);
+/* Which kernel the last forward lookup of the calling thread launched: 0 the dense-product kernel (corr_mm.h: the default for blocked fp16 /
+ * split-blocked fp32 levels), 4 its group form (level 1 from LDS), 1 the exact-fp32 4x4 matrix-core kernel (raw fp32 blocked / channels-last
+ * levels, DEVO_CORR_MM=0), 2 the staged tap-centric kernel (other channel counts, DEVO_CORR_MFMA=0; ~2x), 3 the generic kernel (fp64, raw NCHW,
+ * unaligned strides; ~24x); -1 before the first call.  The first call of a process that takes kernel 2 or 3 with >= 2048 edges also says so on
+ * stderr (DEVO_LOG_FALLBACK=0: silent). */
+int devo_corr_forward_last_path(void);
+/* What the last devo_ba_forward* of the calling thread ran: accumulate kind (0 register-resident, N <= 16; 1 general in LDS; 2 global memory, N > 32)
+ * + 4 * solve kind (0 one-barrier chain, 6N <= 128; 1 general in LDS; 2 global memory); -1 before the first call.  The first call of a process
+ * whose system leaves the LDS says so on stderr (DEVO_LOG_FALLBACK=0: silent). */
+int devo_ba_last_path(void);
 int devo_corr_backward(const void* fmap1, const void* fmap2, const float* coords, const int64_t* ii,
                        const int64_t* jj, const float* grad, void* fmap1_grad, void* fmap2_grad, int B, int E,
                        int Np, int n2, int C, int P, int H2, int W2, const int64_t* f2s /* host, 5 */,

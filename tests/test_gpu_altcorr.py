@@ -783,3 +783,36 @@ def test_lookup_results_do_not_depend_on_the_plan(dtype):
     for fwd in (cuda_corr.forward, cuda_corr._forward_ctypes):
         got = [fwd(d["gmap"], fm, coords / s, d["kk"], jj2, R)[0] for fm, s in zip(d["pyramid"], (1.0, 4.0))]
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+
+def test_every_call_says_which_kernel_it_took():
+    """cuda_corr.last_forward_path() / cuda_ba.last_path(): the kernel family of the calling thread's last call (devo_corr_forward_last_path,
+    devo_ba_last_path) — a layout, dtype or size outside the fast kernels used to cost 2 - 24 x without a trace; the slow lookups also say
+    so once on stderr (DEVO_LOG_FALLBACK=0: silent)."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, torch
+        sys.path.insert(0, %r)
+        import bench
+        from devo_amd import synth
+        from devo_amd.backends import cuda_ba, cuda_corr
+        dev = torch.device("cuda", 0)
+        cfg = synth.workload("cfg2")
+        d, _ = bench.build_inputs(cfg, 1, dev, torch.float32, "blk8")
+        coords = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
+        n, R = cfg["n"], cfg["R"]
+        cuda_corr.forward_pyramid(d["gmap"], d["pyramid"], coords, d["kk"], d["jj"], R, (1, 4))
+        print("A", cuda_corr.last_forward_path())
+        nchw = d["pyramid"][0].permute(0, 1, 2, 5, 3, 4).reshape(1, n, 128, cfg["H"], cfg["W"]).contiguous()
+        cuda_corr._forward_ctypes(d["gmap"].double(), nchw.double(), coords, d["kk"], d["jj"], R)
+        print("B", cuda_corr.last_forward_path())
+        ws = cuda_ba.workspace(d["ii"].numel(), d["patches0"].shape[1], n - 1, dev)
+        tgt = coords[:, :, :, 1, 1].contiguous()
+        cuda_ba.forward(d["poses0"].clone(), d["patches0"].clone(), d["intr"], tgt, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
+        print("C", cuda_ba.last_path())
+    """ % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    out = dict(line.split(" ", 1) for line in r.stdout.strip().splitlines() if line[:2] in ("A ", "B ", "C "))
+    assert out.get("A") == "dense-product" and out.get("B") == "generic" and out.get("C") == "accumulate:register solve:chain", (r.stdout, r.stderr[-1500:])
+    assert r.stderr.count("the generic (slowest") == 1                     # announced once

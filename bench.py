@@ -419,13 +419,14 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         D.barrier_sync(device)
         return D.max_over_ranks(time.perf_counter() - t0, device)
 
-    # The contract's timed region: exactly --steps steps between barrier + synchronize pairs, MAX over ranks.  A region shorter
-    # than ~50 ms (20 steps are 6 ms: two graph launches) is dominated by launch / synchronisation jitter, so short regions are
-    # measured several times and the MEDIAN region is reported ("timed_regions" in the JSON line says how many).
+    # The contract's timed region: exactly --steps steps between barrier + synchronize pairs, MAX over ranks.  A short region
+    # (20 steps are 6 ms: two graph launches; the default 200 steps 45 ms) is dominated by launch / synchronisation jitter and, as the
+    # first thing a fresh box runs, by the clocks still ramping up (54.7 ms seen where every later region takes 45.2), so regions below
+    # 0.25 s are measured several times and the MEDIAN region is reported ("timed_regions" in the JSON line says how many).
     elapsed = timed_region()
     regions = 1
-    if elapsed < 0.05:
-        regions = int(min(25, max(3, 0.25 / max(elapsed, 1e-4)))) | 1
+    if elapsed < 0.25:
+        regions = int(min(25, max(5, 0.25 / max(elapsed, 1e-4)))) | 1
         if world > 1:
             regions = int(D.max_over_ranks(float(regions), device))          # the same count on every rank (collectives inside)
         samples = sorted([elapsed] + [timed_region() for _ in range(regions - 1)])

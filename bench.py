@@ -552,53 +552,56 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
     }
 
     if not args.no_full_iteration and args.workload == "cfg2" and world == 1:
-        # A FULL update iteration as devo.py:305-340 runs it: reprojection, lookup, the Update operator (devo_amd.update, random weights)
-        # on the lookup's output, target = centre + delta, 2 GN iterations with the predicted weights.  An extra field: the headline
-        # metric excludes the Update MLP.  fp32 = every Linear layer on csrc/linear.hip's split-precision GEMM.
-        from devo_amd.update import Update
-        full = {}
-        # (the fp16-storage pass of the bench — DEVO's inference precision: fp16 pyramid, fp16 operator, fp32 BA — times the fp16 operator only)
-        for udt, key in (((torch.float16, "f16"),) if secondary else ((torch.float32, "f32"), (torch.float16, "f16"))):
-            torch.manual_seed(1234 + rank)
-            upd = Update(3).to(device).to(udt).eval()
-            net_h = torch.zeros(1, E, 384, device=device, dtype=udt)
-            inp_h = torch.randn(1, E, 384, device=device, dtype=udt) * 0.1
+        try:                                                         # an extra field must not cost the line
+            # A FULL update iteration as devo.py:305-340 runs it: reprojection, lookup, the Update operator (devo_amd.update, random weights)
+            # on the lookup's output, target = centre + delta, 2 GN iterations with the predicted weights.  An extra field: the headline
+            # metric excludes the Update MLP.  fp32 = every Linear layer on csrc/linear.hip's split-precision GEMM.
+            from devo_amd.update import Update
+            full = {}
+            # (the fp16-storage pass of the bench — DEVO's inference precision: fp16 pyramid, fp16 operator, fp32 BA — times the fp16 operator only)
+            for udt, key in (((torch.float16, "f16"),) if secondary else ((torch.float32, "f32"), (torch.float16, "f16"))):
+                torch.manual_seed(1234 + rank)
+                upd = Update(3).to(device).to(udt).eval()
+                net_h = torch.zeros(1, E, 384, device=device, dtype=udt)
+                inp_h = torch.randn(1, E, 384, device=device, dtype=udt) * 0.1
 
-            def full_iteration():
-                torch.mul(d["state0"], 1.0, out=d["state"])
-                coords = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
-                lookup(coords)
-                with torch.no_grad():
-                    _, (delta, weight, _) = upd(net_h, inp_h, corr_out.to(udt), None, d["ii"], d["jj"], d["kk"])
-                target = coords[:, :, :, 1, 1] + delta.float()
-                cuda_ba.forward(d["poses"], d["patches"], d["intr"], target, weight.float(), d["lmbda"],
-                                d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
-            for _ in range(3):
-                full_iteration()
-            torch.cuda.synchronize()
-            run_full, how = full_iteration, "eager launches"
-            if not args.no_graph:                                      # the Update operator's group tables are cached by now: no host sync left
-                g2 = torch.cuda.CUDAGraph()
-                s2 = torch.cuda.Stream()
-                s2.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s2):
-                    with torch.cuda.graph(g2, stream=s2):
-                        full_iteration()
-                torch.cuda.current_stream().wait_stream(s2)
-                run_full, how = g2.replay, "HIP graph"
-            for _ in range(3):
-                run_full()
-            torch.cuda.synchronize()
-            ev0.record()
-            for _ in range(50):
-                run_full()
-            ev1.record()
-            torch.cuda.synchronize()
-            full[key + "_ms"] = round(ev0.elapsed_time(ev1) / 50, 4)
-            del upd
-        full["note"] = (f"reproject + 2-level lookup ({dtn} pyramid) + Update operator (fp32 / fp16 weights and state, random weights) + "
-                        f"2 GN iterations on its outputs, {how}")
-        out["full_update_iteration"] = full
+                def full_iteration():
+                    torch.mul(d["state0"], 1.0, out=d["state"])
+                    coords = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
+                    lookup(coords)
+                    with torch.no_grad():
+                        _, (delta, weight, _) = upd(net_h, inp_h, corr_out.to(udt), None, d["ii"], d["jj"], d["kk"])
+                    target = coords[:, :, :, 1, 1] + delta.float()
+                    cuda_ba.forward(d["poses"], d["patches"], d["intr"], target, weight.float(), d["lmbda"],
+                                    d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
+                for _ in range(3):
+                    full_iteration()
+                torch.cuda.synchronize()
+                run_full, how = full_iteration, "eager launches"
+                if not args.no_graph:                                      # the Update operator's group tables are cached by now: no host sync left
+                    g2 = torch.cuda.CUDAGraph()
+                    s2 = torch.cuda.Stream()
+                    s2.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s2):
+                        with torch.cuda.graph(g2, stream=s2):
+                            full_iteration()
+                    torch.cuda.current_stream().wait_stream(s2)
+                    run_full, how = g2.replay, "HIP graph"
+                for _ in range(3):
+                    run_full()
+                torch.cuda.synchronize()
+                ev0.record()
+                for _ in range(50):
+                    run_full()
+                ev1.record()
+                torch.cuda.synchronize()
+                full[key + "_ms"] = round(ev0.elapsed_time(ev1) / 50, 4)
+                del upd
+            full["note"] = (f"reproject + 2-level lookup ({dtn} pyramid) + Update operator (fp32 / fp16 weights and state, random weights) + "
+                            f"2 GN iterations on its outputs, {how}")
+            out["full_update_iteration"] = full
+        except Exception as ex:                                      # noqa: BLE001
+            out["full_update_iteration"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     if secondary:
         return out

@@ -140,3 +140,32 @@ def test_batched_nms_is_the_greedy_suppression():
     chain = torch.tensor([[0.0, 0, 4, 4], [2.0, 0, 6, 4], [4.5, 0, 8.5, 4]])      # a-b overlap, b-c overlap, a-c do not
     assert PF.batched_nms(chain, torch.tensor([3.0, 2.0, 1.0]), torch.zeros(3, dtype=torch.long), 0.2).tolist() == [0, 2]
     assert PF.batched_nms(torch.empty(0, 4), torch.empty(0), torch.empty(0, dtype=torch.long), 0.4).numel() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-6), (torch.float32, 2e-3)])
+def test_patchifier_gradients_match_the_reference_module(golden_dir, dt, tol):
+    """tests/golden/patchifier_grad_f64.npz (tools/gen_golden_patchifier_grad.py: the reference's Patchifier in training mode on CPU in fp64, a
+    loss on fmap, the gathered gmap / imap patches and the winners' scores): the same loss and the same gradients in every parameter of
+    both encoders and the scorer — the autograd path through the HIP patch gathers, the channels-last MIOpen encoders and the score lookup."""
+    z = np.load(os.path.join(golden_dir, "patchifier_grad_f64.npz"))
+    dev = "cuda"
+    pf = PF.Patchifier(3, 24, 16, 8, "scorer").to(dev).to(dt).train()
+    pf.load_state_dict({k[3:]: torch.from_numpy(z[k]).to(dt) for k in z.files if k.startswith("sd/")})
+    images = torch.from_numpy(z["images"]).to(dev).to(dt)
+    cand = (torch.from_numpy(z["cand_x"]).to(dev), torch.from_numpy(z["cand_y"]).to(dev))
+    fmap, gmap, imap, patches, index, scores = pf(images, patches_per_image=6, candidates=cand)
+    for name, got in dict(fmap=fmap, gmap=gmap, imap=imap, patches=patches, scores=scores).items():
+        assert rel_err(got.detach().cpu().float(), torch.from_numpy(z["out/" + name]).float().reshape(got.shape)) <= 2e-4, name
+    w = {k: torch.from_numpy(z["w/" + k]).to(dev).to(dt) for k in ("fmap", "gmap", "imap", "scores")}
+    loss = (fmap * w["fmap"]).sum() * 1e-2 + (gmap.to(dt) * w["gmap"]).sum() + (imap.to(dt) * w["imap"]).sum() + (scores * w["scores"]).sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(z["loss"])) <= tol * abs(float(z["loss"]))
+    grads = {k: v.grad for k, v in pf.named_parameters() if v.grad is not None}
+    names = [str(s) for s in z["grad_names"]]
+    assert sorted(grads) == names
+    norms = torch.tensor([float(grads[k].double().norm()) for k in names], dtype=torch.float64)
+    assert rel_err(norms, torch.from_numpy(z["grad_norms"])) <= tol, "gradient norms"
+    for k in z.files:
+        if k.startswith("grad/"):
+            assert rel_err(grads[k[5:]].double().cpu(), torch.from_numpy(z[k])) <= tol, k

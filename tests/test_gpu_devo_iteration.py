@@ -77,3 +77,25 @@ def test_devo_update_iterations_under_autocast_match_the_fp32_sequence():
 def _poses0():
     from devo_amd import synth
     return synth.make_poses(synth.workload("cfg1")["n"], 7).to(DEV)
+
+
+def test_patchifier_under_autocast_as_devo_calls_it():
+    """devo.py:250: `with autocast(enabled=MIXED_PRECISION): fmap, gmap, imap, patches, _, clr = self.network.patchify(...)` — the encoders then
+    run in fp16; the gathers, the patch grid and the colours must cope with fp16 feature maps and stay close to the fp32 call."""
+    from devo_amd.patchifier import Patchifier
+    torch.manual_seed(3)
+    pf = Patchifier(patch_size=3, patch_selector="scorer").to(DEV).eval()
+    g = torch.Generator().manual_seed(4)
+    images = (torch.randn(1, 1, 5, 96, 128, generator=g) * 0.5).to(DEV)
+    with torch.no_grad():
+        torch.manual_seed(9)
+        ref = pf(images, patches_per_image=24, return_color=True, scorer_eval_mode="topk")
+        with torch.autocast("cuda", dtype=torch.float16):
+            got = pf(images, patches_per_image=24, return_color=True, scorer_eval_mode="topk")
+    for name, a, b in zip(("fmap", "gmap", "imap", "patches", "index", "clr"), got, ref):
+        assert bool(torch.isfinite(a.float()).all()), name
+    fmap16, fmap32 = got[0].float(), ref[0].float()
+    assert (fmap16 - fmap32).abs().max().item() <= 3e-2 * max(1.0, fmap32.abs().max().item())
+    if torch.equal(got[3], ref[3]):                                        # the same patch centres (the scorer's fp16 scores may reorder near-ties)
+        assert (got[1].float() - ref[1].float()).abs().max().item() <= 3e-2 * max(1.0, ref[1].abs().max().item())
+        assert (got[2].float() - ref[2].float()).abs().max().item() <= 3e-2 * max(1.0, ref[2].abs().max().item())

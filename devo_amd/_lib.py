@@ -64,6 +64,7 @@ _SIGNATURES.update({
     "devo_upd_layernorm_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp, _vp],
     "devo_upd_masked_gather": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "devo_upd_softagg": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "devo_upd_softagg_hint": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "devo_upd_softagg_backward": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp],
     "devo_upd_expand_add": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "devo_upd_gated_residual": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp],

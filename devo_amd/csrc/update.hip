@@ -670,13 +670,13 @@ __global__ __launch_bounds__(256) void k_heads_q(const T* __restrict__ x, const 
 // per channel walking them one after the other is a chain of ~100 dependent row latencies), 16-byte chunks per lane (NQ <= 2
 // chunks: dim <= 512 floats / 1024 halves), two rows in flight per wave; the four partial (max, normaliser, sum) triples are
 // merged through LDS.  Dynamic LDS: 12 * dim floats.
-template <typename T>
-__global__ __launch_bounds__(256) void k_softagg_v(const T* __restrict__ f, const T* __restrict__ g, int64_t ld_fg,
+template <typename T, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_softagg_v(const T* __restrict__ f, const T* __restrict__ g, int64_t ld_fg,
                                                    const int* __restrict__ perm, const int* __restrict__ seg,
                                                    const int* __restrict__ n_seg_p, T* __restrict__ y,
                                                    int* __restrict__ group_of, int dim, int cpr) {
   constexpr int V = ChunkOf<T>::V;
-  extern __shared__ float s_part[];                          // [3][4][dim]: max, normaliser, weighted sum of every wave
+  extern __shared__ float s_part[];                          // [3][NW][dim]: max, normaliser, weighted sum of every wave
   const int n_seg = *n_seg_p;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int s = blockIdx.x; s < n_seg; s += gridDim.x) {
@@ -694,18 +694,22 @@ __global__ __launch_bounds__(256) void k_softagg_v(const T* __restrict__ f, cons
         den[k][u] = den[k][u] * r + w; num[k][u] = num[k][u] * r + fv[u] * w; m[k][u] = n;
       }
     };
-    for (int a = a0 + wave; a < a1; a += 8) {                // rows a and a + 4 of this wave together
-      const bool two = a + 4 < a1;
-      const int64_t e0 = perm[a], e1 = two ? perm[a + 4] : e0;
+    constexpr int RF = 2;                                      // rows in flight per wave: a, a + NW (4 measured slower: 17.0 / 14.3 us against 14.9 / 13.8)
+    for (int a = a0 + wave; a < a1; a += RF * NW) {
+      int64_t er[RF];
+      bool have[RF];
+#pragma unroll
+      for (int r = 0; r < RF; r++) { have[r] = a + r * NW < a1; er[r] = perm[have[r] ? a + r * NW : a]; }
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const int q = lane + 64 * k;
         if (q < cpr) {
-          float g0[V], f0[V], g1[V], f1[V];
-          ldc(g + e0 * ld_fg + q * V, g0); ldc(f + e0 * ld_fg + q * V, f0);
-          ldc(g + e1 * ld_fg + q * V, g1); ldc(f + e1 * ld_fg + q * V, f1);
-          fold(k, g0, f0);
-          if (two) fold(k, g1, f1);
+          float gr[RF][V], fr[RF][V];
+#pragma unroll
+          for (int r = 0; r < RF; r++) { ldc(g + er[r] * ld_fg + q * V, gr[r]); ldc(f + er[r] * ld_fg + q * V, fr[r]); }
+#pragma unroll
+          for (int r = 0; r < RF; r++)
+            if (have[r]) fold(k, gr[r], fr[r]);
         }
       }
     }
@@ -716,27 +720,27 @@ __global__ __launch_bounds__(256) void k_softagg_v(const T* __restrict__ f, cons
 #pragma unroll
         for (int u = 0; u < V; u++) {
           const int c = q * V + u;
-          s_part[(0 * 4 + wave) * dim + c] = m[k][u];
-          s_part[(1 * 4 + wave) * dim + c] = den[k][u];
-          s_part[(2 * 4 + wave) * dim + c] = num[k][u];
+          s_part[(0 * NW + wave) * dim + c] = m[k][u];
+          s_part[(1 * NW + wave) * dim + c] = den[k][u];
+          s_part[(2 * NW + wave) * dim + c] = num[k][u];
         }
       }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < dim; c += 256) {
+    for (int c = threadIdx.x; c < dim; c += 64 * NW) {
       float M = s_part[c];
 #pragma unroll
-      for (int w = 1; w < 4; w++) M = fmaxf(M, s_part[w * dim + c]);
+      for (int w = 1; w < NW; w++) M = fmaxf(M, s_part[w * dim + c]);
       float dn = 0.0f, nm = 0.0f;
 #pragma unroll
-      for (int w = 0; w < 4; w++) {
+      for (int w = 0; w < NW; w++) {
         const float r = __expf(s_part[w * dim + c] - M);
-        dn += s_part[(4 + w) * dim + c] * r; nm += s_part[(8 + w) * dim + c] * r;
+        dn += s_part[(NW + w) * dim + c] * r; nm += s_part[(2 * NW + w) * dim + c] * r;
       }
       st(y + (int64_t)s * dim + c, nm / dn);
     }
     if (group_of)
-      for (int a = a0 + threadIdx.x; a < a1; a += 256) group_of[perm[a]] = s;
+      for (int a = a0 + threadIdx.x; a < a1; a += 64 * NW) group_of[perm[a]] = s;
     __syncthreads();                                         // s_part is reused by the next group
   }
 }
@@ -842,17 +846,39 @@ int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64
 
 int devo_upd_softagg(const void* f, const void* g, int64_t ld_fg, const int* perm, const int* seg_start, const int* n_seg,
                      void* y, int* group_of, int64_t E, int dim, int dtype, devo_stream_t stream) {
+  return devo_upd_softagg_hint(f, g, ld_fg, perm, seg_start, n_seg, y, group_of, E, dim, dtype, 0, stream);
+}
+
+// rows_per_group: the caller's estimate (E / groups; 0 = unknown).  Groups of many rows (the frame pairs: ~100 edges each, ~200 groups) are
+// a chain of dependent row latencies per wave: they get 16 waves per workgroup instead of 4.
+int devo_upd_softagg_hint(const void* f, const void* g, int64_t ld_fg, const int* perm, const int* seg_start, const int* n_seg,
+                          void* y, int* group_of, int64_t E, int dim, int dtype, int rows_per_group, devo_stream_t stream) {
   DEVO_REQUIRE(E >= 0 && dim > 0 && dim % 2 == 0 && ld_fg >= dim && ld_fg % 2 == 0, "devo_upd_softagg: bad sizes (dim and the row stride must be even)");
   DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y)) & 7) == 0, "devo_upd_softagg: operands must be 8-byte aligned");
   if (E == 0) return DEVO_OK;
   hipStream_t st_ = (hipStream_t)stream;
   if (upd_vec_ok(dtype, E, dim, {f, g}, {ld_fg}) && dim / (dtype == DEVO_F32 ? 4 : 8) <= 128) {
     const int cpr = dim / (dtype == DEVO_F32 ? 4 : 8);
-    const dim3 vgrid(grid_for(E, 1, 4096)), vblock(256);
+    const dim3 vgrid(grid_for(E, 1, 4096));
+    if (rows_per_group >= 48 && sizeof(float) * 48 * (size_t)dim <= 160 * 1024) {
+      const size_t lds = sizeof(float) * 48 * (size_t)dim;
+      static bool attr_done = false;
+      if (!attr_done) {
+        DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_softagg_v<float, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_softagg_v<__half, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                     "devo_upd_softagg: cannot raise the dynamic LDS limit");
+        attr_done = true;
+      }
+      UPD_DISPATCH(dtype,
+        hipLaunchKernelGGL((k_softagg_v<float, 16>), vgrid, dim3(1024), lds, st_, (const float*)f, (const float*)g, ld_fg, perm, seg_start, n_seg, (float*)y, group_of, dim, cpr),
+        hipLaunchKernelGGL((k_softagg_v<__half, 16>), vgrid, dim3(1024), lds, st_, (const __half*)f, (const __half*)g, ld_fg, perm, seg_start, n_seg, (__half*)y, group_of, dim, cpr));
+      return check_launch("devo_upd_softagg");
+    }
+    const dim3 vblock(256);
     const size_t lds = sizeof(float) * 12 * (size_t)dim;
     UPD_DISPATCH(dtype,
-      hipLaunchKernelGGL(k_softagg_v<float>, vgrid, vblock, lds, st_, (const float*)f, (const float*)g, ld_fg, perm, seg_start, n_seg, (float*)y, group_of, dim, cpr),
-      hipLaunchKernelGGL(k_softagg_v<__half>, vgrid, vblock, lds, st_, (const __half*)f, (const __half*)g, ld_fg, perm, seg_start, n_seg, (__half*)y, group_of, dim, cpr));
+      hipLaunchKernelGGL((k_softagg_v<float, 4>), vgrid, vblock, lds, st_, (const float*)f, (const float*)g, ld_fg, perm, seg_start, n_seg, (float*)y, group_of, dim, cpr),
+      hipLaunchKernelGGL((k_softagg_v<__half, 4>), vgrid, vblock, lds, st_, (const __half*)f, (const __half*)g, ld_fg, perm, seg_start, n_seg, (__half*)y, group_of, dim, cpr));
     return check_launch("devo_upd_softagg");
   }
   const dim3 grid(grid_for(E * ((dim + 511) / 512), 1, 4096)), block(256);

@@ -780,8 +780,9 @@ class Update(nn.Module):
             fg = self._lin(net, W, b)                              # [E, 2 dim]: f | g
         E, dim = net.shape
         y = torch.empty(G.n_seg, dim, dtype=net.dtype, device=net.device)
-        L.check(L.lib().devo_upd_softagg(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
-                                         L.ptr(y), L.ptr(G.group_of), E, dim, L.dtype_code(net), L.stream()), "update.softagg")
+        L.check(L.lib().devo_upd_softagg_hint(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
+                                              L.ptr(y), L.ptr(G.group_of), E, dim, L.dtype_code(net), int(E // max(int(G.n_seg), 1)), L.stream()),
+                "update.softagg")
         return F.linear(y, agg.h.weight, agg.h.bias), G.group_of
 
     def _gate_res(self, name, gr, x):

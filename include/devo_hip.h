@@ -378,6 +378,10 @@ int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64
 int devo_upd_softagg(const void* f, const void* g, int64_t ld_fg /* row stride of f and g (>= dim) */, const int* perm,
                      const int* seg_start, const int* n_seg, void* y, int* group_of, int64_t E, int dim, int dtype,
                      devo_stream_t stream);
+/* ... with the caller's estimate of the rows per group (E / groups; 0 = unknown): groups of >= 48 rows (DEVO's frame pairs) run on 16 waves per
+ * workgroup instead of 4 (a wave's rows are a chain of dependent row latencies). */
+int devo_upd_softagg_hint(const void* f, const void* g, int64_t ld_fg, const int* perm, const int* seg_start, const int* n_seg, void* y, int* group_of,
+                          int64_t E, int dim, int dtype, int rows_per_group, devo_stream_t stream);
 
 /* Adjoint of devo_upd_softagg for training (the backward of blocks.py:42-43's scatter_softmax * f -> scatter_sum): dy [n_seg, dim] ->
  * df, dg (rows of stride ld_d; every edge of every group is written):  d f_e = w_e dy,  d g_e = w_e dy (f_e - y),  w = softmax of g

@@ -717,6 +717,94 @@ class Update(nn.Module):
         self._graph_key, self._graph, self._graph_refs = None, None, None
         self.invalidate_weights()
 
+    def _rs_plan(self):
+        """Everything the fp16 row-resident path hands to its ten launches — weight images, bias / LayerNorm vectors as raw pointers, the
+        epsilons — collected once per version of the parameters: the eager call is host-bound otherwise (39 nn.Sequential lookups, 120
+        parameter lookups and 60 pointer conversions per call: 185 us where the GPU needs 230)."""
+        key = sum(p._version for p in self._plist()) + (self.norm.weight.data_ptr() << 8)
+        pl = self.__dict__.get("_rsplan")
+        if pl is not None and pl["key"] == key:
+            return pl
+        P, img, keep = (lambda t: t.data_ptr()), _rs_image, []       # (plain integers: ctypes takes them for void pointers)
+
+        def im(w):
+            t = img(w.detach() if w.requires_grad else w)
+            keep.append(t)
+            return P(t)
+        cat = lambda name, a, b: self._cat(name, a, b)
+        Wkk, bkk = cat("agg_kk", self.agg_kk.f, self.agg_kk.g)
+        Wij, bij = cat("agg_ij", self.agg_ij.f, self.agg_ij.g)
+        W1, b1 = cat("gru1", self.gru[1].gate[0], self.gru[1].res[0])
+        W3, b3 = cat("gru3", self.gru[3].gate[0], self.gru[3].res[0])
+        keep += [Wkk, bkk, Wij, bij, W1, b1, W3, b3]
+        co, g = self.corr, self.gru
+        pl = dict(key=key, keep=keep,
+                  corr=(im(co[0].weight), P(co[0].bias), im(co[2].weight), P(co[2].bias), P(co[3].weight), P(co[3].bias), float(co[3].eps),
+                        im(co[5].weight), P(co[5].bias)),
+                  norm=(P(self.norm.weight), P(self.norm.bias), float(self.norm.eps)),
+                  c1=(im(self.c1[0].weight), P(self.c1[0].bias), im(self.c1[2].weight), P(self.c1[2].bias)),
+                  c2=(im(self.c2[0].weight), P(self.c2[0].bias), im(self.c2[2].weight), P(self.c2[2].bias)),
+                  fg_kk=(im(Wkk), P(bkk)), fg_ij=(im(Wij), P(bij)),
+                  h_kk=(im(self.agg_kk.h.weight), P(self.agg_kk.h.bias)), h_ij=(im(self.agg_ij.h.weight), P(self.agg_ij.h.bias)),
+                  gru=(P(g[0].weight), P(g[0].bias), float(g[0].eps), im(W1), P(b1), im(g[1].res[2].weight), P(g[1].res[2].bias), P(g[2].weight),
+                       P(g[2].bias), float(g[2].eps), im(W3), P(b3), im(g[3].res[2].weight), P(g[3].res[2].bias), P(self.d[1].weight), P(self.d[1].bias),
+                       P(self.w[1].weight), P(self.w[1].bias)))
+        ok = all(t.data_ptr() % 8 == 0 for t in (self.c1[0].bias, self.c1[2].bias, self.c2[0].bias, self.c2[2].bias, bkk, bij)) and \
+            all(t.data_ptr() % 16 == 0 for t in (co[3].weight, co[3].bias, self.norm.weight, self.norm.bias, g[0].weight, g[0].bias, g[2].weight, g[2].bias,
+                                                  self.d[1].weight, self.w[1].weight))
+        pl["ok"] = ok
+        self.__dict__["_rsplan"] = pl
+        return pl
+
+    def __getstate__(self):
+        """(copy.deepcopy, torch.save of the module: the per-version caches stay behind — raw pointers, a half copy of the operator)"""
+        d = self.__dict__.copy()
+        for k in ("_rsplan", "_shadow", "_params"):
+            d.pop(k, None)
+        return d
+
+    def _plist(self):
+        pl = self.__dict__.get("_params")
+        if pl is None:
+            pl = self.__dict__["_params"] = list(self.parameters())
+        return pl
+
+    def _forward_rs(self, x, inp2, c, ix, jx, Gkk, Gij, E):
+        """The fp16 operator on the row-resident kernels (csrc/gemm_rs.hip), ten launches: the correlation branch + norm | c1 | c2 + agg_kk's
+        f | g | SoftAgg | h | expand-add + agg_ij's f | g | SoftAgg | h | both LayerNorms, both GatedResiduals and the heads."""
+        pl = self._rs_plan()
+        if not pl["ok"]:
+            return None
+        lib, st, P, dim, dt, dev = L.lib(), L.stream(), L.ptr, 384, torch.float16, x.device
+        chk = L.check
+        out = torch.empty_like(x)
+        chk(lib.devo_upd_rs_corr_f16(P(c), c.stride(0), c.shape[1], *pl["corr"], P(x), P(inp2), *pl["norm"], P(out), E, st), "update.rs_corr_f16")
+        x = out
+        y = torch.empty_like(x)
+        chk(lib.devo_upd_rs_mlp2_fg_f16(P(x), dim, E, P(ix), *pl["c1"], P(x), P(y), E, None, None, None, st), "update.rs_mlp2_f16")
+        x = y
+        y, fg = torch.empty_like(x), torch.empty(E, 2 * dim, dtype=dt, device=dev)
+        chk(lib.devo_upd_rs_mlp2_fg_f16(P(x), dim, E, P(jx), *pl["c2"], P(x), P(y), E, *pl["fg_kk"], P(fg), st), "update.rs_mlp2_f16")
+        x = y
+        code = L.dtype_code(x)
+
+        def agg(G, h):
+            ys = torch.empty(G.n_seg, dim, dtype=dt, device=dev)
+            chk(lib.devo_upd_softagg_hint(P(fg), P(fg[:, dim:]), 2 * dim, P(G.perm), P(G.seg_start), P(G.n_seg_dev), P(ys), P(G.group_of), E, dim, code,
+                                          E // max(G.n_seg, 1), st), "update.softagg")
+            hy = torch.empty(G.n_seg, dim, dtype=dt, device=dev)
+            chk(lib.devo_upd_rs_linear_f16(P(ys), dim, h[0], h[1], None, P(hy), dim, G.n_seg, dim, dim, dim, st), "update.rs_linear_f16")
+            return hy
+        hy = agg(Gkk, pl["h_kk"])
+        chk(lib.devo_upd_rs_expand_fg_f16(P(x), P(hy), P(Gkk.group_of), *pl["fg_ij"], P(fg), E, st), "update.rs_expand_fg_f16")
+        hy = agg(Gij, pl["h_ij"])
+        net_out = torch.empty_like(x)
+        dw = torch.empty(2, E, 2, dtype=dt, device=dev)
+        g = pl["gru"]
+        chk(lib.devo_upd_rs_gru_f16(P(x), P(hy), P(Gij.group_of), g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[13],
+                                    g[14], g[15], g[16], g[17], P(net_out), P(dw[0]), P(dw[1]), E, st), "update.rs_gru_f16")
+        return net_out.view(1, E, dim), (dw[0].view(1, E, 2), dw[1].view(1, E, 2), None)
+
     def _half_shadow(self):
         """An fp16 copy of this operator (for calls under autocast), rebuilt when a parameter's version counter moves; `.data` edits: invalidate_weights()."""
         key = sum(p._version for p in self.parameters()) + (self.norm.weight.data_ptr() << 8)
@@ -735,6 +823,8 @@ class Update(nn.Module):
         if getattr(self, "_wcat", None) is not None:
             self._wcat.clear()
         self.__dict__.pop("_shadow", None)
+        self.__dict__.pop("_rsplan", None)
+        self.__dict__.pop("_params", None)
         invalidate_weight_images()
 
     def train(self, mode=True):
@@ -822,6 +912,11 @@ class Update(nn.Module):
         x, inp2, c = net.reshape(E, dim).to(dt).contiguous(), inp.reshape(E, dim).to(dt).contiguous(), corr.reshape(E, -1).to(dt)
         lib, code = L.lib(), L.dtype_code(x)
         ix, jx, Gkk, Gij = self._tables(ii, jj, kk)
+        if (RS_CHAINS and RS_GEMM and dt == torch.float16 and dim == 384 and 768 < c.shape[1] <= 896 and c.stride(1) == 1 and c.stride(0) % 2 == 0
+                and c.data_ptr() % 4 == 0 and inp2.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
+            fast = self._forward_rs(x, inp2, c, ix, jx, Gkk, Gij, E)
+            if fast is not None:
+                return fast
 
         # corr MLP (enet.py:59-66) and net = norm(net + inp + corr)  (:82-83), the two adds fused into the LayerNorm
         if (RS_CHAINS and RS_GEMM and dt == torch.float16 and dim == 384 and 768 < c.shape[1] <= 896 and c.stride(1) == 1 and c.stride(0) % 2 == 0

@@ -1088,7 +1088,8 @@ template <int MT, int NK>
 static int rs_launch(const void* x, int64_t ldx, const void* wimg, const void* bias, const void* residual, void* y, int64_t ldy, int M, int NB, int K,
                      int relu_from, hipStream_t stream, unsigned long long* trace = nullptr) {
   constexpr int ROWS = 16 * MT, PITCH = 2 * 32 * NK + 16;
-  const int lds = ROWS * PITCH + (NB > 1 ? RS_NW * 16 * RS_EPI_LD * 4 : 0);
+  // the row tile; the last pass's result tiles lie over it (26.6 KB: more than a 32-row tile), earlier passes' behind it
+  const int lds = std::max(ROWS * PITCH, RS_NW * 16 * RS_EPI_LD * 4) + (NB > 1 ? RS_NW * 16 * RS_EPI_LD * 4 : 0);
   static bool attr_done = false;
   if (!attr_done) {
     DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_linear_f16<MT, NK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
@@ -1172,6 +1173,9 @@ int devo_upd_rs_linear_f16(const void* x, int64_t ldx, const void* wimg, const v
             nwg, rows, NB, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, hi - lo);
     return rc;
   }
+  // few rows (the SoftAggs' h layers: 1 440 / 210 rows): 32-row workgroups — the products of a 96-row tile on three CUs are time added to the
+  // latency of the weight stream, which is what such a launch consists of (9.4 -> ~6 us)
+  if (M <= 2048 && !getenv("DEVO_RS_MT")) return rs_launch<2, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
   if (mt == 6) return rs_launch<6, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
   if (mt == 4) return rs_launch<4, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
   return rs_launch<8, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);

@@ -49,12 +49,17 @@ def parse():
                          "cfg2, profiles/r05_group_form.txt)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--separate-target", action="store_true", help="form target = coords centre + delta with a torch kernel (devo.py:330) instead of inside the BA")
-    ap.add_argument("--steps-per-graph", type=int, default=20,
-                    help="consecutive steps captured into one HIP graph launch (a graph launch costs ~10 us of idle GPU; 1 = one launch per step)")
+    ap.add_argument("--steps-per-graph", type=int, default=18,
+                    help="consecutive steps captured into one HIP graph launch (a graph launch costs ~10 us of idle GPU; 1 = one launch per step).  Default 18 = "
+                         "the update iterations DEVO_base.conf runs on one patch graph (BASELINE configuration 2)")
+    ap.add_argument("--prepare-every", type=int, default=18,
+                    help="the BA's index tables (unique patches, edges grouped by patch: a function of kk alone) are rebuilt every this many steps — 18 = once per "
+                         "patch graph of 18 update iterations, what cuda_ba.forward's prepared-table cache does for an unchanged kk; 1 = every step (a new graph per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-allcores", action="store_true",
-                    help="cpu_baseline also times the BA with one torch thread per host core (field ba_ms_allcores: ~25 s of oversubscribed "
-                         "CPU on a 256-core host, 1000x slower than 16 threads; measured once in profiles/, opt-in since)")
+    ap.add_argument("--cpu-allcores", action="store_true", default=True,
+                    help="(default since round 6) cpu_baseline also times the BA with one torch thread per host core (field ba_ms_allcores: ~25 s of "
+                         "oversubscribed CPU on a 256-core host, 1000x slower than 16 threads)")
+    ap.add_argument("--no-cpu-allcores", dest="cpu_allcores", action="store_false", help="skip the all-cores BA figure of cpu_baseline")
     ap.add_argument("--with-stress", action="store_true",
                     help="also run BASELINE configuration 5 (M=256, n=32, r=5, 1280x720) and add its step rate and lookup roofline as field \"stress\"")
     ap.add_argument("--kernel-reps", type=int, default=50, help="launch pairs timed for the roofline figure")
@@ -351,9 +356,10 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         a.record(); lookup(coords, order=order); b.record()
         probe["ev"].append((a, b))
 
-    def step():
+    def step(k=0, every=None):
         cur = torch.cuda.current_stream()
-        if prep_stream is not None:
+        fresh_graph = (k % max(1, every or args.prepare_every)) == 0      # this step sees a "new" patch graph: the index tables are rebuilt
+        if prep_stream is not None and fresh_graph:
             # the index half of the BA (unique patches, edges grouped by patch) depends on kk only: it runs on a second
             # stream under the reprojection + lookup (a fork/join inside the captured graph)
             prep_stream.wait_stream(cur)
@@ -363,13 +369,17 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         # reprojection; the kernel also emits the lookup's plan bins while it holds the coordinates
         coords, order = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp",
                                           plan_for=(n, cfg["H"], R, cfg["W"], PL1))
-        if args.separate_index_kernels or prep_stream is not None:
+        if args.separate_index_kernels or prep_stream is not None or not fresh_graph:
             order = cuda_corr.plan_finish(order, d["jj"], n, cfg["H"], R, width=cfg["W"], l1=PL1)
+            if not fresh_graph:
+                pass                                                       # the workspace holds this kk's tables already (cuda_ba.forward's cache, here explicit)
+            elif prep_stream is None:
+                cuda_ba.prepare(d["kk"], Np, n - 1, ws)
         else:
             # the plan's ordering step and the BA's index preparation (independent of each other) in ONE launch
             cuda_ba.prepare(d["kk"], Np, n - 1, ws, plan=(order, n, cfg["H"], cfg["W"], PL1))
         lookup_probed(coords, order=order)
-        if prep_stream is not None:
+        if prep_stream is not None and fresh_graph:
             cur.wait_stream(prep_stream)
         if not (args.separate_target or args.separate_index_kernels):
             # devo.py:330 (target = centre of the reprojected patch + delta) formed inside the BA: same fp32 addition
@@ -378,13 +388,18 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
             return
         target = coords[:, :, :, 1, 1] + d["delta"]                        # devo.py:330
         cuda_ba.forward(d["poses"], d["patches"], d["intr"], target, d["weight"], d["lmbda"],
-                        d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws, prepared=(prep_stream is not None) or not args.separate_index_kernels)
+                        d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws, prepared=True)
 
     # ---- warm up eagerly once (library load, kernel code upload), then capture
     step()
     torch.cuda.synchronize()
+    gevery = None
     if args.no_graph:
-        run = step
+        count = [0]
+
+        def run():
+            step(count[0])
+            count[0] += 1
     else:
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
@@ -398,8 +413,13 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
             if args.steps_per_graph > 1:                                   # several consecutive steps in one graph launch
                 gmany = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gmany, stream=side):
-                    for _ in range(args.steps_per_graph):
-                        step()
+                    for k in range(args.steps_per_graph):
+                        step(k)
+                if args.prepare_every > 1 and not secondary:               # the same steps with a NEW patch graph in every one of them
+                    gevery = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gevery, stream=side):
+                        for k in range(args.steps_per_graph):
+                            step(k, every=1)
         torch.cuda.current_stream().wait_stream(side)
         run = graph.replay
     for _ in range(args.warmup):
@@ -433,6 +453,16 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         elapsed = samples[len(samples) // 2]
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
+    ms_every = None
+    if gevery is not None:                                                 # every step rebuilds the BA's index tables (rounds 1-5's step)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gevery.replay()
+        ts = []
+        for _ in range(5):
+            e0.record(); gevery.replay(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / args.steps_per_graph)
+        ms_every = sorted(ts)[2]
 
     # ---- roofline figure for the dominant kernel (altcorr lookup), HIP events on the launch stream
     coords = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
@@ -485,7 +515,10 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
     t_event_pair = sum(a.elapsed_time(b) for a, b in empty) * 1e-3 / len(empty)
     # roofline figure: the back-to-back launches replayed from a graph (no event-pair correction; rocprofv3's per-kernel average of this
     # command, profiles/, lies between this and the raw in-step figure)
-    t_launch = t_back_to_back
+    # round 6 (verdict item 4): the line leads with what the STEP pays — the lookup between the reprojection / ordering kernels and the
+    # BA, cold L2 behind them (events around the launch in eager steps, nothing subtracted; rocprofv3's per-kernel average of this command
+    # is made of these launches) — and carries the warm back-to-back figure as a secondary key
+    t_launch = t_in_step
     b_alg = alg_bytes(cfg, E, 4 if dtype == torch.float32 else 2) / (1.0 if args.fuse_levels else 2.0)   # bytes per launch
     achieved = b_alg / t_launch / 1e9
     f_alg = 2.0 * cfg["C"] * E * 9 * (2 * R + 2) ** 2 * (2.0 if args.fuse_levels else 1.0)    # flops per launch
@@ -498,7 +531,15 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         cuda_ba.forward(d["poses"], d["patches"], d["intr"], tgt, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
     ev1.record()
     torch.cuda.synchronize()
-    t_ba_gpu = ev0.elapsed_time(ev1) * 1e-3 / 20
+    t_ba_gpu = ev0.elapsed_time(ev1) * 1e-3 / 20                           # unchanged kk: the index tables of the first call serve the others
+    ev0.record()
+    for _ in range(20):
+        d["state"].copy_(d["state0"])
+        cuda_ba.prep_invalidate()                                          # a new patch graph every call: the index tables are rebuilt
+        cuda_ba.forward(d["poses"], d["patches"], d["intr"], tgt, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws)
+    ev1.record()
+    torch.cuda.synchronize()
+    t_ba_gpu_new = ev0.elapsed_time(ev1) * 1e-3 / 20
 
     # which lookup kernel the library picks for this configuration (devo_amd/csrc/corr.hip: launch_staged)
     mfma = cfg["C"] == 128 and os.environ.get("DEVO_CORR_MFMA", "1")[:1] != "0"          # fp32 and fp16 storage
@@ -545,11 +586,21 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
                      "alg_bytes_per_launch": int(b_alg), "us_per_launch": round(t_launch * 1e6, 2),
                      "us_per_launch_back_to_back": round(t_back_to_back * 1e6, 2), "us_per_launch_in_step_raw": round(t_in_step * 1e6, 2),
                      "event_pair_us": round(t_event_pair * 1e6, 2),
-                     "timing": "achieved / frac / us_per_launch: HIP events around " + str(args.kernel_reps) + " lookup launches replayed back to back from a HIP graph, nothing "
-                               "subtracted; in_step_raw: events around the lookup of eager steps (includes one event pair, event_pair_us)"},
-        "ba": dict({"gpu_ms": round(t_ba_gpu * 1e3, 4)}, **ba_kernel_report(run_ba=lambda: cuda_ba.forward(
-            d["poses"], d["patches"], d["intr"], tgt, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws))),
+                     "frac_back_to_back": round(b_alg / t_back_to_back / 1e9 / HBM_PEAK_GBS, 4),
+                     "timing": "achieved / frac / us_per_launch: HIP events around the lookup launch of " + str(args.kernel_reps) + " eager steps (the kernel where the step runs "
+                               "it, nothing subtracted: the pair of events itself costs event_pair_us); back_to_back: events around " + str(args.kernel_reps) +
+                               " lookup launches replayed back to back from a HIP graph"},
+        "ba": dict({"gpu_ms": round(t_ba_gpu * 1e3, 4), "gpu_ms_new_graph": round(t_ba_gpu_new * 1e3, 4),
+                    "note": "gpu_ms / launches / kernels: cuda_ba.forward (2 GN iterations) on an unchanged kk — the index tables (unique patches, edges grouped by patch) "
+                            "come from forward()'s prepared-table cache; gpu_ms_new_graph: every call rebuilds them (one more launch)"},
+                   **ba_kernel_report(run_ba=lambda: cuda_ba.forward(
+                       d["poses"], d["patches"], d["intr"], tgt, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws))),
     }
+    out["config"]["ba_index_tables"] = f"rebuilt every {args.prepare_every} steps (one patch graph = {args.prepare_every} update iterations)"
+    if ms_every is not None:
+        out["new_graph_every_step"] = {"ms_per_step": round(ms_every, 4), "value": round(world * 1e3 / ms_every, 2), "unit": "it/s",
+                                       "note": "the same steps with the BA's index tables rebuilt in EVERY step (rounds 1-5's step; DEVO's steady-state inference "
+                                               "appends edges once per frame: one update() per new graph)"}
 
     if not args.no_full_iteration and args.workload == "cfg2" and world == 1:
         try:                                                         # an extra field must not cost the line
@@ -596,6 +647,25 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
                 ev1.record()
                 torch.cuda.synchronize()
                 full[key + "_ms"] = round(ev0.elapsed_time(ev1) / 50, 4)
+                if key == "f16":
+                    # the Update operator alone (verdict r05 item 4): its GEMMs are the one MFMA-roofline part of the path — 16 products of
+                    # E x 384 x 384, the 882-wide first layer of the correlation branch and the two heads
+                    c16 = corr_out.to(udt)
+                    with torch.no_grad():
+                        for _ in range(3):
+                            upd(net_h, inp_h, c16, None, d["ii"], d["jj"], d["kk"])
+                        ev0.record()
+                        for _ in range(20):
+                            upd(net_h, inp_h, c16, None, d["ii"], d["jj"], d["kk"])
+                        ev1.record()
+                    torch.cuda.synchronize()
+                    t_op = ev0.elapsed_time(ev1) * 1e-3 / 20
+                    fl = 2.0 * E * (16 * 384 * 384 + 882 * 384 + 2 * 2 * 384)
+                    out["update_op"] = {"f16_ms": round(t_op * 1e3, 4), "gflop": round(fl / 1e9, 1), "achieved_tflops": round(fl / t_op / 1e12, 1),
+                                        "peak_tflops": 2500.0, "frac": round(fl / t_op / 2.5e15, 4), "bound": "mfma",
+                                        "note": "devo_amd.update.Update (fp16 weights and state), eager launches from pointers collected once per parameter version; "
+                                                "peak = the dense fp16 MFMA figure of MI355X_MICROARCH.md"}
+                    del c16
                 del upd
             full["note"] = (f"reproject + 2-level lookup ({dtn} pyramid) + Update operator (fp32 / fp16 weights and state, random weights) + "
                             f"2 GN iterations on its outputs, {how}")
@@ -797,7 +867,7 @@ def cpu_baseline(cfg, cpu, E, allcores=False):
     return {"value": round(1.0 / step_s, 4), "unit": "it/s", "cores": threads, "kind": "port", "cpu_model": model,
             "host_cores": os.cpu_count(), "ba_ms_1thread": round(t_ba1 * 1e3, 2),
             "ba_ms_allcores": (round(t_ba_all * 1e3, 2) if t_ba_all is not None else None),
-            "ba_ms_allcores_note": "one torch thread per host core (--cpu-allcores): 49 196 ms on the 256-core host of profiles/r04_bench.json against 43 ms with 16 threads",
+            "ba_ms_allcores_note": "one torch thread per host core (ONE Gauss-Newton iteration timed, doubled): oversubscription — these small-tensor ops want <= 16 threads",
             "sample": f"torch-CPU fp32, torch.set_num_threads({threads}): transform (full, {E} edges) + 2x ba.py-style BA (full, median of 3) + "
                       f"2-level lookup on {ns} of {E} edges (median of 3 passes" + (", scaled to E)" if ns < E else ")"),
             "ba_ms": round(t_ba * 1e3, 2), "ba_ms_samples": [round(t * 1e3, 2) for t in ts], "corr_ms_scaled": round(t_corr * 1e3, 1),

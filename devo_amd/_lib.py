@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdevo_hip.so")
 
 DEVO_F32, DEVO_F16, DEVO_F64 = 0, 1, 2
-ABI_VERSION = 2                # include/devo_hip.h DEVO_ABI_VERSION: a library of another version is refused (argument lists differ)
+ABI_VERSION = 3                # include/devo_hip.h DEVO_ABI_VERSION: a library of another version is refused (argument lists differ)
 CBLOCK_SPLIT8 = -8             # DEVO_CBLOCK_SPLIT8: fp32 level in the split-blocked format of devo_corr_pyramid_split
 PLAN_TAIL = 4104               # DEVO_CORR_PLAN_TAIL: a plan buffer that can hold a group plan has 2 n + 2 + PLAN_TAIL ints
 PLAN_EDGES, PLAN_GROUPS = 0, 1
@@ -24,6 +24,7 @@ _vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c
 _SIGNATURES = {
     "devo_abi_version": [],
     "devo_last_error": [],
+    "devo_stream_capturing": [_vp],
     "devo_corr_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i, _i64, _i64, _i64, _i, _i, _vp, ctypes.c_float, _vp, _vp, _vp],
     "devo_corr_forward_pyramid2": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), _c_i64p,
                                    ctypes.POINTER(ctypes.c_int), _i64, _i64, _c_i64p, _i, _i, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp, _vp, _i, _vp],

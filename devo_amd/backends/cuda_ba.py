@@ -43,7 +43,31 @@ def prepare(kk, n_patch_slots, n_opt, ws, plan=None):
         rc = L.lib().devo_ba_prepare_plan(L.ptr(kk), kk.numel(), int(n_patch_slots), int(n_opt), L.ptr(ws), ws.numel(),
                                           L.ptr(buf), int(n_frames), int(height), int(width) if groups else 0, int(l1) if groups else 0, L.stream())
     L.check(rc, "cuda_ba.prepare")
+    prep_invalidate()                                        # the tables in `ws` are this kk's now, whatever forward()'s cache remembers
     return ws
+
+
+# forward()'s prepared-table cache of the ctypes binding (the compiled binding has its own, csrc/bind.cpp): the index half of the BA depends
+# on kk alone and DEVO runs the BA again and again on one graph — key = (kk's storage, version counter, E, patch slots, window size,
+# workspace, stream); kk and the workspace are kept alive, so an equal key is the same storage with the same contents.
+_prep = {"key": None, "keep": None, "hits": 0, "misses": 0}
+_own_ws = {"key": None, "ws": None}
+import os as _os
+PREP_CACHE = _os.environ.get("DEVO_BA_PREP_CACHE", "1") != "0"
+
+
+def prep_invalidate():
+    """Forget the prepared index tables forward() remembers (both bindings)."""
+    _prep["key"] = _prep["keep"] = None
+    N = _nat()
+    if N is not None:
+        N.cuda_ba._prep_invalidate()
+
+
+def prep_stats():
+    """(hits, misses) of forward()'s prepared-table cache in the active binding."""
+    N = _nat()
+    return tuple(N.cuda_ba._prep_stats()) if N is not None else (_prep["hits"], _prep["misses"])
 
 
 def prepared_tables(ws, E, n_patch_slots, n_opt):
@@ -78,6 +102,7 @@ def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t
     P = patches.shape[-1]
     Nbuf = poses.numel() // 7
     Np = patches.numel() // (3 * P * P)
+    kk0 = kk                                                 # (the caller's tensor: what the prepared-table cache is keyed on)
     ii, jj, kk = _idx(ii, jj, kk)
     E = ii.numel()
     intrinsics = intrinsics.float().contiguous()
@@ -86,12 +111,29 @@ def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t
     lmbda = lmbda.float().reshape(-1).contiguous()
     if prepared and ws is None:
         raise RuntimeError("cuda_ba.forward: prepared=True needs the workspace that prepare() filled")
-    if ws is None:
-        ws = workspace(E, Np, int(t1) - int(t0), poses.device)
+    st = L.stream()
+    if ws is None:                                           # one live workspace per (size, device, stream), like the compiled binding
+        wkey = (E, Np, int(t1) - int(t0), str(poses.device), st.value)
+        if _own_ws["key"] != wkey:
+            _own_ws["key"], _own_ws["ws"] = wkey, workspace(E, Np, int(t1) - int(t0), poses.device)
+        ws = _own_ws["ws"]
+    if prepared:
+        _prep["key"] = _prep["keep"] = None
+    elif PREP_CACHE and E > 0 and int(iterations) > 0:
+        if L.lib().devo_stream_capturing(st) != 0:
+            _prep["key"] = _prep["keep"] = None              # (a capture executes nothing; a replay rewrites the tables behind the cache's back)
+        elif not kk0.is_inference():
+            key = (kk0.data_ptr(), kk0._version, E, Np, int(t1) - int(t0), ws.data_ptr(), st.value)
+            if _prep["key"] == key:
+                prepared = True
+                _prep["hits"] += 1
+            else:
+                _prep["key"], _prep["keep"] = key, (kk0, ws)
+                _prep["misses"] += 1
     fn = L.lib().devo_ba_forward_prepared if prepared else L.lib().devo_ba_forward
     rc = fn(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(target), L.ptr(weight),
             L.ptr(lmbda), L.ptr(ii), L.ptr(jj), L.ptr(kk), E, Nbuf, Np, P, int(t0), int(t1),
-            int(iterations), L.ptr(ws), ws.numel(), L.ptr(status), L.stream())
+            int(iterations), L.ptr(ws), ws.numel(), L.ptr(status), st)
     L.check(rc, "cuda_ba.forward")
     return []
 

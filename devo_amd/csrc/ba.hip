@@ -1585,9 +1585,18 @@ constexpr auto k_ba_solve = k_ba_solve_t<false>;
 // triangle are folded into it.
 // Same operations in the same order as k_ba_solve: bit-identical solutions (tests/test_gpu_fastba.py checks that).
 typedef float solve_f2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(1024) void k_ba_solve_chain(const float* __restrict__ S, const float* __restrict__ y, int N,
-                                                         float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps) {
+// FUSED (k_ba_solve_retract, round 6): the launch has G workgroups and EVERY one of them factorises the same 6N x 6N system (the same
+// operations in the same order: the same bits; ~30 KB of S out of the L2 each) and then retracts its own share of the patches with the
+// solution still in its LDS — workgroup 0 also retracts the poses and writes dX / the status.  No workgroup waits for another one: what
+// k_ba_retract did behind a kernel boundary (4.9 us + the boundary for 14 poses and 1 440 dot products) rides on the solver's launch.
+struct BaRetract { float* poses; float* patches; const float* patch_rec; const float* patch_col; const int* kx; int P, t0; };
+template <bool FUSED>
+__device__ __forceinline__ void ba_solve_chain_body(const float* __restrict__ S, const float* __restrict__ y, int N,
+                                                    float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps,
+                                                    const BaRetract& ra) {
   extern __shared__ __attribute__((aligned(16))) float A[];
+  const bool lead = blockIdx.x == 0;                              // (the only workgroup of the unfused launch)
+  const int n_seg_all = FUSED ? meta->n_seg : 0;
   __shared__ int s_fail;
   __shared__ float s_dump[64];
   const int n6 = 6 * N, LDG = n6 + 1, LD = solve_ld(n6), rows = n6 + 1;
@@ -1619,7 +1628,7 @@ __global__ __launch_bounds__(1024) void k_ba_solve_chain(const float* __restrict
   }
   __syncthreads();
   if (failed_before) {                           // an earlier iteration broke down: the reference call has thrown by now
-    if (tid == 0 && failed_before < 0 && status_flag) *status_flag = -1;          // (or the workspace was never prepared)
+    if (lead && tid == 0 && failed_before < 0 && status_flag) *status_flag = -1;  // (or the workspace was never prepared)
     return;
   }
   const unsigned long long st1 = stamps ? __builtin_readcyclecounter() : 0ull;
@@ -1810,14 +1819,17 @@ __global__ __launch_bounds__(1024) void k_ba_solve_chain(const float* __restrict
   }
   const unsigned long long st2 = stamps ? __builtin_readcyclecounter() : 0ull;
   if (stamps && ln == 0 && (wv == CHAIN || wv == 0 || wv == INVW)) g_solve_stamps[wv == CHAIN ? 6 : wv == 0 ? 8 : 9] = ph_work;
-  if (s_fail) {
-    for (int i = tid; i < 6 * N; i += 1024) dX[i] = 0.0f;         // (see k_ba_solve)
-    if (tid == 0) { meta->fail = iter + 1; if (status_flag) *status_flag = iter + 1; }
+  if (s_fail) {                                                    // (FUSED: every workgroup sees the same breakdown; nobody retracts)
+    if (lead) {
+      for (int i = tid; i < 6 * N; i += 1024) dX[i] = 0.0f;       // (see k_ba_solve)
+      if (tid == 0) { meta->fail = iter + 1; if (status_flag) *status_flag = iter + 1; }
+    }
     return;
   }
   // back substitution  L^T x = z  by ONE wave in registers (see k_ba_solve); z = the transposed panel entries of the rhs row
   // (column n6), the rows of L^T a lane needs are contiguous in its own row of the upper triangle
-  if (tid >= 64) return;
+  if (!FUSED && tid >= 64) return;
+  if (tid < 64) {
   const int lr0 = min(tid, n6 - 1), lr1 = min(tid + 64, n6 - 1), lc = min(tid, 5);
   float z0 = (tid < n6) ? A[tid * LD + n6] : 0.0f, z1 = (tid + 64 < n6) ? A[(tid + 64) * LD + n6] : 0.0f;
   struct StepOps { float li[6], a0[6]; };
@@ -1876,8 +1888,67 @@ __global__ __launch_bounds__(1024) void k_ba_solve_chain(const float* __restrict
 #undef DEVO_BS_STEP
   }
   wave_lds_sync();
-  for (int i = tid; i < n6; i += 64) dX[i] = xs[i];
-  if (stamps && tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st2; g_solve_stamps[4] = __builtin_readcyclecounter(); g_solve_stamps[5] = 0; }
+  if (lead) for (int i = tid; i < n6; i += 64) dX[i] = xs[i];
+  if (stamps && lead && tid == 0) { g_solve_stamps[0] = st0; g_solve_stamps[1] = st1; g_solve_stamps[2] = st2; g_solve_stamps[3] = st2; g_solve_stamps[4] = __builtin_readcyclecounter(); g_solve_stamps[5] = 0; }
+  }
+  if constexpr (FUSED) {
+    // ---- retraction with the solution in LDS (k_ba_retract's arithmetic in its order: the same bits).  One wave per patch, the loads of
+    //      a wave's patches (two at cfg2) in flight together; the lead workgroup's first N threads retract the poses.
+    __syncthreads();
+    const int nw = (int)gridDim.x * 16, w0 = (int)blockIdx.x * 16 + wv;
+    const int PP = ra.P * ra.P;
+    constexpr int UP = 2;
+    for (int sb = w0; sb < n_seg_all; sb += nw * UP) {
+      float c0[UP], c1[UP], q[UP], u[UP], d0[UP];
+      float* pd[UP];
+#pragma unroll
+      for (int k = 0; k < UP; k++) {
+        const int s = sb + k * nw;
+        const bool on = s < n_seg_all;
+        const int sc = on ? s : sb;
+        const float* pc = ra.patch_col + (int64_t)sc * n6;
+        c0[k] = (ln < n6) ? pc[ln] : 0.0f;
+        c1[k] = (ln + 64 < n6) ? pc[ln + 64] : 0.0f;
+        q[k] = ra.patch_rec[(int64_t)sc * 2];
+        u[k] = ra.patch_rec[(int64_t)sc * 2 + 1];
+        pd[k] = ra.patches + ((int64_t)ra.kx[sc] * 3 + 2) * PP;
+        d0[k] = pd[k][0];                                          // reads pixel [0][0] (ba_cuda.cu:198)
+      }
+      const float x0 = (ln < n6) ? xs[ln] : 0.0f, x1 = (ln + 64 < n6) ? xs[ln + 64] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < UP; k++) {
+        if (sb + k * nw >= n_seg_all) break;                       // (wave-uniform)
+        float part = 0.0f;
+        if (N > 0) {
+          if (ln < n6) part += c0[k] * x0;
+          if (ln + 64 < n6) part += c1[k] * x1;
+          part = wave_sum(part);
+        }
+        const float dz = q[k] * (u[k] - part);                     // Q (u - E^T dX)  (ba_cuda.cu:523)
+        float d = d0[k] + dz;
+        d = (d > 20.0f) ? 1.0f : d;
+        d = fmaxf(d, 1e-4f);
+        for (int i = ln; i < PP; i += 64) pd[k][i] = d;
+      }
+    }
+    if (lead && tid < N) {
+      float* p = ra.poses + (int64_t)(ra.t0 + tid) * 7;
+      float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]}, t1[3], q1[4], dx[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) dx[k] = xs[6 * tid + k];
+      fb_retrSE3(dx, tt, qq, t1, q1);
+      p[0] = t1[0]; p[1] = t1[1]; p[2] = t1[2]; p[3] = q1[0]; p[4] = q1[1]; p[5] = q1[2]; p[6] = q1[3];
+    }
+  }
+}
+__global__ __launch_bounds__(1024) void k_ba_solve_chain(const float* __restrict__ S, const float* __restrict__ y, int N,
+                                                         float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps) {
+  ba_solve_chain_body<false>(S, y, N, dX, meta, iter, status_flag, stamps, BaRetract{});
+}
+__global__ __launch_bounds__(1024) void k_ba_solve_retract(const float* __restrict__ S, const float* __restrict__ y, int N,
+                                                           float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps,
+                                                           BaRetract ra) {
+  ba_solve_chain_body<true>(S, y, N, dX, meta, iter, status_flag, stamps, ra);
 }
 
 static_assert(SOLVE_THREADS == 1024, "k_ba_solve_chain is written for 16 waves");
@@ -2623,6 +2694,17 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
     }
   }
   solve_fn_t solve_fn = big ? k_ba_solve_t<true> : ba_solve_fn(N);
+  // round 6: the retraction rides on the solver's launch (k_ba_solve_retract: G workgroups factorise the same system, each retracts its
+  // own patches).  G: two patches per wave, at most 64 workgroups.  DEVO_BA_FUSE_RETRACT=0: the two launches of rounds 1-5.
+  static const bool fuse_env = [] { const char* e = getenv("DEVO_BA_FUSE_RETRACT"); return !(e && e[0] == '0'); }();
+  const bool fuse_retract = fuse_env && N > 0 && solve_fn == k_ba_solve_chain;
+  const int retract_wgs = L.max_seg <= 32 ? 1 : (L.max_seg + 31) / 32 > 64 ? 64 : (L.max_seg + 31) / 32;
+  if (fuse_retract && solve_lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)k_ba_solve_retract, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("devo_ba_forward: cannot reserve %zu bytes of LDS", solve_lds);
+    return DEVO_ERR_LAUNCH;
+  }
   if (acc_lds_used > 64 * 1024 || solve_lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)acc_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds_used) != hipSuccess ||
         hipFuncSetAttribute((const void*)solve_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
@@ -2645,7 +2727,11 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       static const bool ba_trace = getenv("DEVO_BA_TRACE") != nullptr;
       static const int ba_trace_mode = ba_trace ? (atoi(getenv("DEVO_BA_TRACE")) > 1 ? atoi(getenv("DEVO_BA_TRACE")) : 1) : 0;
-      hipLaunchKernelGGL(solve_fn, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace_mode);
+      if (fuse_retract)
+        hipLaunchKernelGGL(k_ba_solve_retract, dim3((unsigned)retract_wgs), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace_mode,
+                           BaRetract{poses, patches, patch_rec, edge_ej, kx, P, t0});
+      else
+        hipLaunchKernelGGL(solve_fn, dim3(1), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace_mode);
       if (ba_trace) {
         unsigned long long h[16];
         (void)hipStreamSynchronize(st);
@@ -2671,9 +2757,11 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       }
       if ((rc = check_launch("devo_ba_forward(solve)"))) return rc;
     }
-    hipLaunchKernelGGL(k_ba_retract, dim3(blocks_for((long long)L.max_seg * 64 > N ? (long long)L.max_seg * 64 : N, 256, 2048)), dim3(256), 0, st, poses, patches, dX, patch_rec,
-                       edge_ej, kx, meta, P, t0, N);
-    if ((rc = check_launch("devo_ba_forward(retract)"))) return rc;
+    if (!fuse_retract) {
+      hipLaunchKernelGGL(k_ba_retract, dim3(blocks_for((long long)L.max_seg * 64 > N ? (long long)L.max_seg * 64 : N, 256, 2048)), dim3(256), 0, st, poses, patches, dX, patch_rec,
+                         edge_ej, kx, meta, P, t0, N);
+      if ((rc = check_launch("devo_ba_forward(retract)"))) return rc;
+    }
   }
   return check_launch("devo_ba_forward");
 }

@@ -306,14 +306,16 @@ TensorList patchify_backward(Tensor net, Tensor coords_, Tensor gradient_, int64
 }
 
 // ------------------------------------------------------------------------------------------------ cuda_ba (ba.cpp:152-157)
-struct WsKey { int E, Np, N, dev; bool operator==(const WsKey& o) const { return E == o.E && Np == o.Np && N == o.N && dev == o.dev; } };
+// One live workspace per (problem size, device, STREAM): two streams never share scratch, and a workspace that is replaced stays alive until
+// the work enqueued on it has run (the caching allocator frees a block for reuse on the stream it was allocated on: a stream-ordered free).
+struct WsKey { int E, Np, N, dev; void* stream; bool operator==(const WsKey& o) const { return E == o.E && Np == o.Np && N == o.N && dev == o.dev && stream == o.stream; } };
 std::mutex g_ws_mu;
-WsKey g_ws_key{-1, -1, -1, -1};
+WsKey g_ws_key{-1, -1, -1, -1, nullptr};
 Tensor g_ws;
 
-Tensor ba_workspace(int E, int Np, int N, const at::Device& dev) {
+Tensor ba_workspace(int E, int Np, int N, const at::Device& dev, void* stream) {
   std::lock_guard<std::mutex> g(g_ws_mu);
-  const WsKey k{E, Np, N, (int)dev.index()};
+  const WsKey k{E, Np, N, (int)dev.index(), stream};
   if (g_ws.defined() && g_ws_key == k) return g_ws;
   const size_t nbytes = devo_ba_workspace_bytes(E, Np, N);
   TORCH_CHECK(nbytes > 0, "cuda_ba: unsupported problem size (E=", E, ", Np=", Np, ", N=", N, "; at most 128 optimised poses)");
@@ -321,6 +323,22 @@ Tensor ba_workspace(int E, int Np, int N, const at::Device& dev) {
   g_ws_key = k;
   return g_ws;
 }
+
+// The index half of cuda_ba.forward (unique patches, edges grouped by patch: ba_cuda.cu:435-437) depends on kk alone, and DEVO calls the BA
+// again and again on one graph (18 update iterations per training sequence, train.py / enet.py:313-361; 12 at initialisation, devo.py:545).
+// The prepared tables of the LAST call are kept with the workspace they live in: key = (kk's storage address and version counter, E, patch
+// slots, window size, workspace, stream); the cache keeps kk and the workspace alive, so an equal key is the same storage with the same
+// contents.  A hit runs devo_ba_forward_prepared: one launch (12.6 us at cfg2) less per call.  Never consulted or filled while the stream is
+// being captured into a graph (a capture executes nothing: the tables would not exist).  DEVO_BA_PREP_CACHE=0 switches it off.
+struct PrepKey {
+  const void* kk = nullptr; uint32_t ver = 0; int64_t E = -1; int Np = -1, N = -1; const void* ws = nullptr; void* stream = nullptr;
+  bool operator==(const PrepKey& o) const { return kk == o.kk && ver == o.ver && E == o.E && Np == o.Np && N == o.N && ws == o.ws && stream == o.stream; }
+};
+std::mutex g_prep_mu;
+PrepKey g_prep_key;
+Tensor g_prep_kk, g_prep_ws;
+int64_t g_prep_hits = 0, g_prep_misses = 0;
+void ba_prep_invalidate() { std::lock_guard<std::mutex> g(g_prep_mu); g_prep_key = PrepKey(); g_prep_kk = Tensor(); g_prep_ws = Tensor(); }
 
 // ba.cpp:153.  Mutates poses ([1,Nbuf,7]) and patches ([1,Np,3,P,P]) in place and returns [] (devo/fastba/ba.py:7-8 passes poses.data;
 // devo/devo.py:337 relies on the mutation).  ws / status / prepared: extras of this package's callers (devo_amd.fastba).
@@ -335,12 +353,23 @@ TensorList ba_forward(Tensor poses, Tensor patches, Tensor intrinsics_, Tensor t
   const int64_t E = ii.numel();
   const Tensor intrinsics = f32c(intrinsics_), target = f32c(target_), weight = f32c(weight_), lmbda = f32c(lmbda_.reshape({-1}));
   TORCH_CHECK(!(prepared && !(ws_.has_value() && ws_->defined())), "cuda_ba.forward: prepared=True needs the workspace that prepare() filled");
-  Tensor ws = (ws_.has_value() && ws_->defined()) ? *ws_ : ba_workspace((int)E, (int)Np, (int)(t1 - t0), poses.device());
+  void* st = stream_of(poses);
+  Tensor ws = (ws_.has_value() && ws_->defined()) ? *ws_ : ba_workspace((int)E, (int)Np, (int)(t1 - t0), poses.device(), st);
   int* status = (status_.has_value() && status_->defined()) ? status_->data_ptr<int>() : nullptr;
+  static const bool prep_cache = !env_off("DEVO_BA_PREP_CACHE");
+  if (!prepared && prep_cache && E > 0 && iterations > 0) {
+    if (devo_stream_capturing(st) != 0) ba_prep_invalidate();          // (a graph replay rewrites the workspace's tables behind the cache's back)
+    else if (!kk_.is_inference()) {
+      const PrepKey k{kk_.data_ptr(), (uint32_t)kk_._version(), E, (int)Np, (int)(t1 - t0), ws.data_ptr(), st};
+      std::lock_guard<std::mutex> g(g_prep_mu);
+      if (g_prep_key == k) { prepared = true; g_prep_hits++; }
+      else { g_prep_key = k; g_prep_kk = kk_; g_prep_ws = ws; g_prep_misses++; }     // this call prepares: the tables are in `ws` behind it
+    }
+  } else if (prepared) ba_prep_invalidate();                           // the caller's own prepare() filled the workspace: not the cached graph's tables
   auto fn = prepared ? devo_ba_forward_prepared : devo_ba_forward;
   check(fn(poses.data_ptr<float>(), patches.data_ptr<float>(), intrinsics.data_ptr<float>(), target.data_ptr<float>(), weight.data_ptr<float>(), lmbda.data_ptr<float>(),
            ii.data_ptr<int64_t>(), jj.data_ptr<int64_t>(), kk.data_ptr<int64_t>(), (int)E, (int)Nbuf, (int)Np, (int)P, (int)t0, (int)t1, (int)iterations, ws.data_ptr(),
-           (size_t)ws.numel(), status, stream_of(poses)), "cuda_ba.forward");
+           (size_t)ws.numel(), status, st), "cuda_ba.forward");
   return {};
 }
 
@@ -534,6 +563,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
          py::arg("lmbda"), py::arg("ii"), py::arg("jj"), py::arg("kk"), py::arg("t0"), py::arg("t1"), py::arg("iterations"), py::arg("ws") = py::none(),
          py::arg("status") = py::none(), py::arg("prepared") = false);
   ba.def("neighbors", &ba_neighbors, "ba.cpp:154");
+  ba.def("_prep_invalidate", &ba_prep_invalidate, "forget the prepared index tables of the last forward() (an explicit prepare() rewrote the workspace)");
+  ba.def("_prep_stats", [] { std::lock_guard<std::mutex> g(g_prep_mu); return std::make_pair(g_prep_hits, g_prep_misses); },
+         "(hits, misses) of forward()'s prepared-table cache since the module was loaded");
   ba.def("last_path", [] {
     static const char* acc[] = {"register", "lds", "global"};
     static const char* sol[] = {"chain", "lds", "global"};

@@ -243,6 +243,11 @@ extern "C" {
 
 int devo_abi_version(void) { return DEVO_ABI_VERSION; }
 const char* devo_last_error(void) { return g_err; }
+int devo_stream_capturing(devo_stream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return st == hipStreamCaptureStatusNone ? 0 : 1;
+}
 
 int devo_se3_exp(const void* a, void* X, int64_t n, int dtype, devo_stream_t s) { SE3_DISPATCH("devo_se3_exp", k_exp, CP(a), MP(X), n); }
 int devo_se3_exp_backward(const void* grad, const void* a, void* da, int64_t n, int dtype, devo_stream_t s) { SE3_DISPATCH("devo_se3_exp_backward", k_exp_bwd, CP(grad), CP(a), MP(da), n); }

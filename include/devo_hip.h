@@ -27,9 +27,13 @@ typedef void* devo_stream_t; /* hipStream_t */
 enum { DEVO_OK = 0, DEVO_ERR_ARG = 1, DEVO_ERR_LAUNCH = 2, DEVO_ERR_UNSUPPORTED = 3, DEVO_ERR_WORKSPACE = 4 };
 enum { DEVO_F32 = 0, DEVO_F16 = 1, DEVO_F64 = 2 };
 
-#define DEVO_ABI_VERSION 2 /* 2: fp32 split formats (devo_corr_pyramid_split, exponents), group plans (plan buffer tail); callers compare with devo_abi_version() */
+#define DEVO_ABI_VERSION 3 /* 2: fp32 split formats (devo_corr_pyramid_split, exponents), group plans (plan buffer tail); 3: per-slot conversions of a ring
+                              (devo_corr_pyramid_split_frames, devo_corr_patch_transpose_range), devo_stream_capturing; callers compare with devo_abi_version() */
 int devo_abi_version(void);
 const char* devo_last_error(void); /* thread-local message of the last failing call */
+/* 1 while `stream` is being captured into a HIP graph (a capture executes nothing: a binding must not cache device state a captured call
+ * would have produced — the prepared BA tables, a locality plan), 0 when it is not, -1 if the runtime cannot tell. */
+int devo_stream_capturing(devo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * altcorr  (reference module cuda_corr: devo/altcorr/correlation.cpp:57-63)

@@ -1,0 +1,162 @@
+"""Round 6 of fastba: the retraction on the solver's launch (k_ba_solve_retract) and cuda_ba.forward's prepared-table cache
+(the index half of ba_cuda.cu:435-437 depends on kk alone; DEVO runs the BA many times on one patch graph).  Both change how the
+work is launched, never a result: everything here is an equality of bits."""
+import os
+import subprocess
+import sys
+import pytest
+import torch
+from devo_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _scene(nk=12, M=48, seed=9, shuffle=False):
+    poses = synth.make_poses(nk, seed).to(DEV)
+    patches = synth.make_patches(nk, M, 120, 160, seed=seed)[0].to(DEV)
+    intr = synth.make_intrinsics(nk, 120, 160).to(DEV)
+    ii, jj, kk = synth.full_graph(nk, M)
+    if shuffle:
+        p = torch.randperm(len(ii), generator=torch.Generator().manual_seed(seed))[: int(0.9 * len(ii))]
+        ii, jj, kk = ii[p], jj[p], kk[p]
+    ii, jj, kk = [t.to(DEV) for t in (ii, jj, kk)]
+    delta, weight = [t.to(DEV) for t in synth.make_update_outputs(len(ii), seed, sigma=0.3)]
+    from devo_amd.backends import cuda_ba
+    c = cuda_ba.transform(poses, patches, intr, ii, jj, kk, layout="2pp")
+    return poses, patches, intr, c[:, :, :, 1, 1] + delta, weight, torch.tensor([1e-4], device=DEV), ii, jj, kk
+
+
+_FUSE_AB = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from devo_amd import synth
+from devo_amd.backends import cuda_ba
+out = {}
+for nk, M, t0, shuffle in ((2, 40, 1, False), (3, 7, 1, False), (8, 300, 1, True), (12, 48, 1, False), (15, 96, 1, False), (15, 96, 5, True), (16, 80, 0, True), (20, 30, 1, False),
+                           (21, 64, 0, True)):
+    poses = synth.make_poses(nk, nk).cuda(); patches = synth.make_patches(nk, M, 120, 160, seed=nk)[0].cuda()
+    intr = synth.make_intrinsics(nk, 120, 160).cuda()
+    ii, jj, kk = synth.full_graph(nk, M)
+    if shuffle:
+        p = torch.randperm(len(ii), generator=torch.Generator().manual_seed(nk))[: int(0.9 * len(ii))]
+        ii, jj, kk = ii[p], jj[p], kk[p]
+    ii, jj, kk = [t.cuda() for t in (ii, jj, kk)]
+    delta, weight = [t.cuda() for t in synth.make_update_outputs(len(ii), nk, sigma=0.3)]
+    c = cuda_ba.transform(poses, patches, intr, ii, jj, kk, layout="2pp")
+    cuda_ba.forward(poses, patches, intr, c[:, :, :, 1, 1] + delta, weight, torch.tensor([1e-4]).cuda(), ii, jj, kk, t0, nk, 2)
+    out[f"{nk}_{M}_{t0}"] = (poses.cpu(), patches.cpu(), cuda_ba.last_path())
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_the_retraction_on_the_solvers_launch_changes_no_bit(tmp_path):
+    """k_ba_solve_retract (G workgroups factorise the same system, each retracts its own patches from the solution in its LDS) against the
+    two launches of rounds 1-5 (DEVO_BA_FUSE_RETRACT=0; read once per process: sub-processes) — windows of 1 .. 21 optimised poses, more
+    patches than one workgroup's waves, shuffled edge lists, t0 = 0 / 1 / 5.  Up to 16 optimised poses every summation order is fixed:
+    the same bits; beyond, the general accumulate kernel's atomics move the last bits of the system itself."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for fuse in (True, False):
+        env = dict(os.environ)
+        env.pop("DEVO_BA_FUSE_RETRACT", None)
+        if not fuse:
+            env["DEVO_BA_FUSE_RETRACT"] = "0"
+        path = str(tmp_path / f"fuse_{int(fuse)}.pt")
+        r = subprocess.run([sys.executable, "-c", _FUSE_AB, root, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res.append(torch.load(path))
+    assert res[0].keys() == res[1].keys()
+    for k in res[0]:
+        nk, _, t0 = (int(x) for x in k.split("_"))
+        assert torch.isfinite(res[0][k][0]).all() and torch.isfinite(res[0][k][1]).all()
+        if nk - t0 <= 16:
+            assert torch.equal(res[0][k][0], res[1][k][0]) and torch.equal(res[0][k][1], res[1][k][1]), k
+        else:
+            assert torch.allclose(res[0][k][0], res[1][k][0], atol=1e-4) and torch.allclose(res[0][k][1], res[1][k][1], atol=1e-4), k
+
+
+def test_forward_remembers_the_index_tables_of_an_unchanged_kk():
+    """cuda_ba.forward without a workspace argument (the reference's call, ba.cpp:153): the second call on the same kk tensor takes the
+    prepared tables of the first (one launch less), an in-place edit of kk (version counter) or another tensor rebuilds them, and the
+    results are the bits of a call that prepares."""
+    from devo_amd.backends import cuda_ba
+    poses, patches, intr, target, weight, lm, ii, jj, kk = _scene(shuffle=True)
+    cuda_ba.prep_invalidate()
+    h0, m0 = cuda_ba.prep_stats()
+
+    def run(kk_):
+        P, Q = poses.clone(), patches.clone()
+        cuda_ba.forward(P, Q, intr, target, weight, lm, ii, jj, kk_, 1, 12, 2)
+        return P, Q
+
+    a = run(kk)
+    assert cuda_ba.prep_stats() == (h0, m0 + 1)
+    b = run(kk)
+    c = run(kk)
+    assert cuda_ba.prep_stats() == (h0 + 2, m0 + 1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    # the same values in another tensor: a miss (nothing is assumed about storage the cache does not hold)
+    d = run(kk.clone())
+    assert cuda_ba.prep_stats() == (h0 + 2, m0 + 2) and torch.equal(a[0], d[0]) and torch.equal(a[1], d[1])
+    # an in-place edit bumps the version counter: the tables are rebuilt for the NEW contents
+    kk2 = kk.clone()
+    ref_before = run(kk2)
+    h1, m1 = cuda_ba.prep_stats()
+    swap = torch.randperm(len(kk2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    kk2.copy_(kk2[swap])                                       # the same multiset of patches on other edges: another graph
+    got = run(kk2)
+    assert cuda_ba.prep_stats() == (h1, m1 + 1)
+    P, Q = poses.clone(), patches.clone()
+    ws = cuda_ba.workspace(len(ii), patches.shape[1], 11, DEV)
+    cuda_ba.prepare(kk2, patches.shape[1], 11, ws)
+    cuda_ba.forward(P, Q, intr, target, weight, lm, ii, jj, kk2, 1, 12, 2, ws=ws, prepared=True)
+    assert torch.equal(got[0], P) and torch.equal(got[1], Q) and not torch.equal(got[0], ref_before[0])
+
+
+def test_an_explicit_prepare_or_a_capture_never_leaves_stale_tables_behind():
+    """prepare() on any workspace drops what forward() remembers; a call captured into a HIP graph neither consults nor fills the cache
+    (a capture executes nothing) and the replayed graph prepares by itself."""
+    from devo_amd.backends import cuda_ba
+    poses, patches, intr, target, weight, lm, ii, jj, kk = _scene(nk=10, M=40, seed=4)
+    P0, Q0 = poses.clone(), patches.clone()
+    cuda_ba.forward(P0, Q0, intr, target, weight, lm, ii, jj, kk, 1, 10, 2)
+    h, m = cuda_ba.prep_stats()
+    ws = cuda_ba.workspace(len(ii), patches.shape[1], 9, DEV)
+    cuda_ba.prepare(kk, patches.shape[1], 9, ws)
+    P1, Q1 = poses.clone(), patches.clone()
+    cuda_ba.forward(P1, Q1, intr, target, weight, lm, ii, jj, kk, 1, 10, 2)
+    assert cuda_ba.prep_stats() == (h, m + 1) and torch.equal(P0, P1) and torch.equal(Q0, Q1)
+    # capture
+    Pg, Qg = poses.clone(), patches.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            cuda_ba.forward(Pg, Qg, intr, target, weight, lm, ii, jj, kk, 1, 10, 2)
+    torch.cuda.current_stream().wait_stream(s)
+    h2, m2 = cuda_ba.prep_stats()
+    assert (h2, m2) == (h, m + 1)                             # neither a hit nor a miss was counted during the capture
+    Pg.copy_(poses); Qg.copy_(patches)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(Pg, P0) and torch.equal(Qg, Q0)
+    P2, Q2 = poses.clone(), patches.clone()
+    cuda_ba.forward(P2, Q2, intr, target, weight, lm, ii, jj, kk, 1, 10, 2)      # after the capture: a miss (the cache was dropped), same bits
+    assert cuda_ba.prep_stats() == (h, m + 2) and torch.equal(P2, P0) and torch.equal(Q2, Q0)
+
+
+def test_a_ba_call_is_at_most_seven_launches():
+    """north_star / verdict r05 item 1: accumulate + reduce + (solve | retract) per Gauss-Newton iteration, the index tables once per graph."""
+    from torch.profiler import profile, ProfilerActivity
+    from devo_amd.backends import cuda_ba
+    poses, patches, intr, target, weight, lm, ii, jj, kk = _scene(nk=15, M=96, seed=2)
+    P, Q = poses.clone(), patches.clone()
+    cuda_ba.forward(P, Q, intr, target, weight, lm, ii, jj, kk, 1, 15, 2)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        cuda_ba.forward(P, Q, intr, target, weight, lm, ii, jj, kk, 1, 15, 2)
+        torch.cuda.synchronize()
+    names = [ev.name for ev in prof.events() if "cuda" in str(getattr(ev, "device_type", "")).lower() and "k_ba" in ev.name]
+    assert len(names) == 6 and sum("solve_retract" in n for n in names) == 2 and not any("k_ba_retract" in n or "prepare" in n for n in names), names

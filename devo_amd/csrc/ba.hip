@@ -1597,6 +1597,29 @@ __device__ __forceinline__ void ba_solve_chain_body(const float* __restrict__ S,
   extern __shared__ __attribute__((aligned(16))) float A[];
   const bool lead = blockIdx.x == 0;                              // (the only workgroup of the unfused launch)
   const int n_seg_all = FUSED ? meta->n_seg : 0;
+  // FUSED: what the retraction of this wave's first patches needs (their E columns, (Q, u), the depth they hold now) is requested here and
+  // arrives under the factorisation — two dependent round trips to memory (~2 us) less behind it.  Nothing the solver writes is read.
+  constexpr int UP = 2;
+  const int nw = (int)gridDim.x * 16, w0 = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6);
+  float pre_c0[UP] = {0.0f, 0.0f}, pre_c1[UP] = {0.0f, 0.0f}, pre_q[UP] = {0.0f, 0.0f}, pre_u[UP] = {0.0f, 0.0f}, pre_d0[UP] = {0.0f, 0.0f};
+  float* pre_pd[UP] = {nullptr, nullptr};
+  if constexpr (FUSED) {
+    const int n6p = 6 * N, lnp = threadIdx.x & 63;
+    if (w0 < n_seg_all) {
+#pragma unroll
+      for (int k = 0; k < UP; k++) {
+        const int s = w0 + k * nw;
+        const int sc = s < n_seg_all ? s : w0;
+        const float* pc = ra.patch_col + (int64_t)sc * n6p;
+        pre_c0[k] = (lnp < n6p) ? pc[lnp] : 0.0f;
+        pre_c1[k] = (lnp + 64 < n6p) ? pc[lnp + 64] : 0.0f;
+        pre_q[k] = ra.patch_rec[(int64_t)sc * 2];
+        pre_u[k] = ra.patch_rec[(int64_t)sc * 2 + 1];
+        pre_pd[k] = ra.patches + ((int64_t)ra.kx[sc] * 3 + 2) * (ra.P * ra.P);
+        pre_d0[k] = pre_pd[k][0];
+      }
+    }
+  }
   __shared__ int s_fail;
   __shared__ float s_dump[64];
   const int n6 = 6 * N, LDG = n6 + 1, LD = solve_ld(n6), rows = n6 + 1;
@@ -1895,26 +1918,28 @@ __device__ __forceinline__ void ba_solve_chain_body(const float* __restrict__ S,
     // ---- retraction with the solution in LDS (k_ba_retract's arithmetic in its order: the same bits).  One wave per patch, the loads of
     //      a wave's patches (two at cfg2) in flight together; the lead workgroup's first N threads retract the poses.
     __syncthreads();
-    const int nw = (int)gridDim.x * 16, w0 = (int)blockIdx.x * 16 + wv;
     const int PP = ra.P * ra.P;
-    constexpr int UP = 2;
+    const float x0 = (ln < n6) ? xs[ln] : 0.0f, x1 = (ln + 64 < n6) ? xs[ln + 64] : 0.0f;
     for (int sb = w0; sb < n_seg_all; sb += nw * UP) {
       float c0[UP], c1[UP], q[UP], u[UP], d0[UP];
       float* pd[UP];
+      if (sb == w0) {                                              // the wave's first patches: fetched before the factorisation
 #pragma unroll
-      for (int k = 0; k < UP; k++) {
-        const int s = sb + k * nw;
-        const bool on = s < n_seg_all;
-        const int sc = on ? s : sb;
-        const float* pc = ra.patch_col + (int64_t)sc * n6;
-        c0[k] = (ln < n6) ? pc[ln] : 0.0f;
-        c1[k] = (ln + 64 < n6) ? pc[ln + 64] : 0.0f;
-        q[k] = ra.patch_rec[(int64_t)sc * 2];
-        u[k] = ra.patch_rec[(int64_t)sc * 2 + 1];
-        pd[k] = ra.patches + ((int64_t)ra.kx[sc] * 3 + 2) * PP;
-        d0[k] = pd[k][0];                                          // reads pixel [0][0] (ba_cuda.cu:198)
+        for (int k = 0; k < UP; k++) { c0[k] = pre_c0[k]; c1[k] = pre_c1[k]; q[k] = pre_q[k]; u[k] = pre_u[k]; d0[k] = pre_d0[k]; pd[k] = pre_pd[k]; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < UP; k++) {
+          const int s = sb + k * nw;
+          const int sc = s < n_seg_all ? s : sb;
+          const float* pc = ra.patch_col + (int64_t)sc * n6;
+          c0[k] = (ln < n6) ? pc[ln] : 0.0f;
+          c1[k] = (ln + 64 < n6) ? pc[ln + 64] : 0.0f;
+          q[k] = ra.patch_rec[(int64_t)sc * 2];
+          u[k] = ra.patch_rec[(int64_t)sc * 2 + 1];
+          pd[k] = ra.patches + ((int64_t)ra.kx[sc] * 3 + 2) * PP;
+          d0[k] = pd[k][0];                                        // reads pixel [0][0] (ba_cuda.cu:198)
+        }
       }
-      const float x0 = (ln < n6) ? xs[ln] : 0.0f, x1 = (ln + 64 < n6) ? xs[ln + 64] : 0.0f;
 #pragma unroll
       for (int k = 0; k < UP; k++) {
         if (sb + k * nw >= n_seg_all) break;                       // (wave-uniform)
@@ -2695,10 +2720,12 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   }
   solve_fn_t solve_fn = big ? k_ba_solve_t<true> : ba_solve_fn(N);
   // round 6: the retraction rides on the solver's launch (k_ba_solve_retract: G workgroups factorise the same system, each retracts its
-  // own patches).  G: two patches per wave, at most 64 workgroups.  DEVO_BA_FUSE_RETRACT=0: the two launches of rounds 1-5.
+  // own patches).  G: one patch per wave, at most 128 workgroups.  DEVO_BA_FUSE_RETRACT=0: the two launches of rounds 1-5.
   static const bool fuse_env = [] { const char* e = getenv("DEVO_BA_FUSE_RETRACT"); return !(e && e[0] == '0'); }();
   const bool fuse_retract = fuse_env && N > 0 && solve_fn == k_ba_solve_chain;
-  const int retract_wgs = L.max_seg <= 32 ? 1 : (L.max_seg + 31) / 32 > 64 ? 64 : (L.max_seg + 31) / 32;
+  static const int wgs_env = [] { const char* e = getenv("DEVO_BA_RETRACT_WGS"); return e ? atoi(e) : 0; }();   // (tuning switch)
+  // (measured at cfg2, 1 440 patches, rocprofv3: G = 1 / 4 / 12 / 23 / 45 / 90 / 180 -> 93.9 / 37.5 / 24.7 / 21.3 / 19.6 / 19.2 / 19.1 us; the solver alone 19.5)
+  const int retract_wgs = wgs_env > 0 ? wgs_env : L.max_seg <= 16 ? 1 : (L.max_seg + 15) / 16 > 128 ? 128 : (L.max_seg + 15) / 16;
   if (fuse_retract && solve_lds > 64 * 1024 &&
       hipFuncSetAttribute((const void*)k_ba_solve_retract, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
     (void)hipGetLastError();

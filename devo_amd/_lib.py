@@ -31,6 +31,8 @@ _SIGNATURES = {
     "devo_corr_patch_operand_bytes": [_i, _i, _i],
     "devo_corr_patch_transpose": [_vp, _vp, _i, _i, _i, _vp],
     "devo_corr_pyramid_split": [_vp, _c_i64p, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp],
+    "devo_corr_pyramid_split_frames": [_vp, _c_i64p, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp],
+    "devo_corr_patch_transpose_range": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "devo_pyramid_build": [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i, _vp],
     "devo_corr_order": [_vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_float, _i, _i, _i, _vp],
     "devo_corr_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _c_i64p, _i64, _i, _i, _vp, ctypes.c_size_t, _vp],

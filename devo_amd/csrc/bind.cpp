@@ -16,6 +16,7 @@
 #include <c10/core/DeviceGuard.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <cstdlib>
+#include <algorithm>
 #include <list>
 #include <mutex>
 #include <string>
@@ -87,6 +88,79 @@ struct Lru {
 };
 Lru g_levels(4), g_patches(4), g_cl(4);
 
+// ---- per-slot maintenance of a converted ring (round 6).  The reference writes ONE slot of its ring buffers per frame
+// (`self.fmap1_[:, self.n % self.mem] = ...`, `self.gmap_[self.n % self.mem] = ...`: devo/devo.py:523-527; keyframe removal moves a few
+// slots, :288-291) and then looks the whole ring up: re-converting 32 frames for one new one costs as much as the fp16 lookup itself.
+// devo_amd.backends.install() wraps torch.Tensor.__setitem__ (devo_amd/backends/ring.py): a write into a tensor this cache holds a
+// converted copy of is RECORDED here — (version counter after the write, element range) — and a later lookup whose key differs from a
+// cached entry only in the version converts just the frames / patches the recorded writes touched, PROVIDED every version in between is
+// accounted for by a record with a known range (each __setitem__ bumps the counter by exactly one; any other in-place operation leaves a
+// gap and the whole tensor is converted again, as in rounds 1-5).  Sound by construction: nothing is assumed about unrecorded writes.
+struct WriteRec { uint32_t version; int64_t off, len; };              // elements from the tensor's data_ptr; len < 0: region unknown
+std::mutex g_wr_mu;
+std::vector<std::pair<const void*, std::vector<WriteRec>>> g_writes;  // a handful of tensors: linear search
+struct ConvStats { int64_t level_full = 0, level_frames = 0, patch_full = 0, patch_ranges = 0, patches_partial = 0; } g_conv;
+constexpr size_t MAX_WRITE_RECS = 512;
+
+bool is_tracked(const void* ptr) {
+  for (Lru* c : {&g_levels, &g_patches}) {
+    std::lock_guard<std::mutex> g(c->mu);
+    for (const auto& e : c->items) if (e.key.ptr == ptr) return true;
+  }
+  return false;
+}
+void note_write(const void* ptr, uint32_t version_after, int64_t off, int64_t len) {
+  std::lock_guard<std::mutex> g(g_wr_mu);
+  for (auto& kv : g_writes)
+    if (kv.first == ptr) {
+      if (kv.second.size() >= MAX_WRITE_RECS) kv.second.clear();     // (a gap: the next lookup converts everything)
+      kv.second.push_back({version_after, off, len});
+      return;
+    }
+  g_writes.push_back({ptr, {{version_after, off, len}}});
+}
+void forget_writes(const void* ptr, uint32_t upto) {                  // records of versions <= upto are spent
+  std::lock_guard<std::mutex> g(g_wr_mu);
+  for (auto it = g_writes.begin(); it != g_writes.end(); ++it)
+    if (it->first == ptr) {
+      auto& v = it->second;
+      v.erase(std::remove_if(v.begin(), v.end(), [&](const WriteRec& r) { return (int32_t)(r.version - upto) <= 0; }), v.end());
+      if (v.empty()) g_writes.erase(it);
+      return;
+    }
+}
+// every version in (v0, v1] has a record with a known range -> their ranges; else false
+bool writes_between(const void* ptr, uint32_t v0, uint32_t v1, std::vector<std::pair<int64_t, int64_t>>* ranges) {
+  const uint32_t need = v1 - v0;
+  if (need == 0 || need > MAX_WRITE_RECS) return false;
+  std::lock_guard<std::mutex> g(g_wr_mu);
+  for (auto& kv : g_writes)
+    if (kv.first == ptr) {
+      std::vector<char> seen(need, 0);
+      for (const WriteRec& r : kv.second) {
+        const uint32_t d = r.version - v0 - 1;                         // 0 .. need - 1 for the versions wanted
+        if (d >= need) continue;
+        if (r.len < 0 || seen[d]) return false;
+        seen[d] = 1;
+        ranges->push_back({r.off, r.off + r.len});
+      }
+      for (char c : seen) if (!c) return false;
+      return true;
+    }
+  return false;
+}
+// an entry of the same tensor (storage, shape, strides, dtype, flavour) at an OLDER version
+bool find_older(Lru& c, const VersionKey& k, Entry* out) {
+  std::lock_guard<std::mutex> g(c.mu);
+  for (auto& e : c.items)
+    if (e.key.ptr == k.ptr && e.key.flavour == k.flavour && e.key.dtype == k.dtype && e.key.sizes == k.sizes && e.key.strides == k.strides && e.key.version != k.version) {
+      *out = e;
+      return true;
+    }
+  return false;
+}
+bool slot_updates() { static const bool on = !env_off("DEVO_RING_SLOTS"); return on; }
+
 constexpr int64_t PLAN_MIN_EDGES = 2048, NCHW_CONVERT_MIN_EDGES = 1024;
 bool mm_kernel() { static const bool on = !env_off("DEVO_CORR_MM") && !env_off("DEVO_CORR_MFMA"); return on; }
 
@@ -122,7 +196,43 @@ Level fast_level(const Tensor& fmap2, int64_t n_edges, bool allow_split) {
   Entry e;
   if (g_levels.get(k, &e)) return describe(e.a, e.b, C, want_split);
   void* st = stream_of(fmap2);
+  // the same ring at an older version whose every write since is on record: convert the frames those writes touched, in place
+  if (slot_updates() && !blocked && fmap2.is_contiguous() && find_older(g_levels, k, &e) && devo_stream_capturing(st) == 0) {
+    std::vector<std::pair<int64_t, int64_t>> ranges;
+    if (writes_between(k.ptr, (uint32_t)e.key.version, (uint32_t)k.version, &ranges)) {
+      const int64_t per = (int64_t)C * H * W, total = B * n;
+      std::vector<char> dirty((size_t)total, 0);
+      for (auto& r : ranges)
+        for (int64_t f = std::max<int64_t>(0, r.first / per); f < total && f * per < r.second; f++) dirty[(size_t)f] = 1;
+      const int64_t es = fmap2.element_size();
+      for (int64_t f = 0; f < total; f++) {
+        if (!dirty[(size_t)f]) continue;
+        int64_t f1 = f;
+        while (f1 + 1 < total && dirty[(size_t)(f1 + 1)] && (f1 + 1) / n == f / n) f1++;              // a run of frames of one batch entry
+        const int64_t b = f / n, f0 = f - b * n, cnt = f1 - f + 1;
+        const char* src = (const char*)fmap2.data_ptr() + (b * fmap2.stride(0) + f0 * fmap2.stride(1)) * es;
+        char* dst = (char*)e.a.data_ptr() + (b * e.a.stride(0) + f0 * e.a.stride(1)) * es;
+        if (want_split) {
+          const int64_t f2s[4] = {fmap2.stride(1), fmap2.stride(2), fmap2.stride(3), fmap2.stride(4)};
+          Tensor scratch = at::empty({cnt}, e.b.options());
+          check(devo_corr_pyramid_split_frames(src, f2s, 0, (int)cnt, C, (int)H, (int)W, dst, e.a.stride(1), e.b.data_ptr<int>() + b * n + f0, scratch.data_ptr<int>(), st),
+                "cuda_corr: fp32 ring slot -> split-blocked");
+        } else {
+          check(devo_pyramid_build(src, dst, nullptr, (int)cnt, C, (int)H, (int)W, fmap2.stride(1), e.a.stride(1), 0, dtype_code(fmap2), st), "cuda_corr: NCHW ring slot -> channel-blocked");
+        }
+        g_conv.level_frames += cnt;
+        f = f1;
+      }
+      e.key = k; e.src = fmap2;
+      g_levels.put(e);                                          // (replaces the older version's entry: same converted tensors)
+      forget_writes(k.ptr, (uint32_t)k.version);
+      return describe(e.a, e.b, C, want_split);
+    }
+  }
+  e = Entry();
   e.key = k; e.src = fmap2;
+  g_conv.level_full++;
+  forget_writes(k.ptr, (uint32_t)k.version);
   if (want_split) {
     e.a = at::empty({B, n, C / 8, H, W, 8}, fmap2.options());
     e.b = at::empty({B * n + n}, fmap2.options().dtype(at::kInt));
@@ -150,9 +260,29 @@ Tensor patch_operand(const Tensor& fmap1) {            // undefined: the lookup 
   Entry e;
   if (g_patches.get(k, &e)) return e.a;
   const int64_t n = fmap1.size(0) * fmap1.size(1);
+  void* st = stream_of(fmap1);
+  if (slot_updates() && fmap1.is_contiguous() && find_older(g_patches, k, &e) && devo_stream_capturing(st) == 0) {   // (see fast_level)
+    std::vector<std::pair<int64_t, int64_t>> ranges;
+    if (writes_between(k.ptr, (uint32_t)e.key.version, (uint32_t)k.version, &ranges)) {
+      const int64_t per = C * 9;
+      for (auto& r : ranges) {
+        const int64_t p0 = std::max<int64_t>(0, r.first / per), p1 = std::min<int64_t>(n, (r.second + per - 1) / per);
+        if (p1 <= p0) continue;
+        check(devo_corr_patch_transpose_range(fmap1.data_ptr(), e.a.data_ptr(), (int)n, (int)p0, (int)(p1 - p0), (int)C, dtype_code(fmap1), st), "cuda_corr.patches_transposed (slot)");
+        g_conv.patch_ranges++; g_conv.patches_partial += p1 - p0;
+      }
+      e.key = k; e.src = fmap1;
+      g_patches.put(e);
+      forget_writes(k.ptr, (uint32_t)k.version);
+      return e.a;
+    }
+  }
+  e = Entry();
   const size_t nbytes = devo_corr_patch_operand_bytes((int)n, (int)C, dtype_code(fmap1));
   TORCH_CHECK(nbytes > 0, "cuda_corr: C = ", C, " unsupported by the patch operand (C % 8)");
   e.key = k; e.src = fmap1;
+  g_conv.patch_full++;
+  forget_writes(k.ptr, (uint32_t)k.version);
   e.a = at::empty({(int64_t)nbytes}, fmap1.options().dtype(at::kByte));
   check(devo_corr_patch_transpose(fmap1.data_ptr(), e.a.data_ptr(), (int)n, (int)C, dtype_code(fmap1), stream_of(fmap1)), "cuda_corr.patches_transposed");
   g_patches.put(e);
@@ -194,7 +324,10 @@ void corr_forward_into(Tensor& out, const Tensor& fmap1_, const Tensor& fmap2, c
     // the one that made it, and only for the same jj tensor (storage, version, size), frame count and stream.
     auto& last = g_last_plan;
     void* st = stream_of(coords);
-    if (last.plan.defined() && last.jj == jj_.data_ptr() && last.ver == jj_._version() && last.BE == B * E && last.n == lv.n && last.radius == radius && last.stream == st &&
+    if (devo_stream_capturing(st) != 0) {                     // a capture executes nothing: a plan made now holds garbage until the graph runs
+      last = LastPlan();                                      // — neither handed on nor taken over
+      order = make_plan(coords, jj, lv.n, lv.H, (float)coord_div, radius);
+    } else if (last.plan.defined() && last.jj == jj_.data_ptr() && last.ver == jj_._version() && last.BE == B * E && last.n == lv.n && last.radius == radius && last.stream == st &&
         last.plan.device() == coords.device()) {
       order = last.plan;
       last.plan = Tensor();
@@ -489,8 +622,10 @@ c10::optional<Tensor> corr_patch_operand(Tensor fmap1) {
 void clear_caches() {
   g_levels.clear(); g_patches.clear(); g_cl.clear();
   g_last_plan = LastPlan();
+  ba_prep_invalidate();
+  { std::lock_guard<std::mutex> g(g_wr_mu); g_writes.clear(); }
   std::lock_guard<std::mutex> g(g_ws_mu);
-  g_ws = Tensor(); g_ws_key = WsKey{-1, -1, -1, -1};
+  g_ws = Tensor(); g_ws_key = WsKey{-1, -1, -1, -1, nullptr};
 }
 
 // torch.ops forms of the in-place / list-returning functions
@@ -557,6 +692,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   corr.def("_fast_layout", &corr_fast_layout, py::arg("fmap2"), py::arg("n_edges"), py::arg("allow_split") = true);
   corr.def("_patch_operand", &corr_patch_operand);
   corr.def("_cached_levels", []() { std::lock_guard<std::mutex> g(g_levels.mu); return (int64_t)g_levels.items.size(); });
+  corr.def("_is_tracked", [](int64_t ptr) { return is_tracked((const void*)(intptr_t)ptr); }, "does the cache hold a converted copy of the tensor at this address?");
+  corr.def("_note_write", [](int64_t ptr, int64_t version_after, int64_t off, int64_t len) { note_write((const void*)(intptr_t)ptr, (uint32_t)version_after, off, len); },
+           "a __setitem__ wrote elements [off, off + len) of the tensor at `ptr` and left its version counter at `version_after` (len < 0: region unknown)");
+  corr.def("_convert_stats", [] {
+    return std::make_tuple(g_conv.level_full, g_conv.level_frames, g_conv.patch_full, g_conv.patch_ranges, g_conv.patches_partial);
+  }, "(whole levels converted, single frames converted, whole patch operands, patch ranges, patches in them) since the module was loaded");
 
   auto ba = m.def_submodule("cuda_ba", "devo/fastba/ba.cpp:152-157");
   ba.def("forward", &ba_forward, "ba.cpp:153 (in place, returns [])", py::arg("poses"), py::arg("patches"), py::arg("intrinsics"), py::arg("target"), py::arg("weight"),

@@ -1215,18 +1215,25 @@ size_t devo_corr_patch_operand_bytes(int n_patches, int C, int dtype) {
 }
 
 int devo_corr_patch_transpose(const void* fmap1, void* fmap1_t, int n_patches, int C, int dtype, devo_stream_t stream) {
+  return devo_corr_patch_transpose_range(fmap1, fmap1_t, n_patches, 0, n_patches, C, dtype, stream);
+}
+
+// patches [first, first + count) of an operand of n_patches: DEVO rewrites ONE frame's patches (gmap_[slot] = ..., devo.py:524) per frame
+int devo_corr_patch_transpose_range(const void* fmap1, void* fmap1_t, int n_patches, int first, int count, int C, int dtype, devo_stream_t stream) {
   DEVO_REQUIRE(n_patches >= 0 && C > 0 && C % 8 == 0, "devo_corr_patch_transpose: bad sizes (C must be a multiple of 8)");
+  DEVO_REQUIRE(first >= 0 && count >= 0 && first + count <= n_patches, "devo_corr_patch_transpose_range: patches [%d, %d) of %d", first, first + count, n_patches);
   DEVO_REQUIRE(dtype == DEVO_F32 || dtype == DEVO_F16, "devo_corr_patch_transpose: fp32 / fp16 only");
-  if (n_patches == 0) return DEVO_OK;
+  if (count == 0) return DEVO_OK;
   DEVO_REQUIRE(fmap1 && fmap1_t, "devo_corr_patch_transpose: null tensor");
   const size_t lds = (size_t)C * PP * (dtype == DEVO_F32 ? 4 : 2);
   DEVO_REQUIRE(lds <= 48 * 1024, "devo_corr_patch_transpose: C = %d too large", C);
+  const size_t per = (size_t)C * PP;                                  // elements per patch, source and operand alike
   if (dtype == DEVO_F32)
-    hipLaunchKernelGGL(corr_patch_transpose_kernel<float>, dim3((unsigned)n_patches), dim3(256), lds, (hipStream_t)stream, (const float*)fmap1, (float*)fmap1_t,
-                       reinterpret_cast<int*>(static_cast<char*>(fmap1_t) + (size_t)n_patches * C * PP * 4), n_patches, C);
+    hipLaunchKernelGGL(corr_patch_transpose_kernel<float>, dim3((unsigned)count), dim3(256), lds, (hipStream_t)stream, (const float*)fmap1 + per * first,
+                       (float*)fmap1_t + per * first, reinterpret_cast<int*>(static_cast<char*>(fmap1_t) + (size_t)n_patches * per * 4) + first, count, C);
   else
-    hipLaunchKernelGGL(corr_patch_transpose_kernel<__half>, dim3((unsigned)n_patches), dim3(256), lds, (hipStream_t)stream, (const __half*)fmap1, (__half*)fmap1_t,
-                       (int*)nullptr, n_patches, C);
+    hipLaunchKernelGGL(corr_patch_transpose_kernel<__half>, dim3((unsigned)count), dim3(256), lds, (hipStream_t)stream, (const __half*)fmap1 + per * first,
+                       (__half*)fmap1_t + per * first, (int*)nullptr, count, C);
   return check_launch("devo_corr_patch_transpose");
 }
 
@@ -1289,13 +1296,20 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
 
 int devo_corr_pyramid_split(const void* fmap2, const int64_t* f2s, int cblock, int F, int C, int H, int W, void* dst, int64_t dst_fstride,
                             int* exps, devo_stream_t stream) {
+  return devo_corr_pyramid_split_frames(fmap2, f2s, cblock, F, C, H, W, dst, dst_fstride, exps, exps ? exps + F : nullptr, stream);
+}
+
+// the same with the F ints of scratch given separately: frames [k, k + F) of a ring keep their exponents at exps_ring + k while their
+// neighbours' stay untouched (fmap1_[:, slot] = ..., devo.py:526: one slot per frame)
+int devo_corr_pyramid_split_frames(const void* fmap2, const int64_t* f2s, int cblock, int F, int C, int H, int W, void* dst, int64_t dst_fstride,
+                                   int* exps, int* scratch, devo_stream_t stream) {
   DEVO_REQUIRE(F >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "devo_corr_pyramid_split: bad sizes (C must be a multiple of 8)");
   DEVO_REQUIRE(f2s != nullptr && cblock >= 0 && (cblock <= 1 || C % cblock == 0), "devo_corr_pyramid_split: bad layout description");
   if (F == 0) return DEVO_OK;
-  DEVO_REQUIRE(fmap2 && dst && exps, "devo_corr_pyramid_split: null tensor");
+  DEVO_REQUIRE(fmap2 && dst && exps && scratch, "devo_corr_pyramid_split: null tensor");
   DEVO_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && dst_fstride % 4 == 0 && dst_fstride >= (int64_t)C * H * W, "devo_corr_pyramid_split: dst must be 16-byte aligned frames of C*H*W elements");
   hipStream_t st = (hipStream_t)stream;
-  unsigned* maxbits = reinterpret_cast<unsigned*>(exps + F);
+  unsigned* maxbits = reinterpret_cast<unsigned*>(scratch);
   if (hipMemsetAsync(maxbits, 0, (size_t)F * 4, st) != hipSuccess) { (void)hipGetLastError(); set_error("devo_corr_pyramid_split: memset failed"); return DEVO_ERR_LAUNCH; }
   const SplitSrc S{f2s[0], f2s[1], f2s[2], f2s[3], cblock};
   const long long per = (long long)(C / 8) * H * W;

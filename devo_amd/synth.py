@@ -65,6 +65,29 @@ def full_graph(n, M, n_frames=None):
     return ii, jj, kk
 
 
+def sliding_window_graph(n, M, lifetime=13, removal=22, n_first=0):
+    """The patch graph DEVO's inference holds after n keyframes (config/default.yaml: PATCH_LIFETIME 13, REMOVAL_WINDOW 22), built the way
+    devo/devo.py builds it, frame by frame: for every new keyframe f the forward edges (patches of frames f - 12 .. f - 1 -> frame f,
+    devo.py:366-372) and the backward edges (the new frame's patches -> frames f - 12 .. f, :374-380) are appended (:228-231), then the
+    edges whose patch lives in a frame older than n - removal are dropped (:304-306), order kept.  Frames [n_first, n).
+    Returns ii (source frame = ix[kk]), jj (target frame), kk (global patch index frame * M + m): ~45 k edges at M = 96 once n >= 35; kk is
+    NOT sorted and indices grow past mem * M / mem — the lookups see them modulo the ring (devo.py:213-214)."""
+    ii, jj, kk = [], [], []
+    for f in range(n_first, n):
+        nn = f + 1                                               # self.n after the increment of devo.py:537
+        t0, t1 = M * max(nn - lifetime, 0), M * max(nn - 1, 0)
+        k_f = torch.arange(t0, t1).repeat_interleave(1)           # flatmeshgrid(patches, [f]): every patch once
+        kk.append(k_f); jj.append(torch.full_like(k_f, f))
+        k_b = torch.arange(M * (nn - 1), M * nn)
+        j_b = torch.arange(max(nn - lifetime, 0), nn)
+        kk.append(k_b.repeat_interleave(len(j_b))); jj.append(j_b.repeat(len(k_b)))
+        kk_all, jj_all = torch.cat(kk), torch.cat(jj)
+        keep = (kk_all // M) >= nn - removal
+        kk, jj = [kk_all[keep]], [jj_all[keep]]
+    kk, jj = kk[0], jj[0]
+    return kk // M, jj, kk
+
+
 def make_features(n, M, C, H, W, centres, seed=1234, dtype=torch.float32):
     """fmap ~ N(0,1)/4 (enet.py:124 '/4.0'); gmap = 3x3 integer patches of fmap at the centres."""
     g = _gen(seed + 2)

@@ -95,6 +95,10 @@ int devo_corr_forward_pyramid2(const void* fmap1, const void* fmap2_l0, const vo
  * features of DEVO change once per frame, not per update iteration: convert once, reuse.  DEVO_F32 / DEVO_F16. */
 size_t devo_corr_patch_operand_bytes(int n_patches, int C, int dtype);
 int devo_corr_patch_transpose(const void* fmap1, void* fmap1_t, int n_patches, int C, int dtype, devo_stream_t stream);
+/* The same for patches [first, first + count) of an operand of n_patches (records and exponents of the others untouched): the reference
+ * rewrites one frame's patches per frame (`self.gmap_[self.n % self.mem] = gmap`, devo/devo.py:524), so the operand of the ring's
+ * patch features is maintained slot by slot. */
+int devo_corr_patch_transpose_range(const void* fmap1, void* fmap1_t, int n_patches, int first, int count, int C, int dtype, devo_stream_t stream);
 
 /* fp32 pyramid level -> the SPLIT-BLOCKED format the dense-product lookup kernel multiplies (no reference counterpart; the reference's
  * kernel reads fp32 NCHW, correlation_kernel.cu:82-136).  F frames fmap2 f32 [F, C, H, W] in ANY layout: element strides f2s[4] = (frame,
@@ -105,6 +109,11 @@ int devo_corr_patch_transpose(const void* fmap1, void* fmap1_t, int n_patches, i
  * changes once per frame, not per update iteration: convert once per version, pass cblock = DEVO_CBLOCK_SPLIT8 + exps to the lookups. */
 int devo_corr_pyramid_split(const void* fmap2, const int64_t* f2s /* host, 4 */, int cblock, int F, int C, int H, int W, void* dst,
                             int64_t dst_fstride, int* exps, devo_stream_t stream);
+/* devo_corr_pyramid_split with the F ints of scratch given separately (`exps` i32 [F] receives the exponents only): frames [k, k + F) of a
+ * ring buffer are converted in place of their old records — exps = ring_exps + k, dst = ring_dst + k * dst_fstride — while the other
+ * frames keep theirs (`self.fmap1_[:, self.n % self.mem] = ...`, devo/devo.py:526-527: one slot per frame). */
+int devo_corr_pyramid_split_frames(const void* fmap2, const int64_t* f2s /* host, 4 */, int cblock, int F, int C, int H, int W, void* dst,
+                                   int64_t dst_fstride, int* exps, int* scratch /* i32 [F] */, devo_stream_t stream);
 
 /* Locality plan for devo_corr_forward (no reference counterpart: the reference walks edges in list order).
  * order i32 [2*B*E + 2] (the plan buffer; devo_corr_forward reads the first B*E + 1 entries and the last one (number of DEAD edges at

@@ -312,7 +312,62 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=40):
                         t_all, t_host = ta, th
             out[f"{dtn}_{form}"] = {"it_per_s": round(iters / t_all, 1), "ms_per_iter": round(1e3 * t_all / iters, 4),
                                     "host_us_per_iter": round(1e6 * t_host / iters, 1)}
+        # ---- steady state of the unchanged devo.py (verdict r05 item 2c): every iteration first writes ONE slot of the three rings, the way
+        # devo.py:523-527 does for a new frame (`gmap_[k] = ...`, `fmap1_[:, k] = ...`, `fmap2_[:, k] = ...`), then runs the update of the
+        # config/default.yaml graph — 45 312 edges of the sliding window (PATCH_LIFETIME 13, REMOVAL_WINDOW 22) in DEVO's order, ring indices
+        # modulo mem, t0 = n - OPTIMIZATION_WINDOW.  With the __setitem__ wrapper of devo_amd.backends.ring the lookup converts the written
+        # slot only; `whole_ring` = the wrapper switched off: the three tensors are converted again for every frame (rounds 1-5).
+        try:
+            from devo_amd.backends import ring
+            import devo_amd.backends as B_
+            nk = 40
+            sii, sjj, skk = [t.to(device) for t in synth.sliding_window_graph(nk, M)]
+            sE = sii.numel()
+            sposes = synth.make_poses(48, seed, trans_step=0.01, rot_step=0.002).to(device)      # overlapping frames (tests/test_gpu_steady_state.py)
+            spatches = synth.make_patches(48, M, H, W, seed=seed)[0].to(device)
+            sintr = synth.make_intrinsics(48, H, W).to(device)
+            sdelta, sweight = [t.to(device) for t in synth.make_update_outputs(sE, seed, sigma=0.5)]
+            fm_new = [f0[:, k % n].to(dt).clone() for k in range(4)]          # "new frames" to write (contents do not matter to the clock)
+            f1_new = [synth.pyramid_l1(f0[:, k % n][:, None])[:, 0].to(dt).clone() for k in range(4)]
+            gm_new = [gmap.to(device).view(n, M, C, 3, 3)[k % n].to(dt).clone() for k in range(4)]
+            P1, Q1 = sposes.clone(), spatches.clone()
+            state = {"f": nk}
+
+            def frame_and_update():
+                k = state["f"] % mem
+                state["f"] += 1
+                gmap_[k] = gm_new[k % 4]                                      # devo.py:524
+                fmap1_[:, k] = fm_new[k % 4]                                  # devo.py:526
+                fmap2_[:, k] = f1_new[k % 4]                                  # devo.py:527
+                P1.copy_(sposes); Q1.copy_(spatches)
+                coords = pops.transform(SE3(P1), Q1, sintr, sii, sjj, skk, fused=True).permute(0, 1, 4, 2, 3).contiguous()
+                ii1, jj1 = skk % (M * mem), sjj % mem
+                corr = torch.stack([altcorr.corr(gm, pyramid[0], coords / 1, ii1, jj1, 3), altcorr.corr(gm, pyramid[1], coords / 4, ii1, jj1, 3)], -1).view(1, sE, -1)
+                target = coords[..., 1, 1] + sdelta
+                fastba.BA(P1, Q1, sintr, target, sweight, lmbda, sii, sjj, skk, nk - 10, nk, 2)
+                return corr
+            for label, track in (("per_slot", True), ("whole_ring", False)):
+                on = ring.track_ring_writes(track) if B_.native() is not None else False
+                with torch.no_grad():
+                    for _ in range(10):
+                        frame_and_update()
+                    torch.cuda.synchronize(device)
+                    best = float("inf")
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        for _ in range(30):
+                            frame_and_update()
+                        torch.cuda.synchronize(device)
+                        best = min(best, time.perf_counter() - t0)
+                out[f"{dtn}_steady_state_{label}"] = {"it_per_s": round(30 / best, 1), "ms_per_iter": round(1e3 * best / 30, 4), "edges": sE, "write_tracking": bool(on)}
+            ring.track_ring_writes(False)
+            del P1, Q1, sposes, spatches
+        except Exception as ex:                                      # noqa: BLE001 — an extra field must not cost the probe
+            out[f"{dtn}_steady_state_error"] = f"{type(ex).__name__}: {ex}"[:300]
         del fmap1_, fmap2_, gmap_
+    out["steady_state"] = ("one new frame per iteration written into ONE slot of the fp16 / fp32 rings as devo.py:523-527 does, then the reference's call sequence on the "
+                           "config/default.yaml graph (45 312 edges of the sliding window after 40 keyframes, indices modulo the ring, 10 optimised poses): "
+                           "per_slot = devo_amd.backends.ring records the writes and the lookup converts the written slot; whole_ring = every frame converts the rings again")
     out["what"] = ("devo.py:210-223,308-344 as written (transform, permute, two altcorr.corr on the NCHW ring of 32 frames + torch.stack, "
                    "target, fastba.BA with 2 GN iterations), eager launches, caches warm; package = devo_amd.projective_ops (fused "
                    "reprojection), modules = the reference's SE3 group-op composition over lietorch_backends")

@@ -18,7 +18,10 @@ N_KF, M, MEM, H, W, C, R = 40, 96, 32, 120, 160, 128, 3
 def _scene(seed=11):
     from devo_amd import synth
     nbuf = 48                                                          # (the reference's pose / patch buffers hold 2048 frames: only their size differs)
-    poses = synth.make_poses(nbuf, seed)
+    # a camera that moves like a camera: ~1 cm and 0.1 degree per keyframe, so that the 13 frames a patch is tracked through overlap (86 % of
+    # the reprojections land inside the frame, every patch keeps >= 13 unmasked edges).  synth.make_poses' defaults at n = 40 scatter the frames
+    # (patches whose only unmasked edge is the one into their own frame: depth unobservable, dz = fp32 noise / lambda in any implementation)
+    poses = synth.make_poses(nbuf, seed, trans_step=0.01, rot_step=0.002)
     patches, centres = synth.make_patches(nbuf, M, H, W, seed=seed)
     intr = synth.make_intrinsics(nbuf, H, W)
     ii, jj, kk = synth.sliding_window_graph(N_KF, M)

@@ -2527,14 +2527,14 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
   int* perm_b = (int*)(w + L.perm_b);
   int* kx = (int*)(w + L.kx);
   const size_t prep_lds = sizeof(int) * (1024 + PREP_FLAGS_LDS + 1 + 2 * PREP_SEGS_LDS + 1 + 8);
-  static bool prep_attr = false;
-  if (!prep_attr) {
+  static PerDeviceOnce prep_attr;
+  if (prep_attr.first()) {
     (void)hipFuncSetAttribute((const void*)k_ba_prepare<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
     (void)hipFuncSetAttribute((const void*)k_ba_prepare<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
     (void)hipFuncSetAttribute((const void*)k_ba_prepare<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
     (void)hipFuncSetAttribute((const void*)k_ba_prepare<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
     (void)hipFuncSetAttribute((const void*)k_ba_prepare<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
-    (void)hipGetLastError(); prep_attr = true;
+    (void)hipGetLastError();
   }
   if (E <= (1 << 17)) {
     typedef void (*prep_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, int);
@@ -2545,13 +2545,13 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
       typedef void (*both_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, int, const int*, int, int*, int);
       both_fn_t both = ept <= 8 ? k_prepare_and_order<8> : ept <= 16 ? k_prepare_and_order<16> : ept <= 24 ? k_prepare_and_order<24> :
                        k_prepare_and_order<32>;
-      static bool both_attr = false;
-      if (!both_attr) {
+      static PerDeviceOnce both_attr;
+      if (both_attr.first()) {
         (void)hipFuncSetAttribute((const void*)k_prepare_and_order<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
         (void)hipFuncSetAttribute((const void*)k_prepare_and_order<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
         (void)hipFuncSetAttribute((const void*)k_prepare_and_order<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
         (void)hipFuncSetAttribute((const void*)k_prepare_and_order<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
-        (void)hipGetLastError(); both_attr = true;
+        (void)hipGetLastError();
       }
       hipLaunchKernelGGL(both, dim3(1 + (unsigned)corr_order_workgroups(E, plan_nbins)), dim3(1024), prep_lds, st, kk, E, Np, L.max_seg, meta, rank,
                          counts, cursor, ku, kx, perm_a, perm_b, ba_sig(E, N), plan + E + 1, plan_nbins, plan, plan_starts);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/devo_hip.h"
 
 namespace devo {
@@ -26,6 +27,19 @@ inline int blocks_for(long long n, int threads, int cap = 1 << 20) {
 }
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// "Have I raised this kernel's dynamic-LDS limit on the CURRENT device yet?"  hipFuncSetAttribute is per device: a process that uses a second
+// GPU must set it there too (a launch of > 64 KB of LDS fails otherwise).  One bit per device ordinal (mod 64), set atomically; the caller
+// does its hipFuncSetAttribute calls when this returns true.
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> mask{0ull};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return true; }
+    const unsigned long long bit = 1ull << (d & 63);
+    return (mask.fetch_or(bit, std::memory_order_relaxed) & bit) == 0ull;
+  }
+};
 
 #define DEVO_REQUIRE(cond, ...)            \
   do {                                     \

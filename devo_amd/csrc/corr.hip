@@ -1100,10 +1100,9 @@ static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel&
       constexpr int rw_floats = (PP * (8 * 8 + 1) + 3) / 4 * 4 > PP * (cap + 4) ? (PP * (8 * 8 + 1) + 3) / 4 * 4 : PP * (cap + 4);
       constexpr int wave_lds = rw_floats * 4 + 2 * 16 * 4 * 4 + ((2 * PP * 2 * 4 + 15) / 16) * 16;
       const int lds = mm_region_bytes<MT>(128) + NWG * wave_lds;
-      static bool attr_set = false;
-      if (!attr_set) {
+      static PerDeviceOnce attr_set;
+      if (attr_set.first()) {
         if (hipFuncSetAttribute((const void*)gfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { (void)hipGetLastError(); set_error("devo_corr_forward_pyramid2: %d bytes of LDS refused", lds); return DEVO_ERR_LAUNCH; }
-        attr_set = true;
       }
       const MmGroupArgs ga{order + 2 * BE + 2, (int)nbins, corr_grp_count(lv1.H2), corr_grp_count(lv1.W2)};
       const unsigned items = (unsigned)nbins * MM_ITEMS_PER_BIN;

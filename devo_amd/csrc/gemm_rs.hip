@@ -1090,11 +1090,10 @@ static int rs_launch(const void* x, int64_t ldx, const void* wimg, const void* b
   constexpr int ROWS = 16 * MT, PITCH = 2 * 32 * NK + 16;
   // the row tile; the last pass's result tiles lie over it (26.6 KB: more than a 32-row tile), earlier passes' behind it
   const int lds = std::max(ROWS * PITCH, RS_NW * 16 * RS_EPI_LD * 4) + (NB > 1 ? RS_NW * 16 * RS_EPI_LD * 4 : 0);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.first()) {
     DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_linear_f16<MT, NK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "devo_upd_rs_linear_f16: cannot raise the dynamic LDS limit");
-    attr_done = true;
   }
   hipLaunchKernelGGL((k_rs_linear_f16<MT, NK>), dim3((unsigned)((M + ROWS - 1) / ROWS)), dim3(512), lds, stream, (const __half*)x, ldx, (const rs_u4*)wimg,
                      (const __half*)bias, (const __half*)residual, (__half*)y, ldy, M, NB, K, relu_from, trace);
@@ -1104,11 +1103,10 @@ static int rs_launch(const void* x, int64_t ldx, const void* wimg, const void* b
 template <bool MLP, bool FG>
 static int rs_chain_launch(const void* x, int64_t ldx, int x_rows, const int64_t* gather, const void* w1img, const void* b1, const void* w2img, const void* b2,
                            const void* residual, void* y, int M, const void* hy, const int* grp, const void* wfg, const void* bfg, void* fg, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.first()) {
     DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_mlp2_f16<MLP, FG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "devo_upd_rs_mlp2_f16: cannot raise the dynamic LDS limit");
-    attr_done = true;
   }
   hipLaunchKernelGGL((k_rs_mlp2_f16<MLP, FG>), dim3((unsigned)((M + RG_ROWS - 1) / RG_ROWS)), dim3(512), 2 * RG_ROWS * RG_PITCH, stream, (const __half*)x, ldx, x_rows, gather,
                      (const rs_u4*)w1img, (const __half*)b1, (const rs_u4*)w2img, (const __half*)b2, (const __half*)residual, (__half*)y, M, (const __half*)hy, grp,
@@ -1197,11 +1195,10 @@ int devo_upd_rs_gru_f16(const void* x, const void* hy, const int* group_of, cons
                  reinterpret_cast<uintptr_t>(Wd) | reinterpret_cast<uintptr_t>(Ww) | reinterpret_cast<uintptr_t>(net_out) | reinterpret_cast<uintptr_t>(wgr1_img) |
                  reinterpret_cast<uintptr_t>(wr2_1_img) | reinterpret_cast<uintptr_t>(wgr3_img) | reinterpret_cast<uintptr_t>(wr2_3_img)) & 15) == 0,
                "devo_upd_rs_gru_f16: 16-byte alignment");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.first()) {
     DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_gru_f16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "devo_upd_rs_gru_f16: cannot raise the dynamic LDS limit");
-    attr_done = true;
   }
   RsGru a;
   a.x = (const __half*)x; a.hy = (const __half*)hy; a.grp = group_of; a.ln0_g = (const __half*)ln0_w; a.ln0_b = (const __half*)ln0_b;
@@ -1273,11 +1270,10 @@ int devo_upd_rs_corr_f16(const void* corr, int64_t ldc, int K0, const void* w0im
                  reinterpret_cast<uintptr_t>(ln_b) | reinterpret_cast<uintptr_t>(w0img) | reinterpret_cast<uintptr_t>(w2img) | reinterpret_cast<uintptr_t>(w5img)) & 15) == 0,
                "devo_upd_rs_corr_f16: 16-byte alignment");
   DEVO_REQUIRE(((int64_t)(E - 1) * ldc + K0) * 2 < (1ll << 31), "devo_upd_rs_corr_f16: corr beyond 2 GB");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.first()) {
     DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_corr_f16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "devo_upd_rs_corr_f16: cannot raise the dynamic LDS limit");
-    attr_done = true;
   }
   RsCorr a;
   a.corr = (const __half*)corr; a.ldc = ldc; a.w0 = (const rs_u4*)w0img; a.b0 = (const __half*)b0; a.w2 = (const rs_u4*)w2img; a.b2 = (const __half*)b2;
@@ -1311,11 +1307,10 @@ int devo_upd_rs_linear_split(const float* x, int64_t ldx, const void* wimg, cons
   DEVO_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
                                                   reinterpret_cast<uintptr_t>(gate) | reinterpret_cast<uintptr_t>(wimg)) & 15) == 0,
                "devo_upd_rs_linear_split: 16-byte alignment of the rows");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.first()) {
     DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_linear_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "devo_upd_rs_linear_split: cannot raise the dynamic LDS limit");
-    attr_done = true;
   }
   hipLaunchKernelGGL(k_rs_linear_split, dim3((unsigned)((M + RG_ROWS - 1) / RG_ROWS), (unsigned)(N / RS_BN)), dim3(512), RF_LDS, (hipStream_t)stream, x, ldx,
                      (const rs_u4*)wimg, bias, residual, gate, y, ldy, M, N, K, relu_from < 0 ? 0 : relu_from);

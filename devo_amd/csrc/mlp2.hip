@@ -236,12 +236,11 @@ int devo_upd_mlp2_f16(const void* x, int64_t ldx, int x_rows, const int64_t* gat
   DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(w1image) | reinterpret_cast<uintptr_t>(w2image)) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(x) & 3) == 0, "devo_upd_mlp2_f16: y / residual / the weight images must be 16-byte aligned, x 4-byte");
   DEVO_REQUIRE(((int64_t)(x_rows - 1) * ldx + K1) * 2 < (1LL << 31), "devo_upd_mlp2_f16: input beyond 2 GB");
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute((const void*)k_mlp2_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MP_LDS);
     (void)hipFuncSetAttribute((const void*)k_mlp2_f16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MP_LDS);
     (void)hipGetLastError();
-    attr = true;
   }
   const dim3 grid((unsigned)((M + MP_ROWS - 1) / MP_ROWS)), block(512);
   if (gather)

@@ -862,12 +862,11 @@ int devo_upd_softagg_hint(const void* f, const void* g, int64_t ld_fg, const int
     const dim3 vgrid(grid_for(E, 1, 4096));
     if (rows_per_group >= 48 && sizeof(float) * 48 * (size_t)dim <= 160 * 1024) {
       const size_t lds = sizeof(float) * 48 * (size_t)dim;
-      static bool attr_done = false;
-      if (!attr_done) {
+      static PerDeviceOnce attr_done;
+      if (attr_done.first()) {
         DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_softagg_v<float, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_softagg_v<__half, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                      "devo_upd_softagg: cannot raise the dynamic LDS limit");
-        attr_done = true;
       }
       UPD_DISPATCH(dtype,
         hipLaunchKernelGGL((k_softagg_v<float, 16>), vgrid, dim3(1024), lds, st_, (const float*)f, (const float*)g, ld_fg, perm, seg_start, n_seg, (float*)y, group_of, dim, cpr),

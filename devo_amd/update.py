@@ -383,8 +383,19 @@ def _mlp2(seq, x, residual=None):
     return y if residual is None else residual + y
 
 
+# Bumped whenever a Linear / LayerNorm of this file gets a NEW Parameter object (`m.weight = nn.Parameter(...)`): the plans of the Update
+# operator hold raw pointers of the parameters they were made from and key themselves on (this epoch, every parameter's storage address
+# and version counter) — an edit in place moves a version, `.data = ...` / .to() / .half() move an address, a replaced Parameter moves this.
+_PARAM_EPOCH = [0]
+
+
 class Linear(nn.Linear):
     """nn.Linear (same parameters, same state-dict keys) whose backward over >= 4096 rows splits the weight-gradient product."""
+
+    def __setattr__(self, name, value):
+        if name in ("weight", "bias"):
+            _PARAM_EPOCH[0] += 1
+        super().__setattr__(name, value)
 
     def forward(self, x):
         if torch.is_grad_enabled() and x.is_cuda and x.numel() // x.shape[-1] >= 4096 and (x.requires_grad or self.weight.requires_grad):
@@ -447,6 +458,11 @@ def _ln_train(mod, x, a=None, b=None, relu=False):
 
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm (same parameters, same state-dict keys) whose training path runs the HIP forward / backward pair"""
+
+    def __setattr__(self, name, value):
+        if name in ("weight", "bias"):
+            _PARAM_EPOCH[0] += 1
+        super().__setattr__(name, value)
 
     def forward(self, x):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
@@ -721,7 +737,7 @@ class Update(nn.Module):
         """Everything the fp16 row-resident path hands to its ten launches — weight images, bias / LayerNorm vectors as raw pointers, the
         epsilons — collected once per version of the parameters: the eager call is host-bound otherwise (39 nn.Sequential lookups, 120
         parameter lookups and 60 pointer conversions per call: 185 us where the GPU needs 230)."""
-        key = sum(p._version for p in self._plist()) + (self.norm.weight.data_ptr() << 8)
+        key = self._pkey()
         pl = self.__dict__.get("_rsplan")
         if pl is not None and pl["key"] == key:
             return pl
@@ -765,9 +781,21 @@ class Update(nn.Module):
 
     def _plist(self):
         pl = self.__dict__.get("_params")
-        if pl is None:
-            pl = self.__dict__["_params"] = list(self.parameters())
-        return pl
+        if pl is None or pl[0] != _PARAM_EPOCH[0]:                            # (a replaced Parameter object: the list is re-read from the module tree)
+            pl = self.__dict__["_params"] = (_PARAM_EPOCH[0], list(self.parameters()))
+        return pl[1]
+
+    def _pkey(self):
+        """What every cached plan / shadow of this operator is keyed on: the epoch of Parameter replacements and (storage address, version
+        counter) of every parameter — ~9 us for the 50 parameters (the sum of the versions alone missed `.data = ...`, a
+        .float() / .half() round trip and replaced Parameters, leaving raw pointers of freed storage in the plan)."""
+        return (_PARAM_EPOCH[0], tuple((p.data_ptr(), p._version) for p in self._plist()))
+
+    def _apply(self, fn, recurse=True):
+        """.to() / .half() / .float() / .cuda(): the parameters' storage moves — no cached pointer survives."""
+        out = super()._apply(fn, recurse)
+        self.invalidate_weights()
+        return out
 
     def _forward_rs(self, x, inp2, c, ix, jx, Gkk, Gij, E):
         """The fp16 operator on the row-resident kernels (csrc/gemm_rs.hip), ten launches: the correlation branch + norm | c1 | c2 + agg_kk's
@@ -807,7 +835,7 @@ class Update(nn.Module):
 
     def _half_shadow(self):
         """An fp16 copy of this operator (for calls under autocast), rebuilt when a parameter's version counter moves; `.data` edits: invalidate_weights()."""
-        key = sum(p._version for p in self.parameters()) + (self.norm.weight.data_ptr() << 8)
+        key = self._pkey()
         sh = self.__dict__.get("_shadow")
         if sh is None or sh[0] != key:
             m = Update(int(round((self.corr[0].in_features / 98.0) ** 0.5)), self.dim).to(self.norm.weight.device).half().eval()

@@ -68,6 +68,29 @@ def test_ddp_allreduces_the_reference_sized_gradient_bucket():
     assert res[0][5] == res[1][5]                          # both ranks hold the same parameters
 
 
+def test_eight_rank_harness_and_ddp_bucket():
+    """BASELINE configuration 4's process layout — 8 ranks of one node — on CPU over gloo: the launcher starts eight ranks with distinct
+    LOCAL_RANKs on 127.0.0.1, the sequences are sharded disjointly, the timed region's MAX over ranks is the slowest rank's (8 s), the
+    whole-job rate adds all ranks' units, and DDP's all-reduce of the 13.59 MB gradient bucket averages eight rank-dependent gradients
+    (mean of 1 .. 8 = 4.5) into identical parameters everywhere.  RCCL with 8 ranks has run nowhere (one GPU per box): this is the same
+    wrapper, launcher and reduction arithmetic with the other backend."""
+    from devo_amd import distributed as D, training as T
+    with tempfile.TemporaryDirectory() as td:
+        D.launch(_harness_rank, 8, (td,))
+        res = sorted(json.load(open(os.path.join(td, f"h{r}.json"))) for r in range(8))
+    assert [r[0] for r in res] == list(range(8)) and all(r[4] == 8 and r[5] == r[0] and r[6] == str(r[0]) and r[7] == "127.0.0.1" for r in res)
+    assert sorted(sum((r[1] for r in res), [])) == [0, 1, 2, 3, 4] and [len(r[1]) for r in res] == [1, 1, 1, 1, 1, 0, 0, 0]
+    assert all(r[2] == 8.0 for r in res)                                   # MAX over ranks of 1 + rank
+    assert all(abs(r[3] - 50 / 8.0) < 1e-12 for r in res)                  # 5 sequences x 10 units / the slowest rank
+    with tempfile.TemporaryDirectory() as td:
+        D.launch(_ddp_rank, 8, (td,))
+        res = sorted(json.load(open(os.path.join(td, f"d{r}.json"))) for r in range(8))
+    for r, n, gn, gmin, gmax, w0 in res:
+        assert n == gn == T.N_TOTAL == 3_397_061
+        assert gmin == gmax == 4.5
+    assert len({r[5] for r in res}) == 1
+
+
 def test_launcher_reports_a_failing_rank():
     from devo_amd import distributed as D
     import pytest

@@ -45,6 +45,26 @@ def test_update_op_bench_on_two_ranks_sharing_the_gpu():
     _seen["train_dp_ms"] = d["train_dp"]["ms_per_step"]
 
 
+def test_eight_ranks_first_call_work_stays_inside_the_probe_bound():
+    """What the driver's first real 8-GPU run will do on every rank at once — load the library, build the inputs, hit MIOpen's find DB
+    (devo_amd/miopen_db/) for the training probe's convolutions — here with all eight ranks on ONE GPU and the probe's DEFAULT bound of
+    90 s (no DEVO_BENCH_PROBE_TIMEOUT): the line carries `train_dp` without an error, i.e. eight ranks' cold-start work fits the bound
+    even when they share a device (52 s for the whole command on an MI355X box of this pool)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("DEVO_BENCH_PROBE_TIMEOUT", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--steps", "18", "--warmup", "2", "--no-f16", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    _keep("bench_gpus8_share.json", lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 18 and d["scaling"] == "weak" and d["value"] > 0
+    assert "train_dp" in d and "error" not in d["train_dp"], d.get("train_dp")
+    assert d["train_dp"]["parameters"] == 3_397_061 and d["train_dp"]["grad_bucket_bytes"] == 13_588_244
+
+
 def test_training_bench_on_two_ranks_sharing_the_gpu():
     d, line = _run(["--mode", "train", "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "4", "--train-iters", "2"], timeout=900)
     _keep("bench_train_gpus2_share.json", line)

@@ -1152,7 +1152,10 @@ static int launch_mm(const void* fmap1_t, const CorrLevel& lv0, const CorrLevel&
   const bool do_trace = getenv("DEVO_CORR_TRACE") != nullptr;
   if (do_trace) { (void)hipMalloc(&trace, (size_t)BE * 64); (void)hipMemset(trace, 0, (size_t)BE * 64); }
   const unsigned nwg = DEVO_MM_EPW == 1 ? (unsigned)BE : (unsigned)(((BE + DEVO_MM_EPW - 1) / DEVO_MM_EPW + 7) / 8 * 8);   // whole groups of 8 (one per XCD)
-  hipLaunchKernelGGL(fn, dim3(nwg), dim3(64 * DEVO_MM_EPW), 0, st, (const MT*)fmap1_t, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C,
+  // DEVO_CORR_LDS_PAD=<bytes> (tuning switch, round 6's bounded attempt on the stress size): unused dynamic LDS per one-wave workgroup, i.e. a
+  // cap on the edges resident per compute unit (160 KB / (6.5 KB + pad)) and with it on the footprint an XCD streams through its L2 at a time
+  static const int lds_pad = [] { const char* e = getenv("DEVO_CORR_LDS_PAD"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 60 * 1024 ? v : 0; }();
+  hipLaunchKernelGGL(fn, dim3(nwg), dim3(64 * DEVO_MM_EPW), (size_t)lds_pad, st, (const MT*)fmap1_t, lv0, lv1, nlev, coords, ii, jj, (MT*)out, (int)BE, E, Np, n2, C,
                      oes, ols, R, order, 0, trace, exp1, MmGroupArgs{nullptr, 0, 0, 0});
   if (do_trace) {
     (void)hipDeviceSynchronize();

@@ -1597,29 +1597,10 @@ __device__ __forceinline__ void ba_solve_chain_body(const float* __restrict__ S,
   extern __shared__ __attribute__((aligned(16))) float A[];
   const bool lead = blockIdx.x == 0;                              // (the only workgroup of the unfused launch)
   const int n_seg_all = FUSED ? meta->n_seg : 0;
-  // FUSED: what the retraction of this wave's first patches needs (their E columns, (Q, u), the depth they hold now) is requested here and
-  // arrives under the factorisation — two dependent round trips to memory (~2 us) less behind it.  Nothing the solver writes is read.
+  // (a prefetch of the retraction's operands under the factorisation was measured — no gain: 19.5 us either way — and dropped: it would read
+  // through tables that a never-prepared workspace does not have before the kernel knows the call has failed)
   constexpr int UP = 2;
   const int nw = (int)gridDim.x * 16, w0 = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6);
-  float pre_c0[UP] = {0.0f, 0.0f}, pre_c1[UP] = {0.0f, 0.0f}, pre_q[UP] = {0.0f, 0.0f}, pre_u[UP] = {0.0f, 0.0f}, pre_d0[UP] = {0.0f, 0.0f};
-  float* pre_pd[UP] = {nullptr, nullptr};
-  if constexpr (FUSED) {
-    const int n6p = 6 * N, lnp = threadIdx.x & 63;
-    if (w0 < n_seg_all) {
-#pragma unroll
-      for (int k = 0; k < UP; k++) {
-        const int s = w0 + k * nw;
-        const int sc = s < n_seg_all ? s : w0;
-        const float* pc = ra.patch_col + (int64_t)sc * n6p;
-        pre_c0[k] = (lnp < n6p) ? pc[lnp] : 0.0f;
-        pre_c1[k] = (lnp + 64 < n6p) ? pc[lnp + 64] : 0.0f;
-        pre_q[k] = ra.patch_rec[(int64_t)sc * 2];
-        pre_u[k] = ra.patch_rec[(int64_t)sc * 2 + 1];
-        pre_pd[k] = ra.patches + ((int64_t)ra.kx[sc] * 3 + 2) * (ra.P * ra.P);
-        pre_d0[k] = pre_pd[k][0];
-      }
-    }
-  }
   __shared__ int s_fail;
   __shared__ float s_dump[64];
   const int n6 = 6 * N, LDG = n6 + 1, LD = solve_ld(n6), rows = n6 + 1;
@@ -1923,22 +1904,17 @@ __device__ __forceinline__ void ba_solve_chain_body(const float* __restrict__ S,
     for (int sb = w0; sb < n_seg_all; sb += nw * UP) {
       float c0[UP], c1[UP], q[UP], u[UP], d0[UP];
       float* pd[UP];
-      if (sb == w0) {                                              // the wave's first patches: fetched before the factorisation
 #pragma unroll
-        for (int k = 0; k < UP; k++) { c0[k] = pre_c0[k]; c1[k] = pre_c1[k]; q[k] = pre_q[k]; u[k] = pre_u[k]; d0[k] = pre_d0[k]; pd[k] = pre_pd[k]; }
-      } else {
-#pragma unroll
-        for (int k = 0; k < UP; k++) {
-          const int s = sb + k * nw;
-          const int sc = s < n_seg_all ? s : sb;
-          const float* pc = ra.patch_col + (int64_t)sc * n6;
-          c0[k] = (ln < n6) ? pc[ln] : 0.0f;
-          c1[k] = (ln + 64 < n6) ? pc[ln + 64] : 0.0f;
-          q[k] = ra.patch_rec[(int64_t)sc * 2];
-          u[k] = ra.patch_rec[(int64_t)sc * 2 + 1];
-          pd[k] = ra.patches + ((int64_t)ra.kx[sc] * 3 + 2) * PP;
-          d0[k] = pd[k][0];                                        // reads pixel [0][0] (ba_cuda.cu:198)
-        }
+      for (int k = 0; k < UP; k++) {
+        const int s = sb + k * nw;
+        const int sc = s < n_seg_all ? s : sb;
+        const float* pc = ra.patch_col + (int64_t)sc * n6;
+        c0[k] = (ln < n6) ? pc[ln] : 0.0f;
+        c1[k] = (ln + 64 < n6) ? pc[ln + 64] : 0.0f;
+        q[k] = ra.patch_rec[(int64_t)sc * 2];
+        u[k] = ra.patch_rec[(int64_t)sc * 2 + 1];
+        pd[k] = ra.patches + ((int64_t)ra.kx[sc] * 3 + 2) * PP;
+        d0[k] = pd[k][0];                                          // reads pixel [0][0] (ba_cuda.cu:198)
       }
 #pragma unroll
       for (int k = 0; k < UP; k++) {

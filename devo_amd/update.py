@@ -383,18 +383,23 @@ def _mlp2(seq, x, residual=None):
     return y if residual is None else residual + y
 
 
-# Bumped whenever a Linear / LayerNorm of this file gets a NEW Parameter object (`m.weight = nn.Parameter(...)`): the plans of the Update
-# operator hold raw pointers of the parameters they were made from and key themselves on (this epoch, every parameter's storage address
-# and version counter) — an edit in place moves a version, `.data = ...` / .to() / .half() move an address, a replaced Parameter moves this.
-_PARAM_EPOCH = [0]
+# A Linear / LayerNorm of this file that gets a NEW Parameter object (`m.weight = nn.Parameter(...)`) bumps the epoch cell of the Update
+# operator it belongs to (Update.__init__ hands every layer its cell): the operator's plans hold raw pointers of the parameters they were
+# made from and key themselves on (that epoch, every parameter's storage address and version counter) — an edit in place moves a version,
+# `.data = ...` / .to() / .half() move an address, a replaced Parameter moves the epoch.  (A cell per operator, not one per process: building
+# another operator — the fp16 shadow of an autocast call is one — must not age the plans of this one.)
+def _bump_epoch(module, name):
+    if name in ("weight", "bias"):
+        cell = module.__dict__.get("_epoch_cell")
+        if cell is not None:
+            cell[0] += 1
 
 
 class Linear(nn.Linear):
     """nn.Linear (same parameters, same state-dict keys) whose backward over >= 4096 rows splits the weight-gradient product."""
 
     def __setattr__(self, name, value):
-        if name in ("weight", "bias"):
-            _PARAM_EPOCH[0] += 1
+        _bump_epoch(self, name)
         super().__setattr__(name, value)
 
     def forward(self, x):
@@ -460,8 +465,7 @@ class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm (same parameters, same state-dict keys) whose training path runs the HIP forward / backward pair"""
 
     def __setattr__(self, name, value):
-        if name in ("weight", "bias"):
-            _PARAM_EPOCH[0] += 1
+        _bump_epoch(self, name)
         super().__setattr__(name, value)
 
     def forward(self, x):
@@ -666,6 +670,10 @@ class Update(nn.Module):
         self.d = nn.Sequential(nn.ReLU(inplace=False), Linear(dim, 2), GradientClip())
         self.w = nn.Sequential(nn.ReLU(inplace=False), Linear(dim, 2), GradientClip(), nn.Sigmoid())
         self._graph_key, self._graph, self._graph_refs, self._wcat = None, None, None, {}
+        self.__dict__["_epoch"] = [0]                                     # (see _bump_epoch)
+        for m in self.modules():
+            if isinstance(m, (Linear, LayerNorm)):
+                m.__dict__["_epoch_cell"] = self.__dict__["_epoch"]
 
     # ------------------------------------------------------------------------------------------ torch / autograd path
     def forward_torch(self, net, inp, corr, ii, jj, kk):
@@ -781,15 +789,16 @@ class Update(nn.Module):
 
     def _plist(self):
         pl = self.__dict__.get("_params")
-        if pl is None or pl[0] != _PARAM_EPOCH[0]:                            # (a replaced Parameter object: the list is re-read from the module tree)
-            pl = self.__dict__["_params"] = (_PARAM_EPOCH[0], list(self.parameters()))
+        ep = self.__dict__["_epoch"][0]
+        if pl is None or pl[0] != ep:                                          # (a replaced Parameter object: the list is re-read from the module tree)
+            pl = self.__dict__["_params"] = (ep, list(self.parameters()))
         return pl[1]
 
     def _pkey(self):
         """What every cached plan / shadow of this operator is keyed on: the epoch of Parameter replacements and (storage address, version
         counter) of every parameter — ~9 us for the 50 parameters (the sum of the versions alone missed `.data = ...`, a
         .float() / .half() round trip and replaced Parameters, leaving raw pointers of freed storage in the plan)."""
-        return (_PARAM_EPOCH[0], tuple((p.data_ptr(), p._version) for p in self._plist()))
+        return (self.__dict__["_epoch"][0], tuple((p.data_ptr(), p._version) for p in self._plist()))
 
     def _apply(self, fn, recurse=True):
         """.to() / .half() / .float() / .cuda(): the parameters' storage moves — no cached pointer survives."""

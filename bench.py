@@ -832,10 +832,11 @@ def ba_kernel_report(run_ba):
             if r:
                 v.update({"lds_bytes_per_wg": r["lds_bytes"], "waves_per_simd": r["waves_per_simd"], "vgpr": r["vgpr"]})
         pick = lambda name: next((res[k] for k in res if k.startswith(name)), None)
-        sol, acc = pick("k_ba_solve_chain"), pick("k_ba_accumulate_reg")
+        sname = "k_ba_solve_retract" if pick("k_ba_solve_retract") else "k_ba_solve_chain"
+        sol, acc = pick(sname), pick("k_ba_accumulate_reg")
         if sol:
-            rep["lds_bytes_per_wg"] = {"k_ba_solve_chain": sol["lds_bytes"], "k_ba_accumulate_reg": acc["lds_bytes"] if acc else None}
-            rep["waves_per_simd"] = {"k_ba_solve_chain": sol["waves_per_simd"], "k_ba_accumulate_reg": acc["waves_per_simd"] if acc else None}
+            rep["lds_bytes_per_wg"] = {sname: sol["lds_bytes"], "k_ba_accumulate_reg": acc["lds_bytes"] if acc else None}
+            rep["waves_per_simd"] = {sname: sol["waves_per_simd"], "k_ba_accumulate_reg": acc["waves_per_simd"] if acc else None}
             rep["resources_source"] = "profiles/ba_kernel_resources.json (hipcc -Rpass-analysis=kernel-resource-usage; LDS = static + the launch's dynamic bytes)"
     except (OSError, ValueError, KeyError):
         pass

@@ -3,6 +3,7 @@
 // not depend on each other).
 #pragma once
 #include "corr_tile.h"
+#include <stdlib.h>
 
 namespace devo {
 
@@ -12,7 +13,8 @@ constexpr int ORDER_MAX_WG = 64;
 
 // Workgroups of the ordering step: about 1024 edges of their own each.
 inline int corr_order_workgroups(long long BE, long long nbins) {
-  long long g = BE / 1024;
+  static const int per_wg = [] { const char* e = getenv("DEVO_ORDER_EDGES_PER_WG"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 1024; }();   // (tuning switch)
+  long long g = BE / per_wg;
   if (g > ORDER_MAX_WG) g = ORDER_MAX_WG;
   if (g > nbins) g = nbins;
   return g < 1 ? 1 : (int)g;

@@ -231,7 +231,9 @@ def test_training_step_at_full_size(monkeypatch):
     lookup's edges, two differentiable Gauss-Newton steps per iteration; 2 update iterations instead of 18 to keep the test
     short): the step on the fused HIP paths (differentiable BA solve + adjoint, reprojection adjoint) equals the same step on
     the torch compositions that the reference-generated goldens pin (DEVO_BA_TORCH / DEVO_TRANSFORM_TORCH) — loss and the
-    gradient of every parameter group."""
+    gradient of every parameter group.  A SELF-COMPARISON at this size (both sides are this repo's code; the lookup has no CPU reference):
+    the reference-pinned parts of configuration 3 are the BA at E = 18 000 (test_training_ba_at_full_size_against_the_reference) and the
+    two-iteration golden of tests/test_gpu_train_iteration.py."""
     from devo_amd import training as T
     net, model, opt = T.build_trainer(DEV, 1)
     batch = T.make_batch("cfg2_m80", 1234, DEV)
@@ -262,7 +264,8 @@ def test_training_step_at_full_size(monkeypatch):
 def test_training_step_at_full_size_with_and_without_the_operator_kernels():
     """The same step (BASELINE configuration 3 at full size, 2 update iterations) with the Update operator's training path on this
     repo's kernels — split-precision y / dX / dW + bias gradient, LayerNorm forward / backward, ReLU and residual sums in the GEMM
-    epilogues — and on the library / ATen composition the reference's autograd would run: loss and the gradient of every parameter group."""
+    epilogues — and on the library / ATen composition the reference's autograd would run: loss and the gradient of every parameter group.
+    A SELF-COMPARISON (two paths of this repo); the operator itself is pinned to the reference's module by tests/test_gpu_update.py."""
     from devo_amd import training as T
     from devo_amd import update as UA
     net, model, opt = T.build_trainer(DEV, 1)

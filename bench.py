@@ -360,6 +360,50 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=40):
                         torch.cuda.synchronize(device)
                         best = min(best, time.perf_counter() - t0)
                 out[f"{dtn}_steady_state_{label}"] = {"it_per_s": round(30 / best, 1), "ms_per_iter": round(1e3 * best / 30, 4), "edges": sE, "write_tracking": bool(on)}
+            if dtn == "f16":
+                # ... and the same frame with the Update operator in its place (devo.py:308-317: fp32 parameters under autocast, fp16 rings,
+                # `ctx = imap[:, kk % (M mem)]`, the recurrent state fed back): what ONE frame of the unchanged devo.py costs on this path
+                # behind the patchifier (whose encoders are MIOpen's)
+                from devo_amd.update import Update
+                ring.track_ring_writes(True) if B_.native() is not None else None
+                torch.manual_seed(seed)
+                upd = Update(3).to(device).eval()
+                with torch.no_grad():
+                    for p_ in upd.parameters():
+                        if p_.dim() == 2 and p_.shape[0] == 2:
+                            p_.mul_(0.05)                                     # small flow updates: the adjustment stays in its basin
+                imap_ = (torch.randn(mem, M, 384, device=device) * 0.5).to(dt)
+                st2 = {"f": nk, "net": torch.zeros(1, sE, 384, device=device, dtype=dt)}
+                ring_idx = skk % (M * mem)
+
+                def frame_full():
+                    k = st2["f"] % mem
+                    st2["f"] += 1
+                    gmap_[k] = gm_new[k % 4]; fmap1_[:, k] = fm_new[k % 4]; fmap2_[:, k] = f1_new[k % 4]
+                    P1.copy_(sposes); Q1.copy_(spatches)
+                    coords = pops.transform(SE3(P1), Q1, sintr, sii, sjj, skk, fused=True).permute(0, 1, 4, 2, 3).contiguous()
+                    with torch.autocast("cuda", enabled=True, dtype=torch.float16):
+                        ii1, jj1 = ring_idx, sjj % mem
+                        corr = torch.stack([altcorr.corr(gm, pyramid[0], coords / 1, ii1, jj1, 3), altcorr.corr(gm, pyramid[1], coords / 4, ii1, jj1, 3)], -1).view(1, sE, -1)
+                        ctx = imap_.view(1, mem * M, 384)[:, ring_idx]
+                        st2["net"], (delta_, weight_, _) = upd(st2["net"], ctx, corr, None, sii, sjj, skk)
+                    target = coords[..., 1, 1] + delta_.float()
+                    fastba.BA(P1, Q1, sintr, target, weight_.float(), lmbda, sii, sjj, skk, nk - 10, nk, 2)
+                with torch.no_grad():
+                    for _ in range(10):
+                        frame_full()
+                    torch.cuda.synchronize(device)
+                    best = float("inf")
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        for _ in range(30):
+                            frame_full()
+                        torch.cuda.synchronize(device)
+                        best = min(best, time.perf_counter() - t0)
+                out["f16_steady_state_frame_with_update_operator"] = {"frames_per_s": round(30 / best, 1), "ms_per_frame": round(1e3 * best / 30, 4), "edges": sE,
+                                                                      "note": "one ring slot written + reproject + two-level lookup + Update operator (fp32 parameters under autocast) + 2 GN "
+                                                                              "iterations on its outputs, eager, the reference's call sequence"}
+                del upd, imap_
             ring.track_ring_writes(False)
             del P1, Q1, sposes, spatches
         except Exception as ex:                                      # noqa: BLE001 — an extra field must not cost the probe

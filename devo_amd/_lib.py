@@ -8,7 +8,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdevo_hip.so")
+# DEVO_LIB=<path>: another build of the library (tools/build_variant.sh: A/B of kernels inside one gpurun call); the compiled binding is linked
+# against devo_amd/lib/libdevo_hip.so, so backends.native() steps aside and the ctypes modules carry the calls
+LIB_PATH = os.path.abspath(os.environ["DEVO_LIB"]) if os.environ.get("DEVO_LIB") else os.path.join(_HERE, "lib", "libdevo_hip.so")
 
 DEVO_F32, DEVO_F16, DEVO_F64 = 0, 1, 2
 ABI_VERSION = 3                # include/devo_hip.h DEVO_ABI_VERSION: a library of another version is refused (argument lists differ)

@@ -36,10 +36,25 @@ struct BaMeta { int n_seg; int fail; int sig; int pad; };   // sig: what the wor
 __host__ __device__ __forceinline__ int ba_sig(int E, int N) { return (int)(0x5ec0de00u ^ ((unsigned)E * 2654435761u) ^ ((unsigned)N << 24)); }
 
 // ------------------------------------------------------------------------------------------------- utilities
+// Sum over the 64 lanes, returned to every lane.  DEVO_BA_SHFL_SUM: the butterfly of rounds 1-5 (six ds_bpermute round trips through the LDS
+// crossbar per value); default (round 6): DPP adds on the vector ALU — the scan of corr_tile.h's wave_inclusive_sum (row_shr 1 / 2 / 4 / 8, row_bcast
+// 15 / 31), the total in lane 63, v_readlane.  All 64 lanes must be active (every caller's are).  The order of the additions differs from the
+// butterfly's: results move in the last bits, every kernel of this file uses the same form.
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef DEVO_BA_SHFL_SUM
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
   return v;
+#else
+  auto dpp = [](float x, auto ctrl, auto rows) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xf, false)); };
+  v += dpp(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+#endif
 }
 __device__ __forceinline__ unsigned wave_or(unsigned v) {
 #pragma unroll

@@ -1029,6 +1029,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_ba_accumulate_reg(
   if (N > 0) {
     float* out = partials + (int64_t)blockIdx.x * (nt + n6);
     const bool with_atomic = s_used_atomic != 0;               // workgroup-uniform; usually false: no index arithmetic then
+    if (!with_atomic && ((nt + n6) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(tri_all) & 15) == 0) {
+      // the usual case, four entries per lane and instruction: the same additions in the same order (wave 0's slab first)
+      const int n4 = (nt + n6) >> 2;
+      const float4* t4 = reinterpret_cast<const float4*>(tri_all);
+      float4* o4 = reinterpret_cast<float4*>(out);
+      for (int i = tid; i < n4; i += REG_THREADS) {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int w = 0; w < REG_WAVES; w++) { const float4 a = t4[w * n4 + i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        o4[i] = v;
+      }
+    } else
     for (int i = tid; i < nt + n6; i += REG_THREADS) {
       float v = 0.0f;
       if (with_atomic) {

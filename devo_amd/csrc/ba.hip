@@ -2954,7 +2954,8 @@ int devo_transform(const float* poses, const float* patches, const float* intrin
     }
     pm = CorrPlanMode{plan_width, plan_l1, 16 * corr_region_tmax(plan_radius), (int)nbins - 1};
   }
-  hipLaunchKernelGGL(P == 3 ? k_transform<true> : k_transform<false>, dim3(blocks_for(E, 128, 4096)), dim3(128), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
+  static const int tblock = [] { const char* e = getenv("DEVO_TRANSFORM_BLOCK"); const int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 64; }();   // (tuning switch; 64 / 128 / 256 threads: 7.40 / 7.78 / 8.28 us at cfg2)
+  hipLaunchKernelGGL(P == 3 ? k_transform<true> : k_transform<false>, dim3(blocks_for(E, tblock, 4096)), dim3(tblock), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
                      kk, coords_pp2, coords_2pp, valid, Ji, Jj, Jz, E, P, flags, plan ? plan + E + 1 : nullptr, plan_frames, plan_height,
                      nb, 2 * plan_radius + 2, plan_radius <= 3 ? 1 : 3, pm);
   return check_launch("devo_transform");

@@ -1316,7 +1316,10 @@ int devo_corr_pyramid_split_frames(const void* fmap2, const int64_t* f2s, int cb
   const SplitSrc S{f2s[0], f2s[1], f2s[2], f2s[3], cblock};
   const long long per = (long long)(C / 8) * H * W;
   const dim3 grid((unsigned)std::min<long long>((per + 255) / 256, 2048), (unsigned)F);
-  hipLaunchKernelGGL(corr_split_max_kernel, grid, dim3(256), 0, st, (const float*)fmap2, S, C, H, W, maxbits);
+  // the max pass: ~8 records per thread, at most 256 workgroups per frame and ~2 048 in all (each ends in one atomic on the frames' shared line)
+  const long long want = std::max<long long>(1, std::min<long long>((per + 2047) / 2048, std::max<long long>(8, 2048 / F)));
+  const dim3 mgrid((unsigned)std::min<long long>(want, 256), (unsigned)F);
+  hipLaunchKernelGGL(corr_split_max_kernel, mgrid, dim3(256), 0, st, (const float*)fmap2, S, C, H, W, maxbits);
   hipLaunchKernelGGL(corr_split_kernel, grid, dim3(256), 0, st, (const float*)fmap2, S, C, H, W, (const unsigned*)maxbits, (float*)dst, dst_fstride, exps);
   return check_launch("devo_corr_pyramid_split");
 }

@@ -333,7 +333,12 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=40):
             P1, Q1 = sposes.clone(), spatches.clone()
             state = {"f": nk}
 
+            g_ii, g_jj, g_kk = sii, sjj, skk                                   # the graph's index tensors; every frame gets NEW ones (below)
+
             def frame_and_update():
+                # devo.py:228-231,304-306 rebuild ii / jj / kk with torch.cat / boolean masks for every frame: fresh tensors, so that nothing
+                # keyed on the graph (the BA's remembered index tables, the Update operator's neighbour tables) survives from frame to frame
+                sii, sjj, skk = g_ii.clone(), g_jj.clone(), g_kk.clone()
                 k = state["f"] % mem
                 state["f"] += 1
                 gmap_[k] = gm_new[k % 4]                                      # devo.py:524
@@ -374,9 +379,10 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=40):
                             p_.mul_(0.05)                                     # small flow updates: the adjustment stays in its basin
                 imap_ = (torch.randn(mem, M, 384, device=device) * 0.5).to(dt)
                 st2 = {"f": nk, "net": torch.zeros(1, sE, 384, device=device, dtype=dt)}
-                ring_idx = skk % (M * mem)
 
                 def frame_full():
+                    sii, sjj, skk = g_ii.clone(), g_jj.clone(), g_kk.clone()   # (a new graph per frame, as above)
+                    ring_idx = skk % (M * mem)
                     k = st2["f"] % mem
                     st2["f"] += 1
                     gmap_[k] = gm_new[k % 4]; fmap1_[:, k] = fm_new[k % 4]; fmap2_[:, k] = f1_new[k % 4]

@@ -107,6 +107,57 @@ __global__ __launch_bounds__(1024) void k_excl_scan(int* data, int n, int* total
   if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
+// ---- the multi-kernel preparation works on the RANGE of patch ids the edge list holds, not on all patch slots (round 6): DEVO's buffers have
+// 2048 frames x 96 = 196 608 slots, a sliding-window graph touches the 2 112 patches of 22 frames — flags, scan and the unique-id sweep over the
+// slots cost 380 us there, over the range 30.  range[0] = max(-k), range[1] = max(k) over the valid ids (both start at 0x80808080: "minus infinity").
+__global__ void k_kk_range(const int64_t* __restrict__ kk, int E, int Np, int* __restrict__ range) {
+  int nlo = (int)0x80808080, hi = (int)0x80808080;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
+    const int64_t k = kk[e];
+    if (k >= 0 && k < Np) { nlo = max(nlo, -(int)k); hi = max(hi, (int)k); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { nlo = max(nlo, __shfl_xor(nlo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+  if ((threadIdx.x & 63) == 0 && hi != (int)0x80808080) { atomicMax(&range[0], nlo); atomicMax(&range[1], hi); }
+}
+__device__ __forceinline__ void kk_range(const int* __restrict__ range, int& kmin, int& Rg) {
+  const int nlo = range[0], hi = range[1];
+  const bool any = hi != (int)0x80808080;
+  kmin = any ? -nlo : 0;
+  Rg = any ? hi - kmin + 1 : 0;
+}
+__global__ void k_flag_ids_r(const int64_t* __restrict__ kk, int E, int Np, int* flags, const int* __restrict__ range) {
+  int kmin, Rg;
+  kk_range(range, kmin, Rg);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
+    const int64_t k = kk[e];
+    if (k >= 0 && k < Np) flags[(int)k - kmin] = 1;
+  }
+}
+// k_excl_scan over a length read on the device: mode 0 = the id range (range), mode 1 = min(*n_ptr, cap) (the segment counts: n_seg of them)
+__global__ __launch_bounds__(1024) void k_excl_scan_dev(int* data, const int* __restrict__ n_ptr, int mode, int cap, int* total_out) {
+  __shared__ int s_part[1024];
+  int n;
+  if (mode == 0) { int kmin; kk_range(n_ptr, kmin, n); } else n = min(*n_ptr, cap);
+  const int total = block_excl_scan_1024(data, n, s_part);
+  if (threadIdx.x == 0 && total_out) *total_out = total;
+  if (mode == 1) for (int i = n + 1 + threadIdx.x; i <= cap; i += 1024) data[i] = total;     // segment starts beyond n_seg = E: any reader sees empty tails
+}
+__global__ void k_rank_edges_r(const int64_t* __restrict__ kk, int E, int Np, const int* __restrict__ rank, int* ku, int* kx, int* counts,
+                               const int* __restrict__ range) {
+  int kmin, Rg;
+  kk_range(range, kmin, Rg);
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = blockDim.x * gridDim.x;
+  for (int e = gid; e < E; e += gsz) {
+    const int64_t k = kk[e];
+    const int r = (k >= 0 && k < Np) ? rank[(int)k - kmin] : 0;
+    ku[e] = r;
+    atomicAdd(&counts[r], 1);
+  }
+  for (int p = gid; p < Rg; p += gsz)
+    if (rank[p + 1] != rank[p]) kx[rank[p]] = kmin + p;
+}
+
 __global__ void k_flag_ids(const int64_t* __restrict__ kk, int E, int Np, int* flags) {
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
     int64_t k = kk[e];
@@ -157,6 +208,13 @@ __global__ void k_sort_segments(const int* __restrict__ seg_start, BaMeta* __res
 // patches — DEVO's sliding window is ~2k patches); otherwise the same arrays in the workspace are used.
 constexpr int PREP_FLAGS_LDS = 16384;
 constexpr int PREP_SEGS_LDS = 8192;
+#ifdef DEVO_PREP_TRACE
+// debug build (tools/build_variant.sh preptrace ba -DDEVO_PREP_TRACE; tools/bench_prepare.py): 100 MHz stamps of thread 0 at the phase boundaries
+__device__ unsigned long long g_prep_trace[16];
+#define PREP_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) g_prep_trace[i] = wall_clock64(); } while (0)
+#else
+#define PREP_STAMP(i) do { } while (0)
+#endif
 template <int CACHE>      // CACHE = 0: kk is re-read by every pass; else ceil(E / 1024) <= CACHE edges per thread in registers
 __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, int E, int Np, int max_seg, BaMeta* meta,
                                                 int* g_rank, int* g_counts, int* g_cursor, int* ku, int* kx, int* perm_a,
@@ -169,6 +227,7 @@ __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, 
   __shared__ int s_min, s_max;
   const int t = threadIdx.x;
   if (t == 0) { s_min = 0x7fffffff; s_max = -1; }
+  PREP_STAMP(0);
   // patch id of edge t + 1024 i (or -1: out of range / no edge).  CACHED: all loads in flight at once, every later
   // pass runs from registers; otherwise kk is re-read by every pass.
   constexpr bool CACHED = CACHE > 0;
@@ -194,7 +253,7 @@ __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, 
   // built patch by patch) every segment is a run, the permutation is the identity and the whole counting sort below
   // can be skipped.  headmask bit i = edge t + 1024 i starts a run.
   __shared__ int s_last[16][CACHED ? CACHE : 1];
-  unsigned headmask = 0u;
+  unsigned long long headmask = 0ull;                           // (up to 64 edges per thread)
   int ascending = 0;
   if (CACHED) {
     const int lane_ = t & 63, wave_ = t >> 6;
@@ -211,7 +270,7 @@ __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, 
       if (lane_ == 0) prev = (wave_ > 0) ? s_last[wave_ - 1][i] : (i > 0 ? s_last[15][i > 0 ? i - 1 : 0] : -1);
       if (e < E) {
         ok = ok && kreg[i] >= 0 && (e == 0 || prev <= kreg[i]);
-        if (e == 0 || prev != kreg[i]) headmask |= 1u << i;
+        if (e == 0 || prev != kreg[i]) headmask |= 1ull << i;
       }
     }
     ascending = __syncthreads_and(ok ? 1 : 0);
@@ -226,7 +285,7 @@ __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, 
     constexpr int NCH = 16 * (CACHED ? CACHE : 1);
 #pragma unroll
     for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
-      const unsigned long long hb = __ballot((headmask >> i) & 1u);
+      const unsigned long long hb = __ballot((headmask >> i) & 1ull);
       if (lane_ == 0) s_part[16 * i + wave_] = __popcll(hb);
     }
     __syncthreads();
@@ -248,7 +307,7 @@ __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, 
 #pragma unroll
     for (int i = 0; i < (CACHED ? CACHE : 1); i++) {
       const int e = t + 1024 * i;
-      const bool head = (headmask >> i) & 1u;
+      const bool head = (headmask >> i) & 1ull;
       const unsigned long long hb = __ballot(head);
       if (e < E) {
         perm_b[e] = e;
@@ -258,6 +317,7 @@ __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, 
     for (int i = n_seg + t; i <= max_seg; i += 1024) g_counts[i] = E;      // segment n_seg starts at E; empty tails
     return;
   }
+  PREP_STAMP(1);                                               // kk loaded, ascending test done
   int lo = 0x7fffffff, hi = -1;
 #pragma unroll
   for (int i = 0; i < iters; i++) { const int k = patch_of(i); if (k >= 0) { lo = min(lo, k); hi = max(hi, k); } }
@@ -272,7 +332,9 @@ __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, 
 #pragma unroll
   for (int i = 0; i < iters; i++) { const int k = patch_of(i); if (k >= 0) rank[k - kmin] = 1; }
   __syncthreads();
+  PREP_STAMP(2);                                               // range, flags
   const int n_seg = block_excl_scan_1024(rank, Rg, s_part);
+  PREP_STAMP(3);                                               // unique ids ranked
   // (sig: the workspace holds a prepared graph once this kernel is through — the in-segment order is restored below)
   if (t == 0) { meta->n_seg = n_seg; meta->fail = 0; meta->pad = ascending; meta->sig = sig; }
   int* counts = (n_seg <= PREP_SEGS_LDS) ? s_counts : g_counts;
@@ -334,10 +396,12 @@ __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, 
       if (r >= 0 && hl == lane) atomicAdd(&counts[r], nh - lane);
     }
   }
+  PREP_STAMP(4);                                               // segments counted
   for (int p = t; p < Rg; p += 1024)
     if (rank[p + 1] != rank[p]) kx[rank[p]] = kmin + p;
   __syncthreads();
   block_excl_scan_1024(counts, n_seg, s_part);
+  PREP_STAMP(5);                                               // segment starts
 #pragma unroll
   for (int i = 0; i < iters; i++) {
     const int e = t + 1024 * i;
@@ -354,21 +418,64 @@ __device__ __forceinline__ void ba_prepare_body(const int64_t* __restrict__ kk, 
       if (sgm >= 0) perm_a[counts[sgm] + base + (lane - hl)] = e;
     }
   }
+  PREP_STAMP(6);                                               // scattered
   // publish the segment starts: entries beyond n_seg = E so that any reader sees empty tails
   for (int i = t; i <= max_seg; i += 1024) g_counts[i] = (i <= n_seg) ? counts[i] : E;
+  PREP_STAMP(7);                                               // starts published
   // restore a deterministic (ascending edge id) order inside every segment: rank sort, one wave per segment (the work of
   // k_sort_segments, which the multi-kernel path for huge edge lists still launches)
   __threadfence_block();
   __syncthreads();
-  for (int sgi = t >> 6; sgi < n_seg; sgi += 16) {
-    const int a = counts[sgi], m = counts[sgi + 1] - a;
-    for (int i = lane; i < m; i += 64) {
-      const int x = perm_a[a + i];
-      int r = 0;
-      for (int j = 0; j < m; j++) r += (perm_a[a + j] < x);
-      perm_b[a + r] = x;
+  // round 6: two segments per pass, one per half of the wave, the ranks from v_readlane instead of one (L1-hit) load per comparison, the next
+  // pass's elements requested before this pass's ranks are counted — DEVO's steady-state graph (45 312 edges in devo.py's order, 2 112 patches of
+  // ~21 edges) spent 260 of this kernel's 280 us in the loop below when every comparison was a load
+  {
+    const int wv16 = t >> 6, half = lane >> 5, l = lane & 31;
+    auto fetch = [&](int pair, int& a, int& m, int& x) {
+      const int sg = 2 * pair + half;
+      a = 0; m = 0;
+      if (sg < n_seg) { a = counts[sg]; m = counts[sg + 1] - a; }
+      x = (l < m && m <= 32) ? perm_a[a + l] : 0x7fffffff;
+    };
+    const int npair = (n_seg + 1) >> 1;
+    constexpr int SD = 6;                                        // passes whose elements are in flight together (one round trip per SD passes)
+    for (int base = wv16; base < npair; base += 16 * SD) {
+      int a[SD], m[SD], x[SD];
+#pragma unroll
+      for (int u = 0; u < SD; u++) {
+        a[u] = 0; m[u] = 0; x[u] = 0x7fffffff;
+        if (base + 16 * u < npair) fetch(base + 16 * u, a[u], m[u], x[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < SD; u++) {
+        const int pair = base + 16 * u;
+        if (pair >= npair) break;                                  // (wave-uniform)
+        const int mmax = max(__builtin_amdgcn_readlane(m[u], 0), __builtin_amdgcn_readlane(m[u], 32));
+        if (mmax <= 32) {
+          int r = 0;
+          for (int j = 0; j < mmax; j++) {
+            const int xa = __builtin_amdgcn_readlane(x[u], j), xb = __builtin_amdgcn_readlane(x[u], 32 + j);     // (j is wave-uniform)
+            r += ((half ? xb : xa) < x[u]) ? 1 : 0;
+          }
+          if (l < m[u]) perm_b[a[u] + r] = x[u];
+        } else {
+          // a long segment in the pair: the general loop for both (rare: a patch with more than 32 edges)
+          for (int h = 0; h < 2; h++) {
+            const int sg = 2 * pair + h;
+            if (sg >= n_seg) break;
+            const int a2 = counts[sg], m2 = counts[sg + 1] - a2;
+            for (int i = lane; i < m2; i += 64) {
+              const int x2 = perm_a[a2 + i];
+              int r = 0;
+              for (int jq = 0; jq < m2; jq++) r += (perm_a[a2 + jq] < x2);
+              perm_b[a2 + r] = x2;
+            }
+          }
+        }
+      }
     }
   }
+  PREP_STAMP(8);                                               // segments sorted
 }
 
 template <int CACHE>
@@ -2436,7 +2543,7 @@ __global__ void k_neighbors(const int64_t* __restrict__ jj, int E, const int* __
 
 // ------------------------------------------------------------------------------------------------- workspace
 struct BaLayout {
-  size_t meta, rank, counts, cursor, ku, perm_a, perm_b, kx, partials, S, y, dX, patch_rec, edge_ej, prec, ybar, total, partials_bytes;
+  size_t meta, rank, counts, cursor, ku, perm_a, perm_b, kx, range, partials, S, y, dX, patch_rec, edge_ej, prec, ybar, total, partials_bytes;
   int max_seg, n_part;
 };
 // Form of the register-path accumulate kernel (N <= 16) and its waves per workgroup — DEVO_BA_REGFOLD=1: the register fold.
@@ -2479,6 +2586,7 @@ static BaLayout ba_layout(int E, int Np, int N) {
   L.perm_a = take(sizeof(int) * (size_t)(E > 0 ? E : 1));
   L.perm_b = take(sizeof(int) * (size_t)(E > 0 ? E : 1));
   L.kx = take(sizeof(int) * (size_t)L.max_seg);
+  L.range = take(sizeof(int) * 4);                                  // the multi-kernel preparation's id range
   L.partials_bytes = sizeof(float) * (size_t)L.n_part * (n6 * (n6 + 1) + n6 + 1);
   if (N > BA_MAXN_LDS) {                                            // no partial systems: the area only holds k_ba_schur's partial tiles
     const size_t nt = (n6 + 1 + SCH_T - 1) / SCH_T, ntile = nt * (nt + 1) / 2, nchunk = ((size_t)L.max_seg + SCH_K - 1) / SCH_K;
@@ -2504,6 +2612,9 @@ static unsigned next_pow2(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; r
 using namespace devo;
 
 extern "C" {
+#ifdef DEVO_PREP_TRACE
+int devo_debug_prep_trace(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prep_trace), sizeof(g_prep_trace)); }
+#endif
 #ifdef DEVO_ACC_TRACE
 int devo_debug_acc_trace(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_acc_trace), sizeof(g_acc_trace)); }
 #endif
@@ -2539,7 +2650,10 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     (void)hipFuncSetAttribute((const void*)k_ba_prepare<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
     (void)hipGetLastError();
   }
-  if (E <= (1 << 17)) {
+  // the single workgroup keeps up to 32 edges per thread in registers; beyond (DEVO's steady-state graph: 45 312 edges) its uncached passes and its
+  // 16 waves sorting 2 112 segments take 280 us where the multi-kernel path — on the id RANGE — takes 30 (DEVO_BA_PREP_MULTI_FROM: tuning switch)
+  static const int multi_from = [] { const char* e = getenv("DEVO_BA_PREP_MULTI_FROM"); return e ? atoi(e) : 32 * 1024 + 1; }();
+  if (E <= (1 << 17) && E < multi_from) {
     typedef void (*prep_fn_t)(const int64_t*, int, int, int, BaMeta*, int*, int*, int*, int*, int*, int*, int*, int);
     const int ept = (E + 1023) / 1024;                         // edges per thread
     prep_fn_t prep = ept <= 8 ? k_ba_prepare<8> : ept <= 16 ? k_ba_prepare<16> : ept <= 24 ? k_ba_prepare<24> :
@@ -2564,12 +2678,16 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     }
   } else {
     // (meta, rank, counts, cursor are contiguous at the head of the workspace)
-    if (hipMemsetAsync(w + L.meta, 0, L.ku - L.meta, st) != hipSuccess) { set_error("devo_ba_prepare: memset failed"); return DEVO_ERR_LAUNCH; }
+    int* range = (int*)(w + L.range);
+    if (hipMemsetAsync(w + L.meta, 0, L.ku - L.meta, st) != hipSuccess || hipMemsetAsync(range, 0x80, sizeof(int) * 4, st) != hipSuccess) {
+      (void)hipGetLastError(); set_error("devo_ba_prepare: memset failed"); return DEVO_ERR_LAUNCH;
+    }
     const int eb = blocks_for(E, 256, 1024);
-    hipLaunchKernelGGL(k_flag_ids, dim3(eb), dim3(256), 0, st, kk, E, Np, rank);
-    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, rank, Np, &meta->n_seg);
-    hipLaunchKernelGGL(k_rank_edges, dim3(blocks_for(E > Np ? E : Np, 256, 1024)), dim3(256), 0, st, kk, E, Np, rank, ku, kx, counts);
-    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, st, counts, L.max_seg, (int*)nullptr);
+    hipLaunchKernelGGL(k_kk_range, dim3(eb), dim3(256), 0, st, kk, E, Np, range);
+    hipLaunchKernelGGL(k_flag_ids_r, dim3(eb), dim3(256), 0, st, kk, E, Np, rank, range);
+    hipLaunchKernelGGL(k_excl_scan_dev, dim3(1), dim3(1024), 0, st, rank, range, 0, 0, &meta->n_seg);
+    hipLaunchKernelGGL(k_rank_edges_r, dim3(eb), dim3(256), 0, st, kk, E, Np, rank, ku, kx, counts, range);
+    hipLaunchKernelGGL(k_excl_scan_dev, dim3(1), dim3(1024), 0, st, counts, &meta->n_seg, 1, L.max_seg, (int*)nullptr);
     hipLaunchKernelGGL(k_scatter_edges, dim3(eb), dim3(256), 0, st, ku, E, counts, cursor, perm_a);
     hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, meta, ba_sig(E, N), perm_a, perm_b);
   }
@@ -2577,7 +2695,7 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     typedef void (*order_fn_t)(const int*, int, int, int*, int);
     const long long per_thread = ((long long)E + ORDER_THREADS - 1) / ORDER_THREADS;
     order_fn_t order_fn = per_thread <= 8 ? k_order_only<8> : per_thread <= 16 ? k_order_only<16> : per_thread <= 24 ? k_order_only<24> :
-                          per_thread <= 32 ? k_order_only<32> : k_order_only<0>;
+                          per_thread <= 32 ? k_order_only<32> : per_thread <= 48 ? k_order_only<48> : per_thread <= 64 ? k_order_only<64> : k_order_only<0>;
     hipLaunchKernelGGL(order_fn, dim3((unsigned)corr_order_workgroups(E, plan_nbins)), dim3(ORDER_THREADS), 0, st, plan + E + 1, E, plan_nbins, plan, plan_starts);
   }
   return check_launch("devo_ba_prepare");

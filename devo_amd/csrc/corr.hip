@@ -1364,7 +1364,8 @@ int devo_corr_order(const float* coords, const int64_t* jj, int* order, int B, i
   typedef void (*order_fn_t)(const int*, int, int, int*, int);
   const long long per_thread = (BE + ORDER_THREADS - 1) / ORDER_THREADS;
   order_fn_t order_fn = per_thread <= 8 ? corr_order_kernel<8> : per_thread <= 16 ? corr_order_kernel<16> :
-                        per_thread <= 24 ? corr_order_kernel<24> : per_thread <= 32 ? corr_order_kernel<32> : corr_order_kernel<0>;
+                        per_thread <= 24 ? corr_order_kernel<24> : per_thread <= 32 ? corr_order_kernel<32> :
+                        per_thread <= 48 ? corr_order_kernel<48> : per_thread <= 64 ? corr_order_kernel<64> : corr_order_kernel<0>;   // (DEVO's steady state: 45 312 edges = 45 per thread)
   hipLaunchKernelGGL(order_fn, dim3((unsigned)corr_order_workgroups(BE, nbins)), dim3(ORDER_THREADS), 0, (hipStream_t)stream, bins, (int)BE,
                      (int)nbins, order, l1 >= 2 ? 1 : 0);
   return check_launch("devo_corr_order");

@@ -70,18 +70,21 @@ def prep_stats():
     return tuple(N.cuda_ba._prep_stats()) if N is not None else (_prep["hits"], _prep["misses"])
 
 
-def prepared_tables(ws, E, n_patch_slots, n_opt):
+def prepared_tables(ws, E, n_patch_slots, n_opt, sync=True):
     """(n_seg, kx, seg_start, perm) of a prepared workspace — the sorted unique patch ids of kk and its edges grouped by
-    patch (the index work of ba_cuda.cu:435-437); for tests."""
+    patch (the index work of ba_cuda.cu:435-437).  sync=True (tests): n_seg as a Python int, kx / seg_start cut to it — one host
+    synchronisation; sync=False: n_seg as an int32 device tensor [1], kx / seg_start at their full length (entries beyond n_seg: seg_start = E)."""
     dev = ws.device
     m = min(int(E), int(n_patch_slots))
-    n_seg = torch.zeros(1, dtype=torch.int32, device=dev)
-    kx = torch.zeros(m, dtype=torch.int32, device=dev)
-    seg = torch.zeros(m + 1, dtype=torch.int32, device=dev)
-    perm = torch.zeros(int(E), dtype=torch.int32, device=dev)
+    n_seg = torch.empty(1, dtype=torch.int32, device=dev)
+    kx = torch.empty(m, dtype=torch.int32, device=dev)
+    seg = torch.empty(m + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(int(E), dtype=torch.int32, device=dev)
     rc = L.lib().devo_ba_prepared_tables(L.ptr(ws), ws.numel(), int(E), int(n_patch_slots), int(n_opt), L.ptr(n_seg), L.ptr(kx),
                                          L.ptr(seg), L.ptr(perm), L.stream())
     L.check(rc, "cuda_ba.prepared_tables")
+    if not sync:
+        return n_seg, kx, seg, perm
     n = int(n_seg)
     return n, kx[:n], seg[:n + 1], perm
 

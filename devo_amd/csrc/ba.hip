@@ -74,16 +74,25 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// In-place exclusive scan of data[0..n) by ONE workgroup of 1024 threads; data[n] = total (returned to all).
-// Thread chunks -> wave scan with shuffles -> the 16 wave totals scanned by wave 0: two barriers.  s_part: >= 48 ints.
+// In-place exclusive scan of data[0..n) by ONE workgroup of 1024 threads; data[n] = total (returned to all).  s_part: >= 48 ints.
+// Round 6: every wave owns a contiguous span and walks it 64 consecutive elements at a time — coalesced loads, four steps in flight, a DPP scan per
+// step, the carry in a scalar — where rounds 1-5 gave every THREAD a contiguous chunk and waited for each of its loads in turn: 191 us for the 131 072
+// hash slots of cuda_ba.neighbors at DEVO's steady-state size (45 312 edges), ~0.75 us per element and thread.  Integer sums: any order, the same bits.
 __device__ __forceinline__ int block_excl_scan_1024(int* data, int n, int* s_part) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int chunk = (n + 1023) / 1024;
-  const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
+  const int span = ((n + 16 * 64 - 1) / (16 * 64)) * 64;     // elements per wave, whole steps of 64
+  const int lo = min(n, wave * span), hi = min(n, lo + span);
+  constexpr int UB = 4;
   int s = 0;
-  for (int i = lo; i < hi; i++) s += data[i];
-  const int x = wave_inclusive_sum(s);          // inclusive scan of the chunk sums inside the wave
-  if (lane == 63) s_part[wave] = x;
+  for (int i0 = lo; i0 < hi; i0 += 64 * UB) {
+    int v[UB];
+#pragma unroll
+    for (int u = 0; u < UB; u++) { const int i = i0 + 64 * u + lane; v[u] = (i < hi) ? data[i] : 0; }
+#pragma unroll
+    for (int u = 0; u < UB; u++) s += v[u];
+  }
+  const int x = wave_inclusive_sum(s);
+  if (lane == 63) s_part[wave] = x;              // the wave's total
   __syncthreads();
   if (wave == 0) {
     const int w = (lane < 16) ? s_part[lane] : 0;
@@ -94,8 +103,19 @@ __device__ __forceinline__ int block_excl_scan_1024(int* data, int n, int* s_par
     if (lane == 15) s_part[32] = y;             // grand total
   }
   __syncthreads();
-  int run = s_part[16 + wave] + x - s;          // exclusive prefix of this thread's chunk
-  for (int i = lo; i < hi; i++) { int v = data[i]; data[i] = run; run += v; }
+  int carry = s_part[16 + wave];                 // (wave-uniform)
+  for (int i0 = lo; i0 < hi; i0 += 64 * UB) {
+    int v[UB];
+#pragma unroll
+    for (int u = 0; u < UB; u++) { const int i = i0 + 64 * u + lane; v[u] = (i < hi) ? data[i] : 0; }
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      const int i = i0 + 64 * u + lane;
+      const int inc = wave_inclusive_sum(v[u]);
+      if (i < hi) data[i] = carry + inc - v[u];
+      carry += __builtin_amdgcn_readlane(inc, 63);
+    }
+  }
   const int total = s_part[32];
   if (t == 1023) data[n] = total;
   __syncthreads();

@@ -617,20 +617,59 @@ class _SoftAggFn(torch.autograd.Function):
         return dfg, None
 
 
+_PINNED = {"pool": [], "next": 0}
+
+
+def _pinned_word():
+    """A pinned int32 word + an event from a small ring (hipHostMalloc per graph costs ~100 us of host time).  A slot is reused after 32 other
+    graphs; its previous owner has read it by then or never will."""
+    P = _PINNED
+    if len(P["pool"]) < 32:
+        P["pool"].append((torch.empty(1, dtype=torch.int32).pin_memory(), torch.cuda.Event()))
+        return P["pool"][-1]
+    P["next"] = (P["next"] + 1) % 32
+    return P["pool"][P["next"]]
+
+
 class _Groups:
     """Edges grouped by an integer key, through the BA's index kernels: perm / seg_start / n_seg (+ group_of scratch)."""
 
     def __init__(self, key, bound=None):
+        """round 6: no host synchronisation here.  `bound` only sizes the workspace (any value above the largest key will do: the index kernels
+        work on the range of keys the list holds); the number of groups stays on the device (`n_seg_dev`, what the kernels read) and is copied to
+        a pinned host word behind the preparation — `n_seg` waits for THAT copy when the first caller asks for the integer (an allocation size, a
+        GEMM's row count), by which time the stream has long moved on: DEVO's steady state builds these tables for a new graph every frame, and
+        three stalls per frame (the bounds, two group counts) cost more than the tables."""
         E = key.numel()
         if bound is None:
-            bound = int(key.max()) + 1 if E else 1   # one host sync per distinct graph (cached by the caller)
+            bound = 1 << 20
         ws = cuda_ba.workspace(E, bound, 0, key.device)
         cuda_ba.prepare(key, bound, 0, ws)
-        self.n_seg, _, self.seg_start, self.perm = cuda_ba.prepared_tables(ws, E, bound, 0)
-        self.n_seg_dev = torch.tensor([self.n_seg], dtype=torch.int32, device=key.device)
-        self.seg_start = self.seg_start.contiguous()
+        self.n_seg_dev, _, self.seg_start, self.perm = cuda_ba.prepared_tables(ws, E, bound, 0, sync=False)
+        self._n_host, self._n_event = _pinned_word()
+        self._n_host.copy_(self.n_seg_dev, non_blocking=True)
+        self._n_event.record()
+        self._n_seg = None
+        self.n_edges = E
         self.group_of = torch.empty(E, dtype=torch.int32, device=key.device)
         self._group_of_long = None
+
+    @property
+    def n_seg(self):
+        """The number of groups as a Python int: waits for the copy behind the preparation (the training path's allocations need it)."""
+        if self._n_seg is None:
+            self._n_event.synchronize()
+            self._n_seg = int(self._n_host[0])
+        return self._n_seg
+
+    def rows(self):
+        """Rows to allocate / launch for per-group tensors WITHOUT waiting: the number of groups if its copy has arrived, else the number of
+        edges (an upper bound: the kernels read the true count from `n_seg_dev`, the GEMM behind them multiplies a few thousand idle rows —
+        6 us — where waiting for the count drains the whole eager pipeline, ~0.5 ms per frame in DEVO's steady state)."""
+        if self._n_seg is None and self._n_event.query():
+            self._n_seg = int(self._n_host[0])
+        return self._n_seg if self._n_seg is not None else self.n_edges
+
 
     def group_of_long(self):
         """edge -> group index as int64 (for index_select in the training path), from the tables themselves"""
@@ -725,13 +764,16 @@ class Update(nn.Module):
         if key != self._graph_key:
             ix, jx = cuda_ba.neighbors(kk, jj)
             il, jl = ii.long(), jj.long()
-            # frame-pair key compacted to the window of live frames: the grouping workspace scales with (frame range)^2, not
-            # with 12345 * (absolute frame index); ONE host transfer for the four bounds (+ kk's) per graph change
-            lo_hi = torch.stack([il.min(), il.max(), jl.min(), jl.max(), kk.max()]).tolist() if ii.numel() else [0, 0, 0, 0, 0]
-            imin, imax, jmin, jmax, kmax = (int(v) for v in lo_hi)
-            span = jmax - jmin + 1
-            pair = ((il - imin) * span + (jl - jmin)).contiguous()           # same groups as ii * 12345 + jj (enet.py:94)
-            self._graph = (ix, jx, _Groups(kk.long().contiguous(), kmax + 1), _Groups(pair, (imax - imin + 1) * span))
+            # frame-pair key compacted to the window of live frames ON THE DEVICE (round 6: the bounds never visit the host — this runs once per
+            # graph, i.e. once per frame in DEVO's steady state, and the .tolist() stalled the eager pipeline): (ii - min ii) * span + (jj - min jj)
+            # with span = max jj - min jj + 1 as a 0-d tensor — the same groups as ii * 12345 + jj (enet.py:94), keys in a range of
+            # (frames in the window)^2, which is what the index kernels' flag / scan passes walk
+            if ii.numel():
+                jmin = jl.min()
+                pair = ((il - il.min()) * (jl.max() - jmin + 1) + (jl - jmin)).contiguous()
+            else:
+                pair = il
+            self._graph = (ix, jx, _Groups(kk.long().contiguous()), _Groups(pair))
             self._graph_key = key
             self._graph_refs = (ii, jj, kk)                                  # keep the key's storages alive (see above)
         return self._graph
@@ -825,16 +867,19 @@ class Update(nn.Module):
         x = y
         code = L.dtype_code(x)
 
-        def agg(G, h):
-            ys = torch.empty(G.n_seg, dim, dtype=dt, device=dev)
+        def agg(G, h, hint):
+            # (a graph seen for the first time: the group count may still be on its way to the host — rows() does not wait for it; `hint` = the
+            #  usual rows per group of this aggregation, which only picks the kernel's workgroup shape)
+            rows = G.rows()
+            ys = torch.empty(rows, dim, dtype=dt, device=dev)
             chk(lib.devo_upd_softagg_hint(P(fg), P(fg[:, dim:]), 2 * dim, P(G.perm), P(G.seg_start), P(G.n_seg_dev), P(ys), P(G.group_of), E, dim, code,
-                                          E // max(G.n_seg, 1), st), "update.softagg")
-            hy = torch.empty(G.n_seg, dim, dtype=dt, device=dev)
-            chk(lib.devo_upd_rs_linear_f16(P(ys), dim, h[0], h[1], None, P(hy), dim, G.n_seg, dim, dim, dim, st), "update.rs_linear_f16")
+                                          (E // max(rows, 1)) if rows < E else hint, st), "update.softagg")
+            hy = torch.empty(rows, dim, dtype=dt, device=dev)
+            chk(lib.devo_upd_rs_linear_f16(P(ys), dim, h[0], h[1], None, P(hy), dim, rows, dim, dim, dim, st), "update.rs_linear_f16")
             return hy
-        hy = agg(Gkk, pl["h_kk"])
+        hy = agg(Gkk, pl["h_kk"], 16)
         chk(lib.devo_upd_rs_expand_fg_f16(P(x), P(hy), P(Gkk.group_of), *pl["fg_ij"], P(fg), E, st), "update.rs_expand_fg_f16")
-        hy = agg(Gij, pl["h_ij"])
+        hy = agg(Gij, pl["h_ij"], 96)
         net_out = torch.empty_like(x)
         dw = torch.empty(2, E, 2, dtype=dt, device=dev)
         g = pl["gru"]
@@ -906,9 +951,11 @@ class Update(nn.Module):
             W, b = self._cat(name, agg.f, agg.g)
             fg = self._lin(net, W, b)                              # [E, 2 dim]: f | g
         E, dim = net.shape
-        y = torch.empty(G.n_seg, dim, dtype=net.dtype, device=net.device)
+        rows = G.rows()                                            # (never waits for a new graph's group count: _Groups.rows)
+        y = torch.empty(rows, dim, dtype=net.dtype, device=net.device)
         L.check(L.lib().devo_upd_softagg_hint(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
-                                              L.ptr(y), L.ptr(G.group_of), E, dim, L.dtype_code(net), int(E // max(int(G.n_seg), 1)), L.stream()),
+                                              L.ptr(y), L.ptr(G.group_of), E, dim, L.dtype_code(net),
+                                              int(E // max(rows, 1)) if rows < E else (16 if name == "agg_kk" else 96), L.stream()),
                 "update.softagg")
         return F.linear(y, agg.h.weight, agg.h.bias), G.group_of
 

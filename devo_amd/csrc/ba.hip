@@ -138,7 +138,13 @@ __global__ void k_kk_range(const int64_t* __restrict__ kk, int E, int Np, int* _
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { nlo = max(nlo, __shfl_xor(nlo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-  if ((threadIdx.x & 63) == 0 && hi != (int)0x80808080) { atomicMax(&range[0], nlo); atomicMax(&range[1], hi); }
+  __shared__ int s_r[2][4];                                    // one pair of atomics per workgroup: they all hit one cache line
+  if ((threadIdx.x & 63) == 0) { s_r[0][threadIdx.x >> 6] = nlo; s_r[1][threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int a = max(max(s_r[0][0], s_r[0][1]), max(s_r[0][2], s_r[0][3])), b = max(max(s_r[1][0], s_r[1][1]), max(s_r[1][2], s_r[1][3]));
+    if (b != (int)0x80808080) { atomicMax(&range[0], a); atomicMax(&range[1], b); }
+  }
 }
 __device__ __forceinline__ void kk_range(const int* __restrict__ range, int& kmin, int& Rg) {
   const int nlo = range[0], hi = range[1];
@@ -2703,7 +2709,7 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
       (void)hipGetLastError(); set_error("devo_ba_prepare: memset failed"); return DEVO_ERR_LAUNCH;
     }
     const int eb = blocks_for(E, 256, 1024);
-    hipLaunchKernelGGL(k_kk_range, dim3(eb), dim3(256), 0, st, kk, E, Np, range);
+    hipLaunchKernelGGL(k_kk_range, dim3(blocks_for(E, 256 * 4, 256)), dim3(256), 0, st, kk, E, Np, range);
     hipLaunchKernelGGL(k_flag_ids_r, dim3(eb), dim3(256), 0, st, kk, E, Np, rank, range);
     hipLaunchKernelGGL(k_excl_scan_dev, dim3(1), dim3(1024), 0, st, rank, range, 0, 0, &meta->n_seg);
     hipLaunchKernelGGL(k_rank_edges_r, dim3(eb), dim3(256), 0, st, kk, E, Np, rank, ku, kx, counts, range);

@@ -978,7 +978,12 @@ class Update(nn.Module):
         L.require_gpu(net, inp, corr, ii, jj, kk)
         B, E, dim = net.shape
         if B != 1:
-            raise RuntimeError("Update: batch size 1 (DEVO never batches the update operator)")
+            # enet.py:80-99 is written for a batch; train.py and devo.py always pass ONE sequence.  Batches run entry by entry on the same graph
+            # tables (ii / jj / kk are shared by the batch, as in the reference): the kernels' row count is what matters, not the launch count
+            if B == 0:
+                raise RuntimeError("Update: empty batch")
+            outs = [self.forward(net[b:b + 1], inp[b:b + 1], corr[b:b + 1], flow, ii, jj, kk) for b in range(B)]
+            return torch.cat([o[0] for o in outs], 0), (torch.cat([o[1][0] for o in outs], 0), torch.cat([o[1][1] for o in outs], 0), None)
         dt = self.norm.weight.dtype
         if (AUTOCAST_F16 and dt == torch.float32 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16 and dim == 384):
             # devo.py:311 calls the fp32 operator under autocast: its Linear layers then run in fp16 (fp32 accumulation), its LayerNorms in fp32.

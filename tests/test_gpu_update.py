@@ -708,3 +708,28 @@ def test_fp32_operator_under_autocast_takes_the_fp16_kernels():
         finally:
             UA.AUTOCAST_F16 = True
         assert_rel(n3.float(), ref2[0], 1e-3, "fp32 kernels under autocast")
+
+
+def test_update_operator_on_a_batch_of_sequences():
+    """enet.py:80-99 is written for a batch [B, E, dim] sharing one graph; the HIP inference path runs a batch entry by entry: every entry equals the
+    single-sequence call (bit for bit) and the torch composition of the same module on the whole batch (1e-4)."""
+    from devo_amd import synth
+    from devo_amd.update import Update
+    ii, jj, kk = [t.to(DEV) for t in synth.full_graph(6, 24)]
+    E = ii.numel()
+    torch.manual_seed(5)
+    upd = Update(3).to(DEV).eval()
+    g = torch.Generator().manual_seed(6)
+    net = (torch.randn(3, E, 384, generator=g) * 0.3).to(DEV)
+    inp = (torch.randn(3, E, 384, generator=g) * 0.3).to(DEV)
+    corr = (torch.randn(3, E, 882, generator=g) * 0.3).to(DEV)
+    with torch.no_grad():
+        n, (d, w, _) = upd(net, inp, corr, None, ii, jj, kk)
+        assert n.shape == (3, E, 384) and d.shape == (3, E, 2) and w.shape == (3, E, 2)
+        for b in range(3):
+            nb, (db, wb, _) = upd(net[b:b + 1], inp[b:b + 1], corr[b:b + 1], None, ii, jj, kk)
+            assert torch.equal(n[b:b + 1], nb) and torch.equal(d[b:b + 1], db) and torch.equal(w[b:b + 1], wb)
+        nt, (dt_, wt, _) = upd.forward_torch(net, inp, corr, ii, jj, kk)
+    assert_rel(n, nt, 1e-4, "batched net")
+    assert_rel(d, dt_, 1e-4, "batched delta")
+    assert_rel(w, wt, 1e-4, "batched weight")

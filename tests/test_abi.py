@@ -127,3 +127,31 @@ def test_compiled_binding_has_the_reference_interfaces(libpath):
     finally:
         for m in ("cuda_corr", "cuda_ba", "lietorch_backends"):
             sys.modules.pop(m, None)
+
+
+def test_ring_write_tracker_is_transparent_on_cpu():
+    """devo_amd.backends.ring wraps torch.Tensor.__setitem__ (installed by backends.install() for the per-slot maintenance of the converted ring
+    buffers): CPU tensors — and anything the binding holds no converted copy of — behave exactly as before, version counters included; the wrapper
+    can be removed again and installing twice is harmless."""
+    from devo_amd.backends import ring
+    was = ring.tracking()                                          # (an earlier test's install() may have switched it on)
+    try:
+        ring.track_ring_writes(False)
+        base = torch.Tensor.__setitem__
+        on = ring.track_ring_writes(True)
+        if os.environ.get("DEVO_RING_SLOTS", "1") == "0":
+            assert not on
+            return
+        assert on and ring.tracking() and torch.Tensor.__setitem__ is not base
+        assert ring.track_ring_writes(True)                       # idempotent
+        a = torch.zeros(1, 4, 3, 5, 5)
+        v0 = a._version
+        a[:, 1] = torch.ones(1, 3, 5, 5)
+        a[0, 2] = a[0, 1]
+        a[:, torch.tensor([0, 3])] = 2.0
+        assert a._version == v0 + 3 and float(a[0, 1].sum()) == 75.0 and float(a[0, 2].sum()) == 75.0 and float(a[0, 3].sum()) == 150.0
+        with pytest.raises((IndexError, RuntimeError)):
+            a[:, 9] = 1.0                                          # errors pass through
+        assert not ring.track_ring_writes(False) and torch.Tensor.__setitem__ is base
+    finally:
+        ring.track_ring_writes(was)

@@ -162,3 +162,68 @@ def test_a_ba_call_is_at_most_seven_launches():
         torch.cuda.synchronize()
     names = [ev.name for ev in prof.events() if "cuda" in str(getattr(ev, "device_type", "")).lower() and "k_ba" in ev.name]
     assert len(names) == 6 and sum("solve_retract" in n for n in names) == 2 and not any("k_ba_retract" in n or "prepare" in n for n in names), names
+
+
+def test_index_tables_of_the_sliding_window_graph_with_devos_buffer_size():
+    """cuda_ba.prepare on DEVO's steady-state edge list (45 312 edges in devo.py's order: the multi-kernel path, which works on the RANGE of patch ids)
+    with the patch slots of DEVO's 2048-frame buffers (196 608): sorted unique ids and per patch exactly its edges in ascending order, as torch.unique
+    groups them (ba_cuda.cu:435-437)."""
+    from devo_amd.backends import cuda_ba
+    kk = synth.sliding_window_graph(40, 96)[2]
+    E, Np = len(kk), 2048 * 96
+    ws = cuda_ba.workspace(E, Np, 10, torch.device(DEV))
+    cuda_ba.prepare(kk.to(DEV), Np, 10, ws)
+    n_seg, kx, seg, perm = cuda_ba.prepared_tables(ws, E, Np, 10)
+    kx_ref, inv = torch.unique(kk, sorted=True, return_inverse=True)
+    assert n_seg == len(kx_ref) == 22 * 96 and torch.equal(kx.cpu().long(), kx_ref)
+    seg, perm = seg.cpu().long(), perm.cpu().long()
+    assert seg[0] == 0 and seg[-1] == E and torch.equal(seg[1:] - seg[:-1], torch.bincount(inv, minlength=n_seg))
+    assert torch.equal(inv[perm], torch.repeat_interleave(torch.arange(n_seg), seg[1:] - seg[:-1]))
+    same = inv[perm][1:] == inv[perm][:-1]
+    assert bool((perm[1:][same] > perm[:-1][same]).all())
+    # the full table (sync=False): entries beyond n_seg read E — any reader sees empty tails
+    n_dev, _, seg_full, _ = cuda_ba.prepared_tables(ws, E, Np, 10, sync=False)
+    assert int(n_dev) == n_seg and bool((seg_full[n_seg:] == E).all())
+
+
+_PREP_AB = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from devo_amd.backends import cuda_ba
+out = {}
+g = torch.Generator().manual_seed(7)
+for name, E, Np in (("random", 20000, 900), ("bad_ids", 9000, 400), ("all_bad", 3000, 50), ("ascending", 21600, 1440)):
+    kk = torch.randint(0, Np, (E,), generator=g)
+    if name == "bad_ids":
+        kk[::13] = -1; kk[5::17] = Np + 3
+    if name == "all_bad":
+        kk[:] = Np + 1
+    if name == "ascending":
+        kk = torch.arange(Np).repeat_interleave(E // Np)
+    ws = cuda_ba.workspace(E, Np, 5, "cuda")
+    cuda_ba.prepare(kk.cuda(), Np, 5, ws)
+    n, kx, seg, perm = cuda_ba.prepared_tables(ws, E, Np, 5)
+    out[name] = (n, kx.cpu(), seg.cpu(), perm.cpu())
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_the_two_preparation_paths_build_the_same_tables(tmp_path):
+    """The single-workgroup kernel (<= 32 768 edges) and the multi-kernel path (beyond; DEVO_BA_PREP_MULTI_FROM forces it here) on the same lists —
+    random ids, ids out of range (they join segment 0, as before), nothing but bad ids, ascending ids: identical tables."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for multi in (False, True):
+        env = dict(os.environ)
+        env.pop("DEVO_BA_PREP_MULTI_FROM", None)
+        if multi:
+            env["DEVO_BA_PREP_MULTI_FROM"] = "1"
+        path = str(tmp_path / f"prep_{int(multi)}.pt")
+        r = subprocess.run([sys.executable, "-c", _PREP_AB, root, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res.append(torch.load(path))
+    for name in res[0]:
+        a, b = res[0][name], res[1][name]
+        assert a[0] == b[0], name
+        for x, y in zip(a[1:], b[1:]):
+            assert torch.equal(x, y), name

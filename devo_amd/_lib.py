@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.abspath(os.environ["DEVO_LIB"]) if os.environ.get("DEVO_LIB") else os.path.join(_HERE, "lib", "libdevo_hip.so")
 
 DEVO_F32, DEVO_F16, DEVO_F64 = 0, 1, 2
-ABI_VERSION = 3                # include/devo_hip.h DEVO_ABI_VERSION: a library of another version is refused (argument lists differ)
+ABI_VERSION = 4                # include/devo_hip.h DEVO_ABI_VERSION: a library of another version is refused (argument lists differ)
 CBLOCK_SPLIT8 = -8             # DEVO_CBLOCK_SPLIT8: fp32 level in the split-blocked format of devo_corr_pyramid_split
 PLAN_TAIL = 4104               # DEVO_CORR_PLAN_TAIL: a plan buffer that can hold a group plan has 2 n + 2 + PLAN_TAIL ints
 PLAN_EDGES, PLAN_GROUPS = 0, 1
@@ -58,6 +58,8 @@ _SIGNATURES = {
     "devo_transform_vjp": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "devo_ba_edge_terms": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "devo_ba_edge_terms_backward": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "devo_ba_table_offsets": [_i, _i, _i, _vp],
+    "devo_upd_graph_tables": [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp],
     "devo_neighbors_workspace_bytes": [_i],
     "devo_ba_neighbors": [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp],
     "devo_ba_reproject": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -194,6 +194,50 @@ def neighbors(ii, jj):
     return [ix, jx]
 
 
+_offsets = {}
+
+
+def table_offsets(E, n_patch_slots, n_opt):
+    """(n_seg, kx, seg_start, perm) byte offsets into a prepared workspace of these sizes + the length of kx (devo_ba_table_offsets)."""
+    key = (int(E), int(n_patch_slots), int(n_opt))
+    o = _offsets.get(key)
+    if o is None:
+        buf = (ctypes.c_size_t * 5)()
+        L.check(L.lib().devo_ba_table_offsets(*key, ctypes.cast(buf, ctypes.c_void_p)), "cuda_ba.table_offsets")
+        if len(_offsets) > 64:
+            _offsets.clear()
+        o = _offsets[key] = tuple(int(v) for v in buf)
+    return o
+
+
+def table_views(ws, E, n_patch_slots, n_opt):
+    """(n_seg i32 [1], kx, seg_start, perm) as int32 VIEWS of a prepared workspace (no copies; valid until the workspace is prepared again)."""
+    o_n, o_kx, o_seg, o_perm, m = table_offsets(E, n_patch_slots, n_opt)
+    v = lambda off, n: ws[off:off + 4 * n].view(torch.int32)
+    return v(o_n, 1), v(o_kx, m), v(o_seg, m + 1), v(o_perm, int(E))
+
+
+def graph_tables(ii, jj, kk, bound=1 << 20):
+    """The Update operator's tables of one edge list (devo/enet.py:86-95) from ONE library call (devo_upd_graph_tables): ix, jx =
+    neighbors(kk, jj); the edges grouped by patch kk; the edges grouped by frame pair (ii, jj).  Returns
+    (ix, jx, (n_seg, seg_start, perm) by patch, (n_seg, seg_start, perm) by pair): int32 device views of two workspaces this call
+    allocates (n_seg: [1], the group count stays on the device).  kk in [0, bound), (frames in the window)^2 <= bound."""
+    L.require_gpu(ii, jj, kk)
+    ii, jj, kk = _idx(ii, jj, kk)
+    E, dev = kk.numel(), kk.device
+    if E == 0:
+        raise RuntimeError("cuda_ba.graph_tables: empty edge list")
+    nbytes = int(L.lib().devo_ba_workspace_bytes(E, int(bound), 0))
+    ws = torch.empty(2, nbytes, dtype=torch.uint8, device=dev)
+    nb = torch.empty(2, E, dtype=torch.int64, device=dev)
+    key = torch.empty(E + 2, dtype=torch.int64, device=dev)
+    rc = L.lib().devo_upd_graph_tables(L.ptr(ii), L.ptr(jj), L.ptr(kk), E, int(bound), L.ptr(ws[0]), nbytes, L.ptr(ws[1]), nbytes,
+                                       L.ptr(key), L.ptr(nb[0]), L.ptr(nb[1]), L.stream())
+    L.check(rc, "cuda_ba.graph_tables")
+    tk, tp = table_views(ws[0], E, bound, 0), table_views(ws[1], E, bound, 0)
+    return nb[0], nb[1], (tk[0], tk[2], tk[3]), (tp[0], tp[2], tp[3])
+
+
 def reproject(poses, patches, intrinsics, ii, jj, kk):
     """ba.cpp:155 -> coords [1, E, 2, P, P] (no depth clamp, ba_cuda.cu:368-418)."""
     N = _nat()

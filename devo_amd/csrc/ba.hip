@@ -169,16 +169,36 @@ __global__ __launch_bounds__(1024) void k_excl_scan_dev(int* data, const int* __
   if (threadIdx.x == 0 && total_out) *total_out = total;
   if (mode == 1) for (int i = n + 1 + threadIdx.x; i <= cap; i += 1024) data[i] = total;     // segment starts beyond n_seg = E: any reader sees empty tails
 }
-__global__ void k_rank_edges_r(const int64_t* __restrict__ kk, int E, int Np, const int* __restrict__ rank, int* ku, int* kx, int* counts,
-                               const int* __restrict__ range) {
+// Few, large segments (the Update operator's frame-pair groups: 45 312 edges in 210 groups) make the per-edge device atomics of the counting and
+// scattering passes queue on a handful of addresses (23 us each where the patch groups take 5): when n_seg <= SEG_LDS_MAX and the average segment
+// holds >= 64 edges, every workgroup counts in LDS first and issues ONE device atomic per segment it met.
+constexpr int SEG_LDS_MAX = 1024;
+__device__ __forceinline__ bool seg_lds_path(int n_seg, int E) { return n_seg <= SEG_LDS_MAX && (long long)n_seg * 64 <= E; }
+__global__ __launch_bounds__(256) void k_rank_edges_r(const int64_t* __restrict__ kk, int E, int Np, const int* __restrict__ rank, int* ku, int* kx,
+                                                      int* counts, const int* __restrict__ range, const int* __restrict__ n_seg_p) {
+  __shared__ int s_hist[SEG_LDS_MAX];
   int kmin, Rg;
   kk_range(range, kmin, Rg);
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = blockDim.x * gridDim.x;
-  for (int e = gid; e < E; e += gsz) {
-    const int64_t k = kk[e];
-    const int r = (k >= 0 && k < Np) ? rank[(int)k - kmin] : 0;
-    ku[e] = r;
-    atomicAdd(&counts[r], 1);
+  const int n_seg = max(*n_seg_p, 1);                         // (edges with bad ids count for segment 0, even when no id is good)
+  if (seg_lds_path(n_seg, E)) {
+    for (int b = threadIdx.x; b < n_seg; b += blockDim.x) s_hist[b] = 0;
+    __syncthreads();
+    for (int e = gid; e < E; e += gsz) {
+      const int64_t k = kk[e];
+      const int r = (k >= 0 && k < Np) ? rank[(int)k - kmin] : 0;
+      ku[e] = r;
+      atomicAdd(&s_hist[r], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < n_seg; b += blockDim.x) { const int c = s_hist[b]; if (c) atomicAdd(&counts[b], c); }
+  } else {
+    for (int e = gid; e < E; e += gsz) {
+      const int64_t k = kk[e];
+      const int r = (k >= 0 && k < Np) ? rank[(int)k - kmin] : 0;
+      ku[e] = r;
+      atomicAdd(&counts[r], 1);
+    }
   }
   for (int p = gid; p < Rg; p += gsz)
     if (rank[p + 1] != rank[p]) kx[rank[p]] = kmin + p;
@@ -207,6 +227,32 @@ __global__ void k_scatter_edges(const int* __restrict__ ku, int E, const int* __
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
     int s = ku[e];
     perm[seg_start[s] + atomicAdd(&cursor[s], 1)] = e;
+  }
+}
+// The same with the workgroup's edges ranked in LDS first (see seg_lds_path): one device atomic per (workgroup, segment) reserves the slots.
+__global__ __launch_bounds__(256) void k_scatter_edges_seg(const int* __restrict__ ku, int E, const int* __restrict__ seg_start, int* cursor, int* perm,
+                                                           const int* __restrict__ n_seg_p) {
+  __shared__ int s_hist[SEG_LDS_MAX];
+  const int n_seg = max(*n_seg_p, 1);
+  const int gsz = blockDim.x * gridDim.x;
+  if (!seg_lds_path(n_seg, E)) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gsz) {
+      const int s = ku[e];
+      perm[seg_start[s] + atomicAdd(&cursor[s], 1)] = e;
+    }
+    return;
+  }
+  for (int base = blockIdx.x * blockDim.x; base < E; base += gsz) {          // (uniform per workgroup: the barriers below are safe)
+    for (int b = threadIdx.x; b < n_seg; b += blockDim.x) s_hist[b] = 0;
+    __syncthreads();
+    const int e = base + threadIdx.x;
+    int s = 0, lr = 0;
+    if (e < E) { s = ku[e]; lr = atomicAdd(&s_hist[s], 1); }
+    __syncthreads();
+    for (int b = threadIdx.x; b < n_seg; b += blockDim.x) { const int c = s_hist[b]; if (c) s_hist[b] = atomicAdd(&cursor[b], c); }
+    __syncthreads();
+    if (e < E) perm[seg_start[s] + s_hist[s] + lr] = e;
+    __syncthreads();
   }
 }
 // Restore a deterministic (ascending edge id) order inside every segment: rank sort, one wave per segment.
@@ -2731,9 +2777,9 @@ static int ba_prepare_impl(const int64_t* kk, int E, int Np, int N, void* ws, si
     hipLaunchKernelGGL(k_kk_range, dim3(blocks_for(E, 256 * 4, 256)), dim3(256), 0, st, kk, E, Np, range);
     hipLaunchKernelGGL(k_flag_ids_r, dim3(eb), dim3(256), 0, st, kk, E, Np, rank, range);
     hipLaunchKernelGGL(k_excl_scan_dev, dim3(1), dim3(1024), 0, st, rank, range, 0, 0, &meta->n_seg);
-    hipLaunchKernelGGL(k_rank_edges_r, dim3(eb), dim3(256), 0, st, kk, E, Np, rank, ku, kx, counts, range);
+    hipLaunchKernelGGL(k_rank_edges_r, dim3(eb), dim3(256), 0, st, kk, E, Np, rank, ku, kx, counts, range, &meta->n_seg);
     hipLaunchKernelGGL(k_excl_scan_dev, dim3(1), dim3(1024), 0, st, counts, &meta->n_seg, 1, L.max_seg, (int*)nullptr);
-    hipLaunchKernelGGL(k_scatter_edges, dim3(eb), dim3(256), 0, st, ku, E, counts, cursor, perm_a);
+    hipLaunchKernelGGL(k_scatter_edges_seg, dim3(eb), dim3(256), 0, st, ku, E, counts, cursor, perm_a, &meta->n_seg);
     hipLaunchKernelGGL(k_sort_segments, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, counts, meta, ba_sig(E, N), perm_a, perm_b);
   }
   if (plan) {                                                 // the plan's ordering step on its own
@@ -3087,6 +3133,108 @@ int devo_ba_neighbors(const int64_t* ii, const int64_t* jj, int64_t* ix, int64_t
   hipLaunchKernelGGL(k_scatter_edges, dim3(eb), dim3(256), 0, st, slot_of, E, counts, cursor, perm);                // (cursor[s] ends as the group's size)
   hipLaunchKernelGGL(k_neighbors, dim3(eb), dim3(256), 0, st, jj, E, slot_of, counts, cursor, perm, ix, jx);
   return check_launch("devo_ba_neighbors");
+}
+
+// ---- the Update operator's graph tables in one call (round 6).  DEVO's inference hands the operator NEW ii / jj / kk tensors every frame
+// (devo.py:228-231, :304-306), so what devo_amd.update builds per graph — neighbours by patch, groups by patch, groups by frame pair
+// (enet.py:86-95) — is per-frame work: as torch ops + three separate preparations it was 250 us of a 1.2 ms frame (nine reductions / elementwise
+// kernels for the pair key, a hash grouping for the neighbours that repeats the patch grouping, eight table copies).
+// range[0..3] = max(-ii), max(ii), max(-jj), max(jj), all starting at 0x80808080.
+__global__ void k_pair_range(const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int E, int* __restrict__ range) {
+  int v[4] = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
+    const int i = (int)ii[e], j = (int)jj[e];
+    v[0] = max(v[0], -i); v[1] = max(v[1], i); v[2] = max(v[2], -j); v[3] = max(v[3], j);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int c = 0; c < 4; c++) v[c] = max(v[c], __shfl_xor(v[c], o));
+  __shared__ int s_r[4][4];
+  if ((threadIdx.x & 63) == 0)
+    for (int c = 0; c < 4; c++) s_r[c][threadIdx.x >> 6] = v[c];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int c = threadIdx.x;
+    atomicMax(&range[c], max(max(s_r[c][0], s_r[c][1]), max(s_r[c][2], s_r[c][3])));
+  }
+}
+// key = (ii - min ii) * (max jj - min jj + 1) + (jj - min jj): the groups of ii * 12345 + jj (enet.py:94), keys within (frames in the window)^2
+__global__ void k_pair_key(const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int E, const int* __restrict__ range, int64_t* __restrict__ key) {
+  const int imin = -range[0], jmin = -range[2], span = range[3] - jmin + 1;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x)
+    key[e] = (int64_t)((int)ii[e] - imin) * span + ((int)jj[e] - jmin);
+}
+// cuda_ba.neighbors (ba.cpp:127-139) from the PREPARED tables of the grouping key: one wave per segment, the members' (edge, jj) in the lanes.
+__global__ __launch_bounds__(256) void k_neighbors_seg(const int64_t* __restrict__ jj, const BaMeta* __restrict__ meta, const int* __restrict__ seg_start,
+                                                       const int* __restrict__ perm, int64_t* __restrict__ ix, int64_t* __restrict__ jx) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (blockDim.x * gridDim.x) >> 6;
+  const int n_seg = meta->n_seg;
+  for (int s = wave; s < n_seg; s += nwaves) {
+    const int a = seg_start[s], m = seg_start[s + 1] - a;
+    if (m <= 64) {
+      const int e = lane < m ? perm[a + lane] : -1;
+      const int je = lane < m ? (int)jj[e] : 0;
+      int pj = 0, nj = 0, pe = -1, ne = -1;
+      for (int q = 0; q < m; q++) {
+        const int o = __builtin_amdgcn_readlane(e, q), jo = __builtin_amdgcn_readlane(je, q);
+        if (o == e) continue;
+        const bool less = (jo < je) || (jo == je && o < e);
+        if (less) { if (pe < 0 || jo > pj || (jo == pj && o > pe)) { pe = o; pj = jo; } }
+        else      { if (ne < 0 || jo < nj || (jo == nj && o < ne)) { ne = o; nj = jo; } }
+      }
+      if (lane < m) { ix[e] = pe; jx[e] = ne; }
+    } else {
+      for (int i = lane; i < m; i += 64) {
+        const int e = perm[a + i];
+        const int64_t je = jj[e];
+        int64_t pj = 0, nj = 0; int pe = -1, ne = -1;
+        for (int q = a; q < a + m; q++) {
+          const int o = perm[q];
+          if (o == e) continue;
+          const int64_t jo = jj[o];
+          const bool less = (jo < je) || (jo == je && o < e);
+          if (less) { if (pe < 0 || jo > pj || (jo == pj && o > pe)) { pe = o; pj = jo; } }
+          else      { if (ne < 0 || jo < nj || (jo == nj && o < ne)) { ne = o; nj = jo; } }
+        }
+        ix[e] = pe; jx[e] = ne;
+      }
+    }
+  }
+}
+
+int devo_ba_table_offsets(int E, int Np, int N, size_t* offsets) {
+  DEVO_REQUIRE(E > 0 && Np > 0 && N >= 0 && N <= BA_MAXN && offsets != nullptr, "devo_ba_table_offsets: bad sizes");
+  const BaLayout L = ba_layout(E, Np, N);
+  offsets[0] = L.meta + offsetof(BaMeta, n_seg);
+  offsets[1] = L.kx;
+  offsets[2] = L.counts;
+  offsets[3] = L.perm_b;
+  offsets[4] = (size_t)L.max_seg;
+  return DEVO_OK;
+}
+
+int devo_upd_graph_tables(const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int bound, void* ws_kk, size_t ws_kk_bytes,
+                          void* ws_ij, size_t ws_ij_bytes, int64_t* pair_key, int64_t* ix, int64_t* jx, devo_stream_t stream) {
+  DEVO_REQUIRE(E >= 0 && bound > 0, "devo_upd_graph_tables: bad sizes");
+  if (E == 0) return DEVO_OK;
+  DEVO_REQUIRE(ii && jj && kk && ws_kk && ws_ij && pair_key, "devo_upd_graph_tables: missing argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if ((rc = ba_prepare_impl(kk, E, bound, 0, ws_kk, ws_kk_bytes, st))) return rc;
+  const BaLayout L = ba_layout(E, bound, 0);
+  if (ix && jx) {
+    const char* w = (const char*)ws_kk;
+    hipLaunchKernelGGL(k_neighbors_seg, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, jj, (const BaMeta*)(w + L.meta),
+                       (const int*)(w + L.counts), (const int*)(w + L.perm_b), ix, jx);
+  }
+  int* range = (int*)(pair_key + E);                                // (the two extra words of the key buffer)
+  if (hipMemsetAsync(range, 0x80, sizeof(int) * 4, st) != hipSuccess) { (void)hipGetLastError(); set_error("devo_upd_graph_tables: memset failed"); return DEVO_ERR_LAUNCH; }
+  hipLaunchKernelGGL(k_pair_range, dim3(blocks_for(E, 256 * 4, 256)), dim3(256), 0, st, ii, jj, E, range);
+  hipLaunchKernelGGL(k_pair_key, dim3(blocks_for(E, 256, 1024)), dim3(256), 0, st, ii, jj, E, range, pair_key);
+  if ((rc = ba_prepare_impl(pair_key, E, bound, 0, ws_ij, ws_ij_bytes, st))) return rc;
+  return check_launch("devo_upd_graph_tables");
 }
 
 int devo_ba_reproject(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii, const int64_t* jj,

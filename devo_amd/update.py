@@ -8,6 +8,7 @@ gather, SoftAgg's per-group softmax + weighted sum + expand, gated residual, the
 tables built by the bundle adjustment's own index kernels (`cuda_ba.prepare`) and `cuda_ba.neighbors`.
 With gradients enabled the same computation runs as a plain torch composition (no torch_scatter needed).
 """
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -631,6 +632,9 @@ def _pinned_word():
     return P["pool"][P["next"]]
 
 
+_GRAPH_TABLES = os.environ.get("DEVO_UPD_GRAPH_TABLES", "1") != "0"     # (0: the separate calls of rounds 1-5, for A/B runs)
+
+
 class _Groups:
     """Edges grouped by an integer key, through the BA's index kernels: perm / seg_start / n_seg (+ group_of scratch)."""
 
@@ -645,7 +649,19 @@ class _Groups:
             bound = 1 << 20
         ws = cuda_ba.workspace(E, bound, 0, key.device)
         cuda_ba.prepare(key, bound, 0, ws)
-        self.n_seg_dev, _, self.seg_start, self.perm = cuda_ba.prepared_tables(ws, E, bound, 0, sync=False)
+        self.n_seg_dev, _, self.seg_start, self.perm = cuda_ba.table_views(ws, E, bound, 0)     # (views: `ws` is this object's, nobody prepares it again)
+        self._finish(E)
+
+    @classmethod
+    def from_tables(cls, tables, E):
+        """tables = (n_seg i32 [1], seg_start, perm) of cuda_ba.graph_tables: device views of a workspace that call allocated"""
+        self = cls.__new__(cls)
+        self.n_seg_dev, self.seg_start, self.perm = tables
+        self._finish(E)
+        return self
+
+    def _finish(self, E):
+        key = self.perm
         self._n_host, self._n_event = _pinned_word()
         self._n_host.copy_(self.n_seg_dev, non_blocking=True)
         self._n_event.record()
@@ -761,7 +777,14 @@ class Update(nn.Module):
         and handed to another tensor, so an equal key means the very same storage, and in-place edits bump the version
         counter.  (DEVO rebuilds ii / jj / kk with torch.cat every frame: fresh tensors -> rebuilt tables.)"""
         key = (ii.data_ptr(), jj.data_ptr(), kk.data_ptr(), ii._version, jj._version, kk._version, ii.numel(), jj.numel(), kk.numel())
-        if key != self._graph_key:
+        if key != self._graph_key and ii.numel() and _GRAPH_TABLES:
+            # one library call (round 6, devo_upd_graph_tables): the patch groups, the neighbours read off them, the pair key and its groups
+            ix, jx, tk, tp = cuda_ba.graph_tables(ii, jj, kk)
+            E = kk.numel()
+            self._graph = (ix, jx, _Groups.from_tables(tk, E), _Groups.from_tables(tp, E))
+            self._graph_key = key
+            self._graph_refs = (ii, jj, kk)
+        elif key != self._graph_key:
             ix, jx = cuda_ba.neighbors(kk, jj)
             il, jl = ii.long(), jj.long()
             # frame-pair key compacted to the window of live frames ON THE DEVICE (round 6: the bounds never visit the host — this runs once per

@@ -27,8 +27,9 @@ typedef void* devo_stream_t; /* hipStream_t */
 enum { DEVO_OK = 0, DEVO_ERR_ARG = 1, DEVO_ERR_LAUNCH = 2, DEVO_ERR_UNSUPPORTED = 3, DEVO_ERR_WORKSPACE = 4 };
 enum { DEVO_F32 = 0, DEVO_F16 = 1, DEVO_F64 = 2 };
 
-#define DEVO_ABI_VERSION 3 /* 2: fp32 split formats (devo_corr_pyramid_split, exponents), group plans (plan buffer tail); 3: per-slot conversions of a ring
-                              (devo_corr_pyramid_split_frames, devo_corr_patch_transpose_range), devo_stream_capturing; callers compare with devo_abi_version() */
+#define DEVO_ABI_VERSION 4 /* 2: fp32 split formats (devo_corr_pyramid_split, exponents), group plans (plan buffer tail); 3: per-slot conversions of a ring
+                              (devo_corr_pyramid_split_frames, devo_corr_patch_transpose_range), devo_stream_capturing; 4: devo_ba_table_offsets, devo_upd_graph_tables;
+                              callers compare with devo_abi_version() */
 int devo_abi_version(void);
 const char* devo_last_error(void); /* thread-local message of the last failing call */
 /* 1 while `stream` is being captured into a HIP graph (a capture executes nothing: a binding must not cache device state a captured call
@@ -234,6 +235,10 @@ int devo_ba_prepare_plan(const int64_t* kk, int E, int Np, int N /* t1 - t0 */, 
  * are perm[seg_start[s] .. seg_start[s+1]) in ascending edge order (the inverse map of _unique, grouped). */
 int devo_ba_prepared_tables(const void* ws, size_t ws_bytes, int E, int Np, int N, int* n_seg, int* kx,
                             int* seg_start, int* perm, devo_stream_t stream);
+/* The same tables IN PLACE: byte offsets into a prepared workspace of (E, Np, N) — offsets[0] the i32 n_seg, [1] kx, [2] seg_start, [3] perm —
+ * and offsets[4] = min(E, Np), the element count of kx (seg_start has one more).  A caller that owns the workspace reads the tables where
+ * they lie (devo_amd.update's group tables: eight device copies per frame of DEVO's steady state otherwise).  No device work. */
+int devo_ba_table_offsets(int E, int Np, int N, size_t* offsets /* [5] */);
 int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsics, const float* target,
                              const float* weight, const float* lmbda, const int64_t* ii, const int64_t* jj,
                              const int64_t* kk, int E, int Nbuf, int Np, int P, int t0, int t1, int iterations,
@@ -378,6 +383,17 @@ int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const 
 int devo_upd_layernorm_backward(const float* x, const float* add1, const float* add2, const float* gamma, const float* beta,
                                 const float* dout, float* dx, float* dgamma, float* dbeta, int64_t rows, int dim, float eps, int relu,
                                 float* partials, devo_stream_t stream);
+
+/* The graph tables of the Update operator (devo/enet.py:86-95) for one edge list, in one call:
+ *   ws_kk  <- devo_ba_prepare(kk, bound, 0): the edges grouped by patch (the scatter_softmax / scatter_sum index of agg_kk, blocks.py:42-43)
+ *   ix, jx <- cuda_ba.neighbors(kk, jj) (ba.cpp:104-149) read off those groups (NULL, NULL: skipped); kk must lie in [0, bound)
+ *   ws_ij  <- devo_ba_prepare(pair, bound, 0) with pair = (ii - min ii) * (max jj - min jj + 1) + (jj - min jj): the groups of
+ *             ii * 12345 + jj (enet.py:94) with keys inside (frames in the window)^2, which must stay below bound
+ * ws_kk, ws_ij: devo_ba_workspace_bytes(E, bound, 0) bytes each, read through devo_ba_table_offsets(E, bound, 0); pair_key i64 [E + 2]
+ * scratch (holds the keys afterwards).  DEVO's inference hands the operator new index tensors every frame: this is per-frame work. */
+int devo_upd_graph_tables(const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int bound, void* ws_kk,
+                          size_t ws_kk_bytes, void* ws_ij, size_t ws_ij_bytes, int64_t* pair_key, int64_t* ix, int64_t* jx,
+                          devo_stream_t stream);
 
 /* out[e] = idx[e] >= 0 ? src[idx[e]] : 0   — `mask * net[:, ix]` of enet.py:87-91 (idx from devo_ba_neighbors). */
 int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64_t E, int dim, int dtype,

@@ -188,3 +188,43 @@ def test_one_written_slot_converts_one_frame(dtype):
     s1 = N.cuda_corr._convert_stats()
     assert s1[0] - s0[0] == 2 and s1[1] == s0[1], (s0, s1)
     assert torch.equal(got, whole_ring_reference())
+
+
+@pytest.mark.parametrize("graph", ["sliding", "full", "small"])
+def test_graph_tables_in_one_call_equal_the_separate_calls(graph):
+    """devo_upd_graph_tables (round 6: the Update operator's neighbours + patch groups + frame-pair groups of a NEW edge list from one library call —
+    per-frame work in DEVO's steady state) against the separate entry points it replaces: cuda_ba.neighbors (ba.cpp:104-149), cuda_ba.prepare on kk,
+    and the groups of ii * 12345 + jj (enet.py:94) from torch.unique.  Bit for bit; the frame-pair groups hold >= 64 edges each in the sliding-window
+    graph, which takes the LDS-counted rank / scatter passes of the preparation."""
+    from devo_amd import synth
+    from devo_amd.backends import cuda_ba
+    dev = "cuda"
+    if graph == "sliding":
+        ii, jj, kk = [t.to(dev) for t in synth.sliding_window_graph(40, 96)]
+    elif graph == "full":
+        ii, jj, kk = [t.to(dev) for t in synth.full_graph(15, 96)]
+    else:
+        g = torch.Generator().manual_seed(3)
+        kk = torch.randint(0, 300, (2500,), generator=g).to(dev)
+        ii = kk // 20
+        jj = torch.randint(0, 15, (2500,), generator=g).to(dev)
+    E = kk.numel()
+    ix, jx, tk, tp = cuda_ba.graph_tables(ii, jj, kk)
+    ix0, jx0 = cuda_ba.neighbors(kk, jj)
+    assert torch.equal(ix, ix0) and torch.equal(jx, jx0)
+    ws = cuda_ba.workspace(E, 1 << 20, 0, dev)
+    cuda_ba.prepare(kk, 1 << 20, 0, ws)
+    n, kx, seg, perm = cuda_ba.prepared_tables(ws, E, 1 << 20, 0)
+    assert int(tk[0]) == n and torch.equal(tk[1][:n + 1], seg) and torch.equal(tk[2], perm)
+    # frame-pair groups: the same partition of the edges as torch.unique's, groups in ascending (ii, jj) order, edges ascending inside a group
+    key = ii * 12345 + jj
+    uq, inv = torch.unique(key, return_inverse=True)
+    m = int(tp[0])
+    assert m == uq.numel()
+    segp, permp = tp[1][:m + 1].long(), tp[2].long()
+    assert int(segp[0]) == 0 and int(segp[-1]) == E
+    grp = torch.repeat_interleave(torch.arange(m, device=dev), segp[1:] - segp[:-1])
+    assert torch.equal(inv[permp], grp)
+    inside = (permp[1:] > permp[:-1]) | (grp[1:] != grp[:-1])
+    assert bool(inside.all())
+    assert torch.equal(torch.sort(permp).values, torch.arange(E, device=dev))

@@ -55,6 +55,11 @@ def parse():
     ap.add_argument("--prepare-every", type=int, default=18,
                     help="the BA's index tables (unique patches, edges grouped by patch: a function of kk alone) are rebuilt every this many steps — 18 = once per "
                          "patch graph of 18 update iterations, what cuda_ba.forward's prepared-table cache does for an unchanged kk; 1 = every step (a new graph per step)")
+    ap.add_argument("--plan-lag", type=int, default=1, choices=[0, 1],
+                    help="1 (default): on an unchanged patch graph the lookup of update iteration k + 1 runs under the locality plan made from iteration k's "
+                         "coordinates, whose ordering step rides on iteration k's BA (extra workgroups of the first solver launch: "
+                         "cuda_ba.forward_delta(..., plan_next=...)); a plan only decides which edges run together.  0: every step orders its own plan "
+                         "before its lookup (rounds 1-5; reported as field plan_in_line either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-allcores", action="store_true", default=True,
                     help="(default since round 6) cpu_baseline also times the BA with one torch thread per host core (field ba_ms_allcores: ~25 s of "
@@ -464,9 +469,13 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         a.record(); lookup(coords, order=order); b.record()
         probe["ev"].append((a, b))
 
-    def step(k=0, every=None):
+    plan_prev = [None]                                                   # the finished plan of the previous step (--plan-lag 1)
+
+    def step(k=0, every=None, lag=None):
         cur = torch.cuda.current_stream()
         fresh_graph = (k % max(1, every or args.prepare_every)) == 0      # this step sees a "new" patch graph: the index tables are rebuilt
+        lag_on = bool(args.plan_lag if lag is None else lag) and not (args.separate_target or args.separate_index_kernels) and prep_stream is None
+        lagged = lag_on and not fresh_graph and plan_prev[0] is not None   # this step's lookup runs under the previous step's plan
         if prep_stream is not None and fresh_graph:
             # the index half of the BA (unique patches, edges grouped by patch) depends on kk only: it runs on a second
             # stream under the reprojection + lookup (a fork/join inside the captured graph)
@@ -477,7 +486,10 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         # reprojection; the kernel also emits the lookup's plan bins while it holds the coordinates
         coords, order = cuda_ba.transform(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp",
                                           plan_for=(n, cfg["H"], R, cfg["W"], PL1))
-        if args.separate_index_kernels or prep_stream is not None or not fresh_graph:
+        own_plan = order                                                   # this step's plan buffer (bins written, not yet ordered)
+        if lagged:
+            order = plan_prev[0]                                           # (own_plan is ordered by this step's BA, for the next step)
+        elif args.separate_index_kernels or prep_stream is not None or not fresh_graph:
             order = cuda_corr.plan_finish(order, d["jj"], n, cfg["H"], R, width=cfg["W"], l1=PL1)
             if not fresh_graph:
                 pass                                                       # the workspace holds this kk's tables already (cuda_ba.forward's cache, here explicit)
@@ -492,7 +504,8 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
         if not (args.separate_target or args.separate_index_kernels):
             # devo.py:330 (target = centre of the reprojected patch + delta) formed inside the BA: same fp32 addition
             cuda_ba.forward_delta(d["poses"], d["patches"], d["intr"], coords, d["delta"], d["weight"], d["lmbda"],
-                                  d["ii"], d["jj"], d["kk"], 1, n, 2, ws)
+                                  d["ii"], d["jj"], d["kk"], 1, n, 2, ws, plan_next=(own_plan, n, cfg["H"], cfg["W"], PL1) if lagged else None)
+            plan_prev[0] = own_plan if lag_on else None
             return
         target = coords[:, :, :, 1, 1] + d["delta"]                        # devo.py:330
         cuda_ba.forward(d["poses"], d["patches"], d["intr"], target, d["weight"], d["lmbda"],
@@ -501,7 +514,7 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
     # ---- warm up eagerly once (library load, kernel code upload), then capture
     step()
     torch.cuda.synchronize()
-    gevery = None
+    gevery = ginline = None
     if args.no_graph:
         count = [0]
 
@@ -528,6 +541,11 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
                     with torch.cuda.graph(gevery, stream=side):
                         for k in range(args.steps_per_graph):
                             step(k, every=1)
+                    if args.plan_lag:                                      # ... and with every step ordering its own plan in front of its lookup
+                        ginline = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(ginline, stream=side):
+                            for k in range(args.steps_per_graph):
+                                step(k, lag=0)
         torch.cuda.current_stream().wait_stream(side)
         run = graph.replay
     for _ in range(args.warmup):
@@ -571,6 +589,16 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / args.steps_per_graph)
         ms_every = sorted(ts)[2]
+    ms_inline = None
+    if ginline is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ginline.replay()
+        ts = []
+        for _ in range(5):
+            e0.record(); ginline.replay(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / args.steps_per_graph)
+        ms_inline = sorted(ts)[2]
 
     # ---- roofline figure for the dominant kernel (altcorr lookup), HIP events on the launch stream
     coords = cuda_ba.transform(d["poses0"], d["patches0"], d["intr"], d["ii"], d["jj"], d["kk"], layout="2pp")
@@ -607,8 +635,8 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
     # (the step's launches outnumber the ones above), and it is the lower one: a lookup that follows another lookup starts while
     # the 96 MB output of its predecessor is still draining.
     probe["on"] = True
-    for _ in range(args.kernel_reps):
-        step()
+    for i in range(args.kernel_reps):
+        step(i)                                                            # (the timed region's mix: one new patch graph per prepare_every steps)
     torch.cuda.synchronize()
     probe["on"] = False
     t_in_step = sum(a.elapsed_time(b) for a, b in probe["ev"]) * 1e-3 / max(1, len(probe["ev"])) / (1 if args.fuse_levels else 2)
@@ -705,6 +733,13 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
                        d["poses"], d["patches"], d["intr"], tgt, d["weight"], d["lmbda"], d["ii"], d["jj"], d["kk"], 1, n, 2, ws=ws))),
     }
     out["config"]["ba_index_tables"] = f"rebuilt every {args.prepare_every} steps (one patch graph = {args.prepare_every} update iterations)"
+    out["config"]["lookup_plan"] = ("on an unchanged patch graph the lookup runs under the plan made from the previous iteration's coordinates; its ordering "
+                                    "step rides on the BA's first solver launch (cuda_ba.forward_delta(..., plan_next=...)); a new patch graph orders its plan in line"
+                                    if args.plan_lag else "ordered in line by every step, in front of its lookup")
+    if ms_inline is not None:
+        out["plan_in_line"] = {"ms_per_step": round(ms_inline, 4), "value": round(world * 1e3 / ms_inline, 2), "unit": "it/s",
+                               "note": "the same steps with --plan-lag 0: every step orders its own locality plan (corr_order_kernel, ~9 us) between the "
+                                       "reprojection and its lookup (rounds 1-5's step)"}
     if ms_every is not None:
         out["new_graph_every_step"] = {"ms_per_step": round(ms_every, 4), "value": round(world * 1e3 / ms_every, 2), "unit": "it/s",
                                        "note": "the same steps with the BA's index tables rebuilt in EVERY step (rounds 1-5's step; DEVO's steady-state inference "

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.abspath(os.environ["DEVO_LIB"]) if os.environ.get("DEVO_LIB") else os.path.join(_HERE, "lib", "libdevo_hip.so")
 
 DEVO_F32, DEVO_F16, DEVO_F64 = 0, 1, 2
-ABI_VERSION = 4                # include/devo_hip.h DEVO_ABI_VERSION: a library of another version is refused (argument lists differ)
+ABI_VERSION = 5                # include/devo_hip.h DEVO_ABI_VERSION: a library of another version is refused (argument lists differ)
 CBLOCK_SPLIT8 = -8             # DEVO_CBLOCK_SPLIT8: fp32 level in the split-blocked format of devo_corr_pyramid_split
 PLAN_TAIL = 4104               # DEVO_CORR_PLAN_TAIL: a plan buffer that can hold a group plan has 2 n + 2 + PLAN_TAIL ints
 PLAN_EDGES, PLAN_GROUPS = 0, 1
@@ -51,6 +51,8 @@ _SIGNATURES = {
     "devo_ba_prepared_tables": [_vp, _sz, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "devo_ba_forward_prepared": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
     "devo_ba_forward_prepared_delta": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
+    "devo_ba_forward_prepared_delta_plan": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp,
+                                            _vp, _i, _i, _i, _i, _vp],
     "devo_ba_solve_terms": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _sz, _vp, _vp, _vp, _vp],
     "devo_ba_solve_terms_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp],
     "devo_ba_apply_step": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp],

@@ -142,10 +142,13 @@ def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t
 
 
 def forward_delta(poses, patches, intrinsics, coords, delta, weight, lmbda, ii, jj, kk, t0, t1, iterations, ws, layout="2pp",
-                  status=None):
+                  status=None, plan_next=None):
     """forward(..., prepared=True) with devo/devo.py:330 folded in: target = coords[..., P//2, P//2] + delta is formed inside
     the BA from the buffer transform() returned (`layout` as there) and the update operator's delta [1,E,2] — the same fp32
-    addition, bit-identical results, one elementwise launch less.  `ws` must hold prepare()'s result."""
+    addition, bit-identical results, one elementwise launch less.  `ws` must hold prepare()'s result.
+    plan_next=(buffer, n_frames, height[, width, l1]): the half-built locality plan of transform(..., plan_for=...) — its ordering step
+    rides on the first Gauss-Newton iteration's solver launch (devo_ba_forward_prepared_delta_plan); afterwards the buffer is what
+    cuda_corr.plan_finish returns, for the NEXT update iteration's lookup (a plan only decides which edges run together)."""
     L.require_gpu(poses, patches, intrinsics, coords, delta, weight, lmbda, ii, jj, kk)
     for name, t in (("poses", poses), ("patches", patches)):
         if t.dtype != torch.float32 or not t.is_contiguous():
@@ -170,6 +173,20 @@ def forward_delta(poses, patches, intrinsics, coords, delta, weight, lmbda, ii, 
     lmbda = lmbda.float().reshape(-1).contiguous()
     if delta.numel() != 2 * E:
         raise RuntimeError("cuda_ba.forward_delta: delta must hold 2 values per edge")
+    if plan_next is not None:
+        buf, n_frames, height = plan_next[:3]
+        width, l1 = (tuple(plan_next[3:5]) + (0, 0))[:2]
+        L.require_gpu(buf)
+        if buf.dtype != torch.int32 or buf.numel() < 2 * E + 2:
+            raise RuntimeError("cuda_ba.forward_delta: plan_next must be the int32 buffer of transform(..., plan_for=...)")
+        groups = buf.numel() == 2 * E + 2 + L.PLAN_TAIL and int(l1) >= 2
+        rc = L.lib().devo_ba_forward_prepared_delta_plan(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(coords), se, sc, off,
+                                                         L.ptr(delta), L.ptr(weight), L.ptr(lmbda), L.ptr(ii), L.ptr(jj), L.ptr(kk), E,
+                                                         Nbuf, Np, P, int(t0), int(t1), int(iterations), L.ptr(ws), ws.numel(),
+                                                         L.ptr(status), L.ptr(buf), int(n_frames), int(height), int(width) if groups else 0,
+                                                         int(l1) if groups else 0, L.stream())
+        L.check(rc, "cuda_ba.forward_delta")
+        return []
     rc = L.lib().devo_ba_forward_prepared_delta(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(coords), se, sc, off,
                                                 L.ptr(delta), L.ptr(weight), L.ptr(lmbda), L.ptr(ii), L.ptr(jj), L.ptr(kk), E,
                                                 Nbuf, Np, P, int(t0), int(t1), int(iterations), L.ptr(ws), ws.numel(),

@@ -1799,14 +1799,14 @@ struct BaRetract { float* poses; float* patches; const float* patch_rec; const f
 template <bool FUSED>
 __device__ __forceinline__ void ba_solve_chain_body(const float* __restrict__ S, const float* __restrict__ y, int N,
                                                     float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps,
-                                                    const BaRetract& ra) {
+                                                    const BaRetract& ra, int G = 0) {   // G > 0: the launch's first G workgroups solve (others ride along)
   extern __shared__ __attribute__((aligned(16))) float A[];
   const bool lead = blockIdx.x == 0;                              // (the only workgroup of the unfused launch)
   const int n_seg_all = FUSED ? meta->n_seg : 0;
   // (a prefetch of the retraction's operands under the factorisation was measured — no gain: 19.5 us either way — and dropped: it would read
   // through tables that a never-prepared workspace does not have before the kernel knows the call has failed)
   constexpr int UP = 2;
-  const int nw = (int)gridDim.x * 16, w0 = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6);
+  const int nw = (G > 0 ? G : (int)gridDim.x) * 16, w0 = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6);
   __shared__ int s_fail;
   __shared__ float s_dump[64];
   const int n6 = 6 * N, LDG = n6 + 1, LD = solve_ld(n6), rows = n6 + 1;
@@ -2156,6 +2156,18 @@ __global__ __launch_bounds__(1024) void k_ba_solve_retract(const float* __restri
                                                            float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps,
                                                            BaRetract ra) {
   ba_solve_chain_body<true>(S, y, N, dX, meta, iter, status_flag, stamps, ra);
+}
+
+// k_ba_solve_retract with the ordering step of the NEXT lookup's locality plan (corr_plan.h) in the workgroups behind the G solving ones: the
+// solver's launch is 19 us of 90 busy compute units, the ordering 9 us of twenty others — a plan only decides which edges run together, so the
+// lookup of update iteration k + 1 can take the plan made from iteration k's coordinates (devo_ba_forward_prepared_delta_plan).
+template <int CACHE>
+__global__ __launch_bounds__(1024) void k_ba_solve_retract_order(const float* __restrict__ S, const float* __restrict__ y, int N,
+                                                                 float* __restrict__ dX, BaMeta* meta, int iter, int* status_flag, int stamps,
+                                                                 BaRetract ra, int G, const int* __restrict__ bins, int BE, int nbins,
+                                                                 int* __restrict__ order, int starts) {
+  if ((int)blockIdx.x >= G) { corr_order_body<CACHE>(bins, BE, nbins, order, (int)blockIdx.x - G, (int)gridDim.x - G, starts != 0); return; }
+  ba_solve_chain_body<true>(S, y, N, dX, meta, iter, status_flag, stamps, ra, G);
 }
 
 static_assert(SOLVE_THREADS == 1024, "k_ba_solve_chain is written for 16 waves");
@@ -2861,10 +2873,11 @@ int devo_ba_forward(float* poses, float* patches, const float* intrinsics, const
                                   iterations, ws, ws_bytes, status_flag, stream);
 }
 
+struct PlanRider { int* plan; int nbins; int starts; };          // a plan buffer whose bins devo_transform has written: ordered during the BA
 static int ba_forward_impl(float* poses, float* patches, const float* intrinsics, const TargetSrc target, const float* weight,
                            const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Nbuf,
                            int Np, int P, int t0, int t1, int iterations, void* ws, size_t ws_bytes, int* status_flag,
-                           devo_stream_t stream);
+                           devo_stream_t stream, PlanRider rider = PlanRider{nullptr, 0, 0});
 
 int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
                              const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Nbuf,
@@ -2886,14 +2899,26 @@ int devo_ba_forward_prepared_delta(float* poses, float* patches, const float* in
                          weight, lmbda, ii, jj, kk, E, Nbuf, Np, P, t0, t1, iterations, ws, ws_bytes, status_flag, stream);
 }
 
+static void launch_order_only(hipStream_t st, int E, const PlanRider& r) {
+  typedef void (*order_fn_t)(const int*, int, int, int*, int);
+  const long long per_thread = ((long long)E + ORDER_THREADS - 1) / ORDER_THREADS;
+  order_fn_t order_fn = per_thread <= 8 ? k_order_only<8> : per_thread <= 16 ? k_order_only<16> : per_thread <= 24 ? k_order_only<24> :
+                        per_thread <= 32 ? k_order_only<32> : per_thread <= 48 ? k_order_only<48> : per_thread <= 64 ? k_order_only<64> : k_order_only<0>;
+  hipLaunchKernelGGL(order_fn, dim3((unsigned)corr_order_workgroups(E, r.nbins)), dim3(ORDER_THREADS), 0, st, r.plan + E + 1, E, r.nbins, r.plan, r.starts);
+}
+
 static int ba_forward_impl(float* poses, float* patches, const float* intrinsics, const TargetSrc target, const float* weight,
                            const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Nbuf,
                            int Np, int P, int t0, int t1, int iterations, void* ws, size_t ws_bytes, int* status_flag,
-                           devo_stream_t stream) {
+                           devo_stream_t stream, PlanRider rider) {
   int rc;
   if ((rc = ba_check_args("devo_ba_forward", E, Nbuf, Np, P, t0, t1))) return rc;
   const int N = t1 - t0;
-  if (E == 0 || iterations <= 0) return DEVO_OK;
+  if (E == 0) return DEVO_OK;
+  if (iterations <= 0) {                                          // (no solver launch to ride on)
+    if (rider.plan) { launch_order_only((hipStream_t)stream, E, rider); return check_launch("devo_ba_forward(order)"); }
+    return DEVO_OK;
+  }
   const BaLayout L = ba_layout(E, Np, N);
   if (ws == nullptr || ws_bytes < L.total) { set_error("devo_ba_forward: workspace %zu < %zu bytes", ws_bytes, L.total); return DEVO_ERR_WORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
@@ -2966,7 +2991,21 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       if ((rc = check_launch("devo_ba_forward(reduce)"))) return rc;
       static const bool ba_trace = getenv("DEVO_BA_TRACE") != nullptr;
       static const int ba_trace_mode = ba_trace ? (atoi(getenv("DEVO_BA_TRACE")) > 1 ? atoi(getenv("DEVO_BA_TRACE")) : 1) : 0;
-      if (fuse_retract)
+      const long long order_ept = ((long long)E + ORDER_THREADS - 1) / ORDER_THREADS;
+      if (fuse_retract && rider.plan && order_ept <= 32) {        // the next lookup's plan rides on this launch (once per call)
+        typedef void (*ride_fn_t)(const float*, const float*, int, float*, BaMeta*, int, int*, int, BaRetract, int, const int*, int, int, int*, int);
+        ride_fn_t ride = order_ept <= 8 ? k_ba_solve_retract_order<8> : order_ept <= 16 ? k_ba_solve_retract_order<16> :
+                         order_ept <= 24 ? k_ba_solve_retract_order<24> : k_ba_solve_retract_order<32>;
+        if (solve_lds > 48 * 1024 && hipFuncSetAttribute((const void*)ride, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds) != hipSuccess) {
+          (void)hipGetLastError();
+          set_error("devo_ba_forward: cannot reserve %zu bytes of LDS", solve_lds);
+          return DEVO_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(ride, dim3((unsigned)(retract_wgs + corr_order_workgroups(E, rider.nbins))), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it,
+                           status_flag, ba_trace_mode, BaRetract{poses, patches, patch_rec, edge_ej, kx, P, t0}, retract_wgs, (const int*)(rider.plan + E + 1), E,
+                           rider.nbins, rider.plan, rider.starts);
+        rider.plan = nullptr;                                     // done
+      } else if (fuse_retract)
         hipLaunchKernelGGL(k_ba_solve_retract, dim3((unsigned)retract_wgs), dim3(SOLVE_THREADS), solve_lds, st, S, y, N, dX, meta, it, status_flag, ba_trace_mode,
                            BaRetract{poses, patches, patch_rec, edge_ej, kx, P, t0});
       else
@@ -3002,7 +3041,31 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       if ((rc = check_launch("devo_ba_forward(retract)"))) return rc;
     }
   }
+  if (rider.plan) launch_order_only(st, E, rider);               // (no fused solver launch in this call: structure-only, N > 21, switches)
   return check_launch("devo_ba_forward");
+}
+
+int devo_ba_forward_prepared_delta_plan(float* poses, float* patches, const float* intrinsics, const float* coords, int coords_edge_stride,
+                                        int coords_xy_stride, int coords_centre, const float* delta, const float* weight,
+                                        const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int E, int Nbuf,
+                                        int Np, int P, int t0, int t1, int iterations, void* ws, size_t ws_bytes, int* status_flag,
+                                        int* plan, int plan_frames, int plan_height, int plan_width, int plan_l1, devo_stream_t stream) {
+  DEVO_REQUIRE(coords != nullptr && coords_edge_stride > 0 && coords_xy_stride > 0 && coords_centre >= 0,
+               "devo_ba_forward_prepared_delta_plan: coords %p, strides %d / %d, centre %d", (const void*)coords, coords_edge_stride,
+               coords_xy_stride, coords_centre);
+  DEVO_REQUIRE(plan != nullptr && plan_frames > 0 && plan_height > 0, "devo_ba_forward_prepared_delta_plan: missing plan");
+  PlanRider rider{plan, 0, 0};
+  const CorrPlanGeom pg = corr_plan_geom(1, plan_frames, plan_height);
+  DEVO_REQUIRE(pg.nb > 0, "devo_ba_forward_prepared_delta_plan: too many frames for a locality plan (%d)", plan_frames);
+  if (plan_l1 >= 2) {                                             // GROUP plan: the bins' first slots go into the plan's tail
+    const long long nb = corr_grp_nbins(1, plan_frames, plan_height, plan_width, plan_l1);
+    DEVO_REQUIRE(nb > 0, "devo_ba_forward_prepared_delta_plan: no group plan for this geometry (%d frames of %d x %d)", plan_frames, plan_height, plan_width);
+    rider.nbins = (int)nb; rider.starts = 1;
+  } else {
+    rider.nbins = (int)corr_plan_nbins(1, plan_frames, pg);
+  }
+  return ba_forward_impl(poses, patches, intrinsics, TargetSrc{delta, coords, coords_edge_stride, coords_xy_stride, coords_centre},
+                         weight, lmbda, ii, jj, kk, E, Nbuf, Np, P, t0, t1, iterations, ws, ws_bytes, status_flag, stream, rider);
 }
 
 

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_rs_pack_f16(const __half* __restrict__ 
 
 // y[M, N] = act(x[M, K] W^T + bias) [+ residual], N = 384 NB.  grid = ceil(M / (16 MT)).  NK = K steps of 32 (K <= 32 NK).
 template <int MT, int NK>
-__global__ __launch_bounds__(512) void k_rs_linear_f16(const __half* __restrict__ x, int64_t ldx, const rs_u4* __restrict__ wimg,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MT <= 3 ? 4 : 1, MT <= 3 ? 4 : 8))) void k_rs_linear_f16(const __half* __restrict__ x, int64_t ldx, const rs_u4* __restrict__ wimg,
                                                         const __half* __restrict__ bias, const __half* residual, __half* y, int64_t ldy, int M,
                                                         int NB, int K, int relu_from, unsigned long long* trace) {
   unsigned long long tst[6] = {0, 0, 0, 0, 0, 0};                      // DEVO_RS_TRACE: cycle stamps of every workgroup's wave 0
@@ -1151,11 +1151,13 @@ int devo_upd_rs_linear_f16(const void* x, int64_t ldx, const void* wimg, const v
   if (relu_from < 0) relu_from = 0;
   static const bool tr = getenv("DEVO_RS_TRACE") != nullptr;          // debug: stamps of one launch (synchronous), summary on stderr
   if (tr) {
-    const int rows = mt == 6 ? 96 : mt == 4 ? 64 : 128, nwg = (M + rows - 1) / rows;
+    const int rows = mt == 6 ? 96 : mt == 4 ? 64 : mt == 3 ? 48 : mt == 2 ? 32 : 128, nwg = (M + rows - 1) / rows;
     unsigned long long* d = nullptr;
     if (hipMalloc(&d, (size_t)nwg * 48) != hipSuccess) return DEVO_ERR_LAUNCH;
     int rc = mt == 6 ? rs_launch<6, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream, d)
            : mt == 4 ? rs_launch<4, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream, d)
+           : mt == 3 ? rs_launch<3, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream, d)
+           : mt == 2 ? rs_launch<2, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream, d)
                      : rs_launch<8, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream, d);
     (void)hipStreamSynchronize((hipStream_t)stream);
     std::vector<unsigned long long> h((size_t)nwg * 6);
@@ -1175,6 +1177,8 @@ int devo_upd_rs_linear_f16(const void* x, int64_t ldx, const void* wimg, const v
   // latency of the weight stream, which is what such a launch consists of (9.4 -> ~6 us)
   if (M <= 2048 && !getenv("DEVO_RS_MT")) return rs_launch<2, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
   if (mt == 6) return rs_launch<6, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
+  if (mt == 2) return rs_launch<2, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
+  if (mt == 3) return rs_launch<3, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
   if (mt == 4) return rs_launch<4, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
   return rs_launch<8, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
 }

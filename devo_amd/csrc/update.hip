@@ -859,7 +859,10 @@ int devo_upd_softagg_hint(const void* f, const void* g, int64_t ld_fg, const int
   hipStream_t st_ = (hipStream_t)stream;
   if (upd_vec_ok(dtype, E, dim, {f, g}, {ld_fg}) && dim / (dtype == DEVO_F32 ? 4 : 8) <= 128) {
     const int cpr = dim / (dtype == DEVO_F32 ? 4 : 8);
-    const dim3 vgrid(grid_for(E, 1, 4096));
+    // one workgroup per group: the caller's estimate sizes the grid (a workgroup without a group still has to be placed, read the count and
+    // retire: with E workgroups — 4 096 here — for 225 frame pairs the launch was eight rounds of empty 1 024-thread workgroups); the
+    // kernels stride over the groups, so an estimate that is too low costs balance, not results
+    const dim3 vgrid(grid_for(rows_per_group > 0 ? E / rows_per_group + 1 : E, 1, 4096));
     if (rows_per_group >= 48 && sizeof(float) * 48 * (size_t)dim <= 160 * 1024) {
       const size_t lds = sizeof(float) * 48 * (size_t)dim;
       static PerDeviceOnce attr_done;

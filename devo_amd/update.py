@@ -599,8 +599,8 @@ class _SoftAggFn(torch.autograd.Function):
         E, dim = fg.shape[0], fg.shape[1] // 2
         fg = fg.contiguous()
         y = torch.empty(G.n_seg, dim, dtype=fg.dtype, device=fg.device)
-        L.check(L.lib().devo_upd_softagg(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
-                                         L.ptr(y), None, E, dim, L.dtype_code(fg), L.stream()), "update.softagg")
+        L.check(L.lib().devo_upd_softagg_hint(L.ptr(fg), L.ptr(fg[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev),
+                                              L.ptr(y), None, E, dim, L.dtype_code(fg), int(E // max(int(G.n_seg), 1)), L.stream()), "update.softagg")
         ctx.save_for_backward(fg)
         ctx.G = G
         return y

@@ -27,8 +27,8 @@ typedef void* devo_stream_t; /* hipStream_t */
 enum { DEVO_OK = 0, DEVO_ERR_ARG = 1, DEVO_ERR_LAUNCH = 2, DEVO_ERR_UNSUPPORTED = 3, DEVO_ERR_WORKSPACE = 4 };
 enum { DEVO_F32 = 0, DEVO_F16 = 1, DEVO_F64 = 2 };
 
-#define DEVO_ABI_VERSION 4 /* 2: fp32 split formats (devo_corr_pyramid_split, exponents), group plans (plan buffer tail); 3: per-slot conversions of a ring
-                              (devo_corr_pyramid_split_frames, devo_corr_patch_transpose_range), devo_stream_capturing; 4: devo_ba_table_offsets, devo_upd_graph_tables;
+#define DEVO_ABI_VERSION 5 /* 2: fp32 split formats (devo_corr_pyramid_split, exponents), group plans (plan buffer tail); 3: per-slot conversions of a ring
+                              (devo_corr_pyramid_split_frames, devo_corr_patch_transpose_range), devo_stream_capturing; 4: devo_ba_table_offsets, devo_upd_graph_tables; 5: devo_ba_forward_prepared_delta_plan;
                               callers compare with devo_abi_version() */
 int devo_abi_version(void);
 const char* devo_last_error(void); /* thread-local message of the last failing call */
@@ -254,6 +254,18 @@ int devo_ba_forward_prepared_delta(float* poses, float* patches, const float* in
                                    const float* weight, const float* lmbda, const int64_t* ii, const int64_t* jj,
                                    const int64_t* kk, int E, int Nbuf, int Np, int P, int t0, int t1, int iterations,
                                    void* ws, size_t ws_bytes, int* status_flag, devo_stream_t stream);
+
+/* devo_ba_forward_prepared_delta, and the ordering step of a locality plan (devo_corr_order / devo_ba_prepare_plan's second half) for the
+ * buffer `plan` whose bins devo_transform(..., plan, ...) has written — carried by extra workgroups of the first Gauss-Newton iteration's
+ * solver launch (no launch of its own, nothing on the critical path; a separate launch where this call has no such solver launch).  A plan
+ * only decides which edges run together: the lookup of update iteration k + 1 (devo.py:308-344 runs them back to back on one patch graph)
+ * takes the plan made from iteration k's coordinates, the BA of iteration k carries its ordering.  Same results as the two calls. */
+int devo_ba_forward_prepared_delta_plan(float* poses, float* patches, const float* intrinsics, const float* coords,
+                                        int coords_edge_stride, int coords_xy_stride, int coords_centre, const float* delta,
+                                        const float* weight, const float* lmbda, const int64_t* ii, const int64_t* jj,
+                                        const int64_t* kk, int E, int Nbuf, int Np, int P, int t0, int t1, int iterations,
+                                        void* ws, size_t ws_bytes, int* status_flag, int* plan, int plan_frames, int plan_height,
+                                        int plan_width, int plan_l1, devo_stream_t stream);
 
 /* One differentiable Gauss-Newton step of devo/ba.py:108-170 (normal equations, Schur complement over the patches, damped
  * Cholesky solve) from GIVEN per-edge terms, for devo_amd.ba.BA (the reference builds it with ten matmuls + ten

@@ -227,3 +227,63 @@ def test_the_two_preparation_paths_build_the_same_tables(tmp_path):
         assert a[0] == b[0], name
         for x, y in zip(a[1:], b[1:]):
             assert torch.equal(x, y), name
+
+
+@pytest.mark.parametrize("nk,M,t0,iters,shuffle", [(12, 48, 1, 2, False), (15, 96, 1, 2, False), (15, 96, 5, 1, True), (9, 40, 9, 2, False), (24, 30, 1, 2, False),
+                                                  (15, 96, 1, 0, False)])
+def test_the_next_lookups_plan_rides_on_the_solvers_launch(nk, M, t0, iters, shuffle):
+    """devo_ba_forward_prepared_delta_plan: the ordering step of a locality plan carried by extra workgroups of the first Gauss-Newton
+    iteration's solver launch (k_ba_solve_retract_order).  The BA's results are the bits of forward_delta without the rider; the plan is the
+    one cuda_corr.plan_finish makes from the same bins (a permutation with the heavy list in front and the same (frame, band) key sequence
+    behind it; the same counts); the lookup under it returns the bits of the lookup under plan_finish's plan.  Cases without a fused solver
+    launch (structure-only t0 = t1, 23 optimised poses, zero iterations) order the plan with a launch of their own."""
+    from devo_amd.backends import cuda_ba, cuda_corr
+    H, W, R = 120, 160, 3
+    poses = synth.make_poses(nk, nk).to(DEV)
+    patches = synth.make_patches(nk, M, H, W, seed=nk)[0].to(DEV)
+    intr = synth.make_intrinsics(nk, H, W).to(DEV)
+    ii, jj, kk = synth.full_graph(nk, M)
+    if shuffle:
+        p = torch.randperm(len(ii), generator=torch.Generator().manual_seed(nk))[: int(0.9 * len(ii))]
+        ii, jj, kk = ii[p], jj[p], kk[p]
+    ii, jj, kk = [t.to(DEV) for t in (ii, jj, kk)]
+    E = len(ii)
+    delta, weight = [t.to(DEV) for t in synth.make_update_outputs(E, nk, sigma=0.3)]
+    lm = torch.tensor([1e-4], device=DEV)
+    Np = patches.shape[1]
+    outs, plans, coords = [], [], None
+    for ride in (False, True):
+        P_, Q_ = poses.clone(), patches.clone()
+        ws = cuda_ba.workspace(E, Np, nk - t0, torch.device(DEV))
+        cuda_ba.prepare(kk, Np, nk - t0, ws)
+        c, buf = cuda_ba.transform(P_, Q_, intr, ii, jj, kk, layout="2pp", plan_for=(nk, H, R, W, 0))
+        coords = c
+        if ride:
+            cuda_ba.forward_delta(P_, Q_, intr, c, delta, weight, lm, ii, jj, kk, t0, nk, iters, ws, plan_next=(buf, nk, H, W, 0))
+        else:
+            cuda_corr.plan_finish(buf, jj, nk, H, R, width=W)
+            cuda_ba.forward_delta(P_, Q_, intr, c, delta, weight, lm, ii, jj, kk, t0, nk, iters, ws)
+        outs.append((P_.cpu(), Q_.cpu()))
+        plans.append(buf)
+    if nk - t0 <= 16:
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    else:                                                        # (beyond 16 optimised poses the accumulation uses float atomics: no two calls agree to the bit)
+        assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-5) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-5)
+    a, b = plans[0].cpu(), plans[1].cpu()
+    nh = int(a[E])
+    assert nh == int(b[E]) and int(a[2 * E + 1]) == int(b[2 * E + 1])                       # heavy and dead counts
+    assert sorted(b[:E].tolist()) == list(range(E)) and sorted(a[:nh].tolist()) == sorted(b[:nh].tolist())
+    bins = a[E + 1:2 * E + 1]                                                                # (the scratch half keeps the bins)
+    assert torch.equal(bins, b[E + 1:2 * E + 1])
+    assert torch.equal(bins[a[nh:E].long()], bins[b[nh:E].long()])                           # the same bin at every slot
+    # the lookup under either plan: the same bits (the order never enters a result)
+    g = torch.Generator().manual_seed(3)
+    fmap = (torch.randn(1, nk, 128, H, W, generator=g) * 0.5).to(DEV)
+    gmap = (torch.randn(1, Np, 128, 3, 3, generator=g) * 0.5).to(DEV)
+    Dm = 2 * R + 1
+    res = []
+    for buf in plans:
+        out = torch.zeros(1, E, Dm * Dm * 9, device=DEV)
+        cuda_corr.forward_into(out, gmap, fmap, coords, kk, jj, R, Dm * Dm * 9, 1, 0, order=buf)
+        res.append(out)
+    assert torch.equal(res[0], res[1]) and float(res[0].abs().max()) > 0

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "devo_ba_prepared_tables": [_vp, _sz, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "devo_ba_forward_prepared": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
     "devo_ba_forward_prepared_delta": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp],
+    "devo_ba_import_tables": [_vp, _sz, _i, _i, _vp, _sz, _i, _i, _i, _vp],
     "devo_ba_forward_prepared_delta_plan": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp,
                                             _vp, _i, _i, _i, _i, _vp],
     "devo_ba_solve_terms": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _sz, _vp, _vp, _vp, _vp],

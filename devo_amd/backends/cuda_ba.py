@@ -56,9 +56,56 @@ import os as _os
 PREP_CACHE = _os.environ.get("DEVO_BA_PREP_CACHE", "1") != "0"
 
 
+# The Update operator's patch-group tables as a DONOR of the BA's index tables (round 6): devo.py:311,337 hand the same kk to the operator and,
+# right behind it, to fastba.BA — graph_tables() has then grouped exactly this edge list by patch, in a workspace of other sizes; forward() imports
+# those tables with one launch (devo_ba_import_tables) instead of preparing them again with nine.  key = (kk's storage, version counter, E,
+# stream); the donor keeps kk and its workspace alive, so an equal key is the same storage with the same contents.  _imported: what forward()
+# last put into which BA workspace this way — any other preparation of a workspace (prepare(), a forward() on another kk, a capture) forgets it.
+_donor = {"key": None, "ws": None, "sizes": None, "keep": None}
+_imported = {"key": None, "keep": None, "n": 0}
+SHARE_TABLES = _os.environ.get("DEVO_BA_SHARE_TABLES", "1") != "0"
+
+
+def _kk_key(kk, stream_value):
+    return (kk.data_ptr(), kk._version, kk.numel(), stream_value)
+
+
+def offer_tables(kk, ws, n_patch_slots, n_opt):
+    """`ws` holds devo_ba_prepare's tables of `kk` for (n_patch_slots, n_opt): forward() on the same kk may import them (see _donor)."""
+    if SHARE_TABLES and kk.is_cuda and not kk.is_inference():
+        st = L.stream()
+        if L.lib().devo_stream_capturing(st) == 0:
+            _donor.update(key=_kk_key(kk, st.value), ws=ws, sizes=(int(n_patch_slots), int(n_opt)), keep=kk)
+            return
+    _donor.update(key=None, ws=None, sizes=None, keep=None)
+
+
+def import_stats():
+    """Number of forward() calls that took their index tables from the Update operator's (devo_ba_import_tables)."""
+    return _imported["n"]
+
+
+def _try_import(kk0, E, Np, n_opt, ws, st):
+    """-> True when `ws` holds kk0's tables for (Np, n_opt) through the donor (imported now or by the previous forward() on this workspace)."""
+    if not SHARE_TABLES or _donor["key"] is None or kk0.is_inference() or _donor["key"] != _kk_key(kk0, st.value):
+        return False
+    if L.lib().devo_stream_capturing(st) != 0:
+        return False
+    want = (_donor["key"], id(_donor["ws"]), ws.data_ptr(), int(Np), int(n_opt))
+    if _imported["key"] != want:
+        src = _donor["ws"]
+        rc = L.lib().devo_ba_import_tables(L.ptr(src), src.numel(), _donor["sizes"][0], _donor["sizes"][1], L.ptr(ws), ws.numel(), int(E), int(Np), int(n_opt), st)
+        L.check(rc, "cuda_ba.forward (import of the Update operator's tables)")
+        prep_invalidate()                                    # whatever the bindings' caches remember about this workspace is gone
+        _imported["key"], _imported["keep"] = want, (ws, src)
+        _imported["n"] += 1
+    return True
+
+
 def prep_invalidate():
     """Forget the prepared index tables forward() remembers (both bindings)."""
     _prep["key"] = _prep["keep"] = None
+    _imported["key"] = _imported["keep"] = None
     N = _nat()
     if N is not None:
         N.cuda_ba._prep_invalidate()
@@ -95,6 +142,13 @@ def forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t
     (devo/fastba/ba.py:7-8 passes poses.data; devo/devo.py:337 relies on the mutation).
     prepared=True: `ws` already holds the result of prepare() for this kk / t1 - t0.
     With the compiled binding present this is devo_amd._C.cuda_ba.forward (same arguments)."""
+    imported = False
+    if not prepared and ws is not None and _donor["key"] is not None and int(iterations) > 0 and kk.is_cuda and kk.numel() > 0:
+        P_ = patches.shape[-1]
+        imported = _try_import(kk, kk.numel(), patches.numel() // (3 * P_ * P_), int(t1) - int(t0), ws, L.stream())
+    if not imported and not prepared:
+        _imported["key"] = _imported["keep"] = None          # this call prepares its workspace itself: nothing imported survives in it
+    prepared = bool(prepared) or imported
     N = _nat()
     if N is not None:
         return N.cuda_ba.forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, int(t0), int(t1), int(iterations), ws, status, bool(prepared))
@@ -240,6 +294,7 @@ def graph_tables(ii, jj, kk, bound=1 << 20):
     (ix, jx, (n_seg, seg_start, perm) by patch, (n_seg, seg_start, perm) by pair): int32 device views of two workspaces this call
     allocates (n_seg: [1], the group count stays on the device).  kk in [0, bound), (frames in the window)^2 <= bound."""
     L.require_gpu(ii, jj, kk)
+    kk_given = kk                                            # (the caller's tensor: what the donor is keyed on)
     ii, jj, kk = _idx(ii, jj, kk)
     E, dev = kk.numel(), kk.device
     if E == 0:
@@ -252,6 +307,7 @@ def graph_tables(ii, jj, kk, bound=1 << 20):
                                        L.ptr(key), L.ptr(nb[0]), L.ptr(nb[1]), L.stream())
     L.check(rc, "cuda_ba.graph_tables")
     tk, tp = table_views(ws[0], E, bound, 0), table_views(ws[1], E, bound, 0)
+    offer_tables(kk_given, ws[0], bound, 0)                  # the patch groups: what fastba.BA needs for this kk right behind the operator
     return nb[0], nb[1], (tk[0], tk[2], tk[3]), (tp[0], tp[2], tp[3])
 
 

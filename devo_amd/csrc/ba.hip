@@ -2845,6 +2845,38 @@ int devo_ba_prepared_tables(const void* ws, size_t ws_bytes, int E, int Np, int 
   return DEVO_OK;
 }
 
+// The index tables of one kk (n_seg, kx, segment starts, edges grouped by patch) from a workspace prepared for OTHER sizes of the same edge list —
+// devo_upd_graph_tables' (Np = its bound, N = 0) — into this one: one launch instead of the preparation's nine.  devo.py:311,337 hand the same
+// kk to the Update operator and, right behind it, to the BA.  Ids in [Np, src Np) exist as groups there and count as bad ids here (segment 0 of
+// devo_ba_prepare): such a source leaves the destination UNPREPARED (sig 0: the BA reports status -1) instead of different tables.
+__global__ __launch_bounds__(256) void k_import_tables(const BaMeta* __restrict__ smeta, const int* __restrict__ scounts, const int* __restrict__ sperm,
+                                                       const int* __restrict__ skx, int ssig, BaMeta* __restrict__ dmeta, int* __restrict__ dcounts,
+                                                       int* __restrict__ dperm, int* __restrict__ dkx, int E, int Np, int dmax_seg, int dsig) {
+  const int n = smeta->n_seg;
+  const bool ok = smeta->sig == ssig && n >= 0 && n <= dmax_seg && (n == 0 || skx[n - 1] < Np);
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = blockDim.x * gridDim.x;
+  if (gid == 0) { dmeta->n_seg = ok ? n : 0; dmeta->fail = 0; dmeta->sig = ok ? dsig : 0; dmeta->pad = ok ? smeta->pad : 0; }   // (pad: "perm is the identity")
+  if (!ok) return;
+  for (int i = gid; i <= dmax_seg; i += gsz) dcounts[i] = i <= n ? scounts[i] : E;
+  for (int i = gid; i < n; i += gsz) dkx[i] = skx[i];
+  for (int e = gid; e < E; e += gsz) dperm[e] = sperm[e];
+}
+
+int devo_ba_import_tables(const void* src_ws, size_t src_bytes, int src_Np, int src_N, void* ws, size_t ws_bytes, int E, int Np, int N,
+                          devo_stream_t stream) {
+  DEVO_REQUIRE(E > 0 && Np > 0 && N >= 0 && src_Np > 0 && src_N >= 0, "devo_ba_import_tables: bad sizes");
+  if (N > BA_MAXN || src_N > BA_MAXN) { set_error("devo_ba_import_tables: %d / %d optimised poses > %d supported", N, src_N, BA_MAXN); return DEVO_ERR_UNSUPPORTED; }
+  const BaLayout S = ba_layout(E, src_Np, src_N), D = ba_layout(E, Np, N);
+  if (src_ws == nullptr || src_bytes < S.total) { set_error("devo_ba_import_tables: source workspace %zu < %zu bytes", src_bytes, S.total); return DEVO_ERR_WORKSPACE; }
+  if (ws == nullptr || ws_bytes < D.total) { set_error("devo_ba_import_tables: workspace %zu < %zu bytes", ws_bytes, D.total); return DEVO_ERR_WORKSPACE; }
+  const char* s = (const char*)src_ws;
+  char* d = (char*)ws;
+  hipLaunchKernelGGL(k_import_tables, dim3(blocks_for(E, 256, 256)), dim3(256), 0, (hipStream_t)stream, (const BaMeta*)(s + S.meta), (const int*)(s + S.counts),
+                     (const int*)(s + S.perm_b), (const int*)(s + S.kx), ba_sig(E, src_N), (BaMeta*)(d + D.meta), (int*)(d + D.counts), (int*)(d + D.perm_b),
+                     (int*)(d + D.kx), E, Np, D.max_seg, ba_sig(E, N));
+  return check_launch("devo_ba_import_tables");
+}
+
 int devo_ba_prepare_plan(const int64_t* kk, int E, int Np, int N, void* ws, size_t ws_bytes, int* plan, int plan_frames,
                          int plan_height, int plan_width, int plan_l1, devo_stream_t stream) {
   DEVO_REQUIRE(E >= 0 && Np > 0 && N >= 0, "devo_ba_prepare_plan: bad sizes");

@@ -28,7 +28,7 @@ enum { DEVO_OK = 0, DEVO_ERR_ARG = 1, DEVO_ERR_LAUNCH = 2, DEVO_ERR_UNSUPPORTED 
 enum { DEVO_F32 = 0, DEVO_F16 = 1, DEVO_F64 = 2 };
 
 #define DEVO_ABI_VERSION 5 /* 2: fp32 split formats (devo_corr_pyramid_split, exponents), group plans (plan buffer tail); 3: per-slot conversions of a ring
-                              (devo_corr_pyramid_split_frames, devo_corr_patch_transpose_range), devo_stream_capturing; 4: devo_ba_table_offsets, devo_upd_graph_tables; 5: devo_ba_forward_prepared_delta_plan;
+                              (devo_corr_pyramid_split_frames, devo_corr_patch_transpose_range), devo_stream_capturing; 4: devo_ba_table_offsets, devo_upd_graph_tables; 5: devo_ba_forward_prepared_delta_plan, devo_ba_import_tables;
                               callers compare with devo_abi_version() */
 int devo_abi_version(void);
 const char* devo_last_error(void); /* thread-local message of the last failing call */
@@ -239,6 +239,12 @@ int devo_ba_prepared_tables(const void* ws, size_t ws_bytes, int E, int Np, int 
  * and offsets[4] = min(E, Np), the element count of kx (seg_start has one more).  A caller that owns the workspace reads the tables where
  * they lie (devo_amd.update's group tables: eight device copies per frame of DEVO's steady state otherwise).  No device work. */
 int devo_ba_table_offsets(int E, int Np, int N, size_t* offsets /* [5] */);
+/* The index tables of a kk from a workspace prepared for other sizes of the SAME edge list (src_Np patch slots, src_N optimised poses: e.g.
+ * devo_upd_graph_tables' patch-group workspace: its bound, 0) into `ws` (Np, N): one launch instead of devo_ba_prepare's nine — devo.py:311,337
+ * hand the same kk to the Update operator and, right behind it, to the BA.  Afterwards `ws` is what devo_ba_prepare(kk, E, Np, N) leaves, provided
+ * every id of kk is below Np; a source with ids in [Np, src_Np) leaves `ws` unprepared (the BA then reports status -1). */
+int devo_ba_import_tables(const void* src_ws, size_t src_bytes, int src_Np, int src_N, void* ws, size_t ws_bytes, int E, int Np, int N,
+                          devo_stream_t stream);
 int devo_ba_forward_prepared(float* poses, float* patches, const float* intrinsics, const float* target,
                              const float* weight, const float* lmbda, const int64_t* ii, const int64_t* jj,
                              const int64_t* kk, int E, int Nbuf, int Np, int P, int t0, int t1, int iterations,

@@ -91,10 +91,12 @@ _SIGNATURES.update({
     "devo_upd_rs_pack_weight_f16": [_vp, _i64, _i64, _i, _i, _vp, _vp],
     "devo_upd_rs_linear_f16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],
     "devo_upd_rs_gru_f16": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "devo_upd_rs_gru_f16_out32": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "devo_upd_rs_mlp2_f16": [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "devo_upd_rs_mlp2_fg_f16": [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "devo_upd_rs_expand_fg_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "devo_upd_rs_corr_f16": [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp],
+    "devo_upd_rs_corr_f16_net32": [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp],
     "devo_upd_rs_split_weight_bytes": [_i, _i],
     "devo_upd_rs_split_supported": [_i, _i],
     "devo_upd_rs_split_weight": [_vp, _i64, _i64, _i, _i, _vp, _vp],

@@ -251,6 +251,7 @@ struct RsGru {
   const __half* ln2_g; const __half* ln2_b;
   const __half* Wd; const __half* bd; const __half* Ww; const __half* bw;
   __half* net_out; __half* delta; __half* weight;
+  float* net_out32;                                                    // OUT32 instantiation: the new state in fp32 (what autocast returns)
   int E; float eps0, eps2;
   unsigned long long* trace;                                           // debug (DEVO_RS_TRACE): 24 cycle stamps of every workgroup's wave 0
 };
@@ -260,6 +261,7 @@ constexpr int RG_VEC = 768 + 384 + 768 + 384 + 384 + 384;             // halves:
 constexpr int RG_LDS = 2 * RG_ROWS * RG_PITCH + RG_VEC * 2 + RG_ROWS * 8 * 2 * 4 + RG_ROWS * 2 * 4;      // 163 584 B
 static_assert(RG_LDS <= 160 * 1024, "the chain's LDS");
 
+template <bool OUT32>
 __global__ __launch_bounds__(512) void k_rs_gru_f16(RsGru a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char rs_lds[];
   unsigned long long tst[24];
@@ -476,7 +478,16 @@ __global__ __launch_bounds__(512) void k_rs_gru_f16(RsGru a) {
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const rs_u4 v = *reinterpret_cast<const rs_u4*>(X + rloc * PITCH + (l16 + 16 * k) * 16);
-        if (live) *reinterpret_cast<rs_u4*>(a.net_out + (int64_t)row * D + (l16 + 16 * k) * 8) = v;
+        if constexpr (OUT32) {
+          if (live) {
+            const rs_h8 h8 = __builtin_bit_cast(rs_h8, v);
+            float* op_ = a.net_out32 + (int64_t)row * D + (l16 + 16 * k) * 8;
+            *reinterpret_cast<rs_f4*>(op_) = rs_f4{(float)h8[0], (float)h8[1], (float)h8[2], (float)h8[3]};
+            *reinterpret_cast<rs_f4*>(op_ + 4) = rs_f4{(float)h8[4], (float)h8[5], (float)h8[6], (float)h8[7]};
+          }
+        } else {
+          if (live) *reinterpret_cast<rs_u4*>(a.net_out + (int64_t)row * D + (l16 + 16 * k) * 8) = v;
+        }
         // relu on fp16 pairs, products of fp16 pairs summed in fp32 (v_dot2_f32_f16: exact products, like the fp32 multiply-adds they replace)
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -664,10 +675,12 @@ struct RsCorr {
   const rs_u4* w0; const __half* b0; const rs_u4* w2; const __half* b2; const __half* ln3_g; const __half* ln3_b;
   const rs_u4* w5; const __half* b5; const __half* net; const __half* inp; const __half* ln_g; const __half* ln_b; __half* out;
   int E, K0; float eps3, eps;
+  const float* net32;                                                  // NET32 instantiation: the recurrent state as the caller holds it (autocast keeps it in fp32)
 };
 constexpr int RC_VEC = 5 * 384;                                        // halves: b0 | b2 | ln3 gamma | ln3 beta | b5
 constexpr int RC_LDS = 2 * RG_ROWS * RG_PITCH + RC_VEC * 2 + RG_ROWS * 8 * 2 * 4 + RG_ROWS * 2 * 4;
 
+template <bool NET32>
 __global__ __launch_bounds__(512) void k_rs_corr_f16(RsCorr a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char rs_lds[];
   constexpr int MT = RG_MT, NK = RG_NK, PITCH = RG_PITCH, ROWS = RG_ROWS, D = 384, PPR = D / 8, AP = ROWS * PPR / 512;
@@ -815,13 +828,19 @@ __global__ __launch_bounds__(512) void k_rs_corr_f16(RsCorr a) {
   // ---- out = LN(net + inp + c): a quarter wave per row
   {
     const int l16 = tid & 15;
-    rs_u4 nv[3][3], iv[3][3];
+    rs_u4 nv[3][3], nw[NET32 ? 3 : 1][3], iv[3][3];
 #pragma unroll
     for (int p = 0; p < 3; p++) {
       const int row = row0 + 32 * p + (tid >> 4), rr = row < E ? row : E - 1;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        nv[p][k] = *reinterpret_cast<const rs_u4*>(a.net + (int64_t)rr * D + (l16 + 16 * k) * 8);
+        if constexpr (NET32) {
+          const float* np_ = a.net32 + (int64_t)rr * D + (l16 + 16 * k) * 8;
+          nv[p][k] = *reinterpret_cast<const rs_u4*>(np_);
+          nw[p][k] = *reinterpret_cast<const rs_u4*>(np_ + 4);
+        } else {
+          nv[p][k] = *reinterpret_cast<const rs_u4*>(a.net + (int64_t)rr * D + (l16 + 16 * k) * 8);
+        }
         iv[p][k] = *reinterpret_cast<const rs_u4*>(a.inp + (int64_t)rr * D + (l16 + 16 * k) * 8);
       }
     }
@@ -838,10 +857,20 @@ __global__ __launch_bounds__(512) void k_rs_corr_f16(RsCorr a) {
       float s = 0.f;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        const rs_h8 xh = __builtin_bit_cast(rs_h8, nv[p][k]), ih = __builtin_bit_cast(rs_h8, iv[p][k]),
+        const rs_h8 ih = __builtin_bit_cast(rs_h8, iv[p][k]),
                     ch = __builtin_bit_cast(rs_h8, *reinterpret_cast<const rs_u4*>(R + rloc * PITCH + (l16 + 16 * k) * 16));
+        float xf[8];
+        if constexpr (NET32) {
+          const rs_f4 lo4 = __builtin_bit_cast(rs_f4, nv[p][k]), hi4 = __builtin_bit_cast(rs_f4, nw[p][k]);
 #pragma unroll
-        for (int i = 0; i < 8; i++) { t[k][i] = (float)xh[i] + (float)ih[i] + (float)ch[i]; s += t[k][i]; }
+          for (int i = 0; i < 4; i++) { xf[i] = lo4[i]; xf[4 + i] = hi4[i]; }
+        } else {
+          const rs_h8 xh = __builtin_bit_cast(rs_h8, nv[p][k]);
+#pragma unroll
+          for (int i = 0; i < 8; i++) xf[i] = (float)xh[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) { t[k][i] = xf[i] + (float)ih[i] + (float)ch[i]; s += t[k][i]; }
       }
       const float mean = rs_row16_sum(s) / (float)D;
       float q = 0.f;
@@ -1188,10 +1217,10 @@ int devo_upd_rs_linear_f16(const void* x, int64_t ldx, const void* wimg, const v
 //   net = LN0(x + hy[group_of]);  net = LN2(net + sigmoid(gate1(net)) res1(net));  net_out = net + sigmoid(gate3(net)) res3(net);
 //   delta = d(relu(net_out)), weight = sigmoid(w(relu(net_out))).   x, net_out [E, 384] contiguous, hy [groups, 384]; the [gate | res[0]]
 //   weights concatenated to [768, 384] and res[2] [384, 384] as devo_upd_rs_pack_weight_f16 images; every vector fp16, 16-byte aligned.
-int devo_upd_rs_gru_f16(const void* x, const void* hy, const int* group_of, const void* ln0_w, const void* ln0_b, float eps0, const void* wgr1_img,
-                        const void* bgr1, const void* wr2_1_img, const void* br2_1, const void* ln2_w, const void* ln2_b, float eps2, const void* wgr3_img,
-                        const void* bgr3, const void* wr2_3_img, const void* br2_3, const void* Wd, const void* bd, const void* Ww, const void* bw,
-                        void* net_out, void* delta, void* weight, int E, void* stream) {
+static int rs_gru_impl(const void* x, const void* hy, const int* group_of, const void* ln0_w, const void* ln0_b, float eps0, const void* wgr1_img,
+                       const void* bgr1, const void* wr2_1_img, const void* br2_1, const void* ln2_w, const void* ln2_b, float eps2, const void* wgr3_img,
+                       const void* bgr3, const void* wr2_3_img, const void* br2_3, const void* Wd, const void* bd, const void* Ww, const void* bw,
+                       void* net_out, void* delta, void* weight, int E, void* stream, bool out32) {
   DEVO_REQUIRE(x && hy && group_of && ln0_w && ln0_b && wgr1_img && bgr1 && wr2_1_img && br2_1 && ln2_w && ln2_b && wgr3_img && bgr3 && wr2_3_img && br2_3 && Wd &&
                    bd && Ww && bw && net_out && delta && weight && E > 0,
                "devo_upd_rs_gru_f16: null argument");
@@ -1201,7 +1230,8 @@ int devo_upd_rs_gru_f16(const void* x, const void* hy, const int* group_of, cons
                "devo_upd_rs_gru_f16: 16-byte alignment");
   static PerDeviceOnce attr_done;
   if (attr_done.first()) {
-    DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_gru_f16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+    DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_gru_f16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_gru_f16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "devo_upd_rs_gru_f16: cannot raise the dynamic LDS limit");
   }
   RsGru a;
@@ -1209,11 +1239,13 @@ int devo_upd_rs_gru_f16(const void* x, const void* hy, const int* group_of, cons
   a.w_gr[0] = (const rs_u4*)wgr1_img; a.b_gr[0] = (const __half*)bgr1; a.w_r2[0] = (const rs_u4*)wr2_1_img; a.b_r2[0] = (const __half*)br2_1;
   a.w_gr[1] = (const rs_u4*)wgr3_img; a.b_gr[1] = (const __half*)bgr3; a.w_r2[1] = (const rs_u4*)wr2_3_img; a.b_r2[1] = (const __half*)br2_3;
   a.ln2_g = (const __half*)ln2_w; a.ln2_b = (const __half*)ln2_b; a.Wd = (const __half*)Wd; a.bd = (const __half*)bd; a.Ww = (const __half*)Ww; a.bw = (const __half*)bw;
-  a.net_out = (__half*)net_out; a.delta = (__half*)delta; a.weight = (__half*)weight; a.E = E; a.eps0 = eps0; a.eps2 = eps2; a.trace = nullptr;
+  a.net_out = out32 ? nullptr : (__half*)net_out; a.net_out32 = out32 ? (float*)net_out : nullptr;
+  a.delta = (__half*)delta; a.weight = (__half*)weight; a.E = E; a.eps0 = eps0; a.eps2 = eps2; a.trace = nullptr;
   const int nwg = (E + RG_ROWS - 1) / RG_ROWS;
   static const bool tr = getenv("DEVO_RS_TRACE") != nullptr;          // debug: stamps of this launch (synchronous), mean cycles per phase on stderr
   if (tr && hipMalloc(&a.trace, (size_t)nwg * 24 * 8) != hipSuccess) a.trace = nullptr;
-  hipLaunchKernelGGL(k_rs_gru_f16, dim3((unsigned)nwg), dim3(512), RG_LDS, (hipStream_t)stream, a);
+  if (out32) hipLaunchKernelGGL(k_rs_gru_f16<true>, dim3((unsigned)nwg), dim3(512), RG_LDS, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_rs_gru_f16<false>, dim3((unsigned)nwg), dim3(512), RG_LDS, (hipStream_t)stream, a);
   if (a.trace) {
     (void)hipStreamSynchronize((hipStream_t)stream);
     std::vector<unsigned long long> h((size_t)nwg * 24);
@@ -1230,6 +1262,21 @@ int devo_upd_rs_gru_f16(const void* x, const void* hy, const int* group_of, cons
     fprintf(stderr, " | total %.0f\n", tot / nwg);
   }
   return check_launch("devo_upd_rs_gru_f16");
+}
+int devo_upd_rs_gru_f16(const void* x, const void* hy, const int* group_of, const void* ln0_w, const void* ln0_b, float eps0, const void* wgr1_img,
+                        const void* bgr1, const void* wr2_1_img, const void* br2_1, const void* ln2_w, const void* ln2_b, float eps2, const void* wgr3_img,
+                        const void* bgr3, const void* wr2_3_img, const void* br2_3, const void* Wd, const void* bd, const void* Ww, const void* bw,
+                        void* net_out, void* delta, void* weight, int E, void* stream) {
+  return rs_gru_impl(x, hy, group_of, ln0_w, ln0_b, eps0, wgr1_img, bgr1, wr2_1_img, br2_1, ln2_w, ln2_b, eps2, wgr3_img, bgr3, wr2_3_img, br2_3, Wd, bd, Ww, bw,
+                     net_out, delta, weight, E, stream, false);
+}
+// ... with net_out as fp32 [E, 384] (the values the fp16 form stores, widened: what devo.py:311's autocast call returns — no conversion pass behind the launch)
+int devo_upd_rs_gru_f16_out32(const void* x, const void* hy, const int* group_of, const void* ln0_w, const void* ln0_b, float eps0, const void* wgr1_img,
+                              const void* bgr1, const void* wr2_1_img, const void* br2_1, const void* ln2_w, const void* ln2_b, float eps2, const void* wgr3_img,
+                              const void* bgr3, const void* wr2_3_img, const void* br2_3, const void* Wd, const void* bd, const void* Ww, const void* bw,
+                              float* net_out, void* delta, void* weight, int E, void* stream) {
+  return rs_gru_impl(x, hy, group_of, ln0_w, ln0_b, eps0, wgr1_img, bgr1, wr2_1_img, br2_1, ln2_w, ln2_b, eps2, wgr3_img, bgr3, wr2_3_img, br2_3, Wd, bd, Ww, bw,
+                     net_out, delta, weight, E, stream, true);
 }
 
 
@@ -1265,9 +1312,9 @@ int devo_upd_rs_expand_fg_f16(void* x, const void* hy, const int* group_of, cons
 // The correlation branch and the first LayerNorm of the update operator as one launch, fp16 storage (enet.py:59-66, 82-83):
 //   c = l5(relu(LN3(l2(relu(l0(corr))))));  out = LN(net + inp + c).   corr [E, K0] with 768 < K0 <= 896 (DEVO: 882), rows 4-byte aligned; net / inp /
 //   out [E, 384] contiguous; weight images of devo_upd_rs_pack_weight_f16 ([384, K0], [384, 384], [384, 384]); vectors fp16, 16-byte aligned.
-int devo_upd_rs_corr_f16(const void* corr, int64_t ldc, int K0, const void* w0img, const void* b0, const void* w2img, const void* b2, const void* ln3_w,
-                         const void* ln3_b, float eps3, const void* w5img, const void* b5, const void* net, const void* inp, const void* ln_w, const void* ln_b,
-                         float eps, void* out, int E, void* stream) {
+static int rs_corr_impl(const void* corr, int64_t ldc, int K0, const void* w0img, const void* b0, const void* w2img, const void* b2, const void* ln3_w,
+                        const void* ln3_b, float eps3, const void* w5img, const void* b5, const void* net, const void* inp, const void* ln_w, const void* ln_b,
+                        float eps, void* out, int E, void* stream, bool net32) {
   DEVO_REQUIRE(corr && w0img && b0 && w2img && b2 && ln3_w && ln3_b && w5img && b5 && net && inp && ln_w && ln_b && out && E > 0, "devo_upd_rs_corr_f16: null argument");
   DEVO_REQUIRE(K0 > 768 && K0 <= 896 && ldc >= K0 && ldc % 2 == 0 && (reinterpret_cast<uintptr_t>(corr) & 3) == 0, "devo_upd_rs_corr_f16: 768 < K0 (%d) <= 896, rows 4-byte aligned", K0);
   DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(net) | reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ln_w) |
@@ -1276,15 +1323,29 @@ int devo_upd_rs_corr_f16(const void* corr, int64_t ldc, int K0, const void* w0im
   DEVO_REQUIRE(((int64_t)(E - 1) * ldc + K0) * 2 < (1ll << 31), "devo_upd_rs_corr_f16: corr beyond 2 GB");
   static PerDeviceOnce attr_done;
   if (attr_done.first()) {
-    DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_corr_f16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+    DEVO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_corr_f16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_corr_f16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "devo_upd_rs_corr_f16: cannot raise the dynamic LDS limit");
   }
   RsCorr a;
   a.corr = (const __half*)corr; a.ldc = ldc; a.w0 = (const rs_u4*)w0img; a.b0 = (const __half*)b0; a.w2 = (const rs_u4*)w2img; a.b2 = (const __half*)b2;
-  a.ln3_g = (const __half*)ln3_w; a.ln3_b = (const __half*)ln3_b; a.w5 = (const rs_u4*)w5img; a.b5 = (const __half*)b5; a.net = (const __half*)net;
+  a.ln3_g = (const __half*)ln3_w; a.ln3_b = (const __half*)ln3_b; a.w5 = (const rs_u4*)w5img; a.b5 = (const __half*)b5;
+  a.net = net32 ? nullptr : (const __half*)net; a.net32 = net32 ? (const float*)net : nullptr;
   a.inp = (const __half*)inp; a.ln_g = (const __half*)ln_w; a.ln_b = (const __half*)ln_b; a.out = (__half*)out; a.E = E; a.K0 = K0; a.eps3 = eps3; a.eps = eps;
-  hipLaunchKernelGGL(k_rs_corr_f16, dim3((unsigned)((E + RG_ROWS - 1) / RG_ROWS)), dim3(512), RC_LDS, (hipStream_t)stream, a);
+  if (net32) hipLaunchKernelGGL(k_rs_corr_f16<true>, dim3((unsigned)((E + RG_ROWS - 1) / RG_ROWS)), dim3(512), RC_LDS, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_rs_corr_f16<false>, dim3((unsigned)((E + RG_ROWS - 1) / RG_ROWS)), dim3(512), RC_LDS, (hipStream_t)stream, a);
   return check_launch("devo_upd_rs_corr_f16");
+}
+int devo_upd_rs_corr_f16(const void* corr, int64_t ldc, int K0, const void* w0img, const void* b0, const void* w2img, const void* b2, const void* ln3_w,
+                         const void* ln3_b, float eps3, const void* w5img, const void* b5, const void* net, const void* inp, const void* ln_w, const void* ln_b,
+                         float eps, void* out, int E, void* stream) {
+  return rs_corr_impl(corr, ldc, K0, w0img, b0, w2img, b2, ln3_w, ln3_b, eps3, w5img, b5, net, inp, ln_w, ln_b, eps, out, E, stream, false);
+}
+// ... with `net` as fp32 [E, 384] (devo.py:311 under autocast keeps the recurrent state in fp32: it enters the sum net + inp + c unrounded, no conversion pass in front)
+int devo_upd_rs_corr_f16_net32(const void* corr, int64_t ldc, int K0, const void* w0img, const void* b0, const void* w2img, const void* b2, const void* ln3_w,
+                               const void* ln3_b, float eps3, const void* w5img, const void* b5, const float* net, const void* inp, const void* ln_w,
+                               const void* ln_b, float eps, void* out, int E, void* stream) {
+  return rs_corr_impl(corr, ldc, K0, w0img, b0, w2img, b2, ln3_w, ln3_b, eps3, w5img, b5, net, inp, ln_w, ln_b, eps, out, E, stream, true);
 }
 
 

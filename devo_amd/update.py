@@ -178,6 +178,7 @@ def _mlp2_f16(x2, l1, l2, residual=None, gather=None, fg=None):
     return y
 
 
+MIXED_STATE = __import__("os").environ.get("DEVO_UPD_MIXED_STATE", "1") != "0"      # 0: the autocast call converts the fp32 state with torch in front of / behind the fp16 operator
 AUTOCAST_F16 = __import__("os").environ.get("DEVO_UPD_AUTOCAST_F16", "1") != "0"    # 0: an fp32 operator called under autocast keeps its fp32 kernels
 RS_SPLIT = __import__("os").environ.get("DEVO_UPD_RS_SPLIT", "1") != "0"         # 0: every fp32 Linear layer on csrc/linear.hip's kernel
 
@@ -871,16 +872,19 @@ class Update(nn.Module):
         self.invalidate_weights()
         return out
 
-    def _forward_rs(self, x, inp2, c, ix, jx, Gkk, Gij, E):
+    def _forward_rs(self, x, inp2, c, ix, jx, Gkk, Gij, E, net32=False):
         """The fp16 operator on the row-resident kernels (csrc/gemm_rs.hip), ten launches: the correlation branch + norm | c1 | c2 + agg_kk's
-        f | g | SoftAgg | h | expand-add + agg_ij's f | g | SoftAgg | h | both LayerNorms, both GatedResiduals and the heads."""
+        f | g | SoftAgg | h | expand-add + agg_ij's f | g | SoftAgg | h | both LayerNorms, both GatedResiduals and the heads.
+        net32: `x` (the recurrent state) is fp32 and the new state is returned in fp32 — the call under autocast (devo.py:311), without a
+        conversion pass in front of the first and behind the last launch."""
         pl = self._rs_plan()
         if not pl["ok"]:
             return None
         lib, st, P, dim, dt, dev = L.lib(), L.stream(), L.ptr, 384, torch.float16, x.device
         chk = L.check
-        out = torch.empty_like(x)
-        chk(lib.devo_upd_rs_corr_f16(P(c), c.stride(0), c.shape[1], *pl["corr"], P(x), P(inp2), *pl["norm"], P(out), E, st), "update.rs_corr_f16")
+        out = torch.empty(E, dim, dtype=dt, device=dev)
+        corr_fn = lib.devo_upd_rs_corr_f16_net32 if net32 else lib.devo_upd_rs_corr_f16
+        chk(corr_fn(P(c), c.stride(0), c.shape[1], *pl["corr"], P(x), P(inp2), *pl["norm"], P(out), E, st), "update.rs_corr_f16")
         x = out
         y = torch.empty_like(x)
         chk(lib.devo_upd_rs_mlp2_fg_f16(P(x), dim, E, P(ix), *pl["c1"], P(x), P(y), E, None, None, None, st), "update.rs_mlp2_f16")
@@ -903,12 +907,34 @@ class Update(nn.Module):
         hy = agg(Gkk, pl["h_kk"], 16)
         chk(lib.devo_upd_rs_expand_fg_f16(P(x), P(hy), P(Gkk.group_of), *pl["fg_ij"], P(fg), E, st), "update.rs_expand_fg_f16")
         hy = agg(Gij, pl["h_ij"], 96)
-        net_out = torch.empty_like(x)
+        net_out = torch.empty(E, dim, dtype=torch.float32 if net32 else dt, device=dev)
         dw = torch.empty(2, E, 2, dtype=dt, device=dev)
         g = pl["gru"]
-        chk(lib.devo_upd_rs_gru_f16(P(x), P(hy), P(Gij.group_of), g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[13],
+        gru_fn = lib.devo_upd_rs_gru_f16_out32 if net32 else lib.devo_upd_rs_gru_f16
+        chk(gru_fn(P(x), P(hy), P(Gij.group_of), g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[13],
                                     g[14], g[15], g[16], g[17], P(net_out), P(dw[0]), P(dw[1]), E, st), "update.rs_gru_f16")
         return net_out.view(1, E, dim), (dw[0].view(1, E, 2), dw[1].view(1, E, 2), None)
+
+    def _forward_mixed(self, net, inp, corr, flow, ii, jj, kk):
+        """The fp16 operator for a caller that keeps the recurrent state in fp32 (devo.py:311 under autocast) -> net fp32, (delta, weight fp16):
+        on the row-resident kernels the first launch reads the fp32 state (it enters net + inp + corr unrounded) and the last one writes the new
+        state in fp32 — two conversion passes over [E, 384] less per call (34 us of the 45 312-edge steady-state frame); anything else:
+        the fp16 operator between explicit conversions."""
+        B, E, dim = net.shape
+        if (B == 1 and E > 0 and MIXED_STATE and net.dtype == torch.float32 and net.is_cuda and RS_CHAINS and RS_GEMM and dim == 384
+                and self.norm.weight.dtype == torch.float16):
+            x = net.reshape(E, dim)
+            x = x if x.is_contiguous() else x.contiguous()
+            inp2, c = inp.reshape(E, dim).half().contiguous(), corr.reshape(E, -1).half()
+            if (768 < c.shape[1] <= 896 and c.stride(1) == 1 and c.stride(0) % 2 == 0 and c.data_ptr() % 4 == 0 and inp2.data_ptr() % 16 == 0
+                    and x.data_ptr() % 16 == 0):
+                L.require_gpu(net, inp, corr, ii, jj, kk)
+                ix, jx, Gkk, Gij = self._tables(ii, jj, kk)
+                fast = self._forward_rs(x, inp2, c, ix, jx, Gkk, Gij, E, net32=True)
+                if fast is not None:
+                    return fast
+        n16, (d16, w16, _) = self(net.half(), inp.half(), corr.half(), flow, ii, jj, kk)
+        return n16.float(), (d16, w16, None)
 
     def _half_shadow(self):
         """An fp16 copy of this operator (for calls under autocast), rebuilt when a parameter's version counter moves; `.data` edits: invalidate_weights()."""
@@ -1014,8 +1040,7 @@ class Update(nn.Module):
             # precision class (every layer output rounded to fp16; the statistics, gates and sums in fp32), a third of the fp32 path's time —
             # and returns what autocast returns: net in fp32, delta / weight in fp16.
             with torch.autocast("cuda", enabled=False):
-                n16, (d16, w16, _) = self._half_shadow()(net.half(), inp.half(), corr.half(), flow, ii, jj, kk)
-            return n16.float(), (d16, w16, None)
+                return self._half_shadow()._forward_mixed(net, inp, corr, flow, ii, jj, kk)
         if torch.is_autocast_enabled():
             # (the kernels below take the parameters' dtype from first to last: no autocast inside — the library layers among them would
             #  hand fp16 rows to fp32 kernels)

@@ -28,7 +28,8 @@ enum { DEVO_OK = 0, DEVO_ERR_ARG = 1, DEVO_ERR_LAUNCH = 2, DEVO_ERR_UNSUPPORTED 
 enum { DEVO_F32 = 0, DEVO_F16 = 1, DEVO_F64 = 2 };
 
 #define DEVO_ABI_VERSION 5 /* 2: fp32 split formats (devo_corr_pyramid_split, exponents), group plans (plan buffer tail); 3: per-slot conversions of a ring
-                              (devo_corr_pyramid_split_frames, devo_corr_patch_transpose_range), devo_stream_capturing; 4: devo_ba_table_offsets, devo_upd_graph_tables; 5: devo_ba_forward_prepared_delta_plan, devo_ba_import_tables;
+                              (devo_corr_pyramid_split_frames, devo_corr_patch_transpose_range), devo_stream_capturing; 4: devo_ba_table_offsets, devo_upd_graph_tables; 5: devo_ba_forward_prepared_delta_plan, devo_ba_import_tables, devo_upd_rs_corr_f16_net32,
+                              devo_upd_rs_gru_f16_out32;
                               callers compare with devo_abi_version() */
 int devo_abi_version(void);
 const char* devo_last_error(void); /* thread-local message of the last failing call */
@@ -513,10 +514,20 @@ int devo_upd_rs_expand_fg_f16(void* x, const void* hy, const int* group_of, cons
 int devo_upd_rs_corr_f16(const void* corr, int64_t ldc, int K0, const void* w0image, const void* b0, const void* w2image, const void* b2, const void* ln3_w,
                          const void* ln3_b, float eps3, const void* w5image, const void* b5, const void* net, const void* inp, const void* ln_w, const void* ln_b,
                          float eps, void* out, int E, void* stream);
+/* ... with `net` as fp32 [E, 384] (the recurrent state as autocast keeps it): it enters net + inp + c unrounded, no conversion pass in front. */
+int devo_upd_rs_corr_f16_net32(const void* corr, int64_t ldc, int K0, const void* w0image, const void* b0, const void* w2image, const void* b2, const void* ln3_w,
+                               const void* ln3_b, float eps3, const void* w5image, const void* b5, const float* net, const void* inp, const void* ln_w, const void* ln_b,
+                               float eps, void* out, int E, void* stream);
 int devo_upd_rs_gru_f16(const void* x, const void* hy, const int* group_of, const void* ln0_w, const void* ln0_b, float eps0, const void* wgr1_img,
                         const void* bgr1, const void* wr2_1_img, const void* br2_1, const void* ln2_w, const void* ln2_b, float eps2, const void* wgr3_img,
                         const void* bgr3, const void* wr2_3_img, const void* br2_3, const void* Wd, const void* bd, const void* Ww, const void* bw,
                         void* net_out, void* delta, void* weight, int E, void* stream);
+/* ... with net_out as fp32 [E, 384]: the values the fp16 form stores, widened — what devo.py:311's call under autocast returns (the recurrent
+ * state stays fp32 there), without a conversion pass behind the launch. */
+int devo_upd_rs_gru_f16_out32(const void* x, const void* hy, const int* group_of, const void* ln0_w, const void* ln0_b, float eps0, const void* wgr1_img,
+                              const void* bgr1, const void* wr2_1_img, const void* br2_1, const void* ln2_w, const void* ln2_b, float eps2, const void* wgr3_img,
+                              const void* bgr3, const void* wr2_3_img, const void* br2_3, const void* Wd, const void* bd, const void* Ww, const void* bw,
+                              float* net_out, void* delta, void* weight, int E, void* stream);
 
 /* Linear - ReLU - Linear of the update operator as ONE launch, fp16 storage / fp32 accumulation (csrc/mlp2.hip; enet.py:46-50 c1 / c2,
  * :59-61 the corr MLP's first two layers): y[r] = (residual[r] +) W2 relu(W1 x[src(r)] + b1) + b2 with both layers 384 wide, any K1 (W1 is

@@ -691,7 +691,19 @@ def test_fp32_operator_under_autocast_takes_the_fp16_kernels():
         import copy
         mh = copy.deepcopy(m).half()
         n16, (d16, w16, _) = mh(args[0].half(), args[1].half(), args[2].half(), None, *args[4:])
-        assert torch.equal(n16.float(), n) and torch.equal(d16, d) and torch.equal(w16, w)
+        # round 6: the first launch reads the fp32 state, the last one writes the new state in fp32 (no conversion passes): a state that IS
+        # fp16-exact — what the operator returns and DEVO feeds back — gives the bits of the half copy; any other enters the first sum unrounded
+        with torch.autocast("cuda", dtype=torch.float16):
+            nr, (dr, wr, _) = m(args[0].half().float(), *args[1:])
+        assert torch.equal(n16.float(), nr) and torch.equal(d16, dr) and torch.equal(w16, wr)
+        UA.MIXED_STATE = False                                             # ... and with torch's conversions around the fp16 operator (round 5)
+        try:
+            with torch.autocast("cuda", dtype=torch.float16):
+                no, (do, wo, _) = m(*args)
+        finally:
+            UA.MIXED_STATE = True
+        assert no.dtype == torch.float32 and torch.equal(n16.float(), no) and torch.equal(d16, do) and torch.equal(w16, wo)
+        assert_rel(n, no, 2e-3, "mixed state against converted state")
         n32, _ = m(*args)                                                  # without autocast: the fp32 kernels
         assert_rel(n32, ref[0], 1e-4, "fp32 net")
         for p in m.parameters():                                           # an optimiser-style step: the half copy follows

@@ -385,7 +385,7 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=40):
                 imap_ = (torch.randn(mem, M, 384, device=device) * 0.5).to(dt)
                 st2 = {"f": nk, "net": torch.zeros(1, sE, 384, device=device, dtype=dt)}
 
-                def frame_full():
+                def frame_full(fused_lookup=False):
                     sii, sjj, skk = g_ii.clone(), g_jj.clone(), g_kk.clone()   # (a new graph per frame, as above)
                     ring_idx = skk % (M * mem)
                     k = st2["f"] % mem
@@ -395,7 +395,10 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=40):
                     coords = pops.transform(SE3(P1), Q1, sintr, sii, sjj, skk, fused=True).permute(0, 1, 4, 2, 3).contiguous()
                     with torch.autocast("cuda", enabled=True, dtype=torch.float16):
                         ii1, jj1 = ring_idx, sjj % mem
-                        corr = torch.stack([altcorr.corr(gm, pyramid[0], coords / 1, ii1, jj1, 3), altcorr.corr(gm, pyramid[1], coords / 4, ii1, jj1, 3)], -1).view(1, sE, -1)
+                        if fused_lookup:                                      # DEVO.corr's three lines (devo.py:215-217) as one call
+                            corr = altcorr.corr_pyramid(gm, pyramid, coords, ii1, jj1, 3)
+                        else:
+                            corr = torch.stack([altcorr.corr(gm, pyramid[0], coords / 1, ii1, jj1, 3), altcorr.corr(gm, pyramid[1], coords / 4, ii1, jj1, 3)], -1).view(1, sE, -1)
                         ctx = imap_.view(1, mem * M, 384)[:, ring_idx]
                         st2["net"], (delta_, weight_, _) = upd(st2["net"], ctx, corr, None, sii, sjj, skk)
                     target = coords[..., 1, 1] + delta_.float()
@@ -417,6 +420,21 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=40):
                                                                       "host_ms_per_frame": round(1e3 * best_host / 30, 4),
                                                                       "note": "one ring slot written + reproject + two-level lookup + Update operator (fp32 parameters under autocast) + 2 GN "
                                                                               "iterations on its outputs, eager, the reference's call sequence"}
+                with torch.no_grad():                                        # ... and with DEVO.corr's two calls + torch.stack as ONE altcorr.corr_pyramid call
+                    st2["net"] = torch.zeros(1, sE, 384, device=device, dtype=dt)
+                    for _ in range(10):
+                        frame_full(True)
+                    torch.cuda.synchronize(device)
+                    best = float("inf")
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        for _ in range(30):
+                            frame_full(True)
+                        torch.cuda.synchronize(device)
+                        best = min(best, time.perf_counter() - t0)
+                out["f16_steady_state_frame_fused_lookup"] = {"frames_per_s": round(30 / best, 1), "ms_per_frame": round(1e3 * best / 30, 4), "edges": sE,
+                                                              "note": "the same frame with devo.py:215-217 (two altcorr.corr calls + torch.stack) replaced by altcorr.corr_pyramid "
+                                                                      "(INTEGRATION.md section 2): both levels in one launch, written straight into the stacked layout"}
                 del upd, imap_
             ring.track_ring_writes(False)
             del P1, Q1, sposes, spatches

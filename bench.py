@@ -753,7 +753,8 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
     out["config"]["ba_index_tables"] = f"rebuilt every {args.prepare_every} steps (one patch graph = {args.prepare_every} update iterations)"
     out["config"]["lookup_plan"] = ("on an unchanged patch graph the lookup runs under the plan made from the previous iteration's coordinates; its ordering "
                                     "step rides on the BA's first solver launch (cuda_ba.forward_delta(..., plan_next=...)); a new patch graph orders its plan in line"
-                                    if args.plan_lag else "ordered in line by every step, in front of its lookup")
+                                    if (args.plan_lag and not (args.separate_target or args.separate_index_kernels or args.overlap_prepare))
+                                    else "ordered in line by every step, in front of its lookup")
     if ms_inline is not None:
         out["plan_in_line"] = {"ms_per_step": round(ms_inline, 4), "value": round(world * 1e3 / ms_inline, 2), "unit": "it/s",
                                "note": "the same steps with --plan-lag 0: every step orders its own locality plan (corr_order_kernel, ~9 us) between the "

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(1024) void k_excl_scan(int* data, int n, int* total
 // ---- the multi-kernel preparation works on the RANGE of patch ids the edge list holds, not on all patch slots (round 6): DEVO's buffers have
 // 2048 frames x 96 = 196 608 slots, a sliding-window graph touches the 2 112 patches of 22 frames — flags, scan and the unique-id sweep over the
 // slots cost 380 us there, over the range 30.  range[0] = max(-k), range[1] = max(k) over the valid ids (both start at 0x80808080: "minus infinity").
-__global__ void k_kk_range(const int64_t* __restrict__ kk, int E, int Np, int* __restrict__ range) {
+__device__ __forceinline__ void kk_range_body(const int64_t* __restrict__ kk, int E, int Np, int* __restrict__ range) {
   int nlo = (int)0x80808080, hi = (int)0x80808080;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
     const int64_t k = kk[e];
@@ -146,13 +146,14 @@ __global__ void k_kk_range(const int64_t* __restrict__ kk, int E, int Np, int* _
     if (b != (int)0x80808080) { atomicMax(&range[0], a); atomicMax(&range[1], b); }
   }
 }
+__global__ void k_kk_range(const int64_t* __restrict__ kk, int E, int Np, int* __restrict__ range) { kk_range_body(kk, E, Np, range); }
 __device__ __forceinline__ void kk_range(const int* __restrict__ range, int& kmin, int& Rg) {
   const int nlo = range[0], hi = range[1];
   const bool any = hi != (int)0x80808080;
   kmin = any ? -nlo : 0;
   Rg = any ? hi - kmin + 1 : 0;
 }
-__global__ void k_flag_ids_r(const int64_t* __restrict__ kk, int E, int Np, int* flags, const int* __restrict__ range) {
+__device__ __forceinline__ void flag_ids_r_body(const int64_t* __restrict__ kk, int E, int Np, int* flags, const int* __restrict__ range) {
   int kmin, Rg;
   kk_range(range, kmin, Rg);
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
@@ -160,8 +161,9 @@ __global__ void k_flag_ids_r(const int64_t* __restrict__ kk, int E, int Np, int*
     if (k >= 0 && k < Np) flags[(int)k - kmin] = 1;
   }
 }
+__global__ void k_flag_ids_r(const int64_t* __restrict__ kk, int E, int Np, int* flags, const int* __restrict__ range) { flag_ids_r_body(kk, E, Np, flags, range); }
 // k_excl_scan over a length read on the device: mode 0 = the id range (range), mode 1 = min(*n_ptr, cap) (the segment counts: n_seg of them)
-__global__ __launch_bounds__(1024) void k_excl_scan_dev(int* data, const int* __restrict__ n_ptr, int mode, int cap, int* total_out) {
+__device__ __forceinline__ void excl_scan_dev_body(int* data, const int* __restrict__ n_ptr, int mode, int cap, int* total_out) {
   __shared__ int s_part[1024];
   int n;
   if (mode == 0) { int kmin; kk_range(n_ptr, kmin, n); } else n = min(*n_ptr, cap);
@@ -169,12 +171,13 @@ __global__ __launch_bounds__(1024) void k_excl_scan_dev(int* data, const int* __
   if (threadIdx.x == 0 && total_out) *total_out = total;
   if (mode == 1) for (int i = n + 1 + threadIdx.x; i <= cap; i += 1024) data[i] = total;     // segment starts beyond n_seg = E: any reader sees empty tails
 }
+__global__ __launch_bounds__(1024) void k_excl_scan_dev(int* data, const int* __restrict__ n_ptr, int mode, int cap, int* total_out) { excl_scan_dev_body(data, n_ptr, mode, cap, total_out); }
 // Few, large segments (the Update operator's frame-pair groups: 45 312 edges in 210 groups) make the per-edge device atomics of the counting and
 // scattering passes queue on a handful of addresses (23 us each where the patch groups take 5): when n_seg <= SEG_LDS_MAX and the average segment
 // holds >= 64 edges, every workgroup counts in LDS first and issues ONE device atomic per segment it met.
 constexpr int SEG_LDS_MAX = 1024;
 __device__ __forceinline__ bool seg_lds_path(int n_seg, int E) { return n_seg <= SEG_LDS_MAX && (long long)n_seg * 64 <= E; }
-__global__ __launch_bounds__(256) void k_rank_edges_r(const int64_t* __restrict__ kk, int E, int Np, const int* __restrict__ rank, int* ku, int* kx,
+__device__ __forceinline__ void rank_edges_r_body(const int64_t* __restrict__ kk, int E, int Np, const int* __restrict__ rank, int* ku, int* kx,
                                                       int* counts, const int* __restrict__ range, const int* __restrict__ n_seg_p) {
   __shared__ int s_hist[SEG_LDS_MAX];
   int kmin, Rg;
@@ -203,6 +206,8 @@ __global__ __launch_bounds__(256) void k_rank_edges_r(const int64_t* __restrict_
   for (int p = gid; p < Rg; p += gsz)
     if (rank[p + 1] != rank[p]) kx[rank[p]] = kmin + p;
 }
+__global__ __launch_bounds__(256) void k_rank_edges_r(const int64_t* __restrict__ kk, int E, int Np, const int* __restrict__ rank, int* ku, int* kx,
+                                                      int* counts, const int* __restrict__ range, const int* __restrict__ n_seg_p) { rank_edges_r_body(kk, E, Np, rank, ku, kx, counts, range, n_seg_p); }
 
 __global__ void k_flag_ids(const int64_t* __restrict__ kk, int E, int Np, int* flags) {
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += blockDim.x * gridDim.x) {
@@ -230,7 +235,7 @@ __global__ void k_scatter_edges(const int* __restrict__ ku, int E, const int* __
   }
 }
 // The same with the workgroup's edges ranked in LDS first (see seg_lds_path): one device atomic per (workgroup, segment) reserves the slots.
-__global__ __launch_bounds__(256) void k_scatter_edges_seg(const int* __restrict__ ku, int E, const int* __restrict__ seg_start, int* cursor, int* perm,
+__device__ __forceinline__ void scatter_edges_seg_body(const int* __restrict__ ku, int E, const int* __restrict__ seg_start, int* cursor, int* perm,
                                                            const int* __restrict__ n_seg_p) {
   __shared__ int s_hist[SEG_LDS_MAX];
   const int n_seg = max(*n_seg_p, 1);
@@ -255,8 +260,10 @@ __global__ __launch_bounds__(256) void k_scatter_edges_seg(const int* __restrict
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(256) void k_scatter_edges_seg(const int* __restrict__ ku, int E, const int* __restrict__ seg_start, int* cursor, int* perm,
+                                                           const int* __restrict__ n_seg_p) { scatter_edges_seg_body(ku, E, seg_start, cursor, perm, n_seg_p); }
 // Restore a deterministic (ascending edge id) order inside every segment: rank sort, one wave per segment.
-__global__ void k_sort_segments(const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int sig, const int* __restrict__ in, int* out) {
+__device__ __forceinline__ void sort_segments_body(const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int sig, const int* __restrict__ in, int* out) {
   const int* n_seg_p = &meta->n_seg;
   if (blockIdx.x == 0 && threadIdx.x == 0) meta->sig = sig;      // the workspace now holds a prepared graph
   if (meta->pad) return;                                         // the list was already grouped: perm is the identity
@@ -271,6 +278,38 @@ __global__ void k_sort_segments(const int* __restrict__ seg_start, BaMeta* __res
       out[a + r] = x;
     }
   }
+}
+__global__ void k_sort_segments(const int* __restrict__ seg_start, BaMeta* __restrict__ meta, int sig, const int* __restrict__ in, int* out) { sort_segments_body(seg_start, meta, sig, in, out); }
+
+// ---- the multi-kernel preparation of TWO edge lists of one length in the same launches (devo_upd_graph_tables: the edges grouped by patch and by
+// frame pair, once per frame in DEVO's steady state): blockIdx.y picks the problem, every stage is one launch instead of two — 11 launches for
+// what took 22 (each ~4.5 us of a nearly idle chip).
+struct Prep2 {
+  const int64_t* kk[2]; BaMeta* meta[2]; int* rank[2]; int* counts[2]; int* cursor[2]; int* ku[2]; int* kx[2]; int* perm_a[2]; int* perm_b[2]; int* range[2];
+};
+__global__ void k_kk_range2(Prep2 p, int E, int Np) { const int y = blockIdx.y; kk_range_body(p.kk[y], E, Np, p.range[y]); }
+__global__ void k_flag_ids_r2(Prep2 p, int E, int Np) { const int y = blockIdx.y; flag_ids_r_body(p.kk[y], E, Np, p.rank[y], p.range[y]); }
+__global__ __launch_bounds__(1024) void k_excl_scan_dev2(Prep2 p, int mode, int cap) {
+  const int y = blockIdx.y;
+  if (mode == 0) excl_scan_dev_body(p.rank[y], p.range[y], 0, 0, &p.meta[y]->n_seg);
+  else excl_scan_dev_body(p.counts[y], &p.meta[y]->n_seg, 1, cap, nullptr);
+}
+__global__ __launch_bounds__(256) void k_rank_edges_r2(Prep2 p, int E, int Np) {
+  const int y = blockIdx.y;
+  rank_edges_r_body(p.kk[y], E, Np, p.rank[y], p.ku[y], p.kx[y], p.counts[y], p.range[y], &p.meta[y]->n_seg);
+}
+__global__ __launch_bounds__(256) void k_scatter_edges_seg2(Prep2 p, int E) {
+  const int y = blockIdx.y;
+  scatter_edges_seg_body(p.ku[y], E, p.counts[y], p.cursor[y], p.perm_a[y], &p.meta[y]->n_seg);
+}
+__global__ void k_sort_segments2(Prep2 p, int sig) { const int y = blockIdx.y; sort_segments_body(p.counts[y], p.meta[y], sig, p.perm_a[y], p.perm_b[y]); }
+// what the two hipMemsetAsync pairs of two preparations and the pair key's range fill did: the heads of both workspaces (meta | rank | counts | cursor)
+// to zero, the three id ranges to "minus infinity" (0x80808080)
+__global__ __launch_bounds__(256) void k_prep_clear2(int4* __restrict__ a0, int4* __restrict__ a1, long long n4, int* r0, int* r1, int* r2) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long long)blockDim.x * gridDim.x;
+  const int4 z = make_int4(0, 0, 0, 0);
+  for (long long i = gid; i < n4; i += gsz) { a0[i] = z; a1[i] = z; }
+  if (gid < 4) { r0[gid] = (int)0x80808080; r1[gid] = (int)0x80808080; r2[gid] = (int)0x80808080; }
 }
 
 // Whole graph preparation in ONE launch (one workgroup of 1024 threads) for E <= 2^17:
@@ -3317,8 +3356,42 @@ int devo_upd_graph_tables(const int64_t* ii, const int64_t* jj, const int64_t* k
   DEVO_REQUIRE(ii && jj && kk && ws_kk && ws_ij && pair_key, "devo_upd_graph_tables: missing argument");
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if ((rc = ba_prepare_impl(kk, E, bound, 0, ws_kk, ws_kk_bytes, st))) return rc;
   const BaLayout L = ba_layout(E, bound, 0);
+  // beyond the single-workgroup preparation's size (DEVO's steady-state graph: 45 312 edges) both edge lists go through the multi-kernel stages
+  // TOGETHER (Prep2): 11 launches for what the two preparations, their fills and the key's range fill did in 22
+  static const int multi_from = [] { const char* e = getenv("DEVO_BA_PREP_MULTI_FROM"); return e ? atoi(e) : 32 * 1024 + 1; }();
+  static const bool dual_env = [] { const char* e = getenv("DEVO_UPD_TABLES_DUAL"); return !(e && e[0] == '0'); }();
+  if (dual_env && !(E <= (1 << 17) && E < multi_from)) {
+    if (ws_kk_bytes < L.total || ws_ij_bytes < L.total) { set_error("devo_upd_graph_tables: workspace %zu / %zu < %zu bytes", ws_kk_bytes, ws_ij_bytes, L.total); return DEVO_ERR_WORKSPACE; }
+    char* w0 = (char*)ws_kk;
+    char* w1 = (char*)ws_ij;
+    Prep2 p;
+    const int64_t* keys[2] = {kk, pair_key};
+    char* wsp[2] = {w0, w1};
+    for (int y = 0; y < 2; y++) {
+      p.kk[y] = keys[y]; p.meta[y] = (BaMeta*)(wsp[y] + L.meta); p.rank[y] = (int*)(wsp[y] + L.rank); p.counts[y] = (int*)(wsp[y] + L.counts);
+      p.cursor[y] = (int*)(wsp[y] + L.cursor); p.ku[y] = (int*)(wsp[y] + L.ku); p.kx[y] = (int*)(wsp[y] + L.kx); p.perm_a[y] = (int*)(wsp[y] + L.perm_a);
+      p.perm_b[y] = (int*)(wsp[y] + L.perm_b); p.range[y] = (int*)(wsp[y] + L.range);
+    }
+    int* prange = (int*)(pair_key + E);                             // (the two extra words of the key buffer)
+    const long long n4 = (long long)((L.ku - L.meta) / 16);         // (every region of the layout is a multiple of 256 bytes)
+    hipLaunchKernelGGL(k_prep_clear2, dim3(blocks_for(n4, 256, 2048)), dim3(256), 0, st, (int4*)(w0 + L.meta), (int4*)(w1 + L.meta), n4, p.range[0], p.range[1], prange);
+    hipLaunchKernelGGL(k_pair_range, dim3(blocks_for(E, 256 * 4, 256)), dim3(256), 0, st, ii, jj, E, prange);
+    hipLaunchKernelGGL(k_pair_key, dim3(blocks_for(E, 256, 1024)), dim3(256), 0, st, ii, jj, E, prange, pair_key);
+    const unsigned eb = (unsigned)blocks_for(E, 256, 1024);
+    hipLaunchKernelGGL(k_kk_range2, dim3(blocks_for(E, 256 * 4, 256), 2), dim3(256), 0, st, p, E, bound);
+    hipLaunchKernelGGL(k_flag_ids_r2, dim3(eb, 2), dim3(256), 0, st, p, E, bound);
+    hipLaunchKernelGGL(k_excl_scan_dev2, dim3(1, 2), dim3(1024), 0, st, p, 0, 0);
+    hipLaunchKernelGGL(k_rank_edges_r2, dim3(eb, 2), dim3(256), 0, st, p, E, bound);
+    hipLaunchKernelGGL(k_excl_scan_dev2, dim3(1, 2), dim3(1024), 0, st, p, 1, L.max_seg);
+    hipLaunchKernelGGL(k_scatter_edges_seg2, dim3(eb, 2), dim3(256), 0, st, p, E);
+    hipLaunchKernelGGL(k_sort_segments2, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024), 2), dim3(256), 0, st, p, ba_sig(E, 0));
+    if (ix && jx)
+      hipLaunchKernelGGL(k_neighbors_seg, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, jj, (const BaMeta*)(w0 + L.meta),
+                         (const int*)(w0 + L.counts), (const int*)(w0 + L.perm_b), ix, jx);
+    return check_launch("devo_upd_graph_tables");
+  }
+  if ((rc = ba_prepare_impl(kk, E, bound, 0, ws_kk, ws_kk_bytes, st))) return rc;
   if (ix && jx) {
     const char* w = (const char*)ws_kk;
     hipLaunchKernelGGL(k_neighbors_seg, dim3(blocks_for((long long)L.max_seg * 64, 256, 1024)), dim3(256), 0, st, jj, (const BaMeta*)(w + L.meta),

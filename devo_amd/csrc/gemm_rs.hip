@@ -1202,9 +1202,11 @@ int devo_upd_rs_linear_f16(const void* x, int64_t ldx, const void* wimg, const v
             nwg, rows, NB, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, hi - lo);
     return rc;
   }
-  // few rows (the SoftAggs' h layers: 1 440 / 210 rows): 32-row workgroups — the products of a 96-row tile on three CUs are time added to the
-  // latency of the weight stream, which is what such a launch consists of (9.4 -> ~6 us)
-  if (M <= 2048 && !getenv("DEVO_RS_MT")) return rs_launch<2, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
+  // few rows (the SoftAggs' h layers: 1 440 / 210 rows at cfg2, 2 112 at the steady-state graph): 32-row workgroups — the products of a 96-row tile
+  // on three CUs are time added to the latency of the weight stream, which is what such a launch consists of (9.4 -> ~6 us).  Swept in round 6
+  // (tools/exp_r06y.sh): 32 rows win up to 12 288 rows (2 112: 9.1 -> 5.3 us, 8 192: 9.9 -> 7.4, 12 288: 10.6 -> 10.0), 96 rows at 21 600 (12.8 / 15.0)
+  static const int small_m = [] { const char* e = getenv("DEVO_RS_SMALL_M"); return e ? atoi(e) : 12288; }();   // (tuning switch)
+  if (M <= small_m && !getenv("DEVO_RS_MT")) return rs_launch<2, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
   if (mt == 6) return rs_launch<6, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
   if (mt == 2) return rs_launch<2, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);
   if (mt == 3) return rs_launch<3, 12>(x, ldx, wimg, bias, residual, y, ldy, M, NB, K, relu_from, (hipStream_t)stream);

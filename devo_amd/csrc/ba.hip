@@ -1499,6 +1499,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_ba_solve_t(const float* S, co
   int ty, tx;                                  // this thread's first tile: the only one it has for N <= 14 at 1024 threads
   tile_of(tid, ty, tx);
   __syncthreads();
+  if (iter == 0 && tid == 0 && status_flag) *status_flag = meta->fail < 0 ? -1 : 0;      // (the call's status word starts here: no fill in front of the call)
   if (meta->fail) {                              // an earlier iteration broke down: the reference call has thrown by now
     if (tid == 0 && meta->fail < 0 && status_flag) *status_flag = -1;          // (or the workspace was never prepared)
     return;
@@ -1876,6 +1877,10 @@ __device__ __forceinline__ void ba_solve_chain_body(const float* __restrict__ S,
     }
   }
   __syncthreads();
+  // the call's status word is (re)set by its first solver launch — no fill in front of the call (round 6: the word may live in pinned host memory,
+  // devo_amd.fastba: no copy behind the call either); every workgroup of a fused launch factorises the same system and fails alike, the lead
+  // writes after its own reset
+  if (iter == 0 && lead && tid == 0 && status_flag) *status_flag = failed_before < 0 ? -1 : 0;
   if (failed_before) {                           // an earlier iteration broke down: the reference call has thrown by now
     if (lead && tid == 0 && failed_before < 0 && status_flag) *status_flag = -1;  // (or the workspace was never prepared)
     return;
@@ -3004,7 +3009,8 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   float* dX = (float*)(w + L.dX);
   float* patch_rec = (float*)(w + L.patch_rec);
   float* edge_ej = (float*)(w + L.edge_ej);
-  if (status_flag && hipMemsetAsync(status_flag, 0, sizeof(int), st) != hipSuccess) { set_error("devo_ba_forward: memset failed"); return DEVO_ERR_LAUNCH; }
+  // (with poses to optimise the first solver launch resets the status word; a structure-only call has no solver)
+  if (status_flag && N == 0 && hipMemsetAsync(status_flag, 0, sizeof(int), st) != hipSuccess) { set_error("devo_ba_forward: memset failed"); return DEVO_ERR_LAUNCH; }
 
   const size_t n6 = 6 * (size_t)N;
   const float ep = 1.0f;                                          // ba_cuda.cu:518

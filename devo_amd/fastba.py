@@ -9,6 +9,8 @@ _ws_cache = {}
 _status = {}                  # device -> int32 [1]: 0 = ok, k > 0 = the Cholesky factorisation broke down in iteration k, -1 = bad workspace
 _host = {}                    # device -> two (pinned int32 [1], event) slots: the status is copied out asynchronously after every BA()
 _pending = {}                 # device -> True while the status of the last BA() has not been looked at
+import os as _os
+PINNED_STATUS = _os.environ.get("DEVO_BA_PINNED_STATUS", "1") != "0"   # 0: a device status word + an asynchronous copy behind every BA() (rounds 1-5)
 MAX_OPTIMISED_POSES = 128     # devo_ba_forward: up to 32 the reduced system lives in one workgroup's LDS, beyond in global memory (slower)
 
 
@@ -90,21 +92,33 @@ def BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, it
     # lazy check: finished status copies of EARLIER calls are read now but reported only after THIS call's work is enqueued — a caller
     # that wraps BA() in the reference's try / except (devo.py:336-340) must not lose a healthy adjustment to a predecessor's failure
     prev_code = _collect(dev, wait_all=False) if (check == "lazy" and _pending.get(dev)) else 0
-    st = _status.get(dev)
-    if st is None:
-        st = _status[dev] = torch.zeros(1, dtype=torch.int32, device=pose_data.device)
     ws = _workspace(ii.numel(), patches.numel() // (3 * P * P), n_opt, pose_data.device)
-    out = _ba.forward(pose_data, patches, intrinsics, target, weight, lmbda, ii, jj, kk, int(t0), int(t1), int(iterations), ws=ws, status=st)
     capturing = torch.cuda.is_current_stream_capturing()
-    if not capturing:
+    if not capturing and PINNED_STATUS:
+        # the kernels write the status word straight into one of the two pinned host words (device-visible at its own address): no fill in
+        # front of the call (its first solver launch resets the word), no copy behind it — two launches of ~5 us of GPU time less per adjustment
         h = _slots(dev)
         sl = h["slots"][h["next"]]
         if sl[2]:                                            # (check="never" loops: the slot's old status is dropped with its wait)
             sl[1].synchronize()
-        sl[0].copy_(st, non_blocking=True)
+        out = _ba.forward(pose_data, patches, intrinsics, target, weight, lmbda, ii, jj, kk, int(t0), int(t1), int(iterations), ws=ws, status=sl[0])
         sl[1].record()
         sl[2] = True
         h["next"] = (h["next"] + 1) % 2
+    else:
+        st = _status.get(dev)
+        if st is None:
+            st = _status[dev] = torch.zeros(1, dtype=torch.int32, device=pose_data.device)
+        out = _ba.forward(pose_data, patches, intrinsics, target, weight, lmbda, ii, jj, kk, int(t0), int(t1), int(iterations), ws=ws, status=st)
+        if not capturing:
+            h = _slots(dev)
+            sl = h["slots"][h["next"]]
+            if sl[2]:
+                sl[1].synchronize()
+            sl[0].copy_(st, non_blocking=True)
+            sl[1].record()
+            sl[2] = True
+            h["next"] = (h["next"] + 1) % 2
     _pending[dev] = check != "never" and not capturing
     if check == "now":
         code = last_status(pose_data.device)

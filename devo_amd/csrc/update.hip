@@ -745,6 +745,95 @@ __global__ __launch_bounds__(64 * NW) void k_softagg_v(const T* __restrict__ f, 
   }
 }
 
+// Small groups (the edges of a patch: 15 at cfg2, ~21 in DEVO's sliding window): ONE WAVE per group, no LDS, no barrier — the group's rows are
+// requested together (batches of RB rows: every lane holds its 16-byte chunk of each, raw), the batch's maximum is exact, one exponential per
+// element (the online form of k_softagg_v pays two per row and element, and its four waves meet at two barriers around an LDS merge for 15
+// rows); batches of a longer group are merged online.  Deterministic: rows in the order of perm.  Lanes beyond the row's chunks idle.
+template <typename T>
+__global__ __launch_bounds__(256) void k_softagg_w(const T* __restrict__ f, const T* __restrict__ g, int64_t ld_fg, const int* __restrict__ perm,
+                                                   const int* __restrict__ seg, const int* __restrict__ n_seg_p, T* __restrict__ y,
+                                                   int* __restrict__ group_of, int dim, int cpr) {
+  constexpr int V = ChunkOf<T>::V, RB = sizeof(T) == 2 ? 16 : 8, NQ = sizeof(T) == 2 ? 1 : 2;   // (dim <= 512 halves / 512 floats: cpr <= 64 NQ)
+  typedef uint4 raw_t;
+  const int n_seg = *n_seg_p;
+  const int lane = threadIdx.x & 63;
+  const int w0 = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), nw = (int)gridDim.x * 4;
+  for (int s = w0; s < n_seg; s += nw) {
+    const int a0 = seg[s], a1 = seg[s + 1];
+    float m[NQ][V], den[NQ][V], num[NQ][V];
+#pragma unroll
+    for (int k = 0; k < NQ; k++)
+#pragma unroll
+      for (int u = 0; u < V; u++) { m[k][u] = -3.0e38f; den[k][u] = 0.0f; num[k][u] = 0.0f; }
+    for (int a = a0; a < a1; a += RB) {
+      const int nr = min(RB, a1 - a);                              // wave-uniform
+      const int mine = (lane < nr) ? perm[a + lane] : 0;
+      if (group_of && lane < nr) group_of[mine] = s;
+      raw_t gr[NQ][RB], fr[NQ][RB];
+#pragma unroll
+      for (int r = 0; r < RB; r++) {
+        const int64_t e = (int64_t)__builtin_amdgcn_readlane(mine, r < nr ? r : 0);      // (rows beyond the batch repeat its first: loaded, not used)
+#pragma unroll
+        for (int k = 0; k < NQ; k++) {
+          const int q = lane + 64 * k;
+          if (q < cpr) {
+            gr[k][r] = *reinterpret_cast<const raw_t*>(g + e * ld_fg + q * V);
+            fr[k][r] = *reinterpret_cast<const raw_t*>(f + e * ld_fg + q * V);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+        const int q = lane + 64 * k;
+        if (q < cpr) {
+          float bm[V];
+#pragma unroll
+          for (int u = 0; u < V; u++) bm[u] = m[k][u];
+#pragma unroll
+          for (int r = 0; r < RB; r++) {
+            if (r < nr) {                                          // (converted again below: conversions are cheaper than 128 more registers)
+              float gv[V];
+              ldc(reinterpret_cast<const T*>(&gr[k][r]), gv);
+#pragma unroll
+              for (int u = 0; u < V; u++) bm[u] = fmaxf(bm[u], gv[u]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < V; u++) {
+            const float sc = __expf(m[k][u] - bm[u]);              // (first batch: exp(-3e38 - max) = 0 on zeros)
+            den[k][u] *= sc; num[k][u] *= sc; m[k][u] = bm[u];
+          }
+#pragma unroll
+          for (int r = 0; r < RB; r++) {
+            if (r < nr) {
+              float fv[V], gv[V];
+              raw_t gt = gr[k][r];
+              asm volatile("" : "+v"(gt.x), "+v"(gt.y), "+v"(gt.z), "+v"(gt.w));      // (opaque: or the compiler keeps the first pass's 128 converted values alive)
+              ldc(reinterpret_cast<const T*>(&gt), gv);
+              ldc(reinterpret_cast<const T*>(&fr[k][r]), fv);
+#pragma unroll
+              for (int u = 0; u < V; u++) {
+                const float w = __expf(gv[u] - bm[u]);
+                den[k][u] += w; num[k][u] += fv[u] * w;
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+      const int q = lane + 64 * k;
+      if (q < cpr) {
+        float o[V];
+#pragma unroll
+        for (int u = 0; u < V; u++) o[u] = num[k][u] / den[k][u];
+        stc(y + (int64_t)s * dim + q * V, o);
+      }
+    }
+  }
+}
+
 static unsigned grid_for(long long n, int per_block, int cap) {
   long long b = (n + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -874,6 +963,14 @@ int devo_upd_softagg_hint(const void* f, const void* g, int64_t ld_fg, const int
       UPD_DISPATCH(dtype,
         hipLaunchKernelGGL((k_softagg_v<float, 16>), vgrid, dim3(1024), lds, st_, (const float*)f, (const float*)g, ld_fg, perm, seg_start, n_seg, (float*)y, group_of, dim, cpr),
         hipLaunchKernelGGL((k_softagg_v<__half, 16>), vgrid, dim3(1024), lds, st_, (const __half*)f, (const __half*)g, ld_fg, perm, seg_start, n_seg, (__half*)y, group_of, dim, cpr));
+      return check_launch("devo_upd_softagg");
+    }
+    static const bool wave_form = [] { const char* e = getenv("DEVO_UPD_SOFTAGG_WAVE"); return !(e && e[0] == '0'); }();
+    if (wave_form && rows_per_group > 0 && rows_per_group <= 40 && cpr <= (dtype == DEVO_F32 ? 128 : 64)) {     // one wave per group (a patch's edges)
+      const dim3 wgrid(grid_for((E / rows_per_group + 1 + 3) / 4, 1, 4096));
+      UPD_DISPATCH(dtype,
+        hipLaunchKernelGGL((k_softagg_w<float>), wgrid, dim3(256), 0, st_, (const float*)f, (const float*)g, ld_fg, perm, seg_start, n_seg, (float*)y, group_of, dim, cpr),
+        hipLaunchKernelGGL((k_softagg_w<__half>), wgrid, dim3(256), 0, st_, (const __half*)f, (const __half*)g, ld_fg, perm, seg_start, n_seg, (__half*)y, group_of, dim, cpr));
       return check_launch("devo_upd_softagg");
     }
     const dim3 vblock(256);

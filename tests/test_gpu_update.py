@@ -189,6 +189,36 @@ def test_update_single_ops():
     assert_rel(delta, torch.relu(nref) @ Wd.double().t() + bd.double(), 1e-5, "delta head after the gated residual")
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 2e-3)])
+def test_softagg_one_wave_per_group(dtype, tol):
+    """k_softagg_w (round 6): small groups — a patch's edges — by one wave each, the rows requested together, exact batch maxima, batches of a
+    longer group merged online.  Groups of 1 ... 40 rows (1, 15, 16, 17, 33 among them: below / at / above one and two batches of fp16 and fp32),
+    against the float64 segment softmax (blocks.py:42-43) and against the four-wave form of the same launch (hint 0)."""
+    from devo_amd.update import _Groups
+    g = torch.Generator().manual_seed(11)
+    sizes = [1, 15, 16, 17, 33, 40, 8, 9, 2] + [int(v) for v in torch.randint(1, 30, (150,), generator=g)]
+    key = torch.cat([torch.full((n,), 7 * i + 3, dtype=torch.int64) for i, n in enumerate(sizes)])
+    key = key[torch.randperm(key.numel(), generator=g)]
+    E, dim = key.numel(), 384
+    x = (torch.randn(E, 2 * dim, generator=g) * 2.0).to(DEV).to(dtype)              # f | g
+    G = _Groups(key.to(DEV))
+    lib, code = L.lib(), L.dtype_code(x)
+    outs = []
+    for hint in (E // len(sizes), 0):
+        y = torch.zeros(G.n_seg, dim, device=DEV, dtype=dtype)
+        grp = torch.full((E,), -1, dtype=torch.int32, device=DEV)
+        L.check(lib.devo_upd_softagg_hint(L.ptr(x), L.ptr(x[:, dim:]), 2 * dim, L.ptr(G.perm), L.ptr(G.seg_start), L.ptr(G.n_seg_dev), L.ptr(y), L.ptr(grp),
+                                          E, dim, code, hint, L.stream()), "softagg")
+        outs.append((y, grp))
+    _, inv = torch.unique(key, return_inverse=True)
+    yref = U.segment_softmax_sum(x[:, :dim].cpu().double()[None], x[:, dim:].cpu().double()[None], inv)[0]
+    assert G.n_seg == len(sizes) == yref.shape[0]
+    for y, grp in outs:
+        assert torch.equal(grp.cpu().long(), inv)
+        assert_rel(y.float(), yref, tol, "softagg")
+    assert_rel(outs[0][0].float(), outs[1][0].double(), tol, "one wave per group against four")
+
+
 def test_gradient_clip_backward_semantics():
     """blocks.py:72-81: the delta / weight heads pass gradients through GradClip — NaN -> 0, clamped to +-0.01"""
     from devo_amd.update import GradientClip

@@ -195,6 +195,7 @@ def test_softagg_one_wave_per_group(dtype, tol):
     longer group merged online.  Groups of 1 ... 40 rows (1, 15, 16, 17, 33 among them: below / at / above one and two batches of fp16 and fp32),
     against the float64 segment softmax (blocks.py:42-43) and against the four-wave form of the same launch (hint 0)."""
     from devo_amd.update import _Groups
+    from devo_amd import _lib as L
     g = torch.Generator().manual_seed(11)
     sizes = [1, 15, 16, 17, 33, 40, 8, 9, 2] + [int(v) for v in torch.randint(1, 30, (150,), generator=g)]
     key = torch.cat([torch.full((n,), 7 * i + 3, dtype=torch.int64) for i, n in enumerate(sizes)])

@@ -63,6 +63,9 @@ class _FusedTransform(torch.autograd.Function):
         return gp.view_as(pose_data), gq.view_as(patches), None, None, None, None, None, None, None
 
 
+_VIEW_2PP = __import__("os").environ.get("DEVO_TRANSFORM_2PP_VIEW", "1") != "0"     # 0: the no-gradient coordinates as a contiguous [1,E,P,P,2] tensor
+
+
 def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, jacobian=False, tonly=False, fused=True):
     """coords [1,E,P,P,2(+1)] (+ validity [1,E], + (Ji [1,E,2,6], Jj [1,E,2,6], Jz [1,E,2,1])).
     fused=False: always the reference's composition over the SE3 group ops (projective_ops.py:53-105: what an unmodified checkout of the
@@ -70,6 +73,12 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     import os
     fused_ok = fused and poses.data.dtype == torch.float32 and poses.data.shape[0] == 1 and patches.is_cuda
     if fused_ok and not _needs_grad(poses.data, patches, intrinsics):
+        if _VIEW_2PP and not (depth or valid or jacobian):
+            # coordinates only (devo.py:222, :352, flow_mag): every caller of the reference turns [1,E,P,P,2] into [1,E,2,P,P] right away
+            # (`.permute(0, 1, 4, 2, 3).contiguous()`, devo.py:223) or reads it through arithmetic — so the kernel writes the 2 x P x P layout and
+            # the result is handed out as the [1,E,P,P,2] VIEW of it: the caller's permute + contiguous() finds contiguous memory and copies nothing
+            c = cuda_ba.transform(poses.data, patches, intrinsics, ii, jj, kk, tonly=tonly, layout="2pp")
+            return c.permute(0, 1, 3, 4, 2)
         return cuda_ba.transform(poses.data, patches, intrinsics, ii, jj, kk, depth=depth, valid=valid,
                                  jacobian=jacobian, tonly=tonly, layout="pp2")
     # (not for tonly: the reference's autograd treats the overwritten quaternion slots of `Gij.data[..., 3:] = identity` as cut

@@ -99,3 +99,31 @@ def test_patchifier_under_autocast_as_devo_calls_it():
     if torch.equal(got[3], ref[3]):                                        # the same patch centres (the scorer's fp16 scores may reorder near-ties)
         assert (got[1].float() - ref[1].float()).abs().max().item() <= 3e-2 * max(1.0, ref[1].abs().max().item())
         assert (got[2].float() - ref[2].float()).abs().max().item() <= 3e-2 * max(1.0, ref[2].abs().max().item())
+
+
+def test_reproject_hands_out_the_layout_its_caller_asks_for():
+    """devo.py:222-223: `pops.transform(...).permute(0, 1, 4, 2, 3).contiguous()`.  Without gradients the kernel writes [1,E,2,P,P] and the result
+    is the [1,E,P,P,2] VIEW of it: the caller's permute + contiguous() copies nothing (same storage), every value is the one the contiguous
+    [1,E,P,P,2] form holds (DEVO_TRANSFORM_2PP_VIEW=0), and arithmetic on the view (flow_mag, projective_ops.py:114-121) sees the same numbers."""
+    from devo_amd import synth, projective_ops as pops
+    from devo_amd.lietorch import SE3
+    from devo_amd.backends import cuda_ba
+    nk, Mp = 9, 40
+    poses = synth.make_poses(nk, 2).to(DEV)
+    patches = synth.make_patches(nk, Mp, 120, 160, seed=2)[0].to(DEV)
+    intr = synth.make_intrinsics(nk, 120, 160).to(DEV)
+    ii, jj, kk = [t.to(DEV) for t in synth.full_graph(nk, Mp)]
+    with torch.no_grad():
+        c = pops.transform(SE3(poses), patches, intr, ii, jj, kk)
+        assert c.shape == (1, len(ii), 3, 3, 2)
+        r = c.permute(0, 1, 4, 2, 3)
+        assert r.is_contiguous() and r.contiguous().data_ptr() == c.data_ptr()
+        ref = cuda_ba.transform(poses, patches, intr, ii, jj, kk, layout="pp2")
+        assert ref.is_contiguous() and torch.equal(c, ref) and torch.equal(c.contiguous(), ref)
+        t = pops.transform(SE3(poses), patches, intr, ii, jj, kk, tonly=True)
+        assert torch.equal(t, cuda_ba.transform(poses, patches, intr, ii, jj, kk, tonly=True, layout="pp2"))
+        f = pops.flow_mag(SE3(poses), patches, intr, ii, jj, kk, beta=0.5) if hasattr(pops, "flow_mag") else None
+        if f is not None:
+            c0 = cuda_ba.transform(poses, patches, intr, ii, ii, kk, layout="pp2")
+            want = 0.5 * (ref - c0).norm(dim=-1) + 0.5 * (cuda_ba.transform(poses, patches, intr, ii, jj, kk, tonly=True, layout="pp2") - c0).norm(dim=-1)
+            assert torch.allclose(f, want, rtol=1e-6, atol=1e-6)

@@ -190,7 +190,7 @@ def test_one_written_slot_converts_one_frame(dtype):
     assert torch.equal(got, whole_ring_reference())
 
 
-@pytest.mark.parametrize("graph", ["sliding", "full", "small"])
+@pytest.mark.parametrize("graph", ["sliding", "full", "small", "big_random"])
 def test_graph_tables_in_one_call_equal_the_separate_calls(graph):
     """devo_upd_graph_tables (round 6: the Update operator's neighbours + patch groups + frame-pair groups of a NEW edge list from one library call —
     per-frame work in DEVO's steady state) against the separate entry points it replaces: cuda_ba.neighbors (ba.cpp:104-149), cuda_ba.prepare on kk,
@@ -203,6 +203,11 @@ def test_graph_tables_in_one_call_equal_the_separate_calls(graph):
         ii, jj, kk = [t.to(dev) for t in synth.sliding_window_graph(40, 96)]
     elif graph == "full":
         ii, jj, kk = [t.to(dev) for t in synth.full_graph(15, 96)]
+    elif graph == "big_random":                                        # beyond the single-workgroup preparation: both lists through Prep2, ragged groups
+        g = torch.Generator().manual_seed(5)
+        kk = torch.randint(0, 3000, (50001,), generator=g).to(dev)
+        ii = kk // 100
+        jj = torch.randint(0, 40, (50001,), generator=g).to(dev)
     else:
         g = torch.Generator().manual_seed(3)
         kk = torch.randint(0, 300, (2500,), generator=g).to(dev)

@@ -12,5 +12,5 @@ for rows in (640, 18000):
     dy = torch.randn(rows, 384, device=dev); x = torch.randn(rows, 384, device=dev)
     for _ in range(3): U._dw_split(dy, x, True)
     torch.cuda.synchronize()
-    t = U._dw_ws[dy.device][:40].cpu().long().tolist()
+    t = next(iter(U._dw_ws.values()))[:40].cpu().long().tolist()          # (one workspace per (device, stream): this script uses one)
     print(f"rows {rows}: prologue {t[1]}; steps:", " ".join("[" + " ".join(str(t[2 + 6 * i + j] - t[1 + 6 * i + j]) for j in range(6)) + "]" for i in range(5)))

@@ -917,14 +917,14 @@ def update_op_mode(args, device, rank, world, dtype_name=None, secondary=False):
 
 def ba_kernel_report(run_ba):
     """north_star / SURVEY 8d: what the fastba report carries besides the time — launches per BA call, and per kernel its average duration in
-    this run (torch.profiler over three calls), LDS bytes per workgroup and resident waves per SIMD (compiler figures,
+    this run (torch.profiler over twelve calls behind five warm-up calls, medians), LDS bytes per workgroup and resident waves per SIMD (compiler figures,
     profiles/ba_kernel_resources.json, written by tools/kernel_resources.py --json)."""
     rep = {}
     try:
         from torch.profiler import profile, ProfilerActivity
-        run_ba()
-        torch.cuda.synchronize()
-        calls = 3
+        for _ in range(5):                                       # (the calls behind a synchronisation run on a chip that has clocked down: 31 us where
+            run_ba()                                             #  rocprofv3's trace of 300 calls says 19 — warm up, take medians)
+        calls = 12
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             for _ in range(calls):
                 run_ba()
@@ -934,14 +934,13 @@ def ba_kernel_report(run_ba):
             if getattr(ev, "device_type", None) is not None and "cuda" in str(ev.device_type).lower() and ("devo::" in ev.name or "k_ba" in ev.name):
                 k = ev.name.split("(")[0].replace("void ", "").replace("devo::", "")
                 k = k.split("<")[0]
-                a = ker.setdefault(k, [0, 0.0])
-                a[0] += 1
-                a[1] += float(getattr(ev, "device_time", 0.0) or getattr(ev, "cuda_time", 0.0))
+                ker.setdefault(k, []).append(float(getattr(ev, "device_time", 0.0) or getattr(ev, "cuda_time", 0.0)))
         if ker:
-            rep["launches"] = int(round(sum(v[0] for v in ker.values()) / calls))
-            rep["kernels"] = {k: {"per_call": round(v[0] / calls, 2), "avg_us": round(v[1] / max(v[0], 1), 2)} for k, v in sorted(ker.items(), key=lambda kv: -kv[1][1])}
-            rep["solve_us"] = round(sum(v[1] for k, v in ker.items() if "solve" in k) / calls, 2)
-            rep["accumulate_us"] = round(sum(v[1] for k, v in ker.items() if "accumulate" in k or "reduce" in k) / calls, 2)
+            med = {k: sorted(v)[len(v) // 2] for k, v in ker.items()}
+            rep["launches"] = int(round(sum(len(v) for v in ker.values()) / calls))
+            rep["kernels"] = {k: {"per_call": round(len(v) / calls, 2), "avg_us": round(med[k], 2)} for k, v in sorted(ker.items(), key=lambda kv: -sum(kv[1]))}
+            rep["solve_us"] = round(sum(med[k] * len(v) for k, v in ker.items() if "solve" in k) / calls, 2)
+            rep["accumulate_us"] = round(sum(med[k] * len(v) for k, v in ker.items() if "accumulate" in k or "reduce" in k) / calls, 2)
     except Exception as ex:                                      # noqa: BLE001 — the report is an extra
         rep["profiler_error"] = f"{type(ex).__name__}: {ex}"[:200]
     try:

@@ -76,18 +76,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     gvoff[q] = i0 + (lane & 31) * 4 < No ? (unsigned)(((int64_t)row * ldg + i0) * 4 + (lane & 31) * 16) : OFF_NONE;
     xvoff[q] = j0 + (lane & 31) * 4 < Ni ? (unsigned)(((int64_t)row * ldx + j0) * 4 + (lane & 31) * 16) : OFF_NONE;
   }
+  // ONE descriptor per operand for the whole matrix (round 6: building two per step was 780 of a step's 4 800 cycles, profiles/r06_dw_split.txt):
+  // rows past the end of the matrix are out of range (zeros, no access); operands stay below 2 GB (checked by the host)
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, (unsigned)(((int64_t)(R - 1) * ldg + No) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (unsigned)(((int64_t)(R - 1) * ldx + Ni) * 4), 0x00020000);
+  const unsigned gstep = (unsigned)((int64_t)DW_ROWS * ldg * 4), xstep = (unsigned)((int64_t)DW_ROWS * ldx * 4);
   auto request = [&](int s, int buf) {                                 // rows 32 s .. of both operands -> stage buf
-    const int r0 = s * DW_ROWS;
-    const bool any = s < s_end && r0 < R;
-    // the descriptor starts at the step's first row: rows past the end of the matrix are out of range (zeros, no access)
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G + (int64_t)(any ? r0 : 0) * ldg), 0,
-                                                                         any ? (unsigned)(((int64_t)(R - r0 - 1) * ldg + No) * 4) : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (int64_t)(any ? r0 : 0) * ldx), 0,
-                                                                         any ? (unsigned)(((int64_t)(R - r0 - 1) * ldx + Ni) * 4) : 0u, 0x00020000);
+    const bool any = s < s_end && s * DW_ROWS < R;
+    const unsigned go = (unsigned)s * gstep, xo = (unsigned)s * xstep;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      dw_dma16(any ? gvoff[q] : OFF_NONE, rg, lds0 + (unsigned)(buf * DW_STAGE + (wv + 4 * q) * DW_INSTR));
-      dw_dma16(any ? xvoff[q] : OFF_NONE, rx, lds0 + (unsigned)(buf * DW_STAGE + DW_TILE + (wv + 4 * q) * DW_INSTR));
+      dw_dma16(any && gvoff[q] != OFF_NONE ? gvoff[q] + go : OFF_NONE, rg, lds0 + (unsigned)(buf * DW_STAGE + (wv + 4 * q) * DW_INSTR));
+      dw_dma16(any && xvoff[q] != OFF_NONE ? xvoff[q] + xo : OFF_NONE, rx, lds0 + (unsigned)(buf * DW_STAGE + DW_TILE + (wv + 4 * q) * DW_INSTR));
     }
   };
   // operand reads: lane (column li of tile t, row group kg) -> rows 8 kg + q, q = 0 .. 7: four ds_read2_b32 (rows 2 u, 2 u + 1)

@@ -33,6 +33,8 @@ if os.path.isdir(_DB):
     os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(_DB, "cache"))
 
 DIM_INET, DIM_FNET, DIM_ENC = 384, 128, 32
+_LOWP_CL = os.environ.get("DEVO_PATCHIFIER_LOWP_CL", "0") == "1"   # (experiment: the copy's weights in channels-last format)
+_LOWP = os.environ.get("DEVO_PATCHIFIER_LOWP", "1") != "0"        # 0: an autocast call converts the parameters itself, every call
 
 
 def _norm(kind, x):
@@ -270,6 +272,42 @@ class Patchifier(nn.Module):
         if self.patch_selector == "scorer":
             self.scorer = Scorer(bins)
 
+    # ---- inference under autocast: the encoders on a low-precision copy of their parameters (round 6).  `devo.py:250` calls patchify under
+    # `torch.autocast` with fp32 parameters once per frame: autocast then converts every convolution's weight and bias again for every call (its
+    # cast cache lives as long as the autocast context: one frame) — 70 launches and 0.24 ms of GPU time of a call that is paced by its ~300
+    # launches (2.35 ms per frame of 480 x 640).  The copy (fp16 / bf16, channels-last weights) is kept per version of the parameters; the
+    # arithmetic is autocast's own (convolutions, instance norms, ReLUs and sums in the low precision), the outputs are the same tensors.
+    def _lowp_modules(self, dtype):
+        key = (dtype, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        sh = self.__dict__.get("_lowp")
+        if sh is None or sh[0] != key:
+            import copy
+            mods = {}
+            for name in ("fnet", "inet", "scorer"):
+                m = getattr(self, name, None)
+                if m is None:
+                    continue
+                c = copy.deepcopy(m).to(dtype).eval()
+                if _LOWP_CL:
+                    for mod in c.modules():
+                        if isinstance(mod, nn.Conv2d):
+                            mod.weight.data = mod.weight.data.contiguous(memory_format=torch.channels_last)
+                for q in c.parameters():
+                    q.requires_grad_(False)
+                mods[name] = c
+            sh = (key, mods)
+            self.__dict__["_lowp"] = sh
+        return sh[1]
+
+    def __getstate__(self):
+        d = self.__dict__.copy()                                               # (copy.deepcopy / torch.save: the per-version copy stays behind)
+        d.pop("_lowp", None)
+        return d
+
+    def _apply(self, fn, recurse=True):
+        self.__dict__.pop("_lowp", None)                                       # .to() / .half() / .cuda(): the parameters' storage moves
+        return super()._apply(fn, recurse)
+
     @staticmethod
     def event_gradient(images):
         """enet.py:112-118: gradient magnitude of the event count image at stride 4."""
@@ -282,8 +320,17 @@ class Patchifier(nn.Module):
                 scorer_eval_use_grid=True, candidates=None, coords=None):
         """`candidates` = (x, y) int64 [n, 3 M]: the uniform draws of the training branch, `coords` = (x, y) [n, M]: the final
         patch centres — both optional, for reproducible tests (the reference draws them on the device)."""
-        fmap = self.fnet(images) / 4.0
-        imap = self.inet(images) / 4.0
+        lowp = None
+        if (_LOWP and not torch.is_grad_enabled() and images.is_cuda and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") in (torch.float16, torch.bfloat16) and self.fnet.conv1.weight.dtype == torch.float32):
+            lowp = self._lowp_modules(torch.get_autocast_dtype("cuda"))
+            x_lp = images.to(torch.get_autocast_dtype("cuda"))
+            with torch.autocast("cuda", enabled=False):
+                fmap = lowp["fnet"](x_lp) / 4.0
+                imap = lowp["inet"](x_lp) / 4.0
+        else:
+            fmap = self.fnet(images) / 4.0
+            imap = self.inet(images) / 4.0
         b, n, _, h, w = fmap.shape
         P, M, dev = self.patch_size, patches_per_image, fmap.device
         scores = None
@@ -298,7 +345,11 @@ class Patchifier(nn.Module):
             x = torch.randint(1, w - 1, (n, M), device=dev)
             y = torch.randint(1, h - 1, (n, M), device=dev)
         else:
-            smap = torch.sigmoid(self.scorer(images).float())                   # [1, n, h - 2, w - 2]
+            if lowp is not None:
+                with torch.autocast("cuda", enabled=False):
+                    smap = torch.sigmoid(lowp["scorer"](x_lp).float())
+            else:
+                smap = torch.sigmoid(self.scorer(images).float())               # [1, n, h - 2, w - 2]
             if self.training:
                 x, y, scores = select_three_x_random(smap, M, candidates)
             else:

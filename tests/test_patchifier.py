@@ -169,3 +169,47 @@ def test_patchifier_gradients_match_the_reference_module(golden_dir, dt, tol):
     for k in z.files:
         if k.startswith("grad/"):
             assert rel_err(grads[k[5:]].double().cpu(), torch.from_numpy(z[k])) <= tol, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_autocast_inference_on_the_cached_low_precision_parameters(dt):
+    """devo.py:250 calls patchify under autocast with fp32 parameters, once per frame.  Round 6: that call runs the encoders on a low-precision copy of
+    the parameters kept per parameter version instead of letting autocast convert every weight again for every frame — the same arithmetic: every
+    output equals autocast's own (DEVO_PATCHIFIER_LOWP=0) to the last bits of the low precision, the copy follows the parameters, the module still
+    copies / pickles, and gradients (training) never take this path."""
+    import copy
+    dev = "cuda"
+    torch.manual_seed(3)
+    pf = PF.Patchifier().to(dev).eval()
+    images = torch.randn(1, 2, 5, 96, 128, device=dev)
+    def run(m):
+        with torch.no_grad(), torch.autocast("cuda", dtype=dt):
+            return m(images, patches_per_image=12, scorer_eval_mode="topk")
+    got = run(pf)
+    assert "_lowp" in pf.__dict__
+    PF._LOWP = False
+    try:
+        ref = run(pf)
+    finally:
+        PF._LOWP = True
+    assert got[0].dtype == ref[0].dtype == dt
+    tol = 2e-2 if dt == torch.bfloat16 else 4e-3
+    assert torch.equal(got[4], ref[4])
+    assert rel_err(got[0].float(), ref[0].float()) <= tol and rel_err(got[2].float(), ref[2].float()) <= tol
+    same_patches = torch.equal(got[3], ref[3])                                   # (a score tie decided the other way moves a patch: compare its features only then)
+    if same_patches:
+        assert rel_err(got[1].float(), ref[1].float()) <= tol
+    with torch.no_grad():
+        pf.fnet.conv2.weight.mul_(0.5)                                           # an optimiser-style step: the copy follows
+    got2 = run(pf)
+    assert rel_err(got2[0].float(), 0.5 * (got[0].float() - pf.fnet.conv2.bias.to(dt).float()[None, None, :, None, None] / 4) +
+                   pf.fnet.conv2.bias.to(dt).float()[None, None, :, None, None] / 4) <= 4 * tol
+    c = copy.deepcopy(pf)
+    assert "_lowp" not in c.__dict__ and rel_err(run(c)[0].float(), got2[0].float()) <= tol
+    pf.train()
+    x = images.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=dt):
+        out = pf(x, patches_per_image=12)
+    out[0].float().sum().backward()
+    assert x.grad is not None and float(x.grad.abs().sum()) > 0

@@ -70,6 +70,8 @@ _SIGNATURES = {
 }
 _f = ctypes.c_float
 _SIGNATURES.update({
+    "devo_instnorm_workspace_bytes": [_i, _i],
+    "devo_instnorm_cl": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _sz, _i, _vp],
     "devo_upd_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp],
     "devo_upd_layernorm_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp, _vp],
     "devo_upd_masked_gather": [_vp, _vp, _vp, _i64, _i, _i, _vp],
@@ -120,7 +122,7 @@ for _n in ("mul", "adj", "adjT", "act", "act4"):
     _SIGNATURES[f"devo_se3_{_n}_backward"] = [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]
 _SIGNATURES["devo_se3_as_matrix"] = [_vp, _vp, _i64, _i, _vp]
 _SIGNATURES["devo_se3_jinv"] = [_vp, _vp, _vp, _i64, _i, _vp]
-_RESTYPE = {"devo_last_error": ctypes.c_char_p, "devo_voxel_std_workspace_bytes": _sz, "devo_ba_workspace_bytes": _sz, "devo_neighbors_workspace_bytes": _sz,
+_RESTYPE = {"devo_last_error": ctypes.c_char_p, "devo_instnorm_workspace_bytes": _sz, "devo_voxel_std_workspace_bytes": _sz, "devo_ba_workspace_bytes": _sz, "devo_neighbors_workspace_bytes": _sz,
              "devo_corr_backward_workspace_bytes": _sz, "devo_corr_patch_operand_bytes": _sz, "devo_upd_split_weight_bytes": _sz, "devo_upd_dw_workspace_bytes": _sz, "devo_upd_pack_weight_f16_bytes": _sz, "devo_upd_mlp2_weight_bytes": _sz, "devo_upd_rs_weight_bytes": _sz, "devo_upd_rs_split_weight_bytes": _sz}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -834,6 +834,89 @@ __global__ __launch_bounds__(256) void k_softagg_w(const T* __restrict__ f, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- instance norm, channels-last
+// The encoders' InstanceNorm2d (no affine, no running statistics: extractor.py:27-38; devo_amd/patchifier.py) on a channels-last activation
+// [N, H, W, C]: y = relu((x - mean_nc) * rstd_nc) and, for the tail of a residual block (extractor.py:48-54), relu(res + y).  Through ATen one
+// norm of an NHWC tensor is a copy to NCHW, a statistics kernel, a transform kernel, (a copy back) and the ReLU — 10 norms per frame, 0.6 of the
+// encoders' 1.25 ms at 480 x 640 (tools/probe_patchifier_frame.py).  Here: a partial-sums launch (shifted by the image's first pixel: no
+// cancellation for activations with a large mean) and an apply launch that adds the partials up in a fixed order (deterministic).
+constexpr int IN_PART = 64;                                            // pixel chunks per image
+template <typename T>
+__global__ __launch_bounds__(256) void k_instnorm_stats(const T* __restrict__ x, int HW, int C, float* __restrict__ part) {
+  constexpr int V = ChunkOf<T>::V;
+  const int cpr = C / V, n = blockIdx.y, p = blockIdx.x;
+  const int cv = threadIdx.x % cpr, pl = threadIdx.x / cpr, npl = 256 / cpr;           // (threads beyond npl * cpr idle)
+  const int per = (HW + IN_PART - 1) / IN_PART, i0 = p * per, i1 = min(HW, i0 + per);
+  const T* xn = x + (int64_t)n * HW * C;
+  float k[V], s1[V], s2[V];
+  ldc(xn + cv * V, k);                                                                   // the shift: this image's first pixel
+#pragma unroll
+  for (int u = 0; u < V; u++) { s1[u] = 0.f; s2[u] = 0.f; }
+  if (pl < npl)
+    for (int i = i0 + pl; i < i1; i += npl) {
+      float v[V];
+      ldc(xn + (int64_t)i * C + cv * V, v);
+#pragma unroll
+      for (int u = 0; u < V; u++) { const float d = v[u] - k[u]; s1[u] += d; s2[u] += d * d; }
+    }
+  extern __shared__ float in_lds[];                                                      // [npl][2][C]
+  if (pl < npl) {
+#pragma unroll
+    for (int u = 0; u < V; u++) { in_lds[(pl * 2) * C + cv * V + u] = s1[u]; in_lds[(pl * 2 + 1) * C + cv * V + u] = s2[u]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {                                       // fixed order over the pixel lanes
+    float a = 0.f;
+    const int which = c / C, ch = c - which * C;
+    for (int q = 0; q < npl; q++) a += in_lds[(q * 2 + which) * C + ch];
+    part[(((int64_t)n * IN_PART + p) * 2 + which) * C + ch] = a;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_instnorm_apply(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int HW, int C,
+                                                        const float* __restrict__ part, float eps, int relu) {
+  constexpr int V = ChunkOf<T>::V;
+  extern __shared__ float in_lds[];                                                      // mean [C] | rstd [C]
+  const int n = blockIdx.y;
+  const T* xn = x + (int64_t)n * HW * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int p = 0; p < IN_PART; p++) { a += part[(((int64_t)n * IN_PART + p) * 2) * C + c]; b += part[(((int64_t)n * IN_PART + p) * 2 + 1) * C + c]; }
+    float k1[1];
+    k1[0] = 0.f;
+    {                                                                                    // the shift again (one element)
+      const T* q = xn + c;
+      k1[0] = (float)(*q);
+    }
+    const float m = a / (float)HW, var = fmaxf(b / (float)HW - m * m, 0.f);
+    in_lds[c] = k1[0] + m;
+    in_lds[C + c] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  const int cpr = C / V;
+  const int64_t total = (int64_t)HW * cpr;
+  const T* rn = res ? res + (int64_t)n * HW * C : nullptr;
+  T* yn = y + (int64_t)n * HW * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cpr);
+    float v[V], o[V];
+    ldc(xn + i * V, v);
+#pragma unroll
+    for (int u = 0; u < V; u++) {
+      float t = (v[u] - in_lds[cv * V + u]) * in_lds[C + cv * V + u];
+      t = round_as<T>(t);                                                                // (the norm's output as ATen stores it, then the ReLU on that)
+      o[u] = relu ? fmaxf(t, 0.f) : t;
+    }
+    if (rn) {
+      float r[V];
+      ldc(rn + i * V, r);
+#pragma unroll
+      for (int u = 0; u < V; u++) o[u] = fmaxf(round_as<T>(r[u] + o[u]), 0.f);           // relu(res + y): the residual block's tail
+    }
+    stc(yn + i * V, o);
+  }
+}
+
 static unsigned grid_for(long long n, int per_block, int cap) {
   long long b = (n + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -931,6 +1014,30 @@ int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64
     hipLaunchKernelGGL(k_masked_gather<float>, grid, block, 0, st_, (const float*)src, idx, (float*)out, E, dim),
     hipLaunchKernelGGL(k_masked_gather<__half>, grid, block, 0, st_, (const __half*)src, idx, (__half*)out, E, dim));
   return check_launch("devo_upd_masked_gather");
+}
+
+size_t devo_instnorm_workspace_bytes(int N, int C) { return N > 0 && C > 0 ? (size_t)N * IN_PART * 2 * C * sizeof(float) : 0; }
+
+int devo_instnorm_cl(const void* x, const void* res, void* y, int N, int HW, int C, float eps, int relu, void* workspace, size_t ws_bytes, int dtype,
+                     devo_stream_t stream) {
+  DEVO_REQUIRE(x && y && workspace && N > 0 && HW > 0 && C > 0, "devo_instnorm_cl: null argument or bad sizes");
+  DEVO_REQUIRE(dtype == DEVO_F32 || dtype == DEVO_F16, "devo_instnorm_cl: fp32 / fp16 only (dtype %d)", dtype);
+  const int V = dtype == DEVO_F32 ? 4 : 8;
+  DEVO_REQUIRE(C % V == 0 && C / V <= 256 && 256 / (C / V) >= 1, "devo_instnorm_cl: C = %d must be a multiple of %d, at most %d", C, V, 256 * V);
+  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0, "devo_instnorm_cl: 16-byte alignment");
+  DEVO_REQUIRE(ws_bytes >= devo_instnorm_workspace_bytes(N, C), "devo_instnorm_cl: workspace %zu < %zu bytes", ws_bytes, devo_instnorm_workspace_bytes(N, C));
+  DEVO_REQUIRE(!res || relu, "devo_instnorm_cl: the residual tail is relu(res + relu(norm))");
+  hipStream_t st_ = (hipStream_t)stream;
+  const int npl = 256 / (C / V);
+  const size_t lds1 = sizeof(float) * (size_t)npl * 2 * C, lds2 = sizeof(float) * 2 * (size_t)C;
+  const dim3 g1(IN_PART, (unsigned)N), g2(grid_for((long long)HW * (C / V), 256 * 4, 1024), (unsigned)N);
+  UPD_DISPATCH(dtype,
+    hipLaunchKernelGGL(k_instnorm_stats<float>, g1, dim3(256), lds1, st_, (const float*)x, HW, C, (float*)workspace),
+    hipLaunchKernelGGL(k_instnorm_stats<__half>, g1, dim3(256), lds1, st_, (const __half*)x, HW, C, (float*)workspace));
+  UPD_DISPATCH(dtype,
+    hipLaunchKernelGGL(k_instnorm_apply<float>, g2, dim3(256), lds2, st_, (const float*)x, (const float*)res, (float*)y, HW, C, (const float*)workspace, eps, relu),
+    hipLaunchKernelGGL(k_instnorm_apply<__half>, g2, dim3(256), lds2, st_, (const __half*)x, (const __half*)res, (__half*)y, HW, C, (const float*)workspace, eps, relu));
+  return check_launch("devo_instnorm_cl");
 }
 
 int devo_upd_softagg(const void* f, const void* g, int64_t ld_fg, const int* perm, const int* seg_start, const int* n_seg,

@@ -33,6 +33,8 @@ if os.path.isdir(_DB):
     os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(_DB, "cache"))
 
 DIM_INET, DIM_FNET, DIM_ENC = 384, 128, 32
+_GRAPH = os.environ.get("DEVO_PATCHIFIER_GRAPH", "1") != "0"      # 0: the encoders' launches one by one, every call
+_GRAPH_MAX_FRAMES = 2                                              # (beyond a frame or two the call is paced by the GPU: nothing to gain)
 _LOWP_CL = os.environ.get("DEVO_PATCHIFIER_LOWP_CL", "0") == "1"   # (experiment: the copy's weights in channels-last format)
 _LOWP = os.environ.get("DEVO_PATCHIFIER_LOWP", "1") != "0"        # 0: an autocast call converts the parameters itself, every call
 
@@ -43,6 +45,30 @@ def _norm(kind, x):
     if kind == "none":
         return x
     raise NotImplementedError(f"norm_fn = {kind!r} (DEVO uses 'instance' for fnet and 'none' for inet)")
+
+
+_FUSED_IN = os.environ.get("DEVO_PATCHIFIER_FUSED_NORM", "1") != "0"   # 0: F.instance_norm + F.relu (+ the sum) as separate ATen kernels, always
+
+
+def _in_relu(x, relu=True, residual=None):
+    """relu(instance_norm(x)) — or, with `residual`, relu(residual + relu(instance_norm(x))): the tail of a residual block — in two launches on a
+    channels-last activation when no gradient is needed (devo_instnorm_cl; through ATen one norm of an NHWC tensor is a copy to NCHW, a statistics
+    kernel, a transform kernel and the ReLU: 10 norms per frame were half of the encoders' GPU time).  Anything else: the ATen composition."""
+    if (_FUSED_IN and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.float32)
+            and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % (8 if x.dtype == torch.float16 else 4) == 0
+            and x.data_ptr() % 16 == 0 and (residual is None or (relu and residual.shape == x.shape and residual.dtype == x.dtype and residual.data_ptr() % 16 == 0
+                                                                 and residual.is_contiguous(memory_format=torch.channels_last)))):
+        from . import _lib as L
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)                                                   # (keeps the channels-last strides)
+        ws = torch.empty(int(L.lib().devo_instnorm_workspace_bytes(N, C)), dtype=torch.uint8, device=x.device)
+        L.check(L.lib().devo_instnorm_cl(L.ptr(x), L.ptr(residual), L.ptr(y), N, H * W, C, 1e-5, int(bool(relu)), L.ptr(ws), ws.numel(), L.dtype_code(x),
+                                         L.stream()), "patchifier.instance_norm")
+        return y
+    y = F.instance_norm(x)
+    if relu:
+        y = F.relu(y)
+    return F.relu(residual + y) if residual is not None else y
 
 
 class _Residual(nn.Module):
@@ -57,6 +83,11 @@ class _Residual(nn.Module):
         self.downsample = None if stride == 1 else nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride))
 
     def forward(self, x):
+        if self.norm_fn == "instance" and not torch.is_grad_enabled():           # inference: norm + ReLU (+ the block's sum and ReLU) fused
+            y = _in_relu(self.conv1(x))
+            if self.downsample is not None:
+                x = _in_relu(self.downsample(x), relu=False)
+            return _in_relu(self.conv2(y), residual=x)
         y = F.relu(_norm(self.norm_fn, self.conv1(x)))
         y = F.relu(_norm(self.norm_fn, self.conv2(y)))
         if self.downsample is not None:
@@ -88,7 +119,10 @@ class Encoder(nn.Module):
     def forward(self, x):
         b, n = x.shape[:2]
         x = x.reshape(b * n, *x.shape[2:]).contiguous(memory_format=torch.channels_last)
-        x = F.relu(_norm(self.norm_fn, self.conv1(x)))
+        if self.norm_fn == "instance" and not torch.is_grad_enabled():
+            x = _in_relu(self.conv1(x))
+        else:
+            x = F.relu(_norm(self.norm_fn, self.conv1(x)))
         x = self.conv2(self.layer2(self.layer1(x)))
         return x.reshape(b, n, *x.shape[1:])
 
@@ -299,13 +333,53 @@ class Patchifier(nn.Module):
             self.__dict__["_lowp"] = sh
         return sh[1]
 
+    # One frame at a time (devo.py:250) the three CNNs are ~110 launches of a few microseconds each and the call is paced by the host (2.0 ms per
+    # frame for 1.5 ms of GPU work).  From the third call with the same input shape on, the encoders + scorer replay from ONE HIP graph (static
+    # input: the low-precision copy of the images; the outputs are handed out as copies: nothing the caller holds is overwritten by the next frame).
+    # Never while the caller captures a graph of its own; DEVO_PATCHIFIER_GRAPH=0 switches it off.
+    def _encode_lowp(self, images, lowp, dtype, with_scorer):
+        def run(x):
+            fm = lowp["fnet"](x) / 4.0
+            im = lowp["inet"](x) / 4.0
+            sm = torch.sigmoid(lowp["scorer"](x).float()) if with_scorer else None
+            return fm, im, sm
+        frames = images.shape[0] * images.shape[1]
+        with torch.autocast("cuda", enabled=False):
+            if _GRAPH and frames <= _GRAPH_MAX_FRAMES and not torch.cuda.is_current_stream_capturing():
+                key = (tuple(images.shape), images.dtype, dtype, bool(with_scorer), str(images.device))
+                st = self.__dict__.get("_enc_graph")
+                if st is None or st["key"] != key or st["lowp"] is not lowp:     # (the graph holds the parameter copy it was captured on alive)
+                    st = {"key": key, "lowp": lowp, "calls": 0, "graph": None}
+                    self.__dict__["_enc_graph"] = st
+                st["calls"] += 1
+                if st["graph"] is None and st["calls"] >= 3:                    # (two eager calls first: MIOpen has picked its kernels by then)
+                    cur = torch.cuda.current_stream()
+                    x_static = torch.empty(images.shape, dtype=dtype, device=images.device)
+                    side = torch.cuda.Stream(device=images.device)
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        x_static.copy_(images)
+                        run(x_static)
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=side):
+                            outs = run(x_static)
+                    cur.wait_stream(side)
+                    st.update(graph=g, x=x_static, outs=outs)
+                if st["graph"] is not None:
+                    st["x"].copy_(images)
+                    st["graph"].replay()
+                    return tuple(o.clone() if o is not None else None for o in st["outs"])
+            return run(images.to(dtype))
+
     def __getstate__(self):
         d = self.__dict__.copy()                                               # (copy.deepcopy / torch.save: the per-version copy stays behind)
         d.pop("_lowp", None)
+        d.pop("_enc_graph", None)
         return d
 
     def _apply(self, fn, recurse=True):
         self.__dict__.pop("_lowp", None)                                       # .to() / .half() / .cuda(): the parameters' storage moves
+        self.__dict__.pop("_enc_graph", None)
         return super()._apply(fn, recurse)
 
     @staticmethod
@@ -321,13 +395,12 @@ class Patchifier(nn.Module):
         """`candidates` = (x, y) int64 [n, 3 M]: the uniform draws of the training branch, `coords` = (x, y) [n, M]: the final
         patch centres — both optional, for reproducible tests (the reference draws them on the device)."""
         lowp = None
+        smap_lp = None
         if (_LOWP and not torch.is_grad_enabled() and images.is_cuda and torch.is_autocast_enabled()
                 and torch.get_autocast_dtype("cuda") in (torch.float16, torch.bfloat16) and self.fnet.conv1.weight.dtype == torch.float32):
             lowp = self._lowp_modules(torch.get_autocast_dtype("cuda"))
-            x_lp = images.to(torch.get_autocast_dtype("cuda"))
-            with torch.autocast("cuda", enabled=False):
-                fmap = lowp["fnet"](x_lp) / 4.0
-                imap = lowp["inet"](x_lp) / 4.0
+            fmap, imap, smap_lp = self._encode_lowp(images, lowp, torch.get_autocast_dtype("cuda"),
+                                                   coords is None and self.patch_selector == "scorer")
         else:
             fmap = self.fnet(images) / 4.0
             imap = self.inet(images) / 4.0
@@ -345,9 +418,8 @@ class Patchifier(nn.Module):
             x = torch.randint(1, w - 1, (n, M), device=dev)
             y = torch.randint(1, h - 1, (n, M), device=dev)
         else:
-            if lowp is not None:
-                with torch.autocast("cuda", enabled=False):
-                    smap = torch.sigmoid(lowp["scorer"](x_lp).float())
+            if smap_lp is not None:
+                smap = smap_lp
             else:
                 smap = torch.sigmoid(self.scorer(images).float())               # [1, n, h - 2, w - 2]
             if self.training:

@@ -29,7 +29,7 @@ enum { DEVO_F32 = 0, DEVO_F16 = 1, DEVO_F64 = 2 };
 
 #define DEVO_ABI_VERSION 5 /* 2: fp32 split formats (devo_corr_pyramid_split, exponents), group plans (plan buffer tail); 3: per-slot conversions of a ring
                               (devo_corr_pyramid_split_frames, devo_corr_patch_transpose_range), devo_stream_capturing; 4: devo_ba_table_offsets, devo_upd_graph_tables; 5: devo_ba_forward_prepared_delta_plan, devo_ba_import_tables, devo_upd_rs_corr_f16_net32,
-                              devo_upd_rs_gru_f16_out32;
+                              devo_upd_rs_gru_f16_out32, devo_instnorm_cl;
                               callers compare with devo_abi_version() */
 int devo_abi_version(void);
 const char* devo_last_error(void); /* thread-local message of the last failing call */
@@ -388,6 +388,13 @@ int devo_se3_jinv(const void* X, const void* a, void* b, int64_t n, int dtype, d
  * (enet.py:47,53-55,65) with the sums in front of it fused in: the residual sums of enet.py:82-83 (add1, add2), the
  * SoftAgg expand of blocks.py:46 (hy + group_of) and the GatedResidual of blocks.py:28-29 (gate with row stride
  * ld_gate, res); every term may be NULL.  Optionally followed by ReLU (enet.py:65-66).  dim <= 1024. */
+/* InstanceNorm2d without affine parameters or running statistics (the encoders' norm: devo/extractor.py:27-38) on a CHANNELS-LAST activation
+ * x [N, H, W, C] (HW pixels per image), fp32 / fp16, 16-byte aligned, C a multiple of 4 / 8:  y = (x - mean_nc) * rstd_nc, biased variance,
+ * rounded to the storage type, then ReLU'd when `relu`; with `res` (same layout; needs relu) y = relu(res + relu(norm(x))) — the tail of a
+ * residual block (extractor.py:48-54).  Two launches (partial sums in a fixed order, apply): deterministic.  workspace: devo_instnorm_workspace_bytes. */
+size_t devo_instnorm_workspace_bytes(int N, int C);
+int devo_instnorm_cl(const void* x, const void* res, void* y, int N, int HW, int C, float eps, int relu, void* workspace, size_t ws_bytes, int dtype,
+                     devo_stream_t stream);
 int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const void* hy, const int* group_of,
                        const void* gate, int64_t ld_gate, const void* res, const void* gamma, const void* beta,
                        void* out, int64_t rows, int dim, float eps, int relu, int dtype, devo_stream_t stream);

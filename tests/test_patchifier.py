@@ -206,10 +206,59 @@ def test_autocast_inference_on_the_cached_low_precision_parameters(dt):
     assert rel_err(got2[0].float(), 0.5 * (got[0].float() - pf.fnet.conv2.bias.to(dt).float()[None, None, :, None, None] / 4) +
                    pf.fnet.conv2.bias.to(dt).float()[None, None, :, None, None] / 4) <= 4 * tol
     c = copy.deepcopy(pf)
-    assert "_lowp" not in c.__dict__ and rel_err(run(c)[0].float(), got2[0].float()) <= tol
+    assert "_lowp" not in c.__dict__ and "_enc_graph" not in c.__dict__ and rel_err(run(c)[0].float(), got2[0].float()) <= tol
+    # one frame at a time the encoders replay from a HIP graph from the third call on: the same tensors, and what an earlier call returned stays
+    one = images[:, :1].contiguous()
+    def run1(m, x):
+        with torch.no_grad(), torch.autocast("cuda", dtype=dt):
+            return m(x, patches_per_image=12, scorer_eval_mode="topk")
+    first = run1(pf, one)
+    run1(pf, one)
+    third = run1(pf, one)
+    assert pf.__dict__["_enc_graph"]["graph"] is not None
+    for a, b in zip(first[:4], third[:4]):
+        assert torch.equal(a, b)
+    keep = third[0].clone()
+    other = run1(pf, torch.randn_like(one))
+    assert torch.equal(third[0], keep) and not torch.equal(other[0], keep)
+    with torch.no_grad():
+        pf.inet.conv2.bias.add_(1.0)                                              # new parameter version: a new copy, a new graph later, right values now
+    moved = run1(pf, one)
+    assert rel_err(moved[2].float() - third[2].float(), torch.full_like(moved[2].float(), 0.25)) <= 4 * tol
     pf.train()
     x = images.clone().requires_grad_(True)
     with torch.autocast("cuda", dtype=dt):
         out = pf(x, patches_per_image=12)
     out[0].float().sum().backward()
     assert x.grad is not None and float(x.grad.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3)])
+def test_fused_instance_norm_of_a_channels_last_activation(dt, tol):
+    """devo_instnorm_cl (round 6): relu(instance_norm(x)), instance_norm(x) and the residual block's tail relu(res + relu(instance_norm(x))) on
+    channels-last activations, against float64 (extractor.py:27-54: InstanceNorm2d without affine parameters, biased variance, eps 1e-5) — images
+    with a large mean (the partial sums are shifted), odd sizes, both channel counts of the encoders; run to run the same bits; with gradients
+    enabled the ATen composition runs."""
+    dev = "cuda"
+    g = torch.Generator().manual_seed(5)
+    for N, C, H, W, mean in ((1, 32, 60, 80, 0.0), (3, 64, 31, 45, 0.0), (2, 32, 17, 23, 300.0), (1, 64, 120, 160, -40.0)):
+        x = (torch.randn(N, C, H, W, generator=g) * 2.0 + mean).to(dev).to(dt).contiguous(memory_format=torch.channels_last)
+        r = torch.randn(N, C, H, W, generator=g).to(dev).to(dt).contiguous(memory_format=torch.channels_last)
+        xd = x.double()
+        nd = (xd - xd.mean(dim=(2, 3), keepdim=True)) / torch.sqrt(xd.var(dim=(2, 3), unbiased=False, keepdim=True) + 1e-5)
+        with torch.no_grad():
+            a = PF._in_relu(x)
+            b = PF._in_relu(x, relu=False)
+            c = PF._in_relu(x, residual=r)
+            a2 = PF._in_relu(x)
+        assert a.is_contiguous(memory_format=torch.channels_last) and a.dtype == dt
+        scale = 1.0 if mean == 0.0 else (1.0 + abs(mean) * (1e-3 if dt == torch.float16 else 0.0))      # (fp16 inputs at 300 carry 0.25 of rounding themselves)
+        assert float((b.double() - nd).abs().max()) <= tol * 8 * scale, (N, C, H, W, mean)
+        assert float((a.double() - nd.clamp(min=0)).abs().max()) <= tol * 8 * scale
+        want_c = (r.double() + nd.clamp(min=0).to(dt).double()).clamp(min=0)
+        assert float((c.double() - want_c).abs().max()) <= tol * 16 * scale
+        assert torch.equal(a, a2)
+        x2 = x.clone().requires_grad_(True)
+        y = PF._in_relu(x2)                                                        # gradients: ATen's kernels
+        assert y.requires_grad and float((y.detach().double() - nd.clamp(min=0)).abs().max()) <= tol * 8 * scale

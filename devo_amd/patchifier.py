@@ -432,8 +432,12 @@ class Patchifier(nn.Module):
             smap = torch.sigmoid(self.scorer(images).float())
             scores = smap[0][torch.arange(n, device=dev)[:, None], (y - 1).clamp(0, h - 3), (x - 1).clamp(0, w - 3)]
         xy = torch.stack([x, y], dim=-1).float()                                  # [n, M, 2], feature-map pixels
-        imap_p = altcorr.patchify(imap[0].float(), xy, 0).view(b, -1, self.dim_inet, 1, 1)      # (the kernel takes the channels-last strides: no NCHW copy)
-        gmap = altcorr.patchify(fmap[0].float(), xy, P // 2).view(b, -1, self.dim_fnet, P, P)
+        # (the kernel takes the channels-last strides: no NCHW copy; without gradients the gathers read the maps in their own precision and only the
+        #  gathered patches are widened — the same values as widening 9.8 M map elements first)
+        lazy = not torch.is_grad_enabled() and fmap.dtype in (torch.float16, torch.float32) and imap.dtype == fmap.dtype
+        src_i, src_f = (imap[0], fmap[0]) if lazy else (imap[0].float(), fmap[0].float())
+        imap_p = altcorr.patchify(src_i, xy, 0).float().view(b, -1, self.dim_inet, 1, 1)
+        gmap = altcorr.patchify(src_f, xy, P // 2).float().view(b, -1, self.dim_fnet, P, P)
         # patches = patchify(coords_grid_with_index(disps), xy, P // 2) in closed form: pixel (x + j - r, y + i - r) and its depth
         r = P // 2
         off = torch.arange(-r, r + 1, device=dev, dtype=torch.float32)

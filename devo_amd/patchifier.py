@@ -148,8 +148,11 @@ def _quadrant_order(idx, h2, w2):
     """cell indices chosen inside each of the 2 x 2 quadrants (idx [bn, k, 4], quadrant-local, row-major over h2 x w2)
     -> x, y on the whole pooled map, [bn, 4 k] in the reference's (k-major, quadrant-minor) order (selector.py:72-93)."""
     x, y = idx % w2, torch.div(idx, w2, rounding_mode="floor")
-    qx = torch.tensor([0, 1, 0, 1], device=idx.device) * w2
-    qy = torch.tensor([0, 0, 1, 1], device=idx.device) * h2
+    # (made on the device: torch.tensor(list, device=cuda) is a blocking host -> device copy — it waited for everything enqueued before it, the
+    #  encoders of this frame included: 1.1 ms of host time per frame in 'multi' / 'topk' selection, and no stream capture through it)
+    q = torch.arange(4, device=idx.device)
+    qx = (q % 2) * w2
+    qy = torch.div(q, 2, rounding_mode="floor") * h2
     return (x + qx).flatten(1), (y + qy).flatten(1)
 
 
@@ -312,7 +315,11 @@ class Patchifier(nn.Module):
     # launches (2.35 ms per frame of 480 x 640).  The copy (fp16 / bf16, channels-last weights) is kept per version of the parameters; the
     # arithmetic is autocast's own (convolutions, instance norms, ReLUs and sums in the low precision), the outputs are the same tensors.
     def _lowp_modules(self, dtype):
-        key = (dtype, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        plist = self.__dict__.get("_plist")
+        if plist is None or len(plist[1]) != plist[0]:
+            ps = list(self.parameters())
+            plist = self.__dict__["_plist"] = (len(ps), ps)                      # (walking the module tree costs 0.2 ms per call)
+        key = (dtype, tuple((p.data_ptr(), p._version) for p in plist[1]))
         sh = self.__dict__.get("_lowp")
         if sh is None or sh[0] != key:
             import copy
@@ -375,11 +382,17 @@ class Patchifier(nn.Module):
         d = self.__dict__.copy()                                               # (copy.deepcopy / torch.save: the per-version copy stays behind)
         d.pop("_lowp", None)
         d.pop("_enc_graph", None)
+        d.pop("_plist", None)
         return d
+
+    def train(self, mode=True):
+        self.__dict__.pop("_plist", None)                                      # (mode switches are where checkpoints / replaced parameters come in)
+        return super().train(mode)
 
     def _apply(self, fn, recurse=True):
         self.__dict__.pop("_lowp", None)                                       # .to() / .half() / .cuda(): the parameters' storage moves
         self.__dict__.pop("_enc_graph", None)
+        self.__dict__.pop("_plist", None)
         return super()._apply(fn, recurse)
 
     @staticmethod

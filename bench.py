@@ -432,6 +432,42 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=40):
                             frame_full(True)
                         torch.cuda.synchronize(device)
                         best = min(best, time.perf_counter() - t0)
+                # ... and the WHOLE per-frame work of devo.py's __call__ on this path: the Patchifier on one 480 x 640 event frame (devo.py:250, under autocast),
+                # its outputs written into the rings as devo.py:520-527 does (two avg_pool2d calls among them), then the frame above (unchanged call sequence)
+                try:
+                    from devo_amd.patchifier import Patchifier
+                    torch.manual_seed(seed)
+                    pfm = Patchifier().to(device).eval()
+                    ev = torch.randn(1, 1, 5, 4 * H, 4 * W, device=device)
+
+                    def whole_frame():
+                        with torch.autocast("cuda", enabled=True, dtype=torch.float16):
+                            fm, gmp, imp, pts, _ = pfm(ev, M)
+                        k = st2["f"] % mem
+                        imap_[k] = imp.squeeze()
+                        gmap_[k] = gmp.squeeze()
+                        fmap1_[:, k] = torch.nn.functional.avg_pool2d(fm[0], 1, 1)
+                        fmap2_[:, k] = torch.nn.functional.avg_pool2d(fm[0], 4, 4)
+                        frame_full(False)
+                    with torch.no_grad():
+                        st2["net"] = torch.zeros(1, sE, 384, device=device, dtype=dt)
+                        for _ in range(10):
+                            whole_frame()
+                        torch.cuda.synchronize(device)
+                        best_w = float("inf")
+                        for _ in range(3):
+                            t0 = time.perf_counter()
+                            for _ in range(30):
+                                whole_frame()
+                            torch.cuda.synchronize(device)
+                            best_w = min(best_w, time.perf_counter() - t0)
+                    out["f16_steady_state_whole_frame_with_patchifier"] = {
+                        "frames_per_s": round(30 / best_w, 1), "ms_per_frame": round(1e3 * best_w / 30, 4), "edges": sE,
+                        "note": "the Patchifier on one 480 x 640 event frame under autocast (devo.py:250) + its outputs into the rings (devo.py:520-527) + the frame "
+                                "with the Update operator above: what devo.py's __call__ enqueues per frame on this path, keyframe bookkeeping aside"}
+                    del pfm
+                except Exception as ex:                              # noqa: BLE001 — an extra field
+                    out["f16_steady_state_whole_frame_error"] = f"{type(ex).__name__}: {ex}"[:300]
                 out["f16_steady_state_frame_fused_lookup"] = {"frames_per_s": round(30 / best, 1), "ms_per_frame": round(1e3 * best / 30, 4), "edges": sE,
                                                               "note": "the same frame with devo.py:215-217 (two altcorr.corr calls + torch.stack) replaced by altcorr.corr_pyramid "
                                                                       "(INTEGRATION.md section 2): both levels in one launch, written straight into the stacked layout"}

@@ -141,7 +141,7 @@ class SE3:
         return SE3(self.data[..., None, :]).act(I).transpose(-1, -2)
 
     def translation(self):
-        p = torch.as_tensor([0.0, 0.0, 0.0, 1.0], dtype=self.dtype, device=self.device)
+        p = torch.eye(4, dtype=self.dtype, device=self.device)[3]               # (made on the device: a list -> GPU tensor is a blocking copy)
         return _apply(Act4, self.data, p.view([1] * (self.data.dim() - 1) + [4]))
 
     def scale(self, s):

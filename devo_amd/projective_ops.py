@@ -99,7 +99,7 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     take = lambda t, idx: torch.index_select(t, 1, idx)
     Gij = SE3(take(poses.data, jj)) * SE3(take(poses.data, ii)).inv()
     if tonly:
-        Gij.data[..., 3:] = torch.as_tensor([0, 0, 0, 1], dtype=Gij.data.dtype, device=Gij.data.device)
+        Gij.data[..., 3:] = torch.eye(4, dtype=Gij.data.dtype, device=Gij.data.device)[3]      # (made on the device: no blocking host -> device copy)
     X1 = Gij[:, :, None, None] * iproj(take(patches, kk), take(intrinsics, ii))
     c = X1.shape[2] // 2
     intr_j = take(intrinsics, jj)

@@ -72,6 +72,8 @@ _f = ctypes.c_float
 _SIGNATURES.update({
     "devo_instnorm_workspace_bytes": [_i, _i],
     "devo_instnorm_cl": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _sz, _i, _vp],
+    "devo_instnorm_bias_cl": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _sz, _i, _vp],
+    "devo_bias_act_cl": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "devo_upd_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp],
     "devo_upd_layernorm_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp, _vp],
     "devo_upd_masked_gather": [_vp, _vp, _vp, _i64, _i, _i, _vp],

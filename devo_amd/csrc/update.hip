@@ -841,23 +841,28 @@ __global__ __launch_bounds__(256) void k_softagg_w(const T* __restrict__ f, cons
 // encoders' 1.25 ms at 480 x 640 (tools/probe_patchifier_frame.py).  Here: a partial-sums launch (shifted by the image's first pixel: no
 // cancellation for activations with a large mean) and an apply launch that adds the partials up in a fixed order (deterministic).
 constexpr int IN_PART = 64;                                            // pixel chunks per image
+// bias (optional, [C]): the convolution's bias, added here as ATen adds it behind a bias-free MIOpen call — v = round(x + b) — so that the
+// caller can leave the bias out of the convolution (one elementwise launch per convolution less)
 template <typename T>
-__global__ __launch_bounds__(256) void k_instnorm_stats(const T* __restrict__ x, int HW, int C, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_instnorm_stats(const T* __restrict__ x, const T* __restrict__ bias, int HW, int C, float* __restrict__ part) {
   constexpr int V = ChunkOf<T>::V;
   const int cpr = C / V, n = blockIdx.y, p = blockIdx.x;
   const int cv = threadIdx.x % cpr, pl = threadIdx.x / cpr, npl = 256 / cpr;           // (threads beyond npl * cpr idle)
   const int per = (HW + IN_PART - 1) / IN_PART, i0 = p * per, i1 = min(HW, i0 + per);
   const T* xn = x + (int64_t)n * HW * C;
-  float k[V], s1[V], s2[V];
+  float k[V], s1[V], s2[V], bv[V];
+#pragma unroll
+  for (int u = 0; u < V; u++) bv[u] = 0.f;
+  if (bias) ldc(bias + cv * V, bv);
   ldc(xn + cv * V, k);                                                                   // the shift: this image's first pixel
 #pragma unroll
-  for (int u = 0; u < V; u++) { s1[u] = 0.f; s2[u] = 0.f; }
+  for (int u = 0; u < V; u++) { k[u] = round_as<T>(k[u] + bv[u]); s1[u] = 0.f; s2[u] = 0.f; }
   if (pl < npl)
     for (int i = i0 + pl; i < i1; i += npl) {
       float v[V];
       ldc(xn + (int64_t)i * C + cv * V, v);
 #pragma unroll
-      for (int u = 0; u < V; u++) { const float d = v[u] - k[u]; s1[u] += d; s2[u] += d * d; }
+      for (int u = 0; u < V; u++) { const float d = round_as<T>(v[u] + bv[u]) - k[u]; s1[u] += d; s2[u] += d * d; }
     }
   extern __shared__ float in_lds[];                                                      // [npl][2][C]
   if (pl < npl) {
@@ -873,8 +878,8 @@ __global__ __launch_bounds__(256) void k_instnorm_stats(const T* __restrict__ x,
   }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void k_instnorm_apply(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int HW, int C,
-                                                        const float* __restrict__ part, float eps, int relu) {
+__global__ __launch_bounds__(256) void k_instnorm_apply(const T* __restrict__ x, const T* __restrict__ bias, const T* __restrict__ res, T* __restrict__ y,
+                                                        int HW, int C, const float* __restrict__ part, float eps, int relu) {
   constexpr int V = ChunkOf<T>::V;
   extern __shared__ float in_lds[];                                                      // mean [C] | rstd [C]
   const int n = blockIdx.y;
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(256) void k_instnorm_apply(const T* __restrict__ x,
     k1[0] = 0.f;
     {                                                                                    // the shift again (one element)
       const T* q = xn + c;
-      k1[0] = (float)(*q);
+      k1[0] = round_as<T>((float)(*q) + (bias ? (float)bias[c] : 0.f));
     }
     const float m = a / (float)HW, var = fmaxf(b / (float)HW - m * m, 0.f);
     in_lds[c] = k1[0] + m;
@@ -901,6 +906,12 @@ __global__ __launch_bounds__(256) void k_instnorm_apply(const T* __restrict__ x,
     const int cv = (int)(i % cpr);
     float v[V], o[V];
     ldc(xn + i * V, v);
+    if (bias) {
+      float bv[V];
+      ldc(bias + cv * V, bv);
+#pragma unroll
+      for (int u = 0; u < V; u++) v[u] = round_as<T>(v[u] + bv[u]);
+    }
 #pragma unroll
     for (int u = 0; u < V; u++) {
       float t = (v[u] - in_lds[cv * V + u]) * in_lds[C + cv * V + u];
@@ -914,6 +925,34 @@ __global__ __launch_bounds__(256) void k_instnorm_apply(const T* __restrict__ x,
       for (int u = 0; u < V; u++) o[u] = fmaxf(round_as<T>(r[u] + o[u]), 0.f);           // relu(res + y): the residual block's tail
     }
     stc(yn + i * V, o);
+  }
+}
+
+// y = act(round(x + bias)) and, with res, relu(round(res + y)) on a channels-last activation: what ATen runs as a bias add, a ReLU, a sum and a ReLU
+// behind a convolution of the context encoder (no norm there: extractor.py:27-54 with norm_fn = 'none'), one launch
+template <typename T>
+__global__ __launch_bounds__(256) void k_bias_act_cl(const T* __restrict__ x, const T* __restrict__ bias, const T* __restrict__ res, T* __restrict__ y,
+                                                     int64_t total, int cpr, int relu) {
+  constexpr int V = ChunkOf<T>::V;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cpr);
+    float v[V], o[V];
+    ldc(x + i * V, v);
+    if (bias) {
+      float bv[V];
+      ldc(bias + cv * V, bv);
+#pragma unroll
+      for (int u = 0; u < V; u++) v[u] = round_as<T>(v[u] + bv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < V; u++) o[u] = relu ? fmaxf(v[u], 0.f) : v[u];
+    if (res) {
+      float r[V];
+      ldc(res + i * V, r);
+#pragma unroll
+      for (int u = 0; u < V; u++) o[u] = fmaxf(round_as<T>(r[u] + o[u]), 0.f);
+    }
+    stc(y + i * V, o);
   }
 }
 
@@ -1018,13 +1057,36 @@ int devo_upd_masked_gather(const void* src, const int64_t* idx, void* out, int64
 
 size_t devo_instnorm_workspace_bytes(int N, int C) { return N > 0 && C > 0 ? (size_t)N * IN_PART * 2 * C * sizeof(float) : 0; }
 
+int devo_bias_act_cl(const void* x, const void* bias, const void* res, void* y, int64_t pixels, int C, int relu, int dtype, devo_stream_t stream) {
+  DEVO_REQUIRE(x && y && pixels > 0 && C > 0, "devo_bias_act_cl: null argument or bad sizes");
+  DEVO_REQUIRE(dtype == DEVO_F32 || dtype == DEVO_F16, "devo_bias_act_cl: fp32 / fp16 only (dtype %d)", dtype);
+  const int V = dtype == DEVO_F32 ? 4 : 8;
+  DEVO_REQUIRE(C % V == 0, "devo_bias_act_cl: C = %d must be a multiple of %d", C, V);
+  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+               "devo_bias_act_cl: 16-byte alignment");
+  DEVO_REQUIRE(!res || relu, "devo_bias_act_cl: the residual tail is relu(res + relu(x + bias))");
+  const int cpr = C / V;
+  const int64_t total = pixels * cpr;
+  const dim3 g(grid_for(total, 256 * 4, 2048));
+  UPD_DISPATCH(dtype,
+    hipLaunchKernelGGL(k_bias_act_cl<float>, g, dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)bias, (const float*)res, (float*)y, total, cpr, relu),
+    hipLaunchKernelGGL(k_bias_act_cl<__half>, g, dim3(256), 0, (hipStream_t)stream, (const __half*)x, (const __half*)bias, (const __half*)res, (__half*)y, total, cpr, relu));
+  return check_launch("devo_bias_act_cl");
+}
+
 int devo_instnorm_cl(const void* x, const void* res, void* y, int N, int HW, int C, float eps, int relu, void* workspace, size_t ws_bytes, int dtype,
                      devo_stream_t stream) {
+  return devo_instnorm_bias_cl(x, nullptr, res, y, N, HW, C, eps, relu, workspace, ws_bytes, dtype, stream);
+}
+
+int devo_instnorm_bias_cl(const void* x, const void* bias, const void* res, void* y, int N, int HW, int C, float eps, int relu, void* workspace, size_t ws_bytes,
+                          int dtype, devo_stream_t stream) {
   DEVO_REQUIRE(x && y && workspace && N > 0 && HW > 0 && C > 0, "devo_instnorm_cl: null argument or bad sizes");
   DEVO_REQUIRE(dtype == DEVO_F32 || dtype == DEVO_F16, "devo_instnorm_cl: fp32 / fp16 only (dtype %d)", dtype);
   const int V = dtype == DEVO_F32 ? 4 : 8;
   DEVO_REQUIRE(C % V == 0 && C / V <= 256 && 256 / (C / V) >= 1, "devo_instnorm_cl: C = %d must be a multiple of %d, at most %d", C, V, 256 * V);
-  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0, "devo_instnorm_cl: 16-byte alignment");
+  DEVO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+               "devo_instnorm_cl: 16-byte alignment");
   DEVO_REQUIRE(ws_bytes >= devo_instnorm_workspace_bytes(N, C), "devo_instnorm_cl: workspace %zu < %zu bytes", ws_bytes, devo_instnorm_workspace_bytes(N, C));
   DEVO_REQUIRE(!res || relu, "devo_instnorm_cl: the residual tail is relu(res + relu(norm))");
   hipStream_t st_ = (hipStream_t)stream;
@@ -1032,11 +1094,11 @@ int devo_instnorm_cl(const void* x, const void* res, void* y, int N, int HW, int
   const size_t lds1 = sizeof(float) * (size_t)npl * 2 * C, lds2 = sizeof(float) * 2 * (size_t)C;
   const dim3 g1(IN_PART, (unsigned)N), g2(grid_for((long long)HW * (C / V), 256 * 4, 1024), (unsigned)N);
   UPD_DISPATCH(dtype,
-    hipLaunchKernelGGL(k_instnorm_stats<float>, g1, dim3(256), lds1, st_, (const float*)x, HW, C, (float*)workspace),
-    hipLaunchKernelGGL(k_instnorm_stats<__half>, g1, dim3(256), lds1, st_, (const __half*)x, HW, C, (float*)workspace));
+    hipLaunchKernelGGL(k_instnorm_stats<float>, g1, dim3(256), lds1, st_, (const float*)x, (const float*)bias, HW, C, (float*)workspace),
+    hipLaunchKernelGGL(k_instnorm_stats<__half>, g1, dim3(256), lds1, st_, (const __half*)x, (const __half*)bias, HW, C, (float*)workspace));
   UPD_DISPATCH(dtype,
-    hipLaunchKernelGGL(k_instnorm_apply<float>, g2, dim3(256), lds2, st_, (const float*)x, (const float*)res, (float*)y, HW, C, (const float*)workspace, eps, relu),
-    hipLaunchKernelGGL(k_instnorm_apply<__half>, g2, dim3(256), lds2, st_, (const __half*)x, (const __half*)res, (__half*)y, HW, C, (const float*)workspace, eps, relu));
+    hipLaunchKernelGGL(k_instnorm_apply<float>, g2, dim3(256), lds2, st_, (const float*)x, (const float*)bias, (const float*)res, (float*)y, HW, C, (const float*)workspace, eps, relu),
+    hipLaunchKernelGGL(k_instnorm_apply<__half>, g2, dim3(256), lds2, st_, (const __half*)x, (const __half*)bias, (const __half*)res, (__half*)y, HW, C, (const float*)workspace, eps, relu));
   return check_launch("devo_instnorm_cl");
 }
 

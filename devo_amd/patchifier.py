@@ -50,21 +50,54 @@ def _norm(kind, x):
 _FUSED_IN = os.environ.get("DEVO_PATCHIFIER_FUSED_NORM", "1") != "0"   # 0: F.instance_norm + F.relu (+ the sum) as separate ATen kernels, always
 
 
-def _in_relu(x, relu=True, residual=None):
+def _fusable(x, *others):
+    if not (_FUSED_IN and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.float32)
+            and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % (8 if x.dtype == torch.float16 else 4) == 0 and x.data_ptr() % 16 == 0):
+        return False
+    for o in others:
+        if o is not None and not (o.dtype == x.dtype and o.data_ptr() % 16 == 0 and (o.dim() == 1 or (o.shape == x.shape and o.is_contiguous(memory_format=torch.channels_last)))):
+            return False
+    return True
+
+
+def _conv_nobias(m, x):
+    """the convolution of module `m` without its bias (the fused kernels behind it add the bias as ATen would: one elementwise launch less)"""
+    return F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
+
+
+def _bias_act(x, relu=True, residual=None, bias=None):
+    """act(x + bias) — with `residual`: relu(residual + relu(x + bias)) — as one launch on a channels-last activation (devo_bias_act_cl)."""
+    if bias is not None and bias.dtype != x.dtype:
+        bias = bias.to(x.dtype)                                                   # (fp32 parameters under autocast: the convolution would have cast it too)
+    if _fusable(x, bias, residual) and (residual is None or relu):
+        from . import _lib as L
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        L.check(L.lib().devo_bias_act_cl(L.ptr(x), L.ptr(bias), L.ptr(residual), L.ptr(y), N * H * W, C, int(bool(relu)), L.dtype_code(x), L.stream()),
+                "patchifier.bias_act")
+        return y
+    y = x if bias is None else x + bias.view(1, -1, 1, 1)
+    if relu:
+        y = F.relu(y)
+    return F.relu(residual + y) if residual is not None else y
+
+
+def _in_relu(x, relu=True, residual=None, bias=None):
     """relu(instance_norm(x)) — or, with `residual`, relu(residual + relu(instance_norm(x))): the tail of a residual block — in two launches on a
     channels-last activation when no gradient is needed (devo_instnorm_cl; through ATen one norm of an NHWC tensor is a copy to NCHW, a statistics
     kernel, a transform kernel and the ReLU: 10 norms per frame were half of the encoders' GPU time).  Anything else: the ATen composition."""
-    if (_FUSED_IN and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.float32)
-            and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % (8 if x.dtype == torch.float16 else 4) == 0
-            and x.data_ptr() % 16 == 0 and (residual is None or (relu and residual.shape == x.shape and residual.dtype == x.dtype and residual.data_ptr() % 16 == 0
-                                                                 and residual.is_contiguous(memory_format=torch.channels_last)))):
+    if bias is not None and bias.dtype != x.dtype:
+        bias = bias.to(x.dtype)
+    if _fusable(x, bias, residual) and (residual is None or relu):
         from . import _lib as L
         N, C, H, W = x.shape
         y = torch.empty_like(x)                                                   # (keeps the channels-last strides)
         ws = torch.empty(int(L.lib().devo_instnorm_workspace_bytes(N, C)), dtype=torch.uint8, device=x.device)
-        L.check(L.lib().devo_instnorm_cl(L.ptr(x), L.ptr(residual), L.ptr(y), N, H * W, C, 1e-5, int(bool(relu)), L.ptr(ws), ws.numel(), L.dtype_code(x),
-                                         L.stream()), "patchifier.instance_norm")
+        L.check(L.lib().devo_instnorm_bias_cl(L.ptr(x), L.ptr(bias), L.ptr(residual), L.ptr(y), N, H * W, C, 1e-5, int(bool(relu)), L.ptr(ws), ws.numel(),
+                                              L.dtype_code(x), L.stream()), "patchifier.instance_norm")
         return y
+    if bias is not None:
+        x = x + bias.view(1, -1, 1, 1)
     y = F.instance_norm(x)
     if relu:
         y = F.relu(y)
@@ -83,11 +116,13 @@ class _Residual(nn.Module):
         self.downsample = None if stride == 1 else nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride))
 
     def forward(self, x):
-        if self.norm_fn == "instance" and not torch.is_grad_enabled():           # inference: norm + ReLU (+ the block's sum and ReLU) fused
-            y = _in_relu(self.conv1(x))
+        if not torch.is_grad_enabled() and _FUSED_IN and x.is_cuda:              # inference: bias, norm, ReLU (+ the block's sum and ReLU) fused
+            post = _in_relu if self.norm_fn == "instance" else _bias_act
+            y = post(_conv_nobias(self.conv1, x), bias=self.conv1.bias)
             if self.downsample is not None:
-                x = _in_relu(self.downsample(x), relu=False)
-            return _in_relu(self.conv2(y), residual=x)
+                d = self.downsample[0]
+                x = post(_conv_nobias(d, x), relu=False, bias=d.bias)
+            return post(_conv_nobias(self.conv2, y), residual=x, bias=self.conv2.bias)
         y = F.relu(_norm(self.norm_fn, self.conv1(x)))
         y = F.relu(_norm(self.norm_fn, self.conv2(y)))
         if self.downsample is not None:
@@ -119,11 +154,13 @@ class Encoder(nn.Module):
     def forward(self, x):
         b, n = x.shape[:2]
         x = x.reshape(b * n, *x.shape[2:]).contiguous(memory_format=torch.channels_last)
-        if self.norm_fn == "instance" and not torch.is_grad_enabled():
-            x = _in_relu(self.conv1(x))
+        if not torch.is_grad_enabled() and _FUSED_IN and x.is_cuda:
+            post = _in_relu if self.norm_fn == "instance" else _bias_act
+            x = post(_conv_nobias(self.conv1, x), bias=self.conv1.bias)
+            x = _bias_act(_conv_nobias(self.conv2, self.layer2(self.layer1(x))), relu=False, bias=self.conv2.bias)
         else:
             x = F.relu(_norm(self.norm_fn, self.conv1(x)))
-        x = self.conv2(self.layer2(self.layer1(x)))
+            x = self.conv2(self.layer2(self.layer1(x)))
         return x.reshape(b, n, *x.shape[1:])
 
 
@@ -314,13 +351,14 @@ class Patchifier(nn.Module):
     # cast cache lives as long as the autocast context: one frame) — 70 launches and 0.24 ms of GPU time of a call that is paced by its ~300
     # launches (2.35 ms per frame of 480 x 640).  The copy (fp16 / bf16, channels-last weights) is kept per version of the parameters; the
     # arithmetic is autocast's own (convolutions, instance norms, ReLUs and sums in the low precision), the outputs are the same tensors.
-    def _lowp_modules(self, dtype):
+    def _lowp_modules(self, dtype, cl=False):
         plist = self.__dict__.get("_plist")
         if plist is None or len(plist[1]) != plist[0]:
             ps = list(self.parameters())
             plist = self.__dict__["_plist"] = (len(ps), ps)                      # (walking the module tree costs 0.2 ms per call)
-        key = (dtype, tuple((p.data_ptr(), p._version) for p in plist[1]))
-        sh = self.__dict__.get("_lowp")
+        key = (dtype, bool(cl), tuple((p.data_ptr(), p._version) for p in plist[1]))
+        slot = "_lowp_cl" if cl else "_lowp"
+        sh = self.__dict__.get(slot)
         if sh is None or sh[0] != key:
             import copy
             mods = {}
@@ -329,15 +367,15 @@ class Patchifier(nn.Module):
                 if m is None:
                     continue
                 c = copy.deepcopy(m).to(dtype).eval()
-                if _LOWP_CL:
-                    for mod in c.modules():
+                if cl or _LOWP_CL:                                             # (channels-last weights: no per-call re-layout kernel in front of every
+                    for mod in c.modules():                                      #  convolution — 4.7 us each; with many frames MIOpen picks slower kernels for them)
                         if isinstance(mod, nn.Conv2d):
                             mod.weight.data = mod.weight.data.contiguous(memory_format=torch.channels_last)
                 for q in c.parameters():
                     q.requires_grad_(False)
                 mods[name] = c
             sh = (key, mods)
-            self.__dict__["_lowp"] = sh
+            self.__dict__[slot] = sh
         return sh[1]
 
     # One frame at a time (devo.py:250) the three CNNs are ~110 launches of a few microseconds each and the call is paced by the host (2.0 ms per
@@ -381,6 +419,7 @@ class Patchifier(nn.Module):
     def __getstate__(self):
         d = self.__dict__.copy()                                               # (copy.deepcopy / torch.save: the per-version copy stays behind)
         d.pop("_lowp", None)
+        d.pop("_lowp_cl", None)
         d.pop("_enc_graph", None)
         d.pop("_plist", None)
         return d
@@ -391,6 +430,7 @@ class Patchifier(nn.Module):
 
     def _apply(self, fn, recurse=True):
         self.__dict__.pop("_lowp", None)                                       # .to() / .half() / .cuda(): the parameters' storage moves
+        self.__dict__.pop("_lowp_cl", None)
         self.__dict__.pop("_enc_graph", None)
         self.__dict__.pop("_plist", None)
         return super()._apply(fn, recurse)
@@ -411,7 +451,7 @@ class Patchifier(nn.Module):
         smap_lp = None
         if (_LOWP and not torch.is_grad_enabled() and images.is_cuda and torch.is_autocast_enabled()
                 and torch.get_autocast_dtype("cuda") in (torch.float16, torch.bfloat16) and self.fnet.conv1.weight.dtype == torch.float32):
-            lowp = self._lowp_modules(torch.get_autocast_dtype("cuda"))
+            lowp = self._lowp_modules(torch.get_autocast_dtype("cuda"), cl=images.shape[0] * images.shape[1] <= _GRAPH_MAX_FRAMES)
             fmap, imap, smap_lp = self._encode_lowp(images, lowp, torch.get_autocast_dtype("cuda"),
                                                    coords is None and self.patch_selector == "scorer")
         else:

@@ -29,7 +29,7 @@ enum { DEVO_F32 = 0, DEVO_F16 = 1, DEVO_F64 = 2 };
 
 #define DEVO_ABI_VERSION 5 /* 2: fp32 split formats (devo_corr_pyramid_split, exponents), group plans (plan buffer tail); 3: per-slot conversions of a ring
                               (devo_corr_pyramid_split_frames, devo_corr_patch_transpose_range), devo_stream_capturing; 4: devo_ba_table_offsets, devo_upd_graph_tables; 5: devo_ba_forward_prepared_delta_plan, devo_ba_import_tables, devo_upd_rs_corr_f16_net32,
-                              devo_upd_rs_gru_f16_out32, devo_instnorm_cl;
+                              devo_upd_rs_gru_f16_out32, devo_instnorm_cl, devo_instnorm_bias_cl, devo_bias_act_cl;
                               callers compare with devo_abi_version() */
 int devo_abi_version(void);
 const char* devo_last_error(void); /* thread-local message of the last failing call */
@@ -395,6 +395,14 @@ int devo_se3_jinv(const void* X, const void* a, void* b, int64_t n, int dtype, d
 size_t devo_instnorm_workspace_bytes(int N, int C);
 int devo_instnorm_cl(const void* x, const void* res, void* y, int N, int HW, int C, float eps, int relu, void* workspace, size_t ws_bytes, int dtype,
                      devo_stream_t stream);
+/* ... with the convolution's bias [C] (same dtype, 16-byte aligned; or NULL) added in front as ATen adds it behind a bias-free MIOpen call:
+ * the norm sees round(x + bias) — the caller leaves the bias out of the convolution (one elementwise launch per convolution less). */
+int devo_instnorm_bias_cl(const void* x, const void* bias, const void* res, void* y, int N, int HW, int C, float eps, int relu, void* workspace,
+                          size_t ws_bytes, int dtype, devo_stream_t stream);
+/* y = act(round(x + bias)) — act = ReLU when `relu` — and, with `res` (needs relu), relu(round(res + y)), on a channels-last activation of
+ * `pixels` x C elements (fp32 / fp16, C a multiple of 4 / 8, 16-byte aligned; bias may be NULL): the bias add, ReLU, sum and ReLU behind a
+ * convolution of the context encoder (extractor.py:27-54 with norm_fn = 'none') as one launch. */
+int devo_bias_act_cl(const void* x, const void* bias, const void* res, void* y, int64_t pixels, int C, int relu, int dtype, devo_stream_t stream);
 int devo_upd_layernorm(const void* x, const void* add1, const void* add2, const void* hy, const int* group_of,
                        const void* gate, int64_t ld_gate, const void* res, const void* gamma, const void* beta,
                        void* out, int64_t rows, int dim, float eps, int relu, int dtype, devo_stream_t stream);

@@ -187,7 +187,7 @@ def test_autocast_inference_on_the_cached_low_precision_parameters(dt):
         with torch.no_grad(), torch.autocast("cuda", dtype=dt):
             return m(images, patches_per_image=12, scorer_eval_mode="topk")
     got = run(pf)
-    assert "_lowp" in pf.__dict__
+    assert "_lowp" in pf.__dict__ or "_lowp_cl" in pf.__dict__
     PF._LOWP = False
     try:
         ref = run(pf)
@@ -206,7 +206,7 @@ def test_autocast_inference_on_the_cached_low_precision_parameters(dt):
     assert rel_err(got2[0].float(), 0.5 * (got[0].float() - pf.fnet.conv2.bias.to(dt).float()[None, None, :, None, None] / 4) +
                    pf.fnet.conv2.bias.to(dt).float()[None, None, :, None, None] / 4) <= 4 * tol
     c = copy.deepcopy(pf)
-    assert "_lowp" not in c.__dict__ and "_enc_graph" not in c.__dict__ and rel_err(run(c)[0].float(), got2[0].float()) <= tol
+    assert "_lowp" not in c.__dict__ and "_lowp_cl" not in c.__dict__ and "_enc_graph" not in c.__dict__ and rel_err(run(c)[0].float(), got2[0].float()) <= tol
     # one frame at a time the encoders replay from a HIP graph from the third call on: the same tensors, and what an earlier call returned stays
     one = images[:, :1].contiguous()
     def run1(m, x):
@@ -259,6 +259,15 @@ def test_fused_instance_norm_of_a_channels_last_activation(dt, tol):
         want_c = (r.double() + nd.clamp(min=0).to(dt).double()).clamp(min=0)
         assert float((c.double() - want_c).abs().max()) <= tol * 16 * scale
         assert torch.equal(a, a2)
+        # the convolution's bias added in front, as ATen adds it behind a bias-free convolution: the bits of the norm of (x + bias)
+        bias = torch.randn(C, generator=g).to(dev).to(dt)
+        xb = x + bias.view(1, -1, 1, 1)
+        with torch.no_grad():
+            assert torch.equal(PF._in_relu(x, bias=bias), PF._in_relu(xb)) and torch.equal(PF._in_relu(x, residual=r, bias=bias), PF._in_relu(xb, residual=r))
+            # ... and the context encoder's epilogues (no norm): bias + ReLU (+ the block's sum and ReLU) in one launch: ATen's bits
+            assert torch.equal(PF._bias_act(x, bias=bias), torch.relu(xb))
+            assert torch.equal(PF._bias_act(x, relu=False, bias=bias), xb)
+            assert torch.equal(PF._bias_act(x, residual=r, bias=bias), torch.relu(r + torch.relu(xb)))
         x2 = x.clone().requires_grad_(True)
         y = PF._in_relu(x2)                                                        # gradients: ATen's kernels
         assert y.requires_grad and float((y.detach().double() - nd.clamp(min=0)).abs().max()) <= tol * 8 * scale

@@ -885,8 +885,16 @@ __global__ __launch_bounds__(256) void k_instnorm_apply(const T* __restrict__ x,
   const int n = blockIdx.y;
   const T* xn = x + (int64_t)n * HW * C;
   for (int c = threadIdx.x; c < C; c += 256) {
-    float a = 0.f, b = 0.f;
-    for (int p = 0; p < IN_PART; p++) { a += part[(((int64_t)n * IN_PART + p) * 2) * C + c]; b += part[(((int64_t)n * IN_PART + p) * 2 + 1) * C + c]; }
+    float a4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};   // (four chains, sixteen loads in flight: a fixed order all the same)
+#pragma unroll 2
+    for (int p = 0; p < IN_PART; p += 8) {
+      float va[8], vb[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { va[j] = part[(((int64_t)n * IN_PART + p + j) * 2) * C + c]; vb[j] = part[(((int64_t)n * IN_PART + p + j) * 2 + 1) * C + c]; }
+#pragma unroll
+      for (int j = 0; j < 8; j++) { a4[j & 3] += va[j]; b4[j & 3] += vb[j]; }
+    }
+    const float a = (a4[0] + a4[1]) + (a4[2] + a4[3]), b = (b4[0] + b4[1]) + (b4[2] + b4[3]);
     float k1[1];
     k1[0] = 0.f;
     {                                                                                    // the shift again (one element)

@@ -176,7 +176,13 @@ class Scorer(nn.Module):
 
     def forward(self, x):
         b, n = x.shape[:2]
-        s = self.scorer(x.reshape(b * n, *x.shape[2:]).contiguous(memory_format=torch.channels_last))
+        x = x.reshape(b * n, *x.shape[2:]).contiguous(memory_format=torch.channels_last)
+        if not torch.is_grad_enabled() and _FUSED_IN and x.is_cuda:              # inference: bias + ReLU behind a bias-free convolution, one launch
+            for i in (0, 2, 4):
+                x = _bias_act(_conv_nobias(self.scorer[i], x), bias=self.scorer[i].bias)
+            s = self.scorer[7](self.scorer[6](x))
+        else:
+            s = self.scorer(x)
         return s.reshape(b, n, *s.shape[2:])
 
 

@@ -357,7 +357,7 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=40):
                 fastba.BA(P1, Q1, sintr, target, sweight, lmbda, sii, sjj, skk, nk - 10, nk, 2)
                 return corr
             for label, track in (("per_slot", True), ("whole_ring", False)):
-                on = ring.track_ring_writes(track) if B_.native() is not None else False
+                on = ring.track_ring_writes(track)                             # (both bindings keep write records since round 6)
                 with torch.no_grad():
                     for _ in range(10):
                         frame_and_update()
@@ -375,7 +375,7 @@ def reference_api_probe(args, device, seed=1234, iters=60, warm=40):
                 # `ctx = imap[:, kk % (M mem)]`, the recurrent state fed back): what ONE frame of the unchanged devo.py costs on this path
                 # behind the patchifier (whose encoders are MIOpen's)
                 from devo_amd.update import Update
-                ring.track_ring_writes(True) if B_.native() is not None else None
+                ring.track_ring_writes(True)
                 torch.manual_seed(seed)
                 upd = Update(3).to(device).eval()
                 with torch.no_grad():

@@ -40,7 +40,6 @@ def install():
     n = native()
     mods = (n.cuda_corr, n.cuda_ba, n.lietorch_backends) if n is not None else (cuda_corr, cuda_ba, lietorch_backends)
     sys.modules["cuda_corr"], sys.modules["cuda_ba"], sys.modules["lietorch_backends"] = mods
-    if n is not None:
-        from . import ring
-        ring.track_ring_writes(True)     # per-slot maintenance of the converted ring buffers (ring.py; DEVO_RING_SLOTS=0: off)
+    from . import ring
+    ring.track_ring_writes(True)         # per-slot maintenance of the converted ring buffers (ring.py; both bindings; DEVO_RING_SLOTS=0: off)
     return mods

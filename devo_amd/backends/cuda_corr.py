@@ -30,6 +30,72 @@ NCHW_CONVERT_MIN_EDGES = 1024    # from here on a lookup into the reference's NC
 
 _blocked_cache = {}        # (ptr, version, shape, strides, dtype) -> (source tensor [kept alive], channel-blocked copy); LRU
 BLOCKED_CACHE_ENTRIES = 4
+
+# ---- per-slot maintenance of a converted ring in THIS binding (round 6; csrc/bind.cpp has the same for the compiled one: DESIGN 2).  A write
+# through the `Tensor.__setitem__` wrapper of backends/ring.py into a tensor this cache holds a converted copy of is recorded as (version counter
+# after the write, element range); a lookup whose key differs from a cached entry only in the version converts just the frames / patches the
+# records cover — provided EVERY version in between has a record with a known contiguous range.  Anything else: the whole tensor, as before.
+import os as _os
+RING_SLOTS = _os.environ.get("DEVO_RING_SLOTS", "1") != "0"
+MAX_WRITE_RECS = 512
+_writes = {}               # data_ptr -> [(version after the write, first element, elements | -1 = unknown)]
+_conv_stats = [0, 0, 0, 0, 0]     # whole levels, frames of levels, whole patch operands, patch ranges, patches in those ranges
+
+
+def is_tracked(ptr):
+    return any(k[0] == ptr for k in _blocked_cache) or any(k[0] == ptr for k in _patch_t_cache)
+
+
+def note_write(ptr, version_after, off, length):
+    recs = _writes.setdefault(ptr, [])
+    if len(recs) >= MAX_WRITE_RECS:
+        recs.clear()                                          # (a gap: the next lookup converts everything)
+    recs.append((int(version_after), int(off), int(length)))
+
+
+def _forget_writes(ptr, upto):
+    recs = _writes.get(ptr)
+    if recs is not None:
+        recs[:] = [r for r in recs if r[0] > upto]
+        if not recs:
+            del _writes[ptr]
+
+
+def _writes_between(ptr, v0, v1):
+    """every version in (v0, v1] has a record with a known range -> their (first, end) element ranges; else None"""
+    need = v1 - v0
+    recs = _writes.get(ptr)
+    if need <= 0 or need > MAX_WRITE_RECS or not recs:
+        return None
+    seen, ranges = set(), []
+    for ver, off, length in recs:
+        if v0 < ver <= v1:
+            if length < 0 or ver in seen:
+                return None
+            seen.add(ver)
+            ranges.append((off, off + length))
+    return ranges if len(seen) == need else None
+
+
+def _slot_path_ok(t):
+    return RING_SLOTS and t.is_contiguous() and L.lib().devo_stream_capturing(L.stream()) == 0
+
+
+def convert_stats():
+    """(whole levels, frames of levels, whole patch operands, patch ranges, patches in those ranges) converted so far by the active binding"""
+    N = _nat()
+    return tuple(N.cuda_corr._convert_stats()) if N is not None else tuple(_conv_stats)
+
+
+def clear_caches():
+    """Drop the converted pyramid copies and patch operands of the active binding (tests)."""
+    N = _nat()
+    if N is not None:
+        N.clear_caches()
+        return
+    _blocked_cache.clear()
+    _patch_t_cache.clear()
+    _writes.clear()
 _MM_DEFAULT = MM_KERNEL
 
 
@@ -121,10 +187,55 @@ def _fast_layout(fmap2, n_edges, allow_split=True):
     if hit is not None:
         _blocked_cache[key] = hit                             # (most recently used last)
         return hit[1]
-    for k in [k for k in _blocked_cache if k[0] == key[0]]:
-        del _blocked_cache[k]                                 # an older version of this tensor
+    older = [k for k in _blocked_cache if k[0] == key[0]]
+    if fmap2.dim() == 5 and _slot_path_ok(fmap2):             # the same ring at an older version whose every write since is on record
+        for k in older:
+            if k[2:] != key[2:]:
+                continue
+            ranges = _writes_between(key[0], k[1], key[1])
+            if ranges is None:
+                break
+            _, conv = _blocked_cache.pop(k)
+            Bq, nq, Cq, Hq, Wq = fmap2.shape
+            per, total = Cq * Hq * Wq, Bq * nq
+            dirty = [False] * total
+            for lo, hi in ranges:
+                f = max(0, lo // per)
+                while f < total and f * per < hi:
+                    dirty[f] = True
+                    f += 1
+            f = 0
+            while f < total:
+                if not dirty[f]:
+                    f += 1
+                    continue
+                f1 = f
+                while f1 + 1 < total and dirty[f1 + 1] and (f1 + 1) // nq == f // nq:
+                    f1 += 1
+                b, f0, cnt = f // nq, f % nq, f1 - f + 1
+                if want_split:
+                    scratch = torch.empty(cnt, dtype=torch.int32, device=fmap2.device)
+                    rc = L.lib().devo_corr_pyramid_split_frames(L.ptr(fmap2[b, f0]), L.i64arr([st[1], st[2], st[3], st[4]]), 0, cnt, Cq, Hq, Wq,
+                                                                L.ptr(conv.data[b, f0]), conv.data.stride(1),
+                                                                ctypes.c_void_p(conv.exps.data_ptr() + 4 * (b * nq + f0)), L.ptr(scratch), L.stream())
+                    L.check(rc, "cuda_corr: fp32 ring slot -> split-blocked")
+                else:
+                    rc = L.lib().devo_pyramid_build(L.ptr(fmap2[b, f0]), L.ptr(conv[b, f0]), None, cnt, Cq, Hq, Wq, st[1], conv.stride(1), 0,
+                                                    L.dtype_code(fmap2), L.stream())
+                    L.check(rc, "cuda_corr: NCHW ring slot -> channel-blocked")
+                _conv_stats[1] += cnt
+                f = f1 + 1
+            for k2 in [k2 for k2 in _blocked_cache if k2[0] == key[0]]:
+                del _blocked_cache[k2]
+            _blocked_cache[key] = (fmap2, conv)               # (the same converted tensors under the new version)
+            _forget_writes(key[0], key[1])
+            return conv
+    for k in older:
+        _blocked_cache.pop(k, None)                           # an older version of this tensor
     while len(_blocked_cache) >= BLOCKED_CACHE_ENTRIES:       # least recently used first (dicts keep insertion order): a DEVO
         del _blocked_cache[next(iter(_blocked_cache))]        # process holds two levels of one ring = 2 entries, ~300 MB in fp16
+    _conv_stats[0] += 1
+    _forget_writes(key[0], key[1])
     if want_split:
         lvl = split_level(fmap2)
         _blocked_cache[key] = (fmap2, lvl)
@@ -218,10 +329,36 @@ def patches_transposed(fmap1):
     if hit is not None:
         _patch_t_cache[key] = hit                             # (most recently used last)
         return hit[1]
-    for k in [k for k in _patch_t_cache if k[0] == key[0]]:
-        del _patch_t_cache[k]                                 # an older version of this tensor
+    older = [k for k in _patch_t_cache if k[0] == key[0]]
+    if _slot_path_ok(fmap1):
+        for k in older:
+            if k[2:] != key[2:]:
+                continue
+            ranges = _writes_between(key[0], k[1], key[1])
+            if ranges is None:
+                break
+            _, t = _patch_t_cache.pop(k)
+            n_p, Cq = fmap1.shape[0] * fmap1.shape[1], fmap1.shape[2]
+            per = Cq * 9
+            for lo, hi in ranges:
+                p0, p1 = max(0, lo // per), min(n_p, (hi + per - 1) // per)
+                if p1 <= p0:
+                    continue
+                rc = L.lib().devo_corr_patch_transpose_range(L.ptr(fmap1), L.ptr(t), n_p, p0, p1 - p0, Cq, L.dtype_code(fmap1), L.stream())
+                L.check(rc, "cuda_corr.patches_transposed (slot)")
+                _conv_stats[3] += 1
+                _conv_stats[4] += p1 - p0
+            for k2 in [k2 for k2 in _patch_t_cache if k2[0] == key[0]]:
+                del _patch_t_cache[k2]
+            _patch_t_cache[key] = (fmap1, t)
+            _forget_writes(key[0], key[1])
+            return t
+    for k in older:
+        _patch_t_cache.pop(k, None)                           # an older version of this tensor
     while len(_patch_t_cache) >= BLOCKED_CACHE_ENTRIES:       # least recently used first
         del _patch_t_cache[next(iter(_patch_t_cache))]
+    _conv_stats[2] += 1
+    _forget_writes(key[0], key[1])
     B, Np, C = fmap1.shape[:3]
     nbytes = int(L.lib().devo_corr_patch_operand_bytes(B * Np, C, L.dtype_code(fmap1)))      # (fp32: split records + one exponent per patch)
     if nbytes == 0 and B * Np > 0:

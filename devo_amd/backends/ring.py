@@ -27,15 +27,20 @@ def _setitem(self, idx, value):
             from . import native
             N = native()
             if N is not None:
+                tracked, note = N.cuda_corr._is_tracked, N.cuda_corr._note_write
+            else:                                                        # (the ctypes binding keeps its own records: backends/cuda_corr.py)
+                from . import cuda_corr as _cc
+                tracked, note = _cc.is_tracked, _cc.note_write
+            if True:
                 p = self.data_ptr()
-                if N.cuda_corr._is_tracked(p):
+                if tracked(p):
                     off, length = 0, -1                                  # unknown region unless the index selects ONE contiguous run of this tensor
                     if self.is_contiguous():
                         sub = self[idx]
                         if (sub.is_contiguous() and sub.numel() > 0 and sub.untyped_storage().data_ptr() == self.untyped_storage().data_ptr()
                                 and sub.data_ptr() >= p):
                             off, length = (sub.data_ptr() - p) // self.element_size(), sub.numel()
-                    N.cuda_corr._note_write(p, self._version, off, length)
+                    note(p, self._version, off, length)
     except Exception:                                                    # noqa: BLE001 — a missing record is a gap: the binding converts everything
         pass
     return r
